@@ -1,0 +1,269 @@
+/*  bcfgpu.h -- C-ABI of the MI355X-native `bcftools mpileup | bcftools call -m` hot path.
+ *
+ *  This is the drop-in boundary.  Every entry point is `extern "C"`, takes
+ *  plain pointers and sizes, returns 0 or a negative BCFGPU_E_* code and never
+ *  exits the process (the reference's error()/exit(-1), version.c:43-50, is
+ *  left to the CLI layer).  Each entry cites the reference interface it
+ *  replaces (paths relative to the bcftools source tree):
+ *
+ *    bcfgpu_create / bcfgpu_destroy      <- bcf_call_init / bcf_call_destroy   bam2bcf.h:135-136 (bam2bcf.c:43-77)
+ *                                           + mcall_init / mcall_destroy       call.h:135,139   (mcall.c:361-438)
+ *    bcfgpu_pack_read                    <- the per-read accessors used by bcf_call_glfgen
+ *                                           (bam2bcf.c:80-114 get_position, :189-220, mpileup.c:253-273)
+ *    bcfgpu_mpileup                      <- bcf_callaux_clean + bcf_call_glfgen x n_smpl + bcf_call_combine
+ *                                           for every site of a tile          bam2bcf.h:137-138,142
+ *                                           (call sites mpileup.c:343-347 and :357-360)
+ *    bcfgpu_mcall                        <- mcall()                            call.h:131 (mcall.c:1430-1684)
+ *                                           incl. the per-record prologue of vcfcall.c:1096-1115
+ *    bcfgpu_pipeline                     <- the `mpileup -Ou | call -m` pipe with PL/QS/I16 kept in HBM
+ *
+ *  Memory model: all bulk arrays are *device* pointers (HBM).  Hosts that do
+ *  not link HIP use bcfgpu_malloc/free/memcpy_*.  Kernels are enqueued on the
+ *  context's HIP stream; bcfgpu_sync() waits for them.
+ *
+ *  Data layout (one "tile" = a batch of pileup columns):
+ *     site x sample x read  CSR:  plp_off[site*n_smpl + smpl] .. plp_off[..+1]
+ *     index the per-read arrays `rd` (u32) and `epos` (u8) [and `aux` (u32) at
+ *     indel sites].  Reads keep the order in which bcf_call_glfgen would see
+ *     them (plp[] order, mpileup.c:275-293).
+ */
+#ifndef BCFGPU_H
+#define BCFGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BCFGPU_VERSION 1
+
+/* error codes */
+#define BCFGPU_OK          0
+#define BCFGPU_E_ARG      -1   /* bad argument / NULL pointer                       */
+#define BCFGPU_E_NOMEM    -2   /* host or device allocation failed                  */
+#define BCFGPU_E_HIP      -3   /* a HIP runtime call failed (see bcfgpu_last_error) */
+#define BCFGPU_E_DEPTH    -4   /* a (site,sample) holds >255 usable reads: errmod_cal's
+                                  random 255-subsample (htslib errmod.c) is not restated */
+#define BCFGPU_E_NODEV    -5   /* no HIP device: the product path has no CPU fallback  */
+#define BCFGPU_E_RANGE    -6   /* tile larger than the context's capacity           */
+
+/* annotation flags: values identical to B2B_* (bam2bcf.h:46-62) */
+#define BCFGPU_FMT_DP      (1<<0)
+#define BCFGPU_FMT_SP      (1<<1)
+#define BCFGPU_FMT_DV      (1<<2)
+#define BCFGPU_FMT_DP4     (1<<3)
+#define BCFGPU_FMT_DPR     (1<<4)
+#define BCFGPU_INFO_DPR    (1<<5)
+#define BCFGPU_FMT_AD      (1<<6)
+#define BCFGPU_FMT_ADF     (1<<7)
+#define BCFGPU_FMT_ADR     (1<<8)
+#define BCFGPU_INFO_AD     (1<<9)
+#define BCFGPU_INFO_ADF    (1<<10)
+#define BCFGPU_INFO_ADR    (1<<11)
+#define BCFGPU_INFO_SCR    (1<<12)
+#define BCFGPU_FMT_SCR     (1<<13)
+#define BCFGPU_INFO_VDB    (1<<14)
+#define BCFGPU_INFO_RPB    (1<<15)
+#define BCFGPU_FMT_QS      (1<<16)
+
+/* call flags: values identical to CALL_* (call.h:32-39) */
+#define BCFGPU_CALL_KEEPALT   1
+#define BCFGPU_CALL_VARONLY   (1<<1)
+#define BCFGPU_CALL_FMT_GQ    (1<<6)
+#define BCFGPU_CALL_FMT_GP    (1<<7)
+
+#define BCFGPU_MAX_ALLELES 5          /* B2B_MAX_ALLELES, bam2bcf.h:64 */
+#define BCFGPU_MAX_PL      15         /* 5*(5+1)/2 */
+#define BCFGPU_NPOS        100        /* bca->npos,  bam2bcf.c:55 */
+#define BCFGPU_NQUAL       60         /* bca->nqual, bam2bcf.c:58 */
+#define BCFGPU_MAX_DEPTH   255        /* per (site,sample) reads errmod_cal takes without subsampling */
+
+/* sentinels, identical to htslib's bcf_int32_missing / bcf_int32_vector_end */
+#define BCFGPU_INT32_MISSING     (INT32_MIN)
+#define BCFGPU_INT32_VECTOR_END  (INT32_MIN+1)
+/* genotype encodings in the int8 GT planes */
+#define BCFGPU_GT_MISSING     (-1)
+#define BCFGPU_GT_VECTOR_END  (-2)
+
+/* ---- packed read record `rd` (u32), one per pileup entry ------------------
+ *   bits  0..7   baseQ    bam_get_qual(b)[qpos]                       bam2bcf.c:191 (:183 at indels)
+ *   bits  8..15  mapQ     b->core.qual (255 kept; DEF_MAPQ applied on device, bam2bcf.c:196)
+ *   bits 16..19  nt16     bam_seqi(bam_get_seq(b), qpos)              bam2bcf.c:189,241
+ *   bit  20      is_rev   bam_is_rev(b)
+ *   bit  21      softclip PLP_HAS_SOFT_CLIP(p->cd.i)                  bam2bcf.h:66
+ *   bit  22      is_del   p->is_del
+ *   bit  23      skip     p->is_refskip || (b->core.flag&BAM_FUNMAP)  bam2bcf.c:173
+ *   bits 24..31  tail     min(qpos, l_qseq-1-qpos, 255)  (CAP_DIST applied on device, bam2bcf.c:218-220)
+ * `epos` (u8): (int)((double)get_position()/(len+1)*100), bam2bcf.c:80-114,234-235
+ * `aux` (u32): p->aux as left by bcf_call_gap_prep, type<<16|seqQ<<8|indelQ (bam2bcf_indel.c:423)
+ */
+#define BCFGPU_RD_REV    (1u<<20)
+#define BCFGPU_RD_SCLIP  (1u<<21)
+#define BCFGPU_RD_DEL    (1u<<22)
+#define BCFGPU_RD_SKIP   (1u<<23)
+
+typedef struct bcfgpu_ctx bcfgpu_ctx;
+
+/* configuration = the fields of bcf_callaux_t (bam2bcf.h:69-87) and call_t
+ * (call.h:72-123) that the hot path reads */
+typedef struct {
+    int32_t device;        /* HIP device ordinal */
+    int32_t n_smpl;        /* samples per site (bcf_call_t.n) */
+    int32_t max_sites;     /* tile capacity */
+    uint64_t max_reads;    /* tile capacity */
+    /* mpileup side */
+    int32_t min_baseQ;     /* mpileup -Q, default 13 (mpileup.c:937-950) */
+    int32_t capQ;          /* 60 (bam2bcf.c:48) */
+    double  errmod_theta;  /* <=0 -> CALL_DEFTHETA 0.83 (bam2bcf.c:38,46) */
+    int32_t fmt_flag;      /* BCFGPU_FMT_* | BCFGPU_INFO_*; mpileup default VDB|RPB (mpileup.c:950) */
+    /* call side */
+    double  call_theta;    /* call -P, default 1.1e-3 (vcfcall.c:931-943); <=0: no prior */
+    int32_t call_flag;     /* BCFGPU_CALL_KEEPALT | BCFGPU_CALL_VARONLY */
+    int32_t output_tags;   /* BCFGPU_CALL_FMT_GQ | BCFGPU_CALL_FMT_GP */
+    int32_t n_grp;         /* number of -G sample groups; <=1: one pooled group */
+    int32_t grp_tag_is_qs; /* -G with FORMAT/QS (1) or FORMAT/AD (0) as frequency source */
+    int32_t ploidy_max;    /* ploidy_max(args->ploidy) used for the prior's allele count (vcfcall.c:654-655, mcall.c:397-405); 0 -> 2 */
+} bcfgpu_cfg;
+
+/* one tile of pileup columns (device pointers) */
+typedef struct {
+    int32_t  n_sites;
+    int32_t  is_indel;        /* 0: SNP pass (ref_base>=0); 1: indel pass (ref_base=-1, aux used) */
+    uint64_t n_reads;
+    const int8_t   *ref16;    /* [n_sites] 4-bit reference code handed to bcf_call_glfgen (mpileup.c:341-342) */
+    const uint32_t *plp_off;  /* [n_sites*n_smpl+1] */
+    const uint32_t *rd;       /* [n_reads] */
+    const uint8_t  *epos;     /* [n_reads] */
+    const uint32_t *aux;      /* [n_reads] or NULL */
+} bcfgpu_tile;
+
+/* per-site result of the mpileup stage = the scalar part of bcf_call_t
+ * (bam2bcf.h:111-129) after bcf_call_combine */
+typedef struct {
+    int32_t a[5];             /* allele order, -1 = unused */
+    int32_t n_alleles, unseen, ori_ref, shift;
+    int32_t ret;              /* bcf_call_combine's return: 0, or -1 (indel site without alt) */
+    uint32_t depth, ori_depth, mq0;
+    float   qsum[5];          /* INFO/QS */
+    float   vdb, mwu_pos, mwu_mq, mwu_bq, mwu_mqs, seg_bias;   /* +inf = HUGE_VAL = tag omitted */
+    int32_t adf_tot[5], adr_tot[5];   /* ADF[0..4], ADR[0..4]: site totals, bam2bcf.c:676-690 */
+    int32_t scr_tot;          /* SCR[0] */
+    int32_t pad;
+    double  anno[16];         /* INFO/I16 before the float cast (bam2bcf.c:831) */
+} bcfgpu_site;
+
+/* per-sample results of the mpileup stage, SoA planes in HBM.
+ * plane strides are n_smpl; the per-site block of each array holds `planes`
+ * planes whatever n_alleles is, so addressing does not depend on the data:
+ *      pl [site][BCFGPU_MAX_PL][n_smpl]      u8   PL (<=255, bam2bcf.c:645-647); first n_alleles*(n_alleles+1)/2 planes valid
+ *      dp4[site][4][n_smpl]                  u8   DP4 (anno[0..3], bam2bcf.c:650-659)
+ *      adf/adr[site][5][n_smpl]              u8   ADF/ADR in *allele order* (bam2bcf.c:668-697); first n_alleles planes valid
+ *      qs [site][5][n_smpl]                  u16  FMT/QS in allele order (bam2bcf.c:698-712)
+ *      scr[site][n_smpl]                     u8   SCR[1+i]
+ */
+typedef struct {
+    bcfgpu_site *site;        /* [n_sites] */
+    uint8_t  *pl;
+    uint8_t  *dp4;
+    uint8_t  *adf, *adr;      /* may be NULL when no AD-type flag is set */
+    uint16_t *qs;             /* may be NULL unless BCFGPU_FMT_QS or grouped calling on QS */
+    uint8_t  *scr;            /* may be NULL unless an SCR flag is set */
+} bcfgpu_mplp_out;
+
+/* input of the call stage when it is used on its own (e.g. on records parsed
+ * from a VCF/BCF): everything mcall() reads from the record */
+typedef struct {
+    int32_t n_sites;
+    int32_t n_gt_max;         /* plane count of `pl` per site (>= max over sites of nals*(nals+1)/2) */
+    int32_t n_al_max;         /* plane count of `ad` per site */
+    int32_t reserved;
+    const int32_t *nals;      /* [n_sites] rec->n_allele */
+    const int32_t *unseen;    /* [n_sites] index of <*>/X or 0 if none (vcfcall.c:1102-1111) */
+    const int32_t *pl;        /* [site][n_gt_max][n_smpl]  FORMAT/PL incl. missing / vector_end sentinels */
+    const float   *qs;        /* [site][5] INFO/QS, entries beyond those present = 0 (mcall.c:1456-1464) */
+    const int32_t *ad;        /* [site][n_al_max][n_smpl] FORMAT/AD|QS for -G, or NULL */
+    const uint8_t *ploidy;    /* [n_smpl] (call->ploidy) or NULL = all diploid; constant over the tile */
+    const int32_t *grp;       /* [n_smpl] group id of each sample, or NULL */
+    const int32_t *prior_an;  /* [n_sites] -F AN or NULL */
+    const int32_t *prior_ac;  /* [site][4] -F AC, missing/vector_end sentinels allowed, or NULL */
+} bcfgpu_call_in;
+
+/* per-site result of the call stage */
+typedef struct {
+    int32_t ret;              /* mcall()'s return value: nals_new, 0, or -2 */
+    int32_t nals_new;         /* alleles kept */
+    int32_t als_new;          /* bit mask of kept alleles (call->als_new) */
+    int32_t als_map[5];       /* old -> new allele index or -1 (mcall.c:547-557) */
+    int32_t ac[5];            /* call->ac: per kept allele */
+    int32_t an;               /* INFO/AN */
+    int32_t qual_missing;     /* 1 when QUAL is '.' (mcall.c:1644) */
+    float   qual;             /* rec->qual */
+    int32_t pl_dropped;       /* 1 when FORMAT/PL is removed (mcall.c:1583) */
+} bcfgpu_call_site;
+
+/* per-sample results of the call stage:
+ *      gt [site][2][n_smpl]               i8   allele index, BCFGPU_GT_MISSING or BCFGPU_GT_VECTOR_END
+ *      pl [site][n_gt_max][n_smpl]        i32  trimmed PL (mcall.c:1158-1194) incl. sentinels; first ngts_new planes valid
+ *      gq [site][n_smpl]                  i32  FORMAT/GQ   (NULL unless requested)
+ *      gp [site][n_gt_max][n_smpl]        f32  FORMAT/GP   (NULL unless requested); missing = NaN 0x7F800001, vector_end = 0x7F800002
+ */
+typedef struct {
+    bcfgpu_call_site *site;
+    int8_t  *gt;
+    int32_t *pl;
+    int32_t *gq;
+    float   *gp;
+} bcfgpu_call_out;
+
+/* ---- life cycle ------------------------------------------------------------ */
+int  bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out);
+void bcfgpu_destroy(bcfgpu_ctx *ctx);
+const char *bcfgpu_last_error(void);
+int  bcfgpu_device_count(void);
+
+/* ---- device memory helpers (thin wrappers of hipMalloc/hipMemcpy) ---------- */
+int  bcfgpu_malloc(bcfgpu_ctx *ctx, size_t bytes, void **dptr);
+int  bcfgpu_free(bcfgpu_ctx *ctx, void *dptr);
+int  bcfgpu_memcpy_h2d(bcfgpu_ctx *ctx, void *dst, const void *src, size_t bytes);
+int  bcfgpu_memcpy_d2h(bcfgpu_ctx *ctx, void *dst, const void *src, size_t bytes);
+int  bcfgpu_memset(bcfgpu_ctx *ctx, void *dst, int value, size_t bytes);
+int  bcfgpu_sync(bcfgpu_ctx *ctx);
+/* enqueue on an externally owned hipStream_t (e.g. torch's current stream); NULL = the context's own */
+int  bcfgpu_set_stream(bcfgpu_ctx *ctx, void *hip_stream);
+
+/* ---- host-side read packer -------------------------------------------------
+ * Fills one `rd`/`epos` pair from the fields of a bam_pileup1_t / bam1_t.
+ * cigar = bam_get_cigar(b) (BAM encoding, len<<4|op), want_epos = fmt_flag has
+ * RPB or VDB (bam2bcf.c:232). */
+void bcfgpu_pack_read(int nt16, int baseQ, int mapQ, int is_rev, int has_softclip,
+                      int is_del, int is_refskip_or_unmapped, int qpos, int l_qseq,
+                      const uint32_t *cigar, int n_cigar, int want_epos,
+                      uint32_t *rd, uint8_t *epos);
+
+/* ---- the hot path ------------------------------------------------------------ */
+/* glfgen (+errmod_cal) for every (site,sample) and combine (+SGB/MWU/VDB) for every site of the tile */
+int  bcfgpu_mpileup(bcfgpu_ctx *ctx, const bcfgpu_tile *tile, const bcfgpu_mplp_out *out);
+
+/* mcall for every site of `in`; ploidy/groups/prior as described above */
+int  bcfgpu_mcall(bcfgpu_ctx *ctx, const bcfgpu_call_in *in, const bcfgpu_call_out *out);
+
+/* mpileup stage followed by the call stage with PL/QS kept in HBM (SNP tiles).
+ * `ploidy` and `grp` as in bcfgpu_call_in (device pointers or NULL).  `mout` receives the
+ * mpileup-stage results (input of the call stage), `cout` the calls. */
+int  bcfgpu_pipeline(bcfgpu_ctx *ctx, const bcfgpu_tile *tile, const uint8_t *ploidy, const int32_t *grp,
+                     const bcfgpu_mplp_out *mout, const bcfgpu_call_out *cout);
+
+/* byte sizes of the output planes for a tile of n_sites (n_smpl from the context) */
+size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *ctx, int n_sites, int which /*0 site,1 pl,2 dp4,3 adf,4 adr,5 qs,6 scr*/);
+
+/* timing of the last launches (ms, measured with HIP events on the stream the kernels ran on) */
+typedef struct { float glfgen_ms, combine_ms, mcall_ms, total_ms; } bcfgpu_timing;
+int  bcfgpu_timing_enable(bcfgpu_ctx *ctx, int on);
+int  bcfgpu_timing_get(bcfgpu_ctx *ctx, bcfgpu_timing *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,68 @@
+/*  bcforacle.h -- CPU oracle for the mpileup -> call -m hot path.
+ *
+ *  TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the reference
+ *  algorithm (bam2bcf.c, mcall.c and the htslib routines they call).  Only
+ *  tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ *  it; the product library (bcftools_amd/csrc) never links or calls it.
+ *
+ *  Parity pins (see tests/test_oracle_golden_*.py):
+ *    - glfgen + errmod_cal + combine: test/mpileup/mpileup.3.out from
+ *      mpileup.1.sam (BAQ-free golden of the reference's own test-suite)
+ *    - mcall: test/mpileup*.vcf, call-G*.vcf, call.af-fixation.vcf, mpileup.hwe.vcf,
+ *      mpileup.X.vcf against their .out goldens
+ *    - probaln_glocal / BAQ / kf_betai: parity unpinned
+ *
+ *  It takes and fills the same SoA structures as the device library
+ *  (include/bcfgpu.h), with HOST pointers.
+ */
+#ifndef BCFORACLE_H
+#define BCFORACLE_H
+
+#include "../include/bcfgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_errmod orc_errmod;
+
+/* htslib errmod.c: errmod_init(depcorr) / errmod_cal() -- call sites bam2bcf.c:51,256 */
+orc_errmod *orc_errmod_init(double depcorr);
+void orc_errmod_destroy(orc_errmod *em);
+int  orc_errmod_cal(const orc_errmod *em, int n, int m, uint16_t *bases, float *q);
+const double *orc_errmod_fk(const orc_errmod *em);
+const double *orc_errmod_beta(const orc_errmod *em);
+const double *orc_errmod_lhet(const orc_errmod *em);
+
+/* htslib kfunc.c */
+double orc_kf_erfc(double x);
+double orc_kt_fisher_exact(int n11, int n12, int n21, int n22, double *left, double *right, double *two);
+
+/* bam2bcf.c:281-530 */
+double orc_calc_vdb(const int *pos, int npos);
+double orc_calc_mwu_bias(const int *a, const int *b, int n);
+
+/* Per (site,sample) result of bcf_call_glfgen, for kernel-level checks */
+typedef struct {
+    float    p[25];
+    double   anno[16];
+    int32_t  QS[4], ADF[4], ADR[4];
+    int32_t  SCR, n;          /* n = return value of bcf_call_glfgen (-1 when _n==0) */
+    uint32_t ori_depth, mq0;
+} orc_callret;
+
+/* mpileup stage over a tile: bcf_callaux_clean + glfgen x n_smpl + combine, per site
+ * (mpileup.c:343-347).  `ret_dbg` (may be NULL) receives [n_sites*n_smpl] callrets.
+ * Returns 0 or BCFGPU_E_*. */
+int orc_mpileup(const bcfgpu_cfg *cfg, const bcfgpu_tile *tile, const bcfgpu_mplp_out *out, orc_callret *ret_dbg);
+
+/* call stage over a tile: mcall() per site (mcall.c:1430-1684) */
+int orc_mcall(const bcfgpu_cfg *cfg, const bcfgpu_call_in *in, const bcfgpu_call_out *out);
+
+/* FORMAT/SP from DP4 (bam2bcf.c:867-885) */
+int orc_format_sp(int fwd_ref, int rev_ref, int fwd_alt, int rev_alt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
