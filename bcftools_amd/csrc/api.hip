@@ -1,0 +1,378 @@
+// api.hip -- the C-ABI of include/bcfgpu.h: context, device-memory helpers, launch sequencing.
+//
+// There is deliberately no CPU fallback here: without a HIP device bcfgpu_create() fails with
+// BCFGPU_E_NODEV (the only host-side compute entry, bcfgpu_pack_read, is the data packer).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include "kernels.h"
+#include "tables.h"
+
+using namespace bcfgpu;
+
+static thread_local std::string g_err;
+static int set_err(int code, const char *what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(BCFGPU_E_HIP, #call, e_); } while (0)
+
+struct bcfgpu_ctx {
+    bcfgpu_cfg cfg;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // constant tables in HBM
+    double *d_fk = nullptr, *d_beta = nullptr, *d_lhet = nullptr, *d_pl2p = nullptr, *d_mw = nullptr;
+    double call_theta_log = 0;
+    // workspaces sized by cfg.max_sites / cfg.max_reads
+    uint16_t *d_codes = nullptr;
+    int *d_hist = nullptr, *d_err = nullptr;
+    CallretPlanes cr{};
+    size_t ncells_cap = 0;
+    // timing
+    int timing = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bcfgpu_timing last{};
+    std::vector<void*> owned;
+};
+
+extern "C" {
+
+const char *bcfgpu_last_error(void) { return g_err.c_str(); }
+
+int bcfgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void bcfgpu_abi_sizes(int32_t *out)
+{
+    out[0] = (int32_t)sizeof(bcfgpu_cfg); out[1] = (int32_t)sizeof(bcfgpu_tile); out[2] = (int32_t)sizeof(bcfgpu_site);
+    out[3] = (int32_t)sizeof(bcfgpu_mplp_out); out[4] = (int32_t)sizeof(bcfgpu_call_in); out[5] = (int32_t)sizeof(bcfgpu_call_site);
+    out[6] = (int32_t)sizeof(bcfgpu_call_out); out[7] = (int32_t)sizeof(bcfgpu_timing);
+}
+
+static int dev_alloc(bcfgpu_ctx *c, void **p, size_t bytes)
+{
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return set_err(BCFGPU_E_NOMEM, "hipMalloc", e);
+    c->owned.push_back(*p);
+    return 0;
+}
+
+int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
+{
+    if (!cfg || !out || cfg->n_smpl <= 0) return set_err(BCFGPU_E_ARG, "bcfgpu_create: bad arguments");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_err(BCFGPU_E_NODEV, "bcfgpu_create: no HIP device (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return set_err(BCFGPU_E_ARG, "bcfgpu_create: device ordinal out of range");
+    HIPCHK(hipSetDevice(cfg->device));
+    bcfgpu_ctx *c = new bcfgpu_ctx();
+    c->cfg = *cfg;
+    if (c->cfg.capQ <= 0) c->cfg.capQ = 60;
+    if (c->cfg.min_baseQ < 0) c->cfg.min_baseQ = 0;
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return set_err(BCFGPU_E_HIP, "hipStreamCreate", e); }
+    c->stream = c->own_stream;
+    for (int i = 0; i < 4; ++i) hipEventCreate(&c->ev[i]);
+
+    // tables
+    const double theta = cfg->errmod_theta <= 0. ? 0.83 : cfg->errmod_theta;     // CALL_DEFTHETA, bam2bcf.c:38,46
+    std::vector<double> fk, beta, lhet;
+    build_errmod_tables(1. - theta, fk, beta, lhet);
+    double pl2p[256], mw[6 * 6 * 50];
+    build_pl2p(pl2p);
+    build_mw_table(mw);
+    int rc = 0;
+    if ((rc = dev_alloc(c, (void**)&c->d_fk, fk.size() * 8)) || (rc = dev_alloc(c, (void**)&c->d_beta, beta.size() * 8)) ||
+        (rc = dev_alloc(c, (void**)&c->d_lhet, lhet.size() * 8)) || (rc = dev_alloc(c, (void**)&c->d_pl2p, sizeof pl2p)) ||
+        (rc = dev_alloc(c, (void**)&c->d_mw, sizeof mw)) || (rc = dev_alloc(c, (void**)&c->d_err, sizeof(int)))) {
+        bcfgpu_destroy(c); return rc;
+    }
+    hipMemcpy(c->d_fk, fk.data(), fk.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(c->d_beta, beta.data(), beta.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(c->d_lhet, lhet.data(), lhet.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(c->d_pl2p, pl2p, sizeof pl2p, hipMemcpyHostToDevice);
+    hipMemcpy(c->d_mw, mw, sizeof mw, hipMemcpyHostToDevice);
+    hipMemset(c->d_err, 0, sizeof(int));
+
+    // the prior: theta <- log(theta * sum_{i<n} 1/i), n = ploidy_max * nsamples (mcall.c:396-416, vcfcall.c:654-655)
+    c->call_theta_log = 0;
+    if (cfg->call_theta > 0) {
+        const int pm = cfg->ploidy_max > 0 ? cfg->ploidy_max : 2;
+        const int n = pm * cfg->n_smpl;
+        double aM = 1;
+        for (int i = 2; i < n; i++) aM += 1. / i;
+        double t = cfg->call_theta * aM;
+        if (t >= 1) t = 0.99;
+        c->call_theta_log = std::log(t);
+    }
+
+    // workspaces
+    const size_t ncells = (size_t)(cfg->max_sites > 0 ? cfg->max_sites : 0) * cfg->n_smpl;
+    c->ncells_cap = ncells;
+    if (ncells) {
+        if ((rc = dev_alloc(c, (void**)&c->d_codes, (size_t)cfg->max_reads * 2 + 16)) ||
+            (rc = dev_alloc(c, (void**)&c->d_hist, (size_t)cfg->max_sites * H_SIZE * sizeof(int))) ||
+            (rc = dev_alloc(c, (void**)&c->cr.p15, ncells * 15 * sizeof(float))) ||
+            (rc = dev_alloc(c, (void**)&c->cr.qs64, ncells * 8)) ||
+            (rc = dev_alloc(c, (void**)&c->cr.adf, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->cr.adr, ncells * 4)) ||
+            (rc = dev_alloc(c, (void**)&c->cr.cnt4, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->cr.sums, ncells * 12 * 4)) ||
+            (rc = dev_alloc(c, (void**)&c->cr.misc, ncells * 4))) {
+            bcfgpu_destroy(c); return rc;
+        }
+    }
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) { bcfgpu_destroy(c); return set_err(BCFGPU_E_HIP, "table upload", e); }
+    *out = c;
+    return BCFGPU_OK;
+}
+
+void bcfgpu_destroy(bcfgpu_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->cfg.device);
+    if (c->own_stream) hipStreamSynchronize(c->own_stream);
+    for (void *p : c->owned) hipFree(p);
+    for (int i = 0; i < 4; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int bcfgpu_malloc(bcfgpu_ctx *c, size_t bytes, void **dptr)
+{
+    if (!c || !dptr) return set_err(BCFGPU_E_ARG, "bcfgpu_malloc: bad arguments");
+    hipSetDevice(c->cfg.device);
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) return set_err(BCFGPU_E_NOMEM, "hipMalloc", e);
+    return 0;
+}
+int bcfgpu_free(bcfgpu_ctx *c, void *dptr)
+{
+    if (!c) return set_err(BCFGPU_E_ARG, "bcfgpu_free: bad arguments");
+    HIPCHK(hipFree(dptr));
+    return 0;
+}
+int bcfgpu_memcpy_h2d(bcfgpu_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c) return set_err(BCFGPU_E_ARG, "bcfgpu_memcpy_h2d: bad arguments");
+    if (!bytes) return 0;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int bcfgpu_memcpy_d2h(bcfgpu_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c) return set_err(BCFGPU_E_ARG, "bcfgpu_memcpy_d2h: bad arguments");
+    if (!bytes) return 0;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int bcfgpu_memset(bcfgpu_ctx *c, void *dst, int value, size_t bytes)
+{
+    if (!c) return set_err(BCFGPU_E_ARG, "bcfgpu_memset: bad arguments");
+    if (!bytes) return 0;
+    HIPCHK(hipMemsetAsync(dst, value, bytes, c->stream));
+    return 0;
+}
+int bcfgpu_sync(bcfgpu_ctx *c)
+{
+    if (!c) return set_err(BCFGPU_E_ARG, "bcfgpu_sync: bad arguments");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) {
+        hipMemset(c->d_err, 0, sizeof(int));
+        return set_err(err, err == BCFGPU_E_DEPTH ? "a (site,sample) cell holds more than 255 usable reads" : "device-side error");
+    }
+    return 0;
+}
+int bcfgpu_set_stream(bcfgpu_ctx *c, void *hip_stream)
+{
+    if (!c) return set_err(BCFGPU_E_ARG, "bcfgpu_set_stream: bad arguments");
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return 0;
+}
+
+// get_position (bam2bcf.c:80-114) + the per-read fields of bcf_call_glfgen
+void bcfgpu_pack_read(int nt16, int baseQ, int mapQ, int is_rev, int has_softclip, int is_del,
+                      int is_refskip_or_unmapped, int qpos, int l_qseq, const uint32_t *cigar, int n_cigar,
+                      int want_epos, uint32_t *rd, uint8_t *epos)
+{
+    int tail = l_qseq - 1 - qpos;
+    if (tail > qpos) tail = qpos;
+    if (tail < 0) tail = 0;
+    if (tail > 255) tail = 255;
+    *rd = (uint32_t)(baseQ & 0xff) | (uint32_t)(mapQ & 0xff) << 8 | (uint32_t)(nt16 & 0xf) << 16
+        | (is_rev ? BCFGPU_RD_REV : 0) | (has_softclip ? BCFGPU_RD_SCLIP : 0) | (is_del ? BCFGPU_RD_DEL : 0)
+        | (is_refskip_or_unmapped ? BCFGPU_RD_SKIP : 0) | (uint32_t)tail << 24;
+    int e = 0;
+    if (want_epos && cigar) {
+        int n_tot_bases = 0, iread = 0, edist = qpos + 1;
+        for (int ic = 0; ic < n_cigar; ic++) {
+            const int op = cigar[ic] & 0xf, len = (int)(cigar[ic] >> 4);
+            if (op == 0 /*M*/ || op == 7 /*=*/ || op == 8 /*X*/ || op == 1 /*I*/) { n_tot_bases += len; iread += len; }
+            else if (op == 4 /*S*/) { iread += len; if (iread <= qpos) edist -= len; }
+        }
+        e = (int)((double)edist / (n_tot_bases + 1) * BCFGPU_NPOS);
+        if (e < 0) e = 0;
+        if (e > BCFGPU_NPOS - 1) e = BCFGPU_NPOS - 1;
+    }
+    *epos = (uint8_t)e;
+}
+
+size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *c, int n_sites, int which)
+{
+    if (!c || n_sites < 0) return 0;
+    const size_t S = c->cfg.n_smpl, n = n_sites;
+    switch (which) {
+        case 0: return n * sizeof(bcfgpu_site);
+        case 1: return n * BCFGPU_MAX_PL * S;
+        case 2: return n * 4 * S;
+        case 3: case 4: return n * 5 * S;
+        case 5: return n * 5 * S * 2;
+        case 6: return n * S;
+    }
+    return 0;
+}
+
+int bcfgpu_timing_enable(bcfgpu_ctx *c, int on) { if (!c) return BCFGPU_E_ARG; c->timing = on; return 0; }
+int bcfgpu_timing_get(bcfgpu_ctx *c, bcfgpu_timing *t)
+{
+    if (!c || !t) return set_err(BCFGPU_E_ARG, "bcfgpu_timing_get: bad arguments");
+    *t = c->last;
+    return 0;
+}
+
+static int check_tile(bcfgpu_ctx *c, const bcfgpu_tile *t)
+{
+    if (!t || t->n_sites < 0) return set_err(BCFGPU_E_ARG, "bad tile");
+    if (t->n_sites > c->cfg.max_sites || t->n_reads > c->cfg.max_reads)
+        return set_err(BCFGPU_E_RANGE, "tile exceeds the capacity the context was created with");
+    if (t->n_sites && (!t->plp_off || (!t->is_indel && !t->ref16) || (t->n_reads && (!t->rd || !t->epos))))
+        return set_err(BCFGPU_E_ARG, "tile: NULL array");
+    if (t->is_indel && t->n_reads && !t->aux) return set_err(BCFGPU_E_ARG, "indel tile without aux");
+    return 0;
+}
+
+static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_mplp_out *out)
+{
+    const int S = c->cfg.n_smpl;
+    GlfgenParams g{};
+    g.n_sites = tile->n_sites; g.n_smpl = S; g.is_indel = tile->is_indel;
+    g.min_baseQ = c->cfg.min_baseQ; g.capQ = c->cfg.capQ; g.fmt_flag = c->cfg.fmt_flag;
+    // one workgroup = 256 consecutive cells = at most (255/S)+2 sites
+    const int slots = 255 / S + 2;
+    g.hist_slots = slots <= 8 ? slots : 0;
+    g.ref16 = tile->ref16; g.off = tile->plp_off; g.rd = tile->rd; g.epos = tile->epos; g.aux = tile->aux;
+    g.codes = c->d_codes; g.fk = c->d_fk; g.beta = c->d_beta; g.lhet = c->d_lhet;
+    g.cr = c->cr;
+    // the callret planes are addressed with ncells of *this* tile
+    g.hist = c->d_hist; g.err = c->d_err;
+    HIPCHK(hipMemsetAsync(c->d_hist, 0, (size_t)tile->n_sites * H_SIZE * sizeof(int), c->stream));
+    if (c->timing) hipEventRecord(c->ev[0], c->stream);
+    launch_glfgen(g, c->stream);
+    if (c->timing) hipEventRecord(c->ev[1], c->stream);
+    CombineParams k{};
+    k.n_sites = tile->n_sites; k.n_smpl = S; k.is_indel = tile->is_indel; k.fmt_flag = c->cfg.fmt_flag;
+    k.ref16 = tile->ref16; k.cr = c->cr; k.hist = c->d_hist; k.mw = c->d_mw; k.out = *out;
+    launch_combine(k, c->stream);
+    if (c->timing) hipEventRecord(c->ev[2], c->stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static void finish_timing(bcfgpu_ctx *c, bool with_call)
+{
+    if (!c->timing) return;
+    hipEventSynchronize(with_call ? c->ev[3] : c->ev[2]);
+    bcfgpu_timing t{};
+    hipEventElapsedTime(&t.glfgen_ms, c->ev[0], c->ev[1]);
+    hipEventElapsedTime(&t.combine_ms, c->ev[1], c->ev[2]);
+    if (with_call) hipEventElapsedTime(&t.mcall_ms, c->ev[2], c->ev[3]);
+    hipEventElapsedTime(&t.total_ms, c->ev[0], with_call ? c->ev[3] : c->ev[2]);
+    c->last = t;
+}
+
+int bcfgpu_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_mplp_out *out)
+{
+    if (!c || !out || !out->site || !out->pl || !out->dp4) return set_err(BCFGPU_E_ARG, "bcfgpu_mpileup: bad arguments");
+    int rc = check_tile(c, tile);
+    if (rc) return rc;
+    if (tile->n_sites == 0) return 0;
+    hipSetDevice(c->cfg.device);
+    rc = enqueue_mpileup(c, tile, out);
+    if (rc) return rc;
+    finish_timing(c, false);
+    return 0;
+}
+
+int bcfgpu_mcall(bcfgpu_ctx *c, const bcfgpu_call_in *in, const bcfgpu_call_out *out)
+{
+    if (!c || !in || !out || !out->site || !out->gt) return set_err(BCFGPU_E_ARG, "bcfgpu_mcall: bad arguments");
+    if (in->n_sites == 0) return 0;
+    if (!in->nals || !in->unseen || !in->pl || (!in->qs && !(c->cfg.n_grp > 1)))
+        return set_err(BCFGPU_E_ARG, "bcfgpu_mcall: NULL input array");
+    if (c->cfg.n_grp > 1 && (!in->grp || !in->ad)) return set_err(BCFGPU_E_ARG, "bcfgpu_mcall: -G needs grp and ad");
+    if (in->n_gt_max < 1 || in->n_gt_max > BCFGPU_MAX_PL) return set_err(BCFGPU_E_ARG, "bcfgpu_mcall: n_gt_max out of range");
+    hipSetDevice(c->cfg.device);
+    McallParams m{};
+    m.n_sites = in->n_sites; m.n_smpl = c->cfg.n_smpl; m.n_gt_max = in->n_gt_max; m.n_al_max = in->n_al_max;
+    m.pl_is_u8 = 0; m.call_flag = c->cfg.call_flag; m.output_tags = c->cfg.output_tags; m.n_grp = c->cfg.n_grp;
+    m.theta = c->call_theta_log; m.pl2p = c->d_pl2p;
+    m.nals = in->nals; m.unseen = in->unseen; m.msite = nullptr; m.pl = in->pl; m.qs = in->qs; m.ad = in->ad;
+    m.ploidy = in->ploidy; m.grp = c->cfg.n_grp > 1 ? in->grp : nullptr; m.prior_an = in->prior_an; m.prior_ac = in->prior_ac;
+    m.out = *out; m.out_n_gt_max = in->n_gt_max;
+    if (c->timing) hipEventRecord(c->ev[2], c->stream);
+    launch_mcall(m, c->stream);
+    if (c->timing) { hipEventRecord(c->ev[3], c->stream); hipEventSynchronize(c->ev[3]);
+        bcfgpu_timing t{}; hipEventElapsedTime(&t.mcall_ms, c->ev[2], c->ev[3]); t.total_ms = t.mcall_ms; c->last = t; }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploidy, const int32_t *grp,
+                    const bcfgpu_mplp_out *mout, const bcfgpu_call_out *cout)
+{
+    if (!c || !mout || !cout || !mout->site || !mout->pl || !mout->dp4 || !cout->site || !cout->gt)
+        return set_err(BCFGPU_E_ARG, "bcfgpu_pipeline: bad arguments");
+    int rc = check_tile(c, tile);
+    if (rc) return rc;
+    if (tile->is_indel) return set_err(BCFGPU_E_ARG, "bcfgpu_pipeline: SNP tiles only (run indel tiles through bcfgpu_mpileup + bcfgpu_mcall)");
+    if (tile->n_sites == 0) return 0;
+    if (c->cfg.n_grp > 1 && (!grp || (c->cfg.grp_tag_is_qs ? !mout->qs : (!mout->adf || !mout->adr))))
+        return set_err(BCFGPU_E_ARG, "bcfgpu_pipeline: -G needs grp and the AD (or QS) planes");
+    hipSetDevice(c->cfg.device);
+    rc = enqueue_mpileup(c, tile, mout);
+    if (rc) return rc;
+    McallParams m{};
+    m.n_sites = tile->n_sites; m.n_smpl = c->cfg.n_smpl; m.n_gt_max = BCFGPU_MAX_PL; m.n_al_max = 5;
+    m.pl_is_u8 = 1; m.call_flag = c->cfg.call_flag; m.output_tags = c->cfg.output_tags; m.n_grp = c->cfg.n_grp;
+    m.theta = c->call_theta_log; m.pl2p = c->d_pl2p;
+    m.msite = mout->site; m.pl = mout->pl; m.qs = nullptr; m.ad = nullptr;
+    m.qs_u16 = (c->cfg.n_grp > 1 && c->cfg.grp_tag_is_qs) ? mout->qs : nullptr;
+    if (c->cfg.n_grp > 1 && !c->cfg.grp_tag_is_qs) { m.ad_u8 = mout->adf; m.ad_u8b = mout->adr; }   // FORMAT/AD = ADF+ADR (bam2bcf.c:892-896)
+    m.ploidy = ploidy; m.grp = c->cfg.n_grp > 1 ? grp : nullptr;
+    m.out = *cout; m.out_n_gt_max = BCFGPU_MAX_PL;
+    launch_mcall(m, c->stream);
+    if (c->timing) hipEventRecord(c->ev[3], c->stream);
+    HIPCHK(hipGetLastError());
+    finish_timing(c, true);
+    return 0;
+}
+
+}  // extern "C"

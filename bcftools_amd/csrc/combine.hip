@@ -1,0 +1,371 @@
+// combine.hip -- bcf_call_combine (+ calc_SegBias, calc_mwu_bias x4, calc_vdb) for every site of a tile.
+//
+// Replaces bam2bcf.c:558-754, :281-342, :440-530.  One 256-thread workgroup per site.
+//
+// Order-sensitive pieces are replayed in the reference's order:
+//   * qsum[j] += (float)QS[j]/sum over samples (bam2bcf.c:569-575) decides the ALT allele
+//     order, so it is a sequential float32 sum, one lane per allele, over LDS-staged QS;
+//   * sum_min (bam2bcf.c:642) is a sequential double sum (lane 0).
+// Integer totals (DP4, AD, I16, depth, ...) are exact in any order and use wave reductions.
+// SGB is a sum of log/exp terms whose last bits already differ from glibc's, so it uses a
+// tree reduction (compared with a relative tolerance).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <float.h>
+#include "kernels.h"
+
+namespace bcfgpu {
+
+#define WG 256
+#define CHUNK 2048        // samples staged in LDS per round
+
+__device__ __forceinline__ int nt16_int_c(int c) { return (int)((0x4444444344424104ull >> (4 * (c & 15))) & 7); }
+__device__ __forceinline__ int tri_c(int j, int k) { return j <= k ? k * (k + 1) / 2 + j : j * (j + 1) / 2 + k; }
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// kf_erfc (htslib kfunc.c; Hart/West rational approximation), used by calc_vdb (bam2bcf.c:341)
+__device__ double dev_kf_erfc(double x)
+{
+    const double p0 = 220.2068679123761, p1 = 221.2135961699311, p2 = 112.0792914978709, p3 = 33.912866078383,
+                 p4 = 6.37396220353165, p5 = .7003830644436881, p6 = .03526249659989109;
+    const double q0 = 440.4137358247522, q1 = 793.8265125199484, q2 = 637.3336333788311, q3 = 296.5642487796737,
+                 q4 = 86.78073220294608, q5 = 16.06417757920695, q6 = 1.755667163182642, q7 = .08838834764831844;
+    double expntl, z, p;
+    z = fabs(x) * M_SQRT2;
+    if (z > 37.) return x > 0. ? 0. : 2.;
+    expntl = exp(z * z * -.5);
+    if (z < 10. / M_SQRT2)
+        p = expntl * ((((((p6 * z + p5) * z + p4) * z + p3) * z + p2) * z + p1) * z + p0)
+            / (((((((q7 * z + q6) * z + q5) * z + q4) * z + q3) * z + q2) * z + q1) * z + q0);
+    else p = expntl / 2.506628274631001 / (z + 1. / (z + 2. / (z + 3. / (z + 4. / (z + .65)))));
+    return x > 0. ? 2. * p : 2. * (1. - p);
+}
+
+// calc_vdb, bam2bcf.c:281-342
+__device__ float dev_calc_vdb(const int *pos)
+{
+    const int readlen = 100, nparam = 15;
+    const float param[15][3] = { {3,0.079f,18}, {4,0.09f,19.8f}, {5,0.1f,20.5f}, {6,0.11f,21.5f},
+        {7,0.125f,21.6f}, {8,0.135f,22}, {9,0.14f,22.2f}, {10,0.153f,22.3f}, {15,0.19f,22.8f},
+        {20,0.22f,23.2f}, {30,0.26f,23.4f}, {40,0.29f,23.5f}, {50,0.35f,23.65f}, {100,0.5f,23.7f},
+        {200,0.7f,23.7f} };
+    int i, dp = 0;
+    float mean_pos = 0, mean_diff = 0;
+    for (i = 0; i < readlen; i++) {
+        if (!pos[i]) continue;
+        dp += pos[i];
+        mean_pos += pos[i] * i;
+    }
+    if (dp < 2) return HUGE_VALF;
+    mean_pos /= dp;
+    for (i = 0; i < readlen; i++) {
+        if (!pos[i]) continue;
+        mean_diff = (float)((double)mean_diff + pos[i] * fabs((double)((float)i - mean_pos)));
+    }
+    mean_diff /= dp;
+    int ipos = (int)mean_diff;
+    if (dp == 2)
+        return (float)((2 * readlen - 2 * (ipos + 1) - 1) * (ipos + 1) / (readlen - 1) / (readlen * 0.5));
+    if (dp >= 200) i = nparam;
+    else {
+        for (i = 0; i < nparam; i++)
+            if (param[i][0] >= dp) break;
+    }
+    float pshift, pscale;
+    if (i == nparam) { pscale = param[nparam - 1][1]; pshift = param[nparam - 1][2]; }
+    else if (i > 0 && param[i][0] != dp) {
+        pscale = (float)((param[i - 1][1] + param[i][1]) * 0.5);
+        pshift = (float)((param[i - 1][2] + param[i][2]) * 0.5);
+    } else { pscale = param[i][1]; pshift = param[i][2]; }
+    return (float)(0.5 * dev_kf_erfc(-(double)((mean_diff - pshift) * pscale)));
+}
+
+// calc_mwu_bias, bam2bcf.c:440-484
+__device__ float dev_calc_mwu_bias(const int *a, const int *b, int n, const double *mw)
+{
+    int na = 0, nb = 0, i;
+    double U = 0;
+    for (i = 0; i < n; i++) {
+        if (!a[i]) {
+            if (!b[i]) continue;
+            nb += b[i];
+        } else if (!b[i]) {
+            na += a[i];
+            U += (double)(a[i] * nb);
+        } else {
+            na += a[i];
+            U += a[i] * (nb + b[i] * 0.5);
+            nb += b[i];
+        }
+    }
+    if (!na || !nb) return HUGE_VALF;
+    if (na == 1 || nb == 1) return 1.0f;
+    double mean = ((double)na * nb) * 0.5;
+    if (na == 2 || nb == 2) return (float)(U > mean ? (2.0 * mean - U) / mean : U / mean);
+    double var2 = ((double)na * nb) * (na + nb + 1) / 12.0;
+    if (na >= 8 || nb >= 8) return (float)exp(-0.5 * (U - mean) * (U - mean) / var2);
+    // exact: na,nb in 3..7, U < na*nb <= 49 -> always inside the mw.h table (bam2bcf.c:382)
+    int iu = (int)U;
+    double m = (iu >= 0 && iu < 50) ? mw[((na - 2) * 6 + (nb - 2)) * 50 + iu] : 0.0;
+    return (float)(m * sqrt(2 * M_PI * var2));
+}
+
+__device__ __forceinline__ double dev_logsumexp2(double a, double b)
+{
+    if (a > b) return log(1 + exp(b - a)) + a;
+    else       return log(1 + exp(a - b)) + b;
+}
+
+struct SiteShared {
+    int a[5]; int n_alleles, unseen, ori_ref, x;
+    float qsum_out[5];
+    int g[15];
+    unsigned long long tot[32];   // integer totals
+    double segb_sum; double sum_min;
+    float bias[6];
+};
+
+__global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
+{
+    __shared__ SiteShared sh;
+    __shared__ unsigned long long s_stage[CHUNK];   // QS (4 x u16) per sample, later float mins
+    __shared__ float s_q[4];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int is = blockIdx.x;
+    const int S = P.n_smpl;
+    const long ncells = (long)P.n_sites * S;
+    const long c0 = (long)is * S;
+    bcfgpu_site *site = &P.out.site[is];
+
+    const int ref_base = P.is_indel ? -1 : P.ref16[is];
+    int ref4;
+    if (ref_base >= 0) { ref4 = nt16_int_c(ref_base); if (ref4 > 4) ref4 = 4; } else ref4 = 0;
+
+    if (tid < 32) sh.tot[tid] = 0;
+    if (tid == 0) { sh.segb_sum = 0; sh.sum_min = 0; }
+
+    // ---- qsum: sequential float sum over samples, lane j owns allele j (bam2bcf.c:569-575) ----
+    float myq = 0.f;
+    for (int base = 0; base < S; base += CHUNK) {
+        const int cn = min(CHUNK, S - base);
+        __syncthreads();
+        for (int i = tid; i < cn; i += WG) s_stage[i] = P.cr.qs64[c0 + base + i];
+        __syncthreads();
+        if (tid < 4) {
+            for (int i = 0; i < cn; ++i) {
+                const unsigned long long v = s_stage[i];
+                float sum = 0;
+                sum += (float)(int)(v & 0xffff); sum += (float)(int)((v >> 16) & 0xffff);
+                sum += (float)(int)((v >> 32) & 0xffff); sum += (float)(int)((v >> 48) & 0xffff);
+                if (sum != 0.f) myq += (float)(int)((v >> (16 * tid)) & 0xffff) / sum;
+            }
+        }
+    }
+    if (tid < 4) s_q[tid] = myq;
+    __syncthreads();
+
+    // ---- allele ordering (bam2bcf.c:577-632), lane 0 ----
+    if (tid == 0) {
+        float qsum[5] = { s_q[0], s_q[1], s_q[2], s_q[3], 0.f };
+        int idx[5] = {0, 1, 2, 3, 4};
+        for (int i = 1; i < 4; i++)
+            for (int j = i; j > 0 && qsum[idx[j]] < qsum[idx[j - 1]]; j--) { int t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t; }
+        for (int i = 0; i < 5; i++) { sh.a[i] = -1; sh.qsum_out[i] = 0; }
+        sh.unseen = -1;
+        sh.a[0] = ref4;
+        int i, j;
+        for (i = 3, j = 1; i >= 0; i--) {
+            const int ipos = idx[i];
+            if (ipos == ref4) sh.qsum_out[0] = qsum[ipos];
+            else {
+                if (!qsum[ipos]) break;
+                sh.qsum_out[j] = qsum[ipos];
+                sh.a[j++] = ipos;
+            }
+        }
+        int ret = 0;
+        if (ref_base >= 0) {
+            if (((ref4 < 4 && j < 4) || (ref4 == 4 && j < 5)) && i >= 0) { sh.unseen = j; sh.a[j++] = idx[i]; }
+            sh.n_alleles = j;
+        } else {
+            sh.n_alleles = j;
+            if (j == 1) ret = -1;
+        }
+        sh.ori_ref = ref_base >= 0 ? nt16_int_c(ref_base) : -1;
+        sh.x = sh.n_alleles * (sh.n_alleles + 1) / 2;
+        int z = 0;
+        for (i = 0; i < sh.n_alleles; ++i)
+            for (j = 0; j <= i; ++j) sh.g[z++] = tri_c(sh.a[j], sh.a[i]);
+        site->ret = ret;
+    }
+    __syncthreads();
+    const int nal = sh.n_alleles, x = sh.x;
+    const bool dead = (P.is_indel && nal == 1);     // bcf_call_combine returned -1 (bam2bcf.c:611)
+
+    // ---- per-sample planes + integer totals ----
+    unsigned long long t_adf[5] = {0,0,0,0,0}, t_adr[5] = {0,0,0,0,0};
+    unsigned long long t_scr = 0, t_ori = 0, t_mq0 = 0, t_cnt[4] = {0,0,0,0}, t_sum[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+    const size_t Ss = (size_t)S;
+    for (int base = 0; base < S; base += CHUNK) {
+        const int cn = min(CHUNK, S - base);
+        __syncthreads();
+        float *s_min = reinterpret_cast<float*>(s_stage);
+        for (int i = tid; i < cn; i += WG) {
+            const int s = base + i;
+            const long cell = c0 + s;
+            float mn = 0.f;
+            if (!dead) {
+                float pv[15];
+                mn = FLT_MAX;
+                #pragma unroll
+                for (int j = 0; j < 15; ++j) {
+                    if (j < x) { pv[j] = P.cr.p15[(size_t)sh.g[j] * ncells + cell]; if (mn > pv[j]) mn = pv[j]; }
+                }
+                uint8_t *PL = P.out.pl + (size_t)is * BCFGPU_MAX_PL * Ss + s;
+                #pragma unroll
+                for (int j = 0; j < 15; ++j) {
+                    if (j < x) {
+                        int y = (int)((double)(pv[j] - mn) + .499);
+                        if (y > 255) y = 255;
+                        PL[(size_t)j * Ss] = (uint8_t)y;
+                    }
+                }
+            }
+            s_min[i] = mn;
+            const uint32_t cnt4 = P.cr.cnt4[cell], adf = P.cr.adf[cell], adr = P.cr.adr[cell], misc = P.cr.misc[cell];
+            const unsigned long long qs64 = P.cr.qs64[cell];
+            if (!dead) {
+                uint8_t *DP4 = P.out.dp4 + (size_t)is * 4 * Ss + s;
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) DP4[(size_t)j * Ss] = (uint8_t)((cnt4 >> (8 * j)) & 0xff);
+                const uint32_t scr = (misc >> 8) & 0xff;
+                if (P.out.scr) P.out.scr[(size_t)is * Ss + s] = (uint8_t)scr;
+                t_scr += scr;
+                #pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    if (j < nal) {
+                        const int aj = sh.a[j];
+                        const uint32_t vf = aj < 4 ? (adf >> (8 * aj)) & 0xff : 0;
+                        const uint32_t vr = aj < 4 ? (adr >> (8 * aj)) & 0xff : 0;
+                        t_adf[j] += vf; t_adr[j] += vr;
+                        if (P.out.adf) P.out.adf[((size_t)is * 5 + j) * Ss + s] = (uint8_t)vf;
+                        if (P.out.adr) P.out.adr[((size_t)is * 5 + j) * Ss + s] = (uint8_t)vr;
+                        if (P.out.qs) P.out.qs[((size_t)is * 5 + j) * Ss + s] = (uint16_t)(aj < 4 ? (qs64 >> (16 * aj)) & 0xffff : 0);
+                    }
+                }
+            }
+            t_ori += misc >> 16; t_mq0 += misc & 0xff;
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) t_cnt[j] += (cnt4 >> (8 * j)) & 0xff;
+            #pragma unroll
+            for (int j = 0; j < 12; ++j) t_sum[j] += P.cr.sums[(size_t)j * ncells + cell];
+        }
+        __syncthreads();
+        if (tid == 0 && !dead) {          // sum_min: sequential double sum (bam2bcf.c:642)
+            double sm = sh.sum_min;
+            for (int i = 0; i < cn; ++i) sm += s_min[i];
+            sh.sum_min = sm;
+        }
+    }
+    // wave reductions of the integer totals, then one LDS atomic per wave
+    {
+        unsigned long long v;
+        #pragma unroll
+        for (int j = 0; j < 5; ++j) { v = wave_sum_u64(t_adf[j]); if (lane == 0 && v) atomicAdd(&sh.tot[j], v); }
+        #pragma unroll
+        for (int j = 0; j < 5; ++j) { v = wave_sum_u64(t_adr[j]); if (lane == 0 && v) atomicAdd(&sh.tot[5 + j], v); }
+        v = wave_sum_u64(t_scr); if (lane == 0 && v) atomicAdd(&sh.tot[10], v);
+        v = wave_sum_u64(t_ori); if (lane == 0 && v) atomicAdd(&sh.tot[11], v);
+        v = wave_sum_u64(t_mq0); if (lane == 0 && v) atomicAdd(&sh.tot[12], v);
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) { v = wave_sum_u64(t_cnt[j]); if (lane == 0 && v) atomicAdd(&sh.tot[13 + j], v); }
+        #pragma unroll
+        for (int j = 0; j < 12; ++j) { v = wave_sum_u64(t_sum[j]); if (lane == 0 && v) atomicAdd(&sh.tot[17 + j], v); }
+    }
+    __syncthreads();
+
+    // ---- calc_SegBias (bam2bcf.c:494-530): tree-reduced sum of per-sample terms ----
+    const double an0 = (double)sh.tot[13], an1 = (double)sh.tot[14], an2 = (double)sh.tot[15], an3 = (double)sh.tot[16];
+    const int nr = (int)(an2 + an3);
+    if (nr && !dead) {
+        const int avg_dp = (int)((an0 + an1 + nr) / S);
+        double M = floor((double)nr / avg_dp + 0.5);
+        if (M > S) M = S;
+        else if (M == 0) M = 1;
+        const double f = M / 2. / S;
+        const double p = (double)nr / S;
+        const double q = (double)nr / M;
+        const double log2 = log(2.0);
+        double part = 0;
+        for (int s = tid; s < S; s += WG) {
+            const uint32_t cnt4 = P.cr.cnt4[c0 + s];
+            const int oi = (int)(((cnt4 >> 16) & 0xff) + ((cnt4 >> 24) & 0xff));
+            double tmp;
+            if (oi) {
+                tmp = dev_logsumexp2(log(2 * (1 - f)), log(f) + oi * log2 - q);
+                tmp += log(f) + oi * log(q / p) - q + p;
+            } else
+                tmp = log(2 * f * (1 - f) * exp(-q) + f * f * exp(-2 * q) + (1 - f) * (1 - f)) + p;
+            part += tmp;
+        }
+        part = wave_sum_f64(part);
+        if (lane == 0) atomicAdd(&sh.segb_sum, part);
+    }
+    // ---- MWU x4 and VDB from the site histograms (bam2bcf.c:735-751), lanes 0..4 ----
+    if (tid < 6) sh.bias[tid] = 0.f;
+    __syncthreads();
+    if (!dead) {
+        const int *h = P.hist + (long)is * H_SIZE;
+        if (tid == 0) sh.bias[0] = (P.fmt_flag & BCFGPU_INFO_VDB) ? dev_calc_vdb(h + H_ALT_POS) : 0.f;
+        if (tid == 64) sh.bias[1] = (P.fmt_flag & BCFGPU_INFO_RPB) ? dev_calc_mwu_bias(h + H_REF_POS, h + H_ALT_POS, BCFGPU_NPOS, P.mw) : 0.f;
+        if (tid == 128) sh.bias[2] = dev_calc_mwu_bias(h + H_REF_MQ, h + H_ALT_MQ, BCFGPU_NQUAL, P.mw);
+        if (tid == 192) sh.bias[3] = dev_calc_mwu_bias(h + H_REF_BQ, h + H_ALT_BQ, BCFGPU_NQUAL, P.mw);
+        if (tid == 1) sh.bias[4] = dev_calc_mwu_bias(h + H_FWD_MQS, h + H_REV_MQS, BCFGPU_NQUAL, P.mw);
+    }
+    __syncthreads();
+
+    // ---- the site struct ----
+    if (tid == 0) {
+        for (int i = 0; i < 5; ++i) { site->a[i] = sh.a[i]; site->qsum[i] = sh.qsum_out[i]; }
+        site->n_alleles = nal; site->unseen = sh.unseen; site->ori_ref = sh.ori_ref;
+        site->pad = 0;
+        if (dead) {
+            site->shift = 0; site->depth = site->ori_depth = site->mq0 = 0; site->scr_tot = 0;
+            site->vdb = site->mwu_pos = site->mwu_mq = site->mwu_bq = site->mwu_mqs = site->seg_bias = 0.f;
+            for (int i = 0; i < 5; ++i) site->adf_tot[i] = site->adr_tot[i] = 0;
+            for (int i = 0; i < 16; ++i) site->anno[i] = 0;
+        } else {
+            site->shift = (int)(sh.sum_min + .499);
+            site->depth = (uint32_t)(sh.tot[13] + sh.tot[14] + sh.tot[15] + sh.tot[16]);
+            site->ori_depth = (uint32_t)sh.tot[11]; site->mq0 = (uint32_t)sh.tot[12];
+            site->scr_tot = (int)sh.tot[10];
+            for (int i = 0; i < 5; ++i) { site->adf_tot[i] = (int)sh.tot[i]; site->adr_tot[i] = (int)sh.tot[5 + i]; }
+            for (int i = 0; i < 4; ++i) site->anno[i] = (double)sh.tot[13 + i];
+            for (int i = 0; i < 12; ++i) site->anno[4 + i] = (double)sh.tot[17 + i];
+            site->seg_bias = nr ? (float)sh.segb_sum : HUGE_VALF;
+            site->vdb = sh.bias[0]; site->mwu_pos = sh.bias[1]; site->mwu_mq = sh.bias[2];
+            site->mwu_bq = sh.bias[3]; site->mwu_mqs = sh.bias[4];
+        }
+    }
+}
+
+void launch_combine(const CombineParams &p, hipStream_t s)
+{
+    if (p.n_sites == 0) return;
+    hipLaunchKernelGGL(combine_kernel, dim3(p.n_sites), dim3(WG), 0, s, p);
+}
+
+}  // namespace bcfgpu

@@ -1,0 +1,76 @@
+// kernels.h -- parameter blocks and launchers of the HIP kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/bcfgpu.h"
+
+namespace bcfgpu {
+
+// histogram layout of one site (bcf_callaux_t's bias-test arrays, bam2bcf.h:77)
+enum : int {
+    H_REF_POS = 0, H_ALT_POS = 100, H_REF_MQ = 200, H_ALT_MQ = 260, H_REF_BQ = 320, H_ALT_BQ = 380,
+    H_FWD_MQS = 440, H_REV_MQS = 500, H_SIZE = 560
+};
+
+// per (site,sample) result of the glfgen kernel = bcf_callret1_t (bam2bcf.h:90-108), SoA planes over
+// ncells = n_sites*n_smpl.  Everything but p is an exact integer.
+struct CallretPlanes {
+    float    *p15;    // [15][ncells]  upper triangle of p[5][5]: index k*(k+1)/2+j for j<=k
+    uint64_t *qs64;   // [ncells]      QS[0..3] packed 4 x u16
+    uint32_t *adf;    // [ncells]      ADF[0..3] packed 4 x u8
+    uint32_t *adr;    // [ncells]      ADR[0..3] packed 4 x u8
+    uint32_t *cnt4;   // [ncells]      anno[0..3] packed 4 x u8
+    uint32_t *sums;   // [12][ncells]  anno[4..15]
+    uint32_t *misc;   // [ncells]      mq0 | SCR<<8 | ori_depth<<16
+};
+
+struct GlfgenParams {
+    int n_sites, n_smpl, is_indel;
+    int min_baseQ, capQ, fmt_flag;
+    int hist_slots;                 // >0: per-workgroup LDS histograms with that many site slots; 0: global atomics
+    const int8_t   *ref16;
+    const uint32_t *off;
+    const uint32_t *rd;
+    const uint8_t  *epos;
+    const uint32_t *aux;
+    uint16_t *codes;                // workspace [n_reads]: the `bases` array of bcf_callaux_t
+    const double *fk, *beta, *lhet;
+    CallretPlanes cr;
+    int *hist;                      // [n_sites][H_SIZE], zeroed before launch
+    int *err;                       // device error word
+};
+
+struct CombineParams {
+    int n_sites, n_smpl, is_indel, fmt_flag;
+    const int8_t *ref16;
+    CallretPlanes cr;
+    const int *hist;
+    const double *mw;               // [6][6][50]
+    bcfgpu_mplp_out out;
+};
+
+struct McallParams {
+    int n_sites, n_smpl;
+    int n_gt_max, n_al_max;         // plane counts of pl / ad
+    int pl_is_u8;                   // 1: pl planes are the u8 planes of the mpileup stage (stride BCFGPU_MAX_PL)
+    int call_flag, output_tags, n_grp;
+    double theta;                   // log-scaled prior or 0
+    const double *pl2p;
+    const int32_t *nals, *unseen;   // per site (NULL with pl_is_u8: taken from msite)
+    const bcfgpu_site *msite;       // mpileup-stage site structs (fused path) or NULL
+    const void *pl;
+    const float *qs;                // [site][5] or NULL (fused: msite->qsum)
+    const int32_t *ad;              // i32 planes or NULL
+    const uint8_t *ad_u8, *ad_u8b; const uint16_t *qs_u16;   // fused -G sources (mpileup-stage ADF/ADR or QS planes, stride 5)
+    const uint8_t *ploidy;
+    const int32_t *grp;
+    const int32_t *prior_an, *prior_ac;
+    bcfgpu_call_out out;
+    int out_n_gt_max;               // plane count of out.pl / out.gp
+};
+
+void launch_glfgen(const GlfgenParams &p, hipStream_t s);
+void launch_combine(const CombineParams &p, hipStream_t s);
+void launch_mcall(const McallParams &p, hipStream_t s);
+
+}  // namespace bcfgpu

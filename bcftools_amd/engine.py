@@ -1,0 +1,197 @@
+"""Host-side mirror of the reference's operator interface for the hot path, over the C-ABI.
+
+    Context(cfg)                      ~ bcf_call_init + mcall_init   (bam2bcf.h:135, call.h:135)
+    Context.mpileup(tile)             ~ bcf_call_glfgen x n_smpl + bcf_call_combine per site (mpileup.c:343-347)
+    Context.mcall(call_input)         ~ mcall() per record (vcfcall.c:1137)
+    Context.pipeline(tile, ...)       ~ `mpileup -Ou | call -m` with the PL/QS/I16 hand-off kept in HBM
+    Context.close()                   ~ bcf_call_destroy + mcall_destroy
+
+Inputs/outputs are the numpy containers of bcftools_amd.host; device memory is managed
+through bcfgpu_malloc/memcpy so no other GPU runtime is required.  Every method raises
+BcfGpuError on failure -- nothing here computes on the CPU.
+"""
+import ctypes as C
+import numpy as np
+
+from . import abi, host
+from .lib import load, check, BcfGpuError  # noqa: F401
+
+
+class DevBuf:
+    """A device allocation owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        check(ctx.L.bcfgpu_malloc(ctx.h, max(self.nbytes, 16), C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(self.ctx.L.bcfgpu_memcpy_h2d(self.ctx.h, self.ptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return self
+
+    def download(self, arr):
+        assert arr.flags["C_CONTIGUOUS"] and arr.nbytes <= self.nbytes
+        check(self.ctx.L.bcfgpu_memcpy_d2h(self.ctx.h, arr.ctypes.data_as(C.c_void_p), self.ptr, arr.nbytes))
+        return arr
+
+    def free(self):
+        if self.ptr:
+            self.ctx.L.bcfgpu_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    def __init__(self, cfg):
+        self.L = load()
+        self.cfg = cfg
+        h = C.c_void_p()
+        check(self.L.bcfgpu_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self._bufs = []
+
+    # -- memory ------------------------------------------------------------------------
+    def buf(self, nbytes):
+        b = DevBuf(self, nbytes)
+        self._bufs.append(b)
+        return b
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return self.buf(arr.nbytes).upload(arr)
+
+    def release(self, bufs):
+        for b in bufs:
+            b.free()
+            if b in self._bufs:
+                self._bufs.remove(b)
+
+    def sync(self):
+        check(self.L.bcfgpu_sync(self.h))
+
+    def close(self):
+        if self.h:
+            for b in self._bufs:
+                b.free()
+            self._bufs = []
+            self.L.bcfgpu_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- tiles -------------------------------------------------------------------------
+    def upload_tile(self, t):
+        """HostTile -> (abi.Tile with device pointers, [DevBuf])"""
+        bufs = [self.to_device(t.ref16), self.to_device(t.plp_off), self.to_device(t.rd), self.to_device(t.epos)]
+        d = abi.Tile()
+        d.n_sites, d.is_indel, d.n_reads = t.n_sites, t.is_indel, len(t.rd)
+        d.ref16, d.plp_off, d.rd, d.epos = bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, bufs[3].ptr
+        if t.aux is not None:
+            bufs.append(self.to_device(t.aux))
+            d.aux = bufs[-1].ptr
+        return d, bufs
+
+    def alloc_mplp_out(self, n_sites):
+        S = self.cfg.n_smpl
+        res = host.MplpResult(n_sites, S)
+        names = ["site", "pl", "dp4", "adf", "adr", "qs", "scr"]
+        bufs = {k: self.buf(getattr(res, k).nbytes) for k in names}
+        o = abi.MplpOut()
+        for k in names:
+            setattr(o, k, bufs[k].ptr)
+        return o, bufs, res
+
+    def alloc_call_out(self, n_sites, n_gt_max):
+        S = self.cfg.n_smpl
+        res = host.CallResult(n_sites, S, n_gt_max)
+        names = ["site", "gt", "pl", "gq", "gp"]
+        bufs = {k: self.buf(getattr(res, k).nbytes) for k in names}
+        o = abi.CallOut()
+        for k in names:
+            setattr(o, k, bufs[k].ptr)
+        return o, bufs, res
+
+    @staticmethod
+    def _download(bufs, res):
+        for k, b in bufs.items():
+            b.download(getattr(res, k))
+        return res
+
+    # -- the hot path --------------------------------------------------------------------
+    def mpileup(self, tile):
+        """Run glfgen+combine on a HostTile, return a host MplpResult."""
+        assert tile.n_smpl == self.cfg.n_smpl
+        dt, tb = self.upload_tile(tile)
+        o, ob, res = self.alloc_mplp_out(tile.n_sites)
+        # planes the kernels skip for unused alleles must read as zero, like the oracle's
+        for b in ob.values():
+            check(self.L.bcfgpu_memset(self.h, b.ptr, 0, b.nbytes))
+        try:
+            check(self.L.bcfgpu_mpileup(self.h, C.byref(dt), C.byref(o)))
+            self.sync()
+            self._download(ob, res)
+        finally:
+            self.release(tb + list(ob.values()))
+        return res
+
+    def mcall(self, cin):
+        """Run the caller on a host CallInput, return a host CallResult."""
+        assert cin.n_smpl == self.cfg.n_smpl
+        keep = []
+        d = abi.CallIn()
+        d.n_sites, d.n_gt_max, d.n_al_max = cin.n_sites, cin.n_gt_max, cin.n_al_max
+        for k in ("nals", "unseen", "pl", "qs", "ad", "ploidy", "grp", "prior_an", "prior_ac"):
+            a = getattr(cin, k)
+            if a is not None:
+                b = self.to_device(a)
+                keep.append(b)
+                setattr(d, k, b.ptr)
+        o, ob, res = self.alloc_call_out(cin.n_sites, cin.n_gt_max)
+        for b in ob.values():
+            check(self.L.bcfgpu_memset(self.h, b.ptr, 0, b.nbytes))
+        try:
+            check(self.L.bcfgpu_mcall(self.h, C.byref(d), C.byref(o)))
+            self.sync()
+            self._download(ob, res)
+        finally:
+            self.release(keep + list(ob.values()))
+        return res
+
+    def pipeline(self, tile, ploidy=None, grp=None):
+        """mpileup stage + call stage on a SNP HostTile with the hand-off kept on the device.
+        Returns (MplpResult, CallResult)."""
+        dt, tb = self.upload_tile(tile)
+        mo, mb, mres = self.alloc_mplp_out(tile.n_sites)
+        co, cb, cres = self.alloc_call_out(tile.n_sites, abi.MAX_PL)
+        keep = []
+        pp = gp = None
+        if ploidy is not None:
+            keep.append(self.to_device(np.ascontiguousarray(ploidy, dtype=np.uint8)))
+            pp = keep[-1].ptr
+        if grp is not None:
+            keep.append(self.to_device(np.ascontiguousarray(grp, dtype=np.int32)))
+            gp = keep[-1].ptr
+        for b in list(mb.values()) + list(cb.values()):
+            check(self.L.bcfgpu_memset(self.h, b.ptr, 0, b.nbytes))
+        try:
+            check(self.L.bcfgpu_pipeline(self.h, C.byref(dt), pp, gp, C.byref(mo), C.byref(co)))
+            self.sync()
+            self._download(mb, mres)
+            self._download(cb, cres)
+        finally:
+            self.release(tb + keep + list(mb.values()) + list(cb.values()))
+        return mres, cres
+
+    def timing(self, on=True):
+        check(self.L.bcfgpu_timing_enable(self.h, 1 if on else 0))
+
+    def last_timing(self):
+        t = abi.Timing()
+        check(self.L.bcfgpu_timing_get(self.h, C.byref(t)))
+        return dict(glfgen_ms=t.glfgen_ms, combine_ms=t.combine_ms, mcall_ms=t.mcall_ms, total_ms=t.total_ms)

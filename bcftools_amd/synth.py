@@ -1,0 +1,114 @@
+"""Synthetic 30x-WGS-shaped pileup tiles: the workload of bench.py and of the
+seeded parity tests.  Two generators with the same distributions:
+
+    numpy_tile(...)  -> bcftools_amd.host.HostTile         (Philox counter RNG, CPU)
+    torch_tile(...)  -> dict of torch tensors on a device  (torch's Philox generator, GPU)
+
+Per site: ref ~ U{A,C,G,T}; variant with prob `var_rate` (alt uniform != ref, population AF ~
+Beta(0.5,5) clipped to [1/2S, 0.5], genotypes HWE).  Per (site,sample): depth ~ Poisson(depth)
+truncated to [0, max_depth<=200] (keeps n<=255, the regime of mpileup's default -d 250).
+Per read: strand ~ Bern(.5); baseQ from an Illumina-like pmf over {2,11,25,37,40,41};
+base = true allele, flipped to a uniform other base with prob 10^(-baseQ/10); mapQ = 60 w.p.
+0.92 else U{0..59}; read length 150, qpos ~ U{0..149}; soft-clip flag Bern(0.03).
+"""
+import numpy as np
+
+from . import abi, host
+
+BQ_VALUES = np.array([2, 11, 25, 37, 40, 41], dtype=np.int64)
+BQ_PMF = np.array([.02, .05, .08, .35, .30, .20])
+READ_LEN = 150
+
+
+def numpy_tile(seed, n_sites, n_smpl, depth=30.0, var_rate=0.01, max_depth=200, ref_n_rate=0.0, mapq255_rate=0.0):
+    rng = np.random.Generator(np.random.Philox(key=int(seed)))
+    S = n_smpl
+    ref2 = rng.integers(0, 4, n_sites)
+    is_var = rng.random(n_sites) < var_rate
+    alt2 = (ref2 + rng.integers(1, 4, n_sites)) % 4
+    af = np.clip(rng.beta(0.5, 5.0, n_sites), 1.0 / (2 * S), 0.5)
+    af = np.where(is_var, af, 0.0)
+    ref_is_n = rng.random(n_sites) < ref_n_rate
+    ref16 = np.where(ref_is_n, 15, 1 << ref2).astype(np.int8)
+    nalt = rng.binomial(2, np.repeat(af, S))                       # [cells]
+    n = np.minimum(rng.poisson(depth, n_sites * S), max_depth).astype(np.int64)
+    off = np.zeros(n_sites * S + 1, dtype=np.int64)
+    np.cumsum(n, out=off[1:])
+    R = int(off[-1])
+    cell = np.repeat(np.arange(n_sites * S), n)
+    site = cell // S
+    strand = rng.integers(0, 2, R)
+    bq = BQ_VALUES[rng.choice(len(BQ_VALUES), size=R, p=BQ_PMF)]
+    is_alt = rng.random(R) < nalt[cell] * 0.5
+    base = np.where(is_alt, alt2[site], ref2[site])
+    err = rng.random(R) < 10.0 ** (-bq / 10.0)
+    base = np.where(err, (base + rng.integers(1, 4, R)) % 4, base)
+    mq = np.where(rng.random(R) < 0.92, 60, rng.integers(0, 60, R))
+    if mapq255_rate > 0:
+        mq = np.where(rng.random(R) < mapq255_rate, 255, mq)
+    qpos = rng.integers(0, READ_LEN, R)
+    tail = np.minimum(qpos, READ_LEN - 1 - qpos)
+    epos = ((qpos + 1).astype(np.float64) / (READ_LEN + 1) * 100).astype(np.uint8)
+    sclip = rng.random(R) < 0.03
+    rd = (bq | (mq << 8) | ((1 << base) << 16) | (strand << 20) | (sclip.astype(np.int64) << 21) | (tail << 24)).astype(np.uint32)
+    return host.HostTile(S, ref16, off.astype(np.uint32), rd, epos)
+
+
+def torch_tile(seed, n_sites, n_smpl, device, depth=30.0, var_rate=0.01, max_depth=200):
+    """Same distributions generated on `device` with torch; returns dict(ref16,plp_off,rd,epos,n_reads)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    S = n_smpl
+    dev = device
+
+    def rnd(n):
+        return torch.rand(n, generator=g, device=dev)
+
+    def rint(lo, hi, n):
+        return torch.randint(lo, hi, (n,), generator=g, device=dev)
+
+    ref2 = rint(0, 4, n_sites)
+    is_var = rnd(n_sites) < var_rate
+    alt2 = (ref2 + rint(1, 4, n_sites)) % 4
+    # Beta(0.5,5) via two gammas
+    ga = torch.distributions.Gamma(torch.tensor(0.5, device=dev), torch.tensor(1.0, device=dev))
+    gb = torch.distributions.Gamma(torch.tensor(5.0, device=dev), torch.tensor(1.0, device=dev))
+    torch.manual_seed(int(seed) + 1)
+    xa, xb = ga.sample((n_sites,)), gb.sample((n_sites,))
+    af = torch.clamp(xa / (xa + xb), 1.0 / (2 * S), 0.5)
+    af = torch.where(is_var, af, torch.zeros_like(af))
+    ref16 = (1 << ref2).to(torch.int8)
+    afc = af.repeat_interleave(S)
+    nalt = (rnd(n_sites * S) < afc).to(torch.int64) + (rnd(n_sites * S) < afc).to(torch.int64)
+    n = torch.poisson(torch.full((n_sites * S,), float(depth), device=dev), generator=g).to(torch.int64).clamp_(0, max_depth)
+    off = torch.zeros(n_sites * S + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(n, 0, out=off[1:])
+    R = int(off[-1].item())
+    cell = torch.repeat_interleave(torch.arange(n_sites * S, device=dev), n)
+    site = cell // S
+    strand = rint(0, 2, R)
+    pmf = torch.tensor(BQ_PMF, device=dev, dtype=torch.float32)
+    bq = torch.tensor(BQ_VALUES, device=dev)[torch.multinomial(pmf, R, replacement=True, generator=g)]
+    is_alt = rnd(R) < nalt[cell].to(torch.float32) * 0.5
+    base = torch.where(is_alt, alt2[site], ref2[site])
+    err = rnd(R) < torch.pow(10.0, -bq.to(torch.float32) / 10.0)
+    base = torch.where(err, (base + rint(1, 4, R)) % 4, base)
+    mq = torch.where(rnd(R) < 0.92, torch.full((R,), 60, device=dev, dtype=torch.int64), rint(0, 60, R))
+    qpos = rint(0, READ_LEN, R)
+    tail = torch.minimum(qpos, READ_LEN - 1 - qpos)
+    epos = ((qpos + 1).to(torch.float64) / (READ_LEN + 1) * 100).to(torch.uint8)
+    sclip = (rnd(R) < 0.03).to(torch.int64)
+    rd = (bq | (mq << 8) | ((1 << base) << 16) | (strand << 20) | (sclip << 21) | (tail << 24))
+    rd = (rd & 0xffffffff).to(torch.int64)
+    # store as int32 bit pattern (torch has no uint32 arithmetic); reinterpret on the C side
+    rd32 = torch.where(rd >= 2 ** 31, rd - 2 ** 32, rd).to(torch.int32)
+    del cell, site
+    return dict(ref16=ref16.contiguous(), plp_off=off.to(torch.int32).contiguous(), rd=rd32.contiguous(),
+                epos=epos.contiguous(), n_reads=R, n_sites=n_sites, n_smpl=S)
+
+
+def tile_from_torch(t):
+    """Copy a torch_tile() dict to a HostTile (for the oracle / CPU baseline)."""
+    return host.HostTile(t["n_smpl"], t["ref16"].cpu().numpy(), t["plp_off"].cpu().numpy().view(np.uint32),
+                         t["rd"].cpu().numpy().view(np.uint32), t["epos"].cpu().numpy())

@@ -222,6 +222,8 @@ int  bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out);
 void bcfgpu_destroy(bcfgpu_ctx *ctx);
 const char *bcfgpu_last_error(void);
 int  bcfgpu_device_count(void);
+/* sizeof() of {cfg, tile, site, mplp_out, call_in, call_site, call_out, timing}: lets a binding check its struct mirrors */
+void bcfgpu_abi_sizes(int32_t out[8]);
 
 /* ---- device memory helpers (thin wrappers of hipMalloc/hipMemcpy) ---------- */
 int  bcfgpu_malloc(bcfgpu_ctx *ctx, size_t bytes, void **dptr);

@@ -1,0 +1,117 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on the same
+seeded inputs.  Integer/byte outputs must be bit-exact; float32 site statistics whose last bits
+depend on libm (SGB, MWU, VDB) get a 2e-6 relative tolerance; QUAL 1e-4 (BASELINE.json)."""
+import numpy as np
+import pytest
+
+from bcftools_amd import abi, synth, host
+from tests.helpers import orc
+
+pytestmark = pytest.mark.gpu
+
+EXACT_SITE = ["a", "n_alleles", "unseen", "ori_ref", "shift", "ret", "depth", "ori_depth", "mq0",
+              "adf_tot", "adr_tot", "scr_tot", "anno", "qsum"]
+FLOAT_SITE = ["vdb", "mwu_pos", "mwu_mq", "mwu_bq", "mwu_mqs", "seg_bias"]
+
+
+def assert_mplp_equal(got, want, float_rtol=2e-6):
+    for k in EXACT_SITE:
+        np.testing.assert_array_equal(got.site[k], want.site[k], err_msg="site." + k)
+    for k in FLOAT_SITE:
+        g, w = got.site[k].astype(np.float64), want.site[k].astype(np.float64)
+        assert np.array_equal(np.isinf(g), np.isinf(w)), k
+        m = ~np.isinf(w)
+        np.testing.assert_allclose(g[m], w[m], rtol=float_rtol, atol=1e-30, err_msg="site." + k)
+    for k in ["pl", "dp4", "adf", "adr", "qs", "scr"]:
+        np.testing.assert_array_equal(getattr(got, k), getattr(want, k), err_msg=k)
+
+
+def assert_call_equal(got, want, n_smpl, qual_tol=1e-4):
+    for k in ["ret", "nals_new", "als_new", "als_map", "ac", "an", "qual_missing", "pl_dropped"]:
+        np.testing.assert_array_equal(got.site[k], want.site[k], err_msg="call." + k)
+    np.testing.assert_allclose(got.site["qual"], want.site["qual"], rtol=qual_tol, atol=qual_tol)
+    live = want.site["ret"] > 0
+    np.testing.assert_array_equal(got.gt[live], want.gt[live], err_msg="gt")
+    keep = live & (want.site["pl_dropped"] == 0)
+    for i in np.nonzero(keep)[0]:
+        nn = int(want.site["nals_new"][i])
+        ng = nn * (nn + 1) // 2
+        g, w = got.pl[i, :ng].copy(), want.pl[i, :ng].copy()
+        # values behind a vector_end are never written out (haploid samples): not part of the contract
+        after = np.cumsum(w == abi.INT32_VECTOR_END, axis=0) - (w == abi.INT32_VECTOR_END) > 0
+        g[after] = 0
+        w[after] = 0
+        np.testing.assert_array_equal(g, w, err_msg="pl site %d" % i)
+
+
+@pytest.mark.parametrize("n_sites,n_smpl,depth,var_rate,seed", [
+    (64, 100, 30.0, 0.05, 20260102),      # config[1]-shaped: 100 samples x 30x
+    (16, 1000, 30.0, 0.10, 20260104),     # config[3]-shaped: 1000 samples x 30x
+    (200, 3, 12.0, 0.20, 7),              # few samples: global-atomic histogram path
+    (300, 1, 40.0, 0.20, 8),              # single-sample calling
+    (50, 37, 5.0, 0.30, 9),               # shallow, many empty cells
+    (8, 300, 150.0, 0.20, 10),            # deep cells (up to 200 reads)
+])
+def test_mpileup_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth, var_rate, seed):
+    fmt = abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD | abi.FMT_QS | abi.FMT_SCR | abi.INFO_SCR
+    tile = synth.numpy_tile(seed, n_sites, n_smpl, depth=depth, var_rate=var_rate, ref_n_rate=0.02, mapq255_rate=0.01)
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), fmt_flag=fmt)
+    want = orc.mpileup(cfg, tile)
+    ctx = gpu_ctx_factory(cfg)
+    got = ctx.mpileup(tile)
+    assert_mplp_equal(got, want)
+
+
+@pytest.mark.parametrize("n_sites,n_smpl,seed,flags,tags", [
+    (64, 100, 11, 0, 0),
+    (64, 100, 12, abi.CALL_VARONLY, 0),
+    (32, 1000, 13, 0, abi.CALL_FMT_GQ | abi.CALL_FMT_GP),
+    (100, 5, 14, abi.CALL_KEEPALT, abi.CALL_FMT_GQ),
+])
+def test_pipeline_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, seed, flags, tags):
+    tile = synth.numpy_tile(seed, n_sites, n_smpl, depth=25.0, var_rate=0.3)
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), call_flag=flags, output_tags=tags)
+    rng = np.random.default_rng(seed)
+    ploidy = rng.choice([1, 2, 2, 2], size=n_smpl).astype(np.uint8)
+    mwant = orc.mpileup(cfg, tile)
+    cin = host.CallInput(n_smpl, mwant.site["n_alleles"], np.maximum(mwant.site["unseen"], 0),
+                         mwant.pl.astype(np.int32), mwant.site["qsum"], ploidy=ploidy)
+    cwant = orc.mcall(cfg, cin)
+    ctx = gpu_ctx_factory(cfg)
+    mgot, cgot = ctx.pipeline(tile, ploidy=ploidy)
+    assert_mplp_equal(mgot, mwant)
+    assert_call_equal(cgot, cwant, n_smpl)
+    if tags & abi.CALL_FMT_GQ:
+        live = (cwant.site["ret"] > 0) & (cwant.site["als_new"] != 1)
+        np.testing.assert_array_equal(cgot.gq[live], cwant.gq[live])
+
+
+def test_empty_and_zero_depth(gpu_ctx_factory):
+    n_smpl = 4
+    cfg = abi.default_cfg(n_smpl, max_sites=8, max_reads=64)
+    ctx = gpu_ctx_factory(cfg)
+    # a tile whose cells are all empty: bcf_call_glfgen returns -1 for every sample (bam2bcf.c:162)
+    tile = host.HostTile(n_smpl, np.array([1, 2, 4], dtype=np.int8), np.zeros(3 * n_smpl + 1, dtype=np.uint32),
+                         np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint8))
+    want = orc.mpileup(cfg, tile)
+    got = ctx.mpileup(tile)
+    assert_mplp_equal(got, want)
+    # zero sites: a no-op
+    empty = host.HostTile(n_smpl, np.zeros(0, dtype=np.int8), np.zeros(1, dtype=np.uint32),
+                          np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.uint8))
+    res = ctx.mpileup(empty)
+    assert res.site.shape == (0,)
+
+
+def test_depth_over_255_is_refused(gpu_ctx_factory):
+    from bcftools_amd.lib import BcfGpuError
+    n_smpl = 2
+    n = 300
+    rd = np.full(n, 40 | (60 << 8) | (1 << 16), dtype=np.uint32)
+    tile = host.HostTile(n_smpl, np.array([1], dtype=np.int8), np.array([0, n, n], dtype=np.uint32), rd,
+                         np.zeros(n, dtype=np.uint8))
+    cfg = abi.default_cfg(n_smpl, max_sites=1, max_reads=n)
+    ctx = gpu_ctx_factory(cfg)
+    with pytest.raises(BcfGpuError) as e:
+        ctx.mpileup(tile)
+    assert e.value.code == abi.E_DEPTH
