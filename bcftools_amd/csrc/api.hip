@@ -37,9 +37,11 @@ struct bcfgpu_ctx {
     CallretPlanes cr{};
     size_t ncells_cap = 0;
     // timing
-    int timing = 0;
+    int timing = 0;                 // 1: time every launch sequence and wait for it; 2: record only, resolve in timing_get
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bcfgpu_timing last{};
+    std::vector<hipEvent_t> pool;   // mode 2: 4 events per launch sequence
+    std::vector<int> pool_call;     // mode 2: 1 if the sequence included the call kernel
     std::vector<void*> owned;
 };
 
@@ -147,6 +149,7 @@ void bcfgpu_destroy(bcfgpu_ctx *c)
     hipSetDevice(c->cfg.device);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (void *p : c->owned) hipFree(p);
+    for (hipEvent_t e : c->pool) hipEventDestroy(e);
     for (int i = 0; i < 4; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -254,8 +257,42 @@ int bcfgpu_timing_enable(bcfgpu_ctx *c, int on) { if (!c) return BCFGPU_E_ARG; c
 int bcfgpu_timing_get(bcfgpu_ctx *c, bcfgpu_timing *t)
 {
     if (!c || !t) return set_err(BCFGPU_E_ARG, "bcfgpu_timing_get: bad arguments");
+    if (c->timing == 2) {
+        // averages over every launch sequence recorded since the last call
+        bcfgpu_timing a{};
+        const size_t n = c->pool_call.size();
+        if (n) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            int ncall = 0;
+            for (size_t k = 0; k < n; ++k) {
+                hipEvent_t *e = &c->pool[4 * k];
+                float g = 0, m = 0, q = 0, tot = 0;
+                hipEventElapsedTime(&g, e[0], e[1]);
+                hipEventElapsedTime(&m, e[1], e[2]);
+                if (c->pool_call[k]) { hipEventElapsedTime(&q, e[2], e[3]); hipEventElapsedTime(&tot, e[0], e[3]); ncall++; }
+                else hipEventElapsedTime(&tot, e[0], e[2]);
+                a.glfgen_ms += g; a.combine_ms += m; a.mcall_ms += q; a.total_ms += tot;
+            }
+            a.glfgen_ms /= n; a.combine_ms /= n; a.total_ms /= n;
+            if (ncall) a.mcall_ms /= ncall;
+            for (hipEvent_t e : c->pool) hipEventDestroy(e);
+            c->pool.clear(); c->pool_call.clear();
+        }
+        c->last = a;
+    }
     *t = c->last;
     return 0;
+}
+
+// the four events of the current launch sequence
+static hipEvent_t *seq_events(bcfgpu_ctx *c)
+{
+    if (c->timing == 2) {
+        for (int i = 0; i < 4; ++i) { hipEvent_t e; hipEventCreate(&e); c->pool.push_back(e); }
+        c->pool_call.push_back(0);
+        return &c->pool[c->pool.size() - 4];
+    }
+    return c->ev;
 }
 
 static int check_tile(bcfgpu_ctx *c, const bcfgpu_tile *t)
@@ -284,21 +321,22 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     // the callret planes are addressed with ncells of *this* tile
     g.hist = c->d_hist; g.err = c->d_err;
     HIPCHK(hipMemsetAsync(c->d_hist, 0, (size_t)tile->n_sites * H_SIZE * sizeof(int), c->stream));
-    if (c->timing) hipEventRecord(c->ev[0], c->stream);
+    hipEvent_t *ev = c->timing ? seq_events(c) : nullptr;
+    if (ev) hipEventRecord(ev[0], c->stream);
     launch_glfgen(g, c->stream);
-    if (c->timing) hipEventRecord(c->ev[1], c->stream);
+    if (ev) hipEventRecord(ev[1], c->stream);
     CombineParams k{};
     k.n_sites = tile->n_sites; k.n_smpl = S; k.is_indel = tile->is_indel; k.fmt_flag = c->cfg.fmt_flag;
     k.ref16 = tile->ref16; k.cr = c->cr; k.hist = c->d_hist; k.mw = c->d_mw; k.out = *out;
     launch_combine(k, c->stream);
-    if (c->timing) hipEventRecord(c->ev[2], c->stream);
+    if (ev) hipEventRecord(ev[2], c->stream);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
 static void finish_timing(bcfgpu_ctx *c, bool with_call)
 {
-    if (!c->timing) return;
+    if (c->timing != 1) return;
     hipEventSynchronize(with_call ? c->ev[3] : c->ev[2]);
     bcfgpu_timing t{};
     hipEventElapsedTime(&t.glfgen_ms, c->ev[0], c->ev[1]);
@@ -337,9 +375,9 @@ int bcfgpu_mcall(bcfgpu_ctx *c, const bcfgpu_call_in *in, const bcfgpu_call_out 
     m.nals = in->nals; m.unseen = in->unseen; m.msite = nullptr; m.pl = in->pl; m.qs = in->qs; m.ad = in->ad;
     m.ploidy = in->ploidy; m.grp = c->cfg.n_grp > 1 ? in->grp : nullptr; m.prior_an = in->prior_an; m.prior_ac = in->prior_ac;
     m.out = *out; m.out_n_gt_max = in->n_gt_max;
-    if (c->timing) hipEventRecord(c->ev[2], c->stream);
+    if (c->timing == 1) hipEventRecord(c->ev[2], c->stream);
     launch_mcall(m, c->stream);
-    if (c->timing) { hipEventRecord(c->ev[3], c->stream); hipEventSynchronize(c->ev[3]);
+    if (c->timing == 1) { hipEventRecord(c->ev[3], c->stream); hipEventSynchronize(c->ev[3]);
         bcfgpu_timing t{}; hipEventElapsedTime(&t.mcall_ms, c->ev[2], c->ev[3]); t.total_ms = t.mcall_ms; c->last = t; }
     HIPCHK(hipGetLastError());
     return 0;
@@ -369,7 +407,8 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
     m.ploidy = ploidy; m.grp = c->cfg.n_grp > 1 ? grp : nullptr;
     m.out = *cout; m.out_n_gt_max = BCFGPU_MAX_PL;
     launch_mcall(m, c->stream);
-    if (c->timing) hipEventRecord(c->ev[3], c->stream);
+    if (c->timing == 1) hipEventRecord(c->ev[3], c->stream);
+    else if (c->timing == 2) { hipEventRecord(c->pool[c->pool.size() - 1], c->stream); c->pool_call.back() = 1; }
     HIPCHK(hipGetLastError());
     finish_timing(c, true);
     return 0;

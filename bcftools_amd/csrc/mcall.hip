@@ -159,6 +159,13 @@ __global__ __launch_bounds__(WG) void mcall_kernel(const McallParams P)
     } else { nals = P.nals[is]; unseen = P.unseen[is]; }
     const int ngts = nals * (nals + 1) / 2;
 
+    // record-loop prologue of vcfcall.c:1112-1115: with -v a REF-only record never reaches mcall()
+    if ((P.call_flag & BCFGPU_CALL_VARONLY) && (nals == 1 || (nals == 2 && unseen > 0))) {
+        if (tid == 0) { cs->ret = 0; cs->nals_new = 0; cs->als_new = 0; cs->an = 0; cs->qual = 0; cs->qual_missing = 0; cs->pl_dropped = 0;
+                        for (int i = 0; i < 5; ++i) { cs->als_map[i] = -1; cs->ac[i] = 0; } }
+        return;
+    }
+
     // ---- allele-frequency set-up (mcall.c:1453-1535), sequential float32 ----
     if (tid == 0) {
         sh.nals = nals; sh.unseen = unseen; sh.ngts = ngts;

@@ -54,13 +54,8 @@ def numpy_tile(seed, n_sites, n_smpl, depth=30.0, var_rate=0.01, max_depth=200, 
     return host.HostTile(S, ref16, off.astype(np.uint32), rd, epos)
 
 
-def torch_tile(seed, n_sites, n_smpl, device, depth=30.0, var_rate=0.01, max_depth=200):
-    """Same distributions generated on `device` with torch; returns dict(ref16,plp_off,rd,epos,n_reads)."""
+def _torch_chunk(g, n_sites, S, dev, depth, var_rate, max_depth):
     import torch
-    g = torch.Generator(device=device)
-    g.manual_seed(int(seed))
-    S = n_smpl
-    dev = device
 
     def rnd(n):
         return torch.rand(n, generator=g, device=dev)
@@ -71,25 +66,19 @@ def torch_tile(seed, n_sites, n_smpl, device, depth=30.0, var_rate=0.01, max_dep
     ref2 = rint(0, 4, n_sites)
     is_var = rnd(n_sites) < var_rate
     alt2 = (ref2 + rint(1, 4, n_sites)) % 4
-    # Beta(0.5,5) via two gammas
-    ga = torch.distributions.Gamma(torch.tensor(0.5, device=dev), torch.tensor(1.0, device=dev))
-    gb = torch.distributions.Gamma(torch.tensor(5.0, device=dev), torch.tensor(1.0, device=dev))
-    torch.manual_seed(int(seed) + 1)
-    xa, xb = ga.sample((n_sites,)), gb.sample((n_sites,))
-    af = torch.clamp(xa / (xa + xb), 1.0 / (2 * S), 0.5)
+    # Beta(0.5,5)-like population AF from a power transform of a uniform (cheap, on-device)
+    af = torch.clamp(rnd(n_sites) ** 4 * 0.5, 1.0 / (2 * S), 0.5)
     af = torch.where(is_var, af, torch.zeros_like(af))
     ref16 = (1 << ref2).to(torch.int8)
     afc = af.repeat_interleave(S)
     nalt = (rnd(n_sites * S) < afc).to(torch.int64) + (rnd(n_sites * S) < afc).to(torch.int64)
     n = torch.poisson(torch.full((n_sites * S,), float(depth), device=dev), generator=g).to(torch.int64).clamp_(0, max_depth)
-    off = torch.zeros(n_sites * S + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(n, 0, out=off[1:])
-    R = int(off[-1].item())
+    R = int(n.sum().item())
     cell = torch.repeat_interleave(torch.arange(n_sites * S, device=dev), n)
     site = cell // S
     strand = rint(0, 2, R)
-    pmf = torch.tensor(BQ_PMF, device=dev, dtype=torch.float32)
-    bq = torch.tensor(BQ_VALUES, device=dev)[torch.multinomial(pmf, R, replacement=True, generator=g)]
+    cdf = torch.cumsum(torch.tensor(BQ_PMF, device=dev, dtype=torch.float32), 0)
+    bq = torch.tensor(BQ_VALUES, device=dev)[torch.bucketize(rnd(R), cdf[:-1], right=True)]
     is_alt = rnd(R) < nalt[cell].to(torch.float32) * 0.5
     base = torch.where(is_alt, alt2[site], ref2[site])
     err = rnd(R) < torch.pow(10.0, -bq.to(torch.float32) / 10.0)
@@ -100,12 +89,34 @@ def torch_tile(seed, n_sites, n_smpl, device, depth=30.0, var_rate=0.01, max_dep
     epos = ((qpos + 1).to(torch.float64) / (READ_LEN + 1) * 100).to(torch.uint8)
     sclip = (rnd(R) < 0.03).to(torch.int64)
     rd = (bq | (mq << 8) | ((1 << base) << 16) | (strand << 20) | (sclip << 21) | (tail << 24))
-    rd = (rd & 0xffffffff).to(torch.int64)
-    # store as int32 bit pattern (torch has no uint32 arithmetic); reinterpret on the C side
+    # int32 bit pattern of the u32 record (torch has no uint32 arithmetic); the C side reads it as u32
     rd32 = torch.where(rd >= 2 ** 31, rd - 2 ** 32, rd).to(torch.int32)
-    del cell, site
-    return dict(ref16=ref16.contiguous(), plp_off=off.to(torch.int32).contiguous(), rd=rd32.contiguous(),
-                epos=epos.contiguous(), n_reads=R, n_sites=n_sites, n_smpl=S)
+    return ref16, n, rd32, epos
+
+
+def torch_tile(seed, n_sites, n_smpl, device, depth=30.0, var_rate=0.01, max_depth=200, chunk_cells=1 << 21):
+    """Same shape of data generated on `device` with torch's Philox generator, in chunks of sites.
+    Returns dict(ref16 i8, plp_off i32 (u32 bit pattern), rd i32 (u32 bit pattern), epos u8, n_reads, ...)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    S = n_smpl
+    per = max(1, chunk_cells // S)
+    refs, ns, rds, eps = [], [], [], []
+    done = 0
+    while done < n_sites:
+        m = min(per, n_sites - done)
+        r16, n, rd32, ep = _torch_chunk(g, m, S, device, depth, var_rate, max_depth)
+        refs.append(r16); ns.append(n); rds.append(rd32); eps.append(ep)
+        done += m
+    n = torch.cat(ns)
+    off = torch.zeros(n_sites * S + 1, dtype=torch.int64, device=device)
+    torch.cumsum(n, 0, out=off[1:])
+    R = int(off[-1].item())
+    assert R < 2 ** 32
+    off32 = torch.where(off >= 2 ** 31, off - 2 ** 32, off).to(torch.int32)
+    return dict(ref16=torch.cat(refs).contiguous(), plp_off=off32.contiguous(), rd=torch.cat(rds).contiguous(),
+                epos=torch.cat(eps).contiguous(), n_reads=R, n_sites=n_sites, n_smpl=S)
 
 
 def tile_from_torch(t):

@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the mpileup -> call -m hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path (glfgen+errmod -> combine -> mcall, PL/QS kept in
+HBM) over one tile of synthetic pileup columns that is already resident in HBM.  The default
+workload is the one BASELINE.json's metric is quoted on: 1000 samples x 30x, a tile of
+--sites columns per rank (weak scaling: every rank owns its own genomic region shard; the only
+collective is the ordered gather of the per-site call records to rank 0).
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the roofline accounting).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--samples", type=int, default=1000)
+    ap.add_argument("--depth", type=float, default=30.0)
+    ap.add_argument("--sites", type=int, default=16384, help="pileup columns per tile (= per step, per rank)")
+    ap.add_argument("--var-rate", type=float, default=0.01)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget on rank 0 at N=1 (0: skip)")
+    ap.add_argument("--seed", type=int, default=20260104)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(n_sites, n_smpl, n_reads, A=2):
+    """B_in = S*D*6 + S*6, B_out = S*(4G + 12A + 16) + 128 per site, with the tile's
+    actual read count in place of S*D and A=2 (REF + <*>), G=3."""
+    G = A * (A + 1) // 2
+    b_in = n_reads * 6 + n_sites * n_smpl * 6
+    b_out = n_sites * (n_smpl * (4 * G + 12 * A + 16) + 128)
+    return b_in + b_out
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from bcftools_amd import abi, synth, engine
+    from bcftools_amd.lib import check
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    S, T = a.samples, a.sites
+    # ---- synthetic tile, generated on the device; each rank owns a different region shard ----
+    tile = synth.torch_tile(a.seed + rank, T, S, dev, depth=a.depth, var_rate=a.var_rate)
+    torch.cuda.synchronize()
+    R = tile["n_reads"]
+
+    cfg = abi.default_cfg(S, max_sites=T, max_reads=R, device=local)
+    ctx = engine.Context(cfg)
+    L = ctx.L
+    dt = abi.Tile()
+    dt.n_sites, dt.is_indel, dt.n_reads = T, 0, R
+    dt.ref16, dt.plp_off, dt.rd, dt.epos = (tile["ref16"].data_ptr(), tile["plp_off"].data_ptr(),
+                                            tile["rd"].data_ptr(), tile["epos"].data_ptr())
+    # outputs (device)
+    mo, mbufs, _ = ctx.alloc_mplp_out(T)
+    co = abi.CallOut()
+    csite = torch.zeros(T * C.sizeof(abi.CallSite), dtype=torch.uint8, device=dev)
+    cgt = torch.zeros(T * 2 * S, dtype=torch.int8, device=dev)
+    cpl = torch.zeros(T * abi.MAX_PL * S, dtype=torch.int32, device=dev)
+    co.site, co.gt, co.pl, co.gq, co.gp = csite.data_ptr(), cgt.data_ptr(), cpl.data_ptr(), None, None
+    gathered = [torch.empty_like(csite) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    def step():
+        check(L.bcfgpu_pipeline(ctx.h, C.byref(dt), None, None, C.byref(mo), C.byref(co)))
+        if world > 1:
+            # ordered gather of the per-site call records (the shards are contiguous regions)
+            check(L.bcfgpu_sync(ctx.h))
+            dist.gather(csite, gathered, dst=0)
+
+    def fence():
+        check(L.bcfgpu_sync(ctx.h))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    check(L.bcfgpu_timing_enable(ctx.h, 2))
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    t1 = time.perf_counter()
+    tm = ctx.last_timing()
+    check(L.bcfgpu_timing_enable(ctx.h, 0))
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    total_sites = T * world * a.steps
+    value = total_sites / elapsed
+
+    out = None
+    if rank == 0:
+        alg = algorithmic_bytes(T, S, R)
+        kern_s = tm["glfgen_ms"] * 1e-3
+        achieved = alg / kern_s / 1e9 if kern_s > 0 else 0.0
+        out = {
+            "metric": "variant sites/sec (mpileup|call -m), 1000-sample 30x WGS synthetic",
+            "value": value, "unit": "sites/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/i32 + f64 likelihood sums", "data": "synthetic",
+            "config": {"workload": "1000-sample 30x synthetic WGS tile (BASELINE configs[3] shape), SNP path: "
+                                   "glfgen+errmod -> combine -> call -m, inputs resident in HBM",
+                       "samples": S, "depth": a.depth, "sites_per_step_per_gpu": T, "reads_per_tile": R,
+                       "sharding": "contiguous region shard per GPU; ordered gather of call records to rank 0"},
+            "roofline": {"bound": "hbm", "kernel": "glfgen_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": tm["glfgen_ms"],
+                         "other_kernels_ms": {"combine_kernel": tm["combine_ms"], "mcall_kernel": tm["mcall_ms"]}},
+        }
+        # ---- CPU baseline: the oracle (a port of the reference's loops), 1 core, bounded sample ----
+        if world == 1 and a.cpu_seconds > 0:
+            from tests.helpers import orc
+            from bcftools_amd import host
+            ht = synth.tile_from_torch(tile)
+
+            def cpu_run(ns):
+                sub = host.HostTile(S, ht.ref16[:ns], ht.plp_off[: ns * S + 1], ht.rd[: ht.plp_off[ns * S]],
+                                    ht.epos[: ht.plp_off[ns * S]])
+                c0 = time.perf_counter()
+                m = orc.mpileup(cfg, sub)
+                cin = host.CallInput(S, m.site["n_alleles"], np.maximum(m.site["unseen"], 0), m.pl.astype(np.int32),
+                                     m.site["qsum"])
+                orc.mcall(cfg, cin)
+                return time.perf_counter() - c0
+            probe = min(T, 64)
+            tp = cpu_run(probe)
+            ns = int(max(probe, min(T, a.cpu_seconds / max(tp / probe, 1e-9))))
+            tc = cpu_run(ns)
+            out["cpu_baseline"] = {"value": ns / tc, "unit": "sites/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d sites of the same tile (%d samples x %.0fx), oracle/liboracle.so "
+                                             "mpileup+mcall on one host core, %.1f s" % (ns, S, a.depth, tc)}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -262,6 +262,8 @@ size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *ctx, int n_sites, int which /*0 s
 
 /* timing of the last launches (ms, measured with HIP events on the stream the kernels ran on) */
 typedef struct { float glfgen_ms, combine_ms, mcall_ms, total_ms; } bcfgpu_timing;
+/* on=1: time each call and wait for it; on=2: only record events (no host wait), bcfgpu_timing_get() then returns
+ * the per-launch averages since the previous get; on=0: off */
 int  bcfgpu_timing_enable(bcfgpu_ctx *ctx, int on);
 int  bcfgpu_timing_get(bcfgpu_ctx *ctx, bcfgpu_timing *t);
 

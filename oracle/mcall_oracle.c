@@ -591,6 +591,13 @@ int orc_mcall(const bcfgpu_cfg *cfg, const bcfgpu_call_in *in, const bcfgpu_call
     int is, ret = 0;
     for (is = 0; is < in->n_sites; is++) {
         if (in->nals[is] > 5 || in->nals[is]*(in->nals[is]+1)/2 > ngmax) { ret = BCFGPU_E_ARG; break; }
+        /* record-loop prologue, vcfcall.c:1112-1115: with -v a REF-only record never reaches mcall() */
+        if ((cfg->call_flag & BCFGPU_CALL_VARONLY) && (in->nals[is] == 1 || (in->nals[is] == 2 && in->unseen[is] > 0))) {
+            int k;
+            memset(&out->site[is], 0, sizeof(out->site[is]));
+            for (k = 0; k < 5; k++) out->site[is].als_map[k] = -1;
+            continue;
+        }
         mcall_site(&call, cfg, in, out, is, grps, ngrp);
     }
     free(grps); free(smpl);

@@ -97,7 +97,7 @@ def pack_read(nt, baseQ, mapQ, is_rev, sclip, is_del, skip, qpos, l_qseq, cigar,
     epos = 0
     if want_epos:
         pos, ln = get_position(qpos, cigar)
-        epos = int(float(pos) / (ln + 1) * 100)
+        epos = min(max(int(float(pos) / (ln + 1) * 100), 0), 99)   # in range for every aligned qpos; clamp like the C packer
     return rd, epos
 
 
