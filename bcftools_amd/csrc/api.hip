@@ -32,7 +32,6 @@ struct bcfgpu_ctx {
     double *d_fk = nullptr, *d_beta = nullptr, *d_lhet = nullptr, *d_pl2p = nullptr, *d_mw = nullptr;
     double call_theta_log = 0;
     // workspaces sized by cfg.max_sites / cfg.max_reads
-    uint16_t *d_codes = nullptr;
     int *d_hist = nullptr, *d_err = nullptr;
     CallretPlanes cr{};
     size_t ncells_cap = 0;
@@ -127,8 +126,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
     const size_t ncells = (size_t)(cfg->max_sites > 0 ? cfg->max_sites : 0) * cfg->n_smpl;
     c->ncells_cap = ncells;
     if (ncells) {
-        if ((rc = dev_alloc(c, (void**)&c->d_codes, (size_t)cfg->max_reads * 2 + 16)) ||
-            (rc = dev_alloc(c, (void**)&c->d_hist, (size_t)cfg->max_sites * H_SIZE * sizeof(int))) ||
+        if ((rc = dev_alloc(c, (void**)&c->d_hist, (size_t)cfg->max_sites * H_SIZE * sizeof(int))) ||
             (rc = dev_alloc(c, (void**)&c->cr.p15, ncells * 15 * sizeof(float))) ||
             (rc = dev_alloc(c, (void**)&c->cr.qs64, ncells * 8)) ||
             (rc = dev_alloc(c, (void**)&c->cr.adf, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->cr.adr, ncells * 4)) ||
@@ -303,6 +301,8 @@ static int check_tile(bcfgpu_ctx *c, const bcfgpu_tile *t)
     if (t->n_sites && (!t->plp_off || (!t->is_indel && !t->ref16) || (t->n_reads && (!t->rd || !t->epos))))
         return set_err(BCFGPU_E_ARG, "tile: NULL array");
     if (t->is_indel && t->n_reads && !t->aux) return set_err(BCFGPU_E_ARG, "indel tile without aux");
+    if (((uintptr_t)t->rd & 15) || ((uintptr_t)t->epos & 15)) return set_err(BCFGPU_E_ARG, "tile: rd/epos must be 16-byte aligned");
+    if (t->n_reads >> 32) return set_err(BCFGPU_E_RANGE, "tile: more than 2^32-1 reads");
     return 0;
 }
 
@@ -315,8 +315,15 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     // one workgroup = 256 consecutive cells = at most (255/S)+2 sites
     const int slots = 255 / S + 2;
     g.hist_slots = slots <= 8 ? slots : 0;
+    // LDS budget: two workgroups per CU (160 KiB) -> ~79 KiB each
+    {
+        int cap = 8000;
+        while (cap > 2048 && glfgen_lds_bytes(cap, g.hist_slots) > 80 * 1024) cap -= 16;
+        g.lds_cap = cap;
+    }
+    g.n_reads = (uint32_t)tile->n_reads;
     g.ref16 = tile->ref16; g.off = tile->plp_off; g.rd = tile->rd; g.epos = tile->epos; g.aux = tile->aux;
-    g.codes = c->d_codes; g.fk = c->d_fk; g.beta = c->d_beta; g.lhet = c->d_lhet;
+    g.fk = c->d_fk; g.beta = c->d_beta; g.lhet = c->d_lhet;
     g.cr = c->cr;
     // the callret planes are addressed with ncells of *this* tile
     g.hist = c->d_hist; g.err = c->d_err;

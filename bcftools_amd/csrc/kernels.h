@@ -28,12 +28,13 @@ struct GlfgenParams {
     int n_sites, n_smpl, is_indel;
     int min_baseQ, capQ, fmt_flag;
     int hist_slots;                 // >0: per-workgroup LDS histograms with that many site slots; 0: global atomics
+    int lds_cap;                    // reads staged in LDS per workgroup round (multiple of 16)
+    uint32_t n_reads;               // length of rd/epos (bounds of the vector loads)
     const int8_t   *ref16;
     const uint32_t *off;
     const uint32_t *rd;
     const uint8_t  *epos;
     const uint32_t *aux;
-    uint16_t *codes;                // workspace [n_reads]: the `bases` array of bcf_callaux_t
     const double *fk, *beta, *lhet;
     CallretPlanes cr;
     int *hist;                      // [n_sites][H_SIZE], zeroed before launch
@@ -69,6 +70,7 @@ struct McallParams {
     int out_n_gt_max;               // plane count of out.pl / out.gp
 };
 
+size_t glfgen_lds_bytes(int cap, int hist_slots);
 void launch_glfgen(const GlfgenParams &p, hipStream_t s);
 void launch_combine(const CombineParams &p, hipStream_t s);
 void launch_mcall(const McallParams &p, hipStream_t s);
