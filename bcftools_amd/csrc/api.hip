@@ -84,6 +84,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
     bcfgpu_ctx *c = new bcfgpu_ctx();
     c->cfg = *cfg;
     if (c->cfg.capQ <= 0) c->cfg.capQ = 60;
+    if (c->cfg.capQ > 63) { delete c; return set_err(BCFGPU_E_ARG, "bcfgpu_create: capQ must be <= 63 (the reference fixes it at 60, bam2bcf.c:48)"); }
     if (c->cfg.min_baseQ < 0) c->cfg.min_baseQ = 0;
     hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return set_err(BCFGPU_E_HIP, "hipStreamCreate", e); }
@@ -98,7 +99,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
     build_pl2p(pl2p);
     build_mw_table(mw);
     int rc = 0;
-    if ((rc = dev_alloc(c, (void**)&c->d_fk, fk.size() * 8)) || (rc = dev_alloc(c, (void**)&c->d_beta, beta.size() * 8)) ||
+    if ((rc = dev_alloc(c, (void**)&c->d_fk, fk.size() * 8)) || (rc = dev_alloc(c, (void**)&c->d_beta, beta.size() * 8 + 64)) ||
         (rc = dev_alloc(c, (void**)&c->d_lhet, lhet.size() * 8)) || (rc = dev_alloc(c, (void**)&c->d_pl2p, sizeof pl2p)) ||
         (rc = dev_alloc(c, (void**)&c->d_mw, sizeof mw)) || (rc = dev_alloc(c, (void**)&c->d_err, sizeof(int)))) {
         bcfgpu_destroy(c); return rc;
@@ -322,6 +323,7 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
         g.lds_cap = cap;
     }
     g.n_reads = (uint32_t)tile->n_reads;
+    { const char *ab = getenv("BCFGPU_ABLATE"); g.ablate = ab ? atoi(ab) : 0; }
     g.ref16 = tile->ref16; g.off = tile->plp_off; g.rd = tile->rd; g.epos = tile->epos; g.aux = tile->aux;
     g.fk = c->d_fk; g.beta = c->d_beta; g.lhet = c->d_lhet;
     g.cr = c->cr;

@@ -15,9 +15,13 @@
 // relative order of codes with the same base matters (per-base accumulators), and within a
 // base the code order is the order of key7 = q<<1|strand.  The sort is therefore replaced by
 // a per-base counting pass over the 128 possible key7 values (u8 counters in LDS, one column
-// per lane, conflict-free) followed by a walk over the set bits of a 128-bit presence mask.
+// per lane, conflict-free).  The descending walk is organised key-major: the wave ORs its lanes'
+// 128-bit key-presence masks, iterates the union from the highest key down (scalar loop) and, for
+// each key, every lane consumes its own count of reads with that key, four beta gathers in
+// flight at a time.  Quality and strand are wave-uniform inside that loop.
 // Reads carrying the site's reference base -- almost all of them -- are counted directly in
-// the per-read loop; only the others are kept as codes (in place, in the lane's LDS slice).
+// the per-read loop; the others (exactly the "diff" reads of the I16 annotations) are kept, in
+// place, in the lane's LDS slice as a packed word and handled by a second, short loop.
 //
 // Site-wide bias histograms (bam2bcf.c:228-252) are integer counts: hot bins (mapQ>=59) are
 // counted in registers, the rest with LDS atomics; one flush of global atomics per workgroup.
@@ -32,51 +36,77 @@ namespace bcfgpu {
 
 // seq_nt16_int packed in nibbles: {4,0,1,4,2,4,4,4,3,4,4,4,4,4,4,4}
 __device__ __forceinline__ int nt16_int(int c) { return (int)((0x4444444344424104ull >> (4 * (c & 15))) & 7); }
-
 __device__ __forceinline__ int tri(int j, int k) { return k * (k + 1) / 2 + j; }   // j<=k
 
-struct WalkState {
-    uint64_t mlo, mhi;
-};
-
-// errmod_cal's descending walk for one base: the lane's counts are in s_cnt (column `tid`), the
-// presence mask in (mlo,mhi); `left` reads to process.  Returns bsum[base].
-__device__ __forceinline__ double walk_base(const uint32_t *s_cnt, const double *s_fk, const double *beta,
-                                            int tid, int n, int left, uint64_t mlo, uint64_t mhi)
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
 {
-    int rem = 0, rev = 0;
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+    return v;
+}
+
+// LDS layout (bytes): fk[264] f64 | cnt[32][WG] u32 | msk[4][WG] u32 | rd[cap+4] u32 | epos[cap+32] u8 | hist
+#define LDS_FK   0
+#define LDS_CNT  2112
+#define LDS_MSK  (LDS_CNT + 32 * WG * 4)
+#define LDS_RD   (LDS_MSK + 4 * WG * 4)
+
+// packed "other" (non-primary = diff) read: baseQ:8 | mapQ(capped):6 | q:6 | b:4 | rev:1 | min_dist:5
+#define OW_PACK(baseQ, mapQ, q, b, rev, md) \
+    ((uint32_t)(baseQ) | (uint32_t)(mapQ) << 8 | (uint32_t)(q) << 14 | (uint32_t)(b) << 20 | (uint32_t)(rev) << 24 | (uint32_t)(md) << 25)
+
+// Descending walk of errmod_cal for one base, key-major (see the header comment).  s_cnt/s_msk hold this
+// lane's per-key counts and key-presence bits, `n` selects the beta row of the lane.
+__device__ __forceinline__ double walk_keys(const uint32_t *s_cnt, const uint32_t *s_msk, const double *s_fk,
+                                            const double *beta, int tid, int n)
+{
+    uint32_t u[4];
+    #pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = __builtin_amdgcn_readfirstlane(wave_or(s_msk[k * WG + tid]));
     uint32_t cc = 0, w0 = 0, w1 = 0;
-    const double *brow = beta;
     double bs = 0;
-    while (__any(left > 0)) {
-        if (left > 0) {
-            if (rem == 0) {
-                uint32_t key;
-                if (mhi) { const int k = 63 - __clzll((long long)mhi); mhi &= ~(1ull << k); key = k + 64; }
-                else     { const int k = 63 - __clzll((long long)mlo); mlo &= ~(1ull << k); key = k; }
-                rem = (s_cnt[(key >> 2) * WG + tid] >> (8 * (key & 3))) & 0xff;
-                rev = key & 1;
-                brow = beta + ((size_t)(key >> 1) << 16 | (size_t)n << 8);
+    const double *brow_n = beta + ((size_t)n << 8);
+    #pragma unroll
+    for (int k = 3; k >= 0; --k) {
+        uint32_t m = u[k];                              // wave-uniform
+        while (m) {
+            const int bit = 31 - __builtin_clz(m);
+            m &= ~(1u << bit);
+            const int key = k * 32 + bit;               // q<<1 | strand, wave-uniform
+            const int rev = key & 1;
+            const int cnt = (int)((s_cnt[(key >> 2) * WG + tid] >> (8 * (key & 3))) & 0xff);
+            const double *bp = brow_n + ((size_t)(key >> 1) << 16) + cc;
+            const double *fp = s_fk + (rev ? w1 : w0);
+            for (int r = 0; __any(r < cnt); r += 4) {
+                // up to four reads of this lane with this key: issue the gathers first, then add in order
+                const double b0 = (r     < cnt) ? bp[r]     : 0.0;
+                const double b1 = (r + 1 < cnt) ? bp[r + 1] : 0.0;
+                const double b2 = (r + 2 < cnt) ? bp[r + 2] : 0.0;
+                const double b3 = (r + 3 < cnt) ? bp[r + 3] : 0.0;
+                const double f0 = fp[r], f1 = fp[r + 1], f2 = fp[r + 2], f3 = fp[r + 3];
+                if (r     < cnt) bs += f0 * b0;
+                if (r + 1 < cnt) bs += f1 * b1;
+                if (r + 2 < cnt) bs += f2 * b2;
+                if (r + 3 < cnt) bs += f3 * b3;
             }
-            const double f = s_fk[rev ? w1 : w0];
-            bs += f * brow[cc];
-            ++cc; w1 += rev; w0 += 1 - rev;
-            --rem; --left;
+            cc += cnt;
+            if (rev) w1 += cnt; else w0 += cnt;
         }
     }
     return bs;
 }
 
+template <bool INDEL, bool LDS_HIST>
 __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    // LDS carve-up: fk[256] f64 | cnt[32][WG] u32 | rd[cap] u32 | epos[cap] u8 | hist[slots][H_SIZE] i32
     const int cap = P.lds_cap;
-    double   *s_fk  = reinterpret_cast<double*>(smem);
-    uint32_t *s_cnt = reinterpret_cast<uint32_t*>(smem + 2048);
-    uint32_t *s_rd  = reinterpret_cast<uint32_t*>(smem + 2048 + 32 * WG * 4);
-    uint8_t  *s_ep  = smem + 2048 + 32 * WG * 4 + ((size_t)cap + 4) * 4;
-    int      *s_hist = reinterpret_cast<int*>(smem + 2048 + 32 * WG * 4 + ((size_t)cap + 4) * 4 + (size_t)cap + 32);
+    double   *s_fk  = reinterpret_cast<double*>(smem + LDS_FK);
+    uint32_t *s_cnt = reinterpret_cast<uint32_t*>(smem + LDS_CNT);
+    uint32_t *s_msk = reinterpret_cast<uint32_t*>(smem + LDS_MSK);
+    uint32_t *s_rd  = reinterpret_cast<uint32_t*>(smem + LDS_RD);
+    uint8_t  *s_ep  = smem + LDS_RD + ((size_t)cap + 4) * 4;
+    int      *s_hist = reinterpret_cast<int*>(smem + LDS_RD + ((size_t)cap + 4) * 4 + (size_t)cap + 32);
     __shared__ unsigned int s_next;
 
     const int tid = threadIdx.x;
@@ -87,22 +117,26 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
     const int site0 = (int)(cell0 / P.n_smpl);
 
     s_fk[tid] = P.fk[tid];
-    for (int i = tid; i < P.hist_slots * H_SIZE; i += WG) s_hist[i] = 0;
+    if (tid < 8) s_fk[256 + tid] = 0.0;               // read-ahead slack of the walk (never used in a sum)
+    if (LDS_HIST) for (int i = tid; i < P.hist_slots * H_SIZE; i += WG) s_hist[i] = 0;
 
-    const int is_indel = P.is_indel;
     int site = 0, ref_base = -1, ref4 = 4;
     uint32_t beg = 0, end = 0;
     if (active) {
         site = (int)(cell / P.n_smpl);
         beg = P.off[cell]; end = P.off[cell + 1];
-        if (!is_indel) { ref_base = P.ref16[site]; ref4 = nt16_int(ref_base); }
+        if (!INDEL) { ref_base = P.ref16[site]; ref4 = nt16_int(ref_base); }
     }
-    const int primary = is_indel ? 0 : ref4;          // the base whose reads are counted on the fly
-    int *hist = P.hist_slots ? s_hist + (site - site0) * H_SIZE : P.hist + (long)site * H_SIZE;
+    const int primary = INDEL ? 0 : ref4;             // the base whose reads are counted on the fly
+    int *ghist = P.hist + (long)site * H_SIZE;
+    int *lhist = s_hist + (site - site0) * H_SIZE;
     const bool want_epos = (P.fmt_flag & (BCFGPU_INFO_RPB | BCFGPU_INFO_VDB)) != 0;
     const bool want_scr = (P.fmt_flag & (BCFGPU_INFO_SCR | BCFGPU_FMT_SCR)) != 0;
     const uint32_t span_end = P.off[min(cell0 + WG, ncells)];
     const uint32_t n_reads_tot = P.n_reads;
+    const int min_baseQ = P.min_baseQ, capQ = P.capQ;
+
+    #define HIST_ADD(idx, v) do { if (LDS_HIST) atomicAdd(&lhist[idx], v); else atomicAdd(&ghist[idx], v); } while (0)
 
     bool done = !active;
     if (active && end - beg > (uint32_t)cap) { atomicExch(P.err, BCFGPU_E_DEPTH); done = true; }   // cannot be staged
@@ -111,6 +145,7 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
     for (;;) {
         // ---- stage [base, lim) of rd/epos into LDS, 16 bytes per lane per load ----
         const uint32_t abase = base & ~3u;                       // 16-byte aligned start of the u32 stream
+        const uint32_t ebase = base & ~15u;                      // 16-byte aligned start of the u8 stream
         const uint32_t lim = min(abase + (uint32_t)cap, span_end);
         {
             const uint32_t nvec = (lim - abase + 3) >> 2;
@@ -125,7 +160,6 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
                 }
             }
             if (want_epos) {
-                const uint32_t ebase = base & ~15u;              // 16-byte aligned start of the u8 stream
                 const uint32_t nv16 = (lim - ebase + 15) >> 4;
                 const uint4 *es = reinterpret_cast<const uint4*>(P.epos + ebase);
                 uint4 *ed = reinterpret_cast<uint4*>(s_ep);
@@ -140,129 +174,146 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
 
         const bool part = !done && beg >= base && end <= lim;    // this lane's slice is resident
         const uint32_t lbeg = part ? beg - abase : 0;            // slice start in s_rd
-        const uint32_t ebeg = part ? beg - (base & ~15u) : 0;    // slice start in s_ep
-        const uint32_t cnt_raw = part ? end - beg : 0;
+        const uint32_t ebeg = part ? beg - ebase : 0;            // slice start in s_ep
+        const uint32_t cnt_raw = (part && !(P.ablate & 4)) ? end - beg : 0;
 
         // ---- pass 0: the per-read loop of bcf_call_glfgen (bam2bcf.c:170-253) ----
         #pragma unroll
         for (int k = 0; k < 32; ++k) s_cnt[k * WG + tid] = 0;
-        uint64_t qs64 = 0, c64 = 0, mlo = 0, mhi = 0;
-        uint32_t adf = 0, adr = 0, cnt4 = 0, mq0 = 0, scr = 0, ori_depth = 0;
-        uint32_t t_bq = 0, t_bq2 = 0, t_mq = 0, t_mq2 = 0, t_md = 0, t_md2 = 0;
-        uint32_t d_bq = 0, d_bq2 = 0, d_mq = 0, d_mq2 = 0, d_md = 0, d_md2 = 0;
-        uint32_t h59 = 0;            // reads with mapQ>=59: ref | alt<<8 | fwd<<16 | rev<<24 (flushed once per lane)
+        #pragma unroll
+        for (int k = 0; k < 4; ++k) s_msk[k * WG + tid] = 0;
+        uint64_t qs64 = 0;           // QS[0..3], 16 bits each
+        uint64_t ad64 = 0;           // ADF[0..3] | ADR[0..3]<<32, 8 bits each
+        uint32_t mq0 = 0, scr = 0, ori_depth = 0, n_rev = 0, n_b4 = 0;
+        uint32_t t_bqmd = 0, t_mq = 0, t_bq2 = 0, t_mq2 = 0, t_md2 = 0;   // totals: baseQ | min_dist<<16, mapQ, squares
+        uint32_t h59 = 0;            // reads with mapQ>=59: ref | alt<<8 | fwd<<16 | rev<<24
         int n = 0, n_other = 0;
         bool fail = false;
         for (uint32_t i = 0; i < cnt_raw; ++i) {
             const uint32_t w = s_rd[lbeg + i];
             if (w & BCFGPU_RD_SKIP) continue;
-            if ((w & BCFGPU_RD_DEL) && !is_indel) continue;
+            if (!INDEL && (w & BCFGPU_RD_DEL)) continue;
             ++ori_depth;
             const int nt = (w >> 16) & 15;
-            const int rev = (w >> 20) & 1;
-            int q, b, baseQ, seqQ, is_diff;
-            if (is_indel) {
+            const uint32_t rev = (w >> 20) & 1;
+            int q, b, baseQ, seqQ;
+            if (INDEL) {
                 const uint32_t ax = P.aux[beg + i];
-                b = (ax >> 16) & 0x3f;
+                b = (ax >> 16) & 0xf;                 // 0..4 after bcf_call_gap_prep (bam2bcf_indel.c:449-456)
                 baseQ = q = ax & 0xff;
-                if (q < P.min_baseQ) { b = 0; q = (int)(w & 0xff); }
+                if (q < min_baseQ) { b = 0; q = (int)(w & 0xff); }
                 seqQ = (ax >> 8) & 0xff;
-                is_diff = (b != 0);
             } else {
                 b = nt16_int(nt ? nt : ref_base);
                 baseQ = q = (int)(w & 0xff);
-                if (q < P.min_baseQ) continue;
+                if (q < min_baseQ) continue;
                 seqQ = 99;
-                is_diff = (ref4 < 4 && b == ref4) ? 0 : 1;
             }
             int mapQ = (w >> 8) & 0xff;
             if (mapQ == 255) mapQ = DEF_MAPQ;
-            if (!mapQ) mq0++;
-            if (q > seqQ) q = seqQ;
-            mapQ = mapQ < P.capQ ? mapQ : P.capQ;
-            if (q > mapQ) q = mapQ;
-            if (q > 63) q = 63;
-            if (q < 4) q = 4;
+            mq0 += (mapQ == 0);
+            q = min(q, seqQ);
+            mapQ = min(mapQ, capQ);
+            q = max(min(min(q, mapQ), 63), 4);
             if (n >= BCFGPU_MAX_DEPTH) { fail = true; break; }
             ++n;
-            const uint32_t code = (uint32_t)(q << 5 | rev << 4 | b);
-            if ((int)(code & 0xf) == primary) {
-                const uint32_t key = (code >> 4) & 0x7f;          // q<<1 | strand
+            n_rev += rev;
+            const int min_dist = min((int)(w >> 24), CAP_DIST);
+            const uint32_t key = (uint32_t)(q << 1) | rev;       // (code>>4)&0x7f of bam2bcf.c:203
+            if (b == primary) {
                 s_cnt[(key >> 2) * WG + tid] += 1u << (8 * (key & 3));
-                if (key < 64) mlo |= 1ull << key; else mhi |= 1ull << (key - 64);
+                atomicOr(&s_msk[(key >> 5) * WG + tid], 1u << (key & 31));
             } else {
-                s_rd[lbeg + n_other] = code;                      // n_other <= i: never overtakes the reader
+                s_rd[lbeg + n_other] = OW_PACK(baseQ, mapQ, q, b, rev, min_dist);    // n_other <= i: behind the reader
                 ++n_other;
             }
-            if (want_scr && (w & BCFGPU_RD_SCLIP)) scr++;
+            if (want_scr) scr += (w >> 21) & 1;
             if (b < 4) {
                 qs64 += (uint64_t)q << (16 * b);
-                if (rev) adr += 1u << (8 * b); else adf += 1u << (8 * b);
-            }
-            if (b < 8) c64 += 1ull << (8 * b);
-            cnt4 += 1u << (8 * (is_diff << 1 | rev));
-            int min_dist = (int)(w >> 24);
-            if (min_dist > CAP_DIST) min_dist = CAP_DIST;
-            const uint32_t dm = is_diff ? ~0u : 0u;
-            t_bq += baseQ;    t_bq2 += baseQ * baseQ;        d_bq += baseQ & dm;    d_bq2 += (baseQ * baseQ) & dm;
-            t_mq += mapQ;     t_mq2 += mapQ * mapQ;          d_mq += mapQ & dm;     d_mq2 += (mapQ * mapQ) & dm;
-            t_md += min_dist; t_md2 += min_dist * min_dist;  d_md += min_dist & dm; d_md2 += (min_dist * min_dist) & dm;
+                ad64 += 1ull << (8 * b + 32 * rev);
+            } else n_b4++;
+            t_bqmd += (uint32_t)baseQ | (uint32_t)min_dist << 16;
+            t_mq += mapQ;
+            t_bq2 += baseQ * baseQ; t_mq2 += mapQ * mapQ; t_md2 += min_dist * min_dist;
             // bias-test histograms: ibq = (int)(baseQ/60.*60) is the identity on 0..59 (checked in tests)
-            const int ibq = baseQ > 59 ? 59 : baseQ;
-            const int imq = mapQ > 59 ? 59 : mapQ;
+            if (P.ablate & 1) continue;
+            const int ibq = min(baseQ, 59);
+            const int imq = min(mapQ, 59);
             const int ep = want_epos ? s_ep[ebeg + i] : 0;
             const bool isref = (nt == ref_base);
             if (imq == 59) h59 += (isref ? 1u : 1u << 8) + (rev ? 1u << 24 : 1u << 16);
             else {
-                atomicAdd(&hist[(rev ? H_REV_MQS : H_FWD_MQS) + imq], 1);
-                atomicAdd(&hist[(isref ? H_REF_MQ : H_ALT_MQ) + imq], 1);
+                HIST_ADD((rev ? H_REV_MQS : H_FWD_MQS) + imq, 1);
+                HIST_ADD((isref ? H_REF_MQ : H_ALT_MQ) + imq, 1);
             }
-            atomicAdd(&hist[(isref ? H_REF_POS : H_ALT_POS) + ep], 1);
-            atomicAdd(&hist[(isref ? H_REF_BQ : H_ALT_BQ) + ibq], 1);
+            HIST_ADD((isref ? H_REF_POS : H_ALT_POS) + ep, 1);
+            HIST_ADD((isref ? H_REF_BQ : H_ALT_BQ) + ibq, 1);
         }
         if (h59) {
-            if (h59 & 0xff)         atomicAdd(&hist[H_REF_MQ + 59], (int)(h59 & 0xff));
-            if ((h59 >> 8) & 0xff)  atomicAdd(&hist[H_ALT_MQ + 59], (int)((h59 >> 8) & 0xff));
-            if ((h59 >> 16) & 0xff) atomicAdd(&hist[H_FWD_MQS + 59], (int)((h59 >> 16) & 0xff));
-            if (h59 >> 24)          atomicAdd(&hist[H_REV_MQS + 59], (int)(h59 >> 24));
+            if (h59 & 0xff)         HIST_ADD(H_REF_MQ + 59, (int)(h59 & 0xff));
+            if ((h59 >> 8) & 0xff)  HIST_ADD(H_ALT_MQ + 59, (int)((h59 >> 8) & 0xff));
+            if ((h59 >> 16) & 0xff) HIST_ADD(H_FWD_MQS + 59, (int)((h59 >> 16) & 0xff));
+            if (h59 >> 24)          HIST_ADD(H_REV_MQS + 59, (int)(h59 >> 24));
         }
-        if (fail || ori_depth > 0xffff) { atomicExch(P.err, BCFGPU_E_DEPTH); n = 0; c64 = 0; n_other = 0; mlo = mhi = 0; }
+        if (fail || ori_depth > 0xffff) {
+            atomicExch(P.err, BCFGPU_E_DEPTH);
+            n = 0; n_other = 0; qs64 = ad64 = 0; n_rev = n_b4 = 0;
+            #pragma unroll
+            for (int k = 0; k < 4; ++k) s_msk[k * WG + tid] = 0;
+        }
+        // per-base counts c[0..4] (errmod_cal's aux.c)
+        int c[5];
+        #pragma unroll
+        for (int b = 0; b < 4; ++b) c[b] = (int)((ad64 >> (8 * b)) & 0xff) + (int)((ad64 >> (8 * b + 32)) & 0xff);
+        c[4] = (int)n_b4;
+        const bool skip_walk = (P.ablate & 2) != 0;
 
         // ---- errmod_cal: descending walk per base ----
         double bsum[5] = {0, 0, 0, 0, 0};
         // (a) the primary base, already counted
-        {
-            const int cb = primary < 8 ? (int)((c64 >> (8 * primary)) & 0xff) : 0;
-            const double bs = walk_base(s_cnt, s_fk, P.beta, tid, n, cb, mlo, mhi);
+        if (!skip_walk) {
+            const double bs = walk_keys(s_cnt, s_msk, s_fk, P.beta, tid, n);
             #pragma unroll
             for (int b = 0; b < 5; ++b) if (b == primary) bsum[b] = bs;
         }
-        // (b) every other base present in some lane of the wave: count its codes, then walk
-        #pragma unroll
-        for (int b = 0; b < 5; ++b) {
-            const int cb = (b != primary) ? (int)((c64 >> (8 * b)) & 0xff) : 0;
-            if (!__any(cb > 0)) continue;
-            #pragma unroll
-            for (int k = 0; k < 32; ++k) s_cnt[k * WG + tid] = 0;
-            uint64_t lo = 0, hi = 0;
-            if (cb > 0) {
-                for (int i = 0; i < n_other; ++i) {
-                    const uint32_t code = s_rd[lbeg + i];
-                    if ((int)(code & 0xf) != b) continue;
-                    const uint32_t key = (code >> 4) & 0x7f;
-                    s_cnt[(key >> 2) * WG + tid] += 1u << (8 * (key & 3));
-                    if (key < 64) lo |= 1ull << key; else hi |= 1ull << (key - 64);
-                }
+        // (b) the other reads: the "diff" annotation sums, then count + walk per base present in the wave
+        uint32_t d_bqmd = 0, d_mq = 0, d_bq2 = 0, d_mq2 = 0, d_md2 = 0, d_fwd = 0, d_rev = 0;
+        if (__any(n_other > 0)) {
+            for (int i = 0; i < n_other; ++i) {
+                const uint32_t ow = s_rd[lbeg + i];
+                const uint32_t baseQ = ow & 0xff, mapQ = (ow >> 8) & 0x3f, md = ow >> 25;
+                d_bqmd += baseQ | md << 16;
+                d_mq += mapQ;
+                d_bq2 += baseQ * baseQ; d_mq2 += mapQ * mapQ; d_md2 += md * md;
+                const uint32_t rev = (ow >> 24) & 1;
+                d_rev += rev; d_fwd += 1 - rev;
             }
-            const double bs = walk_base(s_cnt, s_fk, P.beta, tid, n, cb, lo, hi);
-            if (b != primary) bsum[b] = bs;      // lanes of one wave may belong to sites with different reference bases
+            #pragma unroll
+            for (int b = 0; b < 5; ++b) {
+                const int cb = (b != primary) ? c[b] : 0;
+                if (skip_walk || !__any(cb > 0)) continue;
+                #pragma unroll
+                for (int k = 0; k < 32; ++k) s_cnt[k * WG + tid] = 0;
+                #pragma unroll
+                for (int k = 0; k < 4; ++k) s_msk[k * WG + tid] = 0;
+                if (cb > 0) {
+                    for (int i = 0; i < n_other; ++i) {
+                        const uint32_t ow = s_rd[lbeg + i];
+                        int bb = (ow >> 20) & 0xf;
+                        if (bb > 4) bb = 4;
+                        if (bb != b) continue;
+                        const uint32_t key = ((ow >> 14) & 0x3f) << 1 | ((ow >> 24) & 1);
+                        s_cnt[(key >> 2) * WG + tid] += 1u << (8 * (key & 3));
+                        atomicOr(&s_msk[(key >> 5) * WG + tid], 1u << (key & 31));
+                    }
+                }
+                const double bs = walk_keys(s_cnt, s_msk, s_fk, P.beta, tid, n);
+                if (b != primary) bsum[b] = bs;      // lanes of one wave may belong to sites with different reference bases
+            }
         }
 
         // ---- epilogue of errmod_cal (m=5): float accumulators as in the reference ----
         if (part) {
-            int c[5];
-            #pragma unroll
-            for (int b = 0; b < 5; ++b) c[b] = (int)((c64 >> (8 * b)) & 0xff);
             #pragma unroll
             for (int j = 0; j < 5; ++j) {
                 float tmp1 = 0.0f; int tmp2 = 0;
@@ -287,10 +338,17 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
                     P.cr.p15[(size_t)tri(j, k) * ncells + cell] = h;
                 }
             }
+            // anno[0..3]: ref/alt x fwd/rev counts.  "diff" reads are exactly the non-primary ones when the
+            // reference base is A/C/G/T (or at indel sites); with an N reference every read is a diff read.
+            const bool all_diff = (!INDEL && ref4 >= 4);
+            const uint32_t n_fwd = (uint32_t)n - n_rev;
+            if (all_diff) { d_fwd = n_fwd; d_rev = n_rev; d_bqmd = t_bqmd; d_mq = t_mq; d_bq2 = t_bq2; d_mq2 = t_mq2; d_md2 = t_md2; }
+            const uint32_t cnt4 = (n_fwd - d_fwd) | (n_rev - d_rev) << 8 | d_fwd << 16 | d_rev << 24;
             P.cr.qs64[cell] = qs64;
-            P.cr.adf[cell] = adf; P.cr.adr[cell] = adr; P.cr.cnt4[cell] = cnt4;
+            P.cr.adf[cell] = (uint32_t)ad64; P.cr.adr[cell] = (uint32_t)(ad64 >> 32); P.cr.cnt4[cell] = cnt4;
             P.cr.misc[cell] = (mq0 & 0xff) | (scr & 0xff) << 8 | ori_depth << 16;
             uint32_t *sm = P.cr.sums + cell;
+            const uint32_t t_bq = t_bqmd & 0xffff, t_md = t_bqmd >> 16, d_bq = d_bqmd & 0xffff, d_md = d_bqmd >> 16;
             sm[0 * ncells] = t_bq - d_bq; sm[1 * ncells] = t_bq2 - d_bq2; sm[2 * ncells] = d_bq; sm[3 * ncells] = d_bq2;
             sm[4 * ncells] = t_mq - d_mq; sm[5 * ncells] = t_mq2 - d_mq2; sm[6 * ncells] = d_mq; sm[7 * ncells] = d_mq2;
             sm[8 * ncells] = t_md - d_md; sm[9 * ncells] = t_md2 - d_md2; sm[10 * ncells] = d_md; sm[11 * ncells] = d_md2;
@@ -306,18 +364,31 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
     }
 
     // ---- flush the workgroup's histograms ----
-    if (P.hist_slots) {
+    if (LDS_HIST) {
         const int nslot = min(P.hist_slots, P.n_sites - site0);
         for (int i = tid; i < nslot * H_SIZE; i += WG) {
             const int v = s_hist[i];
             if (v) atomicAdd(&P.hist[(long)site0 * H_SIZE + i], v);
         }
     }
+    #undef HIST_ADD
 }
 
 size_t glfgen_lds_bytes(int cap, int hist_slots)
 {
-    return 2048 + 32 * WG * 4 + ((size_t)cap + 4) * 4 + (size_t)cap + 32 + (size_t)hist_slots * H_SIZE * sizeof(int);
+    return LDS_RD + ((size_t)cap + 4) * 4 + (size_t)cap + 32 + (size_t)hist_slots * H_SIZE * sizeof(int);
+}
+
+template <bool INDEL, bool LDS_HIST>
+static void launch_one(const GlfgenParams &p, hipStream_t s, int grid, size_t lds)
+{
+    static size_t lds_attr = 0;
+    if (lds > lds_attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(glfgen_kernel<INDEL, LDS_HIST>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_attr = lds;
+    }
+    hipLaunchKernelGGL((glfgen_kernel<INDEL, LDS_HIST>), dim3(grid), dim3(WG), lds, s, p);
 }
 
 void launch_glfgen(const GlfgenParams &p, hipStream_t s)
@@ -326,12 +397,8 @@ void launch_glfgen(const GlfgenParams &p, hipStream_t s)
     if (ncells == 0) return;
     const int grid = (int)((ncells + WG - 1) / WG);
     const size_t lds = glfgen_lds_bytes(p.lds_cap, p.hist_slots);
-    static size_t lds_attr = 0;
-    if (lds > lds_attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(glfgen_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_attr = lds;
-    }
-    hipLaunchKernelGGL(glfgen_kernel, dim3(grid), dim3(WG), lds, s, p);
+    if (p.is_indel) { if (p.hist_slots) launch_one<true, true>(p, s, grid, lds); else launch_one<true, false>(p, s, grid, lds); }
+    else            { if (p.hist_slots) launch_one<false, true>(p, s, grid, lds); else launch_one<false, false>(p, s, grid, lds); }
 }
 
 }  // namespace bcfgpu

@@ -30,6 +30,7 @@ struct GlfgenParams {
     int hist_slots;                 // >0: per-workgroup LDS histograms with that many site slots; 0: global atomics
     int lds_cap;                    // reads staged in LDS per workgroup round (multiple of 16)
     uint32_t n_reads;               // length of rd/epos (bounds of the vector loads)
+    int ablate;                     // diagnostics only (BCFGPU_ABLATE): 1 no histograms, 2 no errmod walk, 4 no per-read loop
     const int8_t   *ref16;
     const uint32_t *off;
     const uint32_t *rd;

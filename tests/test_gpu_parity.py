@@ -115,3 +115,41 @@ def test_depth_over_255_is_refused(gpu_ctx_factory):
     with pytest.raises(BcfGpuError) as e:
         ctx.mpileup(tile)
     assert e.value.code == abi.E_DEPTH
+
+
+@pytest.mark.parametrize("n_sites,n_smpl,seed", [(40, 100, 21), (64, 7, 22)])
+def test_indel_pass_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, seed):
+    """glfgen/combine with ref_base=-1 and p->aux set (mpileup.c:357-360): type<<16|seqQ<<8|indelQ as left by
+    bcf_call_gap_prep; low indelQ reads fall back to REF (bam2bcf.c:183); sites without ALT support return -1."""
+    base = synth.numpy_tile(seed, n_sites, n_smpl, depth=20.0, var_rate=0.0)
+    rng = np.random.default_rng(seed)
+    R = len(base.rd)
+    cell = np.repeat(np.arange(n_sites * n_smpl), np.diff(base.plp_off.astype(np.int64)))
+    site = cell // n_smpl
+    has_indel = rng.random(n_sites) < 0.7
+    carrier = rng.random(n_sites * n_smpl) < 0.3
+    typ = np.where(has_indel[site] & carrier[cell] & (rng.random(R) < 0.5), rng.integers(1, 5, R), 0)
+    indelQ = rng.integers(0, 80, R)
+    seqQ = rng.integers(10, 200, R)
+    aux = (typ.astype(np.uint32) << 16) | (seqQ.astype(np.uint32) << 8) | indelQ.astype(np.uint32)
+    rd = base.rd | np.where(rng.random(R) < 0.05, abi.RD_DEL, 0).astype(np.uint32)
+    tile = host.HostTile(n_smpl, base.ref16, base.plp_off, rd, base.epos, aux=aux, is_indel=1)
+    fmt = abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=R, fmt_flag=fmt)
+    want = orc.mpileup(cfg, tile)
+    got = gpu_ctx_factory(cfg).mpileup(tile)
+    assert (want.site["ret"] == -1).any() and (want.site["ret"] == 0).any()
+    dead = want.site["ret"] == -1
+    np.testing.assert_array_equal(got.site["ret"], want.site["ret"])
+    for k in ("a", "n_alleles", "qsum"):
+        np.testing.assert_array_equal(got.site[k], want.site[k], err_msg=k)
+    live = ~dead
+    for k in EXACT_SITE:
+        np.testing.assert_array_equal(got.site[k][live], want.site[k][live], err_msg="site." + k)
+    for k in ["pl", "dp4", "adf", "adr"]:
+        np.testing.assert_array_equal(getattr(got, k)[live], getattr(want, k)[live], err_msg=k)
+    for k in FLOAT_SITE:
+        g, w = got.site[k][live].astype(np.float64), want.site[k][live].astype(np.float64)
+        assert np.array_equal(np.isinf(g), np.isinf(w)), k
+        m = ~np.isinf(w)
+        np.testing.assert_allclose(g[m], w[m], rtol=2e-6, atol=1e-30, err_msg=k)
