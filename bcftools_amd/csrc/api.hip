@@ -385,6 +385,7 @@ int bcfgpu_mcall(bcfgpu_ctx *c, const bcfgpu_call_in *in, const bcfgpu_call_out 
     m.ploidy = in->ploidy; m.grp = c->cfg.n_grp > 1 ? in->grp : nullptr; m.prior_an = in->prior_an; m.prior_ac = in->prior_ac;
     m.out = *out; m.out_n_gt_max = in->n_gt_max;
     if (c->timing == 1) hipEventRecord(c->ev[2], c->stream);
+    { const char *ab = getenv("BCFGPU_ABLATE"); m.ablate = ab ? atoi(ab) : 0; }
     launch_mcall(m, c->stream);
     if (c->timing == 1) { hipEventRecord(c->ev[3], c->stream); hipEventSynchronize(c->ev[3]);
         bcfgpu_timing t{}; hipEventElapsedTime(&t.mcall_ms, c->ev[2], c->ev[3]); t.total_ms = t.mcall_ms; c->last = t; }
@@ -415,6 +416,7 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
     if (c->cfg.n_grp > 1 && !c->cfg.grp_tag_is_qs) { m.ad_u8 = mout->adf; m.ad_u8b = mout->adr; }   // FORMAT/AD = ADF+ADR (bam2bcf.c:892-896)
     m.ploidy = ploidy; m.grp = c->cfg.n_grp > 1 ? grp : nullptr;
     m.out = *cout; m.out_n_gt_max = BCFGPU_MAX_PL;
+    { const char *ab = getenv("BCFGPU_ABLATE"); m.ablate = ab ? atoi(ab) : 0; }
     launch_mcall(m, c->stream);
     if (c->timing == 1) hipEventRecord(c->ev[3], c->stream);
     else if (c->timing == 2) { hipEventRecord(c->pool[c->pool.size() - 1], c->stream); c->pool_call.back() = 1; }

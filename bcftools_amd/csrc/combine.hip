@@ -157,21 +157,33 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
     if (tid < 32) sh.tot[tid] = 0;
     if (tid == 0) { sh.segb_sum = 0; sh.sum_min = 0; }
 
-    // ---- qsum: sequential float sum over samples, lane j owns allele j (bam2bcf.c:569-575) ----
+    // ---- qsum (bam2bcf.c:569-575): every thread normalises its samples' QS in parallel, then lane j of
+    // wave 0 adds allele j's fractions in sample order (a sequential float32 sum, as in the reference) ----
     float myq = 0.f;
-    for (int base = 0; base < S; base += CHUNK) {
-        const int cn = min(CHUNK, S - base);
+    float4 *s_frac = reinterpret_cast<float4*>(s_stage);
+    for (int base = 0; base < S; base += CHUNK / 2) {
+        const int cn = min(CHUNK / 2, S - base);
         __syncthreads();
-        for (int i = tid; i < cn; i += WG) s_stage[i] = P.cr.qs64[c0 + base + i];
+        for (int i = tid; i < cn; i += WG) {
+            const unsigned long long v = P.cr.qs64[c0 + base + i];
+            const float q0 = (float)(int)(v & 0xffff), q1 = (float)(int)((v >> 16) & 0xffff);
+            const float q2 = (float)(int)((v >> 32) & 0xffff), q3 = (float)(int)((v >> 48) & 0xffff);
+            float sum = 0;
+            sum += q0; sum += q1; sum += q2; sum += q3;
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sum != 0.f) f = make_float4(q0 / sum, q1 / sum, q2 / sum, q3 / sum);
+            s_frac[i] = f;             // adding +0 for empty samples leaves the running sum unchanged
+        }
         __syncthreads();
         if (tid < 4) {
-            for (int i = 0; i < cn; ++i) {
-                const unsigned long long v = s_stage[i];
-                float sum = 0;
-                sum += (float)(int)(v & 0xffff); sum += (float)(int)((v >> 16) & 0xffff);
-                sum += (float)(int)((v >> 32) & 0xffff); sum += (float)(int)((v >> 48) & 0xffff);
-                if (sum != 0.f) myq += (float)(int)((v >> (16 * tid)) & 0xffff) / sum;
+            const float *fr = reinterpret_cast<const float*>(s_frac) + tid;
+            int i = 0;
+            for (; i + 8 <= cn; i += 8) {
+                const float a0 = fr[4 * i], a1 = fr[4 * i + 4], a2 = fr[4 * i + 8], a3 = fr[4 * i + 12];
+                const float a4 = fr[4 * i + 16], a5 = fr[4 * i + 20], a6 = fr[4 * i + 24], a7 = fr[4 * i + 28];
+                myq += a0; myq += a1; myq += a2; myq += a3; myq += a4; myq += a5; myq += a6; myq += a7;
             }
+            for (; i < cn; ++i) myq += fr[4 * i];
         }
     }
     if (tid < 4) s_q[tid] = myq;
@@ -276,7 +288,13 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
         __syncthreads();
         if (tid == 0 && !dead) {          // sum_min: sequential double sum (bam2bcf.c:642)
             double sm = sh.sum_min;
-            for (int i = 0; i < cn; ++i) sm += s_min[i];
+            int i = 0;
+            for (; i + 8 <= cn; i += 8) {
+                const float m0 = s_min[i], m1 = s_min[i + 1], m2 = s_min[i + 2], m3 = s_min[i + 3];
+                const float m4 = s_min[i + 4], m5 = s_min[i + 5], m6 = s_min[i + 6], m7 = s_min[i + 7];
+                sm += m0; sm += m1; sm += m2; sm += m3; sm += m4; sm += m5; sm += m6; sm += m7;
+            }
+            for (; i < cn; ++i) sm += s_min[i];
             sh.sum_min = sm;
         }
     }
@@ -324,11 +342,17 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
         part = wave_sum_f64(part);
         if (lane == 0) atomicAdd(&sh.segb_sum, part);
     }
-    // ---- MWU x4 and VDB from the site histograms (bam2bcf.c:735-751), lanes 0..4 ----
+    // ---- MWU x4 and VDB from the site histograms (bam2bcf.c:735-751): staged in LDS, one lane per test ----
     if (tid < 6) sh.bias[tid] = 0.f;
+    int *s_h = reinterpret_cast<int*>(s_stage);
     __syncthreads();
     if (!dead) {
         const int *h = P.hist + (long)is * H_SIZE;
+        for (int i = tid; i < H_SIZE; i += WG) s_h[i] = h[i];
+    }
+    __syncthreads();
+    if (!dead) {
+        const int *h = s_h;
         if (tid == 0) sh.bias[0] = (P.fmt_flag & BCFGPU_INFO_VDB) ? dev_calc_vdb(h + H_ALT_POS) : 0.f;
         if (tid == 64) sh.bias[1] = (P.fmt_flag & BCFGPU_INFO_RPB) ? dev_calc_mwu_bias(h + H_REF_POS, h + H_ALT_POS, BCFGPU_NPOS, P.mw) : 0.f;
         if (tid == 128) sh.bias[2] = dev_calc_mwu_bias(h + H_REF_MQ, h + H_ALT_MQ, BCFGPU_NQUAL, P.mw);

@@ -69,6 +69,7 @@ struct McallParams {
     const int32_t *prior_an, *prior_ac;
     bcfgpu_call_out out;
     int out_n_gt_max;               // plane count of out.pl / out.gp
+    int ablate;                     // diagnostics only (BCFGPU_ABLATE)
 };
 
 size_t glfgen_lds_bytes(int cap, int hist_slots);
