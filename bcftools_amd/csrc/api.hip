@@ -337,6 +337,7 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     CombineParams k{};
     k.n_sites = tile->n_sites; k.n_smpl = S; k.is_indel = tile->is_indel; k.fmt_flag = c->cfg.fmt_flag;
     k.ref16 = tile->ref16; k.cr = c->cr; k.hist = c->d_hist; k.mw = c->d_mw; k.out = *out;
+    { const char *ab = getenv("BCFGPU_ABLATE"); k.ablate = ab ? atoi(ab) : 0; }
     launch_combine(k, c->stream);
     if (ev) hipEventRecord(ev[2], c->stream);
     HIPCHK(hipGetLastError());

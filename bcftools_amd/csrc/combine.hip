@@ -1,6 +1,6 @@
 // combine.hip -- bcf_call_combine (+ calc_SegBias, calc_mwu_bias x4, calc_vdb) for every site of a tile.
 //
-// Replaces bam2bcf.c:558-754, :281-342, :440-530.  One 256-thread workgroup per site.
+// Replaces bam2bcf.c:558-754, :281-342, :440-530.  One 64-lane workgroup (a single wavefront) per site.
 //
 // Order-sensitive pieces are replayed in the reference's order:
 //   * qsum[j] += (float)QS[j]/sum over samples (bam2bcf.c:569-575) decides the ALT allele
@@ -16,8 +16,8 @@
 
 namespace bcfgpu {
 
-#define WG 256
-#define CHUNK 2048        // samples staged in LDS per round
+#define WG 64             // one wavefront per site: thousands of sites in flight hide the sequential chains
+#define CHUNK 1024        // samples staged in LDS per round
 
 __device__ __forceinline__ int nt16_int_c(int c) { return (int)((0x4444444344424104ull >> (4 * (c & 15))) & 7); }
 __device__ __forceinline__ int tri_c(int j, int k) { return j <= k ? k * (k + 1) / 2 + j : j * (j + 1) / 2 + k; }
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
             s_frac[i] = f;             // adding +0 for empty samples leaves the running sum unchanged
         }
         __syncthreads();
-        if (tid < 4) {
+        if (tid < 4 && !(P.ablate & 8192)) {
             const float *fr = reinterpret_cast<const float*>(s_frac) + tid;
             int i = 0;
             for (; i + 8 <= cn; i += 8) {
@@ -228,8 +228,11 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
     const bool dead = (P.is_indel && nal == 1);     // bcf_call_combine returned -1 (bam2bcf.c:611)
 
     // ---- per-sample planes + integer totals ----
-    unsigned long long t_adf[5] = {0,0,0,0,0}, t_adr[5] = {0,0,0,0,0};
-    unsigned long long t_scr = 0, t_ori = 0, t_mq0 = 0, t_cnt[4] = {0,0,0,0}, t_sum[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+    // per-lane partial totals: u32 is ample for counts and first-order sums (a lane sees S/64 samples of <=255
+    // reads); the three kinds of squared sums get u64
+    uint32_t t_adf[5] = {0,0,0,0,0}, t_adr[5] = {0,0,0,0,0};
+    uint32_t t_scr = 0, t_ori = 0, t_mq0 = 0, t_cnt[4] = {0,0,0,0};
+    unsigned long long t_sum[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
     const size_t Ss = (size_t)S;
     for (int base = 0; base < S; base += CHUNK) {
         const int cn = min(CHUNK, S - base);
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
             const int s = base + i;
             const long cell = c0 + s;
             float mn = 0.f;
-            if (!dead) {
+            if (!dead && !(P.ablate & 256)) {
                 float pv[15];
                 mn = FLT_MAX;
                 #pragma unroll
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
             s_min[i] = mn;
             const uint32_t cnt4 = P.cr.cnt4[cell], adf = P.cr.adf[cell], adr = P.cr.adr[cell], misc = P.cr.misc[cell];
             const unsigned long long qs64 = P.cr.qs64[cell];
-            if (!dead) {
+            if (!dead && !(P.ablate & 512)) {
                 uint8_t *DP4 = P.out.dp4 + (size_t)is * 4 * Ss + s;
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) DP4[(size_t)j * Ss] = (uint8_t)((cnt4 >> (8 * j)) & 0xff);
@@ -283,10 +286,10 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
             #pragma unroll
             for (int j = 0; j < 4; ++j) t_cnt[j] += (cnt4 >> (8 * j)) & 0xff;
             #pragma unroll
-            for (int j = 0; j < 12; ++j) t_sum[j] += P.cr.sums[(size_t)j * ncells + cell];
+            for (int j = 0; j < 12; ++j) if (!(P.ablate & 1024)) t_sum[j] += P.cr.sums[(size_t)j * ncells + cell];
         }
         __syncthreads();
-        if (tid == 0 && !dead) {          // sum_min: sequential double sum (bam2bcf.c:642)
+        if (tid == 0 && !dead && !(P.ablate & 8192)) {          // sum_min: sequential double sum (bam2bcf.c:642)
             double sm = sh.sum_min;
             int i = 0;
             for (; i + 8 <= cn; i += 8) {
@@ -302,14 +305,14 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
     {
         unsigned long long v;
         #pragma unroll
-        for (int j = 0; j < 5; ++j) { v = wave_sum_u64(t_adf[j]); if (lane == 0 && v) atomicAdd(&sh.tot[j], v); }
+        for (int j = 0; j < 5; ++j) { v = wave_sum_u64((unsigned long long)t_adf[j]); if (lane == 0 && v) atomicAdd(&sh.tot[j], v); }
         #pragma unroll
-        for (int j = 0; j < 5; ++j) { v = wave_sum_u64(t_adr[j]); if (lane == 0 && v) atomicAdd(&sh.tot[5 + j], v); }
-        v = wave_sum_u64(t_scr); if (lane == 0 && v) atomicAdd(&sh.tot[10], v);
-        v = wave_sum_u64(t_ori); if (lane == 0 && v) atomicAdd(&sh.tot[11], v);
-        v = wave_sum_u64(t_mq0); if (lane == 0 && v) atomicAdd(&sh.tot[12], v);
+        for (int j = 0; j < 5; ++j) { v = wave_sum_u64((unsigned long long)t_adr[j]); if (lane == 0 && v) atomicAdd(&sh.tot[5 + j], v); }
+        v = wave_sum_u64((unsigned long long)t_scr); if (lane == 0 && v) atomicAdd(&sh.tot[10], v);
+        v = wave_sum_u64((unsigned long long)t_ori); if (lane == 0 && v) atomicAdd(&sh.tot[11], v);
+        v = wave_sum_u64((unsigned long long)t_mq0); if (lane == 0 && v) atomicAdd(&sh.tot[12], v);
         #pragma unroll
-        for (int j = 0; j < 4; ++j) { v = wave_sum_u64(t_cnt[j]); if (lane == 0 && v) atomicAdd(&sh.tot[13 + j], v); }
+        for (int j = 0; j < 4; ++j) { v = wave_sum_u64((unsigned long long)t_cnt[j]); if (lane == 0 && v) atomicAdd(&sh.tot[13 + j], v); }
         #pragma unroll
         for (int j = 0; j < 12; ++j) { v = wave_sum_u64(t_sum[j]); if (lane == 0 && v) atomicAdd(&sh.tot[17 + j], v); }
     }
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
     // ---- calc_SegBias (bam2bcf.c:494-530): tree-reduced sum of per-sample terms ----
     const double an0 = (double)sh.tot[13], an1 = (double)sh.tot[14], an2 = (double)sh.tot[15], an3 = (double)sh.tot[16];
     const int nr = (int)(an2 + an3);
-    if (nr && !dead) {
+    if (nr && !dead && !(P.ablate & 2048)) {
         const int avg_dp = (int)((an0 + an1 + nr) / S);
         double M = floor((double)nr / avg_dp + 0.5);
         if (M > S) M = S;
@@ -351,13 +354,13 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
         for (int i = tid; i < H_SIZE; i += WG) s_h[i] = h[i];
     }
     __syncthreads();
-    if (!dead) {
+    if (!dead && !(P.ablate & 4096)) {
         const int *h = s_h;
         if (tid == 0) sh.bias[0] = (P.fmt_flag & BCFGPU_INFO_VDB) ? dev_calc_vdb(h + H_ALT_POS) : 0.f;
-        if (tid == 64) sh.bias[1] = (P.fmt_flag & BCFGPU_INFO_RPB) ? dev_calc_mwu_bias(h + H_REF_POS, h + H_ALT_POS, BCFGPU_NPOS, P.mw) : 0.f;
-        if (tid == 128) sh.bias[2] = dev_calc_mwu_bias(h + H_REF_MQ, h + H_ALT_MQ, BCFGPU_NQUAL, P.mw);
-        if (tid == 192) sh.bias[3] = dev_calc_mwu_bias(h + H_REF_BQ, h + H_ALT_BQ, BCFGPU_NQUAL, P.mw);
-        if (tid == 1) sh.bias[4] = dev_calc_mwu_bias(h + H_FWD_MQS, h + H_REV_MQS, BCFGPU_NQUAL, P.mw);
+        if (tid == 1) sh.bias[1] = (P.fmt_flag & BCFGPU_INFO_RPB) ? dev_calc_mwu_bias(h + H_REF_POS, h + H_ALT_POS, BCFGPU_NPOS, P.mw) : 0.f;
+        if (tid == 2) sh.bias[2] = dev_calc_mwu_bias(h + H_REF_MQ, h + H_ALT_MQ, BCFGPU_NQUAL, P.mw);
+        if (tid == 3) sh.bias[3] = dev_calc_mwu_bias(h + H_REF_BQ, h + H_ALT_BQ, BCFGPU_NQUAL, P.mw);
+        if (tid == 4) sh.bias[4] = dev_calc_mwu_bias(h + H_FWD_MQS, h + H_REV_MQS, BCFGPU_NQUAL, P.mw);
     }
     __syncthreads();
 

@@ -48,6 +48,7 @@ struct CombineParams {
     CallretPlanes cr;
     const int *hist;
     const double *mw;               // [6][6][50]
+    int ablate;                     // diagnostics only (BCFGPU_ABLATE)
     bcfgpu_mplp_out out;
 };
 

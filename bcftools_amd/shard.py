@@ -1,0 +1,31 @@
+"""Multi-GPU partitioning of the hot path: sites are independent, so every rank owns a
+contiguous range of sites (a genomic region shard) and no collective touches the data path.  The single
+exchange step is the ordered gather of the fixed-stride per-site records to rank 0 -- shards are contiguous
+and ranks ascending, so concatenating in rank order restores site (= VCF) order."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_sites, rank, world):
+    """[begin, end) of the sites owned by `rank`: contiguous, sizes differ by at most one."""
+    base, rem = divmod(n_sites, world)
+    beg = rank * base + min(rank, rem)
+    return beg, beg + base + (1 if rank < rem else 0)
+
+
+def gather_records(local, dst=0):
+    """Gather byte tensors of per-site records (possibly different lengths) to `dst`, in rank order.
+    Returns the concatenated tensor on `dst`, None elsewhere.  Works on any backend (gloo on CPU, RCCL on GPUs)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([local.numel()], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    pad = torch.zeros(mx, dtype=local.dtype, device=local.device)
+    pad[: local.numel()] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)])

@@ -52,7 +52,7 @@ def main():
     a = parse()
     import torch
     import torch.distributed as dist
-    from bcftools_amd import abi, synth, engine
+    from bcftools_amd import abi, synth, engine, shard
     from bcftools_amd.lib import check
 
     rank = int(os.environ.get("RANK", "0"))
@@ -86,14 +86,13 @@ def main():
     cgt = torch.zeros(T * 2 * S, dtype=torch.int8, device=dev)
     cpl = torch.zeros(T * abi.MAX_PL * S, dtype=torch.int32, device=dev)
     co.site, co.gt, co.pl, co.gq, co.gp = csite.data_ptr(), cgt.data_ptr(), cpl.data_ptr(), None, None
-    gathered = [torch.empty_like(csite) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def step():
         check(L.bcfgpu_pipeline(ctx.h, C.byref(dt), None, None, C.byref(mo), C.byref(co)))
         if world > 1:
             # ordered gather of the per-site call records (the shards are contiguous regions)
             check(L.bcfgpu_sync(ctx.h))
-            dist.gather(csite, gathered, dst=0)
+            shard.gather_records(csite, dst=0)
 
     def fence():
         check(L.bcfgpu_sync(ctx.h))
