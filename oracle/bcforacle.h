@@ -59,6 +59,22 @@ int orc_mpileup(const bcfgpu_cfg *cfg, const bcfgpu_tile *tile, const bcfgpu_mpl
 /* call stage over a tile: mcall() per site (mcall.c:1430-1684) */
 int orc_mcall(const bcfgpu_cfg *cfg, const bcfgpu_call_in *in, const bcfgpu_call_out *out);
 
+/* htslib probaln.c / realn.c (see probaln.c) */
+int orc_probaln_glocal(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
+                       double d, double e, int bw, int *state, uint8_t *q);
+int orc_sam_prob_realn(int pos, int l_qseq, const uint8_t *seq4, uint8_t *qual, const uint32_t *cigar, int n_cigar,
+                       const char *ref, int ref_len, int flag, uint8_t *zq);
+
+/* bcf_call_gap_prep (bam2bcf_indel.c:99-470) over a flat read model, see indel_oracle.c */
+int orc_gap_prep(int n, const int *smpl_off, const int *p_read, const int *p_qpos, const int *p_indel,
+                 const int *r_pos, const int *r_lq, const int *r_flag, const int *r_ncig, const int *r_cig_off,
+                 const uint32_t *cig, const int *r_seq_off, const uint8_t *seq16, const uint8_t *qualp,
+                 const uint8_t *zqp, const uint8_t *r_has_zq,
+                 int pos, const char *ref, int openQ, int extQ, int tandemQ, int min_support, double min_frac,
+                 int per_sample_flt,
+                 uint32_t *p_aux, int *indel_types, char *inscns_out, int inscns_cap, int *maxins_out, int *indelreg_out,
+                 int *max_support_out, float *max_frac_out);
+
 /* FORMAT/SP from DP4 (bam2bcf.c:867-885) */
 int orc_format_sp(int fwd_ref, int rev_ref, int fwd_alt, int rev_alt);
 

@@ -1,0 +1,245 @@
+"""Test-side driver of the mpileup stage on the reference's SAM fixtures with the *default* read preprocessing:
+BAQ (sam_prob_realn, mpileup.c:234) and the mate-overlap quality tweak (bam_mplp_init_overlaps, mpileup.c:640),
+then per-site glfgen/combine (SNP record) and bcf_call_gap_prep + glfgen/combine (indel record), mpileup.c:320-367.
+
+BAQ, probaln and gap_prep run in the C oracle; the overlap tweak and the pileup walk are restated here (htslib
+sam.c: overlap_push / tweak_overlap_quality).  An *engine* (oracle or HIP) turns tiles into results.
+"""
+import ctypes as C
+import numpy as np
+
+from bcftools_amd import abi, host
+from . import sam as S, orc
+
+
+def _realn_lib():
+    L = orc.lib()
+    L.orc_sam_prob_realn.restype = C.c_int
+    L.orc_sam_prob_realn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int,
+                                     C.c_int, C.c_void_p]
+    L.orc_gap_prep.restype = C.c_int
+    return L
+
+
+NT4 = {"A": 0, "C": 1, "G": 2, "T": 3, "a": 0, "c": 1, "g": 2, "t": 3}
+
+
+def apply_baq(read, refseq, flag=3):
+    """sam_prob_realn(b, ref, ref_len, 3): qualities rewritten in place, ZQ kept on the read."""
+    L = _realn_lib()
+    if read.flag & S.BAM_FUNMAP or read.l_qseq == 0:
+        return
+    seq4 = np.array([NT4.get(c, 4) for c in read.seq], dtype=np.uint8)
+    qual = np.ascontiguousarray(read.qual.astype(np.uint8))
+    zq = np.zeros(read.l_qseq, dtype=np.uint8)
+    rc = L.orc_sam_prob_realn(read.pos, read.l_qseq, seq4.ctypes.data, qual.ctypes.data, read.bamcigar.ctypes.data,
+                              len(read.bamcigar), refseq.encode(), len(refseq), flag, zq.ctypes.data)
+    if rc == 0:
+        read.qual = qual.astype(np.int32)
+        read.zq = zq
+    return rc
+
+
+def _iref2iseq(read):
+    """reference position -> query index for M/=/X columns of a read."""
+    m = {}
+    x, y = read.pos, 0
+    for n, op in read.cigar:
+        if op in "M=X":
+            for j in range(n):
+                m[x + j] = y + j
+            x += n
+            y += n
+        elif op in "DN":
+            x += n
+        elif op in "IS":
+            y += n
+    return m
+
+
+def tweak_overlap_quality(a, b):
+    """htslib sam.c tweak_overlap_quality(a,b): a arrived first."""
+    ma, mb = _iref2iseq(a), _iref2iseq(b)
+    for pos in sorted(set(ma) & set(mb)):
+        if pos < b.pos:
+            continue
+        ia, ib = ma[pos], mb[pos]
+        if a.seq[ia].upper() == b.seq[ib].upper():
+            q = int(a.qual[ia]) + int(b.qual[ib])
+            a.qual[ia] = 200 if q > 200 else q
+            b.qual[ib] = 0
+        else:
+            if a.qual[ia] >= b.qual[ib]:
+                a.qual[ia] = int(0.8 * a.qual[ia])
+                b.qual[ib] = 0
+            else:
+                b.qual[ib] = int(0.8 * b.qual[ib])
+                a.qual[ia] = 0
+
+
+def apply_overlaps(reads):
+    """overlap_push over the reads of one file in file order (all reads stay buffered long enough in these fixtures)."""
+    pending = {}
+    for r in reads:
+        f = r.flag
+        if (f & 8) or not (f & S.BAM_FPROPER_PAIR):          # BAM_FMUNMAP
+            continue
+        if r.rnext not in ("=", r.rname) or (abs(r.isize) >= 2 * r.l_qseq and r.mpos >= r.end):
+            continue
+        if r.qname not in pending:
+            if r.mpos >= r.pos or ((f & S.BAM_FPAIRED) and r.mpos == -1):
+                pending[r.qname] = r
+        else:
+            a = pending.pop(r.qname)
+            # the first mate must still be in the pileup buffer: it is, unless it ended before this one starts
+            if a.end > r.pos:
+                tweak_overlap_quality(a, r)
+
+
+class Prepared:
+    """SAM files after mplp_func filtering + BAQ + overlap tweak, ready for pileup."""
+
+    def __init__(self, sams, ref, contig, opts, baq=True, overlaps=True):
+        self.refseq = ref[contig]
+        self.contig = contig
+        self.opts = opts
+        self.samples = []
+        for s in sams:
+            for sm in s.samples:
+                if sm not in self.samples:
+                    self.samples.append(sm)
+        self.files = []
+        for s in sams:
+            rl = []
+            for r in s.reads:
+                if r.rname != contig or not S.keep_read(r, opts):
+                    continue
+                r.zq = None
+                if baq:
+                    apply_baq(r, self.refseq)
+                sm = s.rg2sm.get(r.rg, s.samples[0] if s.samples else None)
+                rl.append((r, self.samples.index(sm)))
+            if overlaps:
+                apply_overlaps([r for r, _ in rl])
+            self.files.append(rl)
+
+
+def column(prep, pos):
+    per = [[] for _ in prep.samples]
+    for rl in prep.files:
+        for r, si in rl:
+            w = S.walk(r, pos)
+            if w is not None:
+                per[si].append((r,) + w)
+    return per
+
+
+def snp_tile(prep, positions):
+    """Pack SNP columns (like sam.build_tile but on prepared reads); returns (HostTile, columns)."""
+    o = prep.opts
+    want_epos = bool(o.fmt_flag & (abi.INFO_RPB | abi.INFO_VDB))
+    ref16, off, rd, epos, cols, kept = [], [0], [], [], [], []
+    for pos in positions:
+        per = column(prep, pos)
+        if sum(len(x) for x in per) == 0:
+            continue
+        kept.append(pos)
+        cols.append(per)
+        rb = prep.refseq[pos] if pos < len(prep.refseq) else "N"
+        ref16.append(S.nt16(rb))
+        for lst in per:
+            for (r, qpos, is_del, is_refskip, indel) in lst:
+                w, e = S.pack_read(S.nt16(r.seq[qpos]) if qpos < r.l_qseq else 15,
+                                   int(r.qual[qpos]) if qpos < r.l_qseq else 0, r.mapq,
+                                   bool(r.flag & S.BAM_FREVERSE), any(op == "S" for _, op in r.cigar),
+                                   is_del, is_refskip, qpos, r.l_qseq, r.cigar, want_epos)
+                rd.append(w)
+                epos.append(e)
+            off.append(len(rd))
+    tile = host.HostTile(len(prep.samples), np.array(ref16, dtype=np.int8), np.array(off, dtype=np.uint32),
+                         np.array(rd, dtype=np.uint32), np.array(epos, dtype=np.uint8))
+    return tile, cols, kept
+
+
+def gap_prep(prep, per, pos, openQ=40, extQ=20, tandemQ=100, min_support=1, min_frac=0.002, per_sample_flt=0):
+    """bcf_call_gap_prep through the oracle.  Returns None (ret<0) or dict(aux per sample list, indel_types, inscns, ...)."""
+    L = _realn_lib()
+    reads, ridx = [], {}
+    smpl_off, p_read, p_qpos, p_indel = [0], [], [], []
+    for lst in per:
+        for (r, qpos, is_del, is_refskip, indel) in lst:
+            if id(r) not in ridx:
+                ridx[id(r)] = len(reads)
+                reads.append(r)
+            p_read.append(ridx[id(r)])
+            p_qpos.append(qpos)
+            p_indel.append(indel)
+        smpl_off.append(len(p_read))
+    if not p_read:
+        return None
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    r_pos = i32([r.pos for r in reads]); r_lq = i32([r.l_qseq for r in reads]); r_flag = i32([r.flag for r in reads])
+    r_ncig = i32([len(r.bamcigar) for r in reads])
+    r_cig_off = i32(np.concatenate([[0], np.cumsum(r_ncig)[:-1]]))
+    cig = np.ascontiguousarray(np.concatenate([r.bamcigar for r in reads]), dtype=np.uint32)
+    r_seq_off = i32(np.concatenate([[0], np.cumsum(r_lq)[:-1]]))
+    seq16 = np.ascontiguousarray(np.concatenate([[S.nt16(c) for c in r.seq] for r in reads]), dtype=np.uint8)
+    qual = np.ascontiguousarray(np.concatenate([r.qual for r in reads]).astype(np.uint8))
+    has_zq = np.ascontiguousarray([1 if r.zq is not None else 0 for r in reads], dtype=np.uint8)
+    zq = np.ascontiguousarray(np.concatenate([r.zq if r.zq is not None else np.zeros(r.l_qseq, dtype=np.uint8) for r in reads]), dtype=np.uint8)
+    smpl_off, p_read, p_qpos, p_indel = i32(smpl_off), i32(p_read), i32(p_qpos), i32(p_indel)
+    aux = np.zeros(len(p_read), dtype=np.uint32)
+    types = np.zeros(4, dtype=np.int32)
+    inscns = np.zeros(4 * 256, dtype=np.int8)
+    maxins, indelreg, msup = C.c_int(), C.c_int(), C.c_int()
+    mfrac = C.c_float()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.orc_gap_prep.argtypes = [C.c_int] + [C.c_void_p] * 15 + [C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                               C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.orc_gap_prep(len(per), p(smpl_off), p(p_read), p(p_qpos), p(p_indel), p(r_pos), p(r_lq), p(r_flag), p(r_ncig),
+                        p(r_cig_off), p(cig), p(r_seq_off), p(seq16), p(qual), p(zq), p(has_zq),
+                        pos, prep.refseq.encode(), openQ, extQ, tandemQ, min_support, min_frac, per_sample_flt,
+                        p(aux), p(types), p(inscns), len(inscns), C.byref(maxins), C.byref(indelreg), C.byref(msup), C.byref(mfrac))
+    if rc < 0:
+        return None
+    return dict(aux=aux, smpl_off=smpl_off, indel_types=types.tolist(), inscns=inscns, maxins=maxins.value,
+                indelreg=indelreg.value, max_support=msup.value, max_frac=float(mfrac.value))
+
+
+def indel_tile(prep, per, g):
+    """The indel pass at one position: same reads, ref_base=-1, aux from gap_prep."""
+    o = prep.opts
+    want_epos = bool(o.fmt_flag & (abi.INFO_RPB | abi.INFO_VDB))
+    off, rd, epos = [0], [], []
+    for lst in per:
+        for (r, qpos, is_del, is_refskip, indel) in lst:
+            w, e = S.pack_read(S.nt16(r.seq[qpos]) if qpos < r.l_qseq else 15, int(r.qual[qpos]) if qpos < r.l_qseq else 0,
+                               r.mapq, bool(r.flag & S.BAM_FREVERSE), any(op == "S" for _, op in r.cigar),
+                               is_del, is_refskip, qpos, r.l_qseq, r.cigar, want_epos)
+            rd.append(w)
+            epos.append(e)
+        off.append(len(rd))
+    return host.HostTile(len(prep.samples), np.array([0], dtype=np.int8), np.array(off, dtype=np.uint32),
+                         np.array(rd, dtype=np.uint32), np.array(epos, dtype=np.uint8), aux=g["aux"], is_indel=1)
+
+
+def indel_alleles(refseq, pos, site, g):
+    """REF/ALT strings of an indel record, bam2bcf.c:767-790."""
+    ref = refseq
+    indelreg = g["indelreg"]
+    REF = ref[pos] + ref[pos + 1: pos + 1 + indelreg]
+    alts = []
+    for i in range(1, 4):
+        ai = int(site["a"][i])
+        if ai < 0:
+            break
+        t = g["indel_types"][ai]
+        s = ref[pos]
+        if t < 0:
+            s += ref[pos + 1 - t: pos + 1 + indelreg]
+        else:
+            ins = g["inscns"][ai * g["maxins"]: ai * g["maxins"] + t]
+            s += "".join("ACGTN"[int(c)] for c in ins) + ref[pos + 1: pos + 1 + indelreg]
+        alts.append(s)
+    return [REF] + alts

@@ -22,12 +22,15 @@ def nt16(ch):
 
 
 class Read:
-    __slots__ = ("qname", "flag", "rname", "pos", "mapq", "cigar", "seq", "qual", "rg", "end", "l_qseq", "bamcigar")
+    __slots__ = ("qname", "flag", "rname", "pos", "mapq", "cigar", "seq", "qual", "rg", "end", "l_qseq", "bamcigar",
+                 "rnext", "mpos", "isize", "zq")
 
     def __init__(self, f):
         self.qname, self.flag, self.rname = f[0], int(f[1]), f[2]
         self.pos, self.mapq = int(f[3]) - 1, int(f[4])
         self.cigar = [(int(n), op) for n, op in re.findall(r"(\d+)([MIDNSHP=X])", f[5])]
+        self.rnext, self.mpos, self.isize = f[6], int(f[7]) - 1, int(f[8])
+        self.zq = None
         self.seq = f[9]
         self.qual = np.frombuffer(f[10].encode(), dtype=np.uint8).astype(np.int32) - 33 if f[10] != "*" \
             else np.full(len(f[9]), 255, dtype=np.int32)

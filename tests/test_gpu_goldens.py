@@ -22,3 +22,24 @@ def test_hip_reproduces_call_golden(golden_dir, idx):
         with engine.Context(cfg) as ctx:
             return ctx.mcall(cin)
     run_case(os.path.join(golden_dir, "call"), idx, hip_engine)
+
+
+from tests.test_oracle_golden_baq import CASES as BAQ_CASES, run_case as run_baq_case
+
+
+@pytest.mark.parametrize("idx", range(len(BAQ_CASES)))
+def test_hip_reproduces_default_mpileup_golden(golden_dir, idx):
+    """SNP and indel records of the BAQ-on goldens through glfgen_kernel/combine_kernel (gap_prep on the host side)."""
+    ctxs = {}
+
+    def hip_engine(cfg, tile):
+        key = tile.n_smpl
+        if key not in ctxs:
+            c = abi.default_cfg(tile.n_smpl, max_sites=1024, max_reads=1 << 20, fmt_flag=cfg.fmt_flag)
+            ctxs[key] = engine.Context(c)
+        return ctxs[key].mpileup(tile)
+    try:
+        run_baq_case(golden_dir, BAQ_CASES[idx], hip_engine)
+    finally:
+        for c in ctxs.values():
+            c.close()

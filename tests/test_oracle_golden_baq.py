@@ -1,0 +1,62 @@
+"""Pins the oracle against the reference's mpileup goldens produced with the DEFAULT read preprocessing
+(test.pl:640-644,658): BAQ + mate-overlap tweak upstream, then glfgen/errmod/combine for the SNP record and
+bcf_call_gap_prep (probaln realignment) + glfgen/combine for the indel record.  Every record field that
+bcf_call2bcf derives from bcf_call_t is compared: alleles, DP, I16, QS, VDB, SGB, RPB, MQB, MQSB, BQB, MQ0F,
+IDV/IMF, PL, DP, DV, DP4, SP (Fisher exact), AD/ADF/ADR/DPR.
+
+This is what pins the restated htslib pieces (probaln_glocal fwd/bwd, sam_prob_realn, tweak_overlap_quality,
+kt_fisher_exact, kf_erfc) that test_oracle_golden_mpileup.py cannot reach."""
+import os
+import pytest
+
+from bcftools_amd import abi as A
+from tests.helpers import sam, orc, vcf, mplpdrv as M, mplpcmp as K
+
+BASE = A.INFO_VDB | A.INFO_RPB
+TRIO = ["mpileup.1.sam", "mpileup.2.sam", "mpileup.3.sam"]
+CASES = [
+    (TRIO, "mpileup.ref.fa", "17", 99, 149, "mpileup.1.out", BASE, 51, 0),
+    (TRIO, "mpileup.ref.fa", "17", 99, 599, "mpileup.2.out", BASE | A.FMT_DP | A.FMT_DV, 501, 1),
+    (TRIO, "mpileup.ref.fa", "17", 99, 599, "mpileup.4.out",
+     BASE | A.FMT_DP | A.FMT_DPR | A.FMT_DV | A.FMT_DP4 | A.INFO_DPR | A.FMT_SP, 501, 1),
+    (TRIO, "mpileup.ref.fa", "17", 99, 599, "mpileup.5.out",
+     BASE | A.FMT_DP | A.FMT_AD | A.FMT_ADF | A.FMT_ADR | A.FMT_SP | A.INFO_AD | A.INFO_ADF | A.INFO_ADR, 501, 1),
+    (["indel-AD.1.sam"], "indel-AD.1.fa", "000000F", 0, 10000, "indel-AD.1.out", BASE | A.FMT_AD, 297, 6),
+]
+
+
+def run_case(golden_dir, case, engine):
+    samfiles, reffa, contig, beg, end, goldf, fmt_flag, n_snp, n_indel = case
+    G = os.path.join(golden_dir, "mpileup")
+    sams = [sam.Sam(os.path.join(G, f)) for f in samfiles]
+    ref = sam.read_fasta(os.path.join(G, reffa))
+    prep = M.Prepared(sams, ref, contig, sam.MplpOpts(fmt_flag=fmt_flag))
+    tile, cols, kept = M.snp_tile(prep, range(beg, end + 1))
+    cfg = A.default_cfg(len(prep.samples), fmt_flag=fmt_flag)
+    res = engine(cfg, tile)
+    gold = vcf.Vcf(os.path.join(G, goldf))
+    snp = {r.pos: r for r in gold.recs if "INDEL" not in r.info}
+    ind = {r.pos: r for r in gold.recs if "INDEL" in r.info}
+    assert (len(snp), len(ind)) == (n_snp, n_indel)
+    assert [p + 1 for p in kept] == sorted(snp)
+    seen_indel = 0
+    for i, p in enumerate(kept):
+        K.check_record(snp[p + 1], res.site[i], res, i, K.snp_alleles(res.site[i]), fmt_flag)
+        # indel record at the same position (mpileup.c:354-365), max_indel_depth 250 per sample
+        g = M.gap_prep(prep, cols[i], p) if sum(len(x) for x in cols[i]) < 250 * len(prep.samples) else None
+        if g is None:
+            assert (p + 1) not in ind
+            continue
+        ir = engine(cfg, M.indel_tile(prep, cols[i], g))
+        if ir.site[0]["ret"] < 0:
+            assert (p + 1) not in ind
+            continue
+        assert (p + 1) in ind, "unexpected indel record at %d" % (p + 1)
+        K.check_record(ind[p + 1], ir.site[0], ir, 0, M.indel_alleles(prep.refseq, p, ir.site[0], g), fmt_flag, extra=g)
+        seen_indel += 1
+    assert seen_indel == n_indel
+
+
+@pytest.mark.parametrize("idx", range(len(CASES)))
+def test_oracle_reproduces_default_mpileup_golden(golden_dir, idx):
+    run_case(golden_dir, CASES[idx], orc.mpileup)
