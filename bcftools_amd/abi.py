@@ -88,6 +88,22 @@ class CallOut(C.Structure):
     ]
 
 
+class Reads(C.Structure):
+    _fields_ = [("n_reads", C.c_int32)] + [(k, C.c_void_p) for k in
+                ("r_pos", "r_lq", "r_flag", "r_ncig", "r_cig_off", "r_seq_off", "cig", "seq16", "qual", "zq", "r_has_zq")]
+
+
+class IndelIn(C.Structure):
+    _fields_ = [("n_sites", C.c_int32), ("n_smpl", C.c_int32), ("pos", C.c_void_p), ("smpl_off", C.c_void_p),
+                ("p_read", C.c_void_p), ("p_qpos", C.c_void_p), ("p_indel", C.c_void_p), ("ref", C.c_char_p),
+                ("openQ", C.c_int32), ("extQ", C.c_int32), ("tandemQ", C.c_int32), ("min_support", C.c_int32),
+                ("per_sample_flt", C.c_int32), ("min_frac", C.c_double)]
+
+
+class IndelOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("ret", "p_aux", "indel_types", "inscns", "maxins", "indelreg", "max_support", "max_frac")]
+
+
 class Timing(C.Structure):
     _fields_ = [("glfgen_ms", C.c_float), ("combine_ms", C.c_float),
                 ("mcall_ms", C.c_float), ("total_ms", C.c_float)]
@@ -110,6 +126,7 @@ PROTOTYPES = {
                                                 C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]),
     "bcfgpu_mpileup": (C.c_int, [C.c_void_p, C.POINTER(Tile), C.POINTER(MplpOut)]),
     "bcfgpu_mcall": (C.c_int, [C.c_void_p, C.POINTER(CallIn), C.POINTER(CallOut)]),
+    "bcfgpu_gap_prep": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.POINTER(IndelIn), C.POINTER(IndelOut), C.c_int]),
     "bcfgpu_pipeline": (C.c_int, [C.c_void_p, C.POINTER(Tile), C.c_void_p, C.c_void_p,
                                   C.POINTER(MplpOut), C.POINTER(CallOut)]),
     "bcfgpu_mplp_out_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),

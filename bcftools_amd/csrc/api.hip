@@ -23,6 +23,7 @@ static int set_err(int code, const char *what, hipError_t e = hipSuccess)
     g_err = buf;
     return code;
 }
+int bcfgpu_set_error(int code, const char *what) { return set_err(code, what); }
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_err(BCFGPU_E_HIP, #call, e_); } while (0)
 
 struct bcfgpu_ctx {
@@ -30,6 +31,7 @@ struct bcfgpu_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     // constant tables in HBM
     double *d_fk = nullptr, *d_beta = nullptr, *d_lhet = nullptr, *d_pl2p = nullptr, *d_mw = nullptr;
+    float *d_q2p = nullptr;         // 10^(-q/10) as float (htslib g_qual2prob), for the realignment kernel
     double call_theta_log = 0;
     // workspaces sized by cfg.max_sites / cfg.max_reads
     int *d_hist = nullptr, *d_err = nullptr;
@@ -101,7 +103,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
     int rc = 0;
     if ((rc = dev_alloc(c, (void**)&c->d_fk, fk.size() * 8)) || (rc = dev_alloc(c, (void**)&c->d_beta, beta.size() * 8 + 64)) ||
         (rc = dev_alloc(c, (void**)&c->d_lhet, lhet.size() * 8)) || (rc = dev_alloc(c, (void**)&c->d_pl2p, sizeof pl2p)) ||
-        (rc = dev_alloc(c, (void**)&c->d_mw, sizeof mw)) || (rc = dev_alloc(c, (void**)&c->d_err, sizeof(int)))) {
+        (rc = dev_alloc(c, (void**)&c->d_mw, sizeof mw)) || (rc = dev_alloc(c, (void**)&c->d_q2p, 256 * sizeof(float))) || (rc = dev_alloc(c, (void**)&c->d_err, sizeof(int)))) {
         bcfgpu_destroy(c); return rc;
     }
     hipMemcpy(c->d_fk, fk.data(), fk.size() * 8, hipMemcpyHostToDevice);
@@ -109,6 +111,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
     hipMemcpy(c->d_lhet, lhet.data(), lhet.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(c->d_pl2p, pl2p, sizeof pl2p, hipMemcpyHostToDevice);
     hipMemcpy(c->d_mw, mw, sizeof mw, hipMemcpyHostToDevice);
+    { float q2p[256]; for (int i = 0; i < 256; ++i) q2p[i] = (float)std::pow(10., -i / 10.); hipMemcpy(c->d_q2p, q2p, sizeof q2p, hipMemcpyHostToDevice); }
     hipMemset(c->d_err, 0, sizeof(int));
 
     // the prior: theta <- log(theta * sum_{i<n} 1/i), n = ploidy_max * nsamples (mcall.c:396-416, vcfcall.c:654-655)
@@ -423,6 +426,52 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
     else if (c->timing == 2) { hipEventRecord(c->pool[c->pool.size() - 1], c->stream); c->pool_call.back() = 1; }
     HIPCHK(hipGetLastError());
     finish_timing(c, true);
+    return 0;
+}
+
+// device half of bcfgpu_gap_prep (indel_host.hip): upload the job pools, run probaln_kernel, download the scores
+int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnJob> &jobs, const std::vector<uint8_t> &ref2,
+                                const std::vector<uint8_t> &query, const std::vector<uint8_t> &qq, int max_bw,
+                                std::vector<int32_t> &score1, std::vector<int32_t> &score2)
+{
+    hipSetDevice(c->cfg.device);
+    const size_t nj = jobs.size();
+    ProbalnParams p{};
+    p.ncell = 3 * (2 * max_bw + 1) + 6;
+    // jobs are run in chunks so that the two rolling rows of every job in flight fit a ~1 GiB scratch
+    size_t chunk = ((size_t)1 << 30) / (2 * (size_t)p.ncell * sizeof(double));
+    chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
+    if (chunk > nj) chunk = (nj + 63) & ~(size_t)63;
+    p.scratch_stride = chunk;
+    void *d_jobs = nullptr, *d_ref2 = nullptr, *d_q = nullptr, *d_qq = nullptr, *d_scr = nullptr, *d_s1 = nullptr, *d_s2 = nullptr;
+    auto cleanup = [&]() { for (void *x : {d_jobs, d_ref2, d_q, d_qq, d_scr, d_s1, d_s2}) if (x) hipFree(x); };
+    #define GP_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return set_err(BCFGPU_E_HIP, #call, e_); } } while (0)
+    GP_CHK(hipMalloc(&d_jobs, nj * sizeof(ProbalnJob)));
+    GP_CHK(hipMalloc(&d_ref2, ref2.size() + 16));
+    GP_CHK(hipMalloc(&d_q, query.size() + 16));
+    GP_CHK(hipMalloc(&d_qq, qq.size() + 16));
+    GP_CHK(hipMalloc(&d_scr, 2 * (size_t)p.ncell * p.scratch_stride * sizeof(double)));
+    GP_CHK(hipMalloc(&d_s1, nj * 4));
+    GP_CHK(hipMalloc(&d_s2, nj * 4));
+    GP_CHK(hipMemcpyAsync(d_jobs, jobs.data(), nj * sizeof(ProbalnJob), hipMemcpyHostToDevice, c->stream));
+    GP_CHK(hipMemcpyAsync(d_ref2, ref2.data(), ref2.size(), hipMemcpyHostToDevice, c->stream));
+    GP_CHK(hipMemcpyAsync(d_q, query.data(), query.size(), hipMemcpyHostToDevice, c->stream));
+    GP_CHK(hipMemcpyAsync(d_qq, qq.data(), qq.size(), hipMemcpyHostToDevice, c->stream));
+    p.ref2 = (const uint8_t*)d_ref2; p.query = (const uint8_t*)d_q; p.qq = (const uint8_t*)d_qq;
+    p.q2p = c->d_q2p; p.scratch = (double*)d_scr;
+    for (size_t j0 = 0; j0 < nj; j0 += chunk) {
+        p.n_jobs = (int)(nj - j0 < chunk ? nj - j0 : chunk);
+        p.jobs = (const ProbalnJob*)d_jobs + j0;
+        p.score1 = (int32_t*)d_s1 + j0; p.score2 = (int32_t*)d_s2 + j0;
+        launch_probaln(p, c->stream);
+    }
+    GP_CHK(hipGetLastError());
+    score1.resize(nj); score2.resize(nj);
+    GP_CHK(hipMemcpyAsync(score1.data(), d_s1, nj * 4, hipMemcpyDeviceToHost, c->stream));
+    GP_CHK(hipMemcpyAsync(score2.data(), d_s2, nj * 4, hipMemcpyDeviceToHost, c->stream));
+    GP_CHK(hipStreamSynchronize(c->stream));
+    #undef GP_CHK
+    cleanup();
     return 0;
 }
 

@@ -73,6 +73,19 @@ struct McallParams {
     int ablate;                     // diagnostics only (BCFGPU_ABLATE)
 };
 
+// one realignment job of bcf_call_gap_prep: probaln_glocal(ref2+ref_off, l_ref, query+query_off, l_query, qq+query_off, {.., bw})
+struct ProbalnJob { uint32_t ref_off, query_off; int32_t l_ref, l_query, bw; };
+struct ProbalnParams {
+    int n_jobs, ncell;              // ncell: scratch cells per row (>= 3*(2*bw+1)+6 for the widest band)
+    size_t scratch_stride;          // jobs rounded up; scratch is [2][ncell][stride] doubles
+    const ProbalnJob *jobs;
+    const uint8_t *ref2, *query, *qq;
+    const float *q2p;               // 10^(-q/10) as float, q = 0..255 (htslib g_qual2prob)
+    double *scratch;
+    int32_t *score1, *score2;       // sc<<8 | norm, bam2bcf_indel.c:348-356
+};
+void launch_probaln(const ProbalnParams &p, hipStream_t s);
+
 size_t glfgen_lds_bytes(int cap, int hist_slots);
 void launch_glfgen(const GlfgenParams &p, hipStream_t s);
 void launch_combine(const CombineParams &p, hipStream_t s);

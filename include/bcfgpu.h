@@ -13,6 +13,7 @@
  *    bcfgpu_mpileup                      <- bcf_callaux_clean + bcf_call_glfgen x n_smpl + bcf_call_combine
  *                                           for every site of a tile          bam2bcf.h:137-138,142
  *                                           (call sites mpileup.c:343-347 and :357-360)
+ *    bcfgpu_gap_prep                     <- bcf_call_gap_prep                  bam2bcf.h:141 (bam2bcf_indel.c:99-470)
  *    bcfgpu_mcall                        <- mcall()                            call.h:131 (mcall.c:1430-1684)
  *                                           incl. the per-record prologue of vcfcall.c:1096-1115
  *    bcfgpu_pipeline                     <- the `mpileup -Ou | call -m` pipe with PL/QS/I16 kept in HBM
@@ -256,6 +257,43 @@ int  bcfgpu_mcall(bcfgpu_ctx *ctx, const bcfgpu_call_in *in, const bcfgpu_call_o
  * mpileup-stage results (input of the call stage), `cout` the calls. */
 int  bcfgpu_pipeline(bcfgpu_ctx *ctx, const bcfgpu_tile *tile, const uint8_t *ploidy, const int32_t *grp,
                      const bcfgpu_mplp_out *mout, const bcfgpu_call_out *cout);
+
+/* ---- indel candidates: bcf_call_gap_prep (bam2bcf.h:141, bam2bcf_indel.c:99-470) for a batch of positions --------
+ * Candidate typing, the per-sample consensus and the insertion consensus are small irregular host work and run on
+ * the CPU inside this call; the realignment of every read against every candidate type (probaln_glocal, "the
+ * bottleneck", bam2bcf_indel.c:335) runs on the device for the whole batch; indelQ/seqQ and the choice of the <=4
+ * output types are finished on the host.  All pointers here are HOST pointers.
+ * Reads are a flat pool: r_* arrays indexed by read, cig/seq16/qual/zq pools indexed through r_cig_off / r_seq_off
+ * (seq16: one 4-bit nt16 code per byte; qual: the qualities the pileup sees; zq: "ZQ" tag bytes, r_has_zq flags).
+ * Pileup entries of (site k, sample s): smpl_off[k*n_smpl+s] .. smpl_off[k*n_smpl+s+1]-1 into p_read/p_qpos/p_indel. */
+typedef struct {
+    int32_t n_reads;
+    const int32_t *r_pos, *r_lq, *r_flag, *r_ncig, *r_cig_off, *r_seq_off;
+    const uint32_t *cig;
+    const uint8_t *seq16, *qual, *zq, *r_has_zq;
+} bcfgpu_reads;
+
+typedef struct {
+    int32_t n_sites, n_smpl;
+    const int32_t *pos;          /* [n_sites] 0-based position of the base before the indel */
+    const int32_t *smpl_off;     /* [n_sites*n_smpl+1] */
+    const int32_t *p_read, *p_qpos, *p_indel;
+    const char *ref;             /* NUL-terminated reference of the contig */
+    int32_t openQ, extQ, tandemQ, min_support, per_sample_flt;   /* bcf_callaux_t, mpileup -o -e -h -m -p */
+    double min_frac;             /* mpileup -F */
+} bcfgpu_indel_in;
+
+typedef struct {
+    int32_t *ret;                /* [n_sites] return value of bcf_call_gap_prep: 0 or -1 */
+    uint32_t *p_aux;             /* [entries] p->aux = type<<16 | seqQ<<8 | indelQ (valid where ret==0) */
+    int32_t *indel_types;        /* [n_sites][4] bca->indel_types */
+    int8_t  *inscns;             /* [n_sites][4*inscns_cap] bca->inscns (stride maxins[k] inside a site) */
+    int32_t *maxins, *indelreg, *max_support;
+    float   *max_frac;
+} bcfgpu_indel_out;
+
+int  bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const bcfgpu_indel_in *in, const bcfgpu_indel_out *out,
+                     int inscns_cap);
 
 /* byte sizes of the output planes for a tile of n_sites (n_smpl from the context) */
 size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *ctx, int n_sites, int which /*0 site,1 pl,2 dp4,3 adf,4 adr,5 qs,6 scr*/);

@@ -38,8 +38,13 @@ def test_hip_reproduces_default_mpileup_golden(golden_dir, idx):
             c = abi.default_cfg(tile.n_smpl, max_sites=1024, max_reads=1 << 20, fmt_flag=cfg.fmt_flag)
             ctxs[key] = engine.Context(c)
         return ctxs[key].mpileup(tile)
+    def gap_ctx():
+        # bcf_call_gap_prep through bcfgpu_gap_prep (host typing + probaln_kernel on the device)
+        if "gap" not in ctxs:
+            ctxs["gap"] = engine.Context(abi.default_cfg(1))
+        return ctxs["gap"]
     try:
-        run_baq_case(golden_dir, BAQ_CASES[idx], hip_engine)
+        run_baq_case(golden_dir, BAQ_CASES[idx], hip_engine, gap_ctx=gap_ctx)
     finally:
         for c in ctxs.values():
             c.close()

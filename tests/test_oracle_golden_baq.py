@@ -25,7 +25,7 @@ CASES = [
 ]
 
 
-def run_case(golden_dir, case, engine):
+def run_case(golden_dir, case, engine, gap_ctx=None):
     samfiles, reffa, contig, beg, end, goldf, fmt_flag, n_snp, n_indel = case
     G = os.path.join(golden_dir, "mpileup")
     sams = [sam.Sam(os.path.join(G, f)) for f in samfiles]
@@ -43,7 +43,7 @@ def run_case(golden_dir, case, engine):
     for i, p in enumerate(kept):
         K.check_record(snp[p + 1], res.site[i], res, i, K.snp_alleles(res.site[i]), fmt_flag)
         # indel record at the same position (mpileup.c:354-365), max_indel_depth 250 per sample
-        g = M.gap_prep(prep, cols[i], p) if sum(len(x) for x in cols[i]) < 250 * len(prep.samples) else None
+        g = M.gap_prep(prep, cols[i], p, ctx=gap_ctx() if gap_ctx else None) if sum(len(x) for x in cols[i]) < 250 * len(prep.samples) else None
         if g is None:
             assert (p + 1) not in ind
             continue
