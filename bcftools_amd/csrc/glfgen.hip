@@ -15,10 +15,9 @@
 // relative order of codes with the same base matters (per-base accumulators), and within a
 // base the code order is the order of key7 = q<<1|strand.  The sort is therefore replaced by
 // a per-base counting pass over the 128 possible key7 values (u8 counters in LDS, one column
-// per lane, conflict-free).  The descending walk is organised key-major: the wave ORs its lanes'
-// 128-bit key-presence masks, iterates the union from the highest key down (scalar loop) and, for
-// each key, every lane consumes its own count of reads with that key, four beta gathers in
-// flight at a time.  Quality and strand are wave-uniform inside that loop.
+// per lane, conflict-free) and a descending walk over the set bits of the lane's 128-bit
+// key-presence mask (a key-major variant that iterates the wave's union of keys was measured
+// slower: random mapQ values make the union ~10x larger than a lane's own key set).
 // Reads carrying the site's reference base -- almost all of them -- are counted directly in
 // the per-read loop; the others (exactly the "diff" reads of the I16 annotations) are kept, in
 // place, in the lane's LDS slice as a packed word and handled by a second, short loop.
@@ -45,54 +44,48 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
     return v;
 }
 
-// LDS layout (bytes): fk[264] f64 | cnt[32][WG] u32 | msk[4][WG] u32 | rd[cap+4] u32 | epos[cap+32] u8 | hist
+// LDS layout (bytes): fk[264] f64 | cnt[32][WG] u32 | rd[cap+4] u32 | epos[cap+32] u8 | hist
 #define LDS_FK   0
 #define LDS_CNT  2112
-#define LDS_MSK  (LDS_CNT + 32 * WG * 4)
-#define LDS_RD   (LDS_MSK + 4 * WG * 4)
+#define LDS_RD   (LDS_CNT + 32 * WG * 4)
 
 // packed "other" (non-primary = diff) read: baseQ:8 | mapQ(capped):6 | q:6 | b:4 | rev:1 | min_dist:5
 #define OW_PACK(baseQ, mapQ, q, b, rev, md) \
     ((uint32_t)(baseQ) | (uint32_t)(mapQ) << 8 | (uint32_t)(q) << 14 | (uint32_t)(b) << 20 | (uint32_t)(rev) << 24 | (uint32_t)(md) << 25)
 
-// Descending walk of errmod_cal for one base, key-major (see the header comment).  s_cnt/s_msk hold this
-// lane's per-key counts and key-presence bits, `n` selects the beta row of the lane.
-__device__ __forceinline__ double walk_keys(const uint32_t *s_cnt, const uint32_t *s_msk, const double *s_fk,
-                                            const double *beta, int tid, int n)
+// Descending walk of errmod_cal for one base: every lane steps through its own reads from the highest key7 down
+// (a small state machine: when the reads of the current key are used up, take the next set bit of the lane's
+// 128-bit key-presence mask and fetch its count).  s_cnt holds this lane's per-key counts, (mlo,mhi) the presence bits,
+// `n` selects the beta row of the lane, `left` is the number of reads of this base.
+__device__ __forceinline__ double walk_keys(const uint32_t *s_cnt, uint64_t mlo, uint64_t mhi, const double *s_fk,
+                                            const double *beta, int tid, int n, int left)
 {
-    uint32_t u[4];
-    #pragma unroll
-    for (int k = 0; k < 4; ++k) u[k] = __builtin_amdgcn_readfirstlane(wave_or(s_msk[k * WG + tid]));
+    int rem = 0, rev = 0;
     uint32_t cc = 0, w0 = 0, w1 = 0;
+    const double *brow = beta + ((size_t)n << 8);
+    const double *bp = brow;
     double bs = 0;
-    const double *brow_n = beta + ((size_t)n << 8);
-    #pragma unroll
-    for (int k = 3; k >= 0; --k) {
-        uint32_t m = u[k];                              // wave-uniform
-        while (m) {
-            const int bit = 31 - __builtin_clz(m);
-            m &= ~(1u << bit);
-            const int key = k * 32 + bit;               // q<<1 | strand, wave-uniform
-            const int rev = key & 1;
-            const int cnt = (int)((s_cnt[(key >> 2) * WG + tid] >> (8 * (key & 3))) & 0xff);
-            const double *bp = brow_n + ((size_t)(key >> 1) << 16) + cc;
-            const double *fp = s_fk + (rev ? w1 : w0);
-            for (int r = 0; __any(r < cnt); r += 4) {
-                // up to four reads of this lane with this key: issue the gathers first, then add in order
-                const double b0 = (r     < cnt) ? bp[r]     : 0.0;
-                const double b1 = (r + 1 < cnt) ? bp[r + 1] : 0.0;
-                const double b2 = (r + 2 < cnt) ? bp[r + 2] : 0.0;
-                const double b3 = (r + 3 < cnt) ? bp[r + 3] : 0.0;
-                const double f0 = fp[r], f1 = fp[r + 1], f2 = fp[r + 2], f3 = fp[r + 3];
-                if (r     < cnt) bs += f0 * b0;
-                if (r + 1 < cnt) bs += f1 * b1;
-                if (r + 2 < cnt) bs += f2 * b2;
-                if (r + 3 < cnt) bs += f3 * b3;
-            }
-            cc += cnt;
-            if (rev) w1 += cnt; else w0 += cnt;
+    #define WALK_ADVANCE() do { \
+        uint32_t key; \
+        if (mhi) { const int k = 63 - __clzll((long long)mhi); mhi &= ~(1ull << k); key = k + 64; } \
+        else     { const int k = 63 - __clzll((long long)mlo); mlo &= ~(1ull << k); key = k; } \
+        rem = (int)((s_cnt[(key >> 2) * WG + tid] >> (8 * (key & 3))) & 0xff); \
+        rev = key & 1; \
+        bp = brow + ((size_t)(key >> 1) << 16); } while (0)
+    // the beta value of the next read is requested one step ahead of its use
+    double nxt = 0.;
+    if (left > 0) { WALK_ADVANCE(); nxt = bp[0]; }
+    while (__any(left > 0)) {
+        if (left > 0) {
+            const double cur = nxt;
+            const double f = s_fk[rev ? w1 : w0];
+            ++cc; w1 += rev; w0 += 1 - rev;
+            --rem; --left;
+            if (left > 0) { if (rem == 0) WALK_ADVANCE(); nxt = bp[cc]; }
+            bs += f * cur;
         }
     }
+    #undef WALK_ADVANCE
     return bs;
 }
 
@@ -103,7 +96,6 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
     const int cap = P.lds_cap;
     double   *s_fk  = reinterpret_cast<double*>(smem + LDS_FK);
     uint32_t *s_cnt = reinterpret_cast<uint32_t*>(smem + LDS_CNT);
-    uint32_t *s_msk = reinterpret_cast<uint32_t*>(smem + LDS_MSK);
     uint32_t *s_rd  = reinterpret_cast<uint32_t*>(smem + LDS_RD);
     uint8_t  *s_ep  = smem + LDS_RD + ((size_t)cap + 4) * 4;
     int      *s_hist = reinterpret_cast<int*>(smem + LDS_RD + ((size_t)cap + 4) * 4 + (size_t)cap + 32);
@@ -180,8 +172,7 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
         // ---- pass 0: the per-read loop of bcf_call_glfgen (bam2bcf.c:170-253) ----
         #pragma unroll
         for (int k = 0; k < 32; ++k) s_cnt[k * WG + tid] = 0;
-        #pragma unroll
-        for (int k = 0; k < 4; ++k) s_msk[k * WG + tid] = 0;
+        uint64_t mlo = 0, mhi = 0;   // key7 presence bits of the primary base
         uint64_t qs64 = 0;           // QS[0..3], 16 bits each
         uint64_t ad64 = 0;           // ADF[0..3] | ADR[0..3]<<32, 8 bits each
         uint32_t mq0 = 0, scr = 0, ori_depth = 0, n_rev = 0, n_b4 = 0;
@@ -189,8 +180,13 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
         uint32_t h59 = 0;            // reads with mapQ>=59: ref | alt<<8 | fwd<<16 | rev<<24
         int n = 0, n_other = 0;
         bool fail = false;
+        // the next record is fetched while the current one is processed (the in-place writes below stay behind index i)
+        uint32_t w_nx = cnt_raw ? s_rd[lbeg] : 0;
+        int ep_nx = (cnt_raw && want_epos) ? s_ep[ebeg] : 0;
         for (uint32_t i = 0; i < cnt_raw; ++i) {
-            const uint32_t w = s_rd[lbeg + i];
+            const uint32_t w = w_nx;
+            const int ep_cur = ep_nx;
+            if (i + 1 < cnt_raw) { w_nx = s_rd[lbeg + i + 1]; if (want_epos) ep_nx = s_ep[ebeg + i + 1]; }
             if (w & BCFGPU_RD_SKIP) continue;
             if (!INDEL && (w & BCFGPU_RD_DEL)) continue;
             ++ori_depth;
@@ -221,8 +217,8 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
             const int min_dist = min((int)(w >> 24), CAP_DIST);
             const uint32_t key = (uint32_t)(q << 1) | rev;       // (code>>4)&0x7f of bam2bcf.c:203
             if (b == primary) {
-                s_cnt[(key >> 2) * WG + tid] += 1u << (8 * (key & 3));
-                atomicOr(&s_msk[(key >> 5) * WG + tid], 1u << (key & 31));
+                atomicAdd(&s_cnt[(key >> 2) * WG + tid], 1u << (8 * (key & 3)));     // ds_add_u32: no round trip
+                if (key < 64) mlo |= 1ull << key; else mhi |= 1ull << (key - 64);
             } else {
                 s_rd[lbeg + n_other] = OW_PACK(baseQ, mapQ, q, b, rev, min_dist);    // n_other <= i: behind the reader
                 ++n_other;
@@ -239,7 +235,7 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
             if (P.ablate & 1) continue;
             const int ibq = min(baseQ, 59);
             const int imq = min(mapQ, 59);
-            const int ep = want_epos ? s_ep[ebeg + i] : 0;
+            const int ep = ep_cur;
             const bool isref = (nt == ref_base);
             if (imq == 59) h59 += (isref ? 1u : 1u << 8) + (rev ? 1u << 24 : 1u << 16);
             else {
@@ -257,9 +253,7 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
         }
         if (fail || ori_depth > 0xffff) {
             atomicExch(P.err, BCFGPU_E_DEPTH);
-            n = 0; n_other = 0; qs64 = ad64 = 0; n_rev = n_b4 = 0;
-            #pragma unroll
-            for (int k = 0; k < 4; ++k) s_msk[k * WG + tid] = 0;
+            n = 0; n_other = 0; qs64 = ad64 = 0; n_rev = n_b4 = 0; mlo = mhi = 0;
         }
         // per-base counts c[0..4] (errmod_cal's aux.c)
         int c[5];
@@ -272,7 +266,10 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
         double bsum[5] = {0, 0, 0, 0, 0};
         // (a) the primary base, already counted
         if (!skip_walk) {
-            const double bs = walk_keys(s_cnt, s_msk, s_fk, P.beta, tid, n);
+            int cprim = 0;
+            #pragma unroll
+            for (int b = 0; b < 5; ++b) if (b == primary) cprim = c[b];
+            const double bs = walk_keys(s_cnt, mlo, mhi, s_fk, P.beta, tid, n, cprim);
             #pragma unroll
             for (int b = 0; b < 5; ++b) if (b == primary) bsum[b] = bs;
         }
@@ -294,8 +291,7 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
                 if (skip_walk || !__any(cb > 0)) continue;
                 #pragma unroll
                 for (int k = 0; k < 32; ++k) s_cnt[k * WG + tid] = 0;
-                #pragma unroll
-                for (int k = 0; k < 4; ++k) s_msk[k * WG + tid] = 0;
+                uint64_t lo = 0, hi = 0;
                 if (cb > 0) {
                     for (int i = 0; i < n_other; ++i) {
                         const uint32_t ow = s_rd[lbeg + i];
@@ -304,10 +300,10 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
                         if (bb != b) continue;
                         const uint32_t key = ((ow >> 14) & 0x3f) << 1 | ((ow >> 24) & 1);
                         s_cnt[(key >> 2) * WG + tid] += 1u << (8 * (key & 3));
-                        atomicOr(&s_msk[(key >> 5) * WG + tid], 1u << (key & 31));
+                        if (key < 64) lo |= 1ull << key; else hi |= 1ull << (key - 64);
                     }
                 }
-                const double bs = walk_keys(s_cnt, s_msk, s_fk, P.beta, tid, n);
+                const double bs = walk_keys(s_cnt, lo, hi, s_fk, P.beta, tid, n, cb);
                 if (b != primary) bsum[b] = bs;      // lanes of one wave may belong to sites with different reference bases
             }
         }
