@@ -35,6 +35,7 @@ struct bcfgpu_ctx {
     double call_theta_log = 0;
     // workspaces sized by cfg.max_sites / cfg.max_reads
     int *d_hist = nullptr, *d_err = nullptr;
+    unsigned long long *d_site_sums = nullptr;
     CallretPlanes cr{};
     size_t ncells_cap = 0;
     // timing
@@ -134,7 +135,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
             (rc = dev_alloc(c, (void**)&c->cr.p15, ncells * 15 * sizeof(float))) ||
             (rc = dev_alloc(c, (void**)&c->cr.qs64, ncells * 8)) ||
             (rc = dev_alloc(c, (void**)&c->cr.adf, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->cr.adr, ncells * 4)) ||
-            (rc = dev_alloc(c, (void**)&c->cr.cnt4, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->cr.sums, ncells * 12 * 4)) ||
+            (rc = dev_alloc(c, (void**)&c->cr.cnt4, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->d_site_sums, (size_t)cfg->max_sites * 12 * 8)) ||
             (rc = dev_alloc(c, (void**)&c->cr.misc, ncells * 4))) {
             bcfgpu_destroy(c); return rc;
         }
@@ -331,15 +332,16 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     g.fk = c->d_fk; g.beta = c->d_beta; g.lhet = c->d_lhet;
     g.cr = c->cr;
     // the callret planes are addressed with ncells of *this* tile
-    g.hist = c->d_hist; g.err = c->d_err;
+    g.hist = c->d_hist; g.err = c->d_err; g.site_sums = c->d_site_sums;
     HIPCHK(hipMemsetAsync(c->d_hist, 0, (size_t)tile->n_sites * H_SIZE * sizeof(int), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_site_sums, 0, (size_t)tile->n_sites * 12 * 8, c->stream));
     hipEvent_t *ev = c->timing ? seq_events(c) : nullptr;
     if (ev) hipEventRecord(ev[0], c->stream);
     launch_glfgen(g, c->stream);
     if (ev) hipEventRecord(ev[1], c->stream);
     CombineParams k{};
     k.n_sites = tile->n_sites; k.n_smpl = S; k.is_indel = tile->is_indel; k.fmt_flag = c->cfg.fmt_flag;
-    k.ref16 = tile->ref16; k.cr = c->cr; k.hist = c->d_hist; k.mw = c->d_mw; k.out = *out;
+    k.ref16 = tile->ref16; k.cr = c->cr; k.hist = c->d_hist; k.site_sums = c->d_site_sums; k.mw = c->d_mw; k.out = *out;
     { const char *ab = getenv("BCFGPU_ABLATE"); k.ablate = ab ? atoi(ab) : 0; }
     launch_combine(k, c->stream);
     if (ev) hipEventRecord(ev[2], c->stream);

@@ -228,11 +228,9 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
     const bool dead = (P.is_indel && nal == 1);     // bcf_call_combine returned -1 (bam2bcf.c:611)
 
     // ---- per-sample planes + integer totals ----
-    // per-lane partial totals: u32 is ample for counts and first-order sums (a lane sees S/64 samples of <=255
-    // reads); the three kinds of squared sums get u64
+    // per-lane partial totals (u32 is ample: a lane sees S/64 samples of <=255 reads); anno[4..15] arrive as site totals
     uint32_t t_adf[5] = {0,0,0,0,0}, t_adr[5] = {0,0,0,0,0};
     uint32_t t_scr = 0, t_ori = 0, t_mq0 = 0, t_cnt[4] = {0,0,0,0};
-    unsigned long long t_sum[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
     const size_t Ss = (size_t)S;
     for (int base = 0; base < S; base += CHUNK) {
         const int cn = min(CHUNK, S - base);
@@ -285,8 +283,6 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
             t_ori += misc >> 16; t_mq0 += misc & 0xff;
             #pragma unroll
             for (int j = 0; j < 4; ++j) t_cnt[j] += (cnt4 >> (8 * j)) & 0xff;
-            #pragma unroll
-            for (int j = 0; j < 12; ++j) if (!(P.ablate & 1024)) t_sum[j] += P.cr.sums[(size_t)j * ncells + cell];
         }
         __syncthreads();
         if (tid == 0 && !dead && !(P.ablate & 8192)) {          // sum_min: sequential double sum (bam2bcf.c:642)
@@ -313,8 +309,7 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
         v = wave_sum_u64((unsigned long long)t_mq0); if (lane == 0 && v) atomicAdd(&sh.tot[12], v);
         #pragma unroll
         for (int j = 0; j < 4; ++j) { v = wave_sum_u64((unsigned long long)t_cnt[j]); if (lane == 0 && v) atomicAdd(&sh.tot[13 + j], v); }
-        #pragma unroll
-        for (int j = 0; j < 12; ++j) { v = wave_sum_u64(t_sum[j]); if (lane == 0 && v) atomicAdd(&sh.tot[17 + j], v); }
+        if (tid < 12) sh.tot[17 + tid] = P.site_sums[(size_t)is * 12 + tid];
     }
     __syncthreads();
 

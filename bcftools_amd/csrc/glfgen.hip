@@ -25,6 +25,7 @@
 // Site-wide bias histograms (bam2bcf.c:228-252) are integer counts: hot bins (mapQ>=59) are
 // counted in registers, the rest with LDS atomics; one flush of global atomics per workgroup.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "kernels.h"
 
 namespace bcfgpu {
@@ -44,7 +45,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
     return v;
 }
 
-// LDS layout (bytes): fk[264] f64 | cnt[32][WG] u32 | rd[cap+4] u32 | epos[cap+32] u8 | hist
+// LDS layout (bytes): fk[264] f64 | cnt[32][WG] u32 | rd[cap+4] u32 | epos[cap+32] u8 | hist | site totals
 #define LDS_FK   0
 #define LDS_CNT  2112
 #define LDS_RD   (LDS_CNT + 32 * WG * 4)
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
     uint32_t *s_rd  = reinterpret_cast<uint32_t*>(smem + LDS_RD);
     uint8_t  *s_ep  = smem + LDS_RD + ((size_t)cap + 4) * 4;
     int      *s_hist = reinterpret_cast<int*>(smem + LDS_RD + ((size_t)cap + 4) * 4 + (size_t)cap + 32);
+    unsigned long long *s_tot = reinterpret_cast<unsigned long long*>(s_hist + (size_t)P.hist_slots * H_SIZE);   // [slots][12]
     __shared__ unsigned int s_next;
 
     const int tid = threadIdx.x;
@@ -110,7 +112,10 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
 
     s_fk[tid] = P.fk[tid];
     if (tid < 8) s_fk[256 + tid] = 0.0;               // read-ahead slack of the walk (never used in a sum)
-    if (LDS_HIST) for (int i = tid; i < P.hist_slots * H_SIZE; i += WG) s_hist[i] = 0;
+    if (LDS_HIST) {
+        for (int i = tid; i < P.hist_slots * H_SIZE; i += WG) s_hist[i] = 0;
+        for (int i = tid; i < P.hist_slots * 12; i += WG) s_tot[i] = 0;
+    }
 
     int site = 0, ref_base = -1, ref4 = 4;
     uint32_t beg = 0, end = 0;
@@ -343,11 +348,14 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
             P.cr.qs64[cell] = qs64;
             P.cr.adf[cell] = (uint32_t)ad64; P.cr.adr[cell] = (uint32_t)(ad64 >> 32); P.cr.cnt4[cell] = cnt4;
             P.cr.misc[cell] = (mq0 & 0xff) | (scr & 0xff) << 8 | ori_depth << 16;
-            uint32_t *sm = P.cr.sums + cell;
+            // anno[4..15] only feed the site totals of bcf_call_combine (bam2bcf.c:718-727): exact integers, so they are
+            // summed here (LDS per workgroup, one global atomic per workgroup and site) instead of crossing HBM per cell
             const uint32_t t_bq = t_bqmd & 0xffff, t_md = t_bqmd >> 16, d_bq = d_bqmd & 0xffff, d_md = d_bqmd >> 16;
-            sm[0 * ncells] = t_bq - d_bq; sm[1 * ncells] = t_bq2 - d_bq2; sm[2 * ncells] = d_bq; sm[3 * ncells] = d_bq2;
-            sm[4 * ncells] = t_mq - d_mq; sm[5 * ncells] = t_mq2 - d_mq2; sm[6 * ncells] = d_mq; sm[7 * ncells] = d_mq2;
-            sm[8 * ncells] = t_md - d_md; sm[9 * ncells] = t_md2 - d_md2; sm[10 * ncells] = d_md; sm[11 * ncells] = d_md2;
+            const uint32_t v12[12] = { t_bq - d_bq, t_bq2 - d_bq2, d_bq, d_bq2, t_mq - d_mq, t_mq2 - d_mq2, d_mq, d_mq2,
+                                       t_md - d_md, t_md2 - d_md2, d_md, d_md2 };
+            unsigned long long *tot = LDS_HIST ? s_tot + (site - site0) * 12 : P.site_sums + (size_t)site * 12;
+            #pragma unroll
+            for (int j = 0; j < 12; ++j) if (v12[j]) atomicAdd(&tot[j], (unsigned long long)v12[j]);
             done = true;
         }
         // ---- next round: the first cell whose reads are not resident yet (deep tiles only) ----
@@ -366,13 +374,17 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
             const int v = s_hist[i];
             if (v) atomicAdd(&P.hist[(long)site0 * H_SIZE + i], v);
         }
+        for (int i = tid; i < nslot * 12; i += WG) {
+            const unsigned long long v = s_tot[i];
+            if (v) atomicAdd(&P.site_sums[(size_t)site0 * 12 + i], v);
+        }
     }
     #undef HIST_ADD
 }
 
 size_t glfgen_lds_bytes(int cap, int hist_slots)
 {
-    return LDS_RD + ((size_t)cap + 4) * 4 + (size_t)cap + 32 + (size_t)hist_slots * H_SIZE * sizeof(int);
+    return LDS_RD + ((size_t)cap + 4) * 4 + (size_t)cap + 32 + (size_t)hist_slots * (H_SIZE * sizeof(int) + 12 * 8);
 }
 
 template <bool INDEL, bool LDS_HIST>
@@ -392,7 +404,8 @@ void launch_glfgen(const GlfgenParams &p, hipStream_t s)
     const long ncells = (long)p.n_sites * p.n_smpl;
     if (ncells == 0) return;
     const int grid = (int)((ncells + WG - 1) / WG);
-    const size_t lds = glfgen_lds_bytes(p.lds_cap, p.hist_slots);
+    size_t lds = glfgen_lds_bytes(p.lds_cap, p.hist_slots);
+    { const char *e = getenv("BCFGPU_LDS_PAD"); if (e) lds += (size_t)atoi(e); }   // diagnostics: lower the occupancy
     if (p.is_indel) { if (p.hist_slots) launch_one<true, true>(p, s, grid, lds); else launch_one<true, false>(p, s, grid, lds); }
     else            { if (p.hist_slots) launch_one<false, true>(p, s, grid, lds); else launch_one<false, false>(p, s, grid, lds); }
 }

@@ -20,7 +20,6 @@ struct CallretPlanes {
     uint32_t *adf;    // [ncells]      ADF[0..3] packed 4 x u8
     uint32_t *adr;    // [ncells]      ADR[0..3] packed 4 x u8
     uint32_t *cnt4;   // [ncells]      anno[0..3] packed 4 x u8
-    uint32_t *sums;   // [12][ncells]  anno[4..15]
     uint32_t *misc;   // [ncells]      mq0 | SCR<<8 | ori_depth<<16
 };
 
@@ -39,6 +38,7 @@ struct GlfgenParams {
     const double *fk, *beta, *lhet;
     CallretPlanes cr;
     int *hist;                      // [n_sites][H_SIZE], zeroed before launch
+    unsigned long long *site_sums;  // [n_sites][12] site totals of anno[4..15] (exact integers), zeroed before launch
     int *err;                       // device error word
 };
 
@@ -47,6 +47,7 @@ struct CombineParams {
     const int8_t *ref16;
     CallretPlanes cr;
     const int *hist;
+    const unsigned long long *site_sums;   // [n_sites][12] from glfgen_kernel
     const double *mw;               // [6][6][50]
     int ablate;                     // diagnostics only (BCFGPU_ABLATE)
     bcfgpu_mplp_out out;
