@@ -91,10 +91,12 @@ __device__ __forceinline__ void load_pl(const McallParams &P, int is, int s, int
 __device__ __attribute__((noinline)) double npow10(double x) { return pow(10., x); }
 __device__ __forceinline__ double pl2prob(const double *pl2p, int v) { return v < 256 ? pl2p[v] : npow10(-v / 10.); }
 
-// set_pdg for one sample (mcall.c:460-543).  `scr` is this lane's LDS column (stride WGS) used
-// only by the rare partially-missing path, which needs run-time indexing.
+// set_pdg for one sample (mcall.c:460-543) without its final normalisation: pdg[] receives the raw 10^(-PL/10)
+// values and the function returns their sum, or 0 when the sample is "all missing" (pdg must then read as zeros).
+// The caller divides (exactly as `pdg[j] /= sum` does) where bit-exact values are needed.  `scr` is this lane's
+// LDS column (stride WGS) used only by the rare partially-missing path, which needs run-time indexing.
 template <int NG>
-__device__ __forceinline__ void set_pdg_one(const double *pl2p, int (&pl)[NG], double (&pdg)[NG], int n_gt, int nals, int unseen, int *scr)
+__device__ __forceinline__ double set_pdg_one(const double *pl2p, int (&pl)[NG], double (&pdg)[NG], int n_gt, int nals, int unseen, int *scr)
 {
     double sum = 0;
     int j = n_gt;               // index of the first missing value, or n_gt
@@ -142,10 +144,11 @@ __device__ __forceinline__ void set_pdg_one(const double *pl2p, int (&pl)[NG], d
     if (sum == (double)n_gt) {
         #pragma unroll
         for (int k = 0; k < NG; ++k) pdg[k] = 0;
-    } else {
-        #pragma unroll
-        for (int k = 0; k < NG; ++k) if (k < n_gt) pdg[k] /= sum; else pdg[k] = 0;
+        return 0.0;
     }
+    #pragma unroll
+    for (int k = 0; k < NG; ++k) if (k >= n_gt) pdg[k] = 0;
+    return sum;
 }
 
 __device__ __forceinline__ void write_skipped(bcfgpu_call_site *cs, int ret)
@@ -154,17 +157,15 @@ __device__ __forceinline__ void write_skipped(bcfgpu_call_site *cs, int ret)
     for (int i = 0; i < 5; ++i) { cs->als_map[i] = -1; cs->ac[i] = 0; }
 }
 
-template <int MAXA>
+template <int MAXA, int NSUB>
 __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
 {
     constexpr int NG = MAXA * (MAXA + 1) / 2;
-    constexpr int NSUB = MAXA == 3 ? 7 : 25;
     extern __shared__ __align__(16) unsigned char dsm[];
     float *s_gq = reinterpret_cast<float*>(dsm);              // [n_grp][5] group qsum, then [n_grp][2] best allele sets
     __shared__ CallShared sh;
-    __shared__ double s_pl2p[256];
-    __shared__ int s_fill[NG * WGS];        // run-time indexed scratch of set_pdg's rare missing-value path
-    __shared__ double s_pdg[NG * WGS];      // the lane's current sample: P(D|G)
+    __shared__ double s_pdg[NG * WGS];      // the lane's current sample: raw P(D|G) (not yet divided by its sum)
+    int *s_fill = reinterpret_cast<int*>(s_pdg);   // scratch of set_pdg's rare missing-value path (used before s_pdg is written)
     // pass 1: per-lane running products of the subset likelihoods, kept as mantissa (f64) and exponent (i32):
     //         sum_s log(val_s) = log(prod_s val_s), so each sample costs a multiply + frexp instead of a log()
     // pass 2: the lane's current sample: PLs after set_pdg's in-place fills, genotype posteriors
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
         if (tid == 0) write_skipped(cs, 0);
         return;
     }
-    for (int i = tid; i < 256; i += WGS) s_pl2p[i] = P.pl2p[i];
+    const double *s_pl2p = P.pl2p;
 
     // ---- allele-frequency set-up (mcall.c:1453-1535), sequential float32 ----
     if (tid == 0) {
@@ -320,13 +321,17 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
         }
         __syncthreads();
         const int nsub = sh.nsub;
+        // the 5-allele instantiations split by the number of subsets to visit (LDS for the running products)
+        if (MAXA == 5 && ((nsub <= 15) != (NSUB == 15))) return;
         for (int t = 0; t < nsub; ++t) { s_man[t * WGS + tid] = 1.0; s_exp[t * WGS + tid] = 0; }
         int setbits = 0;
         for (int s = tid; s < ((P.ablate & 16) ? 0 : S); s += WGS) {
             if (ngrp > 1 && P.grp[s] != g) continue;
             int pl[NG]; double pdg[NG];
             load_pl<NG>(P, is, s, ngts, pl);
-            set_pdg_one<NG>(s_pl2p, pl, pdg, ngts, nals, unseen, s_fill + tid);
+            const double psum = set_pdg_one<NG>(s_pl2p, pl, pdg, ngts, nals, unseen, s_fill + tid);
+            // the subset likelihoods only feed log-sums (QUAL, 1e-4 contract): one reciprocal instead of n_gt divisions
+            const double rsum = psum != 0.0 ? 1.0 / psum : 0.0;
             #pragma unroll
             for (int k = 0; k < NG; ++k) s_pdg[k * WGS + tid] = pdg[k];
             const int ploidy = P.ploidy ? P.ploidy[s] : 2;
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
                     }
                 }
                 if (val != 0.0) {
-                    const double m = s_man[t * WGS + tid] * val;
+                    const double m = s_man[t * WGS + tid] * (val * rsum);
                     s_man[t * WGS + tid] = frexp_mant(m);
                     s_exp[t * WGS + tid] += frexp_exp(m);
                     setbits |= 1 << t;
@@ -446,14 +451,16 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
     for (int s = tid; s < ((P.ablate & 32) ? 0 : S); s += WGS) {
         int pl[NG]; double pdg[NG];
         load_pl<NG>(P, is, s, ngts, pl);
-        set_pdg_one<NG>(s_pl2p, pl, pdg, ngts, nals, unseen, s_fill + tid);
+        const double psum = set_pdg_one<NG>(s_pl2p, pl, pdg, ngts, nals, unseen, s_fill + tid);
         const int ploidy = P.ploidy ? P.ploidy[s] : 2;
+        // pdg = raw/psum is formed lazily below, with the same division the reference performs (bit-exact genotypes)
         bool allzero = true;
         #pragma unroll
         for (int k = 0; k < NG; ++k) {
             if (k < ngts && pdg[k] != 0.0) allzero = false;
             s_pdg[k * WGS + tid] = pdg[k]; s_plc[k * WGS + tid] = pl[k]; s_gps[k * WGS + tid] = 0.f;
         }
+        if (psum == 0.0) allzero = true;
         int g0, g1, gq = 0, gnals = 0;
         if (!is_variant) {
             if (allzero || !ploidy) { g0 = BCFGPU_GT_MISSING; g1 = ploidy == 2 ? BCFGPU_GT_MISSING : BCFGPU_GT_VECTOR_END; }
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
                 for (int ia = 0; ia < nals; ++ia) {
                     if (!(gals & 1 << ia)) continue;
                     const int iaa = (ia + 1) * (ia + 2) / 2 - 1;
-                    const double p = s_pdg[iaa * WGS + tid];
+                    const double p = s_pdg[iaa * WGS + tid] / psum;
                     const double lk = ploidy == 2 ? p * gq5[ia] * gq5[ia] : p * gq5[ia];
                     const int am = sh.als_map[ia];
                     const int igt = ploidy == 2 ? a2gt(am, am) : am;
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
                         for (int ib = 0; ib < ia; ++ib) {
                             if (!(gals & 1 << ib)) continue;
                             const int iab = iaa - ia + ib;
-                            const double lk = 2 * s_pdg[iab * WGS + tid] * gq5[ia] * gq5[ib];
+                            const double lk = 2 * (s_pdg[iab * WGS + tid] / psum) * gq5[ia] * gq5[ib];
                             const int igt = a2gt(sh.als_map[ia], sh.als_map[ib]);
                             s_gps[igt * WGS + tid] = (float)lk;
                             if (best_lk < lk) { best_lk = lk; g0 = sh.als_map[ib]; g1 = sh.als_map[ia]; }
@@ -574,8 +581,9 @@ void launch_mcall(const McallParams &p, hipStream_t s)
     if (p.n_sites == 0) return;
     const int ngrp = p.n_grp > 1 ? p.n_grp : 1;
     const size_t lds = (size_t)ngrp * 5 * sizeof(float) + (size_t)ngrp * 2 * sizeof(int);
-    hipLaunchKernelGGL(mcall_kernel<3>, dim3(p.n_sites), dim3(WGS), lds, s, p);
-    hipLaunchKernelGGL(mcall_kernel<5>, dim3(p.n_sites), dim3(WGS), lds, s, p);
+    hipLaunchKernelGGL((mcall_kernel<3, 7>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+    hipLaunchKernelGGL((mcall_kernel<5, 15>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+    hipLaunchKernelGGL((mcall_kernel<5, 25>), dim3(p.n_sites), dim3(WGS), lds, s, p);
 }
 
 }  // namespace bcfgpu
