@@ -123,6 +123,15 @@ def main():
     out = None
     if rank == 0:
         alg = algorithmic_bytes(T, S, R)
+        # HBM traffic of the dominant kernel: PMC-measured (profiles/r1_traffic.json, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE
+        # as MI355X_MICROARCH.md prescribes for gfx950), scaled from the profiled tile to this one by the site count
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            if tj["samples"] == S and abs(tj["depth"] - a.depth) < 1e-9:
+                traffic = tj["hbm_bytes_per_launch"] * (T / tj["sites"])
+        except Exception:
+            traffic = None
         kern_s = tm["glfgen_ms"] * 1e-3
         achieved = alg / kern_s / 1e9 if kern_s > 0 else 0.0
         out = {
@@ -135,7 +144,7 @@ def main():
                        "samples": S, "depth": a.depth, "sites_per_step_per_gpu": T, "reads_per_tile": R,
                        "sharding": "contiguous region shard per GPU; ordered gather of call records to rank 0"},
             "roofline": {"bound": "hbm", "kernel": "glfgen_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": tm["glfgen_ms"],
                          "other_kernels_ms": {"combine_kernel": tm["combine_ms"], "mcall_kernel": tm["mcall_ms"]}},
         }
