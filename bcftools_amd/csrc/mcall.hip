@@ -64,7 +64,7 @@ struct CallShared {
     float qsum[5];              // current group's allele frequencies
     int nsub;                   // subsets visited for the current group
     Subset sub[25];
-    double red[25];             // reduced log-likelihood sums, indexed like sub[]
+    double red[32];             // reduced log-likelihood sums, indexed like sub[] (FAST: + the sum row at [nsub])
     int redset;
     int als_new, nals_new, is_variant, early;
     int als_map[5]; int pl_map[15];
@@ -157,10 +157,17 @@ __device__ __forceinline__ void write_skipped(bcfgpu_call_site *cs, int ret)
     for (int i = 0; i < 5; ++i) { cs->als_map[i] = -1; cs->ac[i] = 0; }
 }
 
-template <int MAXA, int NSUB>
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// FAST: the diploid, single-group, u8-PL case of the fused pipeline.  The subset scan of find_best_alleles is the
+// matrix product (subset coefficients [rows] x genotypes [k]) * (genotypes [k] x samples [cols]) and runs on the
+// f64 matrix cores (v_mfma_f64_16x16x4_f64), 16 samples per issue; an extra all-ones row yields each sample's
+// normalisation sum, whose product is divided out at the end.
+template <int MAXA, int NSUB, bool FAST>
 __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
 {
     constexpr int NG = MAXA * (MAXA + 1) / 2;
+    constexpr int TILES = NSUB >= 16 ? 2 : 1;     // 16-row tiles of the coefficient matrix (subsets + the sum row)
     extern __shared__ __align__(16) unsigned char dsm[];
     float *s_gq = reinterpret_cast<float*>(dsm);              // [n_grp][5] group qsum, then [n_grp][2] best allele sets
     __shared__ CallShared sh;
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
     // pass 1: per-lane running products of the subset likelihoods, kept as mantissa (f64) and exponent (i32):
     //         sum_s log(val_s) = log(prod_s val_s), so each sample costs a multiply + frexp instead of a log()
     // pass 2: the lane's current sample: PLs after set_pdg's in-place fills, genotype posteriors
-    constexpr int U1 = NSUB * WGS * 12, U2 = NG * WGS * 8, UB = U1 > U2 ? U1 : U2;
+    constexpr int U1 = FAST ? TILES * 16 * 16 * 8 : NSUB * WGS * 12, U2 = NG * WGS * 8, UB = U1 > U2 ? U1 : U2;
     __shared__ __align__(8) unsigned char s_union[UB];
     double *s_man = reinterpret_cast<double*>(s_union);
     int    *s_exp = reinterpret_cast<int*>(s_union + NSUB * WGS * 8);
@@ -199,6 +206,8 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
         return;
     }
     const double *s_pl2p = P.pl2p;
+    __shared__ double s_p2[FAST ? 256 : 1];                   // 10^(-PL/10), PL = 0..255
+    if constexpr (FAST) for (int i = tid; i < 256; i += WGS) s_p2[i] = P.pl2p[i];
 
     // ---- allele-frequency set-up (mcall.c:1453-1535), sequential float32 ----
     if (tid == 0) {
@@ -323,8 +332,102 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
         const int nsub = sh.nsub;
         // the 5-allele instantiations split by the number of subsets to visit (LDS for the running products)
         if (MAXA == 5 && ((nsub <= 15) != (NSUB == 15))) return;
-        for (int t = 0; t < nsub; ++t) { s_man[t * WGS + tid] = 1.0; s_exp[t * WGS + tid] = 0; }
         int setbits = 0;
+        if constexpr (FAST) {
+            // ---- subset scan on the matrix cores ----
+            double *s_coef = reinterpret_cast<double*>(s_union);            // [TILES*16 rows][16 genotypes]
+            for (int i = tid; i < TILES * 256; i += WGS) s_coef[i] = 0.0;
+            __syncthreads();
+            if (tid < nsub) {
+                const Subset &u = sh.sub[tid];
+                double *row = s_coef + tid * 16;
+                if (u.ib < 0) row[u.iaa] = 1.0;
+                else {
+                    row[u.iaa] = u.fa2; row[u.ibb] = u.fb2; row[u.iab] = u.fab;
+                    if (u.ic >= 0) { row[u.icc] = u.fc2; row[u.iac] = u.fac; row[u.ibc] = u.fbc; }
+                }
+            }
+            if (tid < ngts) s_coef[nsub * 16 + tid] = 1.0;                  // the sum row
+            __syncthreads();
+            const int col = tid & 15, kq = tid >> 4;
+            double a[TILES][4];
+            #pragma unroll
+            for (int t = 0; t < TILES; ++t)
+                #pragma unroll
+                for (int kk = 0; kk < 4; ++kk) a[t][kk] = s_coef[(t * 16 + col) * 16 + 4 * kk + kq];
+            // this lane accumulates rows kq + 4r (+16t) over the sample columns col, col+16, ...
+            double man[TILES][4]; int ex[TILES][4];
+            #pragma unroll
+            for (int t = 0; t < TILES; ++t)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) { man[t][r] = 1.0; ex[t][r] = 0; }
+            const uint8_t *plb = reinterpret_cast<const uint8_t*>(P.pl) + (size_t)is * BCFGPU_MAX_PL * Ss;
+            for (int s0 = 0; s0 < ((P.ablate & 16) ? 0 : S); s0 += 64) {
+                // plane 4kk+kq, samples s0+4col .. +3 as one word; samples past the end read as "no data"
+                uint32_t w[4];
+                const int sb = s0 + 4 * col, rem = S - sb;
+                #pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = 4 * kk + kq;
+                    uint32_t v = 0;
+                    if (k < ngts && rem > 0) {
+                        const uint8_t *src = plb + (size_t)k * Ss + sb;
+                        if (rem >= 4) __builtin_memcpy(&v, src, 4);
+                        else { v = src[0]; if (rem > 1) v |= (uint32_t)src[1] << 8; if (rem > 2) v |= (uint32_t)src[2] << 16; }
+                    }
+                    w[kk] = v;
+                }
+                // set_pdg: a sample whose PLs are all 0 (sum == n_gt) carries no data and is skipped (mcall.c:529-535)
+                uint32_t any = w[0] | w[1] | w[2] | w[3];
+                any |= __shfl_xor(any, 16);
+                any |= __shfl_xor(any, 32);
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool has = ((any >> (8 * j)) & 0xff) != 0;
+                    double b[4];
+                    #pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        b[kk] = (has && 4 * kk + kq < ngts) ? s_p2[(w[kk] >> (8 * j)) & 0xff] : 0.0;
+                    #pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+                        d4_t d = {0., 0., 0., 0.};
+                        #pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) d = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][kk], b[kk], d, 0, 0, 0);
+                        #pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (d[r] != 0.0) { man[t][r] *= d[r]; setbits |= 1 << (t * 4 + r); }
+                    }
+                    if (j & 1) {
+                        #pragma unroll
+                        for (int t = 0; t < TILES; ++t)
+                            #pragma unroll
+                            for (int r = 0; r < 4; ++r) { ex[t][r] += frexp_exp(man[t][r]); man[t][r] = frexp_mant(man[t][r]); }
+                    }
+                }
+            }
+            // product over the 16 sample columns of each row, then rows -> sh.red[]
+            int rowbits = 0;
+            #pragma unroll
+            for (int t = 0; t < TILES; ++t)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double m = man[t][r]; int e = ex[t][r]; int f = (setbits >> (t * 4 + r)) & 1;
+                    #pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) {
+                        const double mm = m * __shfl_xor(m, o);
+                        e += __shfl_xor(e, o) + frexp_exp(mm);
+                        m = frexp_mant(mm);
+                        f |= __shfl_xor(f, o);
+                    }
+                    const int row = t * 16 + kq + 4 * r;
+                    if (col == 0 && row <= nsub) {
+                        sh.red[row] = log(m) + (double)e * 0.693147180559945309417232121458;
+                        if (f) rowbits |= 1 << row;
+                    }
+                }
+            setbits = rowbits;
+        } else {
+        for (int t = 0; t < nsub; ++t) { s_man[t * WGS + tid] = 1.0; s_exp[t * WGS + tid] = 0; }
         for (int s = tid; s < ((P.ablate & 16) ? 0 : S); s += WGS) {
             if (ngrp > 1 && P.grp[s] != g) continue;
             int pl[NG]; double pdg[NG];
@@ -374,6 +477,7 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
             }
             if (tid == 0) sh.red[t] = log(m) + (double)e * 0.693147180559945309417232121458;
         }
+        }
         setbits = wor(setbits);
         if (tid == 0) sh.redset = setbits;
         __syncthreads();
@@ -386,6 +490,7 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
             for (int t = 0; t < nsub; ++t) {
                 const Subset &u = sh.sub[t];
                 double lk_tot = sh.red[t];
+                if (FAST) lk_tot -= sh.red[nsub];           // divide out the product of the samples' normalisation sums
                 const int lk_tot_set = (set >> t) & 1;
                 int als = 1 << u.ia;
                 if (u.ib < 0) {
@@ -581,9 +686,15 @@ void launch_mcall(const McallParams &p, hipStream_t s)
     if (p.n_sites == 0) return;
     const int ngrp = p.n_grp > 1 ? p.n_grp : 1;
     const size_t lds = (size_t)ngrp * 5 * sizeof(float) + (size_t)ngrp * 2 * sizeof(int);
-    hipLaunchKernelGGL((mcall_kernel<3, 7>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-    hipLaunchKernelGGL((mcall_kernel<5, 15>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-    hipLaunchKernelGGL((mcall_kernel<5, 25>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+    if (p.pl_is_u8 && !p.ploidy && ngrp == 1 && !(p.ablate & 64)) {
+        hipLaunchKernelGGL((mcall_kernel<3, 7, true>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+        hipLaunchKernelGGL((mcall_kernel<5, 15, true>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+        hipLaunchKernelGGL((mcall_kernel<5, 25, true>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+    } else {
+        hipLaunchKernelGGL((mcall_kernel<3, 7, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+        hipLaunchKernelGGL((mcall_kernel<5, 15, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+        hipLaunchKernelGGL((mcall_kernel<5, 25, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+    }
 }
 
 }  // namespace bcfgpu

@@ -86,6 +86,32 @@ def test_pipeline_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, seed, flags, 
         np.testing.assert_array_equal(cgot.gq[live], cwant.gq[live])
 
 
+@pytest.mark.parametrize("n_sites,n_smpl,depth,seed,flags,tags", [
+    (64, 1000, 30.0, 21, 0, 0),                         # config[3]-shaped cohort
+    (64, 999, 8.0, 22, 0, abi.CALL_FMT_GQ),             # sample count not a multiple of 4 (ragged plane tail)
+    (128, 37, 0.7, 23, 0, 0),                           # most samples carry no reads at a site
+    (128, 130, 3.0, 24, abi.CALL_VARONLY, 0),
+    (200, 1, 20.0, 25, 0, abi.CALL_FMT_GQ | abi.CALL_FMT_GP),
+    (100, 17, 12.0, 26, abi.CALL_KEEPALT, 0),
+])
+def test_pipeline_diploid_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth, seed, flags, tags):
+    """All-diploid, single-group calling from the mpileup stage's u8 PL planes: the allele-subset scan runs on
+    the f64 matrix cores (mcall.hip, FAST instantiations)."""
+    tile = synth.numpy_tile(seed, n_sites, n_smpl, depth=depth, var_rate=0.3)
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), call_flag=flags, output_tags=tags)
+    mwant = orc.mpileup(cfg, tile)
+    cin = host.CallInput(n_smpl, mwant.site["n_alleles"], np.maximum(mwant.site["unseen"], 0),
+                         mwant.pl.astype(np.int32), mwant.site["qsum"])
+    cwant = orc.mcall(cfg, cin)
+    ctx = gpu_ctx_factory(cfg)
+    mgot, cgot = ctx.pipeline(tile)
+    assert_mplp_equal(mgot, mwant)
+    assert_call_equal(cgot, cwant, n_smpl)
+    if tags & abi.CALL_FMT_GQ:
+        live = (cwant.site["ret"] > 0) & (cwant.site["als_new"] != 1)
+        np.testing.assert_array_equal(cgot.gq[live], cwant.gq[live])
+
+
 def test_empty_and_zero_depth(gpu_ctx_factory):
     n_smpl = 4
     cfg = abi.default_cfg(n_smpl, max_sites=8, max_reads=64)
