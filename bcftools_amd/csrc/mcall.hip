@@ -69,7 +69,7 @@ struct CallShared {
     int als_new, nals_new, is_variant, early;
     int als_map[5]; int pl_map[15];
     int ac[5];
-    double max_qual, ref_lk, lk_sum;
+    double max_qual, ref_lk, lk_sum, ref_cur;
     int prior_fail;
 };
 
@@ -282,51 +282,50 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
         __syncthreads();
         if (tid < 5) sh.qsum[tid] = s_gq[g * 5 + tid];
         __syncthreads();
-        // lane 0 lists the subsets that mcall.c:600-698 visits, in its order, with their frequency products
-        if (tid == 0) {
-            int n = 0;
+        // the subsets that mcall.c:600-698 visits, in its order (singles, pairs, triples; alleles of zero frequency are
+        // skipped), with their frequency products: candidate c of the canonical enumeration is decoded by lane c and
+        // the surviving ones are compacted in order
+        {
             const float *qf = sh.qsum;
-            for (int ia = 0; ia < nals; ia++) {
-                Subset &t = sh.sub[n];
-                t.ia = ia; t.ib = t.ic = -1; t.iaa = (ia + 1) * (ia + 2) / 2 - 1;
+            const int npair = nals > 1 ? nals * (nals - 1) / 2 : 0;
+            const int ntrip = nals > 2 ? nals * (nals - 1) * (nals - 2) / 6 : 0;
+            int ia = -1, ib = -1, ic = -1;
+            bool valid = false;
+            if (tid < nals) { ia = tid; valid = true; }
+            else if (tid < nals + npair) {
+                const int c = tid - nals;
+                ia = 1; while ((ia + 1) * ia / 2 <= c) ia++;
+                ib = c - ia * (ia - 1) / 2;
+                valid = qf[ia] != 0 && qf[ib] != 0;
+            } else if (tid < nals + npair + ntrip) {
+                int c = tid - nals - npair;
+                ia = 2; while ((ia + 1) * ia * (ia - 1) / 6 <= c) ia++;
+                c -= ia * (ia - 1) * (ia - 2) / 6;
+                ib = 1; while ((ib + 1) * ib / 2 <= c) ib++;
+                ic = c - ib * (ib - 1) / 2;
+                valid = qf[ia] != 0 && qf[ib] != 0 && qf[ic] != 0;
+            }
+            const unsigned long long bal = __ballot(valid);
+            if (valid) {
+                Subset &t = sh.sub[__popcll(bal & ((1ull << tid) - 1))];
+                t.ia = ia; t.ib = ib; t.ic = ic;
+                t.iaa = (ia + 1) * (ia + 2) / 2 - 1;
                 t.ibb = t.icc = t.iab = t.iac = t.ibc = 0;
                 t.fa = t.fa2 = 1; t.fb = t.fc = t.fb2 = t.fc2 = t.fab = t.fac = t.fbc = 0;
-                n++;
+                if (ib >= 0 && ic < 0) {
+                    t.ibb = (ib + 1) * (ib + 2) / 2 - 1; t.iab = t.iaa - ia + ib;
+                    t.fa = (double)(qf[ia] / (qf[ia] + qf[ib])); t.fb = (double)(qf[ib] / (qf[ia] + qf[ib]));
+                    t.fa2 = t.fa * t.fa; t.fb2 = t.fb * t.fb; t.fab = 2 * t.fa * t.fb;
+                } else if (ic >= 0) {
+                    t.ibb = (ib + 1) * (ib + 2) / 2 - 1; t.icc = (ic + 1) * (ic + 2) / 2 - 1;
+                    t.iab = t.iaa - ia + ib; t.iac = t.iaa - ia + ic; t.ibc = t.ibb - ib + ic;
+                    const float den = qf[ia] + qf[ib] + qf[ic];
+                    t.fa = (double)(qf[ia] / den); t.fb = (double)(qf[ib] / den); t.fc = (double)(qf[ic] / den);
+                    t.fa2 = t.fa * t.fa; t.fb2 = t.fb * t.fb; t.fc2 = t.fc * t.fc;
+                    t.fab = 2 * t.fa * t.fb; t.fac = 2 * t.fa * t.fc; t.fbc = 2 * t.fb * t.fc;
+                }
             }
-            if (nals > 1)
-                for (int ia = 0; ia < nals; ia++) {
-                    if (qf[ia] == 0) continue;
-                    for (int ib = 0; ib < ia; ib++) {
-                        if (qf[ib] == 0) continue;
-                        Subset &t = sh.sub[n];
-                        t.ia = ia; t.ib = ib; t.ic = -1;
-                        t.iaa = (ia + 1) * (ia + 2) / 2 - 1; t.ibb = (ib + 1) * (ib + 2) / 2 - 1; t.iab = t.iaa - ia + ib;
-                        t.icc = t.iac = t.ibc = 0;
-                        t.fa = (double)(qf[ia] / (qf[ia] + qf[ib])); t.fb = (double)(qf[ib] / (qf[ia] + qf[ib])); t.fc = 0;
-                        t.fa2 = t.fa * t.fa; t.fb2 = t.fb * t.fb; t.fab = 2 * t.fa * t.fb; t.fc2 = t.fac = t.fbc = 0;
-                        n++;
-                    }
-                }
-            if (nals > 2)
-                for (int ia = 0; ia < nals; ia++) {
-                    if (qf[ia] == 0) continue;
-                    for (int ib = 0; ib < ia; ib++) {
-                        if (qf[ib] == 0) continue;
-                        for (int ic = 0; ic < ib; ic++) {
-                            if (qf[ic] == 0) continue;
-                            Subset &t = sh.sub[n];
-                            t.ia = ia; t.ib = ib; t.ic = ic;
-                            t.iaa = (ia + 1) * (ia + 2) / 2 - 1; t.ibb = (ib + 1) * (ib + 2) / 2 - 1; t.icc = (ic + 1) * (ic + 2) / 2 - 1;
-                            t.iab = t.iaa - ia + ib; t.iac = t.iaa - ia + ic; t.ibc = t.ibb - ib + ic;
-                            const float den = qf[ia] + qf[ib] + qf[ic];
-                            t.fa = (double)(qf[ia] / den); t.fb = (double)(qf[ib] / den); t.fc = (double)(qf[ic] / den);
-                            t.fa2 = t.fa * t.fa; t.fb2 = t.fb * t.fb; t.fc2 = t.fc * t.fc;
-                            t.fab = 2 * t.fa * t.fb; t.fac = 2 * t.fa * t.fc; t.fbc = 2 * t.fb * t.fc;
-                            n++;
-                        }
-                    }
-                }
-            sh.nsub = n;
+            if (tid == 0) sh.nsub = __popcll(bal);
         }
         __syncthreads();
         const int nsub = sh.nsub;
@@ -481,31 +480,49 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
         setbits = wor(setbits);
         if (tid == 0) sh.redset = setbits;
         __syncthreads();
-        if (tid == 0) {
-            // UPDATE_MAX_LKs over the visited subsets (mcall.c:582-585, 600-698)
+        // UPDATE_MAX_LKs over the visited subsets (mcall.c:582-585, 600-698), lane t = subset t: the first maximum in
+        // visiting order wins, and lk_sum (which only feeds QUAL) is one log-sum-exp instead of a chain of pairwise ones
+        int max_als = 0;
+        double ref_lk, max_lk, lk_sum;
+        {
             const int set = sh.redset;
-            int max_als = 0;
-            double ref_lk = -HUGE_VAL, max_lk = -HUGE_VAL, lk_sum = -HUGE_VAL;
             const double theta = P.theta;
-            for (int t = 0; t < nsub; ++t) {
-                const Subset &u = sh.sub[t];
-                double lk_tot = sh.red[t];
-                if (FAST) lk_tot -= sh.red[nsub];           // divide out the product of the samples' normalisation sums
-                const int lk_tot_set = (set >> t) & 1;
-                int als = 1 << u.ia;
-                if (u.ib < 0) {
-                    if (u.ia == 0) ref_lk = lk_tot; else lk_tot += theta;
-                    if (max_lk < lk_tot && lk_tot_set) { max_lk = lk_tot; max_als = als; }
-                    if (u.ia > 0 && lk_tot_set) lk_sum = lse2(lk_tot, lk_sum);
-                } else {
+            double lk_tot = -HUGE_VAL, lk_add = -HUGE_VAL;
+            int als = 0;
+            if (tid < nsub) {
+                const Subset &u = sh.sub[tid];
+                double v = sh.red[tid];
+                if (FAST) v -= sh.red[nsub];                // divide out the product of the samples' normalisation sums
+                als = 1 << u.ia;
+                if (u.ib < 0) { if (u.ia != 0) v += theta; }
+                else {
                     als |= 1 << u.ib;
-                    if (u.ia != 0) lk_tot += theta;
-                    if (u.ib != 0) lk_tot += theta;
-                    if (u.ic >= 0) { als |= 1 << u.ic; if (u.ic != 0) lk_tot += theta; }
-                    if (max_lk < lk_tot && lk_tot_set) { max_lk = lk_tot; max_als = als; }
-                    if (lk_tot_set) lk_sum = lse2(lk_tot, lk_sum);
+                    if (u.ia != 0) v += theta;
+                    if (u.ib != 0) v += theta;
+                    if (u.ic >= 0) { als |= 1 << u.ic; if (u.ic != 0) v += theta; }
                 }
+                if (tid == 0) sh.ref_cur = v;               // subset 0 is the REF-only one
+                if ((set >> tid) & 1) { lk_tot = v; if (als != 1) lk_add = v; }
             }
+            double m = lk_tot; int mi = tid;
+            double ma = lk_add;
+            #pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double om = __shfl_xor(m, o); const int oi = __shfl_xor(mi, o);
+                if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+                const double oa = __shfl_xor(ma, o);
+                ma = oa > ma ? oa : ma;
+            }
+            max_lk = m;
+            max_als = __shfl(als, mi);
+            if (m == -HUGE_VAL) max_als = 0;
+            double e = lk_add != -HUGE_VAL ? exp(lk_add - ma) : 0.0;
+            e = wsum(e);
+            lk_sum = ma != -HUGE_VAL ? ma + log(e) : -HUGE_VAL;
+            __syncthreads();
+            ref_lk = sh.ref_cur;
+        }
+        if (tid == 0) {
             int n = 0;
             for (int i = 0; i < nals; i++) if (max_als & 1 << i) n++;
             sh.als_new |= max_als;
@@ -556,14 +573,15 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
     for (int s = tid; s < ((P.ablate & 32) ? 0 : S); s += WGS) {
         int pl[NG]; double pdg[NG];
         load_pl<NG>(P, is, s, ngts, pl);
-        const double psum = set_pdg_one<NG>(s_pl2p, pl, pdg, ngts, nals, unseen, s_fill + tid);
+        const double psum = set_pdg_one<NG>(FAST ? s_p2 : s_pl2p, pl, pdg, ngts, nals, unseen, s_fill + tid);
         const int ploidy = P.ploidy ? P.ploidy[s] : 2;
         // pdg = raw/psum is formed lazily below, with the same division the reference performs (bit-exact genotypes)
         bool allzero = true;
         #pragma unroll
         for (int k = 0; k < NG; ++k) {
             if (k < ngts && pdg[k] != 0.0) allzero = false;
-            s_pdg[k * WGS + tid] = pdg[k]; s_plc[k * WGS + tid] = pl[k]; s_gps[k * WGS + tid] = 0.f;
+            s_pdg[k * WGS + tid] = pdg[k]; s_plc[k * WGS + tid] = pl[k];
+            if (want_gqgp) s_gps[k * WGS + tid] = 0.f;
         }
         if (psum == 0.0) allzero = true;
         int g0, g1, gq = 0, gnals = 0;
