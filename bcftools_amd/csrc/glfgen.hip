@@ -58,35 +58,41 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 // (a small state machine: when the reads of the current key are used up, take the next set bit of the lane's
 // 128-bit key-presence mask and fetch its count).  s_cnt holds this lane's per-key counts, (mlo,mhi) the presence bits,
 // `n` selects the beta row of the lane, `left` is the number of reads of this base.
+// The state machine runs two reads ahead of the summation: the beta value (a gather from a 32 MB table, L2 latency)
+// and the fk factor (LDS) of read t+2 are requested before read t is added, in the reference's order.
 __device__ __forceinline__ double walk_keys(const uint32_t *s_cnt, uint64_t mlo, uint64_t mhi, const double *s_fk,
                                             const double *beta, int tid, int n, int left)
 {
-    int rem = 0, rev = 0;
+    int rem = 0, rev = 0, pleft = left;
     uint32_t cc = 0, w0 = 0, w1 = 0;
     const double *brow = beta + ((size_t)n << 8);
     const double *bp = brow;
     double bs = 0;
-    #define WALK_ADVANCE() do { \
-        uint32_t key; \
-        if (mhi) { const int k = 63 - __clzll((long long)mhi); mhi &= ~(1ull << k); key = k + 64; } \
-        else     { const int k = 63 - __clzll((long long)mlo); mlo &= ~(1ull << k); key = k; } \
-        rem = (int)((s_cnt[(key >> 2) * WG + tid] >> (8 * (key & 3))) & 0xff); \
-        rev = key & 1; \
-        bp = brow + ((size_t)(key >> 1) << 16); } while (0)
-    // the beta value of the next read is requested one step ahead of its use
-    double nxt = 0.;
-    if (left > 0) { WALK_ADVANCE(); nxt = bp[0]; }
+    #define WALK_PRODUCE(bv, fv) do { \
+        if (pleft > 0) { \
+            if (rem == 0) { \
+                uint32_t key; \
+                if (mhi) { const int k = 63 - __clzll((long long)mhi); mhi &= ~(1ull << k); key = k + 64; } \
+                else     { const int k = 63 - __clzll((long long)mlo); mlo &= ~(1ull << k); key = k; } \
+                rem = (int)((s_cnt[(key >> 2) * WG + tid] >> (8 * (key & 3))) & 0xff); \
+                rev = key & 1; \
+                bp = brow + ((size_t)(key >> 1) << 16); \
+            } \
+            bv = bp[cc]; \
+            fv = s_fk[rev ? w1 : w0]; \
+            ++cc; w1 += rev; w0 += 1 - rev; --rem; --pleft; \
+        } } while (0)
+    #define WALK_CONSUME(bv, fv) do { if (left > 0) { bs += fv * bv; --left; } } while (0)
+    double bx = 0., fx = 0., by = 0., fy = 0., bz = 0., fz = 0.;
+    WALK_PRODUCE(bx, fx);
+    WALK_PRODUCE(by, fy);
     while (__any(left > 0)) {
-        if (left > 0) {
-            const double cur = nxt;
-            const double f = s_fk[rev ? w1 : w0];
-            ++cc; w1 += rev; w0 += 1 - rev;
-            --rem; --left;
-            if (left > 0) { if (rem == 0) WALK_ADVANCE(); nxt = bp[cc]; }
-            bs += f * cur;
-        }
+        WALK_PRODUCE(bz, fz); WALK_CONSUME(bx, fx);
+        WALK_PRODUCE(bx, fx); WALK_CONSUME(by, fy);
+        WALK_PRODUCE(by, fy); WALK_CONSUME(bz, fz);
     }
-    #undef WALK_ADVANCE
+    #undef WALK_PRODUCE
+    #undef WALK_CONSUME
     return bs;
 }
 
@@ -185,54 +191,68 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
         uint32_t h59 = 0;            // reads with mapQ>=59: ref | alt<<8 | fwd<<16 | rev<<24
         int n = 0, n_other = 0;
         bool fail = false;
-        // the next record is fetched while the current one is processed (the in-place writes below stay behind index i)
-        uint32_t w_nx = cnt_raw ? s_rd[lbeg] : 0;
-        int ep_nx = (cnt_raw && want_epos) ? s_ep[ebeg] : 0;
+        // The loop body is written without early exits: one predicate (`ok`) guards a single divergent region, and the
+        // per-base updates are selects, because a wavefront pays for every branch any of its lanes takes.
+        // The next record is fetched while the current one is processed (the in-place writes below stay behind index i;
+        // the read one past the slice stays inside the staged span's slack).
+        uint32_t w_nx = s_rd[lbeg];
+        int ep_nx = want_epos ? s_ep[ebeg] : 0;
         for (uint32_t i = 0; i < cnt_raw; ++i) {
             const uint32_t w = w_nx;
-            const int ep_cur = ep_nx;
-            if (i + 1 < cnt_raw) { w_nx = s_rd[lbeg + i + 1]; if (want_epos) ep_nx = s_ep[ebeg + i + 1]; }
-            if (w & BCFGPU_RD_SKIP) continue;
-            if (!INDEL && (w & BCFGPU_RD_DEL)) continue;
-            ++ori_depth;
+            const int ep = ep_nx;
+            w_nx = s_rd[lbeg + i + 1];
+            if (want_epos) ep_nx = s_ep[ebeg + i + 1];
             const int nt = (w >> 16) & 15;
             const uint32_t rev = (w >> 20) & 1;
             int q, b, baseQ, seqQ;
+            bool ok;
             if (INDEL) {
                 const uint32_t ax = P.aux[beg + i];
                 b = (ax >> 16) & 0xf;                 // 0..4 after bcf_call_gap_prep (bam2bcf_indel.c:449-456)
                 baseQ = q = ax & 0xff;
                 if (q < min_baseQ) { b = 0; q = (int)(w & 0xff); }
                 seqQ = (ax >> 8) & 0xff;
+                ok = !(w & BCFGPU_RD_SKIP);
+                ori_depth += ok;
             } else {
                 b = nt16_int(nt ? nt : ref_base);
                 baseQ = q = (int)(w & 0xff);
-                if (q < min_baseQ) continue;
                 seqQ = 99;
+                const bool seen = !(w & (BCFGPU_RD_SKIP | BCFGPU_RD_DEL));
+                ori_depth += seen;
+                ok = seen && q >= min_baseQ;
             }
+            if (ok && n >= BCFGPU_MAX_DEPTH) { fail = true; ok = false; }
+            if (!ok) continue;
             int mapQ = (w >> 8) & 0xff;
             if (mapQ == 255) mapQ = DEF_MAPQ;
             mq0 += (mapQ == 0);
             q = min(q, seqQ);
             mapQ = min(mapQ, capQ);
             q = max(min(min(q, mapQ), 63), 4);
-            if (n >= BCFGPU_MAX_DEPTH) { fail = true; break; }
             ++n;
             n_rev += rev;
             const int min_dist = min((int)(w >> 24), CAP_DIST);
             const uint32_t key = (uint32_t)(q << 1) | rev;       // (code>>4)&0x7f of bam2bcf.c:203
-            if (b == primary) {
-                atomicAdd(&s_cnt[(key >> 2) * WG + tid], 1u << (8 * (key & 3)));     // ds_add_u32: no round trip
-                if (key < 64) mlo |= 1ull << key; else mhi |= 1ull << (key - 64);
-            } else {
+            const bool prim = (b == primary);
+            // ds_add_u32 without a round trip; a non-primary read adds 0 instead of branching around the atomic
+            atomicAdd(&s_cnt[(key >> 2) * WG + tid], (prim ? 1u : 0u) << (8 * (key & 3)));
+            {
+                const uint64_t bit = (uint64_t)(prim ? 1u : 0u) << (key & 63);
+                mlo |= key < 64 ? bit : 0ull;
+                mhi |= key < 64 ? 0ull : bit;
+            }
+            if (!prim) {
                 s_rd[lbeg + n_other] = OW_PACK(baseQ, mapQ, q, b, rev, min_dist);    // n_other <= i: behind the reader
                 ++n_other;
             }
             if (want_scr) scr += (w >> 21) & 1;
-            if (b < 4) {
-                qs64 += (uint64_t)q << (16 * b);
-                ad64 += 1ull << (8 * b + 32 * rev);
-            } else n_b4++;
+            {
+                const bool b4 = b >= 4;
+                qs64 += (uint64_t)(b4 ? 0 : q) << (16 * (b & 3));
+                ad64 += (uint64_t)(b4 ? 0u : 1u) << (8 * (b & 3) + 32 * rev);
+                n_b4 += b4;
+            }
             t_bqmd += (uint32_t)baseQ | (uint32_t)min_dist << 16;
             t_mq += mapQ;
             t_bq2 += baseQ * baseQ; t_mq2 += mapQ * mapQ; t_md2 += min_dist * min_dist;
@@ -240,7 +260,6 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
             if (P.ablate & 1) continue;
             const int ibq = min(baseQ, 59);
             const int imq = min(mapQ, 59);
-            const int ep = ep_cur;
             const bool isref = (nt == ref_base);
             if (imq == 59) h59 += (isref ? 1u : 1u << 8) + (rev ? 1u << 24 : 1u << 16);
             else {
