@@ -151,24 +151,50 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
         const uint32_t ebase = base & ~15u;                      // 16-byte aligned start of the u8 stream
         const uint32_t lim = min(abase + (uint32_t)cap, span_end);
         {
+            // all loads of a batch are in flight before the first LDS store: one memory round trip per 8 (4) vectors
             const uint32_t nvec = (lim - abase + 3) >> 2;
             const uint4 *src = reinterpret_cast<const uint4*>(P.rd + abase);
             uint4 *dst = reinterpret_cast<uint4*>(s_rd);
-            for (uint32_t v = tid; v < nvec; v += WG) {
-                if (abase + 4 * v + 3 < n_reads_tot) dst[v] = src[v];
-                else {
-                    uint32_t t4[4] = {0, 0, 0, 0};
-                    for (int k = 0; k < 4; ++k) if (abase + 4 * v + k < n_reads_tot) t4[k] = P.rd[abase + 4 * v + k];
-                    dst[v] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+            for (uint32_t v0 = tid; v0 < nvec; v0 += 8 * WG) {
+                uint4 r[8];
+                #pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t v = v0 + k * WG;
+                    r[k] = make_uint4(0, 0, 0, 0);
+                    if (v < nvec) {
+                        if (abase + 4 * v + 3 < n_reads_tot) r[k] = src[v];
+                        else {
+                            uint32_t t4[4] = {0, 0, 0, 0};
+                            for (int j = 0; j < 4; ++j) if (abase + 4 * v + j < n_reads_tot) t4[j] = P.rd[abase + 4 * v + j];
+                            r[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                        }
+                    }
                 }
+                #pragma unroll
+                for (int k = 0; k < 8; ++k) { const uint32_t v = v0 + k * WG; if (v < nvec) dst[v] = r[k]; }
             }
             if (want_epos) {
                 const uint32_t nv16 = (lim - ebase + 15) >> 4;
                 const uint4 *es = reinterpret_cast<const uint4*>(P.epos + ebase);
                 uint4 *ed = reinterpret_cast<uint4*>(s_ep);
-                for (uint32_t v = tid; v < nv16; v += WG) {
-                    if (ebase + 16 * v + 15 < n_reads_tot) ed[v] = es[v];
-                    else for (int k = 0; k < 16; ++k) s_ep[16 * v + k] = (ebase + 16 * v + k < n_reads_tot) ? P.epos[ebase + 16 * v + k] : 0;
+                for (uint32_t v0 = tid; v0 < nv16; v0 += 4 * WG) {
+                    uint4 r[4];
+                    #pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t v = v0 + k * WG;
+                        r[k] = make_uint4(0, 0, 0, 0);
+                        if (v < nv16) {
+                            if (ebase + 16 * v + 15 < n_reads_tot) r[k] = es[v];
+                            else {
+                                uint32_t t4[4] = {0, 0, 0, 0};
+                                for (int j = 0; j < 16; ++j)
+                                    if (ebase + 16 * v + j < n_reads_tot) t4[j >> 2] |= (uint32_t)P.epos[ebase + 16 * v + j] << (8 * (j & 3));
+                                r[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+                            }
+                        }
+                    }
+                    #pragma unroll
+                    for (int k = 0; k < 4; ++k) { const uint32_t v = v0 + k * WG; if (v < nv16) ed[v] = r[k]; }
                 }
             }
         }
@@ -223,44 +249,54 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
                 ok = seen && q >= min_baseQ;
             }
             if (ok && n >= BCFGPU_MAX_DEPTH) { fail = true; ok = false; }
-            if (!ok) continue;
+            // register accumulators: unconditional arithmetic, a rejected read contributes zeros
+            const uint32_t okm = ok ? 1u : 0u;
             int mapQ = (w >> 8) & 0xff;
             if (mapQ == 255) mapQ = DEF_MAPQ;
-            mq0 += (mapQ == 0);
+            mq0 += (mapQ == 0) & okm;
             q = min(q, seqQ);
             mapQ = min(mapQ, capQ);
             q = max(min(min(q, mapQ), 63), 4);
-            ++n;
-            n_rev += rev;
+            n += okm;
+            n_rev += rev & okm;
             const int min_dist = min((int)(w >> 24), CAP_DIST);
             const uint32_t key = (uint32_t)(q << 1) | rev;       // (code>>4)&0x7f of bam2bcf.c:203
-            const bool prim = (b == primary);
-            // ds_add_u32 without a round trip; a non-primary read adds 0 instead of branching around the atomic
-            atomicAdd(&s_cnt[(key >> 2) * WG + tid], (prim ? 1u : 0u) << (8 * (key & 3)));
+            const bool prim = ok && (b == primary);
             {
                 const uint64_t bit = (uint64_t)(prim ? 1u : 0u) << (key & 63);
                 mlo |= key < 64 ? bit : 0ull;
                 mhi |= key < 64 ? 0ull : bit;
             }
+            if (want_scr) scr += (w >> 21) & okm;
+            {
+                const bool b4 = b >= 4;
+                const bool acgt = ok && !b4;
+                qs64 += (uint64_t)(acgt ? q : 0) << (16 * (b & 3));
+                ad64 += (uint64_t)(acgt ? 1u : 0u) << (8 * (b & 3) + 32 * rev);
+                n_b4 += (ok && b4);
+            }
+            {
+                const uint32_t bq = ok ? (uint32_t)baseQ : 0u, mq = ok ? (uint32_t)mapQ : 0u, md = ok ? (uint32_t)min_dist : 0u;
+                t_bqmd += bq | md << 16;
+                t_mq += mq;
+                t_bq2 += bq * bq; t_mq2 += mq * mq; t_md2 += md * md;
+            }
+            const int ibq = min(baseQ, 59);
+            const int imq = min(mapQ, 59);
+            const bool isref = (nt == ref_base);
+            // All LDS updates of the read come last, after the prefetched next record has arrived: LDS operations
+            // complete in order, so waiting for that record any later would also wait for these atomics.
+            asm volatile("" : "+v"(qs64), "+v"(ad64), "+v"(t_bq2), "+v"(t_mq2), "+v"(t_md2), "+v"(mlo), "+v"(mhi)
+                            : "v"(w_nx), "v"(ep_nx) : "memory");
+            if (!ok) continue;
+            // ds_add_u32 without a round trip; a non-primary read adds 0 instead of branching around the atomic
+            atomicAdd(&s_cnt[(key >> 2) * WG + tid], (prim ? 1u : 0u) << (8 * (key & 3)));
             if (!prim) {
                 s_rd[lbeg + n_other] = OW_PACK(baseQ, mapQ, q, b, rev, min_dist);    // n_other <= i: behind the reader
                 ++n_other;
             }
-            if (want_scr) scr += (w >> 21) & 1;
-            {
-                const bool b4 = b >= 4;
-                qs64 += (uint64_t)(b4 ? 0 : q) << (16 * (b & 3));
-                ad64 += (uint64_t)(b4 ? 0u : 1u) << (8 * (b & 3) + 32 * rev);
-                n_b4 += b4;
-            }
-            t_bqmd += (uint32_t)baseQ | (uint32_t)min_dist << 16;
-            t_mq += mapQ;
-            t_bq2 += baseQ * baseQ; t_mq2 += mapQ * mapQ; t_md2 += min_dist * min_dist;
             // bias-test histograms: ibq = (int)(baseQ/60.*60) is the identity on 0..59 (checked in tests)
             if (P.ablate & 1) continue;
-            const int ibq = min(baseQ, 59);
-            const int imq = min(mapQ, 59);
-            const bool isref = (nt == ref_base);
             if (imq == 59) h59 += (isref ? 1u : 1u << 8) + (rev ? 1u << 24 : 1u << 16);
             else {
                 HIST_ADD((rev ? H_REV_MQS : H_FWD_MQS) + imq, 1);
