@@ -137,6 +137,96 @@ struct SiteShared {
     float bias[6];
 };
 
+// Sequential sums in the reference's order (they decide allele order and the PL shift, so they are not tree-reduced).
+// One lane walks an LDS array; the next 16 values are requested while the current 16 are added, so the chain runs at
+// the latency of the dependent adds rather than that of the LDS.
+__device__ __forceinline__ float seq_sum_f32(float acc, const float *v, int n)
+{
+    const float4 *q = reinterpret_cast<const float4*>(v);
+    const int nb = n >> 4;
+    float4 c0, c1, c2, c3;
+    if (nb > 0) { c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3]; }
+    for (int b = 0; b < nb; ++b) {
+        const float4 a0 = c0, a1 = c1, a2 = c2, a3 = c3;
+        if (b + 1 < nb) { c0 = q[4 * b + 4]; c1 = q[4 * b + 5]; c2 = q[4 * b + 6]; c3 = q[4 * b + 7]; }
+        acc += a0.x; acc += a0.y; acc += a0.z; acc += a0.w; acc += a1.x; acc += a1.y; acc += a1.z; acc += a1.w;
+        acc += a2.x; acc += a2.y; acc += a2.z; acc += a2.w; acc += a3.x; acc += a3.y; acc += a3.z; acc += a3.w;
+    }
+    for (int i = nb << 4; i < n; ++i) acc += v[i];
+    return acc;
+}
+__device__ __forceinline__ double seq_sum_f64(double acc, const float *v, int n)
+{
+    const float4 *q = reinterpret_cast<const float4*>(v);
+    const int nb = n >> 4;
+    float4 c0, c1, c2, c3;
+    if (nb > 0) { c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3]; }
+    for (int b = 0; b < nb; ++b) {
+        const float4 a0 = c0, a1 = c1, a2 = c2, a3 = c3;
+        if (b + 1 < nb) { c0 = q[4 * b + 4]; c1 = q[4 * b + 5]; c2 = q[4 * b + 6]; c3 = q[4 * b + 7]; }
+        acc += a0.x; acc += a0.y; acc += a0.z; acc += a0.w; acc += a1.x; acc += a1.y; acc += a1.z; acc += a1.w;
+        acc += a2.x; acc += a2.y; acc += a2.z; acc += a2.w; acc += a3.x; acc += a3.y; acc += a3.z; acc += a3.w;
+    }
+    for (int i = nb << 4; i < n; ++i) acc += v[i];
+    return acc;
+}
+
+struct SampleTotals { uint32_t adf[5], adr[5], scr, ori, mq0, cnt[4]; };
+
+// The per-sample outputs of bcf_call_combine for one chunk of samples of a site with NAL alleles (NAL = 0: a dead indel
+// site, totals only): PL from the NAL(NAL+1)/2 genotype likelihoods in allele order (bam2bcf.c:634-651), DP4, AD/ADF/ADR,
+// QS, SCR planes, per-lane integer totals, and each sample's minimum for the sequential sum_min.
+template <int NAL>
+__device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTotals &T, const int (&gs)[15], const int (&as)[5],
+                                              int is, long c0, int base, int cn, int tid, long ncells, float *s_min)
+{
+    constexpr int X = NAL * (NAL + 1) / 2;
+    const size_t Ss = (size_t)P.n_smpl;
+    for (int i = tid; i < cn; i += WG) {
+        const int s = base + i;
+        const long cell = c0 + s;
+        float mn = 0.f;
+        if (NAL > 0) {
+            float pv[X > 0 ? X : 1];
+            mn = FLT_MAX;
+            #pragma unroll
+            for (int j = 0; j < X; ++j) { pv[j] = (P.cr.p15 + (size_t)gs[j] * ncells + c0)[s]; if (mn > pv[j]) mn = pv[j]; }
+            uint8_t *PL = P.out.pl + (size_t)is * BCFGPU_MAX_PL * Ss + s;
+            #pragma unroll
+            for (int j = 0; j < X; ++j) {
+                int y = (int)((double)(pv[j] - mn) + .499);
+                if (y > 255) y = 255;
+                PL[(size_t)j * Ss] = (uint8_t)y;
+            }
+        }
+        s_min[i] = mn;
+        const uint32_t cnt4 = P.cr.cnt4[cell], adf = P.cr.adf[cell], adr = P.cr.adr[cell], misc = P.cr.misc[cell];
+        if (NAL > 0 && !(P.ablate & 512)) {
+            uint8_t *DP4 = P.out.dp4 + (size_t)is * 4 * Ss + s;
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) DP4[(size_t)j * Ss] = (uint8_t)((cnt4 >> (8 * j)) & 0xff);
+            const uint32_t scr = (misc >> 8) & 0xff;
+            if (P.out.scr) P.out.scr[(size_t)is * Ss + s] = (uint8_t)scr;
+            T.scr += scr;
+            unsigned long long qs64 = 0;
+            if (P.out.qs) qs64 = P.cr.qs64[cell];
+            #pragma unroll
+            for (int j = 0; j < NAL; ++j) {
+                const int aj = as[j];                         // scalar
+                const uint32_t vf = aj < 4 ? (adf >> (8 * aj)) & 0xff : 0;
+                const uint32_t vr = aj < 4 ? (adr >> (8 * aj)) & 0xff : 0;
+                T.adf[j] += vf; T.adr[j] += vr;
+                if (P.out.adf) P.out.adf[((size_t)is * 5 + j) * Ss + s] = (uint8_t)vf;
+                if (P.out.adr) P.out.adr[((size_t)is * 5 + j) * Ss + s] = (uint8_t)vr;
+                if (P.out.qs) P.out.qs[((size_t)is * 5 + j) * Ss + s] = (uint16_t)(aj < 4 ? (qs64 >> (16 * aj)) & 0xffff : 0);
+            }
+        }
+        T.ori += misc >> 16; T.mq0 += misc & 0xff;
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) T.cnt[j] += (cnt4 >> (8 * j)) & 0xff;
+    }
+}
+
 __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
 {
     __shared__ SiteShared sh;
@@ -160,9 +250,10 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
     // ---- qsum (bam2bcf.c:569-575): every thread normalises its samples' QS in parallel, then lane j of
     // wave 0 adds allele j's fractions in sample order (a sequential float32 sum, as in the reference) ----
     float myq = 0.f;
-    float4 *s_frac = reinterpret_cast<float4*>(s_stage);
-    for (int base = 0; base < S; base += CHUNK / 2) {
-        const int cn = min(CHUNK / 2, S - base);
+    float *s_frt = reinterpret_cast<float*>(s_stage);          // [4 alleles][CHUNK/2] normalised QS of the staged samples
+    constexpr int HC = CHUNK / 2;
+    for (int base = 0; base < S; base += HC) {
+        const int cn = min(HC, S - base);
         __syncthreads();
         for (int i = tid; i < cn; i += WG) {
             const unsigned long long v = P.cr.qs64[c0 + base + i];
@@ -172,19 +263,11 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
             sum += q0; sum += q1; sum += q2; sum += q3;
             float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
             if (sum != 0.f) f = make_float4(q0 / sum, q1 / sum, q2 / sum, q3 / sum);
-            s_frac[i] = f;             // adding +0 for empty samples leaves the running sum unchanged
+            // adding +0 for empty samples leaves the running sum unchanged
+            s_frt[i] = f.x; s_frt[HC + i] = f.y; s_frt[2 * HC + i] = f.z; s_frt[3 * HC + i] = f.w;
         }
         __syncthreads();
-        if (tid < 4 && !(P.ablate & 8192)) {
-            const float *fr = reinterpret_cast<const float*>(s_frac) + tid;
-            int i = 0;
-            for (; i + 8 <= cn; i += 8) {
-                const float a0 = fr[4 * i], a1 = fr[4 * i + 4], a2 = fr[4 * i + 8], a3 = fr[4 * i + 12];
-                const float a4 = fr[4 * i + 16], a5 = fr[4 * i + 20], a6 = fr[4 * i + 24], a7 = fr[4 * i + 28];
-                myq += a0; myq += a1; myq += a2; myq += a3; myq += a4; myq += a5; myq += a6; myq += a7;
-            }
-            for (; i < cn; ++i) myq += fr[4 * i];
-        }
+        if (tid < 4 && !(P.ablate & 8192)) myq = seq_sum_f32(myq, s_frt + tid * HC, cn);
     }
     if (tid < 4) s_q[tid] = myq;
     __syncthreads();
@@ -229,74 +312,34 @@ __global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
 
     // ---- per-sample planes + integer totals ----
     // per-lane partial totals (u32 is ample: a lane sees S/64 samples of <=255 reads); anno[4..15] arrive as site totals
-    uint32_t t_adf[5] = {0,0,0,0,0}, t_adr[5] = {0,0,0,0,0};
-    uint32_t t_scr = 0, t_ori = 0, t_mq0 = 0, t_cnt[4] = {0,0,0,0};
-    const size_t Ss = (size_t)S;
+    SampleTotals T;
+    #pragma unroll
+    for (int j = 0; j < 5; ++j) T.adf[j] = T.adr[j] = 0;
+    T.scr = T.ori = T.mq0 = 0; T.cnt[0] = T.cnt[1] = T.cnt[2] = T.cnt[3] = 0;
+    // the allele order is uniform over the wavefront: keep it in scalar registers so that plane addresses are scalar
+    int gs[15], as[5];
+    #pragma unroll
+    for (int j = 0; j < 15; ++j) gs[j] = __builtin_amdgcn_readfirstlane(j < x ? sh.g[j] : 0);
+    #pragma unroll
+    for (int j = 0; j < 5; ++j) as[j] = __builtin_amdgcn_readfirstlane(j < nal ? sh.a[j] : 4);
+    float *s_min = reinterpret_cast<float*>(s_stage);
     for (int base = 0; base < S; base += CHUNK) {
         const int cn = min(CHUNK, S - base);
         __syncthreads();
-        float *s_min = reinterpret_cast<float*>(s_stage);
-        for (int i = tid; i < cn; i += WG) {
-            const int s = base + i;
-            const long cell = c0 + s;
-            float mn = 0.f;
-            if (!dead && !(P.ablate & 256)) {
-                float pv[15];
-                mn = FLT_MAX;
-                #pragma unroll
-                for (int j = 0; j < 15; ++j) {
-                    if (j < x) { pv[j] = P.cr.p15[(size_t)sh.g[j] * ncells + cell]; if (mn > pv[j]) mn = pv[j]; }
-                }
-                uint8_t *PL = P.out.pl + (size_t)is * BCFGPU_MAX_PL * Ss + s;
-                #pragma unroll
-                for (int j = 0; j < 15; ++j) {
-                    if (j < x) {
-                        int y = (int)((double)(pv[j] - mn) + .499);
-                        if (y > 255) y = 255;
-                        PL[(size_t)j * Ss] = (uint8_t)y;
-                    }
-                }
-            }
-            s_min[i] = mn;
-            const uint32_t cnt4 = P.cr.cnt4[cell], adf = P.cr.adf[cell], adr = P.cr.adr[cell], misc = P.cr.misc[cell];
-            const unsigned long long qs64 = P.cr.qs64[cell];
-            if (!dead && !(P.ablate & 512)) {
-                uint8_t *DP4 = P.out.dp4 + (size_t)is * 4 * Ss + s;
-                #pragma unroll
-                for (int j = 0; j < 4; ++j) DP4[(size_t)j * Ss] = (uint8_t)((cnt4 >> (8 * j)) & 0xff);
-                const uint32_t scr = (misc >> 8) & 0xff;
-                if (P.out.scr) P.out.scr[(size_t)is * Ss + s] = (uint8_t)scr;
-                t_scr += scr;
-                #pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    if (j < nal) {
-                        const int aj = sh.a[j];
-                        const uint32_t vf = aj < 4 ? (adf >> (8 * aj)) & 0xff : 0;
-                        const uint32_t vr = aj < 4 ? (adr >> (8 * aj)) & 0xff : 0;
-                        t_adf[j] += vf; t_adr[j] += vr;
-                        if (P.out.adf) P.out.adf[((size_t)is * 5 + j) * Ss + s] = (uint8_t)vf;
-                        if (P.out.adr) P.out.adr[((size_t)is * 5 + j) * Ss + s] = (uint8_t)vr;
-                        if (P.out.qs) P.out.qs[((size_t)is * 5 + j) * Ss + s] = (uint16_t)(aj < 4 ? (qs64 >> (16 * aj)) & 0xffff : 0);
-                    }
-                }
-            }
-            t_ori += misc >> 16; t_mq0 += misc & 0xff;
-            #pragma unroll
-            for (int j = 0; j < 4; ++j) t_cnt[j] += (cnt4 >> (8 * j)) & 0xff;
+        const bool live = !dead && !(P.ablate & 256);
+        switch (live ? nal : 0) {
+            case 1: sample_planes<1>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break;
+            case 2: sample_planes<2>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break;
+            case 3: sample_planes<3>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break;
+            case 4: sample_planes<4>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break;
+            case 5: sample_planes<5>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break;
+            default: sample_planes<0>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break;
         }
         __syncthreads();
-        if (tid == 0 && !dead && !(P.ablate & 8192)) {          // sum_min: sequential double sum (bam2bcf.c:642)
-            double sm = sh.sum_min;
-            int i = 0;
-            for (; i + 8 <= cn; i += 8) {
-                const float m0 = s_min[i], m1 = s_min[i + 1], m2 = s_min[i + 2], m3 = s_min[i + 3];
-                const float m4 = s_min[i + 4], m5 = s_min[i + 5], m6 = s_min[i + 6], m7 = s_min[i + 7];
-                sm += m0; sm += m1; sm += m2; sm += m3; sm += m4; sm += m5; sm += m6; sm += m7;
-            }
-            for (; i < cn; ++i) sm += s_min[i];
-            sh.sum_min = sm;
-        }
+        if (tid == 0 && !dead && !(P.ablate & 8192)) sh.sum_min = seq_sum_f64(sh.sum_min, s_min, cn);   // bam2bcf.c:642
     }
+    uint32_t (&t_adf)[5] = T.adf; uint32_t (&t_adr)[5] = T.adr; uint32_t (&t_cnt)[4] = T.cnt;
+    const uint32_t t_scr = T.scr, t_ori = T.ori, t_mq0 = T.mq0;
     // wave reductions of the integer totals, then one LDS atomic per wave
     {
         unsigned long long v;

@@ -45,25 +45,61 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
     return v;
 }
 
-// LDS layout (bytes): fk[264] f64 | cnt[32][WG] u32 | rd[cap+4] u32 | epos[cap+32] u8 | hist | site totals
+// LDS layout (bytes): fk[264] f64 | slots[4][WG] u32 | rd[cap+4] u32 | epos[cap+32] u8 | hist | site totals
 #define LDS_FK   0
 #define LDS_CNT  2112
-#define LDS_RD   (LDS_CNT + 32 * WG * 4)
+#define NSLOT    16
+#define LDS_RD   (LDS_CNT + (NSLOT / 4) * WG * 4)
 
 // packed "other" (non-primary = diff) read: baseQ:8 | mapQ(capped):6 | q:6 | b:4 | rev:1 | min_dist:5
 #define OW_PACK(baseQ, mapQ, q, b, rev, md) \
     ((uint32_t)(baseQ) | (uint32_t)(mapQ) << 8 | (uint32_t)(q) << 14 | (uint32_t)(b) << 20 | (uint32_t)(rev) << 24 | (uint32_t)(md) << 25)
 
-// Descending walk of errmod_cal for one base: every lane steps through its own reads from the highest key7 down
-// (a small state machine: when the reads of the current key are used up, take the next set bit of the lane's
-// 128-bit key-presence mask and fetch its count).  s_cnt holds this lane's per-key counts, (mlo,mhi) the presence bits,
-// `n` selects the beta row of the lane, `left` is the number of reads of this base.
+// Number of set bits of the 128-bit mask (lo,hi) above bit `key`, and membership of `key`.
+__device__ __forceinline__ int rank_above(uint64_t lo, uint64_t hi, uint32_t key)
+{
+    const bool up = key >= 64;
+    const uint64_t h = up ? (hi >> (key & 63)) >> 1 : hi;
+    const uint64_t l = up ? 0ull : (lo >> (key & 63)) >> 1;
+    return __popcll(h) + __popcll(l);
+}
+__device__ __forceinline__ bool has_key(uint64_t lo, uint64_t hi, uint32_t key)
+{
+    return (((key >= 64 ? hi : lo) >> (key & 63)) & 1ull) != 0;
+}
+
+// Counts of the NSLOT highest keys of the mask (lo,hi), in descending key order, as u8 in the lane's slot column:
+// slot r counts the source's reads whose key has rank r.  `src(j)` returns the key7 of source element j or -1.
+template <class Src>
+__device__ __forceinline__ void fill_slots(uint32_t *s_slot, uint64_t lo, uint64_t hi, int tid, Src src, int nsrc)
+{
+    #pragma unroll
+    for (int k = 0; k < NSLOT / 4; ++k) s_slot[k * WG + tid] = 0;
+    for (int j = 0; __any(j < nsrc); ++j) {
+        if (j < nsrc) {
+            const int key = src(j);
+            if (key >= 0 && has_key(lo, hi, (uint32_t)key)) {
+                const int r = rank_above(lo, hi, (uint32_t)key);
+                if (r < NSLOT) atomicAdd(&s_slot[(r >> 2) * WG + tid], 1u << (8 * (r & 3)));
+            }
+        }
+    }
+}
+
+// Descending walk of errmod_cal for one base: every lane steps through its own reads from the highest key7 down.
+// errmod_cal sorts the codes; here the lane's keys are the set bits of its 128-bit presence mask (mlo,mhi) and the
+// number of reads per key sits in NSLOT rank-ordered u8 slots (a 128-entry table per lane would halve the occupancy).
+// A small state machine: when the reads of the current key are used up, take the next set bit and the next slot; a
+// lane with more than NSLOT distinct keys refills its slots from the source for the remaining keys (rare: binned
+// base qualities give a handful of keys).  `n` selects the beta row of the lane, `left` is the number of reads.
 // The state machine runs two reads ahead of the summation: the beta value (a gather from a 32 MB table, L2 latency)
 // and the fk factor (LDS) of read t+2 are requested before read t is added, in the reference's order.
-__device__ __forceinline__ double walk_keys(const uint32_t *s_cnt, uint64_t mlo, uint64_t mhi, const double *s_fk,
-                                            const double *beta, int tid, int n, int left)
+template <class Src>
+__device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t mlo, uint64_t mhi, const double *s_fk,
+                                            const double *beta, int tid, int n, int left, Src src, int nsrc)
 {
-    int rem = 0, rev = 0, pleft = left;
+    fill_slots(s_slot, mlo, mhi, tid, src, nsrc);
+    int rem = 0, rev = 0, pleft = left, r = 0;
     uint32_t cc = 0, w0 = 0, w1 = 0;
     const double *brow = beta + ((size_t)n << 8);
     const double *bp = brow;
@@ -71,10 +107,12 @@ __device__ __forceinline__ double walk_keys(const uint32_t *s_cnt, uint64_t mlo,
     #define WALK_PRODUCE(bv, fv) do { \
         if (pleft > 0) { \
             if (rem == 0) { \
+                if (r == NSLOT) { fill_slots(s_slot, mlo, mhi, tid, src, nsrc); r = 0; } \
                 uint32_t key; \
                 if (mhi) { const int k = 63 - __clzll((long long)mhi); mhi &= ~(1ull << k); key = k + 64; } \
                 else     { const int k = 63 - __clzll((long long)mlo); mlo &= ~(1ull << k); key = k; } \
-                rem = (int)((s_cnt[(key >> 2) * WG + tid] >> (8 * (key & 3))) & 0xff); \
+                rem = (int)((s_slot[(r >> 2) * WG + tid] >> (8 * (r & 3))) & 0xff); \
+                ++r; \
                 rev = key & 1; \
                 bp = brow + ((size_t)(key >> 1) << 16); \
             } \
@@ -207,15 +245,13 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
         const uint32_t cnt_raw = (part && !(P.ablate & 4)) ? end - beg : 0;
 
         // ---- pass 0: the per-read loop of bcf_call_glfgen (bam2bcf.c:170-253) ----
-        #pragma unroll
-        for (int k = 0; k < 32; ++k) s_cnt[k * WG + tid] = 0;
         uint64_t mlo = 0, mhi = 0;   // key7 presence bits of the primary base
         uint64_t qs64 = 0;           // QS[0..3], 16 bits each
         uint64_t ad64 = 0;           // ADF[0..3] | ADR[0..3]<<32, 8 bits each
         uint32_t mq0 = 0, scr = 0, ori_depth = 0, n_rev = 0, n_b4 = 0;
         uint32_t t_bqmd = 0, t_mq = 0, t_bq2 = 0, t_mq2 = 0, t_md2 = 0;   // totals: baseQ | min_dist<<16, mapQ, squares
         uint32_t h59 = 0;            // reads with mapQ>=59: ref | alt<<8 | fwd<<16 | rev<<24
-        int n = 0, n_other = 0;
+        int n = 0, n_other = 0, n_prim = 0;
         bool fail = false;
         // The loop body is written without early exits: one predicate (`ok`) guards a single divergent region, and the
         // per-base updates are selects, because a wavefront pays for every branch any of its lanes takes.
@@ -289,9 +325,9 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
             asm volatile("" : "+v"(qs64), "+v"(ad64), "+v"(t_bq2), "+v"(t_mq2), "+v"(t_md2), "+v"(mlo), "+v"(mhi)
                             : "v"(w_nx), "v"(ep_nx) : "memory");
             if (!ok) continue;
-            // ds_add_u32 without a round trip; a non-primary read adds 0 instead of branching around the atomic
-            atomicAdd(&s_cnt[(key >> 2) * WG + tid], (prim ? 1u : 0u) << (8 * (key & 3)));
-            if (!prim) {
+            // the key of a primary read goes, compacted, into the lane's epos slice (byte n_prim <= i is behind the reader)
+            if (prim) { s_ep[ebeg + n_prim] = (uint8_t)key; ++n_prim; }
+            else {
                 s_rd[lbeg + n_other] = OW_PACK(baseQ, mapQ, q, b, rev, min_dist);    // n_other <= i: behind the reader
                 ++n_other;
             }
@@ -313,7 +349,7 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
         }
         if (fail || ori_depth > 0xffff) {
             atomicExch(P.err, BCFGPU_E_DEPTH);
-            n = 0; n_other = 0; qs64 = ad64 = 0; n_rev = n_b4 = 0; mlo = mhi = 0;
+            n = 0; n_other = 0; n_prim = 0; qs64 = ad64 = 0; n_rev = n_b4 = 0; mlo = mhi = 0;
         }
         // per-base counts c[0..4] (errmod_cal's aux.c)
         int c[5];
@@ -329,7 +365,9 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
             int cprim = 0;
             #pragma unroll
             for (int b = 0; b < 5; ++b) if (b == primary) cprim = c[b];
-            const double bs = walk_keys(s_cnt, mlo, mhi, s_fk, P.beta, tid, n, cprim);
+            const uint8_t *kb = s_ep + ebeg;                 // the lane's n_prim (= cprim) key bytes
+            const double bs = walk_keys(s_cnt, mlo, mhi, s_fk, P.beta, tid, n, cprim,
+                                        [kb](int j) { return (int)kb[j]; }, n_prim);
             #pragma unroll
             for (int b = 0; b < 5; ++b) if (b == primary) bsum[b] = bs;
         }
@@ -349,21 +387,23 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
             for (int b = 0; b < 5; ++b) {
                 const int cb = (b != primary) ? c[b] : 0;
                 if (skip_walk || !__any(cb > 0)) continue;
-                #pragma unroll
-                for (int k = 0; k < 32; ++k) s_cnt[k * WG + tid] = 0;
                 uint64_t lo = 0, hi = 0;
+                const uint32_t *ow_p = s_rd + lbeg;
+                // key7 of the lane's i-th other read if it shows base b, else -1
+                auto src = [ow_p, b](int i) {
+                    const uint32_t ow = ow_p[i];
+                    int bb = (ow >> 20) & 0xf;
+                    if (bb > 4) bb = 4;
+                    return bb == b ? (int)(((ow >> 14) & 0x3f) << 1 | ((ow >> 24) & 1)) : -1;
+                };
                 if (cb > 0) {
                     for (int i = 0; i < n_other; ++i) {
-                        const uint32_t ow = s_rd[lbeg + i];
-                        int bb = (ow >> 20) & 0xf;
-                        if (bb > 4) bb = 4;
-                        if (bb != b) continue;
-                        const uint32_t key = ((ow >> 14) & 0x3f) << 1 | ((ow >> 24) & 1);
-                        s_cnt[(key >> 2) * WG + tid] += 1u << (8 * (key & 3));
+                        const int key = src(i);
+                        if (key < 0) continue;
                         if (key < 64) lo |= 1ull << key; else hi |= 1ull << (key - 64);
                     }
                 }
-                const double bs = walk_keys(s_cnt, lo, hi, s_fk, P.beta, tid, n, cb);
+                const double bs = walk_keys(s_cnt, lo, hi, s_fk, P.beta, tid, n, cb, src, cb > 0 ? n_other : 0);
                 if (b != primary) bsum[b] = bs;      // lanes of one wave may belong to sites with different reference bases
             }
         }

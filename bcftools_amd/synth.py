@@ -20,7 +20,10 @@ BQ_PMF = np.array([.02, .05, .08, .35, .30, .20])
 READ_LEN = 150
 
 
-def numpy_tile(seed, n_sites, n_smpl, depth=30.0, var_rate=0.01, max_depth=200, ref_n_rate=0.0, mapq255_rate=0.0):
+def numpy_tile(seed, n_sites, n_smpl, depth=30.0, var_rate=0.01, max_depth=200, ref_n_rate=0.0, mapq255_rate=0.0,
+               wide_qual=False):
+    """`wide_qual`: unbinned base qualities (uniform 2..60) and uniform mapQ, i.e. many distinct (quality, strand)
+    keys per cell -- the case errmod's sort is there for."""
     rng = np.random.Generator(np.random.Philox(key=int(seed)))
     S = n_smpl
     ref2 = rng.integers(0, 4, n_sites)
@@ -39,11 +42,15 @@ def numpy_tile(seed, n_sites, n_smpl, depth=30.0, var_rate=0.01, max_depth=200, 
     site = cell // S
     strand = rng.integers(0, 2, R)
     bq = BQ_VALUES[rng.choice(len(BQ_VALUES), size=R, p=BQ_PMF)]
+    if wide_qual:
+        bq = rng.integers(2, 61, R)
     is_alt = rng.random(R) < nalt[cell] * 0.5
     base = np.where(is_alt, alt2[site], ref2[site])
     err = rng.random(R) < 10.0 ** (-bq / 10.0)
     base = np.where(err, (base + rng.integers(1, 4, R)) % 4, base)
     mq = np.where(rng.random(R) < 0.92, 60, rng.integers(0, 60, R))
+    if wide_qual:
+        mq = rng.integers(0, 61, R)
     if mapq255_rate > 0:
         mq = np.where(rng.random(R) < mapq255_rate, 255, mq)
     qpos = rng.integers(0, READ_LEN, R)

@@ -62,6 +62,21 @@ def test_mpileup_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth, var_rat
     assert_mplp_equal(got, want)
 
 
+@pytest.mark.parametrize("n_sites,n_smpl,depth,var_rate,seed", [
+    (40, 64, 30.0, 0.3, 31),              # ~25 distinct (quality, strand) keys per cell: slot refills in the errmod walk
+    (12, 100, 120.0, 0.5, 32),            # deep cells, up to ~100 distinct keys, het cells with many non-reference reads
+    (60, 7, 60.0, 0.5, 33),
+])
+def test_mpileup_unbinned_qualities(gpu_ctx_factory, n_sites, n_smpl, depth, var_rate, seed):
+    fmt = abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD | abi.FMT_QS | abi.FMT_SCR | abi.INFO_SCR
+    tile = synth.numpy_tile(seed, n_sites, n_smpl, depth=depth, var_rate=var_rate, ref_n_rate=0.05, wide_qual=True)
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), fmt_flag=fmt)
+    want = orc.mpileup(cfg, tile)
+    ctx = gpu_ctx_factory(cfg)
+    got = ctx.mpileup(tile)
+    assert_mplp_equal(got, want)
+
+
 @pytest.mark.parametrize("n_sites,n_smpl,seed,flags,tags", [
     (64, 100, 11, 0, 0),
     (64, 100, 12, abi.CALL_VARONLY, 0),
