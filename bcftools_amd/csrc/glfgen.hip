@@ -55,51 +55,42 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 #define OW_PACK(baseQ, mapQ, q, b, rev, md) \
     ((uint32_t)(baseQ) | (uint32_t)(mapQ) << 8 | (uint32_t)(q) << 14 | (uint32_t)(b) << 20 | (uint32_t)(rev) << 24 | (uint32_t)(md) << 25)
 
-// Number of set bits of the 128-bit mask (lo,hi) above bit `key`, and membership of `key`.
-__device__ __forceinline__ int rank_above(uint64_t lo, uint64_t hi, uint32_t key)
-{
-    const bool up = key >= 64;
-    const uint64_t h = up ? (hi >> (key & 63)) >> 1 : hi;
-    const uint64_t l = up ? 0ull : (lo >> (key & 63)) >> 1;
-    return __popcll(h) + __popcll(l);
-}
-__device__ __forceinline__ bool has_key(uint64_t lo, uint64_t hi, uint32_t key)
-{
-    return (((key >= 64 ? hi : lo) >> (key & 63)) & 1ull) != 0;
-}
-
-// Counts of the NSLOT highest keys of the mask (lo,hi), in descending key order, as u8 in the lane's slot column:
-// slot r counts the source's reads whose key has rank r.  `src(j)` returns the key7 of source element j or -1.
+// Counts, as u8 in the lane's slot column, of the reads with the NSLOT/2 highest qualities of the mask `qm` (bit q = some
+// read of this base has quality q): slot 2*rank(q) holds the reverse-strand reads of q, slot 2*rank(q)+1 the forward
+// ones -- the descending order of errmod_cal's sorted codes q<<5|strand<<4|base (bam2bcf.c:203).  `src(j)` returns
+// key7 = q<<1|strand of source element j, or -1.
 template <class Src>
-__device__ __forceinline__ void fill_slots(uint32_t *s_slot, uint64_t lo, uint64_t hi, int tid, Src src, int nsrc)
+__device__ __forceinline__ void fill_slots(uint32_t *s_slot, uint64_t qm, int tid, Src src, int nsrc)
 {
     #pragma unroll
     for (int k = 0; k < NSLOT / 4; ++k) s_slot[k * WG + tid] = 0;
     for (int j = 0; __any(j < nsrc); ++j) {
         if (j < nsrc) {
             const int key = src(j);
-            if (key >= 0 && has_key(lo, hi, (uint32_t)key)) {
-                const int r = rank_above(lo, hi, (uint32_t)key);
+            const int q = key >> 1;
+            if (key >= 0 && ((qm >> q) & 1ull)) {
+                const int r = 2 * __popcll((qm >> q) >> 1) + 1 - (key & 1);
                 if (r < NSLOT) atomicAdd(&s_slot[(r >> 2) * WG + tid], 1u << (8 * (r & 3)));
             }
         }
     }
 }
 
-// Descending walk of errmod_cal for one base: every lane steps through its own reads from the highest key7 down.
-// errmod_cal sorts the codes; here the lane's keys are the set bits of its 128-bit presence mask (mlo,mhi) and the
-// number of reads per key sits in NSLOT rank-ordered u8 slots (a 128-entry table per lane would halve the occupancy).
-// A small state machine: when the reads of the current key are used up, take the next set bit and the next slot; a
-// lane with more than NSLOT distinct keys refills its slots from the source for the remaining keys (rare: binned
-// base qualities give a handful of keys).  `n` selects the beta row of the lane, `left` is the number of reads.
+// Descending walk of errmod_cal for one base: every lane steps through its own reads from the highest (quality,
+// strand) key down.  errmod_cal sorts the codes; here the lane's qualities are the set bits of a 64-bit mask and the
+// number of reads per (quality, strand) sits in NSLOT rank-ordered u8 slots (a 128-entry table per lane would cost a
+// third of the occupancy).  A small state machine: when the reads of the current key are used up, move to the next
+// slot, taking the next set bit at every other step; a lane with more than NSLOT/2 distinct qualities refills its
+// slots from the source for the remaining ones (binned base qualities give a handful).  `n` selects the beta row of
+// the lane, `left` is the number of reads of this base.
 // The state machine runs two reads ahead of the summation: the beta value (a gather from a 32 MB table, L2 latency)
 // and the fk factor (LDS) of read t+2 are requested before read t is added, in the reference's order.
 template <class Src>
-__device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t mlo, uint64_t mhi, const double *s_fk,
+__device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t qm, const double *s_fk,
                                             const double *beta, int tid, int n, int left, Src src, int nsrc)
 {
-    fill_slots(s_slot, mlo, mhi, tid, src, nsrc);
-    int rem = 0, rev = 0, pleft = left, r = 0;
+    fill_slots(s_slot, qm, tid, src, nsrc);
+    int rem = 0, pend = 0, rev = 0, pleft = left, r = 0;      // r: next slot pair (= rank of the next quality)
     uint32_t cc = 0, w0 = 0, w1 = 0;
     const double *brow = beta + ((size_t)n << 8);
     const double *bp = brow;
@@ -107,14 +98,18 @@ __device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t mlo, uint
     #define WALK_PRODUCE(bv, fv) do { \
         if (pleft > 0) { \
             if (rem == 0) { \
-                if (r == NSLOT) { fill_slots(s_slot, mlo, mhi, tid, src, nsrc); r = 0; } \
-                uint32_t key; \
-                if (mhi) { const int k = 63 - __clzll((long long)mhi); mhi &= ~(1ull << k); key = k + 64; } \
-                else     { const int k = 63 - __clzll((long long)mlo); mlo &= ~(1ull << k); key = k; } \
-                rem = (int)((s_slot[(r >> 2) * WG + tid] >> (8 * (r & 3))) & 0xff); \
-                ++r; \
-                rev = key & 1; \
-                bp = brow + ((size_t)(key >> 1) << 16); \
+                if (pend > 0) { rev = 0; rem = pend; pend = 0; }     /* the forward-strand reads of the same quality */ \
+                else { \
+                    if (r == NSLOT / 2) { fill_slots(s_slot, qm, tid, src, nsrc); r = 0; } \
+                    const int curq = 63 - __clzll((long long)qm); \
+                    qm &= ~(1ull << curq); \
+                    const uint32_t two = (s_slot[(r >> 1) * WG + tid] >> (16 * (r & 1))) & 0xffff; \
+                    ++r; \
+                    const int cr = (int)(two & 0xff), cf = (int)(two >> 8); \
+                    rev = cr ? 1 : 0; rem = cr ? cr : cf; pend = cr ? cf : 0; \
+                    if (rem == 0) rem = pleft;                       /* cannot happen: counts and mask agree */ \
+                    bp = brow + ((size_t)curq << 16); \
+                } \
             } \
             bv = bp[cc]; \
             fv = s_fk[rev ? w1 : w0]; \
@@ -277,10 +272,9 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
         const uint32_t cnt_raw = (part && !(P.ablate & 4)) ? end - beg : 0;
 
         // ---- pass 0: the per-read loop of bcf_call_glfgen (bam2bcf.c:170-253) ----
-        uint64_t mlo = 0, mhi = 0;   // key7 presence bits of the primary base
-        uint64_t qs64 = 0;           // QS[0..3], 16 bits each
-        uint64_t ad64 = 0;           // ADF[0..3] | ADR[0..3]<<32, 8 bits each
-        uint32_t mq0 = 0, scr = 0, ori_depth = 0, n_rev = 0, n_b4 = 0;
+        uint64_t qmask = 0;          // qualities seen among the reads of the primary base
+        uint32_t qs_prim = 0, prim_rev = 0;   // their quality sum and reverse-strand count
+        uint32_t mq0 = 0, scr = 0, ori_depth = 0, n_rev = 0;
         uint32_t t_bqmd = 0, t_mq = 0, t_bq2 = 0, t_mq2 = 0, t_md2 = 0;   // totals: baseQ | min_dist<<16, mapQ, squares
         uint32_t h59 = 0;            // reads with mapQ>=59: ref | alt<<8 | fwd<<16 | rev<<24
         int n = 0, n_other = 0, n_prim = 0;
@@ -297,7 +291,6 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
             w_nx = s_rd[lbeg + i + 1];
             if (want_epos) ep_nx = s_ep[ebeg + i + 1];
             const int nt = (w >> 16) & 15;
-            const uint32_t rev = (w >> 20) & 1;
             int q, b, baseQ, seqQ;
             bool ok;
             if (INDEL) {
@@ -317,44 +310,36 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
                 ok = seen && q >= min_baseQ;
             }
             if (ok && n >= BCFGPU_MAX_DEPTH) { fail = true; ok = false; }
-            // register accumulators: unconditional arithmetic, a rejected read contributes zeros
+            // register accumulators: unconditional arithmetic; a rejected read is a zero record and contributes zeros
             const uint32_t okm = ok ? 1u : 0u;
-            int mapQ = (w >> 8) & 0xff;
+            const uint32_t wz = ok ? w : 0u;
+            if (!ok) baseQ = 0;
+            const uint32_t rev = (wz >> 20) & 1;
+            int mapQ = (wz >> 8) & 0xff;
             if (mapQ == 255) mapQ = DEF_MAPQ;
             mq0 += (mapQ == 0) & okm;
             q = min(q, seqQ);
             mapQ = min(mapQ, capQ);
             q = max(min(min(q, mapQ), 63), 4);
             n += okm;
-            n_rev += rev & okm;
-            const int min_dist = min((int)(w >> 24), CAP_DIST);
+            n_rev += rev;
+            const int min_dist = min((int)(wz >> 24), CAP_DIST);
             const uint32_t key = (uint32_t)(q << 1) | rev;       // (code>>4)&0x7f of bam2bcf.c:203
             const bool prim = ok && (b == primary);
-            {
-                const uint64_t bit = (uint64_t)(prim ? 1u : 0u) << (key & 63);
-                mlo |= key < 64 ? bit : 0ull;
-                mhi |= key < 64 ? 0ull : bit;
-            }
-            if (want_scr) scr += (w >> 21) & okm;
-            {
-                const bool b4 = b >= 4;
-                const bool acgt = ok && !b4;
-                qs64 += (uint64_t)(acgt ? q : 0) << (16 * (b & 3));
-                ad64 += (uint64_t)(acgt ? 1u : 0u) << (8 * (b & 3) + 32 * rev);
-                n_b4 += (ok && b4);
-            }
-            {
-                const uint32_t bq = ok ? (uint32_t)baseQ : 0u, mq = ok ? (uint32_t)mapQ : 0u, md = ok ? (uint32_t)min_dist : 0u;
-                t_bqmd += bq | md << 16;
-                t_mq += mq;
-                t_bq2 += bq * bq; t_mq2 += mq * mq; t_md2 += md * md;
-            }
+            // reads of the primary base: quality mask, QS and strand count (the other bases' come from their stored words)
+            qmask |= (uint64_t)(prim ? 1u : 0u) << q;
+            qs_prim += prim ? (uint32_t)q : 0u;
+            prim_rev += prim ? rev : 0u;
+            if (want_scr) scr += (wz >> 21) & 1;
+            t_bqmd += (uint32_t)baseQ | (uint32_t)min_dist << 16;
+            t_mq += mapQ;
+            t_bq2 += baseQ * baseQ; t_mq2 += mapQ * mapQ; t_md2 += min_dist * min_dist;
             const int ibq = min(baseQ, 59);
             const int imq = min(mapQ, 59);
             const bool isref = (nt == ref_base);
             // All LDS updates of the read come last, after the prefetched next record has arrived: LDS operations
             // complete in order, so waiting for that record any later would also wait for these atomics.
-            asm volatile("" : "+v"(qs64), "+v"(ad64), "+v"(t_bq2), "+v"(t_mq2), "+v"(t_md2), "+v"(mlo), "+v"(mhi)
+            asm volatile("" : "+v"(qs_prim), "+v"(prim_rev), "+v"(t_bq2), "+v"(t_mq2), "+v"(t_md2), "+v"(qmask)
                             : "v"(w_nx), "v"(ep_nx) : "memory");
             if (!ok) continue;
             // the key of a primary read goes, compacted, into the lane's epos slice (byte n_prim <= i is behind the reader)
@@ -381,29 +366,13 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
         }
         if (fail || ori_depth > 0xffff) {
             atomicExch(P.err, BCFGPU_E_DEPTH);
-            n = 0; n_other = 0; n_prim = 0; qs64 = ad64 = 0; n_rev = n_b4 = 0; mlo = mhi = 0;
+            n = 0; n_other = 0; n_prim = 0; n_rev = 0; qmask = 0; qs_prim = 0; prim_rev = 0;
         }
-        // per-base counts c[0..4] (errmod_cal's aux.c)
-        int c[5];
-        #pragma unroll
-        for (int b = 0; b < 4; ++b) c[b] = (int)((ad64 >> (8 * b)) & 0xff) + (int)((ad64 >> (8 * b + 32)) & 0xff);
-        c[4] = (int)n_b4;
-        const bool skip_walk = (P.ablate & 2) != 0;
-
-        // ---- errmod_cal: descending walk per base ----
-        double bsum[5] = {0, 0, 0, 0, 0};
-        // (a) the primary base, already counted
-        if (!skip_walk) {
-            int cprim = 0;
-            #pragma unroll
-            for (int b = 0; b < 5; ++b) if (b == primary) cprim = c[b];
-            const uint8_t *kb = s_ep + ebeg;                 // the lane's n_prim (= cprim) key bytes
-            const double bs = walk_keys(s_cnt, mlo, mhi, s_fk, P.beta, tid, n, cprim,
-                                        [kb](int j) { return (int)kb[j]; }, n_prim);
-            #pragma unroll
-            for (int b = 0; b < 5; ++b) if (b == primary) bsum[b] = bs;
-        }
-        // (b) the other reads: the "diff" annotation sums, then count + walk per base present in the wave
+        // the other reads (exactly the "diff" reads of the I16 annotations): their annotation sums and their share of
+        // QS / ADF / ADR (bam2bcf.c:208-215), from the stored words
+        uint64_t qs64 = 0;           // QS[0..3], 16 bits each
+        uint64_t ad64 = 0;           // ADF[0..3] | ADR[0..3]<<32, 8 bits each
+        uint32_t n_b4 = 0;           // reads showing neither A, C, G nor T
         uint32_t d_bqmd = 0, d_mq = 0, d_bq2 = 0, d_mq2 = 0, d_md2 = 0, d_fwd = 0, d_rev = 0;
         if (__any(n_other > 0)) {
             for (int i = 0; i < n_other; ++i) {
@@ -414,12 +383,40 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
                 d_bq2 += baseQ * baseQ; d_mq2 += mapQ * mapQ; d_md2 += md * md;
                 const uint32_t rev = (ow >> 24) & 1;
                 d_rev += rev; d_fwd += 1 - rev;
+                const uint32_t ob = (ow >> 20) & 0xf, oq = (ow >> 14) & 0x3f;
+                if (ob < 4) {
+                    qs64 += (uint64_t)oq << (16 * ob);
+                    ad64 += 1ull << (8 * ob + 32 * rev);
+                } else ++n_b4;
             }
+        }
+        if (primary < 4) {
+            qs64 += (uint64_t)qs_prim << (16 * primary);
+            ad64 += (uint64_t)((uint32_t)n_prim - prim_rev) << (8 * primary) | (uint64_t)prim_rev << (8 * primary + 32);
+        } else n_b4 += (uint32_t)n_prim;
+        // per-base counts c[0..4] (errmod_cal's aux.c)
+        int c[5];
+        #pragma unroll
+        for (int b = 0; b < 4; ++b) c[b] = (int)((ad64 >> (8 * b)) & 0xff) + (int)((ad64 >> (8 * b + 32)) & 0xff);
+        c[4] = (int)n_b4;
+        const bool skip_walk = (P.ablate & 2) != 0;
+
+        // ---- errmod_cal: descending walk per base ----
+        double bsum[5] = {0, 0, 0, 0, 0};
+        // (a) the primary base
+        if (!skip_walk && !(P.ablate & 16384)) {
+            const uint8_t *kb = s_ep + ebeg;                 // the lane's n_prim key bytes
+            const double bs = walk_keys(s_cnt, qmask, s_fk, P.beta, tid, n, n_prim,
+                                        [kb](int j) { return (int)kb[j]; }, n_prim);
+            #pragma unroll
+            for (int b = 0; b < 5; ++b) if (b == primary) bsum[b] = bs;
+        }
+        // (b) the other bases present in the wave
+        if (!skip_walk && !(P.ablate & 128) && __any(n_other > 0)) {
             #pragma unroll
             for (int b = 0; b < 5; ++b) {
                 const int cb = (b != primary) ? c[b] : 0;
-                if (skip_walk || !__any(cb > 0)) continue;
-                uint64_t lo = 0, hi = 0;
+                if (!__any(cb > 0)) continue;
                 const uint32_t *ow_p = s_rd + lbeg;
                 // key7 of the lane's i-th other read if it shows base b, else -1
                 auto src = [ow_p, b](int i) {
@@ -428,14 +425,10 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
                     if (bb > 4) bb = 4;
                     return bb == b ? (int)(((ow >> 14) & 0x3f) << 1 | ((ow >> 24) & 1)) : -1;
                 };
-                if (cb > 0) {
-                    for (int i = 0; i < n_other; ++i) {
-                        const int key = src(i);
-                        if (key < 0) continue;
-                        if (key < 64) lo |= 1ull << key; else hi |= 1ull << (key - 64);
-                    }
-                }
-                const double bs = walk_keys(s_cnt, lo, hi, s_fk, P.beta, tid, n, cb, src, cb > 0 ? n_other : 0);
+                uint64_t qm = 0;
+                if (cb > 0)
+                    for (int i = 0; i < n_other; ++i) { const int key = src(i); if (key >= 0) qm |= 1ull << (key >> 1); }
+                const double bs = walk_keys(s_cnt, qm, s_fk, P.beta, tid, n, cb, src, cb > 0 ? n_other : 0);
                 if (b != primary) bsum[b] = bs;      // lanes of one wave may belong to sites with different reference bases
             }
         }
