@@ -147,38 +147,7 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
     const long cell0 = (long)blockIdx.x * WG;
     const int site0 = (int)(cell0 / P.n_smpl);
 
-    // Lane assignment: the workgroup's 256 cells are handed to lanes in order of decreasing read count, so that the 64
-    // cells a wavefront steps through in lockstep have similar depths (Poisson depths would otherwise leave about a
-    // third of the lane-iterations idle).  Counting sort over the clipped counts, positions from an exclusive scan.
-    // Which wavefront gets the deepest quarter rotates with the workgroup index, so the SIMDs of a CU see a mix.
-    long cell;
-    {
-        int *s_h = reinterpret_cast<int*>(s_rd);            // [256] bins, [256..259] wave totals, then the permutation
-        int *s_w = s_h + WG;
-        uint16_t *s_perm = reinterpret_cast<uint16_t*>(s_h + WG + 4);
-        s_h[tid] = 0;
-        __syncthreads();
-        const long c = cell0 + tid;
-        const uint32_t cn = c < ncells ? P.off[c + 1] - P.off[c] : 0;
-        const int bin = 255 - (int)min(cn, 255u);
-        const int old = atomicAdd(&s_h[bin], 1);
-        __syncthreads();
-        const int v = s_h[tid];
-        int incl = v;
-        #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((tid & 63) >= o) incl += t; }
-        if ((tid & 63) == 63) s_w[tid >> 6] = incl;
-        __syncthreads();
-        int excl = incl - v;
-        for (int w = 0; w < (tid >> 6); ++w) excl += s_w[w];
-        s_h[tid] = excl;
-        __syncthreads();
-        s_perm[s_h[bin] + old] = (uint16_t)tid;
-        __syncthreads();
-        const int rot = P.ablate & 64 ? 0 : (int)((blockIdx.x >> 3) & 3);
-        cell = cell0 + s_perm[(tid + 64 * rot) & (WG - 1)];
-        __syncthreads();
-    }
+    const long cell = cell0 + tid;
     const bool active = cell < ncells;
 
     s_fk[tid] = P.fk[tid];
