@@ -6,16 +6,17 @@
 // mcall_trim_and_update_PLs (:1158-1194), plus the QS/-G/-F frequency set-up (:1453-1535)
 // and the record-loop prologue of vcfcall.c:1112-1115.
 //
-// The work per site is a chain of short, dependent steps, so throughput comes from having
-// thousands of sites in flight: one 64-lane workgroup per site, ~100 VGPRs, a few KB of LDS, no
-// workgroup barriers that matter.  Lanes run over samples.  A sample's P(D|G) vector is written
-// to the lane's LDS column so that the allele-subset scan of find_best_alleles can index it with
-// run-time genotype indices: one code path and one log() per (subset, sample).
+// The work per site is a chain of short, dependent steps, so throughput comes from having thousands of sites in
+// flight: one 64-lane workgroup per site, no workgroup barriers that matter.  The allele-subset scan of
+// find_best_alleles is a (subsets x genotypes) * (genotypes x samples) product: the FAST instantiations (diploid, one
+// group, u8 PLs of the fused pipeline) run it on the f64 matrix cores; the general ones (ploidy arrays, -G groups,
+// missing PLs, int32 PLs of a VCF) keep a sample's P(D|G) in the lane's LDS column and index it with run-time
+// genotype indices.  Genotype calling runs lanes over samples in both.
 //
-// Integer results (GT, AC/AN, trimmed PL) are exact; log-likelihood sums are tree-reduced, so
-// QUAL agrees with the sequential CPU sum to ~1e-13 relative, far inside the 1e-4 contract.
-// Order-sensitive float32 pieces (group qsum from AD, -F prior, normalisation) are replayed
-// sequentially by single lanes exactly as the reference does.
+// Integer results (GT, AC/AN, trimmed PL, GQ) are exact; log-likelihood sums are accumulated as running products
+// (mantissa, exponent), so QUAL agrees with the sequential CPU sum of logs to ~1e-13 relative, far inside the 1e-4
+// contract.  Order-sensitive float32 pieces (group qsum from AD, -F prior, normalisation) are replayed sequentially
+// by single lanes exactly as the reference does.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "kernels.h"

@@ -10,7 +10,8 @@
  *      mpileup.1.sam (BAQ-free golden of the reference's own test-suite)
  *    - mcall: test/mpileup*.vcf, call-G*.vcf, call.af-fixation.vcf, mpileup.hwe.vcf,
  *      mpileup.X.vcf against their .out goldens
- *    - probaln_glocal / BAQ / kf_betai: parity unpinned
+ *    - probaln_glocal / sam_prob_realn (BAQ) / bcf_call_gap_prep / mate-overlap tweak: test/mpileup/mpileup.{1,2,4,5}.out
+ *      and indel-AD.1.out (goldens made with BAQ on), every record and field
  *
  *  It takes and fills the same SoA structures as the device library
  *  (include/bcfgpu.h), with HOST pointers.
