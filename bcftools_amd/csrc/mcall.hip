@@ -165,24 +165,26 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // f64 matrix cores (v_mfma_f64_16x16x4_f64), 16 samples per issue; an extra all-ones row yields each sample's
 // normalisation sum, whose product is divided out at the end.
 template <int MAXA, int NSUB, bool FAST>
-__global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
+__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 1, FAST ? 4 : 8))) void mcall_kernel(const McallParams P)
 {
     constexpr int NG = MAXA * (MAXA + 1) / 2;
     constexpr int TILES = NSUB >= 16 ? 2 : 1;     // 16-row tiles of the coefficient matrix (subsets + the sum row)
     extern __shared__ __align__(16) unsigned char dsm[];
     float *s_gq = reinterpret_cast<float*>(dsm);              // [n_grp][5] group qsum, then [n_grp][2] best allele sets
     __shared__ CallShared sh;
-    __shared__ double s_pdg[NG * WGS];      // the lane's current sample: raw P(D|G) (not yet divided by its sum)
+    __shared__ double s_pdg[FAST ? 1 : NG * WGS];   // the lane's current sample: raw P(D|G) (not yet divided by its sum)
     int *s_fill = reinterpret_cast<int*>(s_pdg);   // scratch of set_pdg's rare missing-value path (used before s_pdg is written)
     // pass 1: per-lane running products of the subset likelihoods, kept as mantissa (f64) and exponent (i32):
     //         sum_s log(val_s) = log(prod_s val_s), so each sample costs a multiply + frexp instead of a log()
     // pass 2: the lane's current sample: PLs after set_pdg's in-place fills, genotype posteriors
-    constexpr int U1 = FAST ? TILES * 16 * 16 * 8 : NSUB * WGS * 12, U2 = NG * WGS * 8, UB = U1 > U2 ? U1 : U2;
+    // FAST: pass 1 = the coefficient matrix; pass 2 = the lane's PL bytes (u8) and genotype posteriors (f32)
+    constexpr int U1 = FAST ? TILES * 16 * 16 * 8 : NSUB * WGS * 12, U2 = FAST ? NG * WGS * 5 : NG * WGS * 8, UB = U1 > U2 ? U1 : U2;
     __shared__ __align__(8) unsigned char s_union[UB];
     double *s_man = reinterpret_cast<double*>(s_union);
     int    *s_exp = reinterpret_cast<int*>(s_union + NSUB * WGS * 8);
     int    *s_plc = reinterpret_cast<int*>(s_union);
-    float  *s_gps = reinterpret_cast<float*>(s_union + NG * WGS * 4);
+    float  *s_gps = reinterpret_cast<float*>(s_union + (FAST ? 0 : NG * WGS * 4));
+    uint8_t *s_plb = s_union + NG * WGS * 4;               // FAST only
 
     const int tid = threadIdx.x;
     const int is = blockIdx.x;
@@ -571,10 +573,94 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
     // ---- genotypes (mcall_set_ref_genotypes / mcall_call_genotypes) + PL trimming ----
     int ac_loc[5] = {0, 0, 0, 0, 0};
     const int ogt = P.out_n_gt_max;
+    if constexpr (FAST) {
+        // all-diploid, one group, u8 PLs without missing values: set_pdg is a table lookup per byte, so only the PL
+        // bytes are staged (run-time genotype indices) and P(D|G) = pl2p[PL]/sum is formed for the genotypes evaluated
+        const uint8_t *plb = reinterpret_cast<const uint8_t*>(P.pl) + (size_t)is * BCFGPU_MAX_PL * Ss;
+        const int gals = grp_als_tab[0];
+        const float *gq5 = s_gq;
+        for (int s = tid; s < ((P.ablate & 32) ? 0 : S); s += WGS) {
+            double psum = 0;
+            uint32_t anynz = 0;
+            #pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                if (k < ngts) {
+                    const uint32_t v = plb[(size_t)k * Ss + s];
+                    s_plb[k * WGS + tid] = (uint8_t)v;
+                    psum += s_p2[v];
+                    anynz |= v;
+                }
+                if (want_gqgp) s_gps[k * WGS + tid] = 0.f;
+            }
+            const bool allzero = anynz == 0;                 // sum == n_gt: no data (mcall.c:529-535)
+            int g0, g1, gq = 0;
+            if (!is_variant) {
+                if (allzero) g0 = g1 = BCFGPU_GT_MISSING;
+                else { g0 = g1 = 0; ac_loc[0] += 2; }
+            } else {
+                if (allzero) { g0 = g1 = BCFGPU_GT_MISSING; s_gps[tid] = -1; }
+                else {
+                    g0 = 0;
+                    double best_lk = 0;
+                    for (int ia = 0; ia < nals; ++ia) {
+                        if (!(gals & 1 << ia)) continue;
+                        const int iaa = (ia + 1) * (ia + 2) / 2 - 1;
+                        const double p = s_p2[s_plb[iaa * WGS + tid]] / psum;
+                        const double lk = p * gq5[ia] * gq5[ia];
+                        const int am = sh.als_map[ia];
+                        s_gps[a2gt(am, am) * WGS + tid] = (float)lk;
+                        if (best_lk < lk) { best_lk = lk; g0 = am; }
+                    }
+                    g1 = g0;
+                    for (int ia = 1; ia < nals; ++ia) {
+                        if (!(gals & 1 << ia)) continue;
+                        const int iaa = (ia + 1) * (ia + 2) / 2 - 1;
+                        for (int ib = 0; ib < ia; ++ib) {
+                            if (!(gals & 1 << ib)) continue;
+                            const int iab = iaa - ia + ib;
+                            const double lk = 2 * (s_p2[s_plb[iab * WGS + tid]] / psum) * gq5[ia] * gq5[ib];
+                            s_gps[a2gt(sh.als_map[ia], sh.als_map[ib]) * WGS + tid] = (float)lk;
+                            if (best_lk < lk) { best_lk = lk; g0 = sh.als_map[ib]; g1 = sh.als_map[ia]; }
+                        }
+                    }
+                    #pragma unroll
+                    for (int k = 0; k < 5; ++k) { if (g0 == k) ac_loc[k]++; if (g1 == k) ac_loc[k]++; }
+                }
+                if (want_gqgp) {
+                    // mcall.c:842-885
+                    const int nmax = ngts_new;
+                    double mx = s_gps[tid];
+                    if (mx < 0 || nmax == 0) {
+                        if (P.output_tags & BCFGPU_CALL_FMT_GP) for (int k = 0; k < nmax; ++k) s_gps[k * WGS + tid] = 0;
+                        gq = 0;
+                    } else {
+                        double sum = mx;
+                        for (int k = 1; k < nmax; ++k) { const double v = s_gps[k * WGS + tid]; if (mx < v) mx = v; sum += v; }
+                        mx = -4.34294 * log(1 - mx / sum);
+                        gq = mx <= 127 ? (int)mx : 127;
+                        if (P.output_tags & BCFGPU_CALL_FMT_GP)
+                            for (int k = 0; k < nmax; ++k) s_gps[k * WGS + tid] = (float)(s_gps[k * WGS + tid] / sum);
+                    }
+                }
+            }
+            P.out.gt[((size_t)is * 2 + 0) * Ss + s] = (int8_t)g0;
+            P.out.gt[((size_t)is * 2 + 1) * Ss + s] = (int8_t)g1;
+            if (is_variant && want_gqgp) {
+                if ((P.output_tags & BCFGPU_CALL_FMT_GQ) && P.out.gq) P.out.gq[(size_t)is * Ss + s] = gq;
+                if ((P.output_tags & BCFGPU_CALL_FMT_GP) && P.out.gp)
+                    for (int k = 0; k < ngts_new; ++k) P.out.gp[((size_t)is * ogt + k) * Ss + s] = s_gps[k * WGS + tid];
+            }
+            // trimmed PLs (mcall.c:1158-1194)
+            if (!ref_only && P.out.pl) {
+                int32_t *dst = P.out.pl + (size_t)is * ogt * Ss + s;
+                for (int k = 0; k < ngts_new; ++k) dst[(size_t)k * Ss] = (int32_t)s_plb[sh.pl_map[k] * WGS + tid];
+            }
+        }
+    } else {
     for (int s = tid; s < ((P.ablate & 32) ? 0 : S); s += WGS) {
         int pl[NG]; double pdg[NG];
         load_pl<NG>(P, is, s, ngts, pl);
-        const double psum = set_pdg_one<NG>(FAST ? s_p2 : s_pl2p, pl, pdg, ngts, nals, unseen, s_fill + tid);
+        const double psum = set_pdg_one<NG>(s_pl2p, pl, pdg, ngts, nals, unseen, s_fill + tid);
         const int ploidy = P.ploidy ? P.ploidy[s] : 2;
         // pdg = raw/psum is formed lazily below, with the same division the reference performs (bit-exact genotypes)
         bool allzero = true;
@@ -673,6 +759,7 @@ __global__ __launch_bounds__(WGS) void mcall_kernel(const McallParams P)
                 dst[Ss] = VEND;
             }
         }
+    }
     }
     // AC totals
     #pragma unroll
