@@ -227,7 +227,7 @@ __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTota
     }
 }
 
-__global__ __launch_bounds__(WG) void combine_kernel(const CombineParams P)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void combine_kernel(const CombineParams P)
 {
     __shared__ SiteShared sh;
     __shared__ unsigned long long s_stage[CHUNK];   // QS (4 x u16) per sample, later float mins
