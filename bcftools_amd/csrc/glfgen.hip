@@ -90,33 +90,40 @@ __device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t qm, const
                                             const double *beta, int tid, int n, int left, Src src, int nsrc)
 {
     fill_slots(s_slot, qm, tid, src, nsrc);
-    int rem = 0, pend = 0, rev = 0, pleft = left, r = 0;      // r: next slot pair (= rank of the next quality)
-    uint32_t cc = 0, w0 = 0, w1 = 0;
-    const double *brow = beta + ((size_t)n << 8);
-    const double *bp = brow;
+    int rem = 0, pend = 0, pleft = left, r = 0;              // r: next slot pair (= rank of the next quality)
+    uint32_t rev = 0, cc = 0, w0 = 0, w1 = 0;
+    const char *bbase = reinterpret_cast<const char*>(beta);
+    const uint32_t brow = (uint32_t)n << 11;                  // byte offset of beta[0][n][0]; the table is 32 MiB
+    uint32_t boff = brow;
     double bs = 0;
+    // Loads are issued unconditionally (inactive lanes read a valid dummy) and their results never cross a divergent
+    // join, so that three gathers stay in flight; the (divergent) state update carries no memory results.
+    #define SLOT_PAIR(i) (s_slot[(((i) & (NSLOT / 2 - 1)) >> 1) * WG + tid])      /* the dword holding pair i */
+    uint32_t two_nx = SLOT_PAIR(0);
     #define WALK_PRODUCE(bv, fv) do { \
-        if (pleft > 0) { \
-            if (rem == 0) { \
-                if (pend > 0) { rev = 0; rem = pend; pend = 0; }     /* the forward-strand reads of the same quality */ \
-                else { \
-                    if (r == NSLOT / 2) { fill_slots(s_slot, qm, tid, src, nsrc); r = 0; } \
-                    const int curq = 63 - __clzll((long long)qm); \
-                    qm &= ~(1ull << curq); \
-                    const uint32_t two = (s_slot[(r >> 1) * WG + tid] >> (16 * (r & 1))) & 0xffff; \
-                    ++r; \
-                    const int cr = (int)(two & 0xff), cf = (int)(two >> 8); \
-                    rev = cr ? 1 : 0; rem = cr ? cr : cf; pend = cr ? cf : 0; \
-                    if (rem == 0) rem = pleft;                       /* cannot happen: counts and mask agree */ \
-                    bp = brow + ((size_t)curq << 16); \
-                } \
+        if (pleft > 0 && rem == 0) { \
+            if (pend > 0) { rev = 0; rem = pend; pend = 0; }         /* the forward-strand reads of the same quality */ \
+            else { \
+                if (r == NSLOT / 2) { fill_slots(s_slot, qm, tid, src, nsrc); r = 0; two_nx = SLOT_PAIR(0); } \
+                const int curq = 63 - __clzll((long long)(qm | 1ull)); \
+                qm &= ~(1ull << curq); \
+                const uint32_t two = (two_nx >> (16 * (r & 1))) & 0xffffu; \
+                ++r; \
+                const int cr = (int)(two & 0xff), cf = (int)(two >> 8); \
+                rev = cr ? 1u : 0u; rem = cr ? cr : cf; pend = cr ? cf : 0; \
+                if (rem == 0) rem = pleft;                           /* cannot happen: counts and mask agree */ \
+                boff = brow + ((uint32_t)curq << 19); \
             } \
-            bv = bp[cc]; \
-            fv = s_fk[rev ? w1 : w0]; \
-            ++cc; w1 += rev; w0 += 1 - rev; --rem; --pleft; \
+        } \
+        two_nx = SLOT_PAIR(r);                                       /* for the next advance */ \
+        { \
+            const uint32_t act = pleft > 0 ? 1u : 0u; \
+            bv = *reinterpret_cast<const double*>(bbase + (boff + (act ? cc << 3 : 0u))); \
+            fv = s_fk[act ? (rev ? w1 : w0) : 0u]; \
+            cc += act; w1 += act & rev; w0 += act & (rev ^ 1u); rem -= (int)act; pleft -= (int)act; \
         } } while (0)
-    #define WALK_CONSUME(bv, fv) do { if (left > 0) { bs += fv * bv; --left; } } while (0)
-    double bx = 0., fx = 0., by = 0., fy = 0., bz = 0., fz = 0.;
+    #define WALK_CONSUME(bv, fv) do { const double t_ = fv * bv; const bool a_ = left > 0; bs = a_ ? bs + t_ : bs; left -= a_ ? 1 : 0; } while (0)
+    double bx, fx, by, fy, bz, fz;
     WALK_PRODUCE(bx, fx);
     WALK_PRODUCE(by, fy);
     while (__any(left > 0)) {
@@ -126,6 +133,7 @@ __device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t qm, const
     }
     #undef WALK_PRODUCE
     #undef WALK_CONSUME
+    #undef SLOT_PAIR
     return bs;
 }
 
