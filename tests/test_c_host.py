@@ -1,0 +1,135 @@
+"""The plain-C host driver (host/bcfgpu_host.c): the C-ABI used the way a C caller would (gcc, -std=c99).
+
+CPU part: it compiles warning-free against include/bcfgpu.h, links against the library, and fails loudly without a GPU.
+GPU part: its printed call records equal what the oracle gives for the same pileup (the generator is restated here)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from bcftools_amd import abi, host
+from tests.helpers import orc, sam
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "host", "bcfgpu_host")
+READ_LEN = 100
+M64 = (1 << 64) - 1
+
+
+def build_host():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bcftools_amd", "csrc")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host")])
+    assert os.access(EXE, os.X_OK)
+
+
+class Rng:
+    """xorshift64* of host/bcfgpu_host.c"""
+    def __init__(self, seed):
+        self.s = (seed * 2 + 1) & M64
+
+    def r32(self):
+        s = self.s
+        s ^= s >> 12
+        s ^= (s << 25) & M64
+        s ^= s >> 27
+        self.s = s
+        return ((s * 2685821657736338717) & M64) >> 32
+
+    def below(self, n):
+        return (self.r32() * n) >> 32
+
+
+def host_tile(n_sites, n_smpl, depth, seed):
+    """The pileup bcfgpu_host.c generates, packed with the Python twin of bcfgpu_pack_read."""
+    g = Rng(seed)
+    bqv = [11, 25, 37, 40]
+    ref16 = np.zeros(n_sites, dtype=np.int8)
+    off = [0]
+    rd, ep = [], []
+    for k in range(n_sites):
+        ref2 = g.below(4)
+        alt2 = (ref2 + 1 + g.below(3)) & 3
+        is_var = g.below(4) == 0
+        ref16[k] = 1 << ref2
+        for s in range(n_smpl):
+            nalt = g.below(3) if is_var else 0
+            n = depth + g.below(depth)
+            for j in range(n):
+                bq = bqv[g.below(4)]
+                base = alt2 if (nalt == 2 or (nalt == 1 and (g.r32() & 1))) else ref2
+                if g.below(1000) < (80 if bq < 20 else 3):
+                    base = (base + 1 + g.below(3)) & 3
+                mapq = 60 if g.below(10) else g.below(60)
+                qpos = g.below(READ_LEN)
+                rev = g.r32() & 1
+                w, e = sam.pack_read(1 << base, bq, mapq, rev, 0, 0, 0, qpos, READ_LEN, [(READ_LEN, "M")], True)
+                rd.append(w)
+                ep.append(e)
+            off.append(len(rd))
+    return host.HostTile(n_smpl, ref16, np.array(off, dtype=np.uint32), np.array(rd, dtype=np.uint32),
+                         np.array(ep, dtype=np.uint8))
+
+
+def expected_lines(tile, n_smpl, varonly):
+    cfg = abi.default_cfg(n_smpl, max_sites=tile.n_sites, max_reads=len(tile.rd),
+                          call_flag=abi.CALL_VARONLY if varonly else 0)
+    m = orc.mpileup(cfg, tile)
+    cin = host.CallInput(n_smpl, m.site["n_alleles"], np.maximum(m.site["unseen"], 0), m.pl.astype(np.int32), m.site["qsum"])
+    c = orc.mcall(cfg, cin)
+    nt = "ACGTN"
+    out = []
+    for k in range(tile.n_sites):
+        cs, ms = c.site[k], m.site[k]
+        if cs["ret"] <= 0:
+            continue
+        alts = [("*" if i == ms["unseen"] else nt[ms["a"][i]]) for i in range(1, ms["n_alleles"]) if cs["als_map"][i] > 0]
+        acs = [str(int(cs["ac"][i])) for i in range(1, cs["nals_new"])]
+        g0, g1 = int(c.gt[k, 0, 0]), int(c.gt[k, 1, 0])
+        out.append((k + 1, nt[ms["a"][0]], ",".join(alts) or ".", None if cs["qual_missing"] else float(cs["qual"]),
+                    int(cs["an"]), ",".join(acs) or ".", int(ms["depth"]), "./." if g0 < 0 else "%d/%d" % (g0, g1)))
+    return out
+
+
+def test_c_host_builds_and_refuses_to_run_without_a_gpu():
+    build_host()
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the refusal path is covered on CPU-only machines")
+    p = subprocess.run([EXE, "4", "2", "5", "1"], capture_output=True, text=True)
+    assert p.returncode != 0 and p.stdout == ""
+    assert "bcfgpu_create" in p.stderr               # BCFGPU_E_NODEV, reported by the CHECK macro: no CPU fallback
+
+
+def test_generator_twin_packs_like_the_library():
+    """The Python twin of the packer agrees with bcfgpu_pack_read on the driver's reads (host code, no GPU needed)."""
+    import ctypes as C
+    from bcftools_amd import lib
+    L = lib.load()
+    g = Rng(3)
+    for _ in range(200):
+        base, bq, mapq, qpos, rev = g.below(4), [11, 25, 37, 40][g.below(4)], g.below(61), g.below(READ_LEN), g.r32() & 1
+        cig = np.array([READ_LEN << 4], dtype=np.uint32)
+        w, e = C.c_uint32(), C.c_uint8()
+        L.bcfgpu_pack_read(1 << base, bq, mapq, rev, 0, 0, 0, qpos, READ_LEN, cig.ctypes.data_as(C.c_void_p), 1, 1,
+                           C.byref(w), C.byref(e))
+        assert (w.value, e.value) == sam.pack_read(1 << base, bq, mapq, rev, 0, 0, 0, qpos, READ_LEN, [(READ_LEN, "M")], True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_sites,n_smpl,depth,seed,varonly", [(48, 6, 20, 7, False), (64, 33, 12, 11, True)])
+def test_c_host_records_match_oracle(n_sites, n_smpl, depth, seed, varonly):
+    build_host()
+    p = subprocess.run([EXE, str(n_sites), str(n_smpl), str(depth), str(seed)] + (["-v"] if varonly else []),
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    got = [ln.split("\t") for ln in p.stdout.strip().split("\n") if ln]
+    want = expected_lines(host_tile(n_sites, n_smpl, depth, seed), n_smpl, varonly)
+    assert len(got) == len(want) and len(want) > 0
+    for g, w in zip(got, want):
+        assert (int(g[0]), g[1], g[2]) == w[:3]
+        if w[3] is None:
+            assert g[3] == "."
+        else:
+            assert float(g[3]) == pytest.approx(w[3], rel=2e-3, abs=1e-3)      # printed with 4 significant digits
+        assert (int(g[4]), g[5], int(g[6]), g[7]) == w[4:]
