@@ -247,6 +247,7 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
         const uint32_t lbeg = part ? beg - abase : 0;            // slice start in s_rd
         const uint32_t ebeg = part ? beg - ebase : 0;            // slice start in s_ep
         const uint32_t cnt_raw = (part && !(P.ablate & 4)) ? end - beg : 0;
+        const bool skip_hist = (P.ablate & 1) != 0;
 
         // ---- pass 0: the per-read loop of bcf_call_glfgen (bam2bcf.c:170-253) ----
         uint64_t qmask = 0;          // qualities seen among the reads of the primary base
@@ -320,13 +321,15 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
                             : "v"(w_nx), "v"(ep_nx) : "memory");
             if (!ok) continue;
             // the key of a primary read goes, compacted, into the lane's epos slice (byte n_prim <= i is behind the reader)
-            if (prim) { s_ep[ebeg + n_prim] = (uint8_t)key; ++n_prim; }
-            else {
+            // (written for every accepted read: a non-primary one is overwritten by the next primary key or lies past the list)
+            s_ep[ebeg + n_prim] = (uint8_t)key;
+            n_prim += prim ? 1 : 0;
+            if (!prim) {
                 s_rd[lbeg + n_other] = OW_PACK(baseQ, mapQ, q, b, rev, min_dist);    // n_other <= i: behind the reader
                 ++n_other;
             }
             // bias-test histograms: ibq = (int)(baseQ/60.*60) is the identity on 0..59 (checked in tests)
-            if (P.ablate & 1) continue;
+            if (skip_hist) continue;
             if (imq == 59) h59 += (isref ? 1u : 1u << 8) + (rev ? 1u << 24 : 1u << 16);
             else {
                 HIST_ADD((rev ? H_REV_MQS : H_FWD_MQS) + imq, 1);
