@@ -45,6 +45,19 @@ class HostTile:
         assert len(self.plp_off) == self.n_sites * self.n_smpl + 1
         assert len(self.rd) == len(self.epos) == int(self.plp_off[-1])
 
+    def select_sites(self, sites):
+        """A new tile holding the given sites (any order), e.g. a region shard or a spot-check sample."""
+        S = self.n_smpl
+        sites = np.asarray(sites, dtype=np.int64)
+        cells = (sites[:, None] * S + np.arange(S)[None, :]).ravel()
+        beg, end = self.plp_off[cells].astype(np.int64), self.plp_off[cells + 1].astype(np.int64)
+        n = end - beg
+        off = np.zeros(len(cells) + 1, dtype=np.int64)
+        np.cumsum(n, out=off[1:])
+        idx = np.repeat(beg - off[:-1], n) + np.arange(int(off[-1]))
+        return HostTile(S, self.ref16[sites], off.astype(np.uint32), self.rd[idx], self.epos[idx],
+                        None if self.aux is None else self.aux[idx], self.is_indel)
+
     def as_struct(self):
         t = abi.Tile()
         t.n_sites, t.is_indel, t.n_reads = self.n_sites, self.is_indel, len(self.rd)
