@@ -59,7 +59,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 // read of this base has quality q): slot 2*rank(q) holds the reverse-strand reads of q, slot 2*rank(q)+1 the forward
 // ones -- the descending order of errmod_cal's sorted codes q<<5|strand<<4|base (bam2bcf.c:203).  `src(j)` returns
 // key7 = q<<1|strand of source element j, or -1.
-template <class Src>
+template <bool FIRST, class Src>
 __device__ __forceinline__ void fill_slots(uint32_t *s_slot, uint64_t qm, int tid, Src src, int nsrc)
 {
     #pragma unroll
@@ -68,7 +68,7 @@ __device__ __forceinline__ void fill_slots(uint32_t *s_slot, uint64_t qm, int ti
         if (j < nsrc) {
             const int key = src(j);
             const int q = key >> 1;
-            if (key >= 0 && ((qm >> q) & 1ull)) {
+            if (key >= 0 && (FIRST || ((qm >> q) & 1ull))) {       // FIRST: the mask still holds every quality of the source
                 const int r = 2 * __popcll((qm >> q) >> 1) + 1 - (key & 1);
                 if (r < NSLOT) atomicAdd(&s_slot[(r >> 2) * WG + tid], 1u << (8 * (r & 3)));
             }
@@ -89,7 +89,7 @@ template <class Src>
 __device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t qm, const double *s_fk,
                                             const double *beta, int tid, int n, int left, Src src, int nsrc)
 {
-    fill_slots(s_slot, qm, tid, src, nsrc);
+    fill_slots<true>(s_slot, qm, tid, src, nsrc);
     int rem = 0, pend = 0, pleft = left, r = 0;              // r: next slot pair (= rank of the next quality)
     uint32_t rev = 0, cc = 0, w0 = 0, w1 = 0;
     const char *bbase = reinterpret_cast<const char*>(beta);
@@ -104,7 +104,7 @@ __device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t qm, const
         if (pleft > 0 && rem == 0) { \
             if (pend > 0) { rev = 0; rem = pend; pend = 0; }         /* the forward-strand reads of the same quality */ \
             else { \
-                if (r == NSLOT / 2) { fill_slots(s_slot, qm, tid, src, nsrc); r = 0; two_nx = SLOT_PAIR(0); } \
+                if (r == NSLOT / 2) { fill_slots<false>(s_slot, qm, tid, src, nsrc); r = 0; two_nx = SLOT_PAIR(0); } \
                 const int curq = 63 - __clzll((long long)(qm | 1ull)); \
                 qm &= ~(1ull << curq); \
                 const uint32_t two = (two_nx >> (16 * (r & 1))) & 0xffffu; \
