@@ -36,7 +36,21 @@ def parse():
     ap.add_argument("--var-rate", type=float, default=0.01)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget on rank 0 at N=1 (0: skip)")
     ap.add_argument("--seed", type=int, default=20260104)
+    ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the CPU baseline on all host cores (0: skip)")
     return ap.parse_args()
+
+
+def host_cores():
+    """Cores this process may really use: the cgroup CPU quota if there is one, else the affinity mask, and never more
+    than 16 per GPU (the share of a one-GPU box)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
 
 
 def algorithmic_bytes(n_sites, n_smpl, n_reads, A=2):
@@ -164,12 +178,40 @@ def main():
                 orc.mcall(cfg, cin)
                 return time.perf_counter() - c0
             probe = min(T, 64)
+            cpu_run(probe)                                   # first call: library load, errmod tables
             tp = cpu_run(probe)
             ns = int(max(probe, min(T, a.cpu_seconds / max(tp / probe, 1e-9))))
             tc = cpu_run(ns)
+            model = ""
+            try:
+                model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+            except Exception:
+                pass
             out["cpu_baseline"] = {"value": ns / tc, "unit": "sites/s", "cores": 1, "kind": "port",
                                    "sample": "first %d sites of the same tile (%d samples x %.0fx), oracle/liboracle.so "
-                                             "mpileup+mcall on one host core, %.1f s" % (ns, S, a.depth, tc)}
+                                             "mpileup+mcall on one host core, %.1f s" % (ns, S, a.depth, tc),
+                                   "cpu_model": model}
+            # all host cores, region-sharded (how users scale the reference: one process per region, -r + concat)
+            ncore = host_cores()
+            if ncore > 1 and a.cpu_all_cores:
+                import subprocess, tempfile, glob
+                per = int(max(16, min(256, (ns / tc) * a.cpu_seconds / 2)))          # sites per worker tile ...
+                reps = int(max(1, round((ns / tc) * a.cpu_seconds / 2 / per)))       # ... repeated to ~cpu_seconds/2 of work
+                go = os.path.join(tempfile.mkdtemp(prefix="bcfgpu_cpu_"), "go")
+                env = dict(os.environ, OMP_NUM_THREADS="1")
+                procs = [subprocess.Popen([sys.executable, "-m", "tests.helpers.cpu_worker", str(a.seed + 1000 + i), str(per),
+                                           str(S), str(a.depth), go, str(reps)], cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+                         for i in range(ncore)]
+                t_wait = time.time()
+                while len(glob.glob(go + ".ready.*")) < ncore and time.time() - t_wait < 300 and all(p.poll() is None for p in procs):
+                    time.sleep(0.05)
+                open(go, "w").close()
+                res = [p.communicate()[0].split() for p in procs]
+                if all(len(r) == 2 for r in res):
+                    tmax = max(float(r[1]) for r in res)
+                    out["cpu_baseline"]["all_cores"] = {"value": sum(int(r[0]) for r in res) / tmax, "unit": "sites/s",
+                                                        "cores": ncore, "sample": "%d region shards of %d sites x %d passes, one "
+                                                        "oracle process per core, %.1f s" % (ncore, per, reps, tmax)}
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
