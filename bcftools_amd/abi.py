@@ -104,6 +104,11 @@ class IndelOut(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("ret", "p_aux", "indel_types", "inscns", "maxins", "indelreg", "max_support", "max_frac")]
 
 
+class GapStats(C.Structure):
+    _fields_ = [("n_jobs", C.c_uint64), ("n_passes", C.c_uint64), ("dp_cells", C.c_uint64),
+                ("kernel_ms", C.c_float), ("prepare_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float)]
+
+
 class Timing(C.Structure):
     _fields_ = [("glfgen_ms", C.c_float), ("combine_ms", C.c_float),
                 ("mcall_ms", C.c_float), ("total_ms", C.c_float)]
@@ -127,6 +132,7 @@ PROTOTYPES = {
     "bcfgpu_mpileup": (C.c_int, [C.c_void_p, C.POINTER(Tile), C.POINTER(MplpOut)]),
     "bcfgpu_mcall": (C.c_int, [C.c_void_p, C.POINTER(CallIn), C.POINTER(CallOut)]),
     "bcfgpu_gap_prep": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.POINTER(IndelIn), C.POINTER(IndelOut), C.c_int]),
+    "bcfgpu_gap_prep_stats": (C.c_int, [C.c_void_p, C.POINTER(GapStats)]),
     "bcfgpu_pipeline": (C.c_int, [C.c_void_p, C.POINTER(Tile), C.c_void_p, C.c_void_p,
                                   C.POINTER(MplpOut), C.POINTER(CallOut)]),
     "bcfgpu_mplp_out_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),

@@ -45,6 +45,7 @@ struct bcfgpu_ctx {
     std::vector<hipEvent_t> pool;   // mode 2: 4 events per launch sequence
     std::vector<int> pool_call;     // mode 2: 1 if the sequence included the call kernel
     std::vector<void*> owned;
+    bcfgpu_gap_stats gap{};         // statistics of the last bcfgpu_gap_prep
 };
 
 extern "C" {
@@ -461,19 +462,35 @@ int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnJob> &jo
     GP_CHK(hipMemcpyAsync(d_qq, qq.data(), qq.size(), hipMemcpyHostToDevice, c->stream));
     p.ref2 = (const uint8_t*)d_ref2; p.query = (const uint8_t*)d_q; p.qq = (const uint8_t*)d_qq;
     p.q2p = c->d_q2p; p.scratch = (double*)d_scr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, c->stream);
     for (size_t j0 = 0; j0 < nj; j0 += chunk) {
         p.n_jobs = (int)(nj - j0 < chunk ? nj - j0 : chunk);
         p.jobs = (const ProbalnJob*)d_jobs + j0;
         p.score1 = (int32_t*)d_s1 + j0; p.score2 = (int32_t*)d_s2 + j0;
         launch_probaln(p, c->stream);
     }
+    hipEventRecord(e1, c->stream);
     GP_CHK(hipGetLastError());
     score1.resize(nj); score2.resize(nj);
     GP_CHK(hipMemcpyAsync(score1.data(), d_s1, nj * 4, hipMemcpyDeviceToHost, c->stream));
     GP_CHK(hipMemcpyAsync(score2.data(), d_s2, nj * 4, hipMemcpyDeviceToHost, c->stream));
     GP_CHK(hipStreamSynchronize(c->stream));
     #undef GP_CHK
+    c->gap.kernel_ms = 0;
+    hipEventElapsedTime(&c->gap.kernel_ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
     cleanup();
+    return 0;
+}
+
+bcfgpu_gap_stats *bcfgpu_internal_gap_stats(bcfgpu_ctx *c) { return &c->gap; }
+
+int bcfgpu_gap_prep_stats(const bcfgpu_ctx *c, bcfgpu_gap_stats *out)
+{
+    if (!c || !out) return set_err(BCFGPU_E_ARG, "bcfgpu_gap_prep_stats: bad arguments");
+    *out = c->gap;
     return 0;
 }
 

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <vector>
 #include <algorithm>
+#include <chrono>
 #include "kernels.h"
 
 using namespace bcfgpu;
@@ -22,6 +23,7 @@ extern "C" int bcfgpu_internal_run_probaln(bcfgpu_ctx *ctx, const std::vector<Pr
                                            const std::vector<uint8_t> &query, const std::vector<uint8_t> &qq, int max_bw,
                                            std::vector<int32_t> &score1, std::vector<int32_t> &score2);
 int bcfgpu_set_error(int code, const char *what);
+extern "C" bcfgpu_gap_stats *bcfgpu_internal_gap_stats(bcfgpu_ctx *ctx);
 
 namespace {
 
@@ -101,6 +103,11 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
         return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep: bad arguments");
     const int n = in->n_smpl;
     const char *ref = in->ref;
+    bcfgpu_gap_stats &gs = *bcfgpu_internal_gap_stats(ctx);
+    gs = bcfgpu_gap_stats{};
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     std::vector<SiteState> st(in->n_sites);
     std::vector<ProbalnJob> jobs;
     std::vector<uint8_t> ref2pool, qpool, qqpool;
@@ -314,12 +321,25 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
         #undef PE
     }
 
+    gs.prepare_ms = ms_since(t_begin);
     // ---- device: forward scores of every job
     std::vector<int32_t> sc1, sc2;
     if (!jobs.empty()) {
         const int rc = bcfgpu_internal_run_probaln(ctx, jobs, ref2pool, qpool, qqpool, max_bw, sc1, sc2);
         if (rc) return rc;
+        gs.n_jobs = jobs.size();
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            const ProbalnJob &jb = jobs[j];
+            if (jb.l_ref <= 0 || jb.l_query <= 0) continue;
+            int bw = jb.l_ref > jb.l_query ? jb.l_ref : jb.l_query;
+            if (bw > jb.bw) bw = jb.bw;
+            if (bw < std::abs(jb.l_ref - jb.l_query)) bw = std::abs(jb.l_ref - jb.l_query);
+            const uint64_t cells = (uint64_t)jb.l_query * (2 * bw + 1) * 3;
+            const int passes = (sc1[j] >> 8) > 5 ? 2 : 1;          // bam2bcf_indel.c:351
+            gs.n_passes += passes; gs.dp_cells += cells * passes;
+        }
     }
+    const auto t_fin = std::chrono::steady_clock::now();
 
     // ---- finalize (:372-469)
     for (int is = 0; is < in->n_sites; ++is) {
@@ -385,5 +405,7 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
         if (out->indelreg) out->indelreg[is] = S.indelreg;
         out->ret[is] = n_alt > 0 ? 0 : -1;
     }
+    gs.finalize_ms = ms_since(t_fin);
+    gs.total_ms = ms_since(t_begin);
     return BCFGPU_OK;
 }

@@ -130,3 +130,61 @@ def tile_from_torch(t):
     """Copy a torch_tile() dict to a HostTile (for the oracle / CPU baseline)."""
     return host.HostTile(t["n_smpl"], t["ref16"].cpu().numpy(), t["plp_off"].cpu().numpy().view(np.uint32),
                          t["rd"].cpu().numpy().view(np.uint32), t["epos"].cpu().numpy())
+
+
+def indel_batch(seed, n_sites, n_smpl, depth=30.0, read_len=100, max_depth=200):
+    """Synthetic input of bcfgpu_gap_prep (BASELINE configs[2] shape: indel-candidate columns): a random reference with
+    one indel locus every 300 bp (length -3..+3, weights 1/|len|), HWE carriers, Poisson depth, reads of `read_len`
+    bases placed so that the locus falls inside them, substitution errors at 10^(-Q/10).  Every pileup entry owns its
+    read (the flat pool of bcfgpu_reads allows sharing; sharing does not change the work).
+
+    Returns dict(ref=bytes, reads=dict of the bcfgpu_reads arrays, pos, smpl_off, p_read, p_qpos, p_indel, itype)."""
+    rng = np.random.Generator(np.random.Philox(key=int(seed)))
+    S = n_smpl
+    L = 200 + 300 * n_sites + 300
+    ref2 = rng.integers(0, 4, L)
+    pos = (200 + 300 * np.arange(n_sites)).astype(np.int32)
+    lens = np.array([-3, -2, -1, 1, 2, 3])
+    w = 1.0 / np.abs(lens)
+    itype = lens[rng.choice(6, size=n_sites, p=w / w.sum())]
+    ins2 = rng.integers(0, 4, (n_sites, 3))
+    af = np.clip(rng.beta(0.5, 5.0, n_sites), 0.05, 0.5)
+    nalt = rng.binomial(2, np.repeat(af, S))
+    n = np.minimum(rng.poisson(depth, n_sites * S), max_depth).astype(np.int64)
+    off = np.zeros(n_sites * S + 1, dtype=np.int64)
+    np.cumsum(n, out=off[1:])
+    R = int(off[-1])
+    cell = np.repeat(np.arange(n_sites * S), n)
+    site = cell // S
+    carrier = rng.random(R) < nalt[cell] * 0.5
+    carrier ^= rng.random(R) < 0.005                               # alignment/sequencing indel noise
+    qpos = rng.integers(8, read_len - 12, R)
+    start = pos[site].astype(np.int64) - qpos
+    ilen = np.where(carrier, itype[site], 0).astype(np.int64)
+    j = np.arange(read_len)[None, :]
+    after = j > qpos[:, None]
+    shift = np.where(ilen[:, None] < 0, -ilen[:, None], -np.minimum(ilen[:, None], np.maximum(j - qpos[:, None], 0)))
+    base = ref2[start[:, None] + j + np.where(after, shift, 0)]
+    k = j - qpos[:, None] - 1
+    is_ins = after & (ilen[:, None] > 0) & (k < ilen[:, None])
+    base = np.where(is_ins, ins2[site[:, None], np.clip(k, 0, 2)], base)
+    bq = BQ_VALUES[rng.choice(len(BQ_VALUES), size=(R, read_len), p=BQ_PMF)]
+    err = rng.random((R, read_len)) < 10.0 ** (-bq / 10.0)
+    base = np.where(err, (base + rng.integers(1, 4, (R, read_len))) % 4, base)
+    seq16 = (1 << base).astype(np.uint8)
+    # CIGAR (BAM encoding len<<4|op, M=0 I=1 D=2): 100M, or aM xD bM / aM xI bM around the locus
+    a = qpos + 1
+    al = np.abs(ilen)
+    c3 = np.stack([a << 4, (al << 4) | np.where(ilen > 0, 1, 2), (read_len - a - np.where(ilen > 0, al, 0)) << 4], axis=1)
+    ncig = np.where(ilen != 0, 3, 1).astype(np.int32)
+    c3[ilen == 0, 0] = read_len << 4
+    keep = np.arange(3)[None, :] < ncig[:, None]
+    cig = c3[keep].astype(np.uint32)
+    i32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
+    reads = dict(n_reads=R, r_pos=i32(start), r_lq=i32(np.full(R, read_len)), r_flag=i32(rng.integers(0, 2, R) * 16),
+                 r_ncig=ncig, r_cig_off=i32(np.concatenate([[0], np.cumsum(ncig)[:-1]])),
+                 r_seq_off=i32(np.arange(R, dtype=np.int64) * read_len), cig=np.ascontiguousarray(cig),
+                 seq16=np.ascontiguousarray(seq16.ravel()), qual=np.ascontiguousarray(bq.astype(np.uint8).ravel()),
+                 zq=np.zeros(R * read_len, dtype=np.uint8), r_has_zq=np.zeros(R, dtype=np.uint8))
+    return dict(ref=bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[ref2]), reads=reads, pos=pos, smpl_off=i32(off),
+                p_read=i32(np.arange(R)), p_qpos=i32(qpos), p_indel=i32(ilen), itype=itype, n_sites=n_sites, n_smpl=S)

@@ -14,6 +14,7 @@
  *                                           for every site of a tile          bam2bcf.h:137-138,142
  *                                           (call sites mpileup.c:343-347 and :357-360)
  *    bcfgpu_gap_prep                     <- bcf_call_gap_prep                  bam2bcf.h:141 (bam2bcf_indel.c:99-470)
+ *    bcfgpu_gap_prep_stats               <- (measurement only)
  *    bcfgpu_mcall                        <- mcall()                            call.h:131 (mcall.c:1430-1684)
  *                                           incl. the per-record prologue of vcfcall.c:1096-1115
  *    bcfgpu_pipeline                     <- the `mpileup -Ou | call -m` pipe with PL/QS/I16 kept in HBM
@@ -294,6 +295,16 @@ typedef struct {
 
 int  bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const bcfgpu_indel_in *in, const bcfgpu_indel_out *out,
                      int inscns_cap);
+
+/* statistics of the last bcfgpu_gap_prep call on this context (SURVEY 8d "indel stage unit": DP cells per second):
+ * jobs = (site, candidate type, read) realignments, passes = forward passes run (a second parameter set is tried when
+ * the first score exceeds 5, bam2bcf_indel.c:351), dp_cells = sum over passes of l_query * (2*bw+1) * 3 */
+typedef struct {
+    uint64_t n_jobs, n_passes, dp_cells;
+    float kernel_ms;             /* probaln_kernel launches, HIP events on the context's stream */
+    float prepare_ms, finalize_ms, total_ms;   /* host typing/consensus, host scoring, whole call (wall clock) */
+} bcfgpu_gap_stats;
+int  bcfgpu_gap_prep_stats(const bcfgpu_ctx *ctx, bcfgpu_gap_stats *out);
 
 /* byte sizes of the output planes for a tile of n_sites (n_smpl from the context) */
 size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *ctx, int n_sites, int which /*0 site,1 pl,2 dp4,3 adf,4 adr,5 qs,6 scr*/);

@@ -1,0 +1,87 @@
+"""bcf_call_gap_prep on a synthetic batch (synth.indel_batch): through bcfgpu_gap_prep (one call for the whole batch)
+and through the oracle (orc_gap_prep, one site at a time)."""
+import ctypes as C
+
+import numpy as np
+
+from bcftools_amd import abi
+from tests.helpers import mplpdrv
+
+CAP = 64
+READ_KEYS = ("r_pos", "r_lq", "r_flag", "r_ncig", "r_cig_off", "r_seq_off", "cig", "seq16", "qual", "zq", "r_has_zq")
+DEFAULTS = dict(openQ=40, extQ=20, tandemQ=100, min_support=1, min_frac=0.002, per_sample_flt=0)   # mpileup.c:937-950
+
+
+def gap_prep_gpu(ctx, b, **kw):
+    """Returns (dict of output arrays, abi.GapStats)."""
+    from bcftools_amd.lib import check
+    o = dict(DEFAULTS, **kw)
+    ns, E = b["n_sites"], len(b["p_read"])
+    rd = abi.Reads()
+    rd.n_reads = b["reads"]["n_reads"]
+    for k in READ_KEYS:
+        setattr(rd, k, b["reads"][k].ctypes.data)
+    ii = abi.IndelIn()
+    ii.n_sites, ii.n_smpl = ns, b["n_smpl"]
+    ii.pos, ii.smpl_off, ii.p_read, ii.p_qpos, ii.p_indel = (b["pos"].ctypes.data, b["smpl_off"].ctypes.data, b["p_read"].ctypes.data,
+                                                             b["p_qpos"].ctypes.data, b["p_indel"].ctypes.data)
+    ii.ref = b["ref"]
+    ii.openQ, ii.extQ, ii.tandemQ, ii.min_support, ii.per_sample_flt, ii.min_frac = (o["openQ"], o["extQ"], o["tandemQ"],
+                                                                                      o["min_support"], o["per_sample_flt"], o["min_frac"])
+    out = dict(ret=np.zeros(ns, np.int32), aux=np.zeros(E, np.uint32), indel_types=np.zeros((ns, 4), np.int32),
+               inscns=np.zeros((ns, 4 * CAP), np.int8), maxins=np.zeros(ns, np.int32), indelreg=np.zeros(ns, np.int32),
+               max_support=np.zeros(ns, np.int32), max_frac=np.zeros(ns, np.float32))
+    oo = abi.IndelOut()
+    oo.ret, oo.p_aux, oo.indel_types, oo.inscns = (out["ret"].ctypes.data, out["aux"].ctypes.data, out["indel_types"].ctypes.data,
+                                                  out["inscns"].ctypes.data)
+    oo.maxins, oo.indelreg, oo.max_support, oo.max_frac = (out["maxins"].ctypes.data, out["indelreg"].ctypes.data,
+                                                           out["max_support"].ctypes.data, out["max_frac"].ctypes.data)
+    check(ctx.L.bcfgpu_gap_prep(ctx.h, C.byref(rd), C.byref(ii), C.byref(oo), CAP))
+    st = abi.GapStats()
+    check(ctx.L.bcfgpu_gap_prep_stats(ctx.h, C.byref(st)))
+    return out, st
+
+
+def gap_prep_oracle_site(b, k, **kw):
+    """orc_gap_prep for site k of the batch; returns None (ret<0) or dict like one row of gap_prep_gpu's output."""
+    o = dict(DEFAULTS, **kw)
+    L = mplpdrv._realn_lib()
+    S = b["n_smpl"]
+    r = b["reads"]
+    soff = np.ascontiguousarray(b["smpl_off"][k * S:(k + 1) * S + 1])
+    e0, e1 = int(soff[0]), int(soff[-1])
+    soff = soff - e0
+    sl = lambda a: np.ascontiguousarray(a[e0:e1])
+    p_read, p_qpos, p_indel = sl(b["p_read"]), sl(b["p_qpos"]), sl(b["p_indel"])
+    aux = np.zeros(e1 - e0, np.uint32)
+    types = np.zeros(4, np.int32)
+    inscns = np.zeros(4 * CAP, np.int8)
+    maxins, indelreg, msup, mfrac = C.c_int(), C.c_int(), C.c_int(), C.c_float()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    L.orc_gap_prep.restype = C.c_int
+    L.orc_gap_prep.argtypes = [C.c_int] + [C.c_void_p] * 15 + [C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                               C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.orc_gap_prep(S, p(soff), p(p_read), p(p_qpos), p(p_indel), p(r["r_pos"]), p(r["r_lq"]), p(r["r_flag"]), p(r["r_ncig"]),
+                        p(r["r_cig_off"]), p(r["cig"]), p(r["r_seq_off"]), p(r["seq16"]), p(r["qual"]), p(r["zq"]), p(r["r_has_zq"]),
+                        int(b["pos"][k]), b["ref"], o["openQ"], o["extQ"], o["tandemQ"], o["min_support"], o["min_frac"],
+                        o["per_sample_flt"], p(aux), p(types), p(inscns), len(inscns), C.byref(maxins), C.byref(indelreg),
+                        C.byref(msup), C.byref(mfrac))
+    if rc < 0:
+        return None
+    return dict(aux=aux, e0=e0, e1=e1, indel_types=types, inscns=inscns, maxins=maxins.value, indelreg=indelreg.value,
+                max_support=msup.value, max_frac=float(mfrac.value))
+
+
+def assert_site_equal(got, k, want):
+    """Row k of the batched HIP result against the oracle's result for that site."""
+    if want is None:
+        assert got["ret"][k] < 0
+        return
+    assert got["ret"][k] == 0
+    np.testing.assert_array_equal(got["aux"][want["e0"]:want["e1"]], want["aux"], err_msg="p->aux site %d" % k)
+    np.testing.assert_array_equal(got["indel_types"][k], want["indel_types"])
+    assert (got["maxins"][k], got["indelreg"][k], got["max_support"][k]) == (want["maxins"], want["indelreg"], want["max_support"])
+    assert got["max_frac"][k] == np.float32(want["max_frac"])
+    n = 4 * want["maxins"]
+    np.testing.assert_array_equal(got["inscns"][k][:n], want["inscns"][:n])
