@@ -462,6 +462,7 @@ int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnJob> &jo
     GP_CHK(hipMemcpyAsync(d_qq, qq.data(), qq.size(), hipMemcpyHostToDevice, c->stream));
     p.ref2 = (const uint8_t*)d_ref2; p.query = (const uint8_t*)d_q; p.qq = (const uint8_t*)d_qq;
     p.q2p = c->d_q2p; p.scratch = (double*)d_scr;
+    { const char *ab = getenv("BCFGPU_ABLATE"); p.force_scratch = ab && (atoi(ab) & 256) ? 1 : 0; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, c->stream);

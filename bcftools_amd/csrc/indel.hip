@@ -93,6 +93,111 @@ __device__ int probaln_fwd(const uint8_t *ref, int l_ref, const uint8_t *query, 
     return (int)(Pr1 + .499);
 }
 
+// The same forward pass with the scaled row held in registers, for bands of half-width <= BWM (|indel| <= BWM-3: the
+// common case).  A row has 2*bw+1 live cells x 3 states; position p of the register row is reference column
+// k = p + x - 1 with x = max(0, i - bw), exactly the slot set_u() assigns in the rolling-row version, so row i is
+// computed in place from row i-1: while the band hugs the left edge (i <= bw) the diagonal neighbour of p is p-1,
+// afterwards the band slides by one column per row and it is p itself.  The reference window travels in one 64-bit
+// register (3 bits per base, shifted as the band slides).  No scratch memory: the rolling-row version moves
+// 48 bytes per cell through HBM and is bandwidth-bound; this one is bound by fp64 issue.
+template <int BWM>
+__device__ int probaln_fwd_reg(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
+                               const float *q2p, double d, double e_, int bw)
+{
+    constexpr int NP = 2 * BWM + 3;                       // positions 0 .. 2*BWM+2
+    double M[NP], I[NP], D[NP];
+    #pragma unroll
+    for (int p = 0; p < NP; ++p) M[p] = I[p] = D[p] = 0.;
+    const int bw2 = bw * 2 + 1;
+    double m[9];
+    const double sM = 1. / (2 * l_query + 2), sI = sM;
+    m[0] = (1 - d - d) * (1 - sM); m[1] = m[2] = d * (1 - sM);
+    m[3] = (1 - e_) * (1 - sI); m[4] = e_ * (1 - sI); m[5] = 0.;
+    m[6] = 1 - e_; m[7] = 0.; m[8] = e_;
+    const double bM = (1 - d) / l_ref, bI = d / l_ref;
+    // reference window: base of position p (column k = p + x - 1) in bits [3p, 3p+3); x = 0 to begin with
+    uint64_t rw = 0;
+    #pragma unroll
+    for (int p = 2; p < NP; ++p) rw |= (uint64_t)(p - 2 < l_ref ? ref[p - 2] : 4) << (3 * p);
+    double prod = 1., Pr1 = 0.;
+    // f[1]
+    {
+        double sum = 0.;
+        const int end = l_ref < bw + 1 ? l_ref : bw + 1;
+        const double q0 = (double)q2p[iqual[0]];
+        const int qy = query[0];
+        #pragma unroll
+        for (int p = 2; p < NP; ++p) {
+            if (p - 1 <= end) {
+                const int rb = (int)((rw >> (3 * p)) & 7);
+                const double e = (rb > 3 || qy > 3) ? 1. : rb == qy ? 1. - q0 : q0 * EM;
+                const double a = e * bM, b = EI * bI;
+                M[p] = a; I[p] = b;
+                sum += a + b;
+            }
+        }
+        #pragma unroll
+        for (int p = 2; p < NP; ++p)
+            if (p - 1 <= end) { M[p] /= sum; I[p] /= sum; D[p] /= sum; }
+        prod *= sum;
+        if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
+    }
+    int x = 0;                                            // first column of the band minus one: max(0, i - bw)
+    for (int i = 2; i <= l_query; ++i) {
+        const double qli = (double)q2p[iqual[i - 1]];
+        const int qyi = query[i - 1];
+        const bool slide = i > bw;                        // x grows by one on this row
+        if (slide) {
+            ++x;
+            rw >>= 3;
+            const int nk = (NP - 1) + x - 2;              // reference index of the new top position
+            rw |= (uint64_t)(nk < l_ref ? ref[nk] : 4) << (3 * (NP - 1));
+        }
+        const int end = l_ref < i + bw ? l_ref : i + bw;
+        const int plo = x == 0 ? 2 : 1, phi = end - x + 1;
+        double sum = 0.;
+        // in place, ascending p: the left neighbour is the new [p-1]; the diagonal one is the old [p] once the band
+        // slides, the old [p-1] (carried) before; the upper one is the old [p+1] resp. the old [p]
+        double cM = M[0], cI = I[0], cD = D[0];           // old [p-1]
+        M[0] = I[0] = D[0] = 0.;
+        #pragma unroll
+        for (int p = 1; p < NP; ++p) {
+            const double oM = M[p], oI = I[p], oD = D[p];
+            const double nM = p + 1 < NP ? M[p + 1 < NP ? p + 1 : p] : 0., nI = p + 1 < NP ? I[p + 1 < NP ? p + 1 : p] : 0.;
+            double f0 = 0., f1 = 0., f2 = 0.;
+            if (p >= plo && p <= phi) {
+                const int rb = (int)((rw >> (3 * p)) & 7);
+                const double e = (rb > 3 || qyi > 3) ? 1. : rb == qyi ? 1. - qli : qli * EM;
+                const double gM = slide ? oM : cM, gI = slide ? oI : cI, gD = slide ? oD : cD;
+                const double uM = slide ? nM : oM, uI = slide ? nI : oI;
+                f0 = e * (m[0] * gM + m[3] * gI + m[6] * gD);
+                f1 = EI * (m[1] * uM + m[4] * uI);
+                f2 = m[2] * M[p - 1] + m[8] * D[p - 1];
+                sum += f0 + f1 + f2;
+            }
+            M[p] = f0; I[p] = f1; D[p] = f2;
+            cM = oM; cI = oI; cD = oD;
+        }
+        const double r = 1. / sum;
+        #pragma unroll
+        for (int p = 1; p < NP; ++p) { M[p] *= r; I[p] *= r; D[p] *= r; }
+        prod *= sum;
+        if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
+    }
+    {   // f[l_query+1]: columns k = 1..l_ref whose slot lies inside the band of the last row
+        double sum = 0.;
+        const int phi = l_ref - x + 1 < bw2 ? l_ref - x + 1 : bw2;
+        const int plo = x == 0 ? 2 : 1;
+        #pragma unroll
+        for (int p = 1; p < NP; ++p)
+            if (p >= plo && p <= phi) sum += M[p] * sM + I[p] * sI;
+        prod *= sum;
+        if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
+    }
+    Pr1 += -4.343 * log(prod * l_ref * l_query);
+    return (int)(Pr1 + .499);
+}
+
 __global__ __launch_bounds__(64) void probaln_kernel(const ProbalnParams P)
 {
     const int job = blockIdx.x * 64 + threadIdx.x;
@@ -101,16 +206,25 @@ __global__ __launch_bounds__(64) void probaln_kernel(const ProbalnParams P)
     const size_t stride = P.scratch_stride;
     double *row0 = P.scratch + job, *row1 = P.scratch + (size_t)P.ncell * stride + job;
     const uint8_t *ref = P.ref2 + j.ref_off, *query = P.query + j.query_off, *qq = P.qq + j.query_off;
-    // apf1 = {1e-4, 1e-2, bw}, apf2 = {1e-6, 1e-3, bw}  (bam2bcf_indel.c:293-294)
-    int sc = probaln_fwd(ref, j.l_ref, query, j.l_query, qq, P.q2p, 1e-4, 1e-2, j.bw, row0, row1, stride, P.ncell);
-    int l = (int)(100. * sc / j.l_query + .499);
-    if (l > 255) l = 255;
-    int s1 = sc << 8 | l, s2 = s1;
-    if (sc > 5) {
-        sc = probaln_fwd(ref, j.l_ref, query, j.l_query, qq, P.q2p, 1e-6, 1e-3, j.bw, row0, row1, stride, P.ncell);
-        l = (int)(100. * sc / j.l_query + .499);
+    // (bam2bcf_indel.c:293-294, 346-356)
+    // the band probaln_glocal really uses (probaln.c): min(bw, max(l_ref, l_query)), at least |l_ref - l_query|
+    int eff = j.l_ref > j.l_query ? j.l_ref : j.l_query;
+    if (eff > j.bw) eff = j.bw;
+    if (eff < abs(j.l_ref - j.l_query)) eff = abs(j.l_ref - j.l_query);
+    constexpr int BWM = 6;
+    const bool reg = eff <= BWM && j.l_ref > 0 && j.l_query > 0 && !P.force_scratch;
+    // apf1 = {1e-4, 1e-2, bw}; a second parameter set apf2 = {1e-6, 1e-3, bw} is tried when the first score exceeds 5
+    int s1 = 0, s2 = 0;
+    double gd = 1e-4, ge = 1e-2;
+    #pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        const int sc = reg ? probaln_fwd_reg<BWM>(ref, j.l_ref, query, j.l_query, qq, P.q2p, gd, ge, eff)
+                           : probaln_fwd(ref, j.l_ref, query, j.l_query, qq, P.q2p, gd, ge, j.bw, row0, row1, stride, P.ncell);
+        int l = (int)(100. * sc / j.l_query + .499);
         if (l > 255) l = 255;
-        s2 = sc << 8 | l;
+        const int v = sc << 8 | l;
+        if (pass == 0) { s1 = s2 = v; if (sc <= 5) break; gd = 1e-6; ge = 1e-3; }
+        else s2 = v;
     }
     P.score1[job] = s1;
     P.score2[job] = s2;

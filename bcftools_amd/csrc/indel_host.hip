@@ -14,6 +14,8 @@
 #include <vector>
 #include <algorithm>
 #include <chrono>
+#include <thread>
+#include <functional>
 #include "kernels.h"
 
 using namespace bcfgpu;
@@ -109,11 +111,14 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
     auto ms_since = [](std::chrono::steady_clock::time_point t0) {
         return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     std::vector<SiteState> st(in->n_sites);
-    std::vector<ProbalnJob> jobs;
-    std::vector<uint8_t> ref2pool, qpool, qqpool;
-    int max_bw = 0;
-
-    for (int is = 0; is < in->n_sites; ++is) {
+    // Sites are independent: contiguous chunks of sites are prepared by host threads into their own job pools, which
+    // are then concatenated in site order (job and pool offsets rebased).
+    struct Pools { std::vector<ProbalnJob> jobs; std::vector<uint8_t> ref2pool, qpool, qqpool; int max_bw = 0; };
+    auto prepare_range = [&](int is_begin, int is_end, Pools &PL) {
+    std::vector<ProbalnJob> &jobs = PL.jobs;
+    std::vector<uint8_t> &ref2pool = PL.ref2pool, &qpool = PL.qpool, &qqpool = PL.qqpool;
+    int &max_bw = PL.max_bw;
+    for (int is = is_begin; is < is_end; ++is) {
         SiteState &S = st[is];
         const int32_t *soff = in->smpl_off + (size_t)is * n;
         const int pos = in->pos[is];
@@ -257,6 +262,8 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
         const int max_ref2 = right - left + 2 + 2 * (max_ins > -types[0] ? max_ins : -types[0]);
         std::vector<char> ref2(max_ref2);
         S.N = N;
+        struct QSeg { int qbeg = -1, qend = -1; uint32_t off = 0; };
+        std::vector<QSeg> qseg(N);
         S.jobidx.assign((size_t)N * n_types, -1);
         S.job0 = jobs.size();
         S.indelreg = 0;
@@ -301,15 +308,26 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
                         if (eff < std::abs(jb.l_ref - jb.l_query)) eff = std::abs(jb.l_ref - jb.l_query);
                         if (eff > max_bw) max_bw = eff;
                     }
+                    // the query segment of a read is the same for every candidate type unless the window shrank: pooled once
+                    QSeg &qc = qseg[K];
+                    if (qc.qbeg == qbeg && qc.qend == qend) jb.query_off = qc.off;
+                    else {
                     jb.query_off = (uint32_t)qpool.size();
+                    qc.qbeg = qbeg; qc.qend = qend; qc.off = jb.query_off;
                     const uint8_t *qual = rd->qual + rd->r_seq_off[rdx];
                     const uint8_t *bq = (rd->r_has_zq && rd->r_has_zq[rdx] && rd->zq) ? rd->zq + rd->r_seq_off[rdx] : nullptr;
-                    for (int l = qbeg; l < qend; ++l) {
-                        qpool.push_back((uint8_t)nt16_int[seq[l] & 15]);
-                        uint8_t q = bq ? (uint8_t)(qual[l] + (bq[l] - 64)) : qual[l];
-                        if (q > 30) q = 30;
-                        if (q < 7) q = 7;
-                        qqpool.push_back(q);
+                    {
+                        const size_t o = qpool.size(), len = qend > qbeg ? (size_t)(qend - qbeg) : 0;
+                        qpool.resize(o + len); qqpool.resize(o + len);
+                        uint8_t *dq = qpool.data() + o, *dqq = qqpool.data() + o;
+                        for (int l = qbeg; l < qend; ++l) {
+                            dq[l - qbeg] = (uint8_t)nt16_int[seq[l] & 15];
+                            uint8_t q = bq ? (uint8_t)(qual[l] + (bq[l] - 64)) : qual[l];
+                            if (q > 30) q = 30;
+                            if (q < 7) q = 7;
+                            dqq[l - qbeg] = q;
+                        }
+                    }
                     }
                     S.jobidx[(size_t)K * n_types + t] = (int32_t)jobs.size();
                     jobs.push_back(jb);
@@ -319,6 +337,42 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
         S.live = true;
         #undef NPLP
         #undef PE
+    }
+    };  // prepare_range
+
+    std::vector<ProbalnJob> jobs;
+    std::vector<uint8_t> ref2pool, qpool, qqpool;
+    int max_bw = 0;
+    {
+        int nthr = (int)std::thread::hardware_concurrency();
+        if (const char *e = getenv("BCFGPU_HOST_THREADS")) nthr = atoi(e);
+        nthr = std::max(1, std::min(std::min(nthr, 16), in->n_sites));
+        std::vector<Pools> pools(nthr);
+        std::vector<std::thread> thr;
+        auto cut = [&](int t) { return (int)((long)in->n_sites * t / nthr); };
+        for (int t = 1; t < nthr; ++t) thr.emplace_back(prepare_range, cut(t), cut(t + 1), std::ref(pools[t]));
+        prepare_range(cut(0), cut(1), pools[0]);
+        for (auto &th : thr) th.join();
+        size_t nj = 0, nr = 0, nq = 0;
+        for (const Pools &pl : pools) { nj += pl.jobs.size(); nr += pl.ref2pool.size(); nq += pl.qpool.size(); }
+        if (nr >> 32 || nq >> 32 || nj >> 31) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_gap_prep: batch too large (pool offsets are 32-bit), use fewer sites per call");
+        jobs.reserve(nj); ref2pool.reserve(nr); qpool.reserve(nq); qqpool.reserve(nq);
+        for (int t = 0; t < nthr; ++t) {
+            Pools &pl = pools[t];
+            const uint32_t jb0 = (uint32_t)jobs.size(), r0 = (uint32_t)ref2pool.size(), q0 = (uint32_t)qpool.size();
+            for (ProbalnJob j : pl.jobs) { j.ref_off += r0; j.query_off += q0; jobs.push_back(j); }
+            ref2pool.insert(ref2pool.end(), pl.ref2pool.begin(), pl.ref2pool.end());
+            qpool.insert(qpool.end(), pl.qpool.begin(), pl.qpool.end());
+            qqpool.insert(qqpool.end(), pl.qqpool.begin(), pl.qqpool.end());
+            for (int is = cut(t); is < cut(t + 1); ++is) {
+                SiteState &S = st[is];
+                if (!S.live) continue;
+                S.job0 += jb0;
+                for (int32_t &j : S.jobidx) if (j >= 0) j += (int32_t)jb0;
+            }
+            if (pl.max_bw > max_bw) max_bw = pl.max_bw;
+            pl = Pools();
+        }
     }
 
     gs.prepare_ms = ms_since(t_begin);

@@ -78,6 +78,7 @@ struct McallParams {
 struct ProbalnJob { uint32_t ref_off, query_off; int32_t l_ref, l_query, bw; };
 struct ProbalnParams {
     int n_jobs, ncell;              // ncell: scratch cells per row (>= 3*(2*bw+1)+6 for the widest band)
+    int force_scratch;              // diagnostics (BCFGPU_ABLATE & 256): every job through the rolling-row version
     size_t scratch_stride;          // jobs rounded up; scratch is [2][ncell][stride] doubles
     const ProbalnJob *jobs;
     const uint8_t *ref2, *query, *qq;

@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget on rank 0 at N=1 (0: skip)")
     ap.add_argument("--seed", type=int, default=20260104)
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the CPU baseline on all host cores (0: skip)")
+    ap.add_argument("--mode", choices=["snp", "indel"], default="snp",
+                    help="snp: the headline pipeline (default).  indel: bcf_call_gap_prep on synthetic indel-candidate columns "
+                         "(BASELINE configs[2] shape, 500 samples), reports DP cells/s of the realignment kernel")
     return ap.parse_args()
 
 
@@ -62,8 +65,55 @@ def algorithmic_bytes(n_sites, n_smpl, n_reads, A=2):
     return b_in + b_out
 
 
+def main_indel(a):
+    """Secondary measurement (indel stage unit): bcfgpu_gap_prep over batches of 32 candidate columns."""
+    import torch
+    from bcftools_amd import abi, synth, engine
+    from tests.helpers import indeldrv
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    S = 500 if a.samples == 1000 else a.samples
+    n_sites = 128 if a.sites == 16384 else a.sites
+    per = 32
+    ctx = engine.Context(abi.default_cfg(S, max_sites=per, max_reads=64))
+    indeldrv.gap_prep_gpu(ctx, synth.indel_batch(a.seed, 2, 8, depth=10.0))          # warm-up: module load
+    tot = dict(jobs=0, passes=0, cells=0, kernel=0.0, prepare=0.0, finalize=0.0, total=0.0, sites=0, live=0, entries=0)
+    first = None
+    for c in range(0, n_sites, per):
+        b = synth.indel_batch(a.seed + c, min(per, n_sites - c), S, depth=a.depth)
+        got, st = indeldrv.gap_prep_gpu(ctx, b)
+        if first is None:
+            first = (b, got)
+        tot["jobs"] += st.n_jobs; tot["passes"] += st.n_passes; tot["cells"] += st.dp_cells
+        tot["kernel"] += st.kernel_ms; tot["prepare"] += st.prepare_ms; tot["finalize"] += st.finalize_ms; tot["total"] += st.total_ms
+        tot["sites"] += b["n_sites"]; tot["live"] += int((got["ret"] == 0).sum()); tot["entries"] += len(b["p_read"])
+    out = {"metric": "indel-candidate columns/sec through bcf_call_gap_prep (host typing + probaln_kernel), %d samples x %.0fx" % (S, a.depth),
+           "value": tot["sites"] / (tot["total"] * 1e-3), "unit": "sites/s", "n_gpus": 1, "higher_is_better": True,
+           "dtype": "f64 pair-HMM forward", "data": "synthetic",
+           "config": {"workload": "synthetic indel-candidate columns (BASELINE configs[2] shape), batches of %d columns" % per,
+                      "samples": S, "depth": a.depth, "sites": tot["sites"], "pileup_entries": tot["entries"]},
+           "kernel": {"name": "probaln_kernel", "jobs": tot["jobs"], "forward_passes": tot["passes"], "dp_cells": tot["cells"],
+                      "kernel_ms": tot["kernel"], "dp_cells_per_s": tot["cells"] / (tot["kernel"] * 1e-3)},
+           "host_ms": {"prepare": tot["prepare"], "finalize": tot["finalize"], "whole_call": tot["total"]}}
+    if a.cpu_seconds > 0:
+        b, got = first
+        t0 = time.perf_counter()
+        k = 0
+        while k < b["n_sites"] and (k < 1 or time.perf_counter() - t0 < a.cpu_seconds):
+            indeldrv.assert_site_equal(got, k, indeldrv.gap_prep_oracle_site(b, k))
+            k += 1
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": k / tc, "unit": "sites/s", "cores": 1, "kind": "port",
+                               "sample": "first %d columns of the first batch, oracle orc_gap_prep on one host core, %.1f s "
+                                         "(results compared with the device path)" % (k, tc)}
+    print(json.dumps(out), flush=True)
+    ctx.close()
+
+
 def main():
     a = parse()
+    if a.mode == "indel":
+        return main_indel(a)
     import torch
     import torch.distributed as dist
     from bcftools_amd import abi, synth, engine, shard
