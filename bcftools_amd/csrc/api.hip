@@ -488,6 +488,16 @@ int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnJob> &jo
 
 bcfgpu_gap_stats *bcfgpu_internal_gap_stats(bcfgpu_ctx *c) { return &c->gap; }
 
+// for the stages implemented in their own translation units: bind the device, hand out the stream and shared tables
+int bcfgpu_internal_device(bcfgpu_ctx *c, hipStream_t *stream, const float **q2p)
+{
+    if (!c) return -1;
+    hipSetDevice(c->cfg.device);
+    if (stream) *stream = c->stream;
+    if (q2p) *q2p = c->d_q2p;
+    return 0;
+}
+
 int bcfgpu_gap_prep_stats(const bcfgpu_ctx *c, bcfgpu_gap_stats *out)
 {
     if (!c || !out) return set_err(BCFGPU_E_ARG, "bcfgpu_gap_prep_stats: bad arguments");

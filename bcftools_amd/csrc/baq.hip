@@ -1,0 +1,345 @@
+// baq.hip -- BAQ (base alignment quality): htslib's sam_prob_realn() for a pool of reads, as `bcftools mpileup`
+// applies it to every read before the pileup (mpileup.c:234).
+//
+// Per read: reference window and band (realn.c), the banded glocal pair-HMM of probaln_glocal() with the full
+// forward and backward passes and the posterior maximum per query base (probaln.c), then the quality cap
+// (plain or extended).  One lane per read; the scaled forward and backward matrices live in a scratch buffer laid
+// out [row][cell][read] so that the 64 reads of a wavefront touch consecutive doubles.  All arithmetic is fp64 in the
+// reference's operation order, so state / posterior quality, and therefore the new base qualities, are identical to
+// the CPU's.  The host half (window, band, 2-bit reference) is a few integer operations per read.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <vector>
+#include <cstring>
+#include <cstdlib>
+#include "kernels.h"
+
+struct bcfgpu_ctx;
+int bcfgpu_set_error(int code, const char *what);
+extern "C" int bcfgpu_internal_device(bcfgpu_ctx *ctx, hipStream_t *stream, const float **q2p);
+
+namespace bcfgpu {
+
+#define EI .25
+#define EM .33333333333
+
+struct BaqJob {
+    uint32_t ref_off, seq_off, cig_off;       // into the window pool / the reads' seq16+qual pools / the cigar pool
+    int32_t l_ref, l_query, bw, xb, pos, n_cigar, ret;
+};
+
+struct BaqParams {
+    int n_jobs, ncell, max_lq, flag;
+    size_t stride;                            // jobs per chunk (scratch row stride)
+    const BaqJob *jobs;
+    const uint8_t *tref, *seq16, *qual;       // 0..4 codes of the windows; the reads' 4-bit bases and qualities
+    const float *q2p;                         // 10^(-Q/10) as float, Q = 0..255
+    const uint32_t *cig;
+    double *F, *B, *S;                        // [max_lq+1][ncell][stride] forward / backward; [max_lq+2][stride] scales
+    int32_t *state;                           // [pool offset] posterior state per base (k-1)<<2 | {0 M, 1 I}
+    uint8_t *q, *tmp;                         // [pool offset] posterior quality; scratch for the extended cap
+    uint8_t *qual_out, *zq_out;
+};
+
+__device__ __forceinline__ int set_u(int b, int i, int k) { int x = i - b; x = x > 0 ? x : 0; return (k - x + 1) * 3; }
+__device__ __forceinline__ int nt16_to_4(int c) { return (int)((0x4444444344424104ull >> (4 * (c & 15))) & 7); }
+
+__global__ __launch_bounds__(64) void baq_kernel(const BaqParams P)
+{
+    const int job = blockIdx.x * 64 + threadIdx.x;
+    if (job >= P.n_jobs) return;
+    const BaqJob j = P.jobs[job];
+    const uint8_t *seq = P.seq16 + j.seq_off, *iqual = P.qual + j.seq_off;
+    uint8_t *qout = P.qual_out + j.seq_off, *zout = P.zq_out + j.seq_off;
+    const int l_query = j.l_query, l_ref = j.l_ref;
+    if (j.ret < 0 || l_ref <= 0 || l_query <= 0) {
+        for (int i = 0; i < l_query; ++i) { qout[i] = iqual[i]; zout[i] = 0; }
+        return;
+    }
+    const uint8_t *ref = P.tref + j.ref_off;
+    const size_t st = P.stride;
+    #define FM(M_, i, c) (M_)[((size_t)(i) * P.ncell + (c)) * st + job]
+    #define SC(i) P.S[(size_t)(i) * st + job]
+    int bw = l_ref > l_query ? l_ref : l_query;
+    if (bw > j.bw) bw = j.bw;
+    if (bw < abs(l_ref - l_query)) bw = abs(l_ref - l_query);
+    const int bw2 = bw * 2 + 1, nc = bw2 * 3 + 6;
+    const double d = 0.001, e_ = 0.1;                    // realn.c: conf = { 0.001, 0.1, 10 }, bw overridden
+    double m[9];
+    const double sM = 1. / (2 * l_query + 2), sI = sM;
+    m[0] = (1 - d - d) * (1 - sM); m[1] = m[2] = d * (1 - sM);
+    m[3] = (1 - e_) * (1 - sI); m[4] = e_ * (1 - sI); m[5] = 0.;
+    m[6] = 1 - e_; m[7] = 0.; m[8] = e_;
+    const double bM = (1 - d) / l_ref, bI = d / l_ref;
+    // rows 0..l_query of both matrices start as zeros
+    for (int i = 0; i <= l_query; ++i)
+        for (int c = 0; c < nc; ++c) { FM(P.F, i, c) = 0.; FM(P.B, i, c) = 0.; }
+    auto qy = [&](int i) { return nt16_to_4(seq[i]); };
+    auto qp = [&](int i) { return (double)P.q2p[iqual[i]]; };   // (float)pow(10, -Q/10), probaln.c
+    // ---- forward ----
+    FM(P.F, 0, set_u(bw, 0, 0)) = 1.; SC(0) = 1.;
+    {
+        double sum = 0.;
+        const int beg = 1, end = l_ref < bw + 1 ? l_ref : bw + 1;
+        const double q0 = qp(0);
+        const int y0 = qy(0);
+        for (int k = beg; k <= end; ++k) {
+            const double e = (ref[k - 1] > 3 || y0 > 3) ? 1. : ref[k - 1] == y0 ? 1. - q0 : q0 * EM;
+            const int u = set_u(bw, 1, k);
+            const double a = e * bM, b = EI * bI;
+            FM(P.F, 1, u) = a; FM(P.F, 1, u + 1) = b;
+            sum += a + b;
+        }
+        SC(1) = sum;
+        const int _beg = set_u(bw, 1, beg), _end = set_u(bw, 1, end) + 2;
+        for (int k = _beg; k <= _end; ++k) FM(P.F, 1, k) /= sum;
+    }
+    for (int i = 2; i <= l_query; ++i) {
+        const double qli = qp(i - 1);
+        const int qyi = qy(i - 1);
+        int beg = 1, end = l_ref, x;
+        x = i - bw; beg = beg > x ? beg : x;
+        x = i + bw; end = end < x ? end : x;
+        double sum = 0.;
+        for (int k = beg; k <= end; ++k) {
+            const double e = (ref[k - 1] > 3 || qyi > 3) ? 1. : ref[k - 1] == qyi ? 1. - qli : qli * EM;
+            const int u = set_u(bw, i, k), v11 = set_u(bw, i - 1, k - 1), v10 = set_u(bw, i - 1, k), v01 = set_u(bw, i, k - 1);
+            const double f0 = e * (m[0] * FM(P.F, i - 1, v11) + m[3] * FM(P.F, i - 1, v11 + 1) + m[6] * FM(P.F, i - 1, v11 + 2));
+            const double f1 = EI * (m[1] * FM(P.F, i - 1, v10) + m[4] * FM(P.F, i - 1, v10 + 1));
+            const double f2 = m[2] * FM(P.F, i, v01) + m[8] * FM(P.F, i, v01 + 2);
+            FM(P.F, i, u) = f0; FM(P.F, i, u + 1) = f1; FM(P.F, i, u + 2) = f2;
+            sum += f0 + f1 + f2;
+        }
+        SC(i) = sum;
+        const int _beg = set_u(bw, i, beg), _end = set_u(bw, i, end) + 2;
+        const double r = 1. / sum;
+        for (int k = _beg; k <= _end; ++k) FM(P.F, i, k) *= r;
+    }
+    {
+        double sum = 0.;
+        for (int k = 1; k <= l_ref; ++k) {
+            const int u = set_u(bw, l_query, k);
+            if (u < 3 || u >= bw2 * 3 + 3) continue;
+            sum += FM(P.F, l_query, u) * sM + FM(P.F, l_query, u + 1) * sI;
+        }
+        SC(l_query + 1) = sum;
+    }
+    // ---- backward ----
+    {
+        const double sl = SC(l_query), sl1 = SC(l_query + 1);
+        for (int k = 1; k <= l_ref; ++k) {
+            const int u = set_u(bw, l_query, k);
+            if (u < 3 || u >= bw2 * 3 + 3) continue;
+            FM(P.B, l_query, u) = sM / sl / sl1; FM(P.B, l_query, u + 1) = sI / sl / sl1;
+        }
+    }
+    for (int i = l_query - 1; i >= 1; --i) {
+        int beg = 1, end = l_ref, x;
+        double y = (i > 1);
+        const double qli1 = qp(i);
+        const int qyi1 = qy(i);
+        x = i - bw; beg = beg > x ? beg : x;
+        x = i + bw; end = end < x ? end : x;
+        for (int k = end; k >= beg; --k) {
+            const int u = set_u(bw, i, k), v11 = set_u(bw, i + 1, k + 1), v10 = set_u(bw, i + 1, k), v01 = set_u(bw, i, k + 1);
+            const double e = (k >= l_ref ? 0 : (ref[k] > 3 || qyi1 > 3) ? 1. : ref[k] == qyi1 ? 1. - qli1 : qli1 * EM) * FM(P.B, i + 1, v11);
+            const double b10 = FM(P.B, i + 1, v10 + 1), b01 = FM(P.B, i, v01 + 2);
+            FM(P.B, i, u) = e * m[0] + EI * m[1] * b10 + m[2] * b01;
+            FM(P.B, i, u + 1) = e * m[3] + EI * m[4] * b10;
+            FM(P.B, i, u + 2) = (e * m[6] + m[8] * b01) * y;
+        }
+        const int _beg = set_u(bw, i, beg), _end = set_u(bw, i, end) + 2;
+        y = 1. / SC(i);
+        for (int k = _beg; k <= _end; ++k) FM(P.B, i, k) *= y;
+    }
+    // (the backward termination b[0] of probaln.c only feeds a debugging value)
+    // ---- MAP ----
+    int32_t *state = P.state + j.seq_off;
+    uint8_t *q = P.q + j.seq_off;
+    for (int i = 1; i <= l_query; ++i) {
+        double sum = 0., max = 0.;
+        int beg = 1, end = l_ref, x, max_k = -1;
+        x = i - bw; beg = beg > x ? beg : x;
+        x = i + bw; end = end < x ? end : x;
+        for (int k = beg; k <= end; ++k) {
+            const int u = set_u(bw, i, k);
+            double z;
+            z = FM(P.F, i, u) * FM(P.B, i, u);         if (z > max) { max = z; max_k = (k - 1) << 2 | 0; } sum += z;
+            z = FM(P.F, i, u + 1) * FM(P.B, i, u + 1); if (z > max) { max = z; max_k = (k - 1) << 2 | 1; } sum += z;
+        }
+        max /= sum;
+        state[i - 1] = max_k;
+        const int kq = (int)(-4.343 * log(1. - max) + .499);
+        q[i - 1] = (uint8_t)(kq > 100 ? 99 : kq);
+    }
+    // ---- the quality cap of sam_prob_realn (realn.c) ----
+    const uint32_t *cigar = P.cig + j.cig_off;
+    const bool apply = (P.flag & 1) != 0, extend = (P.flag & 2) != 0;
+    uint8_t *bq = zout;                                   // built in place in the ZQ output
+    for (int i = 0; i < l_query; ++i) bq[i] = iqual[i];
+    if (!extend) {
+        int x = j.pos, y = 0;
+        for (int k = 0; k < j.n_cigar; ++k) {
+            const int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
+            if (op == 0 || op == 7 || op == 8) {
+                for (int i = y; i < y + l; ++i) {
+                    if ((state[i] & 3) != 0 || state[i] >> 2 != x - j.xb + (i - y)) bq[i] = 0;
+                    else bq[i] = bq[i] < q[i] ? bq[i] : q[i];
+                }
+                x += l; y += l;
+            } else if (op == 4 || op == 1) y += l;
+            else if (op == 2) x += l;
+        }
+        for (int i = 0; i < l_query; ++i) bq[i] = (uint8_t)(iqual[i] - bq[i] + 64);
+    } else {
+        uint8_t *left = P.tmp + 2 * (size_t)j.seq_off, *rght = left + l_query;
+        int x = j.pos, y = 0;
+        for (int k = 0; k < j.n_cigar; ++k) {
+            const int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
+            if (op == 0 || op == 7 || op == 8) {
+                for (int i = y; i < y + l; ++i)
+                    bq[i] = ((state[i] & 3) != 0 || state[i] >> 2 != x - j.xb + (i - y)) ? 0 : q[i];
+                left[y] = bq[y];
+                for (int i = y + 1; i < y + l; ++i) left[i] = bq[i] > left[i - 1] ? bq[i] : left[i - 1];
+                rght[y + l - 1] = bq[y + l - 1];
+                for (int i = y + l - 2; i >= y; --i) rght[i] = bq[i] > rght[i + 1] ? bq[i] : rght[i + 1];
+                for (int i = y; i < y + l; ++i) bq[i] = left[i] < rght[i] ? left[i] : rght[i];
+                x += l; y += l;
+            } else if (op == 4 || op == 1) y += l;
+            else if (op == 2) x += l;
+        }
+        for (int i = 0; i < l_query; ++i) bq[i] = (uint8_t)(64 + (iqual[i] <= bq[i] ? 0 : iqual[i] - bq[i]));
+    }
+    for (int i = 0; i < l_query; ++i) qout[i] = apply ? (uint8_t)(iqual[i] - (bq[i] - 64)) : iqual[i];
+    #undef FM
+    #undef SC
+}
+
+}  // namespace bcfgpu
+
+using namespace bcfgpu;
+
+#define BQ_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return bcfgpu_set_error(BCFGPU_E_HIP, #call); } } while (0)
+
+extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *ref, int32_t ref_len, int flag,
+                          uint8_t *qual_out, uint8_t *zq_out, int32_t *ret)
+{
+    if (!ctx || !rd || !ref || !qual_out || !zq_out || !ret || rd->n_reads < 0)
+        return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_baq: bad arguments");
+    hipStream_t stream = nullptr;
+    const float *d_q2p = nullptr;
+    if (bcfgpu_internal_device(ctx, &stream, &d_q2p)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_baq: bad context");
+    const int n = rd->n_reads;
+    if (n == 0) return BCFGPU_OK;
+    static const uint8_t nt4[256] = {
+#define N4 4,4,4,4,4,4,4,4,4,4,4,4,4,4,4,4
+        N4,N4,N4,N4,
+        4,0,4,1,4,4,4,2,4,4,4,4,4,4,4,4, 4,4,4,4,3,4,4,4,4,4,4,4,4,4,4,4,
+        4,0,4,1,4,4,4,2,4,4,4,4,4,4,4,4, 4,4,4,4,3,4,4,4,4,4,4,4,4,4,4,4,
+        N4,N4,N4,N4,N4,N4,N4,N4
+#undef N4
+    };
+    // ---- host half: window and band of every read (realn.c), 0..4 codes of the window ----
+    std::vector<BaqJob> jobs(n);
+    std::vector<uint8_t> tref;
+    size_t nbase = 0, ncig = 0;
+    int max_lq = 1;
+    for (int r = 0; r < n; ++r) {
+        BaqJob &j = jobs[r];
+        const int l_qseq = rd->r_lq[r], pos = rd->r_pos[r];
+        const uint32_t *cigar = rd->cig + rd->r_cig_off[r];
+        j.seq_off = (uint32_t)rd->r_seq_off[r]; j.cig_off = (uint32_t)rd->r_cig_off[r];
+        j.l_query = l_qseq; j.n_cigar = rd->r_ncig[r]; j.pos = pos; j.ret = -1; j.l_ref = 0; j.bw = 0; j.xb = 0; j.ref_off = 0;
+        if ((size_t)j.seq_off + l_qseq > nbase) nbase = (size_t)j.seq_off + l_qseq;
+        if ((size_t)j.cig_off + j.n_cigar > ncig) ncig = (size_t)j.cig_off + j.n_cigar;
+        if (l_qseq > max_lq) max_lq = l_qseq;
+        ret[r] = -1;
+        if (l_qseq == 0 || rd->qual[j.seq_off] == 0xff || (rd->r_flag[r] & 4)) continue;
+        int x = pos, y = 0, yb = -1, ye = -1, xb = -1, xe = -1;
+        bool has_n = false;
+        for (int k = 0; k < j.n_cigar; ++k) {
+            const int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
+            if (op == 0 || op == 7 || op == 8) {
+                if (yb < 0) yb = y;
+                if (xb < 0) xb = x;
+                ye = y + l; xe = x + l;
+                x += l; y += l;
+            } else if (op == 4 || op == 1) y += l;
+            else if (op == 2) x += l;
+            else if (op == 3) { has_n = true; break; }
+        }
+        if (has_n || xb == -1) continue;
+        int bw = 7;
+        if (std::abs((xe - xb) - (ye - yb)) > bw) bw = std::abs((xe - xb) - (ye - yb)) + 3;
+        xb -= yb + bw / 2; if (xb < 0) xb = 0;
+        xe += l_qseq - ye + bw / 2;
+        if (xe - xb - l_qseq > bw) { xb += (xe - xb - l_qseq - bw) / 2; xe -= (xe - xb - l_qseq - bw) / 2; }
+        j.ref_off = (uint32_t)tref.size();
+        int k;
+        for (k = xb; k < xe && k < ref_len && ref[k]; ++k) tref.push_back(nt4[(uint8_t)ref[k]]);
+        xe = k;
+        j.l_ref = xe - xb; j.bw = bw; j.xb = xb; j.ret = 0;
+        ret[r] = 0;
+    }
+    if (tref.size() >> 32) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_baq: pool too large, use fewer reads per call");
+    // band classes: reads whose band is the default run together; wide bands (long indels) separately, with their own row width
+    auto eff_bw = [](const BaqJob &j) { int b = j.l_ref > j.l_query ? j.l_ref : j.l_query; if (b > j.bw) b = j.bw;
+                                        if (b < std::abs(j.l_ref - j.l_query)) b = std::abs(j.l_ref - j.l_query); return b; };
+    std::vector<BaqJob> cls[2];
+    int cls_bw[2] = {1, 1};
+    for (const BaqJob &j : jobs) {
+        const int b = j.ret < 0 ? 1 : eff_bw(j), c = b <= 10 ? 0 : 1;
+        cls[c].push_back(j);
+        if (b > cls_bw[c]) cls_bw[c] = b;
+    }
+
+    // ---- device half ----
+    void *d_jobs = nullptr, *d_tref = nullptr, *d_seq = nullptr, *d_qual = nullptr, *d_cig = nullptr, *d_F = nullptr, *d_B = nullptr,
+         *d_S = nullptr, *d_state = nullptr, *d_q = nullptr, *d_tmp = nullptr, *d_qo = nullptr, *d_zo = nullptr;
+    auto cleanup = [&]() { for (void *x : {d_jobs, d_tref, d_seq, d_qual, d_cig, d_F, d_B, d_S, d_state, d_q, d_tmp, d_qo, d_zo}) if (x) hipFree(x); };
+    BQ_CHK(hipMalloc(&d_tref, tref.size() + 16));
+    BQ_CHK(hipMalloc(&d_seq, nbase + 16)); BQ_CHK(hipMalloc(&d_qual, nbase + 16)); BQ_CHK(hipMalloc(&d_cig, (ncig + 4) * 4));
+    BQ_CHK(hipMalloc(&d_state, (nbase + 4) * 4)); BQ_CHK(hipMalloc(&d_q, nbase + 16)); BQ_CHK(hipMalloc(&d_tmp, 2 * nbase + 16));
+    BQ_CHK(hipMalloc(&d_qo, nbase + 16)); BQ_CHK(hipMalloc(&d_zo, nbase + 16));
+    BQ_CHK(hipMemcpyAsync(d_tref, tref.data(), tref.size(), hipMemcpyHostToDevice, stream));
+    BQ_CHK(hipMemcpyAsync(d_seq, rd->seq16, nbase, hipMemcpyHostToDevice, stream));
+    BQ_CHK(hipMemcpyAsync(d_qual, rd->qual, nbase, hipMemcpyHostToDevice, stream));
+    BQ_CHK(hipMemcpyAsync(d_cig, rd->cig, ncig * 4, hipMemcpyHostToDevice, stream));
+    BQ_CHK(hipMemsetAsync(d_zo, 0, nbase, stream));
+    BQ_CHK(hipMemcpyAsync(d_qo, rd->qual, nbase, hipMemcpyHostToDevice, stream));      // bases no job covers keep their quality
+    BaqParams P{};
+    P.flag = flag; P.max_lq = max_lq;
+    P.tref = (const uint8_t*)d_tref; P.seq16 = (const uint8_t*)d_seq; P.qual = (const uint8_t*)d_qual; P.cig = (const uint32_t*)d_cig;
+    P.q2p = d_q2p; P.state = (int32_t*)d_state; P.q = (uint8_t*)d_q; P.tmp = (uint8_t*)d_tmp;
+    P.qual_out = (uint8_t*)d_qo; P.zq_out = (uint8_t*)d_zo;
+    for (int c = 0; c < 2; ++c) {
+        const size_t nj = cls[c].size();
+        if (!nj) continue;
+        P.ncell = 3 * (2 * cls_bw[c] + 1) + 6;
+        const size_t per_job = 2 * (size_t)(max_lq + 1) * P.ncell * sizeof(double);
+        size_t chunk = ((size_t)2 << 30) / per_job;
+        chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
+        if (chunk > nj) chunk = (nj + 63) & ~(size_t)63;
+        P.stride = chunk;
+        if (d_jobs) { hipFree(d_jobs); d_jobs = nullptr; }
+        if (d_F) { hipFree(d_F); d_F = nullptr; }
+        if (d_B) { hipFree(d_B); d_B = nullptr; }
+        if (d_S) { hipFree(d_S); d_S = nullptr; }
+        BQ_CHK(hipMalloc(&d_jobs, nj * sizeof(BaqJob)));
+        BQ_CHK(hipMalloc(&d_F, per_job / 2 * chunk)); BQ_CHK(hipMalloc(&d_B, per_job / 2 * chunk));
+        BQ_CHK(hipMalloc(&d_S, (size_t)(max_lq + 2) * chunk * sizeof(double)));
+        BQ_CHK(hipMemcpyAsync(d_jobs, cls[c].data(), nj * sizeof(BaqJob), hipMemcpyHostToDevice, stream));
+        P.F = (double*)d_F; P.B = (double*)d_B; P.S = (double*)d_S;
+        for (size_t j0 = 0; j0 < nj; j0 += chunk) {
+            P.n_jobs = (int)(nj - j0 < chunk ? nj - j0 : chunk);
+            P.jobs = (const BaqJob*)d_jobs + j0;
+            hipLaunchKernelGGL(baq_kernel, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
+        }
+        BQ_CHK(hipGetLastError());
+    }
+    BQ_CHK(hipMemcpyAsync(qual_out, d_qo, nbase, hipMemcpyDeviceToHost, stream));
+    BQ_CHK(hipMemcpyAsync(zq_out, d_zo, nbase, hipMemcpyDeviceToHost, stream));
+    BQ_CHK(hipStreamSynchronize(stream));
+    cleanup();
+    return BCFGPU_OK;
+}

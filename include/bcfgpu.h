@@ -15,6 +15,7 @@
  *                                           (call sites mpileup.c:343-347 and :357-360)
  *    bcfgpu_gap_prep                     <- bcf_call_gap_prep                  bam2bcf.h:141 (bam2bcf_indel.c:99-470)
  *    bcfgpu_gap_prep_stats               <- (measurement only)
+ *    bcfgpu_baq                          <- sam_prob_realn (htslib realn.c), call site mpileup.c:234
  *    bcfgpu_mcall                        <- mcall()                            call.h:131 (mcall.c:1430-1684)
  *                                           incl. the per-record prologue of vcfcall.c:1096-1115
  *    bcfgpu_pipeline                     <- the `mpileup -Ou | call -m` pipe with PL/QS/I16 kept in HBM
@@ -295,6 +296,17 @@ typedef struct {
 
 int  bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const bcfgpu_indel_in *in, const bcfgpu_indel_out *out,
                      int inscns_cap);
+
+/* ---- BAQ: sam_prob_realn(b, ref, ref_len, flag) of htslib realn.c as mpileup applies it to every read before the
+ * pileup (mpileup.c:234, flag = 1 apply | 2 extended; `mpileup -E` redoes it with 7 = recompute).  For every read of
+ * the pool: the banded glocal pair-HMM forward-backward against its reference window, the per-base posterior of the
+ * aligned column, and the base-quality cap that follows.  HOST pointers.  `reads->qual` is not modified:
+ *   qual_out[r_seq_off[r] + i]  new quality of base i (= qual when the read is left alone, ret[r] < 0)
+ *   zq_out  [r_seq_off[r] + i]  the "ZQ" tag byte (64 + cap offset), 0 when the read is left alone
+ *   ret[r]                      0 applied, -1 left alone (no sequence, qual 0xff, N in CIGAR, no aligned base)
+ * Reads that already carry BQ/ZQ tags are the caller's business (realn.c:60-90); this entry is the computation. */
+int  bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const char *ref, int32_t ref_len, int flag,
+                uint8_t *qual_out, uint8_t *zq_out, int32_t *ret);
 
 /* statistics of the last bcfgpu_gap_prep call on this context (SURVEY 8d "indel stage unit": DP cells per second):
  * jobs = (site, candidate type, read) realignments, passes = forward passes run (a second parameter set is tried when

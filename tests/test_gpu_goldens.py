@@ -29,7 +29,8 @@ from tests.test_oracle_golden_baq import CASES as BAQ_CASES, run_case as run_baq
 
 @pytest.mark.parametrize("idx", range(len(BAQ_CASES)))
 def test_hip_reproduces_default_mpileup_golden(golden_dir, idx):
-    """SNP and indel records of the BAQ-on goldens through glfgen_kernel/combine_kernel (gap_prep on the host side)."""
+    """SNP and indel records of the BAQ-on goldens with every device stage in the loop: BAQ (bcfgpu_baq), the SNP and
+    indel passes (glfgen_kernel/combine_kernel) and the indel realignment (bcfgpu_gap_prep)."""
     ctxs = {}
 
     def hip_engine(cfg, tile):
@@ -44,7 +45,7 @@ def test_hip_reproduces_default_mpileup_golden(golden_dir, idx):
             ctxs["gap"] = engine.Context(abi.default_cfg(1))
         return ctxs["gap"]
     try:
-        run_baq_case(golden_dir, BAQ_CASES[idx], hip_engine, gap_ctx=gap_ctx)
+        run_baq_case(golden_dir, BAQ_CASES[idx], hip_engine, gap_ctx=gap_ctx, baq_ctx=gap_ctx)       # BAQ through bcfgpu_baq too
     finally:
         for c in ctxs.values():
             c.close()

@@ -25,12 +25,12 @@ CASES = [
 ]
 
 
-def run_case(golden_dir, case, engine, gap_ctx=None):
+def run_case(golden_dir, case, engine, gap_ctx=None, baq_ctx=None):
     samfiles, reffa, contig, beg, end, goldf, fmt_flag, n_snp, n_indel = case
     G = os.path.join(golden_dir, "mpileup")
     sams = [sam.Sam(os.path.join(G, f)) for f in samfiles]
     ref = sam.read_fasta(os.path.join(G, reffa))
-    prep = M.Prepared(sams, ref, contig, sam.MplpOpts(fmt_flag=fmt_flag))
+    prep = M.Prepared(sams, ref, contig, sam.MplpOpts(fmt_flag=fmt_flag), baq_ctx=baq_ctx() if baq_ctx else None)
     tile, cols, kept = M.snp_tile(prep, range(beg, end + 1))
     cfg = A.default_cfg(len(prep.samples), fmt_flag=fmt_flag)
     res = engine(cfg, tile)
