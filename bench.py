@@ -37,9 +37,10 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget on rank 0 at N=1 (0: skip)")
     ap.add_argument("--seed", type=int, default=20260104)
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the CPU baseline on all host cores (0: skip)")
-    ap.add_argument("--mode", choices=["snp", "indel"], default="snp",
+    ap.add_argument("--mode", choices=["snp", "indel", "baq"], default="snp",
                     help="snp: the headline pipeline (default).  indel: bcf_call_gap_prep on synthetic indel-candidate columns "
-                         "(BASELINE configs[2] shape, 500 samples), reports DP cells/s of the realignment kernel")
+                         "(BASELINE configs[2] shape, 500 samples), reports DP cells/s of the realignment kernel.  "
+                         "baq: bcfgpu_baq (sam_prob_realn) over the reads of the same synthetic columns")
     return ap.parse_args()
 
 
@@ -110,10 +111,69 @@ def main_indel(a):
     ctx.close()
 
 
+def main_baq(a):
+    """Secondary measurement: BAQ (upstream of the pileup) over a pool of synthetic 100-bp reads."""
+    import torch
+    from bcftools_amd import abi, synth, engine
+    from tests.helpers import mplpdrv
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    from bcftools_amd.lib import check
+    ctx = engine.Context(abi.default_cfg(1, max_sites=1, max_reads=64))
+    S = 500 if a.samples == 1000 else a.samples
+    n_sites = 32 if a.sites == 16384 else a.sites
+    b = synth.indel_batch(a.seed, n_sites, S, depth=a.depth)
+    R = b["reads"]
+    rd = abi.Reads()
+    rd.n_reads = R["n_reads"]
+    for k in ("r_pos", "r_lq", "r_flag", "r_ncig", "r_cig_off", "r_seq_off", "cig", "seq16", "qual", "zq", "r_has_zq"):
+        setattr(rd, k, R[k].ctypes.data)
+    nb = len(R["qual"])
+    qo, zo, ret = np.zeros(nb, np.uint8), np.zeros(nb, np.uint8), np.zeros(R["n_reads"], np.int32)
+
+    def run():
+        t0 = time.perf_counter()
+        check(ctx.L.bcfgpu_baq(ctx.h, C.byref(rd), b["ref"], len(b["ref"]), 3, qo.ctypes.data, zo.ctypes.data, ret.ctypes.data))
+        return time.perf_counter() - t0
+    run()
+    t = min(run() for _ in range(max(1, a.steps // 3)))
+    out = {"metric": "reads/sec through BAQ (sam_prob_realn, extended, applied), %d-bp reads" % int(R["r_lq"][0]),
+           "value": R["n_reads"] / t, "unit": "reads/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64 pair-HMM forward-backward",
+           "data": "synthetic", "config": {"workload": "reads of %d synthetic indel-candidate columns x %d samples x %.0fx" % (n_sites, S, a.depth),
+                                           "reads": int(R["n_reads"]), "bases": int(nb)},
+           "whole_call_ms": t * 1e3, "note": "host pointers in and out: the time includes the window preparation on the host, "
+                                             "uploads, baq_kernel and the download of the new qualities"}
+    if a.cpu_seconds > 0:
+        class Rd:
+            pass
+        nt = "=ACMGRSVTWYHKDBN"
+        refseq = b["ref"].decode()
+        k, t0 = 0, time.perf_counter()
+        while k < R["n_reads"] and (k < 10 or time.perf_counter() - t0 < a.cpu_seconds):
+            o, n = int(R["r_seq_off"][k]), int(R["r_lq"][k])
+            r = Rd()
+            r.pos, r.l_qseq, r.flag = int(R["r_pos"][k]), n, int(R["r_flag"][k])
+            r.bamcigar = R["cig"][R["r_cig_off"][k]:R["r_cig_off"][k] + R["r_ncig"][k]].copy()
+            r.seq = "".join(nt[c] for c in R["seq16"][o:o + n])
+            r.qual = R["qual"][o:o + n].astype(np.int32)
+            r.zq = None
+            mplpdrv.apply_baq(r, refseq, 3)
+            assert ret[k] == 0 and np.array_equal(r.qual, qo[o:o + n]) and np.array_equal(r.zq, zo[o:o + n])
+            k += 1
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": k / tc, "unit": "reads/s", "cores": 1, "kind": "port",
+                               "sample": "first %d reads, oracle orc_sam_prob_realn on one host core incl. the Python call overhead, "
+                                         "%.1f s (results compared with the device path)" % (k, tc)}
+    print(json.dumps(out), flush=True)
+    ctx.close()
+
+
 def main():
     a = parse()
     if a.mode == "indel":
         return main_indel(a)
+    if a.mode == "baq":
+        return main_baq(a)
     import torch
     import torch.distributed as dist
     from bcftools_amd import abi, synth, engine, shard
