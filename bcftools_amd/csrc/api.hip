@@ -433,12 +433,12 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
 }
 
 // device half of bcfgpu_gap_prep (indel_host.hip): upload the job pools, run probaln_kernel, download the scores
-int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnJob> &jobs, const std::vector<uint8_t> &ref2,
-                                const std::vector<uint8_t> &query, const std::vector<uint8_t> &qq, int max_bw,
+int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnPools> &pools, int max_bw,
                                 std::vector<int32_t> &score1, std::vector<int32_t> &score2)
 {
     hipSetDevice(c->cfg.device);
-    const size_t nj = jobs.size();
+    size_t nj = 0, nr = 0, nq = 0;
+    for (const ProbalnPools &pl : pools) { nj += pl.jobs.size(); nr += pl.ref2pool.size(); nq += pl.qpool.size(); }
     ProbalnParams p{};
     p.ncell = 3 * (2 * max_bw + 1) + 6;
     // jobs are run in chunks so that the two rolling rows of every job in flight fit a ~1 GiB scratch
@@ -450,16 +450,24 @@ int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnJob> &jo
     auto cleanup = [&]() { for (void *x : {d_jobs, d_ref2, d_q, d_qq, d_scr, d_s1, d_s2}) if (x) hipFree(x); };
     #define GP_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return set_err(BCFGPU_E_HIP, #call, e_); } } while (0)
     GP_CHK(hipMalloc(&d_jobs, nj * sizeof(ProbalnJob)));
-    GP_CHK(hipMalloc(&d_ref2, ref2.size() + 16));
-    GP_CHK(hipMalloc(&d_q, query.size() + 16));
-    GP_CHK(hipMalloc(&d_qq, qq.size() + 16));
+    GP_CHK(hipMalloc(&d_ref2, nr + 16));
+    GP_CHK(hipMalloc(&d_q, nq + 16));
+    GP_CHK(hipMalloc(&d_qq, nq + 16));
     GP_CHK(hipMalloc(&d_scr, 2 * (size_t)p.ncell * p.scratch_stride * sizeof(double)));
     GP_CHK(hipMalloc(&d_s1, nj * 4));
     GP_CHK(hipMalloc(&d_s2, nj * 4));
-    GP_CHK(hipMemcpyAsync(d_jobs, jobs.data(), nj * sizeof(ProbalnJob), hipMemcpyHostToDevice, c->stream));
-    GP_CHK(hipMemcpyAsync(d_ref2, ref2.data(), ref2.size(), hipMemcpyHostToDevice, c->stream));
-    GP_CHK(hipMemcpyAsync(d_q, query.data(), query.size(), hipMemcpyHostToDevice, c->stream));
-    GP_CHK(hipMemcpyAsync(d_qq, qq.data(), qq.size(), hipMemcpyHostToDevice, c->stream));
+    {   // the pools are already rebased to their place in the concatenation: upload them segment by segment
+        size_t oj = 0, orf = 0, oq = 0;
+        for (const ProbalnPools &pl : pools) {
+            if (!pl.jobs.empty()) GP_CHK(hipMemcpyAsync((ProbalnJob*)d_jobs + oj, pl.jobs.data(), pl.jobs.size() * sizeof(ProbalnJob), hipMemcpyHostToDevice, c->stream));
+            if (!pl.ref2pool.empty()) GP_CHK(hipMemcpyAsync((uint8_t*)d_ref2 + orf, pl.ref2pool.data(), pl.ref2pool.size(), hipMemcpyHostToDevice, c->stream));
+            if (!pl.qpool.empty()) {
+                GP_CHK(hipMemcpyAsync((uint8_t*)d_q + oq, pl.qpool.data(), pl.qpool.size(), hipMemcpyHostToDevice, c->stream));
+                GP_CHK(hipMemcpyAsync((uint8_t*)d_qq + oq, pl.qqpool.data(), pl.qqpool.size(), hipMemcpyHostToDevice, c->stream));
+            }
+            oj += pl.jobs.size(); orf += pl.ref2pool.size(); oq += pl.qpool.size();
+        }
+    }
     p.ref2 = (const uint8_t*)d_ref2; p.query = (const uint8_t*)d_q; p.qq = (const uint8_t*)d_qq;
     p.q2p = c->d_q2p; p.scratch = (double*)d_scr;
     { const char *ab = getenv("BCFGPU_ABLATE"); p.force_scratch = ab && (atoi(ab) & 256) ? 1 : 0; }

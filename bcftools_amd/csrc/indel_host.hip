@@ -21,8 +21,7 @@
 using namespace bcfgpu;
 
 // provided by api.hip
-extern "C" int bcfgpu_internal_run_probaln(bcfgpu_ctx *ctx, const std::vector<ProbalnJob> &jobs, const std::vector<uint8_t> &ref2,
-                                           const std::vector<uint8_t> &query, const std::vector<uint8_t> &qq, int max_bw,
+extern "C" int bcfgpu_internal_run_probaln(bcfgpu_ctx *ctx, const std::vector<ProbalnPools> &pools, int max_bw,
                                            std::vector<int32_t> &score1, std::vector<int32_t> &score2);
 int bcfgpu_set_error(int code, const char *what);
 extern "C" bcfgpu_gap_stats *bcfgpu_internal_gap_stats(bcfgpu_ctx *ctx);
@@ -113,7 +112,7 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
     std::vector<SiteState> st(in->n_sites);
     // Sites are independent: contiguous chunks of sites are prepared by host threads into their own job pools, which
     // are then concatenated in site order (job and pool offsets rebased).
-    struct Pools { std::vector<ProbalnJob> jobs; std::vector<uint8_t> ref2pool, qpool, qqpool; int max_bw = 0; };
+    typedef ProbalnPools Pools;
     auto prepare_range = [&](int is_begin, int is_end, Pools &PL) {
     std::vector<ProbalnJob> &jobs = PL.jobs;
     std::vector<uint8_t> &ref2pool = PL.ref2pool, &qpool = PL.qpool, &qqpool = PL.qqpool;
@@ -262,7 +261,7 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
         const int max_ref2 = right - left + 2 + 2 * (max_ins > -types[0] ? max_ins : -types[0]);
         std::vector<char> ref2(max_ref2);
         S.N = N;
-        struct QSeg { int qbeg = -1, qend = -1; uint32_t off = 0; };
+        struct QSeg { int qbeg = -1, qend = -1; uint32_t off = 0; int left = -1, right = -1, qbeg_w = 0, qend_w = 0, tbeg = 0, tend = 0; };
         std::vector<QSeg> qseg(N);
         S.jobidx.assign((size_t)N * n_types, -1);
         S.job0 = jobs.size();
@@ -293,9 +292,15 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
                     bool skipN = false;
                     for (int kk = 0; kk < rd->r_ncig[rdx]; ++kk) if ((cigar[kk] & 0xf) == 3) { skipN = true; break; }
                     if (skipN) continue;
-                    int tbeg, tend;
-                    const int qbeg = tpos2qpos(rd->r_pos[rdx], rd->r_ncig[rdx], cigar, left, 0, &tbeg);
-                    const int qend = tpos2qpos(rd->r_pos[rdx], rd->r_ncig[rdx], cigar, right, 1, &tend);
+                    // the CIGAR walks depend on the window only, which changes (shrinks) rarely: cached per read across types
+                    QSeg &qc = qseg[K];
+                    if (qc.left != left || qc.right != right) {
+                        qc.left = left; qc.right = right;
+                        qc.qbeg_w = tpos2qpos(rd->r_pos[rdx], rd->r_ncig[rdx], cigar, left, 0, &qc.tbeg);
+                        qc.qend_w = tpos2qpos(rd->r_pos[rdx], rd->r_ncig[rdx], cigar, right, 1, &qc.tend);
+                    }
+                    int tbeg = qc.tbeg;
+                    const int tend = qc.tend, qbeg = qc.qbeg_w, qend = qc.qend_w;
                     if (types[t] < 0) { const int l = -types[t]; tbeg = tbeg - l > left ? tbeg - l : left; }
                     ProbalnJob jb;
                     jb.ref_off = ref2_off + (uint32_t)(tbeg - left);
@@ -309,7 +314,6 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
                         if (eff > max_bw) max_bw = eff;
                     }
                     // the query segment of a read is the same for every candidate type unless the window shrank: pooled once
-                    QSeg &qc = qseg[K];
                     if (qc.qbeg == qbeg && qc.qend == qend) jb.query_off = qc.off;
                     else {
                     jb.query_off = (uint32_t)qpool.size();
@@ -340,63 +344,69 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
     }
     };  // prepare_range
 
-    std::vector<ProbalnJob> jobs;
-    std::vector<uint8_t> ref2pool, qpool, qqpool;
     int max_bw = 0;
+    std::vector<Pools> pools;
+    size_t n_jobs_total = 0;
     {
         int nthr = (int)std::thread::hardware_concurrency();
         if (const char *e = getenv("BCFGPU_HOST_THREADS")) nthr = atoi(e);
         nthr = std::max(1, std::min(std::min(nthr, 16), in->n_sites));
-        std::vector<Pools> pools(nthr);
-        std::vector<std::thread> thr;
+        pools.resize(nthr);
         auto cut = [&](int t) { return (int)((long)in->n_sites * t / nthr); };
-        for (int t = 1; t < nthr; ++t) thr.emplace_back(prepare_range, cut(t), cut(t + 1), std::ref(pools[t]));
-        prepare_range(cut(0), cut(1), pools[0]);
-        for (auto &th : thr) th.join();
-        size_t nj = 0, nr = 0, nq = 0;
-        for (const Pools &pl : pools) { nj += pl.jobs.size(); nr += pl.ref2pool.size(); nq += pl.qpool.size(); }
-        if (nr >> 32 || nq >> 32 || nj >> 31) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_gap_prep: batch too large (pool offsets are 32-bit), use fewer sites per call");
-        jobs.reserve(nj); ref2pool.reserve(nr); qpool.reserve(nq); qqpool.reserve(nq);
+        auto run_all = [&](auto fn) {
+            std::vector<std::thread> thr;
+            for (int t = 1; t < nthr; ++t) thr.emplace_back(fn, t);
+            fn(0);
+            for (auto &th : thr) th.join();
+        };
+        run_all([&](int t) { prepare_range(cut(t), cut(t + 1), pools[t]); });
+        // pool bases in site order, then every thread rebases its own jobs and sites (no host-side concatenation:
+        // the pools are uploaded segment by segment)
+        std::vector<size_t> jb0(nthr + 1, 0), r0(nthr + 1, 0), q0(nthr + 1, 0);
         for (int t = 0; t < nthr; ++t) {
-            Pools &pl = pools[t];
-            const uint32_t jb0 = (uint32_t)jobs.size(), r0 = (uint32_t)ref2pool.size(), q0 = (uint32_t)qpool.size();
-            for (ProbalnJob j : pl.jobs) { j.ref_off += r0; j.query_off += q0; jobs.push_back(j); }
-            ref2pool.insert(ref2pool.end(), pl.ref2pool.begin(), pl.ref2pool.end());
-            qpool.insert(qpool.end(), pl.qpool.begin(), pl.qpool.end());
-            qqpool.insert(qqpool.end(), pl.qqpool.begin(), pl.qqpool.end());
+            jb0[t + 1] = jb0[t] + pools[t].jobs.size(); r0[t + 1] = r0[t] + pools[t].ref2pool.size(); q0[t + 1] = q0[t] + pools[t].qpool.size();
+            if (pools[t].max_bw > max_bw) max_bw = pools[t].max_bw;
+        }
+        if (r0[nthr] >> 32 || q0[nthr] >> 32 || jb0[nthr] >> 31)
+            return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_gap_prep: batch too large (pool offsets are 32-bit), use fewer sites per call");
+        n_jobs_total = jb0[nthr];
+        run_all([&](int t) {
+            for (ProbalnJob &j : pools[t].jobs) { j.ref_off += (uint32_t)r0[t]; j.query_off += (uint32_t)q0[t]; }
             for (int is = cut(t); is < cut(t + 1); ++is) {
                 SiteState &S = st[is];
                 if (!S.live) continue;
-                S.job0 += jb0;
-                for (int32_t &j : S.jobidx) if (j >= 0) j += (int32_t)jb0;
+                S.job0 += jb0[t];
+                for (int32_t &j : S.jobidx) if (j >= 0) j += (int32_t)jb0[t];
             }
-            if (pl.max_bw > max_bw) max_bw = pl.max_bw;
-            pl = Pools();
-        }
+        });
     }
 
     gs.prepare_ms = ms_since(t_begin);
     // ---- device: forward scores of every job
     std::vector<int32_t> sc1, sc2;
-    if (!jobs.empty()) {
-        const int rc = bcfgpu_internal_run_probaln(ctx, jobs, ref2pool, qpool, qqpool, max_bw, sc1, sc2);
+    if (n_jobs_total) {
+        const int rc = bcfgpu_internal_run_probaln(ctx, pools, max_bw, sc1, sc2);
         if (rc) return rc;
-        gs.n_jobs = jobs.size();
-        for (size_t j = 0; j < jobs.size(); ++j) {
-            const ProbalnJob &jb = jobs[j];
-            if (jb.l_ref <= 0 || jb.l_query <= 0) continue;
-            int bw = jb.l_ref > jb.l_query ? jb.l_ref : jb.l_query;
-            if (bw > jb.bw) bw = jb.bw;
-            if (bw < std::abs(jb.l_ref - jb.l_query)) bw = std::abs(jb.l_ref - jb.l_query);
-            const uint64_t cells = (uint64_t)jb.l_query * (2 * bw + 1) * 3;
-            const int passes = (sc1[j] >> 8) > 5 ? 2 : 1;          // bam2bcf_indel.c:351
-            gs.n_passes += passes; gs.dp_cells += cells * passes;
-        }
+        gs.n_jobs = n_jobs_total;
+        size_t j = 0;
+        for (const Pools &pl : pools)
+            for (const ProbalnJob &jb : pl.jobs) {
+                const size_t jj = j++;
+                if (jb.l_ref <= 0 || jb.l_query <= 0) continue;
+                int bw = jb.l_ref > jb.l_query ? jb.l_ref : jb.l_query;
+                if (bw > jb.bw) bw = jb.bw;
+                if (bw < std::abs(jb.l_ref - jb.l_query)) bw = std::abs(jb.l_ref - jb.l_query);
+                const uint64_t cells = (uint64_t)jb.l_query * (2 * bw + 1) * 3;
+                const int passes = (sc1[jj] >> 8) > 5 ? 2 : 1;         // bam2bcf_indel.c:351
+                gs.n_passes += passes; gs.dp_cells += cells * passes;
+            }
     }
+    pools.clear();
     const auto t_fin = std::chrono::steady_clock::now();
 
-    // ---- finalize (:372-469)
-    for (int is = 0; is < in->n_sites; ++is) {
+    // ---- finalize (:372-469): per site, independent -> the same host threads
+    auto finalize_range = [&](int is_begin, int is_end) {
+    for (int is = is_begin; is < is_end; ++is) {
         SiteState &S = st[is];
         if (!S.live) continue;
         const int32_t *soff = in->smpl_off + (size_t)is * n;
@@ -458,6 +468,17 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
         }
         if (out->indelreg) out->indelreg[is] = S.indelreg;
         out->ret[is] = n_alt > 0 ? 0 : -1;
+    }
+    };  // finalize_range
+    {
+        int nthr = (int)std::thread::hardware_concurrency();
+        if (const char *e = getenv("BCFGPU_HOST_THREADS")) nthr = atoi(e);
+        nthr = std::max(1, std::min(std::min(nthr, 16), in->n_sites));
+        std::vector<std::thread> thr;
+        auto cut = [&](int t) { return (int)((long)in->n_sites * t / nthr); };
+        for (int t = 1; t < nthr; ++t) thr.emplace_back(finalize_range, cut(t), cut(t + 1));
+        finalize_range(cut(0), cut(1));
+        for (auto &th : thr) th.join();
     }
     gs.finalize_ms = ms_since(t_fin);
     gs.total_ms = ms_since(t_begin);

@@ -1,6 +1,7 @@
 // kernels.h -- parameter blocks and launchers of the HIP kernels (gfx950).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdint.h>
 #include "../../include/bcfgpu.h"
 
@@ -87,6 +88,8 @@ struct ProbalnParams {
     int32_t *score1, *score2;       // sc<<8 | norm, bam2bcf_indel.c:348-356
 };
 void launch_probaln(const ProbalnParams &p, hipStream_t s);
+// host-side job pools of bcfgpu_gap_prep, one per preparing thread; offsets inside a pool are pool-relative until rebased
+struct ProbalnPools { std::vector<ProbalnJob> jobs; std::vector<uint8_t> ref2pool, qpool, qqpool; int max_bw = 0; };
 
 size_t glfgen_lds_bytes(int cap, int hist_slots);
 void launch_glfgen(const GlfgenParams &p, hipStream_t s);
