@@ -44,19 +44,11 @@ struct BaqParams {
 __device__ __forceinline__ int set_u(int b, int i, int k) { int x = i - b; x = x > 0 ? x : 0; return (k - x + 1) * 3; }
 __device__ __forceinline__ int nt16_to_4(int c) { return (int)((0x4444444344424104ull >> (4 * (c & 15))) & 7); }
 
-__global__ __launch_bounds__(64) void baq_kernel(const BaqParams P)
+// forward, backward and posterior maximum with both matrices in the scratch buffer: any band width
+__device__ void baq_fb_scratch(const BaqParams &P, int job, const BaqJob &j, const uint8_t *ref, const uint8_t *seq,
+                               const uint8_t *iqual, int32_t *state, uint8_t *q)
 {
-    const int job = blockIdx.x * 64 + threadIdx.x;
-    if (job >= P.n_jobs) return;
-    const BaqJob j = P.jobs[job];
-    const uint8_t *seq = P.seq16 + j.seq_off, *iqual = P.qual + j.seq_off;
-    uint8_t *qout = P.qual_out + j.seq_off, *zout = P.zq_out + j.seq_off;
     const int l_query = j.l_query, l_ref = j.l_ref;
-    if (j.ret < 0 || l_ref <= 0 || l_query <= 0) {
-        for (int i = 0; i < l_query; ++i) { qout[i] = iqual[i]; zout[i] = 0; }
-        return;
-    }
-    const uint8_t *ref = P.tref + j.ref_off;
     const size_t st = P.stride;
     #define FM(M_, i, c) (M_)[((size_t)(i) * P.ncell + (c)) * st + job]
     #define SC(i) P.S[(size_t)(i) * st + job]
@@ -154,8 +146,6 @@ __global__ __launch_bounds__(64) void baq_kernel(const BaqParams P)
     }
     // (the backward termination b[0] of probaln.c only feeds a debugging value)
     // ---- MAP ----
-    int32_t *state = P.state + j.seq_off;
-    uint8_t *q = P.q + j.seq_off;
     for (int i = 1; i <= l_query; ++i) {
         double sum = 0., max = 0.;
         int beg = 1, end = l_ref, x, max_k = -1;
@@ -172,7 +162,200 @@ __global__ __launch_bounds__(64) void baq_kernel(const BaqParams P)
         const int kq = (int)(-4.343 * log(1. - max) + .499);
         q[i - 1] = (uint8_t)(kq > 100 ? 99 : kq);
     }
-    // ---- the quality cap of sam_prob_realn (realn.c) ----
+    #undef FM
+    #undef SC
+}
+
+
+// The same with the current row in registers, for bands of half-width <= BWM (the default band of 7 fits): the forward
+// pass keeps its scaled row in registers and stores it once (the posterior needs f*b per cell), the backward pass
+// keeps its row in registers and reads the forward row back.  Position p of a row is reference column
+// k = p + max(0, i-bw) - 1, htslib's set_u() slot, so both passes update in place (see probaln_fwd_reg in indel.hip);
+// the reference window travels in a 64-bit register, 3 bits per base.  One matrix write and one read per cell instead
+// of the ~40 accesses of the scratch version.
+template <int BWM>
+__device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const uint8_t *ref, const uint8_t *seq,
+                           const uint8_t *iqual, int bw, int32_t *state, uint8_t *q)
+{
+    constexpr int NP = 2 * BWM + 3;
+    const int l_query = j.l_query, l_ref = j.l_ref;
+    const size_t st = P.stride;
+    #define FR(i, p, s_) P.F[(((size_t)(i) * NP + (p)) * 3 + (s_)) * st + job]
+    #define SC(i) P.S[(size_t)(i) * st + job]
+    const int bw2 = bw * 2 + 1;
+    const double d = 0.001, e_ = 0.1;
+    double m[9];
+    const double sM = 1. / (2 * l_query + 2), sI = sM;
+    m[0] = (1 - d - d) * (1 - sM); m[1] = m[2] = d * (1 - sM);
+    m[3] = (1 - e_) * (1 - sI); m[4] = e_ * (1 - sI); m[5] = 0.;
+    m[6] = 1 - e_; m[7] = 0.; m[8] = e_;
+    const double bM = (1 - d) / l_ref, bI = d / l_ref;
+    auto qy = [&](int i) { return nt16_to_4(seq[i]); };
+    auto qp = [&](int i) { return (double)P.q2p[iqual[i]]; };
+    double M[NP], I[NP], D[NP];
+    #pragma unroll
+    for (int p = 0; p < NP; ++p) M[p] = I[p] = D[p] = 0.;
+    // ---- forward ----
+    uint64_t rw = 0;                                      // base of position p (column k = p + x - 1, ref[k-1]) in bits [3p, 3p+3)
+    #pragma unroll
+    for (int p = 2; p < NP; ++p) rw |= (uint64_t)(p - 2 < l_ref ? ref[p - 2] : 4) << (3 * p);
+    {
+        double sum = 0.;
+        const int end = l_ref < bw + 1 ? l_ref : bw + 1;
+        const double q0 = qp(0);
+        const int y0 = qy(0);
+        #pragma unroll
+        for (int p = 2; p < NP; ++p) {
+            if (p - 1 <= end) {
+                const int rb = (int)((rw >> (3 * p)) & 7);
+                const double e = (rb > 3 || y0 > 3) ? 1. : rb == y0 ? 1. - q0 : q0 * EM;
+                const double a = e * bM, b = EI * bI;
+                M[p] = a; I[p] = b;
+                sum += a + b;
+            }
+        }
+        SC(1) = sum;
+        #pragma unroll
+        for (int p = 1; p < NP; ++p) {
+            if (p >= 2 && p - 1 <= end) { M[p] /= sum; I[p] /= sum; D[p] /= sum; }
+            FR(1, p, 0) = M[p]; FR(1, p, 1) = I[p]; FR(1, p, 2) = D[p];
+        }
+    }
+    int x = 0;
+    for (int i = 2; i <= l_query; ++i) {
+        const double qli = qp(i - 1);
+        const int qyi = qy(i - 1);
+        const bool slide = i > bw;
+        if (slide) {
+            ++x;
+            rw >>= 3;
+            const int nk = (NP - 1) + x - 2;
+            rw |= (uint64_t)(nk < l_ref ? ref[nk] : 4) << (3 * (NP - 1));
+        }
+        const int end = l_ref < i + bw ? l_ref : i + bw;
+        const int plo = x == 0 ? 2 : 1, phi = end - x + 1;
+        double sum = 0.;
+        double cM = M[0], cI = I[0], cD = D[0];
+        M[0] = I[0] = D[0] = 0.;
+        #pragma unroll
+        for (int p = 1; p < NP; ++p) {
+            const double oM = M[p], oI = I[p], oD = D[p];
+            const double nM = p + 1 < NP ? M[p + 1 < NP ? p + 1 : p] : 0., nI = p + 1 < NP ? I[p + 1 < NP ? p + 1 : p] : 0.;
+            double f0 = 0., f1 = 0., f2 = 0.;
+            if (p >= plo && p <= phi) {
+                const int rb = (int)((rw >> (3 * p)) & 7);
+                const double e = (rb > 3 || qyi > 3) ? 1. : rb == qyi ? 1. - qli : qli * EM;
+                const double gM = slide ? oM : cM, gI = slide ? oI : cI, gD = slide ? oD : cD;
+                const double uM = slide ? nM : oM, uI = slide ? nI : oI;
+                f0 = e * (m[0] * gM + m[3] * gI + m[6] * gD);
+                f1 = EI * (m[1] * uM + m[4] * uI);
+                f2 = m[2] * M[p - 1] + m[8] * D[p - 1];
+                sum += f0 + f1 + f2;
+            }
+            M[p] = f0; I[p] = f1; D[p] = f2;
+            cM = oM; cI = oI; cD = oD;
+        }
+        SC(i) = sum;
+        const double r = 1. / sum;
+        #pragma unroll
+        for (int p = 1; p < NP; ++p) {
+            M[p] *= r; I[p] *= r; D[p] *= r;
+            FR(i, p, 0) = M[p]; FR(i, p, 1) = I[p]; FR(i, p, 2) = D[p];
+        }
+    }
+    {
+        double sum = 0.;
+        const int phi = l_ref - x + 1 < bw2 ? l_ref - x + 1 : bw2;
+        const int plo = x == 0 ? 2 : 1;
+        #pragma unroll
+        for (int p = 1; p < NP; ++p)
+            if (p >= plo && p <= phi) sum += M[p] * sM + I[p] * sI;
+        SC(l_query + 1) = sum;
+    }
+    // ---- backward with the posterior maximum of every row ----
+    // x is max(0, l_query - bw) here.  Row l_query:
+    {
+        const double sl = SC(l_query), sl1 = SC(l_query + 1);
+        const int phi = l_ref - x + 1 < bw2 ? l_ref - x + 1 : bw2;
+        const int plo = x == 0 ? 2 : 1;
+        #pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const bool in = p >= plo && p <= phi;
+            M[p] = in ? sM / sl / sl1 : 0.; I[p] = in ? sI / sl / sl1 : 0.; D[p] = 0.;
+        }
+    }
+    // backward window: position p holds ref[p + x - 1] (the emission of column k+1), 7 beyond the reference
+    auto bcode = [&](int idx) { return (uint64_t)(idx >= 0 && idx < l_ref ? ref[idx] : 7); };
+    uint64_t rb_w = 0;
+    #pragma unroll
+    for (int p = 1; p < NP; ++p) rb_w |= bcode(p + x - 1) << (3 * p);
+    constexpr uint64_t WMASK = (NP * 3 >= 64) ? ~0ull : ((1ull << (NP * 3)) - 1);
+    for (int i = l_query; i >= 1; --i) {
+        if (i < l_query) {
+            // b[i] from b[i+1], in place, descending p
+            const int xi = i - bw > 0 ? i - bw : 0;
+            const bool slide = xi != x;                   // the band of row i+1 sits one column to the right
+            if (slide) { rb_w = ((rb_w << 3) & WMASK & ~7ull) | (bcode(xi) << 3); }
+            x = xi;
+            const double qli1 = qp(i);
+            const int qyi1 = qy(i);
+            const int end = l_ref < i + bw ? l_ref : i + bw;
+            const int plo = x == 0 ? 2 : 1, phi = end - x + 1;
+            const double y = (i > 1);
+            double cM = 0., cI = 0., cD = 0.;             // old [p+1]
+            #pragma unroll
+            for (int p = NP - 2; p >= 1; --p) {
+                const double oM = M[p], oI = I[p], oD = D[p];
+                double nM = 0., nI = 0., nD = 0.;
+                if (p >= plo && p <= phi) {
+                    const int rb = (int)((rb_w >> (3 * p)) & 7);
+                    const double em = rb == 7 ? 0. : (rb > 3 || qyi1 > 3) ? 1. : rb == qyi1 ? 1. - qli1 : qli1 * EM;
+                    const double e = em * (slide ? oM : cM);
+                    const double b10 = slide ? I[p - 1] : oI;
+                    const double b01 = D[p + 1];
+                    nM = e * m[0] + EI * m[1] * b10 + m[2] * b01;
+                    nI = e * m[3] + EI * m[4] * b10;
+                    nD = (e * m[6] + m[8] * b01) * y;
+                }
+                M[p] = nM; I[p] = nI; D[p] = nD;
+                cM = oM; cI = oI; cD = oD;
+            }
+            (void)cI; (void)cD;
+            M[NP - 1] = I[NP - 1] = D[NP - 1] = 0.;
+            const double y2 = 1. / SC(i);
+            #pragma unroll
+            for (int p = 1; p < NP; ++p) { M[p] *= y2; I[p] *= y2; D[p] *= y2; }
+        }
+        // posterior of row i (probaln.c MAP): first maximum over k ascending, M before I
+        {
+            const int end = l_ref < i + bw ? l_ref : i + bw;
+            const int plo = x == 0 ? 2 : 1, phi = end - x + 1;
+            double sum = 0., max = 0.;
+            int max_k = -1;
+            #pragma unroll
+            for (int p = 1; p < NP; ++p) {
+                if (p >= plo && p <= phi) {
+                    const int k = p + x - 1;
+                    double z;
+                    z = FR(i, p, 0) * M[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 0; } sum += z;
+                    z = FR(i, p, 1) * I[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 1; } sum += z;
+                }
+            }
+            max /= sum;
+            state[i - 1] = max_k;
+            const int kq = (int)(-4.343 * log(1. - max) + .499);
+            q[i - 1] = (uint8_t)(kq > 100 ? 99 : kq);
+        }
+    }
+    #undef FR
+    #undef SC
+}
+
+// the quality cap of sam_prob_realn (realn.c) from the posterior states and qualities
+__device__ void baq_cap(const BaqParams &P, const BaqJob &j, const uint8_t *iqual, const int32_t *state, const uint8_t *q,
+                        uint8_t *qout, uint8_t *zout)
+{
+    const int l_query = j.l_query;
     const uint32_t *cigar = P.cig + j.cig_off;
     const bool apply = (P.flag & 1) != 0, extend = (P.flag & 2) != 0;
     uint8_t *bq = zout;                                   // built in place in the ZQ output
@@ -211,8 +394,33 @@ __global__ __launch_bounds__(64) void baq_kernel(const BaqParams P)
         for (int i = 0; i < l_query; ++i) bq[i] = (uint8_t)(64 + (iqual[i] <= bq[i] ? 0 : iqual[i] - bq[i]));
     }
     for (int i = 0; i < l_query; ++i) qout[i] = apply ? (uint8_t)(iqual[i] - (bq[i] - 64)) : iqual[i];
-    #undef FM
-    #undef SC
+}
+
+
+#define BAQ_BWM 7
+
+template <bool REG>
+__global__ __launch_bounds__(64) void baq_kernel(const BaqParams P)
+{
+    const int job = blockIdx.x * 64 + threadIdx.x;
+    if (job >= P.n_jobs) return;
+    const BaqJob j = P.jobs[job];
+    const uint8_t *seq = P.seq16 + j.seq_off, *iqual = P.qual + j.seq_off;
+    uint8_t *qout = P.qual_out + j.seq_off, *zout = P.zq_out + j.seq_off;
+    if (j.ret < 0 || j.l_ref <= 0 || j.l_query <= 0) {
+        for (int i = 0; i < j.l_query; ++i) { qout[i] = iqual[i]; zout[i] = 0; }
+        return;
+    }
+    const uint8_t *ref = P.tref + j.ref_off;
+    int32_t *state = P.state + j.seq_off;
+    uint8_t *q = P.q + j.seq_off;
+    if (REG) {
+        int bw = j.l_ref > j.l_query ? j.l_ref : j.l_query;
+        if (bw > j.bw) bw = j.bw;
+        if (bw < abs(j.l_ref - j.l_query)) bw = abs(j.l_ref - j.l_query);
+        baq_fb_reg<BAQ_BWM>(P, job, j, ref, seq, iqual, bw, state, q);
+    } else baq_fb_scratch(P, job, j, ref, seq, iqual, state, q);
+    baq_cap(P, j, iqual, state, q, qout, zout);
 }
 
 }  // namespace bcfgpu
@@ -282,13 +490,15 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
         ret[r] = 0;
     }
     if (tref.size() >> 32) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_baq: pool too large, use fewer reads per call");
-    // band classes: reads whose band is the default run together; wide bands (long indels) separately, with their own row width
+    // band classes: class 0 = bands that fit the register-row kernel (the default band of 7), class 1 = wide bands
+    // (long indels), run separately with both matrices in scratch and their own row width
     auto eff_bw = [](const BaqJob &j) { int b = j.l_ref > j.l_query ? j.l_ref : j.l_query; if (b > j.bw) b = j.bw;
                                         if (b < std::abs(j.l_ref - j.l_query)) b = std::abs(j.l_ref - j.l_query); return b; };
+    const bool force_scratch = [] { const char *ab = getenv("BCFGPU_ABLATE"); return ab && (atoi(ab) & 512); }();
     std::vector<BaqJob> cls[2];
     int cls_bw[2] = {1, 1};
     for (const BaqJob &j : jobs) {
-        const int b = j.ret < 0 ? 1 : eff_bw(j), c = b <= 10 ? 0 : 1;
+        const int b = j.ret < 0 ? 1 : eff_bw(j), c = (b <= BAQ_BWM && !force_scratch) ? 0 : 1;
         cls[c].push_back(j);
         if (b > cls_bw[c]) cls_bw[c] = b;
     }
@@ -315,8 +525,10 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
     for (int c = 0; c < 2; ++c) {
         const size_t nj = cls[c].size();
         if (!nj) continue;
-        P.ncell = 3 * (2 * cls_bw[c] + 1) + 6;
-        const size_t per_job = 2 * (size_t)(max_lq + 1) * P.ncell * sizeof(double);
+        const bool reg = c == 0;
+        P.ncell = reg ? 3 * (2 * BAQ_BWM + 3) : 3 * (2 * cls_bw[c] + 1) + 6;       // doubles per matrix row
+        const size_t per_mat = (size_t)(max_lq + 1) * P.ncell * sizeof(double);    // one matrix of one read
+        const size_t per_job = reg ? per_mat : 2 * per_mat;
         size_t chunk = ((size_t)2 << 30) / per_job;
         chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
         if (chunk > nj) chunk = (nj + 63) & ~(size_t)63;
@@ -326,14 +538,16 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
         if (d_B) { hipFree(d_B); d_B = nullptr; }
         if (d_S) { hipFree(d_S); d_S = nullptr; }
         BQ_CHK(hipMalloc(&d_jobs, nj * sizeof(BaqJob)));
-        BQ_CHK(hipMalloc(&d_F, per_job / 2 * chunk)); BQ_CHK(hipMalloc(&d_B, per_job / 2 * chunk));
+        BQ_CHK(hipMalloc(&d_F, per_mat * chunk));
+        if (!reg) BQ_CHK(hipMalloc(&d_B, per_mat * chunk));
         BQ_CHK(hipMalloc(&d_S, (size_t)(max_lq + 2) * chunk * sizeof(double)));
         BQ_CHK(hipMemcpyAsync(d_jobs, cls[c].data(), nj * sizeof(BaqJob), hipMemcpyHostToDevice, stream));
         P.F = (double*)d_F; P.B = (double*)d_B; P.S = (double*)d_S;
         for (size_t j0 = 0; j0 < nj; j0 += chunk) {
             P.n_jobs = (int)(nj - j0 < chunk ? nj - j0 : chunk);
             P.jobs = (const BaqJob*)d_jobs + j0;
-            hipLaunchKernelGGL(baq_kernel, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
+            if (reg) hipLaunchKernelGGL(baq_kernel<true>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
+            else     hipLaunchKernelGGL(baq_kernel<false>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
         }
         BQ_CHK(hipGetLastError());
     }
