@@ -46,9 +46,14 @@ struct bcfgpu_ctx {
     std::vector<int> pool_call;     // mode 2: 1 if the sequence included the call kernel
     std::vector<void*> owned;
     bcfgpu_gap_stats gap{};         // statistics of the last bcfgpu_gap_prep
+    // grow-only device workspaces of the indel / BAQ stages (GiB-sized scratch: not reallocated per call)
+    struct Ws { void *p = nullptr; size_t bytes = 0; };
+    Ws ws[16];
 };
 
 extern "C" {
+
+void *bcfgpu_internal_ws(bcfgpu_ctx *c, int slot, size_t bytes);
 
 const char *bcfgpu_last_error(void) { return g_err.c_str(); }
 
@@ -153,6 +158,7 @@ void bcfgpu_destroy(bcfgpu_ctx *c)
     hipSetDevice(c->cfg.device);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (void *p : c->owned) hipFree(p);
+    for (auto &w : c->ws) if (w.p) hipFree(w.p);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     for (int i = 0; i < 4; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -446,16 +452,17 @@ int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnPools> &
     chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
     if (chunk > nj) chunk = (nj + 63) & ~(size_t)63;
     p.scratch_stride = chunk;
-    void *d_jobs = nullptr, *d_ref2 = nullptr, *d_q = nullptr, *d_qq = nullptr, *d_scr = nullptr, *d_s1 = nullptr, *d_s2 = nullptr;
-    auto cleanup = [&]() { for (void *x : {d_jobs, d_ref2, d_q, d_qq, d_scr, d_s1, d_s2}) if (x) hipFree(x); };
+    void *d_jobs, *d_ref2, *d_q, *d_qq, *d_scr, *d_s1, *d_s2;
+    auto cleanup = [&]() {};
     #define GP_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return set_err(BCFGPU_E_HIP, #call, e_); } } while (0)
-    GP_CHK(hipMalloc(&d_jobs, nj * sizeof(ProbalnJob)));
-    GP_CHK(hipMalloc(&d_ref2, nr + 16));
-    GP_CHK(hipMalloc(&d_q, nq + 16));
-    GP_CHK(hipMalloc(&d_qq, nq + 16));
-    GP_CHK(hipMalloc(&d_scr, 2 * (size_t)p.ncell * p.scratch_stride * sizeof(double)));
-    GP_CHK(hipMalloc(&d_s1, nj * 4));
-    GP_CHK(hipMalloc(&d_s2, nj * 4));
+    d_jobs = bcfgpu_internal_ws(c, 0, nj * sizeof(ProbalnJob));
+    d_ref2 = bcfgpu_internal_ws(c, 1, nr + 16);
+    d_q = bcfgpu_internal_ws(c, 2, nq + 16);
+    d_qq = bcfgpu_internal_ws(c, 3, nq + 16);
+    d_scr = bcfgpu_internal_ws(c, 4, 2 * (size_t)p.ncell * p.scratch_stride * sizeof(double));
+    d_s1 = bcfgpu_internal_ws(c, 5, nj * 4);
+    d_s2 = bcfgpu_internal_ws(c, 6, nj * 4);
+    if (!d_jobs || !d_ref2 || !d_q || !d_qq || !d_scr || !d_s1 || !d_s2) return set_err(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
     {   // the pools are already rebased to their place in the concatenation: upload them segment by segment
         size_t oj = 0, orf = 0, oq = 0;
         for (const ProbalnPools &pl : pools) {
@@ -490,11 +497,24 @@ int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnPools> &
     c->gap.kernel_ms = 0;
     hipEventElapsedTime(&c->gap.kernel_ms, e0, e1);
     hipEventDestroy(e0); hipEventDestroy(e1);
-    cleanup();
     return 0;
 }
 
 bcfgpu_gap_stats *bcfgpu_internal_gap_stats(bcfgpu_ctx *c) { return &c->gap; }
+
+// workspace `slot` of at least `bytes` (contents undefined); nullptr when the allocation fails
+void *bcfgpu_internal_ws(bcfgpu_ctx *c, int slot, size_t bytes)
+{
+    if (!c || slot < 0 || slot >= 16) return nullptr;
+    auto &w = c->ws[slot];
+    if (w.bytes >= bytes && w.p) return w.p;
+    hipSetDevice(c->cfg.device);
+    if (w.p) { hipStreamSynchronize(c->stream); hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+    const size_t want = bytes + bytes / 8 + 256;          // a little slack so that slowly growing batches settle
+    if (hipMalloc(&w.p, want) != hipSuccess) { w.p = nullptr; return nullptr; }
+    w.bytes = want;
+    return w.p;
+}
 
 // for the stages implemented in their own translation units: bind the device, hand out the stream and shared tables
 int bcfgpu_internal_device(bcfgpu_ctx *c, hipStream_t *stream, const float **q2p)

@@ -17,6 +17,7 @@
 struct bcfgpu_ctx;
 int bcfgpu_set_error(int code, const char *what);
 extern "C" int bcfgpu_internal_device(bcfgpu_ctx *ctx, hipStream_t *stream, const float **q2p);
+extern "C" void *bcfgpu_internal_ws(bcfgpu_ctx *ctx, int slot, size_t bytes);
 
 namespace bcfgpu {
 
@@ -504,13 +505,16 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
     }
 
     // ---- device half ----
-    void *d_jobs = nullptr, *d_tref = nullptr, *d_seq = nullptr, *d_qual = nullptr, *d_cig = nullptr, *d_F = nullptr, *d_B = nullptr,
-         *d_S = nullptr, *d_state = nullptr, *d_q = nullptr, *d_tmp = nullptr, *d_qo = nullptr, *d_zo = nullptr;
-    auto cleanup = [&]() { for (void *x : {d_jobs, d_tref, d_seq, d_qual, d_cig, d_F, d_B, d_S, d_state, d_q, d_tmp, d_qo, d_zo}) if (x) hipFree(x); };
-    BQ_CHK(hipMalloc(&d_tref, tref.size() + 16));
-    BQ_CHK(hipMalloc(&d_seq, nbase + 16)); BQ_CHK(hipMalloc(&d_qual, nbase + 16)); BQ_CHK(hipMalloc(&d_cig, (ncig + 4) * 4));
-    BQ_CHK(hipMalloc(&d_state, (nbase + 4) * 4)); BQ_CHK(hipMalloc(&d_q, nbase + 16)); BQ_CHK(hipMalloc(&d_tmp, 2 * nbase + 16));
-    BQ_CHK(hipMalloc(&d_qo, nbase + 16)); BQ_CHK(hipMalloc(&d_zo, nbase + 16));
+    // grow-only workspaces of the context (slots 7..): GiB-sized scratch is not reallocated per call
+    void *d_jobs = nullptr, *d_F = nullptr, *d_B = nullptr, *d_S = nullptr;
+    auto cleanup = [&]() {};
+    void *d_tref = bcfgpu_internal_ws(ctx, 7, tref.size() + 16), *d_seq = bcfgpu_internal_ws(ctx, 8, nbase + 16),
+         *d_qual = bcfgpu_internal_ws(ctx, 9, nbase + 16), *d_cig = bcfgpu_internal_ws(ctx, 10, (ncig + 4) * 4),
+         *d_state = bcfgpu_internal_ws(ctx, 11, (nbase + 4) * 4), *d_q = bcfgpu_internal_ws(ctx, 12, nbase + 16),
+         *d_tmp = bcfgpu_internal_ws(ctx, 13, 2 * nbase + 16), *d_qo = bcfgpu_internal_ws(ctx, 14, nbase + 16),
+         *d_zo = bcfgpu_internal_ws(ctx, 15, nbase + 16);
+    if (!d_tref || !d_seq || !d_qual || !d_cig || !d_state || !d_q || !d_tmp || !d_qo || !d_zo)
+        return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_baq: device workspace");
     BQ_CHK(hipMemcpyAsync(d_tref, tref.data(), tref.size(), hipMemcpyHostToDevice, stream));
     BQ_CHK(hipMemcpyAsync(d_seq, rd->seq16, nbase, hipMemcpyHostToDevice, stream));
     BQ_CHK(hipMemcpyAsync(d_qual, rd->qual, nbase, hipMemcpyHostToDevice, stream));
@@ -533,14 +537,12 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
         chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
         if (chunk > nj) chunk = (nj + 63) & ~(size_t)63;
         P.stride = chunk;
-        if (d_jobs) { hipFree(d_jobs); d_jobs = nullptr; }
-        if (d_F) { hipFree(d_F); d_F = nullptr; }
-        if (d_B) { hipFree(d_B); d_B = nullptr; }
-        if (d_S) { hipFree(d_S); d_S = nullptr; }
-        BQ_CHK(hipMalloc(&d_jobs, nj * sizeof(BaqJob)));
-        BQ_CHK(hipMalloc(&d_F, per_mat * chunk));
-        if (!reg) BQ_CHK(hipMalloc(&d_B, per_mat * chunk));
-        BQ_CHK(hipMalloc(&d_S, (size_t)(max_lq + 2) * chunk * sizeof(double)));
+        // (slots 0..6 are shared with the indel stage; both stages finish their stream work before returning)
+        d_jobs = bcfgpu_internal_ws(ctx, 0, nj * sizeof(BaqJob));
+        d_F = bcfgpu_internal_ws(ctx, 4, per_mat * chunk);
+        d_B = reg ? nullptr : bcfgpu_internal_ws(ctx, 1, per_mat * chunk);
+        d_S = bcfgpu_internal_ws(ctx, 2, (size_t)(max_lq + 2) * chunk * sizeof(double));
+        if (!d_jobs || !d_F || (!reg && !d_B) || !d_S) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_baq: device workspace");
         BQ_CHK(hipMemcpyAsync(d_jobs, cls[c].data(), nj * sizeof(BaqJob), hipMemcpyHostToDevice, stream));
         P.F = (double*)d_F; P.B = (double*)d_B; P.S = (double*)d_S;
         for (size_t j0 = 0; j0 < nj; j0 += chunk) {
@@ -554,6 +556,5 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
     BQ_CHK(hipMemcpyAsync(qual_out, d_qo, nbase, hipMemcpyDeviceToHost, stream));
     BQ_CHK(hipMemcpyAsync(zq_out, d_zo, nbase, hipMemcpyDeviceToHost, stream));
     BQ_CHK(hipStreamSynchronize(stream));
-    cleanup();
     return BCFGPU_OK;
 }
