@@ -74,3 +74,64 @@ def test_baq_matches_oracle_on_synthetic_reads(gpu_ctx_factory):
         assert rc == 0
         np.testing.assert_array_equal(r.qual, wq)
         np.testing.assert_array_equal(r.zq, wz)
+
+
+def _random_reads(seed, n, L=600):
+    """Reads with soft clips, insertions, deletions, N bases, low qualities, near both ends of the reference."""
+    rng = np.random.default_rng(seed)
+    ref = "".join("ACGT"[i] for i in rng.integers(0, 4, L))
+    if seed % 2:
+        ref = ref[:200] + "N" * 7 + ref[207:]
+
+    class Rd:
+        pass
+    reads = []
+    for i in range(n):
+        ops = []
+        if rng.random() < 0.3:
+            ops.append((int(rng.integers(1, 12)), "S"))
+        remaining = int(rng.integers(25, 120))
+        while remaining > 0:
+            m = int(min(remaining, rng.integers(5, 60)))
+            ops.append((m, "M"))
+            remaining -= m
+            if remaining > 0 and rng.random() < 0.5:
+                ops.append((int(rng.integers(1, 14 if rng.random() < 0.15 else 4)), "ID"[int(rng.integers(0, 2))]))
+        if rng.random() < 0.3:
+            ops.append((int(rng.integers(1, 12)), "S"))
+        reflen = sum(l for l, o in ops if o in "MD")
+        pos = int(rng.integers(0, 3)) if rng.random() < 0.1 else int(rng.integers(0, L - reflen + 1))
+        if rng.random() < 0.1:
+            pos = L - reflen                                     # flush with the end of the contig
+        seq, x = [], pos
+        for l, o in ops:
+            if o == "M":
+                seq += [ref[x + k] if rng.random() > 0.03 else "ACGT"[int(rng.integers(0, 4))] for k in range(l)]
+                x += l
+            elif o == "D":
+                x += l
+            else:
+                seq += ["ACGT"[int(rng.integers(0, 4))] for _ in range(l)]
+        seq = "".join("N" if (c != "N" and rng.random() < 0.01) else c for c in seq)
+        r = Rd()
+        r.pos, r.seq, r.l_qseq, r.flag, r.qname = pos, seq, len(seq), 0, "f%d" % i
+        r.qual = rng.integers(2, 42, len(seq)).astype(np.int32)
+        r.bamcigar = np.array([(l << 4) | "MIDNS".index(o) for l, o in ops], dtype=np.uint32)
+        r.zq = None
+        reads.append(r)
+    return ref, reads
+
+
+@pytest.mark.parametrize("seed,flag", [(101, 3), (102, 3), (103, 1), (104, 2)])
+def test_baq_matches_oracle_on_random_cigars(gpu_ctx_factory, seed, flag):
+    refseq, reads = _random_reads(seed, 400)
+    ctx = gpu_ctx_factory(abi.default_cfg(1, max_sites=1, max_reads=64))
+    want = _oracle(reads, refseq, flag)
+    ret = M.apply_baq_hip(reads, refseq, ctx, flag)
+    wide = 0
+    for r, (rc, wq, wz), rr in zip(reads, want, ret):
+        assert (rc == 0) == (rr == 0), r.qname
+        if rc == 0:
+            np.testing.assert_array_equal(r.qual, wq, err_msg=r.qname)
+            np.testing.assert_array_equal(r.zq, wz, err_msg=r.qname)
+    assert sum(rc == 0 for rc, _, _ in want) > 300
