@@ -440,11 +440,12 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
 
 // device half of bcfgpu_gap_prep (indel_host.hip): upload the job pools, run probaln_kernel, download the scores
 int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnPools> &pools, int max_bw,
+                                const bcfgpu_reads *rd, size_t nq, bool any_zq,
                                 std::vector<int32_t> &score1, std::vector<int32_t> &score2)
 {
     hipSetDevice(c->cfg.device);
-    size_t nj = 0, nr = 0, nq = 0;
-    for (const ProbalnPools &pl : pools) { nj += pl.jobs.size(); nr += pl.ref2pool.size(); nq += pl.qpool.size(); }
+    size_t nj = 0, nr = 0;
+    for (const ProbalnPools &pl : pools) { nj += pl.jobs.size(); nr += pl.ref2pool.size(); }
     ProbalnParams p{};
     p.ncell = 3 * (2 * max_bw + 1) + 6;
     // jobs are run in chunks so that the two rolling rows of every job in flight fit a ~1 GiB scratch
@@ -452,7 +453,7 @@ int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnPools> &
     chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
     if (chunk > nj) chunk = (nj + 63) & ~(size_t)63;
     p.scratch_stride = chunk;
-    void *d_jobs, *d_ref2, *d_q, *d_qq, *d_scr, *d_s1, *d_s2;
+    void *d_jobs, *d_ref2, *d_q, *d_qq, *d_scr, *d_s1, *d_s2, *d_zq = nullptr;
     auto cleanup = [&]() {};
     #define GP_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return set_err(BCFGPU_E_HIP, #call, e_); } } while (0)
     d_jobs = bcfgpu_internal_ws(c, 0, nj * sizeof(ProbalnJob));
@@ -462,20 +463,21 @@ int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnPools> &
     d_scr = bcfgpu_internal_ws(c, 4, 2 * (size_t)p.ncell * p.scratch_stride * sizeof(double));
     d_s1 = bcfgpu_internal_ws(c, 5, nj * 4);
     d_s2 = bcfgpu_internal_ws(c, 6, nj * 4);
-    if (!d_jobs || !d_ref2 || !d_q || !d_qq || !d_scr || !d_s1 || !d_s2) return set_err(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
-    {   // the pools are already rebased to their place in the concatenation: upload them segment by segment
-        size_t oj = 0, orf = 0, oq = 0;
+    if (any_zq) d_zq = bcfgpu_internal_ws(c, 7, nq + 16);
+    if (!d_jobs || !d_ref2 || !d_q || !d_qq || !d_scr || !d_s1 || !d_s2 || (any_zq && !d_zq)) return set_err(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
+    {   // the job pools are already rebased to their place in the concatenation: uploaded segment by segment;
+        // the reads' base / quality (/ZQ) pools go up as the caller holds them and are converted by the kernel
+        size_t oj = 0, orf = 0;
         for (const ProbalnPools &pl : pools) {
             if (!pl.jobs.empty()) GP_CHK(hipMemcpyAsync((ProbalnJob*)d_jobs + oj, pl.jobs.data(), pl.jobs.size() * sizeof(ProbalnJob), hipMemcpyHostToDevice, c->stream));
             if (!pl.ref2pool.empty()) GP_CHK(hipMemcpyAsync((uint8_t*)d_ref2 + orf, pl.ref2pool.data(), pl.ref2pool.size(), hipMemcpyHostToDevice, c->stream));
-            if (!pl.qpool.empty()) {
-                GP_CHK(hipMemcpyAsync((uint8_t*)d_q + oq, pl.qpool.data(), pl.qpool.size(), hipMemcpyHostToDevice, c->stream));
-                GP_CHK(hipMemcpyAsync((uint8_t*)d_qq + oq, pl.qqpool.data(), pl.qqpool.size(), hipMemcpyHostToDevice, c->stream));
-            }
-            oj += pl.jobs.size(); orf += pl.ref2pool.size(); oq += pl.qpool.size();
+            oj += pl.jobs.size(); orf += pl.ref2pool.size();
         }
+        GP_CHK(hipMemcpyAsync(d_q, rd->seq16, nq, hipMemcpyHostToDevice, c->stream));
+        GP_CHK(hipMemcpyAsync(d_qq, rd->qual, nq, hipMemcpyHostToDevice, c->stream));
+        if (any_zq) GP_CHK(hipMemcpyAsync(d_zq, rd->zq, nq, hipMemcpyHostToDevice, c->stream));
     }
-    p.ref2 = (const uint8_t*)d_ref2; p.query = (const uint8_t*)d_q; p.qq = (const uint8_t*)d_qq;
+    p.ref2 = (const uint8_t*)d_ref2; p.query = (const uint8_t*)d_q; p.qq = (const uint8_t*)d_qq; p.zq = (const uint8_t*)d_zq;
     p.q2p = c->d_q2p; p.scratch = (double*)d_scr;
     { const char *ab = getenv("BCFGPU_ABLATE"); p.force_scratch = ab && (atoi(ab) & 256) ? 1 : 0; }
     hipEvent_t e0 = nullptr, e1 = nullptr;

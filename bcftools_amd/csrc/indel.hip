@@ -14,10 +14,23 @@ namespace bcfgpu {
 #define EI .25
 #define EM .33333333333
 
+// a read's bases and qualities as the caller holds them: 4-bit codes, raw qualities, optional ZQ bytes (BAQ offsets).
+// bam2bcf_indel.c:339-345: query = seq_nt16_int of the base; quality = qual (+ ZQ - 64), capped to [7, 30]
+struct QSrc {
+    const uint8_t *seq, *qual, *zq;
+    __device__ __forceinline__ int base(int i) const { return (int)((0x4444444344424104ull >> (4 * (seq[i] & 15))) & 7); }
+    __device__ __forceinline__ int q(int i) const
+    {
+        int v = zq ? (int)(uint8_t)(qual[i] + (zq[i] - 64)) : (int)qual[i];
+        v = v > 30 ? 30 : v;
+        return v < 7 ? 7 : v;
+    }
+};
+
 __device__ __forceinline__ int set_u(int b, int i, int k) { int x = i - b; x = x > 0 ? x : 0; return (k - x + 1) * 3; }
 
 // forward score of one job with gap-open d / gap-ext e (probaln_par_t {d, e, bw})
-__device__ int probaln_fwd(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
+__device__ int probaln_fwd(const uint8_t *ref, int l_ref, const QSrc qs, int l_query,
                            const float *q2p, double d, double e_, int cbw, double *row0, double *row1, size_t stride, int ncell)
 {
     if (l_ref <= 0 || l_query <= 0) return 0;
@@ -41,9 +54,10 @@ __device__ int probaln_fwd(const uint8_t *ref, int l_ref, const uint8_t *query, 
     {
         double sum = 0.;
         const int beg = 1, end = l_ref < bw + 1 ? l_ref : bw + 1;
-        const double q0 = (double)q2p[iqual[0]];
+        const double q0 = (double)q2p[qs.q(0)];
+        const int qy0 = qs.base(0);
         for (int k = beg; k <= end; ++k) {
-            const double e = (ref[k - 1] > 3 || query[0] > 3) ? 1. : ref[k - 1] == query[0] ? 1. - q0 : q0 * EM;
+            const double e = (ref[k - 1] > 3 || qy0 > 3) ? 1. : ref[k - 1] == qy0 ? 1. - q0 : q0 * EM;
             const int u = set_u(bw, 1, k);
             const double a = e * bM, b = EI * bI;
             F(fi, u) = a; F(fi, u + 1) = b;
@@ -57,8 +71,8 @@ __device__ int probaln_fwd(const uint8_t *ref, int l_ref, const uint8_t *query, 
     for (int i = 2; i <= l_query; ++i) {
         double *t = fi; fi = fi1; fi1 = t;
         for (int c = 0; c < nc; ++c) F(fi, c) = 0.;
-        const double qli = (double)q2p[iqual[i - 1]];
-        const uint8_t qyi = query[i - 1];
+        const double qli = (double)q2p[qs.q(i - 1)];
+        const int qyi = qs.base(i - 1);
         int beg = 1, end = l_ref, x;
         x = i - bw; beg = beg > x ? beg : x;
         x = i + bw; end = end < x ? end : x;
@@ -101,7 +115,7 @@ __device__ int probaln_fwd(const uint8_t *ref, int l_ref, const uint8_t *query, 
 // register (3 bits per base, shifted as the band slides).  No scratch memory: the rolling-row version moves
 // 48 bytes per cell through HBM and is bandwidth-bound; this one is bound by fp64 issue.
 template <int BWM>
-__device__ int probaln_fwd_reg(const uint8_t *ref, int l_ref, const uint8_t *query, int l_query, const uint8_t *iqual,
+__device__ int probaln_fwd_reg(const uint8_t *ref, int l_ref, const QSrc qs, int l_query,
                                const float *q2p, double d, double e_, int bw)
 {
     constexpr int NP = 2 * BWM + 3;                       // positions 0 .. 2*BWM+2
@@ -124,8 +138,8 @@ __device__ int probaln_fwd_reg(const uint8_t *ref, int l_ref, const uint8_t *que
     {
         double sum = 0.;
         const int end = l_ref < bw + 1 ? l_ref : bw + 1;
-        const double q0 = (double)q2p[iqual[0]];
-        const int qy = query[0];
+        const double q0 = (double)q2p[qs.q(0)];
+        const int qy = qs.base(0);
         #pragma unroll
         for (int p = 2; p < NP; ++p) {
             if (p - 1 <= end) {
@@ -144,8 +158,8 @@ __device__ int probaln_fwd_reg(const uint8_t *ref, int l_ref, const uint8_t *que
     }
     int x = 0;                                            // first column of the band minus one: max(0, i - bw)
     for (int i = 2; i <= l_query; ++i) {
-        const double qli = (double)q2p[iqual[i - 1]];
-        const int qyi = query[i - 1];
+        const double qli = (double)q2p[qs.q(i - 1)];
+        const int qyi = qs.base(i - 1);
         const bool slide = i > bw;                        // x grows by one on this row
         if (slide) {
             ++x;
@@ -205,7 +219,8 @@ __global__ __launch_bounds__(64) void probaln_kernel(const ProbalnParams P)
     const ProbalnJob j = P.jobs[job];
     const size_t stride = P.scratch_stride;
     double *row0 = P.scratch + job, *row1 = P.scratch + (size_t)P.ncell * stride + job;
-    const uint8_t *ref = P.ref2 + j.ref_off, *query = P.query + j.query_off, *qq = P.qq + j.query_off;
+    const uint8_t *ref = P.ref2 + j.ref_off;
+    const QSrc qs{P.query + j.query_off, P.qq + j.query_off, (j.flags & 1) ? P.zq + j.query_off : nullptr};
     // (bam2bcf_indel.c:293-294, 346-356)
     // the band probaln_glocal really uses (probaln.c): min(bw, max(l_ref, l_query)), at least |l_ref - l_query|
     int eff = j.l_ref > j.l_query ? j.l_ref : j.l_query;
@@ -218,8 +233,8 @@ __global__ __launch_bounds__(64) void probaln_kernel(const ProbalnParams P)
     double gd = 1e-4, ge = 1e-2;
     #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-        const int sc = reg ? probaln_fwd_reg<BWM>(ref, j.l_ref, query, j.l_query, qq, P.q2p, gd, ge, eff)
-                           : probaln_fwd(ref, j.l_ref, query, j.l_query, qq, P.q2p, gd, ge, j.bw, row0, row1, stride, P.ncell);
+        const int sc = reg ? probaln_fwd_reg<BWM>(ref, j.l_ref, qs, j.l_query, P.q2p, gd, ge, eff)
+                           : probaln_fwd(ref, j.l_ref, qs, j.l_query, P.q2p, gd, ge, j.bw, row0, row1, stride, P.ncell);
         int l = (int)(100. * sc / j.l_query + .499);
         if (l > 255) l = 255;
         const int v = sc << 8 | l;

@@ -22,6 +22,7 @@ using namespace bcfgpu;
 
 // provided by api.hip
 extern "C" int bcfgpu_internal_run_probaln(bcfgpu_ctx *ctx, const std::vector<ProbalnPools> &pools, int max_bw,
+                                           const bcfgpu_reads *rd, size_t nbase, bool any_zq,
                                            std::vector<int32_t> &score1, std::vector<int32_t> &score2);
 int bcfgpu_set_error(int code, const char *what);
 extern "C" bcfgpu_gap_stats *bcfgpu_internal_gap_stats(bcfgpu_ctx *ctx);
@@ -115,8 +116,12 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
     typedef ProbalnPools Pools;
     auto prepare_range = [&](int is_begin, int is_end, Pools &PL) {
     std::vector<ProbalnJob> &jobs = PL.jobs;
-    std::vector<uint8_t> &ref2pool = PL.ref2pool, &qpool = PL.qpool, &qqpool = PL.qqpool;
+    std::vector<uint8_t> &ref2pool = PL.ref2pool;
     int &max_bw = PL.max_bw;
+    {   // one allocation instead of geometric regrowth: ~3 candidate types per read
+        const size_t entries = (size_t)(in->smpl_off[(size_t)is_end * n] - in->smpl_off[(size_t)is_begin * n]);
+        jobs.reserve(entries * 3);
+    }
     for (int is = is_begin; is < is_end; ++is) {
         SiteState &S = st[is];
         const int32_t *soff = in->smpl_off + (size_t)is * n;
@@ -261,7 +266,7 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
         const int max_ref2 = right - left + 2 + 2 * (max_ins > -types[0] ? max_ins : -types[0]);
         std::vector<char> ref2(max_ref2);
         S.N = N;
-        struct QSeg { int qbeg = -1, qend = -1; uint32_t off = 0; int left = -1, right = -1, qbeg_w = 0, qend_w = 0, tbeg = 0, tend = 0; };
+        struct QSeg { int left = -1, right = -1, qbeg_w = 0, qend_w = 0, tbeg = 0, tend = 0; };
         std::vector<QSeg> qseg(N);
         S.jobidx.assign((size_t)N * n_types, -1);
         S.job0 = jobs.size();
@@ -313,26 +318,9 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
                         if (eff < std::abs(jb.l_ref - jb.l_query)) eff = std::abs(jb.l_ref - jb.l_query);
                         if (eff > max_bw) max_bw = eff;
                     }
-                    // the query segment of a read is the same for every candidate type unless the window shrank: pooled once
-                    if (qc.qbeg == qbeg && qc.qend == qend) jb.query_off = qc.off;
-                    else {
-                    jb.query_off = (uint32_t)qpool.size();
-                    qc.qbeg = qbeg; qc.qend = qend; qc.off = jb.query_off;
-                    const uint8_t *qual = rd->qual + rd->r_seq_off[rdx];
-                    const uint8_t *bq = (rd->r_has_zq && rd->r_has_zq[rdx] && rd->zq) ? rd->zq + rd->r_seq_off[rdx] : nullptr;
-                    {
-                        const size_t o = qpool.size(), len = qend > qbeg ? (size_t)(qend - qbeg) : 0;
-                        qpool.resize(o + len); qqpool.resize(o + len);
-                        uint8_t *dq = qpool.data() + o, *dqq = qqpool.data() + o;
-                        for (int l = qbeg; l < qend; ++l) {
-                            dq[l - qbeg] = (uint8_t)nt16_int[seq[l] & 15];
-                            uint8_t q = bq ? (uint8_t)(qual[l] + (bq[l] - 64)) : qual[l];
-                            if (q > 30) q = 30;
-                            if (q < 7) q = 7;
-                            dqq[l - qbeg] = q;
-                        }
-                    }
-                    }
+                    // the query is read from the caller's seq16/qual(/ZQ) pools on the device, converted there
+                    jb.query_off = (uint32_t)(rd->r_seq_off[rdx] + qbeg);
+                    jb.flags = (rd->r_has_zq && rd->r_has_zq[rdx] && rd->zq) ? 1 : 0;
                     S.jobidx[(size_t)K * n_types + t] = (int32_t)jobs.size();
                     jobs.push_back(jb);
                 }
@@ -362,16 +350,16 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
         run_all([&](int t) { prepare_range(cut(t), cut(t + 1), pools[t]); });
         // pool bases in site order, then every thread rebases its own jobs and sites (no host-side concatenation:
         // the pools are uploaded segment by segment)
-        std::vector<size_t> jb0(nthr + 1, 0), r0(nthr + 1, 0), q0(nthr + 1, 0);
+        std::vector<size_t> jb0(nthr + 1, 0), r0(nthr + 1, 0);
         for (int t = 0; t < nthr; ++t) {
-            jb0[t + 1] = jb0[t] + pools[t].jobs.size(); r0[t + 1] = r0[t] + pools[t].ref2pool.size(); q0[t + 1] = q0[t] + pools[t].qpool.size();
+            jb0[t + 1] = jb0[t] + pools[t].jobs.size(); r0[t + 1] = r0[t] + pools[t].ref2pool.size();
             if (pools[t].max_bw > max_bw) max_bw = pools[t].max_bw;
         }
-        if (r0[nthr] >> 32 || q0[nthr] >> 32 || jb0[nthr] >> 31)
+        if (r0[nthr] >> 32 || jb0[nthr] >> 31)
             return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_gap_prep: batch too large (pool offsets are 32-bit), use fewer sites per call");
         n_jobs_total = jb0[nthr];
         run_all([&](int t) {
-            for (ProbalnJob &j : pools[t].jobs) { j.ref_off += (uint32_t)r0[t]; j.query_off += (uint32_t)q0[t]; }
+            for (ProbalnJob &j : pools[t].jobs) j.ref_off += (uint32_t)r0[t];
             for (int is = cut(t); is < cut(t + 1); ++is) {
                 SiteState &S = st[is];
                 if (!S.live) continue;
@@ -385,7 +373,15 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
     // ---- device: forward scores of every job
     std::vector<int32_t> sc1, sc2;
     if (n_jobs_total) {
-        const int rc = bcfgpu_internal_run_probaln(ctx, pools, max_bw, sc1, sc2);
+        size_t nbase = 0;
+        bool any_zq = false;
+        for (int r = 0; r < rd->n_reads; ++r) {
+            const size_t e = (size_t)rd->r_seq_off[r] + rd->r_lq[r];
+            if (e > nbase) nbase = e;
+            if (rd->r_has_zq && rd->r_has_zq[r] && rd->zq) any_zq = true;
+        }
+        if (nbase >> 32) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_gap_prep: read pool too large (32-bit offsets)");
+        const int rc = bcfgpu_internal_run_probaln(ctx, pools, max_bw, rd, nbase, any_zq, sc1, sc2);
         if (rc) return rc;
         gs.n_jobs = n_jobs_total;
         size_t j = 0;

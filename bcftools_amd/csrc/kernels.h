@@ -76,20 +76,20 @@ struct McallParams {
 };
 
 // one realignment job of bcf_call_gap_prep: probaln_glocal(ref2+ref_off, l_ref, query+query_off, l_query, qq+query_off, {.., bw})
-struct ProbalnJob { uint32_t ref_off, query_off; int32_t l_ref, l_query, bw; };
+struct ProbalnJob { uint32_t ref_off, query_off; int32_t l_ref, l_query, bw, flags; };   // query_off: into the reads' seq16/qual pools; flags&1: ZQ present
 struct ProbalnParams {
     int n_jobs, ncell;              // ncell: scratch cells per row (>= 3*(2*bw+1)+6 for the widest band)
     int force_scratch;              // diagnostics (BCFGPU_ABLATE & 256): every job through the rolling-row version
     size_t scratch_stride;          // jobs rounded up; scratch is [2][ncell][stride] doubles
     const ProbalnJob *jobs;
-    const uint8_t *ref2, *query, *qq;
+    const uint8_t *ref2, *query, *qq, *zq;   // consensus windows (0..4 codes); the reads' seq16 / qual / ZQ pools as the caller holds them
     const float *q2p;               // 10^(-q/10) as float, q = 0..255 (htslib g_qual2prob)
     double *scratch;
     int32_t *score1, *score2;       // sc<<8 | norm, bam2bcf_indel.c:348-356
 };
 void launch_probaln(const ProbalnParams &p, hipStream_t s);
 // host-side job pools of bcfgpu_gap_prep, one per preparing thread; offsets inside a pool are pool-relative until rebased
-struct ProbalnPools { std::vector<ProbalnJob> jobs; std::vector<uint8_t> ref2pool, qpool, qqpool; int max_bw = 0; };
+struct ProbalnPools { std::vector<ProbalnJob> jobs; std::vector<uint8_t> ref2pool; int max_bw = 0; };
 
 size_t glfgen_lds_bytes(int cap, int hist_slots);
 void launch_glfgen(const GlfgenParams &p, hipStream_t s);
