@@ -264,7 +264,8 @@ int  bcfgpu_pipeline(bcfgpu_ctx *ctx, const bcfgpu_tile *tile, const uint8_t *pl
  * Candidate typing, the per-sample consensus and the insertion consensus are small irregular host work and run on
  * the CPU inside this call; the realignment of every read against every candidate type (probaln_glocal, "the
  * bottleneck", bam2bcf_indel.c:335) runs on the device for the whole batch; indelQ/seqQ and the choice of the <=4
- * output types are finished on the host.  All pointers here are HOST pointers.
+ * output types are finished on the host (the host parts run on up to 16 threads over contiguous chunks of sites; the
+ * environment variable BCFGPU_HOST_THREADS overrides the count).  All pointers here are HOST pointers.
  * Reads are a flat pool: r_* arrays indexed by read, cig/seq16/qual/zq pools indexed through r_cig_off / r_seq_off
  * (seq16: one 4-bit nt16 code per byte; qual: the qualities the pileup sees; zq: "ZQ" tag bytes, r_has_zq flags).
  * Pileup entries of (site k, sample s): smpl_off[k*n_smpl+s] .. smpl_off[k*n_smpl+s+1]-1 into p_read/p_qpos/p_indel. */
