@@ -188,3 +188,28 @@ def indel_batch(seed, n_sites, n_smpl, depth=30.0, read_len=100, max_depth=200):
                  zq=np.zeros(R * read_len, dtype=np.uint8), r_has_zq=np.zeros(R, dtype=np.uint8))
     return dict(ref=bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[ref2]), reads=reads, pos=pos, smpl_off=i32(off),
                 p_read=i32(np.arange(R)), p_qpos=i32(qpos), p_indel=i32(ilen), itype=itype, n_sites=n_sites, n_smpl=S)
+
+
+def indel_tile_from_batch(b, aux, ret, mapq=60):
+    """The indel pass of mpileup (mpileup.c:354-365) for the columns of an indel_batch() where bcf_call_gap_prep
+    returned 0: the same pileup entries as a tile with ref_base = -1 and aux = p->aux."""
+    S = b["n_smpl"]
+    R = b["reads"]
+    live = np.nonzero(np.asarray(ret) == 0)[0]
+    so = b["smpl_off"].astype(np.int64)
+    cells = (live[:, None] * S + np.arange(S)[None, :]).ravel()
+    beg, end = so[cells], so[cells + 1]
+    n = end - beg
+    off = np.zeros(len(cells) + 1, dtype=np.int64)
+    np.cumsum(n, out=off[1:])
+    e = np.repeat(beg - off[:-1], n) + np.arange(int(off[-1]))            # pileup entries, column-major
+    r, qpos = b["p_read"][e].astype(np.int64), b["p_qpos"][e].astype(np.int64)
+    lq = R["r_lq"][r].astype(np.int64)
+    at = R["r_seq_off"][r].astype(np.int64) + qpos
+    tail = np.minimum(np.minimum(qpos, lq - 1 - qpos), 255)
+    rd = (R["qual"][at].astype(np.int64) | (mapq << 8) | (R["seq16"][at].astype(np.int64) << 16)
+          | ((R["r_flag"][r].astype(np.int64) >> 4 & 1) << 20) | (tail << 24)).astype(np.uint32)
+    # no soft clips in these reads: the aligned length is the read length (bam2bcf.c:80-114)
+    epos = ((qpos + 1).astype(np.float64) / (lq + 1) * 100).astype(np.uint8)
+    return host.HostTile(S, np.zeros(len(live), dtype=np.int8), off.astype(np.uint32), rd, epos,
+                         aux=np.asarray(aux, dtype=np.uint32)[e], is_indel=1), live

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 from bcftools_amd import abi, synth
-from tests.helpers import indeldrv
+from tests.helpers import indeldrv, orc
+from tests.test_gpu_parity import EXACT_SITE, FLOAT_SITE
 
 pytestmark = pytest.mark.gpu
 
@@ -27,3 +28,39 @@ def test_batched_gap_prep_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth
         live += want is not None
     assert live > 0
     assert st.n_jobs > 0 and st.n_passes >= st.n_jobs and st.dp_cells > 0 and st.kernel_ms > 0
+
+
+@pytest.mark.parametrize("n_sites,n_smpl,depth,seed", [(24, 40, 15.0, 51), (10, 200, 25.0, 52)])
+def test_indel_records_match_oracle(gpu_ctx_factory, n_sites, n_smpl, depth, seed):
+    """The whole indel record path on synthetic columns: bcfgpu_gap_prep -> p->aux -> the indel pass of
+    glfgen/combine (ref_base = -1), against the oracle running the same two steps."""
+    b = synth.indel_batch(seed, n_sites, n_smpl, depth=depth)
+    fmt = abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD
+    gctx = gpu_ctx_factory(abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=64))
+    got, _ = indeldrv.gap_prep_gpu(gctx, b)
+    aux_w, ret_w = np.zeros_like(got["aux"]), np.full(n_sites, -1, np.int32)
+    for k in range(n_sites):
+        w = indeldrv.gap_prep_oracle_site(b, k)
+        if w is not None:
+            aux_w[w["e0"]:w["e1"]] = w["aux"]
+            ret_w[k] = 0
+    np.testing.assert_array_equal(got["ret"], ret_w)
+    tile_g, live = synth.indel_tile_from_batch(b, got["aux"], got["ret"])
+    tile_w, _ = synth.indel_tile_from_batch(b, aux_w, ret_w)
+    np.testing.assert_array_equal(tile_g.aux, tile_w.aux)
+    assert len(live) > 0
+    cfg = abi.default_cfg(n_smpl, max_sites=len(live), max_reads=len(tile_g.rd), fmt_flag=fmt)
+    want = orc.mpileup(cfg, tile_w)
+    res = gpu_ctx_factory(cfg).mpileup(tile_g)
+    np.testing.assert_array_equal(res.site["ret"], want.site["ret"])
+    ok = want.site["ret"] == 0
+    assert ok.any()
+    for k in EXACT_SITE:
+        np.testing.assert_array_equal(res.site[k][ok], want.site[k][ok], err_msg="site." + k)
+    for k in ["pl", "dp4", "adf", "adr"]:
+        np.testing.assert_array_equal(getattr(res, k)[ok], getattr(want, k)[ok], err_msg=k)
+    for k in FLOAT_SITE:
+        g, w = res.site[k][ok].astype(np.float64), want.site[k][ok].astype(np.float64)
+        assert np.array_equal(np.isinf(g), np.isinf(w)), k
+        m = ~np.isinf(w)
+        np.testing.assert_allclose(g[m], w[m], rtol=2e-6, atol=1e-30, err_msg="site." + k)
