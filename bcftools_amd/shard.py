@@ -29,3 +29,18 @@ def gather_records(local, dst=0):
     if rank != dst:
         return None
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
+
+
+def gather_buffers(local, dst=0):
+    """Receive buffers for gather_fixed(): one tensor like `local` per rank on `dst`, None elsewhere (allocate once)."""
+    if dist.get_rank() != dst:
+        return None
+    return [torch.empty_like(local) for _ in range(dist.get_world_size())]
+
+
+def gather_fixed(local, bufs, dst=0):
+    """The same exchange when every rank contributes the same number of bytes (equal shards, as in the benchmark):
+    one gather into preallocated buffers, no size exchange and no host synchronisation.  bufs from gather_buffers();
+    on `dst` bufs[r] then holds rank r's records (rank order = site order)."""
+    dist.gather(local, bufs, dst=dst)
+    return bufs

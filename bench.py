@@ -231,12 +231,14 @@ def main():
     cpl = torch.zeros(T * abi.MAX_PL * S, dtype=torch.int32, device=dev)
     co.site, co.gt, co.pl, co.gq, co.gp = csite.data_ptr(), cgt.data_ptr(), cpl.data_ptr(), None, None
 
+    gbufs = shard.gather_buffers(csite, dst=0) if world > 1 else None      # every rank holds T sites: fixed-size gather
+
     def step():
         check(L.bcfgpu_pipeline(ctx.h, C.byref(dt), None, None, C.byref(mo), C.byref(co)))
         if world > 1:
             # ordered gather of the per-site call records (the shards are contiguous regions)
             check(L.bcfgpu_sync(ctx.h))
-            shard.gather_records(csite, dst=0)
+            shard.gather_fixed(csite, gbufs, dst=0)
 
     def fence():
         check(L.bcfgpu_sync(ctx.h))

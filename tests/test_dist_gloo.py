@@ -42,6 +42,15 @@ def _worker(rank, world, port, n_sites, n_smpl, out_path):
     got = shard.gather_records(torch.frombuffer(bytearray(rec), dtype=torch.uint8), dst=0)
     if rank == 0:
         np.save(out_path, got.numpy())
+    # the fixed-size exchange bench.py uses (equal shards, preallocated receive buffers): twice, as consecutive steps do
+    fixed = torch.full((64,), rank + 1, dtype=torch.uint8)
+    bufs = shard.gather_buffers(fixed, dst=0)
+    for it in range(2):
+        fixed.fill_(10 * it + rank + 1)
+        shard.gather_fixed(fixed, bufs, dst=0)
+        if rank == 0:
+            assert [int(b[0]) for b in bufs] == [10 * it + r + 1 for r in range(world)]
+            assert all(bool((b == b[0]).all()) for b in bufs)
     dist.barrier()
     dist.destroy_process_group()
 
