@@ -232,12 +232,15 @@ def main():
     co.site, co.gt, co.pl, co.gq, co.gp = csite.data_ptr(), cgt.data_ptr(), cpl.data_ptr(), None, None
 
     gbufs = shard.gather_buffers(csite, dst=0) if world > 1 else None      # every rank holds T sites: fixed-size gather
+    # the library enqueues on torch's current stream, so the RCCL gather of a step is ordered after that step's kernels and
+    # before the next step's by the streams alone (no host synchronisation inside the timed loop)
+    if world > 1:
+        check(L.bcfgpu_set_stream(ctx.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     def step():
         check(L.bcfgpu_pipeline(ctx.h, C.byref(dt), None, None, C.byref(mo), C.byref(co)))
         if world > 1:
             # ordered gather of the per-site call records (the shards are contiguous regions)
-            check(L.bcfgpu_sync(ctx.h))
             shard.gather_fixed(csite, gbufs, dst=0)
 
     def fence():
