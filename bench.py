@@ -235,7 +235,9 @@ def main():
     # the library enqueues on torch's current stream, so the RCCL gather of a step is ordered after that step's kernels and
     # before the next step's by the streams alone (no host synchronisation inside the timed loop)
     if world > 1:
-        check(L.bcfgpu_set_stream(ctx.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        work_stream = torch.cuda.Stream(device=dev)          # (the default stream has handle 0 = "the library's own stream")
+        torch.cuda.set_stream(work_stream)
+        check(L.bcfgpu_set_stream(ctx.h, C.c_void_p(work_stream.cuda_stream)))
 
     def step():
         check(L.bcfgpu_pipeline(ctx.h, C.byref(dt), None, None, C.byref(mo), C.byref(co)))
