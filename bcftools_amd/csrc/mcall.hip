@@ -225,26 +225,54 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 
             s_gq[tid] = v;
         }
     } else {
-        // group qsum from FORMAT/AD (or QS): qsum[j] += AD[j]/sum in sample order (mcall.c:1478-1503)
+        // group qsum from FORMAT/AD (or QS): qsum[grp][j] += AD[j]/sum in sample order (mcall.c:1478-1503).
+        // 64 samples at a time: every lane normalises one sample (coalesced plane reads), then lane j < 5 adds allele
+        // j's fractions in sample order -- the sequential float32 sum of the reference -- keeping the running sum of
+        // the current group in a register (samples of a group are usually consecutive).
         for (int i = tid; i < ngrp * 5; i += WGS) s_gq[i] = 0;
-        __syncthreads();
-        if (tid < 5 && tid < nals) {
-            const int j = tid;
-            const int nad = P.ad ? P.n_al_max : nals;
-            for (int s = 0; s < S; ++s) {
-                float sum = 0; int myv = MISSING; bool mine_valid = false;
-                for (int k = 0; k < nad; ++k) {
-                    int v;
-                    if (P.ad) v = P.ad[((size_t)is * P.n_al_max + k) * Ss + s];
-                    else if (P.qs_u16) v = k < nals ? (int)P.qs_u16[((size_t)is * 5 + k) * Ss + s] : VEND;
-                    else v = k < nals ? (int)P.ad_u8[((size_t)is * 5 + k) * Ss + s] + (int)P.ad_u8b[((size_t)is * 5 + k) * Ss + s] : VEND;
-                    if (v == VEND) break;
-                    if (v != MISSING) sum += (float)v;
-                    if (k == j) { myv = v; mine_valid = true; }
+        float *s_fr = reinterpret_cast<float*>(s_pdg);              // [5][WGS] fractions of the staged samples
+        int *s_gg = reinterpret_cast<int*>(s_fr + 5 * WGS);         // [WGS] their groups
+        static_assert(FAST || sizeof(double) * NG * WGS >= (5 * WGS) * sizeof(float) + WGS * sizeof(int), "staging fits in s_pdg");
+        const int nad = P.ad ? P.n_al_max : nals;
+        int cur = -1;
+        float acc = 0.f;
+        for (int base = 0; base < S; base += WGS) {
+            const int cn = min(WGS, S - base);
+            __syncthreads();
+            if (tid < cn) {
+                const int s = base + tid;
+                int v[5];
+                float sum = 0;
+                int nvalid = 0;                                   // values before the first vector_end
+                #pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    v[k] = VEND;
+                    if (k < nad && nvalid == k) {
+                        int x;
+                        if (P.ad) x = P.ad[((size_t)is * P.n_al_max + k) * Ss + s];
+                        else if (P.qs_u16) x = k < nals ? (int)P.qs_u16[((size_t)is * 5 + k) * Ss + s] : VEND;
+                        else x = k < nals ? (int)P.ad_u8[((size_t)is * 5 + k) * Ss + s] + (int)P.ad_u8b[((size_t)is * 5 + k) * Ss + s] : VEND;
+                        if (x != VEND) { v[k] = x; nvalid = k + 1; if (x != MISSING) sum += (float)x; }
+                    }
                 }
-                if (sum != 0.f && mine_valid && myv != MISSING) s_gq[P.grp[s] * 5 + j] += (float)myv / sum;
+                #pragma unroll
+                for (int k = 0; k < 5; ++k)                       // +0 where the reference adds nothing
+                    s_fr[k * WGS + tid] = (sum != 0.f && k < nvalid && v[k] != MISSING) ? (float)v[k] / sum : 0.f;
+                s_gg[tid] = P.grp[s];
+            }
+            __syncthreads();
+            if (tid < 5 && tid < nals) {
+                for (int i = 0; i < cn; ++i) {
+                    const int g = s_gg[i];
+                    if (g != cur) {
+                        if (cur >= 0) s_gq[cur * 5 + tid] = acc;
+                        cur = g; acc = s_gq[g * 5 + tid];
+                    }
+                    acc += s_fr[tid * WGS + i];
+                }
             }
         }
+        if (tid < 5 && tid < nals && cur >= 0) s_gq[cur * 5 + tid] = acc;
     }
     __syncthreads();
     // -F AN,AC prior and normalisation: lane g handles group g (mcall.c:1506-1535)

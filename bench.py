@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget on rank 0 at N=1 (0: skip)")
     ap.add_argument("--seed", type=int, default=20260104)
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the CPU baseline on all host cores (0: skip)")
+    ap.add_argument("--groups", type=int, default=1, help="snp mode: call -G with this many sample groups (frequencies from FORMAT/AD); "
+                                                          ">1 takes the general caller path (BASELINE configs[4] shape)")
+    ap.add_argument("--haploid-frac", type=float, default=0.0, help="snp mode: fraction of haploid samples (ploidy array; general caller path)")
     ap.add_argument("--mode", choices=["snp", "indel", "baq"], default="snp",
                     help="snp: the headline pipeline (default).  indel: bcf_call_gap_prep on synthetic indel-candidate columns "
                          "(BASELINE configs[2] shape, 500 samples), reports DP cells/s of the realignment kernel.  "
@@ -216,8 +219,14 @@ def main():
     torch.cuda.synchronize()
     R = tile["n_reads"]
 
-    cfg = abi.default_cfg(S, max_sites=T, max_reads=R, device=local)
+    cfg = abi.default_cfg(S, max_sites=T, max_reads=R, device=local, n_grp=a.groups,
+                          fmt_flag=abi.INFO_VDB | abi.INFO_RPB | (abi.FMT_AD if a.groups > 1 else 0))
     ctx = engine.Context(cfg)
+    d_ploidy = d_grp = None
+    if a.haploid_frac > 0:
+        d_ploidy = torch.where(torch.rand(S, device=dev) < a.haploid_frac, 1, 2).to(torch.uint8)
+    if a.groups > 1:
+        d_grp = (torch.arange(S, device=dev) * a.groups // S).to(torch.int32)
     L = ctx.L
     dt = abi.Tile()
     dt.n_sites, dt.is_indel, dt.n_reads = T, 0, R
@@ -240,7 +249,8 @@ def main():
         check(L.bcfgpu_set_stream(ctx.h, C.c_void_p(work_stream.cuda_stream)))
 
     def step():
-        check(L.bcfgpu_pipeline(ctx.h, C.byref(dt), None, None, C.byref(mo), C.byref(co)))
+        check(L.bcfgpu_pipeline(ctx.h, C.byref(dt), d_ploidy.data_ptr() if d_ploidy is not None else None,
+                                d_grp.data_ptr() if d_grp is not None else None, C.byref(mo), C.byref(co)))
         if world > 1:
             # ordered gather of the per-site call records (the shards are contiguous regions)
             shard.gather_fixed(csite, gbufs, dst=0)
@@ -293,7 +303,8 @@ def main():
             "config": {"workload": "1000-sample 30x synthetic WGS tile (BASELINE configs[3] shape), SNP path: "
                                    "glfgen+errmod -> combine -> call -m, inputs resident in HBM",
                        "samples": S, "depth": a.depth, "sites_per_step_per_gpu": T, "reads_per_tile": R,
-                       "sharding": "contiguous region shard per GPU; ordered gather of call records to rank 0"},
+                       "sharding": "contiguous region shard per GPU; ordered gather of call records to rank 0",
+                       "groups": a.groups, "haploid_frac": a.haploid_frac},
             "roofline": {"bound": "hbm", "kernel": "glfgen_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": tm["glfgen_ms"],
