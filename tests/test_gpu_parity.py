@@ -127,6 +127,32 @@ def test_pipeline_diploid_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth
         np.testing.assert_array_equal(cgot.gq[live], cwant.gq[live])
 
 
+@pytest.mark.parametrize("n_sites,n_smpl,n_grp,seed,use_qs", [(48, 120, 4, 61, False), (32, 1000, 4, 62, False), (40, 33, 33, 63, False),
+                                                              (48, 90, 3, 64, True)])
+def test_pipeline_with_sample_groups_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, n_grp, seed, use_qs):
+    """call -G through the fused pipeline (BASELINE configs[4] shape): group allele frequencies from the mpileup stage's
+    ADF+ADR planes (= FORMAT/AD, bam2bcf.c:892-896) or its QS planes, ploidy array, one group per sample at the extreme."""
+    tile = synth.numpy_tile(seed, n_sites, n_smpl, depth=20.0, var_rate=0.4)
+    fmt = abi.INFO_VDB | abi.INFO_RPB | (abi.FMT_QS if use_qs else abi.FMT_AD)
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), fmt_flag=fmt, n_grp=n_grp)
+    cfg.grp_tag_is_qs = 1 if use_qs else 0
+    rng = np.random.default_rng(seed)
+    ploidy = rng.choice([1, 2, 2], size=n_smpl).astype(np.uint8)
+    grp = (np.arange(n_smpl) * n_grp // n_smpl).astype(np.int32)
+    if n_grp < n_smpl:
+        rng.shuffle(grp)                                       # groups need not be contiguous
+    mwant = orc.mpileup(cfg, tile)
+    src = mwant.qs.astype(np.int32) if use_qs else mwant.adf.astype(np.int32) + mwant.adr.astype(np.int32)
+    na = mwant.site["n_alleles"]
+    ad = np.where(np.arange(5)[None, :, None] < na[:, None, None], src, abi.INT32_VECTOR_END).astype(np.int32)
+    cin = host.CallInput(n_smpl, na, np.maximum(mwant.site["unseen"], 0), mwant.pl.astype(np.int32), mwant.site["qsum"],
+                         ad=ad, ploidy=ploidy, grp=grp)
+    cwant = orc.mcall(cfg, cin)
+    mgot, cgot = gpu_ctx_factory(cfg).pipeline(tile, ploidy=ploidy, grp=grp)
+    assert_mplp_equal(mgot, mwant)
+    assert_call_equal(cgot, cwant, n_smpl)
+
+
 def test_empty_and_zero_depth(gpu_ctx_factory):
     n_smpl = 4
     cfg = abi.default_cfg(n_smpl, max_sites=8, max_reads=64)
