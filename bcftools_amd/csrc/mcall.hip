@@ -71,6 +71,7 @@ struct CallShared {
     int als_map[5]; int pl_map[15];
     int ac[5];
     double max_qual, ref_lk, lk_sum, ref_cur;
+    double red_dip;             // FAST: like red[nsub] but over the samples of ploidy 1 or 2 only (pairs and triples)
     int prior_fail;
 };
 
@@ -160,12 +161,12 @@ __device__ __forceinline__ void write_skipped(bcfgpu_call_site *cs, int ret)
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-// FAST: the diploid, single-group, u8-PL case of the fused pipeline.  The subset scan of find_best_alleles is the
+// FAST: the u8-PL case of the fused pipeline (HAP: with a ploidy array; sample groups in both).  The subset scan of find_best_alleles is the
 // matrix product (subset coefficients [rows] x genotypes [k]) * (genotypes [k] x samples [cols]) and runs on the
 // f64 matrix cores (v_mfma_f64_16x16x4_f64), 16 samples per issue; an extra all-ones row yields each sample's
 // normalisation sum, whose product is divided out at the end.
-template <int MAXA, int NSUB, bool FAST>
-__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 1, FAST ? 4 : 8))) void mcall_kernel(const McallParams P)
+template <int MAXA, int NSUB, bool FAST, bool HAP>
+__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 : !HAP ? 4 : NSUB > 15 ? 1 : 3, !FAST ? 8 : !HAP ? 4 : NSUB > 15 ? 8 : 3))) void mcall_kernel(const McallParams P)
 {
     constexpr int NG = MAXA * (MAXA + 1) / 2;
     constexpr int TILES = NSUB >= 16 ? 2 : 1;     // 16-row tiles of the coefficient matrix (subsets + the sum row)
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 
     //         sum_s log(val_s) = log(prod_s val_s), so each sample costs a multiply + frexp instead of a log()
     // pass 2: the lane's current sample: PLs after set_pdg's in-place fills, genotype posteriors
     // FAST: pass 1 = the coefficient matrix; pass 2 = the lane's PL bytes (u8) and genotype posteriors (f32)
-    constexpr int U1 = FAST ? TILES * 16 * 16 * 8 : NSUB * WGS * 12, U2 = FAST ? NG * WGS * 5 : NG * WGS * 8, UB = U1 > U2 ? U1 : U2;
+    constexpr int U1 = FAST ? TILES * 16 * 16 * 8 * (HAP ? 2 : 1) : NSUB * WGS * 12, U2 = FAST ? NG * WGS * 5 : NG * WGS * 8, UB = U1 > U2 ? U1 : U2;
     __shared__ __align__(8) unsigned char s_union[UB];
     double *s_man = reinterpret_cast<double*>(s_union);
     int    *s_exp = reinterpret_cast<int*>(s_union + NSUB * WGS * 8);
@@ -230,9 +231,9 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 
         // j's fractions in sample order -- the sequential float32 sum of the reference -- keeping the running sum of
         // the current group in a register (samples of a group are usually consecutive).
         for (int i = tid; i < ngrp * 5; i += WGS) s_gq[i] = 0;
-        float *s_fr = reinterpret_cast<float*>(s_pdg);              // [5][WGS] fractions of the staged samples
+        float *s_fr = reinterpret_cast<float*>(s_union);            // [5][WGS] fractions of the staged samples
         int *s_gg = reinterpret_cast<int*>(s_fr + 5 * WGS);         // [WGS] their groups
-        static_assert(FAST || sizeof(double) * NG * WGS >= (5 * WGS) * sizeof(float) + WGS * sizeof(int), "staging fits in s_pdg");
+        static_assert(UB >= (int)((5 * WGS) * sizeof(float) + WGS * sizeof(int)), "staging fits in s_union");
         const int nad = P.ad ? P.n_al_max : nals;
         int cur = -1;
         float acc = 0.f;
@@ -262,13 +263,27 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 
             }
             __syncthreads();
             if (tid < 5 && tid < nals) {
-                for (int i = 0; i < cn; ++i) {
-                    const int g = s_gg[i];
-                    if (g != cur) {
-                        if (cur >= 0) s_gq[cur * 5 + tid] = acc;
-                        cur = g; acc = s_gq[g * 5 + tid];
+                // four samples per LDS read pair, the next four requested while these are added
+                const float4 *fr4 = reinterpret_cast<const float4*>(s_fr + tid * WGS);
+                const int4 *gg4 = reinterpret_cast<const int4*>(s_gg);
+                const int nb = (cn + 3) >> 2;                      // the tail of the last block holds +0 / stale groups: see below
+                float4 fn = fr4[0]; int4 gn = gg4[0];
+                for (int b4 = 0; b4 < nb; ++b4) {
+                    const float4 f = fn; const int4 gv = gn;
+                    if (b4 + 1 < nb) { fn = fr4[b4 + 1]; gn = gg4[b4 + 1]; }
+                    const float fv[4] = {f.x, f.y, f.z, f.w};
+                    const int gs4[4] = {gv.x, gv.y, gv.z, gv.w};
+                    #pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (4 * b4 + k < cn) {
+                            const int g = gs4[k];
+                            if (g != cur) {
+                                if (cur >= 0) s_gq[cur * 5 + tid] = acc;
+                                cur = g; acc = s_gq[g * 5 + tid];
+                            }
+                            acc += fv[k];
+                        }
                     }
-                    acc += s_fr[tid * WGS + i];
                 }
             }
         }
@@ -365,8 +380,12 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 
         int setbits = 0;
         if constexpr (FAST) {
             // ---- subset scan on the matrix cores ----
+            // Rows = subsets (+ an all-ones row for the samples' normalisation sums), columns = samples, k = genotypes.
+            // Haploid samples use a second coefficient matrix (f_a P(aa) + f_b P(bb) [+ f_c P(cc)], mcall.c:643,688);
+            // samples of other groups, of ploidy 0 (pairs/triples only) or without data contribute nothing.
             double *s_coef = reinterpret_cast<double*>(s_union);            // [TILES*16 rows][16 genotypes]
-            for (int i = tid; i < TILES * 256; i += WGS) s_coef[i] = 0.0;
+            double *s_coefh = s_coef + TILES * 256;                         // HAP: the haploid rows
+            for (int i = tid; i < TILES * 256 * (HAP ? 2 : 1); i += WGS) s_coef[i] = 0.0;
             __syncthreads();
             if (tid < nsub) {
                 const Subset &u = sh.sub[tid];
@@ -376,21 +395,36 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 
                     row[u.iaa] = u.fa2; row[u.ibb] = u.fb2; row[u.iab] = u.fab;
                     if (u.ic >= 0) { row[u.icc] = u.fc2; row[u.iac] = u.fac; row[u.ibc] = u.fbc; }
                 }
+                if (HAP) {
+                    double *rh = s_coefh + tid * 16;
+                    rh[u.iaa] = u.fa;
+                    if (u.ib >= 0) rh[u.ibb] = u.fb;
+                    if (u.ic >= 0) rh[u.icc] = u.fc;
+                }
             }
             if (tid < ngts) s_coef[nsub * 16 + tid] = 1.0;                  // the sum row
             __syncthreads();
             const int col = tid & 15, kq = tid >> 4;
-            double a[TILES][4];
+            double a[TILES][4], ah[HAP ? TILES : 1][4];
             #pragma unroll
             for (int t = 0; t < TILES; ++t)
                 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) a[t][kk] = s_coef[(t * 16 + col) * 16 + 4 * kk + kq];
+                for (int kk = 0; kk < 4; ++kk) {
+                    a[t][kk] = s_coef[(t * 16 + col) * 16 + 4 * kk + kq];
+                    if (HAP) ah[t][kk] = s_coefh[(t * 16 + col) * 16 + 4 * kk + kq];
+                }
             // this lane accumulates rows kq + 4r (+16t) over the sample columns col, col+16, ...
             double man[TILES][4]; int ex[TILES][4];
             #pragma unroll
             for (int t = 0; t < TILES; ++t)
                 #pragma unroll
                 for (int r = 0; r < 4; ++r) { man[t][r] = 1.0; ex[t][r] = 0; }
+            double sdm = 1.0; int sde = 0;                                   // HAP: the sum row over ploidy-1/2 samples
+            int singles = 0;                                                // bit t*4+r: a row without ploidy term
+            #pragma unroll
+            for (int t = 0; t < TILES; ++t)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) { const int row = t * 16 + kq + 4 * r; if (row < nals || row == nsub) singles |= 1 << (t * 4 + r); }
             const uint8_t *plb = reinterpret_cast<const uint8_t*>(P.pl) + (size_t)is * BCFGPU_MAX_PL * Ss;
             for (int s0 = 0; s0 < ((P.ablate & 16) ? 0 : S); s0 += 64) {
                 // plane 4kk+kq, samples s0+4col .. +3 as one word; samples past the end read as "no data"
@@ -407,31 +441,59 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 
                     }
                     w[kk] = v;
                 }
+                uint32_t pw = 0x02020202u, gmask = 0xf;                     // ploidy bytes and group membership of the 4 samples
+                if (HAP || ngrp > 1) {
+                    if (rem >= 4) {
+                        if (HAP) __builtin_memcpy(&pw, P.ploidy + sb, 4);
+                        if (ngrp > 1) {
+                            int gv[4];
+                            __builtin_memcpy(gv, P.grp + sb, 16);
+                            gmask = (gv[0] == g ? 1u : 0u) | (gv[1] == g ? 2u : 0u) | (gv[2] == g ? 4u : 0u) | (gv[3] == g ? 8u : 0u);
+                        }
+                    } else {
+                        #pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (j < rem) {
+                                if (HAP) pw = (pw & ~(0xffu << (8 * j))) | (uint32_t)P.ploidy[sb + j] << (8 * j);
+                                if (ngrp > 1 && P.grp[sb + j] != g) gmask &= ~(1u << j);
+                            }
+                    }
+                }
                 // set_pdg: a sample whose PLs are all 0 (sum == n_gt) carries no data and is skipped (mcall.c:529-535)
                 uint32_t any = w[0] | w[1] | w[2] | w[3];
                 any |= __shfl_xor(any, 16);
                 any |= __shfl_xor(any, 32);
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bool has = ((any >> (8 * j)) & 0xff) != 0;
+                    const bool has = ((any >> (8 * j)) & 0xff) != 0 && ((gmask >> j) & 1);
+                    const int pd = (int)((pw >> (8 * j)) & 0xff);
                     double b[4];
                     #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
                         b[kk] = (has && 4 * kk + kq < ngts) ? s_p2[(w[kk] >> (8 * j)) & 0xff] : 0.0;
                     #pragma unroll
                     for (int t = 0; t < TILES; ++t) {
-                        d4_t d = {0., 0., 0., 0.};
+                        d4_t d = {0., 0., 0., 0.}, dh = {0., 0., 0., 0.};
                         #pragma unroll
                         for (int kk = 0; kk < 4; ++kk) d = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][kk], b[kk], d, 0, 0, 0);
+                        if (HAP) {
+                            #pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) dh = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[t][kk], b[kk], dh, 0, 0, 0);
+                        }
                         #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (d[r] != 0.0) { man[t][r] *= d[r]; setbits |= 1 << (t * 4 + r); }
+                        for (int r = 0; r < 4; ++r) {
+                            double v = d[r];
+                            if (HAP && !((singles >> (t * 4 + r)) & 1)) v = pd == 2 ? d[r] : pd == 1 ? dh[r] : 0.0;
+                            if (v != 0.0) { man[t][r] *= v; setbits |= 1 << (t * 4 + r); }
+                            if (HAP && t * 16 + kq + 4 * r == nsub && (pd == 1 || pd == 2) && d[r] != 0.0) sdm *= d[r];
+                        }
                     }
                     if (j & 1) {
                         #pragma unroll
                         for (int t = 0; t < TILES; ++t)
                             #pragma unroll
                             for (int r = 0; r < 4; ++r) { ex[t][r] += frexp_exp(man[t][r]); man[t][r] = frexp_mant(man[t][r]); }
+                        if (HAP) { sde += frexp_exp(sdm); sdm = frexp_mant(sdm); }
                     }
                 }
             }
@@ -455,6 +517,16 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 
                         if (f) rowbits |= 1 << row;
                     }
                 }
+            if (HAP) {
+                double m = sdm; int e = sde;
+                #pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    const double mm = m * __shfl_xor(m, o);
+                    e += __shfl_xor(e, o) + frexp_exp(mm);
+                    m = frexp_mant(mm);
+                }
+                if (col == 0 && kq == (nsub & 3)) sh.red_dip = log(m) + (double)e * 0.693147180559945309417232121458;
+            }
             setbits = rowbits;
         } else {
         for (int t = 0; t < nsub; ++t) { s_man[t * WGS + tid] = 1.0; s_exp[t * WGS + tid] = 0; }
@@ -523,7 +595,8 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 
             if (tid < nsub) {
                 const Subset &u = sh.sub[tid];
                 double v = sh.red[tid];
-                if (FAST) v -= sh.red[nsub];                // divide out the product of the samples' normalisation sums
+                // divide out the product of the normalisation sums of the samples that contributed to this row
+                if (FAST) v -= (HAP && u.ib >= 0) ? sh.red_dip : sh.red[nsub];
                 als = 1 << u.ia;
                 if (u.ib < 0) { if (u.ia != 0) v += theta; }
                 else {
@@ -601,104 +674,42 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 
     // ---- genotypes (mcall_set_ref_genotypes / mcall_call_genotypes) + PL trimming ----
     int ac_loc[5] = {0, 0, 0, 0, 0};
     const int ogt = P.out_n_gt_max;
-    if constexpr (FAST) {
-        // all-diploid, one group, u8 PLs without missing values: set_pdg is a table lookup per byte, so only the PL
-        // bytes are staged (run-time genotype indices) and P(D|G) = pl2p[PL]/sum is formed for the genotypes evaluated
-        const uint8_t *plb = reinterpret_cast<const uint8_t*>(P.pl) + (size_t)is * BCFGPU_MAX_PL * Ss;
-        const int gals = grp_als_tab[0];
-        const float *gq5 = s_gq;
-        for (int s = tid; s < ((P.ablate & 32) ? 0 : S); s += WGS) {
-            double psum = 0;
+    {
+    const uint8_t *plb2 = reinterpret_cast<const uint8_t*>(P.pl) + (size_t)is * BCFGPU_MAX_PL * Ss;
+    for (int s = tid; s < ((P.ablate & 32) ? 0 : S); s += WGS) {
+        const int ploidy = P.ploidy ? P.ploidy[s] : 2;
+        // P(D|G) = raw/psum is formed lazily below, with the same division the reference performs (bit-exact genotypes)
+        double psum = 0;
+        bool allzero = true;
+        if constexpr (FAST) {
+            // u8 PLs of the fused pipeline (no missing values): set_pdg is a table lookup per byte, so only the PL
+            // bytes are staged (run-time genotype indices)
             uint32_t anynz = 0;
             #pragma unroll
             for (int k = 0; k < NG; ++k) {
                 if (k < ngts) {
-                    const uint32_t v = plb[(size_t)k * Ss + s];
+                    const uint32_t v = plb2[(size_t)k * Ss + s];
                     s_plb[k * WGS + tid] = (uint8_t)v;
                     psum += s_p2[v];
                     anynz |= v;
                 }
                 if (want_gqgp) s_gps[k * WGS + tid] = 0.f;
             }
-            const bool allzero = anynz == 0;                 // sum == n_gt: no data (mcall.c:529-535)
-            int g0, g1, gq = 0;
-            if (!is_variant) {
-                if (allzero) g0 = g1 = BCFGPU_GT_MISSING;
-                else { g0 = g1 = 0; ac_loc[0] += 2; }
-            } else {
-                if (allzero) { g0 = g1 = BCFGPU_GT_MISSING; s_gps[tid] = -1; }
-                else {
-                    g0 = 0;
-                    double best_lk = 0;
-                    for (int ia = 0; ia < nals; ++ia) {
-                        if (!(gals & 1 << ia)) continue;
-                        const int iaa = (ia + 1) * (ia + 2) / 2 - 1;
-                        const double p = s_p2[s_plb[iaa * WGS + tid]] / psum;
-                        const double lk = p * gq5[ia] * gq5[ia];
-                        const int am = sh.als_map[ia];
-                        s_gps[a2gt(am, am) * WGS + tid] = (float)lk;
-                        if (best_lk < lk) { best_lk = lk; g0 = am; }
-                    }
-                    g1 = g0;
-                    for (int ia = 1; ia < nals; ++ia) {
-                        if (!(gals & 1 << ia)) continue;
-                        const int iaa = (ia + 1) * (ia + 2) / 2 - 1;
-                        for (int ib = 0; ib < ia; ++ib) {
-                            if (!(gals & 1 << ib)) continue;
-                            const int iab = iaa - ia + ib;
-                            const double lk = 2 * (s_p2[s_plb[iab * WGS + tid]] / psum) * gq5[ia] * gq5[ib];
-                            s_gps[a2gt(sh.als_map[ia], sh.als_map[ib]) * WGS + tid] = (float)lk;
-                            if (best_lk < lk) { best_lk = lk; g0 = sh.als_map[ib]; g1 = sh.als_map[ia]; }
-                        }
-                    }
-                    #pragma unroll
-                    for (int k = 0; k < 5; ++k) { if (g0 == k) ac_loc[k]++; if (g1 == k) ac_loc[k]++; }
-                }
-                if (want_gqgp) {
-                    // mcall.c:842-885
-                    const int nmax = ngts_new;
-                    double mx = s_gps[tid];
-                    if (mx < 0 || nmax == 0) {
-                        if (P.output_tags & BCFGPU_CALL_FMT_GP) for (int k = 0; k < nmax; ++k) s_gps[k * WGS + tid] = 0;
-                        gq = 0;
-                    } else {
-                        double sum = mx;
-                        for (int k = 1; k < nmax; ++k) { const double v = s_gps[k * WGS + tid]; if (mx < v) mx = v; sum += v; }
-                        mx = -4.34294 * log(1 - mx / sum);
-                        gq = mx <= 127 ? (int)mx : 127;
-                        if (P.output_tags & BCFGPU_CALL_FMT_GP)
-                            for (int k = 0; k < nmax; ++k) s_gps[k * WGS + tid] = (float)(s_gps[k * WGS + tid] / sum);
-                    }
-                }
+            allzero = anynz == 0;                            // sum == n_gt: no data (mcall.c:529-535)
+        } else {
+            int pl[NG]; double pdg[NG];
+            load_pl<NG>(P, is, s, ngts, pl);
+            psum = set_pdg_one<NG>(s_pl2p, pl, pdg, ngts, nals, unseen, s_fill + tid);
+            #pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                if (k < ngts && pdg[k] != 0.0) allzero = false;
+                s_pdg[k * WGS + tid] = pdg[k]; s_plc[k * WGS + tid] = pl[k];
+                if (want_gqgp) s_gps[k * WGS + tid] = 0.f;
             }
-            P.out.gt[((size_t)is * 2 + 0) * Ss + s] = (int8_t)g0;
-            P.out.gt[((size_t)is * 2 + 1) * Ss + s] = (int8_t)g1;
-            if (is_variant && want_gqgp) {
-                if ((P.output_tags & BCFGPU_CALL_FMT_GQ) && P.out.gq) P.out.gq[(size_t)is * Ss + s] = gq;
-                if ((P.output_tags & BCFGPU_CALL_FMT_GP) && P.out.gp)
-                    for (int k = 0; k < ngts_new; ++k) P.out.gp[((size_t)is * ogt + k) * Ss + s] = s_gps[k * WGS + tid];
-            }
-            // trimmed PLs (mcall.c:1158-1194)
-            if (!ref_only && P.out.pl) {
-                int32_t *dst = P.out.pl + (size_t)is * ogt * Ss + s;
-                for (int k = 0; k < ngts_new; ++k) dst[(size_t)k * Ss] = (int32_t)s_plb[sh.pl_map[k] * WGS + tid];
-            }
+            if (psum == 0.0) allzero = true;
         }
-    } else {
-    for (int s = tid; s < ((P.ablate & 32) ? 0 : S); s += WGS) {
-        int pl[NG]; double pdg[NG];
-        load_pl<NG>(P, is, s, ngts, pl);
-        const double psum = set_pdg_one<NG>(s_pl2p, pl, pdg, ngts, nals, unseen, s_fill + tid);
-        const int ploidy = P.ploidy ? P.ploidy[s] : 2;
-        // pdg = raw/psum is formed lazily below, with the same division the reference performs (bit-exact genotypes)
-        bool allzero = true;
-        #pragma unroll
-        for (int k = 0; k < NG; ++k) {
-            if (k < ngts && pdg[k] != 0.0) allzero = false;
-            s_pdg[k * WGS + tid] = pdg[k]; s_plc[k * WGS + tid] = pl[k];
-            if (want_gqgp) s_gps[k * WGS + tid] = 0.f;
-        }
-        if (psum == 0.0) allzero = true;
+        auto pdg_at = [&](int i) -> double { if constexpr (FAST) return s_p2[s_plb[i * WGS + tid]]; else return s_pdg[i * WGS + tid]; };
+        auto plc_at = [&](int i) -> int { if constexpr (FAST) return (int)s_plb[i * WGS + tid]; else return s_plc[i * WGS + tid]; };
         int g0, g1, gq = 0, gnals = 0;
         if (!is_variant) {
             if (allzero || !ploidy) { g0 = BCFGPU_GT_MISSING; g1 = ploidy == 2 ? BCFGPU_GT_MISSING : BCFGPU_GT_VECTOR_END; }
@@ -716,7 +727,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 
                 for (int ia = 0; ia < nals; ++ia) {
                     if (!(gals & 1 << ia)) continue;
                     const int iaa = (ia + 1) * (ia + 2) / 2 - 1;
-                    const double p = s_pdg[iaa * WGS + tid] / psum;
+                    const double p = pdg_at(iaa) / psum;
                     const double lk = ploidy == 2 ? p * gq5[ia] * gq5[ia] : p * gq5[ia];
                     const int am = sh.als_map[ia];
                     const int igt = ploidy == 2 ? a2gt(am, am) : am;
@@ -731,7 +742,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 
                         for (int ib = 0; ib < ia; ++ib) {
                             if (!(gals & 1 << ib)) continue;
                             const int iab = iaa - ia + ib;
-                            const double lk = 2 * (s_pdg[iab * WGS + tid] / psum) * gq5[ia] * gq5[ib];
+                            const double lk = 2 * (pdg_at(iab) / psum) * gq5[ia] * gq5[ib];
                             const int igt = a2gt(sh.als_map[ia], sh.als_map[ib]);
                             s_gps[igt * WGS + tid] = (float)lk;
                             if (best_lk < lk) { best_lk = lk; g0 = sh.als_map[ib]; g1 = sh.als_map[ia]; }
@@ -777,10 +788,10 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(FAST ? 4 : 
         if (!ref_only && P.out.pl) {
             int32_t *dst = P.out.pl + (size_t)is * ogt * Ss + s;
             if (ploidy == 2) {
-                for (int k = 0; k < ngts_new; ++k) dst[(size_t)k * Ss] = s_plc[sh.pl_map[k] * WGS + tid];
+                for (int k = 0; k < ngts_new; ++k) dst[(size_t)k * Ss] = plc_at(sh.pl_map[k]);
             } else if (ploidy == 1) {
                 int k;
-                for (k = 0; k < nals_new; ++k) dst[(size_t)k * Ss] = s_plc[sh.pl_map[(k + 1) * (k + 2) / 2 - 1] * WGS + tid];
+                for (k = 0; k < nals_new; ++k) dst[(size_t)k * Ss] = plc_at(sh.pl_map[(k + 1) * (k + 2) / 2 - 1]);
                 if (k < ngts_new) dst[(size_t)k * Ss] = VEND;
             } else {
                 dst[0] = MISSING;
@@ -820,14 +831,21 @@ void launch_mcall(const McallParams &p, hipStream_t s)
     if (p.n_sites == 0) return;
     const int ngrp = p.n_grp > 1 ? p.n_grp : 1;
     const size_t lds = (size_t)ngrp * 5 * sizeof(float) + (size_t)ngrp * 2 * sizeof(int);
-    if (p.pl_is_u8 && !p.ploidy && ngrp == 1 && !(p.ablate & 64)) {
-        hipLaunchKernelGGL((mcall_kernel<3, 7, true>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-        hipLaunchKernelGGL((mcall_kernel<5, 15, true>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-        hipLaunchKernelGGL((mcall_kernel<5, 25, true>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+    if (p.pl_is_u8 && !(p.ablate & 64)) {
+        // u8 PLs (the fused pipeline): subset scan on the matrix cores; the haploid coefficient set only with a ploidy array
+        if (p.ploidy) {
+            hipLaunchKernelGGL((mcall_kernel<3, 7, true, true>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+            hipLaunchKernelGGL((mcall_kernel<5, 15, true, true>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+            hipLaunchKernelGGL((mcall_kernel<5, 25, true, true>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+        } else {
+            hipLaunchKernelGGL((mcall_kernel<3, 7, true, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+            hipLaunchKernelGGL((mcall_kernel<5, 15, true, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+            hipLaunchKernelGGL((mcall_kernel<5, 25, true, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+        }
     } else {
-        hipLaunchKernelGGL((mcall_kernel<3, 7, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-        hipLaunchKernelGGL((mcall_kernel<5, 15, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-        hipLaunchKernelGGL((mcall_kernel<5, 25, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+        hipLaunchKernelGGL((mcall_kernel<3, 7, false, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+        hipLaunchKernelGGL((mcall_kernel<5, 15, false, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+        hipLaunchKernelGGL((mcall_kernel<5, 25, false, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
     }
 }
 

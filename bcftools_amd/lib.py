@@ -36,6 +36,13 @@ def load():
         if not os.path.exists(SO_PATH):
             raise ImportError("%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(there is no CPU fallback for the hot path)" % SO_PATH)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64; if torch is imported after this library has
+        # pulled in the system runtime, torch's device initialisation fails (hipErrorNoDevice).  Importing torch first
+        # makes both use the copy torch loads.  Without torch (a plain C caller, smoke) nothing changes.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(SO_PATH)
         for name, (res, args) in abi.PROTOTYPES.items():
             fn = getattr(L, name)          # AttributeError here = the library does not export a declared symbol
