@@ -220,3 +220,20 @@ def test_indel_pass_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, seed):
         assert np.array_equal(np.isinf(g), np.isinf(w)), k
         m = ~np.isinf(w)
         np.testing.assert_allclose(g[m], w[m], rtol=2e-6, atol=1e-30, err_msg=k)
+
+
+def test_library_and_torch_share_one_hip_runtime():
+    """PyTorch ships its own libamdhip64: the binding imports torch before dlopen()ing libbcfgpu.so, so a process can
+    create a context first and touch torch's device afterwards (the order the unit tests use when run one file at a time)."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from bcftools_amd import abi, engine\n"
+            "ctx = engine.Context(abi.default_cfg(4, max_sites=8, max_reads=64))\n"
+            "import torch\n"
+            "x = torch.ones(8, device='cuda').sum().item()\n"
+            "ctx.close()\n"
+            "print('ok', x)\n")
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
+    assert p.returncode == 0 and "ok 8.0" in p.stdout, p.stderr[-2000:]
