@@ -66,6 +66,7 @@ struct CallShared {
     int nsub;                   // subsets visited for the current group
     Subset sub[25];
     double red[32];             // reduced log-likelihood sums, indexed like sub[] (FAST: + the sum row at [nsub])
+    int rede[32];               // FAST: binary exponents of the row products before the logarithm
     int redset;
     int als_new, nals_new, is_variant, early;
     int als_map[5]; int pl_map[15];
@@ -165,7 +166,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // matrix product (subset coefficients [rows] x genotypes [k]) * (genotypes [k] x samples [cols]) and runs on the
 // f64 matrix cores (v_mfma_f64_16x16x4_f64), 16 samples per issue; an extra all-ones row yields each sample's
 // normalisation sum, whose product is divided out at the end.
-template <int MAXA, int NSUB, bool FAST, bool HAP>
+template <int MAXA, int NSUB, bool FAST, bool HAP, bool GRP>
 __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 : !HAP ? 4 : NSUB > 15 ? 1 : 3, !FAST ? 8 : !HAP ? 4 : NSUB > 15 ? 8 : 3))) void mcall_kernel(const McallParams P)
 {
     constexpr int NG = MAXA * (MAXA + 1) / 2;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     const int is = blockIdx.x;
     const int S = P.n_smpl;
     const size_t Ss = (size_t)S;
-    const int ngrp = P.n_grp > 1 ? P.n_grp : 1;
+    const int ngrp = GRP ? (P.n_grp > 1 ? P.n_grp : 1) : 1;         // GRP = false: launched only for a single group
     bcfgpu_call_site *cs = &P.out.site[is];
 
     int nals, unseen;
@@ -427,22 +428,10 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                 for (int r = 0; r < 4; ++r) { const int row = t * 16 + kq + 4 * r; if (row < nals || row == nsub) singles |= 1 << (t * 4 + r); }
             const uint8_t *plb = reinterpret_cast<const uint8_t*>(P.pl) + (size_t)is * BCFGPU_MAX_PL * Ss;
             for (int s0 = 0; s0 < ((P.ablate & 16) ? 0 : S); s0 += 64) {
-                // plane 4kk+kq, samples s0+4col .. +3 as one word; samples past the end read as "no data"
-                uint32_t w[4];
                 const int sb = s0 + 4 * col, rem = S - sb;
-                #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = 4 * kk + kq;
-                    uint32_t v = 0;
-                    if (k < ngts && rem > 0) {
-                        const uint8_t *src = plb + (size_t)k * Ss + sb;
-                        if (rem >= 4) __builtin_memcpy(&v, src, 4);
-                        else { v = src[0]; if (rem > 1) v |= (uint32_t)src[1] << 8; if (rem > 2) v |= (uint32_t)src[2] << 16; }
-                    }
-                    w[kk] = v;
-                }
                 uint32_t pw = 0x02020202u, gmask = 0xf;                     // ploidy bytes and group membership of the 4 samples
-                if (HAP || ngrp > 1) {
+                if (rem <= 0) gmask = 0;
+                else if (HAP || ngrp > 1) {
                     if (rem >= 4) {
                         if (HAP) __builtin_memcpy(&pw, P.ploidy + sb, 4);
                         if (ngrp > 1) {
@@ -458,6 +447,20 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                                 if (ngrp > 1 && P.grp[sb + j] != g) gmask &= ~(1u << j);
                             }
                     }
+                }
+                if (ngrp > 1 && !__any(gmask != 0)) continue;          // no sample of this group among these 64
+                // plane 4kk+kq, samples s0+4col .. +3 as one word; samples past the end read as "no data"
+                uint32_t w[4];
+                #pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = 4 * kk + kq;
+                    uint32_t v = 0;
+                    if (k < ngts && rem > 0) {
+                        const uint8_t *src = plb + (size_t)k * Ss + sb;
+                        if (rem >= 4) __builtin_memcpy(&v, src, 4);
+                        else { v = src[0]; if (rem > 1) v |= (uint32_t)src[1] << 8; if (rem > 2) v |= (uint32_t)src[2] << 16; }
+                    }
+                    w[kk] = v;
                 }
                 // set_pdg: a sample whose PLs are all 0 (sum == n_gt) carries no data and is skipped (mcall.c:529-535)
                 uint32_t any = w[0] | w[1] | w[2] | w[3];
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                     }
                     const int row = t * 16 + kq + 4 * r;
                     if (col == 0 && row <= nsub) {
-                        sh.red[row] = log(m) + (double)e * 0.693147180559945309417232121458;
+                        sh.red[row] = m; sh.rede[row] = e;          // log taken below, one row per lane
                         if (f) rowbits |= 1 << row;
                     }
                 }
@@ -525,8 +528,12 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                     e += __shfl_xor(e, o) + frexp_exp(mm);
                     m = frexp_mant(mm);
                 }
-                if (col == 0 && kq == (nsub & 3)) sh.red_dip = log(m) + (double)e * 0.693147180559945309417232121458;
+                if (col == 0 && kq == (nsub & 3)) { sh.red[31] = m; sh.rede[31] = e; }      // (at most 26 rows are in use)
             }
+            __syncthreads();
+            if (tid <= nsub || (HAP && tid == 31)) sh.red[tid] = log(sh.red[tid]) + (double)sh.rede[tid] * 0.693147180559945309417232121458;
+            __syncthreads();
+            if (HAP && tid == 0) sh.red_dip = sh.red[31];
             setbits = rowbits;
         } else {
         for (int t = 0; t < nsub; ++t) { s_man[t * WGS + tid] = 1.0; s_exp[t * WGS + tid] = 0; }
@@ -677,7 +684,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     {
     const uint8_t *plb2 = reinterpret_cast<const uint8_t*>(P.pl) + (size_t)is * BCFGPU_MAX_PL * Ss;
     for (int s = tid; s < ((P.ablate & 32) ? 0 : S); s += WGS) {
-        const int ploidy = P.ploidy ? P.ploidy[s] : 2;
+        const int ploidy = (FAST && !HAP) ? 2 : (P.ploidy ? P.ploidy[s] : 2);    // FAST without HAP is launched only without a ploidy array
         // P(D|G) = raw/psum is formed lazily below, with the same division the reference performs (bit-exact genotypes)
         double psum = 0;
         bool allzero = true;
@@ -831,22 +838,20 @@ void launch_mcall(const McallParams &p, hipStream_t s)
     if (p.n_sites == 0) return;
     const int ngrp = p.n_grp > 1 ? p.n_grp : 1;
     const size_t lds = (size_t)ngrp * 5 * sizeof(float) + (size_t)ngrp * 2 * sizeof(int);
+    #define MCALL_LAUNCH3(FAST_, HAP_, GRP_) do { \
+        hipLaunchKernelGGL((mcall_kernel<3, 7, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \
+        hipLaunchKernelGGL((mcall_kernel<5, 15, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \
+        hipLaunchKernelGGL((mcall_kernel<5, 25, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); } while (0)
     if (p.pl_is_u8 && !(p.ablate & 64)) {
-        // u8 PLs (the fused pipeline): subset scan on the matrix cores; the haploid coefficient set only with a ploidy array
-        if (p.ploidy) {
-            hipLaunchKernelGGL((mcall_kernel<3, 7, true, true>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-            hipLaunchKernelGGL((mcall_kernel<5, 15, true, true>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-            hipLaunchKernelGGL((mcall_kernel<5, 25, true, true>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-        } else {
-            hipLaunchKernelGGL((mcall_kernel<3, 7, true, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-            hipLaunchKernelGGL((mcall_kernel<5, 15, true, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-            hipLaunchKernelGGL((mcall_kernel<5, 25, true, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-        }
+        // u8 PLs (the fused pipeline): subset scan on the matrix cores; the haploid coefficient set only with a ploidy
+        // array, the group handling only with more than one group
+        if (p.ploidy) MCALL_LAUNCH3(true, true, true);
+        else if (ngrp > 1) MCALL_LAUNCH3(true, false, true);
+        else MCALL_LAUNCH3(true, false, false);
     } else {
-        hipLaunchKernelGGL((mcall_kernel<3, 7, false, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-        hipLaunchKernelGGL((mcall_kernel<5, 15, false, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
-        hipLaunchKernelGGL((mcall_kernel<5, 25, false, false>), dim3(p.n_sites), dim3(WGS), lds, s, p);
+        MCALL_LAUNCH3(false, false, true);
     }
+    #undef MCALL_LAUNCH3
 }
 
 }  // namespace bcfgpu
