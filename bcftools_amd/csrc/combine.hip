@@ -92,24 +92,27 @@ __device__ float dev_calc_vdb(const int *pos)
     return (float)(0.5 * dev_kf_erfc(-(double)((mean_diff - pshift) * pscale)));
 }
 
-// calc_mwu_bias, bam2bcf.c:440-484
-__device__ float dev_calc_mwu_bias(const int *a, const int *b, int n, const double *mw)
+// calc_mwu_bias, bam2bcf.c:440-484.  The loop over the bins (bam2bcf.c:445-465) is summed by the wavefront, two bins
+// per lane: U = sum_i a_i * (nb_before_i + b_i / 2) has only integer and half-integer terms far below 2^53, so the
+// double sum is exact in any order; the int product of the b_i == 0 branch is kept as the reference writes it.
+__device__ __forceinline__ void dev_mwu_sums(const int *a, const int *b, int n, int lane, int &na, int &nb, double &U)
 {
-    int na = 0, nb = 0, i;
-    double U = 0;
-    for (i = 0; i < n; i++) {
-        if (!a[i]) {
-            if (!b[i]) continue;
-            nb += b[i];
-        } else if (!b[i]) {
-            na += a[i];
-            U += (double)(a[i] * nb);
-        } else {
-            na += a[i];
-            U += a[i] * (nb + b[i] * 0.5);
-            nb += b[i];
-        }
-    }
+    const int i0 = 2 * lane, i1 = i0 + 1;
+    const int a0 = i0 < n ? a[i0] : 0, b0 = i0 < n ? b[i0] : 0, a1 = i1 < n ? a[i1] : 0, b1 = i1 < n ? b[i1] : 0;
+    int incl = b0 + b1;
+    #pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    const int nb0 = incl - (b0 + b1), nb1 = nb0 + b0;       // reads of b before bin i0 / i1
+    double u = 0;
+    if (a0) u += b0 ? a0 * (nb0 + b0 * 0.5) : (double)(a0 * nb0);
+    if (a1) u += b1 ? a1 * (nb1 + b1 * 0.5) : (double)(a1 * nb1);
+    int as = a0 + a1;
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { as += __shfl_xor(as, o); u += __shfl_xor(u, o); }
+    na = as; nb = __shfl(incl, 63); U = u;
+}
+__device__ float dev_mwu_tail(int na, int nb, double U, const double *mw)
+{
     if (!na || !nb) return HUGE_VALF;
     if (na == 1 || nb == 1) return 1.0f;
     double mean = ((double)na * nb) * 0.5;
@@ -176,57 +179,104 @@ struct SampleTotals { uint32_t adf[5], adr[5], scr, ori, mq0, cnt[4]; };
 // The per-sample outputs of bcf_call_combine for one chunk of samples of a site with NAL alleles (NAL = 0: a dead indel
 // site, totals only): PL from the NAL(NAL+1)/2 genotype likelihoods in allele order (bam2bcf.c:634-651), DP4, AD/ADF/ADR,
 // QS, SCR planes, per-lane integer totals, and each sample's minimum for the sequential sum_min.
-template <int NAL>
+// V = 4: a lane takes four consecutive samples, so that every plane is read with 16-byte loads and the u8 planes are
+// written four bytes at a time (the caller checks that n_smpl and the plane addresses allow it); V = 1 otherwise.
+template <int V, class T4> __device__ __forceinline__ void load_v(const T4 *p, T4 (&d)[V])
+{
+    if constexpr (V == 4) { const uint4 u = *reinterpret_cast<const uint4*>(p); __builtin_memcpy(d, &u, 16); }
+    else d[0] = p[0];
+}
+template <int V> __device__ __forceinline__ void store_bytes(uint8_t *p, const uint32_t (&b)[V])
+{
+    if constexpr (V == 4) *reinterpret_cast<uint32_t*>(p) = b[0] | b[1] << 8 | b[2] << 16 | b[3] << 24;
+    else p[0] = (uint8_t)b[0];
+}
+template <int NAL, int V>
 __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTotals &T, const int (&gs)[15], const int (&as)[5],
                                               int is, long c0, int base, int cn, int tid, long ncells, float *s_min)
 {
     constexpr int X = NAL * (NAL + 1) / 2;
     const size_t Ss = (size_t)P.n_smpl;
-    for (int i = tid; i < cn; i += WG) {
+    for (int i = tid * V; i < cn; i += WG * V) {
         const int s = base + i;
         const long cell = c0 + s;
-        float mn = 0.f;
+        float mn[V];
+        #pragma unroll
+        for (int v = 0; v < V; ++v) mn[v] = 0.f;
         if (NAL > 0) {
-            float pv[X > 0 ? X : 1];
-            mn = FLT_MAX;
+            float pv[X > 0 ? X : 1][V];
             #pragma unroll
-            for (int j = 0; j < X; ++j) { pv[j] = (P.cr.p15 + (size_t)gs[j] * ncells + c0)[s]; if (mn > pv[j]) mn = pv[j]; }
+            for (int v = 0; v < V; ++v) mn[v] = FLT_MAX;
+            #pragma unroll
+            for (int j = 0; j < X; ++j) {
+                load_v<V>(P.cr.p15 + (size_t)gs[j] * ncells + c0 + s, pv[j]);
+                #pragma unroll
+                for (int v = 0; v < V; ++v) if (mn[v] > pv[j][v]) mn[v] = pv[j][v];
+            }
             uint8_t *PL = P.out.pl + (size_t)is * BCFGPU_MAX_PL * Ss + s;
             #pragma unroll
             for (int j = 0; j < X; ++j) {
-                int y = (int)((double)(pv[j] - mn) + .499);
-                if (y > 255) y = 255;
-                PL[(size_t)j * Ss] = (uint8_t)y;
+                uint32_t yb[V];
+                #pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    int y = (int)((double)(pv[j][v] - mn[v]) + .499);
+                    if (y > 255) y = 255;
+                    yb[v] = (uint32_t)y;
+                }
+                store_bytes<V>(PL + (size_t)j * Ss, yb);
             }
         }
-        s_min[i] = mn;
-        const uint32_t cnt4 = P.cr.cnt4[cell], adf = P.cr.adf[cell], adr = P.cr.adr[cell], misc = P.cr.misc[cell];
+        #pragma unroll
+        for (int v = 0; v < V; ++v) s_min[i + v] = mn[v];
+        uint32_t cnt4[V], adf[V], adr[V], misc[V];
+        load_v<V>(P.cr.cnt4 + cell, cnt4); load_v<V>(P.cr.adf + cell, adf); load_v<V>(P.cr.adr + cell, adr); load_v<V>(P.cr.misc + cell, misc);
         if (NAL > 0 && !(P.ablate & 512)) {
             uint8_t *DP4 = P.out.dp4 + (size_t)is * 4 * Ss + s;
+            uint32_t b[V];
             #pragma unroll
-            for (int j = 0; j < 4; ++j) DP4[(size_t)j * Ss] = (uint8_t)((cnt4 >> (8 * j)) & 0xff);
-            const uint32_t scr = (misc >> 8) & 0xff;
-            if (P.out.scr) P.out.scr[(size_t)is * Ss + s] = (uint8_t)scr;
-            T.scr += scr;
-            unsigned long long qs64 = 0;
-            if (P.out.qs) qs64 = P.cr.qs64[cell];
+            for (int j = 0; j < 4; ++j) {
+                #pragma unroll
+                for (int v = 0; v < V; ++v) b[v] = (cnt4[v] >> (8 * j)) & 0xff;
+                store_bytes<V>(DP4 + (size_t)j * Ss, b);
+            }
+            #pragma unroll
+            for (int v = 0; v < V; ++v) { b[v] = (misc[v] >> 8) & 0xff; T.scr += b[v]; }
+            if (P.out.scr) store_bytes<V>(P.out.scr + (size_t)is * Ss + s, b);
+            unsigned long long qs64[V];
+            #pragma unroll
+            for (int v = 0; v < V; ++v) qs64[v] = P.out.qs ? P.cr.qs64[cell + v] : 0ull;
             #pragma unroll
             for (int j = 0; j < NAL; ++j) {
                 const int aj = as[j];                         // scalar
-                const uint32_t vf = aj < 4 ? (adf >> (8 * aj)) & 0xff : 0;
-                const uint32_t vr = aj < 4 ? (adr >> (8 * aj)) & 0xff : 0;
-                T.adf[j] += vf; T.adr[j] += vr;
-                if (P.out.adf) P.out.adf[((size_t)is * 5 + j) * Ss + s] = (uint8_t)vf;
-                if (P.out.adr) P.out.adr[((size_t)is * 5 + j) * Ss + s] = (uint8_t)vr;
-                if (P.out.qs) P.out.qs[((size_t)is * 5 + j) * Ss + s] = (uint16_t)(aj < 4 ? (qs64 >> (16 * aj)) & 0xffff : 0);
+                uint32_t vf[V], vr[V];
+                #pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    vf[v] = aj < 4 ? (adf[v] >> (8 * aj)) & 0xff : 0;
+                    vr[v] = aj < 4 ? (adr[v] >> (8 * aj)) & 0xff : 0;
+                    T.adf[j] += vf[v]; T.adr[j] += vr[v];
+                }
+                if (P.out.adf) store_bytes<V>(P.out.adf + ((size_t)is * 5 + j) * Ss + s, vf);
+                if (P.out.adr) store_bytes<V>(P.out.adr + ((size_t)is * 5 + j) * Ss + s, vr);
+                if (P.out.qs) {
+                    uint16_t q[V];
+                    #pragma unroll
+                    for (int v = 0; v < V; ++v) q[v] = (uint16_t)(aj < 4 ? (qs64[v] >> (16 * aj)) & 0xffff : 0);
+                    uint16_t *dst = P.out.qs + ((size_t)is * 5 + j) * Ss + s;
+                    if constexpr (V == 4) { uint2 u; __builtin_memcpy(&u, q, 8); *reinterpret_cast<uint2*>(dst) = u; }
+                    else dst[0] = q[0];
+                }
             }
         }
-        T.ori += misc >> 16; T.mq0 += misc & 0xff;
         #pragma unroll
-        for (int j = 0; j < 4; ++j) T.cnt[j] += (cnt4 >> (8 * j)) & 0xff;
+        for (int v = 0; v < V; ++v) {
+            T.ori += misc[v] >> 16; T.mq0 += misc[v] & 0xff;
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) T.cnt[j] += (cnt4[v] >> (8 * j)) & 0xff;
+        }
     }
 }
 
+template <int V>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void combine_kernel(const CombineParams P)
 {
     __shared__ SiteShared sh;
@@ -327,14 +377,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const int cn = min(CHUNK, S - base);
         __syncthreads();
         const bool live = !dead && !(P.ablate & 256);
-        switch (live ? nal : 0) {
-            case 1: sample_planes<1>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break;
-            case 2: sample_planes<2>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break;
-            case 3: sample_planes<3>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break;
-            case 4: sample_planes<4>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break;
-            case 5: sample_planes<5>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break;
-            default: sample_planes<0>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break;
-        }
+        #define PLANES(V_) switch (live ? nal : 0) { \
+            case 1: sample_planes<1, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; \
+            case 2: sample_planes<2, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; \
+            case 3: sample_planes<3, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; \
+            case 4: sample_planes<4, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; \
+            case 5: sample_planes<5, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; \
+            default: sample_planes<0, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; }
+        PLANES(V)
+        #undef PLANES
         __syncthreads();
         if (tid == 0 && !dead && !(P.ablate & 8192)) sh.sum_min = seq_sum_f64(sh.sum_min, s_min, cn);   // bam2bcf.c:642
     }
@@ -394,11 +445,18 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     __syncthreads();
     if (!dead && !(P.ablate & 4096)) {
         const int *h = s_h;
+        // the four Mann-Whitney tests: bin sums by the whole wavefront, the closed forms in lanes 1..4; lane 0 the VDB
+        int na_t = 0, nb_t = 0; double U_t = 0;
+        #pragma unroll
+        for (int t = 1; t < 5; ++t) {
+            const int *ha = h + (t == 1 ? H_REF_POS : t == 2 ? H_REF_MQ : t == 3 ? H_REF_BQ : H_FWD_MQS);
+            const int *hb = h + (t == 1 ? H_ALT_POS : t == 2 ? H_ALT_MQ : t == 3 ? H_ALT_BQ : H_REV_MQS);
+            int na, nb; double U;
+            dev_mwu_sums(ha, hb, t == 1 ? BCFGPU_NPOS : BCFGPU_NQUAL, lane, na, nb, U);
+            if (tid == t) { na_t = na; nb_t = nb; U_t = U; }
+        }
+        if (tid >= 1 && tid < 5) sh.bias[tid] = (tid == 1 && !(P.fmt_flag & BCFGPU_INFO_RPB)) ? 0.f : dev_mwu_tail(na_t, nb_t, U_t, P.mw);
         if (tid == 0) sh.bias[0] = (P.fmt_flag & BCFGPU_INFO_VDB) ? dev_calc_vdb(h + H_ALT_POS) : 0.f;
-        if (tid == 1) sh.bias[1] = (P.fmt_flag & BCFGPU_INFO_RPB) ? dev_calc_mwu_bias(h + H_REF_POS, h + H_ALT_POS, BCFGPU_NPOS, P.mw) : 0.f;
-        if (tid == 2) sh.bias[2] = dev_calc_mwu_bias(h + H_REF_MQ, h + H_ALT_MQ, BCFGPU_NQUAL, P.mw);
-        if (tid == 3) sh.bias[3] = dev_calc_mwu_bias(h + H_REF_BQ, h + H_ALT_BQ, BCFGPU_NQUAL, P.mw);
-        if (tid == 4) sh.bias[4] = dev_calc_mwu_bias(h + H_FWD_MQS, h + H_REV_MQS, BCFGPU_NQUAL, P.mw);
     }
     __syncthreads();
 
@@ -430,7 +488,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 void launch_combine(const CombineParams &p, hipStream_t s)
 {
     if (p.n_sites == 0) return;
-    hipLaunchKernelGGL(combine_kernel, dim3(p.n_sites), dim3(WG), 0, s, p);
+    CombineParams q = p;
+    // four samples per lane need every site's row of every plane to start on a 16-byte (u8 planes: 4-byte) boundary
+    auto al = [](const void *ptr, uintptr_t a) { return ptr == nullptr || reinterpret_cast<uintptr_t>(ptr) % a == 0; };
+    q.vec4 = (p.n_smpl % 4 == 0) && !(p.ablate & 1024) &&
+             al(p.cr.p15, 16) && al(p.cr.cnt4, 16) && al(p.cr.adf, 16) && al(p.cr.adr, 16) && al(p.cr.misc, 16) && al(p.cr.qs64, 8) &&
+             al(p.out.pl, 4) && al(p.out.dp4, 4) && al(p.out.scr, 4) && al(p.out.adf, 4) && al(p.out.adr, 4) && al(p.out.qs, 8);
+    if (q.vec4) hipLaunchKernelGGL(combine_kernel<4>, dim3(q.n_sites), dim3(WG), 0, s, q);
+    else hipLaunchKernelGGL(combine_kernel<1>, dim3(q.n_sites), dim3(WG), 0, s, q);
 }
 
 }  // namespace bcfgpu

@@ -93,7 +93,7 @@ __device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t qm, const
     int rem = 0, pend = 0, pleft = left, r = 0;              // r: next slot pair (= rank of the next quality)
     uint32_t rev = 0, cc = 0, w0 = 0, w1 = 0;
     const char *bbase = reinterpret_cast<const char*>(beta);
-    const uint32_t brow = (uint32_t)n << 11;                  // byte offset of beta[0][n][0]; the table is 32 MiB
+    const uint32_t brow = (uint32_t)n << 3;                   // byte offset of beta[0][0][n] (stored q, k, n: tables.cpp); 32 MiB
     uint32_t boff = brow;
     double bs = 0;
     // Loads are issued unconditionally (inactive lanes read a valid dummy) and their results never cross a divergent
@@ -118,7 +118,7 @@ __device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t qm, const
         two_nx = SLOT_PAIR(r);                                       /* for the next advance */ \
         { \
             const uint32_t act = pleft > 0 ? 1u : 0u; \
-            bv = *reinterpret_cast<const double*>(bbase + (boff + (act ? cc << 3 : 0u))); \
+            bv = *reinterpret_cast<const double*>(bbase + (boff + (act ? cc << 11 : 0u))); \
             fv = s_fk[act ? (rev ? w1 : w0) : 0u]; \
             cc += act; w1 += act & rev; w0 += act & (rev ^ 1u); rem -= (int)act; pleft -= (int)act; \
         } } while (0)

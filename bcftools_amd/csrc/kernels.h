@@ -51,6 +51,7 @@ struct CombineParams {
     const unsigned long long *site_sums;   // [n_sites][12] from glfgen_kernel
     const double *mw;               // [6][6][50]
     int ablate;                     // diagnostics only (BCFGPU_ABLATE)
+    int vec4;                       // set by launch_combine: n_smpl % 4 == 0 and all planes 16-byte aligned
     bcfgpu_mplp_out out;
 };
 

@@ -1,9 +1,10 @@
 // tables.cpp -- host-side construction of the constant tables the kernels gather from.
 //
 //   errmod tables (fk, beta, lhet): the coefficients of htslib's errmod_init(), which
-//   bcf_call_init() builds with depcorr = 1 - theta (bam2bcf.c:51).  beta is indexed
-//   q<<16 | n<<8 | k exactly as errmod_cal() indexes it, so the device gather uses the
-//   same integer arithmetic as the reference.
+//   bcf_call_init() builds with depcorr = 1 - theta (bam2bcf.c:51).  errmod_cal() indexes beta as
+//   q<<16 | n<<8 | k; the device copy is stored q<<16 | k<<8 | n (depth fastest): the lanes of a wavefront walk
+//   their reads in lock step, so at one step they share k (and mostly q) and differ in the depth n of their
+//   cells -- with n fastest a gather touches a couple of cache lines instead of one per lane.
 //   pl2p: call_init_pl2p (mcall.c:56-61).
 //   mw:   the Mann-Whitney table of mw.h, rebuilt by its own generating recursion
 //         (mw.h:32-37), used by calc_mwu_bias (bam2bcf.c:483).
@@ -34,11 +35,11 @@ void build_errmod_tables(double depcorr, std::vector<double> &fk, std::vector<do
         const double e = std::pow(10.0, -q / 10.0);
         const double le = std::log(e), le1 = std::log(1.0 - e);
         for (int n = 1; n <= 255; ++n) {
-            double *b = &beta[(size_t)q << 16 | n << 8];
+            double *b = &beta[(size_t)q << 16 | n];
             long double sum = 0.0L, sum1 = 0.0L;
             for (int k = n; k >= 0; --k, sum1 = sum) {
                 sum = sum1 + expl(lC[n << 8 | k] + k * le + (n - k) * le1);
-                b[k] = -10. / M_LN10 * logl(sum1 / sum);
+                b[(size_t)k << 8] = -10. / M_LN10 * logl(sum1 / sum);
             }
         }
     }

@@ -1,0 +1,6 @@
+# usage: bash tools/ablate_kernel.sh <kernel-name> mask ...   -- time of one kernel with parts switched off (BCFGPU_ABLATE)
+k=$1; shift
+for a in "$@"; do
+  BCFGPU_ABLATE=$a python bench.py --steps 6 --warmup 2 --cpu-seconds 0 --cpu-all-cores 0 > gpurun_out/abl_$a.log 2>&1 || { echo fail $a; tail -3 gpurun_out/abl_$a.log; }
+  echo "ablate $a: $(grep -o "\"$k\": [0-9.]*" gpurun_out/abl_$a.log | head -1)"
+done
