@@ -439,8 +439,24 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
 }
 
 // device half of bcfgpu_gap_prep (indel_host.hip): upload the job pools, run probaln_kernel, download the scores
+// The reads' base / quality (/ZQ) pools go up as the caller holds them (the kernel converts nt16 codes and caps the
+// qualities).  They do not depend on the host-side typing, so bcfgpu_gap_prep starts this on a helper thread first and
+// the copies overlap the typing; the copies are queued on the context's stream, ahead of the kernel.
+int bcfgpu_internal_upload_reads(bcfgpu_ctx *c, const bcfgpu_reads *rd, size_t nq, bool any_zq)
+{
+    hipSetDevice(c->cfg.device);
+    void *d_q = bcfgpu_internal_ws(c, 2, nq + 16), *d_qq = bcfgpu_internal_ws(c, 3, nq + 16);
+    void *d_zq = any_zq ? bcfgpu_internal_ws(c, 7, nq + 16) : nullptr;
+    if (!d_q || !d_qq || (any_zq && !d_zq)) return set_err(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
+    hipError_t e = hipMemcpyAsync(d_q, rd->seq16, nq, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_qq, rd->qual, nq, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && any_zq) e = hipMemcpyAsync(d_zq, rd->zq, nq, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) return set_err(BCFGPU_E_HIP, "bcfgpu_gap_prep: read pool upload", e);
+    return 0;
+}
+
 int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnPools> &pools, int max_bw,
-                                const bcfgpu_reads *rd, size_t nq, bool any_zq,
+                                size_t nq, bool any_zq,
                                 std::vector<int32_t> &score1, std::vector<int32_t> &score2)
 {
     hipSetDevice(c->cfg.device);
@@ -465,17 +481,14 @@ int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnPools> &
     d_s2 = bcfgpu_internal_ws(c, 6, nj * 4);
     if (any_zq) d_zq = bcfgpu_internal_ws(c, 7, nq + 16);
     if (!d_jobs || !d_ref2 || !d_q || !d_qq || !d_scr || !d_s1 || !d_s2 || (any_zq && !d_zq)) return set_err(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
-    {   // the job pools are already rebased to their place in the concatenation: uploaded segment by segment;
-        // the reads' base / quality (/ZQ) pools go up as the caller holds them and are converted by the kernel
+    {   // the job pools are already rebased to their place in the concatenation: uploaded segment by segment
+        // (the reads' pools are in place: bcfgpu_internal_upload_reads)
         size_t oj = 0, orf = 0;
         for (const ProbalnPools &pl : pools) {
             if (!pl.jobs.empty()) GP_CHK(hipMemcpyAsync((ProbalnJob*)d_jobs + oj, pl.jobs.data(), pl.jobs.size() * sizeof(ProbalnJob), hipMemcpyHostToDevice, c->stream));
             if (!pl.ref2pool.empty()) GP_CHK(hipMemcpyAsync((uint8_t*)d_ref2 + orf, pl.ref2pool.data(), pl.ref2pool.size(), hipMemcpyHostToDevice, c->stream));
             oj += pl.jobs.size(); orf += pl.ref2pool.size();
         }
-        GP_CHK(hipMemcpyAsync(d_q, rd->seq16, nq, hipMemcpyHostToDevice, c->stream));
-        GP_CHK(hipMemcpyAsync(d_qq, rd->qual, nq, hipMemcpyHostToDevice, c->stream));
-        if (any_zq) GP_CHK(hipMemcpyAsync(d_zq, rd->zq, nq, hipMemcpyHostToDevice, c->stream));
     }
     p.ref2 = (const uint8_t*)d_ref2; p.query = (const uint8_t*)d_q; p.qq = (const uint8_t*)d_qq; p.zq = (const uint8_t*)d_zq;
     p.q2p = c->d_q2p; p.scratch = (double*)d_scr;

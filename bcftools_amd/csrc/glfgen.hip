@@ -49,6 +49,9 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 #define LDS_FK   0
 #define LDS_CNT  2112
 #define NSLOT    16
+#ifndef WSTEP
+#define WSTEP    3         // reads of one (quality, strand) run taken per step of the errmod walk
+#endif
 #define LDS_RD   (LDS_CNT + (NSLOT / 4) * WG * 4)
 
 // packed "other" (non-primary = diff) read: baseQ:8 | mapQ(capped):6 | q:6 | b:4 | rev:1 | min_dist:5
@@ -83,8 +86,9 @@ __device__ __forceinline__ void fill_slots(uint32_t *s_slot, uint64_t qm, int ti
 // slot, taking the next set bit at every other step; a lane with more than NSLOT/2 distinct qualities refills its
 // slots from the source for the remaining ones (binned base qualities give a handful).  `n` selects the beta row of
 // the lane, `left` is the number of reads of this base.
-// The state machine runs two reads ahead of the summation: the beta value (a gather from a 32 MB table, L2 latency)
-// and the fk factor (LDS) of read t+2 are requested before read t is added, in the reference's order.
+// The state machine runs one step (one or two reads of a run) ahead of the summation: the beta values (gathers from a
+// 32 MB table, L2 latency) and the fk factors (LDS) of the next step are requested before the current ones are added,
+// in the reference's order.
 template <class Src>
 __device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t qm, const double *s_fk,
                                             const double *beta, int tid, int n, int left, Src src, int nsrc)
@@ -100,7 +104,7 @@ __device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t qm, const
     // join, so that three gathers stay in flight; the (divergent) state update carries no memory results.
     #define SLOT_PAIR(i) (s_slot[(((i) & (NSLOT / 2 - 1)) >> 1) * WG + tid])      /* the dword holding pair i */
     uint32_t two_nx = SLOT_PAIR(0);
-    #define WALK_PRODUCE(bv, fv) do { \
+    #define WALK_PRODUCE(B, F, N) do { \
         if (pleft > 0 && rem == 0) { \
             if (pend > 0) { rev = 0; rem = pend; pend = 0; }         /* the forward-strand reads of the same quality */ \
             else { \
@@ -117,19 +121,29 @@ __device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t qm, const
         } \
         two_nx = SLOT_PAIR(r);                                       /* for the next advance */ \
         { \
-            const uint32_t act = pleft > 0 ? 1u : 0u; \
-            bv = *reinterpret_cast<const double*>(bbase + (boff + (act ? cc << 11 : 0u))); \
-            fv = s_fk[act ? (rev ? w1 : w0) : 0u]; \
-            cc += act; w1 += act & rev; w0 += act & (rev ^ 1u); rem -= (int)act; pleft -= (int)act; \
+            /* one step takes the next read and, inside a run of equal (quality, strand), up to WSTEP - 1 more */ \
+            const uint32_t na_ = pleft > 0 ? (uint32_t)min(rem, WSTEP) : 0u; \
+            const uint32_t o0 = boff + (cc << 11); \
+            const uint32_t wi = rev ? w1 : w0; \
+            _Pragma("unroll") \
+            for (int k_ = 0; k_ < WSTEP; ++k_) { \
+                const bool a_ = (uint32_t)k_ < na_; \
+                B[k_] = *reinterpret_cast<const double*>(bbase + (a_ ? o0 + ((uint32_t)k_ << 11) : boff)); \
+                F[k_] = s_fk[a_ ? wi + (uint32_t)k_ : 0u]; \
+            } \
+            N = na_; \
+            cc += na_; w1 += rev ? na_ : 0u; w0 += rev ? 0u : na_; rem -= (int)na_; pleft -= (int)na_; \
         } } while (0)
-    #define WALK_CONSUME(bv, fv) do { const double t_ = fv * bv; const bool a_ = left > 0; bs = a_ ? bs + t_ : bs; left -= a_ ? 1 : 0; } while (0)
-    double bx, fx, by, fy, bz, fz;
-    WALK_PRODUCE(bx, fx);
-    WALK_PRODUCE(by, fy);
+    #define WALK_CONSUME(B, F, N) do { \
+        _Pragma("unroll") \
+        for (int k_ = 0; k_ < WSTEP; ++k_) { const double t_ = F[k_] * B[k_]; bs = (uint32_t)k_ < N ? bs + t_ : bs; } \
+        left -= (int)N; } while (0)
+    double bx[WSTEP], fx[WSTEP], by[WSTEP], fy[WSTEP];
+    uint32_t nx, ny;
+    WALK_PRODUCE(bx, fx, nx);
     while (__any(left > 0)) {
-        WALK_PRODUCE(bz, fz); WALK_CONSUME(bx, fx);
-        WALK_PRODUCE(bx, fx); WALK_CONSUME(by, fy);
-        WALK_PRODUCE(by, fy); WALK_CONSUME(bz, fz);
+        WALK_PRODUCE(by, fy, ny); WALK_CONSUME(bx, fx, nx);
+        WALK_PRODUCE(bx, fx, nx); WALK_CONSUME(by, fy, ny);
     }
     #undef WALK_PRODUCE
     #undef WALK_CONSUME
@@ -193,12 +207,16 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
         const uint32_t ebase = base & ~15u;                      // 16-byte aligned start of the u8 stream
         const uint32_t lim = min(abase + (uint32_t)cap, span_end);
         {
-            // all loads of a batch are in flight before the first LDS store: one memory round trip per 8 (4) vectors
+            // All loads of a batch -- eight 16-byte vectors of rd and two of epos per lane, which covers a whole span at
+            // the usual LDS capacity -- are in flight before the first LDS store: one memory round trip per batch.
             const uint32_t nvec = (lim - abase + 3) >> 2;
+            const uint32_t nv16 = want_epos ? (lim - ebase + 15) >> 4 : 0;
             const uint4 *src = reinterpret_cast<const uint4*>(P.rd + abase);
+            const uint4 *es = reinterpret_cast<const uint4*>(P.epos + ebase);
             uint4 *dst = reinterpret_cast<uint4*>(s_rd);
-            for (uint32_t v0 = tid; v0 < nvec; v0 += 8 * WG) {
-                uint4 r[8];
+            uint4 *ed = reinterpret_cast<uint4*>(s_ep);
+            for (uint32_t v0 = tid, w0 = tid; v0 < nvec || w0 < nv16; v0 += 8 * WG, w0 += 2 * WG) {
+                uint4 r[8], e[2];
                 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const uint32_t v = v0 + k * WG;
@@ -213,31 +231,23 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
                     }
                 }
                 #pragma unroll
-                for (int k = 0; k < 8; ++k) { const uint32_t v = v0 + k * WG; if (v < nvec) dst[v] = r[k]; }
-            }
-            if (want_epos) {
-                const uint32_t nv16 = (lim - ebase + 15) >> 4;
-                const uint4 *es = reinterpret_cast<const uint4*>(P.epos + ebase);
-                uint4 *ed = reinterpret_cast<uint4*>(s_ep);
-                for (uint32_t v0 = tid; v0 < nv16; v0 += 4 * WG) {
-                    uint4 r[4];
-                    #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const uint32_t v = v0 + k * WG;
-                        r[k] = make_uint4(0, 0, 0, 0);
-                        if (v < nv16) {
-                            if (ebase + 16 * v + 15 < n_reads_tot) r[k] = es[v];
-                            else {
-                                uint32_t t4[4] = {0, 0, 0, 0};
-                                for (int j = 0; j < 16; ++j)
-                                    if (ebase + 16 * v + j < n_reads_tot) t4[j >> 2] |= (uint32_t)P.epos[ebase + 16 * v + j] << (8 * (j & 3));
-                                r[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-                            }
+                for (int k = 0; k < 2; ++k) {
+                    const uint32_t v = w0 + k * WG;
+                    e[k] = make_uint4(0, 0, 0, 0);
+                    if (v < nv16) {
+                        if (ebase + 16 * v + 15 < n_reads_tot) e[k] = es[v];
+                        else {
+                            uint32_t t4[4] = {0, 0, 0, 0};
+                            for (int j = 0; j < 16; ++j)
+                                if (ebase + 16 * v + j < n_reads_tot) t4[j >> 2] |= (uint32_t)P.epos[ebase + 16 * v + j] << (8 * (j & 3));
+                            e[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
                         }
                     }
-                    #pragma unroll
-                    for (int k = 0; k < 4; ++k) { const uint32_t v = v0 + k * WG; if (v < nv16) ed[v] = r[k]; }
                 }
+                #pragma unroll
+                for (int k = 0; k < 8; ++k) { const uint32_t v = v0 + k * WG; if (v < nvec) dst[v] = r[k]; }
+                #pragma unroll
+                for (int k = 0; k < 2; ++k) { const uint32_t v = w0 + k * WG; if (v < nv16) ed[v] = e[k]; }
             }
         }
         if (tid == 0) s_next = 0xffffffffu;

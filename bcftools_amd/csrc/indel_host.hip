@@ -21,8 +21,9 @@
 using namespace bcfgpu;
 
 // provided by api.hip
+extern "C" int bcfgpu_internal_upload_reads(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, size_t nbase, bool any_zq);
 extern "C" int bcfgpu_internal_run_probaln(bcfgpu_ctx *ctx, const std::vector<ProbalnPools> &pools, int max_bw,
-                                           const bcfgpu_reads *rd, size_t nbase, bool any_zq,
+                                           size_t nbase, bool any_zq,
                                            std::vector<int32_t> &score1, std::vector<int32_t> &score2);
 int bcfgpu_set_error(int code, const char *what);
 extern "C" bcfgpu_gap_stats *bcfgpu_internal_gap_stats(bcfgpu_ctx *ctx);
@@ -111,6 +112,19 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
     auto ms_since = [](std::chrono::steady_clock::time_point t0) {
         return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     std::vector<SiteState> st(in->n_sites);
+    // The reads' base/quality pools do not depend on the typing below: a helper thread sends them to the device
+    // meanwhile (pageable host memory: the copies occupy the calling thread).
+    size_t nbase = 0;
+    bool any_zq = false;
+    for (int r = 0; r < rd->n_reads; ++r) {
+        const size_t e = (size_t)rd->r_seq_off[r] + rd->r_lq[r];
+        if (e > nbase) nbase = e;
+        if (rd->r_has_zq && rd->r_has_zq[r] && rd->zq) any_zq = true;
+    }
+    if (nbase >> 32) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_gap_prep: read pool too large (32-bit offsets)");
+    int upload_rc = 0;
+    std::thread uploader([&]() { if (nbase) upload_rc = bcfgpu_internal_upload_reads(ctx, rd, nbase, any_zq); });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};
     // Sites are independent: contiguous chunks of sites are prepared by host threads into their own job pools, which
     // are then concatenated in site order (job and pool offsets rebased).
     typedef ProbalnPools Pools;
@@ -373,17 +387,14 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
     // ---- device: forward scores of every job
     std::vector<int32_t> sc1, sc2;
     if (n_jobs_total) {
-        size_t nbase = 0;
-        bool any_zq = false;
-        for (int r = 0; r < rd->n_reads; ++r) {
-            const size_t e = (size_t)rd->r_seq_off[r] + rd->r_lq[r];
-            if (e > nbase) nbase = e;
-            if (rd->r_has_zq && rd->r_has_zq[r] && rd->zq) any_zq = true;
-        }
-        if (nbase >> 32) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_gap_prep: read pool too large (32-bit offsets)");
-        const int rc = bcfgpu_internal_run_probaln(ctx, pools, max_bw, rd, nbase, any_zq, sc1, sc2);
+        const bool trace = getenv("BCFGPU_TRACE") != nullptr;               // diagnostics: host timeline on stderr
+        uploader.join();
+        if (upload_rc) return bcfgpu_set_error(upload_rc, "bcfgpu_gap_prep: read pool upload failed");
+        if (trace) fprintf(stderr, "[gap_prep] prepare %.2f ms, read pools on device at %.2f ms\n", gs.prepare_ms, ms_since(t_begin));
+        const int rc = bcfgpu_internal_run_probaln(ctx, pools, max_bw, nbase, any_zq, sc1, sc2);
         if (rc) return rc;
         gs.n_jobs = n_jobs_total;
+        if (trace) fprintf(stderr, "[gap_prep] scores back at %.2f ms (kernel %.2f ms)\n", ms_since(t_begin), gs.kernel_ms);
         size_t j = 0;
         for (const Pools &pl : pools)
             for (const ProbalnJob &jb : pl.jobs) {
@@ -398,6 +409,7 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
             }
     }
     pools.clear();
+    if (getenv("BCFGPU_TRACE")) fprintf(stderr, "[gap_prep] finalize starts at %.2f ms\n", ms_since(t_begin));
     const auto t_fin = std::chrono::steady_clock::now();
 
     // ---- finalize (:372-469): per site, independent -> the same host threads
