@@ -321,7 +321,7 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
             if (want_scr) scr += (wz >> 21) & 1;
             t_bqmd += (uint32_t)baseQ | (uint32_t)min_dist << 16;
             t_mq += mapQ;
-            t_bq2 += baseQ * baseQ; t_mq2 += mapQ * mapQ; t_md2 += min_dist * min_dist;
+            t_bq2 += __umul24(baseQ, baseQ); t_mq2 += __umul24(mapQ, mapQ); t_md2 += __umul24(min_dist, min_dist);   // all < 256
             const int ibq = min(baseQ, 59);
             const int imq = min(mapQ, 59);
             const bool isref = (nt == ref_base);
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
                 const uint32_t baseQ = ow & 0xff, mapQ = (ow >> 8) & 0x3f, md = ow >> 25;
                 d_bqmd += baseQ | md << 16;
                 d_mq += mapQ;
-                d_bq2 += baseQ * baseQ; d_mq2 += mapQ * mapQ; d_md2 += md * md;
+                d_bq2 += __umul24(baseQ, baseQ); d_mq2 += __umul24(mapQ, mapQ); d_md2 += __umul24(md, md);
                 const uint32_t rev = (ow >> 24) & 1;
                 d_rev += rev; d_fwd += 1 - rev;
                 const uint32_t ob = (ow >> 20) & 0xf, oq = (ow >> 14) & 0x3f;
