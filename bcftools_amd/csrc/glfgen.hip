@@ -187,6 +187,11 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
         if (!INDEL) { ref_base = P.ref16[site]; ref4 = nt16_int(ref_base); }
     }
     const int primary = INDEL ? 0 : ref4;             // the base whose reads are counted on the fly
+    uint32_t prim_nt = 0;                             // SNP: the nt16 codes that show it (code 0 stands for the reference base)
+    if (!INDEL) {
+        #pragma unroll
+        for (int c = 0; c < 16; ++c) if (nt16_int(c ? c : ref_base) == primary) prim_nt |= 1u << c;
+    }
     int *ghist = P.hist + (long)site * H_SIZE;
     int *lhist = s_hist + (site - site0) * H_SIZE;
     const bool want_epos = (P.fmt_flag & (BCFGPU_INFO_RPB | BCFGPU_INFO_VDB)) != 0;
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
                 ok = !(w & BCFGPU_RD_SKIP);
                 ori_depth += ok;
             } else {
-                b = nt16_int(nt ? nt : ref_base);
+                b = 0;                                // SNP: looked up below, only for the reads that need it
                 baseQ = q = (int)(w & 0xff);
                 seqQ = 99;
                 const bool seen = !(w & (BCFGPU_RD_SKIP | BCFGPU_RD_DEL));
@@ -313,7 +318,9 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
             n_rev += rev;
             const int min_dist = min((int)(wz >> 24), CAP_DIST);
             const uint32_t key = (uint32_t)(q << 1) | rev;       // (code>>4)&0x7f of bam2bcf.c:203
-            const bool prim = ok && (b == primary);
+            // SNP: bit c of prim_nt says whether a read showing nt16 code c carries the primary base (one bit-field
+            // extract instead of the nt16 -> 0..4 lookup; the lookup itself is left to the few non-primary reads)
+            const bool prim = ok && (INDEL ? b == primary : ((prim_nt >> nt) & 1u) != 0);
             // reads of the primary base: quality mask, QS and strand count (the other bases' come from their stored words)
             qmask |= (uint64_t)(prim ? 1u : 0u) << q;
             qs_prim += prim ? (uint32_t)q : 0u;
@@ -335,6 +342,7 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
             s_ep[ebeg + n_prim] = (uint8_t)key;
             n_prim += prim ? 1 : 0;
             if (!prim) {
+                if (!INDEL) b = nt16_int(nt ? nt : ref_base);
                 s_rd[lbeg + n_other] = OW_PACK(baseQ, mapQ, q, b, rev, min_dist);    // n_other <= i: behind the reader
                 ++n_other;
             }
