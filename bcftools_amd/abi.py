@@ -60,7 +60,7 @@ class Site(C.Structure):
 class MplpOut(C.Structure):
     _fields_ = [
         ("site", C.c_void_p), ("pl", C.c_void_p), ("dp4", C.c_void_p),
-        ("adf", C.c_void_p), ("adr", C.c_void_p), ("qs", C.c_void_p), ("scr", C.c_void_p),
+        ("adf", C.c_void_p), ("adr", C.c_void_p), ("qs", C.c_void_p), ("scr", C.c_void_p), ("sp", C.c_void_p),
     ]
 
 

@@ -258,7 +258,7 @@ size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *c, int n_sites, int which)
         case 2: return n * 4 * S;
         case 3: case 4: return n * 5 * S;
         case 5: return n * 5 * S * 2;
-        case 6: return n * S;
+        case 6: case 7: return n * S;
     }
     return 0;
 }

@@ -100,7 +100,7 @@ class Context:
     def alloc_mplp_out(self, n_sites):
         S = self.cfg.n_smpl
         res = host.MplpResult(n_sites, S)
-        names = ["site", "pl", "dp4", "adf", "adr", "qs", "scr"]
+        names = ["site", "pl", "dp4", "adf", "adr", "qs", "scr", "sp"]
         bufs = {k: self.buf(getattr(res, k).nbytes) for k in names}
         o = abi.MplpOut()
         for k in names:

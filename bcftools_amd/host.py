@@ -77,11 +77,12 @@ class MplpResult:
         self.adr = np.zeros((n_sites, 5, n_smpl), dtype=np.uint8)
         self.qs = np.zeros((n_sites, 5, n_smpl), dtype=np.uint16)
         self.scr = np.zeros((n_sites, n_smpl), dtype=np.uint8)
+        self.sp = np.zeros((n_sites, n_smpl), dtype=np.uint8)
 
     def as_struct(self):
         o = abi.MplpOut()
-        o.site, o.pl, o.dp4, o.adf, o.adr, o.qs, o.scr = (_p(self.site), _p(self.pl), _p(self.dp4), _p(self.adf),
-                                                           _p(self.adr), _p(self.qs), _p(self.scr))
+        o.site, o.pl, o.dp4, o.adf, o.adr, o.qs, o.scr, o.sp = (_p(self.site), _p(self.pl), _p(self.dp4), _p(self.adf),
+                                                                 _p(self.adr), _p(self.qs), _p(self.scr), _p(self.sp))
         return o
 
     def pl_of(self, isite):

@@ -165,6 +165,7 @@ typedef struct {
  *      adf/adr[site][5][n_smpl]              u8   ADF/ADR in *allele order* (bam2bcf.c:668-697); first n_alleles planes valid
  *      qs [site][5][n_smpl]                  u16  FMT/QS in allele order (bam2bcf.c:698-712)
  *      scr[site][n_smpl]                     u8   SCR[1+i]
+ *      sp [site][n_smpl]                     u8   FMT/SP: Phred-scaled two-sided Fisher exact test of DP4 (bam2bcf.c:867-885)
  */
 typedef struct {
     bcfgpu_site *site;        /* [n_sites] */
@@ -173,6 +174,7 @@ typedef struct {
     uint8_t  *adf, *adr;      /* may be NULL when no AD-type flag is set */
     uint16_t *qs;             /* may be NULL unless BCFGPU_FMT_QS or grouped calling on QS */
     uint8_t  *scr;            /* may be NULL unless an SCR flag is set */
+    uint8_t  *sp;             /* may be NULL unless BCFGPU_FMT_SP is set */
 } bcfgpu_mplp_out;
 
 /* input of the call stage when it is used on its own (e.g. on records parsed
@@ -320,7 +322,7 @@ typedef struct {
 int  bcfgpu_gap_prep_stats(const bcfgpu_ctx *ctx, bcfgpu_gap_stats *out);
 
 /* byte sizes of the output planes for a tile of n_sites (n_smpl from the context) */
-size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *ctx, int n_sites, int which /*0 site,1 pl,2 dp4,3 adf,4 adr,5 qs,6 scr*/);
+size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *ctx, int n_sites, int which /*0 site,1 pl,2 dp4,3 adf,4 adr,5 qs,6 scr,7 sp*/);
 
 /* timing of the last launches (ms, measured with HIP events on the stream the kernels ran on) */
 typedef struct { float glfgen_ms, combine_ms, mcall_ms, total_ms; } bcfgpu_timing;

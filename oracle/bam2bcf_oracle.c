@@ -309,6 +309,10 @@ static int combine(const bcfgpu_cfg *cfg, int n, const orc_callret *calls, const
             DP4[2*S+i] = (uint8_t)(int) calls[i].anno[2];
             DP4[3*S+i] = (uint8_t)(int) calls[i].anno[3];
         }
+        /* FMT/SP: what bcf_call2bcf derives from DP4 (bam2bcf.c:867-885) */
+        if (out->sp && (cfg->fmt_flag & BCFGPU_FMT_SP))
+            for (i = 0; i < n; i++)
+                out->sp[(size_t)is*S + i] = (uint8_t) orc_format_sp(DP4[0*S+i], DP4[1*S+i], DP4[2*S+i], DP4[3*S+i]);
         for (i = 0; i < n; i++) {
             call->scr_tot += calls[i].SCR;
             if (out->scr) out->scr[(size_t)is*S + i] = (uint8_t) calls[i].SCR;

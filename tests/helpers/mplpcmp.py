@@ -54,7 +54,8 @@ def check_record(rec, site, res, i, alleles, fmt_flag, extra=None):
         if rec.fmt("DP4", s) is not None:
             assert [int(x) for x in rec.fmt("DP4", s).split(",")] == dp4, (where, s, "DP4")
         if rec.fmt("SP", s) is not None:
-            assert int(rec.fmt("SP", s)) == orc.lib().orc_format_sp(*dp4), (where, s, "SP", dp4)
+            assert fmt_flag & abi.FMT_SP, (where, "golden has FMT/SP but the flag is not set")
+            assert int(rec.fmt("SP", s)) == int(res.sp[i, s]), (where, s, "SP", dp4, int(res.sp[i, s]))
         adf = [int(res.adf[i, k, s]) for k in range(na)]
         adr = [int(res.adr[i, k, s]) for k in range(na)]
         if rec.fmt("ADF", s) is not None:

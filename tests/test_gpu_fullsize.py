@@ -97,7 +97,7 @@ def test_sampled_sites_match_oracle(big):
         pass
     mg, cg = Rows(), Rows()
     mg.site = m.site[pick]
-    for k in ["pl", "dp4", "adf", "adr", "qs", "scr"]:
+    for k in ["pl", "dp4", "adf", "adr", "qs", "scr", "sp"]:
         setattr(mg, k, getattr(m, k)[pick])
     cg.site, cg.gt, cg.pl = c.site[pick], c.gt[pick], c.pl[pick]
     mw.qs[:] = mg.qs                                       # FMT/QS and SCR planes are not requested in this run

@@ -22,7 +22,7 @@ def assert_mplp_equal(got, want, float_rtol=2e-6):
         assert np.array_equal(np.isinf(g), np.isinf(w)), k
         m = ~np.isinf(w)
         np.testing.assert_allclose(g[m], w[m], rtol=float_rtol, atol=1e-30, err_msg="site." + k)
-    for k in ["pl", "dp4", "adf", "adr", "qs", "scr"]:
+    for k in ["pl", "dp4", "adf", "adr", "qs", "scr", "sp"]:
         np.testing.assert_array_equal(getattr(got, k), getattr(want, k), err_msg=k)
 
 
@@ -53,13 +53,15 @@ def assert_call_equal(got, want, n_smpl, qual_tol=1e-4):
     (8, 300, 150.0, 0.20, 10),            # deep cells (up to 200 reads)
 ])
 def test_mpileup_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth, var_rate, seed):
-    fmt = abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD | abi.FMT_QS | abi.FMT_SCR | abi.INFO_SCR
+    fmt = abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD | abi.FMT_QS | abi.FMT_SCR | abi.INFO_SCR | abi.FMT_SP
     tile = synth.numpy_tile(seed, n_sites, n_smpl, depth=depth, var_rate=var_rate, ref_n_rate=0.02, mapq255_rate=0.01)
     cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), fmt_flag=fmt)
     want = orc.mpileup(cfg, tile)
     ctx = gpu_ctx_factory(cfg)
     got = ctx.mpileup(tile)
     assert_mplp_equal(got, want)
+    if var_rate >= 0.1 and depth >= 12:
+        assert (want.sp > 0).any()          # FMT/SP: some heterozygous cells went through the Fisher exact test
 
 
 @pytest.mark.parametrize("n_sites,n_smpl,depth,var_rate,seed", [
