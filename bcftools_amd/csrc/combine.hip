@@ -128,27 +128,47 @@ __device__ __forceinline__ uint32_t dev_format_sp(uint32_t cnt4)
     return (uint32_t)(x > 255 ? 255 : x);
 }
 
-// calc_vdb, bam2bcf.c:281-342
-__device__ float dev_calc_vdb(const int *pos)
+// calc_vdb, bam2bcf.c:281-342, called by the whole wavefront (result valid in every lane).  The first loop's float sum of
+// pos[i]*i is a sum of integers: while the total stays below 2^24 every partial sum is exact, so it is the integer total
+// (wave reduction); otherwise lane 0 replays the loop.  The second loop rounds to float after every addition, so it stays
+// sequential on lane 0, but its terms pos[i]*|i - mean| are formed by all lanes first (adding the +0 of an empty bin
+// changes nothing).  s_term: 128 doubles of LDS.
+__device__ float wave_calc_vdb(const int *pos, int lane, double *s_term)
 {
     const int readlen = 100, nparam = 15;
     const float param[15][3] = { {3,0.079f,18}, {4,0.09f,19.8f}, {5,0.1f,20.5f}, {6,0.11f,21.5f},
         {7,0.125f,21.6f}, {8,0.135f,22}, {9,0.14f,22.2f}, {10,0.153f,22.3f}, {15,0.19f,22.8f},
         {20,0.22f,23.2f}, {30,0.26f,23.4f}, {40,0.29f,23.5f}, {50,0.35f,23.65f}, {100,0.5f,23.7f},
         {200,0.7f,23.7f} };
-    int i, dp = 0;
-    float mean_pos = 0, mean_diff = 0;
-    for (i = 0; i < readlen; i++) {
-        if (!pos[i]) continue;
-        dp += pos[i];
-        mean_pos += pos[i] * i;
-    }
+    int i;
+    const int i0 = 2 * lane, i1 = i0 + 1;
+    const int p0 = i0 < readlen ? pos[i0] : 0, p1 = i1 < readlen ? pos[i1] : 0;
+    int dp = p0 + p1;
+    unsigned long long mp = (unsigned long long)p0 * i0 + (unsigned long long)p1 * i1;
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { dp += __shfl_xor(dp, o); mp += __shfl_xor(mp, o); }
     if (dp < 2) return HUGE_VALF;
-    mean_pos /= dp;
-    for (i = 0; i < readlen; i++) {
-        if (!pos[i]) continue;
-        mean_diff = (float)((double)mean_diff + pos[i] * fabs((double)((float)i - mean_pos)));
+    float mean_pos = (float)mp;
+    if (mp >= (1ull << 24)) {
+        mean_pos = 0;
+        if (lane == 0)
+            for (i = 0; i < readlen; i++) { if (!pos[i]) continue; mean_pos += pos[i] * i; }
+        mean_pos = __shfl(mean_pos, 0);
     }
+    mean_pos /= dp;
+    if (i0 < readlen) s_term[i0] = p0 * fabs((double)((float)i0 - mean_pos));
+    if (i1 < readlen) s_term[i1] = p1 * fabs((double)((float)i1 - mean_pos));
+    __syncthreads();
+    float mean_diff = 0;
+    if (lane == 0) {
+        const double2 *t2 = reinterpret_cast<const double2*>(s_term);
+        for (i = 0; i < readlen / 2; i++) {
+            const double2 t = t2[i];
+            mean_diff = (float)((double)mean_diff + t.x);
+            mean_diff = (float)((double)mean_diff + t.y);
+        }
+    }
+    mean_diff = __shfl(mean_diff, 0);
     mean_diff /= dp;
     int ipos = (int)mean_diff;
     if (dp == 2)
@@ -233,19 +253,18 @@ __device__ __forceinline__ float seq_sum_f32(float acc, const float *v, int n)
     for (int i = nb << 4; i < n; ++i) acc += v[i];
     return acc;
 }
-__device__ __forceinline__ double seq_sum_f64(double acc, const float *v, int n)
+__device__ __forceinline__ double seq_sum_f64(double acc, const double *v, int n)
 {
-    const float4 *q = reinterpret_cast<const float4*>(v);
-    const int nb = n >> 4;
-    float4 c0, c1, c2, c3;
+    const double2 *q = reinterpret_cast<const double2*>(v);
+    const int nb = n >> 3;
+    double2 c0, c1, c2, c3;
     if (nb > 0) { c0 = q[0]; c1 = q[1]; c2 = q[2]; c3 = q[3]; }
     for (int b = 0; b < nb; ++b) {
-        const float4 a0 = c0, a1 = c1, a2 = c2, a3 = c3;
+        const double2 a0 = c0, a1 = c1, a2 = c2, a3 = c3;
         if (b + 1 < nb) { c0 = q[4 * b + 4]; c1 = q[4 * b + 5]; c2 = q[4 * b + 6]; c3 = q[4 * b + 7]; }
-        acc += a0.x; acc += a0.y; acc += a0.z; acc += a0.w; acc += a1.x; acc += a1.y; acc += a1.z; acc += a1.w;
-        acc += a2.x; acc += a2.y; acc += a2.z; acc += a2.w; acc += a3.x; acc += a3.y; acc += a3.z; acc += a3.w;
+        acc += a0.x; acc += a0.y; acc += a1.x; acc += a1.y; acc += a2.x; acc += a2.y; acc += a3.x; acc += a3.y;
     }
-    for (int i = nb << 4; i < n; ++i) acc += v[i];
+    for (int i = nb << 3; i < n; ++i) acc += v[i];
     return acc;
 }
 
@@ -268,7 +287,7 @@ template <int V> __device__ __forceinline__ void store_bytes(uint8_t *p, const u
 }
 template <int NAL, int V>
 __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTotals &T, const int (&gs)[15], const int (&as)[5],
-                                              int is, long c0, int base, int cn, int tid, long ncells, float *s_min)
+                                              int is, long c0, int base, int cn, int tid, long ncells, double *s_min)
 {
     constexpr int X = NAL * (NAL + 1) / 2;
     const size_t Ss = (size_t)P.n_smpl;
@@ -302,7 +321,7 @@ __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTota
             }
         }
         #pragma unroll
-        for (int v = 0; v < V; ++v) s_min[i + v] = mn[v];
+        for (int v = 0; v < V; ++v) s_min[i + v] = (double)mn[v];        // widened here, by all lanes, for the sequential sum
         uint32_t cnt4[V], adf[V], adr[V], misc[V];
         load_v<V>(P.cr.cnt4 + cell, cnt4); load_v<V>(P.cr.adf + cell, adf); load_v<V>(P.cr.adr + cell, adr); load_v<V>(P.cr.misc + cell, misc);
         if (NAL > 0 && !(P.ablate & 512)) {
@@ -447,7 +466,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     for (int j = 0; j < 15; ++j) gs[j] = __builtin_amdgcn_readfirstlane(j < x ? sh.g[j] : 0);
     #pragma unroll
     for (int j = 0; j < 5; ++j) as[j] = __builtin_amdgcn_readfirstlane(j < nal ? sh.a[j] : 4);
-    float *s_min = reinterpret_cast<float*>(s_stage);
+    double *s_min = reinterpret_cast<double*>(s_stage);
     for (int base = 0; base < S; base += CHUNK) {
         const int cn = min(CHUNK, S - base);
         __syncthreads();
@@ -499,17 +518,33 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const double p = (double)nr / S;
         const double q = (double)nr / M;
         const double log2 = log(2.0);
+        // The per-sample term depends only on the sample's alt-read count oi (0..510), and most samples of a site share a
+        // handful of values: count the samples per oi (zeros by ballot, the rest by LDS atomics), then evaluate the
+        // log/exp expression once per occurring count.  (The sum is tree-reduced and compared with a tolerance anyway.)
+        int *s_oc = reinterpret_cast<int*>(s_stage);           // [512]
+        for (int i = tid; i < 512; i += WG) s_oc[i] = 0;
+        __syncthreads();
+        int nzero = 0;
+        for (int s0 = 0; s0 < S; s0 += WG) {
+            const int s = s0 + tid;
+            int oi = -1;
+            if (s < S) { const uint32_t cnt4 = P.cr.cnt4[c0 + s]; oi = (int)(((cnt4 >> 16) & 0xff) + ((cnt4 >> 24) & 0xff)); }
+            nzero += __popcll(__ballot(oi == 0));
+            if (oi > 0) atomicAdd(&s_oc[oi], 1);
+        }
+        __syncthreads();
         double part = 0;
-        for (int s = tid; s < S; s += WG) {
-            const uint32_t cnt4 = P.cr.cnt4[c0 + s];
-            const int oi = (int)(((cnt4 >> 16) & 0xff) + ((cnt4 >> 24) & 0xff));
+        for (int k0 = 0; k0 < 512; k0 += WG) {
+            const int oi = k0 + tid;
+            const int cnt = oi == 0 ? nzero : s_oc[oi];
+            if (!__any(cnt > 0)) continue;
             double tmp;
             if (oi) {
                 tmp = dev_logsumexp2(log(2 * (1 - f)), log(f) + oi * log2 - q);
                 tmp += log(f) + oi * log(q / p) - q + p;
             } else
                 tmp = log(2 * f * (1 - f) * exp(-q) + f * f * exp(-2 * q) + (1 - f) * (1 - f)) + p;
-            part += tmp;
+            if (cnt > 0) part += cnt * tmp;
         }
         part = wave_sum_f64(part);
         if (lane == 0) atomicAdd(&sh.segb_sum, part);
@@ -536,7 +571,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (tid == t) { na_t = na; nb_t = nb; U_t = U; }
         }
         if (tid >= 1 && tid < 5) sh.bias[tid] = (tid == 1 && !(P.fmt_flag & BCFGPU_INFO_RPB)) ? 0.f : dev_mwu_tail(na_t, nb_t, U_t, P.mw);
-        if (tid == 0) sh.bias[0] = (P.fmt_flag & BCFGPU_INFO_VDB) ? dev_calc_vdb(h + H_ALT_POS) : 0.f;
+        const float vdb = (P.fmt_flag & BCFGPU_INFO_VDB) ? wave_calc_vdb(h + H_ALT_POS, lane, reinterpret_cast<double*>(s_stage) + 512) : 0.f;
+        if (tid == 0) sh.bias[0] = vdb;
     }
     __syncthreads();
 
