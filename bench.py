@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--groups", type=int, default=1, help="snp mode: call -G with this many sample groups (frequencies from FORMAT/AD); "
                                                           ">1 takes the general caller path (BASELINE configs[4] shape)")
     ap.add_argument("--haploid-frac", type=float, default=0.0, help="snp mode: fraction of haploid samples (ploidy array; general caller path)")
+    ap.add_argument("--indel-callers", type=int, default=2, help="indel mode: also time this many caller threads, one context each (1: skip)")
     ap.add_argument("--mode", choices=["snp", "indel", "baq"], default="snp",
                     help="snp: the headline pipeline (default).  indel: bcf_call_gap_prep on synthetic indel-candidate columns "
                          "(BASELINE configs[2] shape, 500 samples), reports DP cells/s of the realignment kernel.  "
@@ -119,6 +120,35 @@ def main_indel(a):
                           "note": "glfgen_kernel<INDEL> + combine_kernel over the columns gap_prep accepted, kernel times"}}
     for pc in pass_ctx.values():
         pc.close()
+    # The same batches driven by two caller threads, each with its own context (how a host program double-buffers the
+    # stage: one batch is typed on the host while the device scores the other); wall clock over all batches.
+    if a.indel_callers > 1:
+        import threading
+        batches = [synth.indel_batch(a.seed + c, min(per, n_sites - c), S, depth=a.depth) for c in range(0, n_sites, per)]
+        ctxs = [ctx] + [engine.Context(abi.default_cfg(S, max_sites=per, max_reads=64)) for _ in range(a.indel_callers - 1)]
+        for cx in ctxs[1:]:
+            indeldrv.gap_prep_gpu(cx, batches[0])                                    # workspaces sized before the clock starts
+        errs = []
+
+        def run(k):
+            try:
+                for j in range(k, len(batches), len(ctxs)):
+                    indeldrv.gap_prep_gpu(ctxs[k], batches[j])
+            except Exception as e:                                                    # surfaced after the join
+                errs.append(e)
+        th = [threading.Thread(target=run, args=(k,)) for k in range(len(ctxs))]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        tw = time.perf_counter() - t0
+        if errs:
+            raise errs[0]
+        out["overlapped"] = {"callers": len(ctxs), "value": sum(b["n_sites"] for b in batches) / tw, "unit": "sites/s",
+                             "wall_ms": tw * 1e3, "note": "one context per caller thread, batches taken alternately"}
+        for cx in ctxs[1:]:
+            cx.close()
     if a.cpu_seconds > 0:
         b, got = first
         t0 = time.perf_counter()

@@ -64,3 +64,32 @@ def test_indel_records_match_oracle(gpu_ctx_factory, n_sites, n_smpl, depth, see
         assert np.array_equal(np.isinf(g), np.isinf(w)), k
         m = ~np.isinf(w)
         np.testing.assert_allclose(g[m], w[m], rtol=2e-6, atol=1e-30, err_msg="site." + k)
+
+
+def test_two_callers_with_their_own_contexts(gpu_ctx_factory):
+    """Contexts are independent: two caller threads, one context each, run bcfgpu_gap_prep at the same time (how a host
+    program overlaps the typing of one batch with the scoring of another) and get what a single caller gets."""
+    import threading
+    n_smpl = 30
+    batches = [synth.indel_batch(70 + j, 16, n_smpl, depth=12.0) for j in range(6)]
+    ctxs = [gpu_ctx_factory(abi.default_cfg(n_smpl, max_sites=16, max_reads=64)) for _ in range(2)]
+    want = [indeldrv.gap_prep_gpu(ctxs[0], b)[0] for b in batches]
+    got = [None] * len(batches)
+    errs = []
+
+    def run(k):
+        try:
+            for _ in range(3):
+                for j in range(k, len(batches), 2):
+                    got[j] = indeldrv.gap_prep_gpu(ctxs[k], batches[j])[0]
+        except Exception as e:
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for g, w in zip(got, want):
+        for key in w:
+            np.testing.assert_array_equal(g[key], w[key], err_msg=key)
