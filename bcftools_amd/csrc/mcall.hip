@@ -427,41 +427,58 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const int row = t * 16 + kq + 4 * r; if (row < nals || row == nsub) singles |= 1 << (t * 4 + r); }
             const uint8_t *plb = reinterpret_cast<const uint8_t*>(P.pl) + (size_t)is * BCFGPU_MAX_PL * Ss;
-            for (int s0 = 0; s0 < ((P.ablate & 16) ? 0 : S); s0 += 64) {
-                const int sb = s0 + 4 * col, rem = S - sb;
-                uint32_t pw = 0x02020202u, gmask = 0xf;                     // ploidy bytes and group membership of the 4 samples
-                if (rem <= 0) gmask = 0;
-                else if (HAP || ngrp > 1) {
-                    if (rem >= 4) {
-                        if (HAP) __builtin_memcpy(&pw, P.ploidy + sb, 4);
-                        if (ngrp > 1) {
-                            int gv[4];
-                            __builtin_memcpy(gv, P.grp + sb, 16);
-                            gmask = (gv[0] == g ? 1u : 0u) | (gv[1] == g ? 2u : 0u) | (gv[2] == g ? 4u : 0u) | (gv[3] == g ? 8u : 0u);
-                        }
-                    } else {
-                        #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (j < rem) {
-                                if (HAP) pw = (pw & ~(0xffu << (8 * j))) | (uint32_t)P.ploidy[sb + j] << (8 * j);
-                                if (ngrp > 1 && P.grp[sb + j] != g) gmask &= ~(1u << j);
-                            }
-                    }
-                }
-                if (ngrp > 1 && !__any(gmask != 0)) continue;          // no sample of this group among these 64
-                // plane 4kk+kq, samples s0+4col .. +3 as one word; samples past the end read as "no data"
-                uint32_t w[4];
+            // A lane takes 16 consecutive samples of a 256-sample block: the sixteen 4-byte loads of its four plane groups (and the
+            // ploidy / group words) are all issued before the first use, so a block costs one memory round trip -- with
+            // four wavefronts per SIMD the scan is bound by such round trips.  Word q of the block holds the samples
+            // sb+4q .. sb+4q+3; one matrix product covers the 16 lanes' samples sb+4q+j.
+            // (few samples: 4*nq consecutive samples per lane with nq = 2 or 1, so that the 16 lanes' columns stay filled)
+            const int nq = S > 128 ? 4 : S > 64 ? 2 : 1;
+            for (int s0 = 0; s0 < ((P.ablate & 16) ? 0 : S); s0 += 64 * nq) {
+                const int sb0 = s0 + 4 * nq * col;
+                uint32_t wq[4][4], pwq[4], gmq[4];
                 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = 4 * kk + kq;
-                    uint32_t v = 0;
-                    if (k < ngts && rem > 0) {
-                        const uint8_t *src = plb + (size_t)k * Ss + sb;
-                        if (rem >= 4) __builtin_memcpy(&v, src, 4);
-                        else { v = src[0]; if (rem > 1) v |= (uint32_t)src[1] << 8; if (rem > 2) v |= (uint32_t)src[2] << 16; }
+                for (int q = 0; q < 4; ++q) {
+                    if (q >= nq) break;
+                    const int sb = sb0 + 4 * q, rem = S - sb;
+                    uint32_t pw = 0x02020202u, gmask = 0xf;                 // ploidy bytes and group membership of the 4 samples
+                    if (rem <= 0) gmask = 0;
+                    else if (HAP || ngrp > 1) {
+                        if (rem >= 4) {
+                            if (HAP) __builtin_memcpy(&pw, P.ploidy + sb, 4);
+                            if (ngrp > 1) {
+                                int gv[4];
+                                __builtin_memcpy(gv, P.grp + sb, 16);
+                                gmask = (gv[0] == g ? 1u : 0u) | (gv[1] == g ? 2u : 0u) | (gv[2] == g ? 4u : 0u) | (gv[3] == g ? 8u : 0u);
+                            }
+                        } else {
+                            #pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (j < rem) {
+                                    if (HAP) pw = (pw & ~(0xffu << (8 * j))) | (uint32_t)P.ploidy[sb + j] << (8 * j);
+                                    if (ngrp > 1 && P.grp[sb + j] != g) gmask &= ~(1u << j);
+                                }
+                        }
                     }
-                    w[kk] = v;
+                    pwq[q] = pw; gmq[q] = gmask;
+                    // plane 4kk+kq, samples sb .. sb+3 as one word; samples past the end read as "no data"
+                    #pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int k = 4 * kk + kq;
+                        uint32_t v = 0;
+                        if (k < ngts && rem > 0) {
+                            const uint8_t *src = plb + (size_t)k * Ss + sb;
+                            if (rem >= 4) __builtin_memcpy(&v, src, 4);
+                            else { v = src[0]; if (rem > 1) v |= (uint32_t)src[1] << 8; if (rem > 2) v |= (uint32_t)src[2] << 16; }
+                        }
+                        wq[q][kk] = v;
+                    }
                 }
+                #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                const uint32_t pw = pwq[q], gmask = gmq[q];
+                const uint32_t (&w)[4] = wq[q];
+                if (q >= nq) break;
+                if (ngrp > 1 && !__any(gmask != 0)) continue;              // no sample of this group in this word of the 16 lanes
                 // set_pdg: a sample whose PLs are all 0 (sum == n_gt) carries no data and is skipped (mcall.c:529-535)
                 uint32_t any = w[0] | w[1] | w[2] | w[3];
                 any |= __shfl_xor(any, 16);
@@ -498,6 +515,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                             for (int r = 0; r < 4; ++r) { ex[t][r] += frexp_exp(man[t][r]); man[t][r] = frexp_mant(man[t][r]); }
                         if (HAP) { sde += frexp_exp(sdm); sdm = frexp_mant(sdm); }
                     }
+                }
                 }
             }
             // product over the 16 sample columns of each row, then rows -> sh.red[]
@@ -683,6 +701,16 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     const int ogt = P.out_n_gt_max;
     {
     const uint8_t *plb2 = reinterpret_cast<const uint8_t*>(P.pl) + (size_t)is * BCFGPU_MAX_PL * Ss;
+    // FAST: the PL bytes of the lane's next sample are requested before the current one is worked on (the loop is a
+    // chain of memory round trips otherwise: 16 of them for 1000 samples)
+    uint32_t pl_nx[FAST ? NG : 1];
+    auto fetch_pl = [&](int s) {
+        if constexpr (FAST) {
+            #pragma unroll
+            for (int k = 0; k < NG; ++k) pl_nx[k] = (k < ngts && s < S) ? (uint32_t)plb2[(size_t)k * Ss + s] : 0u;
+        }
+    };
+    if (!(P.ablate & 32)) fetch_pl(tid);
     for (int s = tid; s < ((P.ablate & 32) ? 0 : S); s += WGS) {
         const int ploidy = (FAST && !HAP) ? 2 : (P.ploidy ? P.ploidy[s] : 2);    // FAST without HAP is launched only without a ploidy array
         // P(D|G) = raw/psum is formed lazily below, with the same division the reference performs (bit-exact genotypes)
@@ -695,7 +723,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             #pragma unroll
             for (int k = 0; k < NG; ++k) {
                 if (k < ngts) {
-                    const uint32_t v = plb2[(size_t)k * Ss + s];
+                    const uint32_t v = pl_nx[k];
                     s_plb[k * WGS + tid] = (uint8_t)v;
                     psum += s_p2[v];
                     anynz |= v;
@@ -703,6 +731,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                 if (want_gqgp) s_gps[k * WGS + tid] = 0.f;
             }
             allzero = anynz == 0;                            // sum == n_gt: no data (mcall.c:529-535)
+            fetch_pl(s + WGS);
         } else {
             int pl[NG]; double pdg[NG];
             load_pl<NG>(P, is, s, ngts, pl);
