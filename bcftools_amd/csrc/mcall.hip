@@ -274,6 +274,11 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                     if (b4 + 1 < nb) { fn = fr4[b4 + 1]; gn = gg4[b4 + 1]; }
                     const float fv[4] = {f.x, f.y, f.z, f.w};
                     const int gs4[4] = {gv.x, gv.y, gv.z, gv.w};
+                    // four samples of the running group (groups are usually runs of consecutive samples): just the four adds
+                    if (4 * b4 + 3 < cn && ((gv.x ^ cur) | (gv.y ^ cur) | (gv.z ^ cur) | (gv.w ^ cur)) == 0) {
+                        acc += f.x; acc += f.y; acc += f.z; acc += f.w;
+                        continue;
+                    }
                     #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         if (4 * b4 + k < cn) {
