@@ -328,6 +328,18 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
         return;
     }
     int *grp_als_tab = reinterpret_cast<int*>(s_gq + ngrp * 5);
+    // The 5-allele instantiations split the sites by the number of subsets to visit (LDS for the running products): more
+    // than 15 only when all five alleles have a non-zero frequency (5 + 10 + 10 subsets), in any group -- decided once
+    // per site, before the groups are walked, so that exactly one instantiation takes the site.
+    if (MAXA == 5) {
+        bool five = false;
+        if (nals == 5)
+            for (int g = 0; g < ngrp; ++g) {
+                const float *q = s_gq + g * 5;
+                five = five || (q[0] != 0.f && q[1] != 0.f && q[2] != 0.f && q[3] != 0.f && q[4] != 0.f);
+            }
+        if (five != (NSUB == 25)) return;
+    }
 
     // ---- per group: mcall_find_best_alleles ----
     for (int g = 0; g < ngrp; ++g) {
@@ -381,8 +393,6 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
         }
         __syncthreads();
         const int nsub = sh.nsub;
-        // the 5-allele instantiations split by the number of subsets to visit (LDS for the running products)
-        if (MAXA == 5 && ((nsub <= 15) != (NSUB == 15))) return;
         int setbits = 0;
         if constexpr (FAST) {
             // ---- subset scan on the matrix cores ----
