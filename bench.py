@@ -196,6 +196,32 @@ def main_baq(a):
                                            "reads": int(R["n_reads"]), "bases": int(nb)},
            "whole_call_ms": t * 1e3, "note": "host pointers in and out: the time includes the window preparation on the host, "
                                              "uploads, baq_kernel and the download of the new qualities"}
+    # the mate-overlap tweak over the same pool: consecutive reads of the pool taken as mates (reads of one column overlap
+    # around it), whole call with host pointers; the C oracle on one core beside it, results compared
+    npair = R["n_reads"] // 2
+    pa = np.arange(0, 2 * npair, 2, dtype=np.int32)
+    pb = pa + 1
+    ov = np.zeros(nb, np.uint8)
+
+    def run_ov():
+        t0 = time.perf_counter()
+        check(ctx.L.bcfgpu_overlap_tweak(ctx.h, C.byref(rd), npair, pa.ctypes.data, pb.ctypes.data, ov.ctypes.data))
+        return time.perf_counter() - t0
+    run_ov()
+    tov = min(run_ov() for _ in range(3))
+    from tests.helpers import orc
+    OL = orc.lib()
+    OL.orc_overlap_tweak.restype = C.c_int
+    OL.orc_overlap_tweak.argtypes = [C.POINTER(abi.Reads), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    ow = R["qual"].copy()
+    t0 = time.perf_counter()
+    OL.orc_overlap_tweak(C.byref(rd), npair, pa.ctypes.data, pb.ctypes.data, ow.ctypes.data)
+    toc = time.perf_counter() - t0
+    assert np.array_equal(ov, ow)
+    out["overlap_tweak"] = {"pairs": int(npair), "value": npair / tov, "unit": "pairs/s", "whole_call_ms": tov * 1e3,
+                            "cpu_baseline": {"value": npair / toc, "unit": "pairs/s", "cores": 1, "kind": "port"},
+                            "note": "bcfgpu_overlap_tweak with host pointers (uploads, overlap_kernel, download) against "
+                                    "oracle/overlap.c on one core; outputs identical"}
     if a.cpu_seconds > 0:
         class Rd:
             pass

@@ -16,6 +16,7 @@
  *    bcfgpu_gap_prep                     <- bcf_call_gap_prep                  bam2bcf.h:141 (bam2bcf_indel.c:99-470)
  *    bcfgpu_gap_prep_stats               <- (measurement only)
  *    bcfgpu_baq                          <- sam_prob_realn (htslib realn.c), call site mpileup.c:234
+ *    bcfgpu_overlap_tweak                <- tweak_overlap_quality (htslib sam.c) of the pileup engine, switched on at mpileup.c:640
  *    bcfgpu_mcall                        <- mcall()                            call.h:131 (mcall.c:1430-1684)
  *                                           incl. the per-record prologue of vcfcall.c:1096-1115
  *    bcfgpu_pipeline                     <- the `mpileup -Ou | call -m` pipe with PL/QS/I16 kept in HBM
@@ -310,6 +311,16 @@ int  bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const bcfgpu_in
  * Reads that already carry BQ/ZQ tags are the caller's business (realn.c:60-90); this entry is the computation. */
 int  bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const char *ref, int32_t ref_len, int flag,
                 uint8_t *qual_out, uint8_t *zq_out, int32_t *ret);
+
+/* ---- mate overlaps: what bam_mplp_init_overlaps() (mpileup.c:640) makes htslib's pileup do to read pairs whose mates
+ * overlap (sam.c tweak_overlap_quality): at every reference position both reads cover with an aligned base, equal
+ * bases pool their qualities in the first read (at most 200) and different bases keep 0.8 of the better quality (the
+ * first read's on ties); the other read's base gets quality 0.  Pair p is (pair_a[p] = the mate that entered the
+ * pileup first, pair_b[p]); which reads pair up (proper pair, same contig, first mate still buffered) is the pileup
+ * engine's bookkeeping and stays with the caller.  A read may be in one pair only.  HOST pointers; `reads->qual` (the
+ * qualities after BAQ) is not modified: qual_out is the whole quality pool with the pairs' bases rewritten. */
+int  bcfgpu_overlap_tweak(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, int32_t n_pairs, const int32_t *pair_a,
+                          const int32_t *pair_b, uint8_t *qual_out);
 
 /* statistics of the last bcfgpu_gap_prep call on this context (SURVEY 8d "indel stage unit": DP cells per second):
  * jobs = (site, candidate type, read) realignments, passes = forward passes run (a second parameter set is tried when

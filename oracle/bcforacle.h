@@ -78,6 +78,9 @@ int orc_gap_prep(int n, const int *smpl_off, const int *p_read, const int *p_qpo
 
 /* FORMAT/SP from DP4 (bam2bcf.c:867-885) */
 int orc_format_sp(int fwd_ref, int rev_ref, int fwd_alt, int rev_alt);
+/* mate-overlap quality tweak (htslib sam.c tweak_overlap_quality; mpileup.c:640) on the read pool: pair p is
+ * (pair_a[p] arrived first, pair_b[p]); `qual` is the pool of qualities, modified in place */
+int orc_overlap_tweak(const bcfgpu_reads *rd, int32_t n_pairs, const int32_t *pair_a, const int32_t *pair_b, uint8_t *qual);
 
 #ifdef __cplusplus
 }

@@ -2,8 +2,9 @@
 BAQ (sam_prob_realn, mpileup.c:234) and the mate-overlap quality tweak (bam_mplp_init_overlaps, mpileup.c:640),
 then per-site glfgen/combine (SNP record) and bcf_call_gap_prep + glfgen/combine (indel record), mpileup.c:320-367.
 
-BAQ, probaln and gap_prep run in the C oracle; the overlap tweak and the pileup walk are restated here (htslib
-sam.c: overlap_push / tweak_overlap_quality).  An *engine* (oracle or HIP) turns tiles into results.
+BAQ, probaln, gap_prep and the per-base overlap tweak run in the C oracle (or through the HIP library when a context is
+given); the pairing of mates and the pileup walk are restated here (htslib sam.c: overlap_push).  An *engine* (oracle
+or HIP) turns tiles into results.
 """
 import ctypes as C
 import numpy as np
@@ -107,9 +108,10 @@ def tweak_overlap_quality(a, b):
                 a.qual[ia] = 0
 
 
-def apply_overlaps(reads):
-    """overlap_push over the reads of one file in file order (all reads stay buffered long enough in these fixtures)."""
-    pending = {}
+def overlap_pairs(reads):
+    """overlap_push over the reads of one file in file order (all reads stay buffered long enough in these fixtures):
+    the (first mate, second mate) pairs that htslib hands to tweak_overlap_quality."""
+    pending, pairs = {}, []
     for r in reads:
         f = r.flag
         if (f & 8) or not (f & S.BAM_FPROPER_PAIR):          # BAM_FMUNMAP
@@ -123,7 +125,58 @@ def apply_overlaps(reads):
             a = pending.pop(r.qname)
             # the first mate must still be in the pileup buffer: it is, unless it ended before this one starts
             if a.end > r.pos:
-                tweak_overlap_quality(a, r)
+                pairs.append((a, r))
+    return pairs
+
+
+def pack_reads(reads):
+    """The flat read pool of include/bcfgpu.h (bcfgpu_reads) for a list of sam.Read; returns (abi.Reads, arrays kept alive)."""
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    lq = i32([r.l_qseq for r in reads])
+    ncig = i32([len(r.bamcigar) for r in reads])
+    d = dict(r_pos=i32([r.pos for r in reads]), r_lq=lq, r_flag=i32([r.flag for r in reads]), r_ncig=ncig,
+             r_cig_off=i32(np.concatenate([[0], np.cumsum(ncig)[:-1]])), r_seq_off=i32(np.concatenate([[0], np.cumsum(lq)[:-1]])),
+             cig=np.ascontiguousarray(np.concatenate([r.bamcigar for r in reads]), dtype=np.uint32),
+             seq16=np.ascontiguousarray(np.concatenate([[S.nt16(c) for c in r.seq] for r in reads]), dtype=np.uint8),
+             qual=np.ascontiguousarray(np.concatenate([r.qual for r in reads]).astype(np.uint8)))
+    d["zq"] = np.zeros(len(d["qual"]), dtype=np.uint8)
+    d["r_has_zq"] = np.zeros(len(reads), dtype=np.uint8)
+    rd = abi.Reads()
+    rd.n_reads = len(reads)
+    for k in ("r_pos", "r_lq", "r_flag", "r_ncig", "r_cig_off", "r_seq_off", "cig", "seq16", "qual", "zq", "r_has_zq"):
+        setattr(rd, k, d[k].ctypes.data)
+    return rd, d
+
+
+def apply_overlaps(reads, ctx=None, python=False):
+    """The mate-overlap tweak on the reads of one file: pair selection here, the per-base arithmetic in the C oracle
+    (orc_overlap_tweak), through bcfgpu_overlap_tweak when a HIP context is given, or in Python (the first restatement,
+    kept to pin the other two)."""
+    pairs = overlap_pairs(reads)
+    if python:
+        for a, b in pairs:
+            tweak_overlap_quality(a, b)
+        return len(pairs)
+    if not pairs:
+        return 0
+    used = [r for ab in pairs for r in ab]
+    rd, d = pack_reads(used)
+    pa = np.arange(0, len(used), 2, dtype=np.int32)
+    pb = pa + 1
+    if ctx is None:
+        L = orc.lib()
+        L.orc_overlap_tweak.restype = C.c_int
+        L.orc_overlap_tweak.argtypes = [C.POINTER(abi.Reads), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        qo = d["qual"].copy()
+        rc = L.orc_overlap_tweak(C.byref(rd), len(pairs), pa.ctypes.data, pb.ctypes.data, qo.ctypes.data)
+        assert rc == 0
+    else:
+        from bcftools_amd.lib import check
+        qo = np.zeros_like(d["qual"])
+        check(ctx.L.bcfgpu_overlap_tweak(ctx.h, C.byref(rd), len(pairs), pa.ctypes.data, pb.ctypes.data, qo.ctypes.data))
+    for r, o in zip(used, d["r_seq_off"]):
+        r.qual = qo[o:o + r.l_qseq].astype(np.int32)
+    return len(pairs)
 
 
 class Prepared:
@@ -152,7 +205,7 @@ class Prepared:
             if baq and baq_ctx is not None:
                 apply_baq_hip([r for r, _ in rl], self.refseq, baq_ctx)      # bcfgpu_baq, one call per file
             if overlaps:
-                apply_overlaps([r for r, _ in rl])
+                apply_overlaps([r for r, _ in rl], ctx=baq_ctx)      # oracle C, or bcfgpu_overlap_tweak with a HIP context
             self.files.append(rl)
 
 

@@ -67,7 +67,13 @@ def test_shard_ranges_cover_in_order():
 def test_two_rank_gather_matches_single_process(tmp_path):
     n_sites, n_smpl = 37, 9
     out = str(tmp_path / "gathered.npy")
-    mp.spawn(_worker, args=(2, _free_port(), n_sites, n_smpl, out), nprocs=2, join=True)
+    for attempt in range(2):                       # a probed-free port can be taken before the ranks bind it: one retry
+        try:
+            mp.spawn(_worker, args=(2, _free_port(), n_sites, n_smpl, out), nprocs=2, join=True)
+            break
+        except Exception:
+            if attempt:
+                raise
     tile = synth.numpy_tile(99, n_sites, n_smpl, depth=15.0, var_rate=0.3)
     want = _run_shard(tile, abi.default_cfg(n_smpl), 0, n_sites)
     got = np.load(out).tobytes()
