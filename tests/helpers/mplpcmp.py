@@ -38,6 +38,8 @@ def check_record(rec, site, res, i, alleles, fmt_flag, extra=None):
     for tag in ("AD", "DPR"):
         if tag in rec.info:
             assert rec.info_ints(tag) == [a + b for a, b in zip(adf_tot, adr_tot)], (where, "INFO/" + tag)
+    if "SCR" in rec.info:
+        assert fmt_flag & abi.INFO_SCR and int(rec.info["SCR"]) == int(site["scr_tot"]), (where, "INFO/SCR", site["scr_tot"])
     if extra:
         if "IDV" in rec.info:
             assert int(rec.info["IDV"]) == extra["max_support"], (where, "IDV")
@@ -56,6 +58,8 @@ def check_record(rec, site, res, i, alleles, fmt_flag, extra=None):
         if rec.fmt("SP", s) is not None:
             assert fmt_flag & abi.FMT_SP, (where, "golden has FMT/SP but the flag is not set")
             assert int(rec.fmt("SP", s)) == int(res.sp[i, s]), (where, s, "SP", dp4, int(res.sp[i, s]))
+        if rec.fmt("SCR", s) is not None:
+            assert fmt_flag & abi.FMT_SCR and int(rec.fmt("SCR", s)) == int(res.scr[i, s]), (where, s, "FMT/SCR")
         adf = [int(res.adf[i, k, s]) for k in range(na)]
         adr = [int(res.adr[i, k, s]) for k in range(na)]
         if rec.fmt("ADF", s) is not None:

@@ -182,25 +182,30 @@ def apply_overlaps(reads, ctx=None, python=False):
 class Prepared:
     """SAM files after mplp_func filtering + BAQ + overlap tweak, ready for pileup."""
 
-    def __init__(self, sams, ref, contig, opts, baq=True, overlaps=True, baq_ctx=None):
+    def __init__(self, sams, ref, contig, opts, baq=True, overlaps=True, baq_ctx=None, rg_map=None, samples=None):
+        """rg_map / samples: `mpileup -G FILE` (bam_sample.c): read group -> sample name, reads of other read groups are
+        dropped; `samples` fixes the output order (it may name samples that end up without reads)."""
         self.refseq = ref[contig]
         self.contig = contig
         self.opts = opts
-        self.samples = []
-        for s in sams:
-            for sm in s.samples:
-                if sm not in self.samples:
-                    self.samples.append(sm)
+        self.samples = list(samples) if samples else []
+        if not samples:
+            for s in sams:
+                for sm in s.samples:
+                    if sm not in self.samples:
+                        self.samples.append(sm)
         self.files = []
         for s in sams:
             rl = []
             for r in s.reads:
                 if r.rname != contig or not S.keep_read(r, opts):
                     continue
+                if rg_map is not None and r.rg not in rg_map:
+                    continue
                 r.zq = None
                 if baq and baq_ctx is None:
                     apply_baq(r, self.refseq)
-                sm = s.rg2sm.get(r.rg, s.samples[0] if s.samples else None)
+                sm = rg_map[r.rg] if rg_map is not None else s.rg2sm.get(r.rg, s.samples[0] if s.samples else None)
                 rl.append((r, self.samples.index(sm)))
             if baq and baq_ctx is not None:
                 apply_baq_hip([r for r, _ in rl], self.refseq, baq_ctx)      # bcfgpu_baq, one call per file

@@ -64,6 +64,76 @@ class Sam:
                     self.reads.append(Read(line.split("\t")))
 
 
+class Bam(Sam):
+    """The same from a BAM file (the reference keeps some fixtures as BAM only): BGZF blocks are gzip members, the
+    records are turned into SAM fields and go through Read."""
+
+    def __init__(self, path):
+        import struct
+        import zlib
+        self.rg2sm, self.samples, self.reads, self.contigs = {}, [], [], {}
+        raw, data = open(path, "rb").read(), b""
+        while raw:
+            d = zlib.decompressobj(31)
+            data += d.decompress(raw)
+            raw = d.unused_data
+        assert data[:4] == b"BAM\1"
+        l_text, = struct.unpack_from("<i", data, 4)
+        text = data[8:8 + l_text].split(b"\0")[0].decode()
+        o = 8 + l_text
+        n_ref, = struct.unpack_from("<i", data, o)
+        o += 4
+        names = []
+        for _ in range(n_ref):
+            l_name, = struct.unpack_from("<i", data, o)
+            names.append(data[o + 4:o + 4 + l_name - 1].decode())
+            l_ref, = struct.unpack_from("<i", data, o + 4 + l_name)
+            self.contigs[names[-1]] = l_ref
+            o += 8 + l_name
+        for line in text.split("\n"):
+            f = line.split("\t")
+            if f[0] == "@RG":
+                d = dict(x.split(":", 1) for x in f[1:])
+                self.rg2sm[d["ID"]] = d.get("SM", d["ID"])
+                if self.rg2sm[d["ID"]] not in self.samples:
+                    self.samples.append(self.rg2sm[d["ID"]])
+        while o < len(data):
+            bs, = struct.unpack_from("<i", data, o)
+            rec = data[o + 4:o + 4 + bs]
+            o += 4 + bs
+            ref_id, pos, l_rn, mapq, _bin, n_cig, flag, l_seq, nref, npos, tlen = struct.unpack_from("<iiBBHHHiiii", rec, 0)
+            q = 32
+            qname = rec[q:q + l_rn - 1].decode()
+            q += l_rn
+            cig = struct.unpack_from("<%dI" % n_cig, rec, q)
+            q += 4 * n_cig
+            sq = rec[q:q + (l_seq + 1) // 2]
+            q += (l_seq + 1) // 2
+            seq = "".join("=ACMGRSVTWYHKDBN"[(sq[i >> 1] >> (0 if i & 1 else 4)) & 15] for i in range(l_seq))
+            ql = rec[q:q + l_seq]
+            q += l_seq
+            qual = "*" if l_seq == 0 or ql[0] == 0xff else "".join(chr(c + 33) for c in ql)
+            tags = []
+            while q < len(rec):                                  # only RG:Z is of interest; the rest is skipped by type
+                tag, typ = rec[q:q + 2].decode(), chr(rec[q + 2])
+                q += 3
+                if typ in "ZH":
+                    e = rec.index(b"\0", q)
+                    if tag == "RG":
+                        tags.append("RG:Z:" + rec[q:e].decode())
+                    q = e + 1
+                elif typ == "B":
+                    sub, n = chr(rec[q]), struct.unpack_from("<i", rec, q + 1)[0]
+                    q += 5 + n * {"c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[sub]
+                else:
+                    q += {"A": 1, "c": 1, "C": 1, "s": 2, "S": 2, "i": 4, "I": 4, "f": 4}[typ]
+            cs = "".join("%d%s" % (c >> 4, CIG_OPS[c & 15]) for c in cig) or "*"
+            rn = names[ref_id] if ref_id >= 0 else "*"
+            rnext = "*" if nref < 0 else ("=" if nref == ref_id else names[nref])
+            self.reads.append(Read([qname, str(flag), rn, str(pos + 1), str(mapq), cs, rnext, str(npos + 1), str(tlen),
+                                    seq if l_seq else "*", qual] + tags))
+
+
 def read_fasta(path):
     seqs, name = {}, None
     with open(path) as fh:

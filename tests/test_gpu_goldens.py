@@ -36,7 +36,7 @@ def test_hip_reproduces_default_mpileup_golden(golden_dir, idx):
     def hip_engine(cfg, tile):
         key = tile.n_smpl
         if key not in ctxs:
-            c = abi.default_cfg(tile.n_smpl, max_sites=1024, max_reads=1 << 20, fmt_flag=cfg.fmt_flag)
+            c = abi.default_cfg(tile.n_smpl, max_sites=8192, max_reads=1 << 20, fmt_flag=cfg.fmt_flag)
             ctxs[key] = engine.Context(c)
         return ctxs[key].mpileup(tile)
     def gap_ctx():

@@ -22,21 +22,40 @@ CASES = [
     (TRIO, "mpileup.ref.fa", "17", 99, 599, "mpileup.5.out",
      BASE | A.FMT_DP | A.FMT_AD | A.FMT_ADF | A.FMT_ADR | A.FMT_SP | A.INFO_AD | A.INFO_ADF | A.INFO_ADR, 501, 1),
     (["indel-AD.1.sam"], "indel-AD.1.fa", "000000F", 0, 10000, "indel-AD.1.out", BASE | A.FMT_AD, 297, 6),
+    # test.pl:653: one file, no region: every covered position of the contig (4001 SNP records, many of them without a
+    # usable read, and one indel record)
+    (["mpileup.3.sam"], "mpileup.ref.fa", "17", 0, 4100, "mpileup.11.out", BASE, 4001, 1),
+    # test.pl:647-652: sample and read-group selection (bam_sample.c) regroups the same reads: -s keeps two of the three
+    # one-sample files, -s ^ the third, -S renames (names only), -G maps read groups to samples (reads of unlisted read
+    # groups are dropped; SAMPLE2's read group is in none of the three files, its column stays empty)
+    (["mpileup.2.sam", "mpileup.3.sam"], "mpileup.ref.fa", "17", 99, 149, "mpileup.7.out", BASE, 51, 0),
+    (["mpileup.1.sam"], "mpileup.ref.fa", "17", 99, 149, "mpileup.8.out", BASE, 51, 0),
+    (["mpileup.2.sam", "mpileup.3.sam"], "mpileup.ref.fa", "17", 99, 149, "mpileup.9.out", BASE, 51, 0),
+    # test.pl:659: soft-clip counts (the fixture exists as BAM only: tests/helpers/sam.py reads it)
+    (["mpileup-SCR.bam"], "mpileup-SCR.fa", "1", 0, 200, "mpileup-SCR.out", BASE | A.INFO_SCR | A.FMT_SCR, None, None),
+    (TRIO, "mpileup.ref.fa", "17", 99, 149, "mpileup.10.out", BASE, 51, 0,
+     dict(rg_map={"ERR162872": "HG00100", "ERR162875": "SAMPLE1a", "ERR013140": "SAMPLE1b", "ERR229776": "SAMPLE2",
+                  "ERR229775": "SAMPLE3"}, samples=["SAMPLE1b", "HG00100", "SAMPLE1a", "SAMPLE2", "SAMPLE3"])),
 ]
 
 
 def run_case(golden_dir, case, engine, gap_ctx=None, baq_ctx=None):
-    samfiles, reffa, contig, beg, end, goldf, fmt_flag, n_snp, n_indel = case
+    samfiles, reffa, contig, beg, end, goldf, fmt_flag, n_snp, n_indel = case[:9]
+    kw = case[9] if len(case) > 9 else {}
     G = os.path.join(golden_dir, "mpileup")
-    sams = [sam.Sam(os.path.join(G, f)) for f in samfiles]
+    sams = [(sam.Bam if f.endswith(".bam") else sam.Sam)(os.path.join(G, f)) for f in samfiles]
     ref = sam.read_fasta(os.path.join(G, reffa))
-    prep = M.Prepared(sams, ref, contig, sam.MplpOpts(fmt_flag=fmt_flag), baq_ctx=baq_ctx() if baq_ctx else None)
+    prep = M.Prepared(sams, ref, contig, sam.MplpOpts(fmt_flag=fmt_flag), baq_ctx=baq_ctx() if baq_ctx else None, **kw)
     tile, cols, kept = M.snp_tile(prep, range(beg, end + 1))
     cfg = A.default_cfg(len(prep.samples), fmt_flag=fmt_flag)
     res = engine(cfg, tile)
     gold = vcf.Vcf(os.path.join(G, goldf))
+    if kw.get("samples"):
+        assert gold.samples == kw["samples"]
     snp = {r.pos: r for r in gold.recs if "INDEL" not in r.info}
     ind = {r.pos: r for r in gold.recs if "INDEL" in r.info}
+    if n_snp is None:
+        n_snp, n_indel = len(snp), len(ind)
     assert (len(snp), len(ind)) == (n_snp, n_indel)
     assert [p + 1 for p in kept] == sorted(snp)
     seen_indel = 0
