@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--depth", type=float, default=30.0)
-    ap.add_argument("--sites", type=int, default=16384, help="pileup columns per tile (= per step, per rank)")
+    ap.add_argument("--sites", type=int, default=None, help="pileup columns per tile (= per step, per rank); default 32768 (snp), 128 (indel), 32 (baq)")
     ap.add_argument("--var-rate", type=float, default=0.01)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget on rank 0 at N=1 (0: skip)")
     ap.add_argument("--seed", type=int, default=20260104)
@@ -78,7 +78,7 @@ def main_indel(a):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     S = 500 if a.samples == 1000 else a.samples
-    n_sites = 128 if a.sites == 16384 else a.sites
+    n_sites = 128 if a.sites is None else a.sites
     per = 32
     ctx = engine.Context(abi.default_cfg(S, max_sites=per, max_reads=64))
     indeldrv.gap_prep_gpu(ctx, synth.indel_batch(a.seed, 2, 8, depth=10.0))          # warm-up: module load
@@ -174,7 +174,7 @@ def main_baq(a):
     from bcftools_amd.lib import check
     ctx = engine.Context(abi.default_cfg(1, max_sites=1, max_reads=64))
     S = 500 if a.samples == 1000 else a.samples
-    n_sites = 32 if a.sites == 16384 else a.sites
+    n_sites = 32 if a.sites is None else a.sites
     b = synth.indel_batch(a.seed, n_sites, S, depth=a.depth)
     R = b["reads"]
     rd = abi.Reads()
@@ -269,7 +269,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    S, T = a.samples, a.sites
+    # 32768 columns x 1000 samples x 30x = 4.9 GB of reads per tile: twice the tile costs nothing in HBM and the two
+    # one-wavefront-per-site kernels lose less to their last partial round (16384: 3.5, 32768: 3.7, 65536: 3.7 M sites/s)
+    S, T = a.samples, (a.sites if a.sites is not None else 32768)
     # ---- synthetic tile, generated on the device; each rank owns a different region shard ----
     tile = synth.torch_tile(a.seed + rank, T, S, dev, depth=a.depth, var_rate=a.var_rate)
     torch.cuda.synchronize()
