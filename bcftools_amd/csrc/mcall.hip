@@ -238,11 +238,33 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
         const int nad = P.ad ? P.n_al_max : nals;
         int cur = -1;
         float acc = 0.f;
+        // the next 64 samples' counts and groups are requested before the current ones are normalised and added (the loop
+        // is a chain of memory round trips otherwise)
+        int xn[5], gnx = 0;
+        auto fetch_ad = [&](int base) {
+            const int s = base + tid;
+            #pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                int x = VEND;
+                if (s < S && k < nad) {
+                    if (P.ad) x = P.ad[((size_t)is * P.n_al_max + k) * Ss + s];
+                    else if (P.qs_u16) x = k < nals ? (int)P.qs_u16[((size_t)is * 5 + k) * Ss + s] : VEND;
+                    else x = k < nals ? (int)P.ad_u8[((size_t)is * 5 + k) * Ss + s] + (int)P.ad_u8b[((size_t)is * 5 + k) * Ss + s] : VEND;
+                }
+                xn[k] = x;
+            }
+            gnx = s < S ? P.grp[s] : 0;
+        };
+        fetch_ad(0);
         for (int base = 0; base < S; base += WGS) {
             const int cn = min(WGS, S - base);
             __syncthreads();
+            int xc[5];
+            #pragma unroll
+            for (int k = 0; k < 5; ++k) xc[k] = xn[k];
+            const int gcur = gnx;
+            fetch_ad(base + WGS);
             if (tid < cn) {
-                const int s = base + tid;
                 int v[5];
                 float sum = 0;
                 int nvalid = 0;                                   // values before the first vector_end
@@ -250,17 +272,14 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                 for (int k = 0; k < 5; ++k) {
                     v[k] = VEND;
                     if (k < nad && nvalid == k) {
-                        int x;
-                        if (P.ad) x = P.ad[((size_t)is * P.n_al_max + k) * Ss + s];
-                        else if (P.qs_u16) x = k < nals ? (int)P.qs_u16[((size_t)is * 5 + k) * Ss + s] : VEND;
-                        else x = k < nals ? (int)P.ad_u8[((size_t)is * 5 + k) * Ss + s] + (int)P.ad_u8b[((size_t)is * 5 + k) * Ss + s] : VEND;
+                        const int x = xc[k];
                         if (x != VEND) { v[k] = x; nvalid = k + 1; if (x != MISSING) sum += (float)x; }
                     }
                 }
                 #pragma unroll
                 for (int k = 0; k < 5; ++k)                       // +0 where the reference adds nothing
                     s_fr[k * WGS + tid] = (sum != 0.f && k < nvalid && v[k] != MISSING) ? (float)v[k] / sum : 0.f;
-                s_gg[tid] = P.grp[s];
+                s_gg[tid] = gcur;
             }
             __syncthreads();
             if (tid < 5 && tid < nals) {
