@@ -14,7 +14,7 @@ FMT_DP, FMT_SP, FMT_DV, FMT_DP4, FMT_DPR, INFO_DPR = 1 << 0, 1 << 1, 1 << 2, 1 <
 FMT_AD, FMT_ADF, FMT_ADR, INFO_AD, INFO_ADF, INFO_ADR = 1 << 6, 1 << 7, 1 << 8, 1 << 9, 1 << 10, 1 << 11
 INFO_SCR, FMT_SCR, INFO_VDB, INFO_RPB, FMT_QS = 1 << 12, 1 << 13, 1 << 14, 1 << 15, 1 << 16
 # CALL_* (call.h:32-39)
-CALL_KEEPALT, CALL_VARONLY, CALL_FMT_GQ, CALL_FMT_GP = 1, 1 << 1, 1 << 6, 1 << 7
+CALL_KEEPALT, CALL_VARONLY, CALL_FMT_PV4, CALL_FMT_GQ, CALL_FMT_GP = 1, 1 << 1, 1 << 5, 1 << 6, 1 << 7
 
 MAX_ALLELES, MAX_PL, NPOS, NQUAL, MAX_DEPTH = 5, 15, 100, 60, 255
 INT32_MISSING = -2147483648
@@ -69,7 +69,7 @@ class CallIn(C.Structure):
         ("n_sites", C.c_int32), ("n_gt_max", C.c_int32), ("n_al_max", C.c_int32), ("reserved", C.c_int32),
         ("nals", C.c_void_p), ("unseen", C.c_void_p), ("pl", C.c_void_p), ("qs", C.c_void_p),
         ("ad", C.c_void_p), ("ploidy", C.c_void_p), ("grp", C.c_void_p),
-        ("prior_an", C.c_void_p), ("prior_ac", C.c_void_p),
+        ("prior_an", C.c_void_p), ("prior_ac", C.c_void_p), ("i16", C.c_void_p),
     ]
 
 
@@ -78,6 +78,7 @@ class CallSite(C.Structure):
         ("ret", C.c_int32), ("nals_new", C.c_int32), ("als_new", C.c_int32),
         ("als_map", C.c_int32 * 5), ("ac", C.c_int32 * 5), ("an", C.c_int32),
         ("qual_missing", C.c_int32), ("qual", C.c_float), ("pl_dropped", C.c_int32),
+        ("has_i16", C.c_int32), ("dp4", C.c_int32 * 4), ("mq", C.c_int32), ("pv4_tested", C.c_int32), ("pv4", C.c_float * 4),
     ]
 
 

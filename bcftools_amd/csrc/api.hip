@@ -395,7 +395,7 @@ int bcfgpu_mcall(bcfgpu_ctx *c, const bcfgpu_call_in *in, const bcfgpu_call_out 
     m.pl_is_u8 = 0; m.call_flag = c->cfg.call_flag; m.output_tags = c->cfg.output_tags; m.n_grp = c->cfg.n_grp;
     m.theta = c->call_theta_log; m.pl2p = c->d_pl2p;
     m.nals = in->nals; m.unseen = in->unseen; m.msite = nullptr; m.pl = in->pl; m.qs = in->qs; m.ad = in->ad;
-    m.ploidy = in->ploidy; m.grp = c->cfg.n_grp > 1 ? in->grp : nullptr; m.prior_an = in->prior_an; m.prior_ac = in->prior_ac;
+    m.ploidy = in->ploidy; m.grp = c->cfg.n_grp > 1 ? in->grp : nullptr; m.prior_an = in->prior_an; m.prior_ac = in->prior_ac; m.i16 = in->i16;
     m.out = *out; m.out_n_gt_max = in->n_gt_max;
     if (c->timing == 1) hipEventRecord(c->ev[2], c->stream);
     { const char *ab = getenv("BCFGPU_ABLATE"); m.ablate = ab ? atoi(ab) : 0; }

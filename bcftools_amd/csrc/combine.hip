@@ -13,6 +13,7 @@
 #include <math.h>
 #include <float.h>
 #include "kernels.h"
+#include "kfunc_dev.h"
 
 namespace bcfgpu {
 
@@ -53,73 +54,6 @@ __device__ double dev_kf_erfc(double x)
     return x > 0. ? 2. * p : 2. * (1. - p);
 }
 
-// kf_lgamma and kt_fisher_exact (htslib kfunc.c), for FMT/SP (bam2bcf.c:867-885): the two-sided Fisher exact test of a
-// sample's DP4 table, with kfunc's incremental walk over the hypergeometric terms (re-anchored through lgamma at every
-// n11 divisible by 11, as there) so that the rounded Phred value matches.
-__device__ double dev_kf_lgamma(double z)
-{
-    double x = 0;
-    x += 0.1659470187408462e-06 / (z + 7);
-    x += 0.9934937113930748e-05 / (z + 6);
-    x -= 0.1385710331296526     / (z + 5);
-    x += 12.50734324009056      / (z + 4);
-    x -= 176.6150291498386      / (z + 3);
-    x += 771.3234287757674      / (z + 2);
-    x -= 1259.139216722289      / (z + 1);
-    x += 676.5203681218835      / z;
-    x += 0.9999999999995183;
-    return log(x) - 5.58106146679532777 - z + (z - 0.5) * log(z + 6.5);
-}
-__device__ __forceinline__ double dev_lbinom(int n, int k)
-{
-    if (k == 0 || n == k) return 0;
-    return dev_kf_lgamma(n + 1) - dev_kf_lgamma(k + 1) - dev_kf_lgamma(n - k + 1);
-}
-struct HgAcc { int n11, n1_, n_1, n; double p; };
-__device__ __forceinline__ double dev_hypergeo(const HgAcc &a)
-{
-    return exp(dev_lbinom(a.n1_, a.n11) + dev_lbinom(a.n - a.n1_, a.n_1 - a.n11) - dev_lbinom(a.n, a.n_1));
-}
-// the term for a new n11 (only n11 changes): one multiplication from the neighbouring term where kfunc does that
-__device__ double dev_hypergeo_step(int n11, HgAcc &a)
-{
-    if (n11 % 11 && n11 + a.n - a.n1_ - a.n_1) {
-        if (n11 == a.n11 + 1) {
-            a.p *= (double)(a.n1_ - a.n11) / n11 * (a.n_1 - a.n11) / (n11 + a.n - a.n1_ - a.n_1);
-            a.n11 = n11;
-            return a.p;
-        }
-        if (n11 == a.n11 - 1) {
-            a.p *= (double)a.n11 / (a.n1_ - n11) * (a.n11 + a.n - a.n1_ - a.n_1) / (a.n_1 - n11);
-            a.n11 = n11;
-            return a.p;
-        }
-    }
-    a.n11 = n11;
-    a.p = dev_hypergeo(a);
-    return a.p;
-}
-__device__ double dev_fisher_two_sided(int n11, int n12, int n21, int n22)
-{
-    const int n1_ = n11 + n12, n_1 = n11 + n21, n = n11 + n12 + n21 + n22;
-    const int mx = n_1 < n1_ ? n_1 : n1_;
-    int mn = n1_ + n_1 - n;
-    if (mn < 0) mn = 0;
-    if (mn == mx) return 1.;
-    HgAcc a; a.n11 = n11; a.n1_ = n1_; a.n_1 = n_1; a.n = n;
-    const double q = a.p = dev_hypergeo(a);
-    int i, j;
-    double left, right;
-    double p = dev_hypergeo_step(mn, a);
-    for (left = 0., i = mn + 1; p < 0.99999999 * q && i <= mx; ++i) { left += p; p = dev_hypergeo_step(i, a); }
-    --i;
-    if (p < 1.00000001 * q) left += p;
-    p = dev_hypergeo_step(mx, a);
-    for (right = 0., j = mx - 1; p < 0.99999999 * q && j >= 0; --j) { right += p; p = dev_hypergeo_step(j, a); }
-    if (p < 1.00000001 * q) right += p;
-    const double two = left + right;
-    return two > 1. ? 1. : two;
-}
 __device__ __forceinline__ uint32_t dev_format_sp(uint32_t cnt4)
 {
     const int fr = cnt4 & 0xff, rr = (cnt4 >> 8) & 0xff, fa = (cnt4 >> 16) & 0xff, ra = cnt4 >> 24;

@@ -71,6 +71,7 @@ struct McallParams {
     const uint8_t *ploidy;
     const int32_t *grp;
     const int32_t *prior_an, *prior_ac;
+    const float *i16;               // [site][16] INFO/I16 or NULL (fused: msite->anno)
     bcfgpu_call_out out;
     int out_n_gt_max;               // plane count of out.pl / out.gp
     int ablate;                     // diagnostics only (BCFGPU_ABLATE)

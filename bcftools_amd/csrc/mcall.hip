@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "kernels.h"
+#include "kfunc_dev.h"
 
 namespace bcfgpu {
 
@@ -157,6 +158,8 @@ __device__ __forceinline__ double set_pdg_one(const double *pl2p, int (&pl)[NG],
 __device__ __forceinline__ void write_skipped(bcfgpu_call_site *cs, int ret)
 {
     cs->ret = ret; cs->nals_new = 0; cs->als_new = 0; cs->an = 0; cs->qual = 0; cs->qual_missing = 0; cs->pl_dropped = 0;
+    cs->has_i16 = 0; cs->mq = 0; cs->pv4_tested = 0;
+    for (int i = 0; i < 4; ++i) { cs->dp4[i] = 0; cs->pv4[i] = 0.f; }
     for (int i = 0; i < 5; ++i) { cs->als_map[i] = -1; cs->ac[i] = 0; }
 }
 
@@ -893,6 +896,35 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
         for (int i = 0; i < 5; ++i) cs->als_map[i] = i < nals ? sh.als_map[i] : -1;
         cs->ret = nals_new;
         cs->pl_dropped = ref_only ? 1 : 0;
+        cs->has_i16 = 0; cs->mq = 0; cs->pv4_tested = 0;
+        for (int i = 0; i < 4; ++i) { cs->dp4[i] = 0; cs->pv4[i] = 0.f; }
+    }
+}
+
+// DP4, MQ and PV4 from I16 (mcall.c:1659-1679; test16 of ccall.c:103-138): per-site scalar work with loops of its own
+// (Fisher's exact test, the continued fraction of kf_betai), kept out of mcall_kernel so that its registers stay what the
+// calling needs.  Four lanes per site, one per PV4 test; runs after the calling kernels of the same launch sequence.
+__global__ __launch_bounds__(64) void i16_kernel(const McallParams P)
+{
+    const int is = blockIdx.x * 16 + (threadIdx.x >> 2), k = threadIdx.x & 3;
+    if (is >= P.n_sites) return;
+    bcfgpu_call_site *cs = &P.out.site[is];
+    if (cs->ret <= 0 && cs->nals_new == 0) return;               // a skipped record (write_skipped) carries nothing
+    // the reference reads I16 back from the record as floats
+    float a[16];
+    #pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = P.msite ? (float)P.msite[is].anno[i] : P.i16[(size_t)is * 16 + i];
+    const float depth = a[0] + a[1] + a[2] + a[3];
+    if (k == 0) {
+        cs->has_i16 = 1;
+        for (int i = 0; i < 4; ++i) cs->dp4[i] = (int32_t)a[i];
+        // float division truncated to int32; at depth 0 the reference converts a NaN (x86: INT32_MIN = missing)
+        cs->mq = depth != 0.f ? (int32_t)((a[8] + a[10]) / depth) : BCFGPU_INT32_MISSING;
+    }
+    if (P.output_tags & BCFGPU_CALL_FMT_PV4) {
+        const bool tested = depth != 0.f && a[0] + a[1] > 0 && a[2] + a[3] > 0;
+        if (tested) cs->pv4[k] = (float)dev_test16_one(a, k);
+        if (k == 0) cs->pv4_tested = tested ? 1 : 0;
     }
 }
 
@@ -915,6 +947,7 @@ void launch_mcall(const McallParams &p, hipStream_t s)
         MCALL_LAUNCH3(false, false, true);
     }
     #undef MCALL_LAUNCH3
+    if (p.msite || p.i16) hipLaunchKernelGGL(i16_kernel, dim3((p.n_sites + 15) / 16), dim3(64), 0, s, p);
 }
 
 }  // namespace bcfgpu

@@ -146,7 +146,7 @@ class Context:
         keep = []
         d = abi.CallIn()
         d.n_sites, d.n_gt_max, d.n_al_max = cin.n_sites, cin.n_gt_max, cin.n_al_max
-        for k in ("nals", "unseen", "pl", "qs", "ad", "ploidy", "grp", "prior_an", "prior_ac"):
+        for k in ("nals", "unseen", "pl", "qs", "ad", "ploidy", "grp", "prior_an", "prior_ac", "i16"):
             a = getattr(cin, k)
             if a is not None:
                 b = self.to_device(a)

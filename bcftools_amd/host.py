@@ -19,7 +19,8 @@ SITE_DTYPE = np.dtype([("a", "<i4", 5), ("n_alleles", "<i4"), ("unseen", "<i4"),
 
 CALLSITE_DTYPE = np.dtype([("ret", "<i4"), ("nals_new", "<i4"), ("als_new", "<i4"), ("als_map", "<i4", 5),
                            ("ac", "<i4", 5), ("an", "<i4"), ("qual_missing", "<i4"), ("qual", "<f4"),
-                           ("pl_dropped", "<i4")], align=True)
+                           ("pl_dropped", "<i4"), ("has_i16", "<i4"), ("dp4", "<i4", 4), ("mq", "<i4"),
+                           ("pv4_tested", "<i4"), ("pv4", "<f4", 4)], align=True)
 
 assert SITE_DTYPE.itemsize == C.sizeof(abi.Site), (SITE_DTYPE.itemsize, C.sizeof(abi.Site))
 assert CALLSITE_DTYPE.itemsize == C.sizeof(abi.CallSite)
@@ -96,7 +97,7 @@ class MplpResult:
 class CallInput:
     """Host copy of bcfgpu_call_in."""
 
-    def __init__(self, n_smpl, nals, unseen, pl, qs, ad=None, ploidy=None, grp=None, prior_an=None, prior_ac=None):
+    def __init__(self, n_smpl, nals, unseen, pl, qs, ad=None, ploidy=None, grp=None, prior_an=None, prior_ac=None, i16=None):
         self.n_smpl = n_smpl
         self.nals = np.ascontiguousarray(nals, dtype=np.int32)
         self.unseen = np.ascontiguousarray(unseen, dtype=np.int32)
@@ -107,6 +108,7 @@ class CallInput:
         self.grp = None if grp is None else np.ascontiguousarray(grp, dtype=np.int32)
         self.prior_an = None if prior_an is None else np.ascontiguousarray(prior_an, dtype=np.int32)
         self.prior_ac = None if prior_ac is None else np.ascontiguousarray(prior_ac, dtype=np.int32)
+        self.i16 = None if i16 is None else np.ascontiguousarray(i16, dtype=np.float32)     # [site][16]
         self.n_sites = len(self.nals)
         self.n_gt_max = self.pl.shape[1]
         self.n_al_max = 0 if self.ad is None else self.ad.shape[1]
@@ -116,6 +118,7 @@ class CallInput:
         s.n_sites, s.n_gt_max, s.n_al_max = self.n_sites, self.n_gt_max, self.n_al_max
         s.nals, s.unseen, s.pl, s.qs, s.ad = _p(self.nals), _p(self.unseen), _p(self.pl), _p(self.qs), _p(self.ad)
         s.ploidy, s.grp, s.prior_an, s.prior_ac = _p(self.ploidy), _p(self.grp), _p(self.prior_an), _p(self.prior_ac)
+        s.i16 = _p(self.i16)
         return s
 
 

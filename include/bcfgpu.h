@@ -75,6 +75,7 @@ extern "C" {
 /* call flags: values identical to CALL_* (call.h:32-39) */
 #define BCFGPU_CALL_KEEPALT   1
 #define BCFGPU_CALL_VARONLY   (1<<1)
+#define BCFGPU_CALL_FMT_PV4   (1<<5)
 #define BCFGPU_CALL_FMT_GQ    (1<<6)
 #define BCFGPU_CALL_FMT_GP    (1<<7)
 
@@ -125,7 +126,7 @@ typedef struct {
     /* call side */
     double  call_theta;    /* call -P, default 1.1e-3 (vcfcall.c:931-943); <=0: no prior */
     int32_t call_flag;     /* BCFGPU_CALL_KEEPALT | BCFGPU_CALL_VARONLY */
-    int32_t output_tags;   /* BCFGPU_CALL_FMT_GQ | BCFGPU_CALL_FMT_GP */
+    int32_t output_tags;   /* BCFGPU_CALL_FMT_GQ | BCFGPU_CALL_FMT_GP | BCFGPU_CALL_FMT_PV4 */
     int32_t n_grp;         /* number of -G sample groups; <=1: one pooled group */
     int32_t grp_tag_is_qs; /* -G with FORMAT/QS (1) or FORMAT/AD (0) as frequency source */
     int32_t ploidy_max;    /* ploidy_max(args->ploidy) used for the prior's allele count (vcfcall.c:654-655, mcall.c:397-405); 0 -> 2 */
@@ -194,6 +195,7 @@ typedef struct {
     const int32_t *grp;       /* [n_smpl] group id of each sample, or NULL */
     const int32_t *prior_an;  /* [n_sites] -F AN or NULL */
     const int32_t *prior_ac;  /* [site][4] -F AC, missing/vector_end sentinels allowed, or NULL */
+    const float   *i16;       /* [site][16] INFO/I16, or NULL: then DP4/MQ/PV4 are not produced (has_i16 = 0) */
 } bcfgpu_call_in;
 
 /* per-site result of the call stage */
@@ -207,6 +209,12 @@ typedef struct {
     int32_t qual_missing;     /* 1 when QUAL is '.' (mcall.c:1644) */
     float   qual;             /* rec->qual */
     int32_t pl_dropped;       /* 1 when FORMAT/PL is removed (mcall.c:1583) */
+    /* from INFO/I16 (mcall.c:1659-1679), when I16 is available (fused pipeline, or bcfgpu_call_in.i16): */
+    int32_t has_i16;          /* 0: the four fields below are not set */
+    int32_t dp4[4];           /* INFO/DP4 */
+    int32_t mq;               /* INFO/MQ */
+    int32_t pv4_tested;       /* with BCFGPU_CALL_FMT_PV4: 1 when INFO/PV4 is written (test16: both ref and alt reads present) */
+    float   pv4[4];           /* INFO/PV4: strand (Fisher exact), baseQ, mapQ, tail-distance bias (t-tests), ccall.c:89-138 */
 } bcfgpu_call_site;
 
 /* per-sample results of the call stage:

@@ -37,6 +37,9 @@ const double *orc_errmod_lhet(const orc_errmod *em);
 
 /* htslib kfunc.c */
 double orc_kf_erfc(double x);
+double orc_kf_betai(double a, double b, double x);
+/* test16 (ccall.c:103-138) on INFO/I16: the four PV4 p-values; is_tested as in anno16_t; returns -1 at depth 0 */
+int orc_test16(const float anno[16], double p[4], int *is_tested);
 double orc_kt_fisher_exact(int n11, int n12, int n21, int n22, double *left, double *right, double *two);
 
 /* bam2bcf.c:281-530 */

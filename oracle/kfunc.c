@@ -6,9 +6,14 @@
  *    kt_fisher_exact  bam2bcf.c:878 (FMT/SP)     two-sided Fisher exact test with the
  *                                                incremental hypergeometric walk
  *    kf_lgamma        (used by the above)        Lanczos, g=5.5? 8-term form
+ *    kf_betai         ccall.c:91,100 (PV4)       regularised incomplete beta function, continued fraction evaluated with
+ *                                                the modified Lentz algorithm
+ *    test16           ccall.c:89-138 (PV4)       (bcftools' own: restated from the reference) strand bias by Fisher's
+ *                                                exact test, baseQ / mapQ / tail-distance bias by one-sided t-tests
  *
  *  htslib is not part of /root/reference; parity of these is
- *  pinned through the reference's VDB / SP golden values only.
+ *  pinned through the reference's VDB / SP / PV4 golden values only (PV4: the INFO/PV4 values of
+ *  test/mpileup.c.1.out against the INFO/I16 of test/mpileup.c.vcf, tests/test_oracle_pv4.py).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -140,4 +145,63 @@ int orc_format_sp(int fwd_ref, int rev_ref, int fwd_alt, int rev_alt)
     int x = (int)(-4.343 * log(two) + .499);
     if (x > 255) x = 255;
     return x;
+}
+
+/* kf_betai (htslib kfunc.c): I_x(a,b) by its continued fraction, modified Lentz algorithm */
+#define KF_GAMMA_EPS 1e-14
+#define KF_TINY 1e-290
+static double kf_betai_aux(double a, double b, double x)
+{
+    double C, D, f;
+    int j;
+    if (x == 0.) return 0.;
+    if (x == 1.) return 1.;
+    f = 1.; C = f; D = 0.;
+    for (j = 1; j < 200; ++j) {
+        double aa, d;
+        int m = j >> 1;
+        aa = (j & 1) ? -(a + m) * (a + b + m) * x / ((a + 2*m) * (a + 2*m + 1))
+                     : m * (b - m) * x / ((a + 2*m - 1) * (a + 2*m));
+        D = 1. + aa * D;
+        if (D < KF_TINY) D = KF_TINY;
+        C = 1. + aa / C;
+        if (C < KF_TINY) C = KF_TINY;
+        D = 1. / D;
+        d = C * D;
+        f *= d;
+        if (fabs(d - 1.) < KF_GAMMA_EPS) break;
+    }
+    return exp(kf_lgamma(a+b) - kf_lgamma(a) - kf_lgamma(b) + a * log(x) + b * log(1.-x)) / a / f;
+}
+double orc_kf_betai(double a, double b, double x)
+{
+    return x < (a + 1.) / (a + b + 2.) ? kf_betai_aux(a, b, x) : 1. - kf_betai_aux(b, a, 1. - x);
+}
+
+/* ttest, ccall.c:89-101 */
+static double ttest(int n1, int n2, const float a[4])
+{
+    double t, v, u1, u2;
+    if (n1 == 0 || n2 == 0 || n1 + n2 < 3) return 1.0;
+    u1 = (double)a[0] / n1; u2 = (double)a[2] / n2;
+    if (u1 <= u2) return 1.;
+    t = (u1 - u2) / sqrt(((a[1] - n1 * u1 * u1) + (a[3] - n2 * u2 * u2)) / (n1 + n2 - 2) * (1./n1 + 1./n2));
+    v = n1 + n2 - 2;
+    return t < 0. ? 1. : .5 * orc_kf_betai(.5*v, .5, v/(v+t*t));
+}
+
+/* test16, ccall.c:103-138: p[4], is_tested; returns -1 when the depth is 0 */
+int orc_test16(const float anno[16], double p[4], int *is_tested)
+{
+    double left, right;
+    int i;
+    p[0] = p[1] = p[2] = p[3] = 1.;
+    *is_tested = 0;
+    const float depth = anno[0] + anno[1] + anno[2] + anno[3];
+    *is_tested = (anno[0] + anno[1] > 0 && anno[2] + anno[3] > 0);
+    if (depth == 0) { *is_tested = 0; return -1; }
+    orc_kt_fisher_exact((int)anno[0], (int)anno[1], (int)anno[2], (int)anno[3], &left, &right, &p[0]);
+    for (i = 1; i < 4; ++i)
+        p[i] = ttest((int)(anno[0] + anno[1]), (int)(anno[2] + anno[3]), anno + 4*i);
+    return 0;
 }

@@ -532,6 +532,25 @@ static int mcall_site(call_t *call, const bcfgpu_cfg *cfg, const bcfgpu_call_in 
     for (i = 0; i < nals_ori && i < 5; i++) cs->als_map[i] = call->als_map[i];
     cs->ret = call->nals_new;
 
+    /* DP4, MQ and PV4 from I16 (mcall.c:1659-1679) */
+    if (in->i16) {
+        const float *a16 = in->i16 + (size_t)is*16;
+        cs->has_i16 = 1;
+        for (i = 0; i < 4; i++) cs->dp4[i] = (int32_t) a16[i];
+        {   /* float division truncated to int32; at depth 0 the reference converts a NaN, which x86 turns into
+             * INT32_MIN = bcf_int32_missing: MQ is then printed as '.' */
+            const float dsum = a16[0] + a16[1] + a16[2] + a16[3];
+            cs->mq = dsum != 0 ? (int32_t)((a16[8] + a16[10]) / dsum) : BCFGPU_INT32_MISSING;
+        }
+        if (call->output_tags & BCFGPU_CALL_FMT_PV4) {
+            double p4[4]; int tested;
+            if (orc_test16(a16, p4, &tested) >= 0 && tested) {
+                cs->pv4_tested = 1;
+                for (i = 0; i < 4; i++) cs->pv4[i] = (float) p4[i];
+            }
+        }
+    }
+
     for (i = 0; i < nsmpl; i++) {
         out->gt[((size_t)is*2 + 0)*S + i] = (int8_t) call->gts[2*i];
         out->gt[((size_t)is*2 + 1)*S + i] = (int8_t) call->gts[2*i+1];

@@ -51,7 +51,7 @@ def parse_samples_file(path):
 
 class CalledRec:
     __slots__ = ("src", "alleles", "qual", "qual_missing", "ac", "an", "gt", "pl", "gq", "gp", "als_map",
-                 "dp4", "mq", "pl_dropped", "ploidy")
+                 "dp4", "mq", "pl_dropped", "ploidy", "pv4")
 
 
 def fmt_gt(a, b):
@@ -137,6 +137,8 @@ def run_call(vcf, engine, call_flag=0, output_tags=0, theta=1.1e-3, samples=None
         ad = np.full((n, namax, S), abi.INT32_VECTOR_END, dtype=np.int32) if ngrp > 1 else None
         nals = np.zeros(n, dtype=np.int32)
         uns = np.zeros(n, dtype=np.int32)
+        i16 = np.zeros((n, 16), dtype=np.float32)
+        has16 = all("I16" in r.info for r, _, _ in batch)
         pan = np.full(n, abi.INT32_MISSING, dtype=np.int32) if prior else None
         pac = np.full((n, 4), abi.INT32_VECTOR_END, dtype=np.int32) if prior else None
         for k, (rec, unseen, _) in enumerate(batch):
@@ -150,6 +152,8 @@ def run_call(vcf, engine, call_flag=0, output_tags=0, theta=1.1e-3, samples=None
                     a = rec.fmt_ints(grp_tag, c, na)
                     if a is not None:
                         ad[k, :na, si] = a
+            if has16:
+                i16[k] = rec.info_floats("I16")
             if "QS" in rec.info:
                 q = rec.info_floats("QS")[:5]
                 qs[k, :len(q)] = q
@@ -160,7 +164,7 @@ def run_call(vcf, engine, call_flag=0, output_tags=0, theta=1.1e-3, samples=None
                     if prior[1] in rec.info:
                         acv = rec.info_ints(prior[1])[:4]
                         pac[k, :len(acv)] = acv
-        cin = orc.CallInput(S, nals, uns, pl, qs, ad=ad, ploidy=pv, grp=grp, prior_an=pan, prior_ac=pac)
+        cin = orc.CallInput(S, nals, uns, pl, qs, ad=ad, ploidy=pv, grp=grp, prior_an=pan, prior_ac=pac, i16=i16 if has16 else None)
         res = engine(cfg, cin)
         for k, (rec, unseen, _) in enumerate(batch):
             st = res.site[k]
@@ -191,13 +195,12 @@ def run_call(vcf, engine, call_flag=0, output_tags=0, theta=1.1e-3, samples=None
             c.pl = None if c.pl_dropped else [res.pl[k, :ngn, s].tolist() for s in range(S)]
             c.gq = [int(res.gq[k, s]) for s in range(S)]
             c.gp = [res.gp[k, :ngn, s].copy() for s in range(S)]
-            if "I16" in rec.info:
-                a16 = np.array(rec.info_floats("I16"), dtype=np.float32)
-                c.dp4 = [int(a16[0]), int(a16[1]), int(a16[2]), int(a16[3])]
-                c.mq = int(np.float32(a16[8] + a16[10]) / np.float32(np.float32(a16[0] + a16[1]) + a16[2] + a16[3])) \
-                    if (a16[0] + a16[1] + a16[2] + a16[3]) > 0 else 0
+            # DP4 and MQ as the engine derives them from I16 (mcall.c:1659-1666)
+            if int(st["has_i16"]):
+                c.dp4, c.mq = [int(x) for x in st["dp4"]], int(st["mq"])
+                c.pv4 = [float(x) for x in st["pv4"]] if int(st["pv4_tested"]) else None
             else:
-                c.dp4, c.mq = None, None
+                c.dp4, c.mq, c.pv4 = None, None, None
             out.append(c)
     return out, sub_names
 

@@ -90,7 +90,8 @@ def test_sampled_sites_match_oracle(big):
     sub = tile.select_sites(pick)
     scfg = abi.default_cfg(N_SMPL, max_sites=sub.n_sites, max_reads=len(sub.rd), fmt_flag=FMT)
     mw = orc.mpileup(scfg, sub)
-    cin = host.CallInput(N_SMPL, mw.site["n_alleles"], np.maximum(mw.site["unseen"], 0), mw.pl.astype(np.int32), mw.site["qsum"])
+    cin = host.CallInput(N_SMPL, mw.site["n_alleles"], np.maximum(mw.site["unseen"], 0), mw.pl.astype(np.int32), mw.site["qsum"],
+                         i16=mw.site["anno"].astype(np.float32))
     cw = orc.mcall(scfg, cin)
 
     class Rows:                                            # the picked rows of the full-size results

@@ -79,15 +79,26 @@ def random_records(seed, n_sites, n_smpl, use_ploidy, n_grp, use_prior):
                 prior_ac[k, :na - 1] = rng.multinomial(40, np.full(na - 1, 1.0 / (na - 1)))
             if rng.random() < 0.2:
                 prior_an[k] = MISSING
-    return host.CallInput(n_smpl, nals, unseen, pl, qs, ad=ad, ploidy=ploidy, grp=grp, prior_an=prior_an, prior_ac=prior_ac)
+    # INFO/I16 with arbitrary (consistent) moments: counts, then sum and sum of squares of three quantities for ref and alt
+    i16 = np.zeros((n_sites, 16), dtype=np.float32)
+    for k in range(n_sites):
+        cnt = rng.integers(0, 40, 4) * (rng.random(4) < 0.8)
+        i16[k, :4] = cnt
+        for t in range(3):
+            for side, n in ((0, int(cnt[0] + cnt[1])), (1, int(cnt[2] + cnt[3]))):
+                v = rng.integers(0, 60, n) if n else np.zeros(0)
+                i16[k, 4 + 4 * t + 2 * side] = v.sum()
+                i16[k, 5 + 4 * t + 2 * side] = (v * v).sum()
+    return host.CallInput(n_smpl, nals, unseen, pl, qs, ad=ad, ploidy=ploidy, grp=grp, prior_an=prior_an, prior_ac=prior_ac,
+                          i16=i16 if seed % 2 else None)
 
 
 @pytest.mark.parametrize("seed,n_sites,n_smpl,use_ploidy,n_grp,use_prior,flags,tags", [
-    (1, 60, 40, False, 1, False, 0, 0),
+    (1, 60, 40, False, 1, False, 0, abi.CALL_FMT_PV4),
     (2, 60, 70, True, 1, False, 0, abi.CALL_FMT_GQ | abi.CALL_FMT_GP),
-    (3, 40, 33, True, 3, False, abi.CALL_VARONLY, 0),
+    (3, 40, 33, True, 3, False, abi.CALL_VARONLY, abi.CALL_FMT_PV4),
     (4, 40, 20, False, 1, True, abi.CALL_KEEPALT, abi.CALL_FMT_GQ),
-    (5, 30, 130, True, 4, True, 0, 0),
+    (5, 30, 130, True, 4, True, 0, abi.CALL_FMT_PV4),
     (6, 80, 1, False, 1, False, 0, abi.CALL_FMT_GP),
 ])
 def test_mcall_matches_oracle_on_random_records(gpu_ctx_factory, seed, n_sites, n_smpl, use_ploidy, n_grp, use_prior, flags, tags):
@@ -106,3 +117,32 @@ def test_mcall_matches_oracle_on_random_records(gpu_ctx_factory, seed, n_sites, 
             g, w = got.gp[i, :ng], want.gp[i, :ng]
             assert np.array_equal(np.isnan(g), np.isnan(w))
             np.testing.assert_allclose(g[~np.isnan(w)], w[~np.isnan(w)], rtol=1e-5, atol=1e-7)
+
+
+def test_pv4_of_reference_golden_on_device(golden_dir, gpu_ctx_factory):
+    """INFO/PV4, DP4 of the reference's golden test/mpileup.c.1.out (test.pl:298) from the INFO/I16 of its input, through
+    bcfgpu_mcall with the I16 vectors attached to dummy one-sample records (the calling itself is not what is checked)."""
+    import os
+    from tests.helpers import vcf
+    g = os.path.join(golden_dir, "call")
+    src = {(r.pos, "INDEL" in r.info): r for r in vcf.Vcf(os.path.join(g, "mpileup.c.vcf")).recs}
+    out = [r for r in vcf.Vcf(os.path.join(g, "mpileup.c.1.out")).recs]
+    n = len(out)
+    i16 = np.array([src[(r.pos, "INDEL" in r.info)].info_floats("I16") for r in out], dtype=np.float32)
+    pl = np.zeros((n, 3, 1), dtype=np.int32)
+    pl[:, 1, 0], pl[:, 2, 0] = 30, 60
+    cin = host.CallInput(1, np.full(n, 2, np.int32), np.zeros(n, np.int32), pl, np.tile(np.array([[0.9, 0.1, 0, 0, 0]], np.float32), (n, 1)),
+                         i16=i16)
+    cfg = abi.default_cfg(1, max_sites=n, output_tags=abi.CALL_FMT_PV4)
+    got = gpu_ctx_factory(cfg).mcall(cin)
+    n_pv4 = 0
+    for k, r in enumerate(out):
+        st = got.site[k]
+        assert int(st["has_i16"]) == 1 and [int(x) for x in st["dp4"]] == r.info_ints("DP4")
+        if "PV4" in r.info:
+            assert int(st["pv4_tested"]) == 1
+            np.testing.assert_allclose(st["pv4"], r.info_floats("PV4"), rtol=5e-6, atol=1e-12)
+            n_pv4 += 1
+        else:
+            assert int(st["pv4_tested"]) == 0
+    assert n_pv4 == 11

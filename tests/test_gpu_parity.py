@@ -27,8 +27,9 @@ def assert_mplp_equal(got, want, float_rtol=2e-6):
 
 
 def assert_call_equal(got, want, n_smpl, qual_tol=1e-4):
-    for k in ["ret", "nals_new", "als_new", "als_map", "ac", "an", "qual_missing", "pl_dropped"]:
+    for k in ["ret", "nals_new", "als_new", "als_map", "ac", "an", "qual_missing", "pl_dropped", "has_i16", "dp4", "mq", "pv4_tested"]:
         np.testing.assert_array_equal(got.site[k], want.site[k], err_msg="call." + k)
+    np.testing.assert_allclose(got.site["pv4"], want.site["pv4"], rtol=2e-6, atol=1e-30, err_msg="call.pv4")
     np.testing.assert_allclose(got.site["qual"], want.site["qual"], rtol=qual_tol, atol=qual_tol)
     live = want.site["ret"] > 0
     np.testing.assert_array_equal(got.gt[live], want.gt[live], err_msg="gt")
@@ -80,7 +81,7 @@ def test_mpileup_unbinned_qualities(gpu_ctx_factory, n_sites, n_smpl, depth, var
 
 
 @pytest.mark.parametrize("n_sites,n_smpl,seed,flags,tags", [
-    (64, 100, 11, 0, 0),
+    (64, 100, 11, 0, abi.CALL_FMT_PV4),
     (64, 100, 12, abi.CALL_VARONLY, 0),
     (32, 1000, 13, 0, abi.CALL_FMT_GQ | abi.CALL_FMT_GP),
     (100, 5, 14, abi.CALL_KEEPALT, abi.CALL_FMT_GQ),
@@ -92,7 +93,7 @@ def test_pipeline_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, seed, flags, 
     ploidy = rng.choice([1, 2, 2, 2], size=n_smpl).astype(np.uint8)
     mwant = orc.mpileup(cfg, tile)
     cin = host.CallInput(n_smpl, mwant.site["n_alleles"], np.maximum(mwant.site["unseen"], 0),
-                         mwant.pl.astype(np.int32), mwant.site["qsum"], ploidy=ploidy)
+                         mwant.pl.astype(np.int32), mwant.site["qsum"], ploidy=ploidy, i16=mwant.site["anno"].astype(np.float32))
     cwant = orc.mcall(cfg, cin)
     ctx = gpu_ctx_factory(cfg)
     mgot, cgot = ctx.pipeline(tile, ploidy=ploidy)
@@ -104,12 +105,12 @@ def test_pipeline_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, seed, flags, 
 
 
 @pytest.mark.parametrize("n_sites,n_smpl,depth,seed,flags,tags", [
-    (64, 1000, 30.0, 21, 0, 0),                         # config[3]-shaped cohort
+    (64, 1000, 30.0, 21, 0, abi.CALL_FMT_PV4),          # config[3]-shaped cohort; PV4 from the mpileup stage's I16
     (64, 999, 8.0, 22, 0, abi.CALL_FMT_GQ),             # sample count not a multiple of 4 (ragged plane tail)
     (128, 37, 0.7, 23, 0, 0),                           # most samples carry no reads at a site
     (128, 130, 3.0, 24, abi.CALL_VARONLY, 0),
     (200, 1, 20.0, 25, 0, abi.CALL_FMT_GQ | abi.CALL_FMT_GP),
-    (100, 17, 12.0, 26, abi.CALL_KEEPALT, 0),
+    (100, 17, 12.0, 26, abi.CALL_KEEPALT, abi.CALL_FMT_PV4),
 ])
 def test_pipeline_diploid_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth, seed, flags, tags):
     """All-diploid, single-group calling from the mpileup stage's u8 PL planes: the allele-subset scan runs on
@@ -118,7 +119,7 @@ def test_pipeline_diploid_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth
     cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), call_flag=flags, output_tags=tags)
     mwant = orc.mpileup(cfg, tile)
     cin = host.CallInput(n_smpl, mwant.site["n_alleles"], np.maximum(mwant.site["unseen"], 0),
-                         mwant.pl.astype(np.int32), mwant.site["qsum"])
+                         mwant.pl.astype(np.int32), mwant.site["qsum"], i16=mwant.site["anno"].astype(np.float32))
     cwant = orc.mcall(cfg, cin)
     ctx = gpu_ctx_factory(cfg)
     mgot, cgot = ctx.pipeline(tile)
@@ -148,7 +149,7 @@ def test_pipeline_with_sample_groups_matches_oracle(gpu_ctx_factory, n_sites, n_
     na = mwant.site["n_alleles"]
     ad = np.where(np.arange(5)[None, :, None] < na[:, None, None], src, abi.INT32_VECTOR_END).astype(np.int32)
     cin = host.CallInput(n_smpl, na, np.maximum(mwant.site["unseen"], 0), mwant.pl.astype(np.int32), mwant.site["qsum"],
-                         ad=ad, ploidy=ploidy, grp=grp)
+                         ad=ad, ploidy=ploidy, grp=grp, i16=mwant.site["anno"].astype(np.float32))
     cwant = orc.mcall(cfg, cin)
     mgot, cgot = gpu_ctx_factory(cfg).pipeline(tile, ploidy=ploidy, grp=grp)
     assert_mplp_equal(mgot, mwant)
