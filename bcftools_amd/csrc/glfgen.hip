@@ -49,6 +49,9 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 #define LDS_FK   0
 #define LDS_CNT  2112
 #define NSLOT    16
+#ifndef FU
+#define FU       4         // source elements per trip of the slot counting
+#endif
 #ifndef WSTEP
 #define WSTEP    3         // reads of one (quality, strand) run taken per step of the errmod walk
 #endif
@@ -67,10 +70,15 @@ __device__ __forceinline__ void fill_slots(uint32_t *s_slot, uint64_t qm, int ti
 {
     #pragma unroll
     for (int k = 0; k < NSLOT / 4; ++k) s_slot[k * WG + tid] = 0;
-    for (int j = 0; __any(j < nsrc); ++j) {
-        if (j < nsrc) {
-            const int key = src(j);
-            const int q = key >> 1;
+    // FU source elements per trip: their reads are in flight before the first count is added
+    for (int j = 0; __any(j < nsrc); j += FU) {
+        int k4[FU];
+        #pragma unroll
+        for (int u = 0; u < FU; ++u) k4[u] = j + u < nsrc ? src(j + u) : -1;
+        #pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int key = k4[u];
+            const int q = (key >> 1) & 63;
             if (key >= 0 && (FIRST || ((qm >> q) & 1ull))) {       // FIRST: the mask still holds every quality of the source
                 const int r = 2 * __popcll((qm >> q) >> 1) + 1 - (key & 1);
                 if (r < NSLOT) atomicAdd(&s_slot[(r >> 2) * WG + tid], 1u << (8 * (r & 3)));
