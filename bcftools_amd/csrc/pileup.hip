@@ -1,0 +1,370 @@
+// pileup.hip -- the pileup itself on the device: from the reads of a region (a flat pool, as bcfgpu_baq and
+// bcfgpu_gap_prep take it) to the site x sample x read tile that bcfgpu_mpileup / bcfgpu_pipeline run on.
+//
+// In the reference this is htslib's bam_mplp iterator plus the per-read accessors of bcf_call_glfgen (mpileup.c:320-347,
+// bam2bcf.c:170-236): every pileup column lists, per sample, the reads covering the position with their query offset,
+// is_del / is_refskip and the following indel.  A host-built tile costs 5 bytes per (read, position) over PCIe; the read
+// pool it is built from is ~30x smaller (a 100-bp read is in 100 columns), so building the tile in HBM takes the PCIe
+// link out of the way of the kernels.
+//
+// Mapping: one lane per (site, sample) cell -- the same gather-by-cell shape as glfgen_kernel, no atomics.  The reads of
+// a sample are in ascending position order (a sorted BAM), so the reads that can cover position x are the window
+// [first read with pos > x - max_span, first read with pos > x): two binary searches, then a scan of ~depth
+// candidates.  Pass 1 counts the covering reads of every cell, a prefix sum gives plp_off, pass 2 resolves every
+// covering read's CIGAR at x (query offset, deletion / reference skip, indel after the position: htslib's
+// resolve_cigar) and writes the packed records of bcfgpu_pack_read into the cell's slice, in read order.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
+#include "kernels.h"
+
+extern "C" int bcfgpu_internal_device(bcfgpu_ctx *ctx, hipStream_t *stream, const float **q2p);
+extern "C" void *bcfgpu_internal_ws(bcfgpu_ctx *ctx, int slot, size_t bytes);
+extern "C" const bcfgpu_cfg *bcfgpu_internal_cfg(const bcfgpu_ctx *ctx);
+int bcfgpu_set_error(int code, const char *what);
+
+namespace bcfgpu {
+
+// what a pileup entry needs from its read, in one 32-byte record (two 16-byte gathers per entry instead of nine scalar
+// ones); a read whose CIGAR is a single operation -- the common case -- needs no CIGAR access at all
+struct ReadMeta {
+    int32_t pos, end;               // reference span [pos, end)
+    uint32_t seq_off, cig_off;
+    uint16_t lq, ntot;              // query length; M/=/X/I bases (get_position's denominator)
+    uint8_t ncig, bits, mapq, pad;  // bits: 1 reverse strand, 2 has a soft clip, 4 unmapped
+    uint32_t cig0;                  // the first CIGAR operation
+    uint32_t pad2;
+};
+static_assert(sizeof(ReadMeta) == 32, "one read = two 16-byte loads");
+
+struct PileupParams {
+    int n_sites, n_smpl, beg, want_epos, max_span;
+    // reads in (sample, position) order: index k of the sorted list
+    const int32_t *smpl_off;        // [n_smpl+1] into the sorted list
+    const int32_t *s_pos;           // [n_reads] reference start of sorted read k (the binary searches)
+    const ReadMeta *meta;           // [n_reads] everything else about sorted read k, one 32-byte record
+    const uint32_t *cig;
+    const uint8_t *seq16, *qual;
+    // out
+    uint32_t *cnt;                  // [n_cells + 1] pass 1: reads per cell; after the scan: plp_off
+    uint32_t *rd; uint8_t *epos;    // pass 2
+    uint32_t *col_indel;            // [n_sites] != 0 when some entry of the column is followed by an indel
+};
+
+// first k in [lo, hi) with a[k] > x
+__device__ __forceinline__ int upper_bound(const int32_t *a, int lo, int hi, int x)
+{
+    while (lo < hi) { const int m = (lo + hi) >> 1; if (a[m] > x) hi = m; else lo = m + 1; }
+    return lo;
+}
+
+// entries a workgroup's 256 cells may hold for their records to be collected in LDS and written out as one contiguous
+// span (a lane's own stores are 4 + 1 bytes per entry, 120 bytes apart from its neighbour's)
+#define PILEUP_LDS_CAP 9216
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
+{
+    __shared__ uint32_t s_rd[FILL ? PILEUP_LDS_CAP : 1];
+    __shared__ uint8_t s_ep[FILL ? PILEUP_LDS_CAP : 4];
+    const long cell0 = (long)blockIdx.x * 256;
+    const long cell = cell0 + threadIdx.x;
+    const long ncells = (long)P.n_sites * P.n_smpl;
+    // the workgroup's span of the output (plp_off is known in the fill pass)
+    uint32_t span0 = 0, span_n = 0;
+    bool staged = false;
+    if (FILL) {
+        span0 = P.cnt[cell0];
+        span_n = P.cnt[cell0 + 256 < ncells ? cell0 + 256 : ncells] - span0;
+        staged = span_n <= PILEUP_LDS_CAP;
+    }
+    if (cell < ncells) {
+    const int site = (int)(cell / P.n_smpl), s = (int)(cell - (long)site * P.n_smpl);
+    const int x = P.beg + site;
+    const int lo0 = P.smpl_off[s], hi0 = P.smpl_off[s + 1];
+    const int hi = upper_bound(P.s_pos, lo0, hi0, x);                    // reads starting at or before x
+    const int lo = upper_bound(P.s_pos, lo0, hi, x - P.max_span);        // ... that can still reach x
+    if (!FILL) {
+        uint32_t n = 0;
+        for (int k = lo; k < hi; ++k) n += P.meta[k].end > x ? 1u : 0u;
+        P.cnt[cell] = n;
+        return;
+    }
+    uint32_t o = P.cnt[cell];                                            // plp_off after the scan
+
+    uint32_t any_indel = 0;
+    for (int k = lo; k < hi; ++k) {
+        const uint4 m0 = reinterpret_cast<const uint4*>(P.meta + k)[0];
+        if ((int)m0.y <= x) continue;
+        const uint4 m1 = reinterpret_cast<const uint4*>(P.meta + k)[1];
+        const int rpos = (int)m0.x, lq = (int)(m1.x & 0xffff), ntot = (int)(m1.x >> 16);
+        const int ncig = (int)(m1.y & 0xff);
+        const uint32_t bits = (m1.y >> 8) & 0xff, mapq = (m1.y >> 16) & 0xff, so = m0.z;
+        const uint32_t *cg = P.cig + m0.w;
+        int qpos = 0, is_del = 0, is_skip = 0, indel = 0, edist;
+        const int op0 = m1.z & 0xf;
+        if (ncig == 1 && (op0 == 0 || op0 == 7 || op0 == 8)) {          // one aligned block: nothing to resolve
+            qpos = x - rpos;
+            edist = qpos + 1;
+        } else {
+            // htslib's resolve_cigar at reference position x
+            int rx = rpos, y = 0;
+            for (int c = 0; c < ncig; ++c) {
+                const int op = cg[c] & 0xf, l = (int)(cg[c] >> 4);
+                if (op == 0 || op == 7 || op == 8) {
+                    if (x < rx + l) {
+                        qpos = y + (x - rx);
+                        if (x == rx + l - 1) {                           // last base of the block: what follows?
+                            int cc = c + 1;
+                            while (cc < ncig && (cg[cc] & 0xf) == 6) ++cc;   // pads
+                            if (cc < ncig) {
+                                const int nop = cg[cc] & 0xf;
+                                if (nop == 1) {
+                                    indel = (int)(cg[cc] >> 4);
+                                    for (++cc; cc < ncig && ((cg[cc] & 0xf) == 1 || (cg[cc] & 0xf) == 6); ++cc)
+                                        if ((cg[cc] & 0xf) == 1) indel += (int)(cg[cc] >> 4);
+                                } else if (nop == 2) indel = -(int)(cg[cc] >> 4);
+                            }
+                        }
+                        break;
+                    }
+                    rx += l; y += l;
+                } else if (op == 2 || op == 3) {
+                    if (x < rx + l) { qpos = y; is_del = 1; is_skip = op == 3; break; }
+                    rx += l;
+                } else if (op == 1 || op == 4) y += l;
+            }
+            any_indel |= indel != 0;
+            // get_position, bam2bcf.c:80-114
+            int iread = 0;
+            edist = qpos + 1;
+            if (P.want_epos && (bits & 2))
+                for (int c = 0; c < ncig; ++c) {
+                    const int op = cg[c] & 0xf, l = (int)(cg[c] >> 4);
+                    if (op == 0 || op == 7 || op == 8 || op == 1) iread += l;
+                    else if (op == 4) { iread += l; if (iread <= qpos) edist -= l; }
+                }
+        }
+        // the record of bcfgpu_pack_read
+        const int nt = qpos < lq ? (P.seq16[so + qpos] & 15) : 15;
+        const int bq = qpos < lq ? P.qual[so + qpos] : 0;
+        int tail = lq - 1 - qpos;
+        if (tail > qpos) tail = qpos;
+        tail = tail < 0 ? 0 : tail > 255 ? 255 : tail;
+        const uint32_t word = (uint32_t)bq | mapq << 8 | (uint32_t)nt << 16 | ((bits & 1) ? BCFGPU_RD_REV : 0)
+                | ((bits & 2) ? BCFGPU_RD_SCLIP : 0) | (is_del ? BCFGPU_RD_DEL : 0)
+                | ((is_skip || (bits & 4)) ? BCFGPU_RD_SKIP : 0) | (uint32_t)tail << 24;
+        int e = 0;
+        if (P.want_epos) {
+            e = (int)((double)edist / (ntot + 1) * BCFGPU_NPOS);
+            e = e < 0 ? 0 : e > BCFGPU_NPOS - 1 ? BCFGPU_NPOS - 1 : e;
+        }
+        if (staged) { s_rd[o - span0] = word; s_ep[o - span0] = (uint8_t)e; }
+        else { P.rd[o] = word; P.epos[o] = (uint8_t)e; }
+        ++o;
+    }
+    if (any_indel && P.col_indel) atomicOr(&P.col_indel[site], 1u);
+    }
+    if (FILL && staged) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < span_n; i += 256) P.rd[span0 + i] = s_rd[i];
+        // the bytes: single ones up to a 4-byte boundary of the output, then words, then the rest
+        const uint32_t head = min((4u - (span0 & 3u)) & 3u, span_n), nw = (span_n - head) >> 2, tail0 = head + 4 * nw;
+        if (threadIdx.x < head) P.epos[span0 + threadIdx.x] = s_ep[threadIdx.x];
+        for (uint32_t i = threadIdx.x; i < nw; i += 256) {
+            const uint8_t *b = s_ep + head + 4 * i;
+            *reinterpret_cast<uint32_t*>(P.epos + span0 + head + 4 * i) = (uint32_t)b[0] | (uint32_t)b[1] << 8 | (uint32_t)b[2] << 16 | (uint32_t)b[3] << 24;
+        }
+        if (threadIdx.x < span_n - tail0) P.epos[span0 + tail0 + threadIdx.x] = s_ep[tail0 + threadIdx.x];
+    }
+}
+
+}  // namespace bcfgpu
+
+using namespace bcfgpu;
+
+// seq_nt16_table restricted to what a reference sequence holds (IUPAC codes, case-insensitive; anything else is N)
+static int ref_nt16(char c)
+{
+    static const char *codes = "=ACMGRSVTWYHKDBN";
+    if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+    for (int i = 1; i < 16; ++i) if (codes[i] == c) return i;
+    return 15;
+}
+
+extern "C" int bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const uint8_t *r_mapq, const int32_t *r_smpl,
+                             int32_t beg, int32_t end, const char *ref, int32_t ref_len,
+                             bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel)
+{
+    if (!ctx || !rd || !tile || end < beg || rd->n_reads < 0 || (rd->n_reads && (!r_mapq || !r_smpl)) || (ref_len > 0 && !ref))
+        return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup: bad arguments");
+    hipStream_t stream = nullptr;
+    if (bcfgpu_internal_device(ctx, &stream, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup: bad context");
+    const bcfgpu_cfg *cfg = bcfgpu_internal_cfg(ctx);
+    const int n = rd->n_reads, n_sites = end - beg, S = cfg->n_smpl;
+    const bool trace = getenv("BCFGPU_TRACE") != nullptr;          // diagnostics: host timeline on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_now = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    const size_t ncells = (size_t)n_sites * S;
+    std::memset(tile, 0, sizeof *tile);
+    if (ncells >> 31) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_pileup: region x samples too large for one tile");
+    // ---- host: reads grouped by sample (usually they already are: one file per sample), then one record per read with its
+    // reference span and constants (a pass over the CIGARs, on up to 16 threads) ----
+    // (grow-only scratch kept per calling thread: mapping and unmapping 200 MB per call costs more than filling it, and a
+    // std::vector would zero it on one thread first)
+    static thread_local struct Scratch { void *p = nullptr; size_t bytes = 0; ~Scratch() { free(p); } } scratch;
+    {
+        const size_t want = (size_t)(n ? n : 1) * (sizeof(ReadMeta) + 8) + 64;
+        if (scratch.bytes < want) {
+            free(scratch.p);
+            scratch.p = malloc(want + want / 8);
+            scratch.bytes = scratch.p ? want + want / 8 : 0;
+            if (!scratch.p) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup: host scratch");
+        }
+    }
+    ReadMeta *meta = static_cast<ReadMeta*>(scratch.p);
+    int32_t *s_read = reinterpret_cast<int32_t*>(meta + (n ? n : 1)), *s_pos = s_read + (n ? n : 1);
+    std::vector<int32_t> smpl_off(S + 1, 0);
+    bool grouped = true;
+    for (int r = 0; r < n; ++r) {
+        if (r_smpl[r] < 0 || r_smpl[r] >= S) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup: sample index out of range");
+        if (r && r_smpl[r] < r_smpl[r - 1]) grouped = false;
+        ++smpl_off[r_smpl[r] + 1];
+    }
+    for (int s = 0; s < S; ++s) smpl_off[s + 1] += smpl_off[s];
+    if (!grouped) {   // counting sort by sample, the given order kept inside a sample
+        std::vector<int32_t> cur(smpl_off.begin(), smpl_off.end() - 1);
+        for (int r = 0; r < n; ++r) s_read[cur[r_smpl[r]]++] = r;
+    }
+    int nthr = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("BCFGPU_HOST_THREADS")) nthr = atoi(e);
+    nthr = std::max(1, std::min(std::min(nthr, 16), n / 65536 + 1));
+    std::vector<int> t_span(nthr, 1), t_bad(nthr, 0);
+    std::vector<size_t> t_nbase(nthr, 0), t_ncig(nthr, 0);
+    auto fill_meta = [&](int t) {
+        const int k0 = (int)((long)n * t / nthr), k1 = (int)((long)n * (t + 1) / nthr);
+        int span = 1, bad = 0;                    // (thread-local: the per-thread result slots share cache lines)
+        size_t nb = 0, nc = 0;
+        for (int k = k0; k < k1; ++k) {
+            if (grouped) s_read[k] = k;
+            const int r = s_read[k];
+            const uint32_t *cg = rd->cig + rd->r_cig_off[r];
+            int x = rd->r_pos[r], ntot = 0, scl = 0;
+            for (int c = 0; c < rd->r_ncig[r]; ++c) {
+                const int op = cg[c] & 0xf, l = (int)(cg[c] >> 4);
+                if (op == 0 || op == 7 || op == 8) { x += l; ntot += l; }
+                else if (op == 2 || op == 3) x += l;
+                else if (op == 1) ntot += l;
+                else if (op == 4) scl = 1;
+            }
+            ReadMeta &m = meta[k];
+            m.pos = rd->r_pos[r]; m.end = x; m.seq_off = (uint32_t)rd->r_seq_off[r]; m.cig_off = (uint32_t)rd->r_cig_off[r];
+            if (rd->r_lq[r] > 65535 || ntot > 65535 || rd->r_ncig[r] > 255) { bad = 1; continue; }
+            m.lq = (uint16_t)rd->r_lq[r]; m.ntot = (uint16_t)ntot; m.ncig = (uint8_t)rd->r_ncig[r];
+            m.bits = (uint8_t)(((rd->r_flag[r] & 16) ? 1 : 0) | (scl ? 2 : 0) | ((rd->r_flag[r] & 4) ? 4 : 0));
+            m.mapq = r_mapq[r]; m.pad = 0; m.cig0 = rd->r_ncig[r] ? cg[0] : 0; m.pad2 = 0;
+            s_pos[k] = m.pos;
+            if (x - m.pos > span) span = x - m.pos;
+            const size_t e = (size_t)rd->r_seq_off[r] + rd->r_lq[r], c = (size_t)rd->r_cig_off[r] + rd->r_ncig[r];
+            if (e > nb) nb = e;
+            if (c > nc) nc = c;
+            if (k > k0 && r_smpl[r] == r_smpl[s_read[k - 1]] && m.pos < s_pos[k - 1] && !bad) bad = 2;
+        }
+        t_span[t] = span; t_bad[t] = bad; t_nbase[t] = nb; t_ncig[t] = nc;
+    };
+    {
+        std::vector<std::thread> thr;
+        for (int t = 1; t < nthr; ++t) thr.emplace_back(fill_meta, t);
+        fill_meta(0);
+        for (auto &th : thr) th.join();
+    }
+    size_t nbase = 0, ncig = 0;
+    int max_span = 1;
+    for (int t = 0; t < nthr; ++t) {
+        if (t_bad[t] == 1) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_pileup: a read is longer than 65535 bases or has more than 255 CIGAR operations");
+        if (t_bad[t] == 2) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup: the reads of a sample are not in position order");
+        max_span = std::max(max_span, t_span[t]); nbase = std::max(nbase, t_nbase[t]); ncig = std::max(ncig, t_ncig[t]);
+    }
+    for (int t = 1; t < nthr; ++t) {          // order across the threads' chunk boundaries
+        const int k = (int)((long)n * t / nthr);
+        if (k > 0 && k < n && r_smpl[s_read[k]] == r_smpl[s_read[k - 1]] && s_pos[k] < s_pos[k - 1])
+            return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup: the reads of a sample are not in position order");
+    }
+    std::vector<int8_t> ref16(n_sites);
+    for (int k = 0; k < n_sites; ++k) ref16[k] = (int8_t)(beg + k < ref_len ? ref_nt16(ref[beg + k]) : 15);
+
+    if (trace) fprintf(stderr, "[pileup] host preparation done at %.2f ms\n", ms_now());
+    // ---- device ----
+    #define PL_CHK(call) do { if ((call) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, #call); } while (0)
+    auto up = [&](int slot, const void *src, size_t bytes) -> void* {
+        void *d = bcfgpu_internal_ws(ctx, slot, bytes + 16);
+        if (d && bytes && hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
+        return d;
+    };
+    PileupParams P{};
+    P.n_sites = n_sites; P.n_smpl = S; P.beg = beg; P.max_span = max_span;
+    P.want_epos = (cfg->fmt_flag & (BCFGPU_INFO_RPB | BCFGPU_INFO_VDB)) ? 1 : 0;
+    void *d_ref16 = up(16, ref16.data(), (size_t)n_sites);
+    P.smpl_off = (const int32_t*)up(17, smpl_off.data(), (size_t)(S + 1) * 4);
+    P.s_pos = (const int32_t*)up(18, s_pos, (size_t)n * 4);
+    P.meta = (const ReadMeta*)up(19, meta, (size_t)n * sizeof(ReadMeta));
+    P.cig = (const uint32_t*)up(27, rd->cig, ncig * 4);
+    P.seq16 = (const uint8_t*)up(28, rd->seq16, nbase);
+    P.qual = (const uint8_t*)up(29, rd->qual, nbase);
+    uint32_t *d_cnt = (uint32_t*)bcfgpu_internal_ws(ctx, 30, (ncells + 1) * 4 + (size_t)n_sites * 4 + 64);
+    if (!d_ref16 || !P.smpl_off || !P.s_pos || !P.meta || !P.cig || !P.seq16 || !P.qual || !d_cnt)
+        return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup: device workspace");
+    P.cnt = d_cnt;
+    P.col_indel = d_cnt + ncells + 1;
+    PL_CHK(hipMemsetAsync(d_cnt, 0, (ncells + 1) * 4 + (size_t)n_sites * 4, stream));
+    const int grid = (int)((ncells + 255) / 256);
+    uint32_t total = 0;
+    if (trace) { hipStreamSynchronize(stream); fprintf(stderr, "[pileup] pool on the device at %.2f ms\n", ms_now()); }
+    if (ncells) {
+        hipLaunchKernelGGL(pileup_kernel<false>, dim3(grid), dim3(256), 0, stream, P);
+        // plp_off = exclusive prefix sum of the counts (in place, one element past the end for the total)
+        size_t tmp_bytes = 0;
+        PL_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_cnt, (int)(ncells + 1), stream));
+        void *d_tmp = bcfgpu_internal_ws(ctx, 31, tmp_bytes + 16);
+        if (!d_tmp) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup: device workspace");
+        PL_CHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_cnt, (int)(ncells + 1), stream));
+        PL_CHK(hipMemcpyAsync(&total, d_cnt + ncells, 4, hipMemcpyDeviceToHost, stream));
+        PL_CHK(hipStreamSynchronize(stream));
+    }
+    if (trace) fprintf(stderr, "[pileup] counted and scanned at %.2f ms (%u entries)\n", ms_now(), total);
+    // the read records: the scan's temporary storage is done with, its slot is reused (grow-only) for rd + epos
+    const size_t epos_at = (((size_t)total + 4) * 4 + 255) & ~(size_t)255;      // both arrays aligned for 16-byte staging loads
+    uint8_t *d_out = (uint8_t*)bcfgpu_internal_ws(ctx, 31, epos_at + (size_t)total + 64);
+    if (!d_out) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup: device workspace");
+    P.rd = (uint32_t*)d_out; P.epos = d_out + epos_at;
+    if (total) hipLaunchKernelGGL(pileup_kernel<true>, dim3(grid), dim3(256), 0, stream, P);
+    PL_CHK(hipGetLastError());
+    if (trace) { hipStreamSynchronize(stream); fprintf(stderr, "[pileup] tile filled at %.2f ms\n", ms_now()); }
+    if (col_n || col_indel) {
+        std::vector<uint32_t> off, ci;
+        if (col_n) {
+            off.resize(ncells + 1);
+            PL_CHK(hipMemcpyAsync(off.data(), d_cnt, (ncells + 1) * 4, hipMemcpyDeviceToHost, stream));
+        }
+        if (col_indel) {
+            ci.resize(n_sites);
+            PL_CHK(hipMemcpyAsync(ci.data(), P.col_indel, (size_t)n_sites * 4, hipMemcpyDeviceToHost, stream));
+        }
+        PL_CHK(hipStreamSynchronize(stream));
+        for (int k = 0; k < n_sites; ++k) {
+            if (col_n) col_n[k] = (int32_t)(off[(size_t)(k + 1) * S] - off[(size_t)k * S]);
+            if (col_indel) col_indel[k] = ci[k] ? 1 : 0;
+        }
+    }
+    #undef PL_CHK
+    tile->n_sites = n_sites; tile->is_indel = 0; tile->n_reads = total;
+    tile->ref16 = (const int8_t*)d_ref16; tile->plp_off = d_cnt; tile->rd = P.rd; tile->epos = P.epos;
+    return BCFGPU_OK;
+}

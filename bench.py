@@ -41,7 +41,7 @@ def parse():
                                                           ">1 takes the general caller path (BASELINE configs[4] shape)")
     ap.add_argument("--haploid-frac", type=float, default=0.0, help="snp mode: fraction of haploid samples (ploidy array; general caller path)")
     ap.add_argument("--indel-callers", type=int, default=2, help="indel mode: also time this many caller threads, one context each (1: skip)")
-    ap.add_argument("--mode", choices=["snp", "indel", "baq"], default="snp",
+    ap.add_argument("--mode", choices=["snp", "indel", "baq", "pileup"], default="snp",
                     help="snp: the headline pipeline (default).  indel: bcf_call_gap_prep on synthetic indel-candidate columns "
                          "(BASELINE configs[2] shape, 500 samples), reports DP cells/s of the realignment kernel.  "
                          "baq: bcfgpu_baq (sam_prob_realn) over the reads of the same synthetic columns")
@@ -247,8 +247,94 @@ def main_baq(a):
     ctx.close()
 
 
+def main_pileup(a):
+    """Secondary measurement (the pileup engine): bcfgpu_pileup builds the tile in HBM from a pool of reads
+    (host pointers: the pool crosses PCIe, the tile does not), then the pipeline runs on it."""
+    import torch
+    from bcftools_amd import abi, engine
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    from bcftools_amd.lib import check
+    S = a.samples
+    n_sites = 16384 if a.sites is None else a.sites
+    L, beg = 100, 200
+    end = beg + n_sites
+    rng = np.random.default_rng(a.seed)
+    per = int((n_sites + L) * a.depth / L)                      # reads per sample
+    n = per * S
+    pos = np.sort(rng.integers(beg - L + 1, end, size=(S, per)), axis=1).astype(np.int32).ravel()
+    smpl = np.repeat(np.arange(S, dtype=np.int32), per)
+    # CIGARs: 100M, or (6 %) 48M2D52M / 40M3I57M / 5S95M
+    kind = rng.choice(4, n, p=[0.94, 0.02, 0.02, 0.02])
+    table = {0: [L << 4], 1: [48 << 4, 2 << 4 | 2, 52 << 4], 2: [40 << 4, 3 << 4 | 1, 57 << 4], 3: [5 << 4 | 4, 95 << 4]}
+    ncig = np.array([1, 3, 3, 2], np.int32)[kind]
+    cig_off = np.concatenate([[0], np.cumsum(ncig)[:-1]]).astype(np.int32)
+    cig = np.zeros(int(ncig.sum()), np.uint32)
+    for k, ops in table.items():
+        idx = np.nonzero(kind == k)[0]
+        for j, op in enumerate(ops):
+            cig[cig_off[idx] + j] = op
+    refseq = "".join("ACGT"[i] for i in rng.integers(0, 4, end + L))
+    rd = abi.Reads()
+    arrs = dict(r_pos=pos, r_lq=np.full(n, L, np.int32), r_flag=(rng.integers(0, 2, n) * 16).astype(np.int32), r_ncig=ncig,
+                r_cig_off=cig_off, r_seq_off=(np.arange(n, dtype=np.int64) * L).astype(np.int32), cig=cig,
+                seq16=(1 << rng.integers(0, 4, n * L)).astype(np.uint8),
+                qual=rng.choice(np.array([11, 25, 37, 40], np.uint8), n * L), zq=np.zeros(1, np.uint8), r_has_zq=np.zeros(n, np.uint8))
+    rd.n_reads = n
+    for k, v in arrs.items():
+        setattr(rd, k, v.ctypes.data)
+    mapq = np.where(rng.random(n) < 0.92, 60, rng.integers(0, 60, n)).astype(np.uint8)
+    pool_bytes = sum(v.nbytes for v in arrs.values()) + mapq.nbytes + smpl.nbytes
+    # size the context from a first build
+    ctx0 = engine.Context(abi.default_cfg(S, max_sites=1, max_reads=64))
+    t = abi.Tile()
+
+    def build(ctx):
+        t0 = time.perf_counter()
+        check(ctx.L.bcfgpu_pileup(ctx.h, C.byref(rd), mapq.ctypes.data, smpl.ctypes.data, beg, end, refseq.encode(), len(refseq),
+                                  C.byref(t), None, None))
+        ctx.sync()
+        return time.perf_counter() - t0
+    build(ctx0)
+    entries = int(t.n_reads)
+    ctx0.close()
+    ctx = engine.Context(abi.default_cfg(S, max_sites=n_sites, max_reads=entries))
+    build(ctx)
+    tb = min(build(ctx) for _ in range(max(2, a.steps // 3)))
+    # the pipeline on the device-built tile
+    mo, mbufs, _ = ctx.alloc_mplp_out(n_sites)
+    co = abi.CallOut()
+    csite = torch.zeros(n_sites * C.sizeof(abi.CallSite), dtype=torch.uint8, device="cuda")
+    cgt = torch.zeros(n_sites * 2 * S, dtype=torch.int8, device="cuda")
+    cpl = torch.zeros(n_sites * abi.MAX_PL * S, dtype=torch.int32, device="cuda")
+    co.site, co.gt, co.pl, co.gq, co.gp = csite.data_ptr(), cgt.data_ptr(), cpl.data_ptr(), None, None
+
+    def pipe():
+        t0 = time.perf_counter()
+        check(ctx.L.bcfgpu_pipeline(ctx.h, C.byref(t), None, None, C.byref(mo), C.byref(co)))
+        ctx.sync()
+        return time.perf_counter() - t0
+    pipe()
+    tp = min(pipe() for _ in range(3))
+    tile_bytes = entries * 5 + (n_sites * S + 1) * 4 + n_sites
+    out = {"metric": "pileup entries/sec through bcfgpu_pileup (read pool -> site x sample x read tile in HBM), %d samples x %.0fx" % (S, a.depth),
+           "value": entries / tb, "unit": "entries/s", "n_gpus": 1, "higher_is_better": True, "dtype": "u32/u8 records", "data": "synthetic",
+           "config": {"workload": "%d reads of %d bp over %d columns x %d samples" % (n, L, n_sites, S), "reads": n, "entries": entries,
+                      "columns": n_sites},
+           "whole_call_ms": tb * 1e3, "tile_written_gbs": tile_bytes / tb / 1e9,
+           "pcie": {"pool_bytes": int(pool_bytes), "tile_bytes": int(tile_bytes),
+                    "note": "the pool is what crosses PCIe; a host-packed tile of this region would be tile_bytes"},
+           "host_fed_pipeline": {"pipeline_ms": tp * 1e3, "sites_per_s": n_sites / (tb + tp),
+                                 "note": "bcfgpu_pileup (host pointers in) followed by bcfgpu_pipeline on the tile it left in HBM"}}
+    print(json.dumps(out), flush=True)
+    ctx.release(list(mbufs.values()))
+    ctx.close()
+
+
 def main():
     a = parse()
+    if a.mode == "pileup":
+        return main_pileup(a)
     if a.mode == "indel":
         return main_indel(a)
     if a.mode == "baq":

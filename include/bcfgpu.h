@@ -17,6 +17,8 @@
  *    bcfgpu_gap_prep_stats               <- (measurement only)
  *    bcfgpu_baq                          <- sam_prob_realn (htslib realn.c), call site mpileup.c:234
  *    bcfgpu_overlap_tweak                <- tweak_overlap_quality (htslib sam.c) of the pileup engine, switched on at mpileup.c:640
+ *    bcfgpu_pileup                       <- the columns of bam_mplp_auto (htslib) as mpileup_reg() walks them, mpileup.c:320-347,
+ *                                           with the per-read accessors of bcfgpu_pack_read
  *    bcfgpu_mcall                        <- mcall()                            call.h:131 (mcall.c:1430-1684)
  *                                           incl. the per-record prologue of vcfcall.c:1096-1115
  *    bcfgpu_pipeline                     <- the `mpileup -Ou | call -m` pipe with PL/QS/I16 kept in HBM
@@ -329,6 +331,27 @@ int  bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const char *ref, int
  * qualities after BAQ) is not modified: qual_out is the whole quality pool with the pairs' bases rewritten. */
 int  bcfgpu_overlap_tweak(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, int32_t n_pairs, const int32_t *pair_a,
                           const int32_t *pair_b, uint8_t *qual_out);
+
+/* ---- the pileup itself: the columns bam_mplp_auto() hands to mpileup_reg() (mpileup.c:320-347), built on the device
+ * from the reads of a region instead of being packed read by read on the host (bcfgpu_pack_read) and sent over PCIe
+ * at 5 bytes per (read, position): the read pool is ~30x smaller than the tile it expands to.
+ *   reads    the flat pool (HOST pointers), already filtered as mplp_func does (mpileup.c:183-246), with the qualities
+ *            the pileup should see (after bcfgpu_baq / bcfgpu_overlap_tweak); r_pos on the region's contig
+ *   r_mapq   [n_reads] mapping qualities;  r_smpl [n_reads] sample index of each read.  The reads of one sample must
+ *            come in ascending r_pos order (a position-sorted BAM; a sample spread over several files: merged).
+ *   [beg,end) the region, one column per position (columns without reads are there too: every cell empty);
+ *   ref/ref_len  the contig's sequence, for the column's reference base (N past its end)
+ *   tile     out: DEVICE pointers into the context's workspace, valid until the next bcfgpu_pileup on this context;
+ *            ready for bcfgpu_mpileup / bcfgpu_pipeline (a context created with max_sites >= end-beg and max_reads >=
+ *            tile->n_reads).  Entries of a cell are in the order of the reads.
+ *   col_n    out, HOST [end-beg] or NULL: pileup entries per column (0: the reference emits no record there)
+ *   col_indel out, HOST [end-beg] or NULL: 1 when some read of the column is followed by an indel (the columns
+ *            bcf_call_gap_prep looks at, bam2bcf_indel.c:106-113)
+ * Not modelled: the per-file depth cap of the iterator (mpileup -d): cells deeper than BCFGPU_MAX_DEPTH usable reads are
+ * refused by the mpileup stage (BCFGPU_E_DEPTH). */
+int  bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const uint8_t *r_mapq, const int32_t *r_smpl,
+                   int32_t beg, int32_t end, const char *ref, int32_t ref_len,
+                   bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel);
 
 /* statistics of the last bcfgpu_gap_prep call on this context (SURVEY 8d "indel stage unit": DP cells per second):
  * jobs = (site, candidate type, read) realignments, passes = forward passes run (a second parameter set is tried when

@@ -1,0 +1,160 @@
+"""bcfgpu_pileup (the pileup columns built on the device from a read pool) against the test-side pileup walk
+(tests/helpers: htslib's resolve_cigar + bcfgpu_pack_read restated): the reference's SAM fixtures after BAQ and the
+mate-overlap tweak, random reads with every CIGAR operation, and the reference's goldens reproduced from device-built
+tiles (nothing but the read pool crosses PCIe)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from bcftools_amd import abi, engine, host
+from bcftools_amd.lib import check, BcfGpuError
+from tests.helpers import sam, mplpdrv as M, mplpcmp as K, ovlfuzz, vcf, orc
+
+pytestmark = pytest.mark.gpu
+
+
+def device_pileup(ctx, reads_by_sample, refseq, beg, end):
+    """reads_by_sample: list (one per sample) of read lists in position order.  Returns (HostTile, col_n, col_indel)."""
+    reads = [r for rl in reads_by_sample for r in rl]
+    smpl = np.array([si for si, rl in enumerate(reads_by_sample) for _ in rl], dtype=np.int32)
+    n_sites, S = end - beg, len(reads_by_sample)
+    col_n = np.zeros(n_sites, np.int32)
+    col_indel = np.zeros(n_sites, np.uint8)
+    t = abi.Tile()
+    if reads:
+        rd, d = M.pack_reads(reads)
+        mapq = np.array([r.mapq for r in reads], dtype=np.uint8)
+        check(ctx.L.bcfgpu_pileup(ctx.h, C.byref(rd), mapq.ctypes.data, smpl.ctypes.data, beg, end, refseq.encode(), len(refseq),
+                                  C.byref(t), col_n.ctypes.data, col_indel.ctypes.data))
+    else:
+        rd = abi.Reads()
+        check(ctx.L.bcfgpu_pileup(ctx.h, C.byref(rd), None, None, beg, end, refseq.encode(), len(refseq),
+                                  C.byref(t), col_n.ctypes.data, col_indel.ctypes.data))
+    assert t.n_sites == n_sites
+    off = np.zeros(n_sites * S + 1, np.uint32)
+    ref16 = np.zeros(n_sites, np.int8)
+    w = np.zeros(int(t.n_reads), np.uint32)
+    e = np.zeros(int(t.n_reads), np.uint8)
+    for dst, src in ((off, t.plp_off), (ref16, t.ref16), (w, t.rd), (e, t.epos)):
+        if dst.nbytes:
+            check(ctx.L.bcfgpu_memcpy_d2h(ctx.h, dst.ctypes.data, src, dst.nbytes))
+    ctx.sync()
+    return host.HostTile(S, ref16, off, w, e), col_n, col_indel, t
+
+
+def host_pileup(reads_by_sample, refseq, beg, end, want_epos=True):
+    S = len(reads_by_sample)
+    ref16, off, rd, epos, col_indel = [], [0], [], [], []
+    for pos in range(beg, end):
+        ref16.append(sam.nt16(refseq[pos]) if pos < len(refseq) else 15)
+        ind = 0
+        for rl in reads_by_sample:
+            for r in rl:
+                w = sam.walk(r, pos)
+                if w is None:
+                    continue
+                qpos, is_del, is_refskip, indel = w
+                ind |= int(indel != 0)
+                ww, e = sam.pack_read(sam.nt16(r.seq[qpos]) if qpos < r.l_qseq else 15, int(r.qual[qpos]) if qpos < r.l_qseq else 0,
+                                      r.mapq, bool(r.flag & sam.BAM_FREVERSE), any(op == "S" for _, op in r.cigar),
+                                      is_del, is_refskip, qpos, r.l_qseq, r.cigar, want_epos)
+                rd.append(ww)
+                epos.append(e)
+            off.append(len(rd))
+        col_indel.append(ind)
+    return (host.HostTile(S, np.array(ref16, np.int8), np.array(off, np.uint32), np.array(rd, np.uint32), np.array(epos, np.uint8)),
+            np.array(col_indel, np.uint8))
+
+
+def assert_tiles_equal(got, want):
+    np.testing.assert_array_equal(got.ref16, want.ref16)
+    np.testing.assert_array_equal(got.plp_off, want.plp_off)
+    np.testing.assert_array_equal(got.rd, want.rd)
+    np.testing.assert_array_equal(got.epos, want.epos)
+
+
+def _prepared(golden_dir, files, fa, contig):
+    G = os.path.join(golden_dir, "mpileup")
+    sams = [sam.Sam(os.path.join(G, f)) for f in files]
+    ref = sam.read_fasta(os.path.join(G, fa))
+    prep = M.Prepared(sams, ref, contig, sam.MplpOpts())          # BAQ and overlaps by the oracle
+    by_sample = [[] for _ in prep.samples]
+    for rl in prep.files:
+        for r, si in rl:
+            by_sample[si].append(r)
+    return prep, by_sample
+
+
+@pytest.mark.parametrize("files,fa,contig,beg,end", [
+    (["mpileup.1.sam", "mpileup.2.sam", "mpileup.3.sam"], "mpileup.ref.fa", "17", 0, 700),
+    (["indel-AD.1.sam"], "indel-AD.1.fa", "000000F", 0, 1200),
+])
+def test_pileup_matches_host_walk_on_reference_reads(golden_dir, gpu_ctx_factory, files, fa, contig, beg, end):
+    prep, by_sample = _prepared(golden_dir, files, fa, contig)
+    ctx = gpu_ctx_factory(abi.default_cfg(len(by_sample), max_sites=1, max_reads=64))
+    got, col_n, col_indel, _ = device_pileup(ctx, by_sample, prep.refseq, beg, end)
+    want, want_indel = host_pileup(by_sample, prep.refseq, beg, end)
+    assert_tiles_equal(got, want)
+    S = len(by_sample)
+    np.testing.assert_array_equal(col_n, (want.plp_off[S::S] - want.plp_off[:-1:S]).astype(np.int32))
+    np.testing.assert_array_equal(col_indel, want_indel)
+    assert col_indel.any() and len(want.rd) > 1000
+
+
+def test_pileup_matches_host_walk_on_random_reads(gpu_ctx_factory):
+    rng = np.random.default_rng(9)
+    S, L = 7, 600
+    refseq = "".join("ACGTN"[i] for i in rng.choice(5, L, p=[0.25, 0.25, 0.24, 0.24, 0.02]))
+    by_sample = []
+    for s in range(S):
+        n = int(rng.integers(0, 60))
+        rl = [ovlfuzz.make_read(rng, rng.integers(0, L - 50), int(rng.integers(20, 120))) for _ in range(n)]
+        for r in rl:
+            r.mapq = int(rng.integers(0, 61))
+            r.flag = int(rng.choice([0, 16]))
+        rl.sort(key=lambda r: r.pos)
+        by_sample.append(rl)
+    by_sample[3] = []                                              # a sample without reads
+    ctx = gpu_ctx_factory(abi.default_cfg(S, max_sites=1, max_reads=64))
+    got, col_n, col_indel, _ = device_pileup(ctx, by_sample, refseq, 10, L + 40)      # past the end of the reference too
+    want, want_indel = host_pileup(by_sample, refseq + "N" * 200, 10, L + 40)
+    assert_tiles_equal(got, want)
+    np.testing.assert_array_equal(col_indel, want_indel)
+    # no reads at all, and reads out of position order
+    empty, n0, _, _ = device_pileup(ctx, [[] for _ in range(S)], refseq, 0, 50)
+    assert len(empty.rd) == 0 and not n0.any()
+    by_sample[0] = by_sample[0][::-1]
+    if len(by_sample[0]) > 1 and by_sample[0][0].pos != by_sample[0][-1].pos:
+        with pytest.raises(BcfGpuError):
+            device_pileup(ctx, by_sample, refseq, 0, 50)
+
+
+def test_golden_from_device_built_tile(golden_dir):
+    """test/mpileup/mpileup.2.out (SNP records) with the tile built by bcfgpu_pileup and handed to bcfgpu_mpileup as
+    it stands in HBM."""
+    files = ["mpileup.1.sam", "mpileup.2.sam", "mpileup.3.sam"]
+    prep, by_sample = _prepared(golden_dir, files, "mpileup.ref.fa", "17")
+    fmt = abi.INFO_VDB | abi.INFO_RPB | abi.FMT_DP | abi.FMT_DV
+    beg, end = 99, 600
+    S = len(by_sample)
+    with engine.Context(abi.default_cfg(S, max_sites=end - beg, max_reads=1 << 20, fmt_flag=fmt)) as ctx:
+        _, col_n, _, dt = device_pileup(ctx, by_sample, prep.refseq, beg, end)
+        o, ob, res = ctx.alloc_mplp_out(end - beg)
+        for b in ob.values():
+            check(ctx.L.bcfgpu_memset(ctx.h, b.ptr, 0, b.nbytes))
+        check(ctx.L.bcfgpu_mpileup(ctx.h, C.byref(dt), C.byref(o)))
+        ctx.sync()
+        ctx._download(ob, res)
+        ctx.release(list(ob.values()))
+    gold = vcf.Vcf(os.path.join(golden_dir, "mpileup", "mpileup.2.out"))
+    snp = {r.pos: r for r in gold.recs if "INDEL" not in r.info}
+    seen = 0
+    for k in range(end - beg):
+        if col_n[k] == 0:
+            assert (beg + k + 1) not in snp
+            continue
+        K.check_record(snp[beg + k + 1], res.site[k], res, k, K.snp_alleles(res.site[k]), fmt)
+        seen += 1
+    assert seen == len(snp) == 501
