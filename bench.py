@@ -274,12 +274,24 @@ def main_pileup(a):
         idx = np.nonzero(kind == k)[0]
         for j, op in enumerate(ops):
             cig[cig_off[idx] + j] = op
-    refseq = "".join("ACGT"[i] for i in rng.integers(0, 4, end + L))
+    ref_codes = rng.integers(0, 4, end + 2 * L).astype(np.uint8)
+    refseq = "".join("ACGT"[i] for i in ref_codes)
     rd = abi.Reads()
     arrs = dict(r_pos=pos, r_lq=np.full(n, L, np.int32), r_flag=(rng.integers(0, 2, n) * 16).astype(np.int32), r_ncig=ncig,
                 r_cig_off=cig_off, r_seq_off=(np.arange(n, dtype=np.int64) * L).astype(np.int32), cig=cig,
-                seq16=(1 << rng.integers(0, 4, n * L)).astype(np.uint8),
+                seq16=None,
                 qual=rng.choice(np.array([11, 25, 37, 40], np.uint8), n * L), zq=np.zeros(1, np.uint8), r_has_zq=np.zeros(n, np.uint8))
+    # bases: the reference under the read (indel reads are not shifted: a few mismatches), 0.3 % errors
+    seq = np.empty(n * L, np.uint8)
+    step = 1 << 16
+    for r0 in range(0, n, step):
+        r1 = min(n, r0 + step)
+        idx = np.maximum(pos[r0:r1, None], 0) + np.arange(L, dtype=np.int32)[None, :]
+        b = ref_codes[idx]
+        err = rng.random(b.shape) < 0.003
+        b = np.where(err, (b + rng.integers(1, 4, b.shape)) & 3, b)
+        seq[r0 * L:r1 * L] = (1 << b).astype(np.uint8).ravel()
+    arrs["seq16"] = seq
     rd.n_reads = n
     for k, v in arrs.items():
         setattr(rd, k, v.ctypes.data)
