@@ -131,13 +131,25 @@ def test_pileup_matches_host_walk_on_random_reads(gpu_ctx_factory):
             device_pileup(ctx, by_sample, refseq, 0, 50)
 
 
-def test_golden_from_device_built_tile(golden_dir):
-    """test/mpileup/mpileup.2.out (SNP records) with the tile built by bcfgpu_pileup and handed to bcfgpu_mpileup as
-    it stands in HBM."""
-    files = ["mpileup.1.sam", "mpileup.2.sam", "mpileup.3.sam"]
-    prep, by_sample = _prepared(golden_dir, files, "mpileup.ref.fa", "17")
-    fmt = abi.INFO_VDB | abi.INFO_RPB | abi.FMT_DP | abi.FMT_DV
-    beg, end = 99, 600
+@pytest.mark.parametrize("files,fa,contig,beg,end,goldf,fmt,n_snp", [
+    (["mpileup.1.sam", "mpileup.2.sam", "mpileup.3.sam"], "mpileup.ref.fa", "17", 99, 600, "mpileup.2.out",
+     abi.INFO_VDB | abi.INFO_RPB | abi.FMT_DP | abi.FMT_DV, 501),
+    (["mpileup.1.sam", "mpileup.2.sam", "mpileup.3.sam"], "mpileup.ref.fa", "17", 99, 600, "mpileup.4.out",
+     abi.INFO_VDB | abi.INFO_RPB | abi.FMT_DP | abi.FMT_DPR | abi.FMT_DV | abi.FMT_DP4 | abi.INFO_DPR | abi.FMT_SP, 501),
+    (["mpileup.3.sam"], "mpileup.ref.fa", "17", 0, 4100, "mpileup.11.out", abi.INFO_VDB | abi.INFO_RPB, 4001),
+    (["mpileup-SCR.bam"], "mpileup-SCR.fa", "1", 0, 200, "mpileup-SCR.out", abi.INFO_VDB | abi.INFO_RPB | abi.INFO_SCR | abi.FMT_SCR, 86),
+])
+def test_golden_from_device_built_tile(golden_dir, files, fa, contig, beg, end, goldf, fmt, n_snp):
+    """SNP records of the reference's goldens with the tile built by bcfgpu_pileup and handed to bcfgpu_mpileup as it
+    stands in HBM (BAQ and the overlap tweak before it; nothing but the read pool crosses PCIe)."""
+    G = os.path.join(golden_dir, "mpileup")
+    sams = [(sam.Bam if f.endswith(".bam") else sam.Sam)(os.path.join(G, f)) for f in files]
+    ref = sam.read_fasta(os.path.join(G, fa))
+    prep = M.Prepared(sams, ref, contig, sam.MplpOpts(fmt_flag=fmt))
+    by_sample = [[] for _ in prep.samples]
+    for rl in prep.files:
+        for r, si in rl:
+            by_sample[si].append(r)
     S = len(by_sample)
     with engine.Context(abi.default_cfg(S, max_sites=end - beg, max_reads=1 << 20, fmt_flag=fmt)) as ctx:
         _, col_n, _, dt = device_pileup(ctx, by_sample, prep.refseq, beg, end)
@@ -148,7 +160,7 @@ def test_golden_from_device_built_tile(golden_dir):
         ctx.sync()
         ctx._download(ob, res)
         ctx.release(list(ob.values()))
-    gold = vcf.Vcf(os.path.join(golden_dir, "mpileup", "mpileup.2.out"))
+    gold = vcf.Vcf(os.path.join(G, goldf))
     snp = {r.pos: r for r in gold.recs if "INDEL" not in r.info}
     seen = 0
     for k in range(end - beg):
@@ -157,4 +169,4 @@ def test_golden_from_device_built_tile(golden_dir):
             continue
         K.check_record(snp[beg + k + 1], res.site[k], res, k, K.snp_alleles(res.site[k]), fmt)
         seen += 1
-    assert seen == len(snp) == 501
+    assert seen == len(snp) == n_snp
