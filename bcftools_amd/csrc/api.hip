@@ -48,6 +48,7 @@ struct bcfgpu_ctx {
     bcfgpu_gap_stats gap{};         // statistics of the last bcfgpu_gap_prep
     // grow-only device workspaces of the indel / BAQ stages (GiB-sized scratch: not reallocated per call)
     struct Ws { void *p = nullptr; size_t bytes = 0; };
+    alignas(16) unsigned char pileup_state[256] = {0};   // csrc/pileup.hip: the parameters of the last bcfgpu_pileup
     Ws ws[32];                     // grow-only device workspaces of the host-fed stages (0-15: indel / BAQ / overlaps, 16-31: pileup)
 };
 
@@ -517,6 +518,7 @@ int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnPools> &
 
 bcfgpu_gap_stats *bcfgpu_internal_gap_stats(bcfgpu_ctx *c) { return &c->gap; }
 const bcfgpu_cfg *bcfgpu_internal_cfg(const bcfgpu_ctx *c) { return c ? &c->cfg : nullptr; }
+void *bcfgpu_internal_pileup_state(bcfgpu_ctx *c) { return c ? c->pileup_state : nullptr; }
 
 // workspace `slot` of at least `bytes` (contents undefined); nullptr when the allocation fails
 void *bcfgpu_internal_ws(bcfgpu_ctx *c, int slot, size_t bytes)

@@ -28,6 +28,7 @@
 extern "C" int bcfgpu_internal_device(bcfgpu_ctx *ctx, hipStream_t *stream, const float **q2p);
 extern "C" void *bcfgpu_internal_ws(bcfgpu_ctx *ctx, int slot, size_t bytes);
 extern "C" const bcfgpu_cfg *bcfgpu_internal_cfg(const bcfgpu_ctx *ctx);
+extern "C" void *bcfgpu_internal_pileup_state(bcfgpu_ctx *ctx);
 int bcfgpu_set_error(int code, const char *what);
 
 namespace bcfgpu {
@@ -49,6 +50,7 @@ struct PileupParams {
     // reads in (sample, position) order: index k of the sorted list
     const int32_t *smpl_off;        // [n_smpl+1] into the sorted list
     const int32_t *s_pos;           // [n_reads] reference start of sorted read k (the binary searches)
+    const int32_t *s_read;          // [n_reads] pool index of sorted read k
     const ReadMeta *meta;           // [n_reads] everything else about sorted read k, one 32-byte record
     const uint32_t *cig;
     const uint8_t *seq16, *qual;
@@ -186,6 +188,65 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
     }
 }
 
+// The pileup entries of selected columns as bcf_call_gap_prep wants them (read, query offset, indel): the same walk as
+// the fill pass over the cells of those columns only.  sel_off = exclusive prefix sum of the cells' counts.
+struct EntriesParams {
+    PileupParams P;
+    int n_cols;
+    const int32_t *cols;            // [n_cols] column indices
+    uint32_t *sel_cnt;              // [n_cols*n_smpl + 1] counts, then offsets
+    int32_t *e_read, *e_qpos, *e_indel;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void entries_kernel(const EntriesParams E)
+{
+    const PileupParams &P = E.P;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)E.n_cols * P.n_smpl) return;
+    const int ci = (int)(i / P.n_smpl), s = (int)(i - (long)ci * P.n_smpl), site = E.cols[ci];
+    const long cell = (long)site * P.n_smpl + s;
+    if (!FILL) { E.sel_cnt[i] = P.cnt[cell + 1] - P.cnt[cell]; return; }
+    const int x = P.beg + site;
+    const int lo0 = P.smpl_off[s], hi0 = P.smpl_off[s + 1];
+    const int hi = upper_bound(P.s_pos, lo0, hi0, x);
+    const int lo = upper_bound(P.s_pos, lo0, hi, x - P.max_span);
+    uint32_t o = E.sel_cnt[i];
+    for (int k = lo; k < hi; ++k) {
+        const ReadMeta m = P.meta[k];
+        if (m.end <= x) continue;
+        const uint32_t *cg = P.cig + m.cig_off;
+        int rx = m.pos, y = 0, qpos = 0, indel = 0;
+        for (int c = 0; c < m.ncig; ++c) {
+            const int op = cg[c] & 0xf, l = (int)(cg[c] >> 4);
+            if (op == 0 || op == 7 || op == 8) {
+                if (x < rx + l) {
+                    qpos = y + (x - rx);
+                    if (x == rx + l - 1) {
+                        int cc = c + 1;
+                        while (cc < m.ncig && (cg[cc] & 0xf) == 6) ++cc;
+                        if (cc < m.ncig) {
+                            const int nop = cg[cc] & 0xf;
+                            if (nop == 1) {
+                                indel = (int)(cg[cc] >> 4);
+                                for (++cc; cc < m.ncig && ((cg[cc] & 0xf) == 1 || (cg[cc] & 0xf) == 6); ++cc)
+                                    if ((cg[cc] & 0xf) == 1) indel += (int)(cg[cc] >> 4);
+                            } else if (nop == 2) indel = -(int)(cg[cc] >> 4);
+                        }
+                    }
+                    break;
+                }
+                rx += l; y += l;
+            } else if (op == 2 || op == 3) {
+                if (x < rx + l) { qpos = y; break; }
+                rx += l;
+            } else if (op == 1 || op == 4) y += l;
+        }
+        E.e_read[o] = P.s_read[k]; E.e_qpos[o] = qpos; E.e_indel[o] = indel;
+        ++o;
+    }
+}
+
 }  // namespace bcfgpu
 
 using namespace bcfgpu;
@@ -314,12 +375,13 @@ extern "C" int bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const uint
     void *d_ref16 = up(16, ref16.data(), (size_t)n_sites);
     P.smpl_off = (const int32_t*)up(17, smpl_off.data(), (size_t)(S + 1) * 4);
     P.s_pos = (const int32_t*)up(18, s_pos, (size_t)n * 4);
+    P.s_read = (const int32_t*)up(20, s_read, (size_t)n * 4);
     P.meta = (const ReadMeta*)up(19, meta, (size_t)n * sizeof(ReadMeta));
     P.cig = (const uint32_t*)up(27, rd->cig, ncig * 4);
     P.seq16 = (const uint8_t*)up(28, rd->seq16, nbase);
     P.qual = (const uint8_t*)up(29, rd->qual, nbase);
     uint32_t *d_cnt = (uint32_t*)bcfgpu_internal_ws(ctx, 30, (ncells + 1) * 4 + (size_t)n_sites * 4 + 64);
-    if (!d_ref16 || !P.smpl_off || !P.s_pos || !P.meta || !P.cig || !P.seq16 || !P.qual || !d_cnt)
+    if (!d_ref16 || !P.smpl_off || !P.s_pos || !P.s_read || !P.meta || !P.cig || !P.seq16 || !P.qual || !d_cnt)
         return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup: device workspace");
     P.cnt = d_cnt;
     P.col_indel = d_cnt + ncells + 1;
@@ -364,7 +426,60 @@ extern "C" int bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const uint
         }
     }
     #undef PL_CHK
+    static_assert(sizeof(PileupParams) <= 256, "fits the context's pileup_state");
+    std::memcpy(bcfgpu_internal_pileup_state(ctx), &P, sizeof P);          // for bcfgpu_pileup_entries
     tile->n_sites = n_sites; tile->is_indel = 0; tile->n_reads = total;
     tile->ref16 = (const int8_t*)d_ref16; tile->plp_off = d_cnt; tile->rd = P.rd; tile->epos = P.epos;
+    return BCFGPU_OK;
+}
+
+extern "C" int bcfgpu_pileup_entries(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols, int32_t *smpl_off,
+                                     int32_t *p_read, int32_t *p_qpos, int32_t *p_indel, int64_t cap)
+{
+    if (!ctx || n_cols < 0 || (n_cols && (!cols || !smpl_off)))
+        return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup_entries: bad arguments");
+    hipStream_t stream = nullptr;
+    if (bcfgpu_internal_device(ctx, &stream, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup_entries: bad context");
+    EntriesParams E{};
+    std::memcpy(&E.P, bcfgpu_internal_pileup_state(ctx), sizeof E.P);
+    if (!E.P.cnt) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup_entries: no bcfgpu_pileup on this context yet");
+    if (n_cols == 0) return BCFGPU_OK;
+    const int S = E.P.n_smpl;
+    for (int i = 0; i < n_cols; ++i)
+        if (cols[i] < 0 || cols[i] >= E.P.n_sites) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup_entries: column out of range");
+    const size_t nsel = (size_t)n_cols * S;
+    #define PE_CHK(call) do { if ((call) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, #call); } while (0)
+    int32_t *d_cols = (int32_t*)bcfgpu_internal_ws(ctx, 21, (size_t)n_cols * 4 + 16);
+    uint32_t *d_sel = (uint32_t*)bcfgpu_internal_ws(ctx, 22, (nsel + 1) * 4 + 16);
+    if (!d_cols || !d_sel) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup_entries: device workspace");
+    PE_CHK(hipMemcpyAsync(d_cols, cols, (size_t)n_cols * 4, hipMemcpyHostToDevice, stream));
+    PE_CHK(hipMemsetAsync(d_sel, 0, (nsel + 1) * 4, stream));
+    E.n_cols = n_cols; E.cols = d_cols; E.sel_cnt = d_sel;
+    const int grid = (int)((nsel + 255) / 256);
+    hipLaunchKernelGGL(entries_kernel<false>, dim3(grid), dim3(256), 0, stream, E);
+    size_t tmp_bytes = 0;
+    PE_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sel, d_sel, (int)(nsel + 1), stream));
+    void *d_tmp = bcfgpu_internal_ws(ctx, 23, tmp_bytes + 16);
+    if (!d_tmp) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup_entries: device workspace");
+    PE_CHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_sel, d_sel, (int)(nsel + 1), stream));
+    std::vector<uint32_t> off(nsel + 1);
+    PE_CHK(hipMemcpyAsync(off.data(), d_sel, (nsel + 1) * 4, hipMemcpyDeviceToHost, stream));
+    PE_CHK(hipStreamSynchronize(stream));
+    const uint32_t total = off[nsel];
+    for (size_t i = 0; i <= nsel; ++i) smpl_off[i] = (int32_t)off[i];
+    if ((int64_t)total > cap || (total && (!p_read || !p_qpos || !p_indel)))
+        return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_pileup_entries: the output arrays are too small (sum of col_n over the columns)");
+    if (total) {
+        int32_t *d_e = (int32_t*)bcfgpu_internal_ws(ctx, 24, (size_t)total * 12 + 16);
+        if (!d_e) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup_entries: device workspace");
+        E.e_read = d_e; E.e_qpos = d_e + total; E.e_indel = d_e + 2 * (size_t)total;
+        hipLaunchKernelGGL(entries_kernel<true>, dim3(grid), dim3(256), 0, stream, E);
+        PE_CHK(hipGetLastError());
+        PE_CHK(hipMemcpyAsync(p_read, E.e_read, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+        PE_CHK(hipMemcpyAsync(p_qpos, E.e_qpos, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+        PE_CHK(hipMemcpyAsync(p_indel, E.e_indel, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+        PE_CHK(hipStreamSynchronize(stream));
+    }
+    #undef PE_CHK
     return BCFGPU_OK;
 }

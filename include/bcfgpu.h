@@ -19,6 +19,7 @@
  *    bcfgpu_overlap_tweak                <- tweak_overlap_quality (htslib sam.c) of the pileup engine, switched on at mpileup.c:640
  *    bcfgpu_pileup                       <- the columns of bam_mplp_auto (htslib) as mpileup_reg() walks them, mpileup.c:320-347,
  *                                           with the per-read accessors of bcfgpu_pack_read
+ *    bcfgpu_pileup_entries               <- the bam_pileup1_t fields bcf_call_gap_prep reads (b, qpos, indel), bam2bcf_indel.c:106-128
  *    bcfgpu_mcall                        <- mcall()                            call.h:131 (mcall.c:1430-1684)
  *                                           incl. the per-record prologue of vcfcall.c:1096-1115
  *    bcfgpu_pipeline                     <- the `mpileup -Ou | call -m` pipe with PL/QS/I16 kept in HBM
@@ -352,6 +353,13 @@ int  bcfgpu_overlap_tweak(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, int32_t n_
 int  bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const uint8_t *r_mapq, const int32_t *r_smpl,
                    int32_t beg, int32_t end, const char *ref, int32_t ref_len,
                    bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel);
+
+/* The pileup entries of selected columns of the last bcfgpu_pileup on this context, in the form bcfgpu_gap_prep takes them
+ * (bcfgpu_indel_in: what bcf_call_gap_prep reads of bam_pileup1_t): for column cols[i] and sample s the entries
+ * smpl_off[i*n_smpl+s] .. smpl_off[i*n_smpl+s+1]-1 of p_read (index into the read pool), p_qpos, p_indel.
+ * HOST pointers; smpl_off has n_cols*n_smpl+1 elements, the p_* arrays `cap` elements (>= the sum of col_n over cols). */
+int  bcfgpu_pileup_entries(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols, int32_t *smpl_off,
+                           int32_t *p_read, int32_t *p_qpos, int32_t *p_indel, int64_t cap);
 
 /* statistics of the last bcfgpu_gap_prep call on this context (SURVEY 8d "indel stage unit": DP cells per second):
  * jobs = (site, candidate type, read) realignments, passes = forward passes run (a second parameter set is tried when

@@ -170,3 +170,41 @@ def test_golden_from_device_built_tile(golden_dir, files, fa, contig, beg, end, 
         K.check_record(snp[beg + k + 1], res.site[k], res, k, K.snp_alleles(res.site[k]), fmt)
         seen += 1
     assert seen == len(snp) == n_snp
+
+
+@pytest.mark.parametrize("files,fa,contig,beg,end", [
+    (["mpileup.1.sam", "mpileup.2.sam", "mpileup.3.sam"], "mpileup.ref.fa", "17", 0, 700),
+    (["indel-AD.1.sam"], "indel-AD.1.fa", "000000F", 0, 1200),
+])
+def test_entries_of_candidate_columns(golden_dir, gpu_ctx_factory, files, fa, contig, beg, end):
+    """bcfgpu_pileup_entries: (read, qpos, indel) of the indel-candidate columns, as bcfgpu_gap_prep takes them."""
+    prep, by_sample = _prepared(golden_dir, files, fa, contig)
+    S = len(by_sample)
+    ctx = gpu_ctx_factory(abi.default_cfg(S, max_sites=1, max_reads=64))
+    _, col_n, col_indel, _ = device_pileup(ctx, by_sample, prep.refseq, beg, end)
+    cols = np.nonzero(col_indel)[0].astype(np.int32)
+    assert len(cols) > 0
+    cap = int(col_n[cols].sum())
+    so = np.zeros(len(cols) * S + 1, np.int32)
+    pr, pq, pi = (np.zeros(cap, np.int32) for _ in range(3))
+    check(ctx.L.bcfgpu_pileup_entries(ctx.h, len(cols), cols.ctypes.data, so.ctypes.data, pr.ctypes.data, pq.ctypes.data,
+                                       pi.ctypes.data, cap))
+    pool = [r for rl in by_sample for r in rl]
+    index = {id(r): i for i, r in enumerate(pool)}
+    w_so, w_r, w_q, w_i = [0], [], [], []
+    for c in cols:
+        for rl in by_sample:
+            for r in rl:
+                w = sam.walk(r, beg + int(c))
+                if w is not None:
+                    w_r.append(index[id(r)]); w_q.append(w[0]); w_i.append(w[3])
+            w_so.append(len(w_r))
+    np.testing.assert_array_equal(so, np.array(w_so, np.int32))
+    np.testing.assert_array_equal(pr, np.array(w_r, np.int32))
+    np.testing.assert_array_equal(pq, np.array(w_q, np.int32))
+    np.testing.assert_array_equal(pi, np.array(w_i, np.int32))
+    assert (pi != 0).any()
+    # too small an output is refused, not overrun
+    with pytest.raises(BcfGpuError):
+        check(ctx.L.bcfgpu_pileup_entries(ctx.h, len(cols), cols.ctypes.data, so.ctypes.data, pr.ctypes.data, pq.ctypes.data,
+                                           pi.ctypes.data, cap - 1))
