@@ -135,6 +135,7 @@ PROTOTYPES = {
     "bcfgpu_gap_prep": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.POINTER(IndelIn), C.POINTER(IndelOut), C.c_int]),
     "bcfgpu_baq": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.c_char_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcfgpu_overlap_tweak": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bcfgpu_pileup_indel_tile": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Tile)]),
     "bcfgpu_pileup_entries": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "bcfgpu_pileup": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,
                                 C.POINTER(Tile), C.c_void_p, C.c_void_p]),

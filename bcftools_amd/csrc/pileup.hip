@@ -247,6 +247,21 @@ __global__ __launch_bounds__(256) void entries_kernel(const EntriesParams E)
     }
 }
 
+// The records of selected columns copied into a tile of their own (the indel pass runs on the candidate columns only)
+template <bool FILL>
+__global__ __launch_bounds__(256) void subtile_kernel(const EntriesParams E, uint32_t *rd_out, uint8_t *ep_out)
+{
+    const PileupParams &P = E.P;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)E.n_cols * P.n_smpl) return;
+    const int ci = (int)(i / P.n_smpl), s = (int)(i - (long)ci * P.n_smpl);
+    const long cell = (long)E.cols[ci] * P.n_smpl + s;
+    const uint32_t b = P.cnt[cell], e = P.cnt[cell + 1];
+    if (!FILL) { E.sel_cnt[i] = e - b; return; }
+    uint32_t o = E.sel_cnt[i];
+    for (uint32_t k = b; k < e; ++k, ++o) { rd_out[o] = P.rd[k]; ep_out[o] = P.epos[k]; }
+}
+
 }  // namespace bcfgpu
 
 using namespace bcfgpu;
@@ -481,5 +496,56 @@ extern "C" int bcfgpu_pileup_entries(bcfgpu_ctx *ctx, int32_t n_cols, const int3
         PE_CHK(hipStreamSynchronize(stream));
     }
     #undef PE_CHK
+    return BCFGPU_OK;
+}
+
+extern "C" int bcfgpu_pileup_indel_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols, const uint32_t *aux, int64_t n_aux,
+                                        bcfgpu_tile *tile)
+{
+    if (!ctx || n_cols < 0 || (n_cols && !cols) || !tile || n_aux < 0 || (n_aux && !aux))
+        return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup_indel_tile: bad arguments");
+    hipStream_t stream = nullptr;
+    if (bcfgpu_internal_device(ctx, &stream, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup_indel_tile: bad context");
+    EntriesParams E{};
+    std::memcpy(&E.P, bcfgpu_internal_pileup_state(ctx), sizeof E.P);
+    if (!E.P.cnt) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup_indel_tile: no bcfgpu_pileup on this context yet");
+    std::memset(tile, 0, sizeof *tile);
+    const int S = E.P.n_smpl;
+    for (int i = 0; i < n_cols; ++i)
+        if (cols[i] < 0 || cols[i] >= E.P.n_sites) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup_indel_tile: column out of range");
+    const size_t nsel = (size_t)n_cols * S;
+    #define PT_CHK(call) do { if ((call) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, #call); } while (0)
+    int32_t *d_cols = (int32_t*)bcfgpu_internal_ws(ctx, 21, (size_t)n_cols * 4 + 16);
+    uint32_t *d_sel = (uint32_t*)bcfgpu_internal_ws(ctx, 25, (nsel + 1) * 4 + (size_t)n_cols + 64);
+    if (!d_cols || !d_sel) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup_indel_tile: device workspace");
+    PT_CHK(hipMemcpyAsync(d_cols, cols, (size_t)n_cols * 4, hipMemcpyHostToDevice, stream));
+    PT_CHK(hipMemsetAsync(d_sel, 0, (nsel + 1) * 4 + (size_t)n_cols + 64, stream));
+    E.n_cols = n_cols; E.cols = d_cols; E.sel_cnt = d_sel;
+    const int grid = (int)((nsel + 255) / 256);
+    uint32_t total = 0;
+    if (nsel) {
+        hipLaunchKernelGGL(subtile_kernel<false>, dim3(grid), dim3(256), 0, stream, E, (uint32_t*)nullptr, (uint8_t*)nullptr);
+        size_t tmp_bytes = 0;
+        PT_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sel, d_sel, (int)(nsel + 1), stream));
+        void *d_tmp = bcfgpu_internal_ws(ctx, 23, tmp_bytes + 16);
+        if (!d_tmp) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup_indel_tile: device workspace");
+        PT_CHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_sel, d_sel, (int)(nsel + 1), stream));
+        PT_CHK(hipMemcpyAsync(&total, d_sel + nsel, 4, hipMemcpyDeviceToHost, stream));
+        PT_CHK(hipStreamSynchronize(stream));
+    }
+    if ((int64_t)total != n_aux) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup_indel_tile: aux must hold one word per entry of the columns");
+    const size_t ep_at = (((size_t)total + 4) * 4 + 255) & ~(size_t)255, aux_at = (ep_at + total + 64 + 255) & ~(size_t)255;
+    uint8_t *d_out = (uint8_t*)bcfgpu_internal_ws(ctx, 26, aux_at + ((size_t)total + 4) * 4);
+    if (!d_out) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup_indel_tile: device workspace");
+    if (total) {
+        hipLaunchKernelGGL(subtile_kernel<true>, dim3(grid), dim3(256), 0, stream, E, (uint32_t*)d_out, d_out + ep_at);
+        PT_CHK(hipGetLastError());
+        PT_CHK(hipMemcpyAsync(d_out + aux_at, aux, (size_t)total * 4, hipMemcpyHostToDevice, stream));
+        PT_CHK(hipStreamSynchronize(stream));
+    }
+    #undef PT_CHK
+    tile->n_sites = n_cols; tile->is_indel = 1; tile->n_reads = total;
+    tile->ref16 = reinterpret_cast<const int8_t*>(d_sel + nsel + 1);       // (zeros: the indel pass does not read it)
+    tile->plp_off = d_sel; tile->rd = (const uint32_t*)d_out; tile->epos = d_out + ep_at; tile->aux = (const uint32_t*)(d_out + aux_at);
     return BCFGPU_OK;
 }

@@ -19,6 +19,7 @@
  *    bcfgpu_overlap_tweak                <- tweak_overlap_quality (htslib sam.c) of the pileup engine, switched on at mpileup.c:640
  *    bcfgpu_pileup                       <- the columns of bam_mplp_auto (htslib) as mpileup_reg() walks them, mpileup.c:320-347,
  *                                           with the per-read accessors of bcfgpu_pack_read
+ *    bcfgpu_pileup_indel_tile            <- the second pileup pass of mpileup_reg() with p->aux set, mpileup.c:354-360
  *    bcfgpu_pileup_entries               <- the bam_pileup1_t fields bcf_call_gap_prep reads (b, qpos, indel), bam2bcf_indel.c:106-128
  *    bcfgpu_mcall                        <- mcall()                            call.h:131 (mcall.c:1430-1684)
  *                                           incl. the per-record prologue of vcfcall.c:1096-1115
@@ -360,6 +361,14 @@ int  bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const uint8_t *r_
  * HOST pointers; smpl_off has n_cols*n_smpl+1 elements, the p_* arrays `cap` elements (>= the sum of col_n over cols). */
 int  bcfgpu_pileup_entries(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols, int32_t *smpl_off,
                            int32_t *p_read, int32_t *p_qpos, int32_t *p_indel, int64_t cap);
+
+/* The indel pass's tile (mpileup.c:357-360: the same pileup entries with p->aux set by bcf_call_gap_prep, ref_base = -1) for
+ * selected columns of the last bcfgpu_pileup on this context -- the columns where bcfgpu_gap_prep returned 0.
+ * aux: HOST, one word per entry of those columns in bcfgpu_pileup_entries' order (bcfgpu_indel_out.p_aux of the same
+ * columns); n_aux must equal their entry count.  tile: out, DEVICE pointers into the context's workspace (is_indel = 1),
+ * valid until the next call of this function or of bcfgpu_pileup on this context. */
+int  bcfgpu_pileup_indel_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols, const uint32_t *aux, int64_t n_aux,
+                              bcfgpu_tile *tile);
 
 /* statistics of the last bcfgpu_gap_prep call on this context (SURVEY 8d "indel stage unit": DP cells per second):
  * jobs = (site, candidate type, read) realignments, passes = forward passes run (a second parameter set is tried when

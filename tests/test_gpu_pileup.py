@@ -208,3 +208,73 @@ def test_entries_of_candidate_columns(golden_dir, gpu_ctx_factory, files, fa, co
     with pytest.raises(BcfGpuError):
         check(ctx.L.bcfgpu_pileup_entries(ctx.h, len(cols), cols.ctypes.data, so.ctypes.data, pr.ctypes.data, pq.ctypes.data,
                                            pi.ctypes.data, cap - 1))
+
+
+@pytest.mark.parametrize("files,fa,contig,beg,end,goldf,fmt,n_indel", [
+    (["mpileup.1.sam", "mpileup.2.sam", "mpileup.3.sam"], "mpileup.ref.fa", "17", 99, 600, "mpileup.2.out",
+     abi.INFO_VDB | abi.INFO_RPB | abi.FMT_DP | abi.FMT_DV, 1),
+    (["indel-AD.1.sam"], "indel-AD.1.fa", "000000F", 0, 10000, "indel-AD.1.out", abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD, 6),
+])
+def test_indel_records_from_the_device_pileup(golden_dir, files, fa, contig, beg, end, goldf, fmt, n_indel):
+    """The indel records of the reference's goldens with no host pileup anywhere: bcfgpu_pileup -> the candidate columns'
+    entries (bcfgpu_pileup_entries) -> bcfgpu_gap_prep -> the indel pass's tile (bcfgpu_pileup_indel_tile) ->
+    bcfgpu_mpileup."""
+    from tests.helpers import indeldrv
+    G = os.path.join(golden_dir, "mpileup")
+    sams = [sam.Sam(os.path.join(G, f)) for f in files]
+    ref = sam.read_fasta(os.path.join(G, fa))
+    prep = M.Prepared(sams, ref, contig, sam.MplpOpts(fmt_flag=fmt))
+    end = min(end, max(r.end for rl in prep.files for r, _ in rl) + 1)
+    by_sample = [[] for _ in prep.samples]
+    for rl in prep.files:
+        for r, si in rl:
+            by_sample[si].append(r)
+    S = len(by_sample)
+    pool = [r for rl in by_sample for r in rl]
+    gold = vcf.Vcf(os.path.join(G, goldf))
+    ind = {r.pos: r for r in gold.recs if "INDEL" in r.info}
+    assert len(ind) == n_indel
+    with engine.Context(abi.default_cfg(S, max_sites=end - beg, max_reads=1 << 20, fmt_flag=fmt)) as ctx:
+        _, col_n, col_indel, _ = device_pileup(ctx, by_sample, prep.refseq, beg, end)
+        cols = np.nonzero(col_indel & (col_n < 250 * S))[0].astype(np.int32)          # max_indel_depth, mpileup.c:354
+        cap = int(col_n[cols].sum())
+        so = np.zeros(len(cols) * S + 1, np.int32)
+        pr, pq, pi = (np.zeros(cap, np.int32) for _ in range(3))
+        check(ctx.L.bcfgpu_pileup_entries(ctx.h, len(cols), cols.ctypes.data, so.ctypes.data, pr.ctypes.data, pq.ctypes.data,
+                                           pi.ctypes.data, cap))
+        # bcfgpu_gap_prep on the batch of candidate columns, reads = the pool the pileup was built from
+        rd, d = M.pack_reads(pool)
+        d["zq"] = np.ascontiguousarray(np.concatenate([r.zq if r.zq is not None else np.zeros(r.l_qseq, np.uint8) for r in pool]), dtype=np.uint8)
+        d["r_has_zq"] = np.ascontiguousarray([1 if r.zq is not None else 0 for r in pool], dtype=np.uint8)
+        d["n_reads"] = len(pool)
+        b = dict(n_sites=len(cols), n_smpl=S, reads=d, pos=(cols + beg).astype(np.int32), smpl_off=so, p_read=pr, p_qpos=pq,
+                 p_indel=pi, ref=prep.refseq.encode())
+        got, _ = indeldrv.gap_prep_gpu(ctx, b)
+        live = np.nonzero(got["ret"] == 0)[0]
+        # the indel pass on the accepted columns: aux of their entries, in entry order
+        keep = np.zeros(cap, bool)
+        for k in live:
+            keep[so[k * S]:so[(k + 1) * S]] = True
+        aux = np.ascontiguousarray(got["aux"][keep], dtype=np.uint32)
+        lcols = np.ascontiguousarray(cols[live], dtype=np.int32)
+        t = abi.Tile()
+        check(ctx.L.bcfgpu_pileup_indel_tile(ctx.h, len(lcols), lcols.ctypes.data, aux.ctypes.data, len(aux), C.byref(t)))
+        o, ob, res = ctx.alloc_mplp_out(max(1, len(lcols)))
+        for bb in ob.values():
+            check(ctx.L.bcfgpu_memset(ctx.h, bb.ptr, 0, bb.nbytes))
+        check(ctx.L.bcfgpu_mpileup(ctx.h, C.byref(t), C.byref(o)))
+        ctx.sync()
+        ctx._download(ob, res)
+        ctx.release(list(ob.values()))
+    seen = 0
+    for j, k in enumerate(live):
+        p = int(cols[k]) + beg
+        if res.site[j]["ret"] < 0:
+            assert (p + 1) not in ind
+            continue
+        assert (p + 1) in ind, "unexpected indel record at %d" % (p + 1)
+        g = dict(indel_types=got["indel_types"][k], inscns=got["inscns"][k], maxins=int(got["maxins"][k]), indelreg=int(got["indelreg"][k]),
+                 max_support=int(got["max_support"][k]), max_frac=float(got["max_frac"][k]))
+        K.check_record(ind[p + 1], res.site[j], res, j, M.indel_alleles(prep.refseq, p, res.site[j], g), fmt, extra=g)
+        seen += 1
+    assert seen == n_indel
