@@ -1,0 +1,238 @@
+/*  bcfgpu_sam.c -- `bcftools mpileup` over SAM files with every stage of the path on the device, in plain C over the
+ *  C-ABI of include/bcfgpu.h (SNP records; one sample per file, in file order).
+ *
+ *      bcfgpu_sam <ref.fa> <contig> <beg> <end> <file.sam> [<file.sam> ...]         (beg, end 1-based inclusive)
+ *
+ *  What stays on the host is what mpileup.c and htslib's pileup do before any arithmetic: parsing, the read filters of
+ *  mplp_func (mpileup.c:183-246: unmapped, secondary / QC-fail / duplicate, orphans) and the pairing of overlapping mates
+ *  (htslib overlap_push).  Then, each a call on the flat read pool:
+ *      bcfgpu_baq            BAQ (sam_prob_realn, mpileup.c:234)
+ *      bcfgpu_overlap_tweak  mate-overlap qualities (bam_mplp_init_overlaps, mpileup.c:640)
+ *      bcfgpu_pileup         the pileup columns of the region, built in HBM
+ *      bcfgpu_mpileup        bcf_call_glfgen x samples + bcf_call_combine per column (mpileup.c:343-347)
+ *  and the record loop prints, VCF-like, what bcf_call2bcf (bam2bcf.c:756-906) puts in the record:
+ *      CHROM POS . REF ALT 0 . DP=..;I16=..;QS=..   PL   <PL of every sample>
+ *  tests/test_c_host.py compares these lines with the reference's goldens test/mpileup/mpileup.{1,2}.out.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <ctype.h>
+#include "bcfgpu.h"
+
+#define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s: %s (%d)\n", #call, bcfgpu_last_error(), rc_); exit(1); } } while (0)
+#define DIE(...) do { fprintf(stderr, __VA_ARGS__); exit(1); } while (0)
+
+typedef struct {
+    int n, cap;                                   /* reads */
+    int32_t *pos, *lq, *flag, *ncig, *cig_off, *seq_off, *smpl, *end, *mpos, *isize, *rnext_same;
+    uint8_t *mapq, *has_zq;
+    char **qname;
+    uint32_t *cig; size_t ncigs, cigcap;
+    uint8_t *seq16, *qual, *zq; size_t nbase, basecap;
+} pool_t;
+
+static void *grow(void *p, size_t n) { p = realloc(p, n ? n : 1); if (!p) DIE("out of memory\n"); return p; }
+
+static int nt16_of(char c)
+{
+    static const char *codes = "=ACMGRSVTWYHKDBN";
+    const char *q = strchr(codes, toupper((unsigned char)c));
+    return (q && *q) ? (int)(q - codes) : 15;
+}
+
+static char *read_contig(const char *path, const char *name, int *len)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) DIE("cannot open %s\n", path);
+    char line[1 << 16], *seq = NULL;
+    size_t n = 0, cap = 0;
+    int in = 0;
+    while (fgets(line, sizeof line, f)) {
+        if (line[0] == '>') {
+            char *e = line + 1;
+            while (*e && !isspace((unsigned char)*e)) ++e;
+            *e = 0;
+            in = strcmp(line + 1, name) == 0;
+            continue;
+        }
+        if (!in) continue;
+        size_t l = strlen(line);
+        while (l && isspace((unsigned char)line[l - 1])) --l;
+        if (n + l + 1 > cap) { cap = (n + l + 1) * 2; seq = grow(seq, cap); }
+        memcpy(seq + n, line, l); n += l;
+    }
+    fclose(f);
+    if (!seq) DIE("contig %s not found in %s\n", name, path);
+    seq[n] = 0; *len = (int)n;
+    return seq;
+}
+
+/* one SAM file = one sample: reads on `contig` that pass mplp_func's filters, appended to the pool */
+static void read_sam(const char *path, const char *contig, int smpl, pool_t *P)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) DIE("cannot open %s\n", path);
+    static char line[1 << 20];
+    while (fgets(line, sizeof line, f)) {
+        if (line[0] == '@') continue;
+        char *fld[12]; int nf = 0;
+        for (char *s = line; nf < 11 && s; ) { fld[nf++] = s; s = strchr(s, '\t'); if (s) *s++ = 0; }
+        if (nf < 11) continue;
+        { char *e = fld[10]; while (*e && *e != '\t' && *e != '\n' && *e != '\r') ++e; *e = 0; }
+        const int flag = atoi(fld[1]);
+        if (strcmp(fld[2], contig) || (flag & 4)) continue;
+        if (flag & (256 | 512 | 1024)) continue;                             /* --ff UNMAP,SECONDARY,QCFAIL,DUP */
+        if ((flag & 1) && !(flag & 2)) continue;                             /* orphans (no -A) */
+        if (P->n == P->cap) {
+            P->cap = P->cap ? 2 * P->cap : 1024;
+            #define G(a) P->a = grow(P->a, (size_t)P->cap * sizeof *P->a)
+            G(pos); G(lq); G(flag); G(ncig); G(cig_off); G(seq_off); G(smpl); G(end); G(mpos); G(isize); G(rnext_same); G(mapq); G(has_zq); G(qname);
+            #undef G
+        }
+        const int r = P->n++;
+        P->qname[r] = strdup(fld[0]);
+        P->flag[r] = flag; P->pos[r] = atoi(fld[3]) - 1; P->mapq[r] = (uint8_t)atoi(fld[4]); P->smpl[r] = smpl; P->has_zq[r] = 0;
+        P->rnext_same[r] = !strcmp(fld[6], "=") || !strcmp(fld[6], fld[2]);
+        P->mpos[r] = atoi(fld[7]) - 1; P->isize[r] = atoi(fld[8]);
+        /* CIGAR */
+        P->cig_off[r] = (int32_t)P->ncigs; P->ncig[r] = 0;
+        int x = P->pos[r];
+        for (const char *c = fld[5]; *c && *c != '*'; ) {
+            char *e; const long l = strtol(c, &e, 10);
+            const char *ops = "MIDNSHP=X", *o = strchr(ops, *e);
+            if (!o) DIE("bad CIGAR in %s\n", path);
+            if (P->ncigs == P->cigcap) { P->cigcap = P->cigcap ? 2 * P->cigcap : 4096; P->cig = grow(P->cig, P->cigcap * 4); }
+            P->cig[P->ncigs++] = (uint32_t)l << 4 | (uint32_t)(o - ops);
+            ++P->ncig[r];
+            if (*e == 'M' || *e == 'D' || *e == 'N' || *e == '=' || *e == 'X') x += (int)l;
+            c = e + 1;
+        }
+        P->end[r] = x;
+        /* SEQ / QUAL */
+        const int lq = fld[9][0] == '*' ? 0 : (int)strlen(fld[9]);
+        P->lq[r] = lq; P->seq_off[r] = (int32_t)P->nbase;
+        if (P->nbase + lq + 1 > P->basecap) {
+            P->basecap = (P->nbase + lq + 1) * 2;
+            P->seq16 = grow(P->seq16, P->basecap); P->qual = grow(P->qual, P->basecap); P->zq = grow(P->zq, P->basecap);
+        }
+        for (int i = 0; i < lq; ++i) {
+            P->seq16[P->nbase + i] = (uint8_t)nt16_of(fld[9][i]);
+            P->qual[P->nbase + i] = fld[10][0] == '*' ? 0xff : (uint8_t)(fld[10][i] - 33);
+            P->zq[P->nbase + i] = 0;
+        }
+        P->nbase += lq;
+    }
+    fclose(f);
+}
+
+/* overlap_push (htslib sam.c) over the reads of one sample in file order: which pairs tweak_overlap_quality sees */
+static int find_pairs(const pool_t *P, int r0, int r1, int32_t *pa, int32_t *pb)
+{
+    int np = 0, nb = 1;
+    while (nb < 2 * (r1 - r0) + 1) nb <<= 1;
+    int32_t *tab = malloc((size_t)nb * sizeof *tab);                         /* open addressing on the read name */
+    uint8_t *paired = calloc((size_t)(r1 - r0) + 1, 1);
+    for (int i = 0; i < nb; ++i) tab[i] = -1;
+    for (int r = r0; r < r1; ++r) {
+        const int f = P->flag[r];
+        if ((f & 8) || !(f & 2)) continue;
+        if (!P->rnext_same[r] || (abs(P->isize[r]) >= 2 * P->lq[r] && P->mpos[r] >= P->end[r])) continue;
+        uint32_t h = 2166136261u;
+        for (const char *c = P->qname[r]; *c; ++c) h = (h ^ (uint8_t)*c) * 16777619u;
+        int slot = (int)(h & (uint32_t)(nb - 1));
+        while (tab[slot] >= 0 && strcmp(P->qname[tab[slot]], P->qname[r])) slot = (slot + 1) & (nb - 1);
+        if (tab[slot] < 0) {
+            if (P->mpos[r] >= P->pos[r] || ((f & 1) && P->mpos[r] == -1)) tab[slot] = r;
+        } else if (!paired[tab[slot] - r0]) {
+            const int a = tab[slot];
+            paired[a - r0] = 1;                    /* the slot stays occupied (probe chains); the name is done */
+            if (P->end[a] > P->pos[r]) { pa[np] = a; pb[np] = r; ++np; }
+        }
+    }
+    free(tab); free(paired);
+    return np;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 6) { fprintf(stderr, "usage: %s ref.fa contig beg end file.sam [file.sam ...]\n", argv[0]); return 2; }
+    const char *contig = argv[2];
+    const int beg = atoi(argv[3]) - 1, end = atoi(argv[4]);                 /* 0-based [beg, end) */
+    const int S = argc - 5, n_sites = end - beg;
+    int ref_len = 0;
+    char *ref = read_contig(argv[1], contig, &ref_len);
+    pool_t P; memset(&P, 0, sizeof P);
+    int *first = malloc((size_t)(S + 1) * sizeof *first);
+    for (int s = 0; s < S; ++s) { first[s] = P.n; read_sam(argv[5 + s], contig, s, &P); }
+    first[S] = P.n;
+
+    bcfgpu_cfg cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.device = 0; cfg.n_smpl = S; cfg.max_sites = n_sites; cfg.max_reads = (uint64_t)P.nbase + 64;   /* every base is in <= 1 column */
+    cfg.min_baseQ = 13; cfg.capQ = 60; cfg.errmod_theta = 0.; cfg.fmt_flag = BCFGPU_INFO_VDB | BCFGPU_INFO_RPB;
+    cfg.call_theta = 1.1e-3; cfg.n_grp = 1; cfg.ploidy_max = 2;
+    bcfgpu_ctx *ctx = NULL;
+    CHECK(bcfgpu_create(&cfg, &ctx));
+
+    bcfgpu_reads rd; memset(&rd, 0, sizeof rd);
+    rd.n_reads = P.n; rd.r_pos = P.pos; rd.r_lq = P.lq; rd.r_flag = P.flag; rd.r_ncig = P.ncig; rd.r_cig_off = P.cig_off;
+    rd.r_seq_off = P.seq_off; rd.cig = P.cig; rd.seq16 = P.seq16; rd.qual = P.qual; rd.zq = P.zq; rd.r_has_zq = P.has_zq;
+
+    /* BAQ: new qualities for the reads it applies to */
+    uint8_t *q1 = malloc(P.nbase + 1), *zq = malloc(P.nbase + 1), *q2 = malloc(P.nbase + 1);
+    int32_t *ret = malloc((size_t)(P.n + 1) * sizeof *ret);
+    CHECK(bcfgpu_baq(ctx, &rd, ref, ref_len, 3, q1, zq, ret));
+    rd.qual = q1;
+    /* mate overlaps, sample by sample */
+    int32_t *pa = malloc((size_t)(P.n + 1) * sizeof *pa), *pb = malloc((size_t)(P.n + 1) * sizeof *pb);
+    int np = 0;
+    for (int s = 0; s < S; ++s) np += find_pairs(&P, first[s], first[s + 1], pa + np, pb + np);
+    CHECK(bcfgpu_overlap_tweak(ctx, &rd, np, pa, pb, q2));
+    rd.qual = q2;
+    /* the pileup of the region and the SNP pass */
+    bcfgpu_tile tile;
+    int32_t *col_n = malloc((size_t)(n_sites + 1) * sizeof *col_n);
+    CHECK(bcfgpu_pileup(ctx, &rd, P.mapq, P.smpl, beg, end, ref, ref_len, &tile, col_n, NULL));
+    bcfgpu_mplp_out mo; memset(&mo, 0, sizeof mo);
+    void *d_site, *d_pl, *d_dp4;
+    const size_t nb_site = (size_t)n_sites * sizeof(bcfgpu_site), nb_pl = (size_t)n_sites * BCFGPU_MAX_PL * S, nb_dp4 = (size_t)n_sites * 4 * S;
+    CHECK(bcfgpu_malloc(ctx, nb_site, &d_site)); CHECK(bcfgpu_malloc(ctx, nb_pl, &d_pl)); CHECK(bcfgpu_malloc(ctx, nb_dp4, &d_dp4));
+    CHECK(bcfgpu_memset(ctx, d_pl, 0, nb_pl));
+    mo.site = d_site; mo.pl = d_pl; mo.dp4 = d_dp4;
+    CHECK(bcfgpu_mpileup(ctx, &tile, &mo));
+    CHECK(bcfgpu_sync(ctx));
+    bcfgpu_site *site = malloc(nb_site);
+    uint8_t *pl = malloc(nb_pl);
+    CHECK(bcfgpu_memcpy_d2h(ctx, site, d_site, nb_site)); CHECK(bcfgpu_memcpy_d2h(ctx, pl, d_pl, nb_pl));
+    CHECK(bcfgpu_sync(ctx));
+
+    /* the record loop: what bcf_call2bcf writes for a SNP record */
+    static const char *nt = "ACGTN";
+    for (int k = 0; k < n_sites; ++k) {
+        if (col_n[k] == 0) continue;                                         /* no read: no record */
+        const bcfgpu_site *c = &site[k];
+        printf("%s\t%d\t.\t%c\t", contig, beg + k + 1, nt[c->ori_ref < 0 || c->ori_ref > 4 ? 4 : c->ori_ref]);
+        for (int j = 1; j < c->n_alleles; ++j) {
+            if (j > 1) putchar(',');
+            if (j == c->unseen) fputs("<*>", stdout); else putchar(nt[c->a[j]]);
+        }
+        if (c->n_alleles < 2) putchar('.');
+        printf("\t0\t.\tDP=%u;I16=", c->ori_depth);
+        for (int j = 0; j < 16; ++j) printf("%s%g", j ? "," : "", (double)(float)c->anno[j]);
+        fputs(";QS=", stdout);
+        for (int j = 0; j < c->n_alleles; ++j) printf("%s%g", j ? "," : "", (double)c->qsum[j]);
+        fputs("\tPL", stdout);
+        const int x = c->n_alleles * (c->n_alleles + 1) / 2;
+        for (int s = 0; s < S; ++s) {
+            putchar('\t');
+            for (int j = 0; j < x; ++j) printf("%s%d", j ? "," : "", pl[((size_t)k * BCFGPU_MAX_PL + j) * S + s]);
+        }
+        putchar('\n');
+    }
+    fprintf(stderr, "%d reads of %d samples, %d overlapping pairs, %llu pileup entries in %d columns\n",
+            P.n, S, np, (unsigned long long)tile.n_reads, n_sites);
+    bcfgpu_free(ctx, d_site); bcfgpu_free(ctx, d_pl); bcfgpu_free(ctx, d_dp4);
+    bcfgpu_destroy(ctx);
+    return 0;
+}
