@@ -11,7 +11,7 @@
  *      bcfgpu_pileup         the pileup columns of the region, built in HBM
  *      bcfgpu_mpileup        bcf_call_glfgen x samples + bcf_call_combine per column (mpileup.c:343-347)
  *  and the record loop prints, VCF-like, what bcf_call2bcf (bam2bcf.c:756-906) puts in the record:
- *      CHROM POS . REF ALT 0 . DP=..;I16=..;QS=..   PL   <PL of every sample>
+ *      CHROM POS . REF ALT 0 . DP=..;I16=..;QS=..;VDB=..;SGB=..;RPB=..;MQB=..;MQSB=..;BQB=..;MQ0F=..   PL   <PL of every sample>
  *  tests/test_c_host.py compares these lines with the reference's goldens test/mpileup/mpileup.{1,2}.out.
  */
 #include <stdio.h>
@@ -19,6 +19,7 @@
 #include <string.h>
 #include <stdint.h>
 #include <ctype.h>
+#include <math.h>
 #include "bcfgpu.h"
 
 #define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s: %s (%d)\n", #call, bcfgpu_last_error(), rc_); exit(1); } } while (0)
@@ -222,6 +223,13 @@ int main(int argc, char **argv)
         for (int j = 0; j < 16; ++j) printf("%s%g", j ? "," : "", (double)(float)c->anno[j]);
         fputs(";QS=", stdout);
         for (int j = 0; j < c->n_alleles; ++j) printf("%s%g", j ? "," : "", (double)c->qsum[j]);
+        /* the bias statistics: HUGE_VAL = the tag is left out (bam2bcf.c:835-840) */
+        {
+            const char *tag[6] = { "VDB", "SGB", "RPB", "MQB", "MQSB", "BQB" };
+            const float val[6] = { c->vdb, c->seg_bias, c->mwu_pos, c->mwu_mq, c->mwu_mqs, c->mwu_bq };
+            for (int j = 0; j < 6; ++j) if (val[j] != HUGE_VALF) printf(";%s=%g", tag[j], (double)val[j]);
+        }
+        printf(";MQ0F=%g", c->ori_depth ? (double)((float)c->mq0 / (float)c->ori_depth) : 0.);
         fputs("\tPL", stdout);
         const int x = c->n_alleles * (c->n_alleles + 1) / 2;
         for (int s = 0; s < S; ++s) {

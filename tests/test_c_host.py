@@ -159,5 +159,10 @@ def test_c_sam_driver_reproduces_reference_goldens(golden_dir, region, goldf, n_
         assert c.info_floats("I16") == g.info_floats("I16"), (p, c.info["I16"], g.info["I16"])
         for a, b in zip(c.info_floats("QS"), g.info_floats("QS")):
             assert abs(a - b) <= 2e-5 * max(abs(a), abs(b)) + 1e-9, (p, c.info["QS"], g.info["QS"])
+        for tag in ("VDB", "SGB", "RPB", "MQB", "MQSB", "BQB", "MQ0F"):
+            assert (tag in c.info) == (tag in g.info), (p, tag)
+            if tag in g.info:
+                a, b = float(c.info[tag]), float(g.info[tag])
+                assert abs(a - b) <= 2e-5 * max(abs(a), abs(b)) + 1e-9, (p, tag, a, b)
         for s in range(3):
             assert c.fmt("PL", s) == g.fmt("PL", s), (p, s, c.fmt("PL", s), g.fmt("PL", s))
