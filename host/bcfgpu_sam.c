@@ -1,5 +1,5 @@
 /*  bcfgpu_sam.c -- `bcftools mpileup` over SAM files with every stage of the path on the device, in plain C over the
- *  C-ABI of include/bcfgpu.h (SNP records; one sample per file, in file order).
+ *  C-ABI of include/bcfgpu.h (SNP and indel records; one sample per file, in file order).
  *
  *      bcfgpu_sam <ref.fa> <contig> <beg> <end> <file.sam> [<file.sam> ...]         (beg, end 1-based inclusive)
  *
@@ -10,9 +10,12 @@
  *      bcfgpu_overlap_tweak  mate-overlap qualities (bam_mplp_init_overlaps, mpileup.c:640)
  *      bcfgpu_pileup         the pileup columns of the region, built in HBM
  *      bcfgpu_mpileup        bcf_call_glfgen x samples + bcf_call_combine per column (mpileup.c:343-347)
+ *  and for the columns where some read is followed by an indel (mpileup.c:354-365):
+ *      bcfgpu_pileup_entries -> bcfgpu_gap_prep (bcf_call_gap_prep) -> bcfgpu_pileup_indel_tile -> bcfgpu_mpileup
  *  and the record loop prints, VCF-like, what bcf_call2bcf (bam2bcf.c:756-906) puts in the record:
  *      CHROM POS . REF ALT 0 . DP=..;I16=..;QS=..;VDB=..;SGB=..;RPB=..;MQB=..;MQSB=..;BQB=..;MQ0F=..   PL   <PL of every sample>
- *  tests/test_c_host.py compares these lines with the reference's goldens test/mpileup/mpileup.{1,2}.out.
+ *  (indel records: INDEL;IDV=..;IMF=.. in front).  tests/test_c_host.py compares these lines with the reference's goldens
+ *  test/mpileup/mpileup.{1,2}.out.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -156,6 +159,32 @@ static int find_pairs(const pool_t *P, int r0, int r1, int32_t *pa, int32_t *pb)
     return np;
 }
 
+#define INSCNS_CAP 256
+
+/* what bcf_call2bcf writes into a record (bam2bcf.c:756-906); alleles: the ready REF\tALT text */
+static void print_record(const char *contig, int pos1, const char *alleles, const char *prefix, const bcfgpu_site *c,
+                         const uint8_t *pl, size_t k, int S)
+{
+    printf("%s\t%d\t.\t%s\t0\t.\t%sDP=%u;I16=", contig, pos1, alleles, prefix, c->ori_depth);
+    for (int j = 0; j < 16; ++j) printf("%s%g", j ? "," : "", (double)(float)c->anno[j]);
+    fputs(";QS=", stdout);
+    for (int j = 0; j < c->n_alleles; ++j) printf("%s%g", j ? "," : "", (double)c->qsum[j]);
+    /* the bias statistics: HUGE_VAL = the tag is left out (bam2bcf.c:835-840) */
+    {
+        const char *tag[6] = { "VDB", "SGB", "RPB", "MQB", "MQSB", "BQB" };
+        const float val[6] = { c->vdb, c->seg_bias, c->mwu_pos, c->mwu_mq, c->mwu_mqs, c->mwu_bq };
+        for (int j = 0; j < 6; ++j) if (val[j] != HUGE_VALF) printf(";%s=%g", tag[j], (double)val[j]);
+    }
+    printf(";MQ0F=%g", c->ori_depth ? (double)((float)c->mq0 / (float)c->ori_depth) : 0.);
+    fputs("\tPL", stdout);
+    const int x = c->n_alleles * (c->n_alleles + 1) / 2;
+    for (int s = 0; s < S; ++s) {
+        putchar('\t');
+        for (int j = 0; j < x; ++j) printf("%s%d", j ? "," : "", pl[(k * BCFGPU_MAX_PL + j) * (size_t)S + s]);
+    }
+    putchar('\n');
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 6) { fprintf(stderr, "usage: %s ref.fa contig beg end file.sam [file.sam ...]\n", argv[0]); return 2; }
@@ -185,6 +214,8 @@ int main(int argc, char **argv)
     int32_t *ret = malloc((size_t)(P.n + 1) * sizeof *ret);
     CHECK(bcfgpu_baq(ctx, &rd, ref, ref_len, 3, q1, zq, ret));
     rd.qual = q1;
+    for (int r = 0; r < P.n; ++r) P.has_zq[r] = ret[r] == 0;                 /* the "ZQ" tag sam_prob_realn leaves on the read */
+    rd.zq = zq;
     /* mate overlaps, sample by sample */
     int32_t *pa = malloc((size_t)(P.n + 1) * sizeof *pa), *pb = malloc((size_t)(P.n + 1) * sizeof *pb);
     int np = 0;
@@ -194,7 +225,8 @@ int main(int argc, char **argv)
     /* the pileup of the region and the SNP pass */
     bcfgpu_tile tile;
     int32_t *col_n = malloc((size_t)(n_sites + 1) * sizeof *col_n);
-    CHECK(bcfgpu_pileup(ctx, &rd, P.mapq, P.smpl, beg, end, ref, ref_len, &tile, col_n, NULL));
+    uint8_t *col_indel = malloc((size_t)n_sites + 1);
+    CHECK(bcfgpu_pileup(ctx, &rd, P.mapq, P.smpl, beg, end, ref, ref_len, &tile, col_n, col_indel));
     bcfgpu_mplp_out mo; memset(&mo, 0, sizeof mo);
     void *d_site, *d_pl, *d_dp4;
     const size_t nb_site = (size_t)n_sites * sizeof(bcfgpu_site), nb_pl = (size_t)n_sites * BCFGPU_MAX_PL * S, nb_dp4 = (size_t)n_sites * 4 * S;
@@ -208,35 +240,97 @@ int main(int argc, char **argv)
     CHECK(bcfgpu_memcpy_d2h(ctx, site, d_site, nb_site)); CHECK(bcfgpu_memcpy_d2h(ctx, pl, d_pl, nb_pl));
     CHECK(bcfgpu_sync(ctx));
 
-    /* the record loop: what bcf_call2bcf writes for a SNP record */
+    /* ---- indel records (mpileup.c:354-365): candidate columns -> bcf_call_gap_prep -> second pass with p->aux ---- */
+    int nc = 0;
+    int32_t *cand = malloc((size_t)(n_sites + 1) * sizeof *cand);
+    int64_t cap = 0;
+    for (int k = 0; k < n_sites; ++k)
+        if (col_indel[k] && col_n[k] < 250 * S) { cand[nc++] = k; cap += col_n[k]; }      /* max_indel_depth */
+    bcfgpu_site *isite = NULL; uint8_t *ipl = NULL; int32_t *live = NULL; int nlive = 0;
+    int32_t *g_types = NULL, *g_maxins = NULL, *g_indelreg = NULL, *g_support = NULL; float *g_frac = NULL; int8_t *g_inscns = NULL;
+    if (nc) {
+        int32_t *so = malloc(((size_t)nc * S + 1) * sizeof *so), *pr = malloc((size_t)(cap + 1) * 4), *pq = malloc((size_t)(cap + 1) * 4),
+                *pi = malloc((size_t)(cap + 1) * 4), *cpos = malloc((size_t)nc * 4);
+        CHECK(bcfgpu_pileup_entries(ctx, nc, cand, so, pr, pq, pi, cap));
+        for (int i = 0; i < nc; ++i) cpos[i] = beg + cand[i];
+        bcfgpu_indel_in in; memset(&in, 0, sizeof in);
+        in.n_sites = nc; in.n_smpl = S; in.pos = cpos; in.smpl_off = so; in.p_read = pr; in.p_qpos = pq; in.p_indel = pi; in.ref = ref;
+        in.openQ = 40; in.extQ = 20; in.tandemQ = 100; in.min_support = 1; in.per_sample_flt = 0; in.min_frac = 0.002;   /* mpileup.c:937-950 */
+        bcfgpu_indel_out out; memset(&out, 0, sizeof out);
+        int32_t *gret = malloc((size_t)nc * 4);
+        uint32_t *aux = malloc((size_t)(cap + 1) * 4);
+        g_types = malloc((size_t)nc * 16); g_inscns = malloc((size_t)nc * 4 * INSCNS_CAP); g_maxins = malloc((size_t)nc * 4);
+        g_indelreg = malloc((size_t)nc * 4); g_support = malloc((size_t)nc * 4); g_frac = malloc((size_t)nc * 4);
+        out.ret = gret; out.p_aux = aux; out.indel_types = g_types; out.inscns = g_inscns; out.maxins = g_maxins;
+        out.indelreg = g_indelreg; out.max_support = g_support; out.max_frac = g_frac;
+        CHECK(bcfgpu_gap_prep(ctx, &rd, &in, &out, INSCNS_CAP));
+        live = malloc((size_t)nc * 4);
+        int32_t *lcols = malloc((size_t)nc * 4);
+        uint32_t *laux = malloc((size_t)(cap + 1) * 4);
+        int64_t nl = 0;
+        for (int i = 0; i < nc; ++i)
+            if (gret[i] == 0) {
+                live[nlive] = i; lcols[nlive++] = cand[i];
+                for (int e = so[(size_t)i * S]; e < so[(size_t)(i + 1) * S]; ++e) laux[nl++] = aux[e];
+            }
+        if (nlive) {
+            bcfgpu_tile ti;
+            CHECK(bcfgpu_pileup_indel_tile(ctx, nlive, lcols, laux, nl, &ti));
+            void *d_is, *d_ipl, *d_idp4;
+            CHECK(bcfgpu_malloc(ctx, (size_t)nlive * sizeof(bcfgpu_site), &d_is));
+            CHECK(bcfgpu_malloc(ctx, (size_t)nlive * BCFGPU_MAX_PL * S, &d_ipl));
+            CHECK(bcfgpu_malloc(ctx, (size_t)nlive * 4 * S, &d_idp4));
+            CHECK(bcfgpu_memset(ctx, d_ipl, 0, (size_t)nlive * BCFGPU_MAX_PL * S));
+            bcfgpu_mplp_out io; memset(&io, 0, sizeof io);
+            io.site = d_is; io.pl = d_ipl; io.dp4 = d_idp4;
+            CHECK(bcfgpu_mpileup(ctx, &ti, &io));
+            CHECK(bcfgpu_sync(ctx));
+            isite = malloc((size_t)nlive * sizeof *isite); ipl = malloc((size_t)nlive * BCFGPU_MAX_PL * S);
+            CHECK(bcfgpu_memcpy_d2h(ctx, isite, d_is, (size_t)nlive * sizeof *isite));
+            CHECK(bcfgpu_memcpy_d2h(ctx, ipl, d_ipl, (size_t)nlive * BCFGPU_MAX_PL * S));
+            CHECK(bcfgpu_sync(ctx));
+            bcfgpu_free(ctx, d_is); bcfgpu_free(ctx, d_ipl); bcfgpu_free(ctx, d_idp4);
+        }
+    }
+
+    /* ---- the record loop: the SNP record of a column, then its indel record (mpileup.c:343-366) ---- */
     static const char *nt = "ACGTN";
+    int jl = 0;
     for (int k = 0; k < n_sites; ++k) {
         if (col_n[k] == 0) continue;                                         /* no read: no record */
         const bcfgpu_site *c = &site[k];
-        printf("%s\t%d\t.\t%c\t", contig, beg + k + 1, nt[c->ori_ref < 0 || c->ori_ref > 4 ? 4 : c->ori_ref]);
+        char als[64]; int o = 0;
+        als[o++] = nt[c->ori_ref < 0 || c->ori_ref > 4 ? 4 : c->ori_ref]; als[o++] = '\t';
         for (int j = 1; j < c->n_alleles; ++j) {
-            if (j > 1) putchar(',');
-            if (j == c->unseen) fputs("<*>", stdout); else putchar(nt[c->a[j]]);
+            if (j > 1) als[o++] = ',';
+            if (j == c->unseen) { memcpy(als + o, "<*>", 3); o += 3; } else als[o++] = nt[c->a[j]];
         }
-        if (c->n_alleles < 2) putchar('.');
-        printf("\t0\t.\tDP=%u;I16=", c->ori_depth);
-        for (int j = 0; j < 16; ++j) printf("%s%g", j ? "," : "", (double)(float)c->anno[j]);
-        fputs(";QS=", stdout);
-        for (int j = 0; j < c->n_alleles; ++j) printf("%s%g", j ? "," : "", (double)c->qsum[j]);
-        /* the bias statistics: HUGE_VAL = the tag is left out (bam2bcf.c:835-840) */
-        {
-            const char *tag[6] = { "VDB", "SGB", "RPB", "MQB", "MQSB", "BQB" };
-            const float val[6] = { c->vdb, c->seg_bias, c->mwu_pos, c->mwu_mq, c->mwu_mqs, c->mwu_bq };
-            for (int j = 0; j < 6; ++j) if (val[j] != HUGE_VALF) printf(";%s=%g", tag[j], (double)val[j]);
+        if (c->n_alleles < 2) als[o++] = '.';
+        als[o] = 0;
+        print_record(contig, beg + k + 1, als, "", c, pl, (size_t)k, S);
+        while (jl < nlive && cand[live[jl]] < k) ++jl;
+        if (jl < nlive && cand[live[jl]] == k && isite[jl].ret == 0) {
+            /* REF / ALT of an indel record (bam2bcf.c:767-790) */
+            const int i = live[jl], p = beg + k, ireg = g_indelreg[i], mi = g_maxins[i];
+            char *txt = malloc((size_t)(5 * (ireg + mi + 8)) + 64), prefix[64];
+            int t = 0;
+            for (int j = 0; j <= ireg; ++j) txt[t++] = ref[p + j];
+            txt[t++] = '\t';
+            for (int a = 1; a < 4 && isite[jl].a[a] >= 0; ++a) {
+                const int ai = isite[jl].a[a], ty = g_types[i * 4 + ai];
+                if (a > 1) txt[t++] = ',';
+                txt[t++] = ref[p];
+                if (ty < 0) { for (int j = p + 1 - ty; j < p + 1 + ireg; ++j) txt[t++] = ref[j]; }
+                else {
+                    for (int j = 0; j < ty; ++j) txt[t++] = nt[g_inscns[(size_t)i * 4 * INSCNS_CAP + (size_t)ai * mi + j]];
+                    for (int j = p + 1; j < p + 1 + ireg; ++j) txt[t++] = ref[j];
+                }
+            }
+            txt[t] = 0;
+            snprintf(prefix, sizeof prefix, "INDEL;IDV=%d;IMF=%g;", g_support[i], (double)g_frac[i]);
+            print_record(contig, p + 1, txt, prefix, &isite[jl], ipl, (size_t)jl, S);
+            free(txt);
         }
-        printf(";MQ0F=%g", c->ori_depth ? (double)((float)c->mq0 / (float)c->ori_depth) : 0.);
-        fputs("\tPL", stdout);
-        const int x = c->n_alleles * (c->n_alleles + 1) / 2;
-        for (int s = 0; s < S; ++s) {
-            putchar('\t');
-            for (int j = 0; j < x; ++j) printf("%s%d", j ? "," : "", pl[((size_t)k * BCFGPU_MAX_PL + j) * S + s]);
-        }
-        putchar('\n');
     }
     fprintf(stderr, "%d reads of %d samples, %d overlapping pairs, %llu pileup entries in %d columns\n",
             P.n, S, np, (unsigned long long)tile.n_reads, n_sites);

@@ -139,27 +139,30 @@ SAM_EXE = os.path.join(ROOT, "host", "bcfgpu_sam")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("region,goldf,n_snp", [("100-150", "mpileup.1.out", 51), ("100-600", "mpileup.2.out", 501)])
-def test_c_sam_driver_reproduces_reference_goldens(golden_dir, region, goldf, n_snp):
+@pytest.mark.parametrize("region,goldf,n_snp,n_indel", [("100-150", "mpileup.1.out", 51, 0), ("100-600", "mpileup.2.out", 501, 1)])
+def test_c_sam_driver_reproduces_reference_goldens(golden_dir, region, goldf, n_snp, n_indel):
     """host/bcfgpu_sam.c: SAM files in, every stage on the device (BAQ, mate overlaps, pileup, glfgen + combine), VCF-like
-    records out -- against the SNP records of the reference's test/mpileup/mpileup.{1,2}.out (test.pl:640-641)."""
+    records out -- against every record (SNP and indel) of the reference's test/mpileup/mpileup.{1,2}.out (test.pl:640-641)."""
     from tests.helpers import vcf
     build_host()
     G = os.path.join(golden_dir, "mpileup")
     beg, end = region.split("-")
     out = subprocess.run([SAM_EXE, os.path.join(G, "mpileup.ref.fa"), "17", beg, end] +
                          [os.path.join(G, "mpileup.%d.sam" % i) for i in (1, 2, 3)], check=True, stdout=subprocess.PIPE, text=True).stdout
-    got = {r.pos: r for r in (vcf.Rec(ln) for ln in out.splitlines())}
-    gold = {r.pos: r for r in vcf.Vcf(os.path.join(G, goldf)).recs if "INDEL" not in r.info}
-    assert sorted(got) == sorted(gold) and len(gold) == n_snp
-    for p, g in gold.items():
-        c = got[p]
+    recs = [vcf.Rec(ln) for ln in out.splitlines()]
+    allg = vcf.Vcf(os.path.join(G, goldf)).recs
+    key = lambda r: (r.pos, "INDEL" in r.info)
+    got, gold = {key(r): r for r in recs}, {key(r): r for r in allg}
+    assert [key(r) for r in recs] == [key(r) for r in allg]          # same records in the same order (SNP, then indel)
+    assert sum(1 for k in gold if not k[1]) == n_snp and sum(1 for k in gold if k[1]) == n_indel
+    for k, g in gold.items():
+        c, p = got[k], k
         assert c.alleles == g.alleles, (p, c.alleles, g.alleles)
         assert c.info["DP"] == g.info["DP"], p
         assert c.info_floats("I16") == g.info_floats("I16"), (p, c.info["I16"], g.info["I16"])
         for a, b in zip(c.info_floats("QS"), g.info_floats("QS")):
             assert abs(a - b) <= 2e-5 * max(abs(a), abs(b)) + 1e-9, (p, c.info["QS"], g.info["QS"])
-        for tag in ("VDB", "SGB", "RPB", "MQB", "MQSB", "BQB", "MQ0F"):
+        for tag in ("VDB", "SGB", "RPB", "MQB", "MQSB", "BQB", "MQ0F", "IDV", "IMF"):
             assert (tag in c.info) == (tag in g.info), (p, tag)
             if tag in g.info:
                 a, b = float(c.info[tag]), float(g.info[tag])
