@@ -1,7 +1,7 @@
 /*  bcfgpu_sam.c -- `bcftools mpileup` over SAM files with every stage of the path on the device, in plain C over the
  *  C-ABI of include/bcfgpu.h (SNP and indel records; one sample per file, in file order).
  *
- *      bcfgpu_sam <ref.fa> <contig> <beg> <end> <file.sam> [<file.sam> ...]         (beg, end 1-based inclusive)
+ *      bcfgpu_sam [-a DP,DV] <ref.fa> <contig> <beg> <end> <file.sam> [<file.sam> ...]     (beg, end 1-based inclusive)
  *
  *  What stays on the host is what mpileup.c and htslib's pileup do before any arithmetic: parsing, the read filters of
  *  mplp_func (mpileup.c:183-246: unmapped, secondary / QC-fail / duplicate, orphans) and the pairing of overlapping mates
@@ -14,7 +14,8 @@
  *      bcfgpu_pileup_entries -> bcfgpu_gap_prep (bcf_call_gap_prep) -> bcfgpu_pileup_indel_tile -> bcfgpu_mpileup
  *  and the record loop prints, VCF-like, what bcf_call2bcf (bam2bcf.c:756-906) puts in the record:
  *      CHROM POS . REF ALT 0 . DP=..;I16=..;QS=..;VDB=..;SGB=..;RPB=..;MQB=..;MQSB=..;BQB=..;MQ0F=..   PL   <PL of every sample>
- *  (indel records: INDEL;IDV=..;IMF=.. in front).  tests/test_c_host.py compares these lines with the reference's goldens
+ *  (indel records: INDEL;IDV=..;IMF=.. in front; with -a DP,DV the FORMAT column is PL:DP:DV).  The lines are the data lines
+ *  of `bcftools mpileup`'s VCF: tests/test_c_host.py compares them, byte for byte, with the reference's goldens
  *  test/mpileup/mpileup.{1,2}.out.
  */
 #include <stdio.h>
@@ -162,8 +163,10 @@ static int find_pairs(const pool_t *P, int r0, int r1, int32_t *pa, int32_t *pb)
 #define INSCNS_CAP 256
 
 /* what bcf_call2bcf writes into a record (bam2bcf.c:756-906); alleles: the ready REF\tALT text */
+static int want_dp_dv = 0;
+
 static void print_record(const char *contig, int pos1, const char *alleles, const char *prefix, const bcfgpu_site *c,
-                         const uint8_t *pl, size_t k, int S)
+                         const uint8_t *pl, const uint8_t *dp4, size_t k, int S)
 {
     printf("%s\t%d\t.\t%s\t0\t.\t%sDP=%u;I16=", contig, pos1, alleles, prefix, c->ori_depth);
     for (int j = 0; j < 16; ++j) printf("%s%g", j ? "," : "", (double)(float)c->anno[j]);
@@ -176,18 +179,26 @@ static void print_record(const char *contig, int pos1, const char *alleles, cons
         for (int j = 0; j < 6; ++j) if (val[j] != HUGE_VALF) printf(";%s=%g", tag[j], (double)val[j]);
     }
     printf(";MQ0F=%g", c->ori_depth ? (double)((float)c->mq0 / (float)c->ori_depth) : 0.);
-    fputs("\tPL", stdout);
+    fputs(want_dp_dv ? "\tPL:DP:DV" : "\tPL", stdout);
     const int x = c->n_alleles * (c->n_alleles + 1) / 2;
     for (int s = 0; s < S; ++s) {
         putchar('\t');
         for (int j = 0; j < x; ++j) printf("%s%d", j ? "," : "", pl[(k * BCFGPU_MAX_PL + j) * (size_t)S + s]);
+        if (want_dp_dv) {                                                    /* FORMAT/DP, DV from DP4 (bam2bcf.c:851-866) */
+            const uint8_t *d = dp4 + k * 4 * (size_t)S + s;
+            printf(":%d:%d", d[0] + d[(size_t)S] + d[2 * (size_t)S] + d[3 * (size_t)S], d[2 * (size_t)S] + d[3 * (size_t)S]);
+        }
     }
     putchar('\n');
 }
 
 int main(int argc, char **argv)
 {
-    if (argc < 6) { fprintf(stderr, "usage: %s ref.fa contig beg end file.sam [file.sam ...]\n", argv[0]); return 2; }
+    if (argc > 2 && !strcmp(argv[1], "-a")) {
+        if (strcmp(argv[2], "DP,DV")) DIE("only -a DP,DV is known\n");
+        want_dp_dv = 1; argv += 2; argc -= 2;
+    }
+    if (argc < 6) { fprintf(stderr, "usage: bcfgpu_sam [-a DP,DV] ref.fa contig beg end file.sam [file.sam ...]\n"); return 2; }
     const char *contig = argv[2];
     const int beg = atoi(argv[3]) - 1, end = atoi(argv[4]);                 /* 0-based [beg, end) */
     const int S = argc - 5, n_sites = end - beg;
@@ -236,8 +247,9 @@ int main(int argc, char **argv)
     CHECK(bcfgpu_mpileup(ctx, &tile, &mo));
     CHECK(bcfgpu_sync(ctx));
     bcfgpu_site *site = malloc(nb_site);
-    uint8_t *pl = malloc(nb_pl);
+    uint8_t *pl = malloc(nb_pl), *dp4 = malloc(nb_dp4);
     CHECK(bcfgpu_memcpy_d2h(ctx, site, d_site, nb_site)); CHECK(bcfgpu_memcpy_d2h(ctx, pl, d_pl, nb_pl));
+    CHECK(bcfgpu_memcpy_d2h(ctx, dp4, d_dp4, nb_dp4));
     CHECK(bcfgpu_sync(ctx));
 
     /* ---- indel records (mpileup.c:354-365): candidate columns -> bcf_call_gap_prep -> second pass with p->aux ---- */
@@ -246,7 +258,7 @@ int main(int argc, char **argv)
     int64_t cap = 0;
     for (int k = 0; k < n_sites; ++k)
         if (col_indel[k] && col_n[k] < 250 * S) { cand[nc++] = k; cap += col_n[k]; }      /* max_indel_depth */
-    bcfgpu_site *isite = NULL; uint8_t *ipl = NULL; int32_t *live = NULL; int nlive = 0;
+    bcfgpu_site *isite = NULL; uint8_t *ipl = NULL, *idp4 = NULL; int32_t *live = NULL; int nlive = 0;
     int32_t *g_types = NULL, *g_maxins = NULL, *g_indelreg = NULL, *g_support = NULL; float *g_frac = NULL; int8_t *g_inscns = NULL;
     if (nc) {
         int32_t *so = malloc(((size_t)nc * S + 1) * sizeof *so), *pr = malloc((size_t)(cap + 1) * 4), *pq = malloc((size_t)(cap + 1) * 4),
@@ -285,9 +297,10 @@ int main(int argc, char **argv)
             io.site = d_is; io.pl = d_ipl; io.dp4 = d_idp4;
             CHECK(bcfgpu_mpileup(ctx, &ti, &io));
             CHECK(bcfgpu_sync(ctx));
-            isite = malloc((size_t)nlive * sizeof *isite); ipl = malloc((size_t)nlive * BCFGPU_MAX_PL * S);
+            isite = malloc((size_t)nlive * sizeof *isite); ipl = malloc((size_t)nlive * BCFGPU_MAX_PL * S); idp4 = malloc((size_t)nlive * 4 * S);
             CHECK(bcfgpu_memcpy_d2h(ctx, isite, d_is, (size_t)nlive * sizeof *isite));
             CHECK(bcfgpu_memcpy_d2h(ctx, ipl, d_ipl, (size_t)nlive * BCFGPU_MAX_PL * S));
+            CHECK(bcfgpu_memcpy_d2h(ctx, idp4, d_idp4, (size_t)nlive * 4 * S));
             CHECK(bcfgpu_sync(ctx));
             bcfgpu_free(ctx, d_is); bcfgpu_free(ctx, d_ipl); bcfgpu_free(ctx, d_idp4);
         }
@@ -307,7 +320,7 @@ int main(int argc, char **argv)
         }
         if (c->n_alleles < 2) als[o++] = '.';
         als[o] = 0;
-        print_record(contig, beg + k + 1, als, "", c, pl, (size_t)k, S);
+        print_record(contig, beg + k + 1, als, "", c, pl, dp4, (size_t)k, S);
         while (jl < nlive && cand[live[jl]] < k) ++jl;
         if (jl < nlive && cand[live[jl]] == k && isite[jl].ret == 0) {
             /* REF / ALT of an indel record (bam2bcf.c:767-790) */
@@ -328,7 +341,7 @@ int main(int argc, char **argv)
             }
             txt[t] = 0;
             snprintf(prefix, sizeof prefix, "INDEL;IDV=%d;IMF=%g;", g_support[i], (double)g_frac[i]);
-            print_record(contig, p + 1, txt, prefix, &isite[jl], ipl, (size_t)jl, S);
+            print_record(contig, p + 1, txt, prefix, &isite[jl], ipl, idp4, (size_t)jl, S);
             free(txt);
         }
     }
