@@ -1,7 +1,7 @@
 /*  bcfgpu_sam.c -- `bcftools mpileup` over SAM files with every stage of the path on the device, in plain C over the
  *  C-ABI of include/bcfgpu.h (SNP and indel records; one sample per file, in file order).
  *
- *      bcfgpu_sam [-a DP,DV] <ref.fa> <contig> <beg> <end> <file.sam> [<file.sam> ...]     (beg, end 1-based inclusive)
+ *      bcfgpu_sam [-a TAG,TAG,..] <ref.fa> <contig> <beg> <end> <file.sam> [<file.sam> ...]     (beg, end 1-based inclusive)
  *
  *  What stays on the host is what mpileup.c and htslib's pileup do before any arithmetic: parsing, the read filters of
  *  mplp_func (mpileup.c:183-246: unmapped, secondary / QC-fail / duplicate, orphans) and the pairing of overlapping mates
@@ -14,9 +14,10 @@
  *      bcfgpu_pileup_entries -> bcfgpu_gap_prep (bcf_call_gap_prep) -> bcfgpu_pileup_indel_tile -> bcfgpu_mpileup
  *  and the record loop prints, VCF-like, what bcf_call2bcf (bam2bcf.c:756-906) puts in the record:
  *      CHROM POS . REF ALT 0 . DP=..;I16=..;QS=..;VDB=..;SGB=..;RPB=..;MQB=..;MQSB=..;BQB=..;MQ0F=..   PL   <PL of every sample>
- *  (indel records: INDEL;IDV=..;IMF=.. in front; with -a DP,DV the FORMAT column is PL:DP:DV).  The lines are the data lines
+ *  (indel records: INDEL;IDV=..;IMF=.. in front; -a adds DP, DV, SP, DP4, AD, ADF, ADR, DPR, INFO/AD, INFO/ADF, INFO/ADR,
+ *  INFO/DPR in bcf_call2bcf's order).  The lines are the data lines
  *  of `bcftools mpileup`'s VCF: tests/test_c_host.py compares them, byte for byte, with the reference's goldens
- *  test/mpileup/mpileup.{1,2}.out.
+ *  test/mpileup/mpileup.{1,2,4,5}.out.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -163,15 +164,30 @@ static int find_pairs(const pool_t *P, int r0, int r1, int32_t *pa, int32_t *pb)
 #define INSCNS_CAP 256
 
 /* what bcf_call2bcf writes into a record (bam2bcf.c:756-906); alleles: the ready REF\tALT text */
-static int want_dp_dv = 0;
+static int fmt_flag = BCFGPU_INFO_VDB | BCFGPU_INFO_RPB;                     /* mpileup's default annotations + -a */
 
-static void print_record(const char *contig, int pos1, const char *alleles, const char *prefix, const bcfgpu_site *c,
-                         const uint8_t *pl, const uint8_t *dp4, size_t k, int S)
+typedef struct { const uint8_t *pl, *dp4, *adf, *adr, *sp; } planes_t;        /* host copies of bcfgpu_mplp_out's planes */
+
+static void put_counts(const char *lead, const int32_t *f, const int32_t *r, int n)
 {
-    printf("%s\t%d\t.\t%s\t0\t.\t%sDP=%u;I16=", contig, pos1, alleles, prefix, c->ori_depth);
+    fputs(lead, stdout);
+    for (int j = 0; j < n; ++j) printf("%s%d", j ? "," : "", (f ? f[j] : 0) + (r ? r[j] : 0));
+}
+
+/* what bcf_call2bcf writes into a record, in its order (bam2bcf.c:756-906); alleles: the ready REF\tALT text */
+static void print_record(const char *contig, int pos1, const char *alleles, const char *prefix, const bcfgpu_site *c,
+                         const planes_t *pp, size_t k, int S)
+{
+    const int na = c->n_alleles;
+    printf("%s\t%d\t.\t%s\t0\t.\t%sDP=%u", contig, pos1, alleles, prefix, c->ori_depth);
+    if (fmt_flag & BCFGPU_INFO_ADF) put_counts(";ADF=", c->adf_tot, NULL, na);
+    if (fmt_flag & BCFGPU_INFO_ADR) put_counts(";ADR=", NULL, c->adr_tot, na);
+    if (fmt_flag & BCFGPU_INFO_AD)  put_counts(";AD=", c->adf_tot, c->adr_tot, na);
+    if (fmt_flag & BCFGPU_INFO_DPR) put_counts(";DPR=", c->adf_tot, c->adr_tot, na);
+    fputs(";I16=", stdout);
     for (int j = 0; j < 16; ++j) printf("%s%g", j ? "," : "", (double)(float)c->anno[j]);
     fputs(";QS=", stdout);
-    for (int j = 0; j < c->n_alleles; ++j) printf("%s%g", j ? "," : "", (double)c->qsum[j]);
+    for (int j = 0; j < na; ++j) printf("%s%g", j ? "," : "", (double)c->qsum[j]);
     /* the bias statistics: HUGE_VAL = the tag is left out (bam2bcf.c:835-840) */
     {
         const char *tag[6] = { "VDB", "SGB", "RPB", "MQB", "MQSB", "BQB" };
@@ -179,14 +195,33 @@ static void print_record(const char *contig, int pos1, const char *alleles, cons
         for (int j = 0; j < 6; ++j) if (val[j] != HUGE_VALF) printf(";%s=%g", tag[j], (double)val[j]);
     }
     printf(";MQ0F=%g", c->ori_depth ? (double)((float)c->mq0 / (float)c->ori_depth) : 0.);
-    fputs(want_dp_dv ? "\tPL:DP:DV" : "\tPL", stdout);
-    const int x = c->n_alleles * (c->n_alleles + 1) / 2;
+    fputs("\tPL", stdout);
+    if (fmt_flag & BCFGPU_FMT_DP) fputs(":DP", stdout);
+    if (fmt_flag & BCFGPU_FMT_DV) fputs(":DV", stdout);
+    if (fmt_flag & BCFGPU_FMT_SP) fputs(":SP", stdout);
+    if (fmt_flag & BCFGPU_FMT_DP4) fputs(":DP4", stdout);
+    if (fmt_flag & BCFGPU_FMT_ADF) fputs(":ADF", stdout);
+    if (fmt_flag & BCFGPU_FMT_ADR) fputs(":ADR", stdout);
+    if (fmt_flag & BCFGPU_FMT_AD) fputs(":AD", stdout);
+    if (fmt_flag & BCFGPU_FMT_DPR) fputs(":DPR", stdout);
+    const int x = na * (na + 1) / 2;
+    const size_t Ss = (size_t)S;
     for (int s = 0; s < S; ++s) {
         putchar('\t');
-        for (int j = 0; j < x; ++j) printf("%s%d", j ? "," : "", pl[(k * BCFGPU_MAX_PL + j) * (size_t)S + s]);
-        if (want_dp_dv) {                                                    /* FORMAT/DP, DV from DP4 (bam2bcf.c:851-866) */
-            const uint8_t *d = dp4 + k * 4 * (size_t)S + s;
-            printf(":%d:%d", d[0] + d[(size_t)S] + d[2 * (size_t)S] + d[3 * (size_t)S], d[2 * (size_t)S] + d[3 * (size_t)S]);
+        for (int j = 0; j < x; ++j) printf("%s%d", j ? "," : "", pp->pl[(k * BCFGPU_MAX_PL + j) * Ss + s]);
+        const uint8_t *d = pp->dp4 + k * 4 * Ss + s;                         /* FORMAT/DP, DV, DP4 from DP4 (bam2bcf.c:851-886) */
+        if (fmt_flag & BCFGPU_FMT_DP) printf(":%d", d[0] + d[Ss] + d[2 * Ss] + d[3 * Ss]);
+        if (fmt_flag & BCFGPU_FMT_DV) printf(":%d", d[2 * Ss] + d[3 * Ss]);
+        if (fmt_flag & BCFGPU_FMT_SP) printf(":%d", pp->sp[k * Ss + s]);
+        if (fmt_flag & BCFGPU_FMT_DP4) printf(":%d,%d,%d,%d", d[0], d[Ss], d[2 * Ss], d[3 * Ss]);
+        for (int which = 0; which < 4; ++which) {                            /* ADF, ADR, AD, DPR */
+            static const int bit[4] = { BCFGPU_FMT_ADF, BCFGPU_FMT_ADR, BCFGPU_FMT_AD, BCFGPU_FMT_DPR };
+            if (!(fmt_flag & bit[which])) continue;
+            putchar(':');
+            for (int j = 0; j < na; ++j) {
+                const int f = pp->adf[(k * 5 + j) * Ss + s], r = pp->adr[(k * 5 + j) * Ss + s];
+                printf("%s%d", j ? "," : "", which == 0 ? f : which == 1 ? r : f + r);
+            }
         }
     }
     putchar('\n');
@@ -194,11 +229,21 @@ static void print_record(const char *contig, int pos1, const char *alleles, cons
 
 int main(int argc, char **argv)
 {
-    if (argc > 2 && !strcmp(argv[1], "-a")) {
-        if (strcmp(argv[2], "DP,DV")) DIE("only -a DP,DV is known\n");
-        want_dp_dv = 1; argv += 2; argc -= 2;
+    if (argc > 2 && !strcmp(argv[1], "-a")) {                                 /* mpileup -a, mpileup.c:parse_format_flag */
+        static const struct { const char *name; int bit; } tags[] = {
+            { "DP", BCFGPU_FMT_DP }, { "DV", BCFGPU_FMT_DV }, { "SP", BCFGPU_FMT_SP }, { "DP4", BCFGPU_FMT_DP4 }, { "DPR", BCFGPU_FMT_DPR },
+            { "AD", BCFGPU_FMT_AD }, { "ADF", BCFGPU_FMT_ADF }, { "ADR", BCFGPU_FMT_ADR }, { "INFO/DPR", BCFGPU_INFO_DPR },
+            { "INFO/AD", BCFGPU_INFO_AD }, { "INFO/ADF", BCFGPU_INFO_ADF }, { "INFO/ADR", BCFGPU_INFO_ADR } };
+        char *list = strdup(argv[2]);
+        for (char *t = strtok(list, ","); t; t = strtok(NULL, ",")) {
+            size_t i;
+            for (i = 0; i < sizeof tags / sizeof tags[0]; ++i) if (!strcmp(t, tags[i].name)) { fmt_flag |= tags[i].bit; break; }
+            if (i == sizeof tags / sizeof tags[0]) DIE("unknown tag %s\n", t);
+        }
+        free(list);
+        argv += 2; argc -= 2;
     }
-    if (argc < 6) { fprintf(stderr, "usage: bcfgpu_sam [-a DP,DV] ref.fa contig beg end file.sam [file.sam ...]\n"); return 2; }
+    if (argc < 6) { fprintf(stderr, "usage: bcfgpu_sam [-a TAG,..] ref.fa contig beg end file.sam [file.sam ...]\n"); return 2; }
     const char *contig = argv[2];
     const int beg = atoi(argv[3]) - 1, end = atoi(argv[4]);                 /* 0-based [beg, end) */
     const int S = argc - 5, n_sites = end - beg;
@@ -211,7 +256,7 @@ int main(int argc, char **argv)
 
     bcfgpu_cfg cfg; memset(&cfg, 0, sizeof cfg);
     cfg.device = 0; cfg.n_smpl = S; cfg.max_sites = n_sites; cfg.max_reads = (uint64_t)P.nbase + 64;   /* every base is in <= 1 column */
-    cfg.min_baseQ = 13; cfg.capQ = 60; cfg.errmod_theta = 0.; cfg.fmt_flag = BCFGPU_INFO_VDB | BCFGPU_INFO_RPB;
+    cfg.min_baseQ = 13; cfg.capQ = 60; cfg.errmod_theta = 0.; cfg.fmt_flag = fmt_flag;
     cfg.call_theta = 1.1e-3; cfg.n_grp = 1; cfg.ploidy_max = 2;
     bcfgpu_ctx *ctx = NULL;
     CHECK(bcfgpu_create(&cfg, &ctx));
@@ -239,17 +284,22 @@ int main(int argc, char **argv)
     uint8_t *col_indel = malloc((size_t)n_sites + 1);
     CHECK(bcfgpu_pileup(ctx, &rd, P.mapq, P.smpl, beg, end, ref, ref_len, &tile, col_n, col_indel));
     bcfgpu_mplp_out mo; memset(&mo, 0, sizeof mo);
-    void *d_site, *d_pl, *d_dp4;
-    const size_t nb_site = (size_t)n_sites * sizeof(bcfgpu_site), nb_pl = (size_t)n_sites * BCFGPU_MAX_PL * S, nb_dp4 = (size_t)n_sites * 4 * S;
+    void *d_site, *d_pl, *d_dp4, *d_adf, *d_adr, *d_sp;
+    const size_t nb_site = (size_t)n_sites * sizeof(bcfgpu_site), nb_pl = (size_t)n_sites * BCFGPU_MAX_PL * S, nb_dp4 = (size_t)n_sites * 4 * S,
+                 nb_ad = (size_t)n_sites * 5 * S, nb_sp = (size_t)n_sites * S;
     CHECK(bcfgpu_malloc(ctx, nb_site, &d_site)); CHECK(bcfgpu_malloc(ctx, nb_pl, &d_pl)); CHECK(bcfgpu_malloc(ctx, nb_dp4, &d_dp4));
-    CHECK(bcfgpu_memset(ctx, d_pl, 0, nb_pl));
-    mo.site = d_site; mo.pl = d_pl; mo.dp4 = d_dp4;
+    CHECK(bcfgpu_malloc(ctx, nb_ad, &d_adf)); CHECK(bcfgpu_malloc(ctx, nb_ad, &d_adr)); CHECK(bcfgpu_malloc(ctx, nb_sp, &d_sp));
+    CHECK(bcfgpu_memset(ctx, d_pl, 0, nb_pl)); CHECK(bcfgpu_memset(ctx, d_adf, 0, nb_ad)); CHECK(bcfgpu_memset(ctx, d_adr, 0, nb_ad));
+    CHECK(bcfgpu_memset(ctx, d_sp, 0, nb_sp));
+    mo.site = d_site; mo.pl = d_pl; mo.dp4 = d_dp4; mo.adf = d_adf; mo.adr = d_adr; mo.sp = d_sp;
     CHECK(bcfgpu_mpileup(ctx, &tile, &mo));
     CHECK(bcfgpu_sync(ctx));
     bcfgpu_site *site = malloc(nb_site);
-    uint8_t *pl = malloc(nb_pl), *dp4 = malloc(nb_dp4);
+    uint8_t *pl = malloc(nb_pl), *dp4 = malloc(nb_dp4), *adf = malloc(nb_ad), *adr = malloc(nb_ad), *sp = malloc(nb_sp);
     CHECK(bcfgpu_memcpy_d2h(ctx, site, d_site, nb_site)); CHECK(bcfgpu_memcpy_d2h(ctx, pl, d_pl, nb_pl));
-    CHECK(bcfgpu_memcpy_d2h(ctx, dp4, d_dp4, nb_dp4));
+    CHECK(bcfgpu_memcpy_d2h(ctx, dp4, d_dp4, nb_dp4)); CHECK(bcfgpu_memcpy_d2h(ctx, adf, d_adf, nb_ad));
+    CHECK(bcfgpu_memcpy_d2h(ctx, adr, d_adr, nb_ad)); CHECK(bcfgpu_memcpy_d2h(ctx, sp, d_sp, nb_sp));
+    const planes_t snp_planes = { pl, dp4, adf, adr, sp };
     CHECK(bcfgpu_sync(ctx));
 
     /* ---- indel records (mpileup.c:354-365): candidate columns -> bcf_call_gap_prep -> second pass with p->aux ---- */
@@ -258,7 +308,8 @@ int main(int argc, char **argv)
     int64_t cap = 0;
     for (int k = 0; k < n_sites; ++k)
         if (col_indel[k] && col_n[k] < 250 * S) { cand[nc++] = k; cap += col_n[k]; }      /* max_indel_depth */
-    bcfgpu_site *isite = NULL; uint8_t *ipl = NULL, *idp4 = NULL; int32_t *live = NULL; int nlive = 0;
+    bcfgpu_site *isite = NULL;
+    planes_t ind_planes = { NULL, NULL, NULL, NULL, NULL }; int32_t *live = NULL; int nlive = 0;
     int32_t *g_types = NULL, *g_maxins = NULL, *g_indelreg = NULL, *g_support = NULL; float *g_frac = NULL; int8_t *g_inscns = NULL;
     if (nc) {
         int32_t *so = malloc(((size_t)nc * S + 1) * sizeof *so), *pr = malloc((size_t)(cap + 1) * 4), *pq = malloc((size_t)(cap + 1) * 4),
@@ -288,21 +339,23 @@ int main(int argc, char **argv)
         if (nlive) {
             bcfgpu_tile ti;
             CHECK(bcfgpu_pileup_indel_tile(ctx, nlive, lcols, laux, nl, &ti));
-            void *d_is, *d_ipl, *d_idp4;
+            const size_t b_pl = (size_t)nlive * BCFGPU_MAX_PL * S, b_dp4 = (size_t)nlive * 4 * S, b_ad = (size_t)nlive * 5 * S, b_sp = (size_t)nlive * S;
+            void *d_is, *d_p[5];
+            const size_t b_p[5] = { b_pl, b_dp4, b_ad, b_ad, b_sp };
             CHECK(bcfgpu_malloc(ctx, (size_t)nlive * sizeof(bcfgpu_site), &d_is));
-            CHECK(bcfgpu_malloc(ctx, (size_t)nlive * BCFGPU_MAX_PL * S, &d_ipl));
-            CHECK(bcfgpu_malloc(ctx, (size_t)nlive * 4 * S, &d_idp4));
-            CHECK(bcfgpu_memset(ctx, d_ipl, 0, (size_t)nlive * BCFGPU_MAX_PL * S));
+            for (int j = 0; j < 5; ++j) { CHECK(bcfgpu_malloc(ctx, b_p[j], &d_p[j])); CHECK(bcfgpu_memset(ctx, d_p[j], 0, b_p[j])); }
             bcfgpu_mplp_out io; memset(&io, 0, sizeof io);
-            io.site = d_is; io.pl = d_ipl; io.dp4 = d_idp4;
+            io.site = d_is; io.pl = d_p[0]; io.dp4 = d_p[1]; io.adf = d_p[2]; io.adr = d_p[3]; io.sp = d_p[4];
             CHECK(bcfgpu_mpileup(ctx, &ti, &io));
             CHECK(bcfgpu_sync(ctx));
-            isite = malloc((size_t)nlive * sizeof *isite); ipl = malloc((size_t)nlive * BCFGPU_MAX_PL * S); idp4 = malloc((size_t)nlive * 4 * S);
+            isite = malloc((size_t)nlive * sizeof *isite);
+            uint8_t *h_p[5];
             CHECK(bcfgpu_memcpy_d2h(ctx, isite, d_is, (size_t)nlive * sizeof *isite));
-            CHECK(bcfgpu_memcpy_d2h(ctx, ipl, d_ipl, (size_t)nlive * BCFGPU_MAX_PL * S));
-            CHECK(bcfgpu_memcpy_d2h(ctx, idp4, d_idp4, (size_t)nlive * 4 * S));
+            for (int j = 0; j < 5; ++j) { h_p[j] = malloc(b_p[j]); CHECK(bcfgpu_memcpy_d2h(ctx, h_p[j], d_p[j], b_p[j])); }
             CHECK(bcfgpu_sync(ctx));
-            bcfgpu_free(ctx, d_is); bcfgpu_free(ctx, d_ipl); bcfgpu_free(ctx, d_idp4);
+            ind_planes.pl = h_p[0]; ind_planes.dp4 = h_p[1]; ind_planes.adf = h_p[2]; ind_planes.adr = h_p[3]; ind_planes.sp = h_p[4];
+            bcfgpu_free(ctx, d_is);
+            for (int j = 0; j < 5; ++j) bcfgpu_free(ctx, d_p[j]);
         }
     }
 
@@ -320,7 +373,7 @@ int main(int argc, char **argv)
         }
         if (c->n_alleles < 2) als[o++] = '.';
         als[o] = 0;
-        print_record(contig, beg + k + 1, als, "", c, pl, dp4, (size_t)k, S);
+        print_record(contig, beg + k + 1, als, "", c, &snp_planes, (size_t)k, S);
         while (jl < nlive && cand[live[jl]] < k) ++jl;
         if (jl < nlive && cand[live[jl]] == k && isite[jl].ret == 0) {
             /* REF / ALT of an indel record (bam2bcf.c:767-790) */
@@ -341,13 +394,13 @@ int main(int argc, char **argv)
             }
             txt[t] = 0;
             snprintf(prefix, sizeof prefix, "INDEL;IDV=%d;IMF=%g;", g_support[i], (double)g_frac[i]);
-            print_record(contig, p + 1, txt, prefix, &isite[jl], ipl, idp4, (size_t)jl, S);
+            print_record(contig, p + 1, txt, prefix, &isite[jl], &ind_planes, (size_t)jl, S);
             free(txt);
         }
     }
     fprintf(stderr, "%d reads of %d samples, %d overlapping pairs, %llu pileup entries in %d columns\n",
             P.n, S, np, (unsigned long long)tile.n_reads, n_sites);
-    bcfgpu_free(ctx, d_site); bcfgpu_free(ctx, d_pl); bcfgpu_free(ctx, d_dp4);
+    bcfgpu_free(ctx, d_site); bcfgpu_free(ctx, d_pl); bcfgpu_free(ctx, d_dp4); bcfgpu_free(ctx, d_adf); bcfgpu_free(ctx, d_adr); bcfgpu_free(ctx, d_sp);
     bcfgpu_destroy(ctx);
     return 0;
 }

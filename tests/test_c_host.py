@@ -139,16 +139,19 @@ SAM_EXE = os.path.join(ROOT, "host", "bcfgpu_sam")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("region,goldf,n_snp,n_indel", [("100-150", "mpileup.1.out", 51, 0), ("100-600", "mpileup.2.out", 501, 1)])
-def test_c_sam_driver_reproduces_reference_goldens(golden_dir, region, goldf, n_snp, n_indel):
+@pytest.mark.parametrize("region,goldf,tags,n_snp,n_indel", [
+    ("100-150", "mpileup.1.out", None, 51, 0), ("100-600", "mpileup.2.out", "DP,DV", 501, 1),
+    ("100-600", "mpileup.4.out", "DP,DPR,DV,DP4,INFO/DPR,SP", 501, 1),
+    ("100-600", "mpileup.5.out", "DP,AD,ADF,ADR,SP,INFO/AD,INFO/ADF,INFO/ADR", 501, 1)])
+def test_c_sam_driver_reproduces_reference_goldens(golden_dir, region, goldf, tags, n_snp, n_indel):
     """host/bcfgpu_sam.c: SAM files in, every stage on the device (BAQ, mate overlaps, pileup, glfgen + combine), VCF-like
-    records out -- byte-identical to the data lines (SNP and indel records) of the reference's test/mpileup/mpileup.{1,2}.out
-    (test.pl:640-641)."""
+    records out -- byte-identical to the data lines (SNP and indel records) of the reference's test/mpileup/mpileup.{1,2,4,5}.out
+    (test.pl:640-644)."""
     from tests.helpers import vcf
     build_host()
     G = os.path.join(golden_dir, "mpileup")
     beg, end = region.split("-")
-    out = subprocess.run([SAM_EXE] + (["-a", "DP,DV"] if goldf == "mpileup.2.out" else []) + [os.path.join(G, "mpileup.ref.fa"), "17", beg, end] +
+    out = subprocess.run([SAM_EXE] + (["-a", tags] if tags else []) + [os.path.join(G, "mpileup.ref.fa"), "17", beg, end] +
                          [os.path.join(G, "mpileup.%d.sam" % i) for i in (1, 2, 3)], check=True, stdout=subprocess.PIPE, text=True).stdout
     # the data lines of the VCF, byte for byte
     want_lines = [ln.rstrip("\n") for ln in open(os.path.join(G, goldf)) if not ln.startswith("#")]
