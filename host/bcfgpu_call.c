@@ -1,0 +1,205 @@
+/*  bcfgpu_call.c -- `bcftools call -m [-v]` over a VCF from `bcftools mpileup`, in plain C over the C-ABI of
+ *  include/bcfgpu.h: the record loop of main_vcfcall (vcfcall.c:1089-1148) with mcall() on the device.
+ *
+ *      bcfgpu_call [-v] <in.vcf>          (all samples, diploid, one pooled group: the defaults of `call -m`)
+ *
+ *  Host: VCF text in, what mcall() reads from a record (alleles, FORMAT/PL, INFO/QS, INFO/I16) packed into the planes of
+ *  bcfgpu_call_in, one bcfgpu_mcall over all records, then what mcall.c:1627-1681 does to the record: alleles trimmed with
+ *  als_map, GT in front of the FORMAT fields, PL trimmed (or dropped), QUAL, INFO/AC, AN, DP4, MQ appended, I16 and QS
+ *  removed.  Prints the data lines of the output VCF; tests/test_c_host.py compares them, byte for byte, with the
+ *  reference's golden test/mpileup.1.out (`call -mv` on test/mpileup.vcf, test.pl:276).
+ *  Not handled (the reference's other modes): ploidy files / sample lists, -G groups, -F priors, Number=R tags other than PL.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include "bcfgpu.h"
+
+#define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s: %s (%d)\n", #call, bcfgpu_last_error(), rc_); exit(1); } } while (0)
+#define DIE(...) do { fprintf(stderr, __VA_ARGS__); exit(1); } while (0)
+
+typedef struct { char *line; char **fld; int nfld; char **als; int nals, unseen, pl_idx; } rec_t;
+
+static char **split(char *s, char sep, int *n)
+{
+    int cap = 8; char **v = malloc((size_t)cap * sizeof *v); *n = 0;
+    for (;;) {
+        if (*n == cap) { cap *= 2; v = realloc(v, (size_t)cap * sizeof *v); }
+        v[(*n)++] = s;
+        s = strchr(s, sep);
+        if (!s) break;
+        *s++ = 0;
+    }
+    return v;
+}
+
+static void *dev_upload(bcfgpu_ctx *ctx, const void *src, size_t bytes)
+{
+    void *d = NULL;
+    CHECK(bcfgpu_malloc(ctx, bytes ? bytes : 16, &d));
+    if (bytes) CHECK(bcfgpu_memcpy_h2d(ctx, d, src, bytes));
+    return d;
+}
+
+int main(int argc, char **argv)
+{
+    int varonly = 0;
+    if (argc > 1 && !strcmp(argv[1], "-v")) { varonly = 1; ++argv; --argc; }
+    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] in.vcf\n"); return 2; }
+    FILE *f = fopen(argv[1], "r");
+    if (!f) DIE("cannot open %s\n", argv[1]);
+    static char buf[1 << 20];
+    rec_t *recs = NULL; int n = 0, cap = 0, S = -1, ngmax = 1;
+    while (fgets(buf, sizeof buf, f)) {
+        size_t l = strlen(buf);
+        while (l && (buf[l - 1] == '\n' || buf[l - 1] == '\r')) buf[--l] = 0;
+        if (buf[0] == '#') {
+            if (!strncmp(buf, "#CHROM", 6)) { int nf; char *c = strdup(buf); free(split(c, '\t', &nf)); S = nf - 9; free(c); }
+            continue;
+        }
+        if (!l) continue;
+        if (n == cap) { cap = cap ? 2 * cap : 1024; recs = realloc(recs, (size_t)cap * sizeof *recs); }
+        rec_t *r = &recs[n++];
+        r->line = strdup(buf);
+        r->fld = split(r->line, '\t', &r->nfld);
+        if (S < 0 || r->nfld != 9 + S) DIE("malformed VCF\n");
+        /* alleles; the unseen allele as vcfcall.c:1102-1111 finds it */
+        int nalt = 0; char *alt = strdup(r->fld[4]), **alts = split(alt, ',', &nalt);
+        if (!strcmp(r->fld[4], ".")) nalt = 0;
+        r->nals = 1 + nalt; r->als = malloc((size_t)r->nals * sizeof *r->als); r->als[0] = r->fld[3]; r->unseen = 0;
+        for (int i = 0; i < nalt; ++i) {
+            r->als[1 + i] = alts[i];
+            const char *a = alts[i];
+            if (!r->unseen && (a[0] == 'X' || (a[0] == '<' && (a[1] == 'X' || a[1] == '*') && a[2] == '>'))) r->unseen = 1 + i;
+        }
+        free(alts);
+        if (r->nals > 5) DIE("more than 5 alleles at %s:%s\n", r->fld[0], r->fld[1]);
+        const int ng = r->nals * (r->nals + 1) / 2;
+        if (ng > ngmax) ngmax = ng;
+    }
+    fclose(f);
+    if (S <= 0) DIE("no samples\n");
+
+    /* ---- what mcall() reads from the records: PL planes (missing / vector_end kept), QS, I16 ---- */
+    int32_t *nals = malloc((size_t)n * 4), *unseen = malloc((size_t)n * 4);
+    int32_t *pl = malloc((size_t)n * ngmax * S * 4);
+    float *qs = calloc((size_t)n * 5, 4), *i16 = calloc((size_t)n * 16, 4);
+    for (int k = 0; k < n; ++k) {
+        rec_t *r = &recs[k];
+        nals[k] = r->nals; unseen[k] = r->unseen;
+        for (size_t i = 0; i < (size_t)ngmax * S; ++i) pl[(size_t)k * ngmax * S + i] = BCFGPU_INT32_VECTOR_END;
+        /* FORMAT/PL */
+        int nk; char *fmt = strdup(r->fld[8]), **keys = split(fmt, ':', &nk);
+        r->pl_idx = -1;
+        for (int i = 0; i < nk; ++i) if (!strcmp(keys[i], "PL")) r->pl_idx = i;
+        free(keys); free(fmt);
+        if (r->pl_idx < 0) DIE("no FORMAT/PL at %s:%s\n", r->fld[0], r->fld[1]);
+        for (int s = 0; s < S; ++s) {
+            char *smp = strdup(r->fld[9 + s]); int nv; char **vals = split(smp, ':', &nv);
+            if (r->pl_idx < nv) {
+                int np; char **pv = split(vals[r->pl_idx], ',', &np);
+                for (int j = 0; j < np && j < ngmax; ++j)
+                    pl[((size_t)k * ngmax + j) * S + s] = !strcmp(pv[j], ".") ? BCFGPU_INT32_MISSING : atoi(pv[j]);
+                free(pv);
+            } else pl[((size_t)k * ngmax) * S + s] = BCFGPU_INT32_MISSING;
+            free(vals); free(smp);
+        }
+        /* INFO/QS, INFO/I16 */
+        char *info = strdup(r->fld[7]); int ni; char **iv = split(info, ';', &ni);
+        for (int i = 0; i < ni; ++i) {
+            float *dst = !strncmp(iv[i], "QS=", 3) ? qs + (size_t)k * 5 : !strncmp(iv[i], "I16=", 4) ? i16 + (size_t)k * 16 : NULL;
+            if (!dst) continue;
+            const int lim = dst == qs + (size_t)k * 5 ? 5 : 16;
+            int nv; char **v = split(strchr(iv[i], '=') + 1, ',', &nv);
+            for (int j = 0; j < nv && j < lim; ++j) dst[j] = (float)atof(v[j]);
+            free(v);
+        }
+        free(iv); free(info);
+    }
+
+    /* ---- the device ---- */
+    bcfgpu_cfg cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.device = 0; cfg.n_smpl = S; cfg.max_sites = n; cfg.max_reads = 64;
+    cfg.min_baseQ = 13; cfg.capQ = 60; cfg.call_theta = 1.1e-3; cfg.call_flag = varonly ? BCFGPU_CALL_VARONLY : 0; cfg.n_grp = 1; cfg.ploidy_max = 2;
+    bcfgpu_ctx *ctx = NULL;
+    CHECK(bcfgpu_create(&cfg, &ctx));
+    bcfgpu_call_in in; memset(&in, 0, sizeof in);
+    in.n_sites = n; in.n_gt_max = ngmax; in.n_al_max = 0;
+    in.nals = dev_upload(ctx, nals, (size_t)n * 4); in.unseen = dev_upload(ctx, unseen, (size_t)n * 4);
+    in.pl = dev_upload(ctx, pl, (size_t)n * ngmax * S * 4); in.qs = dev_upload(ctx, qs, (size_t)n * 5 * 4);
+    in.i16 = dev_upload(ctx, i16, (size_t)n * 16 * 4);
+    bcfgpu_call_out out; memset(&out, 0, sizeof out);
+    void *d_site, *d_gt, *d_pl;
+    CHECK(bcfgpu_malloc(ctx, (size_t)n * sizeof(bcfgpu_call_site), &d_site)); CHECK(bcfgpu_malloc(ctx, (size_t)n * 2 * S, &d_gt));
+    CHECK(bcfgpu_malloc(ctx, (size_t)n * ngmax * S * 4, &d_pl));
+    out.site = d_site; out.gt = d_gt; out.pl = d_pl;
+    CHECK(bcfgpu_mcall(ctx, &in, &out));
+    CHECK(bcfgpu_sync(ctx));
+    bcfgpu_call_site *cs = malloc((size_t)n * sizeof *cs);
+    int8_t *gt = malloc((size_t)n * 2 * S); int32_t *opl = malloc((size_t)n * ngmax * S * 4);
+    CHECK(bcfgpu_memcpy_d2h(ctx, cs, d_site, (size_t)n * sizeof *cs)); CHECK(bcfgpu_memcpy_d2h(ctx, gt, d_gt, (size_t)n * 2 * S));
+    CHECK(bcfgpu_memcpy_d2h(ctx, opl, d_pl, (size_t)n * ngmax * S * 4));
+    CHECK(bcfgpu_sync(ctx));
+
+    /* ---- the record loop (vcfcall.c:1137-1147, mcall.c:1627-1681) ---- */
+    for (int k = 0; k < n; ++k) {
+        const rec_t *r = &recs[k];
+        const bcfgpu_call_site *c = &cs[k];
+        if (c->ret == -2 || (varonly && c->ret == 0) || c->ret < 0) continue;
+        const int nn = c->nals_new, ngn = nn * (nn + 1) / 2;
+        printf("%s\t%s\t%s\t%s\t", r->fld[0], r->fld[1], r->fld[2], r->fld[3]);
+        {   /* ALT: the kept alleles in their new order */
+            const char *al[5] = { 0, 0, 0, 0, 0 };
+            for (int i = 0; i < r->nals; ++i) if (c->als_map[i] >= 0) al[c->als_map[i]] = r->als[i];
+            if (nn < 2) putchar('.');
+            for (int i = 1; i < nn; ++i) printf("%s%s", i > 1 ? "," : "", al[i]);
+        }
+        if (c->qual_missing) fputs("\t.", stdout); else printf("\t%g", (double)c->qual);
+        printf("\t%s\t", r->fld[6]);
+        {   /* INFO: I16 and QS go, AC / AN / DP4 / MQ come */
+            char *info = strdup(r->fld[7]); int ni, first = 1; char **iv = split(info, ';', &ni);
+            for (int i = 0; i < ni; ++i) {
+                if (!strncmp(iv[i], "I16=", 4) || !strncmp(iv[i], "QS=", 3) || !strcmp(iv[i], ".")) continue;
+                printf("%s%s", first ? "" : ";", iv[i]); first = 0;
+            }
+            free(iv); free(info);
+            if (nn > 1) { printf("%sAC=", first ? "" : ";"); first = 0; for (int i = 1; i < nn; ++i) printf("%s%d", i > 1 ? "," : "", c->ac[i]); }
+            printf("%sAN=%d", first ? "" : ";", c->an);
+            if (c->has_i16) {
+                printf(";DP4=%d,%d,%d,%d", c->dp4[0], c->dp4[1], c->dp4[2], c->dp4[3]);
+                if (c->mq == BCFGPU_INT32_MISSING) fputs(";MQ=.", stdout); else printf(";MQ=%d", c->mq);
+            }
+        }
+        /* FORMAT: GT first, PL trimmed or dropped, the rest as it came */
+        int nk; char *fmt = strdup(r->fld[8]), **keys = split(fmt, ':', &nk);
+        fputs("\tGT", stdout);
+        for (int i = 0; i < nk; ++i) if (i != r->pl_idx || !c->pl_dropped) printf(":%s", keys[i]);
+        for (int s = 0; s < S; ++s) {
+            const int g0 = gt[((size_t)k * 2 + 0) * S + s], g1 = gt[((size_t)k * 2 + 1) * S + s];
+            putchar('\t');
+            if (g0 == BCFGPU_GT_MISSING) putchar('.'); else printf("%d", g0);
+            if (g1 != BCFGPU_GT_VECTOR_END) { putchar('/'); if (g1 == BCFGPU_GT_MISSING) putchar('.'); else printf("%d", g1); }
+            char *smp = strdup(r->fld[9 + s]); int nv; char **vals = split(smp, ':', &nv);
+            for (int i = 0; i < nk; ++i) {
+                if (i == r->pl_idx) {
+                    if (c->pl_dropped) continue;
+                    putchar(':');
+                    int printed = 0;
+                    for (int j = 0; j < ngn; ++j) {
+                        const int32_t v = opl[((size_t)k * ngmax + j) * S + s];
+                        if (v == BCFGPU_INT32_VECTOR_END) break;
+                        if (printed++) putchar(',');
+                        if (v == BCFGPU_INT32_MISSING) putchar('.'); else printf("%d", v);
+                    }
+                    if (!printed) putchar('.');
+                } else printf(":%s", i < nv ? vals[i] : ".");
+            }
+            free(vals); free(smp);
+        }
+        free(keys); free(fmt);
+        putchar('\n');
+    }
+    bcfgpu_destroy(ctx);
+    return 0;
+}

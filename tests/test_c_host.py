@@ -176,3 +176,17 @@ def test_c_sam_driver_reproduces_reference_goldens(golden_dir, region, goldf, ta
                 assert abs(a - b) <= 2e-5 * max(abs(a), abs(b)) + 1e-9, (p, tag, a, b)
         for s in range(3):
             assert c.fmt("PL", s) == g.fmt("PL", s), (p, s, c.fmt("PL", s), g.fmt("PL", s))
+
+
+CALL_EXE = os.path.join(ROOT, "host", "bcfgpu_call")
+
+
+@pytest.mark.gpu
+def test_c_call_driver_reproduces_reference_golden(golden_dir):
+    """host/bcfgpu_call.c: `call -mv` on the reference's test/mpileup.vcf with mcall() on the device -- its output is
+    byte-identical to the data lines of the golden test/mpileup.1.out (test.pl:276)."""
+    build_host()
+    G = os.path.join(golden_dir, "call")
+    out = subprocess.run([CALL_EXE, "-v", os.path.join(G, "mpileup.vcf")], check=True, stdout=subprocess.PIPE, text=True).stdout
+    want = [ln.rstrip("\n") for ln in open(os.path.join(G, "mpileup.1.out")) if not ln.startswith("#")]
+    assert out.splitlines() == want and len(want) == 11
