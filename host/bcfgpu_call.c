@@ -1,14 +1,15 @@
 /*  bcfgpu_call.c -- `bcftools call -m [-v]` over a VCF from `bcftools mpileup`, in plain C over the C-ABI of
  *  include/bcfgpu.h: the record loop of main_vcfcall (vcfcall.c:1089-1148) with mcall() on the device.
  *
- *      bcfgpu_call [-v] <in.vcf>          (all samples, diploid, one pooled group: the defaults of `call -m`)
+ *      bcfgpu_call [-v] [-S samples.txt] <in.vcf>      (diploid, one pooled group: the defaults of `call -m`;
+ *                                                        -S: the samples to keep, one name per line, in that order)
  *
  *  Host: VCF text in, what mcall() reads from a record (alleles, FORMAT/PL, INFO/QS, INFO/I16) packed into the planes of
  *  bcfgpu_call_in, one bcfgpu_mcall over all records, then what mcall.c:1627-1681 does to the record: alleles trimmed with
  *  als_map, GT in front of the FORMAT fields, PL trimmed (or dropped), QUAL, INFO/AC, AN, DP4, MQ appended, I16 and QS
  *  removed.  Prints the data lines of the output VCF; tests/test_c_host.py compares them, byte for byte, with the
- *  reference's golden test/mpileup.1.out (`call -mv` on test/mpileup.vcf, test.pl:276).
- *  Not handled (the reference's other modes): ploidy files / sample lists, -G groups, -F priors, Number=R tags other than PL.
+ *  reference's goldens test/mpileup.{1,3,4,5}.out (`call -mv [-S ..]` on test/mpileup.vcf, test.pl:276-280).
+ *  Not handled (the reference's other modes): ploidy files and ploidy columns in the sample list, -G groups, -F priors, Number=R tags other than PL.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -45,17 +46,44 @@ static void *dev_upload(bcfgpu_ctx *ctx, const void *src, size_t bytes)
 int main(int argc, char **argv)
 {
     int varonly = 0;
-    if (argc > 1 && !strcmp(argv[1], "-v")) { varonly = 1; ++argv; --argc; }
-    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] in.vcf\n"); return 2; }
+    const char *smpl_file = NULL;
+    while (argc > 2 && argv[1][0] == '-') {
+        if (!strcmp(argv[1], "-v")) { varonly = 1; ++argv; --argc; }
+        else if (!strcmp(argv[1], "-S") && argc > 3) { smpl_file = argv[2]; argv += 2; argc -= 2; }
+        else break;
+    }
+    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-S samples.txt] in.vcf\n"); return 2; }
     FILE *f = fopen(argv[1], "r");
     if (!f) DIE("cannot open %s\n", argv[1]);
     static char buf[1 << 20];
-    rec_t *recs = NULL; int n = 0, cap = 0, S = -1, ngmax = 1;
+    rec_t *recs = NULL; int n = 0, cap = 0, S = -1, ngmax = 1, S_in = -1;
+    int *col = NULL;                              /* output sample s = input column col[s] (bcf_subset with -S) */
     while (fgets(buf, sizeof buf, f)) {
         size_t l = strlen(buf);
         while (l && (buf[l - 1] == '\n' || buf[l - 1] == '\r')) buf[--l] = 0;
         if (buf[0] == '#') {
-            if (!strncmp(buf, "#CHROM", 6)) { int nf; char *c = strdup(buf); free(split(c, '\t', &nf)); S = nf - 9; free(c); }
+            if (!strncmp(buf, "#CHROM", 6)) {
+                int nf; char *c = strdup(buf), **h = split(c, '\t', &nf);
+                S_in = S = nf - 9;
+                col = malloc((size_t)(S > 0 ? S : 1) * sizeof *col);
+                for (int s = 0; s < S; ++s) col[s] = s;
+                if (smpl_file) {
+                    FILE *sf = fopen(smpl_file, "r");
+                    if (!sf) DIE("cannot open %s\n", smpl_file);
+                    char name[1024]; int m = 0;
+                    while (fgets(name, sizeof name, sf)) {
+                        name[strcspn(name, " \t\r\n")] = 0;
+                        if (!name[0]) continue;
+                        int i;
+                        for (i = 0; i < S_in; ++i) if (!strcmp(h[9 + i], name)) break;
+                        if (i == S_in || m == S_in) DIE("sample %s is not in the VCF\n", name);
+                        col[m++] = i;
+                    }
+                    fclose(sf);
+                    S = m;
+                }
+                free(h); free(c);
+            }
             continue;
         }
         if (!l) continue;
@@ -63,7 +91,7 @@ int main(int argc, char **argv)
         rec_t *r = &recs[n++];
         r->line = strdup(buf);
         r->fld = split(r->line, '\t', &r->nfld);
-        if (S < 0 || r->nfld != 9 + S) DIE("malformed VCF\n");
+        if (S_in < 0 || r->nfld != 9 + S_in) DIE("malformed VCF\n");
         /* alleles; the unseen allele as vcfcall.c:1102-1111 finds it */
         int nalt = 0; char *alt = strdup(r->fld[4]), **alts = split(alt, ',', &nalt);
         if (!strcmp(r->fld[4], ".")) nalt = 0;
@@ -96,7 +124,7 @@ int main(int argc, char **argv)
         free(keys); free(fmt);
         if (r->pl_idx < 0) DIE("no FORMAT/PL at %s:%s\n", r->fld[0], r->fld[1]);
         for (int s = 0; s < S; ++s) {
-            char *smp = strdup(r->fld[9 + s]); int nv; char **vals = split(smp, ':', &nv);
+            char *smp = strdup(r->fld[9 + col[s]]); int nv; char **vals = split(smp, ':', &nv);
             if (r->pl_idx < nv) {
                 int np; char **pv = split(vals[r->pl_idx], ',', &np);
                 for (int j = 0; j < np && j < ngmax; ++j)
@@ -180,7 +208,7 @@ int main(int argc, char **argv)
             putchar('\t');
             if (g0 == BCFGPU_GT_MISSING) putchar('.'); else printf("%d", g0);
             if (g1 != BCFGPU_GT_VECTOR_END) { putchar('/'); if (g1 == BCFGPU_GT_MISSING) putchar('.'); else printf("%d", g1); }
-            char *smp = strdup(r->fld[9 + s]); int nv; char **vals = split(smp, ':', &nv);
+            char *smp = strdup(r->fld[9 + col[s]]); int nv; char **vals = split(smp, ':', &nv);
             for (int i = 0; i < nk; ++i) {
                 if (i == r->pl_idx) {
                     if (c->pl_dropped) continue;

@@ -182,11 +182,14 @@ CALL_EXE = os.path.join(ROOT, "host", "bcfgpu_call")
 
 
 @pytest.mark.gpu
-def test_c_call_driver_reproduces_reference_golden(golden_dir):
-    """host/bcfgpu_call.c: `call -mv` on the reference's test/mpileup.vcf with mcall() on the device -- its output is
-    byte-identical to the data lines of the golden test/mpileup.1.out (test.pl:276)."""
+@pytest.mark.parametrize("goldf,smpl,n", [("mpileup.1.out", None, 11), ("mpileup.3.out", "mpileup.3.samples", None),
+                                          ("mpileup.4.out", "mpileup.4.samples", None), ("mpileup.5.out", "mpileup.5.samples", None)])
+def test_c_call_driver_reproduces_reference_golden(golden_dir, goldf, smpl, n):
+    """host/bcfgpu_call.c: `call -mv [-S samples]` on the reference's test/mpileup.vcf with mcall() on the device -- its
+    output is byte-identical to the data lines of the goldens test/mpileup.{1,3,4,5}.out (test.pl:276-280)."""
     build_host()
     G = os.path.join(golden_dir, "call")
-    out = subprocess.run([CALL_EXE, "-v", os.path.join(G, "mpileup.vcf")], check=True, stdout=subprocess.PIPE, text=True).stdout
-    want = [ln.rstrip("\n") for ln in open(os.path.join(G, "mpileup.1.out")) if not ln.startswith("#")]
-    assert out.splitlines() == want and len(want) == 11
+    cmd = [CALL_EXE, "-v"] + (["-S", os.path.join(G, smpl)] if smpl else []) + [os.path.join(G, "mpileup.vcf")]
+    out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, text=True).stdout
+    want = [ln.rstrip("\n") for ln in open(os.path.join(G, goldf)) if not ln.startswith("#")]
+    assert out.splitlines() == want and len(want) > 0 and (n is None or len(want) == n)
