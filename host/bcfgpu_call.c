@@ -1,15 +1,16 @@
 /*  bcfgpu_call.c -- `bcftools call -m [-v]` over a VCF from `bcftools mpileup`, in plain C over the C-ABI of
  *  include/bcfgpu.h: the record loop of main_vcfcall (vcfcall.c:1089-1148) with mcall() on the device.
  *
- *      bcfgpu_call [-v] [-S samples.txt] <in.vcf>      (diploid, one pooled group: the defaults of `call -m`;
- *                                                        -S: the samples to keep, one name per line, in that order)
+ *      bcfgpu_call [-v] [-S samples.txt] [--ploidy-file file] <in.vcf>      (one pooled group)
+ *          -S: the samples to keep, in that order: NAME [PLOIDY|SEX] per line, or a PED file (vcfcall.c:202-344)
+ *          --ploidy-file: CHROM FROM TO SEX PLOIDY lines, '*' = default for the sex (ploidy.c)
  *
  *  Host: VCF text in, what mcall() reads from a record (alleles, FORMAT/PL, INFO/QS, INFO/I16) packed into the planes of
  *  bcfgpu_call_in, one bcfgpu_mcall over all records, then what mcall.c:1627-1681 does to the record: alleles trimmed with
  *  als_map, GT in front of the FORMAT fields, PL trimmed (or dropped), QUAL, INFO/AC, AN, DP4, MQ appended, I16 and QS
  *  removed.  Prints the data lines of the output VCF; tests/test_c_host.py compares them, byte for byte, with the
- *  reference's goldens test/mpileup.{1,3,4,5}.out (`call -mv [-S ..]` on test/mpileup.vcf, test.pl:276-280).
- *  Not handled (the reference's other modes): ploidy files and ploidy columns in the sample list, -G groups, -F priors, Number=R tags other than PL.
+ *  reference's goldens test/mpileup.{1,3,4,5}.out and test/mpileup.X{,.2}.out (test.pl:276-283).
+ *  Not handled (the reference's other modes): -G groups, -F priors, Number=R tags other than PL.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,7 +21,9 @@
 #define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s: %s (%d)\n", #call, bcfgpu_last_error(), rc_); exit(1); } } while (0)
 #define DIE(...) do { fprintf(stderr, __VA_ARGS__); exit(1); } while (0)
 
-typedef struct { char *line; char **fld; int nfld; char **als; int nals, unseen, pl_idx; } rec_t;
+typedef struct { char *line; char **fld; int nfld; char **als; int nals, unseen, pl_idx; uint8_t *ploidy; } rec_t;
+
+typedef struct { char chrom[256]; int from, to, ploidy; char sex[64]; } preg_t;
 
 static char **split(char *s, char sep, int *n)
 {
@@ -46,18 +49,36 @@ static void *dev_upload(bcfgpu_ctx *ctx, const void *src, size_t bytes)
 int main(int argc, char **argv)
 {
     int varonly = 0;
-    const char *smpl_file = NULL;
+    const char *smpl_file = NULL, *ploidy_file = NULL;
     while (argc > 2 && argv[1][0] == '-') {
         if (!strcmp(argv[1], "-v")) { varonly = 1; ++argv; --argc; }
         else if (!strcmp(argv[1], "-S") && argc > 3) { smpl_file = argv[2]; argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "--ploidy-file") && argc > 3) { ploidy_file = argv[2]; argv += 2; argc -= 2; }
         else break;
     }
-    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-S samples.txt] in.vcf\n"); return 2; }
+    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-S samples.txt] [--ploidy-file file] in.vcf\n"); return 2; }
+    /* ploidy definition (ploidy.c): regions per sex, '*' lines = the sex's default; the last sex named is the default sex */
+    preg_t *preg = NULL; int npreg = 0; char last_sex[64] = "";
+    if (ploidy_file) {
+        FILE *pf = fopen(ploidy_file, "r");
+        if (!pf) DIE("cannot open %s\n", ploidy_file);
+        char ln[1024], c[256], a[64], b[64], sx[64]; int pl;
+        while (fgets(ln, sizeof ln, pf))
+            if (sscanf(ln, "%255s %63s %63s %63s %d", c, a, b, sx, &pl) == 5) {
+                preg = realloc(preg, (size_t)(npreg + 1) * sizeof *preg);
+                preg_t *q = &preg[npreg++];
+                strcpy(q->chrom, c); strcpy(q->sex, sx); q->ploidy = pl;
+                q->from = !strcmp(a, "*") ? -1 : atoi(a); q->to = !strcmp(b, "*") ? -1 : atoi(b);
+                strcpy(last_sex, sx);
+            }
+        fclose(pf);
+    }
     FILE *f = fopen(argv[1], "r");
     if (!f) DIE("cannot open %s\n", argv[1]);
     static char buf[1 << 20];
     rec_t *recs = NULL; int n = 0, cap = 0, S = -1, ngmax = 1, S_in = -1;
     int *col = NULL;                              /* output sample s = input column col[s] (bcf_subset with -S) */
+    char (*spec)[64] = NULL;                      /* its ploidy ("0", "1", "2") or sex name */
     while (fgets(buf, sizeof buf, f)) {
         size_t l = strlen(buf);
         while (l && (buf[l - 1] == '\n' || buf[l - 1] == '\r')) buf[--l] = 0;
@@ -66,18 +87,22 @@ int main(int argc, char **argv)
                 int nf; char *c = strdup(buf), **h = split(c, '\t', &nf);
                 S_in = S = nf - 9;
                 col = malloc((size_t)(S > 0 ? S : 1) * sizeof *col);
-                for (int s = 0; s < S; ++s) col[s] = s;
+                spec = malloc((size_t)(S > 0 ? S : 1) * sizeof *spec);
+                for (int s = 0; s < S; ++s) { col[s] = s; strcpy(spec[s], ploidy_file ? last_sex : "2"); }   /* vcfcall.c:645-650 */
                 if (smpl_file) {
                     FILE *sf = fopen(smpl_file, "r");
                     if (!sf) DIE("cannot open %s\n", smpl_file);
-                    char name[1024]; int m = 0;
-                    while (fgets(name, sizeof name, sf)) {
-                        name[strcspn(name, " \t\r\n")] = 0;
-                        if (!name[0]) continue;
+                    char ln[1024]; int m = 0;
+                    while (fgets(ln, sizeof ln, sf)) {
+                        char w[6][256]; const int nw = sscanf(ln, "%255s %255s %255s %255s %255s %255s", w[0], w[1], w[2], w[3], w[4], w[5]);
+                        if (nw < 1 || w[0][0] == '#') continue;
+                        const char *name = nw >= 5 ? w[1] : w[0];                   /* PED: family, sample, father, mother, sex */
+                        const char *sp = nw >= 5 ? (!strcmp(w[4], "1") ? "M" : "F") : nw >= 2 ? w[1] : "2";
                         int i;
                         for (i = 0; i < S_in; ++i) if (!strcmp(h[9 + i], name)) break;
-                        if (i == S_in || m == S_in) DIE("sample %s is not in the VCF\n", name);
-                        col[m++] = i;
+                        if (i == S_in) continue;                                    /* not in the VCF: ignored */
+                        if (m == S_in) DIE("too many samples in %s\n", smpl_file);
+                        col[m] = i; strcpy(spec[m], sp); ++m;
                     }
                     fclose(sf);
                     S = m;
@@ -105,6 +130,21 @@ int main(int argc, char **argv)
         if (r->nals > 5) DIE("more than 5 alleles at %s:%s\n", r->fld[0], r->fld[1]);
         const int ng = r->nals * (r->nals + 1) / 2;
         if (ng > ngmax) ngmax = ng;
+        /* the ploidy of every sample at this record (set_ploidy, vcfcall.c:807-825) */
+        r->ploidy = malloc((size_t)S);
+        const int pos1 = atoi(r->fld[1]);
+        for (int s = 0; s < S; ++s) {
+            int pl = 2;
+            if (!strcmp(spec[s], "0") || !strcmp(spec[s], "1") || !strcmp(spec[s], "2")) pl = atoi(spec[s]);
+            else {
+                int found = 0;
+                for (int i = 0; i < npreg && !found; ++i)
+                    if (preg[i].from >= 0 && !strcmp(preg[i].chrom, r->fld[0]) && !strcmp(preg[i].sex, spec[s]) && preg[i].from <= pos1 && pos1 <= preg[i].to) { pl = preg[i].ploidy; found = 1; }
+                for (int i = 0; i < npreg && !found; ++i)
+                    if (preg[i].from < 0 && !strcmp(preg[i].sex, spec[s])) { pl = preg[i].ploidy; found = 1; }
+            }
+            r->ploidy[s] = (uint8_t)pl;
+        }
     }
     fclose(f);
     if (S <= 0) DIE("no samples\n");
@@ -152,18 +192,29 @@ int main(int argc, char **argv)
     cfg.min_baseQ = 13; cfg.capQ = 60; cfg.call_theta = 1.1e-3; cfg.call_flag = varonly ? BCFGPU_CALL_VARONLY : 0; cfg.n_grp = 1; cfg.ploidy_max = 2;
     bcfgpu_ctx *ctx = NULL;
     CHECK(bcfgpu_create(&cfg, &ctx));
-    bcfgpu_call_in in; memset(&in, 0, sizeof in);
-    in.n_sites = n; in.n_gt_max = ngmax; in.n_al_max = 0;
-    in.nals = dev_upload(ctx, nals, (size_t)n * 4); in.unseen = dev_upload(ctx, unseen, (size_t)n * 4);
-    in.pl = dev_upload(ctx, pl, (size_t)n * ngmax * S * 4); in.qs = dev_upload(ctx, qs, (size_t)n * 5 * 4);
-    in.i16 = dev_upload(ctx, i16, (size_t)n * 16 * 4);
-    bcfgpu_call_out out; memset(&out, 0, sizeof out);
-    void *d_site, *d_gt, *d_pl;
+    /* everything goes up once; the records are called in runs of equal ploidy vectors (the ploidy is per call:
+     * vcfcall.c:807-825 re-initialises it when it changes) -- the planes are [record][...]: a run is a slice */
+    int32_t *d_nals = dev_upload(ctx, nals, (size_t)n * 4), *d_unseen = dev_upload(ctx, unseen, (size_t)n * 4);
+    int32_t *d_plin = dev_upload(ctx, pl, (size_t)n * ngmax * S * 4);
+    float *d_qs = dev_upload(ctx, qs, (size_t)n * 5 * 4), *d_i16 = dev_upload(ctx, i16, (size_t)n * 16 * 4);
+    void *d_site, *d_gt, *d_pl, *d_ploidy;
     CHECK(bcfgpu_malloc(ctx, (size_t)n * sizeof(bcfgpu_call_site), &d_site)); CHECK(bcfgpu_malloc(ctx, (size_t)n * 2 * S, &d_gt));
-    CHECK(bcfgpu_malloc(ctx, (size_t)n * ngmax * S * 4, &d_pl));
-    out.site = d_site; out.gt = d_gt; out.pl = d_pl;
-    CHECK(bcfgpu_mcall(ctx, &in, &out));
-    CHECK(bcfgpu_sync(ctx));
+    CHECK(bcfgpu_malloc(ctx, (size_t)n * ngmax * S * 4, &d_pl)); CHECK(bcfgpu_malloc(ctx, (size_t)S + 16, &d_ploidy));
+    for (int i = 0; i < n; ) {
+        int j = i + 1, all2 = 1;
+        while (j < n && !memcmp(recs[j].ploidy, recs[i].ploidy, (size_t)S)) ++j;
+        for (int s = 0; s < S; ++s) all2 &= recs[i].ploidy[s] == 2;
+        bcfgpu_call_in in; memset(&in, 0, sizeof in);
+        in.n_sites = j - i; in.n_gt_max = ngmax; in.n_al_max = 0;
+        in.nals = d_nals + i; in.unseen = d_unseen + i; in.pl = d_plin + (size_t)i * ngmax * S; in.qs = d_qs + (size_t)i * 5;
+        in.i16 = d_i16 + (size_t)i * 16;
+        if (!all2) { CHECK(bcfgpu_memcpy_h2d(ctx, d_ploidy, recs[i].ploidy, (size_t)S)); in.ploidy = d_ploidy; }
+        bcfgpu_call_out out; memset(&out, 0, sizeof out);
+        out.site = (bcfgpu_call_site*)d_site + i; out.gt = (int8_t*)d_gt + (size_t)i * 2 * S; out.pl = (int32_t*)d_pl + (size_t)i * ngmax * S;
+        CHECK(bcfgpu_mcall(ctx, &in, &out));
+        CHECK(bcfgpu_sync(ctx));                               /* (d_ploidy is reused by the next run) */
+        i = j;
+    }
     bcfgpu_call_site *cs = malloc((size_t)n * sizeof *cs);
     int8_t *gt = malloc((size_t)n * 2 * S); int32_t *opl = malloc((size_t)n * ngmax * S * 4);
     CHECK(bcfgpu_memcpy_d2h(ctx, cs, d_site, (size_t)n * sizeof *cs)); CHECK(bcfgpu_memcpy_d2h(ctx, gt, d_gt, (size_t)n * 2 * S));

@@ -182,14 +182,21 @@ CALL_EXE = os.path.join(ROOT, "host", "bcfgpu_call")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("goldf,smpl,n", [("mpileup.1.out", None, 11), ("mpileup.3.out", "mpileup.3.samples", None),
-                                          ("mpileup.4.out", "mpileup.4.samples", None), ("mpileup.5.out", "mpileup.5.samples", None)])
-def test_c_call_driver_reproduces_reference_golden(golden_dir, goldf, smpl, n):
-    """host/bcfgpu_call.c: `call -mv [-S samples]` on the reference's test/mpileup.vcf with mcall() on the device -- its
-    output is byte-identical to the data lines of the goldens test/mpileup.{1,3,4,5}.out (test.pl:276-280)."""
+@pytest.mark.parametrize("vcff,goldf,smpl,ploidy,n", [
+    ("mpileup.vcf", "mpileup.1.out", None, None, 11), ("mpileup.vcf", "mpileup.3.out", "mpileup.3.samples", None, None),
+    ("mpileup.vcf", "mpileup.4.out", "mpileup.4.samples", None, None), ("mpileup.vcf", "mpileup.5.out", "mpileup.5.samples", None, None),
+    ("mpileup.X.vcf", "mpileup.X.out", "mpileup.samples", "mpileup.ploidy", None),          # sexes + ploidy file: haploid males on X
+    ("mpileup.X.vcf", "mpileup.X.out", "mpileup.ped", "mpileup.ploidy", None),              # the same from a PED file
+    ("mpileup.X.vcf", "mpileup.X.2.out", "mpileup.2.samples", "mpileup.ploidy", None),      # ploidy numbers in the sample list
+])
+def test_c_call_driver_reproduces_reference_golden(golden_dir, vcff, goldf, smpl, ploidy, n):
+    """host/bcfgpu_call.c: `call -mv [-S samples] [--ploidy-file f]` on the reference's test VCFs with mcall() on the device --
+    its output is byte-identical to the data lines of the goldens test/mpileup.{1,3,4,5}.out and test/mpileup.X{,.2}.out
+    (test.pl:276-283)."""
     build_host()
     G = os.path.join(golden_dir, "call")
-    cmd = [CALL_EXE, "-v"] + (["-S", os.path.join(G, smpl)] if smpl else []) + [os.path.join(G, "mpileup.vcf")]
+    cmd = [CALL_EXE, "-v"] + (["-S", os.path.join(G, smpl)] if smpl else []) + \
+        (["--ploidy-file", os.path.join(G, ploidy)] if ploidy else []) + [os.path.join(G, vcff)]
     out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, text=True).stdout
     want = [ln.rstrip("\n") for ln in open(os.path.join(G, goldf)) if not ln.startswith("#")]
     assert out.splitlines() == want and len(want) > 0 and (n is None or len(want) == n)
