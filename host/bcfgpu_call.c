@@ -10,7 +10,8 @@
  *  als_map, GT in front of the FORMAT fields, PL trimmed (or dropped), QUAL, INFO/AC, AN, DP4, MQ appended, I16 and QS
  *  removed.  Prints the data lines of the output VCF; tests/test_c_host.py compares them, byte for byte, with the
  *  reference's goldens test/mpileup.{1,3,4,5}.out and test/mpileup.X{,.2}.out (test.pl:276-283).
- *  Not handled (the reference's other modes): -G groups, -F priors, Number=R tags other than PL.
+ *  Number=R tags of INFO and FORMAT follow the alleles (mcall_trim_and_update_numberR, mcall.c:1196-1265).
+ *  Not handled (the reference's other modes): -G groups, -F priors, -a GQ,GP.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,6 +37,41 @@ static char **split(char *s, char sep, int *n)
         *s++ = 0;
     }
     return v;
+}
+
+/* the Number=R tags the header declares (they follow the alleles when some are dropped) */
+static char infoR[64][64], fmtR[64][64];
+static int n_infoR = 0, n_fmtR = 0;
+
+static void header_line(const char *ln)
+{
+    const int is_info = !strncmp(ln, "##INFO=<ID=", 11), is_fmt = !strncmp(ln, "##FORMAT=<ID=", 13);
+    if (!is_info && !is_fmt) return;
+    const char *id = ln + (is_info ? 11 : 13), *e = strchr(id, ',');
+    if (!e || !strstr(e, "Number=R") || e - id > 63) return;
+    char (*tab)[64] = is_info ? infoR : fmtR; int *cnt = is_info ? &n_infoR : &n_fmtR;
+    if (*cnt == 64) return;
+    memcpy(tab[*cnt], id, (size_t)(e - id)); tab[*cnt][e - id] = 0; ++*cnt;
+}
+
+static int is_numberR(char (*tab)[64], int cnt, const char *key, size_t klen)
+{
+    for (int i = 0; i < cnt; ++i) if (strlen(tab[i]) == klen && !strncmp(tab[i], key, klen)) return 1;
+    return 0;
+}
+
+/* a comma-separated Number=R value list with the kept alleles' values in their new places */
+static void print_numberR(const char *vals, const int32_t *als_map, int nals, int nn)
+{
+    char *c = strdup(vals); int nv; char **v = split(c, ',', &nv);
+    if (nv != nals) fputs(vals, stdout);                        /* '.', or not one value per allele: left alone */
+    else if (nn == 1) fputs(v[0], stdout);
+    else {
+        const char *o[5] = { ".", ".", ".", ".", "." };
+        for (int i = 0; i < nals; ++i) if (als_map[i] >= 0) o[als_map[i]] = v[i];
+        for (int i = 0; i < nn; ++i) printf("%s%s", i ? "," : "", o[i]);
+    }
+    free(v); free(c);
 }
 
 static void *dev_upload(bcfgpu_ctx *ctx, const void *src, size_t bytes)
@@ -83,6 +119,7 @@ int main(int argc, char **argv)
         size_t l = strlen(buf);
         while (l && (buf[l - 1] == '\n' || buf[l - 1] == '\r')) buf[--l] = 0;
         if (buf[0] == '#') {
+            header_line(buf);
             if (!strncmp(buf, "#CHROM", 6)) {
                 int nf; char *c = strdup(buf), **h = split(c, '\t', &nf);
                 S_in = S = nf - 9;
@@ -240,7 +277,12 @@ int main(int argc, char **argv)
             char *info = strdup(r->fld[7]); int ni, first = 1; char **iv = split(info, ';', &ni);
             for (int i = 0; i < ni; ++i) {
                 if (!strncmp(iv[i], "I16=", 4) || !strncmp(iv[i], "QS=", 3) || !strcmp(iv[i], ".")) continue;
-                printf("%s%s", first ? "" : ";", iv[i]); first = 0;
+                const char *eq = strchr(iv[i], '=');
+                if (eq && nn != r->nals && is_numberR(infoR, n_infoR, iv[i], (size_t)(eq - iv[i]))) {
+                    printf("%s%.*s=", first ? "" : ";", (int)(eq - iv[i]), iv[i]);
+                    print_numberR(eq + 1, c->als_map, r->nals, nn);
+                } else printf("%s%s", first ? "" : ";", iv[i]);
+                first = 0;
             }
             free(iv); free(info);
             if (nn > 1) { printf("%sAC=", first ? "" : ";"); first = 0; for (int i = 1; i < nn; ++i) printf("%s%d", i > 1 ? "," : "", c->ac[i]); }
@@ -272,6 +314,9 @@ int main(int argc, char **argv)
                         if (v == BCFGPU_INT32_MISSING) putchar('.'); else printf("%d", v);
                     }
                     if (!printed) putchar('.');
+                } else if (i < nv && nn != r->nals && is_numberR(fmtR, n_fmtR, keys[i], strlen(keys[i]))) {
+                    putchar(':');
+                    print_numberR(vals[i], c->als_map, r->nals, nn);
                 } else printf(":%s", i < nv ? vals[i] : ".");
             }
             free(vals); free(smp);

@@ -188,6 +188,8 @@ CALL_EXE = os.path.join(ROOT, "host", "bcfgpu_call")
     ("mpileup.X.vcf", "mpileup.X.out", "mpileup.samples", "mpileup.ploidy", None),          # sexes + ploidy file: haploid males on X
     ("mpileup.X.vcf", "mpileup.X.out", "mpileup.ped", "mpileup.ploidy", None),              # the same from a PED file
     ("mpileup.X.vcf", "mpileup.X.2.out", "mpileup.2.samples", "mpileup.ploidy", None),      # ploidy numbers in the sample list
+    ("mpileup.NA19213.NA19129.vcf", "mpileup.hwe.1.out", None, None, None), ("mpileup.hwe.vcf", "mpileup.hwe.2.out", None, None, None),
+    ("call-G.vcf", "call-G.1.out", None, None, None),
 ])
 def test_c_call_driver_reproduces_reference_golden(golden_dir, vcff, goldf, smpl, ploidy, n):
     """host/bcfgpu_call.c: `call -mv [-S samples] [--ploidy-file f]` on the reference's test VCFs with mcall() on the device --
