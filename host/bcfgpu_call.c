@@ -1,17 +1,22 @@
 /*  bcfgpu_call.c -- `bcftools call -m [-v]` over a VCF from `bcftools mpileup`, in plain C over the C-ABI of
  *  include/bcfgpu.h: the record loop of main_vcfcall (vcfcall.c:1089-1148) with mcall() on the device.
  *
- *      bcfgpu_call [-v] [-S samples.txt] [--ploidy-file file] <in.vcf>      (one pooled group)
+ *      bcfgpu_call [-v] [-S samples.txt] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]]
+ *                  [-F AN_TAG,AC_TAG] [-a GQ,GP] <in.vcf>
  *          -S: the samples to keep, in that order: NAME [PLOIDY|SEX] per line, or a PED file (vcfcall.c:202-344)
  *          --ploidy-file: CHROM FROM TO SEX PLOIDY lines, '*' = default for the sex (ploidy.c)
+ *          -G: sample groups with their own allele frequencies, '-' = every sample alone, or NAME GROUP lines
+ *              (mcall.c:258-345); the frequencies come from FORMAT/QS or FORMAT/AD (--group-samples-tag)
+ *          -F: INFO tags holding AN and AC of a prior population (mcall.c:1499-1520)
+ *          -a: FORMAT/GQ and FORMAT/GP on called variant records (mcall.c:1618-1623)
  *
  *  Host: VCF text in, what mcall() reads from a record (alleles, FORMAT/PL, INFO/QS, INFO/I16) packed into the planes of
  *  bcfgpu_call_in, one bcfgpu_mcall over all records, then what mcall.c:1627-1681 does to the record: alleles trimmed with
  *  als_map, GT in front of the FORMAT fields, PL trimmed (or dropped), QUAL, INFO/AC, AN, DP4, MQ appended, I16 and QS
  *  removed.  Prints the data lines of the output VCF; tests/test_c_host.py compares them, byte for byte, with the
- *  reference's goldens test/mpileup.{1,3,4,5}.out and test/mpileup.X{,.2}.out (test.pl:276-283).
+ *  reference's goldens of `call -m` (test.pl:276-308: mpileup.{1,3,4,5}, mpileup.X{,.2}, mpileup.hwe.*, call-G.*,
+ *  call.af-fixation.*).
  *  Number=R tags of INFO and FORMAT follow the alleles (mcall_trim_and_update_numberR, mcall.c:1196-1265).
- *  Not handled (the reference's other modes): -G groups, -F priors, -a GQ,GP.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,7 +27,7 @@
 #define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s: %s (%d)\n", #call, bcfgpu_last_error(), rc_); exit(1); } } while (0)
 #define DIE(...) do { fprintf(stderr, __VA_ARGS__); exit(1); } while (0)
 
-typedef struct { char *line; char **fld; int nfld; char **als; int nals, unseen, pl_idx; uint8_t *ploidy; } rec_t;
+typedef struct { char *line; char **fld; int nfld; char **als; int nals, unseen, pl_idx, ad_idx; uint8_t *ploidy; } rec_t;
 
 typedef struct { char chrom[256]; int from, to, ploidy; char sex[64]; } preg_t;
 
@@ -41,13 +46,14 @@ static char **split(char *s, char sep, int *n)
 
 /* the Number=R tags the header declares (they follow the alleles when some are dropped) */
 static char infoR[64][64], fmtR[64][64];
-static int n_infoR = 0, n_fmtR = 0;
+static int n_infoR = 0, n_fmtR = 0, has_fmt_qs = 0, has_fmt_ad = 0;
 
 static void header_line(const char *ln)
 {
     const int is_info = !strncmp(ln, "##INFO=<ID=", 11), is_fmt = !strncmp(ln, "##FORMAT=<ID=", 13);
     if (!is_info && !is_fmt) return;
     const char *id = ln + (is_info ? 11 : 13), *e = strchr(id, ',');
+    if (is_fmt && e && e - id == 2) { has_fmt_qs |= !strncmp(id, "QS", 2); has_fmt_ad |= !strncmp(id, "AD", 2); }
     if (!e || !strstr(e, "Number=R") || e - id > 63) return;
     char (*tab)[64] = is_info ? infoR : fmtR; int *cnt = is_info ? &n_infoR : &n_fmtR;
     if (*cnt == 64) return;
@@ -84,15 +90,32 @@ static void *dev_upload(bcfgpu_ctx *ctx, const void *src, size_t bytes)
 
 int main(int argc, char **argv)
 {
-    int varonly = 0;
-    const char *smpl_file = NULL, *ploidy_file = NULL;
+    int varonly = 0, out_tags = 0;
+    const char *smpl_file = NULL, *ploidy_file = NULL, *grp_arg = NULL, *grp_tag = NULL;
+    char prior_an_tag[64] = "", prior_ac_tag[64] = "";
     while (argc > 2 && argv[1][0] == '-') {
         if (!strcmp(argv[1], "-v")) { varonly = 1; ++argv; --argc; }
+        else if (!strcmp(argv[1], "-G") && argc > 3) { grp_arg = argv[2]; argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "--group-samples-tag") && argc > 3) { grp_tag = argv[2]; argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-F") && argc > 3) {
+            const char *c = strchr(argv[2], ',');
+            if (!c || c == argv[2] || !c[1] || c - argv[2] > 63 || strlen(c + 1) > 63) DIE("-F: expected AN_TAG,AC_TAG\n");
+            memcpy(prior_an_tag, argv[2], (size_t)(c - argv[2])); prior_an_tag[c - argv[2]] = 0; strcpy(prior_ac_tag, c + 1);
+            argv += 2; argc -= 2;
+        }
+        else if (!strcmp(argv[1], "-a") && argc > 3) {
+            char *c = strdup(argv[2]); int nt; char **t = split(c, ',', &nt);
+            for (int i = 0; i < nt; ++i)
+                if (!strcmp(t[i], "GQ")) out_tags |= BCFGPU_CALL_FMT_GQ;
+                else if (!strcmp(t[i], "GP")) out_tags |= BCFGPU_CALL_FMT_GP;
+                else DIE("-a: unknown tag %s\n", t[i]);
+            free(t); free(c); argv += 2; argc -= 2;
+        }
         else if (!strcmp(argv[1], "-S") && argc > 3) { smpl_file = argv[2]; argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "--ploidy-file") && argc > 3) { ploidy_file = argv[2]; argv += 2; argc -= 2; }
         else break;
     }
-    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-S samples.txt] [--ploidy-file file] in.vcf\n"); return 2; }
+    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-S samples.txt] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] in.vcf\n"); return 2; }
     /* ploidy definition (ploidy.c): regions per sex, '*' lines = the sex's default; the last sex named is the default sex */
     preg_t *preg = NULL; int npreg = 0; char last_sex[64] = "";
     if (ploidy_file) {
@@ -114,6 +137,7 @@ int main(int argc, char **argv)
     static char buf[1 << 20];
     rec_t *recs = NULL; int n = 0, cap = 0, S = -1, ngmax = 1, S_in = -1;
     int *col = NULL;                              /* output sample s = input column col[s] (bcf_subset with -S) */
+    char **names = NULL;                          /* names of the input columns */
     char (*spec)[64] = NULL;                      /* its ploidy ("0", "1", "2") or sex name */
     while (fgets(buf, sizeof buf, f)) {
         size_t l = strlen(buf);
@@ -123,6 +147,8 @@ int main(int argc, char **argv)
             if (!strncmp(buf, "#CHROM", 6)) {
                 int nf; char *c = strdup(buf), **h = split(c, '\t', &nf);
                 S_in = S = nf - 9;
+                names = malloc((size_t)(S > 0 ? S : 1) * sizeof *names);
+                for (int s = 0; s < S; ++s) names[s] = strdup(h[9 + s]);
                 col = malloc((size_t)(S > 0 ? S : 1) * sizeof *col);
                 spec = malloc((size_t)(S > 0 ? S : 1) * sizeof *spec);
                 for (int s = 0; s < S; ++s) { col[s] = s; strcpy(spec[s], ploidy_file ? last_sex : "2"); }   /* vcfcall.c:645-650 */
@@ -186,20 +212,57 @@ int main(int argc, char **argv)
     fclose(f);
     if (S <= 0) DIE("no samples\n");
 
+    /* ---- -G: the group of every sample; ids in the order the groups first appear in the file (mcall.c:308-330) ---- */
+    int32_t *grp = NULL; int ngrp = 1;
+    if (grp_arg && !strcmp(grp_arg, "-")) {
+        grp = malloc((size_t)S * 4); ngrp = S;
+        for (int s = 0; s < S; ++s) grp[s] = s;
+    } else if (grp_arg) {
+        FILE *gf = fopen(grp_arg, "r");
+        if (!gf) DIE("cannot open %s\n", grp_arg);
+        grp = malloc((size_t)S * 4);
+        for (int s = 0; s < S; ++s) grp[s] = -1;
+        char (*gname)[256] = NULL; char ln[1024], w0[256], w1[256]; ngrp = 0;
+        while (fgets(ln, sizeof ln, gf)) {
+            if (sscanf(ln, "%255s %255s", w0, w1) != 2 || w0[0] == '#') continue;
+            int s, g;
+            for (s = 0; s < S; ++s) if (!strcmp(names[col[s]], w0)) break;
+            if (s == S) continue;                                           /* not among the samples called */
+            for (g = 0; g < ngrp; ++g) if (!strcmp(gname[g], w1)) break;
+            if (g == ngrp) { gname = realloc(gname, (size_t)(ngrp + 1) * sizeof *gname); strcpy(gname[ngrp++], w1); }
+            grp[s] = g;
+        }
+        fclose(gf); free(gname);
+        for (int s = 0; s < S; ++s) if (grp[s] < 0) DIE("sample %s is in no group of %s\n", names[col[s]], grp_arg);
+    }
+    if (ngrp > 1 && !grp_tag) grp_tag = has_fmt_qs ? "QS" : has_fmt_ad ? "AD" : NULL;       /* mcall.c:272-281 */
+    if (ngrp > 1 && !grp_tag) DIE("-G needs FORMAT/QS or FORMAT/AD\n");
+    int namax = 1;
+    for (int k = 0; k < n; ++k) if (recs[k].nals > namax) namax = recs[k].nals;
+
     /* ---- what mcall() reads from the records: PL planes (missing / vector_end kept), QS, I16 ---- */
     int32_t *nals = malloc((size_t)n * 4), *unseen = malloc((size_t)n * 4);
     int32_t *pl = malloc((size_t)n * ngmax * S * 4);
     float *qs = calloc((size_t)n * 5, 4), *i16 = calloc((size_t)n * 16, 4);
+    int32_t *ad = ngrp > 1 ? malloc((size_t)n * namax * S * 4) : NULL;
+    int32_t *pan = prior_an_tag[0] ? malloc((size_t)n * 4) : NULL, *pac = prior_an_tag[0] ? malloc((size_t)n * 4 * 4) : NULL;
+    const size_t l_pan = strlen(prior_an_tag), l_pac = strlen(prior_ac_tag);
     for (int k = 0; k < n; ++k) {
         rec_t *r = &recs[k];
         nals[k] = r->nals; unseen[k] = r->unseen;
         for (size_t i = 0; i < (size_t)ngmax * S; ++i) pl[(size_t)k * ngmax * S + i] = BCFGPU_INT32_VECTOR_END;
+        if (ad) for (size_t i = 0; i < (size_t)namax * S; ++i) ad[(size_t)k * namax * S + i] = BCFGPU_INT32_VECTOR_END;
+        if (pan) { pan[k] = BCFGPU_INT32_MISSING; for (int i = 0; i < 4; ++i) pac[(size_t)k * 4 + i] = BCFGPU_INT32_VECTOR_END; }
         /* FORMAT/PL */
         int nk; char *fmt = strdup(r->fld[8]), **keys = split(fmt, ':', &nk);
-        r->pl_idx = -1;
-        for (int i = 0; i < nk; ++i) if (!strcmp(keys[i], "PL")) r->pl_idx = i;
+        r->pl_idx = r->ad_idx = -1;
+        for (int i = 0; i < nk; ++i) {
+            if (!strcmp(keys[i], "PL")) r->pl_idx = i;
+            if (ad && !strcmp(keys[i], grp_tag)) r->ad_idx = i;
+        }
         free(keys); free(fmt);
         if (r->pl_idx < 0) DIE("no FORMAT/PL at %s:%s\n", r->fld[0], r->fld[1]);
+        if (ad && r->ad_idx < 0) DIE("FORMAT/%s is required with -G (%s:%s)\n", grp_tag, r->fld[0], r->fld[1]);     /* mcall.c:1476 */
         for (int s = 0; s < S; ++s) {
             char *smp = strdup(r->fld[9 + col[s]]); int nv; char **vals = split(smp, ':', &nv);
             if (r->pl_idx < nv) {
@@ -208,11 +271,27 @@ int main(int argc, char **argv)
                     pl[((size_t)k * ngmax + j) * S + s] = !strcmp(pv[j], ".") ? BCFGPU_INT32_MISSING : atoi(pv[j]);
                 free(pv);
             } else pl[((size_t)k * ngmax) * S + s] = BCFGPU_INT32_MISSING;
+            if (ad && r->ad_idx < nv) {
+                int na; char **av = split(vals[r->ad_idx], ',', &na);
+                for (int j = 0; j < na && j < namax; ++j)
+                    ad[((size_t)k * namax + j) * S + s] = !strcmp(av[j], ".") ? BCFGPU_INT32_MISSING : atoi(av[j]);
+                free(av);
+            } else if (ad) ad[((size_t)k * namax) * S + s] = BCFGPU_INT32_MISSING;
             free(vals); free(smp);
         }
         /* INFO/QS, INFO/I16 */
         char *info = strdup(r->fld[7]); int ni; char **iv = split(info, ';', &ni);
         for (int i = 0; i < ni; ++i) {
+            if (pan && !strncmp(iv[i], prior_an_tag, l_pan) && iv[i][l_pan] == '=') {        /* mcall.c:1499-1520 */
+                if (!strchr(iv[i], ',')) pan[k] = atoi(iv[i] + l_pan + 1);
+                continue;
+            }
+            if (pan && !strncmp(iv[i], prior_ac_tag, l_pac) && iv[i][l_pac] == '=') {
+                char *c = strdup(iv[i] + l_pac + 1); int nv; char **v = split(c, ',', &nv);
+                for (int j = 0; j < nv && j < 4; ++j) pac[(size_t)k * 4 + j] = !strcmp(v[j], ".") ? BCFGPU_INT32_MISSING : atoi(v[j]);
+                free(v); free(c);
+                continue;
+            }
             float *dst = !strncmp(iv[i], "QS=", 3) ? qs + (size_t)k * 5 : !strncmp(iv[i], "I16=", 4) ? i16 + (size_t)k * 16 : NULL;
             if (!dst) continue;
             const int lim = dst == qs + (size_t)k * 5 ? 5 : 16;
@@ -226,7 +305,8 @@ int main(int argc, char **argv)
     /* ---- the device ---- */
     bcfgpu_cfg cfg; memset(&cfg, 0, sizeof cfg);
     cfg.device = 0; cfg.n_smpl = S; cfg.max_sites = n; cfg.max_reads = 64;
-    cfg.min_baseQ = 13; cfg.capQ = 60; cfg.call_theta = 1.1e-3; cfg.call_flag = varonly ? BCFGPU_CALL_VARONLY : 0; cfg.n_grp = 1; cfg.ploidy_max = 2;
+    cfg.min_baseQ = 13; cfg.capQ = 60; cfg.call_theta = 1.1e-3; cfg.call_flag = varonly ? BCFGPU_CALL_VARONLY : 0; cfg.n_grp = ngrp; cfg.ploidy_max = 2;
+    cfg.output_tags = out_tags;
     bcfgpu_ctx *ctx = NULL;
     CHECK(bcfgpu_create(&cfg, &ctx));
     /* everything goes up once; the records are called in runs of equal ploidy vectors (the ploidy is per call:
@@ -234,7 +314,11 @@ int main(int argc, char **argv)
     int32_t *d_nals = dev_upload(ctx, nals, (size_t)n * 4), *d_unseen = dev_upload(ctx, unseen, (size_t)n * 4);
     int32_t *d_plin = dev_upload(ctx, pl, (size_t)n * ngmax * S * 4);
     float *d_qs = dev_upload(ctx, qs, (size_t)n * 5 * 4), *d_i16 = dev_upload(ctx, i16, (size_t)n * 16 * 4);
-    void *d_site, *d_gt, *d_pl, *d_ploidy;
+    int32_t *d_ad = ad ? dev_upload(ctx, ad, (size_t)n * namax * S * 4) : NULL, *d_grp = grp ? dev_upload(ctx, grp, (size_t)S * 4) : NULL;
+    int32_t *d_pan = pan ? dev_upload(ctx, pan, (size_t)n * 4) : NULL, *d_pac = pan ? dev_upload(ctx, pac, (size_t)n * 16) : NULL;
+    void *d_site, *d_gt, *d_pl, *d_ploidy, *d_gq = NULL, *d_gp = NULL;
+    if (out_tags & BCFGPU_CALL_FMT_GQ) CHECK(bcfgpu_malloc(ctx, (size_t)n * S * 4, &d_gq));
+    if (out_tags & BCFGPU_CALL_FMT_GP) CHECK(bcfgpu_malloc(ctx, (size_t)n * ngmax * S * 4, &d_gp));
     CHECK(bcfgpu_malloc(ctx, (size_t)n * sizeof(bcfgpu_call_site), &d_site)); CHECK(bcfgpu_malloc(ctx, (size_t)n * 2 * S, &d_gt));
     CHECK(bcfgpu_malloc(ctx, (size_t)n * ngmax * S * 4, &d_pl)); CHECK(bcfgpu_malloc(ctx, (size_t)S + 16, &d_ploidy));
     for (int i = 0; i < n; ) {
@@ -245,9 +329,13 @@ int main(int argc, char **argv)
         in.n_sites = j - i; in.n_gt_max = ngmax; in.n_al_max = 0;
         in.nals = d_nals + i; in.unseen = d_unseen + i; in.pl = d_plin + (size_t)i * ngmax * S; in.qs = d_qs + (size_t)i * 5;
         in.i16 = d_i16 + (size_t)i * 16;
+        if (d_ad) { in.ad = d_ad + (size_t)i * namax * S; in.n_al_max = namax; in.grp = d_grp; }
+        if (d_pan) { in.prior_an = d_pan + i; in.prior_ac = d_pac + (size_t)i * 4; }
         if (!all2) { CHECK(bcfgpu_memcpy_h2d(ctx, d_ploidy, recs[i].ploidy, (size_t)S)); in.ploidy = d_ploidy; }
         bcfgpu_call_out out; memset(&out, 0, sizeof out);
         out.site = (bcfgpu_call_site*)d_site + i; out.gt = (int8_t*)d_gt + (size_t)i * 2 * S; out.pl = (int32_t*)d_pl + (size_t)i * ngmax * S;
+        if (d_gq) out.gq = (int32_t*)d_gq + (size_t)i * S;
+        if (d_gp) out.gp = (float*)d_gp + (size_t)i * ngmax * S;
         CHECK(bcfgpu_mcall(ctx, &in, &out));
         CHECK(bcfgpu_sync(ctx));                               /* (d_ploidy is reused by the next run) */
         i = j;
@@ -256,6 +344,9 @@ int main(int argc, char **argv)
     int8_t *gt = malloc((size_t)n * 2 * S); int32_t *opl = malloc((size_t)n * ngmax * S * 4);
     CHECK(bcfgpu_memcpy_d2h(ctx, cs, d_site, (size_t)n * sizeof *cs)); CHECK(bcfgpu_memcpy_d2h(ctx, gt, d_gt, (size_t)n * 2 * S));
     CHECK(bcfgpu_memcpy_d2h(ctx, opl, d_pl, (size_t)n * ngmax * S * 4));
+    int32_t *gq = d_gq ? malloc((size_t)n * S * 4) : NULL; float *gp = d_gp ? malloc((size_t)n * ngmax * S * 4) : NULL;
+    if (gq) CHECK(bcfgpu_memcpy_d2h(ctx, gq, d_gq, (size_t)n * S * 4));
+    if (gp) CHECK(bcfgpu_memcpy_d2h(ctx, gp, d_gp, (size_t)n * ngmax * S * 4));
     CHECK(bcfgpu_sync(ctx));
 
     /* ---- the record loop (vcfcall.c:1137-1147, mcall.c:1627-1681) ---- */
@@ -296,6 +387,9 @@ int main(int argc, char **argv)
         int nk; char *fmt = strdup(r->fld[8]), **keys = split(fmt, ':', &nk);
         fputs("\tGT", stdout);
         for (int i = 0; i < nk; ++i) if (i != r->pl_idx || !c->pl_dropped) printf(":%s", keys[i]);
+        const int called = nn > 1 && c->ret > 0;               /* mcall_call_genotypes ran: GP and GQ exist (mcall.c:1618-1623) */
+        if (called && gp) fputs(":GP", stdout);
+        if (called && gq) fputs(":GQ", stdout);
         for (int s = 0; s < S; ++s) {
             const int g0 = gt[((size_t)k * 2 + 0) * S + s], g1 = gt[((size_t)k * 2 + 1) * S + s];
             putchar('\t');
@@ -318,6 +412,21 @@ int main(int argc, char **argv)
                     putchar(':');
                     print_numberR(vals[i], c->als_map, r->nals, nn);
                 } else printf(":%s", i < nv ? vals[i] : ".");
+            }
+            if (called && gp) {
+                putchar(':');
+                int printed = 0;
+                for (int j = 0; j < ngn; ++j) {
+                    uint32_t bits; memcpy(&bits, &gp[((size_t)k * ngmax + j) * S + s], 4);
+                    if (bits == 0x7F800002u) break;
+                    if (printed++) putchar(',');
+                    if (bits == 0x7F800001u) putchar('.'); else printf("%g", (double)gp[((size_t)k * ngmax + j) * S + s]);
+                }
+                if (!printed) putchar('.');
+            }
+            if (called && gq) {
+                const int32_t v = gq[(size_t)k * S + s];
+                if (v == BCFGPU_INT32_MISSING) fputs(":.", stdout); else printf(":%d", v);
             }
             free(vals); free(smp);
         }

@@ -182,23 +182,29 @@ CALL_EXE = os.path.join(ROOT, "host", "bcfgpu_call")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("vcff,goldf,smpl,ploidy,n", [
-    ("mpileup.vcf", "mpileup.1.out", None, None, 11), ("mpileup.vcf", "mpileup.3.out", "mpileup.3.samples", None, None),
-    ("mpileup.vcf", "mpileup.4.out", "mpileup.4.samples", None, None), ("mpileup.vcf", "mpileup.5.out", "mpileup.5.samples", None, None),
-    ("mpileup.X.vcf", "mpileup.X.out", "mpileup.samples", "mpileup.ploidy", None),          # sexes + ploidy file: haploid males on X
-    ("mpileup.X.vcf", "mpileup.X.out", "mpileup.ped", "mpileup.ploidy", None),              # the same from a PED file
-    ("mpileup.X.vcf", "mpileup.X.2.out", "mpileup.2.samples", "mpileup.ploidy", None),      # ploidy numbers in the sample list
-    ("mpileup.NA19213.NA19129.vcf", "mpileup.hwe.1.out", None, None, None), ("mpileup.hwe.vcf", "mpileup.hwe.2.out", None, None, None),
-    ("call-G.vcf", "call-G.1.out", None, None, None),
+@pytest.mark.parametrize("vcff,goldf,args,n", [
+    ("mpileup.vcf", "mpileup.1.out", "-v", 11), ("mpileup.vcf", "mpileup.3.out", "-v -S {G}/mpileup.3.samples", None),
+    ("mpileup.vcf", "mpileup.4.out", "-v -S {G}/mpileup.4.samples", None), ("mpileup.vcf", "mpileup.5.out", "-v -S {G}/mpileup.5.samples", None),
+    ("mpileup.X.vcf", "mpileup.X.out", "-v -S {G}/mpileup.samples --ploidy-file {G}/mpileup.ploidy", None),      # sexes + ploidy file: haploid males on X
+    ("mpileup.X.vcf", "mpileup.X.out", "-v -S {G}/mpileup.ped --ploidy-file {G}/mpileup.ploidy", None),          # the same from a PED file
+    ("mpileup.X.vcf", "mpileup.X.2.out", "-v -S {G}/mpileup.2.samples --ploidy-file {G}/mpileup.ploidy", None),  # ploidy numbers in the sample list
+    ("mpileup.NA19213.NA19129.vcf", "mpileup.hwe.1.out", "-v", None), ("mpileup.hwe.vcf", "mpileup.hwe.2.out", "-v", None),
+    ("mpileup.NA19213.NA19129.vcf", "mpileup.hwe.1b.out", "-v -G - --group-samples-tag AD", None),               # every sample its own group
+    ("mpileup.hwe.vcf", "mpileup.hwe.3.out", "-v -G - --group-samples-tag AD", None),
+    ("mpileup.hwe.vcf", "mpileup.hwe.4.out", "-v -G {G}/mpileup.hwe.samples --group-samples-tag AD", None),      # groups from a file
+    ("call-G.vcf", "call-G.1.out", "-v", None), ("call-G.vcf", "call-G.2.out", "-v -G - --group-samples-tag AD", None),
+    ("call-G.2.vcf", "call-G.2.1.out", "-v -F AN_POP,AC_POP", None),                                             # prior from INFO tags
+    ("call.af-fixation.vcf", "call.af-fixation.1.out", "", None),                                                # all records, not only variants
+    ("call.af-fixation.vcf", "call.af-fixation.2.out", "-G {G}/call.af-fixation.txt", None),
+    ("call.af-fixation.vcf", "call.af-fixation.3.out", "-G {G}/call.af-fixation.txt -a GP,GQ", None),
 ])
-def test_c_call_driver_reproduces_reference_golden(golden_dir, vcff, goldf, smpl, ploidy, n):
-    """host/bcfgpu_call.c: `call -mv [-S samples] [--ploidy-file f]` on the reference's test VCFs with mcall() on the device --
-    its output is byte-identical to the data lines of the goldens test/mpileup.{1,3,4,5}.out and test/mpileup.X{,.2}.out
-    (test.pl:276-283)."""
+def test_c_call_driver_reproduces_reference_golden(golden_dir, vcff, goldf, args, n):
+    """host/bcfgpu_call.c: `call -m [-v] [-S samples] [--ploidy-file f] [-G groups] [-F AN,AC] [-a GP,GQ]` on the reference's
+    test VCFs with mcall() on the device -- its output is byte-identical to the data lines of every `call -m` golden of
+    test.pl:276-308."""
     build_host()
     G = os.path.join(golden_dir, "call")
-    cmd = [CALL_EXE, "-v"] + (["-S", os.path.join(G, smpl)] if smpl else []) + \
-        (["--ploidy-file", os.path.join(G, ploidy)] if ploidy else []) + [os.path.join(G, vcff)]
+    cmd = [CALL_EXE] + args.format(G=G).split() + [os.path.join(G, vcff)]
     out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, text=True).stdout
     want = [ln.rstrip("\n") for ln in open(os.path.join(G, goldf)) if not ln.startswith("#")]
     assert out.splitlines() == want and len(want) > 0 and (n is None or len(want) == n)
