@@ -63,11 +63,11 @@ def fmt_gt(a, b):
 
 
 def run_call(vcf, engine, call_flag=0, output_tags=0, theta=1.1e-3, samples=None, ploidy=None,
-             groups=None, grp_tag="AD", prior=None):
+             groups=None, grp_tag="AD", prior=None, recs=None):
     """Returns the list of CalledRec that `bcftools call -m` would print.
 
     samples: [(name, spec)] (-S); ploidy: parsed --ploidy-file; groups: {sample: group} or '-' (-G);
-    prior: (AN_tag, AC_tag) (-F).
+    prior: (AN_tag, AC_tag) (-F); recs: the records to call instead of vcf.recs (helpers/cals.py: -C alleles).
     """
     names = vcf.samples
     if samples is None:
@@ -104,7 +104,7 @@ def run_call(vcf, engine, call_flag=0, output_tags=0, theta=1.1e-3, samples=None
 
     # select candidate records and their per-site ploidy vectors
     cand = []
-    for rec in vcf.recs:
+    for rec in (vcf.recs if recs is None else recs):
         unseen = V.find_unseen(rec)
         nals = len(rec.alleles)
         is_ref = nals == 1 or (nals == 2 and unseen > 0)

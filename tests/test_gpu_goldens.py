@@ -4,6 +4,7 @@ import pytest
 
 from bcftools_amd import abi, engine
 from tests.test_oracle_golden_call import run_case, N_CASES
+from tests.test_oracle_golden_cals import run_cals_case, CASES as CALS_CASES
 from tests.test_oracle_golden_mpileup import build, check_against_golden
 
 pytestmark = pytest.mark.gpu
@@ -22,6 +23,15 @@ def test_hip_reproduces_call_golden(golden_dir, idx):
         with engine.Context(cfg) as ctx:
             return ctx.mcall(cin)
     run_case(os.path.join(golden_dir, "call"), idx, hip_engine)
+
+
+@pytest.mark.parametrize("idx", range(len(CALS_CASES)))
+def test_hip_reproduces_constrained_alleles_golden(golden_dir, idx):
+    """`call -mA -C alleles -T tab [-i]` (test.pl:289-297): mcall with BCFGPU_CALL_KEEPALT on the device."""
+    def hip_engine(cfg, cin):
+        with engine.Context(cfg) as ctx:
+            return ctx.mcall(cin)
+    run_cals_case(os.path.join(golden_dir, "call"), idx, hip_engine)
 
 
 from tests.test_oracle_golden_baq import CASES as BAQ_CASES, run_case as run_baq_case
