@@ -105,6 +105,19 @@ class IndelOut(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("ret", "p_aux", "indel_types", "inscns", "maxins", "indelreg", "max_support", "max_frac")]
 
 
+class GvcfBlock(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("first_site", "last_site", "start_pos", "end1", "min_dp", "range")]
+
+
+class GvcfIn(C.Structure):
+    _fields_ = [("n_sites", C.c_int32), ("n_range", C.c_int32)] + [(k, C.c_void_p) for k in
+                ("dp_range", "pos", "rid", "brk", "site", "pl", "dp4")]
+
+
+class GvcfOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("blk", "min_dp", "block", "dp", "pl")]
+
+
 class GapStats(C.Structure):
     _fields_ = [("n_jobs", C.c_uint64), ("n_passes", C.c_uint64), ("dp_cells", C.c_uint64),
                 ("kernel_ms", C.c_float), ("prepare_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float)]
@@ -139,6 +152,7 @@ PROTOTYPES = {
     "bcfgpu_pileup_entries": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "bcfgpu_pileup": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,
                                 C.POINTER(Tile), C.c_void_p, C.c_void_p]),
+    "bcfgpu_gvcf_blocks": (C.c_int, [C.c_void_p, C.POINTER(GvcfIn), C.POINTER(GvcfOut), C.POINTER(C.c_int32)]),
     "bcfgpu_gap_prep_stats": (C.c_int, [C.c_void_p, C.POINTER(GapStats)]),
     "bcfgpu_pipeline": (C.c_int, [C.c_void_p, C.POINTER(Tile), C.c_void_p, C.c_void_p,
                                   C.POINTER(MplpOut), C.POINTER(CallOut)]),

@@ -49,7 +49,7 @@ struct bcfgpu_ctx {
     // grow-only device workspaces of the indel / BAQ stages (GiB-sized scratch: not reallocated per call)
     struct Ws { void *p = nullptr; size_t bytes = 0; };
     alignas(16) unsigned char pileup_state[256] = {0};   // csrc/pileup.hip: the parameters of the last bcfgpu_pileup
-    Ws ws[32];                     // grow-only device workspaces of the host-fed stages (0-15: indel / BAQ / overlaps, 16-31: pileup)
+    Ws ws[40];                     // grow-only device workspaces of the host-fed stages (0-15: indel / BAQ / overlaps, 16-31: pileup, 32-33: gVCF)
 };
 
 extern "C" {
@@ -523,7 +523,7 @@ void *bcfgpu_internal_pileup_state(bcfgpu_ctx *c) { return c ? c->pileup_state :
 // workspace `slot` of at least `bytes` (contents undefined); nullptr when the allocation fails
 void *bcfgpu_internal_ws(bcfgpu_ctx *c, int slot, size_t bytes)
 {
-    if (!c || slot < 0 || slot >= 32) return nullptr;
+    if (!c || slot < 0 || slot >= 40) return nullptr;
     auto &w = c->ws[slot];
     if (w.bytes >= bytes && w.p) return w.p;
     hipSetDevice(c->cfg.device);

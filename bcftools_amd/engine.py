@@ -140,6 +140,37 @@ class Context:
             self.release(tb + list(ob.values()))
         return res
 
+    def gvcf_blocks(self, res, pos, dp_range, rid=None, brk=None):
+        """gvcf_write over the records of a host MplpResult (bcfgpu_gvcf_blocks); returns a host GvcfResult."""
+        n, S = res.n_sites, self.cfg.n_smpl
+        rng = np.ascontiguousarray(dp_range, dtype=np.int32)
+        bufs = [self.to_device(np.ascontiguousarray(pos, dtype=np.int32)), self.to_device(res.site), self.to_device(res.pl),
+                self.to_device(res.dp4)]
+        gi = abi.GvcfIn()
+        gi.n_sites, gi.n_range, gi.dp_range = n, len(rng), rng.ctypes.data_as(C.c_void_p)
+        gi.pos, gi.site, gi.pl, gi.dp4 = (b.ptr for b in bufs)
+        if rid is not None:
+            bufs.append(self.to_device(np.ascontiguousarray(rid, dtype=np.int32)))
+            gi.rid = bufs[-1].ptr
+        if brk is not None:
+            bufs.append(self.to_device(np.ascontiguousarray(brk, dtype=np.uint8)))
+            gi.brk = bufs[-1].ptr
+        blk, min_dp = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        block = np.zeros(n, host.GVCF_BLOCK_DTYPE)
+        dp, pl = np.zeros((n, S), np.int32), np.zeros((n, 3, S), np.uint8)
+        outs = [(a, self.buf(a.nbytes)) for a in (blk, min_dp, block, dp, pl)]
+        go = abi.GvcfOut()
+        go.blk, go.min_dp, go.block, go.dp, go.pl = (b.ptr for _, b in outs)
+        nb = C.c_int32(0)
+        try:
+            check(self.L.bcfgpu_gvcf_blocks(self.h, C.byref(gi), C.byref(go), C.byref(nb)))
+            self.sync()
+            for a, b in outs:
+                b.download(a)
+        finally:
+            self.release(bufs + [b for _, b in outs])
+        return host.GvcfResult(nb.value, blk, min_dp, block, dp, pl)
+
     def mcall(self, cin):
         """Run the caller on a host CallInput, return a host CallResult."""
         assert cin.n_smpl == self.cfg.n_smpl

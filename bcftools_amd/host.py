@@ -22,6 +22,9 @@ CALLSITE_DTYPE = np.dtype([("ret", "<i4"), ("nals_new", "<i4"), ("als_new", "<i4
                            ("pl_dropped", "<i4"), ("has_i16", "<i4"), ("dp4", "<i4", 4), ("mq", "<i4"),
                            ("pv4_tested", "<i4"), ("pv4", "<f4", 4)], align=True)
 
+GVCF_BLOCK_DTYPE = np.dtype([(k, "<i4") for k in ("first_site", "last_site", "start_pos", "end1", "min_dp", "range")])
+assert GVCF_BLOCK_DTYPE.itemsize == C.sizeof(abi.GvcfBlock)
+
 assert SITE_DTYPE.itemsize == C.sizeof(abi.Site), (SITE_DTYPE.itemsize, C.sizeof(abi.Site))
 assert CALLSITE_DTYPE.itemsize == C.sizeof(abi.CallSite)
 
@@ -92,6 +95,14 @@ class MplpResult:
         x = na * (na + 1) // 2
         return self.pl[isite, :x, :].T.astype(np.int32)
 
+
+
+class GvcfResult:
+    """Host copy of bcfgpu_gvcf_out, cut to the blocks found (PL widened to int32)."""
+
+    def __init__(self, n_blocks, blk, min_dp, block, dp, pl):
+        self.n_blocks, self.blk, self.min_dp = n_blocks, blk, min_dp
+        self.block, self.dp, self.pl = block[:n_blocks], dp[:n_blocks], pl[:n_blocks].astype(np.int32)
 
 
 class CallInput:

@@ -21,6 +21,7 @@
  *                                           with the per-read accessors of bcfgpu_pack_read
  *    bcfgpu_pileup_indel_tile            <- the second pileup pass of mpileup_reg() with p->aux set, mpileup.c:354-360
  *    bcfgpu_pileup_entries               <- the bam_pileup1_t fields bcf_call_gap_prep reads (b, qpos, indel), bam2bcf_indel.c:106-128
+ *    bcfgpu_gvcf_blocks                  <- gvcf_write (gvcf.c:88-226) over the records of a tile, call site mpileup.c:297-316
  *    bcfgpu_mcall                        <- mcall()                            call.h:131 (mcall.c:1430-1684)
  *                                           incl. the per-record prologue of vcfcall.c:1096-1115
  *    bcfgpu_pipeline                     <- the `mpileup -Ou | call -m` pipe with PL/QS/I16 kept in HBM
@@ -369,6 +370,51 @@ int  bcfgpu_pileup_entries(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols,
  * valid until the next call of this function or of bcfgpu_pileup on this context. */
 int  bcfgpu_pileup_indel_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols, const uint32_t *aux, int64_t n_aux,
                               bcfgpu_tile *tile);
+
+/* ---- gVCF blocks (mpileup --gvcf, gvcf.c:88-226) ---------------------------------
+ * gvcf_write() collapses runs of reference-only records into blocks: a record can join when it has only REF and <*>
+ * (mpileup.c:309-315) and the smallest per-sample FORMAT/DP falls into a range > 0 of `dp_range` (gvcf.c:112-128); a block
+ * ends where that range changes, at a record that cannot join, at a gap in positions or a new sequence (gvcf.c:130-131).
+ * Per block and sample: the smallest DP and the smallest (PL[1], PL[2]) pair in that order (gvcf.c:192-210), PL[0], alleles
+ * and INFO/QS are the first record's.  On the device this is a site-local rule for block starts, a prefix sum for block
+ * numbers and a per-sample reduction over the block's sites, on the planes the mpileup stage left in HBM.
+ * A block never spans two calls: a caller that cuts a region into tiles joins the last block of one call with the first
+ * of the next where the rule above allows it (the per-sample rule is associative).
+ */
+typedef struct {
+    int32_t first_site, last_site;    /* sites of the block (indices into the tile) */
+    int32_t start_pos;                /* rec->pos of the first record, 0-based (gvcf.c:183) */
+    int32_t end1;                     /* INFO/END, 1-based (gvcf.c:139-143); written only when start_pos+1 < end1 (gvcf.c:150) */
+    int32_t min_dp;                   /* INFO/MinDP (gvcf.c:188,192) */
+    int32_t range;                    /* 1-based index into dp_range the block belongs to */
+} bcfgpu_gvcf_block;
+
+typedef struct {
+    int32_t n_sites, n_range;
+    const int32_t *dp_range;          /* HOST [n_range], the --gvcf list as given (gvcf.c:44-67) */
+    const int32_t *pos;               /* [n_sites] rec->pos (0-based), ascending within a sequence */
+    const int32_t *rid;               /* [n_sites] sequence of the record, or NULL: all the same */
+    const uint8_t *brk;               /* [n_sites] 1: a record that cannot join (the indel record of mpileup.c:354-365)
+                                         follows this site at the same position -- the block ends here and its END stops
+                                         one short (gvcf.c:139); or NULL */
+    const bcfgpu_site *site;          /* the mpileup stage's output for the tile (n_alleles, unseen are read) */
+    const uint8_t *pl;                /* bcfgpu_mplp_out.pl  */
+    const uint8_t *dp4;               /* bcfgpu_mplp_out.dp4: FORMAT/DP is the sum of the four (bam2bcf.c:853-858) */
+} bcfgpu_gvcf_in;
+
+/*      blk    [n_sites]            i32  block of the site, or -1: its record is written as it is
+ *      min_dp [n_sites]            i32  smallest per-sample DP of the site (INFO/MinDP of an uncollapsed reference record, gvcf.c:221-222)
+ *      block  [n_sites]                 the blocks in order (capacity n_sites)
+ *      dp     [block][n_smpl]      i32  FORMAT/DP of the block
+ *      pl     [block][3][n_smpl]   u8   FORMAT/PL of the block */
+typedef struct {
+    int32_t *blk, *min_dp;
+    bcfgpu_gvcf_block *block;
+    int32_t *dp;
+    uint8_t *pl;
+} bcfgpu_gvcf_out;
+/* n_blocks: HOST, out.  Synchronises the context's stream (the block count decides the launch of the reduction). */
+int  bcfgpu_gvcf_blocks(bcfgpu_ctx *ctx, const bcfgpu_gvcf_in *in, const bcfgpu_gvcf_out *out, int32_t *n_blocks);
 
 /* statistics of the last bcfgpu_gap_prep call on this context (SURVEY 8d "indel stage unit": DP cells per second):
  * jobs = (site, candidate type, read) realignments, passes = forward passes run (a second parameter set is tried when

@@ -85,6 +85,12 @@ int orc_format_sp(int fwd_ref, int rev_ref, int fwd_alt, int rev_alt);
  * (pair_a[p] arrived first, pair_b[p]); `qual` is the pool of qualities, modified in place */
 int orc_overlap_tweak(const bcfgpu_reads *rd, int32_t n_pairs, const int32_t *pair_a, const int32_t *pair_b, uint8_t *qual);
 
+/* gvcf_write (gvcf.c:88-226) over n records: dp [n][S], pl [n][3][S] (FORMAT/DP and FORMAT/PL of the records), is_ref as
+ * mpileup.c:309-315 decides it; outputs as bcfgpu_gvcf_out but with int32 PL.  Returns the number of blocks. */
+int orc_gvcf_blocks(int n, int S, const int32_t *pos, const int32_t *rid, const uint8_t *brk, const uint8_t *is_ref,
+                    const int32_t *dp, const int32_t *pl, const int32_t *dp_range, int n_range,
+                    int32_t *blk, int32_t *min_dp_out, bcfgpu_gvcf_block *block, int32_t *dp_out, int32_t *pl_out);
+
 #ifdef __cplusplus
 }
 #endif

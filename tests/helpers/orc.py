@@ -58,8 +58,29 @@ def lib():
         L.orc_calc_mwu_bias.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_format_sp.restype = C.c_int
         L.orc_format_sp.argtypes = [C.c_int] * 4
+        L.orc_gvcf_blocks.restype = C.c_int
+        L.orc_gvcf_blocks.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 5
         _LIB = L
     return _LIB
+
+
+def gvcf_blocks(res, pos, dp_range, rid=None, brk=None):
+    """gvcf_write over the records of a host MplpResult, sequentially as the reference does it (oracle/gvcf.c)."""
+    from bcftools_amd.host import GVCF_BLOCK_DTYPE, GvcfResult
+    n, S = res.n_sites, res.n_smpl
+    pos = np.ascontiguousarray(pos, dtype=np.int32)
+    rid = None if rid is None else np.ascontiguousarray(rid, dtype=np.int32)
+    brk = None if brk is None else np.ascontiguousarray(brk, dtype=np.uint8)
+    is_ref = np.ascontiguousarray((res.site["n_alleles"] == 2) & (res.site["unseen"] == 1), dtype=np.uint8)   # mpileup.c:309-315
+    dp = np.ascontiguousarray(res.dp4.sum(axis=1, dtype=np.int32))                                       # bam2bcf.c:853-858
+    pl = np.ascontiguousarray(res.pl[:, :3, :].astype(np.int32))
+    rng = np.ascontiguousarray(dp_range, dtype=np.int32)
+    blk, min_dp = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    block = np.zeros(max(n, 1), GVCF_BLOCK_DTYPE)
+    dpo, plo = np.zeros((max(n, 1), S), np.int32), np.zeros((max(n, 1), 3, S), np.int32)
+    nb = lib().orc_gvcf_blocks(n, S, _p(pos), _p(rid), _p(brk), _p(is_ref), _p(dp), _p(pl), _p(rng), len(rng),
+                               _p(blk), _p(min_dp), _p(block), _p(dpo), _p(plo))
+    return GvcfResult(nb, blk, min_dp, block, dpo, plo)
 
 
 def mpileup(cfg, tile, want_callret=False):
