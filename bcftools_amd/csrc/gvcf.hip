@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void gvcf_site_kernel(const GvcfParams P)
     for (int o = 32; o; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
     if (lane) return;
     // REF and <*> only (mpileup.c:309-315)
-    const bool is_ref = P.site[site].n_alleles == 2 && P.site[site].unseen == 1;
+    const bool is_ref = P.site[site].n_alleles == 2 && P.site[site].unseen == 1 && !(P.brk && (P.brk[site] & 2));
     int r = 0;
     if (is_ref) { while (r < P.n_range && m >= P.dp_range[r]) ++r; }
     P.min_dp[site] = is_ref ? m : 0;
@@ -63,7 +63,7 @@ __device__ __forceinline__ bool gvcf_joins(const GvcfParams &P, int i)
     if (!r || P.range[i - 1] != r) return false;
     if (P.rid && P.rid[i] != P.rid[i - 1]) return false;
     if (P.pos[i] > P.pos[i - 1] + 1) return false;
-    return !(P.brk && P.brk[i - 1]);
+    return !(P.brk && (P.brk[i - 1] & 1));
 }
 
 __global__ __launch_bounds__(256) void gvcf_head_kernel(const GvcfParams P)
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void gvcf_block_kernel(const GvcfParams P)
     if (P.head[i]) { B->first_site = i; B->start_pos = P.pos[i]; B->range = P.range[i]; }
     if (i + 1 == P.n_sites || !gvcf_joins(P, i + 1)) {
         B->last_site = i;
-        B->end1 = P.pos[i] + 1 - ((P.brk && P.brk[i]) ? 1 : 0);     // gvcf.c:139-141
+        B->end1 = P.pos[i] + 1 - ((P.brk && (P.brk[i] & 1)) ? 1 : 0);     // gvcf.c:139-141
     }
 }
 

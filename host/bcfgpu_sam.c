@@ -243,7 +243,15 @@ int main(int argc, char **argv)
         free(list);
         argv += 2; argc -= 2;
     }
-    if (argc < 6) { fprintf(stderr, "usage: bcfgpu_sam [-a TAG,..] ref.fa contig beg end file.sam [file.sam ...]\n"); return 2; }
+    int32_t gv_range[16]; int gv_n = 0;                                       /* mpileup --gvcf INT,.. (gvcf.c:44-67) */
+    if (argc > 2 && !strcmp(argv[1], "--gvcf")) {
+        char *list = strdup(argv[2]);
+        for (char *t = strtok(list, ","); t; t = strtok(NULL, ",")) { if (gv_n == 16) DIE("--gvcf: at most 16 limits\n"); gv_range[gv_n++] = atoi(t); }
+        free(list);
+        fmt_flag |= BCFGPU_FMT_DP;                                            /* mpileup.c:1101-1105 */
+        argv += 2; argc -= 2;
+    }
+    if (argc < 6) { fprintf(stderr, "usage: bcfgpu_sam [-a TAG,..] [--gvcf INT,..] ref.fa contig beg end file.sam [file.sam ...]\n"); return 2; }
     const char *contig = argv[2];
     const int beg = atoi(argv[3]) - 1, end = atoi(argv[4]);                 /* 0-based [beg, end) */
     const int S = argc - 5, n_sites = end - beg;
@@ -359,12 +367,53 @@ int main(int argc, char **argv)
         }
     }
 
+    /* ---- --gvcf: reference-only records collapse into blocks (gvcf_write, gvcf.c:88-226) on the planes still in HBM ---- */
+    int32_t *gv_blk = NULL, *gv_dp = NULL; bcfgpu_gvcf_block *gv_block = NULL; uint8_t *gv_pl = NULL;
+    if (gv_n) {
+        int32_t *pos = malloc((size_t)n_sites * 4); uint8_t *brk = calloc((size_t)n_sites, 1);
+        for (int k = 0; k < n_sites; ++k) { pos[k] = beg + k; if (col_n[k] == 0) brk[k] |= 2; }
+        for (int j = 0; j < nlive; ++j) if (isite[j].ret == 0) brk[cand[live[j]]] |= 1;      /* an indel record follows the SNP record */
+        void *d_pos, *d_brk, *d_blk, *d_min, *d_block, *d_gdp, *d_gpl;
+        CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_pos)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites, &d_brk));
+        CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_blk)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_min));
+        CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * sizeof(bcfgpu_gvcf_block), &d_block));
+        CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * S * 4, &d_gdp)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 3 * S, &d_gpl));
+        CHECK(bcfgpu_memcpy_h2d(ctx, d_pos, pos, (size_t)n_sites * 4)); CHECK(bcfgpu_memcpy_h2d(ctx, d_brk, brk, (size_t)n_sites));
+        bcfgpu_gvcf_in gi; memset(&gi, 0, sizeof gi);
+        gi.n_sites = n_sites; gi.n_range = gv_n; gi.dp_range = gv_range; gi.pos = d_pos; gi.brk = d_brk;
+        gi.site = d_site; gi.pl = d_pl; gi.dp4 = d_dp4;
+        bcfgpu_gvcf_out go = { d_blk, d_min, d_block, d_gdp, d_gpl };
+        int32_t nb = 0;
+        CHECK(bcfgpu_gvcf_blocks(ctx, &gi, &go, &nb));
+        gv_blk = malloc((size_t)n_sites * 4); gv_block = malloc((size_t)(nb + 1) * sizeof *gv_block);
+        gv_dp = malloc((size_t)(nb + 1) * S * 4); gv_pl = malloc((size_t)(nb + 1) * 3 * S);
+        CHECK(bcfgpu_memcpy_d2h(ctx, gv_blk, d_blk, (size_t)n_sites * 4)); CHECK(bcfgpu_memcpy_d2h(ctx, gv_block, d_block, (size_t)nb * sizeof *gv_block));
+        CHECK(bcfgpu_memcpy_d2h(ctx, gv_dp, d_gdp, (size_t)nb * S * 4)); CHECK(bcfgpu_memcpy_d2h(ctx, gv_pl, d_gpl, (size_t)nb * 3 * S));
+        CHECK(bcfgpu_sync(ctx));
+        bcfgpu_free(ctx, d_pos); bcfgpu_free(ctx, d_brk); bcfgpu_free(ctx, d_blk); bcfgpu_free(ctx, d_min); bcfgpu_free(ctx, d_block);
+        bcfgpu_free(ctx, d_gdp); bcfgpu_free(ctx, d_gpl); free(pos); free(brk);
+    }
+
     /* ---- the record loop: the SNP record of a column, then its indel record (mpileup.c:343-366) ---- */
     static const char *nt = "ACGTN";
     int jl = 0;
     for (int k = 0; k < n_sites; ++k) {
         if (col_n[k] == 0) continue;                                         /* no read: no record */
         const bcfgpu_site *c = &site[k];
+        if (gv_blk && gv_blk[k] >= 0) {                                      /* inside a block: one line when the block ends */
+            const int b = gv_blk[k];
+            const bcfgpu_gvcf_block *B = &gv_block[b];
+            if (B->last_site == k) {
+                const bcfgpu_site *f = &site[B->first_site];
+                printf("%s\t%d\t.\t%c\t<*>\t.\t.\t", contig, B->start_pos + 1, nt[f->ori_ref < 0 || f->ori_ref > 4 ? 4 : f->ori_ref]);
+                if (B->start_pos + 1 < B->end1) printf("END=%d;", B->end1);                  /* gvcf.c:150-151 */
+                printf("MinDP=%d;QS=%g,%g\tPL:DP", B->min_dp, (double)f->qsum[0], (double)f->qsum[1]);
+                for (int s = 0; s < S; ++s)
+                    printf("\t%d,%d,%d:%d", gv_pl[((size_t)b * 3) * S + s], gv_pl[((size_t)b * 3 + 1) * S + s], gv_pl[((size_t)b * 3 + 2) * S + s],
+                           gv_dp[(size_t)b * S + s]);
+                putchar('\n');
+            }
+        } else {
         char als[64]; int o = 0;
         als[o++] = nt[c->ori_ref < 0 || c->ori_ref > 4 ? 4 : c->ori_ref]; als[o++] = '\t';
         for (int j = 1; j < c->n_alleles; ++j) {
@@ -374,6 +423,7 @@ int main(int argc, char **argv)
         if (c->n_alleles < 2) als[o++] = '.';
         als[o] = 0;
         print_record(contig, beg + k + 1, als, "", c, &snp_planes, (size_t)k, S);
+        }
         while (jl < nlive && cand[live[jl]] < k) ++jl;
         if (jl < nlive && cand[live[jl]] == k && isite[jl].ret == 0) {
             /* REF / ALT of an indel record (bam2bcf.c:767-790) */

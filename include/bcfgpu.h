@@ -394,9 +394,10 @@ typedef struct {
     const int32_t *dp_range;          /* HOST [n_range], the --gvcf list as given (gvcf.c:44-67) */
     const int32_t *pos;               /* [n_sites] rec->pos (0-based), ascending within a sequence */
     const int32_t *rid;               /* [n_sites] sequence of the record, or NULL: all the same */
-    const uint8_t *brk;               /* [n_sites] 1: a record that cannot join (the indel record of mpileup.c:354-365)
+    const uint8_t *brk;               /* [n_sites] bit 0: a record that cannot join (the indel record of mpileup.c:354-365)
                                          follows this site at the same position -- the block ends here and its END stops
-                                         one short (gvcf.c:139); or NULL */
+                                         one short (gvcf.c:139); bit 1: the site has no record at all (a column without
+                                         reads): it joins nothing and blk is -1; or NULL */
     const bcfgpu_site *site;          /* the mpileup stage's output for the tile (n_alleles, unseen are read) */
     const uint8_t *pl;                /* bcfgpu_mplp_out.pl  */
     const uint8_t *dp4;               /* bcfgpu_mplp_out.dp4: FORMAT/DP is the sum of the four (bam2bcf.c:853-858) */

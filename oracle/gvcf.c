@@ -28,6 +28,7 @@ int orc_gvcf_blocks(int n, int S, const int32_t *pos, const int32_t *rid, const 
     gv_state g; memset(&g, 0, sizeof g); g.rid = -1;
     for (int i = 0; i < n; ++i) {
         const int r = rid ? rid[i] : 0;
+        if (brk && (brk[i] & 2)) { blk[i] = -1; min_dp_out[i] = 0; continue; }     /* no record for this site (a column without reads) */
         const int32_t *d = dp + (size_t)i * S, *p = pl + (size_t)i * 3 * S;
         int can = is_ref[i] ? 1 : 0, range = 0, min_dp = 0, needs_flush = can ? 0 : 1;
         if (can) {                                                   /* gvcf.c:106-128 */
@@ -59,7 +60,7 @@ int orc_gvcf_blocks(int n, int S, const int32_t *pos, const int32_t *rid, const 
             g.prev_range = range; g.end = pos[i]; g.last_site = i;
             blk[i] = g.nb;
         }
-        if (brk && brk[i] && g.prev_range) gv_flush(&g, r, pos[i], block);   /* a record that cannot join, same position */
+        if (brk && (brk[i] & 1) && g.prev_range) gv_flush(&g, r, pos[i], block);   /* a record that cannot join, same position */
     }
     if (g.prev_range) gv_flush(&g, -2, 0, block);                    /* gvcf_write(.., NULL, 0) at the end, mpileup.c:303-307 */
     return g.nb;

@@ -208,3 +208,15 @@ def test_c_call_driver_reproduces_reference_golden(golden_dir, vcff, goldf, args
     out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, text=True).stdout
     want = [ln.rstrip("\n") for ln in open(os.path.join(G, goldf)) if not ln.startswith("#")]
     assert out.splitlines() == want and len(want) > 0 and (n is None or len(want) == n)
+
+
+@pytest.mark.gpu
+def test_c_sam_driver_reproduces_gvcf_golden(golden_dir):
+    """`bcfgpu_sam -a DP,DV --gvcf 0,2,5`: the reference-only records collapse into gVCF blocks on the device
+    (bcfgpu_gvcf_blocks) -- byte-identical to the data lines of test/mpileup/mpileup.6.out (test.pl:645)."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    out = subprocess.run([SAM_EXE, "-a", "DP,DV", "--gvcf", "0,2,5", os.path.join(G, "mpileup.ref.fa"), "17", "100", "600"] +
+                         [os.path.join(G, "mpileup.%d.sam" % i) for i in (1, 2, 3)], check=True, stdout=subprocess.PIPE, text=True).stdout
+    want = [ln.rstrip("\n") for ln in open(os.path.join(G, "mpileup.6.out")) if not ln.startswith("#")]
+    assert out.splitlines() == want and len(want) == 42

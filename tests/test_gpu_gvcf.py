@@ -33,7 +33,7 @@ def synth(n, S, seed, p_var=0.1, p_gap=0.05, p_brk=0.05, n_rid=2, depth=6):
     step = np.where(rng.random(n) < p_gap, rng.integers(2, 50, n), 1)
     pos = np.cumsum(step).astype(np.int32)
     rid = np.sort(rng.integers(0, n_rid, n)).astype(np.int32)
-    brk = (rng.random(n) < p_brk).astype(np.uint8)
+    brk = ((rng.random(n) < p_brk) | ((rng.random(n) < p_brk / 2) << 1)).astype(np.uint8)
     return res, pos, rid, brk
 
 
