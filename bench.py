@@ -41,10 +41,11 @@ def parse():
                                                           ">1 takes the general caller path (BASELINE configs[4] shape)")
     ap.add_argument("--haploid-frac", type=float, default=0.0, help="snp mode: fraction of haploid samples (ploidy array; general caller path)")
     ap.add_argument("--indel-callers", type=int, default=2, help="indel mode: also time this many caller threads, one context each (1: skip)")
-    ap.add_argument("--mode", choices=["snp", "indel", "baq", "pileup"], default="snp",
+    ap.add_argument("--mode", choices=["snp", "indel", "baq", "pileup", "gvcf"], default="snp",
                     help="snp: the headline pipeline (default).  indel: bcf_call_gap_prep on synthetic indel-candidate columns "
                          "(BASELINE configs[2] shape, 500 samples), reports DP cells/s of the realignment kernel.  "
-                         "baq: bcfgpu_baq (sam_prob_realn) over the reads of the same synthetic columns")
+                         "baq: bcfgpu_baq (sam_prob_realn) over the reads of the same synthetic columns.  "
+                         "gvcf: bcfgpu_gvcf_blocks (gvcf_write) over the mpileup-stage planes of a tile resident in HBM")
     return ap.parse_args()
 
 
@@ -247,6 +248,75 @@ def main_baq(a):
     ctx.close()
 
 
+def main_gvcf(a):
+    """Secondary measurement: the gVCF block merging of `mpileup --gvcf` over one tile's planes in HBM."""
+    import torch
+    from bcftools_amd import abi, engine, host
+    from bcftools_amd.lib import check
+    from tests.helpers import orc
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    n, S = (32768 if a.sites is None else a.sites), a.samples
+    rng = np.random.default_rng(a.seed)
+    res = host.MplpResult(n, S)
+    var = rng.random(n) < a.var_rate                                  # variant sites keep their records
+    res.site["n_alleles"] = np.where(var, 3, 2)
+    res.site["unseen"] = res.site["n_alleles"] - 1
+    # per-sample depth: Poisson around a slowly drifting coverage, so that the smallest DP of a site crosses the limits
+    cov = np.clip(a.depth + np.cumsum(rng.normal(0, 0.5, n)), 4, 200)
+    tot = np.minimum(rng.poisson(cov[:, None], (n, S)), 255)
+    fwd = rng.binomial(tot, 0.5)
+    res.dp4[:, 0, :], res.dp4[:, 1, :] = fwd, tot - fwd
+    res.pl[:, 1, :] = np.minimum(3 * tot, 255)
+    res.pl[:, 2, :] = np.minimum(20 * tot + rng.integers(0, 40, (n, S)), 255)
+    pos = np.arange(n, dtype=np.int32)
+    ranges = np.array([1, 5, 10, 15, 20, 25, 30, 40, 60], dtype=np.int32)     # a typical --gvcf list
+    ctx = engine.Context(abi.default_cfg(S))
+    d = {k: ctx.to_device(v) for k, v in (("pos", pos), ("site", res.site), ("pl", res.pl), ("dp4", res.dp4))}
+    o = {k: ctx.buf(b) for k, b in (("blk", n * 4), ("min_dp", n * 4), ("block", n * 24), ("dp", n * S * 4), ("pl", n * 3 * S))}
+    gi, go, nb = abi.GvcfIn(), abi.GvcfOut(), C.c_int32(0)
+    gi.n_sites, gi.n_range, gi.dp_range = n, len(ranges), ranges.ctypes.data
+    gi.pos, gi.site, gi.pl, gi.dp4 = d["pos"].ptr, d["site"].ptr, d["pl"].ptr, d["dp4"].ptr
+    go.blk, go.min_dp, go.block, go.dp, go.pl = (o[k].ptr for k in ("blk", "min_dp", "block", "dp", "pl"))
+
+    def run():
+        t0 = time.perf_counter()
+        check(ctx.L.bcfgpu_gvcf_blocks(ctx.h, C.byref(gi), C.byref(go), C.byref(nb)))
+        ctx.sync()
+        return time.perf_counter() - t0
+    for _ in range(max(1, a.warmup)):
+        run()
+    ts = [run() for _ in range(max(1, a.steps))]
+    t = sum(ts) / len(ts)
+    in_blocks = None
+    blk = np.zeros(n, np.int32)
+    o["blk"].download(blk)
+    in_blocks = int((blk >= 0).sum())
+    # algorithmic bytes: FORMAT/DP of every cell once for the range (4 B), DP and PL[1], PL[2] of the cells inside blocks once
+    # for the reduction (6 B), the block's DP and PL out
+    alg = n * S * 4 + in_blocks * S * 6 + nb.value * S * 8
+    out = {"metric": "sites/sec through gvcf_write (gVCF block merging)", "value": n / t, "unit": "sites/s", "n_gpus": 1,
+           "steps": len(ts), "warmup": a.warmup, "ms_per_step": t * 1e3, "higher_is_better": True, "dtype": "u8/int32", "data": "synthetic",
+           "config": {"workload": "%d sites x %d samples, %.0fx, planes of the mpileup stage resident in HBM, --gvcf %s"
+                                  % (n, S, a.depth, ",".join(map(str, ranges))), "blocks": nb.value, "sites_in_blocks": in_blocks},
+           "roofline": {"bound": "hbm", "achieved": alg / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / t / 8e12, "traffic": None},
+           "note": "whole call incl. the host synchronisation for the block count (4 kernels + a hipcub scan)"}
+    if a.cpu_seconds > 0:
+        m = min(n, 4096)
+        sub = host.MplpResult(m, S)
+        sub.site[:], sub.pl[:], sub.dp4[:] = res.site[:m], res.pl[:m], res.dp4[:m]
+        t0 = time.perf_counter()
+        want = orc.gvcf_blocks(sub, pos[:m], ranges)
+        tc = time.perf_counter() - t0
+        got = ctx.gvcf_blocks(sub, pos[:m], ranges)
+        assert got.n_blocks == want.n_blocks and np.array_equal(got.blk, want.blk) and np.array_equal(got.dp, want.dp) and np.array_equal(got.pl, want.pl)
+        out["cpu_baseline"] = {"value": m / tc, "unit": "sites/s", "cores": 1, "kind": "port",
+                               "sample": "first %d sites, oracle/gvcf.c on one host core incl. the widening of the planes to int32 "
+                                         "(results compared with the device path)" % m}
+    print(json.dumps(out), flush=True)
+    ctx.close()
+
+
 def main_pileup(a):
     """Secondary measurement (the pileup engine): bcfgpu_pileup builds the tile in HBM from a pool of reads
     (host pointers: the pool crosses PCIe, the tile does not), then the pipeline runs on it."""
@@ -351,6 +421,8 @@ def main():
         return main_indel(a)
     if a.mode == "baq":
         return main_baq(a)
+    if a.mode == "gvcf":
+        return main_gvcf(a)
     import torch
     import torch.distributed as dist
     from bcftools_amd import abi, synth, engine, shard
