@@ -433,7 +433,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL, one rank per GPU.  BCFGPU_BENCH_REHEARSE=1: a dry run of the N>1 code path on a box with fewer GPUs than
+        # ranks (gloo, ranks share the devices) -- its number means nothing and the JSON line says so
+        rehearse = os.environ.get("BCFGPU_BENCH_REHEARSE") == "1"
+        dist.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world)
+        if rehearse:
+            local %= max(1, torch.cuda.device_count())
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -528,6 +533,8 @@ def main():
             "value": value, "unit": "sites/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/i32 + f64 likelihood sums", "data": "synthetic",
+            **({"rehearsal": "BCFGPU_BENCH_REHEARSE=1: gloo, ranks share devices -- not a measurement"}
+               if world > 1 and os.environ.get("BCFGPU_BENCH_REHEARSE") == "1" else {}),
             "config": {"workload": "1000-sample 30x synthetic WGS tile (BASELINE configs[3] shape), SNP path: "
                                    "glfgen+errmod -> combine -> call -m, inputs resident in HBM",
                        "samples": S, "depth": a.depth, "sites_per_step_per_gpu": T, "reads_per_tile": R,
