@@ -328,10 +328,10 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     // one workgroup = 256 consecutive cells = at most (255/S)+2 sites
     const int slots = 255 / S + 2;
     g.hist_slots = slots <= 8 ? slots : 0;
-    // LDS budget: three workgroups per CU (160 KiB) -> 53 KiB each
+    // LDS budget: three workgroups per CU.  160 KiB are handed out in 128 blocks of 1280 bytes: 42 blocks each
     {
         int cap = 8000;
-        while (cap > 2048 && glfgen_lds_bytes(cap, g.hist_slots) > 53 * 1024) cap -= 16;
+        while (cap > 2048 && glfgen_lds_bytes(cap, g.hist_slots) + 16 > 42 * 1280) cap -= 16;
         g.lds_cap = cap;
     }
     g.n_reads = (uint32_t)tile->n_reads;
