@@ -142,7 +142,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
             (rc = dev_alloc(c, (void**)&c->cr.p15, ncells * 15 * sizeof(float))) ||
             (rc = dev_alloc(c, (void**)&c->cr.qs64, ncells * 8)) ||
             (rc = dev_alloc(c, (void**)&c->cr.adf, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->cr.adr, ncells * 4)) ||
-            (rc = dev_alloc(c, (void**)&c->cr.cnt4, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->d_site_sums, (size_t)cfg->max_sites * 12 * 8)) ||
+            (rc = dev_alloc(c, (void**)&c->cr.cnt4, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->d_site_sums, (size_t)cfg->max_sites * SITE_NSUM * 8)) ||
             (rc = dev_alloc(c, (void**)&c->cr.misc, ncells * 4))) {
             bcfgpu_destroy(c); return rc;
         }
@@ -314,7 +314,8 @@ static int check_tile(bcfgpu_ctx *c, const bcfgpu_tile *t)
     if (t->n_sites && (!t->plp_off || (!t->is_indel && !t->ref16) || (t->n_reads && (!t->rd || !t->epos))))
         return set_err(BCFGPU_E_ARG, "tile: NULL array");
     if (t->is_indel && t->n_reads && !t->aux) return set_err(BCFGPU_E_ARG, "indel tile without aux");
-    if (((uintptr_t)t->rd & 15) || ((uintptr_t)t->epos & 15)) return set_err(BCFGPU_E_ARG, "tile: rd/epos must be 16-byte aligned");
+    if (((uintptr_t)t->rd & 15) || ((uintptr_t)t->epos & 15) || (t->is_indel && ((uintptr_t)t->aux & 15)))
+        return set_err(BCFGPU_E_ARG, "tile: rd/epos/aux must be 16-byte aligned");
     if (t->n_reads >> 32) return set_err(BCFGPU_E_RANGE, "tile: more than 2^32-1 reads");
     return 0;
 }
@@ -328,21 +329,30 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     // one workgroup = 256 consecutive cells = at most (255/S)+2 sites
     const int slots = 255 / S + 2;
     g.hist_slots = slots <= 8 ? slots : 0;
-    // LDS budget: three workgroups per CU.  160 KiB are handed out in 128 blocks of 1280 bytes: 42 blocks each
+    // LDS: two bytes per read of the workgroup's span.  Sized from the tile's mean depth (+15 % and a constant for the
+    // spread of a 256-cell sum) so that shallow tiles leave room for more workgroups per CU; at most what lets four
+    // workgroups share a CU (160 KiB are handed out in 128 blocks of 1280 bytes: 32 blocks each).  A span that does not
+    // fit is worked off in several rounds.
     {
-        int cap = 8000;
-        while (cap > 2048 && glfgen_lds_bytes(cap, g.hist_slots) + 16 > 42 * 1280) cap -= 16;
-        g.lds_cap = cap;
+        const double mean = (double)tile->n_reads / ((double)tile->n_sites * S);
+        long want = (long)(mean * 256 * 1.15) + 768;
+        want = (want + 15) & ~15L;
+        int cap = 16384;
+        while (cap > 2048 && glfgen_lds_bytes(cap, g.hist_slots) + 16 > 32 * 1280) cap -= 16;
+        if (want < 2048) want = 2048;
+        g.lds_cap = want < cap ? (int)want : cap;
     }
     g.n_reads = (uint32_t)tile->n_reads;
+#ifdef BCFGPU_DIAG
     { const char *ab = getenv("BCFGPU_ABLATE"); g.ablate = ab ? atoi(ab) : 0; }
+#endif
     g.ref16 = tile->ref16; g.off = tile->plp_off; g.rd = tile->rd; g.epos = tile->epos; g.aux = tile->aux;
     g.fk = c->d_fk; g.beta = c->d_beta; g.lhet = c->d_lhet;
     g.cr = c->cr;
     // the callret planes are addressed with ncells of *this* tile
     g.hist = c->d_hist; g.err = c->d_err; g.site_sums = c->d_site_sums;
     HIPCHK(hipMemsetAsync(c->d_hist, 0, (size_t)tile->n_sites * H_SIZE * sizeof(int), c->stream));
-    HIPCHK(hipMemsetAsync(c->d_site_sums, 0, (size_t)tile->n_sites * 12 * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_site_sums, 0, (size_t)tile->n_sites * SITE_NSUM * 8, c->stream));
     hipEvent_t *ev = c->timing ? seq_events(c) : nullptr;
     if (ev) hipEventRecord(ev[0], c->stream);
     launch_glfgen(g, c->stream);
@@ -350,7 +360,9 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     CombineParams k{};
     k.n_sites = tile->n_sites; k.n_smpl = S; k.is_indel = tile->is_indel; k.fmt_flag = c->cfg.fmt_flag;
     k.ref16 = tile->ref16; k.cr = c->cr; k.hist = c->d_hist; k.site_sums = c->d_site_sums; k.mw = c->d_mw; k.out = *out;
+#ifdef BCFGPU_DIAG
     { const char *ab = getenv("BCFGPU_ABLATE"); k.ablate = ab ? atoi(ab) : 0; }
+#endif
     launch_combine(k, c->stream);
     if (ev) hipEventRecord(ev[2], c->stream);
     HIPCHK(hipGetLastError());
@@ -399,7 +411,9 @@ int bcfgpu_mcall(bcfgpu_ctx *c, const bcfgpu_call_in *in, const bcfgpu_call_out 
     m.ploidy = in->ploidy; m.grp = c->cfg.n_grp > 1 ? in->grp : nullptr; m.prior_an = in->prior_an; m.prior_ac = in->prior_ac; m.i16 = in->i16;
     m.out = *out; m.out_n_gt_max = in->n_gt_max;
     if (c->timing == 1) hipEventRecord(c->ev[2], c->stream);
+#ifdef BCFGPU_DIAG
     { const char *ab = getenv("BCFGPU_ABLATE"); m.ablate = ab ? atoi(ab) : 0; }
+#endif
     launch_mcall(m, c->stream);
     if (c->timing == 1) { hipEventRecord(c->ev[3], c->stream); hipEventSynchronize(c->ev[3]);
         bcfgpu_timing t{}; hipEventElapsedTime(&t.mcall_ms, c->ev[2], c->ev[3]); t.total_ms = t.mcall_ms; c->last = t; }
@@ -430,7 +444,9 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
     if (c->cfg.n_grp > 1 && !c->cfg.grp_tag_is_qs) { m.ad_u8 = mout->adf; m.ad_u8b = mout->adr; }   // FORMAT/AD = ADF+ADR (bam2bcf.c:892-896)
     m.ploidy = ploidy; m.grp = c->cfg.n_grp > 1 ? grp : nullptr;
     m.out = *cout; m.out_n_gt_max = BCFGPU_MAX_PL;
+#ifdef BCFGPU_DIAG
     { const char *ab = getenv("BCFGPU_ABLATE"); m.ablate = ab ? atoi(ab) : 0; }
+#endif
     launch_mcall(m, c->stream);
     if (c->timing == 1) hipEventRecord(c->ev[3], c->stream);
     else if (c->timing == 2) { hipEventRecord(c->pool[c->pool.size() - 1], c->stream); c->pool_call.back() = 1; }
@@ -493,7 +509,9 @@ int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnPools> &
     }
     p.ref2 = (const uint8_t*)d_ref2; p.query = (const uint8_t*)d_q; p.qq = (const uint8_t*)d_qq; p.zq = (const uint8_t*)d_zq;
     p.q2p = c->d_q2p; p.scratch = (double*)d_scr;
+#ifdef BCFGPU_DIAG
     { const char *ab = getenv("BCFGPU_ABLATE"); p.force_scratch = ab && (atoi(ab) & 256) ? 1 : 0; }
+#endif
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, c->stream);

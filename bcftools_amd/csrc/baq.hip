@@ -495,7 +495,11 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
     // (long indels), run separately with both matrices in scratch and their own row width
     auto eff_bw = [](const BaqJob &j) { int b = j.l_ref > j.l_query ? j.l_ref : j.l_query; if (b > j.bw) b = j.bw;
                                         if (b < std::abs(j.l_ref - j.l_query)) b = std::abs(j.l_ref - j.l_query); return b; };
+#ifdef BCFGPU_DIAG
     const bool force_scratch = [] { const char *ab = getenv("BCFGPU_ABLATE"); return ab && (atoi(ab) & 512); }();
+#else
+    const bool force_scratch = false;
+#endif
     std::vector<BaqJob> cls[2];
     int cls_bw[2] = {1, 1};
     for (const BaqJob &j : jobs) {

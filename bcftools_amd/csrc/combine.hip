@@ -258,7 +258,7 @@ __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTota
         for (int v = 0; v < V; ++v) s_min[i + v] = (double)mn[v];        // widened here, by all lanes, for the sequential sum
         uint32_t cnt4[V], adf[V], adr[V], misc[V];
         load_v<V>(P.cr.cnt4 + cell, cnt4); load_v<V>(P.cr.adf + cell, adf); load_v<V>(P.cr.adr + cell, adr); load_v<V>(P.cr.misc + cell, misc);
-        if (NAL > 0 && !(P.ablate & 512)) {
+        if (NAL > 0 && !BCFGPU_ABL(P, 512)) {
             uint8_t *DP4 = P.out.dp4 + (size_t)is * 4 * Ss + s;
             uint32_t b[V];
             #pragma unroll
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             s_frt[i] = f.x; s_frt[HC + i] = f.y; s_frt[2 * HC + i] = f.z; s_frt[3 * HC + i] = f.w;
         }
         __syncthreads();
-        if (tid < 4 && !(P.ablate & 8192)) myq = seq_sum_f32(myq, s_frt + tid * HC, cn);
+        if (tid < 4 && !BCFGPU_ABL(P, 8192)) myq = seq_sum_f32(myq, s_frt + tid * HC, cn);
     }
     if (tid < 4) s_q[tid] = myq;
     __syncthreads();
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     for (int base = 0; base < S; base += CHUNK) {
         const int cn = min(CHUNK, S - base);
         __syncthreads();
-        const bool live = !dead && !(P.ablate & 256);
+        const bool live = !dead && !BCFGPU_ABL(P, 256);
         #define PLANES(V_) switch (live ? nal : 0) { \
             case 1: sample_planes<1, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; \
             case 2: sample_planes<2, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; \
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         PLANES(V)
         #undef PLANES
         __syncthreads();
-        if (tid == 0 && !dead && !(P.ablate & 8192)) sh.sum_min = seq_sum_f64(sh.sum_min, s_min, cn);   // bam2bcf.c:642
+        if (tid == 0 && !dead && !BCFGPU_ABL(P, 8192)) sh.sum_min = seq_sum_f64(sh.sum_min, s_min, cn);   // bam2bcf.c:642
     }
     // FMT/SP (bam2bcf.c:867-885): a Fisher exact test per sample, in its own pass -- its loops over the table's margins
     // diverge between lanes, and only samples with at least two reads in every margin enter them
@@ -436,14 +436,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         v = wave_sum_u64((unsigned long long)t_mq0); if (lane == 0 && v) atomicAdd(&sh.tot[12], v);
         #pragma unroll
         for (int j = 0; j < 4; ++j) { v = wave_sum_u64((unsigned long long)t_cnt[j]); if (lane == 0 && v) atomicAdd(&sh.tot[13 + j], v); }
-        if (tid < 12) sh.tot[17 + tid] = P.site_sums[(size_t)is * 12 + tid];
+        if (tid < 12) sh.tot[17 + tid] = P.site_sums[(size_t)is * SITE_NSUM + tid];
+        if (tid == 12) sh.tot[29] = P.site_sums[(size_t)is * SITE_NSUM + 12];     // ori_depth and mq0 come as site totals
+        if (tid == 13) sh.tot[30] = P.site_sums[(size_t)is * SITE_NSUM + 13];
     }
     __syncthreads();
 
     // ---- calc_SegBias (bam2bcf.c:494-530): tree-reduced sum of per-sample terms ----
     const double an0 = (double)sh.tot[13], an1 = (double)sh.tot[14], an2 = (double)sh.tot[15], an3 = (double)sh.tot[16];
     const int nr = (int)(an2 + an3);
-    if (nr && !dead && !(P.ablate & 2048)) {
+    if (nr && !dead && !BCFGPU_ABL(P, 2048)) {
         const int avg_dp = (int)((an0 + an1 + nr) / S);
         double M = floor((double)nr / avg_dp + 0.5);
         if (M > S) M = S;
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         for (int i = tid; i < H_SIZE; i += WG) s_h[i] = h[i];
     }
     __syncthreads();
-    if (!dead && !(P.ablate & 4096)) {
+    if (!dead && !BCFGPU_ABL(P, 4096)) {
         const int *h = s_h;
         // the four Mann-Whitney tests: bin sums by the whole wavefront, the closed forms in lanes 1..4; lane 0 the VDB
         int na_t = 0, nb_t = 0; double U_t = 0;
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         } else {
             site->shift = (int)(sh.sum_min + .499);
             site->depth = (uint32_t)(sh.tot[13] + sh.tot[14] + sh.tot[15] + sh.tot[16]);
-            site->ori_depth = (uint32_t)sh.tot[11]; site->mq0 = (uint32_t)sh.tot[12];
+            site->ori_depth = (uint32_t)(sh.tot[11] + sh.tot[29]); site->mq0 = (uint32_t)(sh.tot[12] + sh.tot[30]);
             site->scr_tot = (int)sh.tot[10];
             for (int i = 0; i < 5; ++i) { site->adf_tot[i] = (int)sh.tot[i]; site->adr_tot[i] = (int)sh.tot[5 + i]; }
             for (int i = 0; i < 4; ++i) site->anno[i] = (double)sh.tot[13 + i];
@@ -541,7 +543,7 @@ void launch_combine(const CombineParams &p, hipStream_t s)
     CombineParams q = p;
     // four samples per lane need every site's row of every plane to start on a 16-byte (u8 planes: 4-byte) boundary
     auto al = [](const void *ptr, uintptr_t a) { return ptr == nullptr || reinterpret_cast<uintptr_t>(ptr) % a == 0; };
-    q.vec4 = (p.n_smpl % 4 == 0) && !(p.ablate & 1024) &&
+    q.vec4 = (p.n_smpl % 4 == 0) && !BCFGPU_ABL(p, 1024) &&
              al(p.cr.p15, 16) && al(p.cr.cnt4, 16) && al(p.cr.adf, 16) && al(p.cr.adr, 16) && al(p.cr.misc, 16) && al(p.cr.qs64, 8) &&
              al(p.out.pl, 4) && al(p.out.dp4, 4) && al(p.out.scr, 4) && al(p.out.adf, 4) && al(p.out.adr, 4) && al(p.out.qs, 8);
     if (q.vec4) hipLaunchKernelGGL(combine_kernel<4>, dim3(q.n_sites), dim3(WG), 0, s, q);

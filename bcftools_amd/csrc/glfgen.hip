@@ -2,28 +2,25 @@
 //
 // Replaces bam2bcf.c:147-258 and the errmod_cal() it calls (htslib errmod.c).
 //
-// Mapping: one lane per (site,sample) cell, 256 consecutive cells per workgroup.  A lane
-// replays the reference's per-read loop over its own reads, so every order-sensitive
-// accumulation (the double sums bsum[] of errmod_cal, the float sums of its epilogue)
-// happens in the reference's order and the results are bit-identical to the CPU path.
+// A workgroup owns 256 consecutive (site,sample) cells, whose reads are one contiguous span of the `rd`/`epos`
+// arrays (CSR order).  The work of bcf_call_glfgen's per-read loop splits by what it feeds:
 //
-// Data movement: the reads of the workgroup's 256 cells are one contiguous span of the
-// `rd`/`epos` arrays (CSR order).  The span is staged into LDS with coalesced 16-byte loads and
-// every lane then walks its own slice in LDS; HBM sees each input byte exactly once.
+//   phase A, one lane per READ (read-parallel, every lane busy whatever the depths of the cells):
+//     the span is read straight from HBM, four consecutive reads per lane and trip (one 16-byte load of `rd`, one
+//     4-byte load of `epos`), each input byte exactly once.  Per read: the filters (bam2bcf.c:173-194), the quality
+//     arithmetic (:196-203), and everything that only feeds SITE totals -- the I16 sums anno[4..15] (:221-226),
+//     ori_depth, mq0 and the bias-test histograms (:228-252) -- which therefore never needs to know the read's cell:
+//     per-lane partial sums, one reduction per workgroup and site.  What the cell needs of the read is 11 bits, left in
+//     LDS as a u16 key at the read's position in the span:  strand | q<<1 | base<<7 | softclip<<10  (0 = read rejected).
+//   phase B, one lane per CELL: the lane walks its own slice of keys: per-base counts, QS, ADF/ADR, DP4 counts and
+//     errmod_cal, whose order-sensitive double sums are replayed in the reference's order (bit-identical results).
 //
-// errmod_cal() sorts the n 16-bit codes and walks them from the largest down.  Only the
-// relative order of codes with the same base matters (per-base accumulators), and within a
-// base the code order is the order of key7 = q<<1|strand.  The sort is therefore replaced by
-// a per-base counting pass over the 128 possible key7 values (u8 counters in LDS, one column
-// per lane, conflict-free) and a descending walk over the set bits of the lane's 128-bit
-// key-presence mask (a key-major variant that iterates the wave's union of keys was measured
-// slower: random mapQ values make the union ~10x larger than a lane's own key set).
-// Reads carrying the site's reference base -- almost all of them -- are counted directly in
-// the per-read loop; the others (exactly the "diff" reads of the I16 annotations) are kept, in
-// place, in the lane's LDS slice as a packed word and handled by a second, short loop.
+// LDS holds 2 bytes per read instead of the 5 of the raw tile, which is what lets four to five workgroups share a CU.
 //
-// Site-wide bias histograms (bam2bcf.c:228-252) are integer counts: hot bins (mapQ>=59) are
-// counted in registers, the rest with LDS atomics; one flush of global atomics per workgroup.
+// errmod_cal() sorts the n 16-bit codes and walks them from the largest down.  Only the relative order of codes with
+// the same base matters (per-base accumulators), and within a base the code order is the order of key7 = q<<1|strand.
+// The sort is therefore replaced by a counting pass into rank-ordered u8 slots (rank of a quality = popcount of the
+// lane's quality mask above it) and a descending walk over the slots.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "kernels.h"
@@ -35,17 +32,18 @@ namespace bcfgpu {
 #define CAP_DIST 25
 
 // seq_nt16_int packed in nibbles: {4,0,1,4,2,4,4,4,3,4,4,4,4,4,4,4}
-__device__ __forceinline__ int nt16_int(int c) { return (int)((0x4444444344424104ull >> (4 * (c & 15))) & 7); }
+#define NT16_INT_TBL 0x4444444344424104ull
+__device__ __forceinline__ int nt16_int(int c) { return (int)((NT16_INT_TBL >> (4 * (c & 15))) & 7); }
 __device__ __forceinline__ int tri(int j, int k) { return k * (k + 1) / 2 + j; }   // j<=k
 
-__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
     #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 
-// LDS layout (bytes): fk[264] f64 | slots[4][WG] u32 | rd[cap+4] u32 | epos[cap+32] u8 | hist | site totals
+// LDS layout (bytes): fk[264] f64 | slots[NSLOT/4][WG] u32 | hist [slots][H_SIZE] i32 | site totals [slots][SITE_NSUM] u64 | keys u16[cap+8]
 #define LDS_FK   0
 #define LDS_CNT  2112
 #define NSLOT    16
@@ -55,11 +53,15 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 #ifndef WSTEP
 #define WSTEP    3         // reads of one (quality, strand) run taken per step of the errmod walk
 #endif
-#define LDS_RD   (LDS_CNT + (NSLOT / 4) * WG * 4)
+#define LDS_HIST_OFF (LDS_CNT + (NSLOT / 4) * WG * 4)
+#define NPART 12           // per-lane partial sums of phase A: the I16 site totals anno[4..15]
 
-// packed "other" (non-primary = diff) read: baseQ:8 | mapQ(capped):6 | q:6 | b:4 | rev:1 | min_dist:5
-#define OW_PACK(baseQ, mapQ, q, b, rev, md) \
-    ((uint32_t)(baseQ) | (uint32_t)(mapQ) << 8 | (uint32_t)(q) << 14 | (uint32_t)(b) << 20 | (uint32_t)(rev) << 24 | (uint32_t)(md) << 25)
+// the u16 key phase A leaves for phase B
+#define KEY_PACK(rev, q, b, sc) ((uint32_t)(rev) | (uint32_t)(q) << 1 | (uint32_t)(b) << 7 | (uint32_t)(sc) << 10)
+#define KEY_REV(k)  ((k) & 1u)
+#define KEY_Q(k)    (((k) >> 1) & 63u)
+#define KEY_B(k)    (((k) >> 7) & 7u)
+#define KEY_SC(k)   (((k) >> 10) & 1u)
 
 // Counts, as u8 in the lane's slot column, of the reads with the NSLOT/2 highest qualities of the mask `qm` (bit q = some
 // read of this base has quality q): slot 2*rank(q) holds the reverse-strand reads of q, slot 2*rank(q)+1 the forward
@@ -89,358 +91,413 @@ __device__ __forceinline__ void fill_slots(uint32_t *s_slot, uint64_t qm, int ti
 
 // Descending walk of errmod_cal for one base: every lane steps through its own reads from the highest (quality,
 // strand) key down.  errmod_cal sorts the codes; here the lane's qualities are the set bits of a 64-bit mask and the
-// number of reads per (quality, strand) sits in NSLOT rank-ordered u8 slots (a 128-entry table per lane would cost a
-// third of the occupancy).  A small state machine: when the reads of the current key are used up, move to the next
-// slot, taking the next set bit at every other step; a lane with more than NSLOT/2 distinct qualities refills its
-// slots from the source for the remaining ones (binned base qualities give a handful).  `n` selects the beta row of
-// the lane, `left` is the number of reads of this base.
-// The state machine runs one step (one or two reads of a run) ahead of the summation: the beta values (gathers from a
-// 32 MB table, L2 latency) and the fk factors (LDS) of the next step are requested before the current ones are added,
-// in the reference's order.
+// number of reads per (quality, strand) sits in NSLOT rank-ordered u8 slots.  The control flow is uniform over the
+// wavefront: rank by rank (a lane's r-th highest quality, whatever its value), the reverse-strand run and then the
+// forward-strand run of that quality, each run in chunks of WCH reads.  A read of a run adds
+// fk[reads of its strand so far] * beta[q][reads of the base so far][n] to the double sum, in the reference's order; lanes
+// whose run is shorter than the chunk add fk = +0 times a finite table entry, which leaves their (non-negative) sum as it
+// is, so the sums stay bit-identical while no lane branches.  A lane with more than NSLOT/2 distinct qualities gets its
+// slots refilled for the remaining ones (binned base qualities give a handful).
+// `brow`: byte offset of beta[0][0][n] (stored q, k, n: tables.cpp; the q = 0 row is all zeros).
+#ifndef WCH
+#define WCH 4
+#endif
 template <class Src>
-__device__ __forceinline__ double walk_keys(uint32_t *s_slot, uint64_t qm, const double *s_fk,
-                                            const double *beta, int tid, int n, int left, Src src, int nsrc)
+__device__ __forceinline__ double walk_ranks(uint32_t *s_slot, uint64_t qm, const double *s_fk, const char *bbase, int tid,
+                                             uint32_t brow, Src src, int nsrc, uint32_t &rev_out, uint32_t &qs_out)
 {
-    fill_slots<true>(s_slot, qm, tid, src, nsrc);
-    int rem = 0, pend = 0, pleft = left, r = 0;              // r: next slot pair (= rank of the next quality)
-    uint32_t rev = 0, cc = 0, w0 = 0, w1 = 0;
-    const char *bbase = reinterpret_cast<const char*>(beta);
-    const uint32_t brow = (uint32_t)n << 3;                   // byte offset of beta[0][0][n] (stored q, k, n: tables.cpp); 32 MiB
-    uint32_t boff = brow;
     double bs = 0;
-    // Loads are issued unconditionally (inactive lanes read a valid dummy) and their results never cross a divergent
-    // join, so that three gathers stay in flight; the (divergent) state update carries no memory results.
-    #define SLOT_PAIR(i) (s_slot[(((i) & (NSLOT / 2 - 1)) >> 1) * WG + tid])      /* the dword holding pair i */
-    uint32_t two_nx = SLOT_PAIR(0);
-    #define WALK_PRODUCE(B, F, N) do { \
-        if (pleft > 0 && rem == 0) { \
-            if (pend > 0) { rev = 0; rem = pend; pend = 0; }         /* the forward-strand reads of the same quality */ \
-            else { \
-                if (r == NSLOT / 2) { fill_slots<false>(s_slot, qm, tid, src, nsrc); r = 0; two_nx = SLOT_PAIR(0); } \
-                const int curq = 63 - __clzll((long long)(qm | 1ull)); \
-                qm &= ~(1ull << curq); \
-                const uint32_t two = (two_nx >> (16 * (r & 1))) & 0xffffu; \
-                ++r; \
-                const int cr = (int)(two & 0xff), cf = (int)(two >> 8); \
-                rev = cr ? 1u : 0u; rem = cr ? cr : cf; pend = cr ? cf : 0; \
-                if (rem == 0) rem = pleft;                           /* cannot happen: counts and mask agree */ \
-                boff = brow + ((uint32_t)curq << 19); \
-            } \
-        } \
-        two_nx = SLOT_PAIR(r);                                       /* for the next advance */ \
-        { \
-            /* one step takes the next read and, inside a run of equal (quality, strand), up to WSTEP - 1 more */ \
-            const uint32_t na_ = pleft > 0 ? (uint32_t)min(rem, WSTEP) : 0u; \
-            const uint32_t o0 = boff + (cc << 11); \
-            const uint32_t wi = rev ? w1 : w0; \
-            _Pragma("unroll") \
-            for (int k_ = 0; k_ < WSTEP; ++k_) { \
-                const bool a_ = (uint32_t)k_ < na_; \
-                B[k_] = *reinterpret_cast<const double*>(bbase + (a_ ? o0 + ((uint32_t)k_ << 11) : boff)); \
-                F[k_] = s_fk[a_ ? wi + (uint32_t)k_ : 0u]; \
-            } \
-            N = na_; \
-            cc += na_; w1 += rev ? na_ : 0u; w0 += rev ? 0u : na_; rem -= (int)na_; pleft -= (int)na_; \
-        } } while (0)
-    #define WALK_CONSUME(B, F, N) do { \
-        _Pragma("unroll") \
-        for (int k_ = 0; k_ < WSTEP; ++k_) { const double t_ = F[k_] * B[k_]; bs = (uint32_t)k_ < N ? bs + t_ : bs; } \
-        left -= (int)N; } while (0)
-    double bx[WSTEP], fx[WSTEP], by[WSTEP], fy[WSTEP];
-    uint32_t nx, ny;
-    WALK_PRODUCE(bx, fx, nx);
-    while (__any(left > 0)) {
-        WALK_PRODUCE(by, fy, ny); WALK_CONSUME(bx, fx, nx);
-        WALK_PRODUCE(bx, fx, nx); WALK_CONSUME(by, fy, ny);
+    uint32_t cc = 0, w0 = 0, w1 = 0, qs = 0;
+    bool first = true;
+    while (__any(qm != 0)) {
+        if (first) fill_slots<true>(s_slot, qm, tid, src, nsrc); else fill_slots<false>(s_slot, qm, tid, src, nsrc);
+        first = false;
+        for (int r = 0; r < NSLOT / 2 && __any(qm != 0); ++r) {
+            const int curq = 63 - __clzll((long long)(qm | 1ull));          // a lane that has run out of qualities: 0, with empty slots
+            qm &= ~(1ull << curq);
+            const uint32_t two = (s_slot[(r >> 1) * WG + tid] >> (16 * (r & 1))) & 0xffffu;
+            const uint32_t cr = two & 0xff, cf = two >> 8;
+            qs += (uint32_t)curq * (cr + cf);
+            uint32_t bo = brow + ((uint32_t)curq << 19) + (cc << 11);
+            #pragma unroll 1
+            for (int sd = 0; sd < 2; ++sd) {                                 // reverse strand first: the larger code
+                const uint32_t m = sd ? cf : cr, w = sd ? w0 : w1;
+                for (uint32_t t0 = 0; __any(t0 < m); t0 += WCH) {
+                    double bv[WCH], fv[WCH];
+                    #pragma unroll
+                    for (int j = 0; j < WCH; ++j) {
+                        const bool a = t0 + j < m;
+                        bv[j] = *reinterpret_cast<const double*>(bbase + (a ? bo + ((t0 + j) << 11) : brow));
+                        fv[j] = s_fk[a ? w + t0 + j : 256u];
+                    }
+                    #pragma unroll
+                    for (int j = 0; j < WCH; ++j) bs += fv[j] * bv[j];
+                }
+                bo += m << 11;
+            }
+            cc += cr + cf; w1 += cr; w0 += cf;
+        }
     }
-    #undef WALK_PRODUCE
-    #undef WALK_CONSUME
-    #undef SLOT_PAIR
+    rev_out = w1; qs_out = qs;
     return bs;
 }
 
+// per-lane partial sums of phase A (one site segment of one staging round)
+struct ReadSums {
+    uint32_t t_bq, t_bq2, t_mq, t_mq2, t_md, t_md2;    // all accepted reads: baseQ, mapQ, min_dist and their squares
+    uint32_t d_bq, d_bq2, d_mq, d_mq2, d_md, d_md2;    // the "diff" reads among them (is_diff of bam2bcf.c:186,195)
+    __device__ __forceinline__ void clear() { t_bq = t_bq2 = t_mq = t_mq2 = t_md = t_md2 = d_bq = d_bq2 = d_mq = d_mq2 = d_md = d_md2 = 0; }
+};
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+// wave-uniform counts of phase A (ballots: scalar registers)
+struct WaveCounts {
+    uint32_t ori, mq0, ref59, alt59, fwd59, rev59;
+    __device__ __forceinline__ void clear() { ori = mq0 = ref59 = alt59 = fwd59 = rev59 = 0; }
+};
+
 template <bool INDEL, bool LDS_HIST>
-__global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void glfgen_kernel(const GlfgenParams P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int cap = P.lds_cap;
     double   *s_fk  = reinterpret_cast<double*>(smem + LDS_FK);
     uint32_t *s_cnt = reinterpret_cast<uint32_t*>(smem + LDS_CNT);
-    uint32_t *s_rd  = reinterpret_cast<uint32_t*>(smem + LDS_RD);
-    uint8_t  *s_ep  = smem + LDS_RD + ((size_t)cap + 4) * 4;
-    int      *s_hist = reinterpret_cast<int*>(smem + LDS_RD + ((size_t)cap + 4) * 4 + (size_t)cap + 32);
-    unsigned long long *s_tot = reinterpret_cast<unsigned long long*>(s_hist + (size_t)P.hist_slots * H_SIZE);   // [slots][12]
+    int      *s_hist = reinterpret_cast<int*>(smem + LDS_HIST_OFF);
+    unsigned long long *s_tot = reinterpret_cast<unsigned long long*>(s_hist + (size_t)P.hist_slots * H_SIZE);   // [slots][SITE_NSUM]
+    uint32_t *s_part = reinterpret_cast<uint32_t*>(s_tot + (size_t)P.hist_slots * SITE_NSUM);       // [slots][NPART][64]
+    uint16_t *s_key = reinterpret_cast<uint16_t*>(s_part + (size_t)P.hist_slots * NPART * 64);
     __shared__ unsigned int s_next;
 
     const int tid = threadIdx.x;
-    const long ncells = (long)P.n_sites * P.n_smpl;
+    const int S = P.n_smpl;
+    const long ncells = (long)P.n_sites * S;
     const long cell0 = (long)blockIdx.x * WG;
-    const int site0 = (int)(cell0 / P.n_smpl);
+    const long cell_end = min(cell0 + WG, ncells);
+    const int site0 = (int)(cell0 / S);
+    const int site_last = (int)((cell_end - 1) / S);
 
-    const long cell = cell0 + tid;
+    // Phase B's loops run as long as the deepest cell of a wavefront, so the workgroup's cells are dealt to the lanes in
+    // order of depth (a counting sort on reads per cell): a wavefront then holds cells of similar depth.  Results are
+    // written per cell, so which lane computes a cell shows nowhere in the output.
+    __shared__ unsigned int s_bucket[64];
+    __shared__ unsigned short s_perm[WG];
+    if (tid < 64) s_bucket[tid] = 0;
+    __syncthreads();
+    {
+        const long c = cell0 + tid;
+        uint32_t d = 0;
+        if (c < ncells) d = min((P.off[c + 1] - P.off[c]) >> 1, 63u);
+        const uint32_t pos = atomicAdd(&s_bucket[d], 1u);
+        __syncthreads();
+        if (tid < 64) {                                       // exclusive prefix sum of the 64 buckets (one wave)
+            const uint32_t v = s_bucket[tid];
+            uint32_t incl = v;
+            #pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (tid >= o) incl += t; }
+            s_bucket[tid] = incl - v;
+        }
+        __syncthreads();
+        s_perm[s_bucket[d] + pos] = (unsigned short)tid;
+        __syncthreads();
+    }
+    const long cell = cell0 + s_perm[tid];
     const bool active = cell < ncells;
 
     s_fk[tid] = P.fk[tid];
-    if (tid < 8) s_fk[256 + tid] = 0.0;               // read-ahead slack of the walk (never used in a sum)
+    if (tid < 8) s_fk[256 + tid] = 0.0;               // [256]: the factor of a lane that sits a chunk element out
     if (LDS_HIST) {
         for (int i = tid; i < P.hist_slots * H_SIZE; i += WG) s_hist[i] = 0;
-        for (int i = tid; i < P.hist_slots * 12; i += WG) s_tot[i] = 0;
+        for (int i = tid; i < P.hist_slots * SITE_NSUM; i += WG) s_tot[i] = 0;
+        for (int i = tid; i < P.hist_slots * NPART * 64; i += WG) s_part[i] = 0;
     }
 
-    int site = 0, ref_base = -1, ref4 = 4;
+    int site = 0, ref4c = 4;
     uint32_t beg = 0, end = 0;
     if (active) {
-        site = (int)(cell / P.n_smpl);
+        site = (int)(cell / S);
         beg = P.off[cell]; end = P.off[cell + 1];
-        if (!INDEL) { ref_base = P.ref16[site]; ref4 = nt16_int(ref_base); }
+        if (!INDEL) ref4c = nt16_int(P.ref16[site]);
     }
-    const int primary = INDEL ? 0 : ref4;             // the base whose reads are counted on the fly
-    uint32_t prim_nt = 0;                             // SNP: the nt16 codes that show it (code 0 stands for the reference base)
-    if (!INDEL) {
-        #pragma unroll
-        for (int c = 0; c < 16; ++c) if (nt16_int(c ? c : ref_base) == primary) prim_nt |= 1u << c;
-    }
-    int *ghist = P.hist + (long)site * H_SIZE;
-    int *lhist = s_hist + (site - site0) * H_SIZE;
+    const int primary = INDEL ? 0 : ref4c;            // the base most reads of the cell show
     const bool want_epos = (P.fmt_flag & (BCFGPU_INFO_RPB | BCFGPU_INFO_VDB)) != 0;
     const bool want_scr = (P.fmt_flag & (BCFGPU_INFO_SCR | BCFGPU_FMT_SCR)) != 0;
-    const uint32_t span_end = P.off[min(cell0 + WG, ncells)];
+    const uint32_t span_end = P.off[cell_end];
     const uint32_t n_reads_tot = P.n_reads;
-    const int min_baseQ = P.min_baseQ, capQ = P.capQ;
-
-    #define HIST_ADD(idx, v) do { if (LDS_HIST) atomicAdd(&lhist[idx], v); else atomicAdd(&ghist[idx], v); } while (0)
+    const uint32_t min_baseQ = (uint32_t)P.min_baseQ, capQ = (uint32_t)P.capQ;
 
     bool done = !active;
-    if (active && end - beg > (uint32_t)cap) { atomicExch(P.err, BCFGPU_E_DEPTH); done = true; }   // cannot be staged
+    // a cell must fit one staging round whatever its alignment (the window starts at a multiple of 4 reads)
+    if (active && end - beg > (uint32_t)cap - 3u) { atomicExch(P.err, BCFGPU_E_DEPTH); done = true; }
     uint32_t base = P.off[cell0];
 
     for (;;) {
-        // ---- stage [base, lim) of rd/epos into LDS, 16 bytes per lane per load ----
-        const uint32_t abase = base & ~3u;                       // 16-byte aligned start of the u32 stream
-        const uint32_t ebase = base & ~15u;                      // 16-byte aligned start of the u8 stream
+        const uint32_t abase = base & ~3u;                       // key index 0 of this round
         const uint32_t lim = min(abase + (uint32_t)cap, span_end);
-        {
-            // All loads of a batch -- eight 16-byte vectors of rd and two of epos per lane, which covers a whole span at
-            // the usual LDS capacity -- are in flight before the first LDS store: one memory round trip per batch.
-            const uint32_t nvec = (lim - abase + 3) >> 2;
-            const uint32_t nv16 = want_epos ? (lim - ebase + 15) >> 4 : 0;
-            const uint4 *src = reinterpret_cast<const uint4*>(P.rd + abase);
-            const uint4 *es = reinterpret_cast<const uint4*>(P.epos + ebase);
-            uint4 *dst = reinterpret_cast<uint4*>(s_rd);
-            uint4 *ed = reinterpret_cast<uint4*>(s_ep);
-            for (uint32_t v0 = tid, w0 = tid; v0 < nvec || w0 < nv16; v0 += 8 * WG, w0 += 2 * WG) {
-                uint4 r[8], e[2];
-                #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint32_t v = v0 + k * WG;
-                    r[k] = make_uint4(0, 0, 0, 0);
-                    if (v < nvec) {
-                        if (abase + 4 * v + 3 < n_reads_tot) r[k] = src[v];
-                        else {
-                            uint32_t t4[4] = {0, 0, 0, 0};
-                            for (int j = 0; j < 4; ++j) if (abase + 4 * v + j < n_reads_tot) t4[j] = P.rd[abase + 4 * v + j];
-                            r[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-                        }
-                    }
-                }
-                #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const uint32_t v = w0 + k * WG;
-                    e[k] = make_uint4(0, 0, 0, 0);
-                    if (v < nv16) {
-                        if (ebase + 16 * v + 15 < n_reads_tot) e[k] = es[v];
-                        else {
-                            uint32_t t4[4] = {0, 0, 0, 0};
-                            for (int j = 0; j < 16; ++j)
-                                if (ebase + 16 * v + j < n_reads_tot) t4[j >> 2] |= (uint32_t)P.epos[ebase + 16 * v + j] << (8 * (j & 3));
-                            e[k] = make_uint4(t4[0], t4[1], t4[2], t4[3]);
-                        }
-                    }
-                }
-                #pragma unroll
-                for (int k = 0; k < 8; ++k) { const uint32_t v = v0 + k * WG; if (v < nvec) dst[v] = r[k]; }
-                #pragma unroll
-                for (int k = 0; k < 2; ++k) { const uint32_t v = w0 + k * WG; if (v < nv16) ed[v] = e[k]; }
-            }
-        }
         if (tid == 0) s_next = 0xffffffffu;
         __syncthreads();
+        const bool part = !done && beg >= base && end <= lim;    // this lane's cell is handled in this round
+        if (!done && !part) atomicMin(&s_next, beg);             // the first cell left for the next round (deep tiles only)
+        __syncthreads();
+        const uint32_t nb = s_next;
+        const uint32_t rlim = min(nb, lim);                      // reads [base, rlim) belong to this round's cells
 
-        const bool part = !done && beg >= base && end <= lim;    // this lane's slice is resident
-        const uint32_t lbeg = part ? beg - abase : 0;            // slice start in s_rd
-        const uint32_t ebeg = part ? beg - ebase : 0;            // slice start in s_ep
-        const uint32_t cnt_raw = (part && !(P.ablate & 4)) ? end - beg : 0;
-        const bool skip_hist = (P.ablate & 1) != 0;
+        // ================= phase A: one lane per read =================
+        for (int sg = site0; sg <= site_last; ++sg) {            // uniform: the site segments of the workgroup's span
+            const long c_lo = max(cell0, (long)sg * S), c_hi = min(cell_end, (long)(sg + 1) * S);
+            const uint32_t rb = max(P.off[c_lo], base), re = min(P.off[c_hi], rlim);
+            if (rb >= re) continue;
+            const int ref_base = INDEL ? -1 : (int)P.ref16[sg];
+            const uint32_t ref4 = INDEL ? 4u : (uint32_t)nt16_int(ref_base);
+            // nt16 code -> base 0..4 with code 0 ('=') standing for the reference base (bam2bcf.c:189-190)
+            const unsigned long long tbl = (NT16_INT_TBL & ~0xfull) | (unsigned long long)ref4;
+            int *hist = LDS_HIST ? s_hist + (sg - site0) * H_SIZE : P.hist + (long)sg * H_SIZE;
+            ReadSums A; A.clear();
+            WaveCounts C; C.clear();
 
-        // ---- pass 0: the per-read loop of bcf_call_glfgen (bam2bcf.c:170-253) ----
-        uint64_t qmask = 0;          // qualities seen among the reads of the primary base
-        uint32_t qs_prim = 0, prim_rev = 0;   // their quality sum and reverse-strand count
-        uint32_t mq0 = 0, scr = 0, ori_depth = 0, n_rev = 0;
-        uint32_t t_bqmd = 0, t_mq = 0, t_bq2 = 0, t_mq2 = 0, t_md2 = 0;   // totals: baseQ | min_dist<<16, mapQ, squares
-        uint32_t h59 = 0;            // reads with mapQ>=59: ref | alt<<8 | fwd<<16 | rev<<24
-        int n = 0, n_other = 0, n_prim = 0;
-        bool fail = false;
-        // The loop body is written without early exits: one predicate (`ok`) guards a single divergent region, and the
-        // per-base updates are selects, because a wavefront pays for every branch any of its lanes takes.
-        // The next record is fetched while the current one is processed (the in-place writes below stay behind index i;
-        // the read one past the slice stays inside the staged span's slack).
-        uint32_t w_nx = s_rd[lbeg];
-        int ep_nx = want_epos ? s_ep[ebeg] : 0;
-        for (uint32_t i = 0; i < cnt_raw; ++i) {
-            const uint32_t w = w_nx;
-            const int ep = ep_nx;
-            w_nx = s_rd[lbeg + i + 1];
-            if (want_epos) ep_nx = s_ep[ebeg + i + 1];
-            const int nt = (w >> 16) & 15;
-            int q, b, baseQ, seqQ;
-            bool ok;
-            if (INDEL) {
-                const uint32_t ax = P.aux[beg + i];
-                b = (ax >> 16) & 0xf;                 // 0..4 after bcf_call_gap_prep (bam2bcf_indel.c:449-456)
-                baseQ = q = ax & 0xff;
-                if (q < min_baseQ) { b = 0; q = (int)(w & 0xff); }
-                seqQ = (ax >> 8) & 0xff;
-                ok = !(w & BCFGPU_RD_SKIP);
-                ori_depth += ok;
+            // Four consecutive reads of every lane.  Called in wave-uniform control flow only (the ballots count whole waves
+            // into scalar registers).  CHECK: reads outside [rb, re) are masked (`vm`, one bit per read).
+            // The I16 sums take the reads in pairs: the fields of two reads side by side as u16, one v_dot2_u32_u16 per sum
+            // (a rejected read is a zero record and contributes zeros).
+            auto quad = [&](const uint32_t (&wv)[4], const uint32_t (&av)[4], uint32_t e4, uint32_t vm, uint32_t (&kv)[4]) {
+                uint32_t bqz[4], mqz[4], mdz[4];
+                bool dif[4];
+                #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t w = wv[u];
+                    const bool valid = (vm >> u) & 1;
+                    uint32_t q, b, bq, mapQ, md;
+                    bool ok, seen;
+                    const uint32_t nt = (w >> 16) & 15;
+                    if (INDEL) {
+                        const uint32_t ax = av[u];
+                        b = (ax >> 16) & 0xf;                     // 0..4 after bcf_call_gap_prep (bam2bcf_indel.c:449-456)
+                        bq = q = ax & 0xff;
+                        if (q < min_baseQ) { b = 0; q = w & 0xff; }
+                        b = min(b, 4u);
+                        q = min(q, (ax >> 8) & 0xff);             // seqQ
+                        seen = valid && !(w & BCFGPU_RD_SKIP);
+                        ok = seen;
+                        mapQ = (w >> 8) & 0xff; md = w >> 24;
+                        if (!ok) { bq = 0; mapQ = 0; md = 0; }
+                    } else {
+                        seen = valid && !(w & (BCFGPU_RD_SKIP | BCFGPU_RD_DEL));
+                        ok = seen && (w & 0xff) >= min_baseQ;
+                        const uint32_t wz = ok ? w : 0u;          // a rejected read: a zero record
+                        bq = q = wz & 0xff;                       // seqQ = 99 never binds: q is capped by capQ <= 63 below
+                        mapQ = (wz >> 8) & 0xff; md = wz >> 24;
+                        b = (uint32_t)((tbl >> (4 * nt)) & 7);
+                    }
+                    const unsigned long long b_ok = __ballot(ok);
+                    C.ori += (uint32_t)__popcll(__ballot(seen));
+                    if (mapQ == 255) mapQ = DEF_MAPQ;
+                    C.mq0 += (uint32_t)__popcll(__ballot(mapQ == 0) & b_ok);
+                    mapQ = min(mapQ, capQ);
+                    q = max(min(min(q, mapQ), 63u), 4u);
+                    md = min(md, (uint32_t)CAP_DIST);
+                    const uint32_t rev = (w >> 20) & 1;
+                    uint32_t key = KEY_PACK(rev, q, b, 0);
+                    if (want_scr) key |= ((w >> 21) & 1) << 10;
+                    kv[u] = ok ? key : 0u;
+                    bqz[u] = bq; mqz[u] = mapQ; mdz[u] = md;
+                    dif[u] = ok && (INDEL ? b != 0 : !(ref4 < 4 && b == ref4));
+                    // bias-test histograms: ibq = (int)(baseQ/60.*60) is the identity on 0..59 (checked in tests).
+                    // The mapQ >= 59 bins of the four mapQ histograms (most reads) are counted by ballot; every ALT array sits
+                    // H_ALT_OFF after its REF array.
+                    const bool isref = (int)nt == ref_base;
+                    const bool m59 = mapQ >= 59;
+                    {
+                        const unsigned long long b59 = __ballot(m59) & b_ok, bref = __ballot(isref), brev = __ballot(rev != 0);
+                        C.ref59 += (uint32_t)__popcll(b59 & bref); C.alt59 += (uint32_t)__popcll(b59 & ~bref);
+                        C.rev59 += (uint32_t)__popcll(b59 & brev); C.fwd59 += (uint32_t)__popcll(b59 & ~brev);
+                    }
+                    if (ok && !BCFGPU_ABL(P, 1)) {
+                        const uint32_t aoff = isref ? 0u : (uint32_t)H_ALT_OFF;
+                        atomicAdd(&hist[aoff + H_REF_POS + ((e4 >> (8 * u)) & 0xff)], 1);
+                        atomicAdd(&hist[aoff + H_REF_BQ + min(bq, 59u)], 1);
+                        if (!m59) {
+                            atomicAdd(&hist[aoff + H_REF_MQ + mapQ], 1);
+                            atomicAdd(&hist[(rev ? H_REV_MQS : H_FWD_MQS) + mapQ], 1);
+                        }
+                    }
+                }
+                #pragma unroll
+                for (int h = 0; h < 4; h += 2) {
+                    const v2u16 one2 = { 1, 1 };
+                    const v2u16 bq2 = __builtin_bit_cast(v2u16, bqz[h] | bqz[h + 1] << 16);
+                    const v2u16 mq2 = __builtin_bit_cast(v2u16, mqz[h] | mqz[h + 1] << 16);
+                    const v2u16 md2 = __builtin_bit_cast(v2u16, mdz[h] | mdz[h + 1] << 16);
+                    A.t_bq = __builtin_amdgcn_udot2(bq2, one2, A.t_bq, false); A.t_bq2 = __builtin_amdgcn_udot2(bq2, bq2, A.t_bq2, false);
+                    A.t_mq = __builtin_amdgcn_udot2(mq2, one2, A.t_mq, false); A.t_mq2 = __builtin_amdgcn_udot2(mq2, mq2, A.t_mq2, false);
+                    A.t_md = __builtin_amdgcn_udot2(md2, one2, A.t_md, false); A.t_md2 = __builtin_amdgcn_udot2(md2, md2, A.t_md2, false);
+                    if (__any(dif[h] || dif[h + 1])) {           // rare: sequencing errors and the ALT reads of variant sites
+                        const uint32_t dm = (dif[h] ? 0xffffu : 0u) | (dif[h + 1] ? 0xffff0000u : 0u);
+                        const v2u16 bd = __builtin_bit_cast(v2u16, __builtin_bit_cast(uint32_t, bq2) & dm);
+                        const v2u16 qd = __builtin_bit_cast(v2u16, __builtin_bit_cast(uint32_t, mq2) & dm);
+                        const v2u16 dd = __builtin_bit_cast(v2u16, __builtin_bit_cast(uint32_t, md2) & dm);
+                        A.d_bq = __builtin_amdgcn_udot2(bd, one2, A.d_bq, false); A.d_bq2 = __builtin_amdgcn_udot2(bd, bd, A.d_bq2, false);
+                        A.d_mq = __builtin_amdgcn_udot2(qd, one2, A.d_mq, false); A.d_mq2 = __builtin_amdgcn_udot2(qd, qd, A.d_mq2, false);
+                        A.d_md = __builtin_amdgcn_udot2(dd, one2, A.d_md, false); A.d_md2 = __builtin_amdgcn_udot2(dd, dd, A.d_md2, false);
+                    }
+                }
+            };
+
+            const uint32_t g0 = rb & ~3u;
+            uint4 w4n = make_uint4(0, 0, 0, 0), a4n = make_uint4(0, 0, 0, 0);
+            uint32_t e4n = 0;
+            auto fetch = [&](uint32_t i4) {
+                if (i4 >= re) return;
+                if (i4 + 3 < n_reads_tot) {
+                    w4n = *reinterpret_cast<const uint4*>(P.rd + i4);
+                    if (want_epos) e4n = *reinterpret_cast<const uint32_t*>(P.epos + i4);
+                    if (INDEL) a4n = *reinterpret_cast<const uint4*>(P.aux + i4);
+                } else {                                         // the last reads of the tile
+                    uint32_t t4[4] = {0, 0, 0, 0}, x4[4] = {0, 0, 0, 0};
+                    e4n = 0;
+                    for (int j = 0; j < 4; ++j) if (i4 + j < n_reads_tot) {
+                        t4[j] = P.rd[i4 + j];
+                        if (want_epos) e4n |= (uint32_t)P.epos[i4 + j] << (8 * j);
+                        if (INDEL) x4[j] = P.aux[i4 + j];
+                    }
+                    w4n = make_uint4(t4[0], t4[1], t4[2], t4[3]); a4n = make_uint4(x4[0], x4[1], x4[2], x4[3]);
+                }
+            };
+            fetch(g0 + 4u * tid);
+            const uint32_t ntrip = (re - g0 + 4u * WG - 1) / (4u * WG);       // uniform trip count: the ballots need whole waves
+            for (uint32_t it = 0; it < (BCFGPU_ABL(P, 32) ? 0u : ntrip); ++it) {
+                const uint32_t i4 = g0 + 4u * tid + it * (4u * WG);
+                const uint32_t wv[4] = { w4n.x, w4n.y, w4n.z, w4n.w };
+                const uint32_t av[4] = { a4n.x, a4n.y, a4n.z, a4n.w };
+                const uint32_t e4 = e4n;
+                fetch(i4 + 4u * WG);                             // the next trip's loads fly while this one is worked on
+                const uint32_t ko = i4 - abase;
+                if (__all(i4 >= rb && i4 + 3 < re)) {            // the whole wave inside the segment: no range checks, 8-byte LDS stores
+                    uint32_t kv[4];
+                    quad(wv, av, e4, 15u, kv);
+                    *reinterpret_cast<uint2*>(s_key + ko) = make_uint2(kv[0] | kv[1] << 16, kv[2] | kv[3] << 16);
+                } else {                                         // a wave at a ragged end of the segment
+                    uint32_t kv[4], vm = 0;
+                    #pragma unroll
+                    for (int u = 0; u < 4; ++u) vm |= (i4 + u >= rb && i4 + u < re) ? 1u << u : 0u;
+                    quad(wv, av, e4, vm, kv);
+                    #pragma unroll
+                    for (int u = 0; u < 4; ++u) if ((vm >> u) & 1) s_key[ko + u] = (uint16_t)kv[u];
+                }
+            }
+            // ---- the segment's site totals ----
+            // LDS mode: every lane adds its partial sums to its own column of the slot's [value][64] table (no conflicts
+            // inside a wave); the 64 columns are added up once, when the workgroup is through (below).
+            const uint32_t v[NPART] = { A.t_bq - A.d_bq, A.t_bq2 - A.d_bq2, A.d_bq, A.d_bq2, A.t_mq - A.d_mq, A.t_mq2 - A.d_mq2, A.d_mq, A.d_mq2,
+                                        A.t_md - A.d_md, A.t_md2 - A.d_md2, A.d_md, A.d_md2 };
+            unsigned long long *tot = LDS_HIST ? s_tot + (sg - site0) * SITE_NSUM : P.site_sums + (size_t)sg * SITE_NSUM;
+            if (LDS_HIST) {
+                uint32_t *pt = s_part + (sg - site0) * (NPART * 64) + (tid & 63);
+                #pragma unroll
+                for (int j = 0; j < NPART; ++j) atomicAdd(&pt[j * 64], v[j]);
             } else {
-                b = 0;                                // SNP: looked up below, only for the reads that need it
-                baseQ = q = (int)(w & 0xff);
-                seqQ = 99;
-                const bool seen = !(w & (BCFGPU_RD_SKIP | BCFGPU_RD_DEL));
-                ori_depth += seen;
-                ok = seen && q >= min_baseQ;
+                // global mode (many sites per workgroup, i.e. very few samples): wave sums, one atomic per wave and value
+                #pragma unroll
+                for (int j = 0; j < NPART; ++j) {
+                    const uint32_t x = wave_sum_u32(v[j]);
+                    if ((tid & 63) == 0 && x) atomicAdd(&tot[j], (unsigned long long)x);
+                }
             }
-            if (ok && n >= BCFGPU_MAX_DEPTH) { fail = true; ok = false; }
-            // register accumulators: unconditional arithmetic; a rejected read is a zero record and contributes zeros
-            const uint32_t okm = ok ? 1u : 0u;
-            const uint32_t wz = ok ? w : 0u;
-            if (!ok) baseQ = 0;
-            const uint32_t rev = (wz >> 20) & 1;
-            int mapQ = (wz >> 8) & 0xff;
-            if (mapQ == 255) mapQ = DEF_MAPQ;
-            mq0 += (mapQ == 0) & okm;
-            q = min(q, seqQ);
-            mapQ = min(mapQ, capQ);
-            q = max(min(min(q, mapQ), 63), 4);
-            n += okm;
-            n_rev += rev;
-            const int min_dist = min((int)(wz >> 24), CAP_DIST);
-            const uint32_t key = (uint32_t)(q << 1) | rev;       // (code>>4)&0x7f of bam2bcf.c:203
-            // SNP: bit c of prim_nt says whether a read showing nt16 code c carries the primary base (one bit-field
-            // extract instead of the nt16 -> 0..4 lookup; the lookup itself is left to the few non-primary reads)
-            const bool prim = ok && (INDEL ? b == primary : ((prim_nt >> nt) & 1u) != 0);
-            // reads of the primary base: quality mask, QS and strand count (the other bases' come from their stored words)
-            qmask |= (uint64_t)(prim ? 1u : 0u) << q;
-            qs_prim += prim ? (uint32_t)q : 0u;
-            prim_rev += prim ? rev : 0u;
-            if (want_scr) scr += (wz >> 21) & 1;
-            t_bqmd += (uint32_t)baseQ | (uint32_t)min_dist << 16;
-            t_mq += mapQ;
-            t_bq2 += __umul24(baseQ, baseQ); t_mq2 += __umul24(mapQ, mapQ); t_md2 += __umul24(min_dist, min_dist);   // all < 256
-            const int ibq = min(baseQ, 59);
-            const int imq = min(mapQ, 59);
-            const bool isref = (nt == ref_base);
-            // All LDS updates of the read come last, after the prefetched next record has arrived: LDS operations
-            // complete in order, so waiting for that record any later would also wait for these atomics.
-            asm volatile("" : "+v"(qs_prim), "+v"(prim_rev), "+v"(t_bq2), "+v"(t_mq2), "+v"(t_md2), "+v"(qmask)
-                            : "v"(w_nx), "v"(ep_nx) : "memory");
-            if (!ok) continue;
-            // the key of a primary read goes, compacted, into the lane's epos slice (byte n_prim <= i is behind the reader)
-            // (written for every accepted read: a non-primary one is overwritten by the next primary key or lies past the list)
-            s_ep[ebeg + n_prim] = (uint8_t)key;
-            n_prim += prim ? 1 : 0;
-            if (!prim) {
-                if (!INDEL) b = nt16_int(nt ? nt : ref_base);
-                s_rd[lbeg + n_other] = OW_PACK(baseQ, mapQ, q, b, rev, min_dist);    // n_other <= i: behind the reader
-                ++n_other;
+            if ((tid & 63) == 0) {                               // the wave-uniform counts
+                if (C.ori) atomicAdd(&tot[12], (unsigned long long)C.ori);
+                if (C.mq0) atomicAdd(&tot[13], (unsigned long long)C.mq0);
+                if (C.ref59) atomicAdd(&hist[H_REF_MQ + 59], (int)C.ref59);
+                if (C.alt59) atomicAdd(&hist[H_ALT_MQ + 59], (int)C.alt59);
+                if (C.fwd59) atomicAdd(&hist[H_FWD_MQS + 59], (int)C.fwd59);
+                if (C.rev59) atomicAdd(&hist[H_REV_MQS + 59], (int)C.rev59);
             }
-            // bias-test histograms: ibq = (int)(baseQ/60.*60) is the identity on 0..59 (checked in tests)
-            if (skip_hist) continue;
-            if (imq == 59) h59 += (isref ? 1u : 1u << 8) + (rev ? 1u << 24 : 1u << 16);
-            else {
-                HIST_ADD((rev ? H_REV_MQS : H_FWD_MQS) + imq, 1);
-                HIST_ADD((isref ? H_REF_MQ : H_ALT_MQ) + imq, 1);
-            }
-            HIST_ADD((isref ? H_REF_POS : H_ALT_POS) + ep, 1);
-            HIST_ADD((isref ? H_REF_BQ : H_ALT_BQ) + ibq, 1);
         }
-        if (h59) {
-            if (h59 & 0xff)         HIST_ADD(H_REF_MQ + 59, (int)(h59 & 0xff));
-            if ((h59 >> 8) & 0xff)  HIST_ADD(H_ALT_MQ + 59, (int)((h59 >> 8) & 0xff));
-            if ((h59 >> 16) & 0xff) HIST_ADD(H_FWD_MQS + 59, (int)((h59 >> 16) & 0xff));
-            if (h59 >> 24)          HIST_ADD(H_REV_MQS + 59, (int)(h59 >> 24));
-        }
-        if (fail || ori_depth > 0xffff) {
-            atomicExch(P.err, BCFGPU_E_DEPTH);
-            n = 0; n_other = 0; n_prim = 0; n_rev = 0; qmask = 0; qs_prim = 0; prim_rev = 0;
-        }
-        // the other reads (exactly the "diff" reads of the I16 annotations): their annotation sums and their share of
-        // QS / ADF / ADR (bam2bcf.c:208-215), from the stored words
+        __syncthreads();
+
+        // ================= phase B: one lane per cell =================
+        uint16_t *kp_w = s_key + (part ? beg - abase : 0);       // the lane's keys
+        const uint16_t *kp = kp_w;
+        const int cnt_raw = part ? (int)(end - beg) : 0;
+        // pass 1: the quality mask of the primary base; the few other reads are gathered at the front of the slice
+        uint64_t qmask = 0;          // qualities seen among the reads of the primary base
+        uint32_t n_prim = 0, scr = 0;
         uint64_t qs64 = 0;           // QS[0..3], 16 bits each
         uint64_t ad64 = 0;           // ADF[0..3] | ADR[0..3]<<32, 8 bits each
         uint32_t n_b4 = 0;           // reads showing neither A, C, G nor T
-        uint32_t d_bqmd = 0, d_mq = 0, d_bq2 = 0, d_mq2 = 0, d_md2 = 0, d_fwd = 0, d_rev = 0;
-        if (__any(n_other > 0)) {
-            for (int i = 0; i < n_other; ++i) {
-                const uint32_t ow = s_rd[lbeg + i];
-                const uint32_t baseQ = ow & 0xff, mapQ = (ow >> 8) & 0x3f, md = ow >> 25;
-                d_bqmd += baseQ | md << 16;
-                d_mq += mapQ;
-                d_bq2 += __umul24(baseQ, baseQ); d_mq2 += __umul24(mapQ, mapQ); d_md2 += __umul24(md, md);
-                const uint32_t rev = (ow >> 24) & 1;
-                d_rev += rev; d_fwd += 1 - rev;
-                const uint32_t ob = (ow >> 20) & 0xf, oq = (ow >> 14) & 0x3f;
-                if (ob < 4) {
-                    qs64 += (uint64_t)oq << (16 * ob);
-                    ad64 += 1ull << (8 * ob + 32 * rev);
-                } else ++n_b4;
+        uint32_t o_rev = 0, n_other = 0;
+        {
+            const uint32_t pk = (uint32_t)primary << 7;
+            uint32_t k_nx = kp[0];
+            for (int i = 0; i < (BCFGPU_ABL(P, 4) ? 0 : cnt_raw); ++i) {
+                const uint32_t k = k_nx;
+                k_nx = kp[i + 1];                               // one past the slice stays inside the key array's slack
+                const bool prim = k != 0 && (k & 0x380u) == pk;
+                qmask |= prim ? 1ull << KEY_Q(k) : 0ull;
+                n_prim += prim ? 1u : 0u;
+                if (want_scr) scr += KEY_SC(k);
+                if (k != 0 && !prim) {                          // rare
+                    // swapped to position n_other <= i (behind the reader): the walks only count reads per (base, quality,
+                    // strand), so the order inside a cell is free
+                    const uint32_t t = kp_w[n_other], rev = KEY_REV(k), q = KEY_Q(k), b = KEY_B(k);
+                    kp_w[n_other] = (uint16_t)k; kp_w[i] = (uint16_t)t;
+                    ++n_other; o_rev += rev;
+                    if (b < 4) { qs64 += (uint64_t)q << (16 * b); ad64 += 1ull << (8 * b + 32 * rev); }
+                    else ++n_b4;
+                }
             }
+        }
+        uint32_t n = n_prim + n_other;
+        if (n > BCFGPU_MAX_DEPTH) {
+            atomicExch(P.err, BCFGPU_E_DEPTH);
+            n = 0; n_other = 0; n_prim = 0; qmask = 0; qs64 = 0; ad64 = 0; n_b4 = 0; o_rev = 0; scr = 0;
+        }
+        const bool dead_cell = n == 0;                       // nothing to walk (also the refused cells)
+        const char *bbase = reinterpret_cast<const char*>(P.beta);
+        const uint32_t brow = n << 3;
+
+        // ---- errmod_cal: descending walk per base ----
+        double bsum[5] = {0, 0, 0, 0, 0};
+        uint32_t prim_rev = 0, qs_prim = 0;
+        // (a) the primary base
+        if (!BCFGPU_ABL(P, 2)) {
+            const uint16_t *kpp = kp + n_other;               // primary-base keys and zeros (rejected reads)
+            const double bs = walk_ranks(s_cnt, qmask, s_fk, bbase, tid, brow,
+                                         [=](int j) { const uint32_t k = kpp[j]; return k ? (int)(k & 0x7f) : -1; },
+                                         dead_cell ? 0 : cnt_raw - (int)n_other, prim_rev, qs_prim);
+            #pragma unroll
+            for (int b = 0; b < 5; ++b) if (b == primary) bsum[b] = bs;
         }
         if (primary < 4) {
             qs64 += (uint64_t)qs_prim << (16 * primary);
-            ad64 += (uint64_t)((uint32_t)n_prim - prim_rev) << (8 * primary) | (uint64_t)prim_rev << (8 * primary + 32);
-        } else n_b4 += (uint32_t)n_prim;
+            ad64 += (uint64_t)(n_prim - prim_rev) << (8 * primary) | (uint64_t)prim_rev << (8 * primary + 32);
+        } else n_b4 += n_prim;
         // per-base counts c[0..4] (errmod_cal's aux.c)
         int c[5];
         #pragma unroll
         for (int b = 0; b < 4; ++b) c[b] = (int)((ad64 >> (8 * b)) & 0xff) + (int)((ad64 >> (8 * b + 32)) & 0xff);
         c[4] = (int)n_b4;
-        const bool skip_walk = (P.ablate & 2) != 0;
-
-        // ---- errmod_cal: descending walk per base ----
-        double bsum[5] = {0, 0, 0, 0, 0};
-        // (a) the primary base
-        if (!skip_walk && !(P.ablate & 16384)) {
-            const uint8_t *kb = s_ep + ebeg;                 // the lane's n_prim key bytes
-            const double bs = walk_keys(s_cnt, qmask, s_fk, P.beta, tid, n, n_prim,
-                                        [kb](int j) { return (int)kb[j]; }, n_prim);
-            #pragma unroll
-            for (int b = 0; b < 5; ++b) if (b == primary) bsum[b] = bs;
-        }
         // (b) the other bases present in the wave
-        if (!skip_walk && !(P.ablate & 128) && __any(n_other > 0)) {
-            #pragma unroll
+        if (!BCFGPU_ABL(P, 2) && __any(n_other > 0)) {
+            #pragma unroll 1
             for (int b = 0; b < 5; ++b) {
-                const int cb = (b != primary) ? c[b] : 0;
+                int cb = b == 0 ? c[0] : b == 1 ? c[1] : b == 2 ? c[2] : b == 3 ? c[3] : c[4];
+                if (b == primary || dead_cell) cb = 0;
                 if (!__any(cb > 0)) continue;
-                const uint32_t *ow_p = s_rd + lbeg;
                 // key7 of the lane's i-th other read if it shows base b, else -1
-                auto src = [ow_p, b](int i) {
-                    const uint32_t ow = ow_p[i];
-                    int bb = (ow >> 20) & 0xf;
-                    if (bb > 4) bb = 4;
-                    return bb == b ? (int)(((ow >> 14) & 0x3f) << 1 | ((ow >> 24) & 1)) : -1;
-                };
+                auto src = [=](int i) { const uint32_t k = kp[i]; return (int)KEY_B(k) == b ? (int)(k & 0x7f) : -1; };
                 uint64_t qm = 0;
-                if (cb > 0)
-                    for (int i = 0; i < n_other; ++i) { const int key = src(i); if (key >= 0) qm |= 1ull << (key >> 1); }
-                const double bs = walk_keys(s_cnt, qm, s_fk, P.beta, tid, n, cb, src, cb > 0 ? n_other : 0);
-                if (b != primary) bsum[b] = bs;      // lanes of one wave may belong to sites with different reference bases
+                const int no = cb > 0 ? (int)n_other : 0;
+                for (int i = 0; i < no; ++i) { const int key = src(i); if (key >= 0) qm |= 1ull << (key >> 1); }
+                uint32_t r_, q_;
+                const double bs = walk_ranks(s_cnt, qm, s_fk, bbase, tid, brow, src, no, r_, q_);
+                if (cb > 0) {
+                    #pragma unroll
+                    for (int bb = 0; bb < 5; ++bb) if (bb == b) bsum[bb] = bs;
+                }
             }
         }
+        const uint32_t n_rev = prim_rev + o_rev;
 
         // ---- epilogue of errmod_cal (m=5): float accumulators as in the reference ----
-        if (part) {
+        if (part && !BCFGPU_ABL(P, 64)) {
             #pragma unroll
             for (int j = 0; j < 5; ++j) {
                 float tmp1 = 0.0f; int tmp2 = 0;
@@ -467,61 +524,56 @@ __global__ __launch_bounds__(WG) void glfgen_kernel(const GlfgenParams P)
             }
             // anno[0..3]: ref/alt x fwd/rev counts.  "diff" reads are exactly the non-primary ones when the
             // reference base is A/C/G/T (or at indel sites); with an N reference every read is a diff read.
-            const bool all_diff = (!INDEL && ref4 >= 4);
-            const uint32_t n_fwd = (uint32_t)n - n_rev;
-            if (all_diff) { d_fwd = n_fwd; d_rev = n_rev; d_bqmd = t_bqmd; d_mq = t_mq; d_bq2 = t_bq2; d_mq2 = t_mq2; d_md2 = t_md2; }
+            const bool all_diff = (!INDEL && ref4c >= 4);
+            const uint32_t n_fwd = n - n_rev;
+            const uint32_t d_rev = all_diff ? n_rev : o_rev, d_fwd = all_diff ? n_fwd : n_other - o_rev;
             const uint32_t cnt4 = (n_fwd - d_fwd) | (n_rev - d_rev) << 8 | d_fwd << 16 | d_rev << 24;
             P.cr.qs64[cell] = qs64;
             P.cr.adf[cell] = (uint32_t)ad64; P.cr.adr[cell] = (uint32_t)(ad64 >> 32); P.cr.cnt4[cell] = cnt4;
-            P.cr.misc[cell] = (mq0 & 0xff) | (scr & 0xff) << 8 | ori_depth << 16;
-            // anno[4..15] only feed the site totals of bcf_call_combine (bam2bcf.c:718-727): exact integers, so they are
-            // summed here (LDS per workgroup, one global atomic per workgroup and site) instead of crossing HBM per cell
-            const uint32_t t_bq = t_bqmd & 0xffff, t_md = t_bqmd >> 16, d_bq = d_bqmd & 0xffff, d_md = d_bqmd >> 16;
-            const uint32_t v12[12] = { t_bq - d_bq, t_bq2 - d_bq2, d_bq, d_bq2, t_mq - d_mq, t_mq2 - d_mq2, d_mq, d_mq2,
-                                       t_md - d_md, t_md2 - d_md2, d_md, d_md2 };
-            unsigned long long *tot = LDS_HIST ? s_tot + (site - site0) * 12 : P.site_sums + (size_t)site * 12;
-            #pragma unroll
-            for (int j = 0; j < 12; ++j) if (v12[j]) atomicAdd(&tot[j], (unsigned long long)v12[j]);
+            P.cr.misc[cell] = (scr & 0xff) << 8;         // mq0 and ori_depth only feed site totals: site_sums[12..13]
             done = true;
         }
-        // ---- next round: the first cell whose reads are not resident yet (deep tiles only) ----
-        if (!done) atomicMin(&s_next, beg);
-        __syncthreads();
-        const uint32_t nb = s_next;
         if (nb == 0xffffffffu) break;
         base = nb;
-        __syncthreads();
     }
 
-    // ---- flush the workgroup's histograms ----
+    // ---- flush the workgroup's histograms and site totals ----
     if (LDS_HIST) {
+        __syncthreads();
         const int nslot = min(P.hist_slots, P.n_sites - site0);
+        // the 64 columns of every partial sum: four lanes per value, 16 columns each
+        for (int i = tid; i < nslot * NPART * 4; i += WG) {
+            const int vi = i >> 2, j = vi % NPART, sl = vi / NPART;
+            const uint32_t *pt = s_part + vi * 64 + (i & 3) * 16;
+            unsigned long long x = 0;
+            #pragma unroll
+            for (int k = 0; k < 16; ++k) x += pt[k];
+            x += __shfl_xor(x, 1); x += __shfl_xor(x, 2);
+            if ((i & 3) == 0 && x) s_tot[sl * SITE_NSUM + j] += x;
+        }
+        __syncthreads();
         for (int i = tid; i < nslot * H_SIZE; i += WG) {
             const int v = s_hist[i];
             if (v) atomicAdd(&P.hist[(long)site0 * H_SIZE + i], v);
         }
-        for (int i = tid; i < nslot * 12; i += WG) {
+        for (int i = tid; i < nslot * SITE_NSUM; i += WG) {
             const unsigned long long v = s_tot[i];
-            if (v) atomicAdd(&P.site_sums[(size_t)site0 * 12 + i], v);
+            if (v) atomicAdd(&P.site_sums[(size_t)site0 * SITE_NSUM + i], v);
         }
     }
-    #undef HIST_ADD
 }
 
 size_t glfgen_lds_bytes(int cap, int hist_slots)
 {
-    return LDS_RD + ((size_t)cap + 4) * 4 + (size_t)cap + 32 + (size_t)hist_slots * (H_SIZE * sizeof(int) + 12 * 8);
+    return LDS_HIST_OFF + (size_t)hist_slots * (H_SIZE * sizeof(int) + SITE_NSUM * 8 + NPART * 64 * 4) + ((size_t)cap + 8) * 2;
 }
 
 template <bool INDEL, bool LDS_HIST>
 static void launch_one(const GlfgenParams &p, hipStream_t s, int grid, size_t lds)
 {
-    static size_t lds_attr = 0;
-    if (lds > lds_attr) {
+    if (lds > 48 * 1024)    // per launch, on the device the caller has bound: no process-wide state
         hipFuncSetAttribute(reinterpret_cast<const void*>(glfgen_kernel<INDEL, LDS_HIST>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_attr = lds;
-    }
     hipLaunchKernelGGL((glfgen_kernel<INDEL, LDS_HIST>), dim3(grid), dim3(WG), lds, s, p);
 }
 
@@ -530,8 +582,7 @@ void launch_glfgen(const GlfgenParams &p, hipStream_t s)
     const long ncells = (long)p.n_sites * p.n_smpl;
     if (ncells == 0) return;
     const int grid = (int)((ncells + WG - 1) / WG);
-    size_t lds = glfgen_lds_bytes(p.lds_cap, p.hist_slots);
-    { const char *e = getenv("BCFGPU_LDS_PAD"); if (e) lds += (size_t)atoi(e); }   // diagnostics: lower the occupancy
+    const size_t lds = glfgen_lds_bytes(p.lds_cap, p.hist_slots);
     if (p.is_indel) { if (p.hist_slots) launch_one<true, true>(p, s, grid, lds); else launch_one<true, false>(p, s, grid, lds); }
     else            { if (p.hist_slots) launch_one<false, true>(p, s, grid, lds); else launch_one<false, false>(p, s, grid, lds); }
 }

@@ -5,13 +5,26 @@
 #include <stdint.h>
 #include "../../include/bcfgpu.h"
 
+// Diagnostics (tools/ablate_kernel.sh builds with -DBCFGPU_DIAG): parts of a kernel can be switched off to time the rest.
+// The product build has no such switch: BCFGPU_ABL() is a compile-time 0 and the parameter blocks carry no mask.
+#ifdef BCFGPU_DIAG
+#define BCFGPU_ABL(P, bit) (((P).ablate & (bit)) != 0)
+#define BCFGPU_ABL_FIELD int ablate;
+#else
+#define BCFGPU_ABL(P, bit) false
+#define BCFGPU_ABL_FIELD
+#endif
+
 namespace bcfgpu {
 
 // histogram layout of one site (bcf_callaux_t's bias-test arrays, bam2bcf.h:77)
 enum : int {
-    H_REF_POS = 0, H_ALT_POS = 100, H_REF_MQ = 200, H_ALT_MQ = 260, H_REF_BQ = 320, H_ALT_BQ = 380,
+    H_REF_POS = 0, H_REF_MQ = 100, H_REF_BQ = 160, H_ALT_OFF = 220,      // every ALT array sits H_ALT_OFF after its REF array
+    H_ALT_POS = H_REF_POS + H_ALT_OFF, H_ALT_MQ = H_REF_MQ + H_ALT_OFF, H_ALT_BQ = H_REF_BQ + H_ALT_OFF,
     H_FWD_MQS = 440, H_REV_MQS = 500, H_SIZE = 560
 };
+// site totals glfgen_kernel accumulates read-parallel: anno[4..15] (bam2bcf.c:221-226), then ori_depth and mq0
+enum : int { SITE_NSUM = 14 };
 
 // per (site,sample) result of the glfgen kernel = bcf_callret1_t (bam2bcf.h:90-108), SoA planes over
 // ncells = n_sites*n_smpl.  Everything but p is an exact integer.
@@ -28,9 +41,9 @@ struct GlfgenParams {
     int n_sites, n_smpl, is_indel;
     int min_baseQ, capQ, fmt_flag;
     int hist_slots;                 // >0: per-workgroup LDS histograms with that many site slots; 0: global atomics
-    int lds_cap;                    // reads staged in LDS per workgroup round (multiple of 16)
+    int lds_cap;                    // read keys held in LDS per workgroup round (multiple of 16, <= 16384)
     uint32_t n_reads;               // length of rd/epos (bounds of the vector loads)
-    int ablate;                     // diagnostics only (BCFGPU_ABLATE): 1 no histograms, 2 no errmod walk, 4 no per-read loop
+    BCFGPU_ABL_FIELD
     const int8_t   *ref16;
     const uint32_t *off;
     const uint32_t *rd;
@@ -39,7 +52,7 @@ struct GlfgenParams {
     const double *fk, *beta, *lhet;
     CallretPlanes cr;
     int *hist;                      // [n_sites][H_SIZE], zeroed before launch
-    unsigned long long *site_sums;  // [n_sites][12] site totals of anno[4..15] (exact integers), zeroed before launch
+    unsigned long long *site_sums;  // [n_sites][SITE_NSUM] site totals of anno[4..15], ori_depth, mq0 (exact integers), zeroed before launch
     int *err;                       // device error word
 };
 
@@ -48,9 +61,9 @@ struct CombineParams {
     const int8_t *ref16;
     CallretPlanes cr;
     const int *hist;
-    const unsigned long long *site_sums;   // [n_sites][12] from glfgen_kernel
+    const unsigned long long *site_sums;   // [n_sites][SITE_NSUM] from glfgen_kernel
     const double *mw;               // [6][6][50]
-    int ablate;                     // diagnostics only (BCFGPU_ABLATE)
+    BCFGPU_ABL_FIELD
     int vec4;                       // set by launch_combine: n_smpl % 4 == 0 and all planes 16-byte aligned
     bcfgpu_mplp_out out;
 };
@@ -74,14 +87,14 @@ struct McallParams {
     const float *i16;               // [site][16] INFO/I16 or NULL (fused: msite->anno)
     bcfgpu_call_out out;
     int out_n_gt_max;               // plane count of out.pl / out.gp
-    int ablate;                     // diagnostics only (BCFGPU_ABLATE)
+    BCFGPU_ABL_FIELD
 };
 
 // one realignment job of bcf_call_gap_prep: probaln_glocal(ref2+ref_off, l_ref, query+query_off, l_query, qq+query_off, {.., bw})
 struct ProbalnJob { uint32_t ref_off, query_off; int32_t l_ref, l_query, bw, flags; };   // query_off: into the reads' seq16/qual pools; flags&1: ZQ present
 struct ProbalnParams {
     int n_jobs, ncell;              // ncell: scratch cells per row (>= 3*(2*bw+1)+6 for the widest band)
-    int force_scratch;              // diagnostics (BCFGPU_ABLATE & 256): every job through the rolling-row version
+    int force_scratch;              // diagnostics build only (-DBCFGPU_DIAG): every job through the rolling-row version
     size_t scratch_stride;          // jobs rounded up; scratch is [2][ncell][stride] doubles
     const ProbalnJob *jobs;
     const uint8_t *ref2, *query, *qq, *zq;   // consensus windows (0..4 codes); the reads' seq16 / qual / ZQ pools as the caller holds them

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     const int ngts = nals * (nals + 1) / 2;
     // two instantiations share the grid: sites with <=3 alleles run in the small one, the rest in the general one
     if ((nals <= 3) != (MAXA == 3)) return;
-    if (P.ablate & 8) return;
+    if (BCFGPU_ABL(P, 8)) return;
 
     // record-loop prologue of vcfcall.c:1112-1115: with -v a REF-only record never reaches mcall()
     if ((P.call_flag & BCFGPU_CALL_VARONLY) && (nals == 1 || (nals == 2 && unseen > 0))) {
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             // sb+4q .. sb+4q+3; one matrix product covers the 16 lanes' samples sb+4q+j.
             // (few samples: 4*nq consecutive samples per lane with nq = 2 or 1, so that the 16 lanes' columns stay filled)
             const int nq = S > 128 ? 4 : S > 64 ? 2 : 1;
-            for (int s0 = 0; s0 < ((P.ablate & 16) ? 0 : S); s0 += 64 * nq) {
+            for (int s0 = 0; s0 < (BCFGPU_ABL(P, 16) ? 0 : S); s0 += 64 * nq) {
                 const int sb0 = s0 + 4 * nq * col;
                 uint32_t wq[4][4], pwq[4], gmq[4];
                 #pragma unroll
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             setbits = rowbits;
         } else {
         for (int t = 0; t < nsub; ++t) { s_man[t * WGS + tid] = 1.0; s_exp[t * WGS + tid] = 0; }
-        for (int s = tid; s < ((P.ablate & 16) ? 0 : S); s += WGS) {
+        for (int s = tid; s < (BCFGPU_ABL(P, 16) ? 0 : S); s += WGS) {
             if (ngrp > 1 && P.grp[s] != g) continue;
             int pl[NG]; double pdg[NG];
             load_pl<NG>(P, is, s, ngts, pl);
@@ -747,8 +747,8 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             for (int k = 0; k < NG; ++k) pl_nx[k] = (k < ngts && s < S) ? (uint32_t)plb2[(size_t)k * Ss + s] : 0u;
         }
     };
-    if (!(P.ablate & 32)) fetch_pl(tid);
-    for (int s = tid; s < ((P.ablate & 32) ? 0 : S); s += WGS) {
+    if (!BCFGPU_ABL(P, 32)) fetch_pl(tid);
+    for (int s = tid; s < (BCFGPU_ABL(P, 32) ? 0 : S); s += WGS) {
         const int ploidy = (FAST && !HAP) ? 2 : (P.ploidy ? P.ploidy[s] : 2);    // FAST without HAP is launched only without a ploidy array
         // P(D|G) = raw/psum is formed lazily below, with the same division the reference performs (bit-exact genotypes)
         double psum = 0;
@@ -937,7 +937,7 @@ void launch_mcall(const McallParams &p, hipStream_t s)
         hipLaunchKernelGGL((mcall_kernel<3, 7, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \
         hipLaunchKernelGGL((mcall_kernel<5, 15, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \
         hipLaunchKernelGGL((mcall_kernel<5, 25, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); } while (0)
-    if (p.pl_is_u8 && !(p.ablate & 64)) {
+    if (p.pl_is_u8 && !BCFGPU_ABL(p, 64)) {
         // u8 PLs (the fused pipeline): subset scan on the matrix cores; the haploid coefficient set only with a ploidy
         // array, the group handling only with more than one group
         if (p.ploidy) MCALL_LAUNCH3(true, true, true);
