@@ -49,7 +49,8 @@ struct bcfgpu_ctx {
     // grow-only device workspaces of the indel / BAQ stages (GiB-sized scratch: not reallocated per call)
     struct Ws { void *p = nullptr; size_t bytes = 0; };
     alignas(16) unsigned char pileup_state[256] = {0};   // csrc/pileup.hip: the parameters of the last bcfgpu_pileup
-    Ws ws[40];                     // grow-only device workspaces of the host-fed stages (0-15: indel / BAQ / overlaps, 16-31: pileup, 32-33: gVCF)
+    Ws ws[72];                     // grow-only device workspaces of the host-fed stages (0-15: BAQ / overlaps, 16-31: pileup, 32-33: gVCF, 40-71: gap_prep)
+    Ws pinned[8];                  // grow-only pinned host staging buffers
 };
 
 extern "C" {
@@ -160,6 +161,7 @@ void bcfgpu_destroy(bcfgpu_ctx *c)
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (void *p : c->owned) hipFree(p);
     for (auto &w : c->ws) if (w.p) hipFree(w.p);
+    for (auto &w : c->pinned) if (w.p) hipHostFree(w.p);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     for (int i = 0; i < 4; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -455,85 +457,6 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
     return 0;
 }
 
-// device half of bcfgpu_gap_prep (indel_host.hip): upload the job pools, run probaln_kernel, download the scores
-// The reads' base / quality (/ZQ) pools go up as the caller holds them (the kernel converts nt16 codes and caps the
-// qualities).  They do not depend on the host-side typing, so bcfgpu_gap_prep starts this on a helper thread first and
-// the copies overlap the typing; the copies are queued on the context's stream, ahead of the kernel.
-int bcfgpu_internal_upload_reads(bcfgpu_ctx *c, const bcfgpu_reads *rd, size_t nq, bool any_zq)
-{
-    hipSetDevice(c->cfg.device);
-    void *d_q = bcfgpu_internal_ws(c, 2, nq + 16), *d_qq = bcfgpu_internal_ws(c, 3, nq + 16);
-    void *d_zq = any_zq ? bcfgpu_internal_ws(c, 7, nq + 16) : nullptr;
-    if (!d_q || !d_qq || (any_zq && !d_zq)) return set_err(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
-    hipError_t e = hipMemcpyAsync(d_q, rd->seq16, nq, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_qq, rd->qual, nq, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && any_zq) e = hipMemcpyAsync(d_zq, rd->zq, nq, hipMemcpyHostToDevice, c->stream);
-    if (e != hipSuccess) return set_err(BCFGPU_E_HIP, "bcfgpu_gap_prep: read pool upload", e);
-    return 0;
-}
-
-int bcfgpu_internal_run_probaln(bcfgpu_ctx *c, const std::vector<ProbalnPools> &pools, int max_bw,
-                                size_t nq, bool any_zq,
-                                std::vector<int32_t> &score1, std::vector<int32_t> &score2)
-{
-    hipSetDevice(c->cfg.device);
-    size_t nj = 0, nr = 0;
-    for (const ProbalnPools &pl : pools) { nj += pl.jobs.size(); nr += pl.ref2pool.size(); }
-    ProbalnParams p{};
-    p.ncell = 3 * (2 * max_bw + 1) + 6;
-    // jobs are run in chunks so that the two rolling rows of every job in flight fit a ~1 GiB scratch
-    size_t chunk = ((size_t)1 << 30) / (2 * (size_t)p.ncell * sizeof(double));
-    chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
-    if (chunk > nj) chunk = (nj + 63) & ~(size_t)63;
-    p.scratch_stride = chunk;
-    void *d_jobs, *d_ref2, *d_q, *d_qq, *d_scr, *d_s1, *d_s2, *d_zq = nullptr;
-    auto cleanup = [&]() {};
-    #define GP_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return set_err(BCFGPU_E_HIP, #call, e_); } } while (0)
-    d_jobs = bcfgpu_internal_ws(c, 0, nj * sizeof(ProbalnJob));
-    d_ref2 = bcfgpu_internal_ws(c, 1, nr + 16);
-    d_q = bcfgpu_internal_ws(c, 2, nq + 16);
-    d_qq = bcfgpu_internal_ws(c, 3, nq + 16);
-    d_scr = bcfgpu_internal_ws(c, 4, 2 * (size_t)p.ncell * p.scratch_stride * sizeof(double));
-    d_s1 = bcfgpu_internal_ws(c, 5, nj * 4);
-    d_s2 = bcfgpu_internal_ws(c, 6, nj * 4);
-    if (any_zq) d_zq = bcfgpu_internal_ws(c, 7, nq + 16);
-    if (!d_jobs || !d_ref2 || !d_q || !d_qq || !d_scr || !d_s1 || !d_s2 || (any_zq && !d_zq)) return set_err(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
-    {   // the job pools are already rebased to their place in the concatenation: uploaded segment by segment
-        // (the reads' pools are in place: bcfgpu_internal_upload_reads)
-        size_t oj = 0, orf = 0;
-        for (const ProbalnPools &pl : pools) {
-            if (!pl.jobs.empty()) GP_CHK(hipMemcpyAsync((ProbalnJob*)d_jobs + oj, pl.jobs.data(), pl.jobs.size() * sizeof(ProbalnJob), hipMemcpyHostToDevice, c->stream));
-            if (!pl.ref2pool.empty()) GP_CHK(hipMemcpyAsync((uint8_t*)d_ref2 + orf, pl.ref2pool.data(), pl.ref2pool.size(), hipMemcpyHostToDevice, c->stream));
-            oj += pl.jobs.size(); orf += pl.ref2pool.size();
-        }
-    }
-    p.ref2 = (const uint8_t*)d_ref2; p.query = (const uint8_t*)d_q; p.qq = (const uint8_t*)d_qq; p.zq = (const uint8_t*)d_zq;
-    p.q2p = c->d_q2p; p.scratch = (double*)d_scr;
-#ifdef BCFGPU_DIAG
-    { const char *ab = getenv("BCFGPU_ABLATE"); p.force_scratch = ab && (atoi(ab) & 256) ? 1 : 0; }
-#endif
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0, c->stream);
-    for (size_t j0 = 0; j0 < nj; j0 += chunk) {
-        p.n_jobs = (int)(nj - j0 < chunk ? nj - j0 : chunk);
-        p.jobs = (const ProbalnJob*)d_jobs + j0;
-        p.score1 = (int32_t*)d_s1 + j0; p.score2 = (int32_t*)d_s2 + j0;
-        launch_probaln(p, c->stream);
-    }
-    hipEventRecord(e1, c->stream);
-    GP_CHK(hipGetLastError());
-    score1.resize(nj); score2.resize(nj);
-    GP_CHK(hipMemcpyAsync(score1.data(), d_s1, nj * 4, hipMemcpyDeviceToHost, c->stream));
-    GP_CHK(hipMemcpyAsync(score2.data(), d_s2, nj * 4, hipMemcpyDeviceToHost, c->stream));
-    GP_CHK(hipStreamSynchronize(c->stream));
-    #undef GP_CHK
-    c->gap.kernel_ms = 0;
-    hipEventElapsedTime(&c->gap.kernel_ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    return 0;
-}
-
 bcfgpu_gap_stats *bcfgpu_internal_gap_stats(bcfgpu_ctx *c) { return &c->gap; }
 const bcfgpu_cfg *bcfgpu_internal_cfg(const bcfgpu_ctx *c) { return c ? &c->cfg : nullptr; }
 void *bcfgpu_internal_pileup_state(bcfgpu_ctx *c) { return c ? c->pileup_state : nullptr; }
@@ -541,13 +464,27 @@ void *bcfgpu_internal_pileup_state(bcfgpu_ctx *c) { return c ? c->pileup_state :
 // workspace `slot` of at least `bytes` (contents undefined); nullptr when the allocation fails
 void *bcfgpu_internal_ws(bcfgpu_ctx *c, int slot, size_t bytes)
 {
-    if (!c || slot < 0 || slot >= 40) return nullptr;
+    if (!c || slot < 0 || slot >= 72) return nullptr;
     auto &w = c->ws[slot];
     if (w.bytes >= bytes && w.p) return w.p;
     hipSetDevice(c->cfg.device);
     if (w.p) { hipStreamSynchronize(c->stream); hipFree(w.p); w.p = nullptr; w.bytes = 0; }
     const size_t want = bytes + bytes / 8 + 256;          // a little slack so that slowly growing batches settle
     if (hipMalloc(&w.p, want) != hipSuccess) { w.p = nullptr; return nullptr; }
+    w.bytes = want;
+    return w.p;
+}
+
+// pinned host staging buffer `slot` of at least `bytes` (contents undefined); nullptr when the allocation fails
+void *bcfgpu_internal_pinned(bcfgpu_ctx *c, int slot, size_t bytes)
+{
+    if (!c || slot < 0 || slot >= 8) return nullptr;
+    auto &w = c->pinned[slot];
+    if (w.bytes >= bytes && w.p) return w.p;
+    hipSetDevice(c->cfg.device);
+    if (w.p) { hipStreamSynchronize(c->stream); hipHostFree(w.p); w.p = nullptr; w.bytes = 0; }
+    const size_t want = bytes + bytes / 8 + 256;
+    if (hipHostMalloc(&w.p, want, hipHostMallocDefault) != hipSuccess) { w.p = nullptr; return nullptr; }
     w.bytes = want;
     return w.p;
 }

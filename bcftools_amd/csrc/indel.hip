@@ -212,43 +212,123 @@ __device__ int probaln_fwd_reg(const uint8_t *ref, int l_ref, const QSrc qs, int
     return (int)(Pr1 + .499);
 }
 
-__global__ __launch_bounds__(64) void probaln_kernel(const ProbalnParams P)
+// tpos2qpos, bam2bcf_indel.c:40-66
+__device__ int gap_tpos2qpos(int cpos, int n_cigar, const uint32_t *cigar, int tpos, int is_left, int *_tpos)
 {
-    const int job = blockIdx.x * 64 + threadIdx.x;
-    if (job >= P.n_jobs) return;
-    const ProbalnJob j = P.jobs[job];
-    const size_t stride = P.scratch_stride;
-    double *row0 = P.scratch + job, *row1 = P.scratch + (size_t)P.ncell * stride + job;
-    const uint8_t *ref = P.ref2 + j.ref_off;
-    const QSrc qs{P.query + j.query_off, P.qq + j.query_off, (j.flags & 1) ? P.zq + j.query_off : nullptr};
-    // (bam2bcf_indel.c:293-294, 346-356)
-    // the band probaln_glocal really uses (probaln.c): min(bw, max(l_ref, l_query)), at least |l_ref - l_query|
-    int eff = j.l_ref > j.l_query ? j.l_ref : j.l_query;
-    if (eff > j.bw) eff = j.bw;
-    if (eff < abs(j.l_ref - j.l_query)) eff = abs(j.l_ref - j.l_query);
-    constexpr int BWM = 6;
-    const bool reg = eff <= BWM && j.l_ref > 0 && j.l_query > 0 && !P.force_scratch;
-    // apf1 = {1e-4, 1e-2, bw}; a second parameter set apf2 = {1e-6, 1e-3, bw} is tried when the first score exceeds 5
-    int s1 = 0, s2 = 0;
-    double gd = 1e-4, ge = 1e-2;
-    #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        const int sc = reg ? probaln_fwd_reg<BWM>(ref, j.l_ref, qs, j.l_query, P.q2p, gd, ge, eff)
-                           : probaln_fwd(ref, j.l_ref, qs, j.l_query, P.q2p, gd, ge, j.bw, row0, row1, stride, P.ncell);
-        int l = (int)(100. * sc / j.l_query + .499);
-        if (l > 255) l = 255;
-        const int v = sc << 8 | l;
-        if (pass == 0) { s1 = s2 = v; if (sc <= 5) break; gd = 1e-6; ge = 1e-3; }
-        else s2 = v;
+    int x = cpos, y = 0, last_y = 0;
+    *_tpos = cpos;
+    for (int k = 0; k < n_cigar; ++k) {
+        const int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
+        if (op == 0 || op == 7 || op == 8) {
+            if (cpos > tpos) return y;
+            if (x + l > tpos) { *_tpos = tpos; return y + (tpos - x); }
+            x += l; y += l; last_y = y;
+        } else if (op == 1 || op == 4) y += l;
+        else if (op == 2 || op == 3) {
+            if (x + l > tpos) { *_tpos = is_left ? x : x + l; return y; }
+            x += l;
+        }
     }
-    P.score1[job] = s1;
-    P.score2[job] = s2;
+    *_tpos = x;
+    return last_y;
 }
 
-void launch_probaln(const ProbalnParams &p, hipStream_t s)
+// One realignment of bam2bcf_indel.c:313-357: read K of the site against candidate type t.  Jobs are numbered
+// job0 + t*N + K inside a site (neighbouring lanes: neighbouring reads of one type, i.e. the same band and window).
+struct JobDesc { const uint8_t *ref; int l_ref, l_query, bw, eff; QSrc qs; bool skip; };
+__device__ JobDesc decode_job(const ProbalnParams &P, uint32_t job)
 {
-    if (p.n_jobs == 0) return;
-    hipLaunchKernelGGL(probaln_kernel, dim3((p.n_jobs + 63) / 64), dim3(64), 0, s, p);
+    JobDesc d{};
+    const GapIn &in = P.gin;
+    int lo = 0, hi = P.n_sites - 1;                         // the first site whose running job total exceeds `job`
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (P.sites[mid].job_end > job) hi = mid; else lo = mid + 1; }
+    const GapSite &S = P.sites[lo];
+    const uint32_t rel = job - S.job0;
+    const int t = (int)(rel / (uint32_t)S.N), K = (int)(rel % (uint32_t)S.N), e = S.e0 + K;
+    const int r = in.p_read[e];
+    const uint32_t *cigar = in.cig + in.r_cig_off[r];
+    const int ncig = in.r_ncig[r];
+    d.skip = (in.r_flag[r] & 4) != 0;                       // unmapped reads (:319)
+    for (int k = 0; k < ncig; ++k) if ((cigar[k] & 0xf) == 3) d.skip = true;      // reads with a reference skip (:321-323)
+    if (d.skip) return d;
+    const int32_t *soff = in.smpl_off + (size_t)lo * in.n_smpl;
+    int a = 0, b = in.n_smpl - 1;                           // the sample of entry e: the last s with soff[s] <= e
+    while (a < b) { const int mid = (a + b + 1) >> 1; if (soff[mid] <= e) a = mid; else b = mid - 1; }
+    const int ty = S.types[t], aty = abs(ty);
+    int tbeg, tend;
+    const int qbeg = gap_tpos2qpos(in.r_pos[r], ncig, cigar, S.left, 0, &tbeg);
+    const int qend = gap_tpos2qpos(in.r_pos[r], ncig, cigar, S.right, 1, &tend);
+    if (ty < 0) tbeg = tbeg - aty > S.left ? tbeg - aty : S.left;
+    d.ref = P.ref2 + (size_t)S.ref2_0 + ((size_t)t * in.n_smpl + a) * S.max_ref2 + (tbeg - S.left);
+    d.l_ref = tend - tbeg + aty;
+    d.l_query = qend - qbeg;
+    d.bw = aty + 3;
+    // the band probaln_glocal really uses (probaln.c): min(bw, max(l_ref, l_query)), at least |l_ref - l_query|
+    int eff = d.l_ref > d.l_query ? d.l_ref : d.l_query;
+    if (eff > d.bw) eff = d.bw;
+    if (eff < abs(d.l_ref - d.l_query)) eff = abs(d.l_ref - d.l_query);
+    d.eff = eff;
+    const size_t qo = (size_t)in.r_seq_off[r] + qbeg;
+    d.qs = QSrc{in.seq16 + qo, in.qual + qo, (in.zq && in.r_has_zq && in.r_has_zq[r]) ? in.zq + qo : nullptr};
+    return d;
+}
+
+#define PROBALN_BWM 6
+// WIDE = false: every job; bands up to PROBALN_BWM run here with the row in registers, the others are listed.
+// WIDE = true: the listed jobs, two rolling rows per job in the scratch buffer.
+template <bool WIDE>
+__global__ __launch_bounds__(64) void probaln_kernel(const ProbalnParams P)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    uint32_t job = 0;
+    bool have;
+    if (WIDE) { have = i < P.wide_count; if (have) job = P.wide[P.wide_first + i]; }
+    else { have = i < P.n_jobs; job = (uint32_t)i; }
+    unsigned long long passes = 0, cells = 0;
+    if (have) {
+        const JobDesc j = decode_job(P, job);
+        bool run = !j.skip;
+        const bool degenerate = j.l_ref <= 0 || j.l_query <= 0;           // probaln_glocal has nothing to align: score 0
+        if (!WIDE && run && !degenerate && (j.eff > PROBALN_BWM || P.force_scratch)) {
+            P.wide[atomicAdd(&P.tot->n_wide, 1u)] = job;
+            atomicMax(&P.tot->max_eff, j.eff);
+            run = false;
+        }
+        if (run) {
+            const size_t stride = P.scratch_stride;
+            double *row0 = WIDE ? P.scratch + i : nullptr, *row1 = WIDE ? P.scratch + (size_t)P.ncell * stride + i : nullptr;
+            // apf1 = {1e-4, 1e-2, bw}; a second parameter set apf2 = {1e-6, 1e-3, bw} is tried when the first score exceeds 5
+            // (bam2bcf_indel.c:293-294, 346-356)
+            int s1 = 0, s2 = 0;
+            double gd = 1e-4, ge = 1e-2;
+            #pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                int sc;
+                if (degenerate) sc = 0;
+                else if (WIDE) sc = probaln_fwd(j.ref, j.l_ref, j.qs, j.l_query, P.q2p, gd, ge, j.bw, row0, row1, stride, P.ncell);
+                else sc = probaln_fwd_reg<PROBALN_BWM>(j.ref, j.l_ref, j.qs, j.l_query, P.q2p, gd, ge, j.eff);
+                int l = (int)(100. * sc / j.l_query + .499);
+                if (l > 255) l = 255;
+                const int v = sc << 8 | l;
+                ++passes;
+                if (pass == 0) { s1 = s2 = v; if (sc <= 5) break; gd = 1e-6; ge = 1e-3; }
+                else s2 = v;
+            }
+            P.score1[job] = s1;
+            P.score2[job] = s2;
+            if (!degenerate) cells = (unsigned long long)j.l_query * (2 * j.eff + 1) * 3 * passes;
+        }
+    }
+    // statistics: one atomic per wavefront
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { passes += __shfl_xor(passes, o); cells += __shfl_xor(cells, o); }
+    if (threadIdx.x == 0 && passes) { atomicAdd(&P.tot->n_passes, passes); atomicAdd(&P.tot->dp_cells, cells); }
+}
+
+void launch_probaln(const ProbalnParams &p, hipStream_t s, bool wide_pass)
+{
+    if (wide_pass) { if (p.wide_count > 0) hipLaunchKernelGGL(probaln_kernel<true>, dim3((p.wide_count + 63) / 64), dim3(64), 0, s, p); }
+    else if (p.n_jobs > 0) hipLaunchKernelGGL(probaln_kernel<false>, dim3((p.n_jobs + 63) / 64), dim3(64), 0, s, p);
 }
 
 }  // namespace bcfgpu

@@ -90,21 +90,50 @@ struct McallParams {
     BCFGPU_ABL_FIELD
 };
 
-// one realignment job of bcf_call_gap_prep: probaln_glocal(ref2+ref_off, l_ref, query+query_off, l_query, qq+query_off, {.., bw})
-struct ProbalnJob { uint32_t ref_off, query_off; int32_t l_ref, l_query, bw, flags; };   // query_off: into the reads' seq16/qual pools; flags&1: ZQ present
-struct ProbalnParams {
-    int n_jobs, ncell;              // ncell: scratch cells per row (>= 3*(2*bw+1)+6 for the widest band)
-    int force_scratch;              // diagnostics build only (-DBCFGPU_DIAG): every job through the rolling-row version
-    size_t scratch_stride;          // jobs rounded up; scratch is [2][ncell][stride] doubles
-    const ProbalnJob *jobs;
-    const uint8_t *ref2, *query, *qq, *zq;   // consensus windows (0..4 codes); the reads' seq16 / qual / ZQ pools as the caller holds them
-    const float *q2p;               // 10^(-q/10) as float, q = 0..255 (htslib g_qual2prob)
-    double *scratch;
-    int32_t *score1, *score2;       // sc<<8 | norm, bam2bcf_indel.c:348-356
+// ---- bcf_call_gap_prep on the device (gap_prep.hip, indel.hip) ----
+// the caller's arrays in HBM (bcfgpu_reads, bcfgpu_indel_in) and the slice [ref_lo, ref_hi) of the contig the batch touches
+struct GapIn {
+    int n_sites, n_smpl, n_reads;
+    const int32_t *pos, *smpl_off, *p_read, *p_qpos, *p_indel;
+    const int32_t *r_pos, *r_lq, *r_flag, *r_ncig, *r_cig_off, *r_seq_off;
+    const uint32_t *cig;
+    const uint8_t *seq16, *qual, *zq, *r_has_zq;
+    const char *ref; long ref_lo, ref_hi;        // positions outside the slice read as NUL
+    int openQ, extQ, tandemQ, min_support, per_sample_flt;
+    double min_frac;
 };
-void launch_probaln(const ProbalnParams &p, hipStream_t s);
-// host-side job pools of bcfgpu_gap_prep, one per preparing thread; offsets inside a pool are pool-relative until rebased
-struct ProbalnPools { std::vector<ProbalnJob> jobs; std::vector<uint8_t> ref2pool; int max_bw = 0; };
+// what bcf_call_gap_prep keeps in local variables for one position
+struct GapSite {
+    int32_t live;                                // 0: bcf_call_gap_prep returns -1 before the realignment
+    int32_t n_types, ref_type, l_run, max_ins, N, indelreg, left, right, pos, max_rd_len, max_ref2;
+    int32_t e0;                                  // first pileup entry of the site
+    uint32_t job0, job_end;                      // jobs of the site: job0 + t*N + K (type-major); job_end: running total, all sites
+    uint32_t ref2_0;                             // ref2 rows of the site: ref2_0 + (t*n_smpl + s)*max_ref2
+    uint32_t ins0;                               // insertion consensus of the site: ins0 + t*max_ins
+    int32_t types[64];                           // ascending (bam2bcf_indel.c:145-171); a dropped insertion becomes 0 (:279)
+};
+struct GapTotals {
+    unsigned long long n_jobs, ref2_bytes, ins_bytes;
+    unsigned long long n_passes, dp_cells;       // statistics of the realignment (bcfgpu_gap_stats)
+    int32_t max_L, max_bw, n_live, max_ref2;
+    uint32_t n_wide;                             // jobs whose band does not fit the register-resident pass
+    int32_t max_eff;                             // their widest band
+};
+struct ProbalnParams {
+    GapIn gin;
+    const GapSite *sites;
+    int n_sites, n_jobs;
+    const uint8_t *ref2;                         // realignment targets, base codes 0..4
+    const float *q2p;                            // 10^(-q/10) as float, q = 0..255 (htslib g_qual2prob)
+    int32_t *score1, *score2;                    // sc<<8 | norm, bam2bcf_indel.c:348-356
+    uint32_t *wide; GapTotals *tot;              // out of the first pass: the jobs left for the wide-band pass
+    uint32_t wide_first; int wide_count;         // wide-band pass: jobs wide[wide_first .. +wide_count)
+    int ncell;                                   // scratch cells per row (>= 3*(2*bw+1)+6 for the widest band)
+    size_t scratch_stride;                       // jobs per chunk; scratch is [2][ncell][stride] doubles
+    double *scratch;
+    int force_scratch;                           // diagnostics build only (-DBCFGPU_DIAG): every job through the rolling-row version
+};
+void launch_probaln(const ProbalnParams &p, hipStream_t s, bool wide_pass);
 
 size_t glfgen_lds_bytes(int cap, int hist_slots);
 void launch_glfgen(const GlfgenParams &p, hipStream_t s);
