@@ -157,6 +157,8 @@ PROTOTYPES = {
     "bcfgpu_pipeline": (C.c_int, [C.c_void_p, C.POINTER(Tile), C.c_void_p, C.c_void_p,
                                   C.POINTER(MplpOut), C.POINTER(CallOut)]),
     "bcfgpu_mplp_out_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "bcfgpu_truncated_cells": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "bcfgpu_depth_cap": (C.c_int, [C.POINTER(Reads), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "bcfgpu_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bcfgpu_timing_get": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     "bcfgpu_abi_sizes": (None, [C.POINTER(C.c_int32)]),

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include "kernels.h"
 #include "tables.h"
 
@@ -112,7 +113,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
     int rc = 0;
     if ((rc = dev_alloc(c, (void**)&c->d_fk, fk.size() * 8)) || (rc = dev_alloc(c, (void**)&c->d_beta, beta.size() * 8 + 64)) ||
         (rc = dev_alloc(c, (void**)&c->d_lhet, lhet.size() * 8)) || (rc = dev_alloc(c, (void**)&c->d_pl2p, sizeof pl2p)) ||
-        (rc = dev_alloc(c, (void**)&c->d_mw, sizeof mw)) || (rc = dev_alloc(c, (void**)&c->d_q2p, 256 * sizeof(float))) || (rc = dev_alloc(c, (void**)&c->d_err, sizeof(int)))) {
+        (rc = dev_alloc(c, (void**)&c->d_mw, sizeof mw)) || (rc = dev_alloc(c, (void**)&c->d_q2p, 256 * sizeof(float))) || (rc = dev_alloc(c, (void**)&c->d_err, 2 * sizeof(int)))) {
         bcfgpu_destroy(c); return rc;
     }
     hipMemcpy(c->d_fk, fk.data(), fk.size() * 8, hipMemcpyHostToDevice);
@@ -121,7 +122,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
     hipMemcpy(c->d_pl2p, pl2p, sizeof pl2p, hipMemcpyHostToDevice);
     hipMemcpy(c->d_mw, mw, sizeof mw, hipMemcpyHostToDevice);
     { float q2p[256]; for (int i = 0; i < 256; ++i) q2p[i] = (float)std::pow(10., -i / 10.); hipMemcpy(c->d_q2p, q2p, sizeof q2p, hipMemcpyHostToDevice); }
-    hipMemset(c->d_err, 0, sizeof(int));
+    hipMemset(c->d_err, 0, 2 * sizeof(int));
 
     // the prior: theta <- log(theta * sum_{i<n} 1/i), n = ploidy_max * nsamples (mcall.c:396-416, vcfcall.c:654-655)
     c->call_theta_log = 0;
@@ -213,8 +214,16 @@ int bcfgpu_sync(bcfgpu_ctx *c)
     HIPCHK(hipMemcpy(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
     if (err) {
         hipMemset(c->d_err, 0, sizeof(int));
-        return set_err(err, err == BCFGPU_E_DEPTH ? "a (site,sample) cell holds more than 255 usable reads" : "device-side error");
+        return set_err(err, err == BCFGPU_E_DEPTH ? "a (site,sample) cell holds more pileup entries than a workgroup can stage (several thousand)" : "device-side error");
     }
+    return 0;
+}
+int bcfgpu_truncated_cells(bcfgpu_ctx *c, uint32_t *n_cells)
+{
+    if (!c || !n_cells) return set_err(BCFGPU_E_ARG, "bcfgpu_truncated_cells: bad arguments");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(n_cells, c->d_err + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (*n_cells) hipMemset(c->d_err + 1, 0, sizeof(int));
     return 0;
 }
 int bcfgpu_set_stream(bcfgpu_ctx *c, void *hip_stream)
@@ -249,6 +258,37 @@ void bcfgpu_pack_read(int nt16, int baseQ, int mapQ, int is_rev, int has_softcli
         if (e > BCFGPU_NPOS - 1) e = BCFGPU_NPOS - 1;
     }
     *epos = (uint8_t)e;
+}
+
+// htslib sam.c bam_plp_push: "if (iter->tid == b->core.tid && iter->pos == b->core.pos && iter->mp->cnt > iter->maxcnt)" the
+// read is dropped.  bam_plp_auto pushes a read only when the buffer cannot yield the next column, i.e. iter->pos is the start of
+// the read kept last and every earlier column has been handed out: the buffer then holds the kept reads that end at or after
+// that position (reads are released at the first column they no longer cover), and mp->cnt counts them plus the list's tail node.
+int bcfgpu_depth_cap(const bcfgpu_reads *rd, const int32_t *r_smpl, int32_t n_smpl, int32_t max_depth, uint8_t *keep)
+{
+    if (!rd || !keep || rd->n_reads < 0 || (rd->n_reads && !r_smpl) || n_smpl <= 0) return set_err(BCFGPU_E_ARG, "bcfgpu_depth_cap: bad arguments");
+    const int n = rd->n_reads;
+    if (max_depth <= 0) { for (int r = 0; r < n; ++r) keep[r] = 1; return 0; }
+    struct St { std::vector<int32_t> ends; int32_t last_pos = INT32_MIN; };      // ends: a min-heap of the buffered reads' ends
+    std::vector<St> st(n_smpl);
+    auto cmp = [](int32_t a, int32_t b) { return a > b; };
+    for (int r = 0; r < n; ++r) {
+        const int s = r_smpl[r];
+        if (s < 0 || s >= n_smpl) return set_err(BCFGPU_E_ARG, "bcfgpu_depth_cap: sample index out of range");
+        St &S = st[s];
+        const int32_t p = rd->r_pos[r];
+        if (p < S.last_pos) return set_err(BCFGPU_E_ARG, "bcfgpu_depth_cap: the reads of a sample are not in position order");
+        int32_t e = p;                                          // bam_endpos: the position after the last reference base
+        const uint32_t *cg = rd->cig + rd->r_cig_off[r];
+        for (int k = 0; k < rd->r_ncig[r]; ++k) { const int op = cg[k] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) e += (int32_t)(cg[k] >> 4); }
+        if (e == p) e = p + 1;
+        while (!S.ends.empty() && S.ends.front() < p) { std::pop_heap(S.ends.begin(), S.ends.end(), cmp); S.ends.pop_back(); }
+        if (p == S.last_pos && (int64_t)S.ends.size() + 1 > max_depth) { keep[r] = 0; continue; }
+        keep[r] = 1;
+        S.last_pos = p;
+        S.ends.push_back(e); std::push_heap(S.ends.begin(), S.ends.end(), cmp);
+    }
+    return 0;
 }
 
 size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *c, int n_sites, int which)
@@ -353,6 +393,7 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     g.cr = c->cr;
     // the callret planes are addressed with ncells of *this* tile
     g.hist = c->d_hist; g.err = c->d_err; g.site_sums = c->d_site_sums;
+    g.trunc = reinterpret_cast<unsigned int*>(c->d_err + 1);
     HIPCHK(hipMemsetAsync(c->d_hist, 0, (size_t)tile->n_sites * H_SIZE * sizeof(int), c->stream));
     HIPCHK(hipMemsetAsync(c->d_site_sums, 0, (size_t)tile->n_sites * SITE_NSUM * 8, c->stream));
     hipEvent_t *ev = c->timing ? seq_events(c) : nullptr;

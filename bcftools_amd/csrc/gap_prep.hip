@@ -553,8 +553,9 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
         uint8_t *d_ref2 = (uint8_t*)WS(18, (size_t)tot.ref2_bytes + 16);
         int32_t *d_s1 = (int32_t*)WS(19, nj * 4), *d_s2 = (int32_t*)WS(20, nj * 4);
         uint32_t *d_wide = (uint32_t*)WS(21, nj * 4);
+        GapEntry *d_ent = (GapEntry*)WS(29, n_ent * sizeof(GapEntry));
         if (out->inscns) d_oinscns = (int8_t*)WS(22, (size_t)ns * 4 * inscns_cap);
-        if (!d_inscnt || !d_inscns || !d_ref2 || !d_s1 || !d_s2 || !d_wide || (out->inscns && !d_oinscns))
+        if (!d_inscnt || !d_inscns || !d_ref2 || !d_s1 || !d_s2 || !d_wide || !d_ent || (out->inscns && !d_oinscns))
             return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
         if (tot.ins_bytes) { GP_CHK(hipMemsetAsync(d_inscnt, 0, (size_t)tot.ins_bytes * 5 * 4, st)); GP_CHK(hipMemsetAsync(d_inscns, 0, (size_t)tot.ins_bytes, st)); }
         GP_CHK(hipMemsetAsync(d_s1, 0, nj * 4, st)); GP_CHK(hipMemsetAsync(d_s2, 0, nj * 4, st));
@@ -562,7 +563,9 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
         hipLaunchKernelGGL(gap_inscns_kernel, dim3(ns), dim3(256), 0, st, g, d_sites, d_inscnt, d_inscns);
         hipLaunchKernelGGL(gap_cons_kernel, dim3((unsigned)((size_t)ns * n)), dim3(64), (size_t)tot.max_L * 4 + 16, st, g, d_sites, d_inscns, d_ref2);
         // ---- realignment: register-resident bands first; the jobs with wider bands are listed and run from scratch rows ----
+        launch_gap_entries(g, d_sites, (int)n_ent, d_ent, st);
         ProbalnParams p{};
+        p.ent = d_ent;
         p.gin = g; p.sites = d_sites; p.n_sites = ns; p.n_jobs = (int)nj;
         p.ref2 = d_ref2; p.q2p = q2p; p.score1 = d_s1; p.score2 = d_s2;
         p.wide = d_wide; p.tot = d_tot;

@@ -416,6 +416,48 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         uint16_t *kp_w = s_key + (part ? beg - abase : 0);       // the lane's keys
         const uint16_t *kp = kp_w;
         const int cnt_raw = part ? (int)(end - beg) : 0;
+        // A cell with more than 255 usable reads: errmod_cal would draw a random 255 of them (htslib errmod.c, hts_drand48),
+        // which no parallel order can reproduce.  Here the cell keeps its first 255 usable reads and the later ones are
+        // removed from the pileup altogether, as a depth cap would: their keys are cleared and what phase A added for them
+        // to the site's totals and histograms is taken back.  Counted in P.trunc (bcfgpu_truncated_cells).
+        if (__any(cnt_raw > BCFGPU_MAX_DEPTH)) {
+            uint32_t acc = 0, ntr = 0;
+            const int nchk = cnt_raw > BCFGPU_MAX_DEPTH ? cnt_raw : 0;
+            int *hist_c = LDS_HIST ? s_hist + (site - site0) * H_SIZE : P.hist + (long)site * H_SIZE;
+            unsigned long long *tot_c = LDS_HIST ? s_tot + (site - site0) * SITE_NSUM : P.site_sums + (size_t)site * SITE_NSUM;
+            for (int i = 0; i < nchk; ++i) {
+                if (kp_w[i] == 0) continue;
+                if (acc < BCFGPU_MAX_DEPTH) { ++acc; continue; }
+                kp_w[i] = 0; ++ntr;
+                // the read's contributions, as phase A computed them (bam2bcf.c:173-252)
+                const uint32_t idx = beg + (uint32_t)i, w = P.rd[idx];
+                uint32_t b, bq;
+                if (INDEL) {
+                    const uint32_t ax = P.aux[idx];
+                    b = (ax >> 16) & 0xf; bq = ax & 0xff;
+                    if (bq < min_baseQ) b = 0;
+                    b = min(b, 4u);
+                } else { bq = w & 0xff; b = (uint32_t)nt16_int((int)((w >> 16) & 15) ? (int)((w >> 16) & 15) : (int)P.ref16[site]); }
+                uint32_t mapQ = (w >> 8) & 0xff;
+                if (mapQ == 255) mapQ = DEF_MAPQ;
+                const uint32_t is0 = mapQ == 0;
+                mapQ = min(mapQ, capQ);
+                const uint32_t md = min(w >> 24, (uint32_t)CAP_DIST), rev = (w >> 20) & 1;
+                const bool diff = INDEL ? b != 0 : !(ref4c < 4 && (int)b == ref4c);
+                const bool isref = !INDEL && (int)((w >> 16) & 15) == (int)P.ref16[site];
+                const int o = diff ? 2 : 0;
+                auto sub = [&](int j, uint32_t v) { if (v) atomicAdd(&tot_c[j], 0ull - (unsigned long long)v); };
+                sub(0 + o, bq); sub(1 + o, bq * bq); sub(4 + o, mapQ); sub(5 + o, mapQ * mapQ); sub(8 + o, md); sub(9 + o, md * md);
+                sub(12, 1u); sub(13, is0);
+                const uint32_t aoff = isref ? 0u : (uint32_t)H_ALT_OFF, imq = min(mapQ, 59u);
+                const uint32_t ep = want_epos ? P.epos[idx] : 0u;
+                atomicSub(&hist_c[aoff + H_REF_POS + ep], 1);
+                atomicSub(&hist_c[aoff + H_REF_BQ + min(bq, 59u)], 1);
+                atomicSub(&hist_c[aoff + H_REF_MQ + imq], 1);
+                atomicSub(&hist_c[(rev ? H_REV_MQS : H_FWD_MQS) + imq], 1);
+            }
+            if (ntr) atomicAdd(P.trunc, 1u);
+        }
         // pass 1: the quality mask of the primary base; the few other reads are gathered at the front of the slice
         uint64_t qmask = 0;          // qualities seen among the reads of the primary base
         uint32_t n_prim = 0, scr = 0;
@@ -444,11 +486,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
             }
         }
-        uint32_t n = n_prim + n_other;
-        if (n > BCFGPU_MAX_DEPTH) {
-            atomicExch(P.err, BCFGPU_E_DEPTH);
-            n = 0; n_other = 0; n_prim = 0; qmask = 0; qs64 = 0; ad64 = 0; n_b4 = 0; o_rev = 0; scr = 0;
-        }
+        const uint32_t n = n_prim + n_other;                 // <= 255
         const bool dead_cell = n == 0;                       // nothing to walk (also the refused cells)
         const char *bbase = reinterpret_cast<const char*>(P.beta);
         const uint32_t brow = n << 3;

@@ -235,8 +235,42 @@ __device__ int gap_tpos2qpos(int cpos, int n_cigar, const uint32_t *cigar, int t
 
 // One realignment of bam2bcf_indel.c:313-357: read K of the site against candidate type t.  Jobs are numbered
 // job0 + t*N + K inside a site (neighbouring lanes: neighbouring reads of one type, i.e. the same band and window).
+// What a read contributes to every realignment of its site (it does not depend on the candidate type): the part of the
+// read inside the window and where it starts and ends on the reference -- the two tpos2qpos() calls of
+// bam2bcf_indel.c:326-327 -- and the read's sample.  One lane per pileup entry.
+__global__ __launch_bounds__(256) void gap_entry_kernel(const GapIn in, const GapSite *sites, int n_ent, GapEntry *ent)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_ent) return;
+    int lo = 0, hi = in.n_sites - 1;                        // the site of entry e: the last one with smpl_off[site*n] <= e
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (in.smpl_off[(size_t)mid * in.n_smpl] <= e) lo = mid; else hi = mid - 1; }
+    const GapSite &S = sites[lo];
+    if (!S.live) return;
+    const int32_t *soff = in.smpl_off + (size_t)lo * in.n_smpl;
+    int a = 0, b = in.n_smpl - 1;                           // the sample of entry e: the last s with soff[s] <= e
+    while (a < b) { const int mid = (a + b + 1) >> 1; if (soff[mid] <= e) a = mid; else b = mid - 1; }
+    const int r = in.p_read[e];
+    const uint32_t *cigar = in.cig + in.r_cig_off[r];
+    const int ncig = in.r_ncig[r];
+    bool skip = (in.r_flag[r] & 4) != 0;                    // unmapped reads (:319)
+    for (int k = 0; k < ncig; ++k) if ((cigar[k] & 0xf) == 3) skip = true;        // reads with a reference skip (:321-323)
+    GapEntry g{};
+    g.smpl = skip ? -1 : a;
+    if (!skip) {
+        g.qbeg = gap_tpos2qpos(in.r_pos[r], ncig, cigar, S.left, 0, &g.tbeg);
+        g.qend = gap_tpos2qpos(in.r_pos[r], ncig, cigar, S.right, 1, &g.tend);
+    }
+    ent[e] = g;
+}
+void launch_gap_entries(const GapIn &in, const GapSite *sites, int n_ent, GapEntry *ent, hipStream_t s)
+{
+    if (n_ent > 0) hipLaunchKernelGGL(gap_entry_kernel, dim3((n_ent + 255) / 256), dim3(256), 0, s, in, sites, n_ent, ent);
+}
+
+// One realignment of bam2bcf_indel.c:313-357: read K of the site against candidate type t.  Jobs are numbered
+// job0 + t*N + K inside a site (neighbouring lanes: neighbouring reads of one type, i.e. the same band and window).
 struct JobDesc { const uint8_t *ref; int l_ref, l_query, bw, eff; QSrc qs; bool skip; };
-__device__ JobDesc decode_job(const ProbalnParams &P, uint32_t job)
+__device__ __forceinline__ JobDesc decode_job(const ProbalnParams &P, uint32_t job)
 {
     JobDesc d{};
     const GapIn &in = P.gin;
@@ -245,30 +279,23 @@ __device__ JobDesc decode_job(const ProbalnParams &P, uint32_t job)
     const GapSite &S = P.sites[lo];
     const uint32_t rel = job - S.job0;
     const int t = (int)(rel / (uint32_t)S.N), K = (int)(rel % (uint32_t)S.N), e = S.e0 + K;
-    const int r = in.p_read[e];
-    const uint32_t *cigar = in.cig + in.r_cig_off[r];
-    const int ncig = in.r_ncig[r];
-    d.skip = (in.r_flag[r] & 4) != 0;                       // unmapped reads (:319)
-    for (int k = 0; k < ncig; ++k) if ((cigar[k] & 0xf) == 3) d.skip = true;      // reads with a reference skip (:321-323)
+    const GapEntry g = P.ent[e];
+    d.skip = g.smpl < 0;
     if (d.skip) return d;
-    const int32_t *soff = in.smpl_off + (size_t)lo * in.n_smpl;
-    int a = 0, b = in.n_smpl - 1;                           // the sample of entry e: the last s with soff[s] <= e
-    while (a < b) { const int mid = (a + b + 1) >> 1; if (soff[mid] <= e) a = mid; else b = mid - 1; }
+    const int r = in.p_read[e];
     const int ty = S.types[t], aty = abs(ty);
-    int tbeg, tend;
-    const int qbeg = gap_tpos2qpos(in.r_pos[r], ncig, cigar, S.left, 0, &tbeg);
-    const int qend = gap_tpos2qpos(in.r_pos[r], ncig, cigar, S.right, 1, &tend);
+    int tbeg = g.tbeg;
     if (ty < 0) tbeg = tbeg - aty > S.left ? tbeg - aty : S.left;
-    d.ref = P.ref2 + (size_t)S.ref2_0 + ((size_t)t * in.n_smpl + a) * S.max_ref2 + (tbeg - S.left);
-    d.l_ref = tend - tbeg + aty;
-    d.l_query = qend - qbeg;
+    d.ref = P.ref2 + (size_t)S.ref2_0 + ((size_t)t * in.n_smpl + g.smpl) * S.max_ref2 + (tbeg - S.left);
+    d.l_ref = g.tend - tbeg + aty;
+    d.l_query = g.qend - g.qbeg;
     d.bw = aty + 3;
     // the band probaln_glocal really uses (probaln.c): min(bw, max(l_ref, l_query)), at least |l_ref - l_query|
     int eff = d.l_ref > d.l_query ? d.l_ref : d.l_query;
     if (eff > d.bw) eff = d.bw;
     if (eff < abs(d.l_ref - d.l_query)) eff = abs(d.l_ref - d.l_query);
     d.eff = eff;
-    const size_t qo = (size_t)in.r_seq_off[r] + qbeg;
+    const size_t qo = (size_t)in.r_seq_off[r] + g.qbeg;
     d.qs = QSrc{in.seq16 + qo, in.qual + qo, (in.zq && in.r_has_zq && in.r_has_zq[r]) ? in.zq + qo : nullptr};
     return d;
 }
@@ -277,7 +304,7 @@ __device__ JobDesc decode_job(const ProbalnParams &P, uint32_t job)
 // WIDE = false: every job; bands up to PROBALN_BWM run here with the row in registers, the others are listed.
 // WIDE = true: the listed jobs, two rolling rows per job in the scratch buffer.
 template <bool WIDE>
-__global__ __launch_bounds__(64) void probaln_kernel(const ProbalnParams P)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void probaln_kernel(const ProbalnParams P)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
     uint32_t job = 0;

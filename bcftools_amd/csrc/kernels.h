@@ -54,6 +54,7 @@ struct GlfgenParams {
     int *hist;                      // [n_sites][H_SIZE], zeroed before launch
     unsigned long long *site_sums;  // [n_sites][SITE_NSUM] site totals of anno[4..15], ori_depth, mq0 (exact integers), zeroed before launch
     int *err;                       // device error word
+    unsigned int *trunc;            // cells cut to their first 255 usable reads (counter)
 };
 
 struct CombineParams {
@@ -112,6 +113,8 @@ struct GapSite {
     uint32_t ins0;                               // insertion consensus of the site: ins0 + t*max_ins
     int32_t types[64];                           // ascending (bam2bcf_indel.c:145-171); a dropped insertion becomes 0 (:279)
 };
+// per pileup entry: the read's sample (-1: the read is not realigned) and its window coordinates
+struct GapEntry { int32_t smpl, qbeg, qend, tbeg, tend; };
 struct GapTotals {
     unsigned long long n_jobs, ref2_bytes, ins_bytes;
     unsigned long long n_passes, dp_cells;       // statistics of the realignment (bcfgpu_gap_stats)
@@ -122,6 +125,7 @@ struct GapTotals {
 struct ProbalnParams {
     GapIn gin;
     const GapSite *sites;
+    const GapEntry *ent;
     int n_sites, n_jobs;
     const uint8_t *ref2;                         // realignment targets, base codes 0..4
     const float *q2p;                            // 10^(-q/10) as float, q = 0..255 (htslib g_qual2prob)
@@ -134,6 +138,7 @@ struct ProbalnParams {
     int force_scratch;                           // diagnostics build only (-DBCFGPU_DIAG): every job through the rolling-row version
 };
 void launch_probaln(const ProbalnParams &p, hipStream_t s, bool wide_pass);
+void launch_gap_entries(const GapIn &in, const GapSite *sites, int n_ent, GapEntry *ent, hipStream_t s);
 
 size_t glfgen_lds_bytes(int cap, int hist_slots);
 void launch_glfgen(const GlfgenParams &p, hipStream_t s);

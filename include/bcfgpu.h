@@ -53,8 +53,9 @@ extern "C" {
 #define BCFGPU_E_ARG      -1   /* bad argument / NULL pointer                       */
 #define BCFGPU_E_NOMEM    -2   /* host or device allocation failed                  */
 #define BCFGPU_E_HIP      -3   /* a HIP runtime call failed (see bcfgpu_last_error) */
-#define BCFGPU_E_DEPTH    -4   /* a (site,sample) holds >255 usable reads: errmod_cal's
-                                  random 255-subsample (htslib errmod.c) is not restated */
+#define BCFGPU_E_DEPTH    -4   /* a (site,sample) cell holds more pileup entries than one workgroup can stage (several
+                                  thousand; see bcfgpu_depth_cap).  Cells with more than 255 *usable* reads are not an
+                                  error: they are cut to their first 255 (bcfgpu_truncated_cells) */
 #define BCFGPU_E_NODEV    -5   /* no HIP device: the product path has no CPU fallback  */
 #define BCFGPU_E_RANGE    -6   /* tile larger than the context's capacity           */
 
@@ -88,7 +89,8 @@ extern "C" {
 #define BCFGPU_MAX_PL      15         /* 5*(5+1)/2 */
 #define BCFGPU_NPOS        100        /* bca->npos,  bam2bcf.c:55 */
 #define BCFGPU_NQUAL       60         /* bca->nqual, bam2bcf.c:58 */
-#define BCFGPU_MAX_DEPTH   255        /* per (site,sample) reads errmod_cal takes without subsampling */
+#define BCFGPU_MAX_DEPTH   255        /* usable reads of a (site,sample) cell: what errmod_cal takes without subsampling and what the
+                                         u8 count planes hold; later reads of a deeper cell are dropped */
 
 /* sentinels, identical to htslib's bcf_int32_missing / bcf_int32_vector_end */
 #define BCFGPU_INT32_MISSING     (INT32_MIN)
@@ -251,6 +253,12 @@ int  bcfgpu_memcpy_h2d(bcfgpu_ctx *ctx, void *dst, const void *src, size_t bytes
 int  bcfgpu_memcpy_d2h(bcfgpu_ctx *ctx, void *dst, const void *src, size_t bytes);
 int  bcfgpu_memset(bcfgpu_ctx *ctx, void *dst, int value, size_t bytes);
 int  bcfgpu_sync(bcfgpu_ctx *ctx);
+/* Cells of the launches since the last call that held more than BCFGPU_MAX_DEPTH usable reads.  errmod_cal (htslib errmod.c)
+ * would shuffle such a cell's reads with hts_drand48 and keep 255 -- a draw from a process-wide generator that depends on the
+ * order in which the whole run visits its cells.  Here the cell keeps its first 255 usable reads and the later ones are removed
+ * from the pileup (from PL, AD, DP4, QS and from the site's I16 / histograms alike), as a depth cap would.  With mpileup's
+ * default -d 250 per file (bcfgpu_depth_cap) such cells arise only where the cap lets reads through (new start positions). */
+int  bcfgpu_truncated_cells(bcfgpu_ctx *ctx, uint32_t *n_cells);
 /* enqueue on an externally owned hipStream_t (e.g. torch's current stream); NULL = the context's own */
 int  bcfgpu_set_stream(bcfgpu_ctx *ctx, void *hip_stream);
 
@@ -350,11 +358,18 @@ int  bcfgpu_overlap_tweak(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, int32_t n_
  *   col_n    out, HOST [end-beg] or NULL: pileup entries per column (0: the reference emits no record there)
  *   col_indel out, HOST [end-beg] or NULL: 1 when some read of the column is followed by an indel (the columns
  *            bcf_call_gap_prep looks at, bam2bcf_indel.c:106-113)
- * Not modelled: the per-file depth cap of the iterator (mpileup -d): cells deeper than BCFGPU_MAX_DEPTH usable reads are
- * refused by the mpileup stage (BCFGPU_E_DEPTH). */
+ * The per-file depth cap of the iterator (mpileup -d) is the caller's to apply to the pool first: bcfgpu_depth_cap. */
 int  bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const uint8_t *r_mapq, const int32_t *r_smpl,
                    int32_t beg, int32_t end, const char *ref, int32_t ref_len,
                    bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel);
+
+/* ---- the pileup iterator's per-file depth cap: mpileup -d (mpileup.c:646 bam_mplp_set_maxcnt; htslib sam.c bam_plp_push) -------
+ * Host helper (integer bookkeeping of the read buffer, no device work).  A read is dropped when it starts at the position of
+ * the read kept last while max_depth or more reads are still buffered: reads kept earlier whose end (bam_endpos) is not before
+ * that position.  The first read of every start position is always kept, so a column can exceed max_depth by a little.
+ * One sample = one input file (mpileup counts per file).  reads: the pool after the read filters of mplp_func, every sample's
+ * reads in position order; keep: out [n_reads], 1 = the read enters the pileup.  max_depth <= 0: keep everything. */
+int  bcfgpu_depth_cap(const bcfgpu_reads *reads, const int32_t *r_smpl, int32_t n_smpl, int32_t max_depth, uint8_t *keep);
 
 /* The pileup entries of selected columns of the last bcfgpu_pileup on this context, in the form bcfgpu_gap_prep takes them
  * (bcfgpu_indel_in: what bcf_call_gap_prep reads of bam_pileup1_t): for column cols[i] and sample s the entries

@@ -24,7 +24,7 @@ def _oracle(reads, refseq, flag):
 
 @pytest.mark.parametrize("samf,fa", [("mpileup.1.sam", "mpileup.ref.fa"), ("mpileup.2.sam", "mpileup.ref.fa"),
                                      ("mpileup.4.sam", "mpileup.ref.fa"), ("indel-AD.1.sam", "indel-AD.1.fa")])
-@pytest.mark.parametrize("flag", [3, 1, 2])
+@pytest.mark.parametrize("flag", [3, 1, 2, 7])        # 7: mpileup -E (apply | extended | recompute)
 def test_baq_matches_oracle_on_reference_reads(golden_dir, gpu_ctx_factory, samf, fa, flag):
     G = os.path.join(golden_dir, "mpileup")
     s = sam.Sam(os.path.join(G, samf))

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
     (16, 3, 40.0, 42, dict(min_support=2)),
     (12, 50, 8.0, 43, dict(per_sample_flt=1, min_frac=0.05)),
     (6, 1, 60.0, 44, dict(openQ=30, extQ=10)),
+    (4, 500, 30.0, 45, {}),                               # BASELINE configs[2]: 500 samples x 30x
 ])
 def test_batched_gap_prep_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth, seed, kw):
     b = synth.indel_batch(seed, n_sites, n_smpl, depth=depth)

@@ -130,6 +130,29 @@ def test_pipeline_diploid_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth
         np.testing.assert_array_equal(cgot.gq[live], cwant.gq[live])
 
 
+@pytest.mark.parametrize("theta", [0.0, 1e-2, 1e-4, 0.9])
+@pytest.mark.parametrize("n_smpl,with_ploidy", [(100, False), (40, True)])
+def test_pipeline_nondefault_prior(gpu_ctx_factory, theta, n_smpl, with_ploidy):
+    """call -P / --prior (mcall.c:397-416, the reference-site QUAL of :1639-1644): no prior at all (-P 0), a larger and a
+    smaller mutation rate than the default 1.1e-3, and one large enough for the 0.99 cap (BASELINE configs[4] names --prior)."""
+    n_sites, seed = 96, 71
+    tile = synth.numpy_tile(seed, n_sites, n_smpl, depth=15.0, var_rate=0.3)
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), call_theta=theta, output_tags=abi.CALL_FMT_GQ)
+    ploidy = np.random.default_rng(seed).choice([1, 2, 2], size=n_smpl).astype(np.uint8) if with_ploidy else None
+    mwant = orc.mpileup(cfg, tile)
+    cin = host.CallInput(n_smpl, mwant.site["n_alleles"], np.maximum(mwant.site["unseen"], 0),
+                         mwant.pl.astype(np.int32), mwant.site["qsum"], ploidy=ploidy, i16=mwant.site["anno"].astype(np.float32))
+    cwant = orc.mcall(cfg, cin)
+    mgot, cgot = gpu_ctx_factory(cfg).pipeline(tile, ploidy=ploidy)
+    assert_mplp_equal(mgot, mwant)
+    assert_call_equal(cgot, cwant, n_smpl)
+    # the prior moves calls: the test would be vacuous if every theta gave the default's records
+    if theta != 1e-4:
+        cfg0 = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), output_tags=abi.CALL_FMT_GQ)
+        c0 = orc.mcall(cfg0, cin)
+        assert not np.allclose(c0.site["qual"], cwant.site["qual"], rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("n_sites,n_smpl,n_grp,seed,use_qs", [(48, 120, 4, 61, False), (32, 1000, 4, 62, False), (40, 33, 33, 63, False),
                                                               (48, 90, 3, 64, True)])
 def test_pipeline_with_sample_groups_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, n_grp, seed, use_qs):
@@ -173,18 +196,76 @@ def test_empty_and_zero_depth(gpu_ctx_factory):
     assert res.site.shape == (0,)
 
 
-def test_depth_over_255_is_refused(gpu_ctx_factory):
-    from bcftools_amd.lib import BcfGpuError
-    n_smpl = 2
-    n = 300
-    rd = np.full(n, 40 | (60 << 8) | (1 << 16), dtype=np.uint32)
-    tile = host.HostTile(n_smpl, np.array([1], dtype=np.int8), np.array([0, n, n], dtype=np.uint32), rd,
-                         np.zeros(n, dtype=np.uint8))
-    cfg = abi.default_cfg(n_smpl, max_sites=1, max_reads=n)
+def _cut_to_255(tile, min_baseQ=13):
+    """The tile with every cell's usable reads (bam2bcf.c:173-194) after the 255th removed."""
+    off = tile.plp_off.astype(np.int64)
+    keep = np.ones(len(tile.rd), bool)
+    usable = ((tile.rd & (abi.RD_SKIP | abi.RD_DEL)) == 0) & ((tile.rd & 0xff) >= min_baseQ)
+    for c in np.nonzero(np.diff(off) > 255)[0]:
+        u = np.nonzero(usable[off[c]:off[c + 1]])[0]
+        keep[off[c] + u[255:]] = False
+    n = np.add.reduceat(np.r_[keep, False].astype(np.int64), off[:-1]) if len(off) > 1 else np.zeros(0, np.int64)
+    n[np.diff(off) == 0] = 0
+    new_off = np.zeros_like(off)
+    np.cumsum(n, out=new_off[1:])
+    return host.HostTile(tile.n_smpl, tile.ref16, new_off.astype(np.uint32), tile.rd[keep], tile.epos[keep])
+
+
+@pytest.mark.parametrize("n_smpl,depths,seed", [(2, [420, 0], 31), (40, None, 32), (3, [345, 255, 900], 33)])
+def test_cells_over_255_keep_their_first_255(gpu_ctx_factory, n_smpl, depths, seed):
+    """A cell with more than 255 usable reads is not an error (the reference never fails here): it keeps its first 255 and
+    the later ones are removed from the pileup, for the cell's PL/AD/DP4 and the site's I16 / histograms alike -- the
+    result is the oracle's on the tile without those reads."""
+    if depths is None:
+        tile = synth.numpy_tile(seed, 6, n_smpl, depth=240.0, var_rate=0.5, max_depth=400)
+    else:
+        rng = np.random.default_rng(seed)
+        R = int(sum(depths))
+        rd = (rng.choice([11, 25, 37, 40], R) | (rng.choice([0, 20, 60, 60, 60], R) << 8) | ((1 << rng.integers(0, 4, R)) << 16)
+              | (rng.integers(0, 2, R) << 20) | (rng.integers(0, 40, R) << 24)).astype(np.uint32)
+        tile = host.HostTile(n_smpl, np.array([1], dtype=np.int8), np.r_[0, np.cumsum(depths)].astype(np.uint32), rd,
+                             rng.integers(0, 100, R).astype(np.uint8))
+    cut = _cut_to_255(tile)
+    assert len(cut.rd) < len(tile.rd)
+    cfg = abi.default_cfg(n_smpl, max_sites=len(tile.ref16), max_reads=len(tile.rd), fmt_flag=abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD)
     ctx = gpu_ctx_factory(cfg)
-    with pytest.raises(BcfGpuError) as e:
-        ctx.mpileup(tile)
-    assert e.value.code == abi.E_DEPTH
+    got = ctx.mpileup(tile)
+    assert_mplp_equal(got, orc.mpileup(cfg, cut))
+    n = abi.C.c_uint32()
+    assert ctx.L.bcfgpu_truncated_cells(ctx.h, abi.C.byref(n)) == 0 and n.value > 0
+    assert ctx.L.bcfgpu_truncated_cells(ctx.h, abi.C.byref(n)) == 0 and n.value == 0      # reading resets the counter
+
+
+def test_cell_at_the_edge_of_the_staging_window(gpu_ctx_factory):
+    """Cells that fill a workgroup's LDS window to the last key, at every alignment of their first read: handled or refused
+    with BCFGPU_E_DEPTH, never left spinning (the window starts at a multiple of four reads)."""
+    from bcftools_amd.lib import BcfGpuError
+    n_smpl = 300
+    cfg = abi.default_cfg(n_smpl, max_sites=1, max_reads=13000)
+    ctx = gpu_ctx_factory(cfg)
+    handled = refused = 0
+    # the window of this shape holds 11936 keys (csrc/api.hip sizes it); the sizes straddle that edge
+    for big in (11900, 11929, 11930, 11931, 11932, 11933, 11934, 11935, 11936, 11937, 11940):
+        for lead in (0, 1, 2, 3):
+            depths = np.zeros(n_smpl, np.int64)
+            depths[0] = lead
+            depths[1] = big
+            R = int(depths.sum())
+            rng = np.random.default_rng(big * 4 + lead)
+            # low base qualities: the cell holds thousands of pileup entries but fewer than 255 usable reads
+            bq = np.where(rng.random(R) < 0.015, 30, 5)
+            rd = (bq | (60 << 8) | ((1 << rng.integers(0, 4, R)) << 16) | (rng.integers(0, 2, R) << 20) | (rng.integers(0, 40, R) << 24)).astype(np.uint32)
+            tile = host.HostTile(n_smpl, np.array([1], dtype=np.int8), np.r_[0, np.cumsum(depths)].astype(np.uint32), rd,
+                                 rng.integers(0, 100, R).astype(np.uint8))
+            try:
+                got = ctx.mpileup(tile)
+            except BcfGpuError as e:
+                assert e.code == abi.E_DEPTH
+                refused += 1
+                continue
+            assert_mplp_equal(got, orc.mpileup(cfg, tile))
+            handled += 1
+    assert handled > 0 and refused > 0
 
 
 @pytest.mark.parametrize("n_sites,n_smpl,seed", [(40, 100, 21), (64, 7, 22)])
