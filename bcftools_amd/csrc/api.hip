@@ -214,7 +214,8 @@ int bcfgpu_sync(bcfgpu_ctx *c)
     HIPCHK(hipMemcpy(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
     if (err) {
         hipMemset(c->d_err, 0, sizeof(int));
-        return set_err(err, err == BCFGPU_E_DEPTH ? "a (site,sample) cell holds more pileup entries than a workgroup can stage (several thousand)" : "device-side error");
+        return set_err(err, err == BCFGPU_E_DEPTH ? "a (site,sample) cell holds more pileup entries than a workgroup can stage (several thousand)" :
+                            err == BCFGPU_E_RANGE ? "a record is outside the supported range (more than 5 alleles, or more genotypes / alleles than the planes hold): its ret is -2" : "device-side error");
     }
     return 0;
 }
@@ -445,6 +446,7 @@ int bcfgpu_mcall(bcfgpu_ctx *c, const bcfgpu_call_in *in, const bcfgpu_call_out 
         return set_err(BCFGPU_E_ARG, "bcfgpu_mcall: NULL input array");
     if (c->cfg.n_grp > 1 && (!in->grp || !in->ad)) return set_err(BCFGPU_E_ARG, "bcfgpu_mcall: -G needs grp and ad");
     if (in->n_gt_max < 1 || in->n_gt_max > BCFGPU_MAX_PL) return set_err(BCFGPU_E_ARG, "bcfgpu_mcall: n_gt_max out of range");
+    if (in->ad && (in->n_al_max < 1 || in->n_al_max > BCFGPU_MAX_ALLELES)) return set_err(BCFGPU_E_ARG, "bcfgpu_mcall: n_al_max out of range");
     hipSetDevice(c->cfg.device);
     McallParams m{};
     m.n_sites = in->n_sites; m.n_smpl = c->cfg.n_smpl; m.n_gt_max = in->n_gt_max; m.n_al_max = in->n_al_max;
@@ -452,7 +454,7 @@ int bcfgpu_mcall(bcfgpu_ctx *c, const bcfgpu_call_in *in, const bcfgpu_call_out 
     m.theta = c->call_theta_log; m.pl2p = c->d_pl2p;
     m.nals = in->nals; m.unseen = in->unseen; m.msite = nullptr; m.pl = in->pl; m.qs = in->qs; m.ad = in->ad;
     m.ploidy = in->ploidy; m.grp = c->cfg.n_grp > 1 ? in->grp : nullptr; m.prior_an = in->prior_an; m.prior_ac = in->prior_ac; m.i16 = in->i16;
-    m.out = *out; m.out_n_gt_max = in->n_gt_max;
+    m.out = *out; m.out_n_gt_max = in->n_gt_max; m.err = c->d_err;
     if (c->timing == 1) hipEventRecord(c->ev[2], c->stream);
 #ifdef BCFGPU_DIAG
     { const char *ab = getenv("BCFGPU_ABLATE"); m.ablate = ab ? atoi(ab) : 0; }
@@ -486,7 +488,7 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
     m.qs_u16 = (c->cfg.n_grp > 1 && c->cfg.grp_tag_is_qs) ? mout->qs : nullptr;
     if (c->cfg.n_grp > 1 && !c->cfg.grp_tag_is_qs) { m.ad_u8 = mout->adf; m.ad_u8b = mout->adr; }   // FORMAT/AD = ADF+ADR (bam2bcf.c:892-896)
     m.ploidy = ploidy; m.grp = c->cfg.n_grp > 1 ? grp : nullptr;
-    m.out = *cout; m.out_n_gt_max = BCFGPU_MAX_PL;
+    m.out = *cout; m.out_n_gt_max = BCFGPU_MAX_PL; m.err = c->d_err;
 #ifdef BCFGPU_DIAG
     { const char *ab = getenv("BCFGPU_ABLATE"); m.ablate = ab ? atoi(ab) : 0; }
 #endif

@@ -176,31 +176,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const int site0 = (int)(cell0 / S);
     const int site_last = (int)((cell_end - 1) / S);
 
-    // Phase B's loops run as long as the deepest cell of a wavefront, so the workgroup's cells are dealt to the lanes in
-    // order of depth (a counting sort on reads per cell): a wavefront then holds cells of similar depth.  Results are
-    // written per cell, so which lane computes a cell shows nowhere in the output.
-    __shared__ unsigned int s_bucket[64];
-    __shared__ unsigned short s_perm[WG];
-    if (tid < 64) s_bucket[tid] = 0;
-    __syncthreads();
-    {
-        const long c = cell0 + tid;
-        uint32_t d = 0;
-        if (c < ncells) d = min((P.off[c + 1] - P.off[c]) >> 1, 63u);
-        const uint32_t pos = atomicAdd(&s_bucket[d], 1u);
-        __syncthreads();
-        if (tid < 64) {                                       // exclusive prefix sum of the 64 buckets (one wave)
-            const uint32_t v = s_bucket[tid];
-            uint32_t incl = v;
-            #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (tid >= o) incl += t; }
-            s_bucket[tid] = incl - v;
-        }
-        __syncthreads();
-        s_perm[s_bucket[d] + pos] = (unsigned short)tid;
-        __syncthreads();
-    }
-    const long cell = cell0 + s_perm[tid];
+    const long cell = cell0 + tid;
     const bool active = cell < ncells;
 
     s_fk[tid] = P.fk[tid];

@@ -88,6 +88,7 @@ struct McallParams {
     const float *i16;               // [site][16] INFO/I16 or NULL (fused: msite->anno)
     bcfgpu_call_out out;
     int out_n_gt_max;               // plane count of out.pl / out.gp
+    int *err;                       // device error word
     BCFGPU_ABL_FIELD
 };
 

@@ -155,6 +155,8 @@ __device__ __forceinline__ double set_pdg_one(const double *pl2p, int (&pl)[NG],
     return sum;
 }
 
+// a group id outside [0, n_grp) is reported by grp_check_kernel (BCFGPU_E_RANGE); clamped here so that it cannot index past the tables
+#define GRP_OF(s_) (min(max(P.grp[s_], 0), ngrp - 1))
 __device__ __forceinline__ void write_skipped(bcfgpu_call_site *cs, int ret)
 {
     cs->ret = ret; cs->nals_new = 0; cs->als_new = 0; cs->an = 0; cs->qual = 0; cs->qual_missing = 0; cs->pl_dropped = 0;
@@ -204,6 +206,12 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
         unseen = P.msite[is].unseen > 0 ? P.msite[is].unseen : 0;     // vcfcall.c:1102-1111
     } else { nals = P.nals[is]; unseen = P.unseen[is]; }
     const int ngts = nals * (nals + 1) / 2;
+    // A record outside what the planes can hold (mcall() itself takes up to 32 alleles, mcall.c:1539; B2B_MAX_ALLELES = 5 is
+    // what mpileup writes): refused record by record, ret = -2, and the call as a whole reports BCFGPU_E_RANGE at the next sync.
+    if (nals < 1 || nals > BCFGPU_MAX_ALLELES || ngts > P.n_gt_max || (P.ad && nals > P.n_al_max) || unseen < 0 || unseen >= nals) {
+        if (MAXA == 3 && tid == 0) { write_skipped(cs, -2); atomicExch(P.err, BCFGPU_E_RANGE); }
+        return;
+    }
     // two instantiations share the grid: sites with <=3 alleles run in the small one, the rest in the general one
     if ((nals <= 3) != (MAXA == 3)) return;
     if (BCFGPU_ABL(P, 8)) return;
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                 }
                 xn[k] = x;
             }
-            gnx = s < S ? P.grp[s] : 0;
+            gnx = s < S ? GRP_OF(s) : 0;
         };
         fetch_ad(0);
         for (int base = 0; base < S; base += WGS) {
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             while (nac < 4 && acv[nac] != VEND) nac++;
             if (an > 0 && nac == nals - 1) {
                 int gn = 0;
-                if (ngrp == 1) gn = S; else for (int s = 0; s < S; ++s) gn += (P.grp[s] == g);
+                if (ngrp == 1) gn = S; else for (int s = 0; s < S; ++s) gn += (GRP_OF(s) == g);
                 int ac0 = an;
                 for (int i = 0; i < nals - 1; i++) {
                     if (acv[i] == VEND) break;
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                             for (int j = 0; j < 4; ++j)
                                 if (j < rem) {
                                     if (HAP) pw = (pw & ~(0xffu << (8 * j))) | (uint32_t)P.ploidy[sb + j] << (8 * j);
-                                    if (ngrp > 1 && P.grp[sb + j] != g) gmask &= ~(1u << j);
+                                    if (ngrp > 1 && GRP_OF(sb + j) != g) gmask &= ~(1u << j);
                                 }
                         }
                     }
@@ -593,7 +601,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
         } else {
         for (int t = 0; t < nsub; ++t) { s_man[t * WGS + tid] = 1.0; s_exp[t * WGS + tid] = 0; }
         for (int s = tid; s < (BCFGPU_ABL(P, 16) ? 0 : S); s += WGS) {
-            if (ngrp > 1 && P.grp[s] != g) continue;
+            if (ngrp > 1 && GRP_OF(s) != g) continue;
             int pl[NG]; double pdg[NG];
             load_pl<NG>(P, is, s, ngts, pl);
             const double psum = set_pdg_one<NG>(s_pl2p, pl, pdg, ngts, nals, unseen, s_fill + tid);
@@ -788,7 +796,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             if (allzero || !ploidy) { g0 = BCFGPU_GT_MISSING; g1 = ploidy == 2 ? BCFGPU_GT_MISSING : BCFGPU_GT_VECTOR_END; }
             else { g0 = 0; g1 = ploidy == 2 ? 0 : BCFGPU_GT_VECTOR_END; ac_loc[0] += ploidy; }
         } else {
-            const int g = ngrp > 1 ? P.grp[s] : 0;
+            const int g = ngrp > 1 ? GRP_OF(s) : 0;
             const int gals = grp_als_tab[g * 2];
             gnals = grp_als_tab[g * 2 + 1];
             const float *gq5 = s_gq + g * 5;
@@ -928,11 +936,18 @@ __global__ __launch_bounds__(64) void i16_kernel(const McallParams P)
     }
 }
 
+__global__ void grp_check_kernel(const int32_t *grp, int n_smpl, int n_grp, int *err)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s < n_smpl && (grp[s] < 0 || grp[s] >= n_grp)) atomicExch(err, BCFGPU_E_RANGE);
+}
+
 void launch_mcall(const McallParams &p, hipStream_t s)
 {
     if (p.n_sites == 0) return;
     const int ngrp = p.n_grp > 1 ? p.n_grp : 1;
     const size_t lds = (size_t)ngrp * 5 * sizeof(float) + (size_t)ngrp * 2 * sizeof(int);
+    if (p.grp && ngrp > 1) hipLaunchKernelGGL(grp_check_kernel, dim3((p.n_smpl + 255) / 256), dim3(256), 0, s, p.grp, p.n_smpl, ngrp, p.err);
     #define MCALL_LAUNCH3(FAST_, HAP_, GRP_) do { \
         hipLaunchKernelGGL((mcall_kernel<3, 7, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \
         hipLaunchKernelGGL((mcall_kernel<5, 15, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \

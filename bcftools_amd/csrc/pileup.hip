@@ -267,6 +267,16 @@ __global__ __launch_bounds__(256) void subtile_kernel(const EntriesParams E, uin
 using namespace bcfgpu;
 
 // seq_nt16_table restricted to what a reference sequence holds (IUPAC codes, case-insensitive; anything else is N)
+// sum of the per-cell counts in 64 bits (grid-stride, one atomic per workgroup)
+__global__ __launch_bounds__(256) void count_total_kernel(const uint32_t *cnt, size_t n, unsigned long long *tot)
+{
+    unsigned long long v = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) v += cnt[i];
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(tot, v);
+}
+
 static int ref_nt16(char c)
 {
     static const char *codes = "=ACMGRSVTWYHKDBN";
@@ -406,14 +416,22 @@ extern "C" int bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const uint
     if (trace) { hipStreamSynchronize(stream); fprintf(stderr, "[pileup] pool on the device at %.2f ms\n", ms_now()); }
     if (ncells) {
         hipLaunchKernelGGL(pileup_kernel<false>, dim3(grid), dim3(256), 0, stream, P);
+        // the total in 64 bits first: plp_off is 32-bit, a region whose pileup reaches 2^32 entries must be refused, not wrapped
+        unsigned long long *d_tot64 = (unsigned long long*)bcfgpu_internal_ws(ctx, 34, 64);
+        if (!d_tot64) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup: device workspace");
+        PL_CHK(hipMemsetAsync(d_tot64, 0, 8, stream));
+        hipLaunchKernelGGL(count_total_kernel, dim3((unsigned)std::min<size_t>((ncells + 4095) / 4096, 65535)), dim3(256), 0, stream, d_cnt, ncells, d_tot64);
         // plp_off = exclusive prefix sum of the counts (in place, one element past the end for the total)
         size_t tmp_bytes = 0;
         PL_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_cnt, (int)(ncells + 1), stream));
         void *d_tmp = bcfgpu_internal_ws(ctx, 31, tmp_bytes + 16);
         if (!d_tmp) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup: device workspace");
         PL_CHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_cnt, (int)(ncells + 1), stream));
+        unsigned long long tot64 = 0;
         PL_CHK(hipMemcpyAsync(&total, d_cnt + ncells, 4, hipMemcpyDeviceToHost, stream));
+        PL_CHK(hipMemcpyAsync(&tot64, d_tot64, 8, hipMemcpyDeviceToHost, stream));
         PL_CHK(hipStreamSynchronize(stream));
+        if (tot64 >> 32) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_pileup: the region's pileup has 2^32 or more entries; use a smaller region per call");
     }
     if (trace) fprintf(stderr, "[pileup] counted and scanned at %.2f ms (%u entries)\n", ms_now(), total);
     // the read records: the scan's temporary storage is done with, its slot is reused (grow-only) for rd + epos

@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--groups", type=int, default=1, help="snp mode: call -G with this many sample groups (frequencies from FORMAT/AD); "
                                                           ">1 takes the general caller path (BASELINE configs[4] shape)")
     ap.add_argument("--haploid-frac", type=float, default=0.0, help="snp mode: fraction of haploid samples (ploidy array; general caller path)")
+    ap.add_argument("--extras", type=int, default=1, help="snp mode at N=1: also measure the BASELINE configs[4] shape (sample groups + ploidy array) and "
+                                                          "the indel stage (configs[2] shape) in child processes and embed their results under \"extra\" (0: skip)")
     ap.add_argument("--indel-callers", type=int, default=2, help="indel mode: also time this many caller threads, one context each (1: skip)")
     ap.add_argument("--mode", choices=["snp", "indel", "baq", "pileup", "gvcf"], default="snp",
                     help="snp: the headline pipeline (default).  indel: bcf_call_gap_prep on synthetic indel-candidate columns "
@@ -83,6 +85,7 @@ def main_indel(a):
     per = 32
     ctx = engine.Context(abi.default_cfg(S, max_sites=per, max_reads=64))
     indeldrv.gap_prep_gpu(ctx, synth.indel_batch(a.seed, 2, 8, depth=10.0))          # warm-up: module load
+    indeldrv.gap_prep_gpu(ctx, synth.indel_batch(a.seed, min(per, n_sites), S, depth=a.depth))   # ... and the grow-only workspaces at full size
     tot = dict(jobs=0, passes=0, cells=0, kernel=0.0, prepare=0.0, finalize=0.0, total=0.0, sites=0, live=0, entries=0)
     first = None
     pass_ctx = {}
@@ -108,7 +111,7 @@ def main_indel(a):
             tot["pass_glfgen"] = tot.get("pass_glfgen", 0.0) + tmg["glfgen_ms"]
             tot["pass_combine"] = tot.get("pass_combine", 0.0) + tmg["combine_ms"]
             tot["records"] = tot.get("records", 0) + int((res.site["ret"] == 0).sum())
-    out = {"metric": "indel-candidate columns/sec through bcf_call_gap_prep (host typing + probaln_kernel), %d samples x %.0fx" % (S, a.depth),
+    out = {"metric": "indel-candidate columns/sec through bcf_call_gap_prep (typing, consensus, realignment, indelQ: all device kernels), %d samples x %.0fx" % (S, a.depth),
            "value": tot["sites"] / (tot["total"] * 1e-3), "unit": "sites/s", "n_gpus": 1, "higher_is_better": True,
            "dtype": "f64 pair-HMM forward", "data": "synthetic",
            "config": {"workload": "synthetic indel-candidate columns (BASELINE configs[2] shape), batches of %d columns" % per,
@@ -517,13 +520,14 @@ def main():
     out = None
     if rank == 0:
         alg = algorithmic_bytes(T, S, R)
-        # HBM traffic of the dominant kernel: PMC-measured (profiles/r1_traffic.json, rocprofv3 FETCH_SIZE x2 + WRITE_SIZE
-        # as MI355X_MICROARCH.md prescribes for gfx950), scaled from the profiled tile to this one by the site count
+        # HBM traffic of the dominant kernel: PMC-measured on a launch of this very shape (tools/profile.sh: rocprofv3 --pmc,
+        # FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950, separate passes), never scaled: a run
+        # with another tile shape reports null
         traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-            if tj["samples"] == S and abs(tj["depth"] - a.depth) < 1e-9:
-                traffic = tj["hbm_bytes_per_launch"] * (T / tj["sites"])
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
+            if tj["samples"] == S and abs(tj["depth"] - a.depth) < 1e-9 and tj["sites"] == T:
+                traffic = tj["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
         kern_s = tm["glfgen_ms"] * 1e-3
@@ -545,6 +549,9 @@ def main():
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": tm["glfgen_ms"],
                          "other_kernels_ms": {"combine_kernel": tm["combine_ms"], "mcall_kernel": tm["mcall_ms"]},
                          # the two smaller kernels against the same roofline: bytes they must move per cell
+                         "other_kernels_frac": {
+                             "combine_kernel": (T * S * (84 + 8 + 15 + 4)) / (tm["combine_ms"] * 1e-3) / 8e12 if tm["combine_ms"] > 0 else None,
+                             "mcall_kernel": (T * S * (15 + 2 + 12)) / (tm["mcall_ms"] * 1e-3) / 8e12 if tm["mcall_ms"] > 0 else None},
                          "other_kernels_gbs": {
                              "combine_kernel": (T * S * (84 + 8 + 15 + 4)) / (tm["combine_ms"] * 1e-3) / 1e9 if tm["combine_ms"] > 0 else None,
                              "mcall_kernel": (T * S * (15 + 2 + 12)) / (tm["mcall_ms"] * 1e-3) / 1e9 if tm["mcall_ms"] > 0 else None}},
@@ -599,6 +606,28 @@ def main():
                     out["cpu_baseline"]["all_cores"] = {"value": sum(int(r[0]) for r in res) / tmax, "unit": "sites/s",
                                                         "cores": ncore, "sample": "%d region shards of %d sites x %d passes, one "
                                                         "oracle process per core, %.1f s" % (ncore, per, reps, tmax)}
+        # ---- the other BASELINE shapes, measured in child processes (their own contexts and tiles) ----
+        if world == 1 and a.extras and a.groups == 1 and a.haploid_frac == 0.0:
+            import subprocess
+
+            def child(args, timeout=600):
+                try:
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+                    for ln in reversed(r.stdout.strip().splitlines()):
+                        if ln.startswith("{"):
+                            return json.loads(ln)
+                    return {"error": (r.stderr or r.stdout)[-300:]}
+                except Exception as e:                       # a failed extra must not take the headline with it
+                    return {"error": repr(e)}
+            common = ["--cpu-seconds", "0", "--cpu-all-cores", "0", "--extras", "0", "--seed", str(a.seed)]
+            c4 = child(["--groups", "4", "--haploid-frac", "0.25", "--steps", str(max(3, a.steps // 2)), "--warmup", "2",
+                        "--samples", str(S), "--depth", str(a.depth), "--sites", str(T)] + common)
+            ind = child(["--mode", "indel", "--steps", "4"] + common)
+            out["extra"] = {
+                "configs4_shape": {k: c4.get(k) for k in ("value", "unit", "ms_per_step", "config", "roofline", "error") if k in c4},
+                "indel_stage": {k: ind.get(k) for k in ("metric", "value", "unit", "config", "kernel", "host_ms", "indel_pass", "error") if k in ind},
+                "note": "configs4_shape: the same tile through call -G (4 sample groups on FORMAT/AD) with a ploidy array (25 % haploid); "
+                        "indel_stage: bcf_call_gap_prep on 500-sample indel-candidate columns (BASELINE configs[2] shape), whole calls with host pointers"}
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

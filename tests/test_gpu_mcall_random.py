@@ -146,3 +146,33 @@ def test_pv4_of_reference_golden_on_device(golden_dir, gpu_ctx_factory):
         else:
             assert int(st["pv4_tested"]) == 0
     assert n_pv4 == 11
+
+
+def test_records_outside_the_supported_range_are_refused(gpu_ctx_factory):
+    """mcall() itself takes up to 32 alleles (mcall.c:1539); the planes of this ABI hold B2B_MAX_ALLELES = 5.  A record with
+    more, or a sample group id outside [0, n_grp), must not index past the kernel's tables: the record gets ret = -2, the
+    others are called as usual, and the call reports BCFGPU_E_RANGE."""
+    from bcftools_amd.lib import BcfGpuError
+    n_sites, n_smpl = 12, 30
+    cin = random_records(5, n_sites, n_smpl, False, 1, False)
+    nals0 = cin.nals.copy()
+    cin.nals = cin.nals.copy()
+    cin.nals[3] = 6
+    cin.nals[7] = 0
+    ctx = gpu_ctx_factory(abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=64))
+    with pytest.raises(BcfGpuError) as e:
+        ctx.mcall(cin)
+    assert e.value.code == abi.E_RANGE
+    # the context stays usable and the valid records of a later call are untouched by the refusal
+    cin.nals = nals0
+    res = ctx.mcall(cin)
+    want = orc.mcall(abi.default_cfg(n_smpl), cin)
+    assert_call_equal(res, want, n_smpl)
+    # a group id out of range
+    cing = random_records(6, n_sites, n_smpl, False, 3, False)
+    cing.grp = cing.grp.copy()
+    cing.grp[5] = 7
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=64, n_grp=3)
+    with pytest.raises(BcfGpuError) as e:
+        gpu_ctx_factory(cfg).mcall(cing)
+    assert e.value.code == abi.E_RANGE

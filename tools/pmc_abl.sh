@@ -7,7 +7,7 @@ make -s -C $R/bcftools_amd/csrc clean >/dev/null; make -s -j8 -C $R/bcftools_amd
 for a in "$@"; do
   OUT=$R/gpurun_out/pmcabl_$a; rm -rf $OUT; mkdir -p $OUT
   export BCFGPU_ABLATE=$a
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU -d $OUT -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --sites 4096 --cpu-seconds 0 --cpu-all-cores 0 > $OUT/log 2>&1 || { tail -5 $OUT/log; }
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU -d $OUT -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --sites 4096 --cpu-seconds 0 --cpu-all-cores 0 --extras 0 > $OUT/log 2>&1 || { tail -5 $OUT/log; }
   python3 - <<PY
 import csv,glob
 acc={}
