@@ -145,7 +145,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
             (rc = dev_alloc(c, (void**)&c->cr.qs64, ncells * 8)) ||
             (rc = dev_alloc(c, (void**)&c->cr.adf, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->cr.adr, ncells * 4)) ||
             (rc = dev_alloc(c, (void**)&c->cr.cnt4, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->d_site_sums, (size_t)cfg->max_sites * SITE_NSUM * 8)) ||
-            (rc = dev_alloc(c, (void**)&c->cr.misc, ncells * 4))) {
+            (rc = dev_alloc(c, (void**)&c->cr.misc, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->cr.pa, ncells * 4))) {
             bcfgpu_destroy(c); return rc;
         }
     }
@@ -372,18 +372,25 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     // one workgroup = 256 consecutive cells = at most (255/S)+2 sites
     const int slots = 255 / S + 2;
     g.hist_slots = slots <= 8 ? slots : 0;
-    // LDS: two bytes per read of the workgroup's span.  Sized from the tile's mean depth (+15 % and a constant for the
-    // spread of a 256-cell sum) so that shallow tiles leave room for more workgroups per CU; at most what lets four
-    // workgroups share a CU (160 KiB are handed out in 128 blocks of 1280 bytes: 32 blocks each).  A span that does not
-    // fit is worked off in several rounds.
+    // LDS: two bytes per read of the workgroup's span, sized from the tile's mean depth (a 256-cell sum: +4 % and a
+    // constant cover its spread) so that shallow tiles leave room for more workgroups per CU.  160 KiB are handed out in
+    // 128 blocks of 1280 bytes: the span gets what lets the most workgroups (at most six: the kernel runs five to six
+    // wavefronts per SIMD) share a CU while still holding `want` keys; a span that does not fit is worked off in rounds.
     {
         const double mean = (double)tile->n_reads / ((double)tile->n_sites * S);
-        long want = (long)(mean * 256 * 1.15) + 768;
-        want = (want + 15) & ~15L;
-        int cap = 16384;
-        while (cap > 2048 && glfgen_lds_bytes(cap, g.hist_slots) + 16 > 32 * 1280) cap -= 16;
-        if (want < 2048) want = 2048;
-        g.lds_cap = want < cap ? (int)want : cap;
+        long want = (long)(mean * 256 * 1.04) + 512;
+        want = std::max(2048L, (want + 15) & ~15L);
+        int cap = 0;
+        for (int wgs = 6; wgs >= 3 && !cap; --wgs) {
+            const long budget = (long)(128 / wgs) * 1280 - 32;
+            long c = (budget - (long)glfgen_lds_bytes(0, g.hist_slots)) / 2;
+            c = std::min(c & ~15L, 16384L);
+            if (c >= want || wgs == 3) cap = (int)std::min(std::max(c, 2048L), want);
+        }
+        g.lds_cap = cap;
+        int pc = 64;
+        while (pc > 4 && 12 * std::max(g.hist_slots, 1) * pc > 2048) pc >>= 1;
+        g.part_cols = pc;
     }
     g.n_reads = (uint32_t)tile->n_reads;
 #ifdef BCFGPU_DIAG
@@ -395,6 +402,19 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     // the callret planes are addressed with ncells of *this* tile
     g.hist = c->d_hist; g.err = c->d_err; g.site_sums = c->d_site_sums;
     g.trunc = reinterpret_cast<unsigned int*>(c->d_err + 1);
+#ifdef BCFGPU_DIAG
+    {   // phase stamps of glfgen_kernel: totals of the previous launch are printed, then cleared
+        static unsigned long long *d_st = nullptr;
+        if (!d_st) { hipMalloc(&d_st, 16 * 8); hipMemset(d_st, 0, 16 * 8); }
+        if (getenv("BCFGPU_STAMPS")) {
+            unsigned long long h[16]; hipStreamSynchronize(c->stream); hipMemcpy(h, d_st, sizeof h, hipMemcpyDeviceToHost);
+            unsigned long long tot = 0; for (int i = 0; i < 9; ++i) tot += h[i];
+            if (tot) { fprintf(stderr, "[glfgen stamps %%]"); for (int i = 0; i < 9; ++i) fprintf(stderr, " %.1f", 100.0 * h[i] / tot); fprintf(stderr, "  (total %.3g wave-cycles)\n", (double)tot); }
+            hipMemset(d_st, 0, 16 * 8);
+        }
+        g.stamps = d_st;
+    }
+#endif
     HIPCHK(hipMemsetAsync(c->d_hist, 0, (size_t)tile->n_sites * H_SIZE * sizeof(int), c->stream));
     HIPCHK(hipMemsetAsync(c->d_site_sums, 0, (size_t)tile->n_sites * SITE_NSUM * 8, c->stream));
     hipEvent_t *ev = c->timing ? seq_events(c) : nullptr;

@@ -163,7 +163,7 @@ __device__ __forceinline__ double dev_logsumexp2(double a, double b)
 struct SiteShared {
     int a[5]; int n_alleles, unseen, ori_ref, x;
     float qsum_out[5];
-    int g[15];
+    int g[15], g1[15], g2[15];
     unsigned long long tot[32];   // integer totals
     double segb_sum; double sum_min;
     float bias[6];
@@ -220,7 +220,7 @@ template <int V> __device__ __forceinline__ void store_bytes(uint8_t *p, const u
     else p[0] = (uint8_t)b[0];
 }
 template <int NAL, int V>
-__device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTotals &T, const int (&gs)[15], const int (&as)[5],
+__device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTotals &T, const int (&gs)[15], const int (&g1s)[15], const int (&g2s)[15], const int (&as)[5],
                                               int is, long c0, int base, int cn, int tid, long ncells, double *s_min)
 {
     constexpr int X = NAL * (NAL + 1) / 2;
@@ -231,13 +231,43 @@ __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTota
         float mn[V];
         #pragma unroll
         for (int v = 0; v < V; ++v) mn[v] = 0.f;
+        uint32_t cnt4[V], adf[V], adr[V], misc[V];
+        load_v<V>(P.cr.cnt4 + cell, cnt4); load_v<V>(P.cr.adf + cell, adf); load_v<V>(P.cr.adr + cell, adr); load_v<V>(P.cr.misc + cell, misc);
         if (NAL > 0) {
             float pv[X > 0 ? X : 1][V];
+            // single-base cells: the planes from (A, b, n), see CallretPlanes; the rest from the stored likelihoods
+            float pa[V], ph[V];
+            load_v<V>(P.cr.pa + cell, pa);
+            bool any_full = false;
+            #pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const int nrd = (int)((cnt4[v] & 0xff) + ((cnt4[v] >> 8) & 0xff) + ((cnt4[v] >> 16) & 0xff) + (cnt4[v] >> 24));
+                float h = 0.0f;
+                if (nrd > 0) { h = (float)(-4.343 * (0.0 - M_LN2 * nrd)); if (h < 0.0f) h = 0.0f; }    // lhet[n<<8|n] = lhet[n<<8|0] = -ln2*n (tables.cpp)
+                ph[v] = h;
+                any_full |= (misc[v] & CR_FULL) != 0;
+            }
             #pragma unroll
             for (int v = 0; v < V; ++v) mn[v] = FLT_MAX;
             #pragma unroll
             for (int j = 0; j < X; ++j) {
-                load_v<V>(P.cr.p15 + (size_t)gs[j] * ncells + c0 + s, pv[j]);
+                const int b1 = g1s[j], b2 = g2s[j];                // the two bases of genotype j (scalar)
+                #pragma unroll
+                for (int v = 0; v < V; ++v) {
+                    const int b = (int)(misc[v] & 7);
+                    pv[j][v] = b1 == b2 ? (b1 == b ? 0.0f : pa[v]) : ((b1 == b || b2 == b) ? ph[v] : pa[v]);
+                }
+            }
+            if (__any(any_full)) {
+                #pragma unroll
+                for (int j = 0; j < X; ++j) {
+                    #pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        if (misc[v] & CR_FULL) pv[j][v] = P.cr.p15[(size_t)gs[j] * ncells + c0 + s + v];
+                }
+            }
+            #pragma unroll
+            for (int j = 0; j < X; ++j) {
                 #pragma unroll
                 for (int v = 0; v < V; ++v) if (mn[v] > pv[j][v]) mn[v] = pv[j][v];
             }
@@ -256,8 +286,6 @@ __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTota
         }
         #pragma unroll
         for (int v = 0; v < V; ++v) s_min[i + v] = (double)mn[v];        // widened here, by all lanes, for the sequential sum
-        uint32_t cnt4[V], adf[V], adr[V], misc[V];
-        load_v<V>(P.cr.cnt4 + cell, cnt4); load_v<V>(P.cr.adf + cell, adf); load_v<V>(P.cr.adr + cell, adr); load_v<V>(P.cr.misc + cell, misc);
         if (NAL > 0 && !BCFGPU_ABL(P, 512)) {
             uint8_t *DP4 = P.out.dp4 + (size_t)is * 4 * Ss + s;
             uint32_t b[V];
@@ -297,7 +325,6 @@ __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTota
         }
         #pragma unroll
         for (int v = 0; v < V; ++v) {
-            T.ori += misc[v] >> 16; T.mq0 += misc[v] & 0xff;
             #pragma unroll
             for (int j = 0; j < 4; ++j) T.cnt[j] += (cnt4[v] >> (8 * j)) & 0xff;
         }
@@ -381,7 +408,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         sh.x = sh.n_alleles * (sh.n_alleles + 1) / 2;
         int z = 0;
         for (i = 0; i < sh.n_alleles; ++i)
-            for (j = 0; j <= i; ++j) sh.g[z++] = tri_c(sh.a[j], sh.a[i]);
+            for (j = 0; j <= i; ++j) { sh.g1[z] = sh.a[j]; sh.g2[z] = sh.a[i]; sh.g[z++] = tri_c(sh.a[j], sh.a[i]); }
         site->ret = ret;
     }
     __syncthreads();
@@ -395,9 +422,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     for (int j = 0; j < 5; ++j) T.adf[j] = T.adr[j] = 0;
     T.scr = T.ori = T.mq0 = 0; T.cnt[0] = T.cnt[1] = T.cnt[2] = T.cnt[3] = 0;
     // the allele order is uniform over the wavefront: keep it in scalar registers so that plane addresses are scalar
-    int gs[15], as[5];
+    int gs[15], g1s[15], g2s[15], as[5];
     #pragma unroll
-    for (int j = 0; j < 15; ++j) gs[j] = __builtin_amdgcn_readfirstlane(j < x ? sh.g[j] : 0);
+    for (int j = 0; j < 15; ++j) {
+        gs[j] = __builtin_amdgcn_readfirstlane(j < x ? sh.g[j] : 0);
+        g1s[j] = __builtin_amdgcn_readfirstlane(j < x ? sh.g1[j] : 0); g2s[j] = __builtin_amdgcn_readfirstlane(j < x ? sh.g2[j] : 0);
+    }
     #pragma unroll
     for (int j = 0; j < 5; ++j) as[j] = __builtin_amdgcn_readfirstlane(j < nal ? sh.a[j] : 4);
     double *s_min = reinterpret_cast<double*>(s_stage);
@@ -406,12 +436,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         __syncthreads();
         const bool live = !dead && !BCFGPU_ABL(P, 256);
         #define PLANES(V_) switch (live ? nal : 0) { \
-            case 1: sample_planes<1, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; \
-            case 2: sample_planes<2, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; \
-            case 3: sample_planes<3, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; \
-            case 4: sample_planes<4, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; \
-            case 5: sample_planes<5, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; \
-            default: sample_planes<0, V_>(P, T, gs, as, is, c0, base, cn, tid, ncells, s_min); break; }
+            case 1: sample_planes<1, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min); break; \
+            case 2: sample_planes<2, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min); break; \
+            case 3: sample_planes<3, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min); break; \
+            case 4: sample_planes<4, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min); break; \
+            case 5: sample_planes<5, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min); break; \
+            default: sample_planes<0, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min); break; }
         PLANES(V)
         #undef PLANES
         __syncthreads();
@@ -544,7 +574,7 @@ void launch_combine(const CombineParams &p, hipStream_t s)
     // four samples per lane need every site's row of every plane to start on a 16-byte (u8 planes: 4-byte) boundary
     auto al = [](const void *ptr, uintptr_t a) { return ptr == nullptr || reinterpret_cast<uintptr_t>(ptr) % a == 0; };
     q.vec4 = (p.n_smpl % 4 == 0) && !BCFGPU_ABL(p, 1024) &&
-             al(p.cr.p15, 16) && al(p.cr.cnt4, 16) && al(p.cr.adf, 16) && al(p.cr.adr, 16) && al(p.cr.misc, 16) && al(p.cr.qs64, 8) &&
+             al(p.cr.p15, 16) && al(p.cr.pa, 16) && al(p.cr.cnt4, 16) && al(p.cr.adf, 16) && al(p.cr.adr, 16) && al(p.cr.misc, 16) && al(p.cr.qs64, 8) &&
              al(p.out.pl, 4) && al(p.out.dp4, 4) && al(p.out.scr, 4) && al(p.out.adf, 4) && al(p.out.adr, 4) && al(p.out.qs, 8);
     if (q.vec4) hipLaunchKernelGGL(combine_kernel<4>, dim3(q.n_sites), dim3(WG), 0, s, q);
     else hipLaunchKernelGGL(combine_kernel<1>, dim3(q.n_sites), dim3(WG), 0, s, q);

@@ -27,7 +27,21 @@
 
 namespace bcfgpu {
 
+// Diagnostics build: cycles (s_memtime) every wavefront spends between the kernel's phase boundaries, summed into
+// P.stamps[0..8] (0: prologue up to phase A, 1: phase A, 2: barrier, 3: partial sums + slice set-up, 4: pass 1,
+// 5: walk of the primary base, 6: other bases, 7: epilogue, 8: flush); tools/pmc_abl.sh prints them.
+#ifdef BCFGPU_DIAG
+#define GLF_STAMP_DECL unsigned long long stamp_t_ = __builtin_amdgcn_s_memtime();
+#define GLF_STAMP(i_) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && P.stamps) atomicAdd(&P.stamps[i_], now_ - stamp_t_); stamp_t_ = now_; }
+#else
+#define GLF_STAMP_DECL
+#define GLF_STAMP(i_)
+#endif
+
 #define WG 256
+#ifndef GLF_WAVES
+#define GLF_WAVES 4          // wavefronts per SIMD the register budget is held to
+#endif
 #define DEF_MAPQ 20
 #define CAP_DIST 25
 
@@ -43,7 +57,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return v;
 }
 
-// LDS layout (bytes): fk[264] f64 | slots[NSLOT/4][WG] u32 | hist [slots][H_SIZE] i32 | site totals [slots][SITE_NSUM] u64 | keys u16[cap+8]
+// LDS layout (bytes): fk[264] f64 | slots[NSLOT/2][WG] u32 (a dword per quality rank) | hist [slots][H_SIZE] i32 | site totals [slots][SITE_NSUM] u64 | keys u16[cap+8]
 #define LDS_FK   0
 #define LDS_CNT  2112
 #define NSLOT    16
@@ -53,7 +67,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 #ifndef WSTEP
 #define WSTEP    3         // reads of one (quality, strand) run taken per step of the errmod walk
 #endif
-#define LDS_HIST_OFF (LDS_CNT + (NSLOT / 4) * WG * 4)
+#define LDS_HIST_OFF (LDS_CNT + (NSLOT / 2) * WG * 4)
 #define NPART 12           // per-lane partial sums of phase A: the I16 site totals anno[4..15]
 
 // the u16 key phase A leaves for phase B
@@ -63,15 +77,16 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 #define KEY_B(k)    (((k) >> 7) & 7u)
 #define KEY_SC(k)   (((k) >> 10) & 1u)
 
-// Counts, as u8 in the lane's slot column, of the reads with the NSLOT/2 highest qualities of the mask `qm` (bit q = some
-// read of this base has quality q): slot 2*rank(q) holds the reverse-strand reads of q, slot 2*rank(q)+1 the forward
-// ones -- the descending order of errmod_cal's sorted codes q<<5|strand<<4|base (bam2bcf.c:203).  `src(j)` returns
-// key7 = q<<1|strand of source element j, or -1.
+// Counts of the reads with the NSLOT/2 highest qualities of the mask `qm` (bit q = some read of this base has quality q), in
+// the lane's slot column: the dword of rank(q) holds the reverse-strand reads of q in its low half and the forward-strand
+// ones in its high half -- reverse first is the descending order of errmod_cal's sorted codes q<<5|strand<<4|base
+// (bam2bcf.c:203).  `src(j)` returns key7 = q<<1|strand of source element j, or -1.
 template <bool FIRST, class Src>
 __device__ __forceinline__ void fill_slots(uint32_t *s_slot, uint64_t qm, int tid, Src src, int nsrc)
 {
     #pragma unroll
-    for (int k = 0; k < NSLOT / 4; ++k) s_slot[k * WG + tid] = 0;
+    for (int k = 0; k < NSLOT / 2; ++k) s_slot[k * WG + tid] = 0;
+    const uint64_t qm1 = qm >> 1;                                   // rank of q = qualities above it = popcount(qm >> (q + 1))
     // FU source elements per trip: their reads are in flight before the first count is added
     for (int j = 0; __any(j < nsrc); j += FU) {
         int k4[FU];
@@ -82,8 +97,8 @@ __device__ __forceinline__ void fill_slots(uint32_t *s_slot, uint64_t qm, int ti
             const int key = k4[u];
             const int q = (key >> 1) & 63;
             if (key >= 0 && (FIRST || ((qm >> q) & 1ull))) {       // FIRST: the mask still holds every quality of the source
-                const int r = 2 * __popcll((qm >> q) >> 1) + 1 - (key & 1);
-                if (r < NSLOT) atomicAdd(&s_slot[(r >> 2) * WG + tid], 1u << (8 * (r & 3)));
+                const int r = __popcll(qm1 >> q);
+                if (r < NSLOT / 2) atomicAdd(&s_slot[r * WG + tid], (key & 1) ? 1u : 0x10000u);
             }
         }
     }
@@ -100,7 +115,7 @@ __device__ __forceinline__ void fill_slots(uint32_t *s_slot, uint64_t qm, int ti
 // slots refilled for the remaining ones (binned base qualities give a handful).
 // `brow`: byte offset of beta[0][0][n] (stored q, k, n: tables.cpp; the q = 0 row is all zeros).
 #ifndef WCH
-#define WCH 4
+#define WCH 3
 #endif
 template <class Src>
 __device__ __forceinline__ double walk_ranks(uint32_t *s_slot, uint64_t qm, const double *s_fk, const char *bbase, int tid,
@@ -108,36 +123,60 @@ __device__ __forceinline__ double walk_ranks(uint32_t *s_slot, uint64_t qm, cons
 {
     double bs = 0;
     uint32_t cc = 0, w0 = 0, w1 = 0, qs = 0;
-    bool first = true;
-    while (__any(qm != 0)) {
-        if (first) fill_slots<true>(s_slot, qm, tid, src, nsrc); else fill_slots<false>(s_slot, qm, tid, src, nsrc);
-        first = false;
-        for (int r = 0; r < NSLOT / 2 && __any(qm != 0); ++r) {
-            const int curq = 63 - __clzll((long long)(qm | 1ull));          // a lane that has run out of qualities: 0, with empty slots
-            qm &= ~(1ull << curq);
-            const uint32_t two = (s_slot[(r >> 1) * WG + tid] >> (16 * (r & 1))) & 0xffffu;
-            const uint32_t cr = two & 0xff, cf = two >> 8;
-            qs += (uint32_t)curq * (cr + cf);
-            uint32_t bo = brow + ((uint32_t)curq << 19) + (cc << 11);
-            #pragma unroll 1
-            for (int sd = 0; sd < 2; ++sd) {                                 // reverse strand first: the larger code
-                const uint32_t m = sd ? cf : cr, w = sd ? w0 : w1;
-                for (uint32_t t0 = 0; __any(t0 < m); t0 += WCH) {
-                    double bv[WCH], fv[WCH];
-                    #pragma unroll
-                    for (int j = 0; j < WCH; ++j) {
-                        const bool a = t0 + j < m;
-                        bv[j] = *reinterpret_cast<const double*>(bbase + (a ? bo + ((t0 + j) << 11) : brow));
-                        fv[j] = s_fk[a ? w + t0 + j : 256u];
-                    }
-                    #pragma unroll
-                    for (int j = 0; j < WCH; ++j) bs += fv[j] * bv[j];
-                }
-                bo += m << 11;
+    // the run being walked: m reads, fk index w.., beta offset bo..; (r, sd, t0) are the same in every lane
+    uint32_t cr = 0, cf = 0, m = 0, w = 0, bo = brow, bo_rank = brow, t0 = 0;
+    int r = 0, sd = 0;
+    bool started = false;
+    if (__any(qm != 0)) fill_slots<true>(s_slot, qm, tid, src, nsrc);
+    // moves on to the next run that holds a read in some lane; false when every lane is through (uniform)
+    auto next_run = [&]() -> bool {
+        for (;;) {
+            if (started && sd == 0) {                                     // reverse strand done: the forward reads of the same quality
+                sd = 1; m = cf; w = w0; bo = bo_rank + (cr << 11);
+            } else {
+                if (started) { cc += cr + cf; w1 += cr; w0 += cf; ++r; }
+                started = true;
+                if (!__any(qm != 0)) return false;
+                if (r == NSLOT / 2) { fill_slots<false>(s_slot, qm, tid, src, nsrc); r = 0; }
+                const int curq = 63 - __clzll((long long)(qm | 1ull));    // a lane that has run out of qualities: 0, with empty slots
+                qm &= ~(1ull << curq);
+                const uint32_t two = s_slot[r * WG + tid];
+                cr = two & 0xffff; cf = two >> 16;
+                qs += (uint32_t)curq * (cr + cf);
+                bo_rank = brow + ((uint32_t)curq << 19) + (cc << 11);
+                sd = 0; m = cr; w = w1; bo = bo_rank;
             }
-            cc += cr + cf; w1 += cr; w0 += cf;
+            t0 = 0;
+            if (__any(m > 0)) return true;
         }
+    };
+    // the loads of one chunk (WCH reads of the current run from t0 on); a lane past the end of its run reads fk = +0 and a
+    // finite table entry
+    #define WALK_ISSUE(B, F) do { \
+        _Pragma("unroll") \
+        for (int j_ = 0; j_ < WCH; ++j_) { \
+            const bool a_ = t0 + j_ < m; \
+            B[j_] = *reinterpret_cast<const double*>(bbase + (a_ ? bo + ((t0 + j_) << 11) : brow)); \
+            F[j_] = s_fk[a_ ? w + t0 + j_ : 256u]; \
+        } } while (0)
+    #define WALK_ADD(B, F) do { _Pragma("unroll") for (int j_ = 0; j_ < WCH; ++j_) bs += F[j_] * B[j_]; } while (0)
+    #define WALK_STEP() (t0 += WCH, __any(t0 < m) ? true : next_run())
+    // one chunk ahead: the next chunk's gathers (L2 latency) are in flight while the current one is added, in order
+    double bx[WCH], fx[WCH], by[WCH], fy[WCH];
+    bool more = next_run();
+    if (more) WALK_ISSUE(bx, fx);
+    while (more) {
+        const bool more2 = WALK_STEP();
+        if (more2) WALK_ISSUE(by, fy);
+        WALK_ADD(bx, fx);
+        if (!more2) break;
+        more = WALK_STEP();
+        if (more) WALK_ISSUE(bx, fx);
+        WALK_ADD(by, fy);
     }
+    #undef WALK_ISSUE
+    #undef WALK_ADD
+    #undef WALK_STEP
     rev_out = w1; qs_out = qs;
     return bs;
 }
@@ -156,7 +195,7 @@ struct WaveCounts {
 };
 
 template <bool INDEL, bool LDS_HIST>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void glfgen_kernel(const GlfgenParams P)
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, GLF_WAVES))) void glfgen_kernel(const GlfgenParams P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int cap = P.lds_cap;
@@ -164,11 +203,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     uint32_t *s_cnt = reinterpret_cast<uint32_t*>(smem + LDS_CNT);
     int      *s_hist = reinterpret_cast<int*>(smem + LDS_HIST_OFF);
     unsigned long long *s_tot = reinterpret_cast<unsigned long long*>(s_hist + (size_t)P.hist_slots * H_SIZE);   // [slots][SITE_NSUM]
-    uint32_t *s_part = reinterpret_cast<uint32_t*>(s_tot + (size_t)P.hist_slots * SITE_NSUM);       // [slots][NPART][64]
-    uint16_t *s_key = reinterpret_cast<uint16_t*>(s_part + (size_t)P.hist_slots * NPART * 64);
+    // phase A's per-lane partial sums [slots][NPART][pcol] share the slot counters' LDS: they are added up and cleared
+    // before phase B takes the region
+    uint32_t *s_part = s_cnt;
+    const int pcol = P.part_cols;                    // columns per value: a power of two, NPART * slots * pcol <= 2048
+    uint16_t *s_key = reinterpret_cast<uint16_t*>(s_tot + (size_t)P.hist_slots * SITE_NSUM);
     __shared__ unsigned int s_next;
 
     const int tid = threadIdx.x;
+    GLF_STAMP_DECL
     const int S = P.n_smpl;
     const long ncells = (long)P.n_sites * S;
     const long cell0 = (long)blockIdx.x * WG;
@@ -184,7 +227,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (LDS_HIST) {
         for (int i = tid; i < P.hist_slots * H_SIZE; i += WG) s_hist[i] = 0;
         for (int i = tid; i < P.hist_slots * SITE_NSUM; i += WG) s_tot[i] = 0;
-        for (int i = tid; i < P.hist_slots * NPART * 64; i += WG) s_part[i] = 0;
     }
 
     int site = 0, ref4c = 4;
@@ -210,6 +252,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint32_t abase = base & ~3u;                       // key index 0 of this round
         const uint32_t lim = min(abase + (uint32_t)cap, span_end);
         if (tid == 0) s_next = 0xffffffffu;
+        if (LDS_HIST) for (int i = tid; i < P.hist_slots * NPART * pcol; i += WG) s_part[i] = 0;
         __syncthreads();
         const bool part = !done && beg >= base && end <= lim;    // this lane's cell is handled in this round
         if (!done && !part) atomicMin(&s_next, beg);             // the first cell left for the next round (deep tiles only)
@@ -217,6 +260,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint32_t nb = s_next;
         const uint32_t rlim = min(nb, lim);                      // reads [base, rlim) belong to this round's cells
 
+        GLF_STAMP(0)
         // ================= phase A: one lane per read =================
         for (int sg = site0; sg <= site_last; ++sg) {            // uniform: the site segments of the workgroup's span
             const long c_lo = max(cell0, (long)sg * S), c_hi = min(cell_end, (long)(sg + 1) * S);
@@ -366,9 +410,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                         A.t_md - A.d_md, A.t_md2 - A.d_md2, A.d_md, A.d_md2 };
             unsigned long long *tot = LDS_HIST ? s_tot + (sg - site0) * SITE_NSUM : P.site_sums + (size_t)sg * SITE_NSUM;
             if (LDS_HIST) {
-                uint32_t *pt = s_part + (sg - site0) * (NPART * 64) + (tid & 63);
+                uint32_t *pt = s_part + (sg - site0) * (NPART * pcol) + (tid & (pcol - 1));
                 #pragma unroll
-                for (int j = 0; j < NPART; ++j) atomicAdd(&pt[j * 64], v[j]);
+                for (int j = 0; j < NPART; ++j) atomicAdd(&pt[j * pcol], v[j]);
             } else {
                 // global mode (many sites per workgroup, i.e. very few samples): wave sums, one atomic per wave and value
                 #pragma unroll
@@ -386,7 +430,21 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 if (C.rev59) atomicAdd(&hist[H_REV_MQS + 59], (int)C.rev59);
             }
         }
+        GLF_STAMP(1)
         __syncthreads();
+        GLF_STAMP(2)
+        if (LDS_HIST) {
+            // the columns of every partial sum: four lanes per value
+            const int nslot = min(P.hist_slots, P.n_sites - site0), q4 = pcol >> 2;
+            for (int i = tid; i < nslot * NPART * 4; i += WG) {
+                const uint32_t *pt = s_part + (i >> 2) * pcol + (i & 3) * q4;
+                unsigned long long x = 0;
+                for (int k = 0; k < q4; ++k) x += pt[k];
+                x += __shfl_xor(x, 1); x += __shfl_xor(x, 2);
+                if ((i & 3) == 0 && x) { const int vi = i >> 2; s_tot[(vi / NPART) * SITE_NSUM + vi % NPART] += x; }
+            }
+            __syncthreads();
+        }
 
         // ================= phase B: one lane per cell =================
         uint16_t *kp_w = s_key + (part ? beg - abase : 0);       // the lane's keys
@@ -434,6 +492,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
             if (ntr) atomicAdd(P.trunc, 1u);
         }
+        GLF_STAMP(3)
         // pass 1: the quality mask of the primary base; the few other reads are gathered at the front of the slice
         uint64_t qmask = 0;          // qualities seen among the reads of the primary base
         uint32_t n_prim = 0, scr = 0;
@@ -467,6 +526,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const char *bbase = reinterpret_cast<const char*>(P.beta);
         const uint32_t brow = n << 3;
 
+        GLF_STAMP(4)
         // ---- errmod_cal: descending walk per base ----
         double bsum[5] = {0, 0, 0, 0, 0};
         uint32_t prim_rev = 0, qs_prim = 0;
@@ -488,6 +548,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         #pragma unroll
         for (int b = 0; b < 4; ++b) c[b] = (int)((ad64 >> (8 * b)) & 0xff) + (int)((ad64 >> (8 * b + 32)) & 0xff);
         c[4] = (int)n_b4;
+        GLF_STAMP(5)
         // (b) the other bases present in the wave
         if (!BCFGPU_ABL(P, 2) && __any(n_other > 0)) {
             #pragma unroll 1
@@ -510,32 +571,50 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         const uint32_t n_rev = prim_rev + o_rev;
 
+        GLF_STAMP(6)
         // ---- epilogue of errmod_cal (m=5): float accumulators as in the reference ----
+        uint32_t code = 0;
         if (part && !BCFGPU_ABL(P, 64)) {
-            #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                float tmp1 = 0.0f; int tmp2 = 0;
+            const int nbases = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0) + (c[4] > 0);
+            if (nbases <= 1) {
+                // one base b (or no read at all): every sum over "the other bases" is bsum[b] or nothing, see CallretPlanes
+                const int b = c[1] > 0 ? 1 : c[2] > 0 ? 2 : c[3] > 0 ? 3 : c[4] > 0 ? 4 : 0;
+                double bsb = bsum[0];
                 #pragma unroll
-                for (int k = 0; k < 5; ++k) { if (k == j) continue; tmp1 = (float)((double)tmp1 + bsum[k]); tmp2 += c[k]; }
-                float v = 0.0f;
-                if (n > 0 && tmp2) v = tmp1;
-                if (v < 0.0f) v = 0.0f;
-                P.cr.p15[(size_t)tri(j, j) * ncells + cell] = v;
+                for (int k = 1; k < 5; ++k) if (k == b) bsb = bsum[k];
+                float A = n > 0 ? (float)((double)0.0f + bsb) : 0.0f;
+                if (A < 0.0f) A = 0.0f;
+                P.cr.pa[cell] = A;
+                code = (uint32_t)b;
+            } else {
+                code = CR_FULL;
                 #pragma unroll
-                for (int k = j + 1; k < 5; ++k) {
-                    const int cjk = c[j] + c[k];
-                    float t1 = 0.0f; int t2 = 0;
+                for (int j = 0; j < 5; ++j) {
+                    float tmp1 = 0.0f; int tmp2 = 0;
                     #pragma unroll
-                    for (int i = 0; i < 5; ++i) { if (i == j || i == k) continue; t1 = (float)((double)t1 + bsum[i]); t2 += c[i]; }
-                    float h = 0.0f;
-                    if (n > 0) {
-                        const double lh = -4.343 * P.lhet[cjk << 8 | c[k]];
-                        h = t2 ? (float)(lh + (double)t1) : (float)lh;
-                        if (h < 0.0f) h = 0.0f;
+                    for (int k = 0; k < 5; ++k) { if (k == j) continue; tmp1 = (float)((double)tmp1 + bsum[k]); tmp2 += c[k]; }
+                    float v = 0.0f;
+                    if (n > 0 && tmp2) v = tmp1;
+                    if (v < 0.0f) v = 0.0f;
+                    P.cr.p15[(size_t)tri(j, j) * ncells + cell] = v;
+                    #pragma unroll
+                    for (int k = j + 1; k < 5; ++k) {
+                        const int cjk = c[j] + c[k];
+                        float t1 = 0.0f; int t2 = 0;
+                        #pragma unroll
+                        for (int i = 0; i < 5; ++i) { if (i == j || i == k) continue; t1 = (float)((double)t1 + bsum[i]); t2 += c[i]; }
+                        float h = 0.0f;
+                        if (n > 0) {
+                            const double lh = -4.343 * P.lhet[cjk << 8 | c[k]];
+                            h = t2 ? (float)(lh + (double)t1) : (float)lh;
+                            if (h < 0.0f) h = 0.0f;
+                        }
+                        P.cr.p15[(size_t)tri(j, k) * ncells + cell] = h;
                     }
-                    P.cr.p15[(size_t)tri(j, k) * ncells + cell] = h;
                 }
             }
+        }
+        if (part) {
             // anno[0..3]: ref/alt x fwd/rev counts.  "diff" reads are exactly the non-primary ones when the
             // reference base is A/C/G/T (or at indel sites); with an N reference every read is a diff read.
             const bool all_diff = (!INDEL && ref4c >= 4);
@@ -544,28 +623,19 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const uint32_t cnt4 = (n_fwd - d_fwd) | (n_rev - d_rev) << 8 | d_fwd << 16 | d_rev << 24;
             P.cr.qs64[cell] = qs64;
             P.cr.adf[cell] = (uint32_t)ad64; P.cr.adr[cell] = (uint32_t)(ad64 >> 32); P.cr.cnt4[cell] = cnt4;
-            P.cr.misc[cell] = (scr & 0xff) << 8;         // mq0 and ori_depth only feed site totals: site_sums[12..13]
+            P.cr.misc[cell] = code | (scr & 0xff) << 8;  // mq0 and ori_depth only feed site totals: site_sums[12..13]
             done = true;
         }
         if (nb == 0xffffffffu) break;
         base = nb;
+        __syncthreads();                                         // the slot counters are phase A's partial sums again
     }
 
+    GLF_STAMP(7)
     // ---- flush the workgroup's histograms and site totals ----
     if (LDS_HIST) {
         __syncthreads();
         const int nslot = min(P.hist_slots, P.n_sites - site0);
-        // the 64 columns of every partial sum: four lanes per value, 16 columns each
-        for (int i = tid; i < nslot * NPART * 4; i += WG) {
-            const int vi = i >> 2, j = vi % NPART, sl = vi / NPART;
-            const uint32_t *pt = s_part + vi * 64 + (i & 3) * 16;
-            unsigned long long x = 0;
-            #pragma unroll
-            for (int k = 0; k < 16; ++k) x += pt[k];
-            x += __shfl_xor(x, 1); x += __shfl_xor(x, 2);
-            if ((i & 3) == 0 && x) s_tot[sl * SITE_NSUM + j] += x;
-        }
-        __syncthreads();
         for (int i = tid; i < nslot * H_SIZE; i += WG) {
             const int v = s_hist[i];
             if (v) atomicAdd(&P.hist[(long)site0 * H_SIZE + i], v);
@@ -575,11 +645,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (v) atomicAdd(&P.site_sums[(size_t)site0 * SITE_NSUM + i], v);
         }
     }
+    GLF_STAMP(8)
 }
 
 size_t glfgen_lds_bytes(int cap, int hist_slots)
 {
-    return LDS_HIST_OFF + (size_t)hist_slots * (H_SIZE * sizeof(int) + SITE_NSUM * 8 + NPART * 64 * 4) + ((size_t)cap + 8) * 2;
+    return LDS_HIST_OFF + (size_t)hist_slots * (H_SIZE * sizeof(int) + SITE_NSUM * 8) + ((size_t)cap + 8) * 2;
 }
 
 template <bool INDEL, bool LDS_HIST>

@@ -28,20 +28,28 @@ enum : int { SITE_NSUM = 14 };
 
 // per (site,sample) result of the glfgen kernel = bcf_callret1_t (bam2bcf.h:90-108), SoA planes over
 // ncells = n_sites*n_smpl.  Everything but p is an exact integer.
+// Most cells show a single base (the reference's): their 15 genotype likelihoods take three values -- 0 for the
+// homozygote of that base b, A = (float)bsum[b] for every genotype without b, and H = (float)(4.343 * ln2 * n) for the
+// heterozygotes with b (errmod_cal's lhet term alone, a function of the read count n) -- so such a cell stores A and b and
+// combine_kernel rebuilds the planes it needs; cells with two or more bases store all 15 values.
 struct CallretPlanes {
-    float    *p15;    // [15][ncells]  upper triangle of p[5][5]: index k*(k+1)/2+j for j<=k
+    float    *p15;    // [15][ncells]  upper triangle of p[5][5]: index k*(k+1)/2+j for j<=k; written for CR_FULL cells only
+    float    *pa;     // [ncells]      A of a single-base cell
     uint64_t *qs64;   // [ncells]      QS[0..3] packed 4 x u16
     uint32_t *adf;    // [ncells]      ADF[0..3] packed 4 x u8
     uint32_t *adr;    // [ncells]      ADR[0..3] packed 4 x u8
     uint32_t *cnt4;   // [ncells]      anno[0..3] packed 4 x u8
-    uint32_t *misc;   // [ncells]      mq0 | SCR<<8 | ori_depth<<16
+    uint32_t *misc;   // [ncells]      code | SCR<<8; code = the cell's base 0..4, or CR_FULL: all 15 likelihoods are in p15
 };
+
+enum : uint32_t { CR_FULL = 0x80 };
 
 struct GlfgenParams {
     int n_sites, n_smpl, is_indel;
     int min_baseQ, capQ, fmt_flag;
     int hist_slots;                 // >0: per-workgroup LDS histograms with that many site slots; 0: global atomics
     int lds_cap;                    // read keys held in LDS per workgroup round (multiple of 16, <= 16384)
+    int part_cols;                  // LDS columns per partial sum of phase A (power of two >= 4; 12 * hist_slots * part_cols <= 2048: the slot region)
     uint32_t n_reads;               // length of rd/epos (bounds of the vector loads)
     BCFGPU_ABL_FIELD
     const int8_t   *ref16;
@@ -55,6 +63,9 @@ struct GlfgenParams {
     unsigned long long *site_sums;  // [n_sites][SITE_NSUM] site totals of anno[4..15], ori_depth, mq0 (exact integers), zeroed before launch
     int *err;                       // device error word
     unsigned int *trunc;            // cells cut to their first 255 usable reads (counter)
+#ifdef BCFGPU_DIAG
+    unsigned long long *stamps;     // [16] cycle totals per kernel phase
+#endif
 };
 
 struct CombineParams {
