@@ -23,9 +23,12 @@
 #include <string.h>
 #include <stdint.h>
 #include "bcfgpu.h"
+#include "vcfio.h"
 
 #define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s: %s (%d)\n", #call, bcfgpu_last_error(), rc_); exit(1); } } while (0)
 #define DIE(...) do { fprintf(stderr, __VA_ARGS__); exit(1); } while (0)
+
+static FILE *LN; static char *ln_buf; static size_t ln_len;      /* the record being written: a memory stream, framed by vcfio */
 
 typedef struct { char *line; char **fld; int nfld; char **als; int nals, unseen, pl_idx, ad_idx; uint8_t *ploidy; } rec_t;
 
@@ -70,12 +73,12 @@ static int is_numberR(char (*tab)[64], int cnt, const char *key, size_t klen)
 static void print_numberR(const char *vals, const int32_t *als_map, int nals, int nn)
 {
     char *c = strdup(vals); int nv; char **v = split(c, ',', &nv);
-    if (nv != nals) fputs(vals, stdout);                        /* '.', or not one value per allele: left alone */
-    else if (nn == 1) fputs(v[0], stdout);
+    if (nv != nals) fputs(vals, LN);                        /* '.', or not one value per allele: left alone */
+    else if (nn == 1) fputs(v[0], LN);
     else {
         const char *o[5] = { ".", ".", ".", ".", "." };
         for (int i = 0; i < nals; ++i) if (als_map[i] >= 0) o[als_map[i]] = v[i];
-        for (int i = 0; i < nn; ++i) printf("%s%s", i ? "," : "", o[i]);
+        for (int i = 0; i < nn; ++i) fprintf(LN, "%s%s", i ? "," : "", o[i]);
     }
     free(v); free(c);
 }
@@ -93,8 +96,12 @@ int main(int argc, char **argv)
     int varonly = 0, out_tags = 0;
     const char *smpl_file = NULL, *ploidy_file = NULL, *grp_arg = NULL, *grp_tag = NULL;
     char prior_an_tag[64] = "", prior_ac_tag[64] = "";
+    char out_mode = 'v'; const char *out_path = "-";
     while (argc > 2 && argv[1][0] == '-') {
         if (!strcmp(argv[1], "-v")) { varonly = 1; ++argv; --argc; }
+        else if (!strcmp(argv[1], "-O") && argc > 3) { out_mode = argv[2][0]; argv += 2; argc -= 2; }      /* version.c:67-82 */
+        else if (!strncmp(argv[1], "-O", 2) && argv[1][2]) { out_mode = argv[1][2]; ++argv; --argc; }
+        else if (!strcmp(argv[1], "-o") && argc > 3) { out_path = argv[2]; argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-G") && argc > 3) { grp_arg = argv[2]; argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "--group-samples-tag") && argc > 3) { grp_tag = argv[2]; argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-F") && argc > 3) {
@@ -115,7 +122,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "--ploidy-file") && argc > 3) { ploidy_file = argv[2]; argv += 2; argc -= 2; }
         else break;
     }
-    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-S samples.txt] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] in.vcf\n"); return 2; }
+    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-S samples.txt] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] [-O v|z|u|b] [-o out] in.vcf|in.bcf\n"); return 2; }
     /* ploidy definition (ploidy.c): regions per sex, '*' lines = the sex's default; the last sex named is the default sex */
     preg_t *preg = NULL; int npreg = 0; char last_sex[64] = "";
     if (ploidy_file) {
@@ -132,48 +139,45 @@ int main(int argc, char **argv)
             }
         fclose(pf);
     }
-    FILE *f = fopen(argv[1], "r");
-    if (!f) DIE("cannot open %s\n", argv[1]);
-    static char buf[1 << 20];
+    vio_file *fin = vio_open_read(argv[1]);                  /* VCF, bgzipped VCF or BCF (hts_open of vcfcall.c) */
+    if (!fin) DIE("%s\n", vio_error());
+    vio_hdr *hdr = vio_read_hdr(fin);
+    if (!hdr) DIE("%s\n", vio_error());
+    char *buf = NULL; size_t bufcap = 0;
     rec_t *recs = NULL; int n = 0, cap = 0, S = -1, ngmax = 1, S_in = -1;
     int *col = NULL;                              /* output sample s = input column col[s] (bcf_subset with -S) */
     char **names = NULL;                          /* names of the input columns */
     char (*spec)[64] = NULL;                      /* its ploidy ("0", "1", "2") or sex name */
-    while (fgets(buf, sizeof buf, f)) {
-        size_t l = strlen(buf);
-        while (l && (buf[l - 1] == '\n' || buf[l - 1] == '\r')) buf[--l] = 0;
-        if (buf[0] == '#') {
-            header_line(buf);
-            if (!strncmp(buf, "#CHROM", 6)) {
-                int nf; char *c = strdup(buf), **h = split(c, '\t', &nf);
-                S_in = S = nf - 9;
-                names = malloc((size_t)(S > 0 ? S : 1) * sizeof *names);
-                for (int s = 0; s < S; ++s) names[s] = strdup(h[9 + s]);
-                col = malloc((size_t)(S > 0 ? S : 1) * sizeof *col);
-                spec = malloc((size_t)(S > 0 ? S : 1) * sizeof *spec);
-                for (int s = 0; s < S; ++s) { col[s] = s; strcpy(spec[s], ploidy_file ? last_sex : "2"); }   /* vcfcall.c:645-650 */
-                if (smpl_file) {
-                    FILE *sf = fopen(smpl_file, "r");
-                    if (!sf) DIE("cannot open %s\n", smpl_file);
-                    char ln[1024]; int m = 0;
-                    while (fgets(ln, sizeof ln, sf)) {
-                        char w[6][256]; const int nw = sscanf(ln, "%255s %255s %255s %255s %255s %255s", w[0], w[1], w[2], w[3], w[4], w[5]);
-                        if (nw < 1 || w[0][0] == '#') continue;
-                        const char *name = nw >= 5 ? w[1] : w[0];                   /* PED: family, sample, father, mother, sex */
-                        const char *sp = nw >= 5 ? (!strcmp(w[4], "1") ? "M" : "F") : nw >= 2 ? w[1] : "2";
-                        int i;
-                        for (i = 0; i < S_in; ++i) if (!strcmp(h[9 + i], name)) break;
-                        if (i == S_in) continue;                                    /* not in the VCF: ignored */
-                        if (m == S_in) DIE("too many samples in %s\n", smpl_file);
-                        col[m] = i; strcpy(spec[m], sp); ++m;
-                    }
-                    fclose(sf);
-                    S = m;
-                }
-                free(h); free(c);
+    for (int i = 0; i < vio_hdr_nlines(hdr); ++i) header_line(vio_hdr_line(hdr, i));
+    {
+        S_in = S = vio_hdr_nsamples(hdr);
+        names = malloc((size_t)(S > 0 ? S : 1) * sizeof *names);
+        for (int s = 0; s < S; ++s) names[s] = strdup(vio_hdr_sample(hdr, s));
+        col = malloc((size_t)(S > 0 ? S : 1) * sizeof *col);
+        spec = malloc((size_t)(S > 0 ? S : 1) * sizeof *spec);
+        for (int s = 0; s < S; ++s) { col[s] = s; strcpy(spec[s], ploidy_file ? last_sex : "2"); }   /* vcfcall.c:645-650 */
+        if (smpl_file) {
+            FILE *sf = fopen(smpl_file, "r");
+            if (!sf) DIE("cannot open %s\n", smpl_file);
+            char ln[1024]; int m = 0;
+            while (fgets(ln, sizeof ln, sf)) {
+                char w[6][256]; const int nw = sscanf(ln, "%255s %255s %255s %255s %255s %255s", w[0], w[1], w[2], w[3], w[4], w[5]);
+                if (nw < 1 || w[0][0] == '#') continue;
+                const char *name = nw >= 5 ? w[1] : w[0];                   /* PED: family, sample, father, mother, sex */
+                const char *sp = nw >= 5 ? (!strcmp(w[4], "1") ? "M" : "F") : nw >= 2 ? w[1] : "2";
+                int i;
+                for (i = 0; i < S_in; ++i) if (!strcmp(names[i], name)) break;
+                if (i == S_in) continue;                                    /* not in the VCF: ignored */
+                if (m == S_in) DIE("too many samples in %s\n", smpl_file);
+                col[m] = i; strcpy(spec[m], sp); ++m;
             }
-            continue;
+            fclose(sf);
+            S = m;
         }
+    }
+    int rrc;
+    while ((rrc = vio_read_line(fin, hdr, &buf, &bufcap)) > 0) {
+        size_t l = strlen(buf);
         if (!l) continue;
         if (n == cap) { cap = cap ? 2 * cap : 1024; recs = realloc(recs, (size_t)cap * sizeof *recs); }
         rec_t *r = &recs[n++];
@@ -209,7 +213,8 @@ int main(int argc, char **argv)
             r->ploidy[s] = (uint8_t)pl;
         }
     }
-    fclose(f);
+    if (rrc < 0) DIE("%s\n", vio_error());
+    vio_close(fin);
     if (S <= 0) DIE("no samples\n");
 
     /* ---- -G: the group of every sample; ids in the order the groups first appear in the file (mcall.c:308-330) ---- */
@@ -349,90 +354,109 @@ int main(int argc, char **argv)
     if (gp) CHECK(bcfgpu_memcpy_d2h(ctx, gp, d_gp, (size_t)n * ngmax * S * 4));
     CHECK(bcfgpu_sync(ctx));
 
+    /* ---- the output header: the input's, for the samples kept, without the calling-only tags, plus what mcall_init
+     * declares (vcfcall.c:670,703-704; mcall.c:382-394) ---- */
+    if (smpl_file && vio_hdr_subset(hdr, S, col)) DIE("%s\n", vio_error());
+    vio_hdr_remove(hdr, "INFO", "QS");
+    vio_hdr_remove(hdr, "INFO", "I16");
+    vio_hdr_append(hdr, "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">");
+    if (out_tags & BCFGPU_CALL_FMT_GQ) vio_hdr_append(hdr, "##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Phred-scaled Genotype Quality\">");
+    if (out_tags & BCFGPU_CALL_FMT_GP) vio_hdr_append(hdr, "##FORMAT=<ID=GP,Number=G,Type=Float,Description=\"Genotype posterior probabilities in the range 0 to 1\">");
+    vio_hdr_append(hdr, "##INFO=<ID=AC,Number=A,Type=Integer,Description=\"Allele count in genotypes for each ALT allele, in the same order as listed\">");
+    vio_hdr_append(hdr, "##INFO=<ID=AN,Number=1,Type=Integer,Description=\"Total number of alleles in called genotypes\">");
+    vio_hdr_append(hdr, "##INFO=<ID=DP4,Number=4,Type=Integer,Description=\"Number of high-quality ref-forward , ref-reverse, alt-forward and alt-reverse bases\">");
+    vio_hdr_append(hdr, "##INFO=<ID=MQ,Number=1,Type=Integer,Description=\"Average mapping quality\">");
+    vio_file *fout = vio_open_write(out_path, out_mode);
+    if (!fout || vio_write_hdr(fout, hdr)) DIE("%s\n", vio_error());
+    LN = open_memstream(&ln_buf, &ln_len);
+    if (!LN) DIE("open_memstream failed\n");
     /* ---- the record loop (vcfcall.c:1137-1147, mcall.c:1627-1681) ---- */
     for (int k = 0; k < n; ++k) {
         const rec_t *r = &recs[k];
         const bcfgpu_call_site *c = &cs[k];
         if (c->ret == -2 || (varonly && c->ret == 0) || c->ret < 0) continue;
         const int nn = c->nals_new, ngn = nn * (nn + 1) / 2;
-        printf("%s\t%s\t%s\t%s\t", r->fld[0], r->fld[1], r->fld[2], r->fld[3]);
+        fprintf(LN, "%s\t%s\t%s\t%s\t", r->fld[0], r->fld[1], r->fld[2], r->fld[3]);
         {   /* ALT: the kept alleles in their new order */
             const char *al[5] = { 0, 0, 0, 0, 0 };
             for (int i = 0; i < r->nals; ++i) if (c->als_map[i] >= 0) al[c->als_map[i]] = r->als[i];
-            if (nn < 2) putchar('.');
-            for (int i = 1; i < nn; ++i) printf("%s%s", i > 1 ? "," : "", al[i]);
+            if (nn < 2) fputc('.', LN);
+            for (int i = 1; i < nn; ++i) fprintf(LN, "%s%s", i > 1 ? "," : "", al[i]);
         }
-        if (c->qual_missing) fputs("\t.", stdout); else printf("\t%g", (double)c->qual);
-        printf("\t%s\t", r->fld[6]);
+        if (c->qual_missing) fputs("\t.", LN); else fprintf(LN, "\t%g", (double)c->qual);
+        fprintf(LN, "\t%s\t", r->fld[6]);
         {   /* INFO: I16 and QS go, AC / AN / DP4 / MQ come */
             char *info = strdup(r->fld[7]); int ni, first = 1; char **iv = split(info, ';', &ni);
             for (int i = 0; i < ni; ++i) {
                 if (!strncmp(iv[i], "I16=", 4) || !strncmp(iv[i], "QS=", 3) || !strcmp(iv[i], ".")) continue;
                 const char *eq = strchr(iv[i], '=');
                 if (eq && nn != r->nals && is_numberR(infoR, n_infoR, iv[i], (size_t)(eq - iv[i]))) {
-                    printf("%s%.*s=", first ? "" : ";", (int)(eq - iv[i]), iv[i]);
+                    fprintf(LN, "%s%.*s=", first ? "" : ";", (int)(eq - iv[i]), iv[i]);
                     print_numberR(eq + 1, c->als_map, r->nals, nn);
-                } else printf("%s%s", first ? "" : ";", iv[i]);
+                } else fprintf(LN, "%s%s", first ? "" : ";", iv[i]);
                 first = 0;
             }
             free(iv); free(info);
-            if (nn > 1) { printf("%sAC=", first ? "" : ";"); first = 0; for (int i = 1; i < nn; ++i) printf("%s%d", i > 1 ? "," : "", c->ac[i]); }
-            printf("%sAN=%d", first ? "" : ";", c->an);
+            if (nn > 1) { fprintf(LN, "%sAC=", first ? "" : ";"); first = 0; for (int i = 1; i < nn; ++i) fprintf(LN, "%s%d", i > 1 ? "," : "", c->ac[i]); }
+            fprintf(LN, "%sAN=%d", first ? "" : ";", c->an);
             if (c->has_i16) {
-                printf(";DP4=%d,%d,%d,%d", c->dp4[0], c->dp4[1], c->dp4[2], c->dp4[3]);
-                if (c->mq == BCFGPU_INT32_MISSING) fputs(";MQ=.", stdout); else printf(";MQ=%d", c->mq);
+                fprintf(LN, ";DP4=%d,%d,%d,%d", c->dp4[0], c->dp4[1], c->dp4[2], c->dp4[3]);
+                if (c->mq == BCFGPU_INT32_MISSING) fputs(";MQ=.", LN); else fprintf(LN, ";MQ=%d", c->mq);
             }
         }
         /* FORMAT: GT first, PL trimmed or dropped, the rest as it came */
         int nk; char *fmt = strdup(r->fld[8]), **keys = split(fmt, ':', &nk);
-        fputs("\tGT", stdout);
-        for (int i = 0; i < nk; ++i) if (i != r->pl_idx || !c->pl_dropped) printf(":%s", keys[i]);
+        fputs("\tGT", LN);
+        for (int i = 0; i < nk; ++i) if (i != r->pl_idx || !c->pl_dropped) fprintf(LN, ":%s", keys[i]);
         const int called = nn > 1 && c->ret > 0;               /* mcall_call_genotypes ran: GP and GQ exist (mcall.c:1618-1623) */
-        if (called && gp) fputs(":GP", stdout);
-        if (called && gq) fputs(":GQ", stdout);
+        if (called && gp) fputs(":GP", LN);
+        if (called && gq) fputs(":GQ", LN);
         for (int s = 0; s < S; ++s) {
             const int g0 = gt[((size_t)k * 2 + 0) * S + s], g1 = gt[((size_t)k * 2 + 1) * S + s];
-            putchar('\t');
-            if (g0 == BCFGPU_GT_MISSING) putchar('.'); else printf("%d", g0);
-            if (g1 != BCFGPU_GT_VECTOR_END) { putchar('/'); if (g1 == BCFGPU_GT_MISSING) putchar('.'); else printf("%d", g1); }
+            fputc('\t', LN);
+            if (g0 == BCFGPU_GT_MISSING) fputc('.', LN); else fprintf(LN, "%d", g0);
+            if (g1 != BCFGPU_GT_VECTOR_END) { fputc('/', LN); if (g1 == BCFGPU_GT_MISSING) fputc('.', LN); else fprintf(LN, "%d", g1); }
             char *smp = strdup(r->fld[9 + col[s]]); int nv; char **vals = split(smp, ':', &nv);
             for (int i = 0; i < nk; ++i) {
                 if (i == r->pl_idx) {
                     if (c->pl_dropped) continue;
-                    putchar(':');
+                    fputc(':', LN);
                     int printed = 0;
                     for (int j = 0; j < ngn; ++j) {
                         const int32_t v = opl[((size_t)k * ngmax + j) * S + s];
                         if (v == BCFGPU_INT32_VECTOR_END) break;
-                        if (printed++) putchar(',');
-                        if (v == BCFGPU_INT32_MISSING) putchar('.'); else printf("%d", v);
+                        if (printed++) fputc(',', LN);
+                        if (v == BCFGPU_INT32_MISSING) fputc('.', LN); else fprintf(LN, "%d", v);
                     }
-                    if (!printed) putchar('.');
+                    if (!printed) fputc('.', LN);
                 } else if (i < nv && nn != r->nals && is_numberR(fmtR, n_fmtR, keys[i], strlen(keys[i]))) {
-                    putchar(':');
+                    fputc(':', LN);
                     print_numberR(vals[i], c->als_map, r->nals, nn);
-                } else printf(":%s", i < nv ? vals[i] : ".");
+                } else fprintf(LN, ":%s", i < nv ? vals[i] : ".");
             }
             if (called && gp) {
-                putchar(':');
+                fputc(':', LN);
                 int printed = 0;
                 for (int j = 0; j < ngn; ++j) {
                     uint32_t bits; memcpy(&bits, &gp[((size_t)k * ngmax + j) * S + s], 4);
                     if (bits == 0x7F800002u) break;
-                    if (printed++) putchar(',');
-                    if (bits == 0x7F800001u) putchar('.'); else printf("%g", (double)gp[((size_t)k * ngmax + j) * S + s]);
+                    if (printed++) fputc(',', LN);
+                    if (bits == 0x7F800001u) fputc('.', LN); else fprintf(LN, "%g", (double)gp[((size_t)k * ngmax + j) * S + s]);
                 }
-                if (!printed) putchar('.');
+                if (!printed) fputc('.', LN);
             }
             if (called && gq) {
                 const int32_t v = gq[(size_t)k * S + s];
-                if (v == BCFGPU_INT32_MISSING) fputs(":.", stdout); else printf(":%d", v);
+                if (v == BCFGPU_INT32_MISSING) fputs(":.", LN); else fprintf(LN, ":%d", v);
             }
             free(vals); free(smp);
         }
         free(keys); free(fmt);
-        putchar('\n');
+        fputc(0, LN); fflush(LN);                              /* the record, NUL-terminated, then the stream starts over */
+        if (vio_write_line(fout, hdr, ln_buf)) DIE("%s\n", vio_error());
+        rewind(LN);
     }
+    if (vio_close(fout)) DIE("%s\n", vio_error());
     bcfgpu_destroy(ctx);
     return 0;
 }

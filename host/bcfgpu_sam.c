@@ -26,9 +26,19 @@
 #include <ctype.h>
 #include <math.h>
 #include "bcfgpu.h"
+#include "vcfio.h"
 
 #define CHECK(call) do { int rc_ = (call); if (rc_) { fprintf(stderr, "%s: %s (%d)\n", #call, bcfgpu_last_error(), rc_); exit(1); } } while (0)
 #define DIE(...) do { fprintf(stderr, __VA_ARGS__); exit(1); } while (0)
+
+static FILE *LN; static char *ln_buf; static size_t ln_len;      /* the record being written: a memory stream, framed by vcfio */
+static vio_file *fout; static vio_hdr *hdr;
+static void end_record(void)
+{
+    fputc(0, LN); fflush(LN);
+    if (vio_write_line(fout, hdr, ln_buf)) { fprintf(stderr, "%s\n", vio_error()); exit(1); }
+    rewind(LN);
+}
 
 typedef struct {
     int n, cap;                                   /* reads */
@@ -76,13 +86,29 @@ static char *read_contig(const char *path, const char *name, int *len)
 }
 
 /* one SAM file = one sample: reads on `contig` that pass mplp_func's filters, appended to the pool */
-static void read_sam(const char *path, const char *contig, int smpl, pool_t *P)
+static void read_sam(const char *path, const char *contig, int smpl, pool_t *P, char **sample, vio_hdr *h)
 {
     FILE *f = fopen(path, "r");
     if (!f) DIE("cannot open %s\n", path);
     static char line[1 << 20];
+    *sample = NULL;
     while (fgets(line, sizeof line, f)) {
-        if (line[0] == '@') continue;
+        if (line[0] == '@') {
+            /* @SQ -> ##contig (mpileup.c:533-540, the first file's header); the first @RG's SM names the file's sample (bam_sample.c) */
+            if (h && !strncmp(line, "@SQ\t", 4)) {
+                const char *sn = strstr(line, "\tSN:"), *ln = strstr(line, "\tLN:");
+                if (sn && ln) {
+                    char buf[1024]; int l = 0; sn += 4;
+                    while (sn[l] && sn[l] != '\t' && sn[l] != '\n') ++l;
+                    snprintf(buf, sizeof buf, "##contig=<ID=%.*s,length=%d>", l, sn, atoi(ln + 4));
+                    vio_hdr_append(h, buf);
+                }
+            } else if (!*sample && !strncmp(line, "@RG\t", 4)) {
+                const char *sm = strstr(line, "\tSM:");
+                if (sm) { int l = 0; sm += 4; while (sm[l] && sm[l] != '\t' && sm[l] != '\n' && sm[l] != '\r') ++l; *sample = malloc((size_t)l + 1); memcpy(*sample, sm, (size_t)l); (*sample)[l] = 0; }
+            }
+            continue;
+        }
         char *fld[12]; int nf = 0;
         for (char *s = line; nf < 11 && s; ) { fld[nf++] = s; s = strchr(s, '\t'); if (s) *s++ = 0; }
         if (nf < 11) continue;
@@ -131,6 +157,7 @@ static void read_sam(const char *path, const char *contig, int smpl, pool_t *P)
         P->nbase += lq;
     }
     fclose(f);
+    if (!*sample) *sample = strdup(path);                   /* no read group: the file name (bam_sample.c) */
 }
 
 /* overlap_push (htslib sam.c) over the reads of one sample in file order: which pairs tweak_overlap_quality sees */
@@ -170,8 +197,8 @@ typedef struct { const uint8_t *pl, *dp4, *adf, *adr, *sp; } planes_t;        /*
 
 static void put_counts(const char *lead, const int32_t *f, const int32_t *r, int n)
 {
-    fputs(lead, stdout);
-    for (int j = 0; j < n; ++j) printf("%s%d", j ? "," : "", (f ? f[j] : 0) + (r ? r[j] : 0));
+    fputs(lead, LN);
+    for (int j = 0; j < n; ++j) fprintf(LN, "%s%d", j ? "," : "", (f ? f[j] : 0) + (r ? r[j] : 0));
 }
 
 /* what bcf_call2bcf writes into a record, in its order (bam2bcf.c:756-906); alleles: the ready REF\tALT text */
@@ -179,79 +206,86 @@ static void print_record(const char *contig, int pos1, const char *alleles, cons
                          const planes_t *pp, size_t k, int S)
 {
     const int na = c->n_alleles;
-    printf("%s\t%d\t.\t%s\t0\t.\t%sDP=%u", contig, pos1, alleles, prefix, c->ori_depth);
+    fprintf(LN, "%s\t%d\t.\t%s\t0\t.\t%sDP=%u", contig, pos1, alleles, prefix, c->ori_depth);
     if (fmt_flag & BCFGPU_INFO_ADF) put_counts(";ADF=", c->adf_tot, NULL, na);
     if (fmt_flag & BCFGPU_INFO_ADR) put_counts(";ADR=", NULL, c->adr_tot, na);
     if (fmt_flag & BCFGPU_INFO_AD)  put_counts(";AD=", c->adf_tot, c->adr_tot, na);
     if (fmt_flag & BCFGPU_INFO_DPR) put_counts(";DPR=", c->adf_tot, c->adr_tot, na);
-    fputs(";I16=", stdout);
-    for (int j = 0; j < 16; ++j) printf("%s%g", j ? "," : "", (double)(float)c->anno[j]);
-    fputs(";QS=", stdout);
-    for (int j = 0; j < na; ++j) printf("%s%g", j ? "," : "", (double)c->qsum[j]);
+    fputs(";I16=", LN);
+    for (int j = 0; j < 16; ++j) fprintf(LN, "%s%g", j ? "," : "", (double)(float)c->anno[j]);
+    fputs(";QS=", LN);
+    for (int j = 0; j < na; ++j) fprintf(LN, "%s%g", j ? "," : "", (double)c->qsum[j]);
     /* the bias statistics: HUGE_VAL = the tag is left out (bam2bcf.c:835-840) */
     {
         const char *tag[6] = { "VDB", "SGB", "RPB", "MQB", "MQSB", "BQB" };
         const float val[6] = { c->vdb, c->seg_bias, c->mwu_pos, c->mwu_mq, c->mwu_mqs, c->mwu_bq };
-        for (int j = 0; j < 6; ++j) if (val[j] != HUGE_VALF) printf(";%s=%g", tag[j], (double)val[j]);
+        for (int j = 0; j < 6; ++j) if (val[j] != HUGE_VALF) fprintf(LN, ";%s=%g", tag[j], (double)val[j]);
     }
-    printf(";MQ0F=%g", c->ori_depth ? (double)((float)c->mq0 / (float)c->ori_depth) : 0.);
-    fputs("\tPL", stdout);
-    if (fmt_flag & BCFGPU_FMT_DP) fputs(":DP", stdout);
-    if (fmt_flag & BCFGPU_FMT_DV) fputs(":DV", stdout);
-    if (fmt_flag & BCFGPU_FMT_SP) fputs(":SP", stdout);
-    if (fmt_flag & BCFGPU_FMT_DP4) fputs(":DP4", stdout);
-    if (fmt_flag & BCFGPU_FMT_ADF) fputs(":ADF", stdout);
-    if (fmt_flag & BCFGPU_FMT_ADR) fputs(":ADR", stdout);
-    if (fmt_flag & BCFGPU_FMT_AD) fputs(":AD", stdout);
-    if (fmt_flag & BCFGPU_FMT_DPR) fputs(":DPR", stdout);
+    fprintf(LN, ";MQ0F=%g", c->ori_depth ? (double)((float)c->mq0 / (float)c->ori_depth) : 0.);
+    fputs("\tPL", LN);
+    if (fmt_flag & BCFGPU_FMT_DP) fputs(":DP", LN);
+    if (fmt_flag & BCFGPU_FMT_DV) fputs(":DV", LN);
+    if (fmt_flag & BCFGPU_FMT_SP) fputs(":SP", LN);
+    if (fmt_flag & BCFGPU_FMT_DP4) fputs(":DP4", LN);
+    if (fmt_flag & BCFGPU_FMT_ADF) fputs(":ADF", LN);
+    if (fmt_flag & BCFGPU_FMT_ADR) fputs(":ADR", LN);
+    if (fmt_flag & BCFGPU_FMT_AD) fputs(":AD", LN);
+    if (fmt_flag & BCFGPU_FMT_DPR) fputs(":DPR", LN);
     const int x = na * (na + 1) / 2;
     const size_t Ss = (size_t)S;
     for (int s = 0; s < S; ++s) {
-        putchar('\t');
-        for (int j = 0; j < x; ++j) printf("%s%d", j ? "," : "", pp->pl[(k * BCFGPU_MAX_PL + j) * Ss + s]);
+        fputc('\t', LN);
+        for (int j = 0; j < x; ++j) fprintf(LN, "%s%d", j ? "," : "", pp->pl[(k * BCFGPU_MAX_PL + j) * Ss + s]);
         const uint8_t *d = pp->dp4 + k * 4 * Ss + s;                         /* FORMAT/DP, DV, DP4 from DP4 (bam2bcf.c:851-886) */
-        if (fmt_flag & BCFGPU_FMT_DP) printf(":%d", d[0] + d[Ss] + d[2 * Ss] + d[3 * Ss]);
-        if (fmt_flag & BCFGPU_FMT_DV) printf(":%d", d[2 * Ss] + d[3 * Ss]);
-        if (fmt_flag & BCFGPU_FMT_SP) printf(":%d", pp->sp[k * Ss + s]);
-        if (fmt_flag & BCFGPU_FMT_DP4) printf(":%d,%d,%d,%d", d[0], d[Ss], d[2 * Ss], d[3 * Ss]);
+        if (fmt_flag & BCFGPU_FMT_DP) fprintf(LN, ":%d", d[0] + d[Ss] + d[2 * Ss] + d[3 * Ss]);
+        if (fmt_flag & BCFGPU_FMT_DV) fprintf(LN, ":%d", d[2 * Ss] + d[3 * Ss]);
+        if (fmt_flag & BCFGPU_FMT_SP) fprintf(LN, ":%d", pp->sp[k * Ss + s]);
+        if (fmt_flag & BCFGPU_FMT_DP4) fprintf(LN, ":%d,%d,%d,%d", d[0], d[Ss], d[2 * Ss], d[3 * Ss]);
         for (int which = 0; which < 4; ++which) {                            /* ADF, ADR, AD, DPR */
             static const int bit[4] = { BCFGPU_FMT_ADF, BCFGPU_FMT_ADR, BCFGPU_FMT_AD, BCFGPU_FMT_DPR };
             if (!(fmt_flag & bit[which])) continue;
-            putchar(':');
+            fputc(':', LN);
             for (int j = 0; j < na; ++j) {
                 const int f = pp->adf[(k * 5 + j) * Ss + s], r = pp->adr[(k * 5 + j) * Ss + s];
-                printf("%s%d", j ? "," : "", which == 0 ? f : which == 1 ? r : f + r);
+                fprintf(LN, "%s%d", j ? "," : "", which == 0 ? f : which == 1 ? r : f + r);
             }
         }
     }
-    putchar('\n');
+    end_record();
 }
 
 int main(int argc, char **argv)
 {
-    if (argc > 2 && !strcmp(argv[1], "-a")) {                                 /* mpileup -a, mpileup.c:parse_format_flag */
-        static const struct { const char *name; int bit; } tags[] = {
-            { "DP", BCFGPU_FMT_DP }, { "DV", BCFGPU_FMT_DV }, { "SP", BCFGPU_FMT_SP }, { "DP4", BCFGPU_FMT_DP4 }, { "DPR", BCFGPU_FMT_DPR },
-            { "AD", BCFGPU_FMT_AD }, { "ADF", BCFGPU_FMT_ADF }, { "ADR", BCFGPU_FMT_ADR }, { "INFO/DPR", BCFGPU_INFO_DPR },
-            { "INFO/AD", BCFGPU_INFO_AD }, { "INFO/ADF", BCFGPU_INFO_ADF }, { "INFO/ADR", BCFGPU_INFO_ADR } };
-        char *list = strdup(argv[2]);
-        for (char *t = strtok(list, ","); t; t = strtok(NULL, ",")) {
-            size_t i;
-            for (i = 0; i < sizeof tags / sizeof tags[0]; ++i) if (!strcmp(t, tags[i].name)) { fmt_flag |= tags[i].bit; break; }
-            if (i == sizeof tags / sizeof tags[0]) DIE("unknown tag %s\n", t);
-        }
-        free(list);
-        argv += 2; argc -= 2;
-    }
     int32_t gv_range[16]; int gv_n = 0;                                       /* mpileup --gvcf INT,.. (gvcf.c:44-67) */
-    if (argc > 2 && !strcmp(argv[1], "--gvcf")) {
-        char *list = strdup(argv[2]);
-        for (char *t = strtok(list, ","); t; t = strtok(NULL, ",")) { if (gv_n == 16) DIE("--gvcf: at most 16 limits\n"); gv_range[gv_n++] = atoi(t); }
-        free(list);
-        fmt_flag |= BCFGPU_FMT_DP;                                            /* mpileup.c:1101-1105 */
-        argv += 2; argc -= 2;
+    char out_mode = 'v'; const char *out_path = "-"; int max_depth = 250;      /* mpileup -O, -o, -d (mpileup.c:937-950) */
+    while (argc > 2 && argv[1][0] == '-') {
+        if (!strcmp(argv[1], "-a")) {                                         /* mpileup -a, mpileup.c:parse_format_flag */
+            static const struct { const char *name; int bit; } tags[] = {
+                { "DP", BCFGPU_FMT_DP }, { "DV", BCFGPU_FMT_DV }, { "SP", BCFGPU_FMT_SP }, { "DP4", BCFGPU_FMT_DP4 }, { "DPR", BCFGPU_FMT_DPR },
+                { "AD", BCFGPU_FMT_AD }, { "ADF", BCFGPU_FMT_ADF }, { "ADR", BCFGPU_FMT_ADR }, { "INFO/DPR", BCFGPU_INFO_DPR },
+                { "INFO/AD", BCFGPU_INFO_AD }, { "INFO/ADF", BCFGPU_INFO_ADF }, { "INFO/ADR", BCFGPU_INFO_ADR } };
+            char *list = strdup(argv[2]);
+            for (char *t = strtok(list, ","); t; t = strtok(NULL, ",")) {
+                size_t i;
+                for (i = 0; i < sizeof tags / sizeof tags[0]; ++i) if (!strcmp(t, tags[i].name)) { fmt_flag |= tags[i].bit; break; }
+                if (i == sizeof tags / sizeof tags[0]) DIE("unknown tag %s\n", t);
+            }
+            free(list);
+            argv += 2; argc -= 2;
+        } else if (!strcmp(argv[1], "--gvcf")) {
+            char *list = strdup(argv[2]);
+            for (char *t = strtok(list, ","); t; t = strtok(NULL, ",")) { if (gv_n == 16) DIE("--gvcf: at most 16 limits\n"); gv_range[gv_n++] = atoi(t); }
+            free(list);
+            fmt_flag |= BCFGPU_FMT_DP;                                        /* mpileup.c:1101-1105 */
+            argv += 2; argc -= 2;
+        }
+        else if (!strcmp(argv[1], "-O")) { out_mode = argv[2][0]; argv += 2; argc -= 2; }
+        else if (!strncmp(argv[1], "-O", 2) && argv[1][2]) { out_mode = argv[1][2]; ++argv; --argc; }
+        else if (!strcmp(argv[1], "-o")) { out_path = argv[2]; argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-d")) { max_depth = atoi(argv[2]); argv += 2; argc -= 2; }
+        else break;
     }
-    if (argc < 6) { fprintf(stderr, "usage: bcfgpu_sam [-a TAG,..] [--gvcf INT,..] ref.fa contig beg end file.sam [file.sam ...]\n"); return 2; }
+    if (argc < 6) { fprintf(stderr, "usage: bcfgpu_sam [-a TAG,..] [--gvcf INT,..] [-O v|z|u|b] [-o out] [-d INT] ref.fa contig beg end file.sam [file.sam ...]\n"); return 2; }
     const char *contig = argv[2];
     const int beg = atoi(argv[3]) - 1, end = atoi(argv[4]);                 /* 0-based [beg, end) */
     const int S = argc - 5, n_sites = end - beg;
@@ -259,8 +293,73 @@ int main(int argc, char **argv)
     char *ref = read_contig(argv[1], contig, &ref_len);
     pool_t P; memset(&P, 0, sizeof P);
     int *first = malloc((size_t)(S + 1) * sizeof *first);
-    for (int s = 0; s < S; ++s) { first[s] = P.n; read_sam(argv[5 + s], contig, s, &P); }
+    /* ---- the VCF header, in mpileup's order (mpileup.c:510-602) ---- */
+    hdr = vio_hdr_new();
+    { char b[4096]; snprintf(b, sizeof b, "##reference=file://%s", argv[1]); vio_hdr_append(hdr, b); }
+    char **sample = malloc((size_t)S * sizeof *sample);
+    for (int s = 0; s < S; ++s) { first[s] = P.n; read_sam(argv[5 + s], contig, s, &P, &sample[s], s == 0 ? hdr : NULL); }
     first[S] = P.n;
+    {
+        #define HL(cond, text) do { if (cond) vio_hdr_append(hdr, text); } while (0)
+        HL(1, "##ALT=<ID=*,Description=\"Represents allele(s) other than observed.\">");
+        HL(1, "##INFO=<ID=INDEL,Number=0,Type=Flag,Description=\"Indicates that the variant is an INDEL.\">");
+        HL(1, "##INFO=<ID=IDV,Number=1,Type=Integer,Description=\"Maximum number of raw reads supporting an indel\">");
+        HL(1, "##INFO=<ID=IMF,Number=1,Type=Float,Description=\"Maximum fraction of raw reads supporting an indel\">");
+        HL(1, "##INFO=<ID=DP,Number=1,Type=Integer,Description=\"Raw read depth\">");
+        HL(fmt_flag & BCFGPU_INFO_VDB, "##INFO=<ID=VDB,Number=1,Type=Float,Description=\"Variant Distance Bias for filtering splice-site artefacts in RNA-seq data (bigger is better)\",Version=\"3\">");
+        HL(fmt_flag & BCFGPU_INFO_RPB, "##INFO=<ID=RPB,Number=1,Type=Float,Description=\"Mann-Whitney U test of Read Position Bias (bigger is better)\">");
+        HL(1, "##INFO=<ID=MQB,Number=1,Type=Float,Description=\"Mann-Whitney U test of Mapping Quality Bias (bigger is better)\">");
+        HL(1, "##INFO=<ID=BQB,Number=1,Type=Float,Description=\"Mann-Whitney U test of Base Quality Bias (bigger is better)\">");
+        HL(1, "##INFO=<ID=MQSB,Number=1,Type=Float,Description=\"Mann-Whitney U test of Mapping Quality vs Strand Bias (bigger is better)\">");
+        HL(1, "##INFO=<ID=SGB,Number=1,Type=Float,Description=\"Segregation based metric.\">");
+        HL(1, "##INFO=<ID=MQ0F,Number=1,Type=Float,Description=\"Fraction of MQ0 reads (smaller is better)\">");
+        HL(1, "##INFO=<ID=I16,Number=16,Type=Float,Description=\"Auxiliary tag used for calling, see description of bcf_callret1_t in bam2bcf.h\">");
+        HL(1, "##INFO=<ID=QS,Number=R,Type=Float,Description=\"Auxiliary tag used for calling\">");
+        HL(1, "##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"List of Phred-scaled genotype likelihoods\">");
+        HL(fmt_flag & BCFGPU_FMT_DP, "##FORMAT=<ID=DP,Number=1,Type=Integer,Description=\"Number of high-quality bases\">");
+        HL(fmt_flag & BCFGPU_FMT_DV, "##FORMAT=<ID=DV,Number=1,Type=Integer,Description=\"Number of high-quality non-reference bases\">");
+        HL(fmt_flag & BCFGPU_FMT_DPR, "##FORMAT=<ID=DPR,Number=R,Type=Integer,Description=\"Number of high-quality bases observed for each allele\">");
+        HL(fmt_flag & BCFGPU_INFO_DPR, "##INFO=<ID=DPR,Number=R,Type=Integer,Description=\"Number of high-quality bases observed for each allele\">");
+        HL(fmt_flag & BCFGPU_FMT_DP4, "##FORMAT=<ID=DP4,Number=4,Type=Integer,Description=\"Number of high-quality ref-fwd, ref-reverse, alt-fwd and alt-reverse bases\">");
+        HL(fmt_flag & BCFGPU_FMT_SP, "##FORMAT=<ID=SP,Number=1,Type=Integer,Description=\"Phred-scaled strand bias P-value\">");
+        HL(fmt_flag & BCFGPU_FMT_AD, "##FORMAT=<ID=AD,Number=R,Type=Integer,Description=\"Allelic depths (high-quality bases)\">");
+        HL(fmt_flag & BCFGPU_FMT_ADF, "##FORMAT=<ID=ADF,Number=R,Type=Integer,Description=\"Allelic depths on the forward strand (high-quality bases)\">");
+        HL(fmt_flag & BCFGPU_FMT_ADR, "##FORMAT=<ID=ADR,Number=R,Type=Integer,Description=\"Allelic depths on the reverse strand (high-quality bases)\">");
+        HL(fmt_flag & BCFGPU_INFO_AD, "##INFO=<ID=AD,Number=R,Type=Integer,Description=\"Total allelic depths (high-quality bases)\">");
+        HL(fmt_flag & BCFGPU_INFO_ADF, "##INFO=<ID=ADF,Number=R,Type=Integer,Description=\"Total allelic depths on the forward strand (high-quality bases)\">");
+        HL(fmt_flag & BCFGPU_INFO_ADR, "##INFO=<ID=ADR,Number=R,Type=Integer,Description=\"Total allelic depths on the reverse strand (high-quality bases)\">");
+        HL(gv_n, "##INFO=<ID=END,Number=1,Type=Integer,Description=\"End position of the variant described in this record\">");   /* gvcf.c:42-43 */
+        HL(gv_n, "##INFO=<ID=MinDP,Number=1,Type=Integer,Description=\"Minimum per-sample depth in this gVCF block\">");
+        #undef HL
+        for (int s = 0; s < S; ++s) vio_hdr_add_sample(hdr, sample[s]);
+    }
+    fout = vio_open_write(out_path, out_mode);
+    if (!fout || vio_write_hdr(fout, hdr)) DIE("%s\n", vio_error());
+    LN = open_memstream(&ln_buf, &ln_len);
+    if (!LN) DIE("open_memstream failed\n");
+    /* ---- the per-file depth cap of the pileup iterator (mpileup -d, mpileup.c:646): reads it drops leave the pool ---- */
+    if (max_depth > 0 && P.n) {
+        bcfgpu_reads r0; memset(&r0, 0, sizeof r0);
+        r0.n_reads = P.n; r0.r_pos = P.pos; r0.r_ncig = P.ncig; r0.r_cig_off = P.cig_off; r0.cig = P.cig;
+        uint8_t *keep = malloc((size_t)P.n);
+        CHECK(bcfgpu_depth_cap(&r0, P.smpl, S, max_depth, keep));
+        int m = 0;
+        for (int s = 0, r = 0; s < S; ++s) {
+            const int e = first[s + 1];
+            first[s] = m;
+            for (; r < e; ++r) {
+                if (!keep[r]) { free(P.qname[r]); continue; }
+                if (m != r) {
+                    #define MV(a) P.a[m] = P.a[r]
+                    MV(pos); MV(lq); MV(flag); MV(ncig); MV(cig_off); MV(seq_off); MV(smpl); MV(end); MV(mpos); MV(isize); MV(rnext_same); MV(mapq); MV(has_zq); MV(qname);
+                    #undef MV
+                }
+                ++m;
+            }
+        }
+        first[S] = m; P.n = m;
+        free(keep);
+    }
 
     bcfgpu_cfg cfg; memset(&cfg, 0, sizeof cfg);
     cfg.device = 0; cfg.n_smpl = S; cfg.max_sites = n_sites; cfg.max_reads = (uint64_t)P.nbase + 64;   /* every base is in <= 1 column */
@@ -405,13 +504,13 @@ int main(int argc, char **argv)
             const bcfgpu_gvcf_block *B = &gv_block[b];
             if (B->last_site == k) {
                 const bcfgpu_site *f = &site[B->first_site];
-                printf("%s\t%d\t.\t%c\t<*>\t.\t.\t", contig, B->start_pos + 1, nt[f->ori_ref < 0 || f->ori_ref > 4 ? 4 : f->ori_ref]);
-                if (B->start_pos + 1 < B->end1) printf("END=%d;", B->end1);                  /* gvcf.c:150-151 */
-                printf("MinDP=%d;QS=%g,%g\tPL:DP", B->min_dp, (double)f->qsum[0], (double)f->qsum[1]);
+                fprintf(LN, "%s\t%d\t.\t%c\t<*>\t.\t.\t", contig, B->start_pos + 1, nt[f->ori_ref < 0 || f->ori_ref > 4 ? 4 : f->ori_ref]);
+                if (B->start_pos + 1 < B->end1) fprintf(LN, "END=%d;", B->end1);                  /* gvcf.c:150-151 */
+                fprintf(LN, "MinDP=%d;QS=%g,%g\tPL:DP", B->min_dp, (double)f->qsum[0], (double)f->qsum[1]);
                 for (int s = 0; s < S; ++s)
-                    printf("\t%d,%d,%d:%d", gv_pl[((size_t)b * 3) * S + s], gv_pl[((size_t)b * 3 + 1) * S + s], gv_pl[((size_t)b * 3 + 2) * S + s],
+                    fprintf(LN, "\t%d,%d,%d:%d", gv_pl[((size_t)b * 3) * S + s], gv_pl[((size_t)b * 3 + 1) * S + s], gv_pl[((size_t)b * 3 + 2) * S + s],
                            gv_dp[(size_t)b * S + s]);
-                putchar('\n');
+                end_record();
             }
         } else {
         char als[64]; int o = 0;
@@ -451,6 +550,7 @@ int main(int argc, char **argv)
     fprintf(stderr, "%d reads of %d samples, %d overlapping pairs, %llu pileup entries in %d columns\n",
             P.n, S, np, (unsigned long long)tile.n_reads, n_sites);
     bcfgpu_free(ctx, d_site); bcfgpu_free(ctx, d_pl); bcfgpu_free(ctx, d_dp4); bcfgpu_free(ctx, d_adf); bcfgpu_free(ctx, d_adr); bcfgpu_free(ctx, d_sp);
+    if (vio_close(fout)) DIE("%s\n", vio_error());
     bcfgpu_destroy(ctx);
     return 0;
 }

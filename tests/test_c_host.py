@@ -136,6 +136,26 @@ def test_c_host_records_match_oracle(n_sites, n_smpl, depth, seed, varonly):
 
 
 SAM_EXE = os.path.join(ROOT, "host", "bcfgpu_sam")
+VIEW_EXE = os.path.join(ROOT, "host", "bcfgpu_view")
+
+
+def normalised(text):
+    """what test.pl:1579-1585 compares: the whole file but for the ##bcftools* and ##reference lines"""
+    return [ln for ln in text.splitlines() if not ln.startswith("##bcftools") and not ln.startswith("##reference")]
+
+
+def whole_file_checks(cmd, golden_path):
+    """The driver's VCF output equals the golden file, header and records; so does its BCF output (-Ob and -Ou) once
+    bcfgpu_view has turned it back into text -- the two commands test.pl runs for every mpileup / call test."""
+    want = normalised(open(golden_path).read())
+    out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, text=True).stdout
+    assert normalised(out) == want
+    for mode in ("b", "u"):
+        bcf = subprocess.run(cmd[:1] + ["-O", mode] + cmd[1:], check=True, stdout=subprocess.PIPE).stdout
+        assert bcf[:2] == b"\x1f\x8b"
+        back = subprocess.run([VIEW_EXE, "-"], input=bcf, check=True, stdout=subprocess.PIPE).stdout.decode()
+        assert normalised(back) == want
+    return out
 
 
 @pytest.mark.gpu
@@ -145,18 +165,15 @@ SAM_EXE = os.path.join(ROOT, "host", "bcfgpu_sam")
     ("100-600", "mpileup.5.out", "DP,AD,ADF,ADR,SP,INFO/AD,INFO/ADF,INFO/ADR", 501, 1)])
 def test_c_sam_driver_reproduces_reference_goldens(golden_dir, region, goldf, tags, n_snp, n_indel):
     """host/bcfgpu_sam.c: SAM files in, every stage on the device (BAQ, mate overlaps, pileup, glfgen + combine), VCF-like
-    records out -- byte-identical to the data lines (SNP and indel records) of the reference's test/mpileup/mpileup.{1,2,4,5}.out
-    (test.pl:640-644)."""
+    a VCF or BCF file out -- identical, header and all records (SNP and indel), to the reference's
+    test/mpileup/mpileup.{1,2,4,5}.out (test.pl:640-644; ##bcftools* / ##reference lines aside, as test.pl strips them)."""
     from tests.helpers import vcf
     build_host()
     G = os.path.join(golden_dir, "mpileup")
     beg, end = region.split("-")
-    out = subprocess.run([SAM_EXE] + (["-a", tags] if tags else []) + [os.path.join(G, "mpileup.ref.fa"), "17", beg, end] +
-                         [os.path.join(G, "mpileup.%d.sam" % i) for i in (1, 2, 3)], check=True, stdout=subprocess.PIPE, text=True).stdout
-    # the data lines of the VCF, byte for byte
-    want_lines = [ln.rstrip("\n") for ln in open(os.path.join(G, goldf)) if not ln.startswith("#")]
-    assert out.splitlines() == want_lines
-    recs = [vcf.Rec(ln) for ln in out.splitlines()]
+    out = whole_file_checks([SAM_EXE] + (["-a", tags] if tags else []) + [os.path.join(G, "mpileup.ref.fa"), "17", beg, end] +
+                            [os.path.join(G, "mpileup.%d.sam" % i) for i in (1, 2, 3)], os.path.join(G, goldf))
+    recs = [vcf.Rec(ln) for ln in out.splitlines() if not ln.startswith("#")]
     allg = vcf.Vcf(os.path.join(G, goldf)).recs
     key = lambda r: (r.pos, "INDEL" in r.info)
     got, gold = {key(r): r for r in recs}, {key(r): r for r in allg}
@@ -200,23 +217,40 @@ CALL_EXE = os.path.join(ROOT, "host", "bcfgpu_call")
 ])
 def test_c_call_driver_reproduces_reference_golden(golden_dir, vcff, goldf, args, n):
     """host/bcfgpu_call.c: `call -m [-v] [-S samples] [--ploidy-file f] [-G groups] [-F AN,AC] [-a GP,GQ]` on the reference's
-    test VCFs with mcall() on the device -- its output is byte-identical to the data lines of every `call -m` golden of
-    test.pl:276-308."""
+    test VCFs with mcall() on the device -- its VCF output, and its BCF output read back, equal every `call -m` golden of
+    test.pl:276-308, header included (test.pl:1194-1195)."""
     build_host()
     G = os.path.join(golden_dir, "call")
     cmd = [CALL_EXE] + args.format(G=G).split() + [os.path.join(G, vcff)]
-    out = subprocess.run(cmd, check=True, stdout=subprocess.PIPE, text=True).stdout
-    want = [ln.rstrip("\n") for ln in open(os.path.join(G, goldf)) if not ln.startswith("#")]
-    assert out.splitlines() == want and len(want) > 0 and (n is None or len(want) == n)
+    out = whole_file_checks(cmd, os.path.join(G, goldf))
+    nrec = sum(1 for ln in out.splitlines() if not ln.startswith("#"))
+    assert nrec > 0 and (n is None or nrec == n)
 
 
 @pytest.mark.gpu
 def test_c_sam_driver_reproduces_gvcf_golden(golden_dir):
     """`bcfgpu_sam -a DP,DV --gvcf 0,2,5`: the reference-only records collapse into gVCF blocks on the device
-    (bcfgpu_gvcf_blocks) -- byte-identical to the data lines of test/mpileup/mpileup.6.out (test.pl:645)."""
+    (bcfgpu_gvcf_blocks) -- the whole of test/mpileup/mpileup.6.out (test.pl:645), as VCF and through BCF."""
     build_host()
     G = os.path.join(golden_dir, "mpileup")
-    out = subprocess.run([SAM_EXE, "-a", "DP,DV", "--gvcf", "0,2,5", os.path.join(G, "mpileup.ref.fa"), "17", "100", "600"] +
-                         [os.path.join(G, "mpileup.%d.sam" % i) for i in (1, 2, 3)], check=True, stdout=subprocess.PIPE, text=True).stdout
-    want = [ln.rstrip("\n") for ln in open(os.path.join(G, "mpileup.6.out")) if not ln.startswith("#")]
-    assert out.splitlines() == want and len(want) == 42
+    out = whole_file_checks([SAM_EXE, "-a", "DP,DV", "--gvcf", "0,2,5", os.path.join(G, "mpileup.ref.fa"), "17", "100", "600"] +
+                            [os.path.join(G, "mpileup.%d.sam" % i) for i in (1, 2, 3)], os.path.join(G, "mpileup.6.out"))
+    assert sum(1 for ln in out.splitlines() if not ln.startswith("#")) == 42
+
+
+@pytest.mark.gpu
+def test_c_drivers_pipe_bcf(golden_dir, tmp_path):
+    """`bcfgpu_sam -Ou ... | bcfgpu_call -v -`: the uncompressed-BCF pipe of `bcftools mpileup -Ou | bcftools call -mv` between the
+    two drivers gives the records of the same run through a VCF file."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    sam_cmd = [SAM_EXE, os.path.join(G, "mpileup.ref.fa"), "17", "100", "600"] + [os.path.join(G, "mpileup.%d.sam" % i) for i in (1, 2, 3)]
+    vcf_path = str(tmp_path / "m.vcf")
+    with open(vcf_path, "w") as f:
+        subprocess.run(sam_cmd, check=True, stdout=f)
+    via_file = subprocess.run([CALL_EXE, "-v", vcf_path], check=True, stdout=subprocess.PIPE, text=True).stdout
+    p1 = subprocess.Popen(sam_cmd[:1] + ["-O", "u"] + sam_cmd[1:], stdout=subprocess.PIPE)
+    via_pipe = subprocess.run([CALL_EXE, "-v", "-"], stdin=p1.stdout, check=True, stdout=subprocess.PIPE, text=True).stdout
+    assert p1.wait() == 0
+    assert normalised(via_pipe) == normalised(via_file)
+    assert sum(1 for ln in via_pipe.splitlines() if not ln.startswith("#")) > 3
