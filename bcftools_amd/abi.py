@@ -159,6 +159,11 @@ PROTOTYPES = {
     "bcfgpu_mplp_out_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "bcfgpu_truncated_cells": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "bcfgpu_depth_cap": (C.c_int, [C.POINTER(Reads), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "bcfgpu_compact_calls": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(CallOut), C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "bcfgpu_comm_init_all": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]),
+    "bcfgpu_comm_destroy": (None, [C.c_void_p]),
+    "bcfgpu_gather_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     "bcfgpu_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "bcfgpu_timing_get": (C.c_int, [C.c_void_p, C.POINTER(Timing)]),
     "bcfgpu_abi_sizes": (None, [C.POINTER(C.c_int32)]),

@@ -44,3 +44,31 @@ def gather_fixed(local, bufs, dst=0):
     on `dst` bufs[r] then holds rank r's records (rank order = site order)."""
     dist.gather(local, bufs, dst=dst)
     return bufs
+
+
+def gather_packed(local, n_bytes, out, dst=0):
+    """The ordered gather of packed record buffers (bcfgpu_compact_calls): rank r contributes local[:n_bytes]; `dst` ends up
+    with rank 0's, rank 1's, ... bytes back to back in `out` and gets their sizes back.  The byte counts are exchanged first
+    (a tiny all_gather), then one grouped send/recv: `dst` posts a receive per peer, every peer one send -- ncclGroupStart /
+    ncclRecv x (N-1) / ncclSend / ncclGroupEnd on RCCL, the exchange bcfgpu_gather_bytes makes for the C driver."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = torch.tensor([int(n_bytes)], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(x.item()) for x in sizes]
+    ops = []
+    if rank == dst:
+        assert out.numel() >= sum(sizes)
+        off = 0
+        for r in range(world):
+            if r == dst:
+                out[off:off + sizes[r]] = local[:sizes[r]]
+            elif sizes[r]:
+                ops.append(dist.P2POp(dist.irecv, out[off:off + sizes[r]], r))
+            off += sizes[r]
+    elif sizes[rank]:
+        ops.append(dist.P2POp(dist.isend, local[:sizes[rank]], dst))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return sizes if rank == dst else None

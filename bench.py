@@ -476,7 +476,13 @@ def main():
     cpl = torch.zeros(T * abi.MAX_PL * S, dtype=torch.int32, device=dev)
     co.site, co.gt, co.pl, co.gq, co.gp = csite.data_ptr(), cgt.data_ptr(), cpl.data_ptr(), None, None
 
-    gbufs = shard.gather_buffers(csite, dst=0) if world > 1 else None      # every rank holds T sites: fixed-size gather
+    # What leaves a shard is the records `call -mv` would write: compacted on the device (call record + mpileup site record +
+    # the GT and PL planes of the variant sites, bcfgpu_compact_calls) and, for N > 1, gathered to rank 0 in rank order with
+    # grouped send/recv -- the same two library calls host/bcfgpu_mgpu.c makes.
+    rec_cap = 64 << 20
+    recbuf = torch.empty(rec_cap, dtype=torch.uint8, device=dev)
+    n_bytes, n_rec = C.c_uint64(), C.c_uint32()
+    gathered = torch.empty(rec_cap * world, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
     # the library enqueues on torch's current stream, so the RCCL gather of a step is ordered after that step's kernels and
     # before the next step's by the streams alone (no host synchronisation inside the timed loop)
     if world > 1:
@@ -487,9 +493,10 @@ def main():
     def step():
         check(L.bcfgpu_pipeline(ctx.h, C.byref(dt), d_ploidy.data_ptr() if d_ploidy is not None else None,
                                 d_grp.data_ptr() if d_grp is not None else None, C.byref(mo), C.byref(co)))
+        check(L.bcfgpu_compact_calls(ctx.h, T, rank * T, mo.site, C.byref(co), abi.MAX_PL, 2, recbuf.data_ptr(), rec_cap,
+                                     C.byref(n_bytes), C.byref(n_rec)))
         if world > 1:
-            # ordered gather of the per-site call records (the shards are contiguous regions)
-            shard.gather_fixed(csite, gbufs, dst=0)
+            shard.gather_packed(recbuf, int(n_bytes.value), gathered, dst=0)
 
     def fence():
         check(L.bcfgpu_sync(ctx.h))
@@ -542,7 +549,9 @@ def main():
             "config": {"workload": "1000-sample 30x synthetic WGS tile (BASELINE configs[3] shape), SNP path: "
                                    "glfgen+errmod -> combine -> call -m, inputs resident in HBM",
                        "samples": S, "depth": a.depth, "sites_per_step_per_gpu": T, "reads_per_tile": R,
-                       "sharding": "contiguous region shard per GPU; ordered gather of call records to rank 0",
+                       "sharding": "contiguous region shard per GPU; the records call -mv would write are compacted on the device and "
+                                   "gathered to rank 0 in rank order (grouped send/recv)",
+                       "records_per_step_per_gpu": int(n_rec.value), "record_bytes_per_step_per_gpu": int(n_bytes.value),
                        "groups": a.groups, "haploid_frac": a.haploid_frac},
             "roofline": {"bound": "hbm", "kernel": "glfgen_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,

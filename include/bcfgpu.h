@@ -442,6 +442,40 @@ typedef struct {
 } bcfgpu_gap_stats;
 int  bcfgpu_gap_prep_stats(const bcfgpu_ctx *ctx, bcfgpu_gap_stats *out);
 
+/* ---- several GPUs: region shards and the ordered gather (the reference's -r regions + `bcftools concat`,
+ * mpileup.c:652-683, vcfconcat.c:420) --------------------------------------------------------------------------------
+ * Sites are independent, so a region is cut into contiguous shards, one context (one GPU, one host thread or process)
+ * each, with no exchange on the data path.  What goes to the writer on rank 0 is the records that will be written: they are
+ * compacted on the device -- per record a fixed header with the call record and the mpileup-stage site record, then the
+ * site's GT planes [2][n_smpl] i8 (padded to 4 bytes) and its trimmed PL planes [n_gt][n_smpl] i32, the whole padded to
+ * 16 bytes, records back to back in site order -- and gathered in rank order, which is genomic order. */
+typedef struct {
+    int32_t site;                 /* site0 + index of the site in the shard's tile */
+    int32_t n_gt;                 /* PL planes that follow: nals_new*(nals_new+1)/2, or 0 when FORMAT/PL is dropped */
+    uint32_t bytes;               /* size of the whole record: the next one starts `bytes` further */
+    int32_t pad;
+    bcfgpu_call_site call;
+    bcfgpu_site mplp;             /* zero when no mpileup-stage record was given */
+} bcfgpu_call_rec;
+
+/* The records of a tile's call stage that `bcftools call` would write (ret >= 0; with variants_only = 1 also ret != 0,
+ * vcfcall.c:1140-1144; variants_only = 2: only records with an ALT allele called, i.e. what -v keeps, whatever the context's
+ * call_flag), packed into d_buf (device, cap_bytes).  msite: the mpileup stage's site records (device) or NULL;
+ * n_gt_planes: plane count of cout->pl per site.  n_bytes / n_rec (host, out): what was written.  Synchronises the stream. */
+int  bcfgpu_compact_calls(bcfgpu_ctx *ctx, int32_t n_sites, int32_t site0, const bcfgpu_site *msite, const bcfgpu_call_out *cout,
+                          int32_t n_gt_planes, int32_t variants_only, void *d_buf, uint64_t cap_bytes, uint64_t *n_bytes, uint32_t *n_rec);
+
+/* One communicator over the contexts of a node, rank i = ctxs[i] (RCCL ncclCommInitAll; every context on its own device;
+ * librccl is loaded at this call, a single context needs none). */
+typedef struct bcfgpu_comm bcfgpu_comm;
+int  bcfgpu_comm_init_all(bcfgpu_ctx *const *ctxs, int32_t n, bcfgpu_comm **out);
+void bcfgpu_comm_destroy(bcfgpu_comm *comm);
+/* The gather: every rank calls it (from its own thread) with the same counts[n] -- the byte counts of all ranks, which
+ * the caller shares through host memory.  Rank 0 ends up with rank 0's, rank 1's, ... bytes back to back in d_recv (device,
+ * sum of counts); the others send d_send.  ncclGroupStart / ncclRecv x (n-1) on rank 0, one ncclSend per peer / ncclGroupEnd,
+ * enqueued on each context's stream: bcfgpu_sync(ctx) waits for it. */
+int  bcfgpu_gather_bytes(bcfgpu_comm *comm, int32_t rank, const void *d_send, const uint64_t *counts, void *d_recv);
+
 /* byte sizes of the output planes for a tile of n_sites (n_smpl from the context) */
 size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *ctx, int n_sites, int which /*0 site,1 pl,2 dp4,3 adf,4 adr,5 qs,6 scr,7 sp*/);
 

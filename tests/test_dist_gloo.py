@@ -51,6 +51,14 @@ def _worker(rank, world, port, n_sites, n_smpl, out_path):
         if rank == 0:
             assert [int(b[0]) for b in bufs] == [10 * it + r + 1 for r in range(world)]
             assert all(bool((b == b[0]).all()) for b in bufs)
+    # the packed exchange of the record buffers (uneven sizes, one rank with nothing to send)
+    for sizes in ([5, 11], [0, 7], [9, 0]):
+        local = torch.full((16,), 40 + rank, dtype=torch.uint8)
+        outb = torch.zeros(64, dtype=torch.uint8) if rank == 0 else None
+        got_sizes = shard.gather_packed(local, sizes[rank], outb, dst=0)
+        if rank == 0:
+            assert got_sizes == sizes
+            assert outb[:sum(sizes)].tolist() == [40] * sizes[0] + [41] * sizes[1]
     dist.barrier()
     dist.destroy_process_group()
 
