@@ -43,7 +43,8 @@ struct bcfgpu_ctx {
     int timing = 0;                 // 1: time every launch sequence and wait for it; 2: record only, resolve in timing_get
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bcfgpu_timing last{};
-    std::vector<hipEvent_t> pool;   // mode 2: 4 events per launch sequence
+    std::vector<hipEvent_t> pool;   // mode 2: 4 events per launch sequence; created once and reused after every timing_get
+    size_t pool_used = 0;           // events handed out since the last timing_get
     std::vector<int> pool_call;     // mode 2: 1 if the sequence included the call kernel
     std::vector<void*> owned;
     bcfgpu_gap_stats gap{};         // statistics of the last bcfgpu_gap_prep
@@ -307,7 +308,13 @@ size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *c, int n_sites, int which)
     return 0;
 }
 
-int bcfgpu_timing_enable(bcfgpu_ctx *c, int on) { if (!c) return BCFGPU_E_ARG; c->timing = on; return 0; }
+int bcfgpu_timing_enable(bcfgpu_ctx *c, int on)
+{
+    if (!c) return BCFGPU_E_ARG;
+    c->timing = on;
+    if (on == 2) while (c->pool.size() < 4 * 64) { hipEvent_t e; hipEventCreate(&e); c->pool.push_back(e); }   // 64 sequences' worth up front
+    return 0;
+}
 int bcfgpu_timing_get(bcfgpu_ctx *c, bcfgpu_timing *t)
 {
     if (!c || !t) return set_err(BCFGPU_E_ARG, "bcfgpu_timing_get: bad arguments");
@@ -329,8 +336,7 @@ int bcfgpu_timing_get(bcfgpu_ctx *c, bcfgpu_timing *t)
             }
             a.glfgen_ms /= n; a.combine_ms /= n; a.total_ms /= n;
             if (ncall) a.mcall_ms /= ncall;
-            for (hipEvent_t e : c->pool) hipEventDestroy(e);
-            c->pool.clear(); c->pool_call.clear();
+            c->pool_used = 0; c->pool_call.clear();              // the events stay: the next sequences record into them again
         }
         c->last = a;
     }
@@ -342,9 +348,11 @@ int bcfgpu_timing_get(bcfgpu_ctx *c, bcfgpu_timing *t)
 static hipEvent_t *seq_events(bcfgpu_ctx *c)
 {
     if (c->timing == 2) {
-        for (int i = 0; i < 4; ++i) { hipEvent_t e; hipEventCreate(&e); c->pool.push_back(e); }
+        // no event is created inside a timed loop once the pool has grown to the loop's length (timing_enable(2) pre-grows it)
+        while (c->pool.size() < c->pool_used + 4) { hipEvent_t e; hipEventCreate(&e); c->pool.push_back(e); }
         c->pool_call.push_back(0);
-        return &c->pool[c->pool.size() - 4];
+        c->pool_used += 4;
+        return &c->pool[c->pool_used - 4];
     }
     return c->ev;
 }
@@ -514,7 +522,7 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
 #endif
     launch_mcall(m, c->stream);
     if (c->timing == 1) hipEventRecord(c->ev[3], c->stream);
-    else if (c->timing == 2) { hipEventRecord(c->pool[c->pool.size() - 1], c->stream); c->pool_call.back() = 1; }
+    else if (c->timing == 2) { hipEventRecord(c->pool[c->pool_used - 1], c->stream); c->pool_call.back() = 1; }
     HIPCHK(hipGetLastError());
     finish_timing(c, true);
     return 0;

@@ -91,14 +91,233 @@ static void *dev_upload(bcfgpu_ctx *ctx, const void *src, size_t bytes)
     return d;
 }
 
+/* ---- call -C alleles -T targets [-i]: the record is re-expressed in the alleles of the target file before mcall() sees it
+ * (mcall_constrain_alleles, mcall.c:1271-1421), the target line is chosen as next_line() does (vcfcall.c:501-605) with the
+ * allele comparison of vcmp.c:55-119, and -i writes a line for every target that met no record (tgt_flush, vcfcall.c:408-455).
+ * Host logic on the record text; the call itself is the device's, with -A. ---- */
+typedef struct { char *chrom; int pos; char **als; int nals, used, order; } tgt_t;
+static tgt_t *tgt = NULL; static int n_tgt = 0; static int *tgt_sorted = NULL;
+static int cals = 0, insert_missed = 0;
+
+static void tgt_parse(const char *path)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) DIE("cannot open %s\n", path);
+    char ln[1 << 16], c[256], a[1 << 15]; int pos;
+    while (fgets(ln, sizeof ln, f)) {
+        if (sscanf(ln, "%255s %d %32767s", c, &pos, a) != 3) continue;
+        tgt = realloc(tgt, (size_t)(n_tgt + 1) * sizeof *tgt);
+        tgt_t *t = &tgt[n_tgt];
+        t->chrom = strdup(c); t->pos = pos; t->used = 0; t->order = n_tgt;
+        char *al = strdup(a); t->als = split(al, ',', &t->nals);
+        ++n_tgt;
+    }
+    fclose(f);
+    /* the regions of a sequence sorted by start (regidx), sequences in the order they first appear */
+    tgt_sorted = malloc((size_t)(n_tgt ? n_tgt : 1) * sizeof *tgt_sorted);
+    int m = 0;
+    for (int i = 0; i < n_tgt; ++i) {
+        int seen = 0;
+        for (int j = 0; j < i; ++j) if (!strcmp(tgt[j].chrom, tgt[i].chrom)) { seen = 1; break; }
+        if (seen) continue;
+        const int m0 = m;
+        for (int j = i; j < n_tgt; ++j) if (!strcmp(tgt[j].chrom, tgt[i].chrom)) tgt_sorted[m++] = j;
+        for (int x = m0 + 1; x < m; ++x)                        /* stable insertion sort by position */
+            for (int y = x; y > m0 && tgt[tgt_sorted[y]].pos < tgt[tgt_sorted[y - 1]].pos; --y) { const int t = tgt_sorted[y]; tgt_sorted[y] = tgt_sorted[y - 1]; tgt_sorted[y - 1] = t; }
+    }
+}
+static size_t common_prefix_ci(const char *a, const char *b)
+{
+    size_t i = 0;
+    while (a[i] && b[i] && (a[i] & ~32) == (b[i] & ~32) && ((a[i] | 32) >= 'a' && (a[i] | 32) <= 'z' ? 1 : a[i] == b[i])) ++i;
+    return i;
+}
+static int ci_equal(const char *a, const char *b) { while (*a && *b) { char x = *a, y = *b; if (x >= 'a' && x <= 'z') x -= 32; if (y >= 'a' && y <= 'z') y -= 32; if (x != y) return 0; ++a; ++b; } return !*a && !*b; }
+/* vcmp_set_ref / vcmp_find_allele: the difference of the two REF strings, then allele matching modulo that suffix */
+typedef struct { int ndref; const char *dref; } vcmp_t;
+static int vcmp_set_ref(vcmp_t *v, const char *r1, const char *r2)
+{
+    v->ndref = 0; v->dref = "";
+    const size_t i = common_prefix_ci(r1, r2), l1 = strlen(r1), l2 = strlen(r2);
+    if (i == l1 && i == l2) return 0;
+    if (i < l1 && i < l2) return -1;
+    if (i < l1) { v->dref = r1 + i; v->ndref = (int)(l1 - i); } else { v->dref = r2 + i; v->ndref = -(int)(l2 - i); }
+    return 0;
+}
+static int vcmp_find_allele(const vcmp_t *v, char **als1, int n1, const char *al2)
+{
+    for (int i = 0; i < n1; ++i) {
+        const char *a = als1[i];
+        const size_t k = common_prefix_ci(a, al2), la = strlen(a), lb = strlen(al2);
+        if (k < la && k < lb) continue;
+        if (!v->ndref) { if (k == la && k == lb) return i; continue; }
+        if (k < la) { if (v->ndref < 0 || !ci_equal(a + k, v->dref)) continue; return i; }
+        if (v->ndref > 0 || !ci_equal(al2 + k, v->dref)) continue;
+        return i;
+    }
+    return -1;
+}
+static int als_is_indel(char **als, int n)                     /* vcfcall.c:456-470 */
+{
+    if (n > 1 && als[1][0] == '<') return 0;
+    for (int i = 0; i < n; ++i) if (als[i][0] != '<' && strlen(als[i]) > 1) return 1;
+    return 0;
+}
+static int gt_index(int a, int b) { return a > b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
+static void gt_alleles(int igt, int *a, int *b) { int k = 0; while ((k + 1) * (k + 2) / 2 <= igt) ++k; *b = k; *a = igt - k * (k + 1) / 2; }
+
+/* the -i lines of the targets in [beg0, end0] of `chrom` that met no record, appended to the event list */
+typedef struct { int is_missed; int tgt; } event_t;             /* is_missed: print target `tgt`; else: record (index in recs) */
+static event_t *events = NULL; static int n_events = 0;
+static void push_event(int is_missed, int idx) { events = realloc(events, (size_t)(n_events + 1) * sizeof *events); events[n_events].is_missed = is_missed; events[n_events++].tgt = idx; }
+static void flush_region(const char *chrom, long beg0, long end0)
+{
+    for (int x = 0; x < n_tgt; ++x) {
+        tgt_t *t = &tgt[tgt_sorted[x]];
+        if (strcmp(t->chrom, chrom) || t->pos - 1 < beg0 || t->pos - 1 > end0 || t->used) continue;
+        t->used = 1;
+        push_event(1, tgt_sorted[x]);
+    }
+}
+
+/* The record `line` (S_in sample columns) in the alleles of target t: a new malloc'ed line, the same line when nothing
+ * changes, or NULL when mcall() would return -2 (the site is skipped).  *unseen: in/out. */
+static char *constrain_line(const char *line, const tgt_t *t, int S_in, int *unseen_io)
+{
+    if (t->nals > 5) DIE("Maximum accepted number of alleles is 5\n");
+    char *c = strdup(line); int nf; char **f = split(c, '\t', &nf);
+    int nalt = 0; char *altc = strdup(f[4]), **alts = split(altc, ',', &nalt);
+    if (!strcmp(f[4], ".")) nalt = 0;
+    const int nori = 1 + nalt, unseen = *unseen_io;
+    vcmp_t vc;
+    if (vcmp_set_ref(&vc, f[3], t->als[0]) < 0) DIE("The reference alleles are not compatible at %s:%s\n", f[0], f[1]);
+    int amap[8], nals = 1, has_new = 0; const char *als[8];
+    amap[0] = 0; als[0] = t->als[0];
+    for (int i = 1; i < t->nals; ++i) {
+        const int j = vcmp_find_allele(&vc, alts, nalt, t->als[i]);
+        if (j + 1 == unseen) { free(alts); free(altc); free(f); free(c); return NULL; }   /* mcall.c:1294-1303 */
+        if (j >= 0) amap[nals] = j + 1; else { amap[nals] = unseen >= 0 ? unseen : nori - 1; has_new = 1; }
+        als[nals++] = t->als[i];
+    }
+    char *unseen_al = NULL;
+    if (unseen) { amap[nals] = unseen; unseen_al = strdup(unseen == 0 ? f[3] : alts[unseen - 1]); als[nals++] = unseen_al; }
+    if (!has_new && nals == nori) { free(unseen_al); free(alts); free(altc); free(f); free(c); return strdup(line); }
+    int pl_map[64], npl = 0;
+    for (int i = 0; i < nals; ++i) for (int j = 0; j <= i; ++j) pl_map[npl++] = gt_index(amap[i], amap[j]);
+    /* FORMAT keys */
+    int nk; char *fmt = strdup(f[8]), **keys = split(fmt, ':', &nk);
+    int ipl = -1;
+    for (int i = 0; i < nk; ++i) if (!strcmp(keys[i], "PL")) ipl = i;
+    if (ipl < 0) DIE("no FORMAT/PL at %s:%s\n", f[0], f[1]);
+    /* the widest PL vector of the record is the stride of bcf_get_format_int32 */
+    int width = 1;
+    char ***sv = malloc((size_t)S_in * sizeof *sv); int *snv = malloc((size_t)S_in * sizeof *snv); char **sc = malloc((size_t)S_in * sizeof *sc);
+    for (int s = 0; s < S_in; ++s) {
+        sc[s] = strdup(f[9 + s]); sv[s] = split(sc[s], ':', &snv[s]);
+        if (ipl < snv[s]) { int w = 1; for (const char *q = sv[s][ipl]; *q; ++q) w += *q == ','; if (w > width) width = w; }
+    }
+    const size_t cap = strlen(line) * 4 + 4096 + (size_t)S_in * (size_t)npl * 12;
+    char *out = malloc(cap); size_t o = 0;
+    #define OUT(...) do { o += (size_t)snprintf(out + o, cap - o, __VA_ARGS__); } while (0)
+    OUT("%s\t%s\t%s\t%s\t", f[0], f[1], f[2], als[0]);
+    if (nals == 1) OUT("."); else for (int i = 1; i < nals; ++i) OUT("%s%s", i > 1 ? "," : "", als[i]);
+    OUT("\t%s\t%s\t", f[5], f[6]);
+    {   /* INFO: QS follows the alleles (absent alleles: 0) */
+        int ni; char *info = strdup(f[7]), **iv = split(info, ';', &ni);
+        for (int i = 0; i < ni; ++i) {
+            if (i) OUT(";");
+            if (!strncmp(iv[i], "QS=", 3)) {
+                int nq; char *qc = strdup(iv[i] + 3), **qv = split(qc, ',', &nq);
+                OUT("QS=");
+                for (int k = 0; k < nals; ++k) OUT("%s%.9g", k ? "," : "", amap[k] < nq ? (double)(float)atof(qv[amap[k]]) : 0.);
+                free(qv); free(qc);
+            } else OUT("%s", iv[i]);
+        }
+        free(iv); free(info);
+    }
+    OUT("\t%s", f[8]);
+    int32_t *ori = malloc((size_t)width * 4);
+    for (int s = 0; s < S_in; ++s) {
+        OUT("\t");
+        for (int w = 0; w < width; ++w) ori[w] = BCFGPU_INT32_VECTOR_END;
+        if (ipl < snv[s]) {
+            int np; char *pc = strdup(sv[s][ipl]), **pv = split(pc, ',', &np);
+            for (int j = 0; j < np && j < width; ++j) ori[j] = !strcmp(pv[j], ".") ? BCFGPU_INT32_MISSING : atoi(pv[j]);
+            free(pv); free(pc);
+        } else ori[0] = BCFGPU_INT32_MISSING;
+        for (int k = 0; k < nk; ++k) {
+            if (k) OUT(":");
+            if (k == ipl) {
+                int printed = 0;
+                for (int g = 0; g < npl; ++g) {
+                    int32_t v = pl_map[g] < width ? ori[pl_map[g]] : BCFGPU_INT32_VECTOR_END;
+                    if (v == BCFGPU_INT32_MISSING && unseen >= 0) {          /* an allele mpileup did not see: the unseen allele stands in */
+                        int ia, ib; gt_alleles(pl_map[g], &ia, &ib);
+                        int ko = gt_index(ia, unseen);
+                        if ((ko < width ? ori[ko] : BCFGPU_INT32_VECTOR_END) == BCFGPU_INT32_MISSING) ko = gt_index(ib, unseen);
+                        if ((ko < width ? ori[ko] : BCFGPU_INT32_VECTOR_END) == BCFGPU_INT32_MISSING) ko = gt_index(unseen, unseen);
+                        v = ko < width ? ori[ko] : BCFGPU_INT32_VECTOR_END;
+                    }
+                    if (g == 0 && v == BCFGPU_INT32_VECTOR_END) v = BCFGPU_INT32_MISSING;
+                    if (v == BCFGPU_INT32_VECTOR_END) break;
+                    if (printed++) OUT(",");
+                    if (v == BCFGPU_INT32_MISSING) OUT("."); else OUT("%d", v);
+                }
+            } else if (k < snv[s] && is_numberR(fmtR, n_fmtR, keys[k], strlen(keys[k])) && strcmp(sv[s][k], ".")) {
+                int nv; char *vc2 = strdup(sv[s][k]), **vv = split(vc2, ',', &nv);      /* Number=R: new[k] = old[als_map[k]] */
+                for (int a = 0; a < nals; ++a) OUT("%s%s", a ? "," : "", amap[a] < nv ? vv[amap[a]] : ".");
+                free(vv); free(vc2);
+            } else OUT("%s", k < snv[s] ? sv[s][k] : ".");
+        }
+    }
+    #undef OUT
+    free(ori);
+    for (int s = 0; s < S_in; ++s) { free(sv[s]); free(sc[s]); }
+    free(sv); free(snv); free(sc); free(keys); free(fmt); free(unseen_al); free(alts); free(altc); free(f); free(c);
+    *unseen_io = unseen ? nals - 1 : unseen;
+    return out;
+}
+
+/* next_line (vcfcall.c:501-605): the target of this record, or -1 when the record is not to be called */
+static int pick_target(const char *chrom, int pos, const char *ref, char **alts, int nalt)
+{
+    int best = -1, bestn = 0, any = 0;
+    char **als = malloc((size_t)(nalt + 1) * sizeof *als);
+    als[0] = (char*)ref; for (int i = 0; i < nalt; ++i) als[1 + i] = alts[i];
+    const int rec_indel = als_is_indel(als, nalt + 1) ? 1 : -1;
+    for (int x = 0; x < n_tgt; ++x) {
+        tgt_t *t = &tgt[tgt_sorted[x]];
+        if (strcmp(t->chrom, chrom) || t->pos != pos) continue;
+        any = 1;
+        if (t->used) continue;
+        vcmp_t vc; int n = 0;
+        if (vcmp_set_ref(&vc, ref, t->als[0]) == 0) {
+            n = 1;
+            if (nalt > 0 && t->nals > 1) for (int i = 1; i < t->nals; ++i) n += vcmp_find_allele(&vc, alts, nalt, t->als[i]) >= 0;
+        }
+        n *= rec_indel * (als_is_indel(t->als, t->nals) ? 1 : -1);
+        if (best < 0 || n > bestn) { best = tgt_sorted[x]; bestn = n; }
+    }
+    free(als);
+    (void)any;
+    return best;
+}
+
 int main(int argc, char **argv)
 {
-    int varonly = 0, out_tags = 0;
+    int varonly = 0, out_tags = 0, keepalt = 0;
+    const char *tgt_file = NULL; double prior = 1.1e-3;
     const char *smpl_file = NULL, *ploidy_file = NULL, *grp_arg = NULL, *grp_tag = NULL;
     char prior_an_tag[64] = "", prior_ac_tag[64] = "";
     char out_mode = 'v'; const char *out_path = "-";
     while (argc > 2 && argv[1][0] == '-') {
         if (!strcmp(argv[1], "-v")) { varonly = 1; ++argv; --argc; }
+        else if (!strcmp(argv[1], "-m")) { ++argv; --argc; }                                     /* the multiallelic caller: the only one here */
+        else if (!strcmp(argv[1], "-A")) { keepalt = 1; ++argv; --argc; }
+        else if (!strcmp(argv[1], "-i")) { insert_missed = 1; ++argv; --argc; }
+        else if (!strcmp(argv[1], "-C") && argc > 3) { if (strcmp(argv[2], "alleles")) DIE("-C: only `alleles` is supported\n"); cals = 1; argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-T") && argc > 3) { tgt_file = argv[2]; argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-P") && argc > 3) { prior = atof(argv[2]); argv += 2; argc -= 2; }      /* vcfcall.c:931-943 */
         else if (!strcmp(argv[1], "-O") && argc > 3) { out_mode = argv[2][0]; argv += 2; argc -= 2; }      /* version.c:67-82 */
         else if (!strncmp(argv[1], "-O", 2) && argv[1][2]) { out_mode = argv[1][2]; ++argv; --argc; }
         else if (!strcmp(argv[1], "-o") && argc > 3) { out_path = argv[2]; argv += 2; argc -= 2; }
@@ -122,7 +341,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "--ploidy-file") && argc > 3) { ploidy_file = argv[2]; argv += 2; argc -= 2; }
         else break;
     }
-    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-S samples.txt] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] [-O v|z|u|b] [-o out] in.vcf|in.bcf\n"); return 2; }
+    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-S samples.txt] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] [-A] [-P theta] [-C alleles -T targets.tab [-i]] [-O v|z|u|b] [-o out] in.vcf|in.bcf\n"); return 2; }
     /* ploidy definition (ploidy.c): regions per sex, '*' lines = the sex's default; the last sex named is the default sex */
     preg_t *preg = NULL; int npreg = 0; char last_sex[64] = "";
     if (ploidy_file) {
@@ -175,13 +394,43 @@ int main(int argc, char **argv)
             S = m;
         }
     }
+    char *prev_chrom = NULL; long prev_pos0 = 0;
+    if (cals) { if (!tgt_file) DIE("-C alleles needs -T targets\n"); tgt_parse(tgt_file); }
     int rrc;
     while ((rrc = vio_read_line(fin, hdr, &buf, &bufcap)) > 0) {
         size_t l = strlen(buf);
         if (!l) continue;
+        char *use = buf, *owned = NULL;
+        if (cals) {                                              /* -C alleles: pair the record with a target, rewrite it */
+            char *c2 = strdup(buf); int nf2; char **f2 = split(c2, '\t', &nf2);
+            if (nf2 != 9 + S_in) DIE("malformed VCF\n");
+            int nalt2 = 0; char *ac = strdup(f2[4]), **av = split(ac, ',', &nalt2);
+            if (!strcmp(f2[4], ".")) nalt2 = 0;
+            const int pos2 = atoi(f2[1]);
+            const int ti = pick_target(f2[0], pos2, f2[3], av, nalt2);
+            int skip = ti < 0;
+            if (!skip) {
+                tgt[ti].used = 1;
+                if (insert_missed) {                             /* tgt_flush (vcfcall.c:426-455) */
+                    const long p0 = pos2 - 1;
+                    if (!prev_chrom) flush_region(f2[0], 0, p0 - 1);
+                    else if (strcmp(prev_chrom, f2[0])) { flush_region(prev_chrom, prev_pos0 + 1, 1L << 40); flush_region(f2[0], 0, p0 - 1); }
+                    else flush_region(prev_chrom, prev_pos0, p0 - 1);
+                    free(prev_chrom); prev_chrom = strdup(f2[0]); prev_pos0 = p0;
+                }
+                int un = 0;
+                for (int i = 0; i < nalt2; ++i) { const char *a = av[i]; if (!un && (a[0] == 'X' || (a[0] == '<' && (a[1] == 'X' || a[1] == '*') && a[2] == '>'))) un = 1 + i; }
+                owned = constrain_line(buf, &tgt[ti], S_in, &un);
+                if (!owned) skip = 1; else use = owned;
+            }
+            free(av); free(ac); free(f2); free(c2);
+            if (skip) continue;
+        }
         if (n == cap) { cap = cap ? 2 * cap : 1024; recs = realloc(recs, (size_t)cap * sizeof *recs); }
+        if (cals) push_event(0, n);
         rec_t *r = &recs[n++];
-        r->line = strdup(buf);
+        r->line = strdup(use);
+        free(owned);
         r->fld = split(r->line, '\t', &r->nfld);
         if (S_in < 0 || r->nfld != 9 + S_in) DIE("malformed VCF\n");
         /* alleles; the unseen allele as vcfcall.c:1102-1111 finds it */
@@ -215,6 +464,10 @@ int main(int argc, char **argv)
     }
     if (rrc < 0) DIE("%s\n", vio_error());
     vio_close(fin);
+    if (cals && insert_missed) {                                 /* the targets behind the last record, then the sequences without any */
+        if (prev_chrom) flush_region(prev_chrom, prev_pos0, 1L << 40);
+        for (int x = 0; x < n_tgt; ++x) if (!tgt[tgt_sorted[x]].used) flush_region(tgt[tgt_sorted[x]].chrom, 0, 1L << 40);
+    }
     if (S <= 0) DIE("no samples\n");
 
     /* ---- -G: the group of every sample; ids in the order the groups first appear in the file (mcall.c:308-330) ---- */
@@ -310,7 +563,7 @@ int main(int argc, char **argv)
     /* ---- the device ---- */
     bcfgpu_cfg cfg; memset(&cfg, 0, sizeof cfg);
     cfg.device = 0; cfg.n_smpl = S; cfg.max_sites = n; cfg.max_reads = 64;
-    cfg.min_baseQ = 13; cfg.capQ = 60; cfg.call_theta = 1.1e-3; cfg.call_flag = varonly ? BCFGPU_CALL_VARONLY : 0; cfg.n_grp = ngrp; cfg.ploidy_max = 2;
+    cfg.min_baseQ = 13; cfg.capQ = 60; cfg.call_theta = prior; cfg.call_flag = (varonly ? BCFGPU_CALL_VARONLY : 0) | (keepalt ? BCFGPU_CALL_KEEPALT : 0); cfg.n_grp = ngrp; cfg.ploidy_max = 2;
     cfg.output_tags = out_tags;
     bcfgpu_ctx *ctx = NULL;
     CHECK(bcfgpu_create(&cfg, &ctx));
@@ -371,7 +624,21 @@ int main(int argc, char **argv)
     LN = open_memstream(&ln_buf, &ln_len);
     if (!LN) DIE("open_memstream failed\n");
     /* ---- the record loop (vcfcall.c:1137-1147, mcall.c:1627-1681) ---- */
-    for (int k = 0; k < n; ++k) {
+    const int n_out = cals ? n_events : n;
+    for (int ev = 0; ev < n_out; ++ev) {
+        if (cals && events[ev].is_missed) {                      /* -i: a target that met no record (tgt_flush_region, vcfcall.c:408-424) */
+            const tgt_t *t = &tgt[events[ev].tgt];
+            fprintf(LN, "%s\t%d\t.\t%s\t", t->chrom, t->pos, t->als[0]);
+            if (t->nals < 2) fputc('.', LN);
+            for (int i = 1; i < t->nals; ++i) fprintf(LN, "%s%s", i > 1 ? "," : "", t->als[i]);
+            fputs("\t.\t.\t.\tGT", LN);
+            for (int s2 = 0; s2 < S; ++s2) fputs("\t.", LN);
+            fputc(0, LN); fflush(LN);
+            if (vio_write_line(fout, hdr, ln_buf)) DIE("%s\n", vio_error());
+            rewind(LN);
+            continue;
+        }
+        const int k = cals ? events[ev].tgt : ev;
         const rec_t *r = &recs[k];
         const bcfgpu_call_site *c = &cs[k];
         if (c->ret == -2 || (varonly && c->ret == 0) || c->ret < 0) continue;

@@ -281,3 +281,23 @@ def test_c_multi_gpu_driver_matches_single_gpu(n_sites, n_smpl, depth, seed, var
     # one rank through the library's gather entry (no peer: the local copy only)
     got = subprocess.run([MGPU_EXE] + args + ["--gpus", "1", "--gather", "rccl"], check=True, stdout=subprocess.PIPE, text=True).stdout
     assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vcff,goldf,tab,ins", [
+    ("mpileup.vcf", "mpileup.cAls.out", "mpileup.tab", False), ("mpileup.2.vcf", "mpileup.cAls.2.out", "mpileup.2.tab", False),
+    ("mpileup.3.vcf", "mpileup.cAls.3.out", "mpileup.3.tab", True), ("mpileup.3.vcf", "mpileup.cAls.4.out", "mpileup.4.tab", True),
+    ("mpileup.3.vcf", "mpileup.cAls.5.out", "mpileup.5.tab", True), ("mpileup.4.vcf", "mpileup.cAls.6.out", "mpileup.6.tab", True),
+    ("mpileup.5.vcf", "mpileup.cAls.7.out", "mpileup.7.tab", True),
+    ("mpileup.cals.1.vcf", "mpileup.cals.8.out", "mpileup.cals.1.tab", False),      # an indel target paired with the SNP record
+    ("mpileup.cals.2.vcf", "mpileup.cals.9.out", "mpileup.cals.2.tab", False),      # SNP and indel records at one position
+])
+def test_c_call_driver_constrained_alleles(golden_dir, vcff, goldf, tab, ins):
+    """`bcfgpu_call -mA -C alleles -T targets [-i]` (test.pl:289-297, test_vcf_call_cAls): the records re-expressed in the
+    target alleles on the host (mcall_constrain_alleles, mcall.c:1271-1421; next_line, vcfcall.c:501-605; vcmp.c), called on
+    the device with -A, the lines of unmet targets inserted with -i -- the whole golden file, as VCF and through BCF."""
+    build_host()
+    G = os.path.join(golden_dir, "call")
+    cmd = [CALL_EXE, "-m", "-A", "-C", "alleles", "-T", os.path.join(G, tab)] + (["-i"] if ins else []) + [os.path.join(G, vcff)]
+    out = whole_file_checks(cmd, os.path.join(G, goldf))
+    assert sum(1 for ln in out.splitlines() if not ln.startswith("#")) > 0
