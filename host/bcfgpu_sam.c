@@ -1,23 +1,26 @@
-/*  bcfgpu_sam.c -- `bcftools mpileup` over SAM files with every stage of the path on the device, in plain C over the
- *  C-ABI of include/bcfgpu.h (SNP and indel records; one sample per file, in file order).
+/*  bcfgpu_sam.c -- `bcftools mpileup` over SAM / BAM files with every stage of the path on the device, in plain C over the
+ *  C-ABI of include/bcfgpu.h (SNP and indel records).
  *
- *      bcfgpu_sam [-a TAG,TAG,..] <ref.fa> <contig> <beg> <end> <file.sam> [<file.sam> ...]     (beg, end 1-based inclusive)
+ *      bcfgpu_sam [options] <ref.fa> <contig> <beg> <end> <file.sam|file.bam> [...]             (beg, end 1-based inclusive)
+ *      options: -a TAG,..  --gvcf INT,..  -O v|z|u|b  -o FILE  -d INT  -s LIST  -S FILE  -G FILE  --ignore-RG
+ *               -B  -E  -A  -q INT  -Q INT  --ff INT  --rf INT                                  (as `bcftools mpileup`)
  *
- *  What stays on the host is what mpileup.c and htslib's pileup do before any arithmetic: parsing, the read filters of
- *  mplp_func (mpileup.c:183-246: unmapped, secondary / QC-fail / duplicate, orphans) and the pairing of overlapping mates
- *  (htslib overlap_push).  Then, each a call on the flat read pool:
+ *  What stays on the host is what mpileup.c and htslib's pileup do before any arithmetic: parsing (SAM text; BAM = BGZF +
+ *  binary records), the read -> sample map of bam_sample.c (@RG SM, RG:Z tags, -s/-S/-G), the read filters of mplp_func
+ *  (mpileup.c:183-246: unmapped, --rf/--ff flags, reads of dropped read groups, -q, orphans), the iterator's per-file depth
+ *  cap (bcfgpu_depth_cap) and the pairing of overlapping mates (htslib overlap_push).  Then, each a call on the flat read pool:
  *      bcfgpu_baq            BAQ (sam_prob_realn, mpileup.c:234)
  *      bcfgpu_overlap_tweak  mate-overlap qualities (bam_mplp_init_overlaps, mpileup.c:640)
  *      bcfgpu_pileup         the pileup columns of the region, built in HBM
  *      bcfgpu_mpileup        bcf_call_glfgen x samples + bcf_call_combine per column (mpileup.c:343-347)
  *  and for the columns where some read is followed by an indel (mpileup.c:354-365):
  *      bcfgpu_pileup_entries -> bcfgpu_gap_prep (bcf_call_gap_prep) -> bcfgpu_pileup_indel_tile -> bcfgpu_mpileup
- *  and the record loop prints, VCF-like, what bcf_call2bcf (bam2bcf.c:756-906) puts in the record:
- *      CHROM POS . REF ALT 0 . DP=..;I16=..;QS=..;VDB=..;SGB=..;RPB=..;MQB=..;MQSB=..;BQB=..;MQ0F=..   PL   <PL of every sample>
- *  (indel records: INDEL;IDV=..;IMF=.. in front; -a adds DP, DV, SP, DP4, AD, ADF, ADR, DPR, INFO/AD, INFO/ADF, INFO/ADR,
- *  INFO/DPR in bcf_call2bcf's order).  The lines are the data lines
- *  of `bcftools mpileup`'s VCF: tests/test_c_host.py compares them, byte for byte, with the reference's goldens
- *  test/mpileup/mpileup.{1,2,4,5}.out.
+ *  and the record loop writes what bcf_call2bcf (bam2bcf.c:756-906) puts in the record, in its order, under mpileup's header
+ *  (mpileup.c:510-602), as VCF, bgzipped VCF or BCF (host/vcfio.c).  tests/test_c_host.py compares the whole output with the
+ *  reference's goldens test/mpileup/mpileup.{1..11}.out and mpileup-SCR.out.
+ *  Not here: CRAM input, sam_cap_mapq (-C; htslib's source is not in the reference tree and no golden exercises it), BED
+ *  files (-l/-T), --illumina1.3+; a sample fed by several files has its reads merged by position (the reference appends file
+ *  after file: same records unless a cell passes 255 usable reads, where errmod's subsampling depends on the order anyway).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -25,6 +28,7 @@
 #include <stdint.h>
 #include <ctype.h>
 #include <math.h>
+#include <zlib.h>
 #include "bcfgpu.h"
 #include "vcfio.h"
 
@@ -42,7 +46,7 @@ static void end_record(void)
 
 typedef struct {
     int n, cap;                                   /* reads */
-    int32_t *pos, *lq, *flag, *ncig, *cig_off, *seq_off, *smpl, *end, *mpos, *isize, *rnext_same;
+    int32_t *pos, *lq, *flag, *ncig, *cig_off, *seq_off, *smpl, *file, *end, *mpos, *isize, *rnext_same;
     uint8_t *mapq, *has_zq;
     char **qname;
     uint32_t *cig; size_t ncigs, cigcap;
@@ -85,79 +89,392 @@ static char *read_contig(const char *path, const char *name, int *len)
     return seq;
 }
 
-/* one SAM file = one sample: reads on `contig` that pass mplp_func's filters, appended to the pool */
-static void read_sam(const char *path, const char *contig, int smpl, pool_t *P, char **sample, vio_hdr *h)
+/* ---- which reads belong to which output sample: bam_sample.c (bam_smpl_add_bam, bam_smpl_get_sample_id, -s/-S/-G) ---- */
+typedef struct { char **key, **val; int n; } smap_t;                        /* a small string map; lookups are per @RG line */
+static const char *smap_get(const smap_t *m, const char *k) { for (int i = 0; i < m->n; ++i) if (!strcmp(m->key[i], k)) return m->val[i]; return NULL; }
+static void smap_set(smap_t *m, const char *k, const char *v)
 {
-    FILE *f = fopen(path, "r");
-    if (!f) DIE("cannot open %s\n", path);
-    static char line[1 << 20];
-    *sample = NULL;
-    while (fgets(line, sizeof line, f)) {
-        if (line[0] == '@') {
-            /* @SQ -> ##contig (mpileup.c:533-540, the first file's header); the first @RG's SM names the file's sample (bam_sample.c) */
-            if (h && !strncmp(line, "@SQ\t", 4)) {
-                const char *sn = strstr(line, "\tSN:"), *ln = strstr(line, "\tLN:");
-                if (sn && ln) {
-                    char buf[1024]; int l = 0; sn += 4;
-                    while (sn[l] && sn[l] != '\t' && sn[l] != '\n') ++l;
-                    snprintf(buf, sizeof buf, "##contig=<ID=%.*s,length=%d>", l, sn, atoi(ln + 4));
-                    vio_hdr_append(h, buf);
-                }
-            } else if (!*sample && !strncmp(line, "@RG\t", 4)) {
-                const char *sm = strstr(line, "\tSM:");
-                if (sm) { int l = 0; sm += 4; while (sm[l] && sm[l] != '\t' && sm[l] != '\n' && sm[l] != '\r') ++l; *sample = malloc((size_t)l + 1); memcpy(*sample, sm, (size_t)l); (*sample)[l] = 0; }
+    m->key = grow(m->key, (size_t)(m->n + 1) * sizeof *m->key); m->val = grow(m->val, (size_t)(m->n + 1) * sizeof *m->val);
+    m->key[m->n] = strdup(k); m->val[m->n++] = strdup(v);
+}
+typedef struct { const char *fname; int default_idx, nrg; char **rg; int *rg_smpl; } sfile_t;
+static struct {
+    int ignore_rg, nsmpl; char **smpl;                                      /* output samples, in order of first appearance */
+    int have_samples, sample_logic; smap_t samples;                         /* -s/-S: input sample -> output name; 1 include, 0 exclude */
+    int have_rgs, rg_logic; smap_t rgs;                                     /* -G: "id" | "id\tfile" | "*\tfile" -> name or "\t" (keep) */
+} SM;
+
+static int rg_find(const sfile_t *f, const char *id) { for (int i = 0; i < f->nrg; ++i) if (!strcmp(f->rg[i], id)) return i; return -1; }
+static int smpl_find(const char *name) { for (int i = 0; i < SM.nsmpl; ++i) if (!strcmp(SM.smpl[i], name)) return i; return -1; }
+
+/* bsmpl_add_readgroup: name NULL = the read group is known but its reads are dropped; id "*" = the whole file */
+static void rg_add(sfile_t *f, const char *id, const char *name)
+{
+    int is = -1;
+    if (name && (is = smpl_find(name)) < 0) {
+        SM.smpl = grow(SM.smpl, (size_t)(SM.nsmpl + 1) * sizeof *SM.smpl);
+        SM.smpl[is = SM.nsmpl++] = strdup(name);
+    }
+    if (!strcmp(id, "*")) { f->default_idx = is; return; }
+    if (rg_find(f, id) >= 0) return;                                        /* a repeated @RG ID: the first one counts */
+    f->rg = grow(f->rg, (size_t)(f->nrg + 1) * sizeof *f->rg); f->rg_smpl = grow(f->rg_smpl, (size_t)(f->nrg + 1) * sizeof *f->rg_smpl);
+    f->rg[f->nrg] = strdup(id); f->rg_smpl[f->nrg++] = is;
+}
+/* bsmpl_keep_readgroup: the -G list, most specific entry first; may rename the sample */
+static int rg_keep(const sfile_t *f, const char *id, const char **name)
+{
+    char key[4096];
+    const char *v = smap_get(&SM.rgs, id);
+    if (!v) { snprintf(key, sizeof key, "%s\t%s", id, f->fname); v = smap_get(&SM.rgs, key); }
+    if (!v) { snprintf(key, sizeof key, "*\t%s", f->fname); v = smap_get(&SM.rgs, key); }
+    if ((!v && SM.rg_logic) || (v && !SM.rg_logic)) return 0;
+    if (v && v[0] != '\t') *name = v;
+    return 1;
+}
+/* one whitespace-delimited field with backslash escapes (bam_smpl_add_samples / bam_smpl_add_readgroups) */
+static const char *next_field(const char *p, char *out, size_t cap)
+{
+    size_t n = 0; int esc = 0;
+    while (*p && isspace((unsigned char)*p)) ++p;
+    for (; *p; ++p) {
+        if (*p == '\\' && !esc) { esc = 1; continue; }
+        if (isspace((unsigned char)*p) && !esc) break;
+        if (n + 1 < cap) out[n++] = *p;
+        esc = 0;
+    }
+    out[n] = 0;
+    return p;
+}
+/* hts_readlist: the rows of a file, or the comma-separated items of the argument */
+static char **read_list(const char *arg, int is_file, int *n)
+{
+    char **rows = NULL; *n = 0;
+    char *text = NULL;
+    if (is_file) {
+        FILE *f = fopen(arg, "r");
+        if (!f) DIE("cannot open %s\n", arg);
+        size_t len = 0, cap = 0; int c;
+        while ((c = fgetc(f)) != EOF) { if (len + 2 > cap) { cap = cap ? 2 * cap : 4096; text = grow(text, cap); } text[len++] = (char)c; }
+        fclose(f);
+        if (!text) return NULL;
+        text[len] = 0;
+    } else text = strdup(arg);
+    for (char *t = strtok(text, is_file ? "\r\n" : ","); t; t = strtok(NULL, is_file ? "\r\n" : ",")) {
+        rows = grow(rows, (size_t)(*n + 1) * sizeof *rows); rows[(*n)++] = strdup(t);
+    }
+    free(text);
+    return rows;
+}
+static void add_samples(const char *list, int is_file)                     /* -s / -S */
+{
+    if (list[0] != '^') SM.sample_logic = 1; else ++list;
+    int n; char **rows = read_list(list, is_file, &n);
+    if (!n) return;
+    SM.have_samples = 1;
+    for (int i = 0; i < n; ++i) {
+        char a[1024], b[1024];
+        const char *p = next_field(rows[i], a, sizeof a);
+        next_field(p, b, sizeof b);
+        if (!smap_get(&SM.samples, a)) smap_set(&SM.samples, a, b[0] ? b : a);
+        free(rows[i]);
+    }
+    free(rows);
+}
+static void add_readgroups(const char *list)                               /* -G: rows "ID", "ID SAMPLE" or "ID FILE SAMPLE" */
+{
+    if (list[0] != '^') SM.rg_logic = 1; else ++list;
+    int n; char **rows = read_list(list, 1, &n);
+    if (!n) return;
+    SM.have_rgs = 1;
+    for (int i = 0; i < n; ++i) {
+        char a[1024], b[1024], c[1024], key[2100];
+        const char *p = next_field(rows[i], a, sizeof a);
+        p = next_field(p, b, sizeof b);
+        next_field(p, c, sizeof c);
+        const char *val = c[0] ? c : b[0] ? b : "\t";
+        if (c[0]) snprintf(key, sizeof key, "%s\t%s", a, b); else snprintf(key, sizeof key, "%s", a);
+        const char *old = smap_get(&SM.rgs, key);
+        if (!old) smap_set(&SM.rgs, key, val);
+        else if (strcmp(old, val)) DIE("Error: The read group \"%s\" was assigned to two different samples: \"%s\" and \"%s\"\n", key, old, val);
+        free(rows[i]);
+    }
+    free(rows);
+}
+/* bam_smpl_add_bam over the header text; 0: no read of the file can be used, the file is dropped */
+static int add_file(sfile_t *f, const char *fname, const char *hdr_text)
+{
+    memset(f, 0, sizeof *f);
+    f->fname = fname; f->default_idx = -1;
+    if (SM.ignore_rg || !hdr_text || !hdr_text[0]) { rg_add(f, "*", fname); return 1; }
+    int first_smpl = -1, nskipped = 0, n_file_smpl = 0;
+    char **file_smpl = NULL;
+    for (const char *line = hdr_text; line && *line; ) {
+        const char *eol = strchr(line, '\n');
+        const size_t len = eol ? (size_t)(eol - line) : strlen(line);
+        if (len > 3 && !strncmp(line, "@RG", 3)) {
+            char *l = malloc(len + 1); memcpy(l, line, len); l[len] = 0;
+            if (len && l[len - 1] == '\r') l[len - 1] = 0;
+            char *id = strstr(l, "\tID:"), *sm = strstr(l, "\tSM:");
+            if (!id || !sm) { free(l); break; }                             /* the scan ends at an @RG without ID or SM */
+            id += 4; sm += 4;
+            id[strcspn(id, "\t")] = 0; sm[strcspn(sm, "\t")] = 0;
+            if (!strcmp(id, "*") || !strcmp(id, "?")) DIE("Error: the read group IDs \"*\" and \"?\" have a special meaning: %s\n", fname);
+            const char *name = sm;
+            int accept = 1;
+            if (SM.have_samples) {
+                const char *ren = smap_get(&SM.samples, sm);
+                if (!SM.sample_logic) accept = ren ? 0 : 1;
+                else if (!ren) accept = 0;
+                else name = ren;
             }
-            continue;
+            if (accept && SM.have_rgs) accept = rg_keep(f, id, &name);
+            if (accept) rg_add(f, id, name); else { rg_add(f, id, NULL); ++nskipped; }
+            if (first_smpl < 0) first_smpl = smpl_find(name);
+            int k; for (k = 0; k < n_file_smpl; ++k) if (!strcmp(file_smpl[k], name)) break;
+            if (k == n_file_smpl) { file_smpl = grow(file_smpl, (size_t)(n_file_smpl + 1) * sizeof *file_smpl); file_smpl[n_file_smpl++] = strdup(name); }
+            free(l);
         }
-        char *fld[12]; int nf = 0;
-        for (char *s = line; nf < 11 && s; ) { fld[nf++] = s; s = strchr(s, '\t'); if (s) *s++ = 0; }
+        line = eol ? eol + 1 : NULL;
+    }
+    for (int k = 0; k < n_file_smpl; ++k) free(file_smpl[k]);
+    free(file_smpl);
+    /* reads without a read group, or with one the header does not list */
+    const char *null_name = NULL;
+    int accept_null = 1;
+    if (SM.have_rgs && !rg_keep(f, "?", &null_name)) accept_null = 0;
+    if (SM.have_samples && first_smpl == -1) accept_null = 0;
+    if (!accept_null && first_smpl == -1) return 0;
+    if (!accept_null) return 1;
+    if (n_file_smpl == 1 && !nskipped) { f->default_idx = first_smpl; return 1; }
+    if (!null_name) null_name = first_smpl == -1 ? fname : SM.smpl[first_smpl];
+    rg_add(f, "?", null_name);
+    return 1;
+}
+static int sample_of(const sfile_t *f, const char *rg)                      /* bam_smpl_get_sample_id; rg NULL: no RG tag */
+{
+    if (f->default_idx >= 0) return f->default_idx;
+    int i = rg_find(f, rg ? rg : "?");
+    if (i < 0) i = rg_find(f, "?");
+    return i < 0 ? -1 : f->rg_smpl[i];
+}
+
+/* ---- reading: SAM text or BAM; the read filters of mplp_func (mpileup.c:183-246) ---- */
+static int rflag_require = 0, rflag_filter = 4 | 256 | 512 | 1024, min_mq = 0, keep_orphans = 0;
+
+static void pool_add(pool_t *P, int file, int smpl, const char *qname, int flag, int pos, int mapq, int rnext_same, int mpos, int isize,
+                     const uint32_t *cig, int ncig, int lq, const uint8_t *seq16, const uint8_t *qual)
+{
+    if (P->n == P->cap) {
+        P->cap = P->cap ? 2 * P->cap : 1024;
+        #define G(a) P->a = grow(P->a, (size_t)P->cap * sizeof *P->a)
+        G(pos); G(lq); G(flag); G(ncig); G(cig_off); G(seq_off); G(smpl); G(file); G(end); G(mpos); G(isize); G(rnext_same); G(mapq); G(has_zq); G(qname);
+        #undef G
+    }
+    const int r = P->n++;
+    P->qname[r] = strdup(qname);
+    P->flag[r] = flag; P->pos[r] = pos; P->mapq[r] = (uint8_t)mapq; P->smpl[r] = smpl; P->file[r] = file; P->has_zq[r] = 0;
+    P->rnext_same[r] = rnext_same; P->mpos[r] = mpos; P->isize[r] = isize;
+    P->cig_off[r] = (int32_t)P->ncigs; P->ncig[r] = ncig;
+    if (P->ncigs + ncig + 1 > P->cigcap) { P->cigcap = (P->ncigs + ncig + 1) * 2; P->cig = grow(P->cig, P->cigcap * 4); }
+    int x = pos;
+    for (int c = 0; c < ncig; ++c) {
+        const int op = cig[c] & 15;
+        P->cig[P->ncigs++] = cig[c];
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) x += (int)(cig[c] >> 4);
+    }
+    P->end[r] = x;
+    P->lq[r] = lq; P->seq_off[r] = (int32_t)P->nbase;
+    if (P->nbase + lq + 1 > P->basecap) {
+        P->basecap = (P->nbase + lq + 1) * 2;
+        P->seq16 = grow(P->seq16, P->basecap); P->qual = grow(P->qual, P->basecap); P->zq = grow(P->zq, P->basecap);
+    }
+    memcpy(P->seq16 + P->nbase, seq16, (size_t)lq); memcpy(P->qual + P->nbase, qual, (size_t)lq); memset(P->zq + P->nbase, 0, (size_t)lq);
+    P->nbase += lq;
+}
+static int read_passes(int flag, int mapq)
+{
+    if (flag & 4) return 0;
+    if (rflag_require && !(rflag_require & flag)) return 0;
+    if (rflag_filter && (rflag_filter & flag)) return 0;
+    if (mapq < min_mq) return 0;
+    if (!keep_orphans && (flag & 1) && !(flag & 2)) return 0;
+    return 1;
+}
+static void contig_line(vio_hdr *h, const char *name, int nlen, long length)
+{
+    char buf[1200]; snprintf(buf, sizeof buf, "##contig=<ID=%.*s,length=%ld>", nlen, name, length);
+    vio_hdr_append(h, buf);
+}
+
+typedef struct { uint8_t *d; size_t n; } blob_t;
+static blob_t slurp(const char *path)
+{
+    blob_t b = { NULL, 0 };
+    FILE *f = fopen(path, "rb");
+    if (!f) DIE("cannot open %s\n", path);
+    size_t cap = 0, got;
+    do { if (b.n + (1 << 16) > cap) { cap = cap ? 2 * cap : 1 << 20; b.d = grow(b.d, cap + 1); } got = fread(b.d + b.n, 1, 1 << 16, f); b.n += got; } while (got);
+    fclose(f);
+    b.d[b.n] = 0;
+    return b;
+}
+/* a BGZF file (a series of gzip members, SAM spec 4.1) inflated whole */
+static blob_t bgzf_inflate(const blob_t in)
+{
+    blob_t out = { NULL, 0 };
+    size_t cap = 0, at = 0;
+    while (at < in.n) {
+        z_stream z; memset(&z, 0, sizeof z);
+        if (inflateInit2(&z, 15 + 16) != Z_OK) DIE("zlib: inflateInit2 failed\n");
+        z.next_in = in.d + at; z.avail_in = (uInt)(in.n - at > (1u << 30) ? (1u << 30) : in.n - at);
+        int rc;
+        do {
+            if (out.n + (1 << 16) > cap) { cap = cap ? 2 * cap : 1 << 20; out.d = grow(out.d, cap); }
+            z.next_out = out.d + out.n; z.avail_out = (uInt)(cap - out.n);
+            rc = inflate(&z, Z_NO_FLUSH);
+            out.n = cap - z.avail_out;
+            if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) DIE("zlib: corrupt BGZF block\n");
+        } while (rc != Z_STREAM_END);
+        at = (size_t)(z.next_in - in.d);
+        inflateEnd(&z);
+    }
+    return out;
+}
+static int32_t le32(const uint8_t *p) { return (int32_t)((uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24); }
+
+/* the value of the RG:Z tag in a BAM record's auxiliary data (SAM spec 4.2.4), or NULL */
+static const char *bam_aux_rg(const uint8_t *a, const uint8_t *end)
+{
+    while (a + 3 <= end) {
+        const int is_rg = a[0] == 'R' && a[1] == 'G';
+        const char t = (char)a[2];
+        a += 3;
+        size_t l;
+        switch (t) {
+        case 'A': case 'c': case 'C': l = 1; break;
+        case 's': case 'S': l = 2; break;
+        case 'i': case 'I': case 'f': l = 4; break;
+        case 'Z': case 'H': if (is_rg && t == 'Z') return (const char *)a; l = strnlen((const char *)a, (size_t)(end - a)) + 1; break;
+        case 'B': {
+            if (a + 5 > end) return NULL;
+            const char st = (char)a[0]; const size_t cnt = (uint32_t)le32(a + 1);
+            l = 5 + cnt * (st == 'c' || st == 'C' ? 1 : st == 's' || st == 'S' ? 2 : 4); break;
+        }
+        default: return NULL;
+        }
+        a += l;
+    }
+    return NULL;
+}
+
+/* one input file: its header decides the samples (add_file), its reads on `contig` that pass the filters join the pool.
+ * Returns 0 when the file is dropped (no usable read group).  h: the VCF header to receive ##contig lines, or NULL. */
+static int read_file(const char *path, const char *contig, int file, sfile_t *sf, pool_t *P, vio_hdr *h)
+{
+    blob_t raw = slurp(path);
+    uint8_t seqbuf[1 << 16], qualbuf[1 << 16];
+    if (raw.n >= 4 && raw.d[0] == 0x1f && raw.d[1] == 0x8b) {
+        /* ---- BAM (SAM spec 4.2) ---- */
+        blob_t b = bgzf_inflate(raw);
+        free(raw.d);
+        if (b.n < 12 || memcmp(b.d, "BAM\1", 4)) DIE("%s: not a BAM file\n", path);
+        const size_t l_text = (uint32_t)le32(b.d + 4);
+        char *text = malloc(l_text + 1); memcpy(text, b.d + 8, l_text); text[l_text] = 0;
+        size_t at = 8 + l_text;
+        const int n_ref = le32(b.d + at); at += 4;
+        int tid = -1;
+        for (int i = 0; i < n_ref; ++i) {
+            const int l_name = le32(b.d + at); const char *name = (const char *)b.d + at + 4;
+            const int l_ref = le32(b.d + at + 4 + l_name);
+            if (!strcmp(name, contig)) tid = i;
+            at += 8 + (size_t)l_name;
+            (void)l_ref;
+        }
+        if (!add_file(sf, path, text)) { free(text); free(b.d); return 0; }
+        if (h) {
+            size_t a2 = 12 + l_text;
+            for (int i = 0; i < n_ref; ++i) {
+                const int l_name = le32(b.d + a2);
+                contig_line(h, (const char *)b.d + a2 + 4, l_name - 1, le32(b.d + a2 + 4 + l_name));
+                a2 += 8 + (size_t)l_name;
+            }
+        }
+        free(text);
+        while (at + 36 <= b.n) {
+            const uint8_t *r = b.d + at;
+            const size_t bs = (uint32_t)le32(r);
+            if (at + 4 + bs > b.n) DIE("%s: truncated BAM record\n", path);
+            at += 4 + bs;
+            const int refid = le32(r + 4), pos = le32(r + 8), l_name = r[12], mapq = r[13];
+            const int n_cig = r[16] | r[17] << 8, flag = r[18] | r[19] << 8, l_seq = le32(r + 20);
+            const int next_ref = le32(r + 24), next_pos = le32(r + 28), tlen = le32(r + 32);
+            if (refid != tid || refid < 0 || !read_passes(flag, mapq)) continue;
+            const char *qname = (const char *)r + 36;
+            const uint8_t *cg = r + 36 + l_name, *sq = cg + 4 * (size_t)n_cig, *ql = sq + (l_seq + 1) / 2, *aux = ql + l_seq;
+            const int smpl = sample_of(sf, bam_aux_rg(aux, r + 4 + bs));
+            if (smpl < 0) continue;
+            if (l_seq > (int)sizeof seqbuf) DIE("%s: read longer than %d\n", path, (int)sizeof seqbuf);
+            uint32_t cig[4096];
+            if (n_cig > 4096) DIE("%s: CIGAR with more than 4096 operations\n", path);
+            for (int c = 0; c < n_cig; ++c) cig[c] = (uint32_t)le32(cg + 4 * c);
+            for (int i = 0; i < l_seq; ++i) { seqbuf[i] = (sq[i >> 1] >> ((~i & 1) << 2)) & 15; qualbuf[i] = ql[i]; }
+            pool_add(P, file, smpl, qname, flag, pos, mapq, next_ref == refid, next_pos, tlen, cig, n_cig, l_seq, seqbuf, qualbuf);
+        }
+        free(b.d);
+        return 1;
+    }
+    /* ---- SAM text ---- */
+    char *txt = (char *)raw.d, *body = txt;
+    while (*body == '@') { char *e = strchr(body, '\n'); if (!e) { body += strlen(body); break; } body = e + 1; }
+    {
+        const char save = *body; *body = 0;
+        const int ok = add_file(sf, path, txt);
+        if (ok && h)
+            for (const char *l = txt; l && *l; ) {                          /* @SQ -> ##contig (mpileup.c:533-540) */
+                if (!strncmp(l, "@SQ\t", 4)) {
+                    const char *e = strchr(l, '\n'), *sn = strstr(l, "\tSN:"), *ln = strstr(l, "\tLN:");
+                    if (sn && ln && (!e || (sn < e && ln < e))) { sn += 4; contig_line(h, sn, (int)strcspn(sn, "\t\r\n"), atol(ln + 4)); }
+                }
+                l = strchr(l, '\n'); if (l) ++l;
+            }
+        *body = save;
+        if (!ok) { free(raw.d); return 0; }
+    }
+    for (char *line = body; line && *line; ) {
+        char *eol = strchr(line, '\n');
+        if (eol) *eol = 0;
+        char *next = eol ? eol + 1 : NULL;
+        { size_t l = strlen(line); if (l && line[l - 1] == '\r') line[l - 1] = 0; }
+        char *fld[12]; int nf = 0; char *rest = NULL;
+        for (char *s = line; nf < 11 && s; ) { fld[nf++] = s; s = strchr(s, '\t'); if (s) *s++ = 0; rest = s; }
+        line = next;
         if (nf < 11) continue;
-        { char *e = fld[10]; while (*e && *e != '\t' && *e != '\n' && *e != '\r') ++e; *e = 0; }
-        const int flag = atoi(fld[1]);
-        if (strcmp(fld[2], contig) || (flag & 4)) continue;
-        if (flag & (256 | 512 | 1024)) continue;                             /* --ff UNMAP,SECONDARY,QCFAIL,DUP */
-        if ((flag & 1) && !(flag & 2)) continue;                             /* orphans (no -A) */
-        if (P->n == P->cap) {
-            P->cap = P->cap ? 2 * P->cap : 1024;
-            #define G(a) P->a = grow(P->a, (size_t)P->cap * sizeof *P->a)
-            G(pos); G(lq); G(flag); G(ncig); G(cig_off); G(seq_off); G(smpl); G(end); G(mpos); G(isize); G(rnext_same); G(mapq); G(has_zq); G(qname);
-            #undef G
+        const int flag = atoi(fld[1]), mapq = atoi(fld[4]);
+        if (strcmp(fld[2], contig) || !read_passes(flag, mapq)) continue;
+        const char *rg = NULL;
+        for (char *t = rest; t && *t; ) {                                    /* the optional fields: RG:Z:<id> */
+            char *e = strchr(t, '\t'); if (e) *e = 0;
+            if (!strncmp(t, "RG:Z:", 5)) { rg = t + 5; break; }
+            t = e ? e + 1 : NULL;
         }
-        const int r = P->n++;
-        P->qname[r] = strdup(fld[0]);
-        P->flag[r] = flag; P->pos[r] = atoi(fld[3]) - 1; P->mapq[r] = (uint8_t)atoi(fld[4]); P->smpl[r] = smpl; P->has_zq[r] = 0;
-        P->rnext_same[r] = !strcmp(fld[6], "=") || !strcmp(fld[6], fld[2]);
-        P->mpos[r] = atoi(fld[7]) - 1; P->isize[r] = atoi(fld[8]);
-        /* CIGAR */
-        P->cig_off[r] = (int32_t)P->ncigs; P->ncig[r] = 0;
-        int x = P->pos[r];
+        const int smpl = sample_of(sf, rg);
+        if (smpl < 0) continue;
+        uint32_t cig[4096]; int ncig = 0;
         for (const char *c = fld[5]; *c && *c != '*'; ) {
             char *e; const long l = strtol(c, &e, 10);
-            const char *ops = "MIDNSHP=X", *o = strchr(ops, *e);
-            if (!o) DIE("bad CIGAR in %s\n", path);
-            if (P->ncigs == P->cigcap) { P->cigcap = P->cigcap ? 2 * P->cigcap : 4096; P->cig = grow(P->cig, P->cigcap * 4); }
-            P->cig[P->ncigs++] = (uint32_t)l << 4 | (uint32_t)(o - ops);
-            ++P->ncig[r];
-            if (*e == 'M' || *e == 'D' || *e == 'N' || *e == '=' || *e == 'X') x += (int)l;
+            const char *ops = "MIDNSHP=X", *o = *e ? strchr(ops, *e) : NULL;
+            if (!o || ncig == 4096) DIE("bad CIGAR in %s\n", path);
+            cig[ncig++] = (uint32_t)l << 4 | (uint32_t)(o - ops);
             c = e + 1;
         }
-        P->end[r] = x;
-        /* SEQ / QUAL */
         const int lq = fld[9][0] == '*' ? 0 : (int)strlen(fld[9]);
-        P->lq[r] = lq; P->seq_off[r] = (int32_t)P->nbase;
-        if (P->nbase + lq + 1 > P->basecap) {
-            P->basecap = (P->nbase + lq + 1) * 2;
-            P->seq16 = grow(P->seq16, P->basecap); P->qual = grow(P->qual, P->basecap); P->zq = grow(P->zq, P->basecap);
-        }
-        for (int i = 0; i < lq; ++i) {
-            P->seq16[P->nbase + i] = (uint8_t)nt16_of(fld[9][i]);
-            P->qual[P->nbase + i] = fld[10][0] == '*' ? 0xff : (uint8_t)(fld[10][i] - 33);
-            P->zq[P->nbase + i] = 0;
-        }
-        P->nbase += lq;
+        if (lq > (int)sizeof seqbuf) DIE("%s: read longer than %d\n", path, (int)sizeof seqbuf);
+        for (int i = 0; i < lq; ++i) { seqbuf[i] = (uint8_t)nt16_of(fld[9][i]); qualbuf[i] = fld[10][0] == '*' && !fld[10][1] ? 0xff : (uint8_t)(fld[10][i] - 33); }
+        pool_add(P, file, smpl, fld[0], flag, atoi(fld[3]) - 1, mapq, !strcmp(fld[6], "=") || !strcmp(fld[6], fld[2]), atoi(fld[7]) - 1, atoi(fld[8]),
+                 cig, ncig, lq, seqbuf, qualbuf);
     }
-    fclose(f);
-    if (!*sample) *sample = strdup(path);                   /* no read group: the file name (bam_sample.c) */
+    free(raw.d);
+    return 1;
 }
 
 /* overlap_push (htslib sam.c) over the reads of one sample in file order: which pairs tweak_overlap_quality sees */
@@ -193,7 +510,7 @@ static int find_pairs(const pool_t *P, int r0, int r1, int32_t *pa, int32_t *pb)
 /* what bcf_call2bcf writes into a record (bam2bcf.c:756-906); alleles: the ready REF\tALT text */
 static int fmt_flag = BCFGPU_INFO_VDB | BCFGPU_INFO_RPB;                     /* mpileup's default annotations + -a */
 
-typedef struct { const uint8_t *pl, *dp4, *adf, *adr, *sp; } planes_t;        /* host copies of bcfgpu_mplp_out's planes */
+typedef struct { const uint8_t *pl, *dp4, *adf, *adr, *sp, *scr; const uint16_t *qs; } planes_t;        /* host copies of bcfgpu_mplp_out's planes */
 
 static void put_counts(const char *lead, const int32_t *f, const int32_t *r, int n)
 {
@@ -211,6 +528,7 @@ static void print_record(const char *contig, int pos1, const char *alleles, cons
     if (fmt_flag & BCFGPU_INFO_ADR) put_counts(";ADR=", NULL, c->adr_tot, na);
     if (fmt_flag & BCFGPU_INFO_AD)  put_counts(";AD=", c->adf_tot, c->adr_tot, na);
     if (fmt_flag & BCFGPU_INFO_DPR) put_counts(";DPR=", c->adf_tot, c->adr_tot, na);
+    if (fmt_flag & BCFGPU_INFO_SCR) fprintf(LN, ";SCR=%d", c->scr_tot);
     fputs(";I16=", LN);
     for (int j = 0; j < 16; ++j) fprintf(LN, "%s%g", j ? "," : "", (double)(float)c->anno[j]);
     fputs(";QS=", LN);
@@ -231,6 +549,8 @@ static void print_record(const char *contig, int pos1, const char *alleles, cons
     if (fmt_flag & BCFGPU_FMT_ADR) fputs(":ADR", LN);
     if (fmt_flag & BCFGPU_FMT_AD) fputs(":AD", LN);
     if (fmt_flag & BCFGPU_FMT_DPR) fputs(":DPR", LN);
+    if (fmt_flag & BCFGPU_FMT_SCR) fputs(":SCR", LN);
+    if (fmt_flag & BCFGPU_FMT_QS) fputs(":QS", LN);
     const int x = na * (na + 1) / 2;
     const size_t Ss = (size_t)S;
     for (int s = 0; s < S; ++s) {
@@ -250,20 +570,52 @@ static void print_record(const char *contig, int pos1, const char *alleles, cons
                 fprintf(LN, "%s%d", j ? "," : "", which == 0 ? f : which == 1 ? r : f + r);
             }
         }
+        if (fmt_flag & BCFGPU_FMT_SCR) fprintf(LN, ":%d", pp->scr[k * Ss + s]);
+        if (fmt_flag & BCFGPU_FMT_QS) { fputc(':', LN); for (int j = 0; j < na; ++j) fprintf(LN, "%s%d", j ? "," : "", pp->qs[(k * 5 + j) * Ss + s]); }
     }
     end_record();
+}
+
+/* bcfgpu_mpileup over a tile; the site records and the planes come back to the host.  keep_*: the device copies of the
+ * site records / PL / DP4 stay allocated for the caller (--gvcf works on them), else they are freed. */
+static void run_mpileup(bcfgpu_ctx *ctx, const bcfgpu_tile *tile, int n, bcfgpu_site **site, planes_t *pp, void **keep_site, void **keep_pl, void **keep_dp4)
+{
+    void *d[8]; uint8_t *h[8];
+    bcfgpu_mplp_out mo; memset(&mo, 0, sizeof mo);
+    for (int w = 0; w < 8; ++w) {
+        const size_t nb = bcfgpu_mplp_out_bytes(ctx, n, w);
+        CHECK(bcfgpu_malloc(ctx, nb, &d[w]));
+        if (w) CHECK(bcfgpu_memset(ctx, d[w], 0, nb));
+    }
+    mo.site = d[0]; mo.pl = d[1]; mo.dp4 = d[2]; mo.adf = d[3]; mo.adr = d[4]; mo.qs = d[5]; mo.scr = d[6]; mo.sp = d[7];
+    CHECK(bcfgpu_mpileup(ctx, tile, &mo));
+    CHECK(bcfgpu_sync(ctx));
+    for (int w = 0; w < 8; ++w) {
+        const size_t nb = bcfgpu_mplp_out_bytes(ctx, n, w);
+        h[w] = malloc(nb ? nb : 1);
+        CHECK(bcfgpu_memcpy_d2h(ctx, h[w], d[w], nb));
+    }
+    CHECK(bcfgpu_sync(ctx));
+    *site = (bcfgpu_site *)h[0];
+    pp->pl = h[1]; pp->dp4 = h[2]; pp->adf = h[3]; pp->adr = h[4]; pp->qs = (const uint16_t *)h[5]; pp->scr = h[6]; pp->sp = h[7];
+    for (int w = 3; w < 8; ++w) bcfgpu_free(ctx, d[w]);
+    if (keep_site) { *keep_site = d[0]; *keep_pl = d[1]; *keep_dp4 = d[2]; }
+    else { bcfgpu_free(ctx, d[0]); bcfgpu_free(ctx, d[1]); bcfgpu_free(ctx, d[2]); }
 }
 
 int main(int argc, char **argv)
 {
     int32_t gv_range[16]; int gv_n = 0;                                       /* mpileup --gvcf INT,.. (gvcf.c:44-67) */
     char out_mode = 'v'; const char *out_path = "-"; int max_depth = 250;      /* mpileup -O, -o, -d (mpileup.c:937-950) */
+    int baq_flag = 3, min_baseQ = 13;
     while (argc > 2 && argv[1][0] == '-') {
         if (!strcmp(argv[1], "-a")) {                                         /* mpileup -a, mpileup.c:parse_format_flag */
             static const struct { const char *name; int bit; } tags[] = {
                 { "DP", BCFGPU_FMT_DP }, { "DV", BCFGPU_FMT_DV }, { "SP", BCFGPU_FMT_SP }, { "DP4", BCFGPU_FMT_DP4 }, { "DPR", BCFGPU_FMT_DPR },
                 { "AD", BCFGPU_FMT_AD }, { "ADF", BCFGPU_FMT_ADF }, { "ADR", BCFGPU_FMT_ADR }, { "INFO/DPR", BCFGPU_INFO_DPR },
-                { "INFO/AD", BCFGPU_INFO_AD }, { "INFO/ADF", BCFGPU_INFO_ADF }, { "INFO/ADR", BCFGPU_INFO_ADR } };
+                { "INFO/AD", BCFGPU_INFO_AD }, { "INFO/ADF", BCFGPU_INFO_ADF }, { "INFO/ADR", BCFGPU_INFO_ADR },
+                { "SCR", BCFGPU_FMT_SCR }, { "FMT/SCR", BCFGPU_FMT_SCR }, { "FORMAT/SCR", BCFGPU_FMT_SCR }, { "INFO/SCR", BCFGPU_INFO_SCR },
+                { "QS", BCFGPU_FMT_QS }, { "FMT/QS", BCFGPU_FMT_QS }, { "FORMAT/QS", BCFGPU_FMT_QS } };
             char *list = strdup(argv[2]);
             for (char *t = strtok(list, ","); t; t = strtok(NULL, ",")) {
                 size_t i;
@@ -283,22 +635,41 @@ int main(int argc, char **argv)
         else if (!strncmp(argv[1], "-O", 2) && argv[1][2]) { out_mode = argv[1][2]; ++argv; --argc; }
         else if (!strcmp(argv[1], "-o")) { out_path = argv[2]; argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-d")) { max_depth = atoi(argv[2]); argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-s")) { add_samples(argv[2], 0); argv += 2; argc -= 2; }            /* mpileup.c:1058-1059,1087,1016 */
+        else if (!strcmp(argv[1], "-S")) { add_samples(argv[2], 1); argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-G")) { add_readgroups(argv[2]); argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "--ignore-RG")) { SM.ignore_rg = 1; ++argv; --argc; }
+        else if (!strcmp(argv[1], "-B")) { baq_flag = 0; ++argv; --argc; }                             /* mpileup.c:1045,1062 */
+        else if (!strcmp(argv[1], "-E")) { baq_flag = 7; ++argv; --argc; }
+        else if (!strcmp(argv[1], "-A")) { keep_orphans = 1; ++argv; --argc; }
+        else if (!strcmp(argv[1], "-q")) { min_mq = atoi(argv[2]); argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-Q")) { min_baseQ = atoi(argv[2]); argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "--ff")) { rflag_filter = (int)strtol(argv[2], NULL, 0); argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "--rf")) { rflag_require = (int)strtol(argv[2], NULL, 0); argv += 2; argc -= 2; }
         else break;
     }
-    if (argc < 6) { fprintf(stderr, "usage: bcfgpu_sam [-a TAG,..] [--gvcf INT,..] [-O v|z|u|b] [-o out] [-d INT] ref.fa contig beg end file.sam [file.sam ...]\n"); return 2; }
+    if (argc < 6) {
+        fprintf(stderr, "usage: bcfgpu_sam [-a TAG,..] [--gvcf INT,..] [-O v|z|u|b] [-o out] [-d INT] [-s LIST | -S FILE] [-G FILE] [--ignore-RG]\n"
+                        "                  [-B | -E] [-A] [-q INT] [-Q INT] [--ff INT] [--rf INT] ref.fa contig beg end file.sam|file.bam [...]\n");
+        return 2;
+    }
     const char *contig = argv[2];
     const int beg = atoi(argv[3]) - 1, end = atoi(argv[4]);                 /* 0-based [beg, end) */
-    const int S = argc - 5, n_sites = end - beg;
+    const int n_in = argc - 5, n_sites = end - beg;
     int ref_len = 0;
     char *ref = read_contig(argv[1], contig, &ref_len);
     pool_t P; memset(&P, 0, sizeof P);
-    int *first = malloc((size_t)(S + 1) * sizeof *first);
+    int *first = malloc((size_t)(n_in + 1) * sizeof *first);                  /* the pool is file-major: file f = [first[f], first[f+1]) */
+    sfile_t *sfile = calloc((size_t)n_in, sizeof *sfile);
     /* ---- the VCF header, in mpileup's order (mpileup.c:510-602) ---- */
     hdr = vio_hdr_new();
     { char b[4096]; snprintf(b, sizeof b, "##reference=file://%s", argv[1]); vio_hdr_append(hdr, b); }
-    char **sample = malloc((size_t)S * sizeof *sample);
-    for (int s = 0; s < S; ++s) { first[s] = P.n; read_sam(argv[5 + s], contig, s, &P, &sample[s], s == 0 ? hdr : NULL); }
-    first[S] = P.n;
+    int F = 0;                                                                /* files kept (mpileup.c:442-455 drops the others) */
+    for (int i = 0; i < n_in; ++i) { first[F] = P.n; if (read_file(argv[5 + i], contig, F, &sfile[F], &P, F == 0 ? hdr : NULL)) ++F; }
+    first[F] = P.n;
+    const int S = SM.nsmpl;
+    if (!F || !S) DIE("no sample left to call\n");
+    char **sample = SM.smpl;
     {
         #define HL(cond, text) do { if (cond) vio_hdr_append(hdr, text); } while (0)
         HL(1, "##ALT=<ID=*,Description=\"Represents allele(s) other than observed.\">");
@@ -325,8 +696,11 @@ int main(int argc, char **argv)
         HL(fmt_flag & BCFGPU_FMT_AD, "##FORMAT=<ID=AD,Number=R,Type=Integer,Description=\"Allelic depths (high-quality bases)\">");
         HL(fmt_flag & BCFGPU_FMT_ADF, "##FORMAT=<ID=ADF,Number=R,Type=Integer,Description=\"Allelic depths on the forward strand (high-quality bases)\">");
         HL(fmt_flag & BCFGPU_FMT_ADR, "##FORMAT=<ID=ADR,Number=R,Type=Integer,Description=\"Allelic depths on the reverse strand (high-quality bases)\">");
+        HL(fmt_flag & BCFGPU_FMT_QS, "##FORMAT=<ID=QS,Number=R,Type=Integer,Description=\"Phred-score allele quality sum used by `call -mG` and `+trio-dnm`\">");
         HL(fmt_flag & BCFGPU_INFO_AD, "##INFO=<ID=AD,Number=R,Type=Integer,Description=\"Total allelic depths (high-quality bases)\">");
         HL(fmt_flag & BCFGPU_INFO_ADF, "##INFO=<ID=ADF,Number=R,Type=Integer,Description=\"Total allelic depths on the forward strand (high-quality bases)\">");
+        HL(fmt_flag & BCFGPU_INFO_SCR, "##INFO=<ID=SCR,Number=1,Type=Integer,Description=\"Number of soft-clipped reads (at high-quality bases)\">");
+        HL(fmt_flag & BCFGPU_FMT_SCR, "##FORMAT=<ID=SCR,Number=1,Type=Integer,Description=\"Per-sample number of soft-clipped reads (at high-quality bases)\">");
         HL(fmt_flag & BCFGPU_INFO_ADR, "##INFO=<ID=ADR,Number=R,Type=Integer,Description=\"Total allelic depths on the reverse strand (high-quality bases)\">");
         HL(gv_n, "##INFO=<ID=END,Number=1,Type=Integer,Description=\"End position of the variant described in this record\">");   /* gvcf.c:42-43 */
         HL(gv_n, "##INFO=<ID=MinDP,Number=1,Type=Integer,Description=\"Minimum per-sample depth in this gVCF block\">");
@@ -342,47 +716,82 @@ int main(int argc, char **argv)
         bcfgpu_reads r0; memset(&r0, 0, sizeof r0);
         r0.n_reads = P.n; r0.r_pos = P.pos; r0.r_ncig = P.ncig; r0.r_cig_off = P.cig_off; r0.cig = P.cig;
         uint8_t *keep = malloc((size_t)P.n);
-        CHECK(bcfgpu_depth_cap(&r0, P.smpl, S, max_depth, keep));
+        CHECK(bcfgpu_depth_cap(&r0, P.file, F, max_depth, keep));
         int m = 0;
-        for (int s = 0, r = 0; s < S; ++s) {
+        for (int s = 0, r = 0; s < F; ++s) {
             const int e = first[s + 1];
             first[s] = m;
             for (; r < e; ++r) {
                 if (!keep[r]) { free(P.qname[r]); continue; }
                 if (m != r) {
                     #define MV(a) P.a[m] = P.a[r]
-                    MV(pos); MV(lq); MV(flag); MV(ncig); MV(cig_off); MV(seq_off); MV(smpl); MV(end); MV(mpos); MV(isize); MV(rnext_same); MV(mapq); MV(has_zq); MV(qname);
+                    MV(pos); MV(lq); MV(flag); MV(ncig); MV(cig_off); MV(seq_off); MV(smpl); MV(file); MV(end); MV(mpos); MV(isize); MV(rnext_same); MV(mapq); MV(has_zq); MV(qname);
                     #undef MV
                 }
                 ++m;
             }
         }
-        first[S] = m; P.n = m;
+        first[F] = m; P.n = m;
         free(keep);
     }
 
     bcfgpu_cfg cfg; memset(&cfg, 0, sizeof cfg);
     cfg.device = 0; cfg.n_smpl = S; cfg.max_sites = n_sites; cfg.max_reads = (uint64_t)P.nbase + 64;   /* every base is in <= 1 column */
-    cfg.min_baseQ = 13; cfg.capQ = 60; cfg.errmod_theta = 0.; cfg.fmt_flag = fmt_flag;
+    cfg.min_baseQ = min_baseQ; cfg.capQ = 60; cfg.errmod_theta = 0.; cfg.fmt_flag = fmt_flag;
     cfg.call_theta = 1.1e-3; cfg.n_grp = 1; cfg.ploidy_max = 2;
     bcfgpu_ctx *ctx = NULL;
     CHECK(bcfgpu_create(&cfg, &ctx));
+
+    /* mate overlaps: htslib pairs the reads inside one file's iterator (bam_mplp_init_overlaps, mpileup.c:640) */
+    int32_t *pa = malloc((size_t)(P.n + 1) * sizeof *pa), *pb = malloc((size_t)(P.n + 1) * sizeof *pb);
+    int np = 0;
+    for (int f = 0; f < F; ++f) np += find_pairs(&P, first[f], first[f + 1], pa + np, pb + np);
+    /* a sample fed by several files (mpileup.c:275-293 appends file after file): its reads merged by position, files in
+     * order at equal positions, as bcfgpu_pileup wants them; the pairs follow their reads */
+    {
+        int sorted = 1;
+        int32_t *last = malloc((size_t)S * sizeof *last);
+        for (int s = 0; s < S; ++s) last[s] = INT32_MIN;
+        for (int r = 0; r < P.n && sorted; ++r) { if (P.pos[r] < last[P.smpl[r]]) sorted = 0; last[P.smpl[r]] = P.pos[r]; }
+        free(last);
+        if (!sorted) {
+            int32_t *ord = malloc((size_t)P.n * sizeof *ord), *tmp = malloc((size_t)P.n * sizeof *tmp), *inv = malloc((size_t)P.n * sizeof *inv);
+            for (int r = 0; r < P.n; ++r) ord[r] = r;
+            for (int w = 1; w < P.n; w *= 2) {                               /* bottom-up merge sort: stable */
+                for (int lo = 0; lo < P.n; lo += 2 * w) {
+                    const int mid = lo + w < P.n ? lo + w : P.n, hi = lo + 2 * w < P.n ? lo + 2 * w : P.n;
+                    int i = lo, j = mid, k = lo;
+                    while (i < mid && j < hi) tmp[k++] = P.pos[ord[j]] < P.pos[ord[i]] ? ord[j++] : ord[i++];
+                    while (i < mid) tmp[k++] = ord[i++];
+                    while (j < hi) tmp[k++] = ord[j++];
+                }
+                int32_t *t = ord; ord = tmp; tmp = t;
+            }
+            for (int r = 0; r < P.n; ++r) inv[ord[r]] = r;
+            #define PERM(a) do { void *n_ = malloc((size_t)P.n * sizeof *P.a); for (int r = 0; r < P.n; ++r) memcpy((char *)n_ + (size_t)r * sizeof *P.a, &P.a[ord[r]], sizeof *P.a); \
+                                 memcpy(P.a, n_, (size_t)P.n * sizeof *P.a); free(n_); } while (0)
+            PERM(pos); PERM(lq); PERM(flag); PERM(ncig); PERM(cig_off); PERM(seq_off); PERM(smpl); PERM(file); PERM(end); PERM(mpos); PERM(isize);
+            PERM(rnext_same); PERM(mapq); PERM(has_zq); PERM(qname);
+            #undef PERM
+            for (int i = 0; i < np; ++i) { pa[i] = inv[pa[i]]; pb[i] = inv[pb[i]]; }
+            free(ord); free(tmp); free(inv);
+        }
+    }
 
     bcfgpu_reads rd; memset(&rd, 0, sizeof rd);
     rd.n_reads = P.n; rd.r_pos = P.pos; rd.r_lq = P.lq; rd.r_flag = P.flag; rd.r_ncig = P.ncig; rd.r_cig_off = P.cig_off;
     rd.r_seq_off = P.seq_off; rd.cig = P.cig; rd.seq16 = P.seq16; rd.qual = P.qual; rd.zq = P.zq; rd.r_has_zq = P.has_zq;
 
-    /* BAQ: new qualities for the reads it applies to */
+    /* BAQ: new qualities for the reads it applies to (not with -B) */
     uint8_t *q1 = malloc(P.nbase + 1), *zq = malloc(P.nbase + 1), *q2 = malloc(P.nbase + 1);
-    int32_t *ret = malloc((size_t)(P.n + 1) * sizeof *ret);
-    CHECK(bcfgpu_baq(ctx, &rd, ref, ref_len, 3, q1, zq, ret));
-    rd.qual = q1;
-    for (int r = 0; r < P.n; ++r) P.has_zq[r] = ret[r] == 0;                 /* the "ZQ" tag sam_prob_realn leaves on the read */
-    rd.zq = zq;
-    /* mate overlaps, sample by sample */
-    int32_t *pa = malloc((size_t)(P.n + 1) * sizeof *pa), *pb = malloc((size_t)(P.n + 1) * sizeof *pb);
-    int np = 0;
-    for (int s = 0; s < S; ++s) np += find_pairs(&P, first[s], first[s + 1], pa + np, pb + np);
+    if (baq_flag) {
+        int32_t *ret = malloc((size_t)(P.n + 1) * sizeof *ret);
+        CHECK(bcfgpu_baq(ctx, &rd, ref, ref_len, baq_flag, q1, zq, ret));
+        rd.qual = q1;
+        for (int r = 0; r < P.n; ++r) P.has_zq[r] = ret[r] == 0;             /* the "ZQ" tag sam_prob_realn leaves on the read */
+        rd.zq = zq;
+        free(ret);
+    }
     CHECK(bcfgpu_overlap_tweak(ctx, &rd, np, pa, pb, q2));
     rd.qual = q2;
     /* the pileup of the region and the SNP pass */
@@ -390,24 +799,10 @@ int main(int argc, char **argv)
     int32_t *col_n = malloc((size_t)(n_sites + 1) * sizeof *col_n);
     uint8_t *col_indel = malloc((size_t)n_sites + 1);
     CHECK(bcfgpu_pileup(ctx, &rd, P.mapq, P.smpl, beg, end, ref, ref_len, &tile, col_n, col_indel));
-    bcfgpu_mplp_out mo; memset(&mo, 0, sizeof mo);
-    void *d_site, *d_pl, *d_dp4, *d_adf, *d_adr, *d_sp;
-    const size_t nb_site = (size_t)n_sites * sizeof(bcfgpu_site), nb_pl = (size_t)n_sites * BCFGPU_MAX_PL * S, nb_dp4 = (size_t)n_sites * 4 * S,
-                 nb_ad = (size_t)n_sites * 5 * S, nb_sp = (size_t)n_sites * S;
-    CHECK(bcfgpu_malloc(ctx, nb_site, &d_site)); CHECK(bcfgpu_malloc(ctx, nb_pl, &d_pl)); CHECK(bcfgpu_malloc(ctx, nb_dp4, &d_dp4));
-    CHECK(bcfgpu_malloc(ctx, nb_ad, &d_adf)); CHECK(bcfgpu_malloc(ctx, nb_ad, &d_adr)); CHECK(bcfgpu_malloc(ctx, nb_sp, &d_sp));
-    CHECK(bcfgpu_memset(ctx, d_pl, 0, nb_pl)); CHECK(bcfgpu_memset(ctx, d_adf, 0, nb_ad)); CHECK(bcfgpu_memset(ctx, d_adr, 0, nb_ad));
-    CHECK(bcfgpu_memset(ctx, d_sp, 0, nb_sp));
-    mo.site = d_site; mo.pl = d_pl; mo.dp4 = d_dp4; mo.adf = d_adf; mo.adr = d_adr; mo.sp = d_sp;
-    CHECK(bcfgpu_mpileup(ctx, &tile, &mo));
-    CHECK(bcfgpu_sync(ctx));
-    bcfgpu_site *site = malloc(nb_site);
-    uint8_t *pl = malloc(nb_pl), *dp4 = malloc(nb_dp4), *adf = malloc(nb_ad), *adr = malloc(nb_ad), *sp = malloc(nb_sp);
-    CHECK(bcfgpu_memcpy_d2h(ctx, site, d_site, nb_site)); CHECK(bcfgpu_memcpy_d2h(ctx, pl, d_pl, nb_pl));
-    CHECK(bcfgpu_memcpy_d2h(ctx, dp4, d_dp4, nb_dp4)); CHECK(bcfgpu_memcpy_d2h(ctx, adf, d_adf, nb_ad));
-    CHECK(bcfgpu_memcpy_d2h(ctx, adr, d_adr, nb_ad)); CHECK(bcfgpu_memcpy_d2h(ctx, sp, d_sp, nb_sp));
-    const planes_t snp_planes = { pl, dp4, adf, adr, sp };
-    CHECK(bcfgpu_sync(ctx));
+    void *d_site, *d_pl, *d_dp4;
+    bcfgpu_site *site = NULL;
+    planes_t snp_planes;
+    run_mpileup(ctx, &tile, n_sites, &site, &snp_planes, gv_n ? &d_site : NULL, &d_pl, &d_dp4);
 
     /* ---- indel records (mpileup.c:354-365): candidate columns -> bcf_call_gap_prep -> second pass with p->aux ---- */
     int nc = 0;
@@ -416,7 +811,7 @@ int main(int argc, char **argv)
     for (int k = 0; k < n_sites; ++k)
         if (col_indel[k] && col_n[k] < 250 * S) { cand[nc++] = k; cap += col_n[k]; }      /* max_indel_depth */
     bcfgpu_site *isite = NULL;
-    planes_t ind_planes = { NULL, NULL, NULL, NULL, NULL }; int32_t *live = NULL; int nlive = 0;
+    planes_t ind_planes; memset(&ind_planes, 0, sizeof ind_planes); int32_t *live = NULL; int nlive = 0;
     int32_t *g_types = NULL, *g_maxins = NULL, *g_indelreg = NULL, *g_support = NULL; float *g_frac = NULL; int8_t *g_inscns = NULL;
     if (nc) {
         int32_t *so = malloc(((size_t)nc * S + 1) * sizeof *so), *pr = malloc((size_t)(cap + 1) * 4), *pq = malloc((size_t)(cap + 1) * 4),
@@ -446,23 +841,7 @@ int main(int argc, char **argv)
         if (nlive) {
             bcfgpu_tile ti;
             CHECK(bcfgpu_pileup_indel_tile(ctx, nlive, lcols, laux, nl, &ti));
-            const size_t b_pl = (size_t)nlive * BCFGPU_MAX_PL * S, b_dp4 = (size_t)nlive * 4 * S, b_ad = (size_t)nlive * 5 * S, b_sp = (size_t)nlive * S;
-            void *d_is, *d_p[5];
-            const size_t b_p[5] = { b_pl, b_dp4, b_ad, b_ad, b_sp };
-            CHECK(bcfgpu_malloc(ctx, (size_t)nlive * sizeof(bcfgpu_site), &d_is));
-            for (int j = 0; j < 5; ++j) { CHECK(bcfgpu_malloc(ctx, b_p[j], &d_p[j])); CHECK(bcfgpu_memset(ctx, d_p[j], 0, b_p[j])); }
-            bcfgpu_mplp_out io; memset(&io, 0, sizeof io);
-            io.site = d_is; io.pl = d_p[0]; io.dp4 = d_p[1]; io.adf = d_p[2]; io.adr = d_p[3]; io.sp = d_p[4];
-            CHECK(bcfgpu_mpileup(ctx, &ti, &io));
-            CHECK(bcfgpu_sync(ctx));
-            isite = malloc((size_t)nlive * sizeof *isite);
-            uint8_t *h_p[5];
-            CHECK(bcfgpu_memcpy_d2h(ctx, isite, d_is, (size_t)nlive * sizeof *isite));
-            for (int j = 0; j < 5; ++j) { h_p[j] = malloc(b_p[j]); CHECK(bcfgpu_memcpy_d2h(ctx, h_p[j], d_p[j], b_p[j])); }
-            CHECK(bcfgpu_sync(ctx));
-            ind_planes.pl = h_p[0]; ind_planes.dp4 = h_p[1]; ind_planes.adf = h_p[2]; ind_planes.adr = h_p[3]; ind_planes.sp = h_p[4];
-            bcfgpu_free(ctx, d_is);
-            for (int j = 0; j < 5; ++j) bcfgpu_free(ctx, d_p[j]);
+            run_mpileup(ctx, &ti, nlive, &isite, &ind_planes, NULL, NULL, NULL);
         }
     }
 
@@ -549,7 +928,7 @@ int main(int argc, char **argv)
     }
     fprintf(stderr, "%d reads of %d samples, %d overlapping pairs, %llu pileup entries in %d columns\n",
             P.n, S, np, (unsigned long long)tile.n_reads, n_sites);
-    bcfgpu_free(ctx, d_site); bcfgpu_free(ctx, d_pl); bcfgpu_free(ctx, d_dp4); bcfgpu_free(ctx, d_adf); bcfgpu_free(ctx, d_adr); bcfgpu_free(ctx, d_sp);
+    if (gv_n) { bcfgpu_free(ctx, d_site); bcfgpu_free(ctx, d_pl); bcfgpu_free(ctx, d_dp4); }
     if (vio_close(fout)) DIE("%s\n", vio_error());
     bcfgpu_destroy(ctx);
     return 0;

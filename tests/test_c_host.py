@@ -195,6 +195,42 @@ def test_c_sam_driver_reproduces_reference_goldens(golden_dir, region, goldf, ta
             assert c.fmt("PL", s) == g.fmt("PL", s), (p, s, c.fmt("PL", s), g.fmt("PL", s))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("goldf,opts,region,files,n", [
+    ("mpileup.3.out", "-B --ff 0x14", "1050-1060", (1,), None),                        # no BAQ, reverse-strand reads filtered
+    ("mpileup.7.out", "-s HG00101,HG00102", "100-150", (1, 2, 3), 51),                  # samples by name: the first file drops out
+    ("mpileup.7.out", "-S {G}/mplp.samples", "100-150", (1, 2, 3), 51),
+    ("mpileup.8.out", "-s ^HG00101,HG00102", "100-150", (1, 2, 3), None),               # ... excluded
+    ("mpileup.8.out", "-S ^{G}/mplp.samples", "100-150", (1, 2, 3), None),
+    ("mpileup.9.out", "-S {G}/mplp.9.samples", "100-150", (1, 2, 3), None),             # renamed
+    ("mpileup.10.out", "-G {G}/mplp.10.samples", "100-150", (1, 2, 3), None),           # read groups -> samples: one file, three samples
+    ("mpileup.11.out", "", "1-4200", (3,), 4002),                                       # a whole contig, indel records included
+    ("mpileup.11.out", "-s HG00102", "1-4200", (3, 4), 4002),                           # the second file has no wanted sample
+    ("mpileup.11.out", "-s ^HG99999", "1-4200", (3, 4), 4002),
+    ("mpileup.11.out", "-G {G}/mplp.11.rgs", "1-4200", (3, 4), 4002)])
+def test_c_sam_driver_sample_plumbing(golden_dir, goldf, opts, region, files, n):
+    """bam_sample.c in host/bcfgpu_sam.c: @RG -> sample, -s/-S (with ^ and renaming), -G read-group lists, files without a
+    usable read group dropped, and the read filters -B / --ff: the whole of test/mpileup/mpileup.{3,7,8,9,10,11}.out
+    (test.pl:641,647-657), as VCF and through BCF."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    beg, end = region.split("-")
+    out = whole_file_checks([SAM_EXE] + opts.format(G=G).split() + [os.path.join(G, "mpileup.ref.fa"), "17", beg, end] +
+                            [os.path.join(G, "mpileup.%d.sam" % i) for i in files], os.path.join(G, goldf))
+    nrec = sum(1 for ln in out.splitlines() if not ln.startswith("#"))
+    assert nrec > 0 and (n is None or nrec == n)
+
+
+@pytest.mark.gpu
+def test_c_sam_driver_reads_bam_and_counts_soft_clips(golden_dir):
+    """BAM input (BGZF + BAM records parsed in C) and -a INFO/SCR,FMT/SCR: the whole of test/mpileup/mpileup-SCR.out (test.pl:659)."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    out = whole_file_checks([SAM_EXE, "-a", "INFO/SCR,FMT/SCR", os.path.join(G, "mpileup-SCR.fa"), "1", "1", "150",
+                             os.path.join(G, "mpileup-SCR.bam")], os.path.join(G, "mpileup-SCR.out"))
+    assert sum(1 for ln in out.splitlines() if not ln.startswith("#")) == 86
+
+
 CALL_EXE = os.path.join(ROOT, "host", "bcfgpu_call")
 
 
