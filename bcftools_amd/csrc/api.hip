@@ -416,11 +416,11 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
         if (!d_st) { hipMalloc(&d_st, 16 * 8); hipMemset(d_st, 0, 16 * 8); }
         if (getenv("BCFGPU_STAMPS")) {
             unsigned long long h[16]; hipStreamSynchronize(c->stream); hipMemcpy(h, d_st, sizeof h, hipMemcpyDeviceToHost);
-            unsigned long long tot = 0; for (int i = 0; i < 9; ++i) tot += h[i];
-            if (tot) { fprintf(stderr, "[glfgen stamps %%]"); for (int i = 0; i < 9; ++i) fprintf(stderr, " %.1f", 100.0 * h[i] / tot); fprintf(stderr, "  (total %.3g wave-cycles)\n", (double)tot); }
+            unsigned long long tot = 0; for (int i = 0; i < 10; ++i) tot += h[i];
+            if (tot) { fprintf(stderr, "[glfgen stamps %%]"); for (int i = 0; i < 10; ++i) fprintf(stderr, " %.1f", 100.0 * h[i] / tot); fprintf(stderr, "  (total %.3g wave-cycles)\n", (double)tot); }
             hipMemset(d_st, 0, 16 * 8);
+            g.stamps = d_st;                          // the stamps cost atomics: only when asked for
         }
-        g.stamps = d_st;
     }
 #endif
     HIPCHK(hipMemsetAsync(c->d_hist, 0, (size_t)tile->n_sites * H_SIZE * sizeof(int), c->stream));

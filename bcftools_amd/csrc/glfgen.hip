@@ -15,12 +15,11 @@
 //   phase B, one lane per CELL: the lane walks its own slice of keys: per-base counts, QS, ADF/ADR, DP4 counts and
 //     errmod_cal, whose order-sensitive double sums are replayed in the reference's order (bit-identical results).
 //
-// LDS holds 2 bytes per read instead of the 5 of the raw tile, which is what lets four to five workgroups share a CU.
+// LDS holds 2 bytes per read instead of the 5 of the raw tile, which is what lets four workgroups share a CU.
 //
 // errmod_cal() sorts the n 16-bit codes and walks them from the largest down.  Only the relative order of codes with
-// the same base matters (per-base accumulators), and within a base the code order is the order of key7 = q<<1|strand.
-// The sort is therefore replaced by a counting pass into rank-ordered u8 slots (rank of a quality = popcount of the
-// lane's quality mask above it) and a descending walk over the slots.
+// the same base matters (per-base accumulators), and within a base the code order is the order of key7 = q<<1|strand:
+// a counting pass per lane (count_runs) and a branch-free walk over the (quality, strand) runs (walk_runs).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "kernels.h"
@@ -29,7 +28,7 @@ namespace bcfgpu {
 
 // Diagnostics build: cycles (s_memtime) every wavefront spends between the kernel's phase boundaries, summed into
 // P.stamps[0..8] (0: prologue up to phase A, 1: phase A, 2: barrier, 3: partial sums + slice set-up, 4: pass 1,
-// 5: walk of the primary base, 6: other bases, 7: epilogue, 8: flush); tools/pmc_abl.sh prints them.
+// 5: walk of the primary base, 6: other bases, 7: epilogue, 8: flush, 9: slot fill of the primary base); tools/stamps.sh prints them.
 #ifdef BCFGPU_DIAG
 #define GLF_STAMP_DECL unsigned long long stamp_t_ = __builtin_amdgcn_s_memtime();
 #define GLF_STAMP(i_) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0 && P.stamps) atomicAdd(&P.stamps[i_], now_ - stamp_t_); stamp_t_ = now_; }
@@ -57,17 +56,21 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return v;
 }
 
-// LDS layout (bytes): fk[264] f64 | slots[NSLOT/2][WG] u32 (a dword per quality rank) | hist [slots][H_SIZE] i32 | site totals [slots][SITE_NSUM] u64 | keys u16[cap+8]
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+    return v;
+}
+
+// LDS layout (bytes): fk[264] f64 | slots[NSLOT][WG] u32 (a dword per quality rank) | hist [slots][H_SIZE] i32 | site totals [slots][SITE_NSUM] u64 | keys u16[cap+8]
 #define LDS_FK   0
 #define LDS_CNT  2112
 #define NSLOT    16
 #ifndef FU
 #define FU       4         // source elements per trip of the slot counting
 #endif
-#ifndef WSTEP
-#define WSTEP    3         // reads of one (quality, strand) run taken per step of the errmod walk
-#endif
-#define LDS_HIST_OFF (LDS_CNT + (NSLOT / 2) * WG * 4)
+#define LDS_HIST_OFF (LDS_CNT + NSLOT * WG * 4)
 #define NPART 12           // per-lane partial sums of phase A: the I16 site totals anno[4..15]
 
 // the u16 key phase A leaves for phase B
@@ -77,15 +80,21 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 #define KEY_B(k)    (((k) >> 7) & 7u)
 #define KEY_SC(k)   (((k) >> 10) & 1u)
 
-// Counts of the reads with the NSLOT/2 highest qualities of the mask `qm` (bit q = some read of this base has quality q), in
-// the lane's slot column: the dword of rank(q) holds the reverse-strand reads of q in its low half and the forward-strand
-// ones in its high half -- reverse first is the descending order of errmod_cal's sorted codes q<<5|strand<<4|base
-// (bam2bcf.c:203).  `src(j)` returns key7 = q<<1|strand of source element j, or -1.
-template <bool FIRST, class Src>
-__device__ __forceinline__ void fill_slots(uint32_t *s_slot, uint64_t qm, int tid, Src src, int nsrc)
+// errmod_cal() sorts the cell's codes q<<5|strand<<4|base and walks them from the largest down; only the order among the
+// reads of one base matters (per-base accumulators), and there the order is that of key7 = q<<1|reverse: quality by quality
+// from the highest, the reverse-strand reads of a quality before its forward-strand ones.  The sort is replaced by counts:
+// count_runs() leaves, in the lane's column of `s_slot`, one dword per distinct quality of the lane in descending order
+// (rank r = qualities above it in the lane's mask):  reverse-strand reads | forward-strand reads << 8 | quality << 16.
+// NRANK qualities per round (binned base qualities give a handful; a lane with more goes round again).
+//   qm      bit q = some read of the source has quality q
+//   src(j)  key7 of source element j, or -1 when the element is not of this base / was rejected
+// Returns sum of the qualities of the reads counted (QS).
+#define NRANK 16
+template <class Src>
+__device__ __forceinline__ uint32_t count_runs(uint32_t *s_slot, uint64_t qm, bool first, int tid, Src src, int nsrc)
 {
     #pragma unroll
-    for (int k = 0; k < NSLOT / 2; ++k) s_slot[k * WG + tid] = 0;
+    for (int k = 0; k < NRANK; ++k) s_slot[k * WG + tid] = 0;
     const uint64_t qm1 = qm >> 1;                                   // rank of q = qualities above it = popcount(qm >> (q + 1))
     // FU source elements per trip: their reads are in flight before the first count is added
     for (int j = 0; __any(j < nsrc); j += FU) {
@@ -94,90 +103,95 @@ __device__ __forceinline__ void fill_slots(uint32_t *s_slot, uint64_t qm, int ti
         for (int u = 0; u < FU; ++u) k4[u] = j + u < nsrc ? src(j + u) : -1;
         #pragma unroll
         for (int u = 0; u < FU; ++u) {
-            const int key = k4[u];
-            const int q = (key >> 1) & 63;
-            if (key >= 0 && (FIRST || ((qm >> q) & 1ull))) {       // FIRST: the mask still holds every quality of the source
+            const int key = k4[u], q = (key >> 1) & 63;
+            if (key >= 0 && (first || ((qm >> q) & 1ull))) {       // first round: the mask holds every quality of the source
                 const int r = __popcll(qm1 >> q);
-                if (r < NSLOT / 2) atomicAdd(&s_slot[r * WG + tid], (key & 1) ? 1u : 0x10000u);
+                if (r < NRANK) atomicAdd(&s_slot[r * WG + tid], (key & 1) ? 1u : 0x100u);
             }
         }
     }
+    // the quality of every rank joins its counts
+    uint32_t qs = 0;
+    uint64_t m = qm;
+    for (int r = 0; r < NRANK && __any(m != 0); ++r) {
+        const int q = 63 - __clzll((long long)(m | 1ull));
+        const uint32_t c = s_slot[r * WG + tid];
+        if (m != 0) { s_slot[r * WG + tid] = c | (uint32_t)q << 16; qs += (uint32_t)q * ((c & 0xffu) + (c >> 8)); }
+        m &= ~(1ull << q);
+    }
+    return qs;
 }
 
-// Descending walk of errmod_cal for one base: every lane steps through its own reads from the highest (quality,
-// strand) key down.  errmod_cal sorts the codes; here the lane's qualities are the set bits of a 64-bit mask and the
-// number of reads per (quality, strand) sits in NSLOT rank-ordered u8 slots.  The control flow is uniform over the
-// wavefront: rank by rank (a lane's r-th highest quality, whatever its value), the reverse-strand run and then the
-// forward-strand run of that quality, each run in chunks of WCH reads.  A read of a run adds
-// fk[reads of its strand so far] * beta[q][reads of the base so far][n] to the double sum, in the reference's order; lanes
-// whose run is shorter than the chunk add fk = +0 times a finite table entry, which leaves their (non-negative) sum as it
-// is, so the sums stay bit-identical while no lane branches.  A lane with more than NSLOT/2 distinct qualities gets its
-// slots refilled for the remaining ones (binned base qualities give a handful).
+// The descending walk of errmod_cal for one base over the runs count_runs() left: the t-th read of the lane adds
+//     fk[reads of its strand so far] * beta[q][t][n]
+// to the double sum, in the reference's order.  Every lane steps through its own runs, one read per step, in straight-line
+// code (selects only: 64 lanes are at 64 different places of their runs); the loop runs for as many steps as the deepest
+// cell of the wavefront has reads of the base, and a lane that is through adds fk = +0 times a finite table entry, which
+// leaves its (non-negative) sum as it is.  The loads of a step are in flight while the step before is added; they are
+// issued whether or not a lane still has a read (no branch around them: the compiler can then count the loads in flight
+// and wait for the older one only).
 // `brow`: byte offset of beta[0][0][n] (stored q, k, n: tables.cpp; the q = 0 row is all zeros).
-#ifndef WCH
-#define WCH 3
-#endif
 template <class Src>
-__device__ __forceinline__ double walk_ranks(uint32_t *s_slot, uint64_t qm, const double *s_fk, const char *bbase, int tid,
-                                             uint32_t brow, Src src, int nsrc, uint32_t &rev_out, uint32_t &qs_out)
+__device__ __forceinline__ double walk_runs(uint32_t *s_slot, uint64_t qm, const double *s_fk, const char *bbase, int tid,
+                                            uint32_t brow, Src src, int nsrc, uint32_t &rev_out, uint32_t &qs_out, int ab = 0)
 {
     double bs = 0;
-    uint32_t cc = 0, w0 = 0, w1 = 0, qs = 0;
-    // the run being walked: m reads, fk index w.., beta offset bo..; (r, sd, t0) are the same in every lane
-    uint32_t cr = 0, cf = 0, m = 0, w = 0, bo = brow, bo_rank = brow, t0 = 0;
-    int r = 0, sd = 0;
-    bool started = false;
-    if (__any(qm != 0)) fill_slots<true>(s_slot, qm, tid, src, nsrc);
-    // moves on to the next run that holds a read in some lane; false when every lane is through (uniform)
-    auto next_run = [&]() -> bool {
-        for (;;) {
-            if (started && sd == 0) {                                     // reverse strand done: the forward reads of the same quality
-                sd = 1; m = cf; w = w0; bo = bo_rank + (cr << 11);
-            } else {
-                if (started) { cc += cr + cf; w1 += cr; w0 += cf; ++r; }
-                started = true;
-                if (!__any(qm != 0)) return false;
-                if (r == NSLOT / 2) { fill_slots<false>(s_slot, qm, tid, src, nsrc); r = 0; }
-                const int curq = 63 - __clzll((long long)(qm | 1ull));    // a lane that has run out of qualities: 0, with empty slots
-                qm &= ~(1ull << curq);
-                const uint32_t two = s_slot[r * WG + tid];
-                cr = two & 0xffff; cf = two >> 16;
-                qs += (uint32_t)curq * (cr + cf);
-                bo_rank = brow + ((uint32_t)curq << 19) + (cc << 11);
-                sd = 0; m = cr; w = w1; bo = bo_rank;
-            }
-            t0 = 0;
-            if (__any(m > 0)) return true;
-        }
+    uint32_t qs = 0;
+    uint32_t wpack = 0;      // reads walked so far: reverse strand in the low half, forward strand in the high half
+    uint32_t cnt = 0;        // reads of the current quality still to walk, the same halves
+    uint32_t koff = brow;    // brow + (reads walked so far) << 11: the k row of the next read
+    uint32_t qoff = 0;       // current quality << 19
+    uint32_t r = 0;          // ranks the lane has taken since the slots were filled
+    uint32_t d_nx = 0;       // the dword of rank r, read ahead
+    auto slot_of = [&](uint32_t rk) -> uint32_t { return s_slot[min(rk, (uint32_t)NRANK - 1u) * WG + tid]; };
+    auto step = [&](uint32_t &off, uint32_t &wi) -> bool {
+        // the current quality is used up: the next rank (an empty dword past the lane's last one: the lane stays through)
+        const bool pop = cnt == 0 && r < NRANK;
+        cnt = pop ? (d_nx & 0xffu) | (d_nx & 0xff00u) << 8 : cnt;
+        qoff = pop ? (d_nx & 0x3f0000u) << 3 : qoff;
+        r += pop ? 1u : 0u;
+        d_nx = slot_of(r);                                                // (the same dword again for a lane that did not pop)
+        // one read of the current quality: reverse strand first
+        const bool act = cnt != 0;
+        const uint32_t sh = (cnt & 0xffffu) ? 0u : 16u;
+        const uint32_t one = act ? 1u << sh : 0u;
+        wi = act ? (wpack >> sh) & 0xffffu : 256u;
+        off = act ? qoff + koff : brow;
+        wpack += one; cnt -= one;
+        koff += act ? 1u << 11 : 0u;
+        return __any(act);
     };
-    // the loads of one chunk (WCH reads of the current run from t0 on); a lane past the end of its run reads fk = +0 and a
-    // finite table entry
-    #define WALK_ISSUE(B, F) do { \
-        _Pragma("unroll") \
-        for (int j_ = 0; j_ < WCH; ++j_) { \
-            const bool a_ = t0 + j_ < m; \
-            B[j_] = *reinterpret_cast<const double*>(bbase + (a_ ? bo + ((t0 + j_) << 11) : brow)); \
-            F[j_] = s_fk[a_ ? w + t0 + j_ : 256u]; \
-        } } while (0)
-    #define WALK_ADD(B, F) do { _Pragma("unroll") for (int j_ = 0; j_ < WCH; ++j_) bs += F[j_] * B[j_]; } while (0)
-    #define WALK_STEP() (t0 += WCH, __any(t0 < m) ? true : next_run())
-    // one chunk ahead: the next chunk's gathers (L2 latency) are in flight while the current one is added, in order
-    double bx[WCH], fx[WCH], by[WCH], fy[WCH];
-    bool more = next_run();
-    if (more) WALK_ISSUE(bx, fx);
-    while (more) {
-        const bool more2 = WALK_STEP();
-        if (more2) WALK_ISSUE(by, fy);
-        WALK_ADD(bx, fx);
-        if (!more2) break;
-        more = WALK_STEP();
-        if (more) WALK_ISSUE(bx, fx);
-        WALK_ADD(by, fy);
+    // (diagnostics build: `ab` switches the table gather to one line (512), off (1024), the fk read off (2048))
+    #define WALK_LOAD(B, F, off_, wi_) do { B = (ab & 1024) ? 1.0 : *reinterpret_cast<const double*>(bbase + ((ab & 512) ? (off_) & 0x1f8u : (off_))); \
+                                            F = (ab & 2048) ? (double)(wi_) : s_fk[wi_]; } while (0)
+    bool first = true;
+    while (__any(qm != 0)) {                                              // a round: the next NRANK qualities of every lane
+        qs += count_runs(s_slot, qm, first, tid, src, nsrc);
+        first = false; r = 0;
+        d_nx = slot_of(0);
+        double bx, fx, by, fy;
+        uint32_t off, wi;
+        bool more = step(off, wi);
+        WALK_LOAD(bx, fx, off, wi);
+        while (more) {
+            more = step(off, wi);
+            WALK_LOAD(by, fy, off, wi);
+            bs += fx * bx;
+            if (!more) { bx = by; fx = fy; break; }
+            more = step(off, wi);
+            WALK_LOAD(bx, fx, off, wi);
+            bs += fy * by;
+        }
+        bs += fx * bx;                                                    // the last step issued: no lane had a read, +0
+        // the qualities of this round leave the mask
+        if (__any(__popcll(qm) > NRANK)) {
+            uint64_t m = qm;
+            for (int k = 0; k < NRANK && m; ++k) m &= ~(1ull << (63 - __clzll((long long)m)));
+            qm = m;
+        } else qm = 0;
     }
-    #undef WALK_ISSUE
-    #undef WALK_ADD
-    #undef WALK_STEP
-    rev_out = w1; qs_out = qs;
+    #undef WALK_LOAD
+    rev_out = wpack & 0xffffu; qs_out = qs;
     return bs;
 }
 
@@ -533,9 +547,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
         // (a) the primary base
         if (!BCFGPU_ABL(P, 2)) {
             const uint16_t *kpp = kp + n_other;               // primary-base keys and zeros (rejected reads)
-            const double bs = walk_ranks(s_cnt, qmask, s_fk, bbase, tid, brow,
-                                         [=](int j) { const uint32_t k = kpp[j]; return k ? (int)(k & 0x7f) : -1; },
-                                         dead_cell ? 0 : cnt_raw - (int)n_other, prim_rev, qs_prim);
+            auto psrc = [=](int j) { const uint32_t k = kpp[j]; return k ? (int)(k & 0x7f) : -1; };
+            const double bs = walk_runs(s_cnt, qmask, s_fk, bbase, tid, brow, psrc, dead_cell ? 0 : cnt_raw - (int)n_other, prim_rev, qs_prim,
+                                        BCFGPU_ABL_MASK(P));
             #pragma unroll
             for (int b = 0; b < 5; ++b) if (b == primary) bsum[b] = bs;
         }
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
                 const int no = cb > 0 ? (int)n_other : 0;
                 for (int i = 0; i < no; ++i) { const int key = src(i); if (key >= 0) qm |= 1ull << (key >> 1); }
                 uint32_t r_, q_;
-                const double bs = walk_ranks(s_cnt, qm, s_fk, bbase, tid, brow, src, no, r_, q_);
+                const double bs = walk_runs(s_cnt, qm, s_fk, bbase, tid, brow, src, no, r_, q_);
                 if (cb > 0) {
                     #pragma unroll
                     for (int bb = 0; bb < 5; ++bb) if (bb == b) bsum[bb] = bs;

@@ -9,9 +9,11 @@
 // The product build has no such switch: BCFGPU_ABL() is a compile-time 0 and the parameter blocks carry no mask.
 #ifdef BCFGPU_DIAG
 #define BCFGPU_ABL(P, bit) (((P).ablate & (bit)) != 0)
+#define BCFGPU_ABL_MASK(P) ((P).ablate)
 #define BCFGPU_ABL_FIELD int ablate;
 #else
 #define BCFGPU_ABL(P, bit) false
+#define BCFGPU_ABL_MASK(P) 0
 #define BCFGPU_ABL_FIELD
 #endif
 

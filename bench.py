@@ -480,6 +480,8 @@ def main():
     # the GT and PL planes of the variant sites, bcfgpu_compact_calls) and, for N > 1, gathered to rank 0 in rank order with
     # grouped send/recv -- the same two library calls host/bcfgpu_mgpu.c makes.
     rec_cap = 64 << 20
+    if os.environ.get("BCFGPU_ABLATE"):                        # diagnostics build (tools/ablate_kernel.sh): a kernel with parts switched off
+        rec_cap = T * (512 + S * (2 + 4 * abi.MAX_PL)) + 4096   # calls garbage, so every site may come out a variant
     recbuf = torch.empty(rec_cap, dtype=torch.uint8, device=dev)
     n_bytes, n_rec = C.c_uint64(), C.c_uint32()
     gathered = torch.empty(rec_cap * world, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
