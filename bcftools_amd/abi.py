@@ -140,6 +140,8 @@ PROTOTYPES = {
     "bcfgpu_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bcfgpu_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
     "bcfgpu_sync": (C.c_int, [C.c_void_p]),
+    "bcfgpu_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "bcfgpu_host_free": (C.c_int, [C.c_void_p]),
     "bcfgpu_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bcfgpu_pack_read": (None, [C.c_int] * 9 + [C.c_void_p, C.c_int, C.c_int,
                                                 C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)]),

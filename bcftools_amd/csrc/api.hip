@@ -308,6 +308,21 @@ size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *c, int n_sites, int which)
     return 0;
 }
 
+int bcfgpu_host_alloc(size_t bytes, void **ptr)
+{
+    if (!ptr) return set_err(BCFGPU_E_ARG, "bcfgpu_host_alloc: NULL");
+    *ptr = nullptr;
+    hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) return set_err(BCFGPU_E_NOMEM, "hipHostMalloc", e);
+    return 0;
+}
+int bcfgpu_host_free(void *ptr)
+{
+    if (!ptr) return 0;
+    hipError_t e = hipHostFree(ptr);
+    return e == hipSuccess ? 0 : set_err(BCFGPU_E_HIP, "hipHostFree", e);
+}
+
 int bcfgpu_timing_enable(bcfgpu_ctx *c, int on)
 {
     if (!c) return BCFGPU_E_ARG;

@@ -305,13 +305,21 @@ extern "C" int bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const uint
     // reference span and constants (a pass over the CIGARs, on up to 16 threads) ----
     // (grow-only scratch kept per calling thread: mapping and unmapping 200 MB per call costs more than filling it, and a
     // std::vector would zero it on one thread first)
-    static thread_local struct Scratch { void *p = nullptr; size_t bytes = 0; ~Scratch() { free(p); } } scratch;
+    // (page-locked: the uploads below are then DMA transfers the call does not wait for; pageable as a fallback)
+    static thread_local struct Scratch {
+        void *p = nullptr; size_t bytes = 0; bool pinned = false;
+        void drop() { if (p) { if (pinned) hipHostFree(p); else free(p); } p = nullptr; bytes = 0; }
+        ~Scratch() { if (p && !pinned) free(p); }                 // (a pinned block outlives the runtime's teardown order: left to the process exit)
+    } scratch;
     {
         const size_t want = (size_t)(n ? n : 1) * (sizeof(ReadMeta) + 8) + 64;
         if (scratch.bytes < want) {
-            free(scratch.p);
-            scratch.p = malloc(want + want / 8);
-            scratch.bytes = scratch.p ? want + want / 8 : 0;
+            hipStreamSynchronize(stream);                          // an earlier call's uploads may still read the old block
+            scratch.drop();
+            const size_t sz = want + want / 8;
+            if (hipHostMalloc(&scratch.p, sz, hipHostMallocDefault) == hipSuccess) scratch.pinned = true;
+            else { (void)hipGetLastError(); scratch.p = malloc(sz); scratch.pinned = false; }
+            scratch.bytes = scratch.p ? sz : 0;
             if (!scratch.p) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup: host scratch");
         }
     }

@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--var-rate", type=float, default=0.01)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget on rank 0 at N=1 (0: skip)")
     ap.add_argument("--seed", type=int, default=20260104)
+    ap.add_argument("--pageable", action="store_true", help="--mode pileup: keep the read pool in ordinary (pageable) host memory")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the CPU baseline on all host cores (0: skip)")
     ap.add_argument("--groups", type=int, default=1, help="snp mode: call -G with this many sample groups (frequencies from FORMAT/AD); "
                                                           ">1 takes the general caller path (BASELINE configs[4] shape)")
@@ -365,55 +366,96 @@ def main_pileup(a):
         b = np.where(err, (b + rng.integers(1, 4, b.shape)) & 3, b)
         seq[r0 * L:r1 * L] = (1 << b).astype(np.uint8).ravel()
     arrs["seq16"] = seq
+    mapq = np.where(rng.random(n) < 0.92, 60, rng.integers(0, 60, n)).astype(np.uint8)
+    pool_bytes = sum(v.nbytes for v in arrs.values()) + mapq.nbytes + smpl.nbytes
+    # the pool in page-locked memory (bcfgpu_host_alloc), as a host that parses its reads straight into such buffers has it:
+    # the uploads are then DMA transfers that run beside the other context's kernels
+    from bcftools_amd.lib import load
+    Lib = load()
+    pinned = []
+
+    def pin(v):
+        ptr = C.c_void_p()
+        check(Lib.bcfgpu_host_alloc(max(v.nbytes, 1), C.byref(ptr)))
+        pinned.append(ptr)
+        w = np.ctypeslib.as_array((C.c_uint8 * max(v.nbytes, 1)).from_address(ptr.value))[:v.nbytes].view(v.dtype)
+        w[...] = v
+        return w
+    if not a.pageable:
+        arrs = {k: pin(v) for k, v in arrs.items()}
+        mapq, smpl = pin(mapq), pin(smpl)
     rd.n_reads = n
     for k, v in arrs.items():
         setattr(rd, k, v.ctypes.data)
-    mapq = np.where(rng.random(n) < 0.92, 60, rng.integers(0, 60, n)).astype(np.uint8)
-    pool_bytes = sum(v.nbytes for v in arrs.values()) + mapq.nbytes + smpl.nbytes
-    # size the context from a first build
+    # size the contexts from a first build
     ctx0 = engine.Context(abi.default_cfg(S, max_sites=1, max_reads=64))
     t = abi.Tile()
+    ref_b = refseq.encode()
 
-    def build(ctx):
+    def build(ctx, tile):
         t0 = time.perf_counter()
-        check(ctx.L.bcfgpu_pileup(ctx.h, C.byref(rd), mapq.ctypes.data, smpl.ctypes.data, beg, end, refseq.encode(), len(refseq),
-                                  C.byref(t), None, None))
-        ctx.sync()
+        check(ctx.L.bcfgpu_pileup(ctx.h, C.byref(rd), mapq.ctypes.data, smpl.ctypes.data, beg, end, ref_b, len(refseq),
+                                  C.byref(tile), None, None))
         return time.perf_counter() - t0
-    build(ctx0)
+    build(ctx0, t)
     entries = int(t.n_reads)
     ctx0.close()
-    ctx = engine.Context(abi.default_cfg(S, max_sites=n_sites, max_reads=entries))
-    build(ctx)
-    tb = min(build(ctx) for _ in range(max(2, a.steps // 3)))
-    # the pipeline on the device-built tile
-    mo, mbufs, _ = ctx.alloc_mplp_out(n_sites)
-    co = abi.CallOut()
-    csite = torch.zeros(n_sites * C.sizeof(abi.CallSite), dtype=torch.uint8, device="cuda")
-    cgt = torch.zeros(n_sites * 2 * S, dtype=torch.int8, device="cuda")
-    cpl = torch.zeros(n_sites * abi.MAX_PL * S, dtype=torch.int32, device="cuda")
-    co.site, co.gt, co.pl, co.gq, co.gp = csite.data_ptr(), cgt.data_ptr(), cpl.data_ptr(), None, None
+    # two contexts (a stream and a workspace each): while one region's kernels run, the next region's pool is prepared and
+    # uploaded on the other -- the region loop of mpileup.c:652-683 with the regions in flight two deep
+    ctxs = [engine.Context(abi.default_cfg(S, max_sites=n_sites, max_reads=entries)) for _ in range(2)]
+    tiles = [abi.Tile(), abi.Tile()]
+    outs = []
+    for c in ctxs:
+        mo, mbufs, _ = c.alloc_mplp_out(n_sites)
+        co = abi.CallOut()
+        csite = torch.zeros(n_sites * C.sizeof(abi.CallSite), dtype=torch.uint8, device="cuda")
+        cgt = torch.zeros(n_sites * 2 * S, dtype=torch.int8, device="cuda")
+        cpl = torch.zeros(n_sites * abi.MAX_PL * S, dtype=torch.int32, device="cuda")
+        co.site, co.gt, co.pl, co.gq, co.gp = csite.data_ptr(), cgt.data_ptr(), cpl.data_ptr(), None, None
+        outs.append((mo, mbufs, co, (csite, cgt, cpl)))
 
-    def pipe():
-        t0 = time.perf_counter()
-        check(ctx.L.bcfgpu_pipeline(ctx.h, C.byref(t), None, None, C.byref(mo), C.byref(co)))
-        ctx.sync()
-        return time.perf_counter() - t0
-    pipe()
-    tp = min(pipe() for _ in range(3))
+    def pipe(i):
+        check(ctxs[i].L.bcfgpu_pipeline(ctxs[i].h, C.byref(tiles[i]), None, None, C.byref(outs[i][0]), C.byref(outs[i][2])))
+    # one region at a time, each step waited for (the unoverlapped numbers)
+    def serial():
+        tb = build(ctxs[0], tiles[0]); ctxs[0].sync()
+        t0 = time.perf_counter(); pipe(0); ctxs[0].sync()
+        return tb, time.perf_counter() - t0
+    serial()
+    tb, tp = min(serial() for _ in range(3))
+    # the overlapped loop: K regions (the same pool stands for every region), contexts alternating
+    K = max(4, a.steps)
+    for i in range(2):
+        build(ctxs[i], tiles[i]); pipe(i)
+    for c in ctxs:
+        c.sync()
+    t0 = time.perf_counter()
+    for k in range(K):
+        i = k & 1
+        ctxs[i].sync()                       # the region that used this context two steps ago is done (its records would be read here)
+        build(ctxs[i], tiles[i])             # prepares, uploads, counts; returns with the fill kernel enqueued
+        pipe(i)                              # enqueued behind it; runs while the next region is prepared on the other context
+    for c in ctxs:
+        c.sync()
+    t_loop = (time.perf_counter() - t0) / K
     tile_bytes = entries * 5 + (n_sites * S + 1) * 4 + n_sites
     out = {"metric": "pileup entries/sec through bcfgpu_pileup (read pool -> site x sample x read tile in HBM), %d samples x %.0fx" % (S, a.depth),
            "value": entries / tb, "unit": "entries/s", "n_gpus": 1, "higher_is_better": True, "dtype": "u32/u8 records", "data": "synthetic",
            "config": {"workload": "%d reads of %d bp over %d columns x %d samples" % (n, L, n_sites, S), "reads": n, "entries": entries,
-                      "columns": n_sites},
+                      "columns": n_sites, "pool_memory": "pageable" if a.pageable else "page-locked (bcfgpu_host_alloc)"},
            "whole_call_ms": tb * 1e3, "tile_written_gbs": tile_bytes / tb / 1e9,
-           "pcie": {"pool_bytes": int(pool_bytes), "tile_bytes": int(tile_bytes),
+           "pcie": {"pool_bytes": int(pool_bytes), "tile_bytes": int(tile_bytes), "pool_gbs_in_call": pool_bytes / tb / 1e9,
                     "note": "the pool is what crosses PCIe; a host-packed tile of this region would be tile_bytes"},
-           "host_fed_pipeline": {"pipeline_ms": tp * 1e3, "sites_per_s": n_sites / (tb + tp),
-                                 "note": "bcfgpu_pileup (host pointers in) followed by bcfgpu_pipeline on the tile it left in HBM"}}
+           "host_fed_pipeline": {"pipeline_ms": tp * 1e3, "serial_sites_per_s": n_sites / (tb + tp),
+                                 "overlapped_ms_per_region": t_loop * 1e3, "sites_per_s": n_sites / t_loop, "regions": K,
+                                 "note": "bcfgpu_pileup (host pointers in) then bcfgpu_pipeline on the tile it left in HBM; overlapped = two "
+                                         "contexts alternating, a region's kernels running while the next region is prepared and uploaded"}}
     print(json.dumps(out), flush=True)
-    ctx.release(list(mbufs.values()))
-    ctx.close()
+    for c, o in zip(ctxs, outs):
+        c.release(list(o[1].values()))
+        c.close()
+    for ptr in pinned:
+        Lib.bcfgpu_host_free(ptr)
 
 
 def main():

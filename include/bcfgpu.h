@@ -253,6 +253,11 @@ int  bcfgpu_memcpy_h2d(bcfgpu_ctx *ctx, void *dst, const void *src, size_t bytes
 int  bcfgpu_memcpy_d2h(bcfgpu_ctx *ctx, void *dst, const void *src, size_t bytes);
 int  bcfgpu_memset(bcfgpu_ctx *ctx, void *dst, int value, size_t bytes);
 int  bcfgpu_sync(bcfgpu_ctx *ctx);
+/* Page-locked host memory for the buffers a caller hands to the entries that take HOST pointers (bcfgpu_pileup's read pool,
+ * bcfgpu_baq, ...): from such memory an upload is a DMA transfer that runs beside the kernels of other contexts, from
+ * ordinary memory the runtime stages it through the CPU.  Optional: every entry accepts ordinary memory. */
+int  bcfgpu_host_alloc(size_t bytes, void **ptr);
+int  bcfgpu_host_free(void *ptr);
 /* Cells of the launches since the last call that held more than BCFGPU_MAX_DEPTH usable reads.  errmod_cal (htslib errmod.c)
  * would shuffle such a cell's reads with hts_drand48 and keep 255 -- a draw from a process-wide generator that depends on the
  * order in which the whole run visits its cells.  Here the cell keeps its first 255 usable reads and the later ones are removed
