@@ -4,6 +4,7 @@
  *      bcfgpu_sam [options] <ref.fa> <contig> <beg> <end> <file.sam|file.bam> [...]             (beg, end 1-based inclusive)
  *      options: -a TAG,..  --gvcf INT,..  -O v|z|u|b  -o FILE  -d INT  -s LIST  -S FILE  -G FILE  --ignore-RG
  *               -B  -E  -A  -q INT  -Q INT  --ff INT  --rf INT                                  (as `bcftools mpileup`)
+ *               --list-samples: print "sample <TAB> reads entering the pileup <TAB> files" and stop (no device needed)
  *
  *  What stays on the host is what mpileup.c and htslib's pileup do before any arithmetic: parsing (SAM text; BAM = BGZF +
  *  binary records), the read -> sample map of bam_sample.c (@RG SM, RG:Z tags, -s/-S/-G), the read filters of mplp_func
@@ -607,7 +608,7 @@ int main(int argc, char **argv)
 {
     int32_t gv_range[16]; int gv_n = 0;                                       /* mpileup --gvcf INT,.. (gvcf.c:44-67) */
     char out_mode = 'v'; const char *out_path = "-"; int max_depth = 250;      /* mpileup -O, -o, -d (mpileup.c:937-950) */
-    int baq_flag = 3, min_baseQ = 13;
+    int baq_flag = 3, min_baseQ = 13, list_only = 0;
     while (argc > 2 && argv[1][0] == '-') {
         if (!strcmp(argv[1], "-a")) {                                         /* mpileup -a, mpileup.c:parse_format_flag */
             static const struct { const char *name; int bit; } tags[] = {
@@ -639,6 +640,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "-S")) { add_samples(argv[2], 1); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-G")) { add_readgroups(argv[2]); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "--ignore-RG")) { SM.ignore_rg = 1; ++argv; --argc; }
+        else if (!strcmp(argv[1], "--list-samples")) { list_only = 1; ++argv; --argc; }                 /* host logic only: no device needed */
         else if (!strcmp(argv[1], "-B")) { baq_flag = 0; ++argv; --argc; }                             /* mpileup.c:1045,1062 */
         else if (!strcmp(argv[1], "-E")) { baq_flag = 7; ++argv; --argc; }
         else if (!strcmp(argv[1], "-A")) { keep_orphans = 1; ++argv; --argc; }
@@ -707,10 +709,12 @@ int main(int argc, char **argv)
         #undef HL
         for (int s = 0; s < S; ++s) vio_hdr_add_sample(hdr, sample[s]);
     }
-    fout = vio_open_write(out_path, out_mode);
-    if (!fout || vio_write_hdr(fout, hdr)) DIE("%s\n", vio_error());
-    LN = open_memstream(&ln_buf, &ln_len);
-    if (!LN) DIE("open_memstream failed\n");
+    if (!list_only) {
+        fout = vio_open_write(out_path, out_mode);
+        if (!fout || vio_write_hdr(fout, hdr)) DIE("%s\n", vio_error());
+        LN = open_memstream(&ln_buf, &ln_len);
+        if (!LN) DIE("open_memstream failed\n");
+    }
     /* ---- the per-file depth cap of the pileup iterator (mpileup -d, mpileup.c:646): reads it drops leave the pool ---- */
     if (max_depth > 0 && P.n) {
         bcfgpu_reads r0; memset(&r0, 0, sizeof r0);
@@ -735,6 +739,16 @@ int main(int argc, char **argv)
         free(keep);
     }
 
+    if (list_only) {
+        /* --list-samples: what the host side decided, one line per output sample -- name, reads that enter the pileup, files they
+         * come from -- and nothing else (the read-group plumbing, the filters and the depth cap run without a device) */
+        for (int s = 0; s < S; ++s) {
+            int nr = 0, nf = 0, lastf = -1;
+            for (int r = 0; r < P.n; ++r) if (P.smpl[r] == s) { ++nr; if (P.file[r] != lastf) { ++nf; lastf = P.file[r]; } }
+            printf("%s\t%d\t%d\n", sample[s], nr, nf);
+        }
+        return 0;
+    }
     bcfgpu_cfg cfg; memset(&cfg, 0, sizeof cfg);
     cfg.device = 0; cfg.n_smpl = S; cfg.max_sites = n_sites; cfg.max_reads = (uint64_t)P.nbase + 64;   /* every base is in <= 1 column */
     cfg.min_baseQ = min_baseQ; cfg.capQ = 60; cfg.errmod_theta = 0.; cfg.fmt_flag = fmt_flag;

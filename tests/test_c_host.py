@@ -101,6 +101,65 @@ def test_c_host_builds_and_refuses_to_run_without_a_gpu():
     assert "bcfgpu_create" in p.stderr               # BCFGPU_E_NODEV, reported by the CHECK macro: no CPU fallback
 
 
+def _sam_reads(path):
+    """(read group, flag) of the mapped reads of a SAM file, and its @RG ID -> SM map"""
+    rg2sm, reads = {}, []
+    for ln in open(path):
+        f = ln.rstrip("\n").split("\t")
+        if ln.startswith("@RG"):
+            d = dict(x.split(":", 1) for x in f[1:])
+            rg2sm.setdefault(d["ID"], d["SM"])
+        elif not ln.startswith("@"):
+            rg = [x[5:] for x in f[11:] if x.startswith("RG:Z:")]
+            reads.append((rg[0] if rg else None, int(f[1])))
+    return rg2sm, reads
+
+
+@pytest.mark.parametrize("opts,files,goldf,rename", [
+    ("", (1, 2, 3), "mpileup.1.out", {}),
+    ("-s HG00101,HG00102", (1, 2, 3), "mpileup.7.out", {}),
+    ("-S ^{G}/mplp.samples", (1, 2, 3), "mpileup.8.out", {}),
+    ("-S {G}/mplp.9.samples", (1, 2, 3), "mpileup.9.out", {"HG00101": "SAMPLE1", "HG00102": "SAMPLE2"}),
+    ("-G {G}/mplp.10.samples", (1, 2, 3), "mpileup.10.out", None),
+    ("-s ^HG99999", (3, 4), "mpileup.11.out", {}),
+    ("-G {G}/mplp.11.rgs", (3, 4), "mpileup.11.out", {})])
+def test_c_sam_driver_sample_plumbing_on_the_host(golden_dir, opts, files, goldf, rename):
+    """The host side of host/bcfgpu_sam.c needs no device: `--list-samples` prints the output samples bam_sample.c's rules give
+    (names and order = the golden's #CHROM line) and how many reads of each pass mplp_func's filters into the pileup."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    sams = [os.path.join(G, "mpileup.%d.sam" % i) for i in files]
+    out = subprocess.run([SAM_EXE, "--list-samples"] + opts.format(G=G).split() + [os.path.join(G, "mpileup.ref.fa"), "17", "1", "4200"] + sams,
+                         check=True, stdout=subprocess.PIPE, text=True).stdout
+    got = [ln.split("\t") for ln in out.splitlines()]
+    chrom = [ln for ln in open(os.path.join(G, goldf)) if ln.startswith("#CHROM")][0].rstrip("\n").split("\t")[9:]
+    assert [g[0] for g in got] == chrom
+    # read counts: mapped, not secondary / QC-fail / duplicate, no orphans; grouped as the option says
+    want = {}
+    rgs = None
+    if rename is None:                                                     # -G: read group -> sample (a row without a name keeps the header's)
+        rgs = {}
+        for ln in open(os.path.join(G, "mplp.10.samples")):
+            w = ln.split()
+            rgs[w[0]] = w[1] if len(w) > 1 else None
+    for path in sams:
+        rg2sm, reads = _sam_reads(path)
+        for rg, flag in reads:
+            if flag & (4 | 256 | 512 | 1024) or (flag & 1 and not flag & 2):
+                continue
+            sm = rg2sm.get(rg)
+            if rgs is not None:
+                if rg not in rgs:
+                    continue
+                sm = rgs[rg] or sm
+            else:
+                sm = rename.get(sm, sm)
+            if sm in chrom:
+                want[sm] = want.get(sm, 0) + 1
+    assert {g[0]: int(g[1]) for g in got} == want
+    assert all(int(g[2]) == 1 for g in got)
+
+
 def test_generator_twin_packs_like_the_library():
     """The Python twin of the packer agrees with bcfgpu_pack_read on the driver's reads (host code, no GPU needed)."""
     import ctypes as C
