@@ -445,7 +445,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
             }
         }
         GLF_STAMP(1)
-        __syncthreads();
+        if (!BCFGPU_ABL(P, 16384)) __syncthreads();          // (diagnostics: 16384 times the kernel without the barriers between the phases; results are then wrong)
         GLF_STAMP(2)
         if (LDS_HIST) {
             // the columns of every partial sum: four lanes per value
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
                 x += __shfl_xor(x, 1); x += __shfl_xor(x, 2);
                 if ((i & 3) == 0 && x) { const int vi = i >> 2; s_tot[(vi / NPART) * SITE_NSUM + vi % NPART] += x; }
             }
-            __syncthreads();
+            if (!BCFGPU_ABL(P, 16384)) __syncthreads();
         }
 
         // ================= phase B: one lane per cell =================
