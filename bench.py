@@ -601,12 +601,13 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": tm["glfgen_ms"],
                          "other_kernels_ms": {"combine_kernel": tm["combine_ms"], "mcall_kernel": tm["mcall_ms"]},
-                         # the two smaller kernels against the same roofline: bytes they must move per cell
+                         # the two smaller kernels against the same roofline: bytes they must move per cell (DESIGN.md 3.2, 3.3;
+                         # combine: 28 B of per-cell workspace + QS read twice in, PL + DP4 out)
                          "other_kernels_frac": {
-                             "combine_kernel": (T * S * (84 + 8 + 15 + 4)) / (tm["combine_ms"] * 1e-3) / 8e12 if tm["combine_ms"] > 0 else None,
+                             "combine_kernel": (T * S * (28 + 8 + 15 + 4)) / (tm["combine_ms"] * 1e-3) / 8e12 if tm["combine_ms"] > 0 else None,
                              "mcall_kernel": (T * S * (15 + 2 + 12)) / (tm["mcall_ms"] * 1e-3) / 8e12 if tm["mcall_ms"] > 0 else None},
                          "other_kernels_gbs": {
-                             "combine_kernel": (T * S * (84 + 8 + 15 + 4)) / (tm["combine_ms"] * 1e-3) / 1e9 if tm["combine_ms"] > 0 else None,
+                             "combine_kernel": (T * S * (28 + 8 + 15 + 4)) / (tm["combine_ms"] * 1e-3) / 1e9 if tm["combine_ms"] > 0 else None,
                              "mcall_kernel": (T * S * (15 + 2 + 12)) / (tm["mcall_ms"] * 1e-3) / 1e9 if tm["mcall_ms"] > 0 else None}},
         }
         # ---- CPU baseline: the oracle (a port of the reference's loops), 1 core, bounded sample ----
