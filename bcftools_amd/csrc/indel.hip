@@ -7,6 +7,7 @@
 // order (htslib probaln.c), so the integer scores match the CPU path.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 #include "kernels.h"
 
 namespace bcfgpu {
@@ -157,10 +158,13 @@ __device__ int probaln_fwd_reg(const uint8_t *ref, int l_ref, const QSrc qs, int
         if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
     }
     int x = 0;                                            // first column of the band minus one: max(0, i - bw)
-    for (int i = 2; i <= l_query; ++i) {
+    // one row; `slide`: x grows by one on this row (i > bw).  Two instantiations: the rows before and after the band leaves
+    // the left edge differ in which old cells are the diagonal and the upper neighbour, and a run-time choice costs ten
+    // selects per position
+    auto row = [&](auto slide_c, int i) {
+        constexpr bool slide = decltype(slide_c)::value;
         const double qli = (double)q2p[qs.q(i - 1)];
         const int qyi = qs.base(i - 1);
-        const bool slide = i > bw;                        // x grows by one on this row
         if (slide) {
             ++x;
             rw >>= 3;
@@ -197,6 +201,11 @@ __device__ int probaln_fwd_reg(const uint8_t *ref, int l_ref, const QSrc qs, int
         for (int p = 1; p < NP; ++p) { M[p] *= r; I[p] *= r; D[p] *= r; }
         prod *= sum;
         if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
+    };
+    {
+        int i = 2;
+        for (; i <= l_query && i <= bw; ++i) row(std::false_type{}, i);
+        for (; i <= l_query; ++i) row(std::true_type{}, i);
     }
     {   // f[l_query+1]: columns k = 1..l_ref whose slot lies inside the band of the last row
         double sum = 0.;
