@@ -332,7 +332,10 @@ __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTota
 }
 
 template <int V>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(4, 4))) void combine_kernel(const CombineParams P)
+#ifndef COMB_WAVES
+#define COMB_WAVES 4         // wavefronts per SIMD the register budget is held to
+#endif
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, COMB_WAVES))) void combine_kernel(const CombineParams P)
 {
     __shared__ SiteShared sh;
     __shared__ unsigned long long s_stage[CHUNK];   // QS (4 x u16) per sample, later float mins

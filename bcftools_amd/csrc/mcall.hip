@@ -171,8 +171,11 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // matrix product (subset coefficients [rows] x genotypes [k]) * (genotypes [k] x samples [cols]) and runs on the
 // f64 matrix cores (v_mfma_f64_16x16x4_f64), 16 samples per issue; an extra all-ones row yields each sample's
 // normalisation sum, whose product is divided out at the end.
+#ifndef MCALL_WAVES
+#define MCALL_WAVES 4        // wavefronts per SIMD of the all-diploid FAST instantiations
+#endif
 template <int MAXA, int NSUB, bool FAST, bool HAP, bool GRP>
-__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 : !HAP ? 4 : NSUB > 15 ? 3 : 3, !FAST ? 8 : !HAP ? 4 : NSUB > 15 ? 3 : 3))) void mcall_kernel(const McallParams P)
+__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 : !HAP ? MCALL_WAVES : 3, !FAST ? 8 : !HAP ? MCALL_WAVES : 3))) void mcall_kernel(const McallParams P)
 {
     constexpr int NG = MAXA * (MAXA + 1) / 2;
     constexpr int TILES = NSUB >= 16 ? 2 : 1;     // 16-row tiles of the coefficient matrix (subsets + the sum row)
