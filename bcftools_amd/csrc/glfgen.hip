@@ -90,6 +90,9 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 //   src(j)  key7 of source element j, or -1 when the element is not of this base / was rejected
 // Returns sum of the qualities of the reads counted (QS).
 #define NRANK 16
+#ifndef WR
+#define WR 2            // reads of a run taken per step of the errmod walk
+#endif
 template <class Src>
 __device__ __forceinline__ uint32_t count_runs(uint32_t *s_slot, uint64_t qm, bool first, int tid, Src src, int nsrc)
 {
@@ -144,45 +147,55 @@ __device__ __forceinline__ double walk_runs(uint32_t *s_slot, uint64_t qm, const
     uint32_t r = 0;          // ranks the lane has taken since the slots were filled
     uint32_t d_nx = 0;       // the dword of rank r, read ahead
     auto slot_of = [&](uint32_t rk) -> uint32_t { return s_slot[min(rk, (uint32_t)NRANK - 1u) * WG + tid]; };
-    auto step = [&](uint32_t &off, uint32_t &wi) -> bool {
+    // One step = up to WR reads of the lane's current (quality, strand) run (binned base qualities make runs of several reads
+    // the rule): the run bookkeeping is paid once for all of them.
+    auto step = [&](uint32_t (&off)[WR], uint32_t (&wi)[WR]) -> bool {
         // the current quality is used up: the next rank (an empty dword past the lane's last one: the lane stays through)
         const bool pop = cnt == 0 && r < NRANK;
         cnt = pop ? (d_nx & 0xffu) | (d_nx & 0xff00u) << 8 : cnt;
         qoff = pop ? (d_nx & 0x3f0000u) << 3 : qoff;
         r += pop ? 1u : 0u;
         d_nx = slot_of(r);                                                // (the same dword again for a lane that did not pop)
-        // one read of the current quality: reverse strand first
-        const bool act = cnt != 0;
+        // reverse strand first
         const uint32_t sh = (cnt & 0xffffu) ? 0u : 16u;
-        const uint32_t one = act ? 1u << sh : 0u;
-        wi = act ? (wpack >> sh) & 0xffffu : 256u;
-        off = act ? qoff + koff : brow;
-        wpack += one; cnt -= one;
-        koff += act ? 1u << 11 : 0u;
-        return __any(act);
+        const uint32_t left = (cnt >> sh) & 0xffffu;                      // reads left in the run (0: the lane is through)
+        const uint32_t w = (wpack >> sh) & 0xffffu;
+        const uint32_t o1 = qoff + koff;
+        #pragma unroll
+        for (uint32_t u = 0; u < WR; ++u) {
+            const bool act = left > u;
+            wi[u] = act ? w + u : 256u;
+            off[u] = act ? o1 + (u << 11) : brow;
+        }
+        const uint32_t took = min(left, (uint32_t)WR);
+        wpack += took << sh; cnt -= took << sh;
+        koff += took << 11;
+        return __any(left != 0);
     };
     // (diagnostics build: `ab` switches the table gather to one line (512), off (1024), the fk read off (2048))
-    #define WALK_LOAD(B, F, off_, wi_) do { B = (ab & 1024) ? 1.0 : *reinterpret_cast<const double*>(bbase + ((ab & 512) ? (off_) & 0x1f8u : (off_))); \
-                                            F = (ab & 2048) ? (double)(wi_) : s_fk[wi_]; } while (0)
+    #define WALK_LOAD(B, F, off_, wi_) do { _Pragma("unroll") for (int u_ = 0; u_ < WR; ++u_) { \
+        B[u_] = (ab & 1024) ? 1.0 : *reinterpret_cast<const double*>(bbase + ((ab & 512) ? (off_)[u_] & 0x1f8u : (off_)[u_])); \
+        F[u_] = (ab & 2048) ? (double)(wi_)[u_] : s_fk[(wi_)[u_]]; } } while (0)
+    #define WALK_ADD(B, F) do { _Pragma("unroll") for (int u_ = 0; u_ < WR; ++u_) bs += F[u_] * B[u_]; } while (0)
     bool first = true;
     while (__any(qm != 0)) {                                              // a round: the next NRANK qualities of every lane
         qs += count_runs(s_slot, qm, first, tid, src, nsrc);
         first = false; r = 0;
         d_nx = slot_of(0);
-        double bx, fx, by, fy;
-        uint32_t off, wi;
+        double bx[WR], fx[WR], by[WR], fy[WR];
+        uint32_t off[WR], wi[WR];
         bool more = step(off, wi);
         WALK_LOAD(bx, fx, off, wi);
         while (more) {
             more = step(off, wi);
             WALK_LOAD(by, fy, off, wi);
-            bs += fx * bx;
-            if (!more) { bx = by; fx = fy; break; }
+            WALK_ADD(bx, fx);
+            if (!more) { _Pragma("unroll") for (int u = 0; u < WR; ++u) { bx[u] = by[u]; fx[u] = fy[u]; } break; }
             more = step(off, wi);
             WALK_LOAD(bx, fx, off, wi);
-            bs += fy * by;
+            WALK_ADD(by, fy);
         }
-        bs += fx * bx;                                                    // the last step issued: no lane had a read, +0
+        WALK_ADD(bx, fx);                                                 // the last step issued: no lane had a read, +0
         // the qualities of this round leave the mask
         if (__any(__popcll(qm) > NRANK)) {
             uint64_t m = qm;
@@ -190,6 +203,7 @@ __device__ __forceinline__ double walk_runs(uint32_t *s_slot, uint64_t qm, const
             qm = m;
         } else qm = 0;
     }
+    #undef WALK_ADD
     #undef WALK_LOAD
     rev_out = wpack & 0xffffu; qs_out = qs;
     return bs;
