@@ -93,8 +93,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 #ifndef WR
 #define WR 2            // reads of a run taken per step of the errmod walk
 #endif
-template <class Src>
-__device__ __forceinline__ uint32_t count_runs(uint32_t *s_slot, uint64_t qm, bool first, int tid, Src src, int nsrc)
+template <bool FIRST, class Src>
+__device__ __forceinline__ uint32_t count_runs(uint32_t *s_slot, uint64_t qm, int tid, Src src, int nsrc)
 {
     #pragma unroll
     for (int k = 0; k < NRANK; ++k) s_slot[k * WG + tid] = 0;
@@ -107,7 +107,7 @@ __device__ __forceinline__ uint32_t count_runs(uint32_t *s_slot, uint64_t qm, bo
         #pragma unroll
         for (int u = 0; u < FU; ++u) {
             const int key = k4[u], q = (key >> 1) & 63;
-            if (key >= 0 && (first || ((qm >> q) & 1ull))) {       // first round: the mask holds every quality of the source
+            if (key >= 0 && (FIRST || ((qm >> q) & 1ull))) {       // first round: the mask holds every quality of the source
                 const int r = __popcll(qm1 >> q);
                 if (r < NRANK) atomicAdd(&s_slot[r * WG + tid], (key & 1) ? 1u : 0x100u);
             }
@@ -179,7 +179,7 @@ __device__ __forceinline__ double walk_runs(uint32_t *s_slot, uint64_t qm, const
     #define WALK_ADD(B, F) do { _Pragma("unroll") for (int u_ = 0; u_ < WR; ++u_) bs += F[u_] * B[u_]; } while (0)
     bool first = true;
     while (__any(qm != 0)) {                                              // a round: the next NRANK qualities of every lane
-        qs += count_runs(s_slot, qm, first, tid, src, nsrc);
+        qs += first ? count_runs<true>(s_slot, qm, tid, src, nsrc) : count_runs<false>(s_slot, qm, tid, src, nsrc);
         first = false; r = 0;
         d_nx = slot_of(0);
         double bx[WR], fx[WR], by[WR], fy[WR];
