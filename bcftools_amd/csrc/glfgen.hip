@@ -11,7 +11,8 @@
 //     arithmetic (:196-203), and everything that only feeds SITE totals -- the I16 sums anno[4..15] (:221-226),
 //     ori_depth, mq0 and the bias-test histograms (:228-252) -- which therefore never needs to know the read's cell:
 //     per-lane partial sums, one reduction per workgroup and site.  What the cell needs of the read is 11 bits, left in
-//     LDS as a u16 key at the read's position in the span:  strand | q<<1 | base<<7 | softclip<<10  (0 = read rejected).
+//     LDS as a u16 key at the read's position in the span:  strand | q<<1 | base<<7 | softclip<<10 | primary base<<11
+//     (0 = read rejected).
 //   phase B, one lane per CELL: the lane walks its own slice of keys: per-base counts, QS, ADF/ADR, DP4 counts and
 //     errmod_cal, whose order-sensitive double sums are replayed in the reference's order (bit-identical results).
 //
@@ -79,6 +80,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 #define KEY_Q(k)    (((k) >> 1) & 63u)
 #define KEY_B(k)    (((k) >> 7) & 7u)
 #define KEY_SC(k)   (((k) >> 10) & 1u)
+#define KEY_PRIM    0x800u     // the read shows the cell's primary base (the reference base; type 0 at indel sites)
 
 // errmod_cal() sorts the cell's codes q<<5|strand<<4|base and walks them from the largest down; only the order among the
 // reads of one base matters (per-base accumulators), and there the order is that of key7 = q<<1|reverse: quality by quality
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
             if (rb >= re) continue;
             const int ref_base = INDEL ? -1 : (int)P.ref16[sg];
             const uint32_t ref4 = INDEL ? 4u : (uint32_t)nt16_int(ref_base);
+            const uint32_t primq = INDEL ? 0u : ref4;            // `primary` of the segment's cells
             // nt16 code -> base 0..4 with code 0 ('=') standing for the reference base (bam2bcf.c:189-190)
             const unsigned long long tbl = (NT16_INT_TBL & ~0xfull) | (unsigned long long)ref4;
             int *hist = LDS_HIST ? s_hist + (sg - site0) * H_SIZE : P.hist + (long)sg * H_SIZE;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
                     q = max(min(min(q, mapQ), 63u), 4u);
                     md = min(md, (uint32_t)CAP_DIST);
                     const uint32_t rev = (w >> 20) & 1;
-                    uint32_t key = KEY_PACK(rev, q, b, 0);
+                    uint32_t key = KEY_PACK(rev, q, b, 0) | (b == primq ? KEY_PRIM : 0u);
                     if (want_scr) key |= ((w >> 21) & 1) << 10;
                     kv[u] = ok ? key : 0u;
                     bqz[u] = bq; mqz[u] = mapQ; mdz[u] = md;
@@ -529,16 +532,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
         uint32_t n_b4 = 0;           // reads showing neither A, C, G nor T
         uint32_t o_rev = 0, n_other = 0;
         {
-            const uint32_t pk = (uint32_t)primary << 7;
             uint32_t k_nx = kp[0];
             for (int i = 0; i < (BCFGPU_ABL(P, 4) ? 0 : cnt_raw); ++i) {
                 const uint32_t k = k_nx;
                 k_nx = kp[i + 1];                               // one past the slice stays inside the key array's slack
-                const bool prim = k != 0 && (k & 0x380u) == pk;
-                qmask |= prim ? 1ull << KEY_Q(k) : 0ull;
-                n_prim += prim ? 1u : 0u;
+                const uint32_t pb = (k >> 11) & 1u;             // KEY_PRIM
+                qmask |= (uint64_t)pb << KEY_Q(k);
+                n_prim += pb;
                 if (want_scr) scr += KEY_SC(k);
-                if (k != 0 && !prim) {                          // rare
+                if (k != 0 && !pb) {                            // rare
                     // swapped to position n_other <= i (behind the reader): the walks only count reads per (base, quality,
                     // strand), so the order inside a cell is free
                     const uint32_t t = kp_w[n_other], rev = KEY_REV(k), q = KEY_Q(k), b = KEY_B(k);
