@@ -10,7 +10,7 @@
 //     4-byte load of `epos`), each input byte exactly once.  Per read: the filters (bam2bcf.c:173-194), the quality
 //     arithmetic (:196-203), and everything that only feeds SITE totals -- the I16 sums anno[4..15] (:221-226),
 //     ori_depth, mq0 and the bias-test histograms (:228-252) -- which therefore never needs to know the read's cell:
-//     per-lane partial sums, one reduction per workgroup and site.  What the cell needs of the read is 11 bits, left in
+//     per-lane partial sums, one reduction per workgroup and site.  What the cell needs of the read is 12 bits, left in
 //     LDS as a u16 key at the read's position in the span:  strand | q<<1 | base<<7 | softclip<<10 | primary base<<11
 //     (0 = read rejected).
 //   phase B, one lane per CELL: the lane walks its own slice of keys: per-base counts, QS, ADF/ADR, DP4 counts and
@@ -54,13 +54,6 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
-{
-    #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
     return v;
 }
 
