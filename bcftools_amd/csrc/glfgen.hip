@@ -673,7 +673,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
 
 size_t glfgen_lds_bytes(int cap, int hist_slots)
 {
-    return LDS_HIST_OFF + (size_t)hist_slots * (H_SIZE * sizeof(int) + SITE_NSUM * 8) + ((size_t)cap + 8) * 2;
+#ifndef GLF_LDS_PAD
+#define GLF_LDS_PAD 0        // (occupancy experiments: bytes of LDS a workgroup asks for and does not use)
+#endif
+    return LDS_HIST_OFF + (size_t)hist_slots * (H_SIZE * sizeof(int) + SITE_NSUM * 8) + ((size_t)cap + 8) * 2 + GLF_LDS_PAD;
 }
 
 template <bool INDEL, bool LDS_HIST>
