@@ -36,6 +36,7 @@ struct bcfgpu_ctx {
     double call_theta_log = 0;
     // workspaces sized by cfg.max_sites / cfg.max_reads
     int *d_hist = nullptr, *d_err = nullptr;
+    CallretPlanes *d_crp = nullptr;
     unsigned long long *d_site_sums = nullptr;
     CallretPlanes cr{};
     size_t ncells_cap = 0;
@@ -142,13 +143,17 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
     c->ncells_cap = ncells;
     if (ncells) {
         if ((rc = dev_alloc(c, (void**)&c->d_hist, (size_t)cfg->max_sites * H_SIZE * sizeof(int))) ||
-            (rc = dev_alloc(c, (void**)&c->cr.p15, ncells * 15 * sizeof(float))) ||
+            (rc = dev_alloc(c, (void**)&c->cr.p15, ncells * 16 * sizeof(float))) ||
             (rc = dev_alloc(c, (void**)&c->cr.qs64, ncells * 8)) ||
             (rc = dev_alloc(c, (void**)&c->cr.adf, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->cr.adr, ncells * 4)) ||
             (rc = dev_alloc(c, (void**)&c->cr.cnt4, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->d_site_sums, (size_t)cfg->max_sites * SITE_NSUM * 8)) ||
             (rc = dev_alloc(c, (void**)&c->cr.misc, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->cr.pa, ncells * 4))) {
             bcfgpu_destroy(c); return rc;
         }
+        // the table of plane addresses as glfgen_kernel reads it at the point of its stores (kernels.h: GlfgenParams::crp)
+        if ((rc = dev_alloc(c, (void**)&c->d_crp, sizeof(CallretPlanes)))) { bcfgpu_destroy(c); return rc; }
+        e = hipMemcpy(c->d_crp, &c->cr, sizeof(CallretPlanes), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { bcfgpu_destroy(c); return set_err(BCFGPU_E_HIP, "plane table upload", e); }
     }
     e = hipDeviceSynchronize();
     if (e != hipSuccess) { bcfgpu_destroy(c); return set_err(BCFGPU_E_HIP, "table upload", e); }
@@ -401,7 +406,7 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     // wavefronts per SIMD) share a CU while still holding `want` keys; a span that does not fit is worked off in rounds.
     {
         const double mean = (double)tile->n_reads / ((double)tile->n_sites * S);
-        long want = (long)(mean * 256 * 1.04) + 512;
+        long want = (long)(mean * 256 * 1.03) + 64;
         want = std::max(2048L, (want + 15) & ~15L);
         int cap = 0;
         for (int wgs = 6; wgs >= 3 && !cap; --wgs) {
@@ -421,7 +426,7 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
 #endif
     g.ref16 = tile->ref16; g.off = tile->plp_off; g.rd = tile->rd; g.epos = tile->epos; g.aux = tile->aux;
     g.fk = c->d_fk; g.beta = c->d_beta; g.lhet = c->d_lhet;
-    g.cr = c->cr;
+    g.crp = c->d_crp;
     // the callret planes are addressed with ncells of *this* tile
     g.hist = c->d_hist; g.err = c->d_err; g.site_sums = c->d_site_sums;
     g.trunc = reinterpret_cast<unsigned int*>(c->d_err + 1);

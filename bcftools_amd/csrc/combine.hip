@@ -263,7 +263,7 @@ __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTota
                 for (int j = 0; j < X; ++j) {
                     #pragma unroll
                     for (int v = 0; v < V; ++v)
-                        if (misc[v] & CR_FULL) pv[j][v] = P.cr.p15[(size_t)gs[j] * ncells + c0 + s + v];
+                        if (misc[v] & CR_FULL) pv[j][v] = P.cr.p15[(size_t)(c0 + s + v) * 16 + gs[j]];
                 }
             }
             #pragma unroll

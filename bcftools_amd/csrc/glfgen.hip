@@ -40,7 +40,7 @@ namespace bcfgpu {
 
 #define WG 256
 #ifndef GLF_WAVES
-#define GLF_WAVES 4          // wavefronts per SIMD the register budget is held to
+#define GLF_WAVES 5          // wavefronts per SIMD the register budget is held to
 #endif
 #define DEF_MAPQ 20
 #define CAP_DIST 25
@@ -57,14 +57,23 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return v;
 }
 
-// LDS layout (bytes): fk[264] f64 | slots[NSLOT][WG] u32 (a dword per quality rank) | hist [slots][H_SIZE] i32 | site totals [slots][SITE_NSUM] u64 | keys u16[cap+8]
+// LDS layout (bytes): fk[264] f64 | slots[NSLOT][WG] u32 (a dword per quality rank) | hist [slots][HP_SIZE] 2 x u16 | site totals [slots][SITE_NSUM] u64 | keys u16[cap+8]
 #define LDS_FK   0
 #define LDS_CNT  2112
-#define NSLOT    16
+#ifndef NRANK
+#define NRANK 11         // quality ranks a lane counts per round (count_runs): a dword each in LDS
+#endif
+#define NSLOT    NRANK
 #ifndef FU
 #define FU       4         // source elements per trip of the slot counting
 #endif
 #define LDS_HIST_OFF (LDS_CNT + NSLOT * WG * 4)
+// The workgroup's copy of a site's bias-test histograms, two 16-bit counters per dword (a workgroup has fewer than 2^16
+// reads): dword i < 220 = bin i of the REF arrays (kernels.h: POS, MQ, BQ) in the low half and of the ALT arrays in the high
+// half; dword 220 + mq = the forward- and the reverse-strand mapQ histogram.  Half the LDS of plain counters, and the
+// REF / ALT choice is the increment instead of an address.
+#define HP_SIZE 280
+#define HP_MQS  220
 #define NPART 12           // per-lane partial sums of phase A: the I16 site totals anno[4..15]
 
 // the u16 key phase A leaves for phase B
@@ -84,7 +93,6 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 //   qm      bit q = some read of the source has quality q
 //   src(j)  key7 of source element j, or -1 when the element is not of this base / was rejected
 // Returns sum of the qualities of the reads counted (QS).
-#define NRANK 16
 #ifndef WR
 #define WR 2            // reads of a run taken per step of the errmod walk
 #endif
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
     double   *s_fk  = reinterpret_cast<double*>(smem + LDS_FK);
     uint32_t *s_cnt = reinterpret_cast<uint32_t*>(smem + LDS_CNT);
     int      *s_hist = reinterpret_cast<int*>(smem + LDS_HIST_OFF);
-    unsigned long long *s_tot = reinterpret_cast<unsigned long long*>(s_hist + (size_t)P.hist_slots * H_SIZE);   // [slots][SITE_NSUM]
+    unsigned long long *s_tot = reinterpret_cast<unsigned long long*>(s_hist + (size_t)P.hist_slots * HP_SIZE);   // [slots][SITE_NSUM]
     // phase A's per-lane partial sums [slots][NPART][pcol] share the slot counters' LDS: they are added up and cleared
     // before phase B takes the region
     uint32_t *s_part = s_cnt;
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
     s_fk[tid] = P.fk[tid];
     if (tid < 8) s_fk[256 + tid] = 0.0;               // [256]: the factor of a lane that sits a chunk element out
     if (LDS_HIST) {
-        for (int i = tid; i < P.hist_slots * H_SIZE; i += WG) s_hist[i] = 0;
+        for (int i = tid; i < P.hist_slots * HP_SIZE; i += WG) s_hist[i] = 0;
         for (int i = tid; i < P.hist_slots * SITE_NSUM; i += WG) s_tot[i] = 0;
     }
 
@@ -260,11 +268,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
         if (!INDEL) ref4c = nt16_int(P.ref16[site]);
     }
     const int primary = INDEL ? 0 : ref4c;            // the base most reads of the cell show
-    const bool want_epos = (P.fmt_flag & (BCFGPU_INFO_RPB | BCFGPU_INFO_VDB)) != 0;
-    const bool want_scr = (P.fmt_flag & (BCFGPU_INFO_SCR | BCFGPU_FMT_SCR)) != 0;
+    uint32_t fmt_flag = (uint32_t)P.fmt_flag;
+    asm volatile("" : "+s"(fmt_flag));
+    const bool want_epos = (fmt_flag & (BCFGPU_INFO_RPB | BCFGPU_INFO_VDB)) != 0;
+    const bool want_scr = (fmt_flag & (BCFGPU_INFO_SCR | BCFGPU_FMT_SCR)) != 0;
     const uint32_t span_end = P.off[cell_end];
-    const uint32_t n_reads_tot = P.n_reads;
-    const uint32_t min_baseQ = (uint32_t)P.min_baseQ, capQ = (uint32_t)P.capQ;
+    // The scalar arguments the inner loops use, as values of their own: read straight from the argument block they are
+    // elements of one eight-register tuple, and when the scalar registers run short the whole tuple is spilled and brought
+    // back, all eight, at every use inside phase A's loop.
+    uint32_t n_reads_tot = P.n_reads, min_baseQ = (uint32_t)P.min_baseQ, capQ = (uint32_t)P.capQ;
+    asm volatile("" : "+s"(n_reads_tot), "+s"(min_baseQ), "+s"(capQ));
 
     bool done = !active;
     // a cell must fit one staging round whatever its alignment (the window starts at a multiple of 4 reads)
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
             const uint32_t primq = INDEL ? 0u : ref4;            // `primary` of the segment's cells
             // nt16 code -> base 0..4 with code 0 ('=') standing for the reference base (bam2bcf.c:189-190)
             const unsigned long long tbl = (NT16_INT_TBL & ~0xfull) | (unsigned long long)ref4;
-            int *hist = LDS_HIST ? s_hist + (sg - site0) * H_SIZE : P.hist + (long)sg * H_SIZE;
+            int *hist = LDS_HIST ? s_hist + (sg - site0) * HP_SIZE : P.hist + (long)sg * H_SIZE;
             ReadSums A; A.clear();
             WaveCounts C; C.clear();
 
@@ -355,14 +368,27 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
                         C.rev59 += (uint32_t)__popcll(b59 & brev); C.fwd59 += (uint32_t)__popcll(b59 & ~brev);
                     }
                     if (ok && !BCFGPU_ABL(P, 1)) {
-                        const uint32_t aoff = isref ? 0u : (uint32_t)H_ALT_OFF;
-                        atomicAdd(&hist[aoff + H_REF_POS + ((e4 >> (8 * u)) & 0xff)], 1);
-                        atomicAdd(&hist[aoff + H_REF_BQ + min(bq, 59u)], 1);
-                        if (!m59) {
-                            atomicAdd(&hist[aoff + H_REF_MQ + mapQ], 1);
-                            atomicAdd(&hist[(rev ? H_REV_MQS : H_FWD_MQS) + mapQ], 1);
+                        if (LDS_HIST) {
+                            const int inc = isref ? 1 : 0x10000;
+                            atomicAdd(&hist[H_REF_POS + ((e4 >> (8 * u)) & 0xff)], inc);
+                            atomicAdd(&hist[H_REF_BQ + min(bq, 59u)], inc);
+                            if (!m59) {
+                                atomicAdd(&hist[H_REF_MQ + mapQ], inc);
+                                atomicAdd(&hist[HP_MQS + mapQ], rev ? 0x10000 : 1);
+                            }
+                        } else {
+                            const uint32_t aoff = isref ? 0u : (uint32_t)H_ALT_OFF;
+                            atomicAdd(&hist[aoff + H_REF_POS + ((e4 >> (8 * u)) & 0xff)], 1);
+                            atomicAdd(&hist[aoff + H_REF_BQ + min(bq, 59u)], 1);
+                            if (!m59) {
+                                atomicAdd(&hist[aoff + H_REF_MQ + mapQ], 1);
+                                atomicAdd(&hist[(rev ? H_REV_MQS : H_FWD_MQS) + mapQ], 1);
+                            }
                         }
                     }
+#ifdef GLF_SCHED
+                    if ((u & (GLF_SCHED - 1)) == GLF_SCHED - 1) __builtin_amdgcn_sched_barrier(0);   // the lane masks of these reads end here
+#endif
                 }
                 #pragma unroll
                 for (int h = 0; h < 4; h += 2) {
@@ -448,10 +474,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
             if ((tid & 63) == 0) {                               // the wave-uniform counts
                 if (C.ori) atomicAdd(&tot[12], (unsigned long long)C.ori);
                 if (C.mq0) atomicAdd(&tot[13], (unsigned long long)C.mq0);
-                if (C.ref59) atomicAdd(&hist[H_REF_MQ + 59], (int)C.ref59);
-                if (C.alt59) atomicAdd(&hist[H_ALT_MQ + 59], (int)C.alt59);
-                if (C.fwd59) atomicAdd(&hist[H_FWD_MQS + 59], (int)C.fwd59);
-                if (C.rev59) atomicAdd(&hist[H_REV_MQS + 59], (int)C.rev59);
+                if (LDS_HIST) {
+                    if (C.ref59 | C.alt59) atomicAdd(&hist[H_REF_MQ + 59], (int)(C.ref59 | C.alt59 << 16));
+                    if (C.fwd59 | C.rev59) atomicAdd(&hist[HP_MQS + 59], (int)(C.fwd59 | C.rev59 << 16));
+                } else {
+                    if (C.ref59) atomicAdd(&hist[H_REF_MQ + 59], (int)C.ref59);
+                    if (C.alt59) atomicAdd(&hist[H_ALT_MQ + 59], (int)C.alt59);
+                    if (C.fwd59) atomicAdd(&hist[H_FWD_MQS + 59], (int)C.fwd59);
+                    if (C.rev59) atomicAdd(&hist[H_REV_MQS + 59], (int)C.rev59);
+                }
             }
         }
         GLF_STAMP(1)
@@ -481,7 +512,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
         if (__any(cnt_raw > BCFGPU_MAX_DEPTH)) {
             uint32_t acc = 0, ntr = 0;
             const int nchk = cnt_raw > BCFGPU_MAX_DEPTH ? cnt_raw : 0;
-            int *hist_c = LDS_HIST ? s_hist + (site - site0) * H_SIZE : P.hist + (long)site * H_SIZE;
+            int *hist_c = LDS_HIST ? s_hist + (site - site0) * HP_SIZE : P.hist + (long)site * H_SIZE;
             unsigned long long *tot_c = LDS_HIST ? s_tot + (site - site0) * SITE_NSUM : P.site_sums + (size_t)site * SITE_NSUM;
             for (int i = 0; i < nchk; ++i) {
                 if (kp_w[i] == 0) continue;
@@ -509,10 +540,18 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
                 sub(12, 1u); sub(13, is0);
                 const uint32_t aoff = isref ? 0u : (uint32_t)H_ALT_OFF, imq = min(mapQ, 59u);
                 const uint32_t ep = want_epos ? P.epos[idx] : 0u;
-                atomicSub(&hist_c[aoff + H_REF_POS + ep], 1);
-                atomicSub(&hist_c[aoff + H_REF_BQ + min(bq, 59u)], 1);
-                atomicSub(&hist_c[aoff + H_REF_MQ + imq], 1);
-                atomicSub(&hist_c[(rev ? H_REV_MQS : H_FWD_MQS) + imq], 1);
+                if (LDS_HIST) {
+                    const int inc = isref ? 1 : 0x10000;
+                    atomicSub(&hist_c[H_REF_POS + ep], inc);
+                    atomicSub(&hist_c[H_REF_BQ + min(bq, 59u)], inc);
+                    atomicSub(&hist_c[H_REF_MQ + imq], inc);
+                    atomicSub(&hist_c[HP_MQS + imq], rev ? 0x10000 : 1);
+                } else {
+                    atomicSub(&hist_c[aoff + H_REF_POS + ep], 1);
+                    atomicSub(&hist_c[aoff + H_REF_BQ + min(bq, 59u)], 1);
+                    atomicSub(&hist_c[aoff + H_REF_MQ + imq], 1);
+                    atomicSub(&hist_c[(rev ? H_REV_MQS : H_FWD_MQS) + imq], 1);
+                }
             }
             if (ntr) atomicAdd(P.trunc, 1u);
         }
@@ -597,6 +636,17 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
         GLF_STAMP(6)
         // ---- epilogue of errmod_cal (m=5): float accumulators as in the reference ----
         uint32_t code = 0;
+        // The planes' addresses are read here, from device memory, with loads the optimiser must leave in place: as kernel
+        // arguments they are invariant over the staging rounds, the address of every (plane, cell) would be formed at the
+        // top of the kernel and live in registers (or in scratch) through both phases.
+        CallretPlanes cr;
+        {
+            const volatile unsigned long long *t = reinterpret_cast<const volatile unsigned long long*>(P.crp);
+            cr.p15 = reinterpret_cast<float*>(t[0]); cr.pa = reinterpret_cast<float*>(t[1]);
+            cr.qs64 = reinterpret_cast<uint64_t*>(t[2]); cr.adf = reinterpret_cast<uint32_t*>(t[3]);
+            cr.adr = reinterpret_cast<uint32_t*>(t[4]); cr.cnt4 = reinterpret_cast<uint32_t*>(t[5]);
+            cr.misc = reinterpret_cast<uint32_t*>(t[6]);
+        }
         if (part && !BCFGPU_ABL(P, 64)) {
             const int nbases = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0) + (c[4] > 0);
             if (nbases <= 1) {
@@ -607,10 +657,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
                 for (int k = 1; k < 5; ++k) if (k == b) bsb = bsum[k];
                 float A = n > 0 ? (float)((double)0.0f + bsb) : 0.0f;
                 if (A < 0.0f) A = 0.0f;
-                P.cr.pa[cell] = A;
+                cr.pa[cell] = A;
                 code = (uint32_t)b;
             } else {
                 code = CR_FULL;
+                float *p15c = cr.p15 + (size_t)cell * 16;        // the cell's record: 15 likelihoods in 64 bytes
                 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
                     float tmp1 = 0.0f; int tmp2 = 0;
@@ -619,7 +670,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
                     float v = 0.0f;
                     if (n > 0 && tmp2) v = tmp1;
                     if (v < 0.0f) v = 0.0f;
-                    P.cr.p15[(size_t)tri(j, j) * ncells + cell] = v;
+                    p15c[tri(j, j)] = v;
                     #pragma unroll
                     for (int k = j + 1; k < 5; ++k) {
                         const int cjk = c[j] + c[k];
@@ -632,7 +683,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
                             h = t2 ? (float)(lh + (double)t1) : (float)lh;
                             if (h < 0.0f) h = 0.0f;
                         }
-                        P.cr.p15[(size_t)tri(j, k) * ncells + cell] = h;
+                        p15c[tri(j, k)] = h;
                     }
                 }
             }
@@ -644,9 +695,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
             const uint32_t n_fwd = n - n_rev;
             const uint32_t d_rev = all_diff ? n_rev : o_rev, d_fwd = all_diff ? n_fwd : n_other - o_rev;
             const uint32_t cnt4 = (n_fwd - d_fwd) | (n_rev - d_rev) << 8 | d_fwd << 16 | d_rev << 24;
-            P.cr.qs64[cell] = qs64;
-            P.cr.adf[cell] = (uint32_t)ad64; P.cr.adr[cell] = (uint32_t)(ad64 >> 32); P.cr.cnt4[cell] = cnt4;
-            P.cr.misc[cell] = code | (scr & 0xff) << 8;  // mq0 and ori_depth only feed site totals: site_sums[12..13]
+            cr.qs64[cell] = qs64;
+            cr.adf[cell] = (uint32_t)ad64; cr.adr[cell] = (uint32_t)(ad64 >> 32); cr.cnt4[cell] = cnt4;
+            cr.misc[cell] = code | (scr & 0xff) << 8;  // mq0 and ori_depth only feed site totals: site_sums[12..13]
             done = true;
         }
         if (nb == 0xffffffffu) break;
@@ -659,9 +710,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
     if (LDS_HIST) {
         __syncthreads();
         const int nslot = min(P.hist_slots, P.n_sites - site0);
-        for (int i = tid; i < nslot * H_SIZE; i += WG) {
-            const int v = s_hist[i];
-            if (v) atomicAdd(&P.hist[(long)site0 * H_SIZE + i], v);
+        for (int i = tid; i < nslot * HP_SIZE; i += WG) {
+            const uint32_t v = (uint32_t)s_hist[i];
+            const int sl = i / HP_SIZE, j = i - sl * HP_SIZE;
+            int *g = P.hist + (long)(site0 + sl) * H_SIZE;
+            const int lo = j < HP_MQS ? j : H_FWD_MQS + (j - HP_MQS), hi = j < HP_MQS ? j + H_ALT_OFF : H_REV_MQS + (j - HP_MQS);
+            if (v & 0xffffu) atomicAdd(&g[lo], (int)(v & 0xffffu));
+            if (v >> 16) atomicAdd(&g[hi], (int)(v >> 16));
         }
         for (int i = tid; i < nslot * SITE_NSUM; i += WG) {
             const unsigned long long v = s_tot[i];
@@ -676,7 +731,7 @@ size_t glfgen_lds_bytes(int cap, int hist_slots)
 #ifndef GLF_LDS_PAD
 #define GLF_LDS_PAD 0        // (occupancy experiments: bytes of LDS a workgroup asks for and does not use)
 #endif
-    return LDS_HIST_OFF + (size_t)hist_slots * (H_SIZE * sizeof(int) + SITE_NSUM * 8) + ((size_t)cap + 8) * 2 + GLF_LDS_PAD;
+    return LDS_HIST_OFF + (size_t)hist_slots * (HP_SIZE * sizeof(int) + SITE_NSUM * 8) + ((size_t)cap + 8) * 2 + GLF_LDS_PAD;
 }
 
 template <bool INDEL, bool LDS_HIST>

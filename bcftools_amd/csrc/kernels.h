@@ -35,7 +35,7 @@ enum : int { SITE_NSUM = 14 };
 // heterozygotes with b (errmod_cal's lhet term alone, a function of the read count n) -- so such a cell stores A and b and
 // combine_kernel rebuilds the planes it needs; cells with two or more bases store all 15 values.
 struct CallretPlanes {
-    float    *p15;    // [15][ncells]  upper triangle of p[5][5]: index k*(k+1)/2+j for j<=k; written for CR_FULL cells only
+    float    *p15;    // [ncells][16]  upper triangle of p[5][5]: index k*(k+1)/2+j for j<=k (a 64-byte record per cell); written for CR_FULL cells only
     float    *pa;     // [ncells]      A of a single-base cell
     uint64_t *qs64;   // [ncells]      QS[0..3] packed 4 x u16
     uint32_t *adf;    // [ncells]      ADF[0..3] packed 4 x u8
@@ -60,7 +60,7 @@ struct GlfgenParams {
     const uint8_t  *epos;
     const uint32_t *aux;
     const double *fk, *beta, *lhet;
-    CallretPlanes cr;
+    const CallretPlanes *crp;       // the output planes' addresses, in device memory: read where the stores are (glfgen.hip)
     int *hist;                      // [n_sites][H_SIZE], zeroed before launch
     unsigned long long *site_sums;  // [n_sites][SITE_NSUM] site totals of anno[4..15], ori_depth, mq0 (exact integers), zeroed before launch
     int *err;                       // device error word
