@@ -278,11 +278,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
     // back, all eight, at every use inside phase A's loop.
     uint32_t n_reads_tot = P.n_reads, min_baseQ = (uint32_t)P.min_baseQ, capQ = (uint32_t)P.capQ;
     asm volatile("" : "+s"(n_reads_tot), "+s"(min_baseQ), "+s"(capQ));
+    const uint32_t *p_rd = P.rd, *p_aux = P.aux, *p_off = P.off;          // (the same for the pointers of the inner loops)
+    const uint8_t *p_epos = P.epos;
+    asm volatile("" : "+s"(p_rd), "+s"(p_aux), "+s"(p_off), "+s"(p_epos));
 
     bool done = !active;
     // a cell must fit one staging round whatever its alignment (the window starts at a multiple of 4 reads)
     if (active && end - beg > (uint32_t)cap - 3u) { atomicExch(P.err, BCFGPU_E_DEPTH); done = true; }
-    uint32_t base = P.off[cell0];
+    uint32_t base = p_off[cell0];
 
     for (;;) {
         const uint32_t abase = base & ~3u;                       // key index 0 of this round
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
         // ================= phase A: one lane per read =================
         for (int sg = site0; sg <= site_last; ++sg) {            // uniform: the site segments of the workgroup's span
             const long c_lo = max(cell0, (long)sg * S), c_hi = min(cell_end, (long)(sg + 1) * S);
-            const uint32_t rb = max(P.off[c_lo], base), re = min(P.off[c_hi], rlim);
+            const uint32_t rb = max(p_off[c_lo], base), re = min(p_off[c_hi], rlim);
             if (rb >= re) continue;
             const int ref_base = INDEL ? -1 : (int)P.ref16[sg];
             const uint32_t ref4 = INDEL ? 4u : (uint32_t)nt16_int(ref_base);
@@ -417,16 +420,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
             auto fetch = [&](uint32_t i4) {
                 if (i4 >= re) return;
                 if (i4 + 3 < n_reads_tot) {
-                    w4n = *reinterpret_cast<const uint4*>(P.rd + i4);
-                    if (want_epos) e4n = *reinterpret_cast<const uint32_t*>(P.epos + i4);
-                    if (INDEL) a4n = *reinterpret_cast<const uint4*>(P.aux + i4);
+                    w4n = *reinterpret_cast<const uint4*>(p_rd + i4);
+                    if (want_epos) e4n = *reinterpret_cast<const uint32_t*>(p_epos + i4);
+                    if (INDEL) a4n = *reinterpret_cast<const uint4*>(p_aux + i4);
                 } else {                                         // the last reads of the tile
                     uint32_t t4[4] = {0, 0, 0, 0}, x4[4] = {0, 0, 0, 0};
                     e4n = 0;
                     for (int j = 0; j < 4; ++j) if (i4 + j < n_reads_tot) {
-                        t4[j] = P.rd[i4 + j];
-                        if (want_epos) e4n |= (uint32_t)P.epos[i4 + j] << (8 * j);
-                        if (INDEL) x4[j] = P.aux[i4 + j];
+                        t4[j] = p_rd[i4 + j];
+                        if (want_epos) e4n |= (uint32_t)p_epos[i4 + j] << (8 * j);
+                        if (INDEL) x4[j] = p_aux[i4 + j];
                     }
                     w4n = make_uint4(t4[0], t4[1], t4[2], t4[3]); a4n = make_uint4(x4[0], x4[1], x4[2], x4[3]);
                 }
@@ -519,10 +522,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
                 if (acc < BCFGPU_MAX_DEPTH) { ++acc; continue; }
                 kp_w[i] = 0; ++ntr;
                 // the read's contributions, as phase A computed them (bam2bcf.c:173-252)
-                const uint32_t idx = beg + (uint32_t)i, w = P.rd[idx];
+                const uint32_t idx = beg + (uint32_t)i, w = p_rd[idx];
                 uint32_t b, bq;
                 if (INDEL) {
-                    const uint32_t ax = P.aux[idx];
+                    const uint32_t ax = p_aux[idx];
                     b = (ax >> 16) & 0xf; bq = ax & 0xff;
                     if (bq < min_baseQ) b = 0;
                     b = min(b, 4u);
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
                 sub(0 + o, bq); sub(1 + o, bq * bq); sub(4 + o, mapQ); sub(5 + o, mapQ * mapQ); sub(8 + o, md); sub(9 + o, md * md);
                 sub(12, 1u); sub(13, is0);
                 const uint32_t aoff = isref ? 0u : (uint32_t)H_ALT_OFF, imq = min(mapQ, 59u);
-                const uint32_t ep = want_epos ? P.epos[idx] : 0u;
+                const uint32_t ep = want_epos ? p_epos[idx] : 0u;
                 if (LDS_HIST) {
                     const int inc = isref ? 1 : 0x10000;
                     atomicSub(&hist_c[H_REF_POS + ep], inc);
