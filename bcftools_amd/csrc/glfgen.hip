@@ -185,20 +185,26 @@ __device__ __forceinline__ double walk_runs(uint32_t *s_slot, uint64_t qm, const
         qs += first ? count_runs<true>(s_slot, qm, tid, src, nsrc) : count_runs<false>(s_slot, qm, tid, src, nsrc);
         first = false; r = 0;
         d_nx = slot_of(0);
+        // Two steps in flight, each in its own registers: a trip adds the older one and puts the step after next in its place, so
+        // no step's operands are copied and the wait before an addition is for that step's loads alone.  (Once a step finds
+        // no lane with a read, every later one adds +0: the two left over at the end are added in any order.)
         double bx[WR], fx[WR], by[WR], fy[WR];
         uint32_t off[WR], wi[WR];
-        bool more = step(off, wi);
+        bool ax = step(off, wi);
         WALK_LOAD(bx, fx, off, wi);
-        while (more) {
-            more = step(off, wi);
-            WALK_LOAD(by, fy, off, wi);
+        bool ay = step(off, wi);
+        WALK_LOAD(by, fy, off, wi);
+        while (ax) {
             WALK_ADD(bx, fx);
-            if (!more) { _Pragma("unroll") for (int u = 0; u < WR; ++u) { bx[u] = by[u]; fx[u] = fy[u]; } break; }
-            more = step(off, wi);
+            ax = step(off, wi);
             WALK_LOAD(bx, fx, off, wi);
+            if (!ay) break;
             WALK_ADD(by, fy);
+            ay = step(off, wi);
+            WALK_LOAD(by, fy, off, wi);
         }
-        WALK_ADD(bx, fx);                                                 // the last step issued: no lane had a read, +0
+        WALK_ADD(bx, fx);
+        WALK_ADD(by, fy);
         // the qualities of this round leave the mask
         if (__any(__popcll(qm) > NRANK)) {
             uint64_t m = qm;
