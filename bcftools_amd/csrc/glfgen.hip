@@ -444,6 +444,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
             const uint32_t ntrip = (re - g0 + 4u * WG - 1) / (4u * WG);       // uniform trip count: the ballots need whole waves
             for (uint32_t it = 0; it < (BCFGPU_ABL(P, 32) ? 0u : ntrip); ++it) {
                 const uint32_t i4 = g0 + 4u * tid + it * (4u * WG);
+                if (__all(i4 >= re)) break;                      // the wavefront is past the segment's last read (the last trip's upper waves)
                 const uint32_t wv[4] = { w4n.x, w4n.y, w4n.z, w4n.w };
                 const uint32_t av[4] = { a4n.x, a4n.y, a4n.z, a4n.w };
                 const uint32_t e4 = e4n;
