@@ -1,10 +1,11 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/pmc_ta.sh  -- texture-path counters of glfgen_kernel (product build), 4096-site tile, first dispatch
+# (a pass with TA_FLAT_READ_WAVEFRONTS_sum / TA_*_STALLED_BY_TC_CYCLES_sum did not return on this pool: not in the list)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rocprofv3 --list-avail > $R/gpurun_out/avail.txt 2>&1 || true
 grep -o -E "\b(TA|TCP|TD|TCC|SQ|SQC)_[A-Za-z0-9_]+" $R/gpurun_out/avail.txt | sort -u > $R/gpurun_out/avail_names.txt
-for set in "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_GATE_EN1_sum" "TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TD_TD_BUSY_sum" "SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
+for set in "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_GATE_EN1_sum"; do
   tag=$(echo $set | cut -d' ' -f1)
   OUT=$R/gpurun_out/pmcta_$tag; rm -rf $OUT; mkdir -p $OUT
   rocprofv3 --kernel-trace --pmc $set -d $OUT -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --sites 4096 --cpu-seconds 0 --cpu-all-cores 0 --extras 0 > $OUT/log 2>&1 || { echo "set failed: $set"; tail -3 $OUT/log; continue; }
