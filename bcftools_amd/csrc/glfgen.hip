@@ -622,7 +622,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
         c[4] = (int)n_b4;
         GLF_STAMP(5)
         // (b) the other bases present in the wave
-        if (!BCFGPU_ABL(P, 2) && __any(n_other > 0)) {
+        if (!BCFGPU_ABL(P, 2) && !BCFGPU_ABL(P, 32768) && __any(n_other > 0)) {    // (diagnostics: 32768 times the kernel without the other bases' walks)
             #pragma unroll 1
             for (int b = 0; b < 5; ++b) {
                 int cb = b == 0 ? c[0] : b == 1 ? c[1] : b == 2 ? c[2] : b == 3 ? c[3] : c[4];
