@@ -131,6 +131,54 @@ def test_pileup_matches_host_walk_on_random_reads(gpu_ctx_factory):
             device_pileup(ctx, by_sample, refseq, 0, 50)
 
 
+def test_pileup_from_a_page_locked_pool(gpu_ctx_factory):
+    """bcfgpu_host_alloc: the read pool in page-locked memory (what a caller parses into to make the uploads DMA transfers)
+    gives the tile of the same pool in ordinary memory; two contexts used alternately, as bench.py --mode pileup does."""
+    rng = np.random.default_rng(17)
+    S, L = 5, 400
+    refseq = "".join("ACGT"[i] for i in rng.integers(0, 4, L))
+    by_sample = []
+    for s in range(S):
+        rl = [ovlfuzz.make_read(rng, rng.integers(0, L - 60), int(rng.integers(30, 100))) for _ in range(int(rng.integers(5, 40)))]
+        for r in rl:
+            r.mapq = int(rng.integers(0, 61)); r.flag = int(rng.choice([0, 16]))
+        rl.sort(key=lambda r: r.pos)
+        by_sample.append(rl)
+    reads = [r for rl in by_sample for r in rl]
+    smpl = np.array([si for si, rl in enumerate(by_sample) for _ in rl], dtype=np.int32)
+    mapq = np.array([r.mapq for r in reads], dtype=np.uint8)
+    rd, keep = M.pack_reads(reads)
+    ctxs = [gpu_ctx_factory(abi.default_cfg(S, max_sites=1, max_reads=64)) for _ in range(2)]
+    Lib = ctxs[0].L
+    want, _, _, _ = device_pileup(ctxs[0], by_sample, refseq, 0, L)
+    # the same arrays copied into page-locked buffers
+    ptrs = []
+
+    def pin(addr, nbytes):
+        p = C.c_void_p()
+        check(Lib.bcfgpu_host_alloc(max(nbytes, 1), C.byref(p)))
+        ptrs.append(p)
+        C.memmove(p.value, addr, nbytes)
+        return p.value
+    n = len(reads)
+    rp = abi.Reads()
+    rp.n_reads = n
+    for name, arr in keep.items():
+        setattr(rp, name, pin(arr.ctypes.data, arr.nbytes))
+    pm, ps = pin(mapq.ctypes.data, n), pin(smpl.ctypes.data, 4 * n)
+    for rep in range(3):
+        ctx = ctxs[rep & 1]
+        t = abi.Tile()
+        check(Lib.bcfgpu_pileup(ctx.h, C.byref(rp), pm, ps, 0, L, refseq.encode(), len(refseq), C.byref(t), None, None))
+        off = np.zeros(L * S + 1, np.uint32); w = np.zeros(int(t.n_reads), np.uint32); e = np.zeros(int(t.n_reads), np.uint8)
+        for dst, srcp in ((off, t.plp_off), (w, t.rd), (e, t.epos)):
+            check(Lib.bcfgpu_memcpy_d2h(ctx.h, dst.ctypes.data, srcp, dst.nbytes))
+        ctx.sync()
+        np.testing.assert_array_equal(off, want.plp_off); np.testing.assert_array_equal(w, want.rd); np.testing.assert_array_equal(e, want.epos)
+    for p in ptrs:
+        check(Lib.bcfgpu_host_free(p))
+
+
 @pytest.mark.parametrize("files,fa,contig,beg,end,goldf,fmt,n_snp", [
     (["mpileup.1.sam", "mpileup.2.sam", "mpileup.3.sam"], "mpileup.ref.fa", "17", 99, 600, "mpileup.2.out",
      abi.INFO_VDB | abi.INFO_RPB | abi.FMT_DP | abi.FMT_DV, 501),
