@@ -52,7 +52,8 @@ struct bcfgpu_ctx {
     // grow-only device workspaces of the indel / BAQ stages (GiB-sized scratch: not reallocated per call)
     struct Ws { void *p = nullptr; size_t bytes = 0; };
     alignas(16) unsigned char pileup_state[256] = {0};   // csrc/pileup.hip: the parameters of the last bcfgpu_pileup
-    Ws ws[72];                     // grow-only device workspaces of the host-fed stages (0-15: BAQ / overlaps, 16-31: pileup, 32-33: gVCF, 40-71: gap_prep)
+    Ws ws[104];                    // grow-only device workspaces of the host-fed stages (0-15: BAQ / overlaps, 16-35: pileup, 36-39: gVCF / indel tile, 40-103: gap_prep)
+    int n_cu = 256;                // compute units of the device (grid size of the work-queue kernels)
     Ws pinned[8];                  // grow-only pinned host staging buffers
 };
 
@@ -104,6 +105,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
     if (e != hipSuccess) { delete c; return set_err(BCFGPU_E_HIP, "hipStreamCreate", e); }
     c->stream = c->own_stream;
     for (int i = 0; i < 4; ++i) hipEventCreate(&c->ev[i]);
+    { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
 
     // tables
     const double theta = cfg->errmod_theta <= 0. ? 0.83 : cfg->errmod_theta;     // CALL_DEFTHETA, bam2bcf.c:38,46
@@ -555,7 +557,7 @@ void *bcfgpu_internal_pileup_state(bcfgpu_ctx *c) { return c ? c->pileup_state :
 // workspace `slot` of at least `bytes` (contents undefined); nullptr when the allocation fails
 void *bcfgpu_internal_ws(bcfgpu_ctx *c, int slot, size_t bytes)
 {
-    if (!c || slot < 0 || slot >= 72) return nullptr;
+    if (!c || slot < 0 || slot >= 104) return nullptr;
     auto &w = c->ws[slot];
     if (w.bytes >= bytes && w.p) return w.p;
     hipSetDevice(c->cfg.device);
@@ -581,6 +583,8 @@ void *bcfgpu_internal_pinned(bcfgpu_ctx *c, int slot, size_t bytes)
 }
 
 // for the stages implemented in their own translation units: bind the device, hand out the stream and shared tables
+int bcfgpu_internal_n_cu(const bcfgpu_ctx *c) { return c ? c->n_cu : 256; }
+
 int bcfgpu_internal_device(bcfgpu_ctx *c, hipStream_t *stream, const float **q2p)
 {
     if (!c) return -1;

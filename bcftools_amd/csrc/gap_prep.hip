@@ -22,11 +22,14 @@
 // Two small device->host reads size the buffers of the following stage (job / window totals after the typing; the count
 // of wide-band jobs after the register-resident realignment pass); everything else is queued on the context's stream.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <chrono>
 #include <limits.h>
+#include <vector>
+#include <cstdio>
 #include "kernels.h"
 
 using namespace bcfgpu;
@@ -205,8 +208,8 @@ __global__ __launch_bounds__(256) void gap_type_kernel(const GapIn in, GapSite *
 __global__ void gap_scan_kernel(GapSite *sites, int n_sites, int n_smpl, GapTotals *tot)
 {
     if (threadIdx.x || blockIdx.x) return;
-    uint64_t jobs = 0, ref2 = 0, ins = 0;
-    int maxL = 0, max_bw = 0, n_live = 0, max_ref2 = 0;
+    uint64_t jobs = 0, ref2 = 0, ins = 0, q8 = 0;
+    int maxL = 0, max_bw = 0, n_live = 0, max_ref2 = 0, max_qstride = 0;
     for (int is = 0; is < n_sites; ++is) {
         GapSite &S = sites[is];
         S.job_end = (uint32_t)jobs;
@@ -215,6 +218,10 @@ __global__ void gap_scan_kernel(GapSite *sites, int n_sites, int n_smpl, GapTota
         S.job0 = (uint32_t)jobs; S.ref2_0 = (uint32_t)ref2; S.ins0 = (uint32_t)ins;
         jobs += (uint64_t)S.N * S.n_types;
         S.job_end = (uint32_t)jobs;
+        S.qstride = (S.max_rd_len + 7) & ~7;                    // qend - qbeg of an entry never exceeds its read's length
+        S.q8_0 = (uint32_t)q8;
+        q8 += (uint64_t)S.N * (uint32_t)(S.qstride >> 3);
+        max_qstride = max(max_qstride, S.qstride);
         ref2 += (uint64_t)S.n_types * n_smpl * S.max_ref2;
         ins += (uint64_t)S.n_types * (S.max_ins > 0 ? S.max_ins : 0);
         maxL = max(maxL, S.right - S.left + 1);
@@ -224,7 +231,7 @@ __global__ void gap_scan_kernel(GapSite *sites, int n_sites, int n_smpl, GapTota
     }
     tot->n_wide = 0; tot->max_eff = 0; tot->n_passes = 0; tot->dp_cells = 0;
     tot->n_jobs = jobs; tot->ref2_bytes = ref2; tot->ins_bytes = ins; tot->max_L = maxL; tot->max_bw = max_bw; tot->n_live = n_live;
-    tot->max_ref2 = max_ref2;
+    tot->max_ref2 = max_ref2; tot->qpack8 = q8; tot->max_qstride = max_qstride;
 }
 
 // ---- insertion consensus and est_indelreg ----
@@ -451,14 +458,154 @@ __global__ __launch_bounds__(256) void gap_finalize_kernel(const GapIn in, GapSi
 
 // =====================================================================================================================
 // host: transfers and launch sequencing only
+#define GP_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, #call); } while (0)
+#define WS(slot, bytes) bcfgpu_internal_ws(ctx, 40 + (slot), (bytes) + 64)      /* slots 40..: this stage's own */
+
+extern "C" int bcfgpu_internal_n_cu(const bcfgpu_ctx *c);
+
+// The stage on arrays that are already in HBM (`g`: device pointers throughout; n_ent pileup entries).  d_aux [n_ent]
+// (device) receives p->aux; the per-site outputs go to the host arrays of `out` (out->p_aux is not touched: the callers
+// decide whether the entries' words leave the device).  Three waits on the stream: the totals that size the second
+// half's buffers, the count of wide-band jobs, the per-site results.
+int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint32_t *d_aux, const bcfgpu_indel_out *out, int inscns_cap)
+{
+    hipStream_t st;
+    const float *q2p;
+    if (bcfgpu_internal_device(ctx, &st, &q2p)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep: bad context");
+    bcfgpu_gap_stats &gs = *bcfgpu_internal_gap_stats(ctx);
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    const int ns = g.n_sites, n = g.n_smpl, nr = g.n_reads;
+    GapSite *d_sites = (GapSite*)WS(25, (size_t)ns * sizeof(GapSite));
+    uint32_t *d_rinfo = (uint32_t*)WS(26, (size_t)nr * 4);
+    // small outputs share one block: ret, types[4], maxins, indelreg, max_support, max_frac per site, then the totals
+    const size_t so_ret = 0, so_types = (size_t)ns * 4, so_maxins = so_types + (size_t)ns * 16, so_ireg = so_maxins + (size_t)ns * 4,
+                 so_msup = so_ireg + (size_t)ns * 4, so_mfrac = so_msup + (size_t)ns * 4, so_tot = (so_mfrac + (size_t)ns * 4 + 15) & ~(size_t)15,
+                 so_bytes = so_tot + sizeof(GapTotals);
+    uint8_t *d_small = (uint8_t*)WS(28, so_bytes);
+    uint8_t *h_small = (uint8_t*)bcfgpu_internal_pinned(ctx, 0, so_bytes);
+    if (!d_sites || !d_rinfo || !d_small || !h_small) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
+    int32_t *o_ret = (int32_t*)(d_small + so_ret), *o_types = (int32_t*)(d_small + so_types), *o_maxins = (int32_t*)(d_small + so_maxins);
+    int32_t *o_ireg = (int32_t*)(d_small + so_ireg), *o_msup = (int32_t*)(d_small + so_msup);
+    float *o_mfrac = (float*)(d_small + so_mfrac);
+    GapTotals *d_tot = (GapTotals*)(d_small + so_tot);
+    GP_CHK(hipMemsetAsync(d_small, 0, so_bytes, st));
+    if (n_ent) GP_CHK(hipMemsetAsync(d_aux, 0, n_ent * 4, st));
+
+    // ---- typing ----
+    if (nr) hipLaunchKernelGGL(gap_read_info_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, g, d_rinfo);
+    hipLaunchKernelGGL(gap_type_kernel, dim3(ns), dim3(256), 0, st, g, d_sites, d_rinfo, o_ret, o_types, o_msup, o_mfrac);
+    hipLaunchKernelGGL(gap_scan_kernel, dim3(1), dim3(1), 0, st, d_sites, ns, n, d_tot);
+    GapTotals tot{};
+    GP_CHK(hipMemcpyAsync(h_small, d_tot, sizeof(GapTotals), hipMemcpyDeviceToHost, st));
+    GP_CHK(hipStreamSynchronize(st));                           // sizes of the next stage's buffers
+    memcpy(&tot, h_small, sizeof tot);
+    gs.prepare_ms += ms_since(t_begin);
+    if (tot.n_jobs >> 31 || tot.ref2_bytes >> 32 || tot.qpack8 >> 32)
+        return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_gap_prep: batch too large (pool offsets are 32-bit), use fewer sites per call");
+    gs.n_jobs = tot.n_jobs;
+    int8_t *d_oinscns = nullptr;
+    if (tot.n_live) {
+        const size_t nj = (size_t)tot.n_jobs;
+        int32_t *d_inscnt = (int32_t*)WS(16, (size_t)tot.ins_bytes * 5 * 4);
+        int8_t *d_inscns = (int8_t*)WS(17, (size_t)tot.ins_bytes);
+        uint8_t *d_ref2 = (uint8_t*)WS(18, (size_t)tot.ref2_bytes + 16);
+        int32_t *d_s1 = (int32_t*)WS(19, nj * 4), *d_s2 = (int32_t*)WS(20, nj * 4);
+        uint32_t *d_wide = (uint32_t*)WS(21, nj * 4);
+        GapEntry *d_ent = (GapEntry*)WS(29, n_ent * sizeof(GapEntry));
+        uint8_t *d_qpack = (uint8_t*)WS(30, (size_t)tot.qpack8 * 8 + 16);
+        PJob *d_pjob = (PJob*)WS(31, nj * sizeof(PJob));
+        uint32_t *d_k0 = (uint32_t*)WS(32, nj * 4), *d_v0 = (uint32_t*)WS(33, nj * 4), *d_k1 = (uint32_t*)WS(34, nj * 4), *d_v1 = (uint32_t*)WS(35, nj * 4);
+        uint32_t *d_list2 = (uint32_t*)WS(36, nj * 4);
+        ProbalnQueue *d_queue = (ProbalnQueue*)WS(38, sizeof(ProbalnQueue));
+        size_t sort_bytes = 0;
+        GP_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, d_k0, d_k1, d_v0, d_v1, (int)nj, 0, 17, st));
+        void *d_sort = WS(37, sort_bytes);
+        if (out->inscns) d_oinscns = (int8_t*)WS(22, (size_t)ns * 4 * inscns_cap);
+        if (!d_inscnt || !d_inscns || !d_ref2 || !d_s1 || !d_s2 || !d_wide || !d_ent || !d_qpack || !d_pjob || !d_k0 || !d_v0 || !d_k1 || !d_v1 ||
+            !d_list2 || !d_queue || !d_sort || (out->inscns && !d_oinscns))
+            return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
+        if (tot.ins_bytes) { GP_CHK(hipMemsetAsync(d_inscnt, 0, (size_t)tot.ins_bytes * 5 * 4, st)); GP_CHK(hipMemsetAsync(d_inscns, 0, (size_t)tot.ins_bytes, st)); }
+        GP_CHK(hipMemsetAsync(d_s1, 0, nj * 4, st)); GP_CHK(hipMemsetAsync(d_s2, 0, nj * 4, st));
+        if (d_oinscns) GP_CHK(hipMemsetAsync(d_oinscns, 0, (size_t)ns * 4 * inscns_cap, st));
+        hipLaunchKernelGGL(gap_inscns_kernel, dim3(ns), dim3(256), 0, st, g, d_sites, d_inscnt, d_inscns);
+        hipLaunchKernelGGL(gap_cons_kernel, dim3((unsigned)((size_t)ns * n)), dim3(64), (size_t)tot.max_L * 4 + 16, st, g, d_sites, d_inscns, d_ref2);
+        // ---- realignment: the jobs decoded and sorted by band, register-resident passes per band width; the jobs with
+        // wider bands are listed and run from scratch rows ----
+        launch_gap_entries(g, d_sites, (int)n_ent, d_ent, tot.max_qstride, d_qpack, st);
+        ProbalnParams p{};
+        p.ent = d_ent;
+        p.gin = g; p.sites = d_sites; p.n_sites = ns; p.n_jobs = (int)nj;
+        p.ref2 = d_ref2; p.qpack = d_qpack; p.q2p = q2p; p.score1 = d_s1; p.score2 = d_s2;
+        p.pjob = d_pjob; p.key_in = d_k0; p.val_in = d_v0; p.key_sorted = d_k1; p.val_sorted = d_v1; p.list2 = d_list2; p.queue = d_queue;
+        p.wide = d_wide; p.tot = d_tot;
+        p.force_wide = getenv("BCFGPU_FORCE_WIDE") != nullptr;      // tests: every job through the rolling-row kernel
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, st);
+        launch_probaln_jobs(p, st);
+        GP_CHK(hipcub::DeviceRadixSort::SortPairs(d_sort, sort_bytes, d_k0, d_k1, d_v0, d_v1, (int)nj, 0, 17, st));
+        launch_probaln_bounds(p, st);
+        launch_probaln_exact(p, st, bcfgpu_internal_n_cu(ctx));
+        GP_CHK(hipMemcpyAsync(h_small, d_tot, sizeof(GapTotals), hipMemcpyDeviceToHost, st));
+        GP_CHK(hipStreamSynchronize(st));                       // how many jobs need the wide-band version, and how wide
+        memcpy(&tot, h_small, sizeof tot);
+        if (tot.n_wide) {
+            p.ncell = 3 * (2 * tot.max_eff + 1) + 6;
+            size_t chunk = ((size_t)1 << 30) / (2 * (size_t)p.ncell * sizeof(double));
+            chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
+            if (chunk > tot.n_wide) chunk = ((size_t)tot.n_wide + 63) & ~(size_t)63;
+            p.scratch_stride = chunk;
+            p.scratch = (double*)WS(23, 2 * (size_t)p.ncell * chunk * sizeof(double));
+            if (!p.scratch) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
+            for (size_t j0 = 0; j0 < tot.n_wide; j0 += chunk) {
+                p.wide_first = (uint32_t)j0;
+                p.wide_count = (int)(tot.n_wide - j0 < chunk ? tot.n_wide - j0 : chunk);
+                launch_probaln_wide(p, st);
+            }
+        }
+        hipEventRecord(e1, st);
+        if (const char *dp = getenv("BCFGPU_DUMP_SCORES")) {      // TEMPORARY diagnostics
+            std::vector<int32_t> h1(nj), h2(nj); std::vector<uint32_t> hk(nj); std::vector<PJob> hp(nj);
+            hipMemcpy(h1.data(), d_s1, nj * 4, hipMemcpyDeviceToHost); hipMemcpy(h2.data(), d_s2, nj * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(hk.data(), d_k0, nj * 4, hipMemcpyDeviceToHost); hipMemcpy(hp.data(), d_pjob, nj * sizeof(PJob), hipMemcpyDeviceToHost);
+            FILE *f = fopen(dp, "wb"); int64_t n64 = (int64_t)nj; fwrite(&n64, 8, 1, f);
+            fwrite(h1.data(), 4, nj, f); fwrite(h2.data(), 4, nj, f); fwrite(hk.data(), 4, nj, f); fwrite(hp.data(), sizeof(PJob), nj, f); fclose(f);
+        }
+        hipLaunchKernelGGL(gap_finalize_kernel, dim3(ns), dim3(256), 0, st, g, d_sites, d_s1, d_s2, d_inscns, d_aux, o_ret, o_types,
+                           d_oinscns, inscns_cap, o_maxins, o_ireg);
+        GP_CHK(hipGetLastError());
+        GP_CHK(hipMemcpyAsync(h_small, d_small, so_bytes, hipMemcpyDeviceToHost, st));
+        if (out->inscns) GP_CHK(hipMemcpyAsync(out->inscns, d_oinscns, (size_t)ns * 4 * inscns_cap, hipMemcpyDeviceToHost, st));
+        GP_CHK(hipStreamSynchronize(st));
+        hipEventElapsedTime(&gs.kernel_ms, e0, e1);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        memcpy(&tot, h_small + so_tot, sizeof tot);
+        gs.n_passes = tot.n_passes; gs.dp_cells = tot.dp_cells;
+    } else {
+        GP_CHK(hipMemcpyAsync(h_small, d_small, so_bytes, hipMemcpyDeviceToHost, st));
+        GP_CHK(hipStreamSynchronize(st));
+        if (out->inscns) memset(out->inscns, 0, (size_t)ns * 4 * inscns_cap);
+    }
+    const auto t_fin = std::chrono::steady_clock::now();
+    memcpy(out->ret, h_small + so_ret, (size_t)ns * 4);
+    memcpy(out->indel_types, h_small + so_types, (size_t)ns * 16);
+    if (out->maxins) memcpy(out->maxins, h_small + so_maxins, (size_t)ns * 4);
+    if (out->indelreg) memcpy(out->indelreg, h_small + so_ireg, (size_t)ns * 4);
+    if (out->max_support) memcpy(out->max_support, h_small + so_msup, (size_t)ns * 4);
+    if (out->max_frac) memcpy(out->max_frac, h_small + so_mfrac, (size_t)ns * 4);
+    gs.finalize_ms += ms_since(t_fin);
+    return BCFGPU_OK;
+}
+
 extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bcfgpu_indel_in *in, const bcfgpu_indel_out *out,
                                int inscns_cap)
 {
     if (!ctx || !rd || !in || !out || !out->ret || !out->p_aux || !out->indel_types || !in->ref)
         return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep: bad arguments");
     hipStream_t st;
-    const float *q2p;
-    if (bcfgpu_internal_device(ctx, &st, &q2p)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep: bad context");
+    if (bcfgpu_internal_device(ctx, &st, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep: bad context");
     bcfgpu_gap_stats &gs = *bcfgpu_internal_gap_stats(ctx);
     gs = bcfgpu_gap_stats{};
     const auto t_begin = std::chrono::steady_clock::now();
@@ -485,8 +632,6 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
     const long ref_lo = pmin > 65536 ? pmin - 65536 : 0;
     const long ref_hi = pmax + 1 + (long)strnlen(in->ref + pmax + 1, 65536 + 4096);   // the caller guarantees ref[pos+1] exists (mpileup.c:341)
 
-    #define GP_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, #call); } while (0)
-    #define WS(slot, bytes) bcfgpu_internal_ws(ctx, 40 + (slot), (bytes) + 64)      /* slots 40..: this stage's own */
     // ---- inputs to HBM (queued on the stream; the kernels follow in order) ----
     int32_t *d_rpos = (int32_t*)WS(0, (size_t)nr * 4), *d_rlq = (int32_t*)WS(1, (size_t)nr * 4), *d_rflag = (int32_t*)WS(2, (size_t)nr * 4);
     int32_t *d_rncig = (int32_t*)WS(3, (size_t)nr * 4), *d_rcoff = (int32_t*)WS(4, (size_t)nr * 4), *d_rsoff = (int32_t*)WS(5, (size_t)nr * 4);
@@ -496,17 +641,9 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
     int32_t *d_pos = (int32_t*)WS(11, (size_t)ns * 4), *d_soff = (int32_t*)WS(12, ((size_t)ns * n + 1) * 4);
     int32_t *d_pread = (int32_t*)WS(13, n_ent * 4), *d_pqpos = (int32_t*)WS(14, n_ent * 4), *d_pindel = (int32_t*)WS(15, n_ent * 4);
     char *d_ref = (char*)WS(24, (size_t)(ref_hi - ref_lo));
-    GapSite *d_sites = (GapSite*)WS(25, (size_t)ns * sizeof(GapSite));
-    uint32_t *d_rinfo = (uint32_t*)WS(26, (size_t)nr * 4);
     uint32_t *d_aux = (uint32_t*)WS(27, n_ent * 4);
-    // small outputs share one block: ret, types[4], maxins, indelreg, max_support, max_frac per site, then the totals
-    const size_t so_ret = 0, so_types = (size_t)ns * 4, so_maxins = so_types + (size_t)ns * 16, so_ireg = so_maxins + (size_t)ns * 4,
-                 so_msup = so_ireg + (size_t)ns * 4, so_mfrac = so_msup + (size_t)ns * 4, so_tot = (so_mfrac + (size_t)ns * 4 + 15) & ~(size_t)15,
-                 so_bytes = so_tot + sizeof(GapTotals);
-    uint8_t *d_small = (uint8_t*)WS(28, so_bytes);
-    uint8_t *h_small = (uint8_t*)bcfgpu_internal_pinned(ctx, 0, so_bytes);
     if (!d_rpos || !d_rlq || !d_rflag || !d_rncig || !d_rcoff || !d_rsoff || !d_cig || !d_seq || !d_qual || (any_zq && (!d_zq || !d_haszq)) ||
-        !d_pos || !d_soff || !d_pread || !d_pqpos || !d_pindel || !d_ref || !d_sites || !d_rinfo || !d_aux || !d_small || !h_small)
+        !d_pos || !d_soff || !d_pread || !d_pqpos || !d_pindel || !d_ref || !d_aux)
         return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
     #define UP(dst, src, bytes) GP_CHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st))
     UP(d_rpos, rd->r_pos, (size_t)nr * 4); UP(d_rlq, rd->r_lq, (size_t)nr * 4); UP(d_rflag, rd->r_flag, (size_t)nr * 4);
@@ -526,98 +663,17 @@ extern "C" int bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bc
     g.ref = d_ref; g.ref_lo = ref_lo; g.ref_hi = ref_hi;
     g.openQ = in->openQ; g.extQ = in->extQ; g.tandemQ = in->tandemQ; g.min_support = in->min_support; g.per_sample_flt = in->per_sample_flt;
     g.min_frac = in->min_frac;
-    int32_t *o_ret = (int32_t*)(d_small + so_ret), *o_types = (int32_t*)(d_small + so_types), *o_maxins = (int32_t*)(d_small + so_maxins);
-    int32_t *o_ireg = (int32_t*)(d_small + so_ireg), *o_msup = (int32_t*)(d_small + so_msup);
-    float *o_mfrac = (float*)(d_small + so_mfrac);
-    GapTotals *d_tot = (GapTotals*)(d_small + so_tot);
-    GP_CHK(hipMemsetAsync(d_small, 0, so_bytes, st));
-    if (n_ent) GP_CHK(hipMemsetAsync(d_aux, 0, n_ent * 4, st));
-
-    // ---- typing ----
-    if (nr) hipLaunchKernelGGL(gap_read_info_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, g, d_rinfo);
-    hipLaunchKernelGGL(gap_type_kernel, dim3(ns), dim3(256), 0, st, g, d_sites, d_rinfo, o_ret, o_types, o_msup, o_mfrac);
-    hipLaunchKernelGGL(gap_scan_kernel, dim3(1), dim3(1), 0, st, d_sites, ns, n, d_tot);
-    GapTotals tot{};
-    GP_CHK(hipMemcpyAsync(h_small, d_tot, sizeof(GapTotals), hipMemcpyDeviceToHost, st));
-    GP_CHK(hipStreamSynchronize(st));                           // sizes of the next stage's buffers
-    memcpy(&tot, h_small, sizeof tot);
     gs.prepare_ms = ms_since(t_begin);
-    if (tot.n_jobs >> 31 || tot.ref2_bytes >> 32)
-        return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_gap_prep: batch too large (pool offsets are 32-bit), use fewer sites per call");
-    gs.n_jobs = tot.n_jobs;
-    int8_t *d_oinscns = nullptr;
-    if (tot.n_live) {
-        const size_t nj = (size_t)tot.n_jobs;
-        int32_t *d_inscnt = (int32_t*)WS(16, (size_t)tot.ins_bytes * 5 * 4);
-        int8_t *d_inscns = (int8_t*)WS(17, (size_t)tot.ins_bytes);
-        uint8_t *d_ref2 = (uint8_t*)WS(18, (size_t)tot.ref2_bytes + 16);
-        int32_t *d_s1 = (int32_t*)WS(19, nj * 4), *d_s2 = (int32_t*)WS(20, nj * 4);
-        uint32_t *d_wide = (uint32_t*)WS(21, nj * 4);
-        GapEntry *d_ent = (GapEntry*)WS(29, n_ent * sizeof(GapEntry));
-        if (out->inscns) d_oinscns = (int8_t*)WS(22, (size_t)ns * 4 * inscns_cap);
-        if (!d_inscnt || !d_inscns || !d_ref2 || !d_s1 || !d_s2 || !d_wide || !d_ent || (out->inscns && !d_oinscns))
-            return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
-        if (tot.ins_bytes) { GP_CHK(hipMemsetAsync(d_inscnt, 0, (size_t)tot.ins_bytes * 5 * 4, st)); GP_CHK(hipMemsetAsync(d_inscns, 0, (size_t)tot.ins_bytes, st)); }
-        GP_CHK(hipMemsetAsync(d_s1, 0, nj * 4, st)); GP_CHK(hipMemsetAsync(d_s2, 0, nj * 4, st));
-        if (d_oinscns) GP_CHK(hipMemsetAsync(d_oinscns, 0, (size_t)ns * 4 * inscns_cap, st));
-        hipLaunchKernelGGL(gap_inscns_kernel, dim3(ns), dim3(256), 0, st, g, d_sites, d_inscnt, d_inscns);
-        hipLaunchKernelGGL(gap_cons_kernel, dim3((unsigned)((size_t)ns * n)), dim3(64), (size_t)tot.max_L * 4 + 16, st, g, d_sites, d_inscns, d_ref2);
-        // ---- realignment: register-resident bands first; the jobs with wider bands are listed and run from scratch rows ----
-        launch_gap_entries(g, d_sites, (int)n_ent, d_ent, st);
-        ProbalnParams p{};
-        p.ent = d_ent;
-        p.gin = g; p.sites = d_sites; p.n_sites = ns; p.n_jobs = (int)nj;
-        p.ref2 = d_ref2; p.q2p = q2p; p.score1 = d_s1; p.score2 = d_s2;
-        p.wide = d_wide; p.tot = d_tot;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        hipEventCreate(&e0); hipEventCreate(&e1);
-        hipEventRecord(e0, st);
-        launch_probaln(p, st, false);
-        GP_CHK(hipMemcpyAsync(h_small, d_tot, sizeof(GapTotals), hipMemcpyDeviceToHost, st));
-        GP_CHK(hipStreamSynchronize(st));                       // how many jobs need the wide-band version, and how wide
-        memcpy(&tot, h_small, sizeof tot);
-        if (tot.n_wide) {
-            p.ncell = 3 * (2 * tot.max_eff + 1) + 6;
-            size_t chunk = ((size_t)1 << 30) / (2 * (size_t)p.ncell * sizeof(double));
-            chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
-            if (chunk > tot.n_wide) chunk = ((size_t)tot.n_wide + 63) & ~(size_t)63;
-            p.scratch_stride = chunk;
-            p.scratch = (double*)WS(23, 2 * (size_t)p.ncell * chunk * sizeof(double));
-            if (!p.scratch) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
-            for (size_t j0 = 0; j0 < tot.n_wide; j0 += chunk) {
-                p.wide_first = (uint32_t)j0;
-                p.wide_count = (int)(tot.n_wide - j0 < chunk ? tot.n_wide - j0 : chunk);
-                launch_probaln(p, st, true);
-            }
-        }
-        hipEventRecord(e1, st);
-        hipLaunchKernelGGL(gap_finalize_kernel, dim3(ns), dim3(256), 0, st, g, d_sites, d_s1, d_s2, d_inscns, d_aux, o_ret, o_types,
-                           d_oinscns, inscns_cap, o_maxins, o_ireg);
-        GP_CHK(hipGetLastError());
-        GP_CHK(hipMemcpyAsync(h_small, d_small, so_bytes, hipMemcpyDeviceToHost, st));
-        if (n_ent) GP_CHK(hipMemcpyAsync(out->p_aux, d_aux, n_ent * 4, hipMemcpyDeviceToHost, st));
-        if (out->inscns) GP_CHK(hipMemcpyAsync(out->inscns, d_oinscns, (size_t)ns * 4 * inscns_cap, hipMemcpyDeviceToHost, st));
+    const int rc = bcfgpu_internal_gap_core(ctx, g, n_ent, d_aux, out, inscns_cap);
+    if (rc) return rc;
+    const auto t_dl = std::chrono::steady_clock::now();
+    if (n_ent) {
+        GP_CHK(hipMemcpyAsync(out->p_aux, d_aux, n_ent * 4, hipMemcpyDeviceToHost, st));
         GP_CHK(hipStreamSynchronize(st));
-        hipEventElapsedTime(&gs.kernel_ms, e0, e1);
-        hipEventDestroy(e0); hipEventDestroy(e1);
-        memcpy(&tot, h_small + so_tot, sizeof tot);
-        gs.n_passes = tot.n_passes; gs.dp_cells = tot.dp_cells;
-    } else {
-        GP_CHK(hipMemcpyAsync(h_small, d_small, so_bytes, hipMemcpyDeviceToHost, st));
-        GP_CHK(hipStreamSynchronize(st));
-        if (n_ent) memset(out->p_aux, 0, n_ent * 4);
-        if (out->inscns) memset(out->inscns, 0, (size_t)ns * 4 * inscns_cap);
     }
-    const auto t_fin = std::chrono::steady_clock::now();
-    memcpy(out->ret, h_small + so_ret, (size_t)ns * 4);
-    memcpy(out->indel_types, h_small + so_types, (size_t)ns * 16);
-    if (out->maxins) memcpy(out->maxins, h_small + so_maxins, (size_t)ns * 4);
-    if (out->indelreg) memcpy(out->indelreg, h_small + so_ireg, (size_t)ns * 4);
-    if (out->max_support) memcpy(out->max_support, h_small + so_msup, (size_t)ns * 4);
-    if (out->max_frac) memcpy(out->max_frac, h_small + so_mfrac, (size_t)ns * 4);
-    gs.finalize_ms = ms_since(t_fin);
+    gs.finalize_ms += ms_since(t_dl);
     gs.total_ms = ms_since(t_begin);
-    #undef GP_CHK
-    #undef WS
     return BCFGPU_OK;
 }
+#undef GP_CHK
+#undef WS

@@ -108,117 +108,134 @@ __device__ int probaln_fwd(const uint8_t *ref, int l_ref, const QSrc qs, int l_q
     return (int)(Pr1 + .499);
 }
 
-// The same forward pass with the scaled row held in registers, for bands of half-width <= BWM (|indel| <= BWM-3: the
-// common case).  A row has 2*bw+1 live cells x 3 states; position p of the register row is reference column
-// k = p + x - 1 with x = max(0, i - bw), exactly the slot set_u() assigns in the rolling-row version, so row i is
-// computed in place from row i-1: while the band hugs the left edge (i <= bw) the diagonal neighbour of p is p-1,
-// afterwards the band slides by one column per row and it is p itself.  The reference window travels in one 64-bit
-// register (3 bits per base, shifted as the band slides).  No scratch memory: the rolling-row version moves
-// 48 bytes per cell through HBM and is bandwidth-bound; this one is bound by fp64 issue.
-template <int BWM>
-__device__ int probaln_fwd_reg(const uint8_t *ref, int l_ref, const QSrc qs, int l_query,
-                               const float *q2p, double d, double e_, int bw)
+// ---- the register-resident forward pass: one lane per job, the band exactly as wide as the template ----------------
+// A row of the band has W = 2*BW+1 cells x 3 states, kept in registers in an ALWAYS-SLIDING layout: position p (1..W) of
+// row i is reference column k = p + i - bw - 1, so the diagonal neighbour of p is the old p and the upper one the old
+// p+1 from the first row on (htslib's set_u() layout pins the band to column 0 for the first bw rows; the layout is
+// storage only, the cells and the order of every sum are the reference's).  Cells under the band's lower edge (k < 1)
+// are zero by construction -- their three neighbours are -- so only the upper edge (k > l_ref, or p > 2*bw+1 for a job
+// whose band is narrower than the template's) needs masks.  Two row bodies, each straight-line code:
+//   * fast rows: the band inside the reference for EVERY job of the wavefront, no N under it: 18 fp64 operations per
+//     cell (EI = 1/4 is folded into the two I-state coefficients: scaling by a power of two commutes with rounding) and
+//     4 integer ones for the emission (match / mismatch value of this query base, chosen by comparing 3-bit codes);
+//   * edge rows: the same with the emission zeroed and the D state masked past the upper edge, N handled.
+// The wavefront runs fast rows while all its jobs qualify (a wave-uniform branch: with a divergent one the register
+// allocator keeps both variants' operands apart and the kernel needs twice the registers), then edge rows to the end.
+// The jobs of a launch are sorted by (band, query length, l_ref - l_query), so the jobs of a wavefront leave the fast
+// rows within a row or two of one another and finish together.  The query travels as one byte per base
+// (code | quality << 3, written once per pileup entry by gap_qpack_kernel, eight rows per 8-byte load); the emission
+// values 1 - 10^(-q/10) and 10^(-q/10) / 3 of all 256 byte values sit in a 4 KB LDS table (N in the read: both 1).
+template <int BW>
+__device__ __forceinline__ int probaln_fwd_exact(const uint8_t *ref, int l_ref, const uint8_t *qp, int l_query,
+                                                 const double2 *emt, double d, double e_, int bw)
 {
-    constexpr int NP = 2 * BWM + 3;                       // positions 0 .. 2*BWM+2
-    double M[NP], I[NP], D[NP];
+    constexpr int W = 2 * BW + 1;
+    double M[W + 2], I[W + 2], D[W + 2];
     #pragma unroll
-    for (int p = 0; p < NP; ++p) M[p] = I[p] = D[p] = 0.;
-    const int bw2 = bw * 2 + 1;
-    double m[9];
+    for (int p = 0; p < W + 2; ++p) M[p] = I[p] = D[p] = 0.;
     const double sM = 1. / (2 * l_query + 2), sI = sM;
-    m[0] = (1 - d - d) * (1 - sM); m[1] = m[2] = d * (1 - sM);
-    m[3] = (1 - e_) * (1 - sI); m[4] = e_ * (1 - sI); m[5] = 0.;
-    m[6] = 1 - e_; m[7] = 0.; m[8] = e_;
+    const double m0 = (1 - d - d) * (1 - sM), m1 = d * (1 - sM), m2 = m1;
+    const double m3 = (1 - e_) * (1 - sI), m4 = e_ * (1 - sI);
+    const double m6 = 1 - e_, m8 = e_;
+    const double m1q = EI * m1, m4q = EI * m4;
     const double bM = (1 - d) / l_ref, bI = d / l_ref;
-    // reference window: base of position p (column k = p + x - 1) in bits [3p, 3p+3); x = 0 to begin with
+    const int top = 2 * bw + 1;
+    // reference window: the base of position p in bits [3(p-1), 3p); row 1: k = p - bw
     uint64_t rw = 0;
     #pragma unroll
-    for (int p = 2; p < NP; ++p) rw |= (uint64_t)(p - 2 < l_ref ? ref[p - 2] : 4) << (3 * p);
+    for (int p = 1; p <= W; ++p) { const int k = p - bw; rw |= (uint64_t)((k >= 1 && k <= l_ref) ? ref[k - 1] : 0) << (3 * (p - 1)); }
     double prod = 1., Pr1 = 0.;
-    // f[1]
-    {
+    int result = 0;
+    uint64_t qw = *(const uint64_t*)qp;
+    auto finish = [&]() {             // f[l_query+1] over the cells of the last row (dead ones are zero), then the score
+        double fsum = 0.;
+        #pragma unroll
+        for (int p = 1; p <= W; ++p) fsum += M[p] * sM + I[p] * sI;
+        prod *= fsum;
+        if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
+        Pr1 += -4.343 * log(prod * l_ref * l_query);
+        result = (int)(Pr1 + .499);
+    };
+    {   // f[1]
         double sum = 0.;
         const int end = l_ref < bw + 1 ? l_ref : bw + 1;
-        const double q0 = (double)q2p[qs.q(0)];
-        const int qy = qs.base(0);
+        const int qb = (int)(qw & 0xff);
+        const double2 em = emt[qb];
+        const int qy = qb & 7;
         #pragma unroll
-        for (int p = 2; p < NP; ++p) {
-            if (p - 1 <= end) {
-                const int rb = (int)((rw >> (3 * p)) & 7);
-                const double e = (rb > 3 || qy > 3) ? 1. : rb == qy ? 1. - q0 : q0 * EM;
-                const double a = e * bM, b = EI * bI;
-                M[p] = a; I[p] = b;
-                sum += a + b;
-            }
+        for (int p = 1; p <= W; ++p) {
+            const double lv = (p > bw && p <= bw + end) ? 1. : 0.;
+            const int rb = (int)((rw >> (3 * (p - 1))) & 7);
+            const double e = rb > 3 ? 1. : rb == qy ? em.x : em.y;
+            const double a = lv * (e * bM), b = lv * (EI * bI);
+            M[p] = a; I[p] = b;
+            sum += a + b;
         }
         #pragma unroll
-        for (int p = 2; p < NP; ++p)
-            if (p - 1 <= end) { M[p] /= sum; I[p] /= sum; D[p] /= sum; }
+        for (int p = 1; p <= W; ++p) { M[p] /= sum; I[p] /= sum; }
         prod *= sum;
         if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
+        if (l_query == 1) finish();
     }
-    int x = 0;                                            // first column of the band minus one: max(0, i - bw)
-    // one row; `slide`: x grows by one on this row (i > bw).  Two instantiations: the rows before and after the band leaves
-    // the left edge differ in which old cells are the diagonal and the upper neighbour, and a run-time choice costs ten
-    // selects per position
-    auto row = [&](auto slide_c, int i) {
-        constexpr bool slide = decltype(slide_c)::value;
-        const double qli = (double)q2p[qs.q(i - 1)];
-        const int qyi = qs.base(i - 1);
-        if (slide) {
-            ++x;
-            rw >>= 3;
-            const int nk = (NP - 1) + x - 2;              // reference index of the new top position
-            rw |= (uint64_t)(nk < l_ref ? ref[nk] : 4) << (3 * (NP - 1));
-        }
-        const int end = l_ref < i + bw ? l_ref : i + bw;
-        const int plo = x == 0 ? 2 : 1, phi = end - x + 1;
+    int i = 2;
+    for (;; ++i) {                    // fast rows (the last row of a job is always an edge row: it ends with finish())
+        const int kt = i - bw - 1 + W;                    // column of position W
+        const bool fast = i < l_query && bw == BW && kt <= l_ref;
+        if (__builtin_amdgcn_ballot_w64(!fast) != 0) break;
+        const uint64_t nw = (rw >> 3) | ((uint64_t)ref[kt - 1] << (3 * (W - 1)));
+        if (__builtin_amdgcn_ballot_w64((nw & 0x4924924924924924ull) != 0) != 0) break;
+        rw = nw;
+        if (((i - 1) & 7) == 0) qw = *(const uint64_t*)(qp + (i - 1)); else qw >>= 8;
+        const int qb = (int)(qw & 0xff);
+        const double2 em = emt[qb];
+        const int qyi = qb & 7;
         double sum = 0.;
-        // in place, ascending p: the left neighbour is the new [p-1]; the diagonal one is the old [p] once the band
-        // slides, the old [p-1] (carried) before; the upper one is the old [p+1] resp. the old [p]
-        double cM = M[0], cI = I[0], cD = D[0];           // old [p-1]
-        M[0] = I[0] = D[0] = 0.;
         #pragma unroll
-        for (int p = 1; p < NP; ++p) {
-            const double oM = M[p], oI = I[p], oD = D[p];
-            const double nM = p + 1 < NP ? M[p + 1 < NP ? p + 1 : p] : 0., nI = p + 1 < NP ? I[p + 1 < NP ? p + 1 : p] : 0.;
-            double f0 = 0., f1 = 0., f2 = 0.;
-            if (p >= plo && p <= phi) {
-                const int rb = (int)((rw >> (3 * p)) & 7);
-                const double e = (rb > 3 || qyi > 3) ? 1. : rb == qyi ? 1. - qli : qli * EM;
-                const double gM = slide ? oM : cM, gI = slide ? oI : cI, gD = slide ? oD : cD;
-                const double uM = slide ? nM : oM, uI = slide ? nI : oI;
-                f0 = e * (m[0] * gM + m[3] * gI + m[6] * gD);
-                f1 = EI * (m[1] * uM + m[4] * uI);
-                f2 = m[2] * M[p - 1] + m[8] * D[p - 1];
-                sum += f0 + f1 + f2;
-            }
+        for (int p = 1; p <= W; ++p) {
+            const int rb = (int)((rw >> (3 * (p - 1))) & 7);
+            const double e = rb == qyi ? em.x : em.y;
+            const double f0 = e * (m0 * M[p] + m3 * I[p] + m6 * D[p]);
+            const double f1 = p < W ? m1q * M[p + 1] + m4q * I[p + 1] : 0.;
+            const double f2 = p > 1 ? m2 * M[p - 1] + m8 * D[p - 1] : 0.;
+            sum += f0 + f1 + f2;
             M[p] = f0; I[p] = f1; D[p] = f2;
-            cM = oM; cI = oI; cD = oD;
         }
         const double r = 1. / sum;
         #pragma unroll
-        for (int p = 1; p < NP; ++p) { M[p] *= r; I[p] *= r; D[p] *= r; }
+        for (int p = 1; p <= W; ++p) { M[p] *= r; I[p] *= r; D[p] *= r; }
         prod *= sum;
         if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
-    };
-    {
-        int i = 2;
-        for (; i <= l_query && i <= bw; ++i) row(std::false_type{}, i);
-        for (; i <= l_query; ++i) row(std::true_type{}, i);
     }
-    {   // f[l_query+1]: columns k = 1..l_ref whose slot lies inside the band of the last row
+    for (; i <= l_query; ++i) {       // edge rows
+        qw = *(const uint64_t*)(qp + ((i - 1) & ~7)) >> (8 * ((i - 1) & 7));
+        const int qb = (int)(qw & 0xff);
+        const double2 em = emt[qb];
+        const int qyi = qb & 7;
+        const int kt = i - bw - 1 + W;
+        rw = (rw >> 3) | ((uint64_t)(kt <= l_ref ? ref[kt - 1] : 0) << (3 * (W - 1)));
+        const int hi = l_ref - (i - bw) + 1 < top ? l_ref - (i - bw) + 1 : top;
         double sum = 0.;
-        const int phi = l_ref - x + 1 < bw2 ? l_ref - x + 1 : bw2;
-        const int plo = x == 0 ? 2 : 1;
         #pragma unroll
-        for (int p = 1; p < NP; ++p)
-            if (p >= plo && p <= phi) sum += M[p] * sM + I[p] * sI;
+        for (int p = 1; p <= W; ++p) {
+            const bool live = p <= hi;
+            const int rb = (int)((rw >> (3 * (p - 1))) & 7);
+            double e = rb > 3 ? 1. : rb == qyi ? em.x : em.y;
+            e = live ? e : 0.;
+            const double tv = live ? 1. : 0.;
+            const double f0 = e * (m0 * M[p] + m3 * I[p] + m6 * D[p]);
+            const double f1 = m1q * M[p + 1] + m4q * I[p + 1];
+            const double f2 = tv * (m2 * M[p - 1] + m8 * D[p - 1]);
+            sum += f0 + f1 + f2;
+            M[p] = f0; I[p] = f1; D[p] = f2;
+        }
+        const double r = 1. / sum;
+        #pragma unroll
+        for (int p = 1; p <= W; ++p) { M[p] *= r; I[p] *= r; D[p] *= r; }
         prod *= sum;
         if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
+        if (i == l_query) finish();
     }
-    Pr1 += -4.343 * log(prod * l_ref * l_query);
-    return (int)(Pr1 + .499);
+    return result;
 }
 
 // tpos2qpos, bam2bcf_indel.c:40-66
@@ -242,11 +259,9 @@ __device__ int gap_tpos2qpos(int cpos, int n_cigar, const uint32_t *cigar, int t
     return last_y;
 }
 
-// One realignment of bam2bcf_indel.c:313-357: read K of the site against candidate type t.  Jobs are numbered
-// job0 + t*N + K inside a site (neighbouring lanes: neighbouring reads of one type, i.e. the same band and window).
 // What a read contributes to every realignment of its site (it does not depend on the candidate type): the part of the
 // read inside the window and where it starts and ends on the reference -- the two tpos2qpos() calls of
-// bam2bcf_indel.c:326-327 -- and the read's sample.  One lane per pileup entry.
+// bam2bcf_indel.c:326-327 -- the read's sample, and where its packed query goes.  One lane per pileup entry.
 __global__ __launch_bounds__(256) void gap_entry_kernel(const GapIn in, const GapSite *sites, int n_ent, GapEntry *ent)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(256) void gap_entry_kernel(const GapIn in, const Ga
     int lo = 0, hi = in.n_sites - 1;                        // the site of entry e: the last one with smpl_off[site*n] <= e
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (in.smpl_off[(size_t)mid * in.n_smpl] <= e) lo = mid; else hi = mid - 1; }
     const GapSite &S = sites[lo];
-    if (!S.live) return;
+    if (!S.live) { GapEntry z{}; z.smpl = -1; ent[e] = z; return; }     // (gap_qpack_kernel looks at every entry)
     const int32_t *soff = in.smpl_off + (size_t)lo * in.n_smpl;
     int a = 0, b = in.n_smpl - 1;                           // the sample of entry e: the last s with soff[s] <= e
     while (a < b) { const int mid = (a + b + 1) >> 1; if (soff[mid] <= e) a = mid; else b = mid - 1; }
@@ -265,20 +280,47 @@ __global__ __launch_bounds__(256) void gap_entry_kernel(const GapIn in, const Ga
     for (int k = 0; k < ncig; ++k) if ((cigar[k] & 0xf) == 3) skip = true;        // reads with a reference skip (:321-323)
     GapEntry g{};
     g.smpl = skip ? -1 : a;
+    g.q8 = S.q8_0 + (uint32_t)(e - S.e0) * (uint32_t)(S.qstride >> 3);
     if (!skip) {
         g.qbeg = gap_tpos2qpos(in.r_pos[r], ncig, cigar, S.left, 0, &g.tbeg);
         g.qend = gap_tpos2qpos(in.r_pos[r], ncig, cigar, S.right, 1, &g.tend);
     }
     ent[e] = g;
 }
-void launch_gap_entries(const GapIn &in, const GapSite *sites, int n_ent, GapEntry *ent, hipStream_t s)
+
+// The query of every entry as the realignment reads it (bam2bcf_indel.c:339-345), one byte per base: code 0..4 |
+// capped quality << 3, the entry's qend - qbeg bytes from ent[e].q8 * 8 on.  A lane per (entry, group of eight bases).
+__global__ __launch_bounds__(256) void gap_qpack_kernel(const GapIn in, const GapEntry *ent, int n_ent, int chunks, uint8_t *qpack)
 {
-    if (n_ent > 0) hipLaunchKernelGGL(gap_entry_kernel, dim3((n_ent + 255) / 256), dim3(256), 0, s, in, sites, n_ent, ent);
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int e = (int)(idx / chunks), c = (int)(idx - (long)e * chunks);
+    if (e >= n_ent) return;
+    const GapEntry g = ent[e];
+    const int lq = g.qend - g.qbeg;
+    if (g.smpl < 0 || c * 8 >= lq) return;
+    const int r = in.p_read[e];
+    const size_t qo = (size_t)in.r_seq_off[r] + g.qbeg + (size_t)c * 8;
+    const QSrc qs{in.seq16 + qo, in.qual + qo, (in.zq && in.r_has_zq && in.r_has_zq[r]) ? in.zq + qo : nullptr};
+    const int nb = lq - c * 8 < 8 ? lq - c * 8 : 8;
+    uint64_t v = 0;
+    for (int k = 0; k < nb; ++k) v |= (uint64_t)(qs.base(k) | qs.q(k) << 3) << (8 * k);
+    *(uint64_t*)(qpack + ((size_t)g.q8 + c) * 8) = v;
+}
+
+void launch_gap_entries(const GapIn &in, const GapSite *sites, int n_ent, GapEntry *ent, int max_qstride, uint8_t *qpack, hipStream_t s)
+{
+    if (n_ent <= 0) return;
+    hipLaunchKernelGGL(gap_entry_kernel, dim3((n_ent + 255) / 256), dim3(256), 0, s, in, sites, n_ent, ent);
+    const int chunks = max_qstride >> 3;
+    if (chunks > 0) {
+        const long lanes = (long)n_ent * chunks;
+        hipLaunchKernelGGL(gap_qpack_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, in, ent, n_ent, chunks, qpack);
+    }
 }
 
 // One realignment of bam2bcf_indel.c:313-357: read K of the site against candidate type t.  Jobs are numbered
-// job0 + t*N + K inside a site (neighbouring lanes: neighbouring reads of one type, i.e. the same band and window).
-struct JobDesc { const uint8_t *ref; int l_ref, l_query, bw, eff; QSrc qs; bool skip; };
+// job0 + t*N + K inside a site.
+struct JobDesc { const uint8_t *ref; int l_ref, l_query, bw, eff; uint32_t ref_off, q8; QSrc qs; bool skip; };
 __device__ __forceinline__ JobDesc decode_job(const ProbalnParams &P, uint32_t job)
 {
     JobDesc d{};
@@ -295,7 +337,8 @@ __device__ __forceinline__ JobDesc decode_job(const ProbalnParams &P, uint32_t j
     const int ty = S.types[t], aty = abs(ty);
     int tbeg = g.tbeg;
     if (ty < 0) tbeg = tbeg - aty > S.left ? tbeg - aty : S.left;
-    d.ref = P.ref2 + (size_t)S.ref2_0 + ((size_t)t * in.n_smpl + g.smpl) * S.max_ref2 + (tbeg - S.left);
+    d.ref_off = S.ref2_0 + (uint32_t)(((size_t)t * in.n_smpl + g.smpl) * S.max_ref2 + (tbeg - S.left));
+    d.ref = P.ref2 + d.ref_off;
     d.l_ref = g.tend - tbeg + aty;
     d.l_query = g.qend - g.qbeg;
     d.bw = aty + 3;
@@ -304,67 +347,169 @@ __device__ __forceinline__ JobDesc decode_job(const ProbalnParams &P, uint32_t j
     if (eff > d.bw) eff = d.bw;
     if (eff < abs(d.l_ref - d.l_query)) eff = abs(d.l_ref - d.l_query);
     d.eff = eff;
+    d.q8 = g.q8;
     const size_t qo = (size_t)in.r_seq_off[r] + g.qbeg;
     d.qs = QSrc{in.seq16 + qo, in.qual + qo, (in.zq && in.r_has_zq && in.r_has_zq[r]) ? in.zq + qo : nullptr};
     return d;
 }
 
-#define PROBALN_BWM 6
-// WIDE = false: every job; bands up to PROBALN_BWM run here with the row in registers, the others are listed.
-// WIDE = true: the listed jobs, two rolling rows per job in the scratch buffer.
-template <bool WIDE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void probaln_kernel(const ProbalnParams P)
+// ---- the jobs, decoded once: a 16-byte record and a sort key per job ----
+// key = band class << 13 | min(l_query, 255) << 5 | clamp(l_ref - l_query + 16, 0, 31); classes PROBALN_BW_MIN..PROBALN_BW_MAX
+// run in probaln_exact_kernel<class> (bands narrower than PROBALN_BW_MIN in its kernel), wider bands are listed for
+// probaln_wide_kernel, jobs without a realignment (skipped reads, an empty side: score 0, the arrays are zeroed) sort last.
+__global__ __launch_bounds__(256) void probaln_jobs_kernel(const ProbalnParams P)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    uint32_t job = 0;
-    bool have;
-    if (WIDE) { have = i < P.wide_count; if (have) job = P.wide[P.wide_first + i]; }
-    else { have = i < P.n_jobs; job = (uint32_t)i; }
-    unsigned long long passes = 0, cells = 0;
-    if (have) {
-        const JobDesc j = decode_job(P, job);
-        bool run = !j.skip;
-        const bool degenerate = j.l_ref <= 0 || j.l_query <= 0;           // probaln_glocal has nothing to align: score 0
-        if (!WIDE && run && !degenerate && (j.eff > PROBALN_BWM || P.force_scratch)) {
+    const uint32_t job = blockIdx.x * 256u + threadIdx.x;
+    if (job >= (uint32_t)P.n_jobs) return;
+    const JobDesc j = decode_job(P, job);
+    uint32_t cls = PROBALN_CLS_NONE;
+    PJob pj{};
+    if (!j.skip && j.l_ref > 0 && j.l_query > 0) {
+        if (j.eff > PROBALN_BW_MAX || j.l_ref > 65535 || j.l_query > 65535 || P.force_wide) {
             P.wide[atomicAdd(&P.tot->n_wide, 1u)] = job;
             atomicMax(&P.tot->max_eff, j.eff);
-            run = false;
-        }
-        if (run) {
-            const size_t stride = P.scratch_stride;
-            double *row0 = WIDE ? P.scratch + i : nullptr, *row1 = WIDE ? P.scratch + (size_t)P.ncell * stride + i : nullptr;
-            // apf1 = {1e-4, 1e-2, bw}; a second parameter set apf2 = {1e-6, 1e-3, bw} is tried when the first score exceeds 5
-            // (bam2bcf_indel.c:293-294, 346-356)
-            int s1 = 0, s2 = 0;
-            double gd = 1e-4, ge = 1e-2;
-            #pragma unroll 1
-            for (int pass = 0; pass < 2; ++pass) {
-                int sc;
-                if (degenerate) sc = 0;
-                else if (WIDE) sc = probaln_fwd(j.ref, j.l_ref, j.qs, j.l_query, P.q2p, gd, ge, j.bw, row0, row1, stride, P.ncell);
-                else sc = probaln_fwd_reg<PROBALN_BWM>(j.ref, j.l_ref, j.qs, j.l_query, P.q2p, gd, ge, j.eff);
-                int l = (int)(100. * sc / j.l_query + .499);
-                if (l > 255) l = 255;
-                const int v = sc << 8 | l;
-                ++passes;
-                if (pass == 0) { s1 = s2 = v; if (sc <= 5) break; gd = 1e-6; ge = 1e-3; }
-                else s2 = v;
-            }
-            P.score1[job] = s1;
-            P.score2[job] = s2;
-            if (!degenerate) cells = (unsigned long long)j.l_query * (2 * j.eff + 1) * 3 * passes;
+            cls = PROBALN_CLS_WIDE;
+        } else {
+            cls = j.eff < PROBALN_BW_MIN ? PROBALN_BW_MIN : j.eff;
+            pj.ref_off = j.ref_off; pj.q8 = j.q8; pj.l_ref = (uint16_t)j.l_ref; pj.l_query = (uint16_t)j.l_query; pj.eff = (uint16_t)j.eff;
         }
     }
-    // statistics: one atomic per wavefront
+    int dl = j.l_ref - j.l_query + 16;
+    dl = dl < 0 ? 0 : dl > 31 ? 31 : dl;
+    P.pjob[job] = pj;
+    P.key_in[job] = cls << 13 | (uint32_t)(j.l_query > 255 ? 255 : j.l_query < 0 ? 0 : j.l_query) << 5 | (uint32_t)dl;
+    P.val_in[job] = job;
+}
+
+// first sorted slot of every class: cls_begin[c] = number of keys with class < c, c = 0..16
+__global__ void probaln_bounds_kernel(const uint32_t *key_sorted, int n, ProbalnQueue *q)
+{
+    const int c = threadIdx.x;
+    if (c > 16) return;
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((key_sorted[mid] >> 13) >= (uint32_t)c) hi = mid; else lo = mid + 1; }
+    q->cls_begin[c] = (uint32_t)lo;
+    if (c < 16) { q->next1[c] = 0; q->next2[c] = 0; q->n2[c] = 0; }
+}
+
+// PASS 1: the jobs of class BW in sorted order, parameter set {1e-4, 1e-2}; jobs scoring above 5 are listed for
+// PASS 2 (the second parameter set {1e-6, 1e-3}, bam2bcf_indel.c:293-294, 346-356).  One wavefront per workgroup; the
+// grid is sized for the machine, not for the class: a wavefront takes the next 64 jobs of its class from a counter
+// until none are left (every wavefront reaches that test, also when the class is empty).
+template <int BW, int PASS>
+__global__ __launch_bounds__(64) void probaln_exact_kernel(const ProbalnParams P)
+{
+    __shared__ double2 s_emt[256];
+    ProbalnQueue *Q = P.queue;
+    const uint32_t c0 = Q->cls_begin[BW];
+    const uint32_t n = PASS == 1 ? Q->cls_begin[BW + 1] - c0 : Q->n2[BW];
+    if (n == 0) return;                                   // (the same for every wavefront of the launch)
+    for (int b = threadIdx.x; b < 256; b += 64) {
+        const double ql = (double)P.q2p[b >> 3];
+        s_emt[b] = (b & 7) > 3 ? make_double2(1., 1.) : make_double2(1. - ql, ql * EM);
+    }
+    __syncthreads();
+    unsigned long long cells = 0, passes = 0;
+    const double gd = PASS == 1 ? 1e-4 : 1e-6, ge = PASS == 1 ? 1e-2 : 1e-3;
+    for (;;) {
+        uint32_t base = 0;
+        if (threadIdx.x == 0) base = atomicAdd(PASS == 1 ? &Q->next1[BW] : &Q->next2[BW], 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const uint32_t i = base + threadIdx.x;
+        const bool have = i < n;
+        uint32_t job = 0;
+        int sc = 0;
+        if (have) {
+            job = PASS == 1 ? P.val_sorted[c0 + i] : P.list2[c0 + i];
+            const PJob j = P.pjob[job];
+            sc = probaln_fwd_exact<BW>(P.ref2 + j.ref_off, j.l_ref, P.qpack + (size_t)j.q8 * 8, j.l_query, s_emt, gd, ge, j.eff);
+            int l = (int)(100. * sc / j.l_query + .499);
+            if (l > 255) l = 255;
+            const int v = sc << 8 | l;
+            if (PASS == 1) P.score1[job] = v;
+            P.score2[job] = v;
+            cells += (unsigned long long)j.l_query * (2 * j.eff + 1) * 3;
+            ++passes;
+        }
+        if (PASS == 1) {
+            const bool again = have && sc > 5;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(again);
+            if (m) {
+                uint32_t at = 0;
+                if (threadIdx.x == 0) at = atomicAdd(&Q->n2[BW], (uint32_t)__popcll(m));
+                at = __builtin_amdgcn_readfirstlane(at);
+                if (again) P.list2[c0 + at + __popcll(m & ((1ull << threadIdx.x) - 1))] = job;
+            }
+        }
+    }
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { passes += __shfl_xor(passes, o); cells += __shfl_xor(cells, o); }
     if (threadIdx.x == 0 && passes) { atomicAdd(&P.tot->n_passes, passes); atomicAdd(&P.tot->dp_cells, cells); }
 }
 
-void launch_probaln(const ProbalnParams &p, hipStream_t s, bool wide_pass)
+// The listed jobs with bands wider than PROBALN_BW_MAX: two rolling rows per job in the scratch buffer, both parameter sets.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void probaln_wide_kernel(const ProbalnParams P)
 {
-    if (wide_pass) { if (p.wide_count > 0) hipLaunchKernelGGL(probaln_kernel<true>, dim3((p.wide_count + 63) / 64), dim3(64), 0, s, p); }
-    else if (p.n_jobs > 0) hipLaunchKernelGGL(probaln_kernel<false>, dim3((p.n_jobs + 63) / 64), dim3(64), 0, s, p);
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    unsigned long long passes = 0, cells = 0;
+    if (i < P.wide_count) {
+        const uint32_t job = P.wide[P.wide_first + i];
+        const JobDesc j = decode_job(P, job);
+        const size_t stride = P.scratch_stride;
+        double *row0 = P.scratch + i, *row1 = P.scratch + (size_t)P.ncell * stride + i;
+        int s1 = 0, s2 = 0;
+        double gd = 1e-4, ge = 1e-2;
+        #pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const int sc = probaln_fwd(j.ref, j.l_ref, j.qs, j.l_query, P.q2p, gd, ge, j.bw, row0, row1, stride, P.ncell);
+            int l = (int)(100. * sc / j.l_query + .499);
+            if (l > 255) l = 255;
+            const int v = sc << 8 | l;
+            ++passes;
+            if (pass == 0) { s1 = s2 = v; if (sc <= 5) break; gd = 1e-6; ge = 1e-3; }
+            else s2 = v;
+        }
+        P.score1[job] = s1;
+        P.score2[job] = s2;
+        cells = (unsigned long long)j.l_query * (2 * j.eff + 1) * 3 * passes;
+    }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { passes += __shfl_xor(passes, o); cells += __shfl_xor(cells, o); }
+    if (threadIdx.x == 0 && passes) { atomicAdd(&P.tot->n_passes, passes); atomicAdd(&P.tot->dp_cells, cells); }
+}
+
+void launch_probaln_jobs(const ProbalnParams &p, hipStream_t s)
+{
+    if (p.n_jobs > 0) hipLaunchKernelGGL(probaln_jobs_kernel, dim3((p.n_jobs + 255) / 256), dim3(256), 0, s, p);
+}
+void launch_probaln_bounds(const ProbalnParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(probaln_bounds_kernel, dim3(1), dim3(64), 0, s, p.key_sorted, p.n_jobs, p.queue);
+}
+template <int BW> static void launch_exact_class(const ProbalnParams &p, hipStream_t s, int pass, unsigned grid)
+{
+    if (pass == 1) hipLaunchKernelGGL((probaln_exact_kernel<BW, 1>), dim3(grid), dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((probaln_exact_kernel<BW, 2>), dim3(grid), dim3(64), 0, s, p);
+}
+// both passes of every class with a band up to max_bw_hint + slack (a band can exceed |type|+3 only by l_ref - l_query)
+void launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu)
+{
+    if (p.n_jobs <= 0) return;
+    // wavefronts the machine holds at the kernels' occupancy (2-3 per SIMD), but no more than the jobs can fill
+    unsigned grid = (unsigned)n_cu * 4u * 3u;
+    const unsigned need = (unsigned)((p.n_jobs + 63) / 64);
+    if (grid > need) grid = need;
+    for (int pass = 1; pass <= 2; ++pass) {
+        launch_exact_class<3>(p, s, pass, grid); launch_exact_class<4>(p, s, pass, grid);
+        launch_exact_class<5>(p, s, pass, grid); launch_exact_class<6>(p, s, pass, grid);
+        launch_exact_class<7>(p, s, pass, grid); launch_exact_class<8>(p, s, pass, grid);
+        launch_exact_class<9>(p, s, pass, grid); launch_exact_class<10>(p, s, pass, grid);
+    }
+}
+void launch_probaln_wide(const ProbalnParams &p, hipStream_t s)
+{
+    if (p.wide_count > 0) hipLaunchKernelGGL(probaln_wide_kernel, dim3((p.wide_count + 63) / 64), dim3(64), 0, s, p);
 }
 
 }  // namespace bcfgpu

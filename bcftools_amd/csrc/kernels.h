@@ -125,16 +125,30 @@ struct GapSite {
     uint32_t job0, job_end;                      // jobs of the site: job0 + t*N + K (type-major); job_end: running total, all sites
     uint32_t ref2_0;                             // ref2 rows of the site: ref2_0 + (t*n_smpl + s)*max_ref2
     uint32_t ins0;                               // insertion consensus of the site: ins0 + t*max_ins
+    uint32_t q8_0; int32_t qstride;              // packed queries of the site's entries: 8-byte unit q8_0 + K*(qstride/8); qstride = max_rd_len rounded up to 8
     int32_t types[64];                           // ascending (bam2bcf_indel.c:145-171); a dropped insertion becomes 0 (:279)
 };
 // per pileup entry: the read's sample (-1: the read is not realigned) and its window coordinates
-struct GapEntry { int32_t smpl, qbeg, qend, tbeg, tend; };
+struct GapEntry { int32_t smpl, qbeg, qend, tbeg, tend; uint32_t q8; };
 struct GapTotals {
     unsigned long long n_jobs, ref2_bytes, ins_bytes;
     unsigned long long n_passes, dp_cells;       // statistics of the realignment (bcfgpu_gap_stats)
-    int32_t max_L, max_bw, n_live, max_ref2;
+    unsigned long long qpack8;                   // 8-byte units of the packed-query pool
+    int32_t max_L, max_bw, n_live, max_ref2, max_qstride, pad_;
     uint32_t n_wide;                             // jobs whose band does not fit the register-resident pass
     int32_t max_eff;                             // their widest band
+};
+// realignment jobs (indel.hip): bands of half-width PROBALN_BW_MIN..PROBALN_BW_MAX run with the row in registers, one kernel
+// instantiation per width (narrower bands in the smallest); wider ones from rolling rows in a scratch buffer
+#define PROBALN_BW_MIN 3
+#define PROBALN_BW_MAX 10
+#define PROBALN_CLS_WIDE 14u
+#define PROBALN_CLS_NONE 15u
+struct PJob { uint32_t ref_off, q8; uint16_t l_ref, l_query, eff, pad; };      // one decoded job: offsets into ref2 / the packed queries (8-byte units)
+struct ProbalnQueue {
+    uint32_t cls_begin[17];                      // first sorted slot of every class (class = key >> 13)
+    uint32_t next1[16], next2[16];               // work counters of the two passes
+    uint32_t n2[16];                             // jobs listed for the second parameter set, per class
 };
 struct ProbalnParams {
     GapIn gin;
@@ -142,17 +156,26 @@ struct ProbalnParams {
     const GapEntry *ent;
     int n_sites, n_jobs;
     const uint8_t *ref2;                         // realignment targets, base codes 0..4
+    const uint8_t *qpack;                        // packed queries (gap_qpack_kernel)
     const float *q2p;                            // 10^(-q/10) as float, q = 0..255 (htslib g_qual2prob)
     int32_t *score1, *score2;                    // sc<<8 | norm, bam2bcf_indel.c:348-356
-    uint32_t *wide; GapTotals *tot;              // out of the first pass: the jobs left for the wide-band pass
-    uint32_t wide_first; int wide_count;         // wide-band pass: jobs wide[wide_first .. +wide_count)
+    PJob *pjob;                                  // [n_jobs]
+    uint32_t *key_in, *val_in;                   // [n_jobs] sort keys and job numbers as probaln_jobs_kernel writes them
+    const uint32_t *key_sorted, *val_sorted;     // after the radix sort
+    uint32_t *list2;                             // [n_jobs] jobs of the second pass, class c from cls_begin[c] on
+    ProbalnQueue *queue;
+    uint32_t *wide; GapTotals *tot;              // the jobs left for the wide-band kernel
+    uint32_t wide_first; int wide_count;         // wide-band launch: jobs wide[wide_first .. +wide_count)
     int ncell;                                   // scratch cells per row (>= 3*(2*bw+1)+6 for the widest band)
     size_t scratch_stride;                       // jobs per chunk; scratch is [2][ncell][stride] doubles
     double *scratch;
-    int force_scratch;                           // diagnostics build only (-DBCFGPU_DIAG): every job through the rolling-row version
+    int force_wide;                              // tests: every job through the rolling-row version
 };
-void launch_probaln(const ProbalnParams &p, hipStream_t s, bool wide_pass);
-void launch_gap_entries(const GapIn &in, const GapSite *sites, int n_ent, GapEntry *ent, hipStream_t s);
+void launch_probaln_jobs(const ProbalnParams &p, hipStream_t s);
+void launch_probaln_bounds(const ProbalnParams &p, hipStream_t s);
+void launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu);
+void launch_probaln_wide(const ProbalnParams &p, hipStream_t s);
+void launch_gap_entries(const GapIn &in, const GapSite *sites, int n_ent, GapEntry *ent, int max_qstride, uint8_t *qpack, hipStream_t s);
 
 size_t glfgen_lds_bytes(int cap, int hist_slots);
 void launch_glfgen(const GlfgenParams &p, hipStream_t s);
