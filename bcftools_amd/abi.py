@@ -148,6 +148,8 @@ PROTOTYPES = {
     "bcfgpu_mpileup": (C.c_int, [C.c_void_p, C.POINTER(Tile), C.POINTER(MplpOut)]),
     "bcfgpu_mcall": (C.c_int, [C.c_void_p, C.POINTER(CallIn), C.POINTER(CallOut)]),
     "bcfgpu_gap_prep": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.POINTER(IndelIn), C.POINTER(IndelOut), C.c_int]),
+    "bcfgpu_gap_prep_tile": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Reads), C.POINTER(IndelIn), C.POINTER(IndelOut), C.c_int,
+                                       C.POINTER(Tile)]),
     "bcfgpu_baq": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.c_char_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcfgpu_overlap_tweak": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcfgpu_pileup_indel_tile": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Tile)]),

@@ -54,6 +54,8 @@ struct bcfgpu_ctx {
     alignas(16) unsigned char pileup_state[256] = {0};   // csrc/pileup.hip: the parameters of the last bcfgpu_pileup
     Ws ws[104];                    // grow-only device workspaces of the host-fed stages (0-15: BAQ / overlaps, 16-35: pileup, 36-39: gVCF / indel tile, 40-103: gap_prep)
     int n_cu = 256;                // compute units of the device (grid size of the work-queue kernels)
+    hipStream_t side[8] = {};      // created on first use: the realignment kernels of different band widths run side by side
+    hipEvent_t side_ev[9] = {};    // [0..7] a side stream's work is done, [8] the fork point on the main stream
     Ws pinned[8];                  // grow-only pinned host staging buffers
 };
 
@@ -173,6 +175,8 @@ void bcfgpu_destroy(bcfgpu_ctx *c)
     for (auto &w : c->pinned) if (w.p) hipHostFree(w.p);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
     for (int i = 0; i < 4; ++i) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 8; ++i) if (c->side[i]) { hipStreamSynchronize(c->side[i]); hipStreamDestroy(c->side[i]); }
+    for (int i = 0; i < 9; ++i) if (c->side_ev[i]) hipEventDestroy(c->side_ev[i]);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -584,6 +588,19 @@ void *bcfgpu_internal_pinned(bcfgpu_ctx *c, int slot, size_t bytes)
 
 // for the stages implemented in their own translation units: bind the device, hand out the stream and shared tables
 int bcfgpu_internal_n_cu(const bcfgpu_ctx *c) { return c ? c->n_cu : 256; }
+
+// side streams (fork / join around independent launches); 0 on success
+int bcfgpu_internal_side(bcfgpu_ctx *c, hipStream_t **streams, hipEvent_t **events)
+{
+    if (!c) return -1;
+    hipSetDevice(c->cfg.device);
+    if (!c->side[0]) {
+        for (int i = 0; i < 8; ++i) if (hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) != hipSuccess) return -1;
+        for (int i = 0; i < 9; ++i) if (hipEventCreateWithFlags(&c->side_ev[i], hipEventDisableTiming) != hipSuccess) return -1;
+    }
+    *streams = c->side; *events = c->side_ev;
+    return 0;
+}
 
 int bcfgpu_internal_device(bcfgpu_ctx *c, hipStream_t *stream, const float **q2p)
 {

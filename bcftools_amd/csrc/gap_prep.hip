@@ -28,8 +28,6 @@
 #include <cmath>
 #include <chrono>
 #include <limits.h>
-#include <vector>
-#include <cstdio>
 #include "kernels.h"
 
 using namespace bcfgpu;
@@ -199,45 +197,109 @@ __global__ __launch_bounds__(256) void gap_type_kernel(const GapIn in, GapSite *
         S.l_run = l_run;
         S.n_types = n_types; S.left = left; S.right = right;
         S.max_ins = tl;                                         // max_ins is at least 0 (:249)
-        S.max_ref2 = right - left + 2 + 2 * (tl > -t0 ? tl : -t0);
+        S.max_ref2 = (right - left + 2 + 2 * (tl > -t0 ? tl : -t0) + 3) & ~3;     // (a multiple of four: gap_cons_kernel stores four codes at a time)
         S.live = 1;
     }
 }
 
-// ---- offsets of each live site's share of the job / ref2 / insertion-consensus pools ----
-__global__ void gap_scan_kernel(GapSite *sites, int n_sites, int n_smpl, GapTotals *tot)
+// ---- offsets of each live site's share of the job / ref2 / insertion-consensus / packed-query pools ----
+// One workgroup: every thread sums a contiguous slice of the sites, the 256 slice totals are scanned in LDS, and each
+// thread goes through its slice again handing out the offsets.
+__global__ __launch_bounds__(256) void gap_scan_kernel(GapSite *sites, int n_sites, int n_smpl, GapTotals *tot)
 {
-    if (threadIdx.x || blockIdx.x) return;
+    __shared__ uint64_t s_sum[4][256];
+    __shared__ int s_max[6][256];
+    const int tid = threadIdx.x;
+    const int per = (n_sites + 255) / 256, i0 = tid * per, i1 = min(n_sites, i0 + per);
     uint64_t jobs = 0, ref2 = 0, ins = 0, q8 = 0;
-    int maxL = 0, max_bw = 0, n_live = 0, max_ref2 = 0, max_qstride = 0;
-    for (int is = 0; is < n_sites; ++is) {
-        GapSite &S = sites[is];
-        S.job_end = (uint32_t)jobs;
+    int maxL = 0, max_bw = 0, n_live = 0, max_ref2 = 0, max_qstride = 0, max_N = 0;
+    for (int is = i0; is < i1; ++is) {
+        const GapSite &S = sites[is];
         if (!S.live) continue;
         ++n_live;
-        S.job0 = (uint32_t)jobs; S.ref2_0 = (uint32_t)ref2; S.ins0 = (uint32_t)ins;
         jobs += (uint64_t)S.N * S.n_types;
-        S.job_end = (uint32_t)jobs;
-        S.qstride = (S.max_rd_len + 7) & ~7;                    // qend - qbeg of an entry never exceeds its read's length
-        S.q8_0 = (uint32_t)q8;
-        q8 += (uint64_t)S.N * (uint32_t)(S.qstride >> 3);
-        max_qstride = max(max_qstride, S.qstride);
         ref2 += (uint64_t)S.n_types * n_smpl * S.max_ref2;
         ins += (uint64_t)S.n_types * (S.max_ins > 0 ? S.max_ins : 0);
+        const int qstride = (S.max_rd_len + 7) & ~7;           // qend - qbeg of an entry never exceeds its read's length
+        q8 += (uint64_t)S.N * (uint32_t)(qstride >> 3);
         maxL = max(maxL, S.right - S.left + 1);
         max_ref2 = max(max_ref2, S.max_ref2);
+        max_qstride = max(max_qstride, qstride);
+        max_N = max(max_N, S.N);
         const int a = abs(S.types[0]), b = abs(S.types[S.n_types - 1]);
         max_bw = max(max_bw, max(a, b) + 3);
     }
-    tot->n_wide = 0; tot->max_eff = 0; tot->n_passes = 0; tot->dp_cells = 0;
-    tot->n_jobs = jobs; tot->ref2_bytes = ref2; tot->ins_bytes = ins; tot->max_L = maxL; tot->max_bw = max_bw; tot->n_live = n_live;
-    tot->max_ref2 = max_ref2; tot->qpack8 = q8; tot->max_qstride = max_qstride;
+    s_sum[0][tid] = jobs; s_sum[1][tid] = ref2; s_sum[2][tid] = ins; s_sum[3][tid] = q8;
+    s_max[0][tid] = maxL; s_max[1][tid] = max_bw; s_max[2][tid] = n_live; s_max[3][tid] = max_ref2; s_max[4][tid] = max_qstride; s_max[5][tid] = max_N;
+    __syncthreads();
+    if (tid < 4) {                                             // exclusive scans of the four running totals
+        uint64_t run = 0;
+        for (int k = 0; k < 256; ++k) { const uint64_t v = s_sum[tid][k]; s_sum[tid][k] = run; run += v; }
+        if (tid == 0) tot->n_jobs = run; else if (tid == 1) tot->ref2_bytes = run; else if (tid == 2) tot->ins_bytes = run; else tot->qpack8 = run;
+    } else if (tid < 10) {
+        const int w = tid - 4;
+        int m = 0;
+        for (int k = 0; k < 256; ++k) m = w == 2 ? m + s_max[w][k] : max(m, s_max[w][k]);
+        if (w == 0) tot->max_L = m; else if (w == 1) tot->max_bw = m; else if (w == 2) tot->n_live = m; else if (w == 3) tot->max_ref2 = m; else if (w == 4) tot->max_qstride = m; else tot->max_N = m;
+    } else if (tid == 10) { tot->n_wide = 0; tot->max_eff = 0; tot->n_passes = 0; tot->dp_cells = 0; }
+    __syncthreads();
+    jobs = s_sum[0][tid]; ref2 = s_sum[1][tid]; ins = s_sum[2][tid]; q8 = s_sum[3][tid];
+    for (int is = i0; is < i1; ++is) {
+        GapSite &S = sites[is];
+        S.job_end = (uint32_t)jobs;
+        if (!S.live) continue;
+        S.job0 = (uint32_t)jobs; S.ref2_0 = (uint32_t)ref2; S.ins0 = (uint32_t)ins;
+        jobs += (uint64_t)S.N * S.n_types;
+        S.job_end = (uint32_t)jobs;
+        ref2 += (uint64_t)S.n_types * n_smpl * S.max_ref2;
+        ins += (uint64_t)S.n_types * (S.max_ins > 0 ? S.max_ins : 0);
+        S.qstride = (S.max_rd_len + 7) & ~7;
+        S.q8_0 = (uint32_t)q8;
+        q8 += (uint64_t)S.N * (uint32_t)(S.qstride >> 3);
+    }
+}
+
+// the site of pileup entry e: the last one with smpl_off[site*n] <= e
+__device__ __forceinline__ int gap_site_of_entry(const GapIn &in, int e)
+{
+    int lo = 0, hi = in.n_sites - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (in.smpl_off[(size_t)mid * in.n_smpl] <= e) lo = mid; else hi = mid - 1; }
+    return lo;
 }
 
 // ---- insertion consensus and est_indelreg ----
 // ins_cnt: [ins_bytes][5] counters (zeroed), inscns: [ins_bytes] (zeroed: the positions after a dropped one stay 0 as in the
 // reference's calloc'ed array)
-__global__ __launch_bounds__(256) void gap_inscns_kernel(const GapIn in, GapSite *sites, int32_t *ins_cnt, int8_t *inscns)
+// the occurrences of each base at each position of each type of insertion (:253-269): a lane per pileup entry, the few
+// entries that carry an insertion add their bases
+__global__ __launch_bounds__(256) void gap_inscnt_kernel(const GapIn in, const GapSite *sites, int n_ent, int32_t *ins_cnt)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_ent) return;
+    const int ind = in.p_indel[e];
+    if (ind <= 0) return;
+    const GapSite &S = sites[gap_site_of_entry(in, e)];
+    if (!S.live || S.max_ins <= 0) return;
+    int t = 0;
+    for (; t < S.n_types; ++t) if (S.types[t] == ind) break;
+    const uint8_t *seq = in.seq16 + in.r_seq_off[in.p_read[e]];
+    const int qpos = in.p_qpos[e];
+    // lanes of a wavefront adding to the same counter (the carriers of one insertion, one after another in the pileup) add once
+    const unsigned lane = threadIdx.x & 63;
+    for (int j = 1; j <= ind; ++j) {
+        const int c = gap_nt16_int(seq[qpos + j] & 15);
+        const unsigned long long key = ((unsigned long long)S.ins0 + (size_t)t * S.max_ins + (j - 1)) * 5 + c;
+        bool done = false;
+        while (!done) {                                        // (lanes leave as their counter is served)
+            const int leader = __builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+            const unsigned long long lk = __shfl(key, leader);
+            const unsigned long long same = __builtin_amdgcn_ballot_w64(key == lk);
+            if (key == lk) { if (lane == (unsigned)leader) atomicAdd(&ins_cnt[lk], (int)__popcll(same)); done = true; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void gap_inscns_kernel(const GapIn in, GapSite *sites, const int32_t *ins_cnt, int8_t *inscns)
 {
     __shared__ int s_ir;
     const int is = blockIdx.x, tid = threadIdx.x;
@@ -246,28 +308,13 @@ __global__ __launch_bounds__(256) void gap_inscns_kernel(const GapIn in, GapSite
     const int n_types = S.n_types, max_ins = S.max_ins, pos = S.pos;
     if (tid == 0) s_ir = 0;
     if (max_ins > 0) {
-        // the occurrences of each base at each position of each type of insertion (:253-269)
-        for (int k = tid; k < S.N; k += 256) {
-            const int e = S.e0 + k, ind = in.p_indel[e];
-            if (ind <= 0) continue;
-            int t = 0;
-            for (; t < n_types; ++t) if (S.types[t] == ind) break;
-            const uint8_t *seq = in.seq16 + in.r_seq_off[in.p_read[e]];
-            const int qpos = in.p_qpos[e];
-            for (int j = 1; j <= ind; ++j) {
-                const int c = gap_nt16_int(seq[qpos + j] & 15);
-                atomicAdd(&ins_cnt[((size_t)S.ins0 + (size_t)t * max_ins + (j - 1)) * 5 + c], 1);
-            }
-        }
-        __threadfence();
-        __syncthreads();
         // majority rule (:271-281); an insertion whose consensus holds an N is dropped: its type becomes 0
-        for (int t = tid; t < n_types; t += 256) {
+        for (int t = tid; t < n_types; t += 64) {
             const int len = S.types[t];
             for (int j = 0; j < len; ++j) {
                 const int32_t *ia = &ins_cnt[((size_t)S.ins0 + (size_t)t * max_ins + j) * 5];
                 int mx = 0, mk = -1;
-                for (int k = 0; k < 5; ++k) { const int v = __hip_atomic_load(&ia[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (v > mx) { mx = v; mk = k; } }
+                for (int k = 0; k < 5; ++k) { const int v = ia[k]; if (v > mx) { mx = v; mk = k; } }
                 inscns[(size_t)S.ins0 + (size_t)t * max_ins + j] = mx ? (int8_t)mk : (int8_t)4;
                 if (mk == 4) { S.types[t] = 0; break; }
             }
@@ -275,7 +322,7 @@ __global__ __launch_bounds__(256) void gap_inscns_kernel(const GapIn in, GapSite
     }
     __syncthreads();
     // est_indelreg of every type (:77-88,296-299), the site's value is the largest
-    for (int t = tid; t < n_types; t += 256) {
+    for (int t = tid; t < n_types; t += 64) {
         const int ty = S.types[t];
         int ir = 0;
         if (ty != 0) {
@@ -298,71 +345,159 @@ __global__ __launch_bounds__(256) void gap_inscns_kernel(const GapIn in, GapSite
 }
 
 // ---- per-sample consensus and the realignment targets ----
-// One wavefront per (site, sample).  cns_mask: [site*n_smpl + s][2] the two masked window positions or -1.
-__global__ __launch_bounds__(64) void gap_cons_kernel(const GapIn in, const GapSite *sites, const int8_t *inscns, uint8_t *ref2pool)
+// One workgroup of two wavefronts per (site, sample), a lane per window column: the lane keeps its column's reference
+// code and its match / mismatch counts in registers while the workgroup goes through the sample's reads together
+// (the CIGAR walk is the same for every lane, the read's bases under the window are consecutive bytes): no atomics, and
+// every lane is busy whatever the sample's depth.
+#define GAP_CONS_THREADS 128
+__global__ __launch_bounds__(GAP_CONS_THREADS) void gap_cons_kernel(const GapIn in, const GapSite *sites, const int8_t *inscns, uint8_t *ref2pool)
 {
-    extern __shared__ uint32_t s_cns[];            // [max_L]
+    extern __shared__ uint32_t s_cns[];            // [max_L] counts, then [max_L] bytes: the sample's consensus codes
     __shared__ int s_m[2];
-    const int is = blockIdx.x / in.n_smpl, s = blockIdx.x % in.n_smpl, lane = threadIdx.x;
+    __shared__ int4 s_rd[GAP_CONS_THREADS];        // a read: reference start, offset of its bases, CIGAR length and offset
+    __shared__ uint32_t s_c0[GAP_CONS_THREADS];    // its first CIGAR operation
+    const int is = blockIdx.x / in.n_smpl, s = blockIdx.x % in.n_smpl, tid = threadIdx.x;
     const GapSite &S = sites[is];
     if (!S.live) return;
     const int left = S.left, right = S.right, W = right - left, pos = S.pos;
     const int32_t *soff = in.smpl_off + (size_t)is * in.n_smpl;
-    for (int i = lane; i < W; i += 64) s_cns[i] = 0;
-    __syncthreads();
-    // ref and non-ref counts of every window column (:203-220): a lane per read walks its CIGAR
-    for (int e = soff[s] + lane; e < soff[s + 1]; e += 64) {
-        const int r = in.p_read[e];
-        const uint32_t *cigar = in.cig + in.r_cig_off[r];
-        const uint8_t *seq = in.seq16 + in.r_seq_off[r];
-        int x = in.r_pos[r], y = 0;
-        for (int k = 0; k < in.r_ncig[r]; ++k) {
-            const int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
+    const int e0 = soff[s], e1 = soff[s + 1];
+    // ref and non-ref counts of every window column (:203-220).  The reads' records come through LDS, GAP_CONS_THREADS reads
+    // at a time, fetched by one lane each (four dependent loads per read that the whole workgroup would otherwise wait out
+    // read after read); reads whose CIGAR is one match operation -- the common case -- go four at a time, their base loads
+    // in flight together.
+    uint32_t cnt0 = 0, cnt1 = 0;                              // this lane's columns tid and tid + GAP_CONS_THREADS
+    const int colA = left + tid, colB = colA + GAP_CONS_THREADS;
+    const bool mineA = tid < W, mineB = tid + GAP_CONS_THREADS < W;
+    const int rcA = mineA ? gap_nt16_of(gap_ref(in, colA)) : -1, rcB = mineB ? gap_nt16_of(gap_ref(in, colB)) : -1;
+    auto general = [&](const int4 rd, uint32_t cg) {
+        const uint8_t *seq = in.seq16 + rd.y;
+        int x = rd.x, y = 0;
+        for (int k = 0; k < rd.z; ++k) {
+            if (k) cg = in.cig[rd.w + k];
+            const int op = cg & 0xf, l = (int)(cg >> 4);
             if (op == 0 || op == 7 || op == 8) {
-                const int j0 = max(0, left - x), j1 = min(l, right - x);
-                for (int j = j0; j < j1; ++j) {
-                    const int rc = gap_nt16_of(gap_ref(in, x + j));
-                    atomicAdd(&s_cns[x + j - left], (int)(seq[y + j] & 15) == rc ? 1u : 0x10000u);
-                }
+                if (mineA && colA >= x && colA < x + l) cnt0 += (int)(seq[y + (colA - x)] & 15) == rcA ? 1u : 0x10000u;
+                if (mineB && colB >= x && colB < x + l) cnt1 += (int)(seq[y + (colB - x)] & 15) == rcB ? 1u : 0x10000u;
                 x += l; y += l;
             } else if (op == 2 || op == 3) x += l;
             else if (op == 1 || op == 4) y += l;
         }
+    };
+    for (int eb = e0; eb < e1; eb += GAP_CONS_THREADS) {
+        const int nb = min(GAP_CONS_THREADS, e1 - eb);
+        __syncthreads();
+        if (tid < nb) {
+            const int r = in.p_read[eb + tid];
+            const int ncig = in.r_ncig[r];
+            s_rd[tid] = make_int4(in.r_pos[r], in.r_seq_off[r], ncig, in.r_cig_off[r]);
+            s_c0[tid] = ncig > 0 ? in.cig[in.r_cig_off[r]] : 0u;
+        }
+        __syncthreads();
+        int k0 = 0;
+        for (; k0 + 4 <= nb; k0 += 4) {
+            int4 rd[4]; uint32_t cg[4];
+            bool simple = true;
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) { rd[u] = s_rd[k0 + u]; cg[u] = s_c0[k0 + u]; simple = simple && rd[u].z == 1 && (cg[u] & 0xf) == 0; }
+            if (simple) {                                     // (the same for every lane)
+                int bA[4], bB[4];
+                #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int x = rd[u].x, l = (int)(cg[u] >> 4);
+                    const uint8_t *seq = in.seq16 + rd[u].y;
+                    bA[u] = (mineA && colA >= x && colA < x + l) ? (int)(seq[colA - x] & 15) : -2;
+                    bB[u] = (mineB && colB >= x && colB < x + l) ? (int)(seq[colB - x] & 15) : -2;
+                }
+                #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (bA[u] != -2) cnt0 += bA[u] == rcA ? 1u : 0x10000u;
+                    if (bB[u] != -2) cnt1 += bB[u] == rcB ? 1u : 0x10000u;
+                }
+            } else {
+                #pragma unroll
+                for (int u = 0; u < 4; ++u) general(rd[u], cg[u]);
+            }
+        }
+        for (; k0 < nb; ++k0) general(s_rd[k0], s_c0[k0]);
+    }
+    if (mineA) s_cns[tid] = cnt0;
+    if (mineB) s_cns[tid + GAP_CONS_THREADS] = cnt1;
+    // windows wider than two columns per lane (a deletion longer than ~150 bases among the types): the plain loop
+    for (int c0 = 2 * GAP_CONS_THREADS; c0 < W; c0 += GAP_CONS_THREADS) {
+        const int col = left + c0 + tid;
+        const bool mine = c0 + tid < W;
+        const int rc = mine ? gap_nt16_of(gap_ref(in, col)) : -1;
+        uint32_t cnt = 0;
+        for (int e = e0; e < e1; ++e) {
+            const int r = in.p_read[e];
+            const uint32_t *cigar = in.cig + in.r_cig_off[r];
+            const uint8_t *seq = in.seq16 + in.r_seq_off[r];
+            const int ncig = in.r_ncig[r];
+            int x = in.r_pos[r], y = 0;
+            for (int k = 0; k < ncig; ++k) {
+                const int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
+                if (op == 0 || op == 7 || op == 8) {
+                    if (mine && col >= x && col < x + l) cnt += (int)(seq[y + (col - x)] & 15) == rc ? 1u : 0x10000u;
+                    x += l; y += l;
+                } else if (op == 2 || op == 3) x += l;
+                else if (op == 1 || op == 4) y += l;
+            }
+        }
+        if (mine) s_cns[c0 + tid] = cnt;
     }
     __syncthreads();
-    // the two columns with most mismatches, in the reference's scan order (:223-231)
-    if (lane == 0) {
-        uint32_t mx = 0, mx2 = 0; int max_i = -1, max2_i = -1;
-        for (int i = 0; i < W; ++i) {
-            const uint32_t c = s_cns[i];
-            if (c >> 16 >= mx >> 16) { mx2 = mx; max2_i = max_i; mx = c; max_i = i; }
-            else if (c >> 16 >= mx2 >> 16) { mx2 = c; max2_i = i; }
+    // The two columns with most mismatches (:223-231).  The reference scans the columns in order: a count >= the running
+    // maximum becomes the maximum (the old one the runner-up), else a count >= the runner-up becomes the runner-up.  At the end
+    // the maximum is the LAST column holding the largest count and the runner-up the last column holding the largest count
+    // among the others: two reductions over (count, column) pairs by the first wavefront.
+    if (tid < 64) {
+        auto last_max = [&](int skip) {
+            unsigned long long best = 0;                      // (mismatches + 1) << 32 | column: 0 = none
+            for (int i = tid; i < W; i += 64)
+                if (i != skip) { const unsigned long long k = (unsigned long long)((s_cns[i] >> 16) + 1) << 32 | (unsigned)i; if (k > best) best = k; }
+            #pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned long long k = __shfl_xor(best, o); if (k > best) best = k; }
+            return best ? (int)(best & 0xffffffffu) : -1;
+        };
+        int max_i = last_max(-1);
+        int max2_i = last_max(max_i);
+        if (tid == 0) {
+            const uint32_t mx = max_i >= 0 ? s_cns[max_i] : 0u, mx2 = max2_i >= 0 ? s_cns[max2_i] : 0u;
+            if ((double)(mx & 0xffff) / ((mx & 0xffff) + (mx >> 16)) >= 0.7) max_i = -1;
+            if ((double)(mx2 & 0xffff) / ((mx2 & 0xffff) + (mx2 >> 16)) >= 0.7) max2_i = -1;
+            s_m[0] = max_i; s_m[1] = max2_i;
         }
-        if ((double)(mx & 0xffff) / ((mx & 0xffff) + (mx >> 16)) >= 0.7) max_i = -1;
-        if ((double)(mx2 & 0xffff) / ((mx2 & 0xffff) + (mx2 >> 16)) >= 0.7) max2_i = -1;
-        s_m[0] = max_i; s_m[1] = max2_i;
     }
     __syncthreads();
     const int m1 = s_m[0], m2 = s_m[1];
+    // the sample's consensus over the window as base codes 0..4, once (the masked columns read as N)
+    uint8_t *s_code = reinterpret_cast<uint8_t*>(s_cns + W);
+    for (int c = tid; c < W; c += GAP_CONS_THREADS)
+        s_code[c] = (uint8_t)gap_nt16_int((c == m1 || c == m2) ? 15 : gap_nt16_of(gap_ref(in, left + c)));
+    __syncthreads();
     // ref2 of every type (:302-311): the sample's consensus left of the indel, the inserted consensus or the deletion,
-    // the consensus right of it, padded with N
+    // the consensus right of it, padded with N.  max_ref2 is a multiple of four and so is every row's offset: four codes
+    // per store.
     const int n1 = pos - left + 1, max_ref2 = S.max_ref2;
-    auto cons = [&](int j) {                                  // base code 0..4 of reference position j in this sample
-        const int c = (j - left == m1 || j - left == m2) ? 15 : gap_nt16_of(gap_ref(in, j));
-        return (uint8_t)gap_nt16_int(c);
-    };
     for (int t = 0; t < S.n_types; ++t) {
         const int ty = S.types[t];
-        uint8_t *dst = ref2pool + (size_t)S.ref2_0 + ((size_t)t * in.n_smpl + s) * max_ref2;
+        uint32_t *dst = reinterpret_cast<uint32_t*>(ref2pool + (size_t)S.ref2_0 + ((size_t)t * in.n_smpl + s) * max_ref2);
         const int8_t *ic = inscns + (size_t)S.ins0 + (size_t)t * (S.max_ins > 0 ? S.max_ins : 0);
-        for (int k = lane; k < max_ref2; k += 64) {
-            uint8_t v = 4;
-            if (k < n1) v = cons(left + k);
-            else if (ty > 0) {
-                if (k < n1 + ty) v = (uint8_t)ic[k - n1];
-                else { const int j = pos + 1 + (k - n1 - ty); if (j < right) v = cons(j); }
-            } else { const int j = pos + 1 - ty + (k - n1); if (j < right) v = cons(j); }
-            dst[k] = v;
+        for (int k4 = tid; k4 * 4 < max_ref2; k4 += GAP_CONS_THREADS) {
+            uint32_t w = 0;
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k4 * 4 + u;
+                uint32_t v = 4;
+                if (k < n1) v = s_code[k];
+                else if (ty > 0) {
+                    if (k < n1 + ty) v = (uint8_t)ic[k - n1];
+                    else { const int j = pos + 1 + (k - n1 - ty); if (j < right) v = s_code[j - left]; }
+                } else { const int j = pos + 1 - ty + (k - n1); if (j < right) v = s_code[j - left]; }
+                w |= v << (8 * u);
+            }
+            dst[k4] = w;
         }
     }
 }
@@ -376,17 +511,21 @@ __device__ __forceinline__ int gap_est_seqQ(const GapIn &in, int l, int l_run)
 }
 
 // ---- indelQ / seqQ of every read, the output types, p->aux (:372-459) ----
-__global__ __launch_bounds__(256) void gap_finalize_kernel(const GapIn in, GapSite *sites, const int32_t *score1, const int32_t *score2,
-                                                           const int8_t *inscns, uint32_t *p_aux, int32_t *o_ret, int32_t *o_types,
-                                                           int8_t *o_inscns, int inscns_cap, int32_t *o_maxins, int32_t *o_indelreg)
+// Three launches: (1) per entry the best type, indelQ and seqQ, and per site the types' quality sums (a workgroup works
+// on up to GAP_FIN_SEG entries of ONE site: LDS sums, one global atomic per type and workgroup); (2) per site the <= 4 output
+// types; (3) per entry p->aux with the index among the output types.
+#define GAP_FIN_SEG 1024
+__global__ __launch_bounds__(256) void gap_fin_entries_kernel(const GapIn in, const GapSite *sites, const int32_t *score1, const int32_t *score2,
+                                                              uint32_t *p_aux, int32_t *sumq)
 {
-    __shared__ int s_types[64], s_sumq[64], s_otypes[4], s_nalt;
+    __shared__ int s_types[64], s_sumq[64];
     const int is = blockIdx.x, tid = threadIdx.x;
-    GapSite &S = sites[is];
+    const GapSite &S = sites[is];
     if (!S.live) return;
     const int n_types = S.n_types, ref_type = S.ref_type, N = S.N, l_run = S.l_run;
+    const int k0 = blockIdx.y * GAP_FIN_SEG, k1 = min(N, k0 + GAP_FIN_SEG);
+    if (k0 >= N) return;
     if (tid < 64) { s_types[tid] = tid < n_types ? S.types[tid] : 0; s_sumq[tid] = 0; }
-    if (tid == 0) s_nalt = 0;
     __syncthreads();
     // The reference sorts sc[t] = score<<6 | t and uses the smallest, the second smallest and the reference type's value.
     auto pick = [&](const int32_t *sc, int K, int &v0, int &v1, int &vref) {
@@ -397,7 +536,7 @@ __global__ __launch_bounds__(256) void gap_finalize_kernel(const GapIn in, GapSi
             if (v < v0) { v1 = v0; v0 = v; } else if (v < v1) v1 = v;
         }
     };
-    for (int K = tid; K < N; K += 256) {
+    for (int K = k0 + tid; K < k1; K += 256) {
         int a0, a1, aref, indelQ1, indelQ2, seqQ;
         pick(score1, K, a0, a1, aref);
         if ((a0 & 0x3f) == ref_type) { indelQ1 = (a1 >> 14) - (a0 >> 14); seqQ = gap_est_seqQ(in, s_types[a1 & 0x3f], l_run); }
@@ -416,10 +555,21 @@ __global__ __launch_bounds__(256) void gap_finalize_kernel(const GapIn in, GapSi
         atomicAdd(&s_sumq[a0 & 0x3f], indelQ < seqQ ? indelQ : seqQ);
     }
     __syncthreads();
+    if (tid < n_types && s_sumq[tid]) atomicAdd(&sumq[(size_t)is * 64 + tid], s_sumq[tid]);
+}
+
+__global__ __launch_bounds__(64) void gap_fin_types_kernel(const GapSite *sites, const int32_t *sumq, const int8_t *inscns, int32_t *o_types,
+                                                           int8_t *o_inscns, int inscns_cap, int32_t *o_maxins, int32_t *o_indelreg, uint8_t *otype_of)
+{
+    const int is = blockIdx.x, tid = threadIdx.x;
+    const GapSite &S = sites[is];
+    if (!S.live) return;
+    __shared__ int s_otypes[4];
+    const int n_types = S.n_types, ref_type = S.ref_type;
     if (tid == 0) {
         // the types with the largest quality sums, the reference type first (:431-447)
         int sq[64];
-        for (int t = 0; t < n_types; ++t) sq[t] = s_sumq[t] << 6 | t;
+        for (int t = 0; t < n_types; ++t) sq[t] = sumq[(size_t)is * 64 + t] << 6 | t;
         for (int t = 1; t < n_types; ++t)
             for (int j = t; j > 0 && sq[j] > sq[j - 1]; --j) { const int x = sq[j]; sq[j] = sq[j - 1]; sq[j - 1] = x; }
         int t;
@@ -428,7 +578,7 @@ __global__ __launch_bounds__(256) void gap_finalize_kernel(const GapIn in, GapSi
         for (t = 0; t < 4; ++t) s_otypes[t] = INDEL_NULL;
         const int max_ins = S.max_ins;
         for (t = 0; t < 4 && t < n_types; ++t) {
-            s_otypes[t] = s_types[sq[t] & 0x3f];
+            s_otypes[t] = S.types[sq[t] & 0x3f];
             if (o_inscns && max_ins > 0 && (t + 1) * max_ins <= 4 * inscns_cap)
                 for (int k = 0; k < max_ins; ++k)
                     o_inscns[(size_t)is * 4 * inscns_cap + (size_t)t * max_ins + k] = inscns[(size_t)S.ins0 + (size_t)(sq[t] & 0x3f) * max_ins + k];
@@ -438,20 +588,31 @@ __global__ __launch_bounds__(256) void gap_finalize_kernel(const GapIn in, GapSi
         if (o_indelreg) o_indelreg[is] = S.indelreg;
     }
     __syncthreads();
-    // p->aux with the type index among the output types (:449-458)
-    int my_alt = 0;
-    for (int K = tid; K < N; K += 256) {
-        const uint32_t a = p_aux[S.e0 + K];
-        const int x = s_types[a >> 16 & 0x3f];
+    // type index -> index among the output types (4: not an output type), by VALUE as the reference compares them (:449-458)
+    if (tid < n_types) {
+        const int x = S.types[tid];
         int j;
         for (j = 0; j < 4; ++j) if (x == s_otypes[j]) break;
+        otype_of[(size_t)is * 64 + tid] = (uint8_t)j;
+    }
+}
+
+__global__ __launch_bounds__(256) void gap_fin_aux_kernel(const GapSite *sites, const uint8_t *otype_of, uint32_t *p_aux, int32_t *o_ret)
+{
+    const int is = blockIdx.x, tid = threadIdx.x;
+    const GapSite &S = sites[is];
+    if (!S.live) return;
+    const int N = S.N, k0 = blockIdx.y * GAP_FIN_SEG, k1 = min(N, k0 + GAP_FIN_SEG);
+    if (k0 >= N) return;
+    bool alt = false;
+    for (int K = k0 + tid; K < k1; K += 256) {
+        const uint32_t a = p_aux[S.e0 + K];
+        const int j = otype_of[(size_t)is * 64 + (a >> 16 & 0x3f)];
         const uint32_t v = (uint32_t)(j << 16) | (j == 4 ? 0u : (a & 0xffff));
         p_aux[S.e0 + K] = v;
-        if ((v >> 16 & 0x3f) > 0) ++my_alt;
+        alt |= (v >> 16 & 0x3f) > 0;
     }
-    if (my_alt) atomicAdd(&s_nalt, my_alt);
-    __syncthreads();
-    if (tid == 0) o_ret[is] = s_nalt > 0 ? 0 : -1;
+    if (__any(alt) && (tid & 63) == 0) o_ret[is] = 0;         // (set to -1 by gap_type_kernel; every writer stores the same 0)
 }
 
 }  // namespace bcfgpu
@@ -462,6 +623,7 @@ __global__ __launch_bounds__(256) void gap_finalize_kernel(const GapIn in, GapSi
 #define WS(slot, bytes) bcfgpu_internal_ws(ctx, 40 + (slot), (bytes) + 64)      /* slots 40..: this stage's own */
 
 extern "C" int bcfgpu_internal_n_cu(const bcfgpu_ctx *c);
+extern "C" int bcfgpu_internal_side(bcfgpu_ctx *c, hipStream_t **streams, hipEvent_t **events);
 
 // The stage on arrays that are already in HBM (`g`: device pointers throughout; n_ent pileup entries).  d_aux [n_ent]
 // (device) receives p->aux; the per-site outputs go to the host arrays of `out` (out->p_aux is not touched: the callers
@@ -496,7 +658,7 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
     // ---- typing ----
     if (nr) hipLaunchKernelGGL(gap_read_info_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, g, d_rinfo);
     hipLaunchKernelGGL(gap_type_kernel, dim3(ns), dim3(256), 0, st, g, d_sites, d_rinfo, o_ret, o_types, o_msup, o_mfrac);
-    hipLaunchKernelGGL(gap_scan_kernel, dim3(1), dim3(1), 0, st, d_sites, ns, n, d_tot);
+    hipLaunchKernelGGL(gap_scan_kernel, dim3(1), dim3(256), 0, st, d_sites, ns, n, d_tot);
     GapTotals tot{};
     GP_CHK(hipMemcpyAsync(h_small, d_tot, sizeof(GapTotals), hipMemcpyDeviceToHost, st));
     GP_CHK(hipStreamSynchronize(st));                           // sizes of the next stage's buffers
@@ -519,18 +681,22 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
         uint32_t *d_k0 = (uint32_t*)WS(32, nj * 4), *d_v0 = (uint32_t*)WS(33, nj * 4), *d_k1 = (uint32_t*)WS(34, nj * 4), *d_v1 = (uint32_t*)WS(35, nj * 4);
         uint32_t *d_list2 = (uint32_t*)WS(36, nj * 4);
         ProbalnQueue *d_queue = (ProbalnQueue*)WS(38, sizeof(ProbalnQueue));
+        int32_t *d_sumq = (int32_t*)WS(39, (size_t)ns * 64 * 4);
+        uint8_t *d_otype = (uint8_t*)WS(40, (size_t)ns * 64);
         size_t sort_bytes = 0;
         GP_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, d_k0, d_k1, d_v0, d_v1, (int)nj, 0, 17, st));
         void *d_sort = WS(37, sort_bytes);
         if (out->inscns) d_oinscns = (int8_t*)WS(22, (size_t)ns * 4 * inscns_cap);
         if (!d_inscnt || !d_inscns || !d_ref2 || !d_s1 || !d_s2 || !d_wide || !d_ent || !d_qpack || !d_pjob || !d_k0 || !d_v0 || !d_k1 || !d_v1 ||
-            !d_list2 || !d_queue || !d_sort || (out->inscns && !d_oinscns))
+            !d_list2 || !d_queue || !d_sort || !d_sumq || !d_otype || (out->inscns && !d_oinscns))
             return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
         if (tot.ins_bytes) { GP_CHK(hipMemsetAsync(d_inscnt, 0, (size_t)tot.ins_bytes * 5 * 4, st)); GP_CHK(hipMemsetAsync(d_inscns, 0, (size_t)tot.ins_bytes, st)); }
         GP_CHK(hipMemsetAsync(d_s1, 0, nj * 4, st)); GP_CHK(hipMemsetAsync(d_s2, 0, nj * 4, st));
+        GP_CHK(hipMemsetAsync(d_sumq, 0, (size_t)ns * 64 * 4, st));
         if (d_oinscns) GP_CHK(hipMemsetAsync(d_oinscns, 0, (size_t)ns * 4 * inscns_cap, st));
-        hipLaunchKernelGGL(gap_inscns_kernel, dim3(ns), dim3(256), 0, st, g, d_sites, d_inscnt, d_inscns);
-        hipLaunchKernelGGL(gap_cons_kernel, dim3((unsigned)((size_t)ns * n)), dim3(64), (size_t)tot.max_L * 4 + 16, st, g, d_sites, d_inscns, d_ref2);
+        if (tot.ins_bytes && n_ent) hipLaunchKernelGGL(gap_inscnt_kernel, dim3((unsigned)((n_ent + 255) / 256)), dim3(256), 0, st, g, d_sites, (int)n_ent, d_inscnt);
+        hipLaunchKernelGGL(gap_inscns_kernel, dim3(ns), dim3(64), 0, st, g, d_sites, d_inscnt, d_inscns);
+        hipLaunchKernelGGL(gap_cons_kernel, dim3((unsigned)((size_t)ns * n)), dim3(GAP_CONS_THREADS), (size_t)tot.max_L * 5 + 16, st, g, d_sites, d_inscns, d_ref2);
         // ---- realignment: the jobs decoded and sorted by band, register-resident passes per band width; the jobs with
         // wider bands are listed and run from scratch rows ----
         launch_gap_entries(g, d_sites, (int)n_ent, d_ent, tot.max_qstride, d_qpack, st);
@@ -547,7 +713,11 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
         launch_probaln_jobs(p, st);
         GP_CHK(hipcub::DeviceRadixSort::SortPairs(d_sort, sort_bytes, d_k0, d_k1, d_v0, d_v1, (int)nj, 0, 17, st));
         launch_probaln_bounds(p, st);
-        launch_probaln_exact(p, st, bcfgpu_internal_n_cu(ctx));
+        {
+            hipStream_t *side = nullptr; hipEvent_t *sev = nullptr;
+            if (bcfgpu_internal_side(ctx, &side, &sev) || launch_probaln_exact(p, st, bcfgpu_internal_n_cu(ctx), side, sev))
+                return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_gap_prep: side streams");
+        }
         GP_CHK(hipMemcpyAsync(h_small, d_tot, sizeof(GapTotals), hipMemcpyDeviceToHost, st));
         GP_CHK(hipStreamSynchronize(st));                       // how many jobs need the wide-band version, and how wide
         memcpy(&tot, h_small, sizeof tot);
@@ -566,15 +736,12 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
             }
         }
         hipEventRecord(e1, st);
-        if (const char *dp = getenv("BCFGPU_DUMP_SCORES")) {      // TEMPORARY diagnostics
-            std::vector<int32_t> h1(nj), h2(nj); std::vector<uint32_t> hk(nj); std::vector<PJob> hp(nj);
-            hipMemcpy(h1.data(), d_s1, nj * 4, hipMemcpyDeviceToHost); hipMemcpy(h2.data(), d_s2, nj * 4, hipMemcpyDeviceToHost);
-            hipMemcpy(hk.data(), d_k0, nj * 4, hipMemcpyDeviceToHost); hipMemcpy(hp.data(), d_pjob, nj * sizeof(PJob), hipMemcpyDeviceToHost);
-            FILE *f = fopen(dp, "wb"); int64_t n64 = (int64_t)nj; fwrite(&n64, 8, 1, f);
-            fwrite(h1.data(), 4, nj, f); fwrite(h2.data(), 4, nj, f); fwrite(hk.data(), 4, nj, f); fwrite(hp.data(), sizeof(PJob), nj, f); fclose(f);
+        {
+            const dim3 fgrid((unsigned)ns, (unsigned)((tot.max_N + GAP_FIN_SEG - 1) / GAP_FIN_SEG));
+            hipLaunchKernelGGL(gap_fin_entries_kernel, fgrid, dim3(256), 0, st, g, d_sites, d_s1, d_s2, d_aux, d_sumq);
+            hipLaunchKernelGGL(gap_fin_types_kernel, dim3(ns), dim3(64), 0, st, d_sites, d_sumq, d_inscns, o_types, d_oinscns, inscns_cap, o_maxins, o_ireg, d_otype);
+            hipLaunchKernelGGL(gap_fin_aux_kernel, fgrid, dim3(256), 0, st, d_sites, d_otype, d_aux, o_ret);
         }
-        hipLaunchKernelGGL(gap_finalize_kernel, dim3(ns), dim3(256), 0, st, g, d_sites, d_s1, d_s2, d_inscns, d_aux, o_ret, o_types,
-                           d_oinscns, inscns_cap, o_maxins, o_ireg);
         GP_CHK(hipGetLastError());
         GP_CHK(hipMemcpyAsync(h_small, d_small, so_bytes, hipMemcpyDeviceToHost, st));
         if (out->inscns) GP_CHK(hipMemcpyAsync(out->inscns, d_oinscns, (size_t)ns * 4 * inscns_cap, hipMemcpyDeviceToHost, st));

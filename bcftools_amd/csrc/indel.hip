@@ -487,25 +487,37 @@ void launch_probaln_bounds(const ProbalnParams &p, hipStream_t s)
 {
     hipLaunchKernelGGL(probaln_bounds_kernel, dim3(1), dim3(64), 0, s, p.key_sorted, p.n_jobs, p.queue);
 }
-template <int BW> static void launch_exact_class(const ProbalnParams &p, hipStream_t s, int pass, unsigned grid)
+template <int BW> static void launch_exact_class(const ProbalnParams &p, hipStream_t s, unsigned grid)
 {
-    if (pass == 1) hipLaunchKernelGGL((probaln_exact_kernel<BW, 1>), dim3(grid), dim3(64), 0, s, p);
-    else hipLaunchKernelGGL((probaln_exact_kernel<BW, 2>), dim3(grid), dim3(64), 0, s, p);
+    hipLaunchKernelGGL((probaln_exact_kernel<BW, 1>), dim3(grid), dim3(64), 0, s, p);
+    hipLaunchKernelGGL((probaln_exact_kernel<BW, 2>), dim3(grid), dim3(64), 0, s, p);
 }
-// both passes of every class with a band up to max_bw_hint + slack (a band can exceed |type|+3 only by l_ref - l_query)
-void launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu)
+// Both passes of every band width.  The widths are independent of one another, and the narrow classes hold most jobs while
+// a wide one may hold a few dozen whose single wavefront takes as long as a large class does: each width runs on a stream
+// of its own between a fork and a join on the caller's stream (side[8], ev[9] from the context), widest first.
+int launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu, hipStream_t *side, hipEvent_t *ev)
 {
-    if (p.n_jobs <= 0) return;
+    if (p.n_jobs <= 0) return 0;
     // wavefronts the machine holds at the kernels' occupancy (2-3 per SIMD), but no more than the jobs can fill
     unsigned grid = (unsigned)n_cu * 4u * 3u;
     const unsigned need = (unsigned)((p.n_jobs + 63) / 64);
     if (grid > need) grid = need;
-    for (int pass = 1; pass <= 2; ++pass) {
-        launch_exact_class<3>(p, s, pass, grid); launch_exact_class<4>(p, s, pass, grid);
-        launch_exact_class<5>(p, s, pass, grid); launch_exact_class<6>(p, s, pass, grid);
-        launch_exact_class<7>(p, s, pass, grid); launch_exact_class<8>(p, s, pass, grid);
-        launch_exact_class<9>(p, s, pass, grid); launch_exact_class<10>(p, s, pass, grid);
+    if (hipEventRecord(ev[8], s) != hipSuccess) return -1;
+    for (int i = 0; i < 8; ++i) {
+        if (hipStreamWaitEvent(side[i], ev[8], 0) != hipSuccess) return -1;
+        switch (i) {
+            case 0: launch_exact_class<10>(p, side[i], grid); break;
+            case 1: launch_exact_class<9>(p, side[i], grid); break;
+            case 2: launch_exact_class<8>(p, side[i], grid); break;
+            case 3: launch_exact_class<7>(p, side[i], grid); break;
+            case 4: launch_exact_class<6>(p, side[i], grid); break;
+            case 5: launch_exact_class<5>(p, side[i], grid); break;
+            case 6: launch_exact_class<4>(p, side[i], grid); break;
+            default: launch_exact_class<3>(p, side[i], grid); break;
+        }
+        if (hipEventRecord(ev[i], side[i]) != hipSuccess || hipStreamWaitEvent(s, ev[i], 0) != hipSuccess) return -1;
     }
+    return 0;
 }
 void launch_probaln_wide(const ProbalnParams &p, hipStream_t s)
 {

@@ -134,7 +134,7 @@ struct GapTotals {
     unsigned long long n_jobs, ref2_bytes, ins_bytes;
     unsigned long long n_passes, dp_cells;       // statistics of the realignment (bcfgpu_gap_stats)
     unsigned long long qpack8;                   // 8-byte units of the packed-query pool
-    int32_t max_L, max_bw, n_live, max_ref2, max_qstride, pad_;
+    int32_t max_L, max_bw, n_live, max_ref2, max_qstride, max_N;   // max_N: most pileup entries of a live site
     uint32_t n_wide;                             // jobs whose band does not fit the register-resident pass
     int32_t max_eff;                             // their widest band
 };
@@ -173,7 +173,7 @@ struct ProbalnParams {
 };
 void launch_probaln_jobs(const ProbalnParams &p, hipStream_t s);
 void launch_probaln_bounds(const ProbalnParams &p, hipStream_t s);
-void launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu);
+int launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu, hipStream_t *side, hipEvent_t *ev);
 void launch_probaln_wide(const ProbalnParams &p, hipStream_t s);
 void launch_gap_entries(const GapIn &in, const GapSite *sites, int n_ent, GapEntry *ent, int max_qstride, uint8_t *qpack, hipStream_t s);
 

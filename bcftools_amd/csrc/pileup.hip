@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
+#include <climits>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -58,6 +59,8 @@ struct PileupParams {
     uint32_t *cnt;                  // [n_cells + 1] pass 1: reads per cell; after the scan: plp_off
     uint32_t *rd; uint8_t *epos;    // pass 2
     uint32_t *col_indel;            // [n_sites] != 0 when some entry of the column is followed by an indel
+    int n_reads;                    // reads of the pool (bcfgpu_gap_prep_tile)
+    uint32_t n_bases;               // bases of the pool's seq16 / qual
 };
 
 // first k in [lo, hi) with a[k] > x
@@ -403,7 +406,7 @@ extern "C" int bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const uint
         return d;
     };
     PileupParams P{};
-    P.n_sites = n_sites; P.n_smpl = S; P.beg = beg; P.max_span = max_span;
+    P.n_sites = n_sites; P.n_smpl = S; P.beg = beg; P.max_span = max_span; P.n_reads = n; P.n_bases = (uint32_t)nbase;
     P.want_epos = (cfg->fmt_flag & (BCFGPU_INFO_RPB | BCFGPU_INFO_VDB)) ? 1 : 0;
     void *d_ref16 = up(16, ref16.data(), (size_t)n_sites);
     P.smpl_off = (const int32_t*)up(17, smpl_off.data(), (size_t)(S + 1) * 4);
@@ -573,5 +576,129 @@ extern "C" int bcfgpu_pileup_indel_tile(bcfgpu_ctx *ctx, int32_t n_cols, const i
     tile->n_sites = n_cols; tile->is_indel = 1; tile->n_reads = total;
     tile->ref16 = reinterpret_cast<const int8_t*>(d_sel + nsel + 1);       // (zeros: the indel pass does not read it)
     tile->plp_off = d_sel; tile->rd = (const uint32_t*)d_out; tile->epos = d_out + ep_at; tile->aux = (const uint32_t*)(d_out + aux_at);
+    return BCFGPU_OK;
+}
+
+// ---- bcf_call_gap_prep for candidate columns of the last bcfgpu_pileup, everything staying in HBM -------------------
+namespace bcfgpu {
+// the per-read arrays bcfgpu_gap_prep takes (bcfgpu_reads), rebuilt from the pileup's read records; by pool index
+__global__ __launch_bounds__(256) void gap_unpack_reads_kernel(const PileupParams P, int32_t *r_pos, int32_t *r_lq, int32_t *r_flag,
+                                                               int32_t *r_ncig, int32_t *r_cig_off, int32_t *r_seq_off)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= P.n_reads) return;
+    const ReadMeta m = P.meta[k];
+    const int r = P.s_read[k];
+    r_pos[r] = m.pos; r_lq[r] = m.lq; r_flag[r] = ((m.bits & 1) ? 16 : 0) | ((m.bits & 4) ? 4 : 0);
+    r_ncig[r] = m.ncig; r_cig_off[r] = (int32_t)m.cig_off; r_seq_off[r] = (int32_t)m.seq_off;
+}
+__global__ __launch_bounds__(256) void gap_col_pos_kernel(const int32_t *cols, int n_cols, int beg, int32_t *pos)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_cols) pos[i] = beg + cols[i];
+}
+}  // namespace bcfgpu
+
+int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint32_t *d_aux, const bcfgpu_indel_out *out, int inscns_cap);
+extern "C" bcfgpu_gap_stats *bcfgpu_internal_gap_stats(bcfgpu_ctx *ctx);
+
+extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols, const bcfgpu_reads *reads,
+                                    const bcfgpu_indel_in *par, const bcfgpu_indel_out *out, int inscns_cap, bcfgpu_tile *tile)
+{
+    if (!ctx || n_cols < 0 || (n_cols && !cols) || !par || !par->ref || !out || !out->ret || !out->indel_types || !tile)
+        return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep_tile: bad arguments");
+    hipStream_t stream = nullptr;
+    if (bcfgpu_internal_device(ctx, &stream, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep_tile: bad context");
+    EntriesParams E{};
+    std::memcpy(&E.P, bcfgpu_internal_pileup_state(ctx), sizeof E.P);
+    const PileupParams &P = E.P;
+    if (!P.cnt) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep_tile: no bcfgpu_pileup on this context yet");
+    std::memset(tile, 0, sizeof *tile);
+    bcfgpu_gap_stats &gs = *bcfgpu_internal_gap_stats(ctx);
+    gs = bcfgpu_gap_stats{};
+    if (n_cols == 0) return BCFGPU_OK;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    const int S = P.n_smpl, nr = P.n_reads;
+    int cmin = INT32_MAX, cmax = 0;
+    for (int i = 0; i < n_cols; ++i) {
+        if (cols[i] < 0 || cols[i] >= P.n_sites) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep_tile: column out of range");
+        cmin = std::min(cmin, cols[i]); cmax = std::max(cmax, cols[i]);
+    }
+    const size_t nsel = (size_t)n_cols * S;
+    #define GT_CHK(call) do { if ((call) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, #call); } while (0)
+    #define GWS(slot, bytes) bcfgpu_internal_ws(ctx, 40 + (slot), (bytes) + 64)      /* the slots bcfgpu_gap_prep uses for its uploads */
+    // ---- the columns' pileup entries (read, query offset, indel after the position), on the device ----
+    int32_t *d_cols = (int32_t*)bcfgpu_internal_ws(ctx, 21, (size_t)n_cols * 4 + 16);
+    uint32_t *d_sel = (uint32_t*)bcfgpu_internal_ws(ctx, 25, (nsel + 1) * 4 + (size_t)n_cols + 64);
+    if (!d_cols || !d_sel) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
+    GT_CHK(hipMemcpyAsync(d_cols, cols, (size_t)n_cols * 4, hipMemcpyHostToDevice, stream));
+    GT_CHK(hipMemsetAsync(d_sel, 0, (nsel + 1) * 4 + (size_t)n_cols + 64, stream));
+    E.n_cols = n_cols; E.cols = d_cols; E.sel_cnt = d_sel;
+    const int grid = (int)((nsel + 255) / 256);
+    hipLaunchKernelGGL(entries_kernel<false>, dim3(grid), dim3(256), 0, stream, E);
+    size_t tmp_bytes = 0;
+    GT_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_sel, d_sel, (int)(nsel + 1), stream));
+    void *d_tmp = bcfgpu_internal_ws(ctx, 23, tmp_bytes + 16);
+    if (!d_tmp) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
+    GT_CHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_sel, d_sel, (int)(nsel + 1), stream));
+    uint32_t total = 0;
+    GT_CHK(hipMemcpyAsync(&total, d_sel + nsel, 4, hipMemcpyDeviceToHost, stream));
+    // meanwhile: the reads as bcfgpu_gap_prep's kernels index them, the columns' positions, the reference slice, ZQ
+    int32_t *d_rpos = (int32_t*)GWS(0, (size_t)nr * 4), *d_rlq = (int32_t*)GWS(1, (size_t)nr * 4), *d_rflag = (int32_t*)GWS(2, (size_t)nr * 4);
+    int32_t *d_rncig = (int32_t*)GWS(3, (size_t)nr * 4), *d_rcoff = (int32_t*)GWS(4, (size_t)nr * 4), *d_rsoff = (int32_t*)GWS(5, (size_t)nr * 4);
+    int32_t *d_pos = (int32_t*)GWS(11, (size_t)n_cols * 4);
+    const int pmin = P.beg + cmin, pmax = P.beg + cmax;
+    const long ref_lo = pmin > 65536 ? pmin - 65536 : 0;
+    const long ref_hi = pmax + 1 + (long)strnlen(par->ref + pmax + 1, 65536 + 4096);
+    char *d_ref = (char*)GWS(24, (size_t)(ref_hi - ref_lo));
+    const bool any_zq = reads && reads->zq && reads->r_has_zq;
+    uint8_t *d_zq = any_zq ? (uint8_t*)GWS(9, (size_t)P.n_bases) : nullptr, *d_haszq = any_zq ? (uint8_t*)GWS(10, (size_t)nr) : nullptr;
+    if (!d_rpos || !d_rlq || !d_rflag || !d_rncig || !d_rcoff || !d_rsoff || !d_pos || !d_ref || (any_zq && (!d_zq || !d_haszq)))
+        return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
+    if (any_zq && reads->n_reads != nr) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep_tile: `reads` is not the pool of the last bcfgpu_pileup");
+    if (nr) hipLaunchKernelGGL(gap_unpack_reads_kernel, dim3((nr + 255) / 256), dim3(256), 0, stream, P, d_rpos, d_rlq, d_rflag, d_rncig, d_rcoff, d_rsoff);
+    hipLaunchKernelGGL(gap_col_pos_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, stream, d_cols, n_cols, P.beg, d_pos);
+    GT_CHK(hipMemcpyAsync(d_ref, par->ref + ref_lo, (size_t)(ref_hi - ref_lo), hipMemcpyHostToDevice, stream));
+    if (any_zq) {
+        GT_CHK(hipMemcpyAsync(d_zq, reads->zq, (size_t)P.n_bases, hipMemcpyHostToDevice, stream));
+        GT_CHK(hipMemcpyAsync(d_haszq, reads->r_has_zq, (size_t)nr, hipMemcpyHostToDevice, stream));
+    }
+    GT_CHK(hipStreamSynchronize(stream));                       // the entry count sizes everything that follows
+    if ((total >> 31) != 0) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_gap_prep_tile: too many pileup entries in one call, use fewer columns");
+    int32_t *d_e = (int32_t*)bcfgpu_internal_ws(ctx, 24, (size_t)total * 12 + 16);
+    const size_t ep_at = (((size_t)total + 4) * 4 + 255) & ~(size_t)255;
+    uint8_t *d_out = (uint8_t*)bcfgpu_internal_ws(ctx, 26, ep_at + (size_t)total + 64);
+    uint32_t *d_aux = (uint32_t*)GWS(27, ((size_t)total + 4) * 4);
+    if (!d_e || !d_out || !d_aux) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
+    E.e_read = d_e; E.e_qpos = d_e + total; E.e_indel = d_e + 2 * (size_t)total;
+    if (total) {
+        hipLaunchKernelGGL(entries_kernel<true>, dim3(grid), dim3(256), 0, stream, E);
+        // the indel pass's tile: the same entries' read records, p->aux to come from the stage below
+        hipLaunchKernelGGL(subtile_kernel<true>, dim3(grid), dim3(256), 0, stream, E, (uint32_t*)d_out, d_out + ep_at);
+    }
+    GT_CHK(hipGetLastError());
+    GapIn g{};
+    g.n_sites = n_cols; g.n_smpl = S; g.n_reads = nr;
+    g.pos = d_pos; g.smpl_off = reinterpret_cast<const int32_t*>(d_sel); g.p_read = E.e_read; g.p_qpos = E.e_qpos; g.p_indel = E.e_indel;
+    g.r_pos = d_rpos; g.r_lq = d_rlq; g.r_flag = d_rflag; g.r_ncig = d_rncig; g.r_cig_off = d_rcoff; g.r_seq_off = d_rsoff;
+    g.cig = P.cig; g.seq16 = P.seq16; g.qual = P.qual; g.zq = d_zq; g.r_has_zq = d_haszq;
+    g.ref = d_ref; g.ref_lo = ref_lo; g.ref_hi = ref_hi;
+    g.openQ = par->openQ; g.extQ = par->extQ; g.tandemQ = par->tandemQ; g.min_support = par->min_support; g.per_sample_flt = par->per_sample_flt;
+    g.min_frac = par->min_frac;
+    gs.prepare_ms = ms_since(t_begin);
+    const int rc = bcfgpu_internal_gap_core(ctx, g, (size_t)total, d_aux, out, inscns_cap);
+    if (rc) return rc;
+    if (out->p_aux && total) {                                  // optional: the entries' words for the caller as well
+        GT_CHK(hipMemcpyAsync(out->p_aux, d_aux, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+        GT_CHK(hipStreamSynchronize(stream));
+    }
+    gs.total_ms = ms_since(t_begin);
+    #undef GT_CHK
+    #undef GWS
+    tile->n_sites = n_cols; tile->is_indel = 1; tile->n_reads = total;
+    tile->ref16 = reinterpret_cast<const int8_t*>(d_sel + nsel + 1);       // (zeros: the indel pass does not read it)
+    tile->plp_off = d_sel; tile->rd = (const uint32_t*)d_out; tile->epos = d_out + ep_at; tile->aux = d_aux;
     return BCFGPU_OK;
 }

@@ -190,6 +190,30 @@ def indel_batch(seed, n_sites, n_smpl, depth=30.0, read_len=100, max_depth=200):
                 p_read=i32(np.arange(R)), p_qpos=i32(qpos), p_indel=i32(ilen), itype=itype, n_sites=n_sites, n_smpl=S)
 
 
+def indel_pool(b, mapq=60):
+    """The reads of an indel_batch() as the pool bcfgpu_pileup takes: grouped by sample, ascending position inside a sample
+    (a position-sorted BAM per sample).  Returns (reads dict, r_mapq, r_smpl, order): read k of the pool is read order[k]
+    of the batch; the entries of a pileup column come out in pool order."""
+    S, R = b["n_smpl"], b["reads"]
+    n = R["n_reads"]
+    cell = np.repeat(np.arange(b["n_sites"] * S), np.diff(b["smpl_off"]))      # every entry owns its read: read i = entry i
+    smpl = (cell % S).astype(np.int32)
+    order = np.lexsort((np.arange(n), R["r_pos"], smpl))
+    L = int(R["r_lq"][0])
+    assert (R["r_lq"] == L).all()
+    i32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)
+    ncig = R["r_ncig"][order]
+    coff = np.concatenate([[0], np.cumsum(ncig)[:-1]])
+    idx = np.repeat(R["r_cig_off"][order] - coff, ncig) + np.arange(int(ncig.sum()))
+    reads = dict(n_reads=n, r_pos=i32(R["r_pos"][order]), r_lq=i32(R["r_lq"][order]), r_flag=i32(R["r_flag"][order]),
+                 r_ncig=i32(ncig), r_cig_off=i32(coff), r_seq_off=i32(np.arange(n, dtype=np.int64) * L),
+                 cig=np.ascontiguousarray(R["cig"][idx]),
+                 seq16=np.ascontiguousarray(R["seq16"].reshape(n, L)[order].ravel()),
+                 qual=np.ascontiguousarray(R["qual"].reshape(n, L)[order].ravel()),
+                 zq=np.zeros(n * L, dtype=np.uint8), r_has_zq=np.zeros(n, dtype=np.uint8))
+    return reads, np.full(n, mapq, dtype=np.uint8), np.ascontiguousarray(smpl[order]), order
+
+
 def indel_tile_from_batch(b, aux, ret, mapq=60):
     """The indel pass of mpileup (mpileup.c:354-365) for the columns of an indel_batch() where bcf_call_gap_prep
     returned 0: the same pileup entries as a tile with ref_base = -1 and aux = p->aux."""

@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--haploid-frac", type=float, default=0.0, help="snp mode: fraction of haploid samples (ploidy array; general caller path)")
     ap.add_argument("--extras", type=int, default=1, help="snp mode at N=1: also measure the BASELINE configs[4] shape (sample groups + ploidy array) and "
                                                           "the indel stage (configs[2] shape) in child processes and embed their results under \"extra\" (0: skip)")
-    ap.add_argument("--indel-callers", type=int, default=2, help="indel mode: also time this many caller threads, one context each (1: skip)")
+    ap.add_argument("--indel-callers", type=int, default=1, help="indel mode: also time the host-pointer form of the stage on one 32-column batch (0: skip)")
     ap.add_argument("--mode", choices=["snp", "indel", "baq", "pileup", "gvcf"], default="snp",
                     help="snp: the headline pipeline (default).  indel: bcf_call_gap_prep on synthetic indel-candidate columns "
                          "(BASELINE configs[2] shape, 500 samples), reports DP cells/s of the realignment kernel.  "
@@ -75,95 +75,93 @@ def algorithmic_bytes(n_sites, n_smpl, n_reads, A=2):
 
 
 def main_indel(a):
-    """Secondary measurement (indel stage unit): bcfgpu_gap_prep over batches of 32 candidate columns."""
+    """Secondary measurement (indel stage unit; BASELINE configs[2] shape): bcf_call_gap_prep over the candidate
+    columns of a region whose reads are already in HBM -- bcfgpu_pileup has run (untimed, like the SNP bench's resident
+    tile), then every step is one bcfgpu_gap_prep_tile over all candidate columns plus the indel pass (bcfgpu_mpileup on the
+    tile it returns).  `value` counts the gap_prep_tile calls only (wall clock, host side included)."""
     import torch
     from bcftools_amd import abi, synth, engine
+    from bcftools_amd.lib import check
     from tests.helpers import indeldrv
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     S = 500 if a.samples == 1000 else a.samples
     n_sites = 128 if a.sites is None else a.sites
-    per = 32
-    ctx = engine.Context(abi.default_cfg(S, max_sites=per, max_reads=64))
-    indeldrv.gap_prep_gpu(ctx, synth.indel_batch(a.seed, 2, 8, depth=10.0))          # warm-up: module load
-    indeldrv.gap_prep_gpu(ctx, synth.indel_batch(a.seed, min(per, n_sites), S, depth=a.depth))   # ... and the grow-only workspaces at full size
-    tot = dict(jobs=0, passes=0, cells=0, kernel=0.0, prepare=0.0, finalize=0.0, total=0.0, sites=0, live=0, entries=0)
-    first = None
-    pass_ctx = {}
-    for c in range(0, n_sites, per):
-        b = synth.indel_batch(a.seed + c, min(per, n_sites - c), S, depth=a.depth)
-        got, st = indeldrv.gap_prep_gpu(ctx, b)
-        if first is None:
-            first = (b, got)
+    b = synth.indel_batch(a.seed, n_sites, S, depth=a.depth)
+    E = len(b["p_read"])
+    ctx = engine.Context(abi.default_cfg(S, max_sites=n_sites, max_reads=int(E * 1.05) + 64))
+    t0 = time.perf_counter()
+    pool = indeldrv.DevicePool(ctx, b)
+    ctx.sync()
+    t_pileup = time.perf_counter() - t0
+    steps = max(1, a.steps)
+    pool.gap_prep_tile()                                                            # warm-up: module load, workspaces at full size
+    tot = dict(jobs=0, passes=0, cells=0, kernel=0.0, prepare=0.0, finalize=0.0, total=0.0, wall=0.0, pass_glfgen=0.0, pass_combine=0.0)
+    o, ob, res = ctx.alloc_mplp_out(n_sites)
+    ctx.timing(True)
+    got = None
+    for _ in range(steps):
+        ctx.sync()
+        t0 = time.perf_counter()
+        got, st, tile = pool.gap_prep_tile()
+        tot["wall"] += time.perf_counter() - t0
         tot["jobs"] += st.n_jobs; tot["passes"] += st.n_passes; tot["cells"] += st.dp_cells
         tot["kernel"] += st.kernel_ms; tot["prepare"] += st.prepare_ms; tot["finalize"] += st.finalize_ms; tot["total"] += st.total_ms
-        tot["sites"] += b["n_sites"]; tot["live"] += int((got["ret"] == 0).sum()); tot["entries"] += len(b["p_read"])
-        # the indel records themselves (mpileup.c:357-365): the same entries with p->aux through glfgen (ref_base = -1)
-        # and combine; kernel times from the library's HIP events (the tile goes up from host memory here)
-        tile, live = synth.indel_tile_from_batch(b, got["aux"], got["ret"])
-        if len(live):
-            pctx = pass_ctx.setdefault(0, engine.Context(abi.default_cfg(S, max_sites=per, max_reads=int(len(tile.rd) * 1.2) + 64)))
-            if len(tile.rd) > pctx.cfg.max_reads:
-                pctx.close()
-                pctx = pass_ctx[0] = engine.Context(abi.default_cfg(S, max_sites=per, max_reads=int(len(tile.rd) * 1.2) + 64))
-            pctx.timing(True)
-            res = pctx.mpileup(tile)
-            tmg = pctx.last_timing()
-            tot["pass_glfgen"] = tot.get("pass_glfgen", 0.0) + tmg["glfgen_ms"]
-            tot["pass_combine"] = tot.get("pass_combine", 0.0) + tmg["combine_ms"]
-            tot["records"] = tot.get("records", 0) + int((res.site["ret"] == 0).sum())
+        # the indel records themselves (mpileup.c:357-365): the tile gap_prep_tile left in HBM through glfgen (ref_base = -1)
+        # and combine; kernel times from the library's HIP events
+        check(ctx.L.bcfgpu_mpileup(ctx.h, C.byref(tile), C.byref(o)))
+        ctx.sync()
+        tmg = ctx.last_timing()
+        tot["pass_glfgen"] += tmg["glfgen_ms"]; tot["pass_combine"] += tmg["combine_ms"]
+    ctx._download(ob, res)
+    live = got["ret"] == 0
+    records = int(((res.site["ret"] == 0) & live).sum())
+    per = lambda k: tot[k] / steps
+    cells_per_s = tot["cells"] / (tot["kernel"] * 1e-3)
     out = {"metric": "indel-candidate columns/sec through bcf_call_gap_prep (typing, consensus, realignment, indelQ: all device kernels), %d samples x %.0fx" % (S, a.depth),
-           "value": tot["sites"] / (tot["total"] * 1e-3), "unit": "sites/s", "n_gpus": 1, "higher_is_better": True,
+           "value": n_sites / (per("wall")), "unit": "sites/s", "n_gpus": 1, "higher_is_better": True, "steps": steps,
            "dtype": "f64 pair-HMM forward", "data": "synthetic",
-           "config": {"workload": "synthetic indel-candidate columns (BASELINE configs[2] shape), batches of %d columns" % per,
-                      "samples": S, "depth": a.depth, "sites": tot["sites"], "pileup_entries": tot["entries"]},
-           "kernel": {"name": "probaln_kernel", "jobs": tot["jobs"], "forward_passes": tot["passes"], "dp_cells": tot["cells"],
-                      "kernel_ms": tot["kernel"], "dp_cells_per_s": tot["cells"] / (tot["kernel"] * 1e-3)},
-           "host_ms": {"prepare": tot["prepare"], "finalize": tot["finalize"], "whole_call": tot["total"]},
-           "indel_pass": {"records": tot.get("records", 0), "glfgen_indel_ms": tot.get("pass_glfgen", 0.0),
-                          "combine_ms": tot.get("pass_combine", 0.0),
-                          "note": "glfgen_kernel<INDEL> + combine_kernel over the columns gap_prep accepted, kernel times"}}
-    for pc in pass_ctx.values():
-        pc.close()
-    # The same batches driven by two caller threads, each with its own context (how a host program double-buffers the
-    # stage: one batch is typed on the host while the device scores the other); wall clock over all batches.
-    if a.indel_callers > 1:
-        import threading
-        batches = [synth.indel_batch(a.seed + c, min(per, n_sites - c), S, depth=a.depth) for c in range(0, n_sites, per)]
-        ctxs = [ctx] + [engine.Context(abi.default_cfg(S, max_sites=per, max_reads=64)) for _ in range(a.indel_callers - 1)]
-        for cx in ctxs[1:]:
-            indeldrv.gap_prep_gpu(cx, batches[0])                                    # workspaces sized before the clock starts
-        errs = []
-
-        def run(k):
-            try:
-                for j in range(k, len(batches), len(ctxs)):
-                    indeldrv.gap_prep_gpu(ctxs[k], batches[j])
-            except Exception as e:                                                    # surfaced after the join
-                errs.append(e)
-        th = [threading.Thread(target=run, args=(k,)) for k in range(len(ctxs))]
+           "config": {"workload": "synthetic indel-candidate columns (BASELINE configs[2] shape): one bcfgpu_gap_prep_tile over %d columns of a "
+                                  "region whose read pool bcfgpu_pileup left in HBM" % n_sites,
+                      "samples": S, "depth": a.depth, "sites": n_sites, "pileup_entries": E, "region_columns": len(b["ref"]),
+                      "pileup_ms_untimed": t_pileup * 1e3},
+           "kernel": {"name": "probaln_exact_kernel<band, pass> (+ job decode, radix sort)", "jobs": tot["jobs"] // steps,
+                      "forward_passes": tot["passes"] // steps, "dp_cells": tot["cells"] // steps,
+                      "kernel_ms": per("kernel"), "dp_cells_per_s": cells_per_s,
+                      "fp64_flop_per_s": cells_per_s * 6.0,
+                      "fp64_frac_of_vector_peak": cells_per_s * 6.0 / 78.6e12, "fp64_frac_of_mul_add_peak": cells_per_s * 6.0 / 39.3e12,
+                      "flop_note": "18 fp64 multiplies/adds per band position (3 cells) in the reference's operation order, no FMA "
+                                   "(contraction would change the integer scores): the mul/add-only peak is half the 78.6 TFLOP/s vector FMA peak"},
+           "host_ms": {"prepare": per("prepare"), "finalize": per("finalize"), "whole_call": per("wall") * 1e3, "library_total": per("total")},
+           "indel_pass": {"records": records, "glfgen_indel_ms": per("pass_glfgen"), "combine_ms": per("pass_combine"),
+                          "note": "glfgen_kernel<INDEL> + combine_kernel on the tile gap_prep_tile left in HBM (all candidate columns), kernel times"}}
+    # the host-pointer form of the same stage (every array over PCIe both ways), for comparison: 32-column batches
+    if a.indel_callers > 0:
+        hb = synth.indel_batch(a.seed, min(32, n_sites), S, depth=a.depth)
+        hctx = engine.Context(abi.default_cfg(S, max_sites=32, max_reads=64))
+        indeldrv.gap_prep_gpu(hctx, hb)
         t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        tw = time.perf_counter() - t0
-        if errs:
-            raise errs[0]
-        out["overlapped"] = {"callers": len(ctxs), "value": sum(b["n_sites"] for b in batches) / tw, "unit": "sites/s",
-                             "wall_ms": tw * 1e3, "note": "one context per caller thread, batches taken alternately"}
-        for cx in ctxs[1:]:
-            cx.close()
+        _, hst = indeldrv.gap_prep_gpu(hctx, hb)
+        th = time.perf_counter() - t0
+        out["host_pointer_form"] = {"value": hb["n_sites"] / th, "unit": "sites/s", "whole_call_ms": th * 1e3, "prepare_ms": hst.prepare_ms,
+                                    "note": "bcfgpu_gap_prep with host pointers, one 32-column batch: uploads of the reads and entries, download of p->aux"}
+        hctx.close()
     if a.cpu_seconds > 0:
-        b, got = first
+        # the oracle on one host core, first columns; results compared with the device path (entries matched through the pool order)
+        cell = np.repeat(np.arange(n_sites * S), np.diff(b["smpl_off"]))
+        dev2batch = pool.order[np.argsort(cell[pool.order], kind="stable")]
+        gaux, _, _ = pool.gap_prep_tile(want_aux=True)
+        aux_batch = np.zeros(E, np.uint32)
+        aux_batch[dev2batch] = gaux["aux"]
+        chk = dict(got, aux=aux_batch)
         t0 = time.perf_counter()
         k = 0
-        while k < b["n_sites"] and (k < 1 or time.perf_counter() - t0 < a.cpu_seconds):
-            indeldrv.assert_site_equal(got, k, indeldrv.gap_prep_oracle_site(b, k))
+        while k < n_sites and (k < 1 or time.perf_counter() - t0 < a.cpu_seconds):
+            indeldrv.assert_site_equal(chk, k, indeldrv.gap_prep_oracle_site(b, k))
             k += 1
         tc = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": k / tc, "unit": "sites/s", "cores": 1, "kind": "port",
-                               "sample": "first %d columns of the first batch, oracle orc_gap_prep on one host core, %.1f s "
+                               "sample": "first %d columns, oracle orc_gap_prep on one host core, %.1f s "
                                          "(results compared with the device path)" % (k, tc)}
     print(json.dumps(out), flush=True)
     ctx.close()
@@ -676,12 +674,12 @@ def main():
             common = ["--cpu-seconds", "0", "--cpu-all-cores", "0", "--extras", "0", "--seed", str(a.seed)]
             c4 = child(["--groups", "4", "--haploid-frac", "0.25", "--steps", str(max(3, a.steps // 2)), "--warmup", "2",
                         "--samples", str(S), "--depth", str(a.depth), "--sites", str(T)] + common)
-            ind = child(["--mode", "indel", "--steps", "4"] + common)
+            ind = child(["--mode", "indel", "--steps", "4", "--cpu-seconds", "8", "--cpu-all-cores", "0", "--extras", "0", "--seed", str(a.seed)])
             out["extra"] = {
                 "configs4_shape": {k: c4.get(k) for k in ("value", "unit", "ms_per_step", "config", "roofline", "error") if k in c4},
-                "indel_stage": {k: ind.get(k) for k in ("metric", "value", "unit", "config", "kernel", "host_ms", "indel_pass", "error") if k in ind},
+                "indel_stage": {k: ind.get(k) for k in ("metric", "value", "unit", "config", "kernel", "host_ms", "indel_pass", "host_pointer_form", "cpu_baseline", "error") if k in ind},
                 "note": "configs4_shape: the same tile through call -G (4 sample groups on FORMAT/AD) with a ploidy array (25 % haploid); "
-                        "indel_stage: bcf_call_gap_prep on 500-sample indel-candidate columns (BASELINE configs[2] shape), whole calls with host pointers"}
+                        "indel_stage: bcf_call_gap_prep on 500-sample indel-candidate columns (BASELINE configs[2] shape), bcfgpu_gap_prep_tile on a read pool resident in HBM"}
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

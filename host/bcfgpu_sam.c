@@ -15,7 +15,7 @@
  *      bcfgpu_pileup         the pileup columns of the region, built in HBM
  *      bcfgpu_mpileup        bcf_call_glfgen x samples + bcf_call_combine per column (mpileup.c:343-347)
  *  and for the columns where some read is followed by an indel (mpileup.c:354-365):
- *      bcfgpu_pileup_entries -> bcfgpu_gap_prep (bcf_call_gap_prep) -> bcfgpu_pileup_indel_tile -> bcfgpu_mpileup
+ *      bcfgpu_gap_prep_tile (bcf_call_gap_prep on the candidate columns, in HBM) -> bcfgpu_mpileup on its indel tile
  *  and the record loop writes what bcf_call2bcf (bam2bcf.c:756-906) puts in the record, in its order, under mpileup's header
  *  (mpileup.c:510-602), as VCF, bgzipped VCF or BCF (host/vcfio.c).  tests/test_c_host.py compares the whole output with the
  *  reference's goldens test/mpileup/mpileup.{1..11}.out and mpileup-SCR.out.
@@ -821,42 +821,29 @@ int main(int argc, char **argv)
     /* ---- indel records (mpileup.c:354-365): candidate columns -> bcf_call_gap_prep -> second pass with p->aux ---- */
     int nc = 0;
     int32_t *cand = malloc((size_t)(n_sites + 1) * sizeof *cand);
-    int64_t cap = 0;
     for (int k = 0; k < n_sites; ++k)
-        if (col_indel[k] && col_n[k] < 250 * S) { cand[nc++] = k; cap += col_n[k]; }      /* max_indel_depth */
+        if (col_indel[k] && col_n[k] < 250 * S) cand[nc++] = k;      /* max_indel_depth */
     bcfgpu_site *isite = NULL;
     planes_t ind_planes; memset(&ind_planes, 0, sizeof ind_planes); int32_t *live = NULL; int nlive = 0;
     int32_t *g_types = NULL, *g_maxins = NULL, *g_indelreg = NULL, *g_support = NULL; float *g_frac = NULL; int8_t *g_inscns = NULL;
     if (nc) {
-        int32_t *so = malloc(((size_t)nc * S + 1) * sizeof *so), *pr = malloc((size_t)(cap + 1) * 4), *pq = malloc((size_t)(cap + 1) * 4),
-                *pi = malloc((size_t)(cap + 1) * 4), *cpos = malloc((size_t)nc * 4);
-        CHECK(bcfgpu_pileup_entries(ctx, nc, cand, so, pr, pq, pi, cap));
-        for (int i = 0; i < nc; ++i) cpos[i] = beg + cand[i];
+        /* everything stays in HBM: the candidates' entries, the stage on the pool bcfgpu_pileup left there, p->aux straight
+         * into the indel pass's tile over all candidate columns (the host pool is passed for its ZQ bytes) */
         bcfgpu_indel_in in; memset(&in, 0, sizeof in);
-        in.n_sites = nc; in.n_smpl = S; in.pos = cpos; in.smpl_off = so; in.p_read = pr; in.p_qpos = pq; in.p_indel = pi; in.ref = ref;
+        in.n_sites = nc; in.n_smpl = S; in.ref = ref;
         in.openQ = 40; in.extQ = 20; in.tandemQ = 100; in.min_support = 1; in.per_sample_flt = 0; in.min_frac = 0.002;   /* mpileup.c:937-950 */
         bcfgpu_indel_out out; memset(&out, 0, sizeof out);
         int32_t *gret = malloc((size_t)nc * 4);
-        uint32_t *aux = malloc((size_t)(cap + 1) * 4);
         g_types = malloc((size_t)nc * 16); g_inscns = malloc((size_t)nc * 4 * INSCNS_CAP); g_maxins = malloc((size_t)nc * 4);
         g_indelreg = malloc((size_t)nc * 4); g_support = malloc((size_t)nc * 4); g_frac = malloc((size_t)nc * 4);
-        out.ret = gret; out.p_aux = aux; out.indel_types = g_types; out.inscns = g_inscns; out.maxins = g_maxins;
+        out.ret = gret; out.p_aux = NULL; out.indel_types = g_types; out.inscns = g_inscns; out.maxins = g_maxins;
         out.indelreg = g_indelreg; out.max_support = g_support; out.max_frac = g_frac;
-        CHECK(bcfgpu_gap_prep(ctx, &rd, &in, &out, INSCNS_CAP));
+        bcfgpu_tile ti;
+        CHECK(bcfgpu_gap_prep_tile(ctx, nc, cand, &rd, &in, &out, INSCNS_CAP, &ti));
         live = malloc((size_t)nc * 4);
-        int32_t *lcols = malloc((size_t)nc * 4);
-        uint32_t *laux = malloc((size_t)(cap + 1) * 4);
-        int64_t nl = 0;
-        for (int i = 0; i < nc; ++i)
-            if (gret[i] == 0) {
-                live[nlive] = i; lcols[nlive++] = cand[i];
-                for (int e = so[(size_t)i * S]; e < so[(size_t)(i + 1) * S]; ++e) laux[nl++] = aux[e];
-            }
-        if (nlive) {
-            bcfgpu_tile ti;
-            CHECK(bcfgpu_pileup_indel_tile(ctx, nlive, lcols, laux, nl, &ti));
-            run_mpileup(ctx, &ti, nlive, &isite, &ind_planes, NULL, NULL, NULL);
-        }
+        for (int i = 0; i < nc; ++i) if (gret[i] == 0) live[nlive++] = i;
+        if (nlive) run_mpileup(ctx, &ti, nc, &isite, &ind_planes, NULL, NULL, NULL);      /* records of columns with ret < 0 are not used */
+        free(gret);
     }
 
     /* ---- --gvcf: reference-only records collapse into blocks (gvcf_write, gvcf.c:88-226) on the planes still in HBM ---- */
@@ -864,7 +851,7 @@ int main(int argc, char **argv)
     if (gv_n) {
         int32_t *pos = malloc((size_t)n_sites * 4); uint8_t *brk = calloc((size_t)n_sites, 1);
         for (int k = 0; k < n_sites; ++k) { pos[k] = beg + k; if (col_n[k] == 0) brk[k] |= 2; }
-        for (int j = 0; j < nlive; ++j) if (isite[j].ret == 0) brk[cand[live[j]]] |= 1;      /* an indel record follows the SNP record */
+        for (int j = 0; j < nlive; ++j) if (isite[live[j]].ret == 0) brk[cand[live[j]]] |= 1;      /* an indel record follows the SNP record */
         void *d_pos, *d_brk, *d_blk, *d_min, *d_block, *d_gdp, *d_gpl;
         CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_pos)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites, &d_brk));
         CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_blk)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_min));
@@ -917,15 +904,15 @@ int main(int argc, char **argv)
         print_record(contig, beg + k + 1, als, "", c, &snp_planes, (size_t)k, S);
         }
         while (jl < nlive && cand[live[jl]] < k) ++jl;
-        if (jl < nlive && cand[live[jl]] == k && isite[jl].ret == 0) {
+        if (jl < nlive && cand[live[jl]] == k && isite[live[jl]].ret == 0) {
             /* REF / ALT of an indel record (bam2bcf.c:767-790) */
             const int i = live[jl], p = beg + k, ireg = g_indelreg[i], mi = g_maxins[i];
             char *txt = malloc((size_t)(5 * (ireg + mi + 8)) + 64), prefix[64];
             int t = 0;
             for (int j = 0; j <= ireg; ++j) txt[t++] = ref[p + j];
             txt[t++] = '\t';
-            for (int a = 1; a < 4 && isite[jl].a[a] >= 0; ++a) {
-                const int ai = isite[jl].a[a], ty = g_types[i * 4 + ai];
+            for (int a = 1; a < 4 && isite[i].a[a] >= 0; ++a) {
+                const int ai = isite[i].a[a], ty = g_types[i * 4 + ai];
                 if (a > 1) txt[t++] = ',';
                 txt[t++] = ref[p];
                 if (ty < 0) { for (int j = p + 1 - ty; j < p + 1 + ireg; ++j) txt[t++] = ref[j]; }
@@ -936,7 +923,7 @@ int main(int argc, char **argv)
             }
             txt[t] = 0;
             snprintf(prefix, sizeof prefix, "INDEL;IDV=%d;IMF=%g;", g_support[i], (double)g_frac[i]);
-            print_record(contig, p + 1, txt, prefix, &isite[jl], &ind_planes, (size_t)jl, S);
+            print_record(contig, p + 1, txt, prefix, &isite[i], &ind_planes, (size_t)i, S);
             free(txt);
         }
     }

@@ -290,11 +290,11 @@ int  bcfgpu_pipeline(bcfgpu_ctx *ctx, const bcfgpu_tile *tile, const uint8_t *pl
                      const bcfgpu_mplp_out *mout, const bcfgpu_call_out *cout);
 
 /* ---- indel candidates: bcf_call_gap_prep (bam2bcf.h:141, bam2bcf_indel.c:99-470) for a batch of positions --------
- * Candidate typing, the per-sample consensus and the insertion consensus are small irregular host work and run on
- * the CPU inside this call; the realignment of every read against every candidate type (probaln_glocal, "the
- * bottleneck", bam2bcf_indel.c:335) runs on the device for the whole batch; indelQ/seqQ and the choice of the <=4
- * output types are finished on the host (the host parts run on up to 16 threads over contiguous chunks of sites; the
- * environment variable BCFGPU_HOST_THREADS overrides the count).  All pointers here are HOST pointers.
+ * Every stage runs on the device (csrc/gap_prep.hip, csrc/indel.hip): candidate typing, the insertion and per-sample
+ * consensus, the realignment of every read against every candidate type (probaln_glocal, "the bottleneck",
+ * bam2bcf_indel.c:335) and indelQ / seqQ with the choice of the <= 4 output types.  The host side of this call uploads
+ * the arrays, launches, and brings the results back.  All pointers here are HOST pointers; bcfgpu_gap_prep_tile is the
+ * form for callers whose reads are already in HBM (after bcfgpu_pileup).
  * Reads are a flat pool: r_* arrays indexed by read, cig/seq16/qual/zq pools indexed through r_cig_off / r_seq_off
  * (seq16: one 4-bit nt16 code per byte; qual: the qualities the pileup sees; zq: "ZQ" tag bytes, r_has_zq flags).
  * Pileup entries of (site k, sample s): smpl_off[k*n_smpl+s] .. smpl_off[k*n_smpl+s+1]-1 into p_read/p_qpos/p_indel. */
@@ -390,6 +390,22 @@ int  bcfgpu_pileup_entries(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols,
  * valid until the next call of this function or of bcfgpu_pileup on this context. */
 int  bcfgpu_pileup_indel_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols, const uint32_t *aux, int64_t n_aux,
                               bcfgpu_tile *tile);
+
+/* bcf_call_gap_prep for candidate columns of the last bcfgpu_pileup on this context with everything staying in HBM: the
+ * entries of the columns are listed on the device (what bcfgpu_pileup_entries would download), the stage runs on the read
+ * pool bcfgpu_pileup left there, and p->aux goes straight into the indel pass's tile (what bcfgpu_pileup_indel_tile would
+ * build from an uploaded array).  The host-pointer chain bcfgpu_pileup_entries -> bcfgpu_gap_prep -> bcfgpu_pileup_indel_tile
+ * gives the same results.
+ *   cols   HOST [n_cols], ascending column indices of the last bcfgpu_pileup (the candidates: col_indel != 0)
+ *   reads  HOST, the pool handed to bcfgpu_pileup, or NULL: only zq / r_has_zq are read (the "ZQ" bytes bcfgpu_baq left;
+ *          uploaded here because the pileup itself does not need them)
+ *   par    the options of bcfgpu_indel_in (openQ ... min_frac) and `ref`; its array pointers are ignored
+ *   out    HOST arrays per column as for bcfgpu_gap_prep; p_aux may be NULL (the words stay on the device)
+ *   tile   out: DEVICE pointers, the indel pass's tile over ALL n_cols columns (is_indel = 1, aux set), ready for
+ *          bcfgpu_mpileup; the records of columns with ret[i] < 0 are to be dropped by the caller (mpileup.c:354).
+ *          Valid until the next bcfgpu_gap_prep_tile / bcfgpu_gap_prep / bcfgpu_pileup* call on this context. */
+int  bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols, const bcfgpu_reads *reads,
+                          const bcfgpu_indel_in *par, const bcfgpu_indel_out *out, int inscns_cap, bcfgpu_tile *tile);
 
 /* ---- gVCF blocks (mpileup --gvcf, gvcf.c:88-226) ---------------------------------
  * gvcf_write() collapses runs of reference-only records into blocks: a record can join when it has only REF and <*>

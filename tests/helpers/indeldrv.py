@@ -42,6 +42,53 @@ def gap_prep_gpu(ctx, b, **kw):
     return out, st
 
 
+class DevicePool:
+    """A synthetic batch's reads as a pool in HBM: bcfgpu_pileup over the batch's whole reference (done once), after which
+    bcfgpu_gap_prep_tile runs on the candidate columns with nothing crossing PCIe but the per-column results."""
+
+    def __init__(self, ctx, b):
+        from bcftools_amd import synth
+        from bcftools_amd.lib import check
+        self.ctx, self.b = ctx, b
+        self.reads, mapq, smpl, self.order = synth.indel_pool(b)
+        self.rd = abi.Reads()
+        self.rd.n_reads = self.reads["n_reads"]
+        for k in READ_KEYS:
+            setattr(self.rd, k, self.reads[k].ctypes.data)
+        self.beg, self.end = 0, len(b["ref"])
+        self.tile = abi.Tile()
+        self.col_n = np.zeros(self.end - self.beg, np.int32)
+        self.col_indel = np.zeros(self.end - self.beg, np.uint8)
+        check(ctx.L.bcfgpu_pileup(ctx.h, C.byref(self.rd), mapq.ctypes.data, smpl.ctypes.data, self.beg, self.end, b["ref"], len(b["ref"]),
+                                  C.byref(self.tile), self.col_n.ctypes.data, self.col_indel.ctypes.data))
+        self.cols = np.ascontiguousarray(b["pos"] - self.beg, dtype=np.int32)
+
+    def gap_prep_tile(self, want_aux=False, **kw):
+        """Returns (dict of output arrays, abi.GapStats, abi.Tile): bcfgpu_gap_prep_tile over the batch's columns."""
+        from bcftools_amd.lib import check
+        o = dict(DEFAULTS, **kw)
+        ctx, b = self.ctx, self.b
+        ns = b["n_sites"]
+        par = abi.IndelIn()
+        par.ref = b["ref"]
+        for k, v in o.items():
+            setattr(par, k, v)
+        E = int(self.col_n[self.cols].sum())
+        out = dict(ret=np.zeros(ns, np.int32), aux=np.zeros(E if want_aux else 0, np.uint32), indel_types=np.zeros((ns, 4), np.int32),
+                   inscns=np.zeros((ns, 4 * CAP), np.int8), maxins=np.zeros(ns, np.int32), indelreg=np.zeros(ns, np.int32),
+                   max_support=np.zeros(ns, np.int32), max_frac=np.zeros(ns, np.float32))
+        oo = abi.IndelOut()
+        oo.ret, oo.indel_types, oo.inscns = out["ret"].ctypes.data, out["indel_types"].ctypes.data, out["inscns"].ctypes.data
+        oo.p_aux = out["aux"].ctypes.data if want_aux else None
+        oo.maxins, oo.indelreg, oo.max_support, oo.max_frac = (out["maxins"].ctypes.data, out["indelreg"].ctypes.data,
+                                                               out["max_support"].ctypes.data, out["max_frac"].ctypes.data)
+        t = abi.Tile()
+        check(ctx.L.bcfgpu_gap_prep_tile(ctx.h, ns, self.cols.ctypes.data, None, C.byref(par), C.byref(oo), CAP, C.byref(t)))
+        st = abi.GapStats()
+        check(ctx.L.bcfgpu_gap_prep_stats(ctx.h, C.byref(st)))
+        return out, st, t
+
+
 def gap_prep_oracle_site(b, k, **kw):
     """orc_gap_prep for site k of the batch; returns None (ret<0) or dict like one row of gap_prep_gpu's output."""
     o = dict(DEFAULTS, **kw)

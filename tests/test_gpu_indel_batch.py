@@ -94,3 +94,24 @@ def test_two_callers_with_their_own_contexts(gpu_ctx_factory):
     for g, w in zip(got, want):
         for key in w:
             np.testing.assert_array_equal(g[key], w[key], err_msg=key)
+
+
+@pytest.mark.parametrize("seed,n_sites,n_smpl,depth", [(91, 12, 20, 15.0), (92, 5, 64, 30.0)])
+def test_gap_prep_tile_on_a_device_pool_matches_the_host_batch(gpu_ctx_factory, seed, n_sites, n_smpl, depth):
+    """bcfgpu_gap_prep_tile (reads and entries never leave HBM after bcfgpu_pileup) against bcfgpu_gap_prep on the same
+    batch with host pointers (itself checked against the oracle above).  The pool is position-sorted per sample, so the
+    entries of a column come in another order than the batch lists them: p->aux is compared read by read."""
+    b = synth.indel_batch(seed, n_sites, n_smpl, depth=depth)
+    ctx = gpu_ctx_factory(abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(b["p_read"]) + 64))
+    want, _ = indeldrv.gap_prep_gpu(ctx, b)
+    pool = indeldrv.DevicePool(ctx, b)
+    assert np.array_equal(pool.col_n[pool.cols], np.diff(b["smpl_off"][::n_smpl]))
+    for rep in range(2):                      # the second call runs on workspaces the first one left behind
+        got, st, tile = pool.gap_prep_tile(want_aux=True)
+        for key in ("ret", "indel_types", "inscns", "maxins", "indelreg", "max_support", "max_frac"):
+            np.testing.assert_array_equal(got[key], want[key], err_msg=key)
+        cell = np.repeat(np.arange(n_sites * n_smpl), np.diff(b["smpl_off"]))
+        dev2batch = pool.order[np.argsort(cell[pool.order], kind="stable")]
+        np.testing.assert_array_equal(got["aux"], want["aux"][dev2batch], err_msg="p->aux")
+        assert tile.n_sites == n_sites and tile.n_reads == len(b["p_read"]) and tile.is_indel == 1
+        assert st.n_jobs > 0 and st.n_passes >= st.n_jobs // 2

@@ -314,6 +314,39 @@ def test_indel_records_from_the_device_pileup(golden_dir, files, fa, contig, beg
         ctx.sync()
         ctx._download(ob, res)
         ctx.release(list(ob.values()))
+        # the same with everything staying in HBM: bcfgpu_gap_prep_tile on the pool the pileup left there (the host pool is
+        # passed for its ZQ bytes only), p->aux written straight into the indel pass's tile over all candidate columns
+        rdz = abi.Reads()
+        rdz.n_reads = len(pool)
+        rdz.zq, rdz.r_has_zq = d["zq"].ctypes.data, d["r_has_zq"].ctypes.data
+        par = abi.IndelIn()
+        par.ref = prep.refseq.encode()
+        for kk, vv in indeldrv.DEFAULTS.items():
+            setattr(par, kk, vv)
+        got2 = dict(ret=np.zeros(len(cols), np.int32), aux=np.zeros(cap, np.uint32), indel_types=np.zeros((len(cols), 4), np.int32),
+                    inscns=np.zeros((len(cols), 4 * indeldrv.CAP), np.int8), maxins=np.zeros(len(cols), np.int32),
+                    indelreg=np.zeros(len(cols), np.int32), max_support=np.zeros(len(cols), np.int32), max_frac=np.zeros(len(cols), np.float32))
+        oo = abi.IndelOut()
+        oo.ret, oo.p_aux, oo.indel_types, oo.inscns = (got2["ret"].ctypes.data, got2["aux"].ctypes.data, got2["indel_types"].ctypes.data,
+                                                      got2["inscns"].ctypes.data)
+        oo.maxins, oo.indelreg, oo.max_support, oo.max_frac = (got2["maxins"].ctypes.data, got2["indelreg"].ctypes.data,
+                                                               got2["max_support"].ctypes.data, got2["max_frac"].ctypes.data)
+        t2 = abi.Tile()
+        check(ctx.L.bcfgpu_gap_prep_tile(ctx.h, len(cols), cols.ctypes.data, C.byref(rdz), C.byref(par), C.byref(oo), indeldrv.CAP, C.byref(t2)))
+        for key in got:
+            np.testing.assert_array_equal(got2[key], got[key], err_msg="gap_prep_tile " + key)
+        assert t2.n_sites == len(cols) and t2.n_reads == cap and t2.is_indel == 1
+        o2, ob2, res2 = ctx.alloc_mplp_out(len(cols))
+        for bb in ob2.values():
+            check(ctx.L.bcfgpu_memset(ctx.h, bb.ptr, 0, bb.nbytes))
+        check(ctx.L.bcfgpu_mpileup(ctx.h, C.byref(t2), C.byref(o2)))
+        ctx.sync()
+        ctx._download(ob2, res2)
+        ctx.release(list(ob2.values()))
+        for j, k in enumerate(live):            # column k of the all-candidates tile = accepted column j of the host chain
+            assert res2.site[k].tobytes() == res.site[j].tobytes()
+            for name in ("pl", "dp4", "adf", "adr", "qs"):
+                np.testing.assert_array_equal(getattr(res2, name)[k], getattr(res, name)[j], err_msg=name)
     seen = 0
     for j, k in enumerate(live):
         p = int(cols[k]) + beg
