@@ -345,69 +345,70 @@ __global__ __launch_bounds__(64) void gap_inscns_kernel(const GapIn in, GapSite 
 }
 
 // ---- per-sample consensus and the realignment targets ----
-// One workgroup of two wavefronts per (site, sample), a lane per window column: the lane keeps its column's reference
-// code and its match / mismatch counts in registers while the workgroup goes through the sample's reads together
-// (the CIGAR walk is the same for every lane, the read's bases under the window are consecutive bytes): no atomics, and
-// every lane is busy whatever the sample's depth.
-#define GAP_CONS_THREADS 128
+// One wavefront per (site, sample), a lane per window column (two columns per lane: the window is ~100 wide): the lane
+// keeps its columns' reference codes and match / mismatch counts in registers while the wavefront goes through the
+// sample's reads together.  Each lane fetches one read's record (four dependent loads that the whole wavefront would
+// otherwise wait out read after read); the record travels to every lane through v_readlane into scalar registers, so the
+// CIGAR walk is scalar code and only the base under the lane's column is a vector load.  Reads whose CIGAR is one match
+// operation -- the common case -- go four at a time, their base loads in flight together.  No atomics, no LDS traffic,
+// no workgroup barrier in this phase, and every lane is busy whatever the sample's depth.
+#define GAP_CONS_THREADS 64
 __global__ __launch_bounds__(GAP_CONS_THREADS) void gap_cons_kernel(const GapIn in, const GapSite *sites, const int8_t *inscns, uint8_t *ref2pool)
 {
     extern __shared__ uint32_t s_cns[];            // [max_L] counts, then [max_L] bytes: the sample's consensus codes
     __shared__ int s_m[2];
-    __shared__ int4 s_rd[GAP_CONS_THREADS];        // a read: reference start, offset of its bases, CIGAR length and offset
-    __shared__ uint32_t s_c0[GAP_CONS_THREADS];    // its first CIGAR operation
     const int is = blockIdx.x / in.n_smpl, s = blockIdx.x % in.n_smpl, tid = threadIdx.x;
     const GapSite &S = sites[is];
     if (!S.live) return;
     const int left = S.left, right = S.right, W = right - left, pos = S.pos;
     const int32_t *soff = in.smpl_off + (size_t)is * in.n_smpl;
     const int e0 = soff[s], e1 = soff[s + 1];
-    // ref and non-ref counts of every window column (:203-220).  The reads' records come through LDS, GAP_CONS_THREADS reads
-    // at a time, fetched by one lane each (four dependent loads per read that the whole workgroup would otherwise wait out
-    // read after read); reads whose CIGAR is one match operation -- the common case -- go four at a time, their base loads
-    // in flight together.
-    uint32_t cnt0 = 0, cnt1 = 0;                              // this lane's columns tid and tid + GAP_CONS_THREADS
+    uint32_t cnt0 = 0, cnt1 = 0;                              // this lane's columns tid and tid + 64
     const int colA = left + tid, colB = colA + GAP_CONS_THREADS;
     const bool mineA = tid < W, mineB = tid + GAP_CONS_THREADS < W;
     const int rcA = mineA ? gap_nt16_of(gap_ref(in, colA)) : -1, rcB = mineB ? gap_nt16_of(gap_ref(in, colB)) : -1;
-    auto general = [&](const int4 rd, uint32_t cg) {
-        const uint8_t *seq = in.seq16 + rd.y;
-        int x = rd.x, y = 0;
-        for (int k = 0; k < rd.z; ++k) {
-            if (k) cg = in.cig[rd.w + k];
-            const int op = cg & 0xf, l = (int)(cg >> 4);
-            if (op == 0 || op == 7 || op == 8) {
-                if (mineA && colA >= x && colA < x + l) cnt0 += (int)(seq[y + (colA - x)] & 15) == rcA ? 1u : 0x10000u;
-                if (mineB && colB >= x && colB < x + l) cnt1 += (int)(seq[y + (colB - x)] & 15) == rcB ? 1u : 0x10000u;
-                x += l; y += l;
-            } else if (op == 2 || op == 3) x += l;
-            else if (op == 1 || op == 4) y += l;
-        }
-    };
     for (int eb = e0; eb < e1; eb += GAP_CONS_THREADS) {
         const int nb = min(GAP_CONS_THREADS, e1 - eb);
-        __syncthreads();
+        int my_pos = 0, my_soff = 0, my_ncig = 0, my_coff = 0; uint32_t my_c0 = 0;
         if (tid < nb) {
             const int r = in.p_read[eb + tid];
-            const int ncig = in.r_ncig[r];
-            s_rd[tid] = make_int4(in.r_pos[r], in.r_seq_off[r], ncig, in.r_cig_off[r]);
-            s_c0[tid] = ncig > 0 ? in.cig[in.r_cig_off[r]] : 0u;
+            my_pos = in.r_pos[r]; my_soff = in.r_seq_off[r]; my_ncig = in.r_ncig[r]; my_coff = in.r_cig_off[r];
+            my_c0 = my_ncig > 0 ? in.cig[my_coff] : 0u;
         }
-        __syncthreads();
+        auto general = [&](int k) {                           // read k of this round, any CIGAR
+            const int x0 = __builtin_amdgcn_readlane(my_pos, k), ncig = __builtin_amdgcn_readlane(my_ncig, k);
+            const int coff = __builtin_amdgcn_readlane(my_coff, k);
+            const uint8_t *seq = in.seq16 + __builtin_amdgcn_readlane(my_soff, k);
+            uint32_t cg = (uint32_t)__builtin_amdgcn_readlane((int)my_c0, k);
+            int x = x0, y = 0;
+            for (int c = 0; c < ncig; ++c) {
+                if (c) cg = in.cig[coff + c];
+                const int op = cg & 0xf, l = (int)(cg >> 4);
+                if (op == 0 || op == 7 || op == 8) {
+                    if (mineA && colA >= x && colA < x + l) cnt0 += (int)(seq[y + (colA - x)] & 15) == rcA ? 1u : 0x10000u;
+                    if (mineB && colB >= x && colB < x + l) cnt1 += (int)(seq[y + (colB - x)] & 15) == rcB ? 1u : 0x10000u;
+                    x += l; y += l;
+                } else if (op == 2 || op == 3) x += l;
+                else if (op == 1 || op == 4) y += l;
+            }
+        };
         int k0 = 0;
         for (; k0 + 4 <= nb; k0 += 4) {
-            int4 rd[4]; uint32_t cg[4];
+            int x[4], l[4], so[4];
             bool simple = true;
             #pragma unroll
-            for (int u = 0; u < 4; ++u) { rd[u] = s_rd[k0 + u]; cg[u] = s_c0[k0 + u]; simple = simple && rd[u].z == 1 && (cg[u] & 0xf) == 0; }
-            if (simple) {                                     // (the same for every lane)
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t cg = (uint32_t)__builtin_amdgcn_readlane((int)my_c0, k0 + u);
+                x[u] = __builtin_amdgcn_readlane(my_pos, k0 + u); so[u] = __builtin_amdgcn_readlane(my_soff, k0 + u); l[u] = (int)(cg >> 4);
+                simple = simple && __builtin_amdgcn_readlane(my_ncig, k0 + u) == 1 && (cg & 0xf) == 0;
+            }
+            if (simple) {
                 int bA[4], bB[4];
                 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int x = rd[u].x, l = (int)(cg[u] >> 4);
-                    const uint8_t *seq = in.seq16 + rd[u].y;
-                    bA[u] = (mineA && colA >= x && colA < x + l) ? (int)(seq[colA - x] & 15) : -2;
-                    bB[u] = (mineB && colB >= x && colB < x + l) ? (int)(seq[colB - x] & 15) : -2;
+                    const uint8_t *seq = in.seq16 + so[u];
+                    bA[u] = (mineA && colA >= x[u] && colA < x[u] + l[u]) ? (int)(seq[colA - x[u]] & 15) : -2;
+                    bB[u] = (mineB && colB >= x[u] && colB < x[u] + l[u]) ? (int)(seq[colB - x[u]] & 15) : -2;
                 }
                 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -415,11 +416,11 @@ __global__ __launch_bounds__(GAP_CONS_THREADS) void gap_cons_kernel(const GapIn 
                     if (bB[u] != -2) cnt1 += bB[u] == rcB ? 1u : 0x10000u;
                 }
             } else {
-                #pragma unroll
-                for (int u = 0; u < 4; ++u) general(rd[u], cg[u]);
+                #pragma unroll 1
+                for (int u = 0; u < 4; ++u) general(k0 + u);
             }
         }
-        for (; k0 < nb; ++k0) general(s_rd[k0], s_c0[k0]);
+        for (; k0 < nb; ++k0) general(k0);
     }
     if (mineA) s_cns[tid] = cnt0;
     if (mineB) s_cns[tid + GAP_CONS_THREADS] = cnt1;
@@ -672,11 +673,11 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
         const size_t nj = (size_t)tot.n_jobs;
         int32_t *d_inscnt = (int32_t*)WS(16, (size_t)tot.ins_bytes * 5 * 4);
         int8_t *d_inscns = (int8_t*)WS(17, (size_t)tot.ins_bytes);
-        uint8_t *d_ref2 = (uint8_t*)WS(18, (size_t)tot.ref2_bytes + 16);
+        uint8_t *d_ref2 = (uint8_t*)WS(18, (size_t)tot.ref2_bytes + 64);      // (the realignment reads 8 bytes at a time, up to two groups ahead)
         int32_t *d_s1 = (int32_t*)WS(19, nj * 4), *d_s2 = (int32_t*)WS(20, nj * 4);
         uint32_t *d_wide = (uint32_t*)WS(21, nj * 4);
         GapEntry *d_ent = (GapEntry*)WS(29, n_ent * sizeof(GapEntry));
-        uint8_t *d_qpack = (uint8_t*)WS(30, (size_t)tot.qpack8 * 8 + 16);
+        uint8_t *d_qpack = (uint8_t*)WS(30, (size_t)tot.qpack8 * 8 + 64);
         PJob *d_pjob = (PJob*)WS(31, nj * sizeof(PJob));
         uint32_t *d_k0 = (uint32_t*)WS(32, nj * 4), *d_v0 = (uint32_t*)WS(33, nj * 4), *d_k1 = (uint32_t*)WS(34, nj * 4), *d_v1 = (uint32_t*)WS(35, nj * 4);
         uint32_t *d_list2 = (uint32_t*)WS(36, nj * 4);

@@ -129,7 +129,7 @@ template <int BW>
 __device__ __forceinline__ int probaln_fwd_exact(const uint8_t *ref, int l_ref, const uint8_t *qp, int l_query,
                                                  const double2 *emt, double d, double e_, int bw)
 {
-    constexpr int W = 2 * BW + 1;
+    constexpr int W = 2 * BW + 1, NB = (W + 3) / 4;
     double M[W + 2], I[W + 2], D[W + 2];
     #pragma unroll
     for (int p = 0; p < W + 2; ++p) M[p] = I[p] = D[p] = 0.;
@@ -140,10 +140,20 @@ __device__ __forceinline__ int probaln_fwd_exact(const uint8_t *ref, int l_ref, 
     const double m1q = EI * m1, m4q = EI * m4;
     const double bM = (1 - d) / l_ref, bI = d / l_ref;
     const int top = 2 * bw + 1;
-    // reference window: the base of position p in bits [3(p-1), 3p); row 1: k = p - bw
-    uint64_t rw = 0;
+    // reference window: the base code of position p in byte p-1 of wv[] (a byte per position: the comparison with the query
+    // base reads it through an operand byte-select, no shift or mask); row 1: k = p - bw
+    uint32_t wv[NB];
     #pragma unroll
-    for (int p = 1; p <= W; ++p) { const int k = p - bw; rw |= (uint64_t)((k >= 1 && k <= l_ref) ? ref[k - 1] : 0) << (3 * (p - 1)); }
+    for (int j = 0; j < NB; ++j) wv[j] = 0;
+    #pragma unroll
+    for (int p = 1; p <= W; ++p) { const int k = p - bw; wv[(p - 1) >> 2] |= (uint32_t)((k >= 1 && k <= l_ref) ? ref[k - 1] : 0) << (8 * ((p - 1) & 3)); }
+    auto wbyte = [&](int p) { return (wv[(p - 1) >> 2] >> (8 * ((p - 1) & 3))) & 0xffu; };
+    auto wshift = [&](uint32_t top_code) {                    // every position one down, top_code into position W
+        #pragma unroll
+        for (int j = 0; j + 1 < NB; ++j) wv[j] = __builtin_amdgcn_alignbyte(wv[j + 1], wv[j], 1);
+        wv[NB - 1] >>= 8;
+        wv[(W - 1) >> 2] |= top_code << (8 * ((W - 1) & 3));
+    };
     double prod = 1., Pr1 = 0.;
     int result = 0;
     uint64_t qw = *(const uint64_t*)qp;
@@ -161,11 +171,11 @@ __device__ __forceinline__ int probaln_fwd_exact(const uint8_t *ref, int l_ref, 
         const int end = l_ref < bw + 1 ? l_ref : bw + 1;
         const int qb = (int)(qw & 0xff);
         const double2 em = emt[qb];
-        const int qy = qb & 7;
+        const uint32_t qy = qb & 7;
         #pragma unroll
         for (int p = 1; p <= W; ++p) {
             const double lv = (p > bw && p <= bw + end) ? 1. : 0.;
-            const int rb = (int)((rw >> (3 * (p - 1))) & 7);
+            const uint32_t rb = wbyte(p);
             const double e = rb > 3 ? 1. : rb == qy ? em.x : em.y;
             const double a = lv * (e * bM), b = lv * (EI * bI);
             M[p] = a; I[p] = b;
@@ -178,47 +188,66 @@ __device__ __forceinline__ int probaln_fwd_exact(const uint8_t *ref, int l_ref, 
         if (l_query == 1) finish();
     }
     int i = 2;
-    for (;; ++i) {                    // fast rows (the last row of a job is always an edge row: it ends with finish())
-        const int kt = i - bw - 1 + W;                    // column of position W
-        const bool fast = i < l_query && bw == BW && kt <= l_ref;
-        if (__builtin_amdgcn_ballot_w64(!fast) != 0) break;
-        const uint64_t nw = (rw >> 3) | ((uint64_t)ref[kt - 1] << (3 * (W - 1)));
-        if (__builtin_amdgcn_ballot_w64((nw & 0x4924924924924924ull) != 0) != 0) break;
-        rw = nw;
-        if (((i - 1) & 7) == 0) qw = *(const uint64_t*)(qp + (i - 1)); else qw >>= 8;
-        const int qb = (int)(qw & 0xff);
-        const double2 em = emt[qb];
-        const int qyi = qb & 7;
-        double sum = 0.;
-        #pragma unroll
-        for (int p = 1; p <= W; ++p) {
-            const int rb = (int)((rw >> (3 * (p - 1))) & 7);
-            const double e = rb == qyi ? em.x : em.y;
-            const double f0 = e * (m0 * M[p] + m3 * I[p] + m6 * D[p]);
-            const double f1 = p < W ? m1q * M[p + 1] + m4q * I[p + 1] : 0.;
-            const double f2 = p > 1 ? m2 * M[p - 1] + m8 * D[p - 1] : 0.;
-            sum += f0 + f1 + f2;
-            M[p] = f0; I[p] = f1; D[p] = f2;
+    if (__builtin_amdgcn_ballot_w64(bw != BW || l_query < 3 || l_ref < bw + 2) == 0) {
+        // Fast rows (the last row of a job is always an edge row: it ends with finish()).  Row i shifts reference base
+        // ref[i + bw - 1] into the window and reads query byte i - 1: both streams come eight rows at a time as one 8-byte
+        // load each, issued a group ahead of its first use.
+        const uint8_t *rp = ref + bw + 1;                     // ref[i + bw - 1] for i = 2
+        uint64_t rq, rq_next, qw_next;
+        __builtin_memcpy(&rq, rp, 8);
+        __builtin_memcpy(&rq_next, rp + 8, 8);
+        qw_next = *(const uint64_t*)(qp + 8);
+        qw >>= 8;                                             // byte of row 2
+        for (;; ++i) {
+            const bool fast = i < l_query && i + bw <= l_ref;
+            if (__builtin_amdgcn_ballot_w64(!fast) != 0) break;
+            const uint32_t nb = (uint32_t)(rq & 0xff);
+            // an N about to enter the window (or already in it from row 1): the masked rows handle it
+            uint32_t anyn = nb;
+            #pragma unroll
+            for (int j = 0; j < NB; ++j) anyn |= wv[j];
+            if (__builtin_amdgcn_ballot_w64((anyn & 0x04040404u) != 0) != 0) break;
+            wshift(nb);
+            const int qb = (int)(qw & 0xff);
+            const double2 em = emt[qb];
+            const uint32_t qyi = qb & 7;
+            // the streams move on: row i+1 reads the next byte; every eighth row the group loaded eight rows ago takes over
+            if (((i - 1) & 7) == 0) { rq = rq_next; __builtin_memcpy(&rq_next, rp + (i - 1) + 8, 8); } else rq >>= 8;
+            if ((i & 7) == 0) { qw = qw_next; qw_next = *(const uint64_t*)(qp + i + 8); } else qw >>= 8;
+            double sum = 0.;
+            #pragma unroll
+            for (int p = 1; p <= W; ++p) {
+                const double e = wbyte(p) == qyi ? em.x : em.y;
+                const double f0 = e * (m0 * M[p] + m3 * I[p] + m6 * D[p]);
+                if (p == 1) { const double f1 = m1q * M[p + 1] + m4q * I[p + 1]; sum += f0 + f1; M[p] = f0; I[p] = f1; D[p] = 0.; }
+                else if (p == W) { const double f2 = m2 * M[p - 1] + m8 * D[p - 1]; sum += f0 + f2; M[p] = f0; I[p] = 0.; D[p] = f2; }
+                else {
+                    const double f1 = m1q * M[p + 1] + m4q * I[p + 1];
+                    const double f2 = m2 * M[p - 1] + m8 * D[p - 1];
+                    sum += f0 + f1 + f2;
+                    M[p] = f0; I[p] = f1; D[p] = f2;
+                }
+            }
+            const double r = 1. / sum;
+            #pragma unroll
+            for (int p = 1; p <= W; ++p) { M[p] *= r; I[p] *= r; D[p] *= r; }
+            prod *= sum;
+            if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
         }
-        const double r = 1. / sum;
-        #pragma unroll
-        for (int p = 1; p <= W; ++p) { M[p] *= r; I[p] *= r; D[p] *= r; }
-        prod *= sum;
-        if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
     }
     for (; i <= l_query; ++i) {       // edge rows
         qw = *(const uint64_t*)(qp + ((i - 1) & ~7)) >> (8 * ((i - 1) & 7));
         const int qb = (int)(qw & 0xff);
         const double2 em = emt[qb];
-        const int qyi = qb & 7;
+        const uint32_t qyi = qb & 7;
         const int kt = i - bw - 1 + W;
-        rw = (rw >> 3) | ((uint64_t)(kt <= l_ref ? ref[kt - 1] : 0) << (3 * (W - 1)));
+        wshift(kt <= l_ref ? (uint32_t)ref[kt - 1] : 0u);
         const int hi = l_ref - (i - bw) + 1 < top ? l_ref - (i - bw) + 1 : top;
         double sum = 0.;
         #pragma unroll
         for (int p = 1; p <= W; ++p) {
             const bool live = p <= hi;
-            const int rb = (int)((rw >> (3 * (p - 1))) & 7);
+            const uint32_t rb = wbyte(p);
             double e = rb > 3 ? 1. : rb == qyi ? em.x : em.y;
             e = live ? e : 0.;
             const double tv = live ? 1. : 0.;
@@ -300,10 +329,23 @@ __global__ __launch_bounds__(256) void gap_qpack_kernel(const GapIn in, const Ga
     if (g.smpl < 0 || c * 8 >= lq) return;
     const int r = in.p_read[e];
     const size_t qo = (size_t)in.r_seq_off[r] + g.qbeg + (size_t)c * 8;
-    const QSrc qs{in.seq16 + qo, in.qual + qo, (in.zq && in.r_has_zq && in.r_has_zq[r]) ? in.zq + qo : nullptr};
+    const bool has_zq = in.zq && in.r_has_zq && in.r_has_zq[r];
+    // eight bases, qualities (and ZQ bytes) as one unaligned 8-byte load each (the pools end in >= 8 bytes of slack)
+    uint64_t sv, qv, zv = 0;
+    __builtin_memcpy(&sv, in.seq16 + qo, 8);
+    __builtin_memcpy(&qv, in.qual + qo, 8);
+    if (has_zq) __builtin_memcpy(&zv, in.zq + qo, 8);
     const int nb = lq - c * 8 < 8 ? lq - c * 8 : 8;
     uint64_t v = 0;
-    for (int k = 0; k < nb; ++k) v |= (uint64_t)(qs.base(k) | qs.q(k) << 3) << (8 * k);
+    #pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int base = (int)((0x4444444344424104ull >> (4 * ((sv >> (8 * k)) & 15))) & 7);
+        int q = (int)((qv >> (8 * k)) & 0xff);
+        if (has_zq) q = (int)(uint8_t)(q + ((int)((zv >> (8 * k)) & 0xff) - 64));
+        q = q > 30 ? 30 : q < 7 ? 7 : q;
+        v |= (uint64_t)(base | q << 3) << (8 * k);
+    }
+    if (nb < 8) v &= (1ull << (8 * nb)) - 1;
     *(uint64_t*)(qpack + ((size_t)g.q8 + c) * 8) = v;
 }
 

@@ -201,52 +201,77 @@ struct EntriesParams {
     int32_t *e_read, *e_qpos, *e_indel;
 };
 
+// what the pileup says about read record m at reference position x (htslib resolve_cigar): query offset, indel after x
+__device__ __forceinline__ void entry_of_read(const ReadMeta &m, const uint32_t *cig, int x, int &qpos, int &indel)
+{
+    const uint32_t *cg = cig + m.cig_off;
+    int rx = m.pos, y = 0;
+    qpos = 0; indel = 0;
+    for (int c = 0; c < m.ncig; ++c) {
+        const int op = cg[c] & 0xf, l = (int)(cg[c] >> 4);
+        if (op == 0 || op == 7 || op == 8) {
+            if (x < rx + l) {
+                qpos = y + (x - rx);
+                if (x == rx + l - 1) {
+                    int cc = c + 1;
+                    while (cc < m.ncig && (cg[cc] & 0xf) == 6) ++cc;
+                    if (cc < m.ncig) {
+                        const int nop = cg[cc] & 0xf;
+                        if (nop == 1) {
+                            indel = (int)(cg[cc] >> 4);
+                            for (++cc; cc < m.ncig && ((cg[cc] & 0xf) == 1 || (cg[cc] & 0xf) == 6); ++cc)
+                                if ((cg[cc] & 0xf) == 1) indel += (int)(cg[cc] >> 4);
+                        } else if (nop == 2) indel = -(int)(cg[cc] >> 4);
+                    }
+                }
+                break;
+            }
+            rx += l; y += l;
+        } else if (op == 2 || op == 3) {
+            if (x < rx + l) { qpos = y; break; }
+            rx += l;
+        } else if (op == 1 || op == 4) y += l;
+    }
+}
+
+// FILL = false: a lane per cell (the counts are already in plp_off).  FILL = true: a wavefront per cell, a lane per
+// candidate read; the covering reads keep their order through a ballot prefix count.
 template <bool FILL>
 __global__ __launch_bounds__(256) void entries_kernel(const EntriesParams E)
 {
     const PileupParams &P = E.P;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (!FILL) {
+        const long i = (long)blockIdx.x * 256 + threadIdx.x;
+        if (i >= (long)E.n_cols * P.n_smpl) return;
+        const int ci = (int)(i / P.n_smpl), s = (int)(i - (long)ci * P.n_smpl);
+        const long cell = (long)E.cols[ci] * P.n_smpl + s;
+        E.sel_cnt[i] = P.cnt[cell + 1] - P.cnt[cell];
+        return;
+    }
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i >= (long)E.n_cols * P.n_smpl) return;
     const int ci = (int)(i / P.n_smpl), s = (int)(i - (long)ci * P.n_smpl), site = E.cols[ci];
-    const long cell = (long)site * P.n_smpl + s;
-    if (!FILL) { E.sel_cnt[i] = P.cnt[cell + 1] - P.cnt[cell]; return; }
     const int x = P.beg + site;
     const int lo0 = P.smpl_off[s], hi0 = P.smpl_off[s + 1];
     const int hi = upper_bound(P.s_pos, lo0, hi0, x);
     const int lo = upper_bound(P.s_pos, lo0, hi, x - P.max_span);
     uint32_t o = E.sel_cnt[i];
-    for (int k = lo; k < hi; ++k) {
-        const ReadMeta m = P.meta[k];
-        if (m.end <= x) continue;
-        const uint32_t *cg = P.cig + m.cig_off;
-        int rx = m.pos, y = 0, qpos = 0, indel = 0;
-        for (int c = 0; c < m.ncig; ++c) {
-            const int op = cg[c] & 0xf, l = (int)(cg[c] >> 4);
-            if (op == 0 || op == 7 || op == 8) {
-                if (x < rx + l) {
-                    qpos = y + (x - rx);
-                    if (x == rx + l - 1) {
-                        int cc = c + 1;
-                        while (cc < m.ncig && (cg[cc] & 0xf) == 6) ++cc;
-                        if (cc < m.ncig) {
-                            const int nop = cg[cc] & 0xf;
-                            if (nop == 1) {
-                                indel = (int)(cg[cc] >> 4);
-                                for (++cc; cc < m.ncig && ((cg[cc] & 0xf) == 1 || (cg[cc] & 0xf) == 6); ++cc)
-                                    if ((cg[cc] & 0xf) == 1) indel += (int)(cg[cc] >> 4);
-                            } else if (nop == 2) indel = -(int)(cg[cc] >> 4);
-                        }
-                    }
-                    break;
-                }
-                rx += l; y += l;
-            } else if (op == 2 || op == 3) {
-                if (x < rx + l) { qpos = y; break; }
-                rx += l;
-            } else if (op == 1 || op == 4) y += l;
+    for (int kb = lo; kb < hi; kb += 64) {
+        const int k = kb + lane;
+        bool covers = false;
+        int qpos = 0, indel = 0;
+        if (k < hi) {
+            const ReadMeta m = P.meta[k];
+            covers = m.end > x;
+            if (covers) entry_of_read(m, P.cig, x, qpos, indel);
         }
-        E.e_read[o] = P.s_read[k]; E.e_qpos[o] = qpos; E.e_indel[o] = indel;
-        ++o;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(covers);
+        if (covers) {
+            const uint32_t at = o + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+            E.e_read[at] = P.s_read[k]; E.e_qpos[at] = qpos; E.e_indel[at] = indel;
+        }
+        o += (uint32_t)__popcll(mask);
     }
 }
 
@@ -517,7 +542,7 @@ extern "C" int bcfgpu_pileup_entries(bcfgpu_ctx *ctx, int32_t n_cols, const int3
         int32_t *d_e = (int32_t*)bcfgpu_internal_ws(ctx, 24, (size_t)total * 12 + 16);
         if (!d_e) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup_entries: device workspace");
         E.e_read = d_e; E.e_qpos = d_e + total; E.e_indel = d_e + 2 * (size_t)total;
-        hipLaunchKernelGGL(entries_kernel<true>, dim3(grid), dim3(256), 0, stream, E);
+        hipLaunchKernelGGL(entries_kernel<true>, dim3((unsigned)((nsel + 3) / 4)), dim3(256), 0, stream, E);
         PE_CHK(hipGetLastError());
         PE_CHK(hipMemcpyAsync(p_read, E.e_read, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
         PE_CHK(hipMemcpyAsync(p_qpos, E.e_qpos, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
@@ -674,7 +699,7 @@ extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32
     if (!d_e || !d_out || !d_aux) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
     E.e_read = d_e; E.e_qpos = d_e + total; E.e_indel = d_e + 2 * (size_t)total;
     if (total) {
-        hipLaunchKernelGGL(entries_kernel<true>, dim3(grid), dim3(256), 0, stream, E);
+        hipLaunchKernelGGL(entries_kernel<true>, dim3((unsigned)((nsel + 3) / 4)), dim3(256), 0, stream, E);
         // the indel pass's tile: the same entries' read records, p->aux to come from the stage below
         hipLaunchKernelGGL(subtile_kernel<true>, dim3(grid), dim3(256), 0, stream, E, (uint32_t*)d_out, d_out + ep_at);
     }
