@@ -111,7 +111,7 @@ class GvcfBlock(C.Structure):
 
 class GvcfIn(C.Structure):
     _fields_ = [("n_sites", C.c_int32), ("n_range", C.c_int32)] + [(k, C.c_void_p) for k in
-                ("dp_range", "pos", "rid", "brk", "site", "pl", "dp4")]
+                ("dp_range", "pos", "rid", "brk", "site", "pl", "dp4", "ref_only", "dp", "end")]
 
 
 class GvcfOut(C.Structure):
@@ -151,6 +151,7 @@ PROTOTYPES = {
     "bcfgpu_gap_prep_tile": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Reads), C.POINTER(IndelIn), C.POINTER(IndelOut), C.c_int,
                                        C.POINTER(Tile)]),
     "bcfgpu_baq": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.c_char_p, C.c_int32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bcfgpu_cap_mapq": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]),
     "bcfgpu_overlap_tweak": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcfgpu_pileup_indel_tile": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(Tile)]),
     "bcfgpu_pileup_entries": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),

@@ -30,6 +30,7 @@ struct GvcfParams {
     const uint8_t *brk;
     const bcfgpu_site *site;
     const uint8_t *pl, *dp4;
+    const uint8_t *ref_only; const int32_t *dp32, *end;      // the `call -g` form (bcfgpu.h)
     int32_t *range, *head, *scan;       // workspace
     int32_t *blk, *min_dp;
     bcfgpu_gvcf_block *block;
@@ -42,13 +43,18 @@ __global__ __launch_bounds__(256) void gvcf_site_kernel(const GvcfParams P)
     const int site = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (site >= P.n_sites) return;
     const int S = P.n_smpl;
-    const uint8_t *d = P.dp4 + (size_t)site * 4 * S;
     int m = INT32_MAX;
-    for (int s = lane; s < S; s += 64) m = min(m, (int)d[s] + d[S + s] + d[2 * S + s] + d[3 * S + s]);
+    if (P.dp32) {
+        const int32_t *d = P.dp32 + (size_t)site * S;
+        for (int s = lane; s < S; s += 64) m = min(m, d[s]);
+    } else {
+        const uint8_t *d = P.dp4 + (size_t)site * 4 * S;
+        for (int s = lane; s < S; s += 64) m = min(m, (int)d[s] + d[S + s] + d[2 * S + s] + d[3 * S + s]);
+    }
     for (int o = 32; o; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
     if (lane) return;
-    // REF and <*> only (mpileup.c:309-315)
-    const bool is_ref = P.site[site].n_alleles == 2 && P.site[site].unseen == 1 && !(P.brk && (P.brk[site] & 2));
+    // REF and <*> only (mpileup.c:309-315); `call -g`: the records mcall() left with the reference allele alone
+    const bool is_ref = (P.ref_only ? P.ref_only[site] != 0 : P.site[site].n_alleles == 2 && P.site[site].unseen == 1) && !(P.brk && (P.brk[site] & 2));
     int r = 0;
     if (is_ref) { while (r < P.n_range && m >= P.dp_range[r]) ++r; }
     P.min_dp[site] = is_ref ? m : 0;
@@ -62,7 +68,7 @@ __device__ __forceinline__ bool gvcf_joins(const GvcfParams &P, int i)
     const int r = P.range[i];
     if (!r || P.range[i - 1] != r) return false;
     if (P.rid && P.rid[i] != P.rid[i - 1]) return false;
-    if (P.pos[i] > P.pos[i - 1] + 1) return false;
+    if (P.pos[i] > (P.end ? P.end[i - 1] : P.pos[i - 1]) + 1) return false;
     return !(P.brk && (P.brk[i - 1] & 1));
 }
 
@@ -84,7 +90,12 @@ __global__ __launch_bounds__(256) void gvcf_block_kernel(const GvcfParams P)
     if (P.head[i]) { B->first_site = i; B->start_pos = P.pos[i]; B->range = P.range[i]; }
     if (i + 1 == P.n_sites || !gvcf_joins(P, i + 1)) {
         B->last_site = i;
-        B->end1 = P.pos[i] + 1 - ((P.brk && (P.brk[i] & 1)) ? 1 : 0);     // gvcf.c:139-141
+        // gvcf.c:139-141: a record at the block's last position (the indel record after the SNP record: flagged in brk when it
+        // is not in the list, the next record when it is) cuts the block one short
+        const int e0 = P.end ? P.end[i] : P.pos[i];
+        const bool cut = (P.brk && (P.brk[i] & 1)) ||
+                         (i + 1 < P.n_sites && !(P.brk && (P.brk[i + 1] & 2)) && (!P.rid || P.rid[i + 1] == P.rid[i]) && P.pos[i + 1] == e0);
+        B->end1 = e0 + 1 - (cut ? 1 : 0);
     }
 }
 
@@ -99,6 +110,12 @@ __global__ __launch_bounds__(64) void gvcf_reduce_kernel(const GvcfParams P, int
         P.block[b].min_dp = m;
     }
     if (s >= S) return;
+    if (P.dp32) {                                              // `call -g`: FORMAT/DP only
+        int dp = P.dp32[(size_t)first * S + s];
+        for (int i = first + 1; i <= last; ++i) dp = min(dp, P.dp32[(size_t)i * S + s]);
+        P.dp_out[(size_t)b * S + s] = dp;
+        return;
+    }
     const uint8_t *d = P.dp4 + (size_t)first * 4 * S + s, *p = P.pl + (size_t)first * BCFGPU_MAX_PL * S + s;
     int dp = (int)d[0] + d[S] + d[2 * S] + d[3 * S];
     const int pl0 = p[0];
@@ -127,7 +144,9 @@ extern "C" int bcfgpu_gvcf_blocks(bcfgpu_ctx *ctx, const bcfgpu_gvcf_in *in, con
         return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gvcf_blocks: n_sites < 0 or 1..16 depth ranges expected");
     *n_blocks = 0;
     if (!in->n_sites) return BCFGPU_OK;
-    if (!in->pos || !in->site || !in->pl || !in->dp4 || !out->blk || !out->min_dp || !out->block || !out->dp || !out->pl)
+    const bool call_form = in->dp != nullptr || in->ref_only != nullptr;
+    if (!in->pos || !out->blk || !out->min_dp || !out->block || !out->dp ||
+        (call_form ? (!in->dp || !in->ref_only) : (!in->site || !in->pl || !in->dp4 || !out->pl)))
         return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gvcf_blocks: null plane");
     hipStream_t stream;
     bcfgpu_internal_device(ctx, &stream, nullptr);
@@ -137,6 +156,7 @@ extern "C" int bcfgpu_gvcf_blocks(bcfgpu_ctx *ctx, const bcfgpu_gvcf_in *in, con
     P.n_sites = n; P.n_smpl = cfg->n_smpl; P.n_range = in->n_range;
     for (int i = 0; i < GVCF_MAX_RANGE; ++i) P.dp_range[i] = i < in->n_range ? in->dp_range[i] : INT32_MAX;
     P.pos = in->pos; P.rid = in->rid; P.brk = in->brk; P.site = in->site; P.pl = in->pl; P.dp4 = in->dp4;
+    P.ref_only = in->ref_only; P.dp32 = in->dp; P.end = in->end;
     P.blk = out->blk; P.min_dp = out->min_dp; P.block = out->block; P.dp_out = out->dp; P.pl_out = out->pl;
     size_t tmp_bytes = 0;
     GV_CHK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, (int32_t*)nullptr, (int32_t*)nullptr, n, stream));

@@ -171,6 +171,40 @@ class Context:
             self.release(bufs + [b for _, b in outs])
         return host.GvcfResult(nb.value, blk, min_dp, block, dp, pl)
 
+    def gvcf_call_blocks(self, pos, ref_only, dp, dp_range, rid=None, end=None):
+        """The `call -g` form of bcfgpu_gvcf_blocks: records given by position, "may join" flag and FORMAT/DP [n][n_smpl].
+        Returns (n_blocks, blk, min_dp, block table, block DP)."""
+        dp = np.ascontiguousarray(dp, dtype=np.int32)
+        n, S = dp.shape
+        assert S == self.cfg.n_smpl
+        rng = np.ascontiguousarray(dp_range, dtype=np.int32)
+        bufs = [self.to_device(np.ascontiguousarray(pos, dtype=np.int32)), self.to_device(np.ascontiguousarray(ref_only, dtype=np.uint8)),
+                self.to_device(dp)]
+        gi = abi.GvcfIn()
+        gi.n_sites, gi.n_range, gi.dp_range = n, len(rng), rng.ctypes.data_as(C.c_void_p)
+        gi.pos, gi.ref_only, gi.dp = (b.ptr for b in bufs)
+        if rid is not None:
+            bufs.append(self.to_device(np.ascontiguousarray(rid, dtype=np.int32)))
+            gi.rid = bufs[-1].ptr
+        if end is not None:
+            bufs.append(self.to_device(np.ascontiguousarray(end, dtype=np.int32)))
+            gi.end = bufs[-1].ptr
+        blk, min_dp = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        block = np.zeros(max(n, 1), host.GVCF_BLOCK_DTYPE)
+        bdp = np.zeros((max(n, 1), S), np.int32)
+        outs = [(a, self.buf(a.nbytes)) for a in (blk, min_dp, block, bdp)]
+        go = abi.GvcfOut()
+        go.blk, go.min_dp, go.block, go.dp = (b.ptr for _, b in outs)
+        nb = C.c_int32(0)
+        try:
+            check(self.L.bcfgpu_gvcf_blocks(self.h, C.byref(gi), C.byref(go), C.byref(nb)))
+            self.sync()
+            for a, b in outs:
+                b.download(a)
+        finally:
+            self.release(bufs + [b for _, b in outs])
+        return nb.value, blk, min_dp, block, bdp
+
     def mcall(self, cin):
         """Run the caller on a host CallInput, return a host CallResult."""
         assert cin.n_smpl == self.cfg.n_smpl

@@ -310,6 +310,7 @@ int main(int argc, char **argv)
     const char *smpl_file = NULL, *ploidy_file = NULL, *grp_arg = NULL, *grp_tag = NULL;
     char prior_an_tag[64] = "", prior_ac_tag[64] = "";
     char out_mode = 'v'; const char *out_path = "-";
+    int32_t gv_range[16]; int gv_n = 0;                         /* -g INT,...: gvcf_init (gvcf.c:47-73) */
     while (argc > 2 && argv[1][0] == '-') {
         if (!strcmp(argv[1], "-v")) { varonly = 1; ++argv; --argc; }
         else if (!strcmp(argv[1], "-m")) { ++argv; --argc; }                                     /* the multiallelic caller: the only one here */
@@ -337,11 +338,25 @@ int main(int argc, char **argv)
                 else DIE("-a: unknown tag %s\n", t[i]);
             free(t); free(c); argv += 2; argc -= 2;
         }
+        else if ((!strcmp(argv[1], "-g") || !strcmp(argv[1], "--gvcf")) && argc > 3) {
+            char *c = strdup(argv[2]); int nt; char **t = split(c, ',', &nt);
+            if (nt < 1 || nt > 16) DIE("Could not parse: --gvcf %s\n", argv[2]);
+            for (int i = 0; i < nt; ++i) { char *e; gv_range[i] = (int32_t)strtol(t[i], &e, 10); if (e == t[i] || *e) DIE("Could not parse: --gvcf %s\n", argv[2]); }
+            gv_n = nt; free(t); free(c); argv += 2; argc -= 2;
+        }
+        else if ((!strncmp(argv[1], "-g", 2) && argv[1][2]) || (!strncmp(argv[1], "-mg", 3) && argv[1][3])) {   /* -g0,2,5; the `-mg0` of test.pl:277 */
+            char *c = strdup(argv[1] + (argv[1][1] == 'm' ? 3 : 2)); int nt; char **t = split(c, ',', &nt);
+            if (nt < 1 || nt > 16) DIE("Could not parse: --gvcf %s\n", argv[1] + 2);
+            for (int i = 0; i < nt; ++i) { char *e; gv_range[i] = (int32_t)strtol(t[i], &e, 10); if (e == t[i] || *e) DIE("Could not parse: --gvcf %s\n", argv[1] + 2); }
+            gv_n = nt; free(t); free(c); ++argv; --argc;
+        }
         else if (!strcmp(argv[1], "-S") && argc > 3) { smpl_file = argv[2]; argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "--ploidy-file") && argc > 3) { ploidy_file = argv[2]; argv += 2; argc -= 2; }
         else break;
     }
-    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-S samples.txt] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] [-A] [-P theta] [-C alleles -T targets.tab [-i]] [-O v|z|u|b] [-o out] in.vcf|in.bcf\n"); return 2; }
+    if (gv_n && varonly) DIE("The two options cannot be combined: --variants-only and --gvcf\n");       /* vcfcall.c:1085 */
+    if (gv_n && cals) DIE("-g with -C alleles is not supported\n");
+    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-g INT,...] [-S samples.txt] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] [-A] [-P theta] [-C alleles -T targets.tab [-i]] [-O v|z|u|b] [-o out] in.vcf|in.bcf\n"); return 2; }
     /* ploidy definition (ploidy.c): regions per sex, '*' lines = the sex's default; the last sex named is the default sex */
     preg_t *preg = NULL; int npreg = 0; char last_sex[64] = "";
     if (ploidy_file) {
@@ -612,6 +627,10 @@ int main(int argc, char **argv)
     if (smpl_file && vio_hdr_subset(hdr, S, col)) DIE("%s\n", vio_error());
     vio_hdr_remove(hdr, "INFO", "QS");
     vio_hdr_remove(hdr, "INFO", "I16");
+    if (gv_n) {                                                  /* gvcf_update_header, on the reader's header (vcfcall.c:661-666) */
+        vio_hdr_append(hdr, "##INFO=<ID=END,Number=1,Type=Integer,Description=\"End position of the variant described in this record\">");
+        vio_hdr_append(hdr, "##INFO=<ID=MinDP,Number=1,Type=Integer,Description=\"Minimum per-sample depth in this gVCF block\">");
+    }
     vio_hdr_append(hdr, "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">");
     if (out_tags & BCFGPU_CALL_FMT_GQ) vio_hdr_append(hdr, "##FORMAT=<ID=GQ,Number=1,Type=Integer,Description=\"Phred-scaled Genotype Quality\">");
     if (out_tags & BCFGPU_CALL_FMT_GP) vio_hdr_append(hdr, "##FORMAT=<ID=GP,Number=G,Type=Float,Description=\"Genotype posterior probabilities in the range 0 to 1\">");
@@ -623,6 +642,62 @@ int main(int argc, char **argv)
     if (!fout || vio_write_hdr(fout, hdr)) DIE("%s\n", vio_error());
     LN = open_memstream(&ln_buf, &ln_len);
     if (!LN) DIE("open_memstream failed\n");
+    /* ---- -g: gVCF blocks over the records that are written (vcfcall.c:1145-1149; gvcf_write, gvcf.c:88-226).  What
+     * gvcf_write looks at goes to the device as arrays: may the record join (mcall() returned 1: the reference allele alone),
+     * FORMAT/DP of every sample, position, sequence, INFO/END; the block table and the blocks' DP come back. ---- */
+    int32_t *gv_w = NULL, *gv_blk = NULL, *gv_min = NULL, *gv_dp = NULL; bcfgpu_gvcf_block *gv_block = NULL; int gv_nw = 0;
+    if (gv_n) {
+        gv_w = malloc((size_t)(n + 1) * 4);                      /* record k is written record gv_w[k], or -1 */
+        int32_t *pos = malloc((size_t)(n + 1) * 4), *rid = malloc((size_t)(n + 1) * 4), *endp = malloc((size_t)(n + 1) * 4);
+        uint8_t *ro = malloc((size_t)n + 1);
+        int32_t *dp = malloc(((size_t)n * S + 1) * 4);
+        char **chroms = NULL; int nchrom = 0;
+        for (int k = 0; k < n; ++k) {
+            const rec_t *r = &recs[k];
+            if (cs[k].ret < 0) { gv_w[k] = -1; continue; }
+            const int w = gv_nw++;
+            gv_w[k] = w;
+            pos[w] = atoi(r->fld[1]) - 1; endp[w] = pos[w];
+            int ci; for (ci = 0; ci < nchrom; ++ci) if (!strcmp(chroms[ci], r->fld[0])) break;
+            if (ci == nchrom) { chroms = realloc(chroms, (size_t)(nchrom + 1) * sizeof *chroms); chroms[nchrom++] = r->fld[0]; }
+            rid[w] = ci;
+            ro[w] = cs[k].ret == 1;
+            const char *e = strstr(r->fld[7], "END=");
+            if (e && (e == r->fld[7] || e[-1] == ';')) endp[w] = atoi(e + 4) - 1;
+            int nk, dpi = -1; char *fmt = strdup(r->fld[8]), **keys = split(fmt, ':', &nk);
+            for (int i = 0; i < nk; ++i) if (!strcmp(keys[i], "DP")) dpi = i;
+            free(keys); free(fmt);
+            for (int s2 = 0; s2 < S; ++s2) {
+                int32_t v = INT32_MIN;                           /* missing: the record stays as it is */
+                if (dpi >= 0) {
+                    char *smp = strdup(r->fld[9 + col[s2]]); int nv; char **vals = split(smp, ':', &nv);
+                    if (dpi < nv && strcmp(vals[dpi], ".")) v = atoi(vals[dpi]);
+                    free(vals); free(smp);
+                }
+                dp[(size_t)w * S + s2] = v;
+            }
+        }
+        free(chroms);
+        if (gv_nw) {
+            void *d_pos = dev_upload(ctx, pos, (size_t)gv_nw * 4), *d_rid = dev_upload(ctx, rid, (size_t)gv_nw * 4), *d_end = dev_upload(ctx, endp, (size_t)gv_nw * 4);
+            void *d_ro = dev_upload(ctx, ro, (size_t)gv_nw), *d_dp = dev_upload(ctx, dp, (size_t)gv_nw * S * 4);
+            void *d_blk, *d_min, *d_block, *d_gdp;
+            CHECK(bcfgpu_malloc(ctx, (size_t)gv_nw * 4, &d_blk)); CHECK(bcfgpu_malloc(ctx, (size_t)gv_nw * 4, &d_min));
+            CHECK(bcfgpu_malloc(ctx, (size_t)gv_nw * sizeof(bcfgpu_gvcf_block), &d_block)); CHECK(bcfgpu_malloc(ctx, (size_t)gv_nw * S * 4, &d_gdp));
+            bcfgpu_gvcf_in gi; memset(&gi, 0, sizeof gi);
+            gi.n_sites = gv_nw; gi.n_range = gv_n; gi.dp_range = gv_range; gi.pos = d_pos; gi.rid = d_rid; gi.end = d_end; gi.ref_only = d_ro; gi.dp = d_dp;
+            bcfgpu_gvcf_out go; memset(&go, 0, sizeof go);
+            go.blk = d_blk; go.min_dp = d_min; go.block = d_block; go.dp = d_gdp;
+            int32_t nb = 0;
+            CHECK(bcfgpu_gvcf_blocks(ctx, &gi, &go, &nb));
+            gv_blk = malloc((size_t)gv_nw * 4); gv_min = malloc((size_t)gv_nw * 4);
+            gv_block = malloc((size_t)(nb + 1) * sizeof *gv_block); gv_dp = malloc(((size_t)nb * S + 1) * 4);
+            CHECK(bcfgpu_memcpy_d2h(ctx, gv_blk, d_blk, (size_t)gv_nw * 4)); CHECK(bcfgpu_memcpy_d2h(ctx, gv_min, d_min, (size_t)gv_nw * 4));
+            if (nb) { CHECK(bcfgpu_memcpy_d2h(ctx, gv_block, d_block, (size_t)nb * sizeof *gv_block)); CHECK(bcfgpu_memcpy_d2h(ctx, gv_dp, d_gdp, (size_t)nb * S * 4)); }
+            CHECK(bcfgpu_sync(ctx));
+        }
+        free(pos); free(rid); free(endp); free(ro); free(dp);
+    }
     /* ---- the record loop (vcfcall.c:1137-1147, mcall.c:1627-1681) ---- */
     const int n_out = cals ? n_events : n;
     for (int ev = 0; ev < n_out; ++ev) {
@@ -643,6 +718,39 @@ int main(int argc, char **argv)
         const bcfgpu_call_site *c = &cs[k];
         if (c->ret == -2 || (varonly && c->ret == 0) || c->ret < 0) continue;
         const int nn = c->nals_new, ngn = nn * (nn + 1) / 2;
+        int gv_min_dp = 0;
+        if (gv_n) {
+            const int w = gv_w[k], b = gv_blk[w];
+            if (b >= 0) {                                        /* inside a block: one line when the block ends (gvcf.c:134-166) */
+                const bcfgpu_gvcf_block *B = &gv_block[b];
+                if (B->last_site != w) continue;
+                int kf = k; while (gv_w[kf] != B->first_site) --kf;  /* the block's first record: alleles and genotypes are its */
+                const rec_t *rf = &recs[kf]; const bcfgpu_call_site *cf = &cs[kf];
+                fprintf(LN, "%s\t%d\t.\t%s\t", rf->fld[0], B->start_pos + 1, rf->fld[3]);
+                {
+                    const char *al[5] = { 0, 0, 0, 0, 0 };
+                    for (int i = 0; i < rf->nals; ++i) if (cf->als_map[i] >= 0) al[cf->als_map[i]] = rf->als[i];
+                    if (cf->nals_new < 2) fputc('.', LN);
+                    for (int i = 1; i < cf->nals_new; ++i) fprintf(LN, "%s%s", i > 1 ? "," : "", al[i]);
+                }
+                fputs("\t.\t.\t", LN);
+                if (B->start_pos + 1 < B->end1) fprintf(LN, "END=%d;", B->end1);
+                fprintf(LN, "MinDP=%d\tGT:DP", B->min_dp);
+                for (int s2 = 0; s2 < S; ++s2) {
+                    const int g0 = gt[((size_t)kf * 2 + 0) * S + s2], g1 = gt[((size_t)kf * 2 + 1) * S + s2];
+                    fputc('\t', LN);
+                    if (g0 == BCFGPU_GT_MISSING) fputc('.', LN); else fprintf(LN, "%d", g0);
+                    if (g1 != BCFGPU_GT_VECTOR_END) { fputc('/', LN); if (g1 == BCFGPU_GT_MISSING) fputc('.', LN); else fprintf(LN, "%d", g1); }
+                    const int32_t v = gv_dp[(size_t)b * S + s2];
+                    if (v == INT32_MIN) fputs(":.", LN); else fprintf(LN, ":%d", v);
+                }
+                fputc(0, LN); fflush(LN);
+                if (vio_write_line(fout, hdr, ln_buf)) DIE("%s\n", vio_error());
+                rewind(LN);
+                continue;
+            }
+            if (c->ret == 1) gv_min_dp = gv_min[w];                /* a reference record outside the ranges keeps MinDP (gvcf.c:221-222) */
+        }
         fprintf(LN, "%s\t%s\t%s\t%s\t", r->fld[0], r->fld[1], r->fld[2], r->fld[3]);
         {   /* ALT: the kept alleles in their new order */
             const char *al[5] = { 0, 0, 0, 0, 0 };
@@ -670,6 +778,7 @@ int main(int argc, char **argv)
                 fprintf(LN, ";DP4=%d,%d,%d,%d", c->dp4[0], c->dp4[1], c->dp4[2], c->dp4[3]);
                 if (c->mq == BCFGPU_INT32_MISSING) fputs(";MQ=.", LN); else fprintf(LN, ";MQ=%d", c->mq);
             }
+            if (gv_min_dp == INT32_MIN) fputs(";MinDP=.", LN); else if (gv_min_dp) fprintf(LN, ";MinDP=%d", gv_min_dp);
         }
         /* FORMAT: GT first, PL trimmed or dropped, the rest as it came */
         int nk; char *fmt = strdup(r->fld[8]), **keys = split(fmt, ':', &nk);

@@ -261,6 +261,7 @@ static int sample_of(const sfile_t *f, const char *rg)                      /* b
 
 /* ---- reading: SAM text or BAM; the read filters of mplp_func (mpileup.c:183-246) ---- */
 static int rflag_require = 0, rflag_filter = 4 | 256 | 512 | 1024, min_mq = 0, keep_orphans = 0;
+static int defer_mq_filters = 0;      /* -C: sam_cap_mapq comes between the flag filters and the -q / orphan filters (mpileup.c:234-241) */
 
 static void pool_add(pool_t *P, int file, int smpl, const char *qname, int flag, int pos, int mapq, int rnext_same, int mpos, int isize,
                      const uint32_t *cig, int ncig, int lq, const uint8_t *seq16, const uint8_t *qual)
@@ -297,6 +298,7 @@ static int read_passes(int flag, int mapq)
     if (flag & 4) return 0;
     if (rflag_require && !(rflag_require & flag)) return 0;
     if (rflag_filter && (rflag_filter & flag)) return 0;
+    if (defer_mq_filters) return 1;
     if (mapq < min_mq) return 0;
     if (!keep_orphans && (flag & 1) && !(flag & 2)) return 0;
     return 1;
@@ -511,6 +513,26 @@ static int find_pairs(const pool_t *P, int r0, int r1, int32_t *pa, int32_t *pb)
 /* what bcf_call2bcf writes into a record (bam2bcf.c:756-906); alleles: the ready REF\tALT text */
 static int fmt_flag = BCFGPU_INFO_VDB | BCFGPU_INFO_RPB;                     /* mpileup's default annotations + -a */
 
+/* the reads with keep[r] != 0 stay, in order; first[] (the pool is file-major) follows */
+static void pool_keep(pool_t *P, int *first, int F, const uint8_t *keep)
+{
+    int m = 0;
+    for (int s = 0, r = 0; s < F; ++s) {
+        const int e = first[s + 1];
+        first[s] = m;
+        for (; r < e; ++r) {
+            if (!keep[r]) { free(P->qname[r]); continue; }
+            if (m != r) {
+                #define MV(a) P->a[m] = P->a[r]
+                MV(pos); MV(lq); MV(flag); MV(ncig); MV(cig_off); MV(seq_off); MV(smpl); MV(file); MV(end); MV(mpos); MV(isize); MV(rnext_same); MV(mapq); MV(has_zq); MV(qname);
+                #undef MV
+            }
+            ++m;
+        }
+    }
+    first[F] = m; P->n = m;
+}
+
 typedef struct { const uint8_t *pl, *dp4, *adf, *adr, *sp, *scr; const uint16_t *qs; } planes_t;        /* host copies of bcfgpu_mplp_out's planes */
 
 static void put_counts(const char *lead, const int32_t *f, const int32_t *r, int n)
@@ -609,6 +631,8 @@ int main(int argc, char **argv)
     int32_t gv_range[16]; int gv_n = 0;                                       /* mpileup --gvcf INT,.. (gvcf.c:44-67) */
     char out_mode = 'v'; const char *out_path = "-"; int max_depth = 250;      /* mpileup -O, -o, -d (mpileup.c:937-950) */
     int baq_flag = 3, min_baseQ = 13, list_only = 0;
+    int cap_thres = 0;                                                        /* mpileup -C (adjust-MQ), mpileup.c:938 */
+    int openQ = 40, extQ = 20, tandemQ = 100, min_support = 1, per_sample_flt = 0, no_indels = 0, max_indel_depth = 250; double min_frac = 0.002;   /* mpileup.c:937-950 */
     while (argc > 2 && argv[1][0] == '-') {
         if (!strcmp(argv[1], "-a")) {                                         /* mpileup -a, mpileup.c:parse_format_flag */
             static const struct { const char *name; int bit; } tags[] = {
@@ -634,7 +658,12 @@ int main(int argc, char **argv)
         }
         else if (!strcmp(argv[1], "-O")) { out_mode = argv[2][0]; argv += 2; argc -= 2; }
         else if (!strncmp(argv[1], "-O", 2) && argv[1][2]) { out_mode = argv[1][2]; ++argv; --argc; }
-        else if (!strcmp(argv[1], "-o")) { out_path = argv[2]; argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-o")) {                                    /* -o INT: --open-prob, -o FILE: --output (the reference's own rule, mpileup.c:1073-1079) */
+            char *e; const long v = strtol(argv[2], &e, 10);
+            if (*e == 0) openQ = (int)v; else out_path = argv[2];
+            argv += 2; argc -= 2;
+        }
+        else if (!strcmp(argv[1], "--output")) { out_path = argv[2]; argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-d")) { max_depth = atoi(argv[2]); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-s")) { add_samples(argv[2], 0); argv += 2; argc -= 2; }            /* mpileup.c:1058-1059,1087,1016 */
         else if (!strcmp(argv[1], "-S")) { add_samples(argv[2], 1); argv += 2; argc -= 2; }
@@ -646,15 +675,25 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "-A")) { keep_orphans = 1; ++argv; --argc; }
         else if (!strcmp(argv[1], "-q")) { min_mq = atoi(argv[2]); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-Q")) { min_baseQ = atoi(argv[2]); argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-C")) { cap_thres = atoi(argv[2]); argv += 2; argc -= 2; }          /* mpileup.c:1069 */
+        else if (!strcmp(argv[1], "-e")) { extQ = atoi(argv[2]); argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-h")) { tandemQ = atoi(argv[2]); argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-m")) { min_support = atoi(argv[2]); argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-F")) { min_frac = atof(argv[2]); argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-L")) { max_indel_depth = atoi(argv[2]); argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-p")) { per_sample_flt = 1; ++argv; --argc; }
+        else if (!strcmp(argv[1], "-I")) { no_indels = 1; ++argv; --argc; }
         else if (!strcmp(argv[1], "--ff")) { rflag_filter = (int)strtol(argv[2], NULL, 0); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "--rf")) { rflag_require = (int)strtol(argv[2], NULL, 0); argv += 2; argc -= 2; }
         else break;
     }
     if (argc < 6) {
         fprintf(stderr, "usage: bcfgpu_sam [-a TAG,..] [--gvcf INT,..] [-O v|z|u|b] [-o out] [-d INT] [-s LIST | -S FILE] [-G FILE] [--ignore-RG]\n"
-                        "                  [-B | -E] [-A] [-q INT] [-Q INT] [--ff INT] [--rf INT] ref.fa contig beg end file.sam|file.bam [...]\n");
+                        "                  [-B | -E] [-A] [-q INT] [-Q INT] [-C INT] [--ff INT] [--rf INT] [-I] [-o INT] [-e INT] [-h INT] [-m INT] [-F FLOAT] [-p] [-L INT]\n"
+                        "                  ref.fa contig beg end file.sam|file.bam [...]\n");
         return 2;
     }
+    defer_mq_filters = cap_thres > 10;
     const char *contig = argv[2];
     const int beg = atoi(argv[3]) - 1, end = atoi(argv[4]);                 /* 0-based [beg, end) */
     const int n_in = argc - 5, n_sites = end - beg;
@@ -715,27 +754,44 @@ int main(int argc, char **argv)
         LN = open_memstream(&ln_buf, &ln_len);
         if (!LN) DIE("open_memstream failed\n");
     }
+    /* ---- mpileup -C INT (mpileup.c:234-241): after BAQ, sam_cap_mapq lowers the mapping quality of reads with many
+     * mismatches or drops them; then the -q and orphan filters, which read_passes() left for here ---- */
+    if (cap_thres > 10 && P.n && !list_only) {
+        bcfgpu_cfg c0; memset(&c0, 0, sizeof c0);
+        c0.device = 0; c0.n_smpl = S; c0.max_sites = 1; c0.max_reads = 64; c0.min_baseQ = min_baseQ; c0.capQ = 60; c0.n_grp = 1; c0.ploidy_max = 2;
+        bcfgpu_ctx *cx = NULL;
+        CHECK(bcfgpu_create(&c0, &cx));
+        bcfgpu_reads r0; memset(&r0, 0, sizeof r0);
+        r0.n_reads = P.n; r0.r_pos = P.pos; r0.r_lq = P.lq; r0.r_flag = P.flag; r0.r_ncig = P.ncig; r0.r_cig_off = P.cig_off;
+        r0.r_seq_off = P.seq_off; r0.cig = P.cig; r0.seq16 = P.seq16; r0.qual = P.qual; r0.zq = P.zq; r0.r_has_zq = P.has_zq;
+        uint8_t *qb = NULL, *zb = NULL;
+        if (baq_flag) {                                                       /* the qualities sam_cap_mapq sees are BAQ's */
+            qb = malloc(P.nbase + 1); zb = malloc(P.nbase + 1);
+            int32_t *bret = malloc((size_t)(P.n + 1) * sizeof *bret);
+            CHECK(bcfgpu_baq(cx, &r0, ref, ref_len, baq_flag, qb, zb, bret));
+            r0.qual = qb;
+            free(bret);
+        }
+        int32_t *capv = malloc((size_t)P.n * sizeof *capv);
+        CHECK(bcfgpu_cap_mapq(cx, &r0, ref, ref_len, cap_thres, capv));
+        uint8_t *keep = malloc((size_t)P.n);
+        for (int r = 0; r < P.n; ++r) {
+            keep[r] = capv[r] >= 0;
+            if (keep[r] && P.mapq[r] > capv[r]) P.mapq[r] = (uint8_t)capv[r];
+            if (P.mapq[r] < min_mq) keep[r] = 0;
+            if (!keep_orphans && (P.flag[r] & 1) && !(P.flag[r] & 2)) keep[r] = 0;
+        }
+        pool_keep(&P, first, F, keep);
+        free(keep); free(capv); free(qb); free(zb);
+        bcfgpu_destroy(cx);
+    }
     /* ---- the per-file depth cap of the pileup iterator (mpileup -d, mpileup.c:646): reads it drops leave the pool ---- */
     if (max_depth > 0 && P.n) {
         bcfgpu_reads r0; memset(&r0, 0, sizeof r0);
         r0.n_reads = P.n; r0.r_pos = P.pos; r0.r_ncig = P.ncig; r0.r_cig_off = P.cig_off; r0.cig = P.cig;
         uint8_t *keep = malloc((size_t)P.n);
         CHECK(bcfgpu_depth_cap(&r0, P.file, F, max_depth, keep));
-        int m = 0;
-        for (int s = 0, r = 0; s < F; ++s) {
-            const int e = first[s + 1];
-            first[s] = m;
-            for (; r < e; ++r) {
-                if (!keep[r]) { free(P.qname[r]); continue; }
-                if (m != r) {
-                    #define MV(a) P.a[m] = P.a[r]
-                    MV(pos); MV(lq); MV(flag); MV(ncig); MV(cig_off); MV(seq_off); MV(smpl); MV(file); MV(end); MV(mpos); MV(isize); MV(rnext_same); MV(mapq); MV(has_zq); MV(qname);
-                    #undef MV
-                }
-                ++m;
-            }
-        }
-        first[F] = m; P.n = m;
+        pool_keep(&P, first, F, keep);
         free(keep);
     }
 
@@ -822,7 +878,7 @@ int main(int argc, char **argv)
     int nc = 0;
     int32_t *cand = malloc((size_t)(n_sites + 1) * sizeof *cand);
     for (int k = 0; k < n_sites; ++k)
-        if (col_indel[k] && col_n[k] < 250 * S) cand[nc++] = k;      /* max_indel_depth */
+        if (!no_indels && col_indel[k] && col_n[k] < max_indel_depth * S) cand[nc++] = k;     /* mpileup.c:354 */      /* max_indel_depth */
     bcfgpu_site *isite = NULL;
     planes_t ind_planes; memset(&ind_planes, 0, sizeof ind_planes); int32_t *live = NULL; int nlive = 0;
     int32_t *g_types = NULL, *g_maxins = NULL, *g_indelreg = NULL, *g_support = NULL; float *g_frac = NULL; int8_t *g_inscns = NULL;
@@ -831,7 +887,7 @@ int main(int argc, char **argv)
          * into the indel pass's tile over all candidate columns (the host pool is passed for its ZQ bytes) */
         bcfgpu_indel_in in; memset(&in, 0, sizeof in);
         in.n_sites = nc; in.n_smpl = S; in.ref = ref;
-        in.openQ = 40; in.extQ = 20; in.tandemQ = 100; in.min_support = 1; in.per_sample_flt = 0; in.min_frac = 0.002;   /* mpileup.c:937-950 */
+        in.openQ = openQ; in.extQ = extQ; in.tandemQ = tandemQ; in.min_support = min_support; in.per_sample_flt = per_sample_flt; in.min_frac = min_frac;
         bcfgpu_indel_out out; memset(&out, 0, sizeof out);
         int32_t *gret = malloc((size_t)nc * 4);
         g_types = malloc((size_t)nc * 16); g_inscns = malloc((size_t)nc * 4 * INSCNS_CAP); g_maxins = malloc((size_t)nc * 4);

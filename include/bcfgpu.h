@@ -338,6 +338,13 @@ int  bcfgpu_gap_prep(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const bcfgpu_in
 int  bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const char *ref, int32_t ref_len, int flag,
                 uint8_t *qual_out, uint8_t *zq_out, int32_t *ret);
 
+/* ---- mpileup -C INT: sam_cap_mapq(b, ref, ref_len, thres) of htslib sam.c as mplp_func applies it to every read after
+ * BAQ (mpileup.c:235-239, only when thres > 10): a cap on the read's mapping quality from its mismatches against the
+ * reference (their count and capped base qualities, the aligned length, the clipped bases).  HOST pointers; reads->qual =
+ * the qualities after bcfgpu_baq.  cap[r]: -1 = the read is dropped (mpileup.c:237), else the caller lowers the read's
+ * mapping quality to cap[r] when it is above it (:238).  The filters that follow in mplp_func (-q, orphans) are the caller's. */
+int  bcfgpu_cap_mapq(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const char *ref, int32_t ref_len, int32_t thres, int32_t *cap);
+
 /* ---- mate overlaps: what bam_mplp_init_overlaps() (mpileup.c:640) makes htslib's pileup do to read pairs whose mates
  * overlap (sam.c tweak_overlap_quality): at every reference position both reads cover with an aligned base, equal
  * bases pool their qualities in the first read (at most 200) and different bases keep 0.8 of the better quality (the
@@ -437,6 +444,17 @@ typedef struct {
     const bcfgpu_site *site;          /* the mpileup stage's output for the tile (n_alleles, unseen are read) */
     const uint8_t *pl;                /* bcfgpu_mplp_out.pl  */
     const uint8_t *dp4;               /* bcfgpu_mplp_out.dp4: FORMAT/DP is the sum of the four (bam2bcf.c:853-858) */
+    /* The form `bcftools call -g` needs (vcfcall.c:1145-1149: gvcf_write(.., ret==1)): the records are whatever the caller
+     * read, so what gvcf_write looks at comes as arrays of its own, and site / pl / dp4 are not read (may be NULL):
+     *   ref_only [n_sites] u8: 1 = the record may join a block (mcall() kept the reference allele only)
+     *   dp       [n_sites][n_smpl] i32: FORMAT/DP as it stands in the record (missing = INT32_MIN: the record stays alone)
+     *   end      [n_sites] i32 or NULL: 0-based last position the record covers (INFO/END - 1 of a record that is a block
+     *            already, gvcf.c:215-218); NULL: pos
+     * A record that follows a block at the block's last position cuts it one short (gvcf.c:139) whichever form is used.
+     * out->pl may be NULL in this form (call drops FORMAT/PL of reference-only records: a block carries GT and DP). */
+    const uint8_t *ref_only;
+    const int32_t *dp;
+    const int32_t *end;
 } bcfgpu_gvcf_in;
 
 /*      blk    [n_sites]            i32  block of the site, or -1: its record is written as it is

@@ -51,7 +51,7 @@ def parse_samples_file(path):
 
 class CalledRec:
     __slots__ = ("src", "alleles", "qual", "qual_missing", "ac", "an", "gt", "pl", "gq", "gp", "als_map",
-                 "dp4", "mq", "pl_dropped", "ploidy", "pv4")
+                 "dp4", "mq", "pl_dropped", "ploidy", "pv4", "ret")
 
 
 def fmt_gt(a, b):
@@ -175,6 +175,7 @@ def run_call(vcf, engine, call_flag=0, output_tags=0, theta=1.1e-3, samples=None
                 continue
             c = CalledRec()
             c.src = rec
+            c.ret = ret
             c.ploidy = pv
             na = len(rec.alleles)
             amap = [int(x) for x in st["als_map"][:na]]

@@ -179,6 +179,17 @@ def apply_overlaps(reads, ctx=None, python=False):
     return len(pairs)
 
 
+def cap_mapq_oracle(r, refseq, thres):
+    """orc_cap_mapq (oracle/capmapq.c: sam_cap_mapq of htslib) for one read object with its current qualities."""
+    L = _realn_lib()
+    cig = np.array([(n << 4) | "MIDNSHP=X".index(op) for n, op in r.cigar], dtype=np.uint32)
+    seq16 = np.array([S.nt16(c) for c in r.seq], dtype=np.uint8)
+    qual = np.ascontiguousarray(r.qual, dtype=np.uint8)
+    L.orc_cap_mapq.restype = C.c_int
+    L.orc_cap_mapq.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_int]
+    return L.orc_cap_mapq(r.pos, len(cig), cig.ctypes.data, seq16.ctypes.data, qual.ctypes.data, refseq.encode(), len(refseq), thres)
+
+
 class Prepared:
     """SAM files after mplp_func filtering + BAQ + overlap tweak, ready for pileup."""
 
@@ -209,6 +220,16 @@ class Prepared:
                 rl.append((r, self.samples.index(sm)))
             if baq and baq_ctx is not None:
                 apply_baq_hip([r for r, _ in rl], self.refseq, baq_ctx)      # bcfgpu_baq, one call per file
+            if getattr(opts, "cap_thres", 0) > 10:                           # mpileup -C (mpileup.c:235-241)
+                kept = []
+                for r, si in rl:
+                    q = cap_mapq_oracle(r, self.refseq, opts.cap_thres)
+                    if q < 0:
+                        continue
+                    r.mapq = min(r.mapq, q)
+                    if S.keep_read_late(r, opts):
+                        kept.append((r, si))
+                rl = kept
             if overlaps:
                 apply_overlaps([r for r, _ in rl], ctx=baq_ctx)      # oracle C, or bcfgpu_overlap_tweak with a HIP context
             self.files.append(rl)

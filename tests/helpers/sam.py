@@ -217,20 +217,32 @@ class MplpOpts:
     """The read-level options of `bcftools mpileup` that matter for the fixtures (mpileup.c:937-950)."""
 
     def __init__(self, rflag_require=0, rflag_filter=BAM_FUNMAP | BAM_FSECONDARY | BAM_FQCFAIL | BAM_FDUP,
-                 min_mq=0, no_orphan=True, min_baseQ=13, fmt_flag=abi.INFO_VDB | abi.INFO_RPB):
+                 min_mq=0, no_orphan=True, min_baseQ=13, fmt_flag=abi.INFO_VDB | abi.INFO_RPB, cap_thres=0):
+        self.cap_thres = cap_thres          # mpileup -C: sam_cap_mapq after BAQ, then the -q / orphan filters (mpileup.c:234-241)
         self.rflag_require, self.rflag_filter = rflag_require, rflag_filter
         self.min_mq, self.no_orphan = min_mq, no_orphan
         self.min_baseQ, self.fmt_flag = min_baseQ, fmt_flag
 
 
+def keep_read_late(r, o):
+    """The two filters of mplp_func that come after BAQ and -C (mpileup.c:240-241)."""
+    if r.mapq < o.min_mq:
+        return False
+    if o.no_orphan and (r.flag & BAM_FPAIRED) and not (r.flag & BAM_FPROPER_PAIR):
+        return False
+    return True
+
+
 def keep_read(r, o):
-    """mplp_func, mpileup.c:183-246 (without BED, BAQ and -C)."""
+    """mplp_func, mpileup.c:183-246 (without BED and BAQ; with -C the last two filters wait for keep_read_late)."""
     if r.rname == "*" or (r.flag & BAM_FUNMAP):
         return False
     if o.rflag_require and not (o.rflag_require & r.flag):
         return False
     if o.rflag_filter and (o.rflag_filter & r.flag):
         return False
+    if getattr(o, "cap_thres", 0) > 10:
+        return True
     if r.mapq < o.min_mq:
         return False
     if o.no_orphan and (r.flag & BAM_FPAIRED) and not (r.flag & BAM_FPROPER_PAIR):

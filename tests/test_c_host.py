@@ -309,6 +309,7 @@ CALL_EXE = os.path.join(ROOT, "host", "bcfgpu_call")
     ("call.af-fixation.vcf", "call.af-fixation.1.out", "", None),                                                # all records, not only variants
     ("call.af-fixation.vcf", "call.af-fixation.2.out", "-G {G}/call.af-fixation.txt", None),
     ("call.af-fixation.vcf", "call.af-fixation.3.out", "-G {G}/call.af-fixation.txt -a GP,GQ", None),
+    ("mpileup.vcf", "mpileup.2.out", "-mg0", 23),                                                               # call-side gVCF blocks (test.pl:277)
 ])
 def test_c_call_driver_reproduces_reference_golden(golden_dir, vcff, goldf, args, n):
     """host/bcfgpu_call.c: `call -m [-v] [-S samples] [--ploidy-file f] [-G groups] [-F AN,AC] [-a GP,GQ]` on the reference's

@@ -94,3 +94,50 @@ def test_hip_reproduces_gvcf_golden(golden_dir):
     finally:
         for c in ctxs.values():
             c.close()
+
+
+def test_call_side_gvcf_blocks_match_golden_and_oracle(golden_dir, gpu_ctx_factory):
+    """`bcftools call -mg0` (test/mpileup.2.out): mcall() on the device, then the `call -g` form of bcfgpu_gvcf_blocks --
+    every block line of the golden; and against the oracle's sequential gvcf_write on random records with several ranges,
+    sequences, records at one position and records that are blocks already (INFO/END)."""
+    from tests.test_oracle_golden_gvcf import run_call_gvcf_case, orc_call_blocks
+    from tests.helpers import orc
+    import ctypes as C
+    ctxs = {}
+
+    def dev_mcall(cfg, cin):
+        key = (cfg.n_smpl, cin.n_sites)
+        c = ctxs.get(key)
+        if c is None:
+            cfg.max_sites = cin.n_sites
+            c = ctxs[key] = gpu_ctx_factory(cfg)
+        return c.mcall(cin)
+
+    def dev_blocks(n, S, pos, is_ref, dp, ranges):
+        c = gpu_ctx_factory(abi.default_cfg(S, max_sites=n, max_reads=64))
+        return c.gvcf_call_blocks(pos, is_ref, dp, ranges)
+    run_call_gvcf_case(golden_dir, dev_mcall, dev_blocks)
+    # random records
+    rng = np.random.default_rng(77)
+    for S, n in ((3, 400), (70, 900), (1, 50)):
+        ctx = gpu_ctx_factory(abi.default_cfg(S, max_sites=n, max_reads=64))
+        step = rng.choice([0, 1, 1, 1, 1, 3], size=n)                       # 0: a second record at the position (SNP + indel)
+        pos = np.cumsum(step).astype(np.int32)
+        rid = np.sort(rng.integers(0, 3, n)).astype(np.int32)
+        is_ref = (rng.random(n) < 0.85).astype(np.uint8)
+        dp = (rng.integers(0, 9, n)[:, None] + rng.integers(0, 3, (n, S))).astype(np.int32)     # a record's samples are about equally deep
+        dp[rng.random((n, S)) < 0.01] = np.iinfo(np.int32).min              # FORMAT/DP missing
+        got = ctx.gvcf_call_blocks(pos, is_ref, dp, [1, 3, 6], rid=rid)
+        p = orc._p
+        rngs = np.array([1, 3, 6], np.int32)
+        from bcftools_amd.host import GVCF_BLOCK_DTYPE
+        blk, mdp = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        block = np.zeros(n, GVCF_BLOCK_DTYPE)
+        dpo, plo, pl = np.zeros((n, S), np.int32), np.zeros((n, 3, S), np.int32), np.zeros((n, 3, S), np.int32)
+        nb = orc.lib().orc_gvcf_blocks(n, S, p(pos), p(rid), None, p(is_ref), p(dp), p(pl), p(rngs), 3, p(blk), p(mdp), p(block), p(dpo), p(plo))
+        assert got[0] == nb and nb > 0
+        np.testing.assert_array_equal(got[1], blk)
+        np.testing.assert_array_equal(got[2], mdp)
+        for f in ("first_site", "last_site", "start_pos", "end1", "min_dp", "range"):
+            np.testing.assert_array_equal(got[3][f][:nb], block[f][:nb], err_msg=f)
+        np.testing.assert_array_equal(got[4][:nb], dpo[:nb])

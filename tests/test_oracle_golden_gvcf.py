@@ -72,3 +72,62 @@ def orc_gvcf(cfg, res, pos, dp_range, brk):
 
 def test_oracle_reproduces_gvcf_golden(golden_dir):
     run_gvcf_case(golden_dir, orc.mpileup, orc_gvcf)
+
+
+def run_call_gvcf_case(golden_dir, engine, blocks):
+    """`bcftools call -mg0` (test.pl:277, vcfcall.c:1145-1149): the records mcall() leaves with the reference allele alone
+    (ret == 1) collapse into blocks by FORMAT/DP; golden test/mpileup.2.out.  `blocks(n, S, pos, is_ref, dp, ranges)` returns
+    (n_blocks, blk, min_dp, block table, block DP)."""
+    from tests.helpers import calldrv as D
+    G = os.path.join(golden_dir, "call")
+    v, gold = vcf.Vcf(os.path.join(G, "mpileup.vcf")), vcf.Vcf(os.path.join(G, "mpileup.2.out"))
+    called, names = D.run_call(v, engine)
+    assert gold.samples == names
+    S, n = len(names), len(called)
+    pos = np.array([c.src.pos - 1 for c in called], dtype=np.int32)
+    is_ref = np.array([1 if c.ret == 1 else 0 for c in called], dtype=np.uint8)
+    dp = np.array([[int(c.src.fmt("DP", s)) for s in range(S)] for c in called], dtype=np.int32)
+    nb, blk, min_dp, block, bdp = blocks(n, S, pos, is_ref, dp, [0])
+    it = iter(gold.recs)
+    n_blocks = n_plain = 0
+    for i, c in enumerate(called):
+        b = int(blk[i])
+        if b < 0:
+            r = next(it)
+            assert r.pos == c.src.pos and r.alleles == c.alleles, (r.pos, c.src.pos)
+            assert (c.ret == 1 and int(min_dp[i]) != 0) == ("MinDP" in r.info), r.pos
+            n_plain += 1
+        elif int(block[b]["last_site"]) == i:
+            B, r = block[b], next(it)
+            first = called[int(B["first_site"])]
+            where = "17:%d" % r.pos
+            assert r.pos == int(B["start_pos"]) + 1 == first.src.pos, where
+            assert r.alleles == first.alleles and len(r.alleles) == 1 and r.qual is None, where
+            assert set(r.info) == ({"END", "MinDP"} if int(B["start_pos"]) + 1 < int(B["end1"]) else {"MinDP"}), (where, r.info)
+            if "END" in r.info:
+                assert int(r.info["END"]) == int(B["end1"]), (where, r.info["END"], B)
+            assert int(r.info["MinDP"]) == int(B["min_dp"]), (where, r.info["MinDP"], B)
+            assert r.fmt_keys == ["GT", "DP"], where
+            for s in range(S):
+                assert r.fmt("GT", s) == first.gt[s], (where, s)
+                assert int(r.fmt("DP", s)) == int(bdp[b, s]), (where, s, "DP")
+            n_blocks += 1
+    assert next(it, None) is None, "golden has more records"
+    assert n_blocks == nb == 12 and n_plain == 11, (n_blocks, nb, n_plain)
+
+
+def orc_call_blocks(n, S, pos, is_ref, dp, ranges):
+    from bcftools_amd.host import GVCF_BLOCK_DTYPE
+    rng = np.ascontiguousarray(ranges, dtype=np.int32)
+    blk, min_dp = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    block = np.zeros(max(n, 1), GVCF_BLOCK_DTYPE)
+    dpo, plo = np.zeros((max(n, 1), S), np.int32), np.zeros((max(n, 1), 3, S), np.int32)
+    pl = np.zeros((n, 3, S), np.int32)
+    p = orc._p
+    nb = orc.lib().orc_gvcf_blocks(n, S, p(pos), None, None, p(is_ref), p(np.ascontiguousarray(dp)), p(pl), p(rng), len(rng),
+                                   p(blk), p(min_dp), p(block), p(dpo), p(plo))
+    return nb, blk, min_dp, block, dpo
+
+
+def test_oracle_reproduces_call_gvcf_golden(golden_dir):
+    run_call_gvcf_case(golden_dir, orc.mcall, orc_call_blocks)
