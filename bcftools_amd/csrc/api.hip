@@ -35,7 +35,8 @@ struct bcfgpu_ctx {
     float *d_q2p = nullptr;         // 10^(-q/10) as float (htslib g_qual2prob), for the realignment kernel
     double call_theta_log = 0;
     // workspaces sized by cfg.max_sites / cfg.max_reads
-    int *d_hist = nullptr, *d_err = nullptr;
+    int *d_hist = nullptr, *d_err = nullptr;       // d_err: [0] error word, [1] truncated cells, [2..4] counters of glfgen's deep-cell list
+    uint32_t *d_deep_list = nullptr; uint16_t *d_deep_keys = nullptr; uint32_t deep_cap = 0, deep_key_cap = 0;
     CallretPlanes *d_crp = nullptr;
     unsigned long long *d_site_sums = nullptr;
     CallretPlanes cr{};
@@ -119,7 +120,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
     int rc = 0;
     if ((rc = dev_alloc(c, (void**)&c->d_fk, fk.size() * 8)) || (rc = dev_alloc(c, (void**)&c->d_beta, beta.size() * 8 + 64)) ||
         (rc = dev_alloc(c, (void**)&c->d_lhet, lhet.size() * 8)) || (rc = dev_alloc(c, (void**)&c->d_pl2p, sizeof pl2p)) ||
-        (rc = dev_alloc(c, (void**)&c->d_mw, sizeof mw)) || (rc = dev_alloc(c, (void**)&c->d_q2p, 256 * sizeof(float))) || (rc = dev_alloc(c, (void**)&c->d_err, 2 * sizeof(int)))) {
+        (rc = dev_alloc(c, (void**)&c->d_mw, sizeof mw)) || (rc = dev_alloc(c, (void**)&c->d_q2p, 256 * sizeof(float))) || (rc = dev_alloc(c, (void**)&c->d_err, 8 * sizeof(int)))) {
         bcfgpu_destroy(c); return rc;
     }
     hipMemcpy(c->d_fk, fk.data(), fk.size() * 8, hipMemcpyHostToDevice);
@@ -128,7 +129,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
     hipMemcpy(c->d_pl2p, pl2p, sizeof pl2p, hipMemcpyHostToDevice);
     hipMemcpy(c->d_mw, mw, sizeof mw, hipMemcpyHostToDevice);
     { float q2p[256]; for (int i = 0; i < 256; ++i) q2p[i] = (float)std::pow(10., -i / 10.); hipMemcpy(c->d_q2p, q2p, sizeof q2p, hipMemcpyHostToDevice); }
-    hipMemset(c->d_err, 0, 2 * sizeof(int));
+    hipMemset(c->d_err, 0, 8 * sizeof(int));
 
     // the prior: theta <- log(theta * sum_{i<n} 1/i), n = ploidy_max * nsamples (mcall.c:396-416, vcfcall.c:654-655)
     c->call_theta_log = 0;
@@ -152,6 +153,13 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
             (rc = dev_alloc(c, (void**)&c->cr.adf, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->cr.adr, ncells * 4)) ||
             (rc = dev_alloc(c, (void**)&c->cr.cnt4, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->d_site_sums, (size_t)cfg->max_sites * SITE_NSUM * 8)) ||
             (rc = dev_alloc(c, (void**)&c->cr.misc, ncells * 4)) || (rc = dev_alloc(c, (void**)&c->cr.pa, ncells * 4))) {
+            bcfgpu_destroy(c); return rc;
+        }
+        // glfgen's list of cells deeper than its LDS key window, and the scratch their keys go to (2 bytes per pileup entry):
+        // up to 1024 such cells per tile, with at most 32 Mi entries between them (or the whole tile's, when it is smaller)
+        c->deep_cap = 1024;
+        c->deep_key_cap = (uint32_t)std::min<uint64_t>((uint64_t)cfg->max_reads + 16 * 1024, 32u << 20);
+        if ((rc = dev_alloc(c, (void**)&c->d_deep_list, (size_t)c->deep_cap * 8)) || (rc = dev_alloc(c, (void**)&c->d_deep_keys, (size_t)c->deep_key_cap * 2 + 64))) {
             bcfgpu_destroy(c); return rc;
         }
         // the table of plane addresses as glfgen_kernel reads it at the point of its stores (kernels.h: GlfgenParams::crp)
@@ -419,7 +427,7 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
             const long budget = (long)(128 / wgs) * 1280 - 32;
             long c = (budget - (long)glfgen_lds_bytes(0, g.hist_slots)) / 2;
             c = std::min(c & ~15L, 16384L);
-            if (c >= want || wgs == 3) cap = (int)std::min(std::max(c, 2048L), want);
+            if (c >= want || wgs == 3) cap = (int)std::max(c, 2048L);     // the whole window of the tier: `want` only chooses the tier
         }
         g.lds_cap = cap;
         int pc = 64;
@@ -436,6 +444,9 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     // the callret planes are addressed with ncells of *this* tile
     g.hist = c->d_hist; g.err = c->d_err; g.site_sums = c->d_site_sums;
     g.trunc = reinterpret_cast<unsigned int*>(c->d_err + 1);
+    g.deep_list = c->d_deep_list; g.deep_ctr = reinterpret_cast<uint32_t*>(c->d_err + 2); g.deep_keys = c->d_deep_keys;
+    g.deep_cap = c->deep_cap; g.deep_key_cap = c->deep_key_cap;
+    HIPCHK(hipMemsetAsync(c->d_err + 2, 0, 3 * sizeof(int), c->stream));
 #ifdef BCFGPU_DIAG
     {   // phase stamps of glfgen_kernel: totals of the previous launch are printed, then cleared
         static unsigned long long *d_st = nullptr;

@@ -231,11 +231,16 @@ struct WaveCounts {
     __device__ __forceinline__ void clear() { ori = mq0 = ref59 = alt59 = fwd59 = rev59 = 0; }
 };
 
-template <bool INDEL, bool LDS_HIST>
+// DEEP = false: the tile, 256 consecutive cells per workgroup.  A cell with more pileup entries than the LDS key window holds is
+// not worked on here: it is listed (P.deep_*), and the launch that follows (DEEP = true) gives each listed cell a workgroup
+// of its own -- phase A over the cell's reads with all 256 lanes, the keys in a global scratch array instead of LDS, phase B
+// by the one lane that owns the cell.
+template <bool INDEL, bool LDS_HIST, bool DEEP>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, GLF_WAVES))) void glfgen_kernel(const GlfgenParams P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int cap = P.lds_cap;
+    if (DEEP && (blockIdx.x >= P.deep_ctr[0] || P.deep_list[2 * blockIdx.x] == 0xffffffffu)) return;
+    const int cap = DEEP ? 0x7ffffff0 : P.lds_cap;
     double   *s_fk  = reinterpret_cast<double*>(smem + LDS_FK);
     uint32_t *s_cnt = reinterpret_cast<uint32_t*>(smem + LDS_CNT);
     int      *s_hist = reinterpret_cast<int*>(smem + LDS_HIST_OFF);
@@ -244,20 +249,20 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
     // before phase B takes the region
     uint32_t *s_part = s_cnt;
     const int pcol = P.part_cols;                    // columns per value: a power of two, NPART * slots * pcol <= 2048
-    uint16_t *s_key = reinterpret_cast<uint16_t*>(s_tot + (size_t)P.hist_slots * SITE_NSUM);
-    __shared__ unsigned int s_next;
+    uint16_t *s_key = DEEP ? P.deep_keys + P.deep_list[2 * blockIdx.x + 1] : reinterpret_cast<uint16_t*>(s_tot + (size_t)P.hist_slots * SITE_NSUM);
+    __shared__ unsigned int s_next, s_skip;
 
     const int tid = threadIdx.x;
     GLF_STAMP_DECL
     const int S = P.n_smpl;
     const long ncells = (long)P.n_sites * S;
-    const long cell0 = (long)blockIdx.x * WG;
-    const long cell_end = min(cell0 + WG, ncells);
+    const long cell0 = DEEP ? (long)P.deep_list[2 * blockIdx.x] : (long)blockIdx.x * WG;
+    const long cell_end = DEEP ? cell0 + 1 : min(cell0 + WG, ncells);
     const int site0 = (int)(cell0 / S);
     const int site_last = (int)((cell_end - 1) / S);
 
     const long cell = cell0 + tid;
-    const bool active = cell < ncells;
+    const bool active = cell < cell_end;
 
     s_fk[tid] = P.fk[tid];
     if (tid < 8) s_fk[256 + tid] = 0.0;               // [256]: the factor of a lane that sits a chunk element out
@@ -289,21 +294,32 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
     asm volatile("" : "+s"(p_rd), "+s"(p_aux), "+s"(p_off), "+s"(p_epos));
 
     bool done = !active;
-    // a cell must fit one staging round whatever its alignment (the window starts at a multiple of 4 reads)
-    if (active && end - beg > (uint32_t)cap - 3u) { atomicExch(P.err, BCFGPU_E_DEPTH); done = true; }
+    // A cell must fit one staging round whatever its alignment (the window starts at a multiple of 4 reads).  One that does
+    // not is listed for the launch that follows, with room for its keys in the scratch array; the rounds here step over its
+    // reads.  Only when the list or the scratch array is full is the tile refused.
+    bool deep = false;
+    if (!DEEP && active && end - beg > (uint32_t)cap - 3u) {
+        deep = true;
+        const uint32_t need = (end - beg + 16u) & ~7u;           // keys of the cell, the slack of the 8-byte stores, a multiple of 8
+        const uint32_t slot = atomicAdd(&P.deep_ctr[0], 1u), at = atomicAdd(&P.deep_ctr[1], need);
+        const bool room = at + need <= P.deep_key_cap;
+        if (slot < P.deep_cap) { P.deep_list[2 * slot] = room ? (uint32_t)cell : 0xffffffffu; P.deep_list[2 * slot + 1] = room ? at : 0u; }
+        if (slot >= P.deep_cap || !room) { atomicExch(P.err, BCFGPU_E_DEPTH); atomicExch(&P.deep_ctr[2], 1u); }
+    }
     uint32_t base = p_off[cell0];
 
     for (;;) {
         const uint32_t abase = base & ~3u;                       // key index 0 of this round
-        const uint32_t lim = min(abase + (uint32_t)cap, span_end);
-        if (tid == 0) s_next = 0xffffffffu;
+        const uint32_t lim = DEEP ? span_end : min(abase + (uint32_t)cap, span_end);
+        if (tid == 0) { s_next = 0xffffffffu; s_skip = 0; }
         if (LDS_HIST) for (int i = tid; i < P.hist_slots * NPART * pcol; i += WG) s_part[i] = 0;
         __syncthreads();
-        const bool part = !done && beg >= base && end <= lim;    // this lane's cell is handled in this round
-        if (!done && !part) atomicMin(&s_next, beg);             // the first cell left for the next round (deep tiles only)
-        __syncthreads();
+        const bool cand = !done && !deep && beg >= base && end <= lim;
+        if (!done && !cand) atomicMin(&s_next, beg);             // the first cell left for a later round (deep tiles only): one that
+        __syncthreads();                                         // does not fit the window any more, or a listed cell
         const uint32_t nb = s_next;
         const uint32_t rlim = min(nb, lim);                      // reads [base, rlim) belong to this round's cells
+        const bool part = cand && end <= rlim;                   // this lane's cell is handled in this round (cells behind a listed cell wait)
 
         GLF_STAMP(0)
         // ================= phase A: one lane per read =================
@@ -712,7 +728,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
         }
         if (nb == 0xffffffffu) break;
         base = nb;
+        if (!DEEP && !done && deep && beg == base) s_skip = end; // a listed cell at the head of the line: the rounds step over its reads
         __syncthreads();                                         // the slot counters are phase A's partial sums again
+        if (!DEEP) {
+            const uint32_t sk = s_skip;
+            if (sk) { if (deep && beg == base) done = true; base = sk; }
+            __syncthreads();                                     // (s_skip is cleared at the top of the round)
+        }
     }
 
     GLF_STAMP(7)
@@ -748,9 +770,11 @@ template <bool INDEL, bool LDS_HIST>
 static void launch_one(const GlfgenParams &p, hipStream_t s, int grid, size_t lds)
 {
     if (lds > 48 * 1024)    // per launch, on the device the caller has bound: no process-wide state
-        hipFuncSetAttribute(reinterpret_cast<const void*>(glfgen_kernel<INDEL, LDS_HIST>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(glfgen_kernel<INDEL, LDS_HIST, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((glfgen_kernel<INDEL, LDS_HIST>), dim3(grid), dim3(WG), lds, s, p);
+    hipLaunchKernelGGL((glfgen_kernel<INDEL, LDS_HIST, false>), dim3(grid), dim3(WG), lds, s, p);
+    // the cells the launch above listed (none, as a rule: the workgroups leave at once); no key window in LDS
+    if (p.deep_cap) hipLaunchKernelGGL((glfgen_kernel<INDEL, LDS_HIST, true>), dim3(p.deep_cap), dim3(WG), glfgen_lds_bytes(0, p.hist_slots), s, p);
 }
 
 void launch_glfgen(const GlfgenParams &p, hipStream_t s)

@@ -65,6 +65,11 @@ struct GlfgenParams {
     unsigned long long *site_sums;  // [n_sites][SITE_NSUM] site totals of anno[4..15], ori_depth, mq0 (exact integers), zeroed before launch
     int *err;                       // device error word
     unsigned int *trunc;            // cells cut to their first 255 usable reads (counter)
+    // cells whose pileup does not fit the LDS key window: listed by the tile launch, worked on by the launch that follows
+    uint32_t *deep_list;            // [deep_cap][2]: cell, offset of its keys in deep_keys
+    uint32_t *deep_ctr;             // [0] cells listed, [1] keys handed out, [2] set when the list or the scratch ran out (zeroed before launch)
+    uint16_t *deep_keys;            // [deep_key_cap] key scratch
+    uint32_t deep_cap, deep_key_cap;
 #ifdef BCFGPU_DIAG
     unsigned long long *stamps;     // [16] cycle totals per kernel phase
 #endif

@@ -902,6 +902,12 @@ int main(int argc, char **argv)
         free(gret);
     }
 
+    {   /* cells cut to their first 255 usable reads (errmod_cal would draw a random 255: bcfgpu.h, bcfgpu_truncated_cells) */
+        uint32_t ncut = 0;
+        CHECK(bcfgpu_truncated_cells(ctx, &ncut));
+        if (ncut) fprintf(stderr, "[bcfgpu_sam] warning: %u (site, sample) cells held more than 255 usable reads and were cut to their first 255 "
+                                  "(DP, AD, QS count the kept reads only; bcftools subsamples at random inside errmod_cal): lower -d or split the sample's files\n", ncut);
+    }
     /* ---- --gvcf: reference-only records collapse into blocks (gvcf_write, gvcf.c:88-226) on the planes still in HBM ---- */
     int32_t *gv_blk = NULL, *gv_dp = NULL; bcfgpu_gvcf_block *gv_block = NULL; uint8_t *gv_pl = NULL;
     if (gv_n) {

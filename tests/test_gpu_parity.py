@@ -236,37 +236,64 @@ def test_cells_over_255_keep_their_first_255(gpu_ctx_factory, n_smpl, depths, se
     assert ctx.L.bcfgpu_truncated_cells(ctx.h, abi.C.byref(n)) == 0 and n.value == 0      # reading resets the counter
 
 
+def _lone_deep_cells(n_smpl, depths, seed, usable_frac=0.015, n_sites=1):
+    """A tile of `n_sites` x n_smpl cells with the given entries per cell (low base qualities: thousands of pileup entries,
+    few usable reads)."""
+    rng = np.random.default_rng(seed)
+    R = int(np.sum(depths))
+    bq = np.where(rng.random(R) < usable_frac, rng.choice([25, 37, 40], R), 5)
+    rd = (bq | (rng.choice([0, 20, 60, 60, 60], R) << 8) | ((1 << rng.integers(0, 4, R)) << 16) | (rng.integers(0, 2, R) << 20)
+          | (rng.integers(0, 40, R) << 24)).astype(np.uint32)
+    return host.HostTile(n_smpl, rng.choice([1, 2, 4, 8], n_sites).astype(np.int8), np.r_[0, np.cumsum(depths)].astype(np.uint32), rd,
+                         rng.integers(0, 100, R).astype(np.uint8))
+
+
 def test_cell_at_the_edge_of_the_staging_window(gpu_ctx_factory):
-    """Cells that fill a workgroup's LDS window to the last key, at every alignment of their first read: handled or refused
-    with BCFGPU_E_DEPTH, never left spinning (the window starts at a multiple of four reads)."""
-    from bcftools_amd.lib import BcfGpuError
+    """Cells that fill a workgroup's LDS key window to the last key and beyond, at every alignment of their first read (the
+    window starts at a multiple of four reads): inside the window they are worked on in the tile launch, past it in the launch
+    for listed cells -- the same results either way, the oracle's; nothing is refused (the reference never fails here)."""
     n_smpl = 300
     cfg = abi.default_cfg(n_smpl, max_sites=1, max_reads=13000)
     ctx = gpu_ctx_factory(cfg)
-    handled = refused = 0
-    # the window is sized from the tile's mean depth with a floor of 2048 keys (csrc/api.hip): for this shape the floor holds,
-    # a lone cell stops fitting at 2046 entries; the sweep crosses that edge at every alignment
-    for big in range(2010, 2090, 3):
+    # a shallow tile of 300 samples gets the six-workgroups-per-CU window: 6016 keys (csrc/api.hip), a lone cell stops
+    # fitting at 6014 entries; the sweep crosses that edge at every alignment
+    for big in range(5990, 6040, 3):
         for lead in (0, 1, 2, 3):
             depths = np.zeros(n_smpl, np.int64)
             depths[0] = lead
             depths[1] = big
-            R = int(depths.sum())
-            rng = np.random.default_rng(big * 4 + lead)
-            # low base qualities: the cell holds thousands of pileup entries but fewer than 255 usable reads
-            bq = np.where(rng.random(R) < 0.015, 30, 5)
-            rd = (bq | (60 << 8) | ((1 << rng.integers(0, 4, R)) << 16) | (rng.integers(0, 2, R) << 20) | (rng.integers(0, 40, R) << 24)).astype(np.uint32)
-            tile = host.HostTile(n_smpl, np.array([1], dtype=np.int8), np.r_[0, np.cumsum(depths)].astype(np.uint32), rd,
-                                 rng.integers(0, 100, R).astype(np.uint8))
-            try:
-                got = ctx.mpileup(tile)
-            except BcfGpuError as e:
-                assert e.code == abi.E_DEPTH
-                refused += 1
-                continue
-            assert_mplp_equal(got, orc.mpileup(cfg, tile))
-            handled += 1
-    assert handled > 0 and refused > 0
+            tile = _lone_deep_cells(n_smpl, depths, big * 4 + lead)
+            assert_mplp_equal(ctx.mpileup(tile), orc.mpileup(cfg, tile))
+
+
+@pytest.mark.parametrize("n_smpl,n_sites,where,size,usable,seed", [
+    (40, 3, [5], 3000, 0.015, 51),                       # a shallow tile with one cell of a few thousand entries (ADVICE r2)
+    (40, 3, [0, 60, 119], 7000, 0.015, 52),              # the first cell of the tile, one in the middle, the last one
+    (8, 2, [3, 4, 5], 20000, 0.01, 53),                  # neighbours, each far past the largest window (16384 keys)
+    (3, 1, [1], 40000, 0.02, 54),                        # > 255 usable reads inside a listed cell: the first 255 count
+    (300, 1, [7, 250], 9000, 0.05, 55),
+])
+def test_cells_deeper_than_the_key_window(gpu_ctx_factory, n_smpl, n_sites, where, size, usable, seed):
+    """Amplicon-like pile-ups: a few cells with thousands of entries in an otherwise ordinary tile.  They are listed by the tile
+    launch and worked on by a workgroup each; the rest of the tile proceeds.  Equal to the oracle on the pileup cut to every
+    cell's first 255 usable reads."""
+    rng = np.random.default_rng(seed)
+    depths = rng.poisson(12, n_sites * n_smpl).astype(np.int64)
+    for k, c in enumerate(where):
+        depths[c] = size + 37 * k
+    tile = _lone_deep_cells(n_smpl, depths, seed, usable_frac=usable, n_sites=n_sites)
+    # the ordinary cells carry ordinary reads
+    off = tile.plp_off.astype(np.int64)
+    cell = np.repeat(np.arange(n_sites * n_smpl), np.diff(off))
+    plain = ~np.isin(cell, where)
+    tile.rd[plain] = (tile.rd[plain] & ~np.uint32(0xff)) | rng.choice([11, 25, 37, 40], int(plain.sum())).astype(np.uint32)
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), fmt_flag=abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD)
+    ctx = gpu_ctx_factory(cfg)
+    cut = _cut_to_255(tile)
+    got = ctx.mpileup(tile)
+    assert_mplp_equal(got, orc.mpileup(cfg, cut))
+    got2 = ctx.mpileup(tile)                              # the list and its counters start over with every launch
+    assert_mplp_equal(got2, got)
 
 
 @pytest.mark.parametrize("n_sites,n_smpl,seed", [(40, 100, 21), (64, 7, 22)])
