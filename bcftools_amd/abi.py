@@ -166,6 +166,9 @@ PROTOTYPES = {
     "bcfgpu_depth_cap": (C.c_int, [C.POINTER(Reads), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "bcfgpu_compact_calls": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(CallOut), C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    "bcfgpu_compact_calls_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(CallOut), C.c_int32, C.c_int32, C.c_void_p,
+                                             C.c_uint64, C.c_void_p]),
+    "bcfgpu_compact_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "bcfgpu_comm_init_all": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]),
     "bcfgpu_comm_destroy": (None, [C.c_void_p]),
     "bcfgpu_gather_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),

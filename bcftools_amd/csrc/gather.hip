@@ -37,18 +37,28 @@ __device__ __forceinline__ uint32_t rec_bytes(const bcfgpu_call_site &cs, int n_
 }
 
 __global__ __launch_bounds__(256) void compact_size_kernel(const bcfgpu_call_site *cs, int n_sites, int n_smpl, int variants_only,
-                                                           unsigned long long *size)
+                                                           unsigned long long *size, unsigned long long *counts)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k <= n_sites) size[k] = k < n_sites ? rec_bytes(cs[k], n_smpl, variants_only) : 0;
+    uint32_t b = 0;
+    if (k < n_sites) b = rec_bytes(cs[k], n_smpl, variants_only);
+    if (k <= n_sites) size[k] = b;
+    // the number of records: one add per wavefront
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(b != 0);
+    if (m && (threadIdx.x & 63) == 0) atomicAdd(&counts[1], (unsigned long long)__popcll(m));
 }
 
-// one workgroup per site: header, then the GT planes, then the kept PL planes
+// one workgroup per site: header, then the GT planes, then the kept PL planes.  counts: [0] bytes of all records, [1] records
+// (compact_size_kernel), [2] set when the records do not fit cap_bytes (nothing is written then)
 __global__ __launch_bounds__(256) void compact_copy_kernel(const bcfgpu_call_site *cs, const bcfgpu_site *ms, const int8_t *gt, const int32_t *pl,
-                                                           int n_gt_planes, int n_smpl, int site0, int variants_only,
-                                                           const unsigned long long *off, unsigned char *buf)
+                                                           int n_gt_planes, int n_smpl, int n_sites, int site0, int variants_only,
+                                                           const unsigned long long *off, unsigned char *buf, unsigned long long cap_bytes,
+                                                           unsigned long long *counts)
 {
     const int k = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long total = off[n_sites];
+    if (k == 0 && tid == 0) { counts[0] = total; counts[2] = total > cap_bytes ? 1ull : 0ull; }
+    if (total > cap_bytes) return;
     const uint32_t bytes = rec_bytes(cs[k], n_smpl, variants_only);
     if (!bytes) return;
     unsigned char *dst = buf + off[k];
@@ -70,47 +80,57 @@ __global__ __launch_bounds__(256) void compact_copy_kernel(const bcfgpu_call_sit
 
 }  // namespace bcfgpu
 
+// Everything is queued on the context's stream; nothing comes back to the host here.
+extern "C" int bcfgpu_compact_calls_async(bcfgpu_ctx *ctx, int32_t n_sites, int32_t site0, const bcfgpu_site *msite, const bcfgpu_call_out *cout,
+                                          int32_t n_gt_planes, int32_t variants_only, void *d_buf, uint64_t cap_bytes, uint64_t *d_counts)
+{
+    if (!ctx || !cout || !cout->site || !cout->gt || !cout->pl || !d_counts || n_sites < 0 || n_gt_planes < 1 || (cap_bytes && !d_buf))
+        return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_compact_calls_async: bad arguments");
+    hipStream_t st;
+    if (bcfgpu_internal_device(ctx, &st, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_compact_calls_async: bad context");
+    if (hipMemsetAsync(d_counts, 0, 4 * sizeof(uint64_t), st) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_compact_calls_async: counters");
+    if (n_sites == 0) return 0;
+    const int S = bcfgpu_internal_cfg(ctx)->n_smpl;
+    unsigned long long *d_size = (unsigned long long*)bcfgpu_internal_ws(ctx, 35, ((size_t)n_sites + 1) * 8 + 64);
+    if (!d_size) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_compact_calls_async: device workspace");
+    hipLaunchKernelGGL(compact_size_kernel, dim3((n_sites + 256) / 256), dim3(256), 0, st, cout->site, n_sites, S, variants_only, d_size,
+                       reinterpret_cast<unsigned long long*>(d_counts));
+    size_t tmp = 0;
+    if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, d_size, d_size, n_sites + 1, st) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "scan");
+    void *d_tmp = bcfgpu_internal_ws(ctx, 36, tmp + 64);
+    if (!d_tmp) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_compact_calls_async: device workspace");
+    if (hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp, d_size, d_size, n_sites + 1, st) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "scan");
+    hipLaunchKernelGGL(compact_copy_kernel, dim3(n_sites), dim3(256), 0, st, cout->site, msite, cout->gt, cout->pl, n_gt_planes, S, n_sites, site0,
+                       variants_only, d_size, (unsigned char*)d_buf, (unsigned long long)cap_bytes, reinterpret_cast<unsigned long long*>(d_counts));
+    if (hipGetLastError() != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_compact_calls_async: launch");
+    return 0;
+}
+
+extern "C" int bcfgpu_compact_counts(bcfgpu_ctx *ctx, const uint64_t *d_counts, uint64_t *n_bytes, uint32_t *n_rec)
+{
+    if (!ctx || !d_counts || !n_bytes) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_compact_counts: bad arguments");
+    hipStream_t st;
+    if (bcfgpu_internal_device(ctx, &st, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_compact_counts: bad context");
+    uint64_t *h = (uint64_t*)bcfgpu_internal_pinned(ctx, 1, 4 * sizeof(uint64_t));
+    if (!h) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_compact_counts: staging");
+    if (hipMemcpyAsync(h, d_counts, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_compact_counts: read");
+    *n_bytes = h[0]; if (n_rec) *n_rec = (uint32_t)h[1];
+    if (h[2]) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_compact_calls: the buffer is too small for the records (see bcfgpu_call_rec)");
+    return 0;
+}
+
 extern "C" int bcfgpu_compact_calls(bcfgpu_ctx *ctx, int32_t n_sites, int32_t site0, const bcfgpu_site *msite, const bcfgpu_call_out *cout,
                                     int32_t n_gt_planes, int32_t variants_only, void *d_buf, uint64_t cap_bytes,
                                     uint64_t *n_bytes, uint32_t *n_rec)
 {
-    if (!ctx || !cout || !cout->site || !cout->gt || !cout->pl || !n_bytes || n_sites < 0 || n_gt_planes < 1)
-        return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_compact_calls: bad arguments");
-    hipStream_t st;
-    if (bcfgpu_internal_device(ctx, &st, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_compact_calls: bad context");
+    if (!n_bytes) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_compact_calls: bad arguments");
     *n_bytes = 0; if (n_rec) *n_rec = 0;
-    if (n_sites == 0) return 0;
-    const int S = bcfgpu_internal_cfg(ctx)->n_smpl;
-    unsigned long long *d_size = (unsigned long long*)bcfgpu_internal_ws(ctx, 35, ((size_t)n_sites + 1) * 8 + 64);
-    if (!d_size) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_compact_calls: device workspace");
-    hipLaunchKernelGGL(compact_size_kernel, dim3((n_sites + 256) / 256), dim3(256), 0, st, cout->site, n_sites, S, variants_only, d_size);
-    size_t tmp = 0;
-    if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, d_size, d_size, n_sites + 1, st) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "scan");
-    void *d_tmp = bcfgpu_internal_ws(ctx, 36, tmp + 64);
-    if (!d_tmp) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_compact_calls: device workspace");
-    if (hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp, d_size, d_size, n_sites + 1, st) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "scan");
-    unsigned long long total = 0;
-    if (hipMemcpyAsync(&total, d_size + n_sites, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-        return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_compact_calls: total");
-    if (total > cap_bytes) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_compact_calls: the buffer is too small for the records (see bcfgpu_call_rec)");
-    if (total) {
-        if (!d_buf) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_compact_calls: NULL buffer");
-        hipLaunchKernelGGL(compact_copy_kernel, dim3(n_sites), dim3(256), 0, st, cout->site, msite, cout->gt, cout->pl, n_gt_planes, S, site0,
-                           variants_only, d_size, (unsigned char*)d_buf);
-    }
-    if (hipGetLastError() != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_compact_calls: launch");
-    *n_bytes = total;
-    if (n_rec) {
-        // the count: records are at least sizeof(bcfgpu_call_rec) apart; counted on the host from the sizes would need them back,
-        // so a second tiny reduction: the number of non-empty sites
-        std::vector<unsigned long long> h((size_t)n_sites + 1);
-        if (hipMemcpyAsync(h.data(), d_size, ((size_t)n_sites + 1) * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
-            return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_compact_calls: offsets");
-        uint32_t c = 0;
-        for (int k = 0; k < n_sites; ++k) c += h[k + 1] > h[k];
-        *n_rec = c;
-    }
-    return 0;
+    uint64_t *d_counts = (uint64_t*)bcfgpu_internal_ws(ctx, 37, 64);
+    if (!d_counts) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_compact_calls: device workspace");
+    const int rc = bcfgpu_compact_calls_async(ctx, n_sites, site0, msite, cout, n_gt_planes, variants_only, d_buf, cap_bytes, d_counts);
+    if (rc) return rc;
+    return bcfgpu_compact_counts(ctx, d_counts, n_bytes, n_rec);
 }
 
 // ---- RCCL, loaded on first use --------------------------------------------------------------------------------------

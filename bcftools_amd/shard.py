@@ -52,7 +52,10 @@ def gather_packed(local, n_bytes, out, dst=0):
     (a tiny all_gather), then one grouped send/recv: `dst` posts a receive per peer, every peer one send -- ncclGroupStart /
     ncclRecv x (N-1) / ncclSend / ncclGroupEnd on RCCL, the exchange bcfgpu_gather_bytes makes for the C driver."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    n = torch.tensor([int(n_bytes)], dtype=torch.int64, device=local.device)
+    # n_bytes: a host integer, or a one-element int64 tensor on the device (the counter bcfgpu_compact_calls_async leaves there:
+    # then the only host wait is the .item() below, on whatever stream is current -- bench.py makes that a side stream that
+    # waits for the compaction alone, so the next step's kernels run meanwhile)
+    n = n_bytes.reshape(1).to(torch.int64) if torch.is_tensor(n_bytes) else torch.tensor([int(n_bytes)], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n)
     sizes = [int(x.item()) for x in sizes]

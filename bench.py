@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--extras", type=int, default=1, help="snp mode at N=1: also measure the BASELINE configs[4] shape (sample groups + ploidy array) and "
                                                           "the indel stage (configs[2] shape) in child processes and embed their results under \"extra\" (0: skip)")
     ap.add_argument("--indel-callers", type=int, default=1, help="indel mode: also time the host-pointer form of the stage on one 32-column batch (0: skip)")
-    ap.add_argument("--mode", choices=["snp", "indel", "baq", "pileup", "gvcf"], default="snp",
+    ap.add_argument("--mode", choices=["snp", "indel", "baq", "pileup", "gvcf", "mixed"], default="snp",
                     help="snp: the headline pipeline (default).  indel: bcf_call_gap_prep on synthetic indel-candidate columns "
                          "(BASELINE configs[2] shape, 500 samples), reports DP cells/s of the realignment kernel.  "
                          "baq: bcfgpu_baq (sam_prob_realn) over the reads of the same synthetic columns.  "
@@ -163,6 +163,97 @@ def main_indel(a):
         out["cpu_baseline"] = {"value": k / tc, "unit": "sites/s", "cores": 1, "kind": "port",
                                "sample": "first %d columns, oracle orc_gap_prep on one host core, %.1f s "
                                          "(results compared with the device path)" % (k, tc)}
+    print(json.dumps(out), flush=True)
+    ctx.close()
+
+
+def main_mixed(a):
+    """BASELINE configs[2] end to end (100 k sites, 10 % of them indel sites, 500 samples), scaled to one step: the SNP path over
+    a tile of T pileup columns (glfgen + combine + call -m + compaction of the variant records) AND the indel path over T/10
+    candidate columns of a read pool resident in HBM (bcfgpu_gap_prep_tile and the indel pass of bcfgpu_mpileup on the tile it
+    returns: the indel records as `mpileup` writes them).  value = T / wall time of a step: pileup columns per second with their indel
+    records.  The CPU baseline runs the oracle on the first sites / columns of the same inputs, one core."""
+    import torch
+    from bcftools_amd import abi, synth, engine, host
+    from bcftools_amd.lib import check
+    from tests.helpers import indeldrv
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    dev = torch.device("cuda", 0)
+    S = 500 if a.samples == 1000 else a.samples
+    n_ind = 128 if a.sites is None else max(1, a.sites // 10)
+    T = 10 * n_ind
+    # ---- SNP side: a synthetic tile on the device ----
+    tile = synth.torch_tile(a.seed, T, S, dev, depth=a.depth, var_rate=a.var_rate)
+    R = tile["n_reads"]
+    b = synth.indel_batch(a.seed, n_ind, S, depth=a.depth)
+    E = len(b["p_read"])
+    cfg = abi.default_cfg(S, max_sites=T, max_reads=max(R, int(E * 1.05)) + 64)
+    ctx = engine.Context(cfg)
+    L = ctx.L
+    dt = abi.Tile()
+    dt.n_sites, dt.is_indel, dt.n_reads = T, 0, R
+    dt.ref16, dt.plp_off, dt.rd, dt.epos = (tile["ref16"].data_ptr(), tile["plp_off"].data_ptr(), tile["rd"].data_ptr(), tile["epos"].data_ptr())
+    mo, mbufs, _ = ctx.alloc_mplp_out(T)
+    co, cbufs, _ = ctx.alloc_call_out(T, abi.MAX_PL)
+    rec_cap = 64 << 20
+    recbuf = torch.empty(rec_cap, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(4, dtype=torch.int64, device=dev)
+    # ---- indel side: the pool in HBM (bcfgpu_pileup, untimed like the resident SNP tile), outputs of the indel pass and its calls ----
+    pool = indeldrv.DevicePool(ctx, b)
+    imo, imb, ires = ctx.alloc_mplp_out(n_ind)
+    ctx.sync()
+
+    def step():
+        check(L.bcfgpu_pipeline(ctx.h, C.byref(dt), None, None, C.byref(mo), C.byref(co)))
+        check(L.bcfgpu_compact_calls_async(ctx.h, T, 0, mo.site, C.byref(co), abi.MAX_PL, 2, recbuf.data_ptr(), rec_cap, counts.data_ptr()))
+        got, st, itile = pool.gap_prep_tile()
+        check(L.bcfgpu_mpileup(ctx.h, C.byref(itile), C.byref(imo)))
+        return got, st
+    for _ in range(max(1, a.warmup)):
+        step()
+    ctx.sync()
+    steps = max(1, a.steps)
+    t0 = time.perf_counter()
+    prep = kern = 0.0
+    for _ in range(steps):
+        got, st = step()
+        prep += st.prepare_ms; kern += st.kernel_ms
+    ctx.sync()
+    t1 = time.perf_counter()
+    nb_, nr_ = C.c_uint64(), C.c_uint32()
+    check(L.bcfgpu_compact_counts(ctx.h, counts.data_ptr(), C.byref(nb_), C.byref(nr_)))
+    ctx._download(imb, ires)
+    live = got["ret"] == 0
+    per_step = (t1 - t0) / steps
+    out = {"metric": "pileup columns/sec with their indel records (mpileup | call -m, 10 %% indel sites), %d samples x %.0fx" % (S, a.depth),
+           "value": T / per_step, "unit": "sites/s", "n_gpus": 1, "steps": steps, "ms_per_step": per_step * 1e3, "higher_is_better": True,
+           "dtype": "u8/i32 + f64 likelihood sums; f64 pair-HMM", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[2] shape scaled to one step: SNP path over %d columns + bcf_call_gap_prep and the indel pass over %d "
+                                  "candidate columns, inputs resident in HBM" % (T, n_ind),
+                      "samples": S, "depth": a.depth, "snp_columns": T, "indel_columns": n_ind, "snp_reads": R, "indel_pileup_entries": E,
+                      "variant_records": int(nr_.value), "indel_records": int(((ires.site["ret"] == 0) & live).sum())},
+           "split_ms": {"gap_prep_realignment_kernels": kern / steps, "gap_prep_host_prepare": prep / steps},
+           "note": "the indel path is the Amdahl term: %d candidate columns cost far more than %d SNP columns" % (n_ind, T)}
+    if a.cpu_seconds > 0:
+        from tests.helpers import orc
+        ht = synth.tile_from_torch(tile)
+        ns = min(T, 64)
+        sub = host.HostTile(S, ht.ref16[:ns], ht.plp_off[: ns * S + 1], ht.rd[: ht.plp_off[ns * S]], ht.epos[: ht.plp_off[ns * S]])
+        orc.mpileup(cfg, sub)
+        c0 = time.perf_counter()
+        m = orc.mpileup(cfg, sub)
+        orc.mcall(cfg, host.CallInput(S, m.site["n_alleles"], np.maximum(m.site["unseen"], 0), m.pl.astype(np.int32), m.site["qsum"]))
+        t_snp = (time.perf_counter() - c0) / ns
+        c0 = time.perf_counter()
+        k = 0
+        while k < n_ind and (k < 1 or time.perf_counter() - c0 < a.cpu_seconds):
+            indeldrv.gap_prep_oracle_site(b, k)
+            k += 1
+        t_ind = (time.perf_counter() - c0) / k
+        out["cpu_baseline"] = {"value": 1.0 / (t_snp + 0.1 * t_ind), "unit": "sites/s", "cores": 1, "kind": "port",
+                               "sample": "oracle on one host core: mpileup+mcall on the first %d columns (%.2f ms each), orc_gap_prep on the first %d "
+                                         "candidate columns (%.1f ms each); per pileup column = SNP cost + a tenth of the indel cost" % (ns, t_snp * 1e3, k, t_ind * 1e3)}
     print(json.dumps(out), flush=True)
     ctx.close()
 
@@ -462,6 +553,8 @@ def main():
         return main_pileup(a)
     if a.mode == "indel":
         return main_indel(a)
+    if a.mode == "mixed":
+        return main_mixed(a)
     if a.mode == "baq":
         return main_baq(a)
     if a.mode == "gvcf":
@@ -519,28 +612,64 @@ def main():
     # What leaves a shard is the records `call -mv` would write: compacted on the device (call record + mpileup site record +
     # the GT and PL planes of the variant sites, bcfgpu_compact_calls) and, for N > 1, gathered to rank 0 in rank order with
     # grouped send/recv -- the same two library calls host/bcfgpu_mgpu.c makes.
-    rec_cap = 64 << 20
+    # room for the records of a step: every site a variant with all PL planes would be T * (400 + 62 S) bytes; variant sites are
+    # a few per cent of the tile, a quarter of that bound (at least 64 MiB) is held and an overflow is reported, never overrun
+    rec_cap = max(64 << 20, (T * (512 + S * (2 + 4 * abi.MAX_PL))) // 4)
     if os.environ.get("BCFGPU_ABLATE"):                        # diagnostics build (tools/ablate_kernel.sh): a kernel with parts switched off
         rec_cap = T * (512 + S * (2 + 4 * abi.MAX_PL)) + 4096   # calls garbage, so every site may come out a variant
-    recbuf = torch.empty(rec_cap, dtype=torch.uint8, device=dev)
     n_bytes, n_rec = C.c_uint64(), C.c_uint32()
-    gathered = torch.empty(rec_cap * world, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
-    # the library enqueues on torch's current stream, so the RCCL gather of a step is ordered after that step's kernels and
-    # before the next step's by the streams alone (no host synchronisation inside the timed loop)
+    # Two record buffers with their counters (bytes, records, overflow: on the device).  N = 1: nothing comes back to the host
+    # inside the timed loop.  N > 1: the gather of step i-1 runs on a side stream beside the kernels of step i -- the only
+    # host wait is for step i-1's byte count, while the device works on step i (the two library calls
+    # host/bcfgpu_mgpu.c makes, bcfgpu_compact_calls* and the ordered gather).
+    recbuf = [torch.empty(rec_cap, dtype=torch.uint8, device=dev) for _ in range(2 if world > 1 else 1)]
+    counts = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in recbuf]
+    rehearse = world > 1 and os.environ.get("BCFGPU_BENCH_REHEARSE") == "1"
+    gathered = torch.empty(rec_cap * world, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0 and not rehearse) else None
+    gathered_host = torch.empty(rec_cap * world, dtype=torch.uint8) if (rehearse and rank == 0) else None
+    work_stream = comm_stream = None
     if world > 1:
         work_stream = torch.cuda.Stream(device=dev)          # (the default stream has handle 0 = "the library's own stream")
+        comm_stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(work_stream)
         check(L.bcfgpu_set_stream(ctx.h, C.c_void_p(work_stream.cuda_stream)))
+        ev_done = [torch.cuda.Event() for _ in recbuf]       # compaction into buffer j queued up to here
+        ev_free = [torch.cuda.Event() for _ in recbuf]       # the gather has read buffer j
+    state = {"i": 0, "pending": None}
+
+    def gather(j):
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ev_done[j])
+            if rehearse:                                      # gloo moves host tensors: the dry run stages the records through the host
+                nb_ = int(counts[j][0].item())
+                sz = shard.gather_packed(recbuf[j][:nb_].cpu(), nb_, gathered_host, dst=0)
+                if rank == 0:
+                    state["gathered_bytes"] = sum(sz)
+            else:
+                sz = shard.gather_packed(recbuf[j], counts[j][0:1], gathered, dst=0)
+                if rank == 0:
+                    state["gathered_bytes"] = sum(sz)
+            ev_free[j].record(comm_stream)
 
     def step():
+        j = state["i"] % len(recbuf)
+        if world > 1 and state["i"] >= len(recbuf):
+            work_stream.wait_event(ev_free[j])                # the buffer's previous records have left
         check(L.bcfgpu_pipeline(ctx.h, C.byref(dt), d_ploidy.data_ptr() if d_ploidy is not None else None,
                                 d_grp.data_ptr() if d_grp is not None else None, C.byref(mo), C.byref(co)))
-        check(L.bcfgpu_compact_calls(ctx.h, T, rank * T, mo.site, C.byref(co), abi.MAX_PL, 2, recbuf.data_ptr(), rec_cap,
-                                     C.byref(n_bytes), C.byref(n_rec)))
+        check(L.bcfgpu_compact_calls_async(ctx.h, T, rank * T, mo.site, C.byref(co), abi.MAX_PL, 2, recbuf[j].data_ptr(), rec_cap,
+                                           counts[j].data_ptr()))
         if world > 1:
-            shard.gather_packed(recbuf, int(n_bytes.value), gathered, dst=0)
+            ev_done[j].record(work_stream)
+            if state["pending"] is not None:
+                gather(state["pending"])
+            state["pending"] = j
+        state["i"] += 1
 
     def fence():
+        if world > 1 and state["pending"] is not None:
+            gather(state["pending"])
+            state["pending"] = None
         check(L.bcfgpu_sync(ctx.h))
         torch.cuda.synchronize()
         if world > 1:
@@ -558,6 +687,7 @@ def main():
     t1 = time.perf_counter()
     tm = ctx.last_timing()
     check(L.bcfgpu_timing_enable(ctx.h, 0))
+    check(L.bcfgpu_compact_counts(ctx.h, counts[(state["i"] - 1) % len(recbuf)].data_ptr(), C.byref(n_bytes), C.byref(n_rec)))   # (BCFGPU_E_RANGE on overflow)
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
@@ -572,13 +702,16 @@ def main():
         # HBM traffic of the dominant kernel: PMC-measured on a launch of this very shape (tools/profile.sh: rocprofv3 --pmc,
         # FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950, separate passes), never scaled: a run
         # with another tile shape reports null
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
-            if tj["samples"] == S and abs(tj["depth"] - a.depth) < 1e-9 and tj["sites"] == T:
-                traffic = tj["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        traffic = traffic_source = None
+        for tf in ("r3_traffic.json", "r2_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+                if tj["samples"] == S and abs(tj["depth"] - a.depth) < 1e-9 and tj["sites"] == T:
+                    traffic = tj["hbm_bytes_per_launch"]
+                    traffic_source = "profiles/%s (builder-side tools/profile.sh run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this launch shape; not measured in this run)" % tf
+                    break
+            except Exception:
+                pass
         kern_s = tm["glfgen_ms"] * 1e-3
         achieved = alg / kern_s / 1e9 if kern_s > 0 else 0.0
         out = {
@@ -594,9 +727,11 @@ def main():
                        "sharding": "contiguous region shard per GPU; the records call -mv would write are compacted on the device and "
                                    "gathered to rank 0 in rank order (grouped send/recv)",
                        "records_per_step_per_gpu": int(n_rec.value), "record_bytes_per_step_per_gpu": int(n_bytes.value),
+                       **({"gathered_bytes_last_step": int(state.get("gathered_bytes", 0)),
+                           "transport": "gloo (rehearsal, staged through the host)" if rehearse else "RCCL grouped send/recv (torch.distributed nccl backend), side stream"} if world > 1 else {}),
                        "groups": a.groups, "haploid_frac": a.haploid_frac},
             "roofline": {"bound": "hbm", "kernel": "glfgen_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": tm["glfgen_ms"],
                          "other_kernels_ms": {"combine_kernel": tm["combine_ms"], "mcall_kernel": tm["mcall_ms"]},
                          # the two smaller kernels against the same roofline: bytes they must move per cell (DESIGN.md 3.2, 3.3;
@@ -675,11 +810,17 @@ def main():
             c4 = child(["--groups", "4", "--haploid-frac", "0.25", "--steps", str(max(3, a.steps // 2)), "--warmup", "2",
                         "--samples", str(S), "--depth", str(a.depth), "--sites", str(T)] + common)
             ind = child(["--mode", "indel", "--steps", "4", "--cpu-seconds", "8", "--cpu-all-cores", "0", "--extras", "0", "--seed", str(a.seed)])
+            mix = child(["--mode", "mixed", "--steps", "4", "--warmup", "1", "--cpu-seconds", "6", "--cpu-all-cores", "0", "--extras", "0", "--seed", str(a.seed)])
+            hf = child(["--mode", "pileup", "--steps", "6", "--cpu-seconds", "0", "--cpu-all-cores", "0", "--extras", "0", "--seed", str(a.seed)])
             out["extra"] = {
+                "configs2_mixed": {k: mix.get(k) for k in ("metric", "value", "unit", "ms_per_step", "config", "split_ms", "cpu_baseline", "error") if k in mix},
+                "host_fed_pileup": {k: hf.get(k) for k in ("metric", "value", "unit", "config", "whole_call_ms", "pcie", "host_fed_pipeline", "error") if k in hf},
                 "configs4_shape": {k: c4.get(k) for k in ("value", "unit", "ms_per_step", "config", "roofline", "error") if k in c4},
                 "indel_stage": {k: ind.get(k) for k in ("metric", "value", "unit", "config", "kernel", "host_ms", "indel_pass", "host_pointer_form", "cpu_baseline", "error") if k in ind},
                 "note": "configs4_shape: the same tile through call -G (4 sample groups on FORMAT/AD) with a ploidy array (25 % haploid); "
-                        "indel_stage: bcf_call_gap_prep on 500-sample indel-candidate columns (BASELINE configs[2] shape), bcfgpu_gap_prep_tile on a read pool resident in HBM"}
+                        "indel_stage: bcf_call_gap_prep on 500-sample indel-candidate columns (BASELINE configs[2] shape), bcfgpu_gap_prep_tile on a read pool resident in HBM; "
+                        "configs2_mixed: SNP path + indel path per step at the configs[2] mix (10 % indel sites); host_fed_pileup: --mode pileup, the read "
+                        "pool crossing PCIe every region (what a user of host/bcfgpu_sam sees, DESIGN.md 5)"}
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

@@ -504,6 +504,14 @@ typedef struct {
 int  bcfgpu_compact_calls(bcfgpu_ctx *ctx, int32_t n_sites, int32_t site0, const bcfgpu_site *msite, const bcfgpu_call_out *cout,
                           int32_t n_gt_planes, int32_t variants_only, void *d_buf, uint64_t cap_bytes, uint64_t *n_bytes, uint32_t *n_rec);
 
+/* The same without a word coming back to the host: everything is queued on the context's stream.  d_counts: DEVICE, four
+ * 64-bit words the caller owns (so that several compactions can be in flight): [0] bytes of all records, [1] records,
+ * [2] != 0 when they did not fit cap_bytes (nothing was written then).  bcfgpu_compact_counts waits for the stream and
+ * reads them (BCFGPU_E_RANGE when [2] is set); a caller with streams of its own may read them any other way. */
+int  bcfgpu_compact_calls_async(bcfgpu_ctx *ctx, int32_t n_sites, int32_t site0, const bcfgpu_site *msite, const bcfgpu_call_out *cout,
+                                int32_t n_gt_planes, int32_t variants_only, void *d_buf, uint64_t cap_bytes, uint64_t *d_counts);
+int  bcfgpu_compact_counts(bcfgpu_ctx *ctx, const uint64_t *d_counts, uint64_t *n_bytes, uint32_t *n_rec);
+
 /* One communicator over the contexts of a node, rank i = ctxs[i] (RCCL ncclCommInitAll; every context on its own device;
  * librccl is loaded at this call, a single context needs none). */
 typedef struct bcfgpu_comm bcfgpu_comm;
