@@ -190,6 +190,8 @@ extern "C" int bcfgpu_comm_init_all(bcfgpu_ctx *const *ctxs, int32_t n, bcfgpu_c
         if (!R) { delete c; return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_comm_init_all: librccl.so could not be loaded"); }
         const ncclResult_t rc = R->CommInitAll(c->comm.data(), n, dev.data());
         if (rc) { delete c; return bcfgpu_set_error(BCFGPU_E_HIP, R->GetErrorString ? R->GetErrorString(rc) : "ncclCommInitAll failed"); }
+        // one line, once per communicator: which transport the ordered gather runs on (the first multi-GPU box tells us)
+        fprintf(stderr, "[bcfgpu] gather transport: RCCL (ncclCommInitAll over %d devices; grouped ncclSend / ncclRecv to rank 0)\n", n);
     }
     *out = c;
     return 0;

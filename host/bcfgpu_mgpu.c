@@ -146,6 +146,9 @@ int main(int argc, char **argv)
     if (n_ranks < 1) n_ranks = 1;
     if (!share && n_ranks > ndev) { fprintf(stderr, "%d ranks but %d device(s): use --share-devices to rehearse\n", n_ranks, ndev); return 1; }
     use_rccl = n_ranks > 1 && !share && (!gather || !strcmp(gather, "rccl"));
+    if (n_ranks > 1)
+        fprintf(stderr, "[bcfgpu_mgpu] %d ranks on %d device(s); ordered gather over %s\n", n_ranks, ndev,
+                use_rccl ? "RCCL (bcfgpu_gather_bytes: grouped ncclSend / ncclRecv)" : "host memory (--gather host / --share-devices)");
     static const uint8_t bq_values[4] = { 11, 25, 37, 40 };
 
     /* ---- the column loop of bcfgpu_host.c: the whole region ---- */

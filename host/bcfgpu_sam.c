@@ -30,6 +30,10 @@
 #include <ctype.h>
 #include <math.h>
 #include <zlib.h>
+#include <spawn.h>
+#include <unistd.h>
+#include <sys/types.h>
+#include <sys/wait.h>
 #include "bcfgpu.h"
 #include "vcfio.h"
 
@@ -261,11 +265,18 @@ static int sample_of(const sfile_t *f, const char *rg)                      /* b
 
 /* ---- reading: SAM text or BAM; the read filters of mplp_func (mpileup.c:183-246) ---- */
 static int rflag_require = 0, rflag_filter = 4 | 256 | 512 | 1024, min_mq = 0, keep_orphans = 0;
-static int defer_mq_filters = 0;      /* -C: sam_cap_mapq comes between the flag filters and the -q / orphan filters (mpileup.c:234-241) */
+static int defer_mq_filters = 0;
+static int reg_beg = 0, reg_end = 0x7fffffff;   /* the region: only reads that overlap it enter the pool, as htslib's region iterator hands them out */      /* -C: sam_cap_mapq comes between the flag filters and the -q / orphan filters (mpileup.c:234-241) */
 
 static void pool_add(pool_t *P, int file, int smpl, const char *qname, int flag, int pos, int mapq, int rnext_same, int mpos, int isize,
                      const uint32_t *cig, int ncig, int lq, const uint8_t *seq16, const uint8_t *qual)
 {
+    {   /* [pos, endpos) against the region (a read without a reference span counts as one base: bam_endpos) */
+        int e = pos;
+        for (int c = 0; c < ncig; ++c) { const int op = cig[c] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) e += (int)(cig[c] >> 4); }
+        if (e == pos) e = pos + 1;
+        if (pos >= reg_end || e <= reg_beg) return;
+    }
     if (P->n == P->cap) {
         P->cap = P->cap ? 2 * P->cap : 1024;
         #define G(a) P->a = grow(P->a, (size_t)P->cap * sizeof *P->a)
@@ -631,6 +642,8 @@ int main(int argc, char **argv)
     int32_t gv_range[16]; int gv_n = 0;                                       /* mpileup --gvcf INT,.. (gvcf.c:44-67) */
     char out_mode = 'v'; const char *out_path = "-"; int max_depth = 250;      /* mpileup -O, -o, -d (mpileup.c:937-950) */
     int baq_flag = 3, min_baseQ = 13, list_only = 0;
+    int n_gpus = 1, shard = -1;                                               /* --gpus N: region shards, one process per shard; --shard K: this is shard K */
+    char **argv0 = argv; const int argc0 = argc;
     int cap_thres = 0;                                                        /* mpileup -C (adjust-MQ), mpileup.c:938 */
     int openQ = 40, extQ = 20, tandemQ = 100, min_support = 1, per_sample_flt = 0, no_indels = 0, max_indel_depth = 250; double min_frac = 0.002;   /* mpileup.c:937-950 */
     while (argc > 2 && argv[1][0] == '-') {
@@ -669,7 +682,9 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "-S")) { add_samples(argv[2], 1); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-G")) { add_readgroups(argv[2]); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "--ignore-RG")) { SM.ignore_rg = 1; ++argv; --argc; }
-        else if (!strcmp(argv[1], "--list-samples")) { list_only = 1; ++argv; --argc; }                 /* host logic only: no device needed */
+        else if (!strcmp(argv[1], "--list-samples")) { list_only = 1; ++argv; --argc; }
+        else if (!strcmp(argv[1], "--gpus")) { n_gpus = atoi(argv[2]); argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "--shard")) { shard = atoi(argv[2]); argv += 2; argc -= 2; }                 /* host logic only: no device needed */
         else if (!strcmp(argv[1], "-B")) { baq_flag = 0; ++argv; --argc; }                             /* mpileup.c:1045,1062 */
         else if (!strcmp(argv[1], "-E")) { baq_flag = 7; ++argv; --argc; }
         else if (!strcmp(argv[1], "-A")) { keep_orphans = 1; ++argv; --argc; }
@@ -696,6 +711,74 @@ int main(int argc, char **argv)
     defer_mq_filters = cap_thres > 10;
     const char *contig = argv[2];
     const int beg = atoi(argv[3]) - 1, end = atoi(argv[4]);                 /* 0-based [beg, end) */
+    if (n_gpus > 1 && shard < 0 && !list_only) {
+        /* ---- several GPUs (the reference's -r regions + `bcftools concat`, mpileup.c:652-683, vcfconcat.c:420):
+         * the region is cut into contiguous shards, a process per shard (shard k on device k mod the devices present), each
+         * writing its records as VCF text; rank order is genomic order, so the files are written out one after the other, the
+         * header from the first.  Sites are independent, and a shard reads the reads that overlap it: the records equal the
+         * single-process run's.  (This process makes no device call before it starts the others.) ---- */
+        if (gv_n) DIE("--gpus with --gvcf: a block would end at every shard boundary; not supported\n");
+        const int n_sh = n_gpus < end - beg ? n_gpus : (end - beg > 0 ? end - beg : 1);
+        pid_t *pid = malloc((size_t)n_sh * sizeof *pid);
+        char (*tmp)[256] = malloc((size_t)n_sh * sizeof *tmp);
+        for (int k = 0; k < n_sh; ++k) {
+            const long b0 = beg + (long)(end - beg) * k / n_sh, e0 = beg + (long)(end - beg) * (k + 1) / n_sh;
+            snprintf(tmp[k], sizeof tmp[k], "/tmp/bcfgpu_sam.%d.%d.vcf", (int)getpid(), k);
+            char **av = malloc((size_t)(argc0 + 12) * sizeof *av);
+            int n = 0;
+            av[n++] = argv0[0];
+            static char sb[16][24];
+            snprintf(sb[0], 24, "%d", k); snprintf(sb[1], 24, "%ld", b0 + 1); snprintf(sb[2], 24, "%ld", e0);
+            av[n++] = "--shard"; av[n++] = sb[0];
+            const int first_pos = argc0 - argc + 1;              /* index of ref.fa in argv0 */
+            for (int i = 1; i < first_pos; ++i) {                /* the options, without -O / -o FILE / --output / --gpus */
+                const char *o = argv0[i];
+                if (!strcmp(o, "--gpus") || !strcmp(o, "--output") || !strcmp(o, "-O")) { ++i; continue; }
+                if (!strncmp(o, "-O", 2) && o[2]) continue;
+                if (!strcmp(o, "-o")) { char *e; strtol(argv0[i + 1], &e, 10); if (*e) { ++i; continue; } }
+                av[n++] = argv0[i];
+            }
+            av[n++] = "-O"; av[n++] = "v"; av[n++] = "--output"; av[n++] = tmp[k];
+            av[n++] = argv0[first_pos]; av[n++] = argv0[first_pos + 1];
+            char *rb = strdup(sb[1]), *re = strdup(sb[2]);
+            av[n++] = rb; av[n++] = re;
+            for (int i = first_pos + 4; i < argc0; ++i) av[n++] = argv0[i];
+            av[n] = NULL;
+            extern char **environ;
+            if (posix_spawn(&pid[k], "/proc/self/exe", NULL, NULL, av, environ)) DIE("cannot start shard %d\n", k);
+            free(av);
+        }
+        int bad = 0;
+        for (int k = 0; k < n_sh; ++k) { int st = 0; if (waitpid(pid[k], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st)) bad = 1; }
+        if (bad) { for (int k = 0; k < n_sh; ++k) unlink(tmp[k]); DIE("a shard failed\n"); }
+        fprintf(stderr, "[bcfgpu_sam] %d region shards, one process each; ordered emit on the host (records are text: no device gather)\n", n_sh);
+        vio_file *f0 = vio_open_read(tmp[0]);
+        if (!f0) DIE("%s\n", vio_error());
+        hdr = vio_read_hdr(f0);
+        if (!hdr) DIE("%s\n", vio_error());
+        fout = vio_open_write(out_path, out_mode);
+        if (!fout || vio_write_hdr(fout, hdr)) DIE("%s\n", vio_error());
+        char *lb = NULL; size_t lcap = 0; int rr;
+        while ((rr = vio_read_line(f0, hdr, &lb, &lcap)) > 0) if (lb[0] && vio_write_line(fout, hdr, lb)) DIE("%s\n", vio_error());
+        if (rr < 0) DIE("%s\n", vio_error());
+        vio_close(f0); unlink(tmp[0]);
+        for (int k = 1; k < n_sh; ++k) {                         /* the other shards wrote records only */
+            FILE *fk = fopen(tmp[k], "r");
+            if (!fk) DIE("cannot read %s\n", tmp[k]);
+            ssize_t nl;
+            while ((nl = getline(&lb, &lcap, fk)) > 0) {
+                if (lb[nl - 1] == '\n') lb[nl - 1] = 0;
+                if (lb[0] && lb[0] != '#' && vio_write_line(fout, hdr, lb)) DIE("%s\n", vio_error());
+            }
+            fclose(fk); unlink(tmp[k]);
+        }
+        free(lb);
+        if (vio_close(fout)) DIE("%s\n", vio_error());
+        return 0;
+    }
+    reg_beg = beg; reg_end = end;
+    int device = 0;                                                           /* shard k of --gpus runs on device k mod the devices present */
+    if (shard > 0 && !list_only) { const int nd = bcfgpu_device_count(); device = nd > 0 ? shard % nd : 0; if (nd > 1) fprintf(stderr, "[bcfgpu_sam] shard %d on device %d of %d\n", shard, device, nd); }
     const int n_in = argc - 5, n_sites = end - beg;
     int ref_len = 0;
     char *ref = read_contig(argv[1], contig, &ref_len);
@@ -758,7 +841,7 @@ int main(int argc, char **argv)
      * mismatches or drops them; then the -q and orphan filters, which read_passes() left for here ---- */
     if (cap_thres > 10 && P.n && !list_only) {
         bcfgpu_cfg c0; memset(&c0, 0, sizeof c0);
-        c0.device = 0; c0.n_smpl = S; c0.max_sites = 1; c0.max_reads = 64; c0.min_baseQ = min_baseQ; c0.capQ = 60; c0.n_grp = 1; c0.ploidy_max = 2;
+        c0.device = device; c0.n_smpl = S; c0.max_sites = 1; c0.max_reads = 64; c0.min_baseQ = min_baseQ; c0.capQ = 60; c0.n_grp = 1; c0.ploidy_max = 2;
         bcfgpu_ctx *cx = NULL;
         CHECK(bcfgpu_create(&c0, &cx));
         bcfgpu_reads r0; memset(&r0, 0, sizeof r0);
@@ -806,7 +889,7 @@ int main(int argc, char **argv)
         return 0;
     }
     bcfgpu_cfg cfg; memset(&cfg, 0, sizeof cfg);
-    cfg.device = 0; cfg.n_smpl = S; cfg.max_sites = n_sites; cfg.max_reads = (uint64_t)P.nbase + 64;   /* every base is in <= 1 column */
+    cfg.device = device; cfg.n_smpl = S; cfg.max_sites = n_sites; cfg.max_reads = (uint64_t)P.nbase + 64;   /* every base is in <= 1 column */
     cfg.min_baseQ = min_baseQ; cfg.capQ = 60; cfg.errmod_theta = 0.; cfg.fmt_flag = fmt_flag;
     cfg.call_theta = 1.1e-3; cfg.n_grp = 1; cfg.ploidy_max = 2;
     bcfgpu_ctx *ctx = NULL;

@@ -281,6 +281,20 @@ def test_c_sam_driver_sample_plumbing(golden_dir, goldf, opts, region, files, n)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [2, 3, 5])
+def test_c_sam_driver_region_shards_match_the_whole_contig(golden_dir, gpus):
+    """`bcfgpu_sam --gpus N`: the region cut into N contiguous shards, a process per shard (shard k on device k mod the devices
+    present: on a one-GPU box they share it), each reading the reads that overlap its shard; the records are emitted in shard
+    order = genomic order.  The whole of test/mpileup/mpileup.11.out (a contig with SNP and indel records), byte for byte as
+    the single-process run gives it, as VCF and through BCF."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    out = whole_file_checks([SAM_EXE, "--gpus", str(gpus), "-s", "^HG99999", os.path.join(G, "mpileup.ref.fa"), "17", "1", "4200"] +
+                            [os.path.join(G, "mpileup.%d.sam" % i) for i in (3, 4)], os.path.join(G, "mpileup.11.out"))
+    assert sum(1 for ln in out.splitlines() if not ln.startswith("#")) == 4002
+
+
+@pytest.mark.gpu
 def test_c_sam_driver_reads_bam_and_counts_soft_clips(golden_dir):
     """BAM input (BGZF + BAM records parsed in C) and -a INFO/SCR,FMT/SCR: the whole of test/mpileup/mpileup-SCR.out (test.pl:659)."""
     build_host()

@@ -83,6 +83,7 @@ def _worker(rank, world, port, backend, out_path):
 def test_two_ranks_on_the_device_engine_match_one_context(tmp_path, gpu_ctx_factory):
     out = str(tmp_path / "gathered.npy")
     backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    print("[test_gpu_dist] transport of the ordered gather: %s (%d device(s) visible)" % ("RCCL (backend nccl)" if backend == "nccl" else "gloo, ranks share the device", torch.cuda.device_count()))
     for attempt in range(2):
         try:
             mp.spawn(_worker, args=(2, _free_port(), backend, out), nprocs=2, join=True)
