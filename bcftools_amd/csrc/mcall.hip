@@ -175,7 +175,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 #define MCALL_WAVES 4        // wavefronts per SIMD of the all-diploid FAST instantiations
 #endif
 template <int MAXA, int NSUB, bool FAST, bool HAP, bool GRP>
-__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 : !HAP ? MCALL_WAVES : 3, !FAST ? 8 : !HAP ? MCALL_WAVES : 3))) void mcall_kernel(const McallParams P)
+__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 : (HAP || GRP) ? 3 : MCALL_WAVES, !FAST ? 8 : (HAP || GRP) ? 3 : MCALL_WAVES))) void mcall_kernel(const McallParams P)
 {
     constexpr int NG = MAXA * (MAXA + 1) / 2;
     constexpr int TILES = NSUB >= 16 ? 2 : 1;     // 16-row tiles of the coefficient matrix (subsets + the sum row)
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     //         sum_s log(val_s) = log(prod_s val_s), so each sample costs a multiply + frexp instead of a log()
     // pass 2: the lane's current sample: PLs after set_pdg's in-place fills, genotype posteriors
     // FAST: pass 1 = the coefficient matrix; pass 2 = the lane's PL bytes (u8) and genotype posteriors (f32)
-    constexpr int U1 = FAST ? TILES * 16 * 16 * 8 * (HAP ? 2 : 1) : NSUB * WGS * 12, U2 = FAST ? NG * WGS * 5 : NG * WGS * 8, UB = U1 > U2 ? U1 : U2;
+    constexpr int U1 = FAST ? TILES * 16 * 16 * 8 * (HAP ? 2 : 1) : NSUB * WGS * 12, U2 = FAST ? NG * WGS * 5 : NG * WGS * 8, U3 = GRP ? 6 * 4 * WGS * 4 : 0,
+                  UB = (U1 > U2 ? U1 : U2) > U3 ? (U1 > U2 ? U1 : U2) : U3;     // U3: the staging of the group frequencies (6 words x 256 samples)
     __shared__ __align__(8) unsigned char s_union[UB];
     double *s_man = reinterpret_cast<double*>(s_union);
     int    *s_exp = reinterpret_cast<int*>(s_union + NSUB * WGS * 8);
@@ -228,6 +229,11 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     __shared__ double s_p2[FAST ? 256 : 1];                   // 10^(-PL/10), PL = 0..255
     if constexpr (FAST) for (int i = tid; i < 256; i += WGS) s_p2[i] = P.pl2p[i];
 
+    // The 5-allele instantiations split the sites by the number of subsets to visit (LDS for the running products): more
+    // than 15 only when all five alleles have a non-zero frequency (5 + 10 + 10 subsets).  With sample groups the
+    // frequencies are sequential float32 sums over all samples (below): the split is then by the number of alleles alone,
+    // before those sums are formed -- the 25-subset instantiation takes every 5-allele site.
+    if (MAXA == 5 && ngrp > 1 && (nals == 5) != (NSUB == 25)) return;
     // ---- allele-frequency set-up (mcall.c:1453-1535), sequential float32 ----
     if (tid == 0) {
         sh.als_new = 0; sh.early = 0; sh.prior_fail = 0;
@@ -240,87 +246,115 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             if (tid < nals) v = P.msite ? P.msite[is].qsum[tid] : P.qs[(size_t)is * 5 + tid];
             s_gq[tid] = v;
         }
-    } else {
+    } else if constexpr (GRP) {
         // group qsum from FORMAT/AD (or QS): qsum[grp][j] += AD[j]/sum in sample order (mcall.c:1478-1503).
         // 64 samples at a time: every lane normalises one sample (coalesced plane reads), then lane j < 5 adds allele
         // j's fractions in sample order -- the sequential float32 sum of the reference -- keeping the running sum of
         // the current group in a register (samples of a group are usually consecutive).
         for (int i = tid; i < ngrp * 5; i += WGS) s_gq[i] = 0;
-        float *s_fr = reinterpret_cast<float*>(s_union);            // [5][WGS] fractions of the staged samples
-        int *s_gg = reinterpret_cast<int*>(s_fr + 5 * WGS);         // [WGS] their groups
-        static_assert(UB >= (int)((5 * WGS) * sizeof(float) + WGS * sizeof(int)), "staging fits in s_union");
+        constexpr int SB = 4 * WGS;                                 // samples per staging round: four consecutive ones per lane
+        float *s_fr = reinterpret_cast<float*>(s_union);            // [5][SB] fractions of the staged samples
+        int *s_gg = reinterpret_cast<int*>(s_fr + 5 * SB);          // [SB] their groups
+        static_assert(UB >= (int)((5 * SB) * sizeof(float) + SB * sizeof(int)), "staging fits in s_union");
         const int nad = P.ad ? P.n_al_max : nals;
         int cur = -1;
         float acc = 0.f;
-        // the next 64 samples' counts and groups are requested before the current ones are normalised and added (the loop
-        // is a chain of memory round trips otherwise)
-        int xn[5], gnx = 0;
+        // the next round's counts and groups are requested before the current ones are normalised and added (the loop is a
+        // chain of memory round trips otherwise); a lane's four samples of a byte plane are one 4-byte load
+        int xn[5][4], gnx[4];
         auto fetch_ad = [&](int base) {
-            const int s = base + tid;
+            const int s = base + 4 * tid, rem = S - s;
             #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                int x = VEND;
-                if (s < S && k < nad) {
-                    if (P.ad) x = P.ad[((size_t)is * P.n_al_max + k) * Ss + s];
-                    else if (P.qs_u16) x = k < nals ? (int)P.qs_u16[((size_t)is * 5 + k) * Ss + s] : VEND;
-                    else x = k < nals ? (int)P.ad_u8[((size_t)is * 5 + k) * Ss + s] + (int)P.ad_u8b[((size_t)is * 5 + k) * Ss + s] : VEND;
-                }
-                xn[k] = x;
-            }
-            gnx = s < S ? GRP_OF(s) : 0;
-        };
-        fetch_ad(0);
-        for (int base = 0; base < S; base += WGS) {
-            const int cn = min(WGS, S - base);
-            __syncthreads();
-            int xc[5];
-            #pragma unroll
-            for (int k = 0; k < 5; ++k) xc[k] = xn[k];
-            const int gcur = gnx;
-            fetch_ad(base + WGS);
-            if (tid < cn) {
-                int v[5];
-                float sum = 0;
-                int nvalid = 0;                                   // values before the first vector_end
                 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    v[k] = VEND;
-                    if (k < nad && nvalid == k) {
-                        const int x = xc[k];
-                        if (x != VEND) { v[k] = x; nvalid = k + 1; if (x != MISSING) sum += (float)x; }
+                for (int j = 0; j < 4; ++j) xn[k][j] = VEND;
+                if (rem <= 0 || k >= nad) continue;
+                if (P.ad) {
+                    #pragma unroll
+                    for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = P.ad[((size_t)is * P.n_al_max + k) * Ss + s + j];
+                } else if (k < nals) {
+                    if (P.qs_u16) {
+                        #pragma unroll
+                        for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = (int)P.qs_u16[((size_t)is * 5 + k) * Ss + s + j];
+                    } else {
+                        const uint8_t *pa = P.ad_u8 + ((size_t)is * 5 + k) * Ss + s, *pb = P.ad_u8b + ((size_t)is * 5 + k) * Ss + s;
+                        uint32_t wa = 0, wb = 0;
+                        if (rem >= 4) { __builtin_memcpy(&wa, pa, 4); __builtin_memcpy(&wb, pb, 4); }
+                        else for (int j = 0; j < rem; ++j) { wa |= (uint32_t)pa[j] << (8 * j); wb |= (uint32_t)pb[j] << (8 * j); }
+                        #pragma unroll
+                        for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = (int)((wa >> (8 * j)) & 0xff) + (int)((wb >> (8 * j)) & 0xff);
                     }
                 }
+            }
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) gnx[j] = j < rem ? GRP_OF(s + j) : 0;
+        };
+        fetch_ad(0);
+        for (int base = 0; base < S; base += SB) {
+            const int cn = min(SB, S - base);
+            __syncthreads();
+            int xc[5][4], gcur[4];
+            #pragma unroll
+            for (int k = 0; k < 5; ++k)
                 #pragma unroll
-                for (int k = 0; k < 5; ++k)                       // +0 where the reference adds nothing
-                    s_fr[k * WGS + tid] = (sum != 0.f && k < nvalid && v[k] != MISSING) ? (float)v[k] / sum : 0.f;
-                s_gg[tid] = gcur;
+                for (int j = 0; j < 4; ++j) xc[k][j] = xn[k][j];
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) gcur[j] = gnx[j];
+            fetch_ad(base + SB);
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ls = 4 * tid + j;                        // the sample's place in the round
+                if (ls < cn) {
+                    int v[5];
+                    float sum = 0;
+                    int nvalid = 0;                                   // values before the first vector_end
+                    #pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        v[k] = VEND;
+                        if (k < nad && nvalid == k) {
+                            const int x = xc[k][j];
+                            if (x != VEND) { v[k] = x; nvalid = k + 1; if (x != MISSING) sum += (float)x; }
+                        }
+                    }
+                    #pragma unroll
+                    for (int k = 0; k < 5; ++k)                       // +0 where the reference adds nothing
+                        s_fr[k * SB + ls] = (sum != 0.f && k < nvalid && v[k] != MISSING) ? (float)v[k] / sum : 0.f;
+                    s_gg[ls] = gcur[j];
+                }
             }
             __syncthreads();
             if (tid < 5 && tid < nals) {
-                // four samples per LDS read pair, the next four requested while these are added
-                const float4 *fr4 = reinterpret_cast<const float4*>(s_fr + tid * WGS);
+                // sixteen samples per trip: their four LDS read pairs are in flight together (one read pair per trip leaves the
+                // lane waiting out an LDS round trip for every four additions)
+                const float4 *fr4 = reinterpret_cast<const float4*>(s_fr + tid * SB);
                 const int4 *gg4 = reinterpret_cast<const int4*>(s_gg);
                 const int nb = (cn + 3) >> 2;                      // the tail of the last block holds +0 / stale groups: see below
-                float4 fn = fr4[0]; int4 gn = gg4[0];
-                for (int b4 = 0; b4 < nb; ++b4) {
-                    const float4 f = fn; const int4 gv = gn;
-                    if (b4 + 1 < nb) { fn = fr4[b4 + 1]; gn = gg4[b4 + 1]; }
-                    const float fv[4] = {f.x, f.y, f.z, f.w};
-                    const int gs4[4] = {gv.x, gv.y, gv.z, gv.w};
-                    // four samples of the running group (groups are usually runs of consecutive samples): just the four adds
-                    if (4 * b4 + 3 < cn && ((gv.x ^ cur) | (gv.y ^ cur) | (gv.z ^ cur) | (gv.w ^ cur)) == 0) {
-                        acc += f.x; acc += f.y; acc += f.z; acc += f.w;
-                        continue;
-                    }
+                for (int b0 = 0; b0 < nb; b0 += 4) {
+                    float4 fq[4]; int4 gq4[4];
                     #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (4 * b4 + k < cn) {
-                            const int g = gs4[k];
-                            if (g != cur) {
-                                if (cur >= 0) s_gq[cur * 5 + tid] = acc;
-                                cur = g; acc = s_gq[g * 5 + tid];
+                    for (int u = 0; u < 4; ++u) if (b0 + u < nb) { fq[u] = fr4[b0 + u]; gq4[u] = gg4[b0 + u]; }
+                    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int b4 = b0 + u;
+                        if (b4 >= nb) break;
+                        const float4 f = fq[u]; const int4 gv = gq4[u];
+                        const float fv[4] = {f.x, f.y, f.z, f.w};
+                        const int gs4[4] = {gv.x, gv.y, gv.z, gv.w};
+                        // four samples of the running group (groups are usually runs of consecutive samples): just the four adds
+                        if (4 * b4 + 3 < cn && ((gv.x ^ cur) | (gv.y ^ cur) | (gv.z ^ cur) | (gv.w ^ cur)) == 0) {
+                            acc += f.x; acc += f.y; acc += f.z; acc += f.w;
+                            continue;
+                        }
+                        #pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (4 * b4 + k < cn) {
+                                const int g = gs4[k];
+                                if (g != cur) {
+                                    if (cur >= 0) s_gq[cur * 5 + tid] = acc;
+                                    cur = g; acc = s_gq[g * 5 + tid];
+                                }
+                                acc += fv[k];
                             }
-                            acc += fv[k];
                         }
                     }
                 }
@@ -364,7 +398,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     // The 5-allele instantiations split the sites by the number of subsets to visit (LDS for the running products): more
     // than 15 only when all five alleles have a non-zero frequency (5 + 10 + 10 subsets), in any group -- decided once
     // per site, before the groups are walked, so that exactly one instantiation takes the site.
-    if (MAXA == 5) {
+    if (MAXA == 5 && ngrp == 1) {
         bool five = false;
         if (nals == 5)
             for (int g = 0; g < ngrp; ++g) {
@@ -480,8 +514,12 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             // four wavefronts per SIMD the scan is bound by such round trips.  Word q of the block holds the samples
             // sb+4q .. sb+4q+3; one matrix product covers the 16 lanes' samples sb+4q+j.
             // (few samples: 4*nq consecutive samples per lane with nq = 2 or 1, so that the 16 lanes' columns stay filled)
-            const int nq = S > 128 ? 4 : S > 64 ? 2 : 1;
-            for (int s0 = 0; s0 < (BCFGPU_ABL(P, 16) ? 0 : S); s0 += 64 * nq) {
+            // a group's samples lie in [first, last] (grp_range_kernel): consecutive for populations listed one after the
+            // other, and then the groups' scans together read every sample once
+            const int s_first = (ngrp > 1 && P.grp_rng) ? (P.grp_rng[2 * g] & ~3) : 0, s_last = (ngrp > 1 && P.grp_rng) ? P.grp_rng[2 * g + 1] : S;
+            const int span = s_last - s_first;
+            const int nq = span > 128 ? 4 : span > 64 ? 2 : 1;
+            for (int s0 = s_first; s0 < (BCFGPU_ABL(P, 16) ? 0 : s_last); s0 += 64 * nq) {
                 const int sb0 = s0 + 4 * nq * col;
                 uint32_t wq[4][4], pwq[4], gmq[4];
                 #pragma unroll
@@ -603,7 +641,8 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             setbits = rowbits;
         } else {
         for (int t = 0; t < nsub; ++t) { s_man[t * WGS + tid] = 1.0; s_exp[t * WGS + tid] = 0; }
-        for (int s = tid; s < (BCFGPU_ABL(P, 16) ? 0 : S); s += WGS) {
+        const int g_first = (ngrp > 1 && P.grp_rng) ? P.grp_rng[2 * g] : 0, g_last = (ngrp > 1 && P.grp_rng) ? P.grp_rng[2 * g + 1] : S;
+        for (int s = g_first + tid; s < (BCFGPU_ABL(P, 16) ? 0 : g_last); s += WGS) {
             if (ngrp > 1 && GRP_OF(s) != g) continue;
             int pl[NG]; double pdg[NG];
             load_pl<NG>(P, is, s, ngts, pl);
@@ -939,10 +978,19 @@ __global__ __launch_bounds__(64) void i16_kernel(const McallParams P)
     }
 }
 
-__global__ void grp_check_kernel(const int32_t *grp, int n_smpl, int n_grp, int *err)
+__global__ void grp_range_init_kernel(int32_t *rng, int n_grp)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g < n_grp) { rng[2 * g] = 0x7fffffff; rng[2 * g + 1] = 0; }
+}
+// group ids are checked (BCFGPU_E_RANGE) and every group's sample range [first, last + 1) is taken
+__global__ void grp_check_kernel(const int32_t *grp, int n_smpl, int n_grp, int *err, int32_t *rng)
 {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s < n_smpl && (grp[s] < 0 || grp[s] >= n_grp)) atomicExch(err, BCFGPU_E_RANGE);
+    if (s >= n_smpl) return;
+    const int g = grp[s];
+    if (g < 0 || g >= n_grp) { atomicExch(err, BCFGPU_E_RANGE); return; }
+    if (rng) { atomicMin(&rng[2 * g], s); atomicMax(&rng[2 * g + 1], s + 1); }
 }
 
 void launch_mcall(const McallParams &p, hipStream_t s)
@@ -950,7 +998,10 @@ void launch_mcall(const McallParams &p, hipStream_t s)
     if (p.n_sites == 0) return;
     const int ngrp = p.n_grp > 1 ? p.n_grp : 1;
     const size_t lds = (size_t)ngrp * 5 * sizeof(float) + (size_t)ngrp * 2 * sizeof(int);
-    if (p.grp && ngrp > 1) hipLaunchKernelGGL(grp_check_kernel, dim3((p.n_smpl + 255) / 256), dim3(256), 0, s, p.grp, p.n_smpl, ngrp, p.err);
+    if (p.grp && ngrp > 1) {
+        if (p.grp_rng) hipLaunchKernelGGL(grp_range_init_kernel, dim3((ngrp + 255) / 256), dim3(256), 0, s, p.grp_rng, ngrp);
+        hipLaunchKernelGGL(grp_check_kernel, dim3((p.n_smpl + 255) / 256), dim3(256), 0, s, p.grp, p.n_smpl, ngrp, p.err, p.grp_rng);
+    }
     #define MCALL_LAUNCH3(FAST_, HAP_, GRP_) do { \
         hipLaunchKernelGGL((mcall_kernel<3, 7, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \
         hipLaunchKernelGGL((mcall_kernel<5, 15, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \
