@@ -36,6 +36,7 @@ struct bcfgpu_ctx {
     double call_theta_log = 0;
     // workspaces sized by cfg.max_sites / cfg.max_reads
     int *d_hist = nullptr, *d_err = nullptr;       // d_err: [0] error word, [1] truncated cells, [2..4] counters of glfgen's deep-cell list
+    uint16_t *d_keys = nullptr;                    // glfgen in two launches (BCFGPU_GLFGEN_SPLIT=1): 2 bytes per read between them
     int32_t *d_grp_rng = nullptr;                  // mcall: sample range of every -G group
     uint32_t *d_deep_list = nullptr; uint16_t *d_deep_keys = nullptr; uint32_t deep_cap = 0, deep_key_cap = 0;
     CallretPlanes *d_crp = nullptr;
@@ -159,6 +160,7 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
         }
         // glfgen's list of cells deeper than its LDS key window, and the scratch their keys go to (2 bytes per pileup entry):
         // up to 1024 such cells per tile, with at most 32 Mi entries between them (or the whole tile's, when it is smaller)
+        if (const char *sp = getenv("BCFGPU_GLFGEN_SPLIT")) if (atoi(sp) && (rc = dev_alloc(c, (void**)&c->d_keys, ((size_t)cfg->max_reads + 64) * 2))) { bcfgpu_destroy(c); return rc; }
         c->deep_cap = 1024;
         c->deep_key_cap = (uint32_t)std::min<uint64_t>((uint64_t)cfg->max_reads + 16 * 1024, 32u << 20);
         if ((rc = dev_alloc(c, (void**)&c->d_deep_list, (size_t)c->deep_cap * 8)) || (rc = dev_alloc(c, (void**)&c->d_deep_keys, (size_t)c->deep_key_cap * 2 + 64))) {
@@ -448,6 +450,7 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     g.trunc = reinterpret_cast<unsigned int*>(c->d_err + 1);
     g.deep_list = c->d_deep_list; g.deep_ctr = reinterpret_cast<uint32_t*>(c->d_err + 2); g.deep_keys = c->d_deep_keys;
     g.deep_cap = c->deep_cap; g.deep_key_cap = c->deep_key_cap;
+    g.keys = c->d_keys;
     HIPCHK(hipMemsetAsync(c->d_err + 2, 0, 3 * sizeof(int), c->stream));
 #ifdef BCFGPU_DIAG
     {   // phase stamps of glfgen_kernel: totals of the previous launch are printed, then cleared

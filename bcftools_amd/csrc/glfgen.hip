@@ -235,12 +235,20 @@ struct WaveCounts {
 // not worked on here: it is listed (P.deep_*), and the launch that follows (DEEP = true) gives each listed cell a workgroup
 // of its own -- phase A over the cell's reads with all 256 lanes, the keys in a global scratch array instead of LDS, phase B
 // by the one lane that owns the cell.
-template <bool INDEL, bool LDS_HIST, bool DEEP>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, GLF_WAVES))) void glfgen_kernel(const GlfgenParams P)
+// PHASE = 0: both phases in one kernel (the keys never leave LDS).  PHASE = 1 / 2: the two phases as kernels of their own --
+// phase A streams the reads once and leaves the keys in HBM (P.keys, 2 bytes per read) with nothing but the site
+// histograms in LDS, at the occupancy its registers allow; phase B copies its span's keys into LDS with coalesced loads
+// and keeps keys + fk + run counters there (no histograms: the rare take-back of a truncated cell goes to global memory).
+#ifndef GLF_WAVES_A
+#define GLF_WAVES_A 6
+#endif
+template <bool INDEL, bool LDS_HIST, bool DEEP, int PHASE>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ? GLF_WAVES_A : GLF_WAVES, PHASE == 1 ? GLF_WAVES_A : GLF_WAVES))) void glfgen_kernel(const GlfgenParams P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     if (DEEP && (blockIdx.x >= P.deep_ctr[0] || P.deep_list[2 * blockIdx.x] == 0xffffffffu)) return;
-    const int cap = DEEP ? 0x7ffffff0 : P.lds_cap;
+    constexpr bool KEYS_GLOBAL = PHASE == 1 || (PHASE == 2 && DEEP);       // the key of read i at P.keys[i]
+    const int cap = (DEEP || PHASE == 1) ? 0x7ffffff0 : P.lds_cap;
     double   *s_fk  = reinterpret_cast<double*>(smem + LDS_FK);
     uint32_t *s_cnt = reinterpret_cast<uint32_t*>(smem + LDS_CNT);
     int      *s_hist = reinterpret_cast<int*>(smem + LDS_HIST_OFF);
@@ -249,7 +257,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
     // before phase B takes the region
     uint32_t *s_part = s_cnt;
     const int pcol = P.part_cols;                    // columns per value: a power of two, NPART * slots * pcol <= 2048
-    uint16_t *s_key = DEEP ? P.deep_keys + P.deep_list[2 * blockIdx.x + 1] : reinterpret_cast<uint16_t*>(s_tot + (size_t)P.hist_slots * SITE_NSUM);
+    uint16_t *s_key = KEYS_GLOBAL ? P.keys : DEEP ? P.deep_keys + P.deep_list[2 * blockIdx.x + 1]
+                                                  : reinterpret_cast<uint16_t*>(s_tot + (size_t)P.hist_slots * SITE_NSUM);
     __shared__ unsigned int s_next, s_skip;
 
     const int tid = threadIdx.x;
@@ -264,8 +273,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
     const long cell = cell0 + tid;
     const bool active = cell < cell_end;
 
-    s_fk[tid] = P.fk[tid];
-    if (tid < 8) s_fk[256 + tid] = 0.0;               // [256]: the factor of a lane that sits a chunk element out
+    if (PHASE != 1) {
+        s_fk[tid] = P.fk[tid];
+        if (tid < 8) s_fk[256 + tid] = 0.0;           // [256]: the factor of a lane that sits a chunk element out
+    }
     if (LDS_HIST) {
         for (int i = tid; i < P.hist_slots * HP_SIZE; i += WG) s_hist[i] = 0;
         for (int i = tid; i < P.hist_slots * SITE_NSUM; i += WG) s_tot[i] = 0;
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
     // not is listed for the launch that follows, with room for its keys in the scratch array; the rounds here step over its
     // reads.  Only when the list or the scratch array is full is the tile refused.
     bool deep = false;
-    if (!DEEP && active && end - beg > (uint32_t)cap - 3u) {
+    if (!DEEP && PHASE != 1 && active && end - beg > (uint32_t)cap - 3u) {
         deep = true;
         const uint32_t need = (end - beg + 16u) & ~7u;           // keys of the cell, the slack of the 8-byte stores, a multiple of 8
         const uint32_t slot = atomicAdd(&P.deep_ctr[0], 1u), at = atomicAdd(&P.deep_ctr[1], need);
@@ -309,8 +320,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
     uint32_t base = p_off[cell0];
 
     for (;;) {
-        const uint32_t abase = base & ~3u;                       // key index 0 of this round
-        const uint32_t lim = DEEP ? span_end : min(abase + (uint32_t)cap, span_end);
+        const uint32_t abase = KEYS_GLOBAL ? 0u : base & ~3u;    // key index 0 of this round
+        const uint32_t lim = (DEEP || PHASE == 1) ? span_end : min(abase + (uint32_t)cap, span_end);
         if (tid == 0) { s_next = 0xffffffffu; s_skip = 0; }
         if (LDS_HIST) for (int i = tid; i < P.hist_slots * NPART * pcol; i += WG) s_part[i] = 0;
         __syncthreads();
@@ -322,6 +333,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
         const bool part = cand && end <= rlim;                   // this lane's cell is handled in this round (cells behind a listed cell wait)
 
         GLF_STAMP(0)
+        if constexpr (PHASE == 2) {
+            // the keys phase A left in HBM: this round's window into LDS, 16 bytes per lane and trip (a listed cell reads its own
+            // from HBM: KEYS_GLOBAL)
+            if (!KEYS_GLOBAL) {
+                const uint32_t nk = (rlim > abase ? rlim - abase : 0u) + 8u;        // (one key past the last cell: phase B reads ahead)
+                for (uint32_t i = 8u * tid; i < nk; i += 8u * WG)
+                    *reinterpret_cast<uint4*>(s_key + i) = *reinterpret_cast<const uint4*>(P.keys + abase + i);
+            }
+        } else
         // ================= phase A: one lane per read =================
         for (int sg = site0; sg <= site_last; ++sg) {            // uniform: the site segments of the workgroup's span
             const long c_lo = max(cell0, (long)sg * S), c_hi = min(cell_end, (long)(sg + 1) * S);
@@ -392,11 +412,30 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
                         C.ref59 += (uint32_t)__popcll(b59 & bref); C.alt59 += (uint32_t)__popcll(b59 & ~bref);
                         C.rev59 += (uint32_t)__popcll(b59 & brev); C.fwd59 += (uint32_t)__popcll(b59 & ~brev);
                     }
+#ifdef GLF_AGG_BQ
+                    if (LDS_HIST) {
+                        // base-quality bins: binned qualities put the 64 reads of a wave instruction on a handful of counters; one
+                        // add per distinct value present, with the REF / ALT counts of its lanes (ballots), instead of 64 adds on
+                        // <= 8 addresses
+                        const uint32_t bin = min(bq, 59u);
+                        const unsigned long long bref2 = __ballot(isref);
+                        unsigned long long todo = b_ok;
+                        while (todo) {
+                            const int ldr = __builtin_ctzll(todo);
+                            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)bin, ldr);
+                            const unsigned long long m = __ballot(bin == v) & todo;
+                            if ((int)(tid & 63) == ldr) atomicAdd(&hist[H_REF_BQ + v], (int)((uint32_t)__popcll(m & bref2) | (uint32_t)__popcll(m & ~bref2) << 16));
+                            todo &= ~m;
+                        }
+                    }
+#endif
                     if (ok && !BCFGPU_ABL(P, 1)) {
                         if (LDS_HIST) {
                             const int inc = isref ? 1 : 0x10000;
                             atomicAdd(&hist[H_REF_POS + ((e4 >> (8 * u)) & 0xff)], inc);
+#ifndef GLF_AGG_BQ
                             atomicAdd(&hist[H_REF_BQ + min(bq, 59u)], inc);
+#endif
                             if (!m59) {
                                 atomicAdd(&hist[H_REF_MQ + mapQ], inc);
                                 atomicAdd(&hist[HP_MQS + mapQ], rev ? 0x10000 : 1);
@@ -526,6 +565,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(GLF_WAVES, G
             }
             if (!BCFGPU_ABL(P, 16384)) __syncthreads();
         }
+
+        if constexpr (PHASE == 1) break;                         // the keys are in HBM: phase B is the next launch
 
         // ================= phase B: one lane per cell =================
         uint16_t *kp_w = s_key + (part ? beg - abase : 0);       // the lane's keys
@@ -769,12 +810,24 @@ size_t glfgen_lds_bytes(int cap, int hist_slots)
 template <bool INDEL, bool LDS_HIST>
 static void launch_one(const GlfgenParams &p, hipStream_t s, int grid, size_t lds)
 {
+    if (p.keys) {
+        // the two phases as launches of their own: A with the histograms in LDS, B with the key window (and listed cells after it)
+        const size_t lds_a = glfgen_lds_bytes(0, p.hist_slots), lds_b = glfgen_lds_bytes(p.lds_cap, 0);
+        GlfgenParams pb = p;
+        pb.hist_slots = 0;                                  // phase B keeps no histograms: its LDS is fk + run counters + keys
+        if (lds_b > 48 * 1024)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(glfgen_kernel<INDEL, false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
+        hipLaunchKernelGGL((glfgen_kernel<INDEL, LDS_HIST, false, 1>), dim3(grid), dim3(WG), lds_a, s, p);
+        hipLaunchKernelGGL((glfgen_kernel<INDEL, false, false, 2>), dim3(grid), dim3(WG), lds_b, s, pb);
+        if (p.deep_cap) hipLaunchKernelGGL((glfgen_kernel<INDEL, false, true, 2>), dim3(p.deep_cap), dim3(WG), glfgen_lds_bytes(0, 0), s, pb);
+        return;
+    }
     if (lds > 48 * 1024)    // per launch, on the device the caller has bound: no process-wide state
-        hipFuncSetAttribute(reinterpret_cast<const void*>(glfgen_kernel<INDEL, LDS_HIST, false>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(glfgen_kernel<INDEL, LDS_HIST, false, 0>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((glfgen_kernel<INDEL, LDS_HIST, false>), dim3(grid), dim3(WG), lds, s, p);
+    hipLaunchKernelGGL((glfgen_kernel<INDEL, LDS_HIST, false, 0>), dim3(grid), dim3(WG), lds, s, p);
     // the cells the launch above listed (none, as a rule: the workgroups leave at once); no key window in LDS
-    if (p.deep_cap) hipLaunchKernelGGL((glfgen_kernel<INDEL, LDS_HIST, true>), dim3(p.deep_cap), dim3(WG), glfgen_lds_bytes(0, p.hist_slots), s, p);
+    if (p.deep_cap) hipLaunchKernelGGL((glfgen_kernel<INDEL, LDS_HIST, true, 0>), dim3(p.deep_cap), dim3(WG), glfgen_lds_bytes(0, p.hist_slots), s, p);
 }
 
 void launch_glfgen(const GlfgenParams &p, hipStream_t s)

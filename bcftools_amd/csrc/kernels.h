@@ -70,6 +70,7 @@ struct GlfgenParams {
     uint32_t *deep_ctr;             // [0] cells listed, [1] keys handed out, [2] set when the list or the scratch ran out (zeroed before launch)
     uint16_t *deep_keys;            // [deep_key_cap] key scratch
     uint32_t deep_cap, deep_key_cap;
+    uint16_t *keys;                 // NULL: one fused kernel; else [n_reads + 64] the keys between the phase-A and the phase-B launch
 #ifdef BCFGPU_DIAG
     unsigned long long *stamps;     // [16] cycle totals per kernel phase
 #endif
