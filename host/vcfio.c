@@ -233,7 +233,7 @@ static int bgzf_flush_block(vio_file *f, const char *data, size_t n)
 {
     unsigned char out[BGZF_BLOCK + 1024];
     z_stream z; memset(&z, 0, sizeof z);
-    if (deflateInit2(&z, f->mode == 'u' ? 0 : Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return fail("deflateInit2");
+    if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return fail("deflateInit2");
     z.next_in = (unsigned char*)data; z.avail_in = (uInt)n; z.next_out = out + 18; z.avail_out = sizeof out - 26;
     if (deflate(&z, Z_FINISH) != Z_STREAM_END) { deflateEnd(&z); return fail("deflate"); }
     const size_t clen = z.total_out;
@@ -248,7 +248,7 @@ static int bgzf_flush_block(vio_file *f, const char *data, size_t n)
 }
 static int out_bytes(vio_file *f, const void *p, size_t n)
 {
-    if (f->mode == 'v') return fwrite(p, 1, n, f->fp) == n ? 0 : fail("write error");
+    if (f->mode == 'v' || f->mode == 'u') return fwrite(p, 1, n, f->fp) == n ? 0 : fail("write error");   /* -Ou: the BCF stream as it is, no BGZF framing (htslib mode "wbu") */
     const char *c = p;
     while (n) {
         size_t k = BGZF_BLOCK - f->blk.l; if (k > n) k = n;
@@ -271,7 +271,7 @@ int vio_close(vio_file *f)
     int rc = 0;
     if (!f) return 0;
     if (f->is_write) {
-        if (f->mode != 'v') {
+        if (f->mode != 'v' && f->mode != 'u') {
             if (f->blk.l && bgzf_flush_block(f, f->blk.s, f->blk.l)) rc = -1;
             /* the 28-byte empty block that marks the end of a BGZF file (SAM specification 4.1.2) */
             static const unsigned char eof[28] = { 0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -582,11 +582,13 @@ static int encode_record(const vio_hdr *h, const char *line, sbuf *out)
 }
 
 /* ---- BCF2 -> text ---- */
-typedef struct { const unsigned char *p, *e; } rd_t;
+typedef struct { const unsigned char *p, *e; int bad; } rd_t;      /* bad: a read ran past e (a truncated or malformed record) */
+#define RD_NEED(r, k) ((r)->e && (size_t)((r)->e - (r)->p) < (size_t)(k) ? ((r)->bad = 1, (r)->p = (r)->e, 0) : 1)
 static int dec_size(rd_t *r, int *type);
 static int32_t dec_int(rd_t *r, int type)
 {
     int32_t v = 0;
+    if (!RD_NEED(r, type == BT_INT8 ? 1 : type == BT_INT16 ? 2 : type == BT_INT32 ? 4 : 0)) return 0;
     if (type == BT_INT8) { v = (int8_t)*r->p; r->p += 1; if (v == -128) v = I_MISSING; else if (v == -127) v = I_VEND; }
     else if (type == BT_INT16) { int16_t z; memcpy(&z, r->p, 2); r->p += 2; v = z; if (z == INT16_MIN) v = I_MISSING; else if (z == INT16_MIN + 1) v = I_VEND; }
     else if (type == BT_INT32) { memcpy(&v, r->p, 4); r->p += 4; }
@@ -594,6 +596,8 @@ static int32_t dec_int(rd_t *r, int type)
 }
 static int dec_size(rd_t *r, int *type)
 {
+    *type = 0;
+    if (!RD_NEED(r, 1)) return 0;
     const unsigned b = *r->p++;
     *type = b & 0xf;
     int n = b >> 4;
@@ -610,7 +614,9 @@ static void put_float(sbuf *b, uint32_t u)
 static int tsz(int t) { return t == BT_INT8 || t == BT_CHAR ? 1 : t == BT_INT16 ? 2 : 4; }
 static int decode_record(const vio_hdr *h, const unsigned char *sh, uint32_t lsh, const unsigned char *in, uint32_t lin, sbuf *b)
 {
-    rd_t r = { sh, sh + lsh };
+    rd_t r = { sh, sh + lsh, 0 };
+    if (lsh < 24) return fail("truncated BCF record");
+    #define SKIP(rr, k) do { const long long k_ = (long long)(k); if (k_ < 0 || !RD_NEED(rr, k_)) return fail("truncated BCF record"); (rr)->p += k_; } while (0)
     int32_t chrom, pos, rlen; uint32_t qb, nai, nfs;
     memcpy(&chrom, r.p, 4); memcpy(&pos, r.p + 4, 4); memcpy(&rlen, r.p + 8, 4); memcpy(&qb, r.p + 12, 4); memcpy(&nai, r.p + 16, 4); memcpy(&nfs, r.p + 20, 4);
     r.p += 24; (void)rlen;
@@ -618,11 +624,13 @@ static int decode_record(const vio_hdr *h, const unsigned char *sh, uint32_t lsh
     if (chrom < 0 || chrom >= h->n_ctg) return fail("BCF record with an unknown contig index");
     sb_puts(b, h->ctg[chrom]); sb_printf(b, "\t%d\t", pos + 1);
     int t, n = dec_size(&r, &t);
+    if (n < 0 || !RD_NEED(&r, n)) return fail("truncated BCF record");
     if (n) sb_put(b, r.p, (size_t)n); else sb_putc(b, '.');
     r.p += n; sb_putc(b, '\t');
     for (int a = 0; a < n_allele; ++a) {
         n = dec_size(&r, &t);
         if (a == 1) sb_putc(b, '\t'); else if (a > 1) sb_putc(b, ',');
+        if (n < 0 || !RD_NEED(&r, n)) return fail("truncated BCF record");
         sb_put(b, r.p, (size_t)n); r.p += n;
     }
     if (n_allele == 1) sb_puts(b, "\t.");
@@ -641,32 +649,36 @@ static int decode_record(const vio_hdr *h, const unsigned char *sh, uint32_t lsh
         n = dec_size(&r, &t);
         if (!n) continue;                                        /* a flag */
         sb_putc(b, '=');
+        if (n < 0 || !RD_NEED(&r, (long long)n * tsz(t))) return fail("truncated BCF record");
         if (t == BT_CHAR) { sb_put(b, r.p, strnlen((const char*)r.p, (size_t)n)); r.p += n; }
         else for (int k = 0; k < n; ++k) {
             if (t == BT_FLOAT) { uint32_t u; memcpy(&u, r.p, 4); r.p += 4; if (u == F_VEND) { r.p += 4 * (n - k - 1); break; } if (k) sb_putc(b, ','); put_float(b, u); }
             else { const int32_t v = dec_int(&r, t); if (v == I_VEND) { r.p += tsz(t) * (n - k - 1); break; } if (k) sb_putc(b, ','); if (v == I_MISSING) sb_putc(b, '.'); else sb_printf(b, "%d", v); }
         }
     }
+    if (r.bad) return fail("truncated BCF record");
     if (!n_sample) return 0;
     /* FORMAT: the keys, then every sample's values from the per-key blocks */
-    rd_t q = { in, in + lin };
+    rd_t q = { in, in + lin, 0 };
     struct { int d, t, n; const unsigned char *p; } fm[64];
     sb_putc(b, '\t');
     for (int k = 0; k < n_fmt && k < 64; ++k) {
         fm[k].d = dec_typed_int(&q);
         if (fm[k].d < 0 || fm[k].d >= h->n_dict || !h->dict[fm[k].d].id) return fail("BCF record with an unknown FORMAT index");
         fm[k].n = dec_size(&q, &fm[k].t); fm[k].p = q.p;
-        q.p += (size_t)fm[k].n * (size_t)tsz(fm[k].t) * (size_t)n_sample;
+        if (fm[k].n < 0) return fail("truncated BCF record");
+        SKIP(&q, (long long)fm[k].n * tsz(fm[k].t) * n_sample);          /* the block of this key lies inside the record */
         if (k) sb_putc(b, ':');
         sb_puts(b, h->dict[fm[k].d].id);
     }
+    if (q.bad) return fail("truncated BCF record");
     if (!n_fmt) sb_putc(b, '.');
     for (int s = 0; s < n_sample; ++s) {
         sb_putc(b, '\t');
         if (!n_fmt) sb_putc(b, '.');
         for (int k = 0; k < n_fmt && k < 64; ++k) {
             if (k) sb_putc(b, ':');
-            rd_t v = { fm[k].p + (size_t)s * (size_t)fm[k].n * (size_t)tsz(fm[k].t), NULL };
+            rd_t v = { fm[k].p + (size_t)s * (size_t)fm[k].n * (size_t)tsz(fm[k].t), NULL, 0 };   /* (checked above: inside the record) */
             const int is_gt = !strcmp(h->dict[fm[k].d].id, "GT");
             if (fm[k].t == BT_CHAR) { const size_t l = strnlen((const char*)v.p, (size_t)fm[k].n); if (l) sb_put(b, v.p, l); else sb_putc(b, '.'); continue; }
             int printed = 0;

@@ -166,7 +166,8 @@ def records(raw, hdr, off):
 
 def read(path):
     """(header text, [VCF record lines]) of a BCF2 file"""
-    raw = b"".join(r for _, r in bgzf_blocks(open(path, "rb").read()))
+    data = open(path, "rb").read()
+    raw = data if data[:5] == b"BCF\x02\x02" else b"".join(r for _, r in bgzf_blocks(data))     # -Ou: no BGZF framing
     assert raw[:5] == b"BCF\x02\x02"
     l_text = struct.unpack_from("<I", raw, 5)[0]
     text = raw[9:9 + l_text]

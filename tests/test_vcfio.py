@@ -46,7 +46,8 @@ def test_goldens_survive_every_output_mode(golden_dir, tmp_path):
         for mode in "ubz":
             mid = str(tmp_path / ("x." + mode))
             subprocess.check_call([VIEW, "-O", mode, "-o", mid, f])
-            assert open(mid, "rb").read(2) == b"\x1f\x8b"
+            head = open(mid, "rb").read(5)
+            assert head == b"BCF\x02\x02" if mode == "u" else head[:2] == b"\x1f\x8b"     # -Ou: the BCF stream itself (htslib "wbu"); -Ob / -Oz: BGZF
             back = subprocess.run([VIEW, mid], check=True, stdout=subprocess.PIPE).stdout
             assert back == want, (f, mode)
         # BCF -> BCF keeps the bytes of the records (the text form is a faithful intermediate)
@@ -84,7 +85,8 @@ def test_typed_value_known_answers(tmp_path):
                    "c1\t10\t.\tA\tC,<*>\t.\tPASS\tA=300;B=1,-2,.;F;R=0.5\tGT:PL\t0|1:0,300,.\t.:5\n")
     out = str(tmp_path / "k.bcf")
     subprocess.check_call([VIEW, "-O", "u", "-o", out, str(vcf)])
-    raw = b"".join(r for _, r in bcf2.bgzf_blocks(open(out, "rb").read()))
+    raw = open(out, "rb").read()                                               # -Ou: the BCF stream itself, no BGZF framing
+    assert raw[:5] == b"BCF\x02\x02"
     l_text = struct.unpack_from("<I", raw, 5)[0]
     rec = raw[9 + l_text:]
     l_shared, l_indiv = struct.unpack_from("<II", rec, 0)
@@ -104,3 +106,30 @@ def test_typed_value_known_answers(tmp_path):
     assert ind[:7] == b"\x11\x05\x21" + bytes([2, 5, 0, 0x81])                 # GT 0|1 -> 2,5; "." -> 0 then end-of-vector
     w = struct.pack("<6h", 0, 300, -32768, 5, -32767, -32767)                  # PL as int16: ".", then end-of-vector padding
     assert ind[7:] == b"\x11\x06\x32" + w
+
+
+def test_truncated_and_malformed_bcf_is_refused_not_overrun(tmp_path, golden_dir):
+    """A BCF whose record claims more bytes than it has, or whose typed vectors run past the record, makes bcfgpu_view fail
+    with "truncated BCF record" instead of reading out of bounds."""
+    build()
+    f = goldens(golden_dir)[0]
+    out = str(tmp_path / "t.bcf")
+    subprocess.check_call([VIEW, "-O", "u", "-o", out, f])
+    raw = bytearray(open(out, "rb").read())
+    l_text = struct.unpack_from("<I", raw, 5)[0]
+    at = 9 + l_text
+    l_shared, l_indiv = struct.unpack_from("<II", raw, at)
+    cases = []
+    cut = bytes(raw[:at + 8 + l_shared // 2])                                  # the file ends inside the first record
+    cases.append(cut)
+    bad = bytearray(raw)
+    bad[at + 8 + 24] = 0xf7                                                    # ID: a character vector with a 15+ length that is not there
+    cases.append(bytes(bad))
+    bad = bytearray(raw)
+    struct.pack_into("<I", bad, at + 8 + 20, (1 << 24) | 0xffffff)             # 16 M samples in a record of a few hundred bytes
+    cases.append(bytes(bad))
+    for i, data in enumerate(cases):
+        p = str(tmp_path / ("bad%d.bcf" % i))
+        open(p, "wb").write(data)
+        r = subprocess.run([VIEW, p], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode != 0, i
