@@ -94,6 +94,21 @@ class Reads(C.Structure):
                 ("r_pos", "r_lq", "r_flag", "r_ncig", "r_cig_off", "r_seq_off", "cig", "seq16", "qual", "zq", "r_has_zq")]
 
 
+class Packed(C.Structure):
+    """bcfgpu_packed: the pool as BAM records hold it (4-bit bases, optional 4-bit palette qualities)."""
+    _fields_ = [("seq4", C.c_void_p), ("qual4", C.c_void_p), ("palette", C.c_uint8 * 16), ("n_bases", C.c_int64), ("n_cig", C.c_int64),
+                ("smpl_off", C.c_void_p)]
+
+
+def pack_nibbles(a):
+    """Two 4-bit values per byte, the even index in the high nibble (bam_get_seq's order); odd lengths padded with 0."""
+    import numpy as np
+    a = np.asarray(a, np.uint8)
+    if a.size & 1:
+        a = np.concatenate([a, np.zeros(1, np.uint8)])
+    return ((a[0::2] << 4) | (a[1::2] & 15)).astype(np.uint8)
+
+
 class IndelIn(C.Structure):
     _fields_ = [("n_sites", C.c_int32), ("n_smpl", C.c_int32), ("pos", C.c_void_p), ("smpl_off", C.c_void_p),
                 ("p_read", C.c_void_p), ("p_qpos", C.c_void_p), ("p_indel", C.c_void_p), ("ref", C.c_char_p),
@@ -157,6 +172,8 @@ PROTOTYPES = {
     "bcfgpu_pileup_entries": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "bcfgpu_pileup": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32,
                                 C.POINTER(Tile), C.c_void_p, C.c_void_p]),
+    "bcfgpu_pileup_packed": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.POINTER(Packed), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p,
+                                       C.c_int32, C.POINTER(Tile), C.c_void_p, C.c_void_p]),
     "bcfgpu_gvcf_blocks": (C.c_int, [C.c_void_p, C.POINTER(GvcfIn), C.POINTER(GvcfOut), C.POINTER(C.c_int32)]),
     "bcfgpu_gap_prep_stats": (C.c_int, [C.c_void_p, C.POINTER(GapStats)]),
     "bcfgpu_pipeline": (C.c_int, [C.c_void_p, C.POINTER(Tile), C.c_void_p, C.c_void_p,

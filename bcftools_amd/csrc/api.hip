@@ -55,7 +55,7 @@ struct bcfgpu_ctx {
     // grow-only device workspaces of the indel / BAQ stages (GiB-sized scratch: not reallocated per call)
     struct Ws { void *p = nullptr; size_t bytes = 0; };
     alignas(16) unsigned char pileup_state[256] = {0};   // csrc/pileup.hip: the parameters of the last bcfgpu_pileup
-    Ws ws[104];                    // grow-only device workspaces of the host-fed stages (0-15: BAQ / overlaps, 16-35: pileup, 36-39: gVCF / indel tile, 40-103: gap_prep)
+    Ws ws[120];                    // grow-only device workspaces of the host-fed stages (0-15: BAQ / overlaps, 16-35: pileup, 36-39: gVCF / indel tile, 40-103: gap_prep, 104-119: pileup pool)
     int n_cu = 256;                // compute units of the device (grid size of the work-queue kernels)
     hipStream_t side[8] = {};      // created on first use: the realignment kernels of different band widths run side by side
     hipEvent_t side_ev[9] = {};    // [0..7] a side stream's work is done, [8] the fork point on the main stream
@@ -579,7 +579,7 @@ void *bcfgpu_internal_pileup_state(bcfgpu_ctx *c) { return c ? c->pileup_state :
 // workspace `slot` of at least `bytes` (contents undefined); nullptr when the allocation fails
 void *bcfgpu_internal_ws(bcfgpu_ctx *c, int slot, size_t bytes)
 {
-    if (!c || slot < 0 || slot >= 104) return nullptr;
+    if (!c || slot < 0 || slot >= 120) return nullptr;
     auto &w = c->ws[slot];
     if (w.bytes >= bytes && w.p) return w.p;
     hipSetDevice(c->cfg.device);

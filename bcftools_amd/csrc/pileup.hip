@@ -61,6 +61,7 @@ struct PileupParams {
     uint32_t *col_indel;            // [n_sites] != 0 when some entry of the column is followed by an indel
     int n_reads;                    // reads of the pool (bcfgpu_gap_prep_tile)
     uint32_t n_bases;               // bases of the pool's seq16 / qual
+    const int *d_span;              // the longest reference span of a read, as pileup_meta_kernel left it (max_span once the host has read it)
 };
 
 // first k in [lo, hi) with a[k] > x
@@ -70,8 +71,18 @@ __device__ __forceinline__ int upper_bound(const int32_t *a, int lo, int hi, int
     return lo;
 }
 
-// entries a workgroup's 256 cells may hold for their records to be collected in LDS and written out as one contiguous
-// span (a lane's own stores are 4 + 1 bytes per entry, 120 bytes apart from its neighbour's)
+// A workgroup owns PT_COLS consecutive columns x PT_SMPL consecutive samples.  Lanes that are neighbours in the column index
+// walk the same reads of one sample one base apart: their record loads fall on the same cache lines and their base / quality
+// bytes are consecutive (a lane per cell in cell order -- neighbours = different samples -- made every load of every lane a
+// cache line of its own: 14 ms for the 16 384-column x 1000-sample region of bench.py --mode pileup, this mapping: see DESIGN 5).
+// In the tile a column's PT_SMPL cells are one contiguous chunk (site-major plp_off): the records are collected in LDS chunk
+// by chunk and written out as PT_COLS contiguous spans.
+#ifndef PT_COLS
+#define PT_COLS 16
+#endif
+#define PT_SMPL (256 / PT_COLS)
+// entries a workgroup's 256 cells may hold for that (a lane's own stores would be 4 + 1 bytes per entry, 120 bytes apart
+// from its neighbour's); beyond it the lanes store directly
 #define PILEUP_LDS_CAP 9216
 
 template <bool FILL>
@@ -79,23 +90,45 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
 {
     __shared__ uint32_t s_rd[FILL ? PILEUP_LDS_CAP : 1];
     __shared__ uint8_t s_ep[FILL ? PILEUP_LDS_CAP : 4];
-    const long cell0 = (long)blockIdx.x * 256;
-    const long cell = cell0 + threadIdx.x;
-    const long ncells = (long)P.n_sites * P.n_smpl;
-    // the workgroup's span of the output (plp_off is known in the fill pass)
-    uint32_t span0 = 0, span_n = 0;
+    __shared__ uint32_t s_cb[PT_COLS], s_lb[PT_COLS + 1];        // chunk begin in the tile; chunk begin in LDS (+ total)
+    // Workgroups are dealt to the 8 XCDs round-robin, and each XCD has its own L2: every XCD gets a contiguous range of
+    // (sample tile, column tile) pairs with the column tile running fastest, so that the workgroups in flight on one XCD
+    // walk the same samples' reads a few columns apart and find them in that L2.
+    const unsigned n_bt = (unsigned)((P.n_sites + PT_COLS - 1) / PT_COLS), n_work = n_bt * (unsigned)((P.n_smpl + PT_SMPL - 1) / PT_SMPL);
+    const unsigned per_xcd = gridDim.x >> 3;             // (the grid is a multiple of 8)
+    const unsigned w = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const bool in_grid = w < n_work;
+    const int st = in_grid ? (int)(w / n_bt) : 0, bt = in_grid ? (int)(w - (unsigned)st * n_bt) : 0;
+    const int c_local = threadIdx.x & (PT_COLS - 1), s_local = threadIdx.x / PT_COLS;
+    const int site = bt * PT_COLS + c_local, s = st * PT_SMPL + s_local;
+    const bool live = in_grid && site < P.n_sites && s < P.n_smpl;
+    const long cell = (long)site * P.n_smpl + s;
     bool staged = false;
     if (FILL) {
-        span0 = P.cnt[cell0];
-        span_n = P.cnt[cell0 + 256 < ncells ? cell0 + 256 : ncells] - span0;
-        staged = span_n <= PILEUP_LDS_CAP;
+        if (threadIdx.x < PT_COLS) {
+            const int st_site = bt * PT_COLS + (int)threadIdx.x;
+            uint32_t b = 0, e = 0;
+            if (in_grid && st_site < P.n_sites) {
+                const long c0 = (long)st_site * P.n_smpl + st * PT_SMPL;
+                const int s1 = min(st * PT_SMPL + PT_SMPL, P.n_smpl);
+                b = P.cnt[c0]; e = P.cnt[(long)st_site * P.n_smpl + s1];
+            }
+            s_cb[threadIdx.x] = b;
+            // exclusive prefix sum of the chunk sizes over the 16 lanes
+            uint32_t v = e - b, inc = v;
+            #pragma unroll
+            for (int d = 1; d < PT_COLS; d <<= 1) { const uint32_t u = __shfl_up(inc, d, PT_COLS); if ((int)threadIdx.x >= d) inc += u; }
+            s_lb[threadIdx.x] = inc - v;
+            if (threadIdx.x == PT_COLS - 1) s_lb[PT_COLS] = inc;
+        }
+        __syncthreads();
+        staged = s_lb[PT_COLS] <= PILEUP_LDS_CAP;
     }
-    if (cell < ncells) {
-    const int site = (int)(cell / P.n_smpl), s = (int)(cell - (long)site * P.n_smpl);
+    if (live) {
     const int x = P.beg + site;
     const int lo0 = P.smpl_off[s], hi0 = P.smpl_off[s + 1];
     const int hi = upper_bound(P.s_pos, lo0, hi0, x);                    // reads starting at or before x
-    const int lo = upper_bound(P.s_pos, lo0, hi, x - P.max_span);        // ... that can still reach x
+    const int lo = upper_bound(P.s_pos, lo0, hi, x - (FILL ? P.max_span : *P.d_span));   // ... that can still reach x
     if (!FILL) {
         uint32_t n = 0;
         for (int k = lo; k < hi; ++k) n += P.meta[k].end > x ? 1u : 0u;
@@ -103,91 +136,124 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
         return;
     }
     uint32_t o = P.cnt[cell];                                            // plp_off after the scan
+    if (staged) o = o - s_cb[c_local] + s_lb[c_local];
 
+    // The walk over the sample's reads that can reach x, software-pipelined by hand: a read's record (two 16-byte loads) is
+    // fetched one trip ahead, its base and quality bytes are requested in the trip that resolves its CIGAR and used two
+    // trips later, so that a trip waits for loads issued one and two trips ago instead of three dependent ones in a row
+    // (at three wavefronts per SIMD -- the LDS staging -- the wavefronts sat in s_waitcnt 70 % of their time).
     uint32_t any_indel = 0;
-    for (int k = lo; k < hi; ++k) {
-        const uint4 m0 = reinterpret_cast<const uint4*>(P.meta + k)[0];
-        if ((int)m0.y <= x) continue;
-        const uint4 m1 = reinterpret_cast<const uint4*>(P.meta + k)[1];
-        const int rpos = (int)m0.x, lq = (int)(m1.x & 0xffff), ntot = (int)(m1.x >> 16);
-        const int ncig = (int)(m1.y & 0xff);
-        const uint32_t bits = (m1.y >> 8) & 0xff, mapq = (m1.y >> 16) & 0xff, so = m0.z;
-        const uint32_t *cg = P.cig + m0.w;
-        int qpos = 0, is_del = 0, is_skip = 0, indel = 0, edist;
-        const int op0 = m1.z & 0xf;
-        if (ncig == 1 && (op0 == 0 || op0 == 7 || op0 == 8)) {          // one aligned block: nothing to resolve
-            qpos = x - rpos;
-            edist = qpos + 1;
-        } else {
-            // htslib's resolve_cigar at reference position x
-            int rx = rpos, y = 0;
-            for (int c = 0; c < ncig; ++c) {
-                const int op = cg[c] & 0xf, l = (int)(cg[c] >> 4);
-                if (op == 0 || op == 7 || op == 8) {
-                    if (x < rx + l) {
-                        qpos = y + (x - rx);
-                        if (x == rx + l - 1) {                           // last base of the block: what follows?
-                            int cc = c + 1;
-                            while (cc < ncig && (cg[cc] & 0xf) == 6) ++cc;   // pads
-                            if (cc < ncig) {
-                                const int nop = cg[cc] & 0xf;
-                                if (nop == 1) {
-                                    indel = (int)(cg[cc] >> 4);
-                                    for (++cc; cc < ncig && ((cg[cc] & 0xf) == 1 || (cg[cc] & 0xf) == 6); ++cc)
-                                        if ((cg[cc] & 0xf) == 1) indel += (int)(cg[cc] >> 4);
-                                } else if (nop == 2) indel = -(int)(cg[cc] >> 4);
-                            }
-                        }
-                        break;
-                    }
-                    rx += l; y += l;
-                } else if (op == 2 || op == 3) {
-                    if (x < rx + l) { qpos = y; is_del = 1; is_skip = op == 3; break; }
-                    rx += l;
-                } else if (op == 1 || op == 4) y += l;
-            }
-            any_indel |= indel != 0;
-            // get_position, bam2bcf.c:80-114
-            int iread = 0;
-            edist = qpos + 1;
-            if (P.want_epos && (bits & 2))
+    const uint4 *meta4 = reinterpret_cast<const uint4*>(P.meta);
+    uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;                          // the record of read k, fetched ahead
+    const int k_last = P.n_reads - 1;
+    if (lo < hi) { n0 = meta4[2 * (size_t)lo]; n1 = meta4[2 * (size_t)lo + 1]; }
+    // two entries in flight: what is known of the entry without the bytes (w, e), whether a base exists (h), the bytes.
+    // (Two register sets for the records and two for the entries, the trips written out in pairs: a value that is moved
+    // from one variable to the next at the end of a trip counts as used there, and the compiler waits for every load.)
+    struct Pend { bool v, h; uint32_t w, e, nt, bq; };
+    Pend qa = {false, false, 0, 0, 0, 0}, qb = qa;
+    uint4 na0 = make_uint4(0, 0, 0, 0), na1 = na0;
+    auto trip = [&](const int k, const uint4 &m0, const uint4 &m1, uint4 &f0, uint4 &f1, Pend &q) __attribute__((always_inline)) {
+        // (fetched whether or not there is a next read, from a clamped index: a load under a condition makes the compiler
+        // wait for all outstanding loads at the next use instead of counting them)
+        const size_t kf = (size_t)min(k + 1, k_last);
+        f0 = meta4[2 * kf]; f1 = meta4[2 * kf + 1];
+        bool v0 = false, h0 = false;
+        uint32_t w0 = 0, e0 = 0, idx = 0;
+        if (k < hi && (int)m0.y > x) {
+            const int rpos = (int)m0.x, lq = (int)(m1.x & 0xffff), ntot = (int)(m1.x >> 16);
+            const int ncig = (int)(m1.y & 0xff);
+            const uint32_t bits = (m1.y >> 8) & 0xff, mapq = (m1.y >> 16) & 0xff, so = m0.z;
+            int qpos = 0, is_del = 0, is_skip = 0, indel = 0, edist;
+            const int op0 = m1.z & 0xf;
+            if (ncig == 1 && (op0 == 0 || op0 == 7 || op0 == 8)) {      // one aligned block: nothing to resolve
+                qpos = x - rpos;
+                edist = qpos + 1;
+            } else {
+                // htslib's resolve_cigar at reference position x
+                const uint32_t *cg = P.cig + m0.w;
+                int rx = rpos, y = 0;
                 for (int c = 0; c < ncig; ++c) {
                     const int op = cg[c] & 0xf, l = (int)(cg[c] >> 4);
-                    if (op == 0 || op == 7 || op == 8 || op == 1) iread += l;
-                    else if (op == 4) { iread += l; if (iread <= qpos) edist -= l; }
+                    if (op == 0 || op == 7 || op == 8) {
+                        if (x < rx + l) {
+                            qpos = y + (x - rx);
+                            if (x == rx + l - 1) {                       // last base of the block: what follows?
+                                int cc = c + 1;
+                                while (cc < ncig && (cg[cc] & 0xf) == 6) ++cc;   // pads
+                                if (cc < ncig) {
+                                    const int nop = cg[cc] & 0xf;
+                                    if (nop == 1) {
+                                        indel = (int)(cg[cc] >> 4);
+                                        for (++cc; cc < ncig && ((cg[cc] & 0xf) == 1 || (cg[cc] & 0xf) == 6); ++cc)
+                                            if ((cg[cc] & 0xf) == 1) indel += (int)(cg[cc] >> 4);
+                                    } else if (nop == 2) indel = -(int)(cg[cc] >> 4);
+                                }
+                            }
+                            break;
+                        }
+                        rx += l; y += l;
+                    } else if (op == 2 || op == 3) {
+                        if (x < rx + l) { qpos = y; is_del = 1; is_skip = op == 3; break; }
+                        rx += l;
+                    } else if (op == 1 || op == 4) y += l;
                 }
+                any_indel |= indel != 0;
+                // get_position, bam2bcf.c:80-114
+                int iread = 0;
+                edist = qpos + 1;
+                if (P.want_epos && (bits & 2))
+                    for (int c = 0; c < ncig; ++c) {
+                        const int op = cg[c] & 0xf, l = (int)(cg[c] >> 4);
+                        if (op == 0 || op == 7 || op == 8 || op == 1) iread += l;
+                        else if (op == 4) { iread += l; if (iread <= qpos) edist -= l; }
+                    }
+            }
+            // the record of bcfgpu_pack_read, but for the base and its quality
+            int tail = lq - 1 - qpos;
+            if (tail > qpos) tail = qpos;
+            tail = tail < 0 ? 0 : tail > 255 ? 255 : tail;
+            w0 = mapq << 8 | ((bits & 1) ? BCFGPU_RD_REV : 0) | ((bits & 2) ? BCFGPU_RD_SCLIP : 0) | (is_del ? BCFGPU_RD_DEL : 0)
+                    | ((is_skip || (bits & 4)) ? BCFGPU_RD_SKIP : 0) | (uint32_t)tail << 24;
+            if (P.want_epos) {
+                int e = (int)((double)edist / (ntot + 1) * BCFGPU_NPOS);
+                e0 = (uint32_t)(e < 0 ? 0 : e > BCFGPU_NPOS - 1 ? BCFGPU_NPOS - 1 : e);
+            }
+            v0 = true; h0 = qpos < lq;
+            idx = h0 ? so + (uint32_t)qpos : 0u;
         }
-        // the record of bcfgpu_pack_read
-        const int nt = qpos < lq ? (P.seq16[so + qpos] & 15) : 15;
-        const int bq = qpos < lq ? P.qual[so + qpos] : 0;
-        int tail = lq - 1 - qpos;
-        if (tail > qpos) tail = qpos;
-        tail = tail < 0 ? 0 : tail > 255 ? 255 : tail;
-        const uint32_t word = (uint32_t)bq | mapq << 8 | (uint32_t)nt << 16 | ((bits & 1) ? BCFGPU_RD_REV : 0)
-                | ((bits & 2) ? BCFGPU_RD_SCLIP : 0) | (is_del ? BCFGPU_RD_DEL : 0)
-                | ((is_skip || (bits & 4)) ? BCFGPU_RD_SKIP : 0) | (uint32_t)tail << 24;
-        int e = 0;
-        if (P.want_epos) {
-            e = (int)((double)edist / (ntot + 1) * BCFGPU_NPOS);
-            e = e < 0 ? 0 : e > BCFGPU_NPOS - 1 ? BCFGPU_NPOS - 1 : e;
+        // the entry whose bytes were requested two trips ago
+        if (q.v) {
+            const uint32_t word = q.w | (q.h ? q.bq : 0u) | (q.h ? (q.nt & 15u) : 15u) << 16;
+            if (staged) { s_rd[o] = word; s_ep[o] = (uint8_t)q.e; }
+            else { P.rd[o] = word; P.epos[o] = (uint8_t)q.e; }
+            ++o;
         }
-        if (staged) { s_rd[o - span0] = word; s_ep[o - span0] = (uint8_t)e; }
-        else { P.rd[o] = word; P.epos[o] = (uint8_t)e; }
-        ++o;
+        q.v = v0; q.h = h0; q.w = w0; q.e = e0;
+        q.nt = P.seq16[idx]; q.bq = P.qual[idx];                          // (unconditional: the pool is never empty, see bcfgpu_pileup)
+    };
+    if (lo < hi)
+    for (int k = lo; k < hi + 2; k += 2) {
+        trip(k, n0, n1, na0, na1, qa);
+        trip(k + 1, na0, na1, n0, n1, qb);
     }
     if (any_indel && P.col_indel) atomicOr(&P.col_indel[site], 1u);
     }
     if (FILL && staged) {
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < span_n; i += 256) P.rd[span0 + i] = s_rd[i];
-        // the bytes: single ones up to a 4-byte boundary of the output, then words, then the rest
-        const uint32_t head = min((4u - (span0 & 3u)) & 3u, span_n), nw = (span_n - head) >> 2, tail0 = head + 4 * nw;
-        if (threadIdx.x < head) P.epos[span0 + threadIdx.x] = s_ep[threadIdx.x];
-        for (uint32_t i = threadIdx.x; i < nw; i += 256) {
-            const uint8_t *b = s_ep + head + 4 * i;
-            *reinterpret_cast<uint32_t*>(P.epos + span0 + head + 4 * i) = (uint32_t)b[0] | (uint32_t)b[1] << 8 | (uint32_t)b[2] << 16 | (uint32_t)b[3] << 24;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int c = wave; c < PT_COLS; c += 4) {
+            const uint32_t gb = s_cb[c], lb = s_lb[c], n = s_lb[c + 1] - lb;
+            for (uint32_t i = lane; i < n; i += 64) P.rd[gb + i] = s_rd[lb + i];
+            // the bytes: single ones up to a 4-byte boundary of the output, then words, then the rest
+            const uint32_t head = min((4u - (gb & 3u)) & 3u, n), nw = (n - head) >> 2, tail0 = head + 4 * nw;
+            if ((uint32_t)lane < head) P.epos[gb + lane] = s_ep[lb + lane];
+            for (uint32_t i = lane; i < nw; i += 64) {
+                const uint8_t *b = s_ep + lb + head + 4 * i;
+                *reinterpret_cast<uint32_t*>(P.epos + gb + head + 4 * i) = (uint32_t)b[0] | (uint32_t)b[1] << 8 | (uint32_t)b[2] << 16 | (uint32_t)b[3] << 24;
+            }
+            if ((uint32_t)lane < n - tail0) P.epos[gb + tail0 + lane] = s_ep[lb + tail0 + lane];
         }
-        if (threadIdx.x < span_n - tail0) P.epos[span0 + tail0 + threadIdx.x] = s_ep[tail0 + threadIdx.x];
     }
 }
 
@@ -269,7 +335,7 @@ __global__ __launch_bounds__(256) void entries_kernel(const EntriesParams E)
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(covers);
         if (covers) {
             const uint32_t at = o + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
-            E.e_read[at] = P.s_read[k]; E.e_qpos[at] = qpos; E.e_indel[at] = indel;
+            E.e_read[at] = P.s_read ? P.s_read[k] : k; E.e_qpos[at] = qpos; E.e_indel[at] = indel;
         }
         o += (uint32_t)__popcll(mask);
     }
@@ -288,6 +354,94 @@ __global__ __launch_bounds__(256) void subtile_kernel(const EntriesParams E, uin
     if (!FILL) { E.sel_cnt[i] = e - b; return; }
     uint32_t o = E.sel_cnt[i];
     for (uint32_t k = b; k < e; ++k, ++o) { rd_out[o] = P.rd[k]; ep_out[o] = P.epos[k]; }
+}
+
+// One record per read (reference span, constants) from the caller's per-read arrays: a pass over the CIGARs, one lane per read
+// of the (sample, position)-ordered list.  status[0] = the longest reference span, status[1] = 1: a read too long for the
+// record's fields, 2: a sample's reads out of position order.
+struct MetaParams {
+    int n, n_smpl;
+    const int32_t *r_pos, *r_lq, *r_flag, *r_ncig, *r_cig_off, *r_seq_off;
+    const uint8_t *r_mapq;
+    const int32_t *s_read;          // pool index of sorted read k, or NULL: the pool is in that order already
+    const int32_t *smpl_off;
+    const uint32_t *cig;
+    ReadMeta *meta; int32_t *s_pos; int *status;
+};
+__global__ __launch_bounds__(256) void pileup_meta_kernel(const MetaParams M)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    int span = 1, bad = 0;
+    if (k < M.n) {
+        const int r = M.s_read ? M.s_read[k] : k;
+        const int pos = M.r_pos[r], ncig = M.r_ncig[r], lq = M.r_lq[r], flag = M.r_flag[r];
+        const uint32_t coff = (uint32_t)M.r_cig_off[r];
+        const uint32_t *cg = M.cig + coff;
+        int x = pos, ntot = 0, scl = 0;
+        for (int c = 0; c < ncig; ++c) {
+            const int op = cg[c] & 0xf, l = (int)(cg[c] >> 4);
+            if (op == 0 || op == 7 || op == 8) { x += l; ntot += l; }
+            else if (op == 2 || op == 3) x += l;
+            else if (op == 1) ntot += l;
+            else if (op == 4) scl = 1;
+        }
+        if (lq > 65535 || lq < 0 || ntot > 65535 || ncig > 255 || ncig < 0) bad = 1;
+        ReadMeta m;
+        m.pos = pos; m.end = bad ? pos : x; m.seq_off = (uint32_t)M.r_seq_off[r]; m.cig_off = coff;
+        m.lq = (uint16_t)lq; m.ntot = (uint16_t)ntot; m.ncig = (uint8_t)ncig;
+        m.bits = (uint8_t)(((flag & 16) ? 1 : 0) | (scl ? 2 : 0) | ((flag & 4) ? 4 : 0));
+        m.mapq = M.r_mapq[r]; m.pad = 0; m.cig0 = ncig > 0 ? cg[0] : 0; m.pad2 = 0;
+        uint4 *o = reinterpret_cast<uint4*>(M.meta + k);
+        const uint4 *mi = reinterpret_cast<const uint4*>(&m);
+        o[0] = mi[0]; o[1] = mi[1];
+        M.s_pos[k] = pos;
+        if (!bad) span = x - pos;
+        if (k > 0) {
+            const int rp = M.s_read ? M.s_read[k - 1] : k - 1;
+            if (pos < M.r_pos[rp]) {                                     // fine only across a sample boundary
+                const int idx = upper_bound(M.smpl_off, 0, M.n_smpl + 1, k);
+                if (M.smpl_off[idx - 1] != k) bad |= 2;
+            }
+        }
+    }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { span = max(span, __shfl_xor(span, o)); bad |= __shfl_xor(bad, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (span > 1) atomicMax(&M.status[0], span);
+        if (bad) atomicOr(&M.status[1], bad);
+    }
+}
+
+// The pool as BAM records hold it (two 4-bit base codes per byte, high nibble first) and qualities as palette indices, to the
+// one-byte-per-base arrays every kernel of the host-fed stages reads.  A lane per four input bytes = eight bases.
+__global__ __launch_bounds__(256) void pileup_unpack_kernel(const uint8_t *seq4, const uint8_t *qual4, unsigned long long pal_lo,
+                                                            unsigned long long pal_hi, size_t n_in, uint8_t *seq16, uint8_t *qual)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (4 * t >= n_in) return;
+    if (seq4) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(seq4 + 4 * t);
+        uint32_t lo = 0, hi = 0;
+        #pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const uint32_t by = (v >> (8 * b)) & 0xff, by2 = (v >> (8 * b + 16)) & 0xff;
+            lo |= ((by >> 4) | (by & 15) << 8) << (16 * b);
+            hi |= ((by2 >> 4) | (by2 & 15) << 8) << (16 * b);
+        }
+        *reinterpret_cast<uint2*>(seq16 + 8 * t) = make_uint2(lo, hi);
+    }
+    if (qual4) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(qual4 + 4 * t);
+        auto pal = [&](uint32_t j) -> uint32_t { return (uint32_t)(((j & 8) ? pal_hi : pal_lo) >> (8 * (j & 7))) & 0xff; };
+        uint32_t lo = 0, hi = 0;
+        #pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const uint32_t by = (v >> (8 * b)) & 0xff, by2 = (v >> (8 * b + 16)) & 0xff;
+            lo |= (pal(by >> 4) | pal(by & 15) << 8) << (16 * b);
+            hi |= (pal(by2 >> 4) | pal(by2 & 15) << 8) << (16 * b);
+        }
+        *reinterpret_cast<uint2*>(qual + 8 * t) = make_uint2(lo, hi);
+    }
 }
 
 }  // namespace bcfgpu
@@ -313,14 +467,19 @@ static int ref_nt16(char c)
     return 15;
 }
 
-extern "C" int bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const uint8_t *r_mapq, const int32_t *r_smpl,
-                             int32_t beg, int32_t end, const char *ref, int32_t ref_len,
-                             bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel)
+// bcfgpu_pileup and bcfgpu_pileup_packed: the host part is argument checks, the read -> sample bookkeeping (one pass over
+// r_smpl, none when the caller hands over smpl_off), uploads of the caller's arrays as they are, and launches.
+static int pileup_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bcfgpu_packed *pk, const uint8_t *r_mapq,
+                       const int32_t *r_smpl, int32_t beg, int32_t end, const char *ref, int32_t ref_len,
+                       bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel)
 {
-    if (!ctx || !rd || !tile || end < beg || rd->n_reads < 0 || (rd->n_reads && (!r_mapq || !r_smpl)) || (ref_len > 0 && !ref))
-        return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup: bad arguments");
+    auto fail = [&](int code, const char *what) { char msg[160]; snprintf(msg, sizeof msg, "%s: %s", who, what); return bcfgpu_set_error(code, msg); };
+    const int32_t *given_off = pk ? pk->smpl_off : nullptr;
+    if (!ctx || !rd || !tile || end < beg || rd->n_reads < 0 || (rd->n_reads && (!r_mapq || (!r_smpl && !given_off))) || (ref_len > 0 && !ref))
+        return fail(BCFGPU_E_ARG, "bad arguments");
+    if (pk && (!pk->seq4 || pk->n_bases < 0 || pk->n_cig < 0 || (pk->n_bases >> 32))) return fail(BCFGPU_E_ARG, "bad packed pool");
     hipStream_t stream = nullptr;
-    if (bcfgpu_internal_device(ctx, &stream, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup: bad context");
+    if (bcfgpu_internal_device(ctx, &stream, nullptr)) return fail(BCFGPU_E_ARG, "bad context");
     const bcfgpu_cfg *cfg = bcfgpu_internal_cfg(ctx);
     const int n = rd->n_reads, n_sites = end - beg, S = cfg->n_smpl;
     const bool trace = getenv("BCFGPU_TRACE") != nullptr;          // diagnostics: host timeline on stderr
@@ -328,152 +487,184 @@ extern "C" int bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const uint
     auto ms_now = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     const size_t ncells = (size_t)n_sites * S;
     std::memset(tile, 0, sizeof *tile);
-    if (ncells >> 31) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_pileup: region x samples too large for one tile");
-    // ---- host: reads grouped by sample (usually they already are: one file per sample), then one record per read with its
-    // reference span and constants (a pass over the CIGARs, on up to 16 threads) ----
-    // (grow-only scratch kept per calling thread: mapping and unmapping 200 MB per call costs more than filling it, and a
-    // std::vector would zero it on one thread first)
-    // (page-locked: the uploads below are then DMA transfers the call does not wait for; pageable as a fallback)
+    if (ncells >> 31) return fail(BCFGPU_E_RANGE, "region x samples too large for one tile");
+    int nthr = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("BCFGPU_HOST_THREADS")) nthr = atoi(e);
+    nthr = std::max(1, std::min(std::min(nthr, 16), n / 262144 + 1));
+    auto on_threads = [&](auto &&fn) {
+        std::vector<std::thread> thr;
+        for (int t = 1; t < nthr; ++t) thr.emplace_back(fn, t);
+        fn(0);
+        for (auto &th : thr) th.join();
+    };
+    // ---- host: which reads belong to which sample (usually they come grouped: one file per sample) ----
+    std::vector<int32_t> smpl_off(S + 1, 0);
+    bool grouped = true;
+    if (given_off) {
+        for (int s = 0; s <= S; ++s) smpl_off[s] = given_off[s];
+        if (smpl_off[0] != 0 || smpl_off[S] != n) return fail(BCFGPU_E_ARG, "smpl_off does not cover the pool");
+        for (int s = 0; s < S; ++s) if (smpl_off[s + 1] < smpl_off[s]) return fail(BCFGPU_E_ARG, "smpl_off is not ascending");
+    } else {
+        std::vector<std::vector<int32_t>> t_cnt(nthr);
+        std::vector<int> t_flag(nthr, 0);
+        on_threads([&](int t) {
+            const int k0 = (int)((long)n * t / nthr), k1 = (int)((long)n * (t + 1) / nthr);
+            std::vector<int32_t> &c = t_cnt[t];
+            c.assign(S, 0);
+            int flag = 0;
+            for (int r = k0; r < k1; ++r) {
+                const int sm = r_smpl[r];
+                if (sm < 0 || sm >= S) { flag |= 1; continue; }
+                if (r && sm < r_smpl[r - 1]) flag |= 2;
+                ++c[sm];
+            }
+            t_flag[t] = flag;
+        });
+        for (int t = 0; t < nthr; ++t) {
+            if (t_flag[t] & 1) return fail(BCFGPU_E_ARG, "sample index out of range");
+            if (t_flag[t] & 2) grouped = false;
+            for (int s = 0; s < S; ++s) smpl_off[s + 1] += t_cnt[t][s];
+        }
+        for (int s = 0; s < S; ++s) smpl_off[s + 1] += smpl_off[s];
+    }
+    // (grow-only scratch kept per calling thread and page-locked: the upload below is then a DMA transfer the call does not wait for)
     static thread_local struct Scratch {
         void *p = nullptr; size_t bytes = 0; bool pinned = false;
         void drop() { if (p) { if (pinned) hipHostFree(p); else free(p); } p = nullptr; bytes = 0; }
         ~Scratch() { if (p && !pinned) free(p); }                 // (a pinned block outlives the runtime's teardown order: left to the process exit)
     } scratch;
-    {
-        const size_t want = (size_t)(n ? n : 1) * (sizeof(ReadMeta) + 8) + 64;
+    int32_t *s_read = nullptr;
+    if (!grouped) {   // counting sort by sample, the given order kept inside a sample
+        const size_t want = (size_t)n * 4 + 64;
         if (scratch.bytes < want) {
-            hipStreamSynchronize(stream);                          // an earlier call's uploads may still read the old block
+            hipStreamSynchronize(stream);                          // an earlier call's upload may still read the old block
             scratch.drop();
             const size_t sz = want + want / 8;
             if (hipHostMalloc(&scratch.p, sz, hipHostMallocDefault) == hipSuccess) scratch.pinned = true;
             else { (void)hipGetLastError(); scratch.p = malloc(sz); scratch.pinned = false; }
             scratch.bytes = scratch.p ? sz : 0;
-            if (!scratch.p) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup: host scratch");
+            if (!scratch.p) return fail(BCFGPU_E_NOMEM, "host scratch");
         }
-    }
-    ReadMeta *meta = static_cast<ReadMeta*>(scratch.p);
-    int32_t *s_read = reinterpret_cast<int32_t*>(meta + (n ? n : 1)), *s_pos = s_read + (n ? n : 1);
-    std::vector<int32_t> smpl_off(S + 1, 0);
-    bool grouped = true;
-    for (int r = 0; r < n; ++r) {
-        if (r_smpl[r] < 0 || r_smpl[r] >= S) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup: sample index out of range");
-        if (r && r_smpl[r] < r_smpl[r - 1]) grouped = false;
-        ++smpl_off[r_smpl[r] + 1];
-    }
-    for (int s = 0; s < S; ++s) smpl_off[s + 1] += smpl_off[s];
-    if (!grouped) {   // counting sort by sample, the given order kept inside a sample
+        s_read = static_cast<int32_t*>(scratch.p);
         std::vector<int32_t> cur(smpl_off.begin(), smpl_off.end() - 1);
         for (int r = 0; r < n; ++r) s_read[cur[r_smpl[r]]++] = r;
     }
-    int nthr = (int)std::thread::hardware_concurrency();
-    if (const char *e = getenv("BCFGPU_HOST_THREADS")) nthr = atoi(e);
-    nthr = std::max(1, std::min(std::min(nthr, 16), n / 65536 + 1));
-    std::vector<int> t_span(nthr, 1), t_bad(nthr, 0);
-    std::vector<size_t> t_nbase(nthr, 0), t_ncig(nthr, 0);
-    auto fill_meta = [&](int t) {
-        const int k0 = (int)((long)n * t / nthr), k1 = (int)((long)n * (t + 1) / nthr);
-        int span = 1, bad = 0;                    // (thread-local: the per-thread result slots share cache lines)
-        size_t nb = 0, nc = 0;
-        for (int k = k0; k < k1; ++k) {
-            if (grouped) s_read[k] = k;
-            const int r = s_read[k];
-            const uint32_t *cg = rd->cig + rd->r_cig_off[r];
-            int x = rd->r_pos[r], ntot = 0, scl = 0;
-            for (int c = 0; c < rd->r_ncig[r]; ++c) {
-                const int op = cg[c] & 0xf, l = (int)(cg[c] >> 4);
-                if (op == 0 || op == 7 || op == 8) { x += l; ntot += l; }
-                else if (op == 2 || op == 3) x += l;
-                else if (op == 1) ntot += l;
-                else if (op == 4) scl = 1;
-            }
-            ReadMeta &m = meta[k];
-            m.pos = rd->r_pos[r]; m.end = x; m.seq_off = (uint32_t)rd->r_seq_off[r]; m.cig_off = (uint32_t)rd->r_cig_off[r];
-            if (rd->r_lq[r] > 65535 || ntot > 65535 || rd->r_ncig[r] > 255) { bad = 1; continue; }
-            m.lq = (uint16_t)rd->r_lq[r]; m.ntot = (uint16_t)ntot; m.ncig = (uint8_t)rd->r_ncig[r];
-            m.bits = (uint8_t)(((rd->r_flag[r] & 16) ? 1 : 0) | (scl ? 2 : 0) | ((rd->r_flag[r] & 4) ? 4 : 0));
-            m.mapq = r_mapq[r]; m.pad = 0; m.cig0 = rd->r_ncig[r] ? cg[0] : 0; m.pad2 = 0;
-            s_pos[k] = m.pos;
-            if (x - m.pos > span) span = x - m.pos;
-            const size_t e = (size_t)rd->r_seq_off[r] + rd->r_lq[r], c = (size_t)rd->r_cig_off[r] + rd->r_ncig[r];
-            if (e > nb) nb = e;
-            if (c > nc) nc = c;
-            if (k > k0 && r_smpl[r] == r_smpl[s_read[k - 1]] && m.pos < s_pos[k - 1] && !bad) bad = 2;
-        }
-        t_span[t] = span; t_bad[t] = bad; t_nbase[t] = nb; t_ncig[t] = nc;
-    };
-    {
-        std::vector<std::thread> thr;
-        for (int t = 1; t < nthr; ++t) thr.emplace_back(fill_meta, t);
-        fill_meta(0);
-        for (auto &th : thr) th.join();
-    }
+    // the extent of the pools (the packed form states it)
     size_t nbase = 0, ncig = 0;
-    int max_span = 1;
-    for (int t = 0; t < nthr; ++t) {
-        if (t_bad[t] == 1) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_pileup: a read is longer than 65535 bases or has more than 255 CIGAR operations");
-        if (t_bad[t] == 2) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup: the reads of a sample are not in position order");
-        max_span = std::max(max_span, t_span[t]); nbase = std::max(nbase, t_nbase[t]); ncig = std::max(ncig, t_ncig[t]);
-    }
-    for (int t = 1; t < nthr; ++t) {          // order across the threads' chunk boundaries
-        const int k = (int)((long)n * t / nthr);
-        if (k > 0 && k < n && r_smpl[s_read[k]] == r_smpl[s_read[k - 1]] && s_pos[k] < s_pos[k - 1])
-            return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup: the reads of a sample are not in position order");
+    if (pk) { nbase = (size_t)pk->n_bases; ncig = (size_t)pk->n_cig; }
+    else {
+        std::vector<size_t> t_nbase(nthr, 0), t_ncig(nthr, 0);
+        on_threads([&](int t) {
+            const int k0 = (int)((long)n * t / nthr), k1 = (int)((long)n * (t + 1) / nthr);
+            size_t nb = 0, nc = 0;
+            for (int r = k0; r < k1; ++r) {
+                const size_t e = (size_t)rd->r_seq_off[r] + (size_t)std::max(rd->r_lq[r], 0), c = (size_t)rd->r_cig_off[r] + (size_t)std::max(rd->r_ncig[r], 0);
+                if (e > nb) nb = e;
+                if (c > nc) nc = c;
+            }
+            t_nbase[t] = nb; t_ncig[t] = nc;
+        });
+        for (int t = 0; t < nthr; ++t) { nbase = std::max(nbase, t_nbase[t]); ncig = std::max(ncig, t_ncig[t]); }
+        if (nbase >> 32) return fail(BCFGPU_E_RANGE, "the pool holds 2^32 or more bases");
     }
     std::vector<int8_t> ref16(n_sites);
     for (int k = 0; k < n_sites; ++k) ref16[k] = (int8_t)(beg + k < ref_len ? ref_nt16(ref[beg + k]) : 15);
 
     if (trace) fprintf(stderr, "[pileup] host preparation done at %.2f ms\n", ms_now());
     // ---- device ----
-    #define PL_CHK(call) do { if ((call) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, #call); } while (0)
+    #define PL_CHK(call) do { if ((call) != hipSuccess) return fail(BCFGPU_E_HIP, #call); } while (0)
     auto up = [&](int slot, const void *src, size_t bytes) -> void* {
-        void *d = bcfgpu_internal_ws(ctx, slot, bytes + 16);
+        void *d = bcfgpu_internal_ws(ctx, slot, bytes + 64);
         if (d && bytes && hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
         return d;
     };
     PileupParams P{};
-    P.n_sites = n_sites; P.n_smpl = S; P.beg = beg; P.max_span = max_span; P.n_reads = n; P.n_bases = (uint32_t)nbase;
+    P.n_sites = n_sites; P.n_smpl = S; P.beg = beg; P.max_span = 1; P.n_reads = n; P.n_bases = (uint32_t)nbase;
     P.want_epos = (cfg->fmt_flag & (BCFGPU_INFO_RPB | BCFGPU_INFO_VDB)) ? 1 : 0;
     void *d_ref16 = up(16, ref16.data(), (size_t)n_sites);
     P.smpl_off = (const int32_t*)up(17, smpl_off.data(), (size_t)(S + 1) * 4);
-    P.s_pos = (const int32_t*)up(18, s_pos, (size_t)n * 4);
-    P.s_read = (const int32_t*)up(20, s_read, (size_t)n * 4);
-    P.meta = (const ReadMeta*)up(19, meta, (size_t)n * sizeof(ReadMeta));
+    MetaParams M{};
+    M.n = n; M.n_smpl = S; M.smpl_off = P.smpl_off;
+    M.r_pos = (const int32_t*)up(104, rd->r_pos, (size_t)n * 4);
+    M.r_lq = (const int32_t*)up(105, rd->r_lq, (size_t)n * 4);
+    M.r_flag = (const int32_t*)up(106, rd->r_flag, (size_t)n * 4);
+    M.r_ncig = (const int32_t*)up(107, rd->r_ncig, (size_t)n * 4);
+    M.r_cig_off = (const int32_t*)up(108, rd->r_cig_off, (size_t)n * 4);
+    M.r_seq_off = (const int32_t*)up(109, rd->r_seq_off, (size_t)n * 4);
+    M.r_mapq = (const uint8_t*)up(110, r_mapq, (size_t)n);
+    M.s_read = s_read ? (const int32_t*)up(20, s_read, (size_t)n * 4) : nullptr;
     P.cig = (const uint32_t*)up(27, rd->cig, ncig * 4);
-    P.seq16 = (const uint8_t*)up(28, rd->seq16, nbase);
-    P.qual = (const uint8_t*)up(29, rd->qual, nbase);
+    M.cig = P.cig;
+    M.meta = (ReadMeta*)bcfgpu_internal_ws(ctx, 19, (size_t)n * sizeof(ReadMeta) + 64);
+    M.s_pos = (int32_t*)bcfgpu_internal_ws(ctx, 18, (size_t)n * 4 + 64);
+    M.status = (int*)bcfgpu_internal_ws(ctx, 113, 64);
+    uint8_t *d_seq16 = nullptr, *d_qual = nullptr;
+    const uint8_t *d_seq4 = nullptr, *d_qual4 = nullptr;
+    if (pk) {
+        const size_t n_in = (nbase + 1) / 2;
+        d_seq16 = (uint8_t*)bcfgpu_internal_ws(ctx, 28, nbase + 64);
+        d_seq4 = (const uint8_t*)up(111, pk->seq4, n_in);
+        if (pk->qual4) { d_qual = (uint8_t*)bcfgpu_internal_ws(ctx, 29, nbase + 64); d_qual4 = (const uint8_t*)up(112, pk->qual4, n_in); }
+        else d_qual = (uint8_t*)up(29, rd->qual, nbase);
+        if (!d_seq4 || (pk->qual4 && !d_qual4)) return fail(BCFGPU_E_NOMEM, "device workspace");
+    } else {
+        d_seq16 = (uint8_t*)up(28, rd->seq16, nbase);
+        d_qual = (uint8_t*)up(29, rd->qual, nbase);
+    }
+    P.seq16 = d_seq16; P.qual = d_qual; P.s_read = M.s_read; P.meta = M.meta; P.s_pos = M.s_pos; P.d_span = M.status;
     uint32_t *d_cnt = (uint32_t*)bcfgpu_internal_ws(ctx, 30, (ncells + 1) * 4 + (size_t)n_sites * 4 + 64);
-    if (!d_ref16 || !P.smpl_off || !P.s_pos || !P.s_read || !P.meta || !P.cig || !P.seq16 || !P.qual || !d_cnt)
-        return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup: device workspace");
+    if (!d_ref16 || !P.smpl_off || !M.r_pos || !M.r_lq || !M.r_flag || !M.r_ncig || !M.r_cig_off || !M.r_seq_off || !M.r_mapq || (s_read && !M.s_read)
+            || !P.cig || !M.meta || !M.s_pos || !M.status || !P.seq16 || !P.qual || !d_cnt)
+        return fail(BCFGPU_E_NOMEM, "device workspace");
     P.cnt = d_cnt;
     P.col_indel = d_cnt + ncells + 1;
     PL_CHK(hipMemsetAsync(d_cnt, 0, (ncells + 1) * 4 + (size_t)n_sites * 4, stream));
-    const int grid = (int)((ncells + 255) / 256);
+    const int init_status[2] = {1, 0};
+    PL_CHK(hipMemcpyAsync(M.status, init_status, 8, hipMemcpyHostToDevice, stream));
+    if (pk) {
+        unsigned long long pal[2] = {0, 0};
+        std::memcpy(pal, pk->palette, 16);
+        const size_t n_in = (nbase + 1) / 2, nthreads = (n_in + 3) / 4;
+        if (nthreads) hipLaunchKernelGGL(pileup_unpack_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream,
+                                         d_seq4, d_qual4, pal[0], pal[1], n_in, d_seq16, d_qual);
+    }
+    if (n) hipLaunchKernelGGL(pileup_meta_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, M);
+    const int n_work = ((n_sites + PT_COLS - 1) / PT_COLS) * ((S + PT_SMPL - 1) / PT_SMPL);
+    const int grid = (n_work + 7) / 8 * 8;           // (a multiple of the XCD count: see the kernel's work mapping)
     uint32_t total = 0;
+    int status[2] = {1, 0};
     if (trace) { hipStreamSynchronize(stream); fprintf(stderr, "[pileup] pool on the device at %.2f ms\n", ms_now()); }
     if (ncells) {
         hipLaunchKernelGGL(pileup_kernel<false>, dim3(grid), dim3(256), 0, stream, P);
         // the total in 64 bits first: plp_off is 32-bit, a region whose pileup reaches 2^32 entries must be refused, not wrapped
         unsigned long long *d_tot64 = (unsigned long long*)bcfgpu_internal_ws(ctx, 34, 64);
-        if (!d_tot64) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup: device workspace");
+        if (!d_tot64) return fail(BCFGPU_E_NOMEM, "device workspace");
         PL_CHK(hipMemsetAsync(d_tot64, 0, 8, stream));
         hipLaunchKernelGGL(count_total_kernel, dim3((unsigned)std::min<size_t>((ncells + 4095) / 4096, 65535)), dim3(256), 0, stream, d_cnt, ncells, d_tot64);
         // plp_off = exclusive prefix sum of the counts (in place, one element past the end for the total)
         size_t tmp_bytes = 0;
         PL_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_cnt, (int)(ncells + 1), stream));
         void *d_tmp = bcfgpu_internal_ws(ctx, 31, tmp_bytes + 16);
-        if (!d_tmp) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup: device workspace");
+        if (!d_tmp) return fail(BCFGPU_E_NOMEM, "device workspace");
         PL_CHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt, d_cnt, (int)(ncells + 1), stream));
         unsigned long long tot64 = 0;
         PL_CHK(hipMemcpyAsync(&total, d_cnt + ncells, 4, hipMemcpyDeviceToHost, stream));
         PL_CHK(hipMemcpyAsync(&tot64, d_tot64, 8, hipMemcpyDeviceToHost, stream));
+        PL_CHK(hipMemcpyAsync(status, M.status, 8, hipMemcpyDeviceToHost, stream));
         PL_CHK(hipStreamSynchronize(stream));
-        if (tot64 >> 32) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_pileup: the region's pileup has 2^32 or more entries; use a smaller region per call");
+        if (tot64 >> 32) return fail(BCFGPU_E_RANGE, "the region's pileup has 2^32 or more entries; use a smaller region per call");
+    } else {
+        PL_CHK(hipMemcpyAsync(status, M.status, 8, hipMemcpyDeviceToHost, stream));
+        PL_CHK(hipStreamSynchronize(stream));
     }
+    if (status[1] & 1) return fail(BCFGPU_E_RANGE, "a read is longer than 65535 bases or has more than 255 CIGAR operations");
+    if (status[1] & 2) return fail(BCFGPU_E_ARG, "the reads of a sample are not in position order");
+    P.max_span = status[0];
     if (trace) fprintf(stderr, "[pileup] counted and scanned at %.2f ms (%u entries)\n", ms_now(), total);
     // the read records: the scan's temporary storage is done with, its slot is reused (grow-only) for rd + epos
     const size_t epos_at = (((size_t)total + 4) * 4 + 255) & ~(size_t)255;      // both arrays aligned for 16-byte staging loads
     uint8_t *d_out = (uint8_t*)bcfgpu_internal_ws(ctx, 31, epos_at + (size_t)total + 64);
-    if (!d_out) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pileup: device workspace");
+    if (!d_out) return fail(BCFGPU_E_NOMEM, "device workspace");
     P.rd = (uint32_t*)d_out; P.epos = d_out + epos_at;
     if (total) hipLaunchKernelGGL(pileup_kernel<true>, dim3(grid), dim3(256), 0, stream, P);
     PL_CHK(hipGetLastError());
@@ -500,6 +691,21 @@ extern "C" int bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const uint
     tile->n_sites = n_sites; tile->is_indel = 0; tile->n_reads = total;
     tile->ref16 = (const int8_t*)d_ref16; tile->plp_off = d_cnt; tile->rd = P.rd; tile->epos = P.epos;
     return BCFGPU_OK;
+}
+
+extern "C" int bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const uint8_t *r_mapq, const int32_t *r_smpl,
+                             int32_t beg, int32_t end, const char *ref, int32_t ref_len,
+                             bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel)
+{
+    return pileup_impl("bcfgpu_pileup", ctx, rd, nullptr, r_mapq, r_smpl, beg, end, ref, ref_len, tile, col_n, col_indel);
+}
+
+extern "C" int bcfgpu_pileup_packed(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bcfgpu_packed *pk, const uint8_t *r_mapq,
+                                    const int32_t *r_smpl, int32_t beg, int32_t end, const char *ref, int32_t ref_len,
+                                    bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel)
+{
+    if (!pk) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup_packed: bad arguments");
+    return pileup_impl("bcfgpu_pileup_packed", ctx, rd, pk, r_mapq, r_smpl, beg, end, ref, ref_len, tile, col_n, col_indel);
 }
 
 extern "C" int bcfgpu_pileup_entries(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols, int32_t *smpl_off,
@@ -613,7 +819,7 @@ __global__ __launch_bounds__(256) void gap_unpack_reads_kernel(const PileupParam
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= P.n_reads) return;
     const ReadMeta m = P.meta[k];
-    const int r = P.s_read[k];
+    const int r = P.s_read ? P.s_read[k] : k;
     r_pos[r] = m.pos; r_lq[r] = m.lq; r_flag[r] = ((m.bits & 1) ? 16 : 0) | ((m.bits & 4) ? 4 : 0);
     r_ncig[r] = m.ncig; r_cig_off[r] = (int32_t)m.cig_off; r_seq_off[r] = (int32_t)m.seq_off;
 }

@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--var-rate", type=float, default=0.01)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget on rank 0 at N=1 (0: skip)")
     ap.add_argument("--seed", type=int, default=20260104)
+    ap.add_argument("--packed", type=int, default=1, help="--mode pileup: 1 = the pool as bcfgpu_pileup_packed takes it (4-bit bases, palette qualities), 0 = a byte per base")
     ap.add_argument("--pageable", action="store_true", help="--mode pileup: keep the read pool in ordinary (pageable) host memory")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the CPU baseline on all host cores (0: skip)")
     ap.add_argument("--groups", type=int, default=1, help="snp mode: call -G with this many sample groups (frequencies from FORMAT/AD); "
@@ -457,6 +458,12 @@ def main_pileup(a):
     arrs["seq16"] = seq
     mapq = np.where(rng.random(n) < 0.92, 60, rng.integers(0, 60, n)).astype(np.uint8)
     pool_bytes = sum(v.nbytes for v in arrs.values()) + mapq.nbytes + smpl.nbytes
+    # the same pool as BAM records hold it: two bases per byte, the (binned) qualities as palette indices, the samples' offsets
+    palette = np.unique(arrs["qual"])
+    packed_arrs = dict(seq4=abi.pack_nibbles(seq), qual4=abi.pack_nibbles(np.searchsorted(palette, arrs["qual"])),
+                       smpl_off=(np.arange(S + 1, dtype=np.int64) * per).astype(np.int32))
+    packed_bytes = (sum(v.nbytes for k, v in arrs.items() if k not in ("seq16", "qual", "zq", "r_has_zq")) + mapq.nbytes
+                    + sum(v.nbytes for v in packed_arrs.values()))
     # the pool in page-locked memory (bcfgpu_host_alloc), as a host that parses its reads straight into such buffers has it:
     # the uploads are then DMA transfers that run beside the other context's kernels
     from bcftools_amd.lib import load
@@ -472,19 +479,31 @@ def main_pileup(a):
         return w
     if not a.pageable:
         arrs = {k: pin(v) for k, v in arrs.items()}
+        packed_arrs = {k: pin(v) for k, v in packed_arrs.items()}
         mapq, smpl = pin(mapq), pin(smpl)
     rd.n_reads = n
     for k, v in arrs.items():
         setattr(rd, k, v.ctypes.data)
+    pk = abi.Packed()
+    pk.seq4, pk.qual4, pk.smpl_off = (packed_arrs[k].ctypes.data for k in ("seq4", "qual4", "smpl_off"))
+    pk.n_bases, pk.n_cig = n * L, len(cig)
+    for j, q in enumerate(palette):
+        pk.palette[j] = int(q)
     # size the contexts from a first build
     ctx0 = engine.Context(abi.default_cfg(S, max_sites=1, max_reads=64))
     t = abi.Tile()
     ref_b = refseq.encode()
 
+    use_packed = [bool(a.packed)]
+
     def build(ctx, tile):
         t0 = time.perf_counter()
-        check(ctx.L.bcfgpu_pileup(ctx.h, C.byref(rd), mapq.ctypes.data, smpl.ctypes.data, beg, end, ref_b, len(refseq),
-                                  C.byref(tile), None, None))
+        if use_packed[0]:
+            check(ctx.L.bcfgpu_pileup_packed(ctx.h, C.byref(rd), C.byref(pk), mapq.ctypes.data, None, beg, end, ref_b, len(refseq),
+                                             C.byref(tile), None, None))
+        else:
+            check(ctx.L.bcfgpu_pileup(ctx.h, C.byref(rd), mapq.ctypes.data, smpl.ctypes.data, beg, end, ref_b, len(refseq),
+                                      C.byref(tile), None, None))
         return time.perf_counter() - t0
     build(ctx0, t)
     entries = int(t.n_reads)
@@ -510,28 +529,42 @@ def main_pileup(a):
         t0 = time.perf_counter(); build(ctxs[0], tiles[0]); ctxs[0].sync()     # (the call returns with its fill kernel enqueued)
         t1 = time.perf_counter(); pipe(0); ctxs[0].sync()
         return t1 - t0, time.perf_counter() - t1
-    serial()
-    tb, tp = min(serial() for _ in range(3))
     # the overlapped loop: K regions (the same pool stands for every region), contexts alternating
     K = max(4, a.steps)
-    for i in range(2):
-        build(ctxs[i], tiles[i]); pipe(i)
-    for c in ctxs:
-        c.sync()
-    t0 = time.perf_counter()
-    for k in range(K):
-        i = k & 1
-        ctxs[i].sync()                       # the region that used this context two steps ago is done (its records would be read here)
-        build(ctxs[i], tiles[i])             # prepares, uploads, counts; returns with the fill kernel enqueued
-        pipe(i)                              # enqueued behind it; runs while the next region is prepared on the other context
-    for c in ctxs:
-        c.sync()
-    t_loop = (time.perf_counter() - t0) / K
+
+    def overlapped():
+        for i in range(2):
+            build(ctxs[i], tiles[i]); pipe(i)
+        for c in ctxs:
+            c.sync()
+        t0 = time.perf_counter()
+        for k in range(K):
+            i = k & 1
+            ctxs[i].sync()                   # the region that used this context two steps ago is done (its records would be read here)
+            build(ctxs[i], tiles[i])         # uploads, counts; returns with the fill kernel enqueued
+            pipe(i)                          # enqueued behind it; runs while the next region is uploaded on the other context
+        for c in ctxs:
+            c.sync()
+        return (time.perf_counter() - t0) / K
+    other = None
+    if a.packed:                             # the byte-per-base form of the same pool, for comparison
+        use_packed[0] = False
+        serial()
+        tb_u, _ = min(serial() for _ in range(3))
+        other = {"pool_bytes": int(pool_bytes), "whole_call_ms": tb_u * 1e3, "overlapped_ms_per_region": overlapped() * 1e3}
+        other["sites_per_s"] = n_sites / (other["overlapped_ms_per_region"] * 1e-3)
+        use_packed[0] = True
+        pool_bytes = packed_bytes
+    serial()
+    tb, tp = min(serial() for _ in range(3))
+    t_loop = overlapped()
     tile_bytes = entries * 5 + (n_sites * S + 1) * 4 + n_sites
     out = {"metric": "pileup entries/sec through bcfgpu_pileup (read pool -> site x sample x read tile in HBM), %d samples x %.0fx" % (S, a.depth),
            "value": entries / tb, "unit": "entries/s", "n_gpus": 1, "higher_is_better": True, "dtype": "u32/u8 records", "data": "synthetic",
            "config": {"workload": "%d reads of %d bp over %d columns x %d samples" % (n, L, n_sites, S), "reads": n, "entries": entries,
-                      "columns": n_sites, "pool_memory": "pageable" if a.pageable else "page-locked (bcfgpu_host_alloc)"},
+                      "columns": n_sites, "pool_memory": "pageable" if a.pageable else "page-locked (bcfgpu_host_alloc)",
+                      "pool_form": ("bcfgpu_pileup_packed: 4-bit bases, %d-value quality palette (4-bit), per-sample offsets" % len(palette))
+                                   if a.packed else "bcfgpu_pileup: one byte per base and per quality"},
            "whole_call_ms": tb * 1e3, "tile_written_gbs": tile_bytes / tb / 1e9,
            "pcie": {"pool_bytes": int(pool_bytes), "tile_bytes": int(tile_bytes), "pool_gbs_in_call": pool_bytes / tb / 1e9,
                     "note": "the pool is what crosses PCIe; a host-packed tile of this region would be tile_bytes"},
@@ -539,6 +572,8 @@ def main_pileup(a):
                                  "overlapped_ms_per_region": t_loop * 1e3, "sites_per_s": n_sites / t_loop, "regions": K,
                                  "note": "bcfgpu_pileup (host pointers in) then bcfgpu_pipeline on the tile it left in HBM; overlapped = two "
                                          "contexts alternating, a region's kernels running while the next region is prepared and uploaded"}}
+    if other:
+        out["byte_per_base_form"] = other
     print(json.dumps(out), flush=True)
     for c, o in zip(ctxs, outs):
         c.release(list(o[1].values()))
@@ -814,7 +849,7 @@ def main():
             hf = child(["--mode", "pileup", "--steps", "6", "--cpu-seconds", "0", "--cpu-all-cores", "0", "--extras", "0", "--seed", str(a.seed)])
             out["extra"] = {
                 "configs2_mixed": {k: mix.get(k) for k in ("metric", "value", "unit", "ms_per_step", "config", "split_ms", "cpu_baseline", "error") if k in mix},
-                "host_fed_pileup": {k: hf.get(k) for k in ("metric", "value", "unit", "config", "whole_call_ms", "pcie", "host_fed_pipeline", "error") if k in hf},
+                "host_fed_pileup": {k: hf.get(k) for k in ("metric", "value", "unit", "config", "whole_call_ms", "pcie", "host_fed_pipeline", "byte_per_base_form", "error") if k in hf},
                 "configs4_shape": {k: c4.get(k) for k in ("value", "unit", "ms_per_step", "config", "roofline", "error") if k in c4},
                 "indel_stage": {k: ind.get(k) for k in ("metric", "value", "unit", "config", "kernel", "host_ms", "indel_pass", "host_pointer_form", "cpu_baseline", "error") if k in ind},
                 "note": "configs4_shape: the same tile through call -G (4 sample groups on FORMAT/AD) with a ploidy array (25 % haploid); "

@@ -375,6 +375,28 @@ int  bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const uint8_t *r_
                    int32_t beg, int32_t end, const char *ref, int32_t ref_len,
                    bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel);
 
+/* The same call for a pool in the form BAM records hold it, for hosts that feed the device over PCIe (the pool's bytes are what
+ * bounds that path): bases as two 4-bit codes per byte, qualities optionally as 4-bit indices into a palette of <= 16 values
+ * (binned qualities; after BAQ the values are too many and qual4 is left NULL).  `reads` as for bcfgpu_pileup, except that
+ * reads->seq16 is not read, nor reads->qual when qual4 is given; the pool is expanded on the device.
+ *   seq4     base i of read r is nibble r_seq_off[r] + i: byte (r_seq_off[r]+i)/2, the HIGH nibble when that index is even
+ *            (bam_get_seq's order; a host that copies the records' sequence bytes keeps every r_seq_off even)
+ *   qual4    NULL, or palette indices addressed the same way;  palette[j] = the quality index j stands for
+ *   n_bases  bases the pools hold (the largest r_seq_off[r] + r_lq[r]);  n_cig  operations in reads->cig
+ *   smpl_off NULL, or [n_smpl+1]: the reads of sample s are smpl_off[s] .. smpl_off[s+1]-1 of the pool (then r_smpl is not
+ *            read and the call makes no pass over the reads on the host at all)
+ * bcfgpu_gap_prep_tile, bcfgpu_pileup_entries and bcfgpu_pileup_indel_tile follow it as they follow bcfgpu_pileup. */
+typedef struct {
+    const uint8_t *seq4, *qual4;
+    uint8_t palette[16];
+    int64_t n_bases, n_cig;
+    const int32_t *smpl_off;
+} bcfgpu_packed;
+
+int  bcfgpu_pileup_packed(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const bcfgpu_packed *pk, const uint8_t *r_mapq,
+                          const int32_t *r_smpl, int32_t beg, int32_t end, const char *ref, int32_t ref_len,
+                          bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel);
+
 /* ---- the pileup iterator's per-file depth cap: mpileup -d (mpileup.c:646 bam_mplp_set_maxcnt; htslib sam.c bam_plp_push) -------
  * Host helper (integer bookkeeping of the read buffer, no device work).  A read is dropped when it starts at the position of
  * the read kept last while max_depth or more reads are still buffered: reads kept earlier whose end (bam_endpos) is not before

@@ -15,15 +15,41 @@ from tests.helpers import sam, mplpdrv as M, mplpcmp as K, ovlfuzz, vcf, orc
 pytestmark = pytest.mark.gpu
 
 
-def device_pileup(ctx, reads_by_sample, refseq, beg, end):
-    """reads_by_sample: list (one per sample) of read lists in position order.  Returns (HostTile, col_n, col_indel)."""
+def device_pileup(ctx, reads_by_sample, refseq, beg, end, packed=None, order=None):
+    """reads_by_sample: list (one per sample) of read lists in position order.  Returns (HostTile, col_n, col_indel).
+    packed: None = bcfgpu_pileup; "seq" / "seq+qual" / "seq+qual+off" = bcfgpu_pileup_packed with 4-bit bases, palette qualities
+    too, and the samples' offsets instead of r_smpl.  order: a permutation of the pool (reads of the samples interleaved)."""
     reads = [r for rl in reads_by_sample for r in rl]
     smpl = np.array([si for si, rl in enumerate(reads_by_sample) for _ in rl], dtype=np.int32)
+    if order is not None:
+        reads = [reads[i] for i in order]
+        smpl = np.ascontiguousarray(smpl[order])
     n_sites, S = end - beg, len(reads_by_sample)
     col_n = np.zeros(n_sites, np.int32)
     col_indel = np.zeros(n_sites, np.uint8)
     t = abi.Tile()
-    if reads:
+    if reads and packed:
+        rd, d = M.pack_reads(reads)
+        mapq = np.array([r.mapq for r in reads], dtype=np.uint8)
+        pk = abi.Packed()
+        seq4 = abi.pack_nibbles(d["seq16"])
+        pk.seq4, pk.n_bases, pk.n_cig = seq4.ctypes.data, len(d["seq16"]), len(d["cig"])
+        rd.seq16 = None
+        if "qual" in packed:
+            pal = np.unique(d["qual"])
+            assert len(pal) <= 16
+            qual4 = abi.pack_nibbles(np.searchsorted(pal, d["qual"]))
+            pk.qual4 = qual4.ctypes.data
+            for j, q in enumerate(pal):
+                pk.palette[j] = int(q)
+            rd.qual = None
+        smpl_ptr = smpl.ctypes.data
+        if "off" in packed:
+            off = np.concatenate([[0], np.cumsum([len(rl) for rl in reads_by_sample])]).astype(np.int32)
+            pk.smpl_off, smpl_ptr = off.ctypes.data, None
+        check(ctx.L.bcfgpu_pileup_packed(ctx.h, C.byref(rd), C.byref(pk), mapq.ctypes.data, smpl_ptr, beg, end, refseq.encode(),
+                                         len(refseq), C.byref(t), col_n.ctypes.data, col_indel.ctypes.data))
+    elif reads:
         rd, d = M.pack_reads(reads)
         mapq = np.array([r.mapq for r in reads], dtype=np.uint8)
         check(ctx.L.bcfgpu_pileup(ctx.h, C.byref(rd), mapq.ctypes.data, smpl.ctypes.data, beg, end, refseq.encode(), len(refseq),
@@ -129,6 +155,41 @@ def test_pileup_matches_host_walk_on_random_reads(gpu_ctx_factory):
     if len(by_sample[0]) > 1 and by_sample[0][0].pos != by_sample[0][-1].pos:
         with pytest.raises(BcfGpuError):
             device_pileup(ctx, by_sample, refseq, 0, 50)
+
+
+def test_packed_pool_and_interleaved_samples_give_the_same_tile(gpu_ctx_factory):
+    """bcfgpu_pileup_packed (4-bit bases as in BAM records, palette qualities, the samples' offsets instead of r_smpl) and a
+    pool whose samples' reads are interleaved (a merged input) give the tile of the plain call; reads of odd lengths, so that
+    reads start on either nibble of a byte."""
+    rng = np.random.default_rng(21)
+    S, L = 19, 900                                                  # more samples than a workgroup's 16: tiles with a ragged edge
+    refseq = "".join("ACGT"[i] for i in rng.integers(0, 4, L))
+    quals = np.array([2, 11, 12, 25, 37, 40], np.uint8)
+    by_sample = []
+    for s in range(S):
+        rl = [ovlfuzz.make_read(rng, rng.integers(0, L - 50), int(rng.integers(21, 131))) for _ in range(int(rng.integers(0, 90)))]
+        for r in rl:
+            r.mapq = int(rng.integers(0, 61))
+            r.flag = int(rng.choice([0, 16]))
+            r.qual = quals[rng.integers(0, len(quals), r.l_qseq)]
+        rl.sort(key=lambda r: r.pos)
+        by_sample.append(rl)
+    by_sample[5] = []
+    ctx = gpu_ctx_factory(abi.default_cfg(S, max_sites=1, max_reads=64))
+    want, want_indel = host_pileup(by_sample, refseq + "N" * 100, 0, L + 20)
+    for packed in (None, "seq", "seq+qual", "seq+qual+off"):
+        got, col_n, col_indel, _ = device_pileup(ctx, by_sample, refseq, 0, L + 20, packed=packed)
+        assert_tiles_equal(got, want)
+        np.testing.assert_array_equal(col_indel, want_indel)
+    n = sum(len(rl) for rl in by_sample)
+    # interleaved: the pool merged by position (every sample's reads stay in position order)
+    smpl = np.array([si for si, rl in enumerate(by_sample) for _ in rl])
+    order = np.argsort(np.array([r.pos for rl in by_sample for r in rl]), kind="stable")
+    assert len(order) == n
+    assert (np.diff(smpl[order]) < 0).any()
+    for packed in (None, "seq+qual"):
+        got, _, _, _ = device_pileup(ctx, by_sample, refseq, 0, L + 20, packed=packed, order=order)
+        assert_tiles_equal(got, want)
 
 
 def test_pileup_from_a_page_locked_pool(gpu_ctx_factory):
