@@ -303,15 +303,16 @@ int bcfgpu_depth_cap(const bcfgpu_reads *rd, const int32_t *r_smpl, int32_t n_sm
         St &S = st[s];
         const int32_t p = rd->r_pos[r];
         if (p < S.last_pos) return set_err(BCFGPU_E_ARG, "bcfgpu_depth_cap: the reads of a sample are not in position order");
-        int32_t e = p;                                          // bam_endpos: the position after the last reference base
-        const uint32_t *cg = rd->cig + rd->r_cig_off[r];
+        int32_t e = p;                                          // pos + bam_cigar2rlen: the raw end, not bam_endpos (which makes a read
+        const uint32_t *cg = rd->cig + rd->r_cig_off[r];        // without reference bases one long; bam_plp_push says so too)
         for (int k = 0; k < rd->r_ncig[r]; ++k) { const int op = cg[k] & 0xf; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) e += (int32_t)(cg[k] >> 4); }
-        if (e == p) e = p + 1;
         while (!S.ends.empty() && S.ends.front() < p) { std::pop_heap(S.ends.begin(), S.ends.end(), cmp); S.ends.pop_back(); }
         if (p == S.last_pos && (int64_t)S.ends.size() + 1 > max_depth) { keep[r] = 0; continue; }
         keep[r] = 1;
+        // linked into the buffer only when it ends past the iterator's position (= the start of the read kept last): a read
+        // without reference bases that is not the first of its start position is not (it never reaches a column either way)
+        if (e > S.last_pos) { S.ends.push_back(e); std::push_heap(S.ends.begin(), S.ends.end(), cmp); }
         S.last_pos = p;
-        S.ends.push_back(e); std::push_heap(S.ends.begin(), S.ends.end(), cmp);
     }
     return 0;
 }

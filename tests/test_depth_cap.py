@@ -25,7 +25,8 @@ def _replay(pos, end, smpl, n_smpl, maxcnt):
             if it_pos == pos[r] and len(buf) + 1 > maxcnt:
                 continue
             keep[r] = 1
-            buf.append(end[r])
+            if end[r] > it_pos:        # the tail node is linked only then (a read without reference bases: not always)
+                buf.append(end[r])
             max_pos = pos[r]
     return keep
 
@@ -40,6 +41,7 @@ def test_depth_cap_matches_iterator_replay(seed, n_smpl, n_reads, maxcnt):
         # pile-ups: many reads share start positions
         pos[m] = np.sort(rng.integers(0, 60, m.sum()) * rng.integers(1, 4)).astype(np.int32)
     lens = rng.integers(1, 120, n_reads)
+    lens[rng.random(n_reads) < 0.05] = 0                       # reads without a reference base (all clipped / inserted)
     dele = rng.integers(0, 30, n_reads) * (rng.random(n_reads) < 0.2)
     cig, coff = [], []
     for i in range(n_reads):
@@ -47,6 +49,8 @@ def test_depth_cap_matches_iterator_replay(seed, n_smpl, n_reads, maxcnt):
         a = int(lens[i])
         if dele[i] and a > 2:
             cig += [(a // 2) << 4 | 0, int(dele[i]) << 4 | 2, (a - a // 2) << 4 | 0]
+        elif a == 0:
+            cig += [7 << 4 | 4, 9 << 4 | 1]
         else:
             cig += [5 << 4 | 4, a << 4 | 0]
     cig = np.array(cig, np.uint32)
