@@ -174,6 +174,14 @@ PROTOTYPES = {
                                 C.POINTER(Tile), C.c_void_p, C.c_void_p]),
     "bcfgpu_pileup_packed": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.POINTER(Packed), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p,
                                        C.c_int32, C.POINTER(Tile), C.c_void_p, C.c_void_p]),
+    "bcfgpu_pool_upload": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.POINTER(Packed), C.c_void_p]),
+    "bcfgpu_pool_baq": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int, C.c_void_p]),
+    "bcfgpu_pool_cap_mapq": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "bcfgpu_pool_keep": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bcfgpu_pool_overlap_tweak": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "bcfgpu_pool_pileup": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(Tile),
+                                     C.c_void_p, C.c_void_p]),
+    "bcfgpu_pool_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bcfgpu_gvcf_blocks": (C.c_int, [C.c_void_p, C.POINTER(GvcfIn), C.POINTER(GvcfOut), C.POINTER(C.c_int32)]),
     "bcfgpu_gap_prep_stats": (C.c_int, [C.c_void_p, C.POINTER(GapStats)]),
     "bcfgpu_pipeline": (C.c_int, [C.c_void_p, C.POINTER(Tile), C.c_void_p, C.c_void_p,

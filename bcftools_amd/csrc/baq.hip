@@ -424,6 +424,67 @@ __global__ __launch_bounds__(64) void baq_kernel(const BaqParams P)
     baq_cap(P, j, iqual, state, q, qout, zout);
 }
 
+// ---- the same stage on the pool bcfgpu_pool_upload left in HBM: the host half above as a kernel ----
+// One lane per read: the window and band of realn.c; the read's job goes to the list of its band class (class 0 = the
+// register-row kernel's band, class 1 = wider), reads that BAQ leaves alone get ret = -1 and keep their qualities.
+struct BaqPrepParams {
+    DevPool D;
+    int ref_len;                     // bases of the contig (up to its terminating NUL)
+    BaqJob *jobs0, *jobs1;
+    int *counts;                     // [0],[1] jobs per class  [2] widest band of class 1  [3] longest query  [4] lowest xb  [5] highest xe
+    int32_t *ret; uint8_t *has_zq;
+};
+__global__ __launch_bounds__(256) void baq_prep_kernel(const BaqPrepParams P)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= P.D.n_reads) return;
+    const int l_qseq = P.D.r_lq[r], pos = P.D.r_pos[r], n_cigar = P.D.r_ncig[r];
+    const uint32_t soff = (uint32_t)P.D.r_seq_off[r], coff = (uint32_t)P.D.r_cig_off[r];
+    const uint32_t *cigar = P.D.cig + coff;
+    P.ret[r] = -1; P.has_zq[r] = 0;
+    if (l_qseq <= 0 || P.D.qual[soff] == 0xff || (P.D.r_flag[r] & 4)) return;
+    int x = pos, y = 0, yb = -1, ye = -1, xb = -1, xe = -1;
+    for (int k = 0; k < n_cigar; ++k) {
+        const int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
+        if (op == 0 || op == 7 || op == 8) {
+            if (yb < 0) yb = y;
+            if (xb < 0) xb = x;
+            ye = y + l; xe = x + l;
+            x += l; y += l;
+        } else if (op == 4 || op == 1) y += l;
+        else if (op == 2) x += l;
+        else if (op == 3) return;
+    }
+    if (xb == -1) return;
+    int bw = 7;
+    if (abs((xe - xb) - (ye - yb)) > bw) bw = abs((xe - xb) - (ye - yb)) + 3;
+    xb -= yb + bw / 2; if (xb < 0) xb = 0;
+    xe += l_qseq - ye + bw / 2;
+    if (xe - xb - l_qseq > bw) { xb += (xe - xb - l_qseq - bw) / 2; xe -= (xe - xb - l_qseq - bw) / 2; }
+    if (xe > P.ref_len) xe = P.ref_len;
+    if (xe < xb) xe = xb;
+    BaqJob j;
+    j.seq_off = soff; j.cig_off = coff; j.l_query = l_qseq; j.n_cigar = n_cigar; j.pos = pos;
+    j.l_ref = xe - xb; j.bw = bw; j.xb = xb; j.ret = 0; j.ref_off = (uint32_t)xb;          // (made relative to the slice by the launch: P.tref - lowest xb)
+    P.ret[r] = 0; P.has_zq[r] = 1;
+    int b = j.l_ref > j.l_query ? j.l_ref : j.l_query;
+    if (b > j.bw) b = j.bw;
+    if (b < abs(j.l_ref - j.l_query)) b = abs(j.l_ref - j.l_query);
+    const int c = b <= BAQ_BWM ? 0 : 1;
+    const int at = atomicAdd(&P.counts[c], 1);
+    (c ? P.jobs1 : P.jobs0)[at] = j;
+    if (c) atomicMax(&P.counts[2], b);
+    atomicMax(&P.counts[3], l_qseq);
+    if (j.l_ref > 0) { atomicMin(&P.counts[4], xb); atomicMax(&P.counts[5], xe); }
+}
+__global__ __launch_bounds__(256) void baq_ref4_kernel(const char *ref, size_t n, uint8_t *out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const char c = ref[i];
+    out[i] = (c == 'A' || c == 'a') ? 0 : (c == 'C' || c == 'c') ? 1 : (c == 'G' || c == 'g') ? 2 : (c == 'T' || c == 't') ? 3 : 4;
+}
+
 }  // namespace bcfgpu
 
 using namespace bcfgpu;
@@ -562,3 +623,87 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
     BQ_CHK(hipStreamSynchronize(stream));
     return BCFGPU_OK;
 }
+
+extern "C" void *bcfgpu_internal_pool_state(bcfgpu_ctx *ctx);
+
+// sam_prob_realn on every read of the pool in HBM: the pool's qualities become the new ones, the ZQ bytes stay there for
+// bcfgpu_gap_prep_tile.  The host part: the contig's length, one wait for the job counts (they size the scratch and the
+// reference slice to upload), launches.
+extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len, int flag, int32_t *ret)
+{
+    if (!ctx || !ref || ref_len < 0) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_baq: bad arguments");
+    hipStream_t stream = nullptr;
+    const float *d_q2p = nullptr;
+    if (bcfgpu_internal_device(ctx, &stream, &d_q2p)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_baq: bad context");
+    DevPool &D = *static_cast<DevPool*>(bcfgpu_internal_pool_state(ctx));
+    if (!D.valid) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_baq: no read pool on this context (bcfgpu_pool_upload)");
+    const int n = D.n_reads;
+    if (n == 0) return BCFGPU_OK;
+    auto cleanup = [&]() {};
+    const size_t nbase = D.n_bases;
+    BaqPrepParams Q{};
+    Q.D = D; Q.ref_len = (int)strnlen(ref, (size_t)ref_len);
+    Q.jobs0 = (BaqJob*)bcfgpu_internal_ws(ctx, 0, (size_t)n * sizeof(BaqJob) + 64);
+    Q.jobs1 = (BaqJob*)bcfgpu_internal_ws(ctx, 3, (size_t)n * sizeof(BaqJob) + 64);
+    Q.counts = (int*)bcfgpu_internal_ws(ctx, 115, 64);
+    Q.ret = (int32_t*)bcfgpu_internal_ws(ctx, 116, (size_t)n * 4 + 64);
+    Q.has_zq = (uint8_t*)bcfgpu_internal_ws(ctx, 117, (size_t)n + 64);
+    uint8_t *d_qo = (uint8_t*)bcfgpu_internal_ws(ctx, D.qual == bcfgpu_internal_ws(ctx, 118, nbase + 64) ? 119 : 118, nbase + 64);   // not the buffer the pool's qualities are in now
+    uint8_t *d_zo = (uint8_t*)bcfgpu_internal_ws(ctx, 120, nbase + 64);
+    void *d_state = bcfgpu_internal_ws(ctx, 11, (nbase + 4) * 4), *d_q = bcfgpu_internal_ws(ctx, 12, nbase + 16), *d_tmp = bcfgpu_internal_ws(ctx, 13, 2 * nbase + 16);
+    if (!Q.jobs0 || !Q.jobs1 || !Q.counts || !Q.ret || !Q.has_zq || !d_qo || !d_zo || !d_state || !d_q || !d_tmp)
+        return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_baq: device workspace");
+    const int init[6] = {0, 0, 1, 1, INT32_MAX, 0};
+    int counts[6];
+    BQ_CHK(hipMemcpyAsync(Q.counts, init, sizeof init, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(baq_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, Q);
+    BQ_CHK(hipMemcpyAsync(counts, Q.counts, sizeof counts, hipMemcpyDeviceToHost, stream));
+    BQ_CHK(hipMemcpyAsync(d_qo, D.qual, nbase, hipMemcpyDeviceToDevice, stream));     // reads without a job keep their qualities
+    BQ_CHK(hipMemsetAsync(d_zo, 0, nbase, stream));
+    BQ_CHK(hipStreamSynchronize(stream));
+    // the reference slice the windows touch, as 0..4 codes
+    const int lo = counts[4] == INT32_MAX ? 0 : counts[4], hi = std::max(counts[5], lo);
+    char *d_refc = (char*)bcfgpu_internal_ws(ctx, 121, (size_t)(hi - lo) + 64);
+    uint8_t *d_ref4 = (uint8_t*)bcfgpu_internal_ws(ctx, 7, (size_t)(hi - lo) + 64);
+    if (!d_refc || !d_ref4) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_baq: device workspace");
+    if (hi > lo) {
+        BQ_CHK(hipMemcpyAsync(d_refc, ref + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(baq_ref4_kernel, dim3((unsigned)(((size_t)(hi - lo) + 255) / 256)), dim3(256), 0, stream, d_refc, (size_t)(hi - lo), d_ref4);
+    }
+    BaqParams P{};
+    P.flag = flag; P.max_lq = counts[3];
+    P.tref = d_ref4 - lo;                      // (jobs carry absolute window starts)
+    P.seq16 = D.seq16; P.qual = D.qual; P.cig = D.cig;
+    P.q2p = d_q2p; P.state = (int32_t*)d_state; P.q = (uint8_t*)d_q; P.tmp = (uint8_t*)d_tmp;
+    P.qual_out = d_qo; P.zq_out = d_zo;
+    for (int c = 0; c < 2; ++c) {
+        const size_t nj = (size_t)counts[c];
+        if (!nj) continue;
+        const bool reg = c == 0;
+        P.ncell = reg ? 3 * (2 * BAQ_BWM + 3) : 3 * (2 * counts[2] + 1) + 6;       // doubles per matrix row
+        const size_t per_mat = (size_t)(P.max_lq + 1) * P.ncell * sizeof(double);  // one matrix of one read
+        const size_t per_job = reg ? per_mat : 2 * per_mat;
+        size_t chunk = ((size_t)8 << 30) / per_job;                                // (8 GiB of scratch: 288 GB of HBM are there to be used)
+        chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
+        if (chunk > nj) chunk = (nj + 63) & ~(size_t)63;
+        P.stride = chunk;
+        void *d_F = bcfgpu_internal_ws(ctx, 4, per_mat * chunk), *d_B = reg ? nullptr : bcfgpu_internal_ws(ctx, 1, per_mat * chunk);
+        void *d_S = bcfgpu_internal_ws(ctx, 2, (size_t)(P.max_lq + 2) * chunk * sizeof(double));
+        if (!d_F || (!reg && !d_B) || !d_S) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_baq: device workspace");
+        P.F = (double*)d_F; P.B = (double*)d_B; P.S = (double*)d_S;
+        for (size_t j0 = 0; j0 < nj; j0 += chunk) {
+            P.n_jobs = (int)(nj - j0 < chunk ? nj - j0 : chunk);
+            P.jobs = (c ? Q.jobs1 : Q.jobs0) + j0;
+            if (reg) hipLaunchKernelGGL(baq_kernel<true>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
+            else     hipLaunchKernelGGL(baq_kernel<false>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
+        }
+        BQ_CHK(hipGetLastError());
+    }
+    if (ret) {
+        BQ_CHK(hipMemcpyAsync(ret, Q.ret, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        BQ_CHK(hipStreamSynchronize(stream));
+    }
+    D.qual = d_qo; D.zq = d_zo; D.r_has_zq = Q.has_zq;
+    return BCFGPU_OK;
+}
+

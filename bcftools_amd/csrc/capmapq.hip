@@ -95,6 +95,52 @@ __global__ __launch_bounds__(256) void cap_mapq_kernel(const CapParams P)
 
 using namespace bcfgpu;
 
+namespace bcfgpu {
+// mpileup.c:238: a read whose mapping quality is above its cap is lowered to it
+__global__ __launch_bounds__(256) void cap_apply_kernel(int n, const int32_t *cap, uint8_t *mapq)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < n && cap[r] >= 0 && (int)mapq[r] > cap[r]) mapq[r] = (uint8_t)cap[r];
+}
+}
+
+extern "C" void *bcfgpu_internal_pool_state(bcfgpu_ctx *ctx);
+int bcfgpu_internal_pool_extent(bcfgpu_ctx *ctx, int *lo, int *hi);
+
+// The same on the pool in HBM (after bcfgpu_pool_baq): the caps come back for the caller's filters (cap < 0: the read is
+// dropped, mpileup.c:237), the pool's mapping qualities are lowered in place.
+extern "C" int bcfgpu_pool_cap_mapq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len, int32_t thres, int32_t *cap)
+{
+    if (!ctx || !cap || (ref_len > 0 && !ref)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_cap_mapq: bad arguments");
+    hipStream_t st = nullptr;
+    if (bcfgpu_internal_device(ctx, &st, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_cap_mapq: bad context");
+    const DevPool &D = *static_cast<const DevPool*>(bcfgpu_internal_pool_state(ctx));
+    if (!D.valid) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_cap_mapq: no read pool on this context (bcfgpu_pool_upload)");
+    const int n = D.n_reads;
+    if (!n) return BCFGPU_OK;
+    int lo = 0, hi = 0;
+    if (bcfgpu_internal_pool_extent(ctx, &lo, &hi)) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_cap_mapq: pool extent");
+    if (lo < 0) lo = 0;
+    if (hi > ref_len) hi = ref_len;
+    if (hi < lo) hi = lo;
+    CapParams P{};
+    P.n_reads = n; P.thres = thres;
+    P.r_pos = D.r_pos; P.r_lq = D.r_lq; P.r_ncig = D.r_ncig; P.r_cig_off = D.r_cig_off; P.r_seq_off = D.r_seq_off;
+    P.cig = D.cig; P.seq16 = D.seq16; P.qual = D.qual;
+    char *d_ref = (char*)bcfgpu_internal_ws(ctx, 125, (size_t)(hi - lo) + 64);
+    P.out = (int32_t*)bcfgpu_internal_ws(ctx, 126, (size_t)n * 4 + 64);
+    if (!d_ref || !P.out) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_cap_mapq: device workspace");
+    if (hi > lo && hipMemcpyAsync(d_ref, ref + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, st) != hipSuccess)
+        return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_cap_mapq: upload");
+    P.ref = d_ref; P.ref_lo = lo; P.ref_hi = hi;
+    hipLaunchKernelGGL(cap_mapq_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(cap_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, (const int32_t*)P.out, D.r_mapq);
+    if (hipGetLastError() != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_cap_mapq: launch");
+    if (hipMemcpyAsync(cap, P.out, (size_t)n * 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_cap_mapq: download");
+    return BCFGPU_OK;
+}
+
 extern "C" int bcfgpu_cap_mapq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *ref, int32_t ref_len, int32_t thres, int32_t *cap)
 {
     if (!ctx || !rd || !cap || rd->n_reads < 0 || (ref_len > 0 && !ref)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_cap_mapq: bad arguments");

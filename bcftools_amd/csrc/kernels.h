@@ -112,6 +112,22 @@ struct McallParams {
     BCFGPU_ABL_FIELD
 };
 
+// ---- the read pool of a region kept in HBM (bcfgpu_pool_upload; pileup.hip, baq.hip, overlap.hip, capmapq.hip) ----
+// The caller's per-read arrays as they were handed over, the pools one byte per base; the stages replace `qual` / `r_mapq`
+// in place or swing the pointer to a buffer of their own.
+struct DevPool {
+    int valid, n_reads;
+    uint32_t n_bases, n_cig;
+    const int32_t *r_pos, *r_lq, *r_flag, *r_ncig, *r_cig_off, *r_seq_off;
+    uint8_t *r_mapq;
+    const uint32_t *cig;
+    const uint8_t *seq16;
+    uint8_t *qual;
+    uint8_t *zq, *r_has_zq;          // the "ZQ" bytes bcfgpu_pool_baq left and which reads have them; NULL before
+    uint8_t *keep;                   // [n_reads] 0 = the read does not enter the pileup (bcfgpu_pool_keep); NULL = all do
+    int ext_valid, ext_lo, ext_hi;   // [lowest start, highest end) of the reads on the reference, once something asked for it
+};
+
 // ---- bcf_call_gap_prep on the device (gap_prep.hip, indel.hip) ----
 // the caller's arrays in HBM (bcfgpu_reads, bcfgpu_indel_in) and the slice [ref_lo, ref_hi) of the contig the batch touches
 struct GapIn {

@@ -126,3 +126,40 @@ extern "C" int bcfgpu_overlap_tweak(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, int
     #undef OV_CHK
     return BCFGPU_OK;
 }
+
+extern "C" void *bcfgpu_internal_pool_state(bcfgpu_ctx *ctx);
+
+// The same tweak on the pool bcfgpu_pool_upload left in HBM (after bcfgpu_pool_baq): the pairs go up, nothing comes back.
+extern "C" int bcfgpu_pool_overlap_tweak(bcfgpu_ctx *ctx, int32_t n_pairs, const int32_t *pair_a, const int32_t *pair_b)
+{
+    if (!ctx || n_pairs < 0 || (n_pairs && (!pair_a || !pair_b))) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_overlap_tweak: bad arguments");
+    hipStream_t stream = nullptr;
+    if (bcfgpu_internal_device(ctx, &stream, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_overlap_tweak: bad context");
+    const DevPool &D = *static_cast<const DevPool*>(bcfgpu_internal_pool_state(ctx));
+    if (!D.valid) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_overlap_tweak: no read pool on this context (bcfgpu_pool_upload)");
+    const int n = D.n_reads;
+    {   // every read may be in one pair only (a second pair would race with the first on the read's qualities)
+        std::vector<uint8_t> seen((size_t)n, 0);
+        for (int p = 0; p < n_pairs; ++p) {
+            const int a = pair_a[p], b = pair_b[p];
+            if (a < 0 || a >= n || b < 0 || b >= n || a == b || seen[a] || seen[b])
+                return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_overlap_tweak: a read index is out of range or used twice");
+            seen[a] = seen[b] = 1;
+        }
+    }
+    if (n_pairs == 0 || D.n_bases == 0) return BCFGPU_OK;
+    void *d_pa = bcfgpu_internal_ws(ctx, 123, (size_t)n_pairs * 4 + 64), *d_pb = bcfgpu_internal_ws(ctx, 124, (size_t)n_pairs * 4 + 64);
+    if (!d_pa || !d_pb) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_overlap_tweak: device workspace");
+    if (hipMemcpyAsync(d_pa, pair_a, (size_t)n_pairs * 4, hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(d_pb, pair_b, (size_t)n_pairs * 4, hipMemcpyHostToDevice, stream) != hipSuccess)
+        return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_overlap_tweak: upload");
+    OverlapParams P{};
+    P.n_pairs = n_pairs; P.pair_a = (const int32_t*)d_pa; P.pair_b = (const int32_t*)d_pb;
+    P.r_pos = D.r_pos; P.r_ncig = D.r_ncig; P.r_cig_off = D.r_cig_off; P.r_seq_off = D.r_seq_off;
+    P.cig = D.cig; P.seq16 = D.seq16; P.qual = D.qual;
+    hipLaunchKernelGGL(overlap_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, stream, P);
+    if (hipGetLastError() != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_overlap_tweak: launch");
+    if (hipStreamSynchronize(stream) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_overlap_tweak");      // (the pair arrays are the caller's)
+    return BCFGPU_OK;
+}
+

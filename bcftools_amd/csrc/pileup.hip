@@ -363,6 +363,7 @@ struct MetaParams {
     int n, n_smpl;
     const int32_t *r_pos, *r_lq, *r_flag, *r_ncig, *r_cig_off, *r_seq_off;
     const uint8_t *r_mapq;
+    const uint8_t *keep;            // NULL, or [n] by pool index: 0 = the read does not enter the pileup
     const int32_t *s_read;          // pool index of sorted read k, or NULL: the pool is in that order already
     const int32_t *smpl_off;
     const uint32_t *cig;
@@ -386,8 +387,9 @@ __global__ __launch_bounds__(256) void pileup_meta_kernel(const MetaParams M)
             else if (op == 4) scl = 1;
         }
         if (lq > 65535 || lq < 0 || ntot > 65535 || ncig > 255 || ncig < 0) bad = 1;
+        const bool out = M.keep && !M.keep[r];                      // dropped by the caller's filters: covers no column
         ReadMeta m;
-        m.pos = pos; m.end = bad ? pos : x; m.seq_off = (uint32_t)M.r_seq_off[r]; m.cig_off = coff;
+        m.pos = pos; m.end = (bad || out) ? pos : x; m.seq_off = (uint32_t)M.r_seq_off[r]; m.cig_off = coff;
         m.lq = (uint16_t)lq; m.ntot = (uint16_t)ntot; m.ncig = (uint8_t)ncig;
         m.bits = (uint8_t)(((flag & 16) ? 1 : 0) | (scl ? 2 : 0) | ((flag & 4) ? 4 : 0));
         m.mapq = M.r_mapq[r]; m.pad = 0; m.cig0 = ncig > 0 ? cg[0] : 0; m.pad2 = 0;
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256) void pileup_meta_kernel(const MetaParams M)
         const uint4 *mi = reinterpret_cast<const uint4*>(&m);
         o[0] = mi[0]; o[1] = mi[1];
         M.s_pos[k] = pos;
-        if (!bad) span = x - pos;
+        if (!bad && !out) span = x - pos;
         if (k > 0) {
             const int rp = M.s_read ? M.s_read[k - 1] : k - 1;
             if (pos < M.r_pos[rp]) {                                     // fine only across a sample boundary
@@ -410,6 +412,23 @@ __global__ __launch_bounds__(256) void pileup_meta_kernel(const MetaParams M)
         if (span > 1) atomicMax(&M.status[0], span);
         if (bad) atomicOr(&M.status[1], bad);
     }
+}
+
+// [lowest start, highest end) of the pool's reads on the reference
+__global__ __launch_bounds__(256) void pool_extent_kernel(const DevPool D, int *out)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    int lo = INT32_MAX, hi = 0;
+    if (r < D.n_reads) {
+        int x = D.r_pos[r];
+        lo = x;
+        const uint32_t *cg = D.cig + D.r_cig_off[r];
+        for (int k = 0; k < D.r_ncig[r]; ++k) { const int op = cg[k] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) x += (int)(cg[k] >> 4); }
+        hi = x;
+    }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+    if ((threadIdx.x & 63) == 0 && lo != INT32_MAX) { atomicMin(&out[0], lo); atomicMax(&out[1], hi); }
 }
 
 // The pool as BAM records hold it (two 4-bit base codes per byte, high nibble first) and qualities as palette indices, to the
@@ -467,36 +486,114 @@ static int ref_nt16(char c)
     return 15;
 }
 
-// bcfgpu_pileup and bcfgpu_pileup_packed: the host part is argument checks, the read -> sample bookkeeping (one pass over
-// r_smpl, none when the caller hands over smpl_off), uploads of the caller's arrays as they are, and launches.
-static int pileup_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bcfgpu_packed *pk, const uint8_t *r_mapq,
-                       const int32_t *r_smpl, int32_t beg, int32_t end, const char *ref, int32_t ref_len,
-                       bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel)
+// ---- the read pool in HBM, and the tile built from it ----------------------------------------------------------------
+// bcfgpu_pileup / bcfgpu_pileup_packed = pool_upload + pool_pileup.  The host part is argument checks, the read -> sample
+// bookkeeping (one pass over r_smpl, none when the caller hands over smpl_off), uploads of the caller's arrays as they are,
+// and launches.
+extern "C" void *bcfgpu_internal_pool_state(bcfgpu_ctx *ctx);
+
+static int host_threads(int n)
+{
+    int nthr = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("BCFGPU_HOST_THREADS")) nthr = atoi(e);
+    return std::max(1, std::min(std::min(nthr, 16), n / 262144 + 1));
+}
+template <class F> static void on_threads(int nthr, F &&fn)
+{
+    std::vector<std::thread> thr;
+    for (int t = 1; t < nthr; ++t) thr.emplace_back(fn, t);
+    fn(0);
+    for (auto &th : thr) th.join();
+}
+
+static int pool_upload_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bcfgpu_packed *pk, const uint8_t *r_mapq)
 {
     auto fail = [&](int code, const char *what) { char msg[160]; snprintf(msg, sizeof msg, "%s: %s", who, what); return bcfgpu_set_error(code, msg); };
-    const int32_t *given_off = pk ? pk->smpl_off : nullptr;
-    if (!ctx || !rd || !tile || end < beg || rd->n_reads < 0 || (rd->n_reads && (!r_mapq || (!r_smpl && !given_off))) || (ref_len > 0 && !ref))
-        return fail(BCFGPU_E_ARG, "bad arguments");
+    if (!ctx || !rd || rd->n_reads < 0 || (rd->n_reads && !r_mapq)) return fail(BCFGPU_E_ARG, "bad arguments");
     if (pk && (!pk->seq4 || pk->n_bases < 0 || pk->n_cig < 0 || (pk->n_bases >> 32))) return fail(BCFGPU_E_ARG, "bad packed pool");
     hipStream_t stream = nullptr;
     if (bcfgpu_internal_device(ctx, &stream, nullptr)) return fail(BCFGPU_E_ARG, "bad context");
+    DevPool &D = *static_cast<DevPool*>(bcfgpu_internal_pool_state(ctx));
+    static_assert(sizeof(DevPool) <= 256, "fits the context's pool_state");
+    D = DevPool{};
+    const int n = rd->n_reads;
+    // the extent of the pools (the packed form states it)
+    size_t nbase = 0, ncig = 0;
+    if (pk) { nbase = (size_t)pk->n_bases; ncig = (size_t)pk->n_cig; }
+    else {
+        const int nthr = host_threads(n);
+        std::vector<size_t> t_nbase(nthr, 0), t_ncig(nthr, 0);
+        on_threads(nthr, [&](int t) {
+            const int k0 = (int)((long)n * t / nthr), k1 = (int)((long)n * (t + 1) / nthr);
+            size_t nb = 0, nc = 0;
+            for (int r = k0; r < k1; ++r) {
+                const size_t e = (size_t)rd->r_seq_off[r] + (size_t)std::max(rd->r_lq[r], 0), c = (size_t)rd->r_cig_off[r] + (size_t)std::max(rd->r_ncig[r], 0);
+                if (e > nb) nb = e;
+                if (c > nc) nc = c;
+            }
+            t_nbase[t] = nb; t_ncig[t] = nc;
+        });
+        for (int t = 0; t < nthr; ++t) { nbase = std::max(nbase, t_nbase[t]); ncig = std::max(ncig, t_ncig[t]); }
+        if (nbase >> 32) return fail(BCFGPU_E_RANGE, "the pool holds 2^32 or more bases");
+    }
+    auto up = [&](int slot, const void *src, size_t bytes) -> void* {
+        void *d = bcfgpu_internal_ws(ctx, slot, bytes + 64);
+        if (d && bytes && hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
+        return d;
+    };
+    D.n_reads = n; D.n_bases = (uint32_t)nbase; D.n_cig = (uint32_t)ncig;
+    D.r_pos = (const int32_t*)up(104, rd->r_pos, (size_t)n * 4);
+    D.r_lq = (const int32_t*)up(105, rd->r_lq, (size_t)n * 4);
+    D.r_flag = (const int32_t*)up(106, rd->r_flag, (size_t)n * 4);
+    D.r_ncig = (const int32_t*)up(107, rd->r_ncig, (size_t)n * 4);
+    D.r_cig_off = (const int32_t*)up(108, rd->r_cig_off, (size_t)n * 4);
+    D.r_seq_off = (const int32_t*)up(109, rd->r_seq_off, (size_t)n * 4);
+    D.r_mapq = (uint8_t*)up(110, r_mapq, (size_t)n);
+    D.cig = (const uint32_t*)up(27, rd->cig, ncig * 4);
+    uint8_t *d_seq16 = nullptr, *d_qual = nullptr;
+    if (pk) {
+        const size_t n_in = (nbase + 1) / 2;
+        d_seq16 = (uint8_t*)bcfgpu_internal_ws(ctx, 28, nbase + 64);
+        const uint8_t *d_seq4 = (const uint8_t*)up(111, pk->seq4, n_in), *d_qual4 = nullptr;
+        if (pk->qual4) { d_qual = (uint8_t*)bcfgpu_internal_ws(ctx, 29, nbase + 64); d_qual4 = (const uint8_t*)up(112, pk->qual4, n_in); }
+        else d_qual = (uint8_t*)up(29, rd->qual, nbase);
+        if (!d_seq4 || (pk->qual4 && !d_qual4) || !d_seq16 || !d_qual) return fail(BCFGPU_E_NOMEM, "device workspace");
+        unsigned long long pal[2] = {0, 0};
+        std::memcpy(pal, pk->palette, 16);
+        const size_t nthreads = (n_in + 3) / 4;
+        if (nthreads) hipLaunchKernelGGL(pileup_unpack_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream,
+                                         d_seq4, d_qual4, pal[0], pal[1], n_in, d_seq16, d_qual);
+    } else {
+        d_seq16 = (uint8_t*)up(28, rd->seq16, nbase);
+        d_qual = (uint8_t*)up(29, rd->qual, nbase);
+    }
+    D.seq16 = d_seq16; D.qual = d_qual;
+    if (!D.r_pos || !D.r_lq || !D.r_flag || !D.r_ncig || !D.r_cig_off || !D.r_seq_off || !D.r_mapq || !D.cig || !D.seq16 || !D.qual)
+        return fail(BCFGPU_E_NOMEM, "device workspace");
+    if (hipGetLastError() != hipSuccess) return fail(BCFGPU_E_HIP, "launch");
+    D.valid = 1;
+    return BCFGPU_OK;
+}
+
+static int pool_pileup_impl(const char *who, bcfgpu_ctx *ctx, const int32_t *r_smpl, const int32_t *given_off, int32_t beg, int32_t end,
+                            const char *ref, int32_t ref_len, bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel)
+{
+    auto fail = [&](int code, const char *what) { char msg[160]; snprintf(msg, sizeof msg, "%s: %s", who, what); return bcfgpu_set_error(code, msg); };
+    if (!ctx || !tile || end < beg || (ref_len > 0 && !ref)) return fail(BCFGPU_E_ARG, "bad arguments");
+    hipStream_t stream = nullptr;
+    if (bcfgpu_internal_device(ctx, &stream, nullptr)) return fail(BCFGPU_E_ARG, "bad context");
+    const DevPool &D = *static_cast<const DevPool*>(bcfgpu_internal_pool_state(ctx));
+    if (!D.valid) return fail(BCFGPU_E_ARG, "no read pool on this context (bcfgpu_pool_upload)");
+    if (D.n_reads && !r_smpl && !given_off) return fail(BCFGPU_E_ARG, "bad arguments");
     const bcfgpu_cfg *cfg = bcfgpu_internal_cfg(ctx);
-    const int n = rd->n_reads, n_sites = end - beg, S = cfg->n_smpl;
+    const int n = D.n_reads, n_sites = end - beg, S = cfg->n_smpl;
     const bool trace = getenv("BCFGPU_TRACE") != nullptr;          // diagnostics: host timeline on stderr
     const auto t_begin = std::chrono::steady_clock::now();
     auto ms_now = [&]() { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     const size_t ncells = (size_t)n_sites * S;
     std::memset(tile, 0, sizeof *tile);
     if (ncells >> 31) return fail(BCFGPU_E_RANGE, "region x samples too large for one tile");
-    int nthr = (int)std::thread::hardware_concurrency();
-    if (const char *e = getenv("BCFGPU_HOST_THREADS")) nthr = atoi(e);
-    nthr = std::max(1, std::min(std::min(nthr, 16), n / 262144 + 1));
-    auto on_threads = [&](auto &&fn) {
-        std::vector<std::thread> thr;
-        for (int t = 1; t < nthr; ++t) thr.emplace_back(fn, t);
-        fn(0);
-        for (auto &th : thr) th.join();
-    };
+    const int nthr = host_threads(n);
     // ---- host: which reads belong to which sample (usually they come grouped: one file per sample) ----
     std::vector<int32_t> smpl_off(S + 1, 0);
     bool grouped = true;
@@ -507,7 +604,7 @@ static int pileup_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads *rd,
     } else {
         std::vector<std::vector<int32_t>> t_cnt(nthr);
         std::vector<int> t_flag(nthr, 0);
-        on_threads([&](int t) {
+        on_threads(nthr, [&](int t) {
             const int k0 = (int)((long)n * t / nthr), k1 = (int)((long)n * (t + 1) / nthr);
             std::vector<int32_t> &c = t_cnt[t];
             c.assign(S, 0);
@@ -549,24 +646,6 @@ static int pileup_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads *rd,
         std::vector<int32_t> cur(smpl_off.begin(), smpl_off.end() - 1);
         for (int r = 0; r < n; ++r) s_read[cur[r_smpl[r]]++] = r;
     }
-    // the extent of the pools (the packed form states it)
-    size_t nbase = 0, ncig = 0;
-    if (pk) { nbase = (size_t)pk->n_bases; ncig = (size_t)pk->n_cig; }
-    else {
-        std::vector<size_t> t_nbase(nthr, 0), t_ncig(nthr, 0);
-        on_threads([&](int t) {
-            const int k0 = (int)((long)n * t / nthr), k1 = (int)((long)n * (t + 1) / nthr);
-            size_t nb = 0, nc = 0;
-            for (int r = k0; r < k1; ++r) {
-                const size_t e = (size_t)rd->r_seq_off[r] + (size_t)std::max(rd->r_lq[r], 0), c = (size_t)rd->r_cig_off[r] + (size_t)std::max(rd->r_ncig[r], 0);
-                if (e > nb) nb = e;
-                if (c > nc) nc = c;
-            }
-            t_nbase[t] = nb; t_ncig[t] = nc;
-        });
-        for (int t = 0; t < nthr; ++t) { nbase = std::max(nbase, t_nbase[t]); ncig = std::max(ncig, t_ncig[t]); }
-        if (nbase >> 32) return fail(BCFGPU_E_RANGE, "the pool holds 2^32 or more bases");
-    }
     std::vector<int8_t> ref16(n_sites);
     for (int k = 0; k < n_sites; ++k) ref16[k] = (int8_t)(beg + k < ref_len ? ref_nt16(ref[beg + k]) : 15);
 
@@ -579,55 +658,26 @@ static int pileup_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads *rd,
         return d;
     };
     PileupParams P{};
-    P.n_sites = n_sites; P.n_smpl = S; P.beg = beg; P.max_span = 1; P.n_reads = n; P.n_bases = (uint32_t)nbase;
+    P.n_sites = n_sites; P.n_smpl = S; P.beg = beg; P.max_span = 1; P.n_reads = n; P.n_bases = D.n_bases;
     P.want_epos = (cfg->fmt_flag & (BCFGPU_INFO_RPB | BCFGPU_INFO_VDB)) ? 1 : 0;
     void *d_ref16 = up(16, ref16.data(), (size_t)n_sites);
     P.smpl_off = (const int32_t*)up(17, smpl_off.data(), (size_t)(S + 1) * 4);
     MetaParams M{};
     M.n = n; M.n_smpl = S; M.smpl_off = P.smpl_off;
-    M.r_pos = (const int32_t*)up(104, rd->r_pos, (size_t)n * 4);
-    M.r_lq = (const int32_t*)up(105, rd->r_lq, (size_t)n * 4);
-    M.r_flag = (const int32_t*)up(106, rd->r_flag, (size_t)n * 4);
-    M.r_ncig = (const int32_t*)up(107, rd->r_ncig, (size_t)n * 4);
-    M.r_cig_off = (const int32_t*)up(108, rd->r_cig_off, (size_t)n * 4);
-    M.r_seq_off = (const int32_t*)up(109, rd->r_seq_off, (size_t)n * 4);
-    M.r_mapq = (const uint8_t*)up(110, r_mapq, (size_t)n);
+    M.r_pos = D.r_pos; M.r_lq = D.r_lq; M.r_flag = D.r_flag; M.r_ncig = D.r_ncig; M.r_cig_off = D.r_cig_off; M.r_seq_off = D.r_seq_off;
+    M.r_mapq = D.r_mapq; M.keep = D.keep; M.cig = D.cig;
     M.s_read = s_read ? (const int32_t*)up(20, s_read, (size_t)n * 4) : nullptr;
-    P.cig = (const uint32_t*)up(27, rd->cig, ncig * 4);
-    M.cig = P.cig;
     M.meta = (ReadMeta*)bcfgpu_internal_ws(ctx, 19, (size_t)n * sizeof(ReadMeta) + 64);
     M.s_pos = (int32_t*)bcfgpu_internal_ws(ctx, 18, (size_t)n * 4 + 64);
     M.status = (int*)bcfgpu_internal_ws(ctx, 113, 64);
-    uint8_t *d_seq16 = nullptr, *d_qual = nullptr;
-    const uint8_t *d_seq4 = nullptr, *d_qual4 = nullptr;
-    if (pk) {
-        const size_t n_in = (nbase + 1) / 2;
-        d_seq16 = (uint8_t*)bcfgpu_internal_ws(ctx, 28, nbase + 64);
-        d_seq4 = (const uint8_t*)up(111, pk->seq4, n_in);
-        if (pk->qual4) { d_qual = (uint8_t*)bcfgpu_internal_ws(ctx, 29, nbase + 64); d_qual4 = (const uint8_t*)up(112, pk->qual4, n_in); }
-        else d_qual = (uint8_t*)up(29, rd->qual, nbase);
-        if (!d_seq4 || (pk->qual4 && !d_qual4)) return fail(BCFGPU_E_NOMEM, "device workspace");
-    } else {
-        d_seq16 = (uint8_t*)up(28, rd->seq16, nbase);
-        d_qual = (uint8_t*)up(29, rd->qual, nbase);
-    }
-    P.seq16 = d_seq16; P.qual = d_qual; P.s_read = M.s_read; P.meta = M.meta; P.s_pos = M.s_pos; P.d_span = M.status;
+    P.cig = D.cig; P.seq16 = D.seq16; P.qual = D.qual; P.s_read = M.s_read; P.meta = M.meta; P.s_pos = M.s_pos; P.d_span = M.status;
     uint32_t *d_cnt = (uint32_t*)bcfgpu_internal_ws(ctx, 30, (ncells + 1) * 4 + (size_t)n_sites * 4 + 64);
-    if (!d_ref16 || !P.smpl_off || !M.r_pos || !M.r_lq || !M.r_flag || !M.r_ncig || !M.r_cig_off || !M.r_seq_off || !M.r_mapq || (s_read && !M.s_read)
-            || !P.cig || !M.meta || !M.s_pos || !M.status || !P.seq16 || !P.qual || !d_cnt)
-        return fail(BCFGPU_E_NOMEM, "device workspace");
+    if (!d_ref16 || !P.smpl_off || (s_read && !M.s_read) || !M.meta || !M.s_pos || !M.status || !d_cnt) return fail(BCFGPU_E_NOMEM, "device workspace");
     P.cnt = d_cnt;
     P.col_indel = d_cnt + ncells + 1;
     PL_CHK(hipMemsetAsync(d_cnt, 0, (ncells + 1) * 4 + (size_t)n_sites * 4, stream));
     const int init_status[2] = {1, 0};
     PL_CHK(hipMemcpyAsync(M.status, init_status, 8, hipMemcpyHostToDevice, stream));
-    if (pk) {
-        unsigned long long pal[2] = {0, 0};
-        std::memcpy(pal, pk->palette, 16);
-        const size_t n_in = (nbase + 1) / 2, nthreads = (n_in + 3) / 4;
-        if (nthreads) hipLaunchKernelGGL(pileup_unpack_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream,
-                                         d_seq4, d_qual4, pal[0], pal[1], n_in, d_seq16, d_qual);
-    }
     if (n) hipLaunchKernelGGL(pileup_meta_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, M);
     const int n_work = ((n_sites + PT_COLS - 1) / PT_COLS) * ((S + PT_SMPL - 1) / PT_SMPL);
     const int grid = (n_work + 7) / 8 * 8;           // (a multiple of the XCD count: see the kernel's work mapping)
@@ -697,15 +747,83 @@ extern "C" int bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const uint
                              int32_t beg, int32_t end, const char *ref, int32_t ref_len,
                              bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel)
 {
-    return pileup_impl("bcfgpu_pileup", ctx, rd, nullptr, r_mapq, r_smpl, beg, end, ref, ref_len, tile, col_n, col_indel);
+    if (!rd || !tile || (rd->n_reads > 0 && !r_smpl)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup: bad arguments");
+    const int rc = pool_upload_impl("bcfgpu_pileup", ctx, rd, nullptr, r_mapq);
+    return rc ? rc : pool_pileup_impl("bcfgpu_pileup", ctx, r_smpl, nullptr, beg, end, ref, ref_len, tile, col_n, col_indel);
 }
 
 extern "C" int bcfgpu_pileup_packed(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bcfgpu_packed *pk, const uint8_t *r_mapq,
                                     const int32_t *r_smpl, int32_t beg, int32_t end, const char *ref, int32_t ref_len,
                                     bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel)
 {
-    if (!pk) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup_packed: bad arguments");
-    return pileup_impl("bcfgpu_pileup_packed", ctx, rd, pk, r_mapq, r_smpl, beg, end, ref, ref_len, tile, col_n, col_indel);
+    if (!rd || !pk || !tile || (rd->n_reads > 0 && !r_smpl && !pk->smpl_off)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pileup_packed: bad arguments");
+    const int rc = pool_upload_impl("bcfgpu_pileup_packed", ctx, rd, pk, r_mapq);
+    return rc ? rc : pool_pileup_impl("bcfgpu_pileup_packed", ctx, r_smpl, pk->smpl_off, beg, end, ref, ref_len, tile, col_n, col_indel);
+}
+
+// ---- the pool as an object of its own: upload once, run the stages on it, build the tile ----
+// [lowest start, highest end) of the pool's reads (one small kernel and a wait, once per pool)
+int bcfgpu_internal_pool_extent(bcfgpu_ctx *ctx, int *lo, int *hi)
+{
+    hipStream_t stream = nullptr;
+    if (bcfgpu_internal_device(ctx, &stream, nullptr)) return BCFGPU_E_ARG;
+    DevPool &D = *static_cast<DevPool*>(bcfgpu_internal_pool_state(ctx));
+    if (!D.valid) return BCFGPU_E_ARG;
+    if (!D.ext_valid) {
+        int *d = (int*)bcfgpu_internal_ws(ctx, 122, 64);
+        if (!d) return BCFGPU_E_NOMEM;
+        int v[2] = {INT32_MAX, 0};
+        if (hipMemcpyAsync(d, v, 8, hipMemcpyHostToDevice, stream) != hipSuccess) return BCFGPU_E_HIP;
+        if (D.n_reads) hipLaunchKernelGGL(pool_extent_kernel, dim3((D.n_reads + 255) / 256), dim3(256), 0, stream, D, d);
+        if (hipMemcpyAsync(v, d, 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return BCFGPU_E_HIP;
+        if (v[0] == INT32_MAX) v[0] = 0;
+        D.ext_lo = v[0]; D.ext_hi = v[1] > v[0] ? v[1] : v[0]; D.ext_valid = 1;
+    }
+    *lo = D.ext_lo; *hi = D.ext_hi;
+    return BCFGPU_OK;
+}
+
+extern "C" int bcfgpu_pool_upload(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bcfgpu_packed *pk, const uint8_t *r_mapq)
+{
+    return pool_upload_impl("bcfgpu_pool_upload", ctx, rd, pk, r_mapq);
+}
+
+extern "C" int bcfgpu_pool_keep(bcfgpu_ctx *ctx, const uint8_t *keep)
+{
+    hipStream_t stream = nullptr;
+    if (!ctx || bcfgpu_internal_device(ctx, &stream, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_keep: bad context");
+    DevPool &D = *static_cast<DevPool*>(bcfgpu_internal_pool_state(ctx));
+    if (!D.valid) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_keep: no read pool on this context (bcfgpu_pool_upload)");
+    if (!keep) { D.keep = nullptr; return BCFGPU_OK; }
+    uint8_t *d = (uint8_t*)bcfgpu_internal_ws(ctx, 114, (size_t)D.n_reads + 64);
+    if (!d) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_keep: device workspace");
+    if (D.n_reads && hipMemcpyAsync(d, keep, (size_t)D.n_reads, hipMemcpyHostToDevice, stream) != hipSuccess)
+        return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_keep: upload");
+    if (hipStreamSynchronize(stream) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_keep: upload");   // (keep may be the caller's stack)
+    D.keep = d;
+    return BCFGPU_OK;
+}
+
+extern "C" int bcfgpu_pool_pileup(bcfgpu_ctx *ctx, const int32_t *r_smpl, const int32_t *smpl_off, int32_t beg, int32_t end,
+                                  const char *ref, int32_t ref_len, bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel)
+{
+    return pool_pileup_impl("bcfgpu_pool_pileup", ctx, r_smpl, smpl_off, beg, end, ref, ref_len, tile, col_n, col_indel);
+}
+
+extern "C" int bcfgpu_pool_download(bcfgpu_ctx *ctx, uint8_t *qual, uint8_t *zq, uint8_t *r_mapq)
+{
+    hipStream_t stream = nullptr;
+    if (!ctx || bcfgpu_internal_device(ctx, &stream, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_download: bad context");
+    const DevPool &D = *static_cast<const DevPool*>(bcfgpu_internal_pool_state(ctx));
+    if (!D.valid) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_pool_download: no read pool on this context (bcfgpu_pool_upload)");
+    if (qual && D.n_bases && hipMemcpyAsync(qual, D.qual, D.n_bases, hipMemcpyDeviceToHost, stream) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_download");
+    if (zq && D.n_bases) {
+        if (D.zq) { if (hipMemcpyAsync(zq, D.zq, D.n_bases, hipMemcpyDeviceToHost, stream) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_download"); }
+        else std::memset(zq, 0, D.n_bases);
+    }
+    if (r_mapq && D.n_reads && hipMemcpyAsync(r_mapq, D.r_mapq, (size_t)D.n_reads, hipMemcpyDeviceToHost, stream) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_download");
+    if (hipStreamSynchronize(stream) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_download");
+    return BCFGPU_OK;
 }
 
 extern "C" int bcfgpu_pileup_entries(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols, int32_t *smpl_off,
@@ -886,6 +1004,10 @@ extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32
     char *d_ref = (char*)GWS(24, (size_t)(ref_hi - ref_lo));
     const bool any_zq = reads && reads->zq && reads->r_has_zq;
     uint8_t *d_zq = any_zq ? (uint8_t*)GWS(9, (size_t)P.n_bases) : nullptr, *d_haszq = any_zq ? (uint8_t*)GWS(10, (size_t)nr) : nullptr;
+    {   // no ZQ bytes from the host: those bcfgpu_pool_baq left in HBM, if the pool of the pileup is still the context's pool
+        const DevPool &D = *static_cast<const DevPool*>(bcfgpu_internal_pool_state(ctx));
+        if (!any_zq && D.valid && D.zq && D.r_has_zq && D.n_reads == nr && D.seq16 == P.seq16) { d_zq = D.zq; d_haszq = D.r_has_zq; }
+    }
     if (!d_rpos || !d_rlq || !d_rflag || !d_rncig || !d_rcoff || !d_rsoff || !d_pos || !d_ref || (any_zq && (!d_zq || !d_haszq)))
         return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
     if (any_zq && reads->n_reads != nr) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep_tile: `reads` is not the pool of the last bcfgpu_pileup");

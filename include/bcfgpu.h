@@ -397,6 +397,32 @@ int  bcfgpu_pileup_packed(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const bcfg
                           const int32_t *r_smpl, int32_t beg, int32_t end, const char *ref, int32_t ref_len,
                           bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel);
 
+/* ---- the read pool of a region kept in HBM: what mplp_func does to a read (mpileup.c:183-246: BAQ :234, the -C cap :235-239)
+ * and what the iterator does to pairs (:640) without the pool crossing PCIe between the stages.  bcfgpu_baq, bcfgpu_cap_mapq,
+ * bcfgpu_overlap_tweak and bcfgpu_pileup each take the pool from the host and (but for the last) hand their result back; here the
+ * pool is uploaded once -- packed (bcfgpu_packed) or a byte per base -- and the stages work on that copy, in mplp_func's order:
+ *   bcfgpu_pool_upload        reads / pk / r_mapq as for bcfgpu_pileup[_packed]; replaces the context's pool
+ *   bcfgpu_pool_baq           sam_prob_realn on every read: the pool's qualities become the new ones, the ZQ bytes stay in HBM
+ *                             (bcfgpu_gap_prep_tile finds them there when its `reads` is NULL); ret: HOST [n_reads] as for
+ *                             bcfgpu_baq, or NULL
+ *   bcfgpu_pool_cap_mapq      sam_cap_mapq: cap: HOST [n_reads] out as for bcfgpu_cap_mapq; the pool's mapping qualities above
+ *                             their cap are lowered to it (mpileup.c:238); dropping the reads with cap < 0 (:237) and the -q /
+ *                             orphan filters that follow are the caller's: bcfgpu_pool_keep
+ *   bcfgpu_pool_keep          keep: HOST [n_reads], 0 = the read does not enter the pileup (filters, bcfgpu_depth_cap); NULL = all
+ *   bcfgpu_pool_overlap_tweak the pairs as for bcfgpu_overlap_tweak; the pool's qualities are rewritten in place
+ *   bcfgpu_pool_pileup        the tile, as bcfgpu_pileup builds it (r_smpl, or smpl_off as in bcfgpu_packed)
+ *   bcfgpu_pool_download      the pool's current qualities / ZQ bytes / mapping qualities back to the host (any may be NULL): tests,
+ *                             and callers that want BQ/ZQ tags written
+ * The pool lives in the context's workspace until the next bcfgpu_pool_upload / bcfgpu_pileup[_packed] on that context. */
+int  bcfgpu_pool_upload(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const bcfgpu_packed *pk, const uint8_t *r_mapq);
+int  bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len, int flag, int32_t *ret);
+int  bcfgpu_pool_cap_mapq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len, int32_t thres, int32_t *cap);
+int  bcfgpu_pool_keep(bcfgpu_ctx *ctx, const uint8_t *keep);
+int  bcfgpu_pool_overlap_tweak(bcfgpu_ctx *ctx, int32_t n_pairs, const int32_t *pair_a, const int32_t *pair_b);
+int  bcfgpu_pool_pileup(bcfgpu_ctx *ctx, const int32_t *r_smpl, const int32_t *smpl_off, int32_t beg, int32_t end,
+                        const char *ref, int32_t ref_len, bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel);
+int  bcfgpu_pool_download(bcfgpu_ctx *ctx, uint8_t *qual, uint8_t *zq, uint8_t *r_mapq);
+
 /* ---- the pileup iterator's per-file depth cap: mpileup -d (mpileup.c:646 bam_mplp_set_maxcnt; htslib sam.c bam_plp_push) -------
  * Host helper (integer bookkeeping of the read buffer, no device work).  A read is dropped when it starts at the position of
  * the read kept last while max_depth or more reads are still buffered: reads kept earlier whose end (bam_endpos) is not before

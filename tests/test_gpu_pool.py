@@ -1,0 +1,144 @@
+"""The read pool kept in HBM (bcfgpu_pool_upload -> bcfgpu_pool_baq -> bcfgpu_pool_cap_mapq -> bcfgpu_pool_keep ->
+bcfgpu_pool_overlap_tweak -> bcfgpu_pool_pileup) against the same stages with host pointers between them (bcfgpu_baq,
+bcfgpu_cap_mapq, bcfgpu_overlap_tweak, bcfgpu_pileup), which the other GPU tests pin to the oracle and the goldens: the
+reference's SAM fixtures, raw reads in, every intermediate (new qualities, ZQ bytes, BAQ's ret, the caps, the lowered mapping
+qualities) and the final tile compared."""
+import copy
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from bcftools_amd import abi
+from bcftools_amd.lib import check
+from tests.helpers import sam, mplpdrv as M
+from tests.test_gpu_pileup import assert_tiles_equal, device_pileup
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw(golden_dir, files, fa, contig):
+    G = os.path.join(golden_dir, "mpileup")
+    sams = [sam.Sam(os.path.join(G, f)) for f in files]
+    ref = sam.read_fasta(os.path.join(G, fa))
+    prep = M.Prepared(sams, ref, contig, sam.MplpOpts(), baq=False, overlaps=False)
+    return prep
+
+
+def _tile_of(ctx, t, n_sites, S):
+    from bcftools_amd import host
+    off = np.zeros(n_sites * S + 1, np.uint32)
+    ref16 = np.zeros(n_sites, np.int8)
+    w = np.zeros(int(t.n_reads), np.uint32)
+    e = np.zeros(int(t.n_reads), np.uint8)
+    for dst, src in ((off, t.plp_off), (ref16, t.ref16), (w, t.rd), (e, t.epos)):
+        if dst.nbytes:
+            check(ctx.L.bcfgpu_memcpy_d2h(ctx.h, dst.ctypes.data, src, dst.nbytes))
+    ctx.sync()
+    return host.HostTile(S, ref16, off, w, e)
+
+
+@pytest.mark.parametrize("files,fa,contig,beg,end,flag,packed", [
+    (["mpileup.1.sam", "mpileup.2.sam", "mpileup.3.sam"], "mpileup.ref.fa", "17", 0, 700, 3, True),
+    (["mpileup.1.sam", "mpileup.2.sam", "mpileup.3.sam"], "mpileup.ref.fa", "17", 100, 600, 7, False),
+    (["indel-AD.1.sam"], "indel-AD.1.fa", "000000F", 0, 1200, 3, True),
+])
+def test_pool_chain_matches_the_host_pointer_chain(golden_dir, gpu_ctx_factory, files, fa, contig, beg, end, flag, packed):
+    prep = _raw(golden_dir, files, fa, contig)
+    S = len(prep.samples)
+    by_sample = [[] for _ in range(S)]
+    for rl in prep.files:
+        for r, si in rl:
+            by_sample[si].append(r)
+    reads = [r for rl in by_sample for r in rl]
+    smpl = np.array([si for si, rl in enumerate(by_sample) for _ in rl], np.int32)
+    n = len(reads)
+    refb = prep.refseq.encode()
+    ctx = gpu_ctx_factory(abi.default_cfg(S, max_sites=1, max_reads=64))
+    L = ctx.L
+    thres = 50
+
+    # ---- host pointers between the stages ----
+    rd, d = M.pack_reads(reads)
+    nb = len(d["qual"])
+    qo, zo, ret = np.zeros(nb, np.uint8), np.zeros(nb, np.uint8), np.zeros(n, np.int32)
+    check(L.bcfgpu_baq(ctx.h, C.byref(rd), refb, len(prep.refseq), flag, qo.ctypes.data, zo.ctypes.data, ret.ctypes.data))
+    assert (ret == 0).any()
+    rd.qual = qo.ctypes.data
+    cap = np.zeros(n, np.int32)
+    check(L.bcfgpu_cap_mapq(ctx.h, C.byref(rd), refb, len(prep.refseq), thres, cap.ctypes.data))
+    mapq = np.array([r.mapq for r in reads], np.uint8)
+    mapq_a = np.where((cap >= 0) & (mapq > cap), cap, mapq).astype(np.uint8)
+    keep = (cap >= 0).astype(np.uint8)
+    keep[::17] = 0                                                  # and some dropped by a filter of the caller's
+    # pairs among the kept reads, file by file as the iterator sees them
+    index = {id(r): i for i, r in enumerate(reads)}
+    pa, pb = [], []
+    for rl in prep.files:
+        for a, b in M.overlap_pairs([r for r, _ in rl if keep[index[id(r)]]]):
+            pa.append(index[id(a)]); pb.append(index[id(b)])
+    pa, pb = np.array(pa, np.int32), np.array(pb, np.int32)
+    q2 = np.zeros(nb, np.uint8)
+    check(L.bcfgpu_overlap_tweak(ctx.h, C.byref(rd), len(pa), pa.ctypes.data, pb.ctypes.data, q2.ctypes.data))
+    if len(pa) == 0:
+        q2 = qo.copy()
+    # the kept reads as a pool of their own, with the qualities and mapping qualities the stages left
+    kept_by_sample = []
+    for si, rl in enumerate(by_sample):
+        out = []
+        for r in rl:
+            i = index[id(r)]
+            if not keep[i]:
+                continue
+            o = int(d["r_seq_off"][i])
+            r2 = copy.copy(r)
+            r2.qual = q2[o:o + r.l_qseq].astype(np.int32)
+            r2.mapq = int(mapq_a[i])
+            out.append(r2)
+        kept_by_sample.append(out)
+    want, want_n, want_indel, _ = device_pileup(ctx, kept_by_sample, prep.refseq, beg, end)
+
+    # ---- the pool in HBM ----
+    rd2, d2 = M.pack_reads(reads)
+    pk = None
+    if packed:
+        pk = abi.Packed()
+        seq4 = abi.pack_nibbles(d2["seq16"])
+        pk.seq4, pk.n_bases, pk.n_cig = seq4.ctypes.data, nb, len(d2["cig"])
+        rd2.seq16 = None
+    check(L.bcfgpu_pool_upload(ctx.h, C.byref(rd2), C.byref(pk) if pk is not None else None, mapq.ctypes.data))
+    ret_b = np.full(n, 99, np.int32)
+    check(L.bcfgpu_pool_baq(ctx.h, refb, len(prep.refseq), flag, ret_b.ctypes.data))
+    np.testing.assert_array_equal(ret_b, ret)
+    q_b, z_b = np.zeros(nb, np.uint8), np.zeros(nb, np.uint8)
+    check(L.bcfgpu_pool_download(ctx.h, q_b.ctypes.data, z_b.ctypes.data, None))
+    np.testing.assert_array_equal(q_b, qo)
+    np.testing.assert_array_equal(z_b, zo)
+    cap_b = np.zeros(n, np.int32)
+    check(L.bcfgpu_pool_cap_mapq(ctx.h, refb, len(prep.refseq), thres, cap_b.ctypes.data))
+    np.testing.assert_array_equal(cap_b, cap)
+    m_b = np.zeros(n, np.uint8)
+    check(L.bcfgpu_pool_download(ctx.h, None, None, m_b.ctypes.data))
+    np.testing.assert_array_equal(m_b, mapq_a)
+    check(L.bcfgpu_pool_keep(ctx.h, keep.ctypes.data))
+    check(L.bcfgpu_pool_overlap_tweak(ctx.h, len(pa), pa.ctypes.data if len(pa) else None, pb.ctypes.data if len(pb) else None))
+    check(L.bcfgpu_pool_download(ctx.h, q_b.ctypes.data, None, None))
+    np.testing.assert_array_equal(q_b, q2)
+    t = abi.Tile()
+    n_sites = end - beg
+    col_n, col_indel = np.zeros(n_sites, np.int32), np.zeros(n_sites, np.uint8)
+    check(L.bcfgpu_pool_pileup(ctx.h, smpl.ctypes.data, None, beg, end, refb, len(prep.refseq), C.byref(t), col_n.ctypes.data, col_indel.ctypes.data))
+    got = _tile_of(ctx, t, n_sites, S)
+    assert_tiles_equal(got, want)
+    np.testing.assert_array_equal(col_n, want_n)
+    np.testing.assert_array_equal(col_indel, want_indel)
+    assert len(want.rd) > 1000
+
+
+def test_pool_stages_need_a_pool(gpu_ctx_factory):
+    ctx = gpu_ctx_factory(abi.default_cfg(2, max_sites=1, max_reads=64))
+    t = abi.Tile()
+    assert ctx.L.bcfgpu_pool_baq(ctx.h, b"ACGT", 4, 3, None) != 0
+    assert ctx.L.bcfgpu_pool_pileup(ctx.h, None, None, 0, 4, b"ACGT", 4, C.byref(t), None, None) != 0
+    assert b"bcfgpu_pool_upload" in ctx.L.bcfgpu_last_error()
