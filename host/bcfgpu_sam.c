@@ -10,9 +10,10 @@
  *  binary records), the read -> sample map of bam_sample.c (@RG SM, RG:Z tags, -s/-S/-G), the read filters of mplp_func
  *  (mpileup.c:183-246: unmapped, --rf/--ff flags, reads of dropped read groups, -q, orphans), the iterator's per-file depth
  *  cap (bcfgpu_depth_cap) and the pairing of overlapping mates (htslib overlap_push).  Then, each a call on the flat read pool:
- *      bcfgpu_baq            BAQ (sam_prob_realn, mpileup.c:234)
- *      bcfgpu_overlap_tweak  mate-overlap qualities (bam_mplp_init_overlaps, mpileup.c:640)
- *      bcfgpu_pileup         the pileup columns of the region, built in HBM
+ *      bcfgpu_pool_upload          the pool to HBM, once
+ *      bcfgpu_pool_baq             BAQ (sam_prob_realn, mpileup.c:234)
+ *      bcfgpu_pool_overlap_tweak   mate-overlap qualities (bam_mplp_init_overlaps, mpileup.c:640)
+ *      bcfgpu_pool_pileup          the pileup columns of the region, built in HBM
  *      bcfgpu_mpileup        bcf_call_glfgen x samples + bcf_call_combine per column (mpileup.c:343-347)
  *  and for the columns where some read is followed by an indel (mpileup.c:354-365):
  *      bcfgpu_gap_prep_tile (bcf_call_gap_prep on the candidate columns, in HBM) -> bcfgpu_mpileup on its indel tile
@@ -847,16 +848,11 @@ int main(int argc, char **argv)
         bcfgpu_reads r0; memset(&r0, 0, sizeof r0);
         r0.n_reads = P.n; r0.r_pos = P.pos; r0.r_lq = P.lq; r0.r_flag = P.flag; r0.r_ncig = P.ncig; r0.r_cig_off = P.cig_off;
         r0.r_seq_off = P.seq_off; r0.cig = P.cig; r0.seq16 = P.seq16; r0.qual = P.qual; r0.zq = P.zq; r0.r_has_zq = P.has_zq;
-        uint8_t *qb = NULL, *zb = NULL;
-        if (baq_flag) {                                                       /* the qualities sam_cap_mapq sees are BAQ's */
-            qb = malloc(P.nbase + 1); zb = malloc(P.nbase + 1);
-            int32_t *bret = malloc((size_t)(P.n + 1) * sizeof *bret);
-            CHECK(bcfgpu_baq(cx, &r0, ref, ref_len, baq_flag, qb, zb, bret));
-            r0.qual = qb;
-            free(bret);
-        }
+        /* the pool goes up once; BAQ and the cap run on that copy (the qualities sam_cap_mapq sees are BAQ's) */
+        CHECK(bcfgpu_pool_upload(cx, &r0, NULL, P.mapq));
+        if (baq_flag) CHECK(bcfgpu_pool_baq(cx, ref, ref_len, baq_flag, NULL));
         int32_t *capv = malloc((size_t)P.n * sizeof *capv);
-        CHECK(bcfgpu_cap_mapq(cx, &r0, ref, ref_len, cap_thres, capv));
+        CHECK(bcfgpu_pool_cap_mapq(cx, ref, ref_len, cap_thres, capv));
         uint8_t *keep = malloc((size_t)P.n);
         for (int r = 0; r < P.n; ++r) {
             keep[r] = capv[r] >= 0;
@@ -865,7 +861,7 @@ int main(int argc, char **argv)
             if (!keep_orphans && (P.flag[r] & 1) && !(P.flag[r] & 2)) keep[r] = 0;
         }
         pool_keep(&P, first, F, keep);
-        free(keep); free(capv); free(qb); free(zb);
+        free(keep); free(capv);
         bcfgpu_destroy(cx);
     }
     /* ---- the per-file depth cap of the pileup iterator (mpileup -d, mpileup.c:646): reads it drops leave the pool ---- */
@@ -935,23 +931,16 @@ int main(int argc, char **argv)
     rd.n_reads = P.n; rd.r_pos = P.pos; rd.r_lq = P.lq; rd.r_flag = P.flag; rd.r_ncig = P.ncig; rd.r_cig_off = P.cig_off;
     rd.r_seq_off = P.seq_off; rd.cig = P.cig; rd.seq16 = P.seq16; rd.qual = P.qual; rd.zq = P.zq; rd.r_has_zq = P.has_zq;
 
-    /* BAQ: new qualities for the reads it applies to (not with -B) */
-    uint8_t *q1 = malloc(P.nbase + 1), *zq = malloc(P.nbase + 1), *q2 = malloc(P.nbase + 1);
-    if (baq_flag) {
-        int32_t *ret = malloc((size_t)(P.n + 1) * sizeof *ret);
-        CHECK(bcfgpu_baq(ctx, &rd, ref, ref_len, baq_flag, q1, zq, ret));
-        rd.qual = q1;
-        for (int r = 0; r < P.n; ++r) P.has_zq[r] = ret[r] == 0;             /* the "ZQ" tag sam_prob_realn leaves on the read */
-        rd.zq = zq;
-        free(ret);
-    }
-    CHECK(bcfgpu_overlap_tweak(ctx, &rd, np, pa, pb, q2));
-    rd.qual = q2;
+    /* the pool goes up once and stays in HBM: BAQ (new qualities and ZQ bytes for the reads it applies to; not with -B), the
+     * mate-overlap tweak, the pileup of the region -- each on the copy the stage before left there */
+    CHECK(bcfgpu_pool_upload(ctx, &rd, NULL, P.mapq));
+    if (baq_flag) CHECK(bcfgpu_pool_baq(ctx, ref, ref_len, baq_flag, NULL));
+    CHECK(bcfgpu_pool_overlap_tweak(ctx, np, pa, pb));
     /* the pileup of the region and the SNP pass */
     bcfgpu_tile tile;
     int32_t *col_n = malloc((size_t)(n_sites + 1) * sizeof *col_n);
     uint8_t *col_indel = malloc((size_t)n_sites + 1);
-    CHECK(bcfgpu_pileup(ctx, &rd, P.mapq, P.smpl, beg, end, ref, ref_len, &tile, col_n, col_indel));
+    CHECK(bcfgpu_pool_pileup(ctx, P.smpl, NULL, beg, end, ref, ref_len, &tile, col_n, col_indel));
     void *d_site, *d_pl, *d_dp4;
     bcfgpu_site *site = NULL;
     planes_t snp_planes;
@@ -978,7 +967,8 @@ int main(int argc, char **argv)
         out.ret = gret; out.p_aux = NULL; out.indel_types = g_types; out.inscns = g_inscns; out.maxins = g_maxins;
         out.indelreg = g_indelreg; out.max_support = g_support; out.max_frac = g_frac;
         bcfgpu_tile ti;
-        CHECK(bcfgpu_gap_prep_tile(ctx, nc, cand, &rd, &in, &out, INSCNS_CAP, &ti));
+        /* (with BAQ the ZQ bytes are the pool's, in HBM; with -B the reads' own tags, if any, go up from the host) */
+        CHECK(bcfgpu_gap_prep_tile(ctx, nc, cand, baq_flag ? NULL : &rd, &in, &out, INSCNS_CAP, &ti));
         live = malloc((size_t)nc * 4);
         for (int i = 0; i < nc; ++i) if (gret[i] == 0) live[nlive++] = i;
         if (nlive) run_mpileup(ctx, &ti, nc, &isite, &ind_planes, NULL, NULL, NULL);      /* records of columns with ret < 0 are not used */
