@@ -176,13 +176,18 @@ __device__ void baq_fb_scratch(const BaqParams &P, int job, const BaqJob &j, con
 // of the ~40 accesses of the scratch version.
 template <int BWM>
 __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const uint8_t *ref, const uint8_t *seq,
-                           const uint8_t *iqual, int bw, int32_t *state, uint8_t *q)
+                           const uint8_t *iqual, int bw, int32_t *state, uint8_t *q, const float *lq2p)
 {
     constexpr int NP = 2 * BWM + 3;
     const int l_query = j.l_query, l_ref = j.l_ref;
     const size_t st = P.stride;
-    #define FR(i, p, s_) P.F[(((size_t)(i) * NP + (p)) * 3 + (s_)) * st + job]
-    #define SC(i) P.S[(size_t)(i) * st + job]
+    // A wavefront's rows are one contiguous block, [row][cell][lane]: consecutive stores are 512 bytes apart.  (With the
+    // rows of all reads of a launch interleaved -- [row][cell][read] -- consecutive stores of a wavefront were megabytes
+    // apart, every one on a DRAM page and a TLB entry of its own: 1.8 TB/s.)  M and I only: the posterior never reads D.
+    const size_t wbase = (size_t)(job >> 6) * (size_t)(P.max_lq + 2);
+    const int wl = job & 63;
+    #define FR(i, p, s_) P.F[((wbase + (size_t)(i)) * (NP * 2) + (size_t)((p) * 2 + (s_))) * 64 + wl]
+    #define SC(i) P.S[(wbase + (size_t)(i)) * 64 + wl]
     const int bw2 = bw * 2 + 1;
     const double d = 0.001, e_ = 0.1;
     double m[9];
@@ -192,11 +197,15 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
     m[6] = 1 - e_; m[7] = 0.; m[8] = e_;
     const double bM = (1 - d) / l_ref, bI = d / l_ref;
     auto qy = [&](int i) { return nt16_to_4(seq[i]); };
-    auto qp = [&](int i) { return (double)P.q2p[iqual[i]]; };
+    auto qp = [&](int i) { return (double)lq2p[iqual[i]]; };          // (float)pow(10, -Q/10), from the workgroup's copy in LDS
     double M[NP], I[NP], D[NP];
     #pragma unroll
     for (int p = 0; p < NP; ++p) M[p] = I[p] = D[p] = 0.;
     // ---- forward ----
+    // The bytes a row needs (the query base, its quality, the reference base that slides into the band) are requested one row
+    // ahead, BEFORE the 32 stores of the row in between: vmcnt counts loads and stores in issue order, so a load requested
+    // after a row's stores is only known to be there when those stores are -- every row waited for its predecessor's writes
+    // to reach memory (80 % of a wavefront's life in s_waitcnt).
     uint64_t rw = 0;                                      // base of position p (column k = p + x - 1, ref[k-1]) in bits [3p, 3p+3)
     #pragma unroll
     for (int p = 2; p < NP; ++p) rw |= (uint64_t)(p - 2 < l_ref ? ref[p - 2] : 4) << (3 * p);
@@ -219,19 +228,27 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
         #pragma unroll
         for (int p = 1; p < NP; ++p) {
             if (p >= 2 && p - 1 <= end) { M[p] /= sum; I[p] /= sum; D[p] /= sum; }
-            FR(1, p, 0) = M[p]; FR(1, p, 1) = I[p]; FR(1, p, 2) = D[p];
+            FR(1, p, 0) = M[p]; FR(1, p, 1) = I[p];
         }
     }
     int x = 0;
+    const int lq1 = l_query - 1, lr1 = l_ref - 1;
+    auto ref_at = [&](int k) { return (uint32_t)ref[k < 0 ? 0 : k > lr1 ? lr1 : k]; };   // (clamped: requested whether or not the band slides)
+    uint32_t nq = iqual[1 < lq1 ? 1 : lq1], ns = seq[1 < lq1 ? 1 : lq1], nr = ref_at(NP - 3 + 2 - bw);
     for (int i = 2; i <= l_query; ++i) {
-        const double qli = qp(i - 1);
-        const int qyi = qy(i - 1);
+        const uint32_t cq = nq, cs = ns, cr = nr;
+        {   // row i + 1's bytes
+            const int in = i < lq1 ? i : lq1;
+            nq = iqual[in]; ns = seq[in]; nr = ref_at(NP - 3 + (i + 1) - bw);
+        }
+        const double qli = (double)lq2p[cq];
+        const int qyi = nt16_to_4((int)cs);
         const bool slide = i > bw;
         if (slide) {
             ++x;
             rw >>= 3;
-            const int nk = (NP - 1) + x - 2;
-            rw |= (uint64_t)(nk < l_ref ? ref[nk] : 4) << (3 * (NP - 1));
+            const int nk = (NP - 1) + x - 2;                      // = NP - 3 + i - bw
+            rw |= (uint64_t)(nk < l_ref ? cr : 4u) << (3 * (NP - 1));
         }
         const int end = l_ref < i + bw ? l_ref : i + bw;
         const int plo = x == 0 ? 2 : 1, phi = end - x + 1;
@@ -261,7 +278,7 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
         #pragma unroll
         for (int p = 1; p < NP; ++p) {
             M[p] *= r; I[p] *= r; D[p] *= r;
-            FR(i, p, 0) = M[p]; FR(i, p, 1) = I[p]; FR(i, p, 2) = D[p];
+            FR(i, p, 0) = M[p]; FR(i, p, 1) = I[p];
         }
     }
     {
@@ -273,6 +290,9 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
             if (p >= plo && p <= phi) sum += M[p] * sM + I[p] * sI;
         SC(l_query + 1) = sum;
     }
+#ifdef BAQ_EXP_SKIP_BWD
+    if (l_query > 0) return;
+#endif
     // ---- backward with the posterior maximum of every row ----
     // x is max(0, l_query - bw) here.  Row l_query:
     {
@@ -291,15 +311,32 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
     #pragma unroll
     for (int p = 1; p < NP; ++p) rb_w |= bcode(p + x - 1) << (3 * p);
     constexpr uint64_t WMASK = (NP * 3 >= 64) ? ~0ull : ((1ull << (NP * 3)) - 1);
+    // The forward row of the posterior, the scale, the query byte and the reference byte of a row are requested while the row
+    // before it (i + 1) is being worked on: the forward values of row i - 1 right after row i's posterior has consumed its own.
+    double fr0[NP], fr1[NP];
+    #pragma unroll
+    for (int p = 1; p < NP; ++p) { fr0[p] = FR(l_query, p, 0); fr1[p] = FR(l_query, p, 1); }
+    uint32_t bq_n = 0, bs_n = 0, br_n = 0;                // bytes of row l_query - 1
+    double sc_n = 1.;
+    {
+        const int in = lq1 > 0 ? lq1 : 0, i1 = l_query - 1, xi1 = i1 - bw > 0 ? i1 - bw : 0;
+        bq_n = iqual[in]; bs_n = seq[in]; br_n = ref_at(xi1); sc_n = SC(i1 > 1 ? i1 : 1);
+    }
     for (int i = l_query; i >= 1; --i) {
         if (i < l_query) {
             // b[i] from b[i+1], in place, descending p
             const int xi = i - bw > 0 ? i - bw : 0;
             const bool slide = xi != x;                   // the band of row i+1 sits one column to the right
-            if (slide) { rb_w = ((rb_w << 3) & WMASK & ~7ull) | (bcode(xi) << 3); }
+            const uint32_t cq = bq_n, cs = bs_n, cr = br_n;
+            const double csc = sc_n;
+            {   // row i - 1's bytes and scale
+                const int i1 = i - 1 > 1 ? i - 1 : 1, xi1 = i1 - bw > 0 ? i1 - bw : 0;
+                bq_n = iqual[i1]; bs_n = seq[i1]; br_n = ref_at(xi1); sc_n = SC(i1);
+            }
+            if (slide) { rb_w = ((rb_w << 3) & WMASK & ~7ull) | ((uint64_t)(xi < l_ref ? cr : 7u) << 3); }
             x = xi;
-            const double qli1 = qp(i);
-            const int qyi1 = qy(i);
+            const double qli1 = (double)lq2p[cq];
+            const int qyi1 = nt16_to_4((int)cs);
             const int end = l_ref < i + bw ? l_ref : i + bw;
             const int plo = x == 0 ? 2 : 1, phi = end - x + 1;
             const double y = (i > 1);
@@ -323,7 +360,7 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
             }
             (void)cI; (void)cD;
             M[NP - 1] = I[NP - 1] = D[NP - 1] = 0.;
-            const double y2 = 1. / SC(i);
+            const double y2 = 1. / csc;
             #pragma unroll
             for (int p = 1; p < NP; ++p) { M[p] *= y2; I[p] *= y2; D[p] *= y2; }
         }
@@ -338,9 +375,14 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
                 if (p >= plo && p <= phi) {
                     const int k = p + x - 1;
                     double z;
-                    z = FR(i, p, 0) * M[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 0; } sum += z;
-                    z = FR(i, p, 1) * I[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 1; } sum += z;
+                    z = fr0[p] * M[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 0; } sum += z;
+                    z = fr1[p] * I[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 1; } sum += z;
                 }
+            }
+            {   // the forward values of row i - 1
+                const int i1 = i > 1 ? i - 1 : 1;
+                #pragma unroll
+                for (int p = 1; p < NP; ++p) { fr0[p] = FR(i1, p, 0); fr1[p] = FR(i1, p, 1); }
             }
             max /= sum;
             state[i - 1] = max_k;
@@ -352,57 +394,77 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
     #undef SC
 }
 
-// the quality cap of sam_prob_realn (realn.c) from the posterior states and qualities
+// the quality cap of sam_prob_realn (realn.c) from the posterior states and qualities.
+// Per aligned block of the CIGAR the reference computes bq[i] = (state agrees with the alignment ? q[i] : 0) and, extended,
+// replaces it by min(running maximum from the left, running maximum from the right) in five passes over three byte arrays;
+// here: one ascending pass that leaves the left maxima in the scratch array and one descending pass that forms the right
+// maximum, the minimum, the ZQ byte and the new quality, four bases per trip with all loads of a trip issued before the
+// first is used (a lane's bytes are its own 100-byte stretch: every access is a round trip to L2, and one wait per byte
+// made this phase a third of the kernel).
 __device__ void baq_cap(const BaqParams &P, const BaqJob &j, const uint8_t *iqual, const int32_t *state, const uint8_t *q,
                         uint8_t *qout, uint8_t *zout)
 {
-    const int l_query = j.l_query;
     const uint32_t *cigar = P.cig + j.cig_off;
     const bool apply = (P.flag & 1) != 0, extend = (P.flag & 2) != 0;
-    uint8_t *bq = zout;                                   // built in place in the ZQ output
-    for (int i = 0; i < l_query; ++i) bq[i] = iqual[i];
-    if (!extend) {
-        int x = j.pos, y = 0;
-        for (int k = 0; k < j.n_cigar; ++k) {
-            const int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
-            if (op == 0 || op == 7 || op == 8) {
-                for (int i = y; i < y + l; ++i) {
-                    if ((state[i] & 3) != 0 || state[i] >> 2 != x - j.xb + (i - y)) bq[i] = 0;
-                    else bq[i] = bq[i] < q[i] ? bq[i] : q[i];
+    uint8_t *left = P.tmp + 2 * (size_t)j.seq_off;
+    int x = j.pos, y = 0;
+    for (int k = 0; k < j.n_cigar; ++k) {
+        const int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
+        if (op == 0 || op == 7 || op == 8) {
+            const int exp0 = x - j.xb - y;                      // the state an aligned base i of this block must have: exp0 + i
+            auto bqv = [&](int st, uint32_t qq, int i) -> uint32_t { return ((st & 3) != 0 || (st >> 2) != exp0 + i) ? 0u : qq; };
+            if (extend) {
+                uint32_t L = 0;
+                int i = y;
+                for (; i + 4 <= y + l; i += 4) {
+                    const int s0 = state[i], s1 = state[i + 1], s2 = state[i + 2], s3 = state[i + 3];
+                    const uint32_t q0 = q[i], q1 = q[i + 1], q2 = q[i + 2], q3 = q[i + 3];
+                    L = max(L, bqv(s0, q0, i)); const uint32_t l0 = L;
+                    L = max(L, bqv(s1, q1, i + 1)); const uint32_t l1 = L;
+                    L = max(L, bqv(s2, q2, i + 2)); const uint32_t l2 = L;
+                    L = max(L, bqv(s3, q3, i + 3));
+                    left[i] = (uint8_t)l0; left[i + 1] = (uint8_t)l1; left[i + 2] = (uint8_t)l2; left[i + 3] = (uint8_t)L;
                 }
-                x += l; y += l;
-            } else if (op == 4 || op == 1) y += l;
-            else if (op == 2) x += l;
-        }
-        for (int i = 0; i < l_query; ++i) bq[i] = (uint8_t)(iqual[i] - bq[i] + 64);
-    } else {
-        uint8_t *left = P.tmp + 2 * (size_t)j.seq_off, *rght = left + l_query;
-        int x = j.pos, y = 0;
-        for (int k = 0; k < j.n_cigar; ++k) {
-            const int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
-            if (op == 0 || op == 7 || op == 8) {
-                for (int i = y; i < y + l; ++i)
-                    bq[i] = ((state[i] & 3) != 0 || state[i] >> 2 != x - j.xb + (i - y)) ? 0 : q[i];
-                left[y] = bq[y];
-                for (int i = y + 1; i < y + l; ++i) left[i] = bq[i] > left[i - 1] ? bq[i] : left[i - 1];
-                rght[y + l - 1] = bq[y + l - 1];
-                for (int i = y + l - 2; i >= y; --i) rght[i] = bq[i] > rght[i + 1] ? bq[i] : rght[i + 1];
-                for (int i = y; i < y + l; ++i) bq[i] = left[i] < rght[i] ? left[i] : rght[i];
-                x += l; y += l;
-            } else if (op == 4 || op == 1) y += l;
-            else if (op == 2) x += l;
-        }
-        for (int i = 0; i < l_query; ++i) bq[i] = (uint8_t)(64 + (iqual[i] <= bq[i] ? 0 : iqual[i] - bq[i]));
+                for (; i < y + l; ++i) { L = max(L, bqv(state[i], q[i], i)); left[i] = (uint8_t)L; }
+            }
+            uint32_t R = 0;
+            auto fin = [&](int i, int st, uint32_t qq, uint32_t lf, uint32_t iq) {
+                uint32_t v = bqv(st, qq, i), z;
+                if (extend) { R = max(R, v); v = lf < R ? lf : R; z = iq <= v ? 0u : iq - v; }
+                else { v = iq < v ? iq : v; if (((st & 3) != 0 || (st >> 2) != exp0 + i)) v = 0; z = iq - v; }
+                zout[i] = (uint8_t)(64 + z);
+                qout[i] = apply ? (uint8_t)(iq - z) : (uint8_t)iq;
+            };
+            int i = y + l - 1;
+            for (; i - 3 >= y; i -= 4) {
+                const int s0 = state[i], s1 = state[i - 1], s2 = state[i - 2], s3 = state[i - 3];
+                const uint32_t q0 = q[i], q1 = q[i - 1], q2 = q[i - 2], q3 = q[i - 3];
+                const uint32_t i0 = iqual[i], i1 = iqual[i - 1], i2 = iqual[i - 2], i3 = iqual[i - 3];
+                uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+                if (extend) { l0 = left[i]; l1 = left[i - 1]; l2 = left[i - 2]; l3 = left[i - 3]; }
+                fin(i, s0, q0, l0, i0); fin(i - 1, s1, q1, l1, i1); fin(i - 2, s2, q2, l2, i2); fin(i - 3, s3, q3, l3, i3);
+            }
+            for (; i >= y; --i) fin(i, state[i], q[i], extend ? left[i] : 0u, iqual[i]);
+            x += l; y += l;
+        } else if (op == 4 || op == 1) {
+            for (int i = y; i < y + l && i < j.l_query; ++i) { zout[i] = 64; qout[i] = iqual[i]; }     // bases outside the aligned blocks keep their quality
+            y += l;
+        } else if (op == 2) x += l;
     }
-    for (int i = 0; i < l_query; ++i) qout[i] = apply ? (uint8_t)(iqual[i] - (bq[i] - 64)) : iqual[i];
+    for (int i = y; i < j.l_query; ++i) { zout[i] = 64; qout[i] = iqual[i]; }      // (a CIGAR shorter than the query)
 }
 
-
+// band classes: bands of up to 7 (a read without indels: 7) and of 8 (realn.c trims the window to the read's length + 7 or
+// + 8: a deletion of even length gives 8) keep their rows in registers; wider ones (indels of 8 and more) go through scratch
 #define BAQ_BWM 7
+#define BAQ_BWM2 8
 
-template <bool REG>
+template <int BWM>          // 0: both matrices in scratch, any band
 __global__ __launch_bounds__(64) void baq_kernel(const BaqParams P)
 {
+    __shared__ float s_q2p[256];
+    for (int t = threadIdx.x; t < 256; t += 64) s_q2p[t] = P.q2p[t];
+    __syncthreads();
     const int job = blockIdx.x * 64 + threadIdx.x;
     if (job >= P.n_jobs) return;
     const BaqJob j = P.jobs[job];
@@ -415,13 +477,15 @@ __global__ __launch_bounds__(64) void baq_kernel(const BaqParams P)
     const uint8_t *ref = P.tref + j.ref_off;
     int32_t *state = P.state + j.seq_off;
     uint8_t *q = P.q + j.seq_off;
-    if (REG) {
+    if (BWM > 0) {
         int bw = j.l_ref > j.l_query ? j.l_ref : j.l_query;
         if (bw > j.bw) bw = j.bw;
         if (bw < abs(j.l_ref - j.l_query)) bw = abs(j.l_ref - j.l_query);
-        baq_fb_reg<BAQ_BWM>(P, job, j, ref, seq, iqual, bw, state, q);
+        baq_fb_reg<(BWM > 0 ? BWM : 1)>(P, job, j, ref, seq, iqual, bw, state, q, s_q2p);
     } else baq_fb_scratch(P, job, j, ref, seq, iqual, state, q);
+#ifndef BAQ_EXP_SKIP_CAP
     baq_cap(P, j, iqual, state, q, qout, zout);
+#endif
 }
 
 // ---- the same stage on the pool bcfgpu_pool_upload left in HBM: the host half above as a kernel ----
@@ -430,52 +494,71 @@ __global__ __launch_bounds__(64) void baq_kernel(const BaqParams P)
 struct BaqPrepParams {
     DevPool D;
     int ref_len;                     // bases of the contig (up to its terminating NUL)
-    BaqJob *jobs0, *jobs1;
-    int *counts;                     // [0],[1] jobs per class  [2] widest band of class 1  [3] longest query  [4] lowest xb  [5] highest xe
+    BaqJob *jobs0, *jobs1, *jobs2;
+    int *counts;                     // [0],[1],[6] jobs per class (band <= 7, 8, wider)  [2] widest band  [3] longest query  [4] lowest xb  [5] highest xe
     int32_t *ret; uint8_t *has_zq;
 };
 __global__ __launch_bounds__(256) void baq_prep_kernel(const BaqPrepParams P)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= P.D.n_reads) return;
-    const int l_qseq = P.D.r_lq[r], pos = P.D.r_pos[r], n_cigar = P.D.r_ncig[r];
-    const uint32_t soff = (uint32_t)P.D.r_seq_off[r], coff = (uint32_t)P.D.r_cig_off[r];
-    const uint32_t *cigar = P.D.cig + coff;
-    P.ret[r] = -1; P.has_zq[r] = 0;
-    if (l_qseq <= 0 || P.D.qual[soff] == 0xff || (P.D.r_flag[r] & 4)) return;
-    int x = pos, y = 0, yb = -1, ye = -1, xb = -1, xe = -1;
-    for (int k = 0; k < n_cigar; ++k) {
-        const int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
-        if (op == 0 || op == 7 || op == 8) {
-            if (yb < 0) yb = y;
-            if (xb < 0) xb = x;
-            ye = y + l; xe = x + l;
-            x += l; y += l;
-        } else if (op == 4 || op == 1) y += l;
-        else if (op == 2) x += l;
-        else if (op == 3) return;
+    const int lane = threadIdx.x & 63;
+    BaqJob j{};
+    int cls = -1, b = 0, lq = 0, wlo = INT32_MAX, whi = 0;      // the read's class (-1: no job), band, query length, window
+    if (r < P.D.n_reads) {
+        const int l_qseq = P.D.r_lq[r], pos = P.D.r_pos[r], n_cigar = P.D.r_ncig[r];
+        const uint32_t soff = (uint32_t)P.D.r_seq_off[r], coff = (uint32_t)P.D.r_cig_off[r];
+        const uint32_t *cigar = P.D.cig + coff;
+        bool ok = !(l_qseq <= 0 || P.D.qual[soff] == 0xff || (P.D.r_flag[r] & 4));
+        int x = pos, y = 0, yb = -1, ye = -1, xb = -1, xe = -1;
+        for (int k = 0; ok && k < n_cigar; ++k) {
+            const int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
+            if (op == 0 || op == 7 || op == 8) {
+                if (yb < 0) yb = y;
+                if (xb < 0) xb = x;
+                ye = y + l; xe = x + l;
+                x += l; y += l;
+            } else if (op == 4 || op == 1) y += l;
+            else if (op == 2) x += l;
+            else if (op == 3) ok = false;
+        }
+        if (xb == -1) ok = false;
+        P.ret[r] = ok ? 0 : -1; P.has_zq[r] = ok ? 1 : 0;
+        if (ok) {
+            int bw = 7;
+            if (abs((xe - xb) - (ye - yb)) > bw) bw = abs((xe - xb) - (ye - yb)) + 3;
+            xb -= yb + bw / 2; if (xb < 0) xb = 0;
+            xe += l_qseq - ye + bw / 2;
+            if (xe - xb - l_qseq > bw) { xb += (xe - xb - l_qseq - bw) / 2; xe -= (xe - xb - l_qseq - bw) / 2; }
+            if (xe > P.ref_len) xe = P.ref_len;
+            if (xe < xb) xe = xb;
+            j.seq_off = soff; j.cig_off = coff; j.l_query = l_qseq; j.n_cigar = n_cigar; j.pos = pos;
+            j.l_ref = xe - xb; j.bw = bw; j.xb = xb; j.ret = 0; j.ref_off = (uint32_t)xb;      // (relative to the slice through P.tref - lowest xb)
+            b = j.l_ref > j.l_query ? j.l_ref : j.l_query;
+            if (b > j.bw) b = j.bw;
+            if (b < abs(j.l_ref - j.l_query)) b = abs(j.l_ref - j.l_query);
+            cls = b <= BAQ_BWM ? 0 : b <= BAQ_BWM2 ? 1 : 2;
+            lq = l_qseq;
+            if (j.l_ref > 0) { wlo = xb; whi = xe; }
+        }
     }
-    if (xb == -1) return;
-    int bw = 7;
-    if (abs((xe - xb) - (ye - yb)) > bw) bw = abs((xe - xb) - (ye - yb)) + 3;
-    xb -= yb + bw / 2; if (xb < 0) xb = 0;
-    xe += l_qseq - ye + bw / 2;
-    if (xe - xb - l_qseq > bw) { xb += (xe - xb - l_qseq - bw) / 2; xe -= (xe - xb - l_qseq - bw) / 2; }
-    if (xe > P.ref_len) xe = P.ref_len;
-    if (xe < xb) xe = xb;
-    BaqJob j;
-    j.seq_off = soff; j.cig_off = coff; j.l_query = l_qseq; j.n_cigar = n_cigar; j.pos = pos;
-    j.l_ref = xe - xb; j.bw = bw; j.xb = xb; j.ret = 0; j.ref_off = (uint32_t)xb;          // (made relative to the slice by the launch: P.tref - lowest xb)
-    P.ret[r] = 0; P.has_zq[r] = 1;
-    int b = j.l_ref > j.l_query ? j.l_ref : j.l_query;
-    if (b > j.bw) b = j.bw;
-    if (b < abs(j.l_ref - j.l_query)) b = abs(j.l_ref - j.l_query);
-    const int c = b <= BAQ_BWM ? 0 : 1;
-    const int at = atomicAdd(&P.counts[c], 1);
-    (c ? P.jobs1 : P.jobs0)[at] = j;
-    if (c) atomicMax(&P.counts[2], b);
-    atomicMax(&P.counts[3], l_qseq);
-    if (j.l_ref > 0) { atomicMin(&P.counts[4], xb); atomicMax(&P.counts[5], xe); }
+    // one atomic per wavefront and class (every lane on the two counters would queue up behind one another)
+    #pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == c);
+        if (!m) continue;
+        int base = 0;
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(&P.counts[c == 2 ? 6 : c], (int)__popcll(m));
+        base = __shfl(base, __builtin_ctzll(m));
+        if (cls == c) (c == 0 ? P.jobs0 : c == 1 ? P.jobs1 : P.jobs2)[base + (int)__popcll(m & ((1ull << lane) - 1))] = j;
+    }
+    int wb = cls == 2 ? b : 1;
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { wb = max(wb, __shfl_xor(wb, o)); lq = max(lq, __shfl_xor(lq, o)); wlo = min(wlo, __shfl_xor(wlo, o)); whi = max(whi, __shfl_xor(whi, o)); }
+    if (lane == 0) {
+        if (wb > 1) atomicMax(&P.counts[2], wb);
+        if (lq > 1) atomicMax(&P.counts[3], lq);
+        if (wlo != INT32_MAX) { atomicMin(&P.counts[4], wlo); atomicMax(&P.counts[5], whi); }
+    }
 }
 __global__ __launch_bounds__(256) void baq_ref4_kernel(const char *ref, size_t n, uint8_t *out)
 {
@@ -561,10 +644,10 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
 #else
     const bool force_scratch = false;
 #endif
-    std::vector<BaqJob> cls[2];
-    int cls_bw[2] = {1, 1};
+    std::vector<BaqJob> cls[3];
+    int cls_bw[3] = {1, 1, 1};
     for (const BaqJob &j : jobs) {
-        const int b = j.ret < 0 ? 1 : eff_bw(j), c = (b <= BAQ_BWM && !force_scratch) ? 0 : 1;
+        const int b = j.ret < 0 ? 1 : eff_bw(j), c = force_scratch ? 2 : b <= BAQ_BWM ? 0 : b <= BAQ_BWM2 ? 1 : 2;
         cls[c].push_back(j);
         if (b > cls_bw[c]) cls_bw[c] = b;
     }
@@ -591,12 +674,12 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
     P.tref = (const uint8_t*)d_tref; P.seq16 = (const uint8_t*)d_seq; P.qual = (const uint8_t*)d_qual; P.cig = (const uint32_t*)d_cig;
     P.q2p = d_q2p; P.state = (int32_t*)d_state; P.q = (uint8_t*)d_q; P.tmp = (uint8_t*)d_tmp;
     P.qual_out = (uint8_t*)d_qo; P.zq_out = (uint8_t*)d_zo;
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < 3; ++c) {
         const size_t nj = cls[c].size();
         if (!nj) continue;
-        const bool reg = c == 0;
-        P.ncell = reg ? 3 * (2 * BAQ_BWM + 3) : 3 * (2 * cls_bw[c] + 1) + 6;       // doubles per matrix row
-        const size_t per_mat = (size_t)(max_lq + 1) * P.ncell * sizeof(double);    // one matrix of one read
+        const bool reg = c < 2;
+        P.ncell = reg ? 2 * (2 * (c ? BAQ_BWM2 : BAQ_BWM) + 3) : 3 * (2 * cls_bw[c] + 1) + 6;       // doubles per matrix row
+        const size_t per_mat = (size_t)(max_lq + 2) * P.ncell * sizeof(double);    // one matrix of one read
         const size_t per_job = reg ? per_mat : 2 * per_mat;
         size_t chunk = ((size_t)2 << 30) / per_job;
         chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
@@ -613,8 +696,9 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
         for (size_t j0 = 0; j0 < nj; j0 += chunk) {
             P.n_jobs = (int)(nj - j0 < chunk ? nj - j0 : chunk);
             P.jobs = (const BaqJob*)d_jobs + j0;
-            if (reg) hipLaunchKernelGGL(baq_kernel<true>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
-            else     hipLaunchKernelGGL(baq_kernel<false>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
+            if (c == 0)      hipLaunchKernelGGL(baq_kernel<BAQ_BWM>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
+            else if (c == 1) hipLaunchKernelGGL(baq_kernel<BAQ_BWM2>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
+            else             hipLaunchKernelGGL(baq_kernel<0>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
         }
         BQ_CHK(hipGetLastError());
     }
@@ -645,16 +729,17 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
     Q.D = D; Q.ref_len = (int)strnlen(ref, (size_t)ref_len);
     Q.jobs0 = (BaqJob*)bcfgpu_internal_ws(ctx, 0, (size_t)n * sizeof(BaqJob) + 64);
     Q.jobs1 = (BaqJob*)bcfgpu_internal_ws(ctx, 3, (size_t)n * sizeof(BaqJob) + 64);
+    Q.jobs2 = (BaqJob*)bcfgpu_internal_ws(ctx, 127, (size_t)n * sizeof(BaqJob) + 64);
     Q.counts = (int*)bcfgpu_internal_ws(ctx, 115, 64);
     Q.ret = (int32_t*)bcfgpu_internal_ws(ctx, 116, (size_t)n * 4 + 64);
     Q.has_zq = (uint8_t*)bcfgpu_internal_ws(ctx, 117, (size_t)n + 64);
     uint8_t *d_qo = (uint8_t*)bcfgpu_internal_ws(ctx, D.qual == bcfgpu_internal_ws(ctx, 118, nbase + 64) ? 119 : 118, nbase + 64);   // not the buffer the pool's qualities are in now
     uint8_t *d_zo = (uint8_t*)bcfgpu_internal_ws(ctx, 120, nbase + 64);
     void *d_state = bcfgpu_internal_ws(ctx, 11, (nbase + 4) * 4), *d_q = bcfgpu_internal_ws(ctx, 12, nbase + 16), *d_tmp = bcfgpu_internal_ws(ctx, 13, 2 * nbase + 16);
-    if (!Q.jobs0 || !Q.jobs1 || !Q.counts || !Q.ret || !Q.has_zq || !d_qo || !d_zo || !d_state || !d_q || !d_tmp)
+    if (!Q.jobs0 || !Q.jobs1 || !Q.jobs2 || !Q.counts || !Q.ret || !Q.has_zq || !d_qo || !d_zo || !d_state || !d_q || !d_tmp)
         return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_baq: device workspace");
-    const int init[6] = {0, 0, 1, 1, INT32_MAX, 0};
-    int counts[6];
+    const int init[8] = {0, 0, 1, 1, INT32_MAX, 0, 0, 0};
+    int counts[8];
     BQ_CHK(hipMemcpyAsync(Q.counts, init, sizeof init, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(baq_prep_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, Q);
     BQ_CHK(hipMemcpyAsync(counts, Q.counts, sizeof counts, hipMemcpyDeviceToHost, stream));
@@ -676,12 +761,12 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
     P.seq16 = D.seq16; P.qual = D.qual; P.cig = D.cig;
     P.q2p = d_q2p; P.state = (int32_t*)d_state; P.q = (uint8_t*)d_q; P.tmp = (uint8_t*)d_tmp;
     P.qual_out = d_qo; P.zq_out = d_zo;
-    for (int c = 0; c < 2; ++c) {
-        const size_t nj = (size_t)counts[c];
+    for (int c = 0; c < 3; ++c) {
+        const size_t nj = (size_t)counts[c == 2 ? 6 : c];
         if (!nj) continue;
-        const bool reg = c == 0;
-        P.ncell = reg ? 3 * (2 * BAQ_BWM + 3) : 3 * (2 * counts[2] + 1) + 6;       // doubles per matrix row
-        const size_t per_mat = (size_t)(P.max_lq + 1) * P.ncell * sizeof(double);  // one matrix of one read
+        const bool reg = c < 2;
+        P.ncell = reg ? 2 * (2 * (c ? BAQ_BWM2 : BAQ_BWM) + 3) : 3 * (2 * counts[2] + 1) + 6;       // doubles per matrix row
+        const size_t per_mat = (size_t)(P.max_lq + 2) * P.ncell * sizeof(double);  // one matrix of one read
         const size_t per_job = reg ? per_mat : 2 * per_mat;
         size_t chunk = ((size_t)8 << 30) / per_job;                                // (8 GiB of scratch: 288 GB of HBM are there to be used)
         chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
@@ -693,9 +778,10 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
         P.F = (double*)d_F; P.B = (double*)d_B; P.S = (double*)d_S;
         for (size_t j0 = 0; j0 < nj; j0 += chunk) {
             P.n_jobs = (int)(nj - j0 < chunk ? nj - j0 : chunk);
-            P.jobs = (c ? Q.jobs1 : Q.jobs0) + j0;
-            if (reg) hipLaunchKernelGGL(baq_kernel<true>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
-            else     hipLaunchKernelGGL(baq_kernel<false>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
+            P.jobs = (c == 0 ? Q.jobs0 : c == 1 ? Q.jobs1 : Q.jobs2) + j0;
+            if (c == 0)      hipLaunchKernelGGL(baq_kernel<BAQ_BWM>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
+            else if (c == 1) hipLaunchKernelGGL(baq_kernel<BAQ_BWM2>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
+            else             hipLaunchKernelGGL(baq_kernel<0>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
         }
         BQ_CHK(hipGetLastError());
     }

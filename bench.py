@@ -291,6 +291,30 @@ def main_baq(a):
                                            "reads": int(R["n_reads"]), "bases": int(nb)},
            "whole_call_ms": t * 1e3, "note": "host pointers in and out: the time includes the window preparation on the host, "
                                              "uploads, baq_kernel and the download of the new qualities"}
+    # the same stage on the pool kept in HBM (bcfgpu_pool_upload once, then bcfgpu_pool_baq on that copy): what a caller that
+    # chains BAQ -> overlaps -> pileup on the device pays for BAQ
+    mapq = np.full(R["n_reads"], 60, np.uint8)
+
+    def run_pool():
+        check(ctx.L.bcfgpu_pool_upload(ctx.h, C.byref(rd), None, mapq.ctypes.data))
+        ctx.sync()
+        t0 = time.perf_counter()
+        check(ctx.L.bcfgpu_pool_baq(ctx.h, b["ref"], len(b["ref"]), 3, None))
+        ctx.sync()
+        return time.perf_counter() - t0
+    run_pool()
+    tpool = min(run_pool() for _ in range(max(1, a.steps // 3)))
+    qp, zp = np.zeros(nb, np.uint8), np.zeros(nb, np.uint8)
+    check(ctx.L.bcfgpu_pool_download(ctx.h, qp.ctypes.data, zp.ctypes.data, None))
+    assert np.array_equal(qp, qo) and np.array_equal(zp, zo)
+    lq = int(R["r_lq"][0])
+    scratch = 2 * (lq + 1) * 34 * 8                                 # the forward rows of a read (M and I of 17 cells): written once, read once
+    out["pool_form"] = {"stage_ms": tpool * 1e3, "value": R["n_reads"] / tpool, "unit": "reads/s",
+                        "roofline": {"bound": "hbm", "bytes_per_read": scratch + 4 * lq, "achieved": R["n_reads"] * (scratch + 4 * lq) / tpool / 1e9,
+                                     "peak": 8000.0, "unit": "GB/s", "frac": R["n_reads"] * (scratch + 4 * lq) / tpool / 8e12},
+                        "note": "bcfgpu_pool_baq on the pool in HBM (window and band per read on the device, forward rows through a "
+                                "[row][cell][read] scratch, backward rows in registers), wall time of the call incl. its one wait; results "
+                                "equal to the host-pointer call"}
     # the mate-overlap tweak over the same pool: consecutive reads of the pool taken as mates (reads of one column overlap
     # around it), whole call with host pointers; the C oracle on one core beside it, results compared
     npair = R["n_reads"] // 2
