@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget on rank 0 at N=1 (0: skip)")
     ap.add_argument("--seed", type=int, default=20260104)
     ap.add_argument("--packed", type=int, default=1, help="--mode pileup: 1 = the pool as bcfgpu_pileup_packed takes it (4-bit bases, palette qualities), 0 = a byte per base")
+    ap.add_argument("--baq", type=int, default=0, help="--mode pileup: 1 = BAQ on the pool in HBM between the upload and the pileup (bcfgpu_pool_upload -> bcfgpu_pool_baq -> bcfgpu_pool_pileup)")
     ap.add_argument("--pageable", action="store_true", help="--mode pileup: keep the read pool in ordinary (pageable) host memory")
     ap.add_argument("--cpu-all-cores", type=int, default=1, help="also time the CPU baseline on all host cores (0: skip)")
     ap.add_argument("--groups", type=int, default=1, help="snp mode: call -G with this many sample groups (frequencies from FORMAT/AD); "
@@ -522,7 +523,12 @@ def main_pileup(a):
 
     def build(ctx, tile):
         t0 = time.perf_counter()
-        if use_packed[0]:
+        if a.baq:
+            check(ctx.L.bcfgpu_pool_upload(ctx.h, C.byref(rd), C.byref(pk) if use_packed[0] else None, mapq.ctypes.data))
+            check(ctx.L.bcfgpu_pool_baq(ctx.h, ref_b, len(refseq), 3, None))
+            check(ctx.L.bcfgpu_pool_pileup(ctx.h, None if use_packed[0] else smpl.ctypes.data, pk.smpl_off if use_packed[0] else None, beg, end,
+                                           ref_b, len(refseq), C.byref(tile), None, None))
+        elif use_packed[0]:
             check(ctx.L.bcfgpu_pileup_packed(ctx.h, C.byref(rd), C.byref(pk), mapq.ctypes.data, None, beg, end, ref_b, len(refseq),
                                              C.byref(tile), None, None))
         else:
@@ -588,7 +594,8 @@ def main_pileup(a):
            "config": {"workload": "%d reads of %d bp over %d columns x %d samples" % (n, L, n_sites, S), "reads": n, "entries": entries,
                       "columns": n_sites, "pool_memory": "pageable" if a.pageable else "page-locked (bcfgpu_host_alloc)",
                       "pool_form": ("bcfgpu_pileup_packed: 4-bit bases, %d-value quality palette (4-bit), per-sample offsets" % len(palette))
-                                   if a.packed else "bcfgpu_pileup: one byte per base and per quality"},
+                                   if a.packed else "bcfgpu_pileup: one byte per base and per quality",
+                      "stages": "bcfgpu_pool_upload -> bcfgpu_pool_baq (flag 3) -> bcfgpu_pool_pileup -> bcfgpu_pipeline" if a.baq else "pileup -> bcfgpu_pipeline"},
            "whole_call_ms": tb * 1e3, "tile_written_gbs": tile_bytes / tb / 1e9,
            "pcie": {"pool_bytes": int(pool_bytes), "tile_bytes": int(tile_bytes), "pool_gbs_in_call": pool_bytes / tb / 1e9,
                     "note": "the pool is what crosses PCIe; a host-packed tile of this region would be tile_bytes"},
@@ -871,15 +878,21 @@ def main():
             ind = child(["--mode", "indel", "--steps", "4", "--cpu-seconds", "8", "--cpu-all-cores", "0", "--extras", "0", "--seed", str(a.seed)])
             mix = child(["--mode", "mixed", "--steps", "4", "--warmup", "1", "--cpu-seconds", "6", "--cpu-all-cores", "0", "--extras", "0", "--seed", str(a.seed)])
             hf = child(["--mode", "pileup", "--steps", "6", "--cpu-seconds", "0", "--cpu-all-cores", "0", "--extras", "0", "--seed", str(a.seed)])
+            hfb = child(["--mode", "pileup", "--baq", "1", "--packed", "1", "--sites", "4096", "--steps", "4", "--cpu-seconds", "0", "--cpu-all-cores", "0",
+                         "--extras", "0", "--seed", str(a.seed)])
+            bq = child(["--mode", "baq", "--steps", "6", "--cpu-seconds", "5", "--cpu-all-cores", "0", "--extras", "0", "--seed", str(a.seed)])
             out["extra"] = {
                 "configs2_mixed": {k: mix.get(k) for k in ("metric", "value", "unit", "ms_per_step", "config", "split_ms", "cpu_baseline", "error") if k in mix},
                 "host_fed_pileup": {k: hf.get(k) for k in ("metric", "value", "unit", "config", "whole_call_ms", "pcie", "host_fed_pipeline", "byte_per_base_form", "error") if k in hf},
+                "host_fed_chain_with_baq": {k: hfb.get(k) for k in ("config", "whole_call_ms", "pcie", "host_fed_pipeline", "error") if k in hfb},
+                "baq_stage": {k: bq.get(k) for k in ("metric", "value", "unit", "config", "whole_call_ms", "pool_form", "cpu_baseline", "error") if k in bq},
                 "configs4_shape": {k: c4.get(k) for k in ("value", "unit", "ms_per_step", "config", "roofline", "error") if k in c4},
                 "indel_stage": {k: ind.get(k) for k in ("metric", "value", "unit", "config", "kernel", "host_ms", "indel_pass", "host_pointer_form", "cpu_baseline", "error") if k in ind},
                 "note": "configs4_shape: the same tile through call -G (4 sample groups on FORMAT/AD) with a ploidy array (25 % haploid); "
                         "indel_stage: bcf_call_gap_prep on 500-sample indel-candidate columns (BASELINE configs[2] shape), bcfgpu_gap_prep_tile on a read pool resident in HBM; "
                         "configs2_mixed: SNP path + indel path per step at the configs[2] mix (10 % indel sites); host_fed_pileup: --mode pileup, the read "
-                        "pool crossing PCIe every region (what a user of host/bcfgpu_sam sees, DESIGN.md 5)"}
+                        "pool crossing PCIe every region (DESIGN.md 5); host_fed_chain_with_baq: the same with BAQ on the pool in HBM before the pileup (what a user of "
+                        "host/bcfgpu_sam sees with BAQ on: BAQ is the stage that bounds it); baq_stage: --mode baq (bcfgpu_baq with host pointers, bcfgpu_pool_baq on the resident pool)"}
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
