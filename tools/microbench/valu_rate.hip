@@ -20,6 +20,10 @@
     asm volatile(PRE INS " %0, %0, %8" POST "\n" PRE INS " %1, %1, %8" POST "\n" PRE INS " %2, %2, %8" POST "\n" PRE INS " %3, %3, %8" POST "\n" \
                  PRE INS " %4, %4, %8" POST "\n" PRE INS " %5, %5, %8" POST "\n" PRE INS " %6, %6, %8" POST "\n" PRE INS " %7, %7, %8" POST "\n" \
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) : "vcc", "s10", "s11")
+#define OP8_64C(INS) \
+    asm volatile(INS " %0, %8, %0\n" INS " %1, %8, %1\n" INS " %2, %8, %2\n" INS " %3, %8, %3\n" \
+                 INS " %4, %8, %4\n" INS " %5, %8, %5\n" INS " %6, %8, %6\n" INS " %7, %8, %7\n" \
+                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(c))
 #define OP8_FMT(F0, F1, F2, F3, F4, F5, F6, F7) \
     asm volatile(F0 "\n" F1 "\n" F2 "\n" F3 "\n" F4 "\n" F5 "\n" F6 "\n" F7 "\n" \
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(c) \
@@ -107,6 +111,25 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned *out, int reps, unsi
                                     "v_cndmask_b32_e64 %4, %4, %8, s[10:11]", "v_add_u32 %5, %5, %8", "v_add_u32 %6, %6, %8", "v_add_u32 %7, %7, %8");
             if (KIND == 76) OP8_FMT("v_cndmask_b32_e32 %0, %0, %8, vcc", "v_cndmask_b32_e32 %1, %8, %1, vcc", "v_cndmask_b32_e32 %2, %2, %8, vcc", "v_cndmask_b32_e32 %3, %8, %3, vcc",
                                     "v_cndmask_b32_e32 %4, %4, %8, vcc", "v_cndmask_b32_e32 %5, %8, %5, vcc", "v_cndmask_b32_e32 %6, %6, %8, vcc", "v_cndmask_b32_e32 %7, %8, %7, vcc");
+            if (KIND == 80) OP8_64C("v_lshlrev_b64");
+            if (KIND == 81) OP8_64C("v_lshrrev_b64");
+            if (KIND == 82) OP8_FMT("v_ffbh_u32 %0, %0", "v_ffbh_u32 %1, %1", "v_ffbh_u32 %2, %2", "v_ffbh_u32 %3, %3", "v_ffbh_u32 %4, %4", "v_ffbh_u32 %5, %5", "v_ffbh_u32 %6, %6", "v_ffbh_u32 %7, %7");
+            if (KIND == 83) OP8_FMT("v_ffbl_b32 %0, %0", "v_ffbl_b32 %1, %1", "v_ffbl_b32 %2, %2", "v_ffbl_b32 %3, %3", "v_ffbl_b32 %4, %4", "v_ffbl_b32 %5, %5", "v_ffbl_b32 %6, %6", "v_ffbl_b32 %7, %7");
+            if (KIND == 84) OP8_FMT("v_readlane_b32 s10, %0, 3", "v_readlane_b32 s11, %1, 3", "v_readlane_b32 s12, %2, 3", "v_readlane_b32 s13, %3, 3",
+                                    "v_readlane_b32 s14, %4, 3", "v_readlane_b32 s15, %5, 3", "v_readlane_b32 s16, %6, 3", "v_readlane_b32 s17, %7, 3");
+            if (KIND == 85) OP8_FMT("v_writelane_b32 %0, s10, 3", "v_writelane_b32 %1, s10, 3", "v_writelane_b32 %2, s10, 3", "v_writelane_b32 %3, s10, 3",
+                                    "v_writelane_b32 %4, s10, 3", "v_writelane_b32 %5, s10, 3", "v_writelane_b32 %6, s10, 3", "v_writelane_b32 %7, s10, 3");
+            if (KIND == 86) OP8_64("v_fma_f64 %0, %0, %8, %8\n;");
+            if (KIND == 88) OP8_32("v_fmac_f32");
+            if (KIND == 89) OP8_3("v_dot4_u32_u8");
+            if (KIND == 90) OP8_32("v_pk_add_u16 %0, %0, %8\n;");
+            if (KIND == 91) OP8_3("v_pk_mad_u16");
+            if (KIND == 92) OP8_32("v_mul_hi_u32");
+            if (KIND == 93) OP8_FMT("v_rcp_f32 %0, %0", "v_rcp_f32 %1, %1", "v_rcp_f32 %2, %2", "v_rcp_f32 %3, %3", "v_rcp_f32 %4, %4", "v_rcp_f32 %5, %5", "v_rcp_f32 %6, %6", "v_rcp_f32 %7, %7");
+            if (KIND == 94) OP8_FMT("v_mbcnt_lo_u32_b32 %0, %8, %0", "v_mbcnt_lo_u32_b32 %1, %8, %1", "v_mbcnt_lo_u32_b32 %2, %8, %2", "v_mbcnt_lo_u32_b32 %3, %8, %3",
+                                    "v_mbcnt_lo_u32_b32 %4, %8, %4", "v_mbcnt_lo_u32_b32 %5, %8, %5", "v_mbcnt_lo_u32_b32 %6, %8, %6", "v_mbcnt_lo_u32_b32 %7, %8, %7");
+            if (KIND == 95) OP8_FMT("v_mov_b32_dpp %0, %0 row_shr:1", "v_mov_b32_dpp %1, %1 row_shr:1", "v_mov_b32_dpp %2, %2 row_shr:1", "v_mov_b32_dpp %3, %3 row_shr:1",
+                                    "v_mov_b32_dpp %4, %4 row_shr:1", "v_mov_b32_dpp %5, %5 row_shr:1", "v_mov_b32_dpp %6, %6 row_shr:1", "v_mov_b32_dpp %7, %7 row_shr:1");
             if (KIND == 18) OP8_3("v_and_or_b32");
             if (KIND == 19) OP8_3("v_lshl_add_u32");
             if (KIND == 20) OP8_3("v_add3_u32");
@@ -202,8 +225,6 @@ int main(int argc, char **argv)
     run<67>("mul24 chain of 2", d_out, n, ghz);
     run<62>("cmp>cnd vcc noWAR", d_out, n, ghz);
     run<63>("cmp,add noWAR", d_out, n, ghz);
-    run<65>("mul24,add WAR", d_out, n, ghz);
-    run<68>("mul24,add indep", d_out, n, ghz);
     run<66>("cmp,3add,cnd,3add", d_out, n, ghz);
     run<70>("s_and>cnd sgpr", d_out, n, ghz);
     run<72>("cmp, 7 cnd vcc", d_out, n, ghz);
@@ -231,6 +252,21 @@ int main(int argc, char **argv)
     run<29>("v_fma_f32", d_out, n, ghz);
     run<30>("v_mul_f32", d_out, n, ghz);
     run<34>("v_cvt_f32_u32", d_out, n, ghz);
+    run<88>("v_fmac_f32", d_out, n, ghz);
+    run<89>("v_dot4_u32_u8", d_out, n, ghz);
+    run<90>("v_pk_add_u16", d_out, n, ghz);
+    run<91>("v_pk_mad_u16", d_out, n, ghz);
+    run<92>("v_mul_hi_u32", d_out, n, ghz);
+    run<93>("v_rcp_f32", d_out, n, ghz);
+    run<94>("v_mbcnt_lo", d_out, n, ghz);
+    run<95>("v_mov_b32_dpp", d_out, n, ghz);
+    run<82>("v_ffbh_u32", d_out, n, ghz);
+    run<83>("v_ffbl_b32", d_out, n, ghz);
+    run<84>("v_readlane_b32", d_out, n, ghz);
+    run<85>("v_writelane_b32", d_out, n, ghz);
+    run<80>("v_lshlrev_b64", d_out, n, ghz);
+    run<81>("v_lshrrev_b64", d_out, n, ghz);
+    run<86>("v_fma_f64", d_out, n, ghz);
     run<3>("v_add_f64", d_out, n, ghz);
     run<4>("v_mul_f64", d_out, n, ghz);
     return 0;
