@@ -136,6 +136,44 @@ def test_pool_chain_matches_the_host_pointer_chain(golden_dir, gpu_ctx_factory, 
     assert len(want.rd) > 1000
 
 
+def test_empty_pool_and_keep_reset(gpu_ctx_factory):
+    """A pool without reads goes through every stage and gives an empty tile; bcfgpu_pool_keep(NULL) lets every read in again."""
+    ctx = gpu_ctx_factory(abi.default_cfg(3, max_sites=1, max_reads=64))
+    L = ctx.L
+    rd = abi.Reads()
+    check(L.bcfgpu_pool_upload(ctx.h, C.byref(rd), None, None))
+    check(L.bcfgpu_pool_baq(ctx.h, b"ACGTACGT", 8, 3, None))
+    check(L.bcfgpu_pool_overlap_tweak(ctx.h, 0, None, None))
+    t = abi.Tile()
+    col_n = np.ones(8, np.int32)
+    check(L.bcfgpu_pool_pileup(ctx.h, None, None, 0, 8, b"ACGTACGT", 8, C.byref(t), col_n.ctypes.data, None))
+    assert t.n_reads == 0 and t.n_sites == 8 and not col_n.any()
+    # a small pool: one read per sample; dropping a read by the mask and letting it in again
+    rng = np.random.default_rng(4)
+    from tests.helpers import ovlfuzz
+    by_sample = [[ovlfuzz.make_read(rng, 2 + s, 40)] for s in range(3)]
+    for rl in by_sample:
+        for r in rl:
+            r.mapq, r.flag = 50, 0
+    reads = [r for rl in by_sample for r in rl]
+    rd2, d2 = M.pack_reads(reads)
+    mapq = np.full(3, 50, np.uint8)
+    smpl = np.arange(3, dtype=np.int32)
+    refseq = "ACGT" * 30
+    check(L.bcfgpu_pool_upload(ctx.h, C.byref(rd2), None, mapq.ctypes.data))
+    full, n_full, _, _ = device_pileup(ctx, by_sample, refseq, 0, 80)
+    check(L.bcfgpu_pool_upload(ctx.h, C.byref(rd2), None, mapq.ctypes.data))
+    keep = np.array([1, 0, 1], np.uint8)
+    check(L.bcfgpu_pool_keep(ctx.h, keep.ctypes.data))
+    cn = np.zeros(80, np.int32)
+    check(L.bcfgpu_pool_pileup(ctx.h, smpl.ctypes.data, None, 0, 80, refseq.encode(), len(refseq), C.byref(t), cn.ctypes.data, None))
+    assert 0 < cn.sum() < n_full.sum()
+    check(L.bcfgpu_pool_keep(ctx.h, None))
+    check(L.bcfgpu_pool_pileup(ctx.h, smpl.ctypes.data, None, 0, 80, refseq.encode(), len(refseq), C.byref(t), cn.ctypes.data, None))
+    np.testing.assert_array_equal(cn, n_full)
+    assert_tiles_equal(_tile_of(ctx, t, 80, 3), full)
+
+
 def test_pool_stages_need_a_pool(gpu_ctx_factory):
     ctx = gpu_ctx_factory(abi.default_cfg(2, max_sites=1, max_reads=64))
     t = abi.Tile()
