@@ -186,7 +186,9 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
     // apart, every one on a DRAM page and a TLB entry of its own: 1.8 TB/s.)  M and I only: the posterior never reads D.
     const size_t wbase = (size_t)(job >> 6) * (size_t)(P.max_lq + 2);
     const int wl = job & 63;
-    #define FR(i, p, s_) P.F[((wbase + (size_t)(i)) * (NP * 2) + (size_t)((p) * 2 + (s_))) * 64 + wl]
+    // (M and I of a cell side by side in a lane's 16 bytes: one dwordx4 store / load per cell -- the phase is bound by the
+    // issue of its vector-memory instructions, and there are half as many this way)
+    #define FR2(i, p) reinterpret_cast<double2*>(P.F)[((wbase + (size_t)(i)) * NP + (size_t)(p)) * 64 + wl]
     #define SC(i) P.S[(wbase + (size_t)(i)) * 64 + wl]
     const int bw2 = bw * 2 + 1;
     const double d = 0.001, e_ = 0.1;
@@ -228,7 +230,7 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
         #pragma unroll
         for (int p = 1; p < NP; ++p) {
             if (p >= 2 && p - 1 <= end) { M[p] /= sum; I[p] /= sum; D[p] /= sum; }
-            FR(1, p, 0) = M[p]; FR(1, p, 1) = I[p];
+            FR2(1, p) = make_double2(M[p], I[p]);
         }
     }
     int x = 0;
@@ -278,7 +280,7 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
         #pragma unroll
         for (int p = 1; p < NP; ++p) {
             M[p] *= r; I[p] *= r; D[p] *= r;
-            FR(i, p, 0) = M[p]; FR(i, p, 1) = I[p];
+            FR2(i, p) = make_double2(M[p], I[p]);
         }
     }
     {
@@ -290,9 +292,6 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
             if (p >= plo && p <= phi) sum += M[p] * sM + I[p] * sI;
         SC(l_query + 1) = sum;
     }
-#ifdef BAQ_EXP_SKIP_BWD
-    if (l_query > 0) return;
-#endif
     // ---- backward with the posterior maximum of every row ----
     // x is max(0, l_query - bw) here.  Row l_query:
     {
@@ -315,7 +314,8 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
     // before it (i + 1) is being worked on: the forward values of row i - 1 right after row i's posterior has consumed its own.
     double fr0[NP], fr1[NP];
     #pragma unroll
-    for (int p = 1; p < NP; ++p) { fr0[p] = FR(l_query, p, 0); fr1[p] = FR(l_query, p, 1); }
+    for (int p = 1; p < NP; ++p) { const double2 t = FR2(l_query, p); fr0[p] = t.x; fr1[p] = t.y; }
+
     uint32_t bq_n = 0, bs_n = 0, br_n = 0;                // bytes of row l_query - 1
     double sc_n = 1.;
     {
@@ -382,7 +382,7 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
             {   // the forward values of row i - 1
                 const int i1 = i > 1 ? i - 1 : 1;
                 #pragma unroll
-                for (int p = 1; p < NP; ++p) { fr0[p] = FR(i1, p, 0); fr1[p] = FR(i1, p, 1); }
+                for (int p = 1; p < NP; ++p) { const double2 t = FR2(i1, p); fr0[p] = t.x; fr1[p] = t.y; }
             }
             max /= sum;
             state[i - 1] = max_k;
@@ -390,7 +390,7 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
             q[i - 1] = (uint8_t)(kq > 100 ? 99 : kq);
         }
     }
-    #undef FR
+    #undef FR2
     #undef SC
 }
 
@@ -459,8 +459,11 @@ __device__ void baq_cap(const BaqParams &P, const BaqJob &j, const uint8_t *iqua
 #define BAQ_BWM 7
 #define BAQ_BWM2 8
 
+#ifndef BAQ_WAVES
+#define BAQ_WAVES 2          // wavefronts per SIMD the register rows allow; 3 and 4 (spills, or without the one-row-ahead loads): 1.4x - 2.3x slower
+#endif
 template <int BWM>          // 0: both matrices in scratch, any band
-__global__ __launch_bounds__(64) void baq_kernel(const BaqParams P)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAQ_WAVES, 8))) void baq_kernel(const BaqParams P)
 {
     __shared__ float s_q2p[256];
     for (int t = threadIdx.x; t < 256; t += 64) s_q2p[t] = P.q2p[t];
@@ -483,9 +486,7 @@ __global__ __launch_bounds__(64) void baq_kernel(const BaqParams P)
         if (bw < abs(j.l_ref - j.l_query)) bw = abs(j.l_ref - j.l_query);
         baq_fb_reg<(BWM > 0 ? BWM : 1)>(P, job, j, ref, seq, iqual, bw, state, q, s_q2p);
     } else baq_fb_scratch(P, job, j, ref, seq, iqual, state, q);
-#ifndef BAQ_EXP_SKIP_CAP
     baq_cap(P, j, iqual, state, q, qout, zout);
-#endif
 }
 
 // ---- the same stage on the pool bcfgpu_pool_upload left in HBM: the host half above as a kernel ----
