@@ -290,7 +290,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             for (int j = 0; j < 4; ++j) gnx[j] = j < rem ? GRP_OF(s + j) : 0;
         };
         fetch_ad(0);
-        for (int base = 0; base < S; base += SB) {
+        for (int base = 0; base < (BCFGPU_ABL(P, 128) ? 0 : S); base += SB) {
             const int cn = min(SB, S - base);
             __syncthreads();
             int xc[5][4], gcur[4];
