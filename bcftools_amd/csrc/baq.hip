@@ -734,7 +734,8 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
     Q.counts = (int*)bcfgpu_internal_ws(ctx, 115, 64);
     Q.ret = (int32_t*)bcfgpu_internal_ws(ctx, 116, (size_t)n * 4 + 64);
     Q.has_zq = (uint8_t*)bcfgpu_internal_ws(ctx, 117, (size_t)n + 64);
-    uint8_t *d_qo = (uint8_t*)bcfgpu_internal_ws(ctx, D.qual == bcfgpu_internal_ws(ctx, 118, nbase + 64) ? 119 : 118, nbase + 64);   // not the buffer the pool's qualities are in now
+    const int qo_slot = D.qual_slot == 118 ? 119 : 118;                 // not the buffer the pool's qualities are in now
+    uint8_t *d_qo = (uint8_t*)bcfgpu_internal_ws(ctx, qo_slot, nbase + 64);
     uint8_t *d_zo = (uint8_t*)bcfgpu_internal_ws(ctx, 120, nbase + 64);
     void *d_state = bcfgpu_internal_ws(ctx, 11, (nbase + 4) * 4), *d_q = bcfgpu_internal_ws(ctx, 12, nbase + 16), *d_tmp = bcfgpu_internal_ws(ctx, 13, 2 * nbase + 16);
     if (!Q.jobs0 || !Q.jobs1 || !Q.jobs2 || !Q.counts || !Q.ret || !Q.has_zq || !d_qo || !d_zo || !d_state || !d_q || !d_tmp)
@@ -790,7 +791,7 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
         BQ_CHK(hipMemcpyAsync(ret, Q.ret, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
         BQ_CHK(hipStreamSynchronize(stream));
     }
-    D.qual = d_qo; D.zq = d_zo; D.r_has_zq = Q.has_zq;
+    D.qual = d_qo; D.qual_slot = qo_slot; D.zq = d_zo; D.r_has_zq = Q.has_zq;
     return BCFGPU_OK;
 }
 

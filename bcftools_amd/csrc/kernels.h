@@ -126,6 +126,7 @@ struct DevPool {
     uint8_t *zq, *r_has_zq;          // the "ZQ" bytes bcfgpu_pool_baq left and which reads have them; NULL before
     uint8_t *keep;                   // [n_reads] 0 = the read does not enter the pileup (bcfgpu_pool_keep); NULL = all do
     int ext_valid, ext_lo, ext_hi;   // [lowest start, highest end) of the reads on the reference, once something asked for it
+    int qual_slot;                   // the workspace slot `qual` lives in (bcfgpu_pool_baq writes the new qualities to another one)
 };
 
 // ---- bcf_call_gap_prep on the device (gap_prep.hip, indel.hip) ----

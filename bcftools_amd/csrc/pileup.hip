@@ -567,7 +567,7 @@ static int pool_upload_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads
         d_seq16 = (uint8_t*)up(28, rd->seq16, nbase);
         d_qual = (uint8_t*)up(29, rd->qual, nbase);
     }
-    D.seq16 = d_seq16; D.qual = d_qual;
+    D.seq16 = d_seq16; D.qual = d_qual; D.qual_slot = 29;
     if (!D.r_pos || !D.r_lq || !D.r_flag || !D.r_ncig || !D.r_cig_off || !D.r_seq_off || !D.r_mapq || !D.cig || !D.seq16 || !D.qual)
         return fail(BCFGPU_E_NOMEM, "device workspace");
     if (hipGetLastError() != hipSuccess) return fail(BCFGPU_E_HIP, "launch");
