@@ -192,6 +192,29 @@ def test_packed_pool_and_interleaved_samples_give_the_same_tile(gpu_ctx_factory)
         assert_tiles_equal(got, want)
 
 
+def test_pileup_of_a_deep_region(gpu_ctx_factory):
+    """Sixteen samples with 45 reads each over the same columns: a workgroup's 16 x 16 cells hold more entries than its LDS
+    staging takes (the lanes then store straight to the tile), next to shallow columns that are staged."""
+    rng = np.random.default_rng(33)
+    S, L = 16, 300
+    refseq = "".join("ACGT"[i] for i in rng.integers(0, 4, L))
+    by_sample = []
+    for s in range(S):
+        rl = [ovlfuzz.make_read(rng, rng.integers(0, 6), int(rng.integers(50, 70))) for _ in range(45)]
+        rl += [ovlfuzz.make_read(rng, rng.integers(100, 200), int(rng.integers(30, 60))) for _ in range(6)]
+        for r in rl:
+            r.mapq = int(rng.integers(0, 61))
+            r.flag = int(rng.choice([0, 16]))
+        rl.sort(key=lambda r: r.pos)
+        by_sample.append(rl)
+    ctx = gpu_ctx_factory(abi.default_cfg(S, max_sites=1, max_reads=64))
+    got, col_n, col_indel, _ = device_pileup(ctx, by_sample, refseq, 0, L)
+    want, want_indel = host_pileup(by_sample, refseq, 0, L)
+    assert_tiles_equal(got, want)
+    np.testing.assert_array_equal(col_indel, want_indel)
+    assert int(want.plp_off[16 * S] - want.plp_off[0]) > 9216                    # the first 16 columns: past the staging capacity
+
+
 def test_pileup_from_a_page_locked_pool(gpu_ctx_factory):
     """bcfgpu_host_alloc: the read pool in page-locked memory (what a caller parses into to make the uploads DMA transfers)
     gives the tile of the same pool in ordinary memory; two contexts used alternately, as bench.py --mode pileup does."""
