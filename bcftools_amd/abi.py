@@ -97,7 +97,7 @@ class Reads(C.Structure):
 class Packed(C.Structure):
     """bcfgpu_packed: the pool as BAM records hold it (4-bit bases, optional 4-bit palette qualities)."""
     _fields_ = [("seq4", C.c_void_p), ("qual4", C.c_void_p), ("palette", C.c_uint8 * 16), ("n_bases", C.c_int64), ("n_cig", C.c_int64),
-                ("smpl_off", C.c_void_p)]
+                ("smpl_off", C.c_void_p), ("qual_bits", C.c_int32)]
 
 
 def pack_nibbles(a):
@@ -107,6 +107,15 @@ def pack_nibbles(a):
     if a.size & 1:
         a = np.concatenate([a, np.zeros(1, np.uint8)])
     return ((a[0::2] << 4) | (a[1::2] & 15)).astype(np.uint8)
+
+
+def pack_crumbs(a):
+    """Four 2-bit values per byte, index 0 in the two highest bits; lengths padded to a multiple of four with 0."""
+    import numpy as np
+    a = np.asarray(a, np.uint8)
+    if a.size & 3:
+        a = np.concatenate([a, np.zeros(4 - (a.size & 3), np.uint8)])
+    return ((a[0::4] << 6) | ((a[1::4] & 3) << 4) | ((a[2::4] & 3) << 2) | (a[3::4] & 3)).astype(np.uint8)
 
 
 class IndelIn(C.Structure):

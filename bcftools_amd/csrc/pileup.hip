@@ -434,10 +434,21 @@ __global__ __launch_bounds__(256) void pool_extent_kernel(const DevPool D, int *
 // The pool as BAM records hold it (two 4-bit base codes per byte, high nibble first) and qualities as palette indices, to the
 // one-byte-per-base arrays every kernel of the host-fed stages reads.  A lane per four input bytes = eight bases.
 __global__ __launch_bounds__(256) void pileup_unpack_kernel(const uint8_t *seq4, const uint8_t *qual4, unsigned long long pal_lo,
-                                                            unsigned long long pal_hi, size_t n_in, uint8_t *seq16, uint8_t *qual)
+                                                            unsigned long long pal_hi, size_t n_in, uint8_t *seq16, uint8_t *qual, int qual_bits)
 {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (4 * t >= n_in) return;
+    if (qual4 && qual_bits == 2) {               // four indices per byte: this lane's eight bases are two input bytes
+        const uint32_t v = *reinterpret_cast<const uint16_t*>(qual4 + 2 * t);
+        uint32_t lo = 0, hi = 0;
+        #pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            lo |= (uint32_t)((pal_lo >> (8 * ((v >> (6 - 2 * b)) & 3))) & 0xff) << (8 * b);
+            hi |= (uint32_t)((pal_lo >> (8 * ((v >> (14 - 2 * b)) & 3))) & 0xff) << (8 * b);
+        }
+        *reinterpret_cast<uint2*>(qual + 8 * t) = make_uint2(lo, hi);
+        qual4 = nullptr;
+    }
     if (seq4) {
         const uint32_t v = *reinterpret_cast<const uint32_t*>(seq4 + 4 * t);
         uint32_t lo = 0, hi = 0;
@@ -510,7 +521,8 @@ static int pool_upload_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads
 {
     auto fail = [&](int code, const char *what) { char msg[160]; snprintf(msg, sizeof msg, "%s: %s", who, what); return bcfgpu_set_error(code, msg); };
     if (!ctx || !rd || rd->n_reads < 0 || (rd->n_reads && !r_mapq)) return fail(BCFGPU_E_ARG, "bad arguments");
-    if (pk && (!pk->seq4 || pk->n_bases < 0 || pk->n_cig < 0 || (pk->n_bases >> 32))) return fail(BCFGPU_E_ARG, "bad packed pool");
+    if (pk && (!pk->seq4 || pk->n_bases < 0 || pk->n_cig < 0 || (pk->n_bases >> 32) || (pk->qual_bits != 0 && pk->qual_bits != 2 && pk->qual_bits != 4)))
+        return fail(BCFGPU_E_ARG, "bad packed pool");
     hipStream_t stream = nullptr;
     if (bcfgpu_internal_device(ctx, &stream, nullptr)) return fail(BCFGPU_E_ARG, "bad context");
     DevPool &D = *static_cast<DevPool*>(bcfgpu_internal_pool_state(ctx));
@@ -555,14 +567,14 @@ static int pool_upload_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads
         const size_t n_in = (nbase + 1) / 2;
         d_seq16 = (uint8_t*)bcfgpu_internal_ws(ctx, 28, nbase + 64);
         const uint8_t *d_seq4 = (const uint8_t*)up(111, pk->seq4, n_in), *d_qual4 = nullptr;
-        if (pk->qual4) { d_qual = (uint8_t*)bcfgpu_internal_ws(ctx, 29, nbase + 64); d_qual4 = (const uint8_t*)up(112, pk->qual4, n_in); }
+        if (pk->qual4) { d_qual = (uint8_t*)bcfgpu_internal_ws(ctx, 29, nbase + 64); d_qual4 = (const uint8_t*)up(112, pk->qual4, pk->qual_bits == 2 ? (nbase + 3) / 4 : n_in); }
         else d_qual = (uint8_t*)up(29, rd->qual, nbase);
         if (!d_seq4 || (pk->qual4 && !d_qual4) || !d_seq16 || !d_qual) return fail(BCFGPU_E_NOMEM, "device workspace");
         unsigned long long pal[2] = {0, 0};
         std::memcpy(pal, pk->palette, 16);
         const size_t nthreads = (n_in + 3) / 4;
         if (nthreads) hipLaunchKernelGGL(pileup_unpack_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream,
-                                         d_seq4, d_qual4, pal[0], pal[1], n_in, d_seq16, d_qual);
+                                         d_seq4, d_qual4, pal[0], pal[1], n_in, d_seq16, d_qual, (int)pk->qual_bits);
     } else {
         d_seq16 = (uint8_t*)up(28, rd->seq16, nbase);
         d_qual = (uint8_t*)up(29, rd->qual, nbase);

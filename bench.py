@@ -485,7 +485,8 @@ def main_pileup(a):
     pool_bytes = sum(v.nbytes for v in arrs.values()) + mapq.nbytes + smpl.nbytes
     # the same pool as BAM records hold it: two bases per byte, the (binned) qualities as palette indices, the samples' offsets
     palette = np.unique(arrs["qual"])
-    packed_arrs = dict(seq4=abi.pack_nibbles(seq), qual4=abi.pack_nibbles(np.searchsorted(palette, arrs["qual"])),
+    qual_bits = 2 if len(palette) <= 4 else 4
+    packed_arrs = dict(seq4=abi.pack_nibbles(seq), qual4=(abi.pack_crumbs if qual_bits == 2 else abi.pack_nibbles)(np.searchsorted(palette, arrs["qual"])),
                        smpl_off=(np.arange(S + 1, dtype=np.int64) * per).astype(np.int32))
     packed_bytes = (sum(v.nbytes for k, v in arrs.items() if k not in ("seq16", "qual", "zq", "r_has_zq")) + mapq.nbytes
                     + sum(v.nbytes for v in packed_arrs.values()))
@@ -511,7 +512,7 @@ def main_pileup(a):
         setattr(rd, k, v.ctypes.data)
     pk = abi.Packed()
     pk.seq4, pk.qual4, pk.smpl_off = (packed_arrs[k].ctypes.data for k in ("seq4", "qual4", "smpl_off"))
-    pk.n_bases, pk.n_cig = n * L, len(cig)
+    pk.n_bases, pk.n_cig, pk.qual_bits = n * L, len(cig), qual_bits
     for j, q in enumerate(palette):
         pk.palette[j] = int(q)
     # size the contexts from a first build
@@ -593,7 +594,7 @@ def main_pileup(a):
            "value": entries / tb, "unit": "entries/s", "n_gpus": 1, "higher_is_better": True, "dtype": "u32/u8 records", "data": "synthetic",
            "config": {"workload": "%d reads of %d bp over %d columns x %d samples" % (n, L, n_sites, S), "reads": n, "entries": entries,
                       "columns": n_sites, "pool_memory": "pageable" if a.pageable else "page-locked (bcfgpu_host_alloc)",
-                      "pool_form": ("bcfgpu_pileup_packed: 4-bit bases, %d-value quality palette (4-bit), per-sample offsets" % len(palette))
+                      "pool_form": ("bcfgpu_pileup_packed: 4-bit bases, %d-value quality palette (%d-bit), per-sample offsets" % (len(palette), qual_bits))
                                    if a.packed else "bcfgpu_pileup: one byte per base and per quality",
                       "stages": "bcfgpu_pool_upload -> bcfgpu_pool_baq (flag 3) -> bcfgpu_pool_pileup -> bcfgpu_pipeline" if a.baq else "pileup -> bcfgpu_pipeline"},
            "whole_call_ms": tb * 1e3, "tile_written_gbs": tile_bytes / tb / 1e9,

@@ -391,6 +391,9 @@ typedef struct {
     uint8_t palette[16];
     int64_t n_bases, n_cig;
     const int32_t *smpl_off;
+    int32_t qual_bits;           /* bits per palette index in qual4: 0 or 4 = two per byte (above); 2 = four per byte, index i of a
+                                    byte in bits 7-2i..6-2i (the first base highest; a palette of <= 4 values: the four bins of
+                                    current sequencers); reads then start at multiples of four bases when copied bytewise */
 } bcfgpu_packed;
 
 int  bcfgpu_pileup_packed(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const bcfgpu_packed *pk, const uint8_t *r_mapq,

@@ -38,7 +38,12 @@ def device_pileup(ctx, reads_by_sample, refseq, beg, end, packed=None, order=Non
         if "qual" in packed:
             pal = np.unique(d["qual"])
             assert len(pal) <= 16
-            qual4 = abi.pack_nibbles(np.searchsorted(pal, d["qual"]))
+            if "qual2" in packed:
+                assert len(pal) <= 4
+                qual4 = abi.pack_crumbs(np.searchsorted(pal, d["qual"]))
+                pk.qual_bits = 2
+            else:
+                qual4 = abi.pack_nibbles(np.searchsorted(pal, d["qual"]))
             pk.qual4 = qual4.ctypes.data
             for j, q in enumerate(pal):
                 pk.palette[j] = int(q)
@@ -190,6 +195,14 @@ def test_packed_pool_and_interleaved_samples_give_the_same_tile(gpu_ctx_factory)
     for packed in (None, "seq+qual"):
         got, _, _, _ = device_pileup(ctx, by_sample, refseq, 0, L + 20, packed=packed, order=order)
         assert_tiles_equal(got, want)
+    # four quality values (the bins of current sequencers): two bits per quality
+    for rl in by_sample:
+        for r in rl:
+            r.qual = np.array([2, 12, 23, 37], np.uint8)[r.qual % 4]
+    want4, _ = host_pileup(by_sample, refseq + "N" * 100, 0, L + 20)
+    for packed in ("seq+qual2", "seq+qual2+off"):
+        got, _, _, _ = device_pileup(ctx, by_sample, refseq, 0, L + 20, packed=packed)
+        assert_tiles_equal(got, want4)
 
 
 def test_pileup_of_a_deep_region(gpu_ctx_factory):
