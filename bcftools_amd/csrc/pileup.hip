@@ -409,7 +409,9 @@ __global__ __launch_bounds__(256) void pileup_meta_kernel(const MetaParams M)
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { span = max(span, __shfl_xor(span, o)); bad |= __shfl_xor(bad, o); }
     if ((threadIdx.x & 63) == 0) {
-        if (span > 1) atomicMax(&M.status[0], span);
+        // (the maximum only grows: a wavefront that does not raise what is there already stays away from the word -- 77 000
+        // wavefronts queueing on one address were most of this kernel's time)
+        if (span > 1 && span > *reinterpret_cast<volatile int*>(&M.status[0])) atomicMax(&M.status[0], span);
         if (bad) atomicOr(&M.status[1], bad);
     }
 }
@@ -702,7 +704,7 @@ static int pool_pileup_impl(const char *who, bcfgpu_ctx *ctx, const int32_t *r_s
         unsigned long long *d_tot64 = (unsigned long long*)bcfgpu_internal_ws(ctx, 34, 64);
         if (!d_tot64) return fail(BCFGPU_E_NOMEM, "device workspace");
         PL_CHK(hipMemsetAsync(d_tot64, 0, 8, stream));
-        hipLaunchKernelGGL(count_total_kernel, dim3((unsigned)std::min<size_t>((ncells + 4095) / 4096, 65535)), dim3(256), 0, stream, d_cnt, ncells, d_tot64);
+        hipLaunchKernelGGL(count_total_kernel, dim3((unsigned)std::min<size_t>((ncells + 4095) / 4096, 1024)), dim3(256), 0, stream, d_cnt, ncells, d_tot64);   // (one atomic per wavefront on one word: few, long-running workgroups)
         // plp_off = exclusive prefix sum of the counts (in place, one element past the end for the total)
         size_t tmp_bytes = 0;
         PL_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_cnt, (int)(ncells + 1), stream));
