@@ -18,6 +18,7 @@ struct bcfgpu_ctx;
 int bcfgpu_set_error(int code, const char *what);
 extern "C" int bcfgpu_internal_device(bcfgpu_ctx *ctx, hipStream_t *stream, const float **q2p);
 extern "C" void *bcfgpu_internal_ws(bcfgpu_ctx *ctx, int slot, size_t bytes);
+extern "C" void *bcfgpu_internal_pinned(bcfgpu_ctx *ctx, int slot, size_t bytes);
 
 namespace bcfgpu {
 
@@ -754,7 +755,11 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
     uint8_t *d_ref4 = (uint8_t*)bcfgpu_internal_ws(ctx, 7, (size_t)(hi - lo) + 64);
     if (!d_refc || !d_ref4) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_baq: device workspace");
     if (hi > lo) {
-        BQ_CHK(hipMemcpyAsync(d_refc, ref + lo, (size_t)(hi - lo), hipMemcpyHostToDevice, stream));
+        // (through the context's page-locked staging buffer: the call returns with the copy in flight, `ref` is the caller's)
+        char *h_ref = (char*)bcfgpu_internal_pinned(ctx, 6, (size_t)(hi - lo));
+        if (!h_ref) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_baq: host staging");
+        std::memcpy(h_ref, ref + lo, (size_t)(hi - lo));
+        BQ_CHK(hipMemcpyAsync(d_refc, h_ref, (size_t)(hi - lo), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(baq_ref4_kernel, dim3((unsigned)(((size_t)(hi - lo) + 255) / 256)), dim3(256), 0, stream, d_refc, (size_t)(hi - lo), d_ref4);
     }
     BaqParams P{};

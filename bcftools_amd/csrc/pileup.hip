@@ -523,6 +523,9 @@ static int pool_upload_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads
 {
     auto fail = [&](int code, const char *what) { char msg[160]; snprintf(msg, sizeof msg, "%s: %s", who, what); return bcfgpu_set_error(code, msg); };
     if (!ctx || !rd || rd->n_reads < 0 || (rd->n_reads && !r_mapq)) return fail(BCFGPU_E_ARG, "bad arguments");
+    if (rd->n_reads && (!rd->r_pos || !rd->r_lq || !rd->r_flag || !rd->r_ncig || !rd->r_cig_off || !rd->r_seq_off ||
+                        (!pk && !rd->seq16) || (!(pk && pk->qual4) && !rd->qual)))
+        return fail(BCFGPU_E_ARG, "a read array is missing");
     if (pk && (!pk->seq4 || pk->n_bases < 0 || pk->n_cig < 0 || (pk->n_bases >> 32) || (pk->qual_bits != 0 && pk->qual_bits != 2 && pk->qual_bits != 4)))
         return fail(BCFGPU_E_ARG, "bad packed pool");
     hipStream_t stream = nullptr;
@@ -799,7 +802,13 @@ int bcfgpu_internal_pool_extent(bcfgpu_ctx *ctx, int *lo, int *hi)
 
 extern "C" int bcfgpu_pool_upload(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bcfgpu_packed *pk, const uint8_t *r_mapq)
 {
-    return pool_upload_impl("bcfgpu_pool_upload", ctx, rd, pk, r_mapq);
+    const int rc = pool_upload_impl("bcfgpu_pool_upload", ctx, rd, pk, r_mapq);
+    if (rc) return rc;
+    // the arrays are the caller's: they are free again when this call returns (bcfgpu_pileup[_packed] wait later, with the counts)
+    hipStream_t stream = nullptr;
+    bcfgpu_internal_device(ctx, &stream, nullptr);
+    if (hipStreamSynchronize(stream) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_upload: upload");
+    return BCFGPU_OK;
 }
 
 extern "C" int bcfgpu_pool_keep(bcfgpu_ctx *ctx, const uint8_t *keep)
