@@ -404,7 +404,8 @@ int  bcfgpu_pileup_packed(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const bcfg
  * and what the iterator does to pairs (:640) without the pool crossing PCIe between the stages.  bcfgpu_baq, bcfgpu_cap_mapq,
  * bcfgpu_overlap_tweak and bcfgpu_pileup each take the pool from the host and (but for the last) hand their result back; here the
  * pool is uploaded once -- packed (bcfgpu_packed) or a byte per base -- and the stages work on that copy, in mplp_func's order:
- *   bcfgpu_pool_upload        reads / pk / r_mapq as for bcfgpu_pileup[_packed]; replaces the context's pool
+ *   bcfgpu_pool_upload        reads / pk / r_mapq as for bcfgpu_pileup[_packed]; replaces the context's pool; the caller's arrays
+ *                             are its own again when the call returns (so is `ref` of the calls below)
  *   bcfgpu_pool_baq           sam_prob_realn on every read: the pool's qualities become the new ones, the ZQ bytes stay in HBM
  *                             (bcfgpu_gap_prep_tile finds them there when its `reads` is NULL); ret: HOST [n_reads] as for
  *                             bcfgpu_baq, or NULL
