@@ -158,18 +158,20 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
         // wait for all outstanding loads at the next use instead of counting them)
         const size_t kf = (size_t)min(k + 1, k_last);
         f0 = meta4[2 * kf]; f1 = meta4[2 * kf + 1];
-        bool v0 = false, h0 = false;
+        // Straight-line code for the common read (one aligned block), for every lane whether its read covers x or not (v0 says
+        // so at the end); the walk over a longer CIGAR only when some lane of the wavefront needs it.  Nested per-lane
+        // branches around both cases cost as many scalar instructions (exec masks) as the entry did vector ones.
+        bool v0 = k < hi && (int)m0.y > x, h0 = false;
         uint32_t w0 = 0, e0 = 0, idx = 0;
-        if (k < hi && (int)m0.y > x) {
+        {
             const int rpos = (int)m0.x, lq = (int)(m1.x & 0xffff), ntot = (int)(m1.x >> 16);
             const int ncig = (int)(m1.y & 0xff);
             const uint32_t bits = (m1.y >> 8) & 0xff, mapq = (m1.y >> 16) & 0xff, so = m0.z;
-            int qpos = 0, is_del = 0, is_skip = 0, indel = 0, edist;
+            int qpos = x - rpos, is_del = 0, is_skip = 0, indel = 0, edist = qpos + 1;
             const int op0 = m1.z & 0xf;
-            if (ncig == 1 && (op0 == 0 || op0 == 7 || op0 == 8)) {      // one aligned block: nothing to resolve
-                qpos = x - rpos;
-                edist = qpos + 1;
-            } else {
+            const bool walk = v0 && !(ncig == 1 && (op0 == 0 || op0 == 7 || op0 == 8));
+            if (__any(walk)) if (walk) {
+                qpos = 0;
                 // htslib's resolve_cigar at reference position x
                 const uint32_t *cg = P.cig + m0.w;
                 int rx = rpos, y = 0;
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
                 int e = (int)((double)edist / (ntot + 1) * BCFGPU_NPOS);
                 e0 = (uint32_t)(e < 0 ? 0 : e > BCFGPU_NPOS - 1 ? BCFGPU_NPOS - 1 : e);
             }
-            v0 = true; h0 = qpos < lq;
+            h0 = v0 && qpos >= 0 && qpos < lq;
             idx = h0 ? so + (uint32_t)qpos : 0u;
         }
         // the entry whose bytes were requested two trips ago
