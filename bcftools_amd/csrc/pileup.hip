@@ -124,18 +124,26 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
         __syncthreads();
         staged = s_lb[PT_COLS] <= PILEUP_LDS_CAP;
     }
-    if (live) {
-    const int x = P.beg + site;
+    // (the PT_COLS lanes of a sample act together below: columns past the tile's edge walk along with the last column and
+    // produce nothing)
+    if (in_grid && s < P.n_smpl) {
+    const int x = P.beg + min(site, P.n_sites - 1);
     const int lo0 = P.smpl_off[s], hi0 = P.smpl_off[s + 1];
     const int hi = upper_bound(P.s_pos, lo0, hi0, x);                    // reads starting at or before x
     const int lo = upper_bound(P.s_pos, lo0, hi, x - (FILL ? P.max_span : *P.d_span));   // ... that can still reach x
     if (!FILL) {
         uint32_t n = 0;
         for (int k = lo; k < hi; ++k) n += P.meta[k].end > x ? 1u : 0u;
-        P.cnt[cell] = n;
+        if (live) P.cnt[cell] = n;
         return;
     }
-    uint32_t o = P.cnt[cell];                                            // plp_off after the scan
+    // One walk for the sample's PT_COLS columns: from the first column's first candidate to the last column's last, every
+    // lane testing the read against its own column.  The lanes then ask for the same record in the same trip (one cache line
+    // for the group instead of one per lane whose own range starts a read or two later) and for neighbouring bytes.
+    int lo_c = lo, hi_c = hi;
+    #pragma unroll
+    for (int d = 1; d < PT_COLS; d <<= 1) { lo_c = min(lo_c, __shfl_xor(lo_c, d)); hi_c = max(hi_c, __shfl_xor(hi_c, d)); }
+    uint32_t o = live ? P.cnt[cell] : 0u;                                // plp_off after the scan
     if (staged) o = o - s_cb[c_local] + s_lb[c_local];
 
     // The walk over the sample's reads that can reach x, software-pipelined by hand: a read's record (two 16-byte loads) is
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
     const uint4 *meta4 = reinterpret_cast<const uint4*>(P.meta);
     uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;                          // the record of read k, fetched ahead
     const int k_last = P.n_reads - 1;
-    if (lo < hi) { n0 = meta4[2 * (size_t)lo]; n1 = meta4[2 * (size_t)lo + 1]; }
+    if (lo_c < hi_c) { n0 = meta4[2 * (size_t)lo_c]; n1 = meta4[2 * (size_t)lo_c + 1]; }
     // two entries in flight: what is known of the entry without the bytes (w, e), whether a base exists (h), the bytes.
     // (Two register sets for the records and two for the entries, the trips written out in pairs: a value that is moved
     // from one variable to the next at the end of a trip counts as used there, and the compiler waits for every load.)
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
         // Straight-line code for the common read (one aligned block), for every lane whether its read covers x or not (v0 says
         // so at the end); the walk over a longer CIGAR only when some lane of the wavefront needs it.  Nested per-lane
         // branches around both cases cost as many scalar instructions (exec masks) as the entry did vector ones.
-        bool v0 = k < hi && (int)m0.y > x, h0 = false;
+        bool v0 = live && k < hi_c && (int)m0.x <= x && (int)m0.y > x, h0 = false;
         uint32_t w0 = 0, e0 = 0, idx = 0;
         {
             const int rpos = (int)m0.x, lq = (int)(m1.x & 0xffff), ntot = (int)(m1.x >> 16);
@@ -234,12 +242,12 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
         q.v = v0; q.h = h0; q.w = w0; q.e = e0;
         q.nt = P.seq16[idx]; q.bq = P.qual[idx];                          // (unconditional: the pool is never empty, see bcfgpu_pileup)
     };
-    if (lo < hi)
-    for (int k = lo; k < hi + 2; k += 2) {
+    if (lo_c < hi_c)
+    for (int k = lo_c; k < hi_c + 2; k += 2) {
         trip(k, n0, n1, na0, na1, qa);
         trip(k + 1, na0, na1, n0, n1, qb);
     }
-    if (any_indel && P.col_indel) atomicOr(&P.col_indel[site], 1u);
+    if (any_indel && live && P.col_indel) atomicOr(&P.col_indel[site], 1u);
     }
     if (FILL && staged) {
         __syncthreads();
