@@ -38,6 +38,7 @@ struct bcfgpu_ctx {
     int *d_hist = nullptr, *d_err = nullptr;       // d_err: [0] error word, [1] truncated cells, [2..4] counters of glfgen's deep-cell list
     uint16_t *d_keys = nullptr;                    // glfgen in two launches (BCFGPU_GLFGEN_SPLIT=1): 2 bytes per read between them
     int32_t *d_grp_rng = nullptr;                  // mcall: sample range of every -G group
+    float *d_grp_frac = nullptr;                   // mcall -G: a site's allele fractions per sample (the group sums run side by side from it)
     uint32_t *d_deep_list = nullptr; uint16_t *d_deep_keys = nullptr; uint32_t deep_cap = 0, deep_key_cap = 0;
     CallretPlanes *d_crp = nullptr;
     unsigned long long *d_site_sums = nullptr;
@@ -126,7 +127,13 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
         (rc = dev_alloc(c, (void**)&c->d_mw, sizeof mw)) || (rc = dev_alloc(c, (void**)&c->d_q2p, 256 * sizeof(float))) || (rc = dev_alloc(c, (void**)&c->d_err, 8 * sizeof(int)))) {
         bcfgpu_destroy(c); return rc;
     }
-    if (cfg->n_grp > 1 && (rc = dev_alloc(c, (void**)&c->d_grp_rng, (size_t)cfg->n_grp * 2 * sizeof(int32_t)))) { bcfgpu_destroy(c); return rc; }
+    if (cfg->n_grp > 1 && (rc = dev_alloc(c, (void**)&c->d_grp_rng, (size_t)cfg->n_grp * 3 * sizeof(int32_t)))) { bcfgpu_destroy(c); return rc; }
+    if (cfg->n_grp > 1) {   // the fractions scratch is optional: without it the group sums take their slower path
+        const size_t bytes = (size_t)(cfg->max_sites > 0 ? cfg->max_sites : 1) * 5 * (((size_t)cfg->n_smpl + 3) & ~(size_t)3) * sizeof(float);
+        void *p = nullptr;
+        if (bytes <= ((size_t)16 << 30) && hipMalloc(&p, bytes) == hipSuccess) { c->owned.push_back(p); c->d_grp_frac = (float*)p; }
+        else (void)hipGetLastError();
+    }
     hipMemcpy(c->d_fk, fk.data(), fk.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(c->d_beta, beta.data(), beta.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(c->d_lhet, lhet.data(), lhet.size() * 8, hipMemcpyHostToDevice);
@@ -525,7 +532,7 @@ int bcfgpu_mcall(bcfgpu_ctx *c, const bcfgpu_call_in *in, const bcfgpu_call_out 
     m.pl_is_u8 = 0; m.call_flag = c->cfg.call_flag; m.output_tags = c->cfg.output_tags; m.n_grp = c->cfg.n_grp;
     m.theta = c->call_theta_log; m.pl2p = c->d_pl2p;
     m.nals = in->nals; m.unseen = in->unseen; m.msite = nullptr; m.pl = in->pl; m.qs = in->qs; m.ad = in->ad;
-    m.grp_rng = c->d_grp_rng;
+    m.grp_rng = c->d_grp_rng; m.grp_frac = c->d_grp_frac;
     m.ploidy = in->ploidy; m.grp = c->cfg.n_grp > 1 ? in->grp : nullptr; m.prior_an = in->prior_an; m.prior_ac = in->prior_ac; m.i16 = in->i16;
     m.out = *out; m.out_n_gt_max = in->n_gt_max; m.err = c->d_err;
     if (c->timing == 1) hipEventRecord(c->ev[2], c->stream);
@@ -560,7 +567,7 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
     m.msite = mout->site; m.pl = mout->pl; m.qs = nullptr; m.ad = nullptr;
     m.qs_u16 = (c->cfg.n_grp > 1 && c->cfg.grp_tag_is_qs) ? mout->qs : nullptr;
     if (c->cfg.n_grp > 1 && !c->cfg.grp_tag_is_qs) { m.ad_u8 = mout->adf; m.ad_u8b = mout->adr; }   // FORMAT/AD = ADF+ADR (bam2bcf.c:892-896)
-    m.grp_rng = c->d_grp_rng;
+    m.grp_rng = c->d_grp_rng; m.grp_frac = c->d_grp_frac;
     m.ploidy = ploidy; m.grp = c->cfg.n_grp > 1 ? grp : nullptr;
     m.out = *cout; m.out_n_gt_max = BCFGPU_MAX_PL; m.err = c->d_err;
 #ifdef BCFGPU_DIAG

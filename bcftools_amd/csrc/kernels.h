@@ -103,7 +103,8 @@ struct McallParams {
     const uint8_t *ad_u8, *ad_u8b; const uint16_t *qs_u16;   // fused -G sources (mpileup-stage ADF/ADR or QS planes, stride 5)
     const uint8_t *ploidy;
     const int32_t *grp;
-    int32_t *grp_rng;               // [n_grp][2] workspace: first sample and last sample + 1 of every group (launch_mcall fills it)
+    int32_t *grp_rng;               // [n_grp][3] workspace: first sample, last sample + 1 and number of samples of every group (launch_mcall fills it)
+    float *grp_frac;                // [n_sites][5][(n_smpl + 3) & ~3] workspace, or NULL: the samples' allele fractions of a site, for the group sums
     const int32_t *prior_an, *prior_ac;
     const float *i16;               // [site][16] INFO/I16 or NULL (fused: msite->anno)
     bcfgpu_call_out out;

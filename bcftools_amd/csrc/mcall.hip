@@ -289,7 +289,83 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             #pragma unroll
             for (int j = 0; j < 4; ++j) gnx[j] = j < rem ? GRP_OF(s + j) : 0;
         };
+        // Groups that are runs of consecutive samples (the usual -G file): their sums are independent chains.  Every lane
+        // normalises its samples as below and leaves the fractions in a global scratch row per allele; then lane (group,
+        // allele) adds its group's stretch in sample order -- ngrp x 5 chains of a group's length side by side instead of
+        // five chains over all samples with a group test per sample.
+        bool side_by_side = P.grp_frac != nullptr && P.grp_rng != nullptr && ngrp * 5 <= WGS;
+        if (side_by_side) {
+            bool ok = true;
+            if (tid < ngrp) { const int f = P.grp_rng[3 * tid], l = P.grp_rng[3 * tid + 1], n = P.grp_rng[3 * tid + 2]; ok = n == 0 || l - f == n; }
+            side_by_side = __all(ok);
+        }
+        const size_t S4 = ((size_t)S + 3) & ~(size_t)3;
+        float *frow = side_by_side ? P.grp_frac + (size_t)is * 5 * S4 : nullptr;
         fetch_ad(0);
+        if (side_by_side) {
+            for (int base = 0; base < S; base += SB) {
+                int xc[5][4];
+                #pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    #pragma unroll
+                    for (int j = 0; j < 4; ++j) xc[k][j] = xn[k][j];
+                fetch_ad(base + SB);
+                const int s = base + 4 * tid;
+                if (s < S) {
+                    float fr[5][4];
+                    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int v[5];
+                        float sum = 0;
+                        int nvalid = 0;                                   // values before the first vector_end
+                        #pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            v[k] = VEND;
+                            if (k < nad && nvalid == k) {
+                                const int x = xc[k][j];
+                                if (x != VEND) { v[k] = x; nvalid = k + 1; if (x != MISSING) sum += (float)x; }
+                            }
+                        }
+                        #pragma unroll
+                        for (int k = 0; k < 5; ++k)                       // +0 where the reference adds nothing (and past the last sample)
+                            fr[k][j] = (s + j < S && sum != 0.f && k < nvalid && v[k] != MISSING) ? (float)v[k] / sum : 0.f;
+                    }
+                    #pragma unroll
+                    for (int k = 0; k < 5; ++k)
+                        if (k < nals) *reinterpret_cast<float4*>(frow + k * S4 + s) = make_float4(fr[k][0], fr[k][1], fr[k][2], fr[k][3]);
+                }
+            }
+            __syncthreads();                                             // (the fractions are this workgroup's own: a workgroup-scope fence)
+            if (tid < ngrp * 5 && tid % 5 < nals) {
+                const int g = tid / 5, a = tid % 5;
+                const int first = P.grp_rng[3 * g], last = P.grp_rng[3 * g + 2] ? P.grp_rng[3 * g + 1] : first;
+                const float *fp = frow + a * S4;
+                float acc = 0.f;
+                int i = first;
+                for (; i < last && (i & 3); ++i) acc += fp[i];
+                const float4 *q4 = reinterpret_cast<const float4*>(fp + i);
+                const int nb = (last - i) >> 2;                            // whole float4s; four of them in flight
+                float4 c0 = make_float4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
+                if (nb > 0) c0 = q4[0];
+                if (nb > 1) c1 = q4[1];
+                if (nb > 2) c2 = q4[2];
+                if (nb > 3) c3 = q4[3];
+                for (int b4 = 0; b4 < nb; b4 += 4) {
+                    const float4 a0 = c0, a1 = c1, a2 = c2, a3 = c3;
+                    if (b4 + 4 < nb) c0 = q4[b4 + 4];
+                    if (b4 + 5 < nb) c1 = q4[b4 + 5];
+                    if (b4 + 6 < nb) c2 = q4[b4 + 6];
+                    if (b4 + 7 < nb) c3 = q4[b4 + 7];
+                    acc += a0.x; acc += a0.y; acc += a0.z; acc += a0.w;
+                    if (b4 + 1 < nb) { acc += a1.x; acc += a1.y; acc += a1.z; acc += a1.w; }
+                    if (b4 + 2 < nb) { acc += a2.x; acc += a2.y; acc += a2.z; acc += a2.w; }
+                    if (b4 + 3 < nb) { acc += a3.x; acc += a3.y; acc += a3.z; acc += a3.w; }
+                }
+                for (i += 4 * nb; i < last; ++i) acc += fp[i];
+                s_gq[g * 5 + a] = acc;
+            }
+            cur = -1;                                                     // (nothing left in the running-group register)
+        } else
         for (int base = 0; base < (BCFGPU_ABL(P, 128) ? 0 : S); base += SB) {
             const int cn = min(SB, S - base);
             __syncthreads();
@@ -516,7 +592,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             // (few samples: 4*nq consecutive samples per lane with nq = 2 or 1, so that the 16 lanes' columns stay filled)
             // a group's samples lie in [first, last] (grp_range_kernel): consecutive for populations listed one after the
             // other, and then the groups' scans together read every sample once
-            const int s_first = (ngrp > 1 && P.grp_rng) ? (P.grp_rng[2 * g] & ~3) : 0, s_last = (ngrp > 1 && P.grp_rng) ? P.grp_rng[2 * g + 1] : S;
+            const int s_first = (ngrp > 1 && P.grp_rng) ? (P.grp_rng[3 * g] & ~3) : 0, s_last = (ngrp > 1 && P.grp_rng) ? P.grp_rng[3 * g + 1] : S;
             const int span = s_last - s_first;
             const int nq = span > 128 ? 4 : span > 64 ? 2 : 1;
             for (int s0 = s_first; s0 < (BCFGPU_ABL(P, 16) ? 0 : s_last); s0 += 64 * nq) {
@@ -641,7 +717,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             setbits = rowbits;
         } else {
         for (int t = 0; t < nsub; ++t) { s_man[t * WGS + tid] = 1.0; s_exp[t * WGS + tid] = 0; }
-        const int g_first = (ngrp > 1 && P.grp_rng) ? P.grp_rng[2 * g] : 0, g_last = (ngrp > 1 && P.grp_rng) ? P.grp_rng[2 * g + 1] : S;
+        const int g_first = (ngrp > 1 && P.grp_rng) ? P.grp_rng[3 * g] : 0, g_last = (ngrp > 1 && P.grp_rng) ? P.grp_rng[3 * g + 1] : S;
         for (int s = g_first + tid; s < (BCFGPU_ABL(P, 16) ? 0 : g_last); s += WGS) {
             if (ngrp > 1 && GRP_OF(s) != g) continue;
             int pl[NG]; double pdg[NG];
@@ -981,7 +1057,7 @@ __global__ __launch_bounds__(64) void i16_kernel(const McallParams P)
 __global__ void grp_range_init_kernel(int32_t *rng, int n_grp)
 {
     const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g < n_grp) { rng[2 * g] = 0x7fffffff; rng[2 * g + 1] = 0; }
+    if (g < n_grp) { rng[3 * g] = 0x7fffffff; rng[3 * g + 1] = 0; rng[3 * g + 2] = 0; }
 }
 // group ids are checked (BCFGPU_E_RANGE) and every group's sample range [first, last + 1) is taken
 __global__ void grp_check_kernel(const int32_t *grp, int n_smpl, int n_grp, int *err, int32_t *rng)
@@ -990,7 +1066,7 @@ __global__ void grp_check_kernel(const int32_t *grp, int n_smpl, int n_grp, int 
     if (s >= n_smpl) return;
     const int g = grp[s];
     if (g < 0 || g >= n_grp) { atomicExch(err, BCFGPU_E_RANGE); return; }
-    if (rng) { atomicMin(&rng[2 * g], s); atomicMax(&rng[2 * g + 1], s + 1); }
+    if (rng) { atomicMin(&rng[3 * g], s); atomicMax(&rng[3 * g + 1], s + 1); atomicAdd(&rng[3 * g + 2], 1); }
 }
 
 void launch_mcall(const McallParams &p, hipStream_t s)

@@ -153,9 +153,13 @@ def test_pipeline_nondefault_prior(gpu_ctx_factory, theta, n_smpl, with_ploidy):
         assert not np.allclose(c0.site["qual"], cwant.site["qual"], rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("n_sites,n_smpl,n_grp,seed,use_qs", [(48, 120, 4, 61, False), (32, 1000, 4, 62, False), (40, 33, 33, 63, False),
-                                                              (48, 90, 3, 64, True)])
-def test_pipeline_with_sample_groups_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, n_grp, seed, use_qs):
+@pytest.mark.parametrize("n_sites,n_smpl,n_grp,seed,use_qs,runs", [
+    (48, 120, 4, 61, False, False), (32, 1000, 4, 62, False, False), (40, 33, 33, 63, False, False), (48, 90, 3, 64, True, False),
+    # groups as runs of consecutive samples (the usual -G file): their sums run side by side from the fractions scratch;
+    # 1001 samples: a ragged last four; 12 groups: the most the 64 lanes take; 13: the general path again; an empty group
+    (32, 1000, 4, 65, False, True), (40, 1001, 5, 66, False, True), (24, 97, 12, 67, True, True), (24, 97, 13, 68, False, True),
+    (30, 50, 6, 69, False, "gap")])
+def test_pipeline_with_sample_groups_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, n_grp, seed, use_qs, runs):
     """call -G through the fused pipeline (BASELINE configs[4] shape): group allele frequencies from the mpileup stage's
     ADF+ADR planes (= FORMAT/AD, bam2bcf.c:892-896) or its QS planes, ploidy array, one group per sample at the extreme."""
     tile = synth.numpy_tile(seed, n_sites, n_smpl, depth=20.0, var_rate=0.4)
@@ -165,7 +169,9 @@ def test_pipeline_with_sample_groups_matches_oracle(gpu_ctx_factory, n_sites, n_
     rng = np.random.default_rng(seed)
     ploidy = rng.choice([1, 2, 2], size=n_smpl).astype(np.uint8)
     grp = (np.arange(n_smpl) * n_grp // n_smpl).astype(np.int32)
-    if n_grp < n_smpl:
+    if runs == "gap":
+        grp[grp == 2] = 3                                      # a group without samples between the runs
+    elif n_grp < n_smpl and not runs:
         rng.shuffle(grp)                                       # groups need not be contiguous
     mwant = orc.mpileup(cfg, tile)
     src = mwant.qs.astype(np.int32) if use_qs else mwant.adf.astype(np.int32) + mwant.adr.astype(np.int32)
