@@ -174,6 +174,55 @@ def test_empty_pool_and_keep_reset(gpu_ctx_factory):
     assert_tiles_equal(_tile_of(ctx, t, 80, 3), full)
 
 
+@pytest.mark.parametrize("seed,flag", [(5, 3), (6, 7), (7, 1)])
+def test_pool_baq_matches_the_host_pointer_call_on_random_reads(gpu_ctx_factory, seed, flag):
+    """bcfgpu_pool_baq (windows and bands on the device, the reference slice uploaded once) against bcfgpu_baq (windows on the
+    host, a window copy per read), which tests/test_gpu_baq.py pins to the oracle: reads with every CIGAR operation, starting
+    before the window can open and ending past the reference, unmapped reads, reads without qualities, long indels (the
+    wide-band class)."""
+    from tests.helpers import ovlfuzz
+    rng = np.random.default_rng(seed)
+    Lr = 400
+    refseq = "".join("ACGTN"[i] for i in rng.choice(5, Lr, p=[0.25, 0.25, 0.24, 0.24, 0.02]))
+    reads = []
+    for k in range(300):
+        pos = int(rng.choice([0, 1, 2, Lr - 30, Lr - 5])) if k % 7 == 0 else int(rng.integers(0, Lr - 20))
+        r = ovlfuzz.make_read(rng, pos, int(rng.integers(1, 140)))
+        r.flag = int(rng.choice([0, 16, 4, 0, 0]))
+        r.mapq = 30
+        if k % 11 == 0:
+            r.qual = np.full(r.l_qseq, 255, np.int32)                # no qualities: left alone
+        if k % 13 == 0 and r.l_qseq > 40:                             # one long deletion: a band wider than the register rows take
+            a = r.l_qseq // 2
+            r.cigar = [(a, "M"), (int(rng.integers(9, 25)), "D"), (r.l_qseq - a, "M")]
+            r.bamcigar = np.array([n << 4 | "MIDNSHP=X".index(op) for n, op in r.cigar], dtype=np.uint32)
+        reads.append(r)
+    rd, d = M.pack_reads(reads)
+    nb, n = len(d["qual"]), len(reads)
+    ctx = gpu_ctx_factory(abi.default_cfg(1, max_sites=1, max_reads=64))
+    L = ctx.L
+    qo, zo, ret = np.zeros(nb, np.uint8), np.zeros(nb, np.uint8), np.zeros(n, np.int32)
+    check(L.bcfgpu_baq(ctx.h, C.byref(rd), refseq.encode(), Lr, flag, qo.ctypes.data, zo.ctypes.data, ret.ctypes.data))
+    assert (ret == 0).sum() > 100 and (ret < 0).sum() > 20
+    mapq = np.full(n, 30, np.uint8)
+    check(L.bcfgpu_pool_upload(ctx.h, C.byref(rd), None, mapq.ctypes.data))
+    ret_b = np.full(n, 99, np.int32)
+    check(L.bcfgpu_pool_baq(ctx.h, refseq.encode(), Lr, flag, ret_b.ctypes.data))
+    q_b, z_b = np.zeros(nb, np.uint8), np.zeros(nb, np.uint8)
+    check(L.bcfgpu_pool_download(ctx.h, q_b.ctypes.data, z_b.ctypes.data, None))
+    np.testing.assert_array_equal(ret_b, ret)
+    np.testing.assert_array_equal(q_b, qo)
+    np.testing.assert_array_equal(z_b, zo)
+    # a second BAQ over the pool's new qualities (mpileup -E redoes it): again what the host-pointer call gives on them
+    rd.qual = qo.ctypes.data
+    qo2, zo2 = np.zeros(nb, np.uint8), np.zeros(nb, np.uint8)
+    check(L.bcfgpu_baq(ctx.h, C.byref(rd), refseq.encode(), Lr, flag, qo2.ctypes.data, zo2.ctypes.data, ret.ctypes.data))
+    check(L.bcfgpu_pool_baq(ctx.h, refseq.encode(), Lr, flag, None))
+    check(L.bcfgpu_pool_download(ctx.h, q_b.ctypes.data, z_b.ctypes.data, None))
+    np.testing.assert_array_equal(q_b, qo2)
+    np.testing.assert_array_equal(z_b, zo2)
+
+
 def test_pool_stages_need_a_pool(gpu_ctx_factory):
     ctx = gpu_ctx_factory(abi.default_cfg(2, max_sites=1, max_reads=64))
     t = abi.Tile()
