@@ -97,7 +97,7 @@ class Reads(C.Structure):
 class Packed(C.Structure):
     """bcfgpu_packed: the pool as BAM records hold it (4-bit bases, optional 4-bit palette qualities)."""
     _fields_ = [("seq4", C.c_void_p), ("qual4", C.c_void_p), ("palette", C.c_uint8 * 16), ("n_bases", C.c_int64), ("n_cig", C.c_int64),
-                ("smpl_off", C.c_void_p), ("qual_bits", C.c_int32)]
+                ("smpl_off", C.c_void_p), ("qual_bits", C.c_int32), ("recs", C.c_void_p)]
 
 
 def pack_nibbles(a):
@@ -107,6 +107,18 @@ def pack_nibbles(a):
     if a.size & 1:
         a = np.concatenate([a, np.zeros(1, np.uint8)])
     return ((a[0::2] << 4) | (a[1::2] & 15)).astype(np.uint8)
+
+
+READ12 = [("pos", "<i4"), ("lq", "<u2"), ("ncig", "u1"), ("flag8", "u1"), ("mapq", "u1"), ("pad", "u1", 3)]     # bcfgpu_read12
+
+
+def read12(r_pos, r_lq, r_ncig, r_flag, r_mapq):
+    """The per-read arrays as bcfgpu_read12 records (numpy structured array, 12 bytes a read)."""
+    import numpy as np
+    rec = np.zeros(len(r_pos), dtype=READ12)
+    rec["pos"], rec["lq"], rec["ncig"], rec["mapq"] = r_pos, r_lq, r_ncig, r_mapq
+    rec["flag8"] = ((np.asarray(r_flag) & 16) != 0) * 1 + ((np.asarray(r_flag) & 4) != 0) * 2
+    return rec
 
 
 def pack_crumbs(a):

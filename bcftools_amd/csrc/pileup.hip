@@ -443,6 +443,22 @@ __global__ __launch_bounds__(256) void pool_extent_kernel(const DevPool D, int *
     if ((threadIdx.x & 63) == 0 && lo != INT32_MAX) { atomicMin(&out[0], lo); atomicMax(&out[1], hi); }
 }
 
+// bcfgpu_read12 records to the per-read arrays the stages index; the lengths (rounded up to four bases) and operation counts
+// in the offset arrays, which an exclusive prefix sum then turns into r_seq_off / r_cig_off
+__global__ __launch_bounds__(256) void pool_expand_kernel(const bcfgpu_read12 *rec, int n, int32_t *r_pos, int32_t *r_lq, int32_t *r_flag,
+                                                         int32_t *r_ncig, int32_t *r_cig_off, int32_t *r_seq_off, uint8_t *r_mapq)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r > n) return;
+    if (r == n) { r_cig_off[n] = 0; r_seq_off[n] = 0; return; }           // (the scans run over n + 1 elements)
+    const uint32_t *w = reinterpret_cast<const uint32_t*>(rec + r);
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    const int lq = (int)(w1 & 0xffff), ncig = (int)((w1 >> 16) & 0xff), f8 = (int)(w1 >> 24);
+    r_pos[r] = (int32_t)w0; r_lq[r] = lq; r_ncig[r] = ncig; r_flag[r] = ((f8 & 1) ? 16 : 0) | ((f8 & 2) ? 4 : 0);
+    r_mapq[r] = (uint8_t)(w2 & 0xff);
+    r_seq_off[r] = (lq + 3) & ~3; r_cig_off[r] = ncig;
+}
+
 // The pool as BAM records hold it (two 4-bit base codes per byte, high nibble first) and qualities as palette indices, to the
 // one-byte-per-base arrays every kernel of the host-fed stages reads.  A lane per four input bytes = eight bases.
 __global__ __launch_bounds__(256) void pileup_unpack_kernel(const uint8_t *seq4, const uint8_t *qual4, unsigned long long pal_lo,
@@ -532,8 +548,9 @@ template <class F> static void on_threads(int nthr, F &&fn)
 static int pool_upload_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const bcfgpu_packed *pk, const uint8_t *r_mapq)
 {
     auto fail = [&](int code, const char *what) { char msg[160]; snprintf(msg, sizeof msg, "%s: %s", who, what); return bcfgpu_set_error(code, msg); };
-    if (!ctx || !rd || rd->n_reads < 0 || (rd->n_reads && !r_mapq)) return fail(BCFGPU_E_ARG, "bad arguments");
-    if (rd->n_reads && (!rd->r_pos || !rd->r_lq || !rd->r_flag || !rd->r_ncig || !rd->r_cig_off || !rd->r_seq_off ||
+    const bool recs = pk && pk->recs;
+    if (!ctx || !rd || rd->n_reads < 0 || (rd->n_reads && !recs && !r_mapq)) return fail(BCFGPU_E_ARG, "bad arguments");
+    if (rd->n_reads && ((!recs && (!rd->r_pos || !rd->r_lq || !rd->r_flag || !rd->r_ncig || !rd->r_cig_off || !rd->r_seq_off)) ||
                         (!pk && !rd->seq16) || (!(pk && pk->qual4) && !rd->qual)))
         return fail(BCFGPU_E_ARG, "a read array is missing");
     if (pk && (!pk->seq4 || pk->n_bases < 0 || pk->n_cig < 0 || (pk->n_bases >> 32) || (pk->qual_bits != 0 && pk->qual_bits != 2 && pk->qual_bits != 4)))
@@ -569,6 +586,23 @@ static int pool_upload_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads
         return d;
     };
     D.n_reads = n; D.n_bases = (uint32_t)nbase; D.n_cig = (uint32_t)ncig;
+    if (pk && pk->recs) {
+        // the 12-byte records: the arrays are formed here, the offsets by two prefix sums
+        const bcfgpu_read12 *d_rec = (const bcfgpu_read12*)up(128, pk->recs, (size_t)n * sizeof(bcfgpu_read12));
+        int32_t *a_pos = (int32_t*)bcfgpu_internal_ws(ctx, 104, (size_t)n * 4 + 64), *a_lq = (int32_t*)bcfgpu_internal_ws(ctx, 105, (size_t)n * 4 + 64);
+        int32_t *a_flag = (int32_t*)bcfgpu_internal_ws(ctx, 106, (size_t)n * 4 + 64), *a_ncig = (int32_t*)bcfgpu_internal_ws(ctx, 107, (size_t)n * 4 + 64);
+        int32_t *a_coff = (int32_t*)bcfgpu_internal_ws(ctx, 108, (size_t)(n + 1) * 4 + 64), *a_soff = (int32_t*)bcfgpu_internal_ws(ctx, 109, (size_t)(n + 1) * 4 + 64);
+        uint8_t *a_mapq = (uint8_t*)bcfgpu_internal_ws(ctx, 110, (size_t)n + 64);
+        if (!d_rec || !a_pos || !a_lq || !a_flag || !a_ncig || !a_coff || !a_soff || !a_mapq) return fail(BCFGPU_E_NOMEM, "device workspace");
+        hipLaunchKernelGGL(pool_expand_kernel, dim3((n + 256) / 256), dim3(256), 0, stream, d_rec, n, a_pos, a_lq, a_flag, a_ncig, a_coff, a_soff, a_mapq);
+        size_t tmp_bytes = 0;
+        if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, a_soff, a_soff, n + 1, stream) != hipSuccess) return fail(BCFGPU_E_HIP, "scan");
+        void *d_tmp = bcfgpu_internal_ws(ctx, 129, tmp_bytes + 64);
+        if (!d_tmp) return fail(BCFGPU_E_NOMEM, "device workspace");
+        if (hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, a_soff, a_soff, n + 1, stream) != hipSuccess ||
+            hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, a_coff, a_coff, n + 1, stream) != hipSuccess) return fail(BCFGPU_E_HIP, "scan");
+        D.r_pos = a_pos; D.r_lq = a_lq; D.r_flag = a_flag; D.r_ncig = a_ncig; D.r_cig_off = a_coff; D.r_seq_off = a_soff; D.r_mapq = a_mapq;
+    } else {
     D.r_pos = (const int32_t*)up(104, rd->r_pos, (size_t)n * 4);
     D.r_lq = (const int32_t*)up(105, rd->r_lq, (size_t)n * 4);
     D.r_flag = (const int32_t*)up(106, rd->r_flag, (size_t)n * 4);
@@ -576,6 +610,7 @@ static int pool_upload_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads
     D.r_cig_off = (const int32_t*)up(108, rd->r_cig_off, (size_t)n * 4);
     D.r_seq_off = (const int32_t*)up(109, rd->r_seq_off, (size_t)n * 4);
     D.r_mapq = (uint8_t*)up(110, r_mapq, (size_t)n);
+    }
     D.cig = (const uint32_t*)up(27, rd->cig, ncig * 4);
     uint8_t *d_seq16 = nullptr, *d_qual = nullptr;
     if (pk) {

@@ -488,8 +488,9 @@ def main_pileup(a):
     qual_bits = 2 if len(palette) <= 4 else 4
     packed_arrs = dict(seq4=abi.pack_nibbles(seq), qual4=(abi.pack_crumbs if qual_bits == 2 else abi.pack_nibbles)(np.searchsorted(palette, arrs["qual"])),
                        smpl_off=(np.arange(S + 1, dtype=np.int64) * per).astype(np.int32))
-    packed_bytes = (sum(v.nbytes for k, v in arrs.items() if k not in ("seq16", "qual", "zq", "r_has_zq")) + mapq.nbytes
-                    + sum(v.nbytes for v in packed_arrs.values()))
+    packed_arrs["recs"] = abi.read12(pos, arrs["r_lq"], ncig, arrs["r_flag"], mapq).view(np.uint8)      # the per-read fields, 12 bytes a read
+    assert L % 4 == 0                                                # (records need every read at a multiple of four bases: dense here)
+    packed_bytes = arrs["cig"].nbytes + sum(v.nbytes for v in packed_arrs.values())
     # the pool in page-locked memory (bcfgpu_host_alloc), as a host that parses its reads straight into such buffers has it:
     # the uploads are then DMA transfers that run beside the other context's kernels
     from bcftools_amd.lib import load
@@ -511,7 +512,7 @@ def main_pileup(a):
     for k, v in arrs.items():
         setattr(rd, k, v.ctypes.data)
     pk = abi.Packed()
-    pk.seq4, pk.qual4, pk.smpl_off = (packed_arrs[k].ctypes.data for k in ("seq4", "qual4", "smpl_off"))
+    pk.seq4, pk.qual4, pk.smpl_off, pk.recs = (packed_arrs[k].ctypes.data for k in ("seq4", "qual4", "smpl_off", "recs"))
     pk.n_bases, pk.n_cig, pk.qual_bits = n * L, len(cig), qual_bits
     for j, q in enumerate(palette):
         pk.palette[j] = int(q)
@@ -594,7 +595,7 @@ def main_pileup(a):
            "value": entries / tb, "unit": "entries/s", "n_gpus": 1, "higher_is_better": True, "dtype": "u32/u8 records", "data": "synthetic",
            "config": {"workload": "%d reads of %d bp over %d columns x %d samples" % (n, L, n_sites, S), "reads": n, "entries": entries,
                       "columns": n_sites, "pool_memory": "pageable" if a.pageable else "page-locked (bcfgpu_host_alloc)",
-                      "pool_form": ("bcfgpu_pileup_packed: 4-bit bases, %d-value quality palette (%d-bit), per-sample offsets" % (len(palette), qual_bits))
+                      "pool_form": ("bcfgpu_pileup_packed: 4-bit bases, %d-value quality palette (%d-bit), 12-byte read records, per-sample offsets" % (len(palette), qual_bits))
                                    if a.packed else "bcfgpu_pileup: one byte per base and per quality",
                       "stages": "bcfgpu_pool_upload -> bcfgpu_pool_baq (flag 3) -> bcfgpu_pool_pileup -> bcfgpu_pipeline" if a.baq else "pileup -> bcfgpu_pipeline"},
            "whole_call_ms": tb * 1e3, "tile_written_gbs": tile_bytes / tb / 1e9,

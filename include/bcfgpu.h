@@ -385,7 +385,17 @@ int  bcfgpu_pileup(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const uint8_t *r_
  *   n_bases  bases the pools hold (the largest r_seq_off[r] + r_lq[r]);  n_cig  operations in reads->cig
  *   smpl_off NULL, or [n_smpl+1]: the reads of sample s are smpl_off[s] .. smpl_off[s+1]-1 of the pool (then r_smpl is not
  *            read and the call makes no pass over the reads on the host at all)
+ *   recs     NULL, or the per-read fields as 12-byte records (bcfgpu_read12), see there
  * bcfgpu_gap_prep_tile, bcfgpu_pileup_entries and bcfgpu_pileup_indel_tile follow it as they follow bcfgpu_pileup. */
+typedef struct {
+    int32_t  pos;                /* r_pos */
+    uint16_t lq;                 /* r_lq */
+    uint8_t  ncig;               /* r_ncig */
+    uint8_t  flag8;              /* bit 0: reverse strand (BAM flag 16), bit 1: unmapped (4) -- what the stages read of r_flag */
+    uint8_t  mapq;               /* r_mapq */
+    uint8_t  pad[3];
+} bcfgpu_read12;
+
 typedef struct {
     const uint8_t *seq4, *qual4;
     uint8_t palette[16];
@@ -394,6 +404,10 @@ typedef struct {
     int32_t qual_bits;           /* bits per palette index in qual4: 0 or 4 = two per byte (above); 2 = four per byte, index i of a
                                     byte in bits 7-2i..6-2i (the first base highest; a palette of <= 4 values: the four bins of
                                     current sequencers); reads then start at multiples of four bases when copied bytewise */
+    const bcfgpu_read12 *recs;   /* NULL, or [n_reads]: the per-read arrays as one 12-byte record a read (half the bytes of the six
+                                    arrays and r_mapq, which are then not read).  The pools are then dense: read r's bases start at
+                                    the sum of the earlier reads' lengths, each rounded up to a multiple of four, its CIGAR at the
+                                    sum of the earlier reads' operation counts (r_seq_off / r_cig_off are formed on the device) */
 } bcfgpu_packed;
 
 int  bcfgpu_pileup_packed(bcfgpu_ctx *ctx, const bcfgpu_reads *reads, const bcfgpu_packed *pk, const uint8_t *r_mapq,

@@ -32,18 +32,33 @@ def device_pileup(ctx, reads_by_sample, refseq, beg, end, packed=None, order=Non
         rd, d = M.pack_reads(reads)
         mapq = np.array([r.mapq for r in reads], dtype=np.uint8)
         pk = abi.Packed()
+        pal = np.unique(d["qual"])                                  # (before any padding below)
+        if "recs" in packed:
+            # the per-read arrays as 12-byte records: the pools dense, every read at a multiple of four bases
+            lq4 = (d["r_lq"] + 3) & ~3
+            off4 = np.concatenate([[0], np.cumsum(lq4)[:-1]]).astype(np.int64)
+            s2, q2 = np.zeros(int(lq4.sum()), np.uint8), np.zeros(int(lq4.sum()), np.uint8)
+            for o_new, o_old, n_ in zip(off4, d["r_seq_off"], d["r_lq"]):
+                s2[o_new:o_new + n_] = d["seq16"][o_old:o_old + n_]
+                q2[o_new:o_new + n_] = d["qual"][o_old:o_old + n_]
+            d["seq16"], d["qual"] = s2, q2
+            rd.qual = q2.ctypes.data
+            rec = abi.read12(d["r_pos"], d["r_lq"], d["r_ncig"], d["r_flag"], mapq)
+            pk.recs = rec.ctypes.data
+            for k in ("r_pos", "r_lq", "r_flag", "r_ncig", "r_cig_off", "r_seq_off"):
+                setattr(rd, k, None)
         seq4 = abi.pack_nibbles(d["seq16"])
         pk.seq4, pk.n_bases, pk.n_cig = seq4.ctypes.data, len(d["seq16"]), len(d["cig"])
         rd.seq16 = None
         if "qual" in packed:
-            pal = np.unique(d["qual"])
             assert len(pal) <= 16
+            qidx = np.minimum(np.searchsorted(pal, d["qual"]), len(pal) - 1)
             if "qual2" in packed:
                 assert len(pal) <= 4
-                qual4 = abi.pack_crumbs(np.searchsorted(pal, d["qual"]))
+                qual4 = abi.pack_crumbs(qidx)
                 pk.qual_bits = 2
             else:
-                qual4 = abi.pack_nibbles(np.searchsorted(pal, d["qual"]))
+                qual4 = abi.pack_nibbles(qidx)
             pk.qual4 = qual4.ctypes.data
             for j, q in enumerate(pal):
                 pk.palette[j] = int(q)
@@ -52,7 +67,7 @@ def device_pileup(ctx, reads_by_sample, refseq, beg, end, packed=None, order=Non
         if "off" in packed:
             off = np.concatenate([[0], np.cumsum([len(rl) for rl in reads_by_sample])]).astype(np.int32)
             pk.smpl_off, smpl_ptr = off.ctypes.data, None
-        check(ctx.L.bcfgpu_pileup_packed(ctx.h, C.byref(rd), C.byref(pk), mapq.ctypes.data, smpl_ptr, beg, end, refseq.encode(),
+        check(ctx.L.bcfgpu_pileup_packed(ctx.h, C.byref(rd), C.byref(pk), None if "recs" in packed else mapq.ctypes.data, smpl_ptr, beg, end, refseq.encode(),
                                          len(refseq), C.byref(t), col_n.ctypes.data, col_indel.ctypes.data))
     elif reads:
         rd, d = M.pack_reads(reads)
@@ -200,7 +215,7 @@ def test_packed_pool_and_interleaved_samples_give_the_same_tile(gpu_ctx_factory)
         for r in rl:
             r.qual = np.array([2, 12, 23, 37], np.uint8)[r.qual % 4]
     want4, _ = host_pileup(by_sample, refseq + "N" * 100, 0, L + 20)
-    for packed in ("seq+qual2", "seq+qual2+off"):
+    for packed in ("seq+qual2", "seq+qual2+off", "seq+recs", "seq+qual2+off+recs"):
         got, _, _, _ = device_pileup(ctx, by_sample, refseq, 0, L + 20, packed=packed)
         assert_tiles_equal(got, want4)
 
