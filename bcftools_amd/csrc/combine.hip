@@ -448,7 +448,25 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, 
         PLANES(V)
         #undef PLANES
         __syncthreads();
-        if (tid == 0 && !dead && !BCFGPU_ABL(P, 8192)) sh.sum_min = seq_sum_f64(sh.sum_min, s_min, cn);   // bam2bcf.c:642
+        // bam2bcf.c:642, sum_min += the sample's smallest likelihood, in sample order.  A cell whose reads all show one base has
+        // a zero there (nine in ten do): x + 0.0 is x, so only the other terms are added, in their order -- found by the whole
+        // wavefront 64 samples at a time, added by the scalar walk over the ballot (every lane computes the same sum).
+        if (!dead && !BCFGPU_ABL(P, 8192)) {
+            double acc = sh.sum_min;
+            for (int b0 = 0; b0 < cn; b0 += WG) {
+                const double v = b0 + tid < cn ? s_min[b0 + tid] : 0.0;
+                unsigned long long m = __ballot(v != 0.0);
+                while (m) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bits, l), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(bits >> 32), l);
+                    acc += __builtin_bit_cast(double, (unsigned long long)hi << 32 | lo);
+                }
+            }
+            __syncthreads();                                          // (sh.sum_min was read by every lane above)
+            if (tid == 0) sh.sum_min = acc;
+        }
     }
     // FMT/SP (bam2bcf.c:867-885): a Fisher exact test per sample, in its own pass -- its loops over the table's margins
     // diverge between lanes, and only samples with at least two reads in every margin enter them
