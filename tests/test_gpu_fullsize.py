@@ -105,3 +105,81 @@ def test_sampled_sites_match_oracle(big):
     mw.scr[:] = mg.scr
     assert_mplp_equal(mg, mw)
     assert_call_equal(cg, cw, N_SMPL)
+
+
+def test_pileup_at_scale_counts_and_packed_form(gpu_ctx_factory):
+    """bcfgpu_pileup over 2048 columns x 1000 samples x 30x (6e7 entries): every cell's entry count equals the number of the
+    sample's reads whose reference span covers the column (a difference array on the host), and the packed form of the same
+    pool (4-bit bases, 2-bit palette qualities, 12-byte read records, the samples' offsets) gives the same tile byte for byte."""
+    import ctypes as C
+    from bcftools_amd.lib import check
+    S, n_sites, L, beg = N_SMPL, 2048, 100, 300
+    end = beg + n_sites
+    rng = np.random.default_rng(20260106)
+    per = int((n_sites + L) * 30.0 / L)
+    n = per * S
+    pos = np.sort(rng.integers(beg - L + 1, end, size=(S, per)), axis=1).astype(np.int32).ravel()
+    smpl = np.repeat(np.arange(S, dtype=np.int32), per)
+    kind = rng.choice(4, n, p=[0.94, 0.02, 0.02, 0.02])
+    table = {0: [L << 4], 1: [48 << 4, 2 << 4 | 2, 50 << 4], 2: [40 << 4, 3 << 4 | 1, 57 << 4], 3: [8 << 4 | 4, 92 << 4]}
+    span = np.array([100, 100, 97, 92], np.int32)[kind]              # reference bases a read of each kind covers
+    ncig = np.array([1, 3, 3, 2], np.int32)[kind]
+    cig_off = np.concatenate([[0], np.cumsum(ncig)[:-1]]).astype(np.int32)
+    cig = np.zeros(int(ncig.sum()), np.uint32)
+    for k, ops in table.items():
+        idx = np.nonzero(kind == k)[0]
+        for j, op in enumerate(ops):
+            cig[cig_off[idx] + j] = op
+    refseq = "".join("ACGT"[i] for i in rng.integers(0, 4, end + 2 * L))
+    seq = (1 << rng.integers(0, 4, n * L)).astype(np.uint8)
+    palette = np.array([2, 12, 23, 37], np.uint8)
+    qidx = rng.integers(0, 4, n * L).astype(np.uint8)
+    qual = palette[qidx]
+    lq = np.full(n, L, np.int32)
+    flag = (rng.integers(0, 2, n) * 16).astype(np.int32)
+    seq_off = (np.arange(n, dtype=np.int64) * L).astype(np.int32)
+    mapq = rng.integers(0, 61, n).astype(np.uint8)
+    rd = abi.Reads()
+    rd.n_reads = n
+    keep = dict(r_pos=pos, r_lq=lq, r_flag=flag, r_ncig=ncig, r_cig_off=cig_off, r_seq_off=seq_off, cig=cig, seq16=seq, qual=qual)
+    for k, v in keep.items():
+        setattr(rd, k, v.ctypes.data)
+    ctx = gpu_ctx_factory(abi.default_cfg(S, max_sites=1, max_reads=64))
+    t = abi.Tile()
+    col_n = np.zeros(n_sites, np.int32)
+    check(ctx.L.bcfgpu_pileup(ctx.h, C.byref(rd), mapq.ctypes.data, smpl.ctypes.data, beg, end, refseq.encode(), len(refseq), C.byref(t), col_n.ctypes.data, None))
+    total = int(t.n_reads)
+
+    def fetch():
+        off = np.zeros(n_sites * S + 1, np.uint32)
+        w, e = np.zeros(total, np.uint32), np.zeros(total, np.uint8)
+        for dst, src in ((off, t.plp_off), (w, t.rd), (e, t.epos)):
+            check(ctx.L.bcfgpu_memcpy_d2h(ctx.h, dst.ctypes.data, src, dst.nbytes))
+        ctx.sync()
+        return off, w, e
+    off, w, e = fetch()
+    # coverage by a difference array: +1 at the read's first column, -1 past its last
+    d = np.zeros((S, n_sites + 1), np.int32)
+    a = np.clip(pos - beg, 0, n_sites)
+    b = np.clip(pos + span - beg, 0, n_sites)
+    np.add.at(d, (smpl, a), 1)
+    np.add.at(d, (smpl, b), -1)
+    cov = np.cumsum(d[:, :n_sites], axis=1).T                         # [site][sample]
+    np.testing.assert_array_equal(np.diff(off.astype(np.int64)).reshape(n_sites, S), cov)
+    np.testing.assert_array_equal(col_n, cov.sum(axis=1))
+    assert total == int(cov.sum()) and total > 5e7
+    # the packed form of the same pool
+    pk = abi.Packed()
+    seq4, qual2 = abi.pack_nibbles(seq), abi.pack_crumbs(qidx)
+    rec = abi.read12(pos, lq, ncig, flag, mapq)
+    soff = (np.arange(S + 1, dtype=np.int64) * per).astype(np.int32)
+    pk.seq4, pk.qual4, pk.qual_bits, pk.recs, pk.smpl_off = seq4.ctypes.data, qual2.ctypes.data, 2, rec.ctypes.data, soff.ctypes.data
+    pk.n_bases, pk.n_cig = n * L, len(cig)
+    for j, q in enumerate(palette):
+        pk.palette[j] = int(q)
+    rd2 = abi.Reads()
+    rd2.n_reads, rd2.cig = n, cig.ctypes.data
+    check(ctx.L.bcfgpu_pileup_packed(ctx.h, C.byref(rd2), C.byref(pk), None, None, beg, end, refseq.encode(), len(refseq), C.byref(t), None, None))
+    assert int(t.n_reads) == total
+    off2, w2, e2 = fetch()
+    assert off2.tobytes() == off.tobytes() and w2.tobytes() == w.tobytes() and e2.tobytes() == e.tobytes()
