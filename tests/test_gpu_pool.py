@@ -223,6 +223,45 @@ def test_pool_baq_matches_the_host_pointer_call_on_random_reads(gpu_ctx_factory,
     np.testing.assert_array_equal(z_b, zo2)
 
 
+def test_pool_baq_at_scale_is_invariant_to_how_the_pool_is_cut(gpu_ctx_factory):
+    """3e5 reads of 100 bases (3e7 bases: several scratch blocks of wavefronts): BAQ of the whole pool equals BAQ of its two
+    halves uploaded one after the other -- a read's result depends on nothing but the read -- and two runs are identical."""
+    from bcftools_amd import synth
+    b = synth.indel_batch(77, 24, 420, depth=30.0)
+    R = b["reads"]
+    n = int(R["n_reads"])
+    assert n > 2.5e5
+    ctx = gpu_ctx_factory(abi.default_cfg(1, max_sites=1, max_reads=64))
+    L = ctx.L
+    mapq = np.full(n, 60, np.uint8)
+
+    def run(lo, hi):
+        rd = abi.Reads()
+        rd.n_reads = hi - lo
+        b0, c0 = int(R["r_seq_off"][lo]), int(R["r_cig_off"][lo])
+        b1 = int(R["r_seq_off"][hi - 1] + R["r_lq"][hi - 1])
+        arrs = dict(r_pos=R["r_pos"][lo:hi].copy(), r_lq=R["r_lq"][lo:hi].copy(), r_flag=R["r_flag"][lo:hi].copy(), r_ncig=R["r_ncig"][lo:hi].copy(),
+                    r_cig_off=(R["r_cig_off"][lo:hi] - c0).astype(np.int32), r_seq_off=(R["r_seq_off"][lo:hi] - b0).astype(np.int32),
+                    cig=R["cig"][c0:].copy(), seq16=R["seq16"][b0:b1].copy(), qual=R["qual"][b0:b1].copy())
+        for k, v in arrs.items():
+            setattr(rd, k, v.ctypes.data)
+        check(L.bcfgpu_pool_upload(ctx.h, C.byref(rd), None, mapq[lo:hi].ctypes.data))
+        ret = np.zeros(hi - lo, np.int32)
+        check(L.bcfgpu_pool_baq(ctx.h, b["ref"], len(b["ref"]), 3, ret.ctypes.data))
+        q, z = np.zeros(b1 - b0, np.uint8), np.zeros(b1 - b0, np.uint8)
+        check(L.bcfgpu_pool_download(ctx.h, q.ctypes.data, z.ctypes.data, None))
+        return q, z, ret
+    q, z, ret = run(0, n)
+    q_again, z_again, _ = run(0, n)
+    assert q.tobytes() == q_again.tobytes() and z.tobytes() == z_again.tobytes()
+    cut = n // 2 + 13
+    qa, za, ra = run(0, cut)
+    qb, zb, rb = run(cut, n)
+    assert np.concatenate([qa, qb]).tobytes() == q.tobytes() and np.concatenate([za, zb]).tobytes() == z.tobytes()
+    np.testing.assert_array_equal(np.concatenate([ra, rb]), ret)
+    assert (ret == 0).mean() > 0.9 and (q != R["qual"][:len(q)]).mean() > 0.01      # BAQ did lower qualities
+
+
 def test_pool_stages_need_a_pool(gpu_ctx_factory):
     ctx = gpu_ctx_factory(abi.default_cfg(2, max_sites=1, max_reads=64))
     t = abi.Tile()
