@@ -35,11 +35,11 @@ struct bcfgpu_ctx {
     float *d_q2p = nullptr;         // 10^(-q/10) as float (htslib g_qual2prob), for the realignment kernel
     double call_theta_log = 0;
     // workspaces sized by cfg.max_sites / cfg.max_reads
-    int *d_hist = nullptr, *d_err = nullptr;       // d_err: [0] error word, [1] truncated cells, [2..4] counters of glfgen's deep-cell list
+    int *d_hist = nullptr, *d_err = nullptr;       // d_err: [0] error word, [1] cells past 255 usable reads, [2..4] counters of glfgen's deep-cell list, [5] WideRecs of the launch
     uint16_t *d_keys = nullptr;                    // glfgen in two launches (BCFGPU_GLFGEN_SPLIT=1): 2 bytes per read between them
     int32_t *d_grp_rng = nullptr;                  // mcall: sample range of every -G group
-    float *d_grp_frac = nullptr;                   // mcall -G: a site's allele fractions per sample (the group sums run side by side from it)
-    uint32_t *d_deep_list = nullptr; uint16_t *d_deep_keys = nullptr; uint32_t deep_cap = 0, deep_key_cap = 0;
+    float *d_grp_frac = nullptr; size_t grp_frac_bytes = 0;   // mcall -G: a site's allele fractions per sample (the group sums run side by side from it); grow-only, sized per launch
+    uint32_t *d_deep_list = nullptr; uint16_t *d_deep_keys = nullptr; uint32_t deep_cap = 0, deep_key_cap = 0, wide_cap = 0;
     CallretPlanes *d_crp = nullptr;
     unsigned long long *d_site_sums = nullptr;
     CallretPlanes cr{};
@@ -128,12 +128,6 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
         bcfgpu_destroy(c); return rc;
     }
     if (cfg->n_grp > 1 && (rc = dev_alloc(c, (void**)&c->d_grp_rng, (size_t)cfg->n_grp * 3 * sizeof(int32_t)))) { bcfgpu_destroy(c); return rc; }
-    if (cfg->n_grp > 1) {   // the fractions scratch is optional: without it the group sums take their slower path
-        const size_t bytes = (size_t)(cfg->max_sites > 0 ? cfg->max_sites : 1) * 5 * (((size_t)cfg->n_smpl + 3) & ~(size_t)3) * sizeof(float);
-        void *p = nullptr;
-        if (bytes <= ((size_t)16 << 30) && hipMalloc(&p, bytes) == hipSuccess) { c->owned.push_back(p); c->d_grp_frac = (float*)p; }
-        else (void)hipGetLastError();
-    }
     hipMemcpy(c->d_fk, fk.data(), fk.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(c->d_beta, beta.data(), beta.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(c->d_lhet, lhet.data(), lhet.size() * 8, hipMemcpyHostToDevice);
@@ -168,12 +162,17 @@ int bcfgpu_create(const bcfgpu_cfg *cfg, bcfgpu_ctx **out)
         }
         // glfgen's list of cells deeper than its LDS key window, and the scratch their keys go to (2 bytes per pileup entry):
         // up to 1024 such cells per tile, with at most 32 Mi entries between them (or the whole tile's, when it is smaller)
+#ifdef BCFGPU_DIAG      // the two-launch form of glfgen is a measurement variant (make DIAG=1), never the product path
         if (const char *sp = getenv("BCFGPU_GLFGEN_SPLIT")) if (atoi(sp) && (rc = dev_alloc(c, (void**)&c->d_keys, ((size_t)cfg->max_reads + 64) * 2))) { bcfgpu_destroy(c); return rc; }
+#endif
         c->deep_cap = 1024;
         c->deep_key_cap = (uint32_t)std::min<uint64_t>((uint64_t)cfg->max_reads + 16 * 1024, 32u << 20);
         if ((rc = dev_alloc(c, (void**)&c->d_deep_list, (size_t)c->deep_cap * 8)) || (rc = dev_alloc(c, (void**)&c->d_deep_keys, (size_t)c->deep_key_cap * 2 + 64))) {
             bcfgpu_destroy(c); return rc;
         }
+        // the records of cells past 255 usable reads (kernels.h WideRec): a tile of n reads has at most n / 256 such cells
+        c->wide_cap = (uint32_t)std::min<uint64_t>((uint64_t)cfg->max_reads / 256 + 1, 1u << 26);
+        if ((rc = dev_alloc(c, (void**)&c->cr.wide, (size_t)c->wide_cap * sizeof(WideRec)))) { bcfgpu_destroy(c); return rc; }
         // the table of plane addresses as glfgen_kernel reads it at the point of its stores (kernels.h: GlfgenParams::crp)
         if ((rc = dev_alloc(c, (void**)&c->d_crp, sizeof(CallretPlanes)))) { bcfgpu_destroy(c); return rc; }
         e = hipMemcpy(c->d_crp, &c->cr, sizeof(CallretPlanes), hipMemcpyHostToDevice);
@@ -191,6 +190,7 @@ void bcfgpu_destroy(bcfgpu_ctx *c)
     hipSetDevice(c->cfg.device);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (void *p : c->owned) hipFree(p);
+    if (c->d_grp_frac) hipFree(c->d_grp_frac);
     for (auto &w : c->ws) if (w.p) hipFree(w.p);
     for (auto &w : c->pinned) if (w.p) hipHostFree(w.p);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
@@ -246,7 +246,7 @@ int bcfgpu_sync(bcfgpu_ctx *c)
     HIPCHK(hipMemcpy(&err, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
     if (err) {
         hipMemset(c->d_err, 0, sizeof(int));
-        return set_err(err, err == BCFGPU_E_DEPTH ? "a (site,sample) cell holds more pileup entries than a workgroup can stage (several thousand)" :
+        return set_err(err, err == BCFGPU_E_DEPTH ? "a (site,sample) cell holds more pileup entries than the scratch for over-deep cells takes, or more than 65535 reads of one base and strand" :
                             err == BCFGPU_E_RANGE ? "a record is outside the supported range (more than 5 alleles, or more genotypes / alleles than the planes hold): its ret is -2" : "device-side error");
     }
     return 0;
@@ -332,10 +332,11 @@ size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *c, int n_sites, int which)
     switch (which) {
         case 0: return n * sizeof(bcfgpu_site);
         case 1: return n * BCFGPU_MAX_PL * S;
-        case 2: return n * 4 * S;
-        case 3: case 4: return n * 5 * S;
-        case 5: return n * 5 * S * 2;
-        case 6: case 7: return n * S;
+        case 2: return n * 4 * S * 2;
+        case 3: case 4: return n * 5 * S * 2;
+        case 5: return n * 5 * S * 4;
+        case 6: return n * S * 2;
+        case 7: return n * S;
     }
     return 0;
 }
@@ -460,7 +461,8 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     g.deep_list = c->d_deep_list; g.deep_ctr = reinterpret_cast<uint32_t*>(c->d_err + 2); g.deep_keys = c->d_deep_keys;
     g.deep_cap = c->deep_cap; g.deep_key_cap = c->deep_key_cap;
     g.keys = c->d_keys;
-    HIPCHK(hipMemsetAsync(c->d_err + 2, 0, 3 * sizeof(int), c->stream));
+    g.wide_ctr = reinterpret_cast<uint32_t*>(c->d_err + 5); g.wide_cap = c->wide_cap;
+    HIPCHK(hipMemsetAsync(c->d_err + 2, 0, 4 * sizeof(int), c->stream));
 #ifdef BCFGPU_DIAG
     {   // phase stamps of glfgen_kernel: totals of the previous launch are printed, then cleared
         static unsigned long long *d_st = nullptr;
@@ -517,6 +519,22 @@ int bcfgpu_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_mplp_out
     return 0;
 }
 
+// The -G fractions scratch [n_sites][5][n_smpl rounded up to 4] for a launch of n_sites (grow-only; the kernel indexes it by
+// site, so it is sized from the launch, not from cfg.max_sites: a call-only context has max_sites = 0).  NULL when it cannot
+// be had: the kernel then takes the chained group sums.
+static float *grp_frac_for(bcfgpu_ctx *c, int n_sites)
+{
+    if (c->cfg.n_grp <= 1 || n_sites <= 0) return nullptr;
+    const size_t bytes = (size_t)n_sites * 5 * (((size_t)c->cfg.n_smpl + 3) & ~(size_t)3) * sizeof(float);
+    if (bytes <= c->grp_frac_bytes) return c->d_grp_frac;
+    if (bytes > ((size_t)16 << 30)) return nullptr;
+    if (c->d_grp_frac) { hipStreamSynchronize(c->stream); hipFree(c->d_grp_frac); c->d_grp_frac = nullptr; c->grp_frac_bytes = 0; }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    c->d_grp_frac = (float*)p; c->grp_frac_bytes = bytes;
+    return c->d_grp_frac;
+}
+
 int bcfgpu_mcall(bcfgpu_ctx *c, const bcfgpu_call_in *in, const bcfgpu_call_out *out)
 {
     if (!c || !in || !out || !out->site || !out->gt) return set_err(BCFGPU_E_ARG, "bcfgpu_mcall: bad arguments");
@@ -532,7 +550,7 @@ int bcfgpu_mcall(bcfgpu_ctx *c, const bcfgpu_call_in *in, const bcfgpu_call_out 
     m.pl_is_u8 = 0; m.call_flag = c->cfg.call_flag; m.output_tags = c->cfg.output_tags; m.n_grp = c->cfg.n_grp;
     m.theta = c->call_theta_log; m.pl2p = c->d_pl2p;
     m.nals = in->nals; m.unseen = in->unseen; m.msite = nullptr; m.pl = in->pl; m.qs = in->qs; m.ad = in->ad;
-    m.grp_rng = c->d_grp_rng; m.grp_frac = c->d_grp_frac;
+    m.grp_rng = c->d_grp_rng; m.grp_frac = grp_frac_for(c, m.n_sites);
     m.ploidy = in->ploidy; m.grp = c->cfg.n_grp > 1 ? in->grp : nullptr; m.prior_an = in->prior_an; m.prior_ac = in->prior_ac; m.i16 = in->i16;
     m.out = *out; m.out_n_gt_max = in->n_gt_max; m.err = c->d_err;
     if (c->timing == 1) hipEventRecord(c->ev[2], c->stream);
@@ -565,9 +583,9 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
     m.pl_is_u8 = 1; m.call_flag = c->cfg.call_flag; m.output_tags = c->cfg.output_tags; m.n_grp = c->cfg.n_grp;
     m.theta = c->call_theta_log; m.pl2p = c->d_pl2p;
     m.msite = mout->site; m.pl = mout->pl; m.qs = nullptr; m.ad = nullptr;
-    m.qs_u16 = (c->cfg.n_grp > 1 && c->cfg.grp_tag_is_qs) ? mout->qs : nullptr;
-    if (c->cfg.n_grp > 1 && !c->cfg.grp_tag_is_qs) { m.ad_u8 = mout->adf; m.ad_u8b = mout->adr; }   // FORMAT/AD = ADF+ADR (bam2bcf.c:892-896)
-    m.grp_rng = c->d_grp_rng; m.grp_frac = c->d_grp_frac;
+    m.qs_i32 = (c->cfg.n_grp > 1 && c->cfg.grp_tag_is_qs) ? mout->qs : nullptr;
+    if (c->cfg.n_grp > 1 && !c->cfg.grp_tag_is_qs) { m.ad_u16 = mout->adf; m.ad_u16b = mout->adr; }   // FORMAT/AD = ADF+ADR (bam2bcf.c:892-896)
+    m.grp_rng = c->d_grp_rng; m.grp_frac = grp_frac_for(c, m.n_sites);
     m.ploidy = ploidy; m.grp = c->cfg.n_grp > 1 ? grp : nullptr;
     m.out = *cout; m.out_n_gt_max = BCFGPU_MAX_PL; m.err = c->d_err;
 #ifdef BCFGPU_DIAG

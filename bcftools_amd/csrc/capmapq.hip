@@ -36,6 +36,7 @@ __device__ __forceinline__ int cap_nt16_of(char c)
         case 'M': case 'm': return 3;  case 'R': case 'r': return 5;  case 'S': case 's': return 6;  case 'V': case 'v': return 7;
         case 'W': case 'w': return 9;  case 'Y': case 'y': return 10; case 'H': case 'h': return 11; case 'K': case 'k': return 12;
         case 'D': case 'd': return 13; case 'B': case 'b': return 14;
+        case 'U': case 'u': return 8;  case '0': return 1; case '1': return 2; case '2': return 4; case '3': return 8;   /* the rest of htslib's seq_nt16_table */
         default: return 15;
     }
 }

@@ -54,9 +54,8 @@ __device__ double dev_kf_erfc(double x)
     return x > 0. ? 2. * p : 2. * (1. - p);
 }
 
-__device__ __forceinline__ uint32_t dev_format_sp(uint32_t cnt4)
+__device__ __forceinline__ uint32_t dev_format_sp(int fr, int rr, int fa, int ra)
 {
-    const int fr = cnt4 & 0xff, rr = (cnt4 >> 8) & 0xff, fa = (cnt4 >> 16) & 0xff, ra = cnt4 >> 24;
     if (fr + rr < 2 || fa + ra < 2 || fr + fa < 2 || rr + ra < 2) return 0;
     int x = (int)(-4.343 * log(dev_fisher_two_sided(fr, rr, fa, ra)) + .499);
     return (uint32_t)(x > 255 ? 255 : x);
@@ -219,6 +218,16 @@ template <int V> __device__ __forceinline__ void store_bytes(uint8_t *p, const u
     if constexpr (V == 4) *reinterpret_cast<uint32_t*>(p) = b[0] | b[1] << 8 | b[2] << 16 | b[3] << 24;
     else p[0] = (uint8_t)b[0];
 }
+template <int V> __device__ __forceinline__ void store_u16(uint16_t *p, const uint32_t (&b)[V])
+{
+    if constexpr (V == 4) *reinterpret_cast<uint2*>(p) = make_uint2(b[0] | b[1] << 16, b[2] | b[3] << 16);
+    else p[0] = (uint16_t)b[0];
+}
+template <int V> __device__ __forceinline__ void store_i32(int32_t *p, const uint32_t (&b)[V])
+{
+    if constexpr (V == 4) *reinterpret_cast<uint4*>(p) = make_uint4(b[0], b[1], b[2], b[3]);
+    else p[0] = (int32_t)b[0];
+}
 template <int NAL, int V>
 __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTotals &T, const int (&gs)[15], const int (&g1s)[15], const int (&g2s)[15], const int (&as)[5],
                                               int is, long c0, int base, int cn, int tid, long ncells, double *s_min)
@@ -286,18 +295,21 @@ __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTota
         }
         #pragma unroll
         for (int v = 0; v < V; ++v) s_min[i + v] = (double)mn[v];        // widened here, by all lanes, for the sequential sum
+        bool any_wide = false;
+        #pragma unroll
+        for (int v = 0; v < V; ++v) any_wide |= (misc[v] & CR_WIDE) != 0;
         if (NAL > 0 && !BCFGPU_ABL(P, 512)) {
-            uint8_t *DP4 = P.out.dp4 + (size_t)is * 4 * Ss + s;
+            uint16_t *DP4 = P.out.dp4 + (size_t)is * 4 * Ss + s;
             uint32_t b[V];
             #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 #pragma unroll
                 for (int v = 0; v < V; ++v) b[v] = (cnt4[v] >> (8 * j)) & 0xff;
-                store_bytes<V>(DP4 + (size_t)j * Ss, b);
+                store_u16<V>(DP4 + (size_t)j * Ss, b);
             }
             #pragma unroll
             for (int v = 0; v < V; ++v) { b[v] = (misc[v] >> 8) & 0xff; T.scr += b[v]; }
-            if (P.out.scr) store_bytes<V>(P.out.scr + (size_t)is * Ss + s, b);
+            if (P.out.scr) store_u16<V>(P.out.scr + (size_t)is * Ss + s, b);
             unsigned long long qs64[V];
             #pragma unroll
             for (int v = 0; v < V; ++v) qs64[v] = P.out.qs ? P.cr.qs64[cell + v] : 0ull;
@@ -311,15 +323,42 @@ __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTota
                     vr[v] = aj < 4 ? (adr[v] >> (8 * aj)) & 0xff : 0;
                     T.adf[j] += vf[v]; T.adr[j] += vr[v];
                 }
-                if (P.out.adf) store_bytes<V>(P.out.adf + ((size_t)is * 5 + j) * Ss + s, vf);
-                if (P.out.adr) store_bytes<V>(P.out.adr + ((size_t)is * 5 + j) * Ss + s, vr);
+                if (P.out.adf) store_u16<V>(P.out.adf + ((size_t)is * 5 + j) * Ss + s, vf);
+                if (P.out.adr) store_u16<V>(P.out.adr + ((size_t)is * 5 + j) * Ss + s, vr);
                 if (P.out.qs) {
-                    uint16_t q[V];
+                    uint32_t q[V];
                     #pragma unroll
-                    for (int v = 0; v < V; ++v) q[v] = (uint16_t)(aj < 4 ? (qs64[v] >> (16 * aj)) & 0xffff : 0);
-                    uint16_t *dst = P.out.qs + ((size_t)is * 5 + j) * Ss + s;
-                    if constexpr (V == 4) { uint2 u; __builtin_memcpy(&u, q, 8); *reinterpret_cast<uint2*>(dst) = u; }
-                    else dst[0] = q[0];
+                    for (int v = 0; v < V; ++v) q[v] = (uint32_t)(aj < 4 ? (qs64[v] >> (16 * aj)) & 0xffff : 0);
+                    store_i32<V>(P.out.qs + ((size_t)is * 5 + j) * Ss + s, q);
+                }
+            }
+        }
+        // Cells of more than 255 usable reads (rare): the packed counts above are those of the 255 reads the likelihoods were made
+        // of; what the record carries is the counts over all reads (kernels.h WideRec).  The cell's plane entries are written again
+        // and what it added to the lane's totals is replaced (the same expressions subtracted: exact in modular arithmetic).
+        if (__any(any_wide)) {
+            #pragma unroll
+            for (int v = 0; v < V; ++v) {
+                if (!(misc[v] & CR_WIDE)) continue;
+                const WideRec *w = P.cr.wide + (uint32_t)P.cr.qs64[cell + v];
+                const uint32_t wc[4] = { w->cnt[0] & 0xffffu, w->cnt[0] >> 16, w->cnt[1] & 0xffffu, w->cnt[1] >> 16 };
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) T.cnt[j] += wc[j] - ((cnt4[v] >> (8 * j)) & 0xff);
+                if (NAL > 0 && !BCFGPU_ABL(P, 512)) {
+                    #pragma unroll
+                    for (int j = 0; j < 4; ++j) P.out.dp4[((size_t)is * 4 + j) * Ss + s + v] = (uint16_t)wc[j];
+                    T.scr += w->scr - ((misc[v] >> 8) & 0xff);
+                    if (P.out.scr) P.out.scr[(size_t)is * Ss + s + v] = (uint16_t)w->scr;
+                    #pragma unroll
+                    for (int j = 0; j < NAL; ++j) {
+                        const int aj = as[j];
+                        const uint32_t ad = aj < 4 ? w->ad[aj] : 0u, nf = ad & 0xffffu, nr = ad >> 16;
+                        T.adf[j] += nf - (aj < 4 ? (adf[v] >> (8 * aj)) & 0xff : 0);
+                        T.adr[j] += nr - (aj < 4 ? (adr[v] >> (8 * aj)) & 0xff : 0);
+                        if (P.out.adf) P.out.adf[((size_t)is * 5 + j) * Ss + s + v] = (uint16_t)nf;
+                        if (P.out.adr) P.out.adr[((size_t)is * 5 + j) * Ss + s + v] = (uint16_t)nr;
+                        if (P.out.qs) P.out.qs[((size_t)is * 5 + j) * Ss + s + v] = (int32_t)(aj < 4 ? w->qs[aj] : 0u);
+                    }
                 }
             }
         }
@@ -365,8 +404,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, 
         __syncthreads();
         for (int i = tid; i < cn; i += WG) {
             const unsigned long long v = P.cr.qs64[c0 + base + i];
-            const float q0 = (float)(int)(v & 0xffff), q1 = (float)(int)((v >> 16) & 0xffff);
-            const float q2 = (float)(int)((v >> 32) & 0xffff), q3 = (float)(int)((v >> 48) & 0xffff);
+            float q0 = (float)(int)(v & 0xffff), q1 = (float)(int)((v >> 16) & 0xffff);
+            float q2 = (float)(int)((v >> 32) & 0xffff), q3 = (float)(int)((v >> 48) & 0xffff);
+            if ((uint32_t)(v >> 48) == 0xffffu) {               // WIDE_QS_MARK: a cell of more than 255 usable reads, QS over all of them
+                const WideRec *w = P.cr.wide + (uint32_t)v;
+                q0 = (float)(int)w->qs[0]; q1 = (float)(int)w->qs[1]; q2 = (float)(int)w->qs[2]; q3 = (float)(int)w->qs[3];
+            }
             float sum = 0;
             sum += q0; sum += q1; sum += q2; sum += q3;
             float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -419,7 +462,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, 
     const bool dead = (P.is_indel && nal == 1);     // bcf_call_combine returned -1 (bam2bcf.c:611)
 
     // ---- per-sample planes + integer totals ----
-    // per-lane partial totals (u32 is ample: a lane sees S/64 samples of <=255 reads); anno[4..15] arrive as site totals
+    // per-lane partial totals (u32 is ample: a lane sees S/64 samples of <= 4 x 65535 reads); anno[4..15] arrive as site totals
     SampleTotals T;
     #pragma unroll
     for (int j = 0; j < 5; ++j) T.adf[j] = T.adr[j] = 0;
@@ -471,7 +514,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, 
     // FMT/SP (bam2bcf.c:867-885): a Fisher exact test per sample, in its own pass -- its loops over the table's margins
     // diverge between lanes, and only samples with at least two reads in every margin enter them
     if (P.out.sp && (P.fmt_flag & BCFGPU_FMT_SP) && !dead) {
-        for (int s = tid; s < S; s += WG) P.out.sp[(size_t)is * S + s] = (uint8_t)dev_format_sp(P.cr.cnt4[c0 + s]);
+        // (from the DP4 planes this wavefront has just written: they hold the counts over all reads, whatever the cell's depth)
+        const uint16_t *d4 = P.out.dp4 + (size_t)is * 4 * S;
+        for (int s = tid; s < S; s += WG)
+            P.out.sp[(size_t)is * S + s] = (uint8_t)dev_format_sp(d4[s], d4[(size_t)S + s], d4[2 * (size_t)S + s], d4[3 * (size_t)S + s]);
     }
     uint32_t (&t_adf)[5] = T.adf; uint32_t (&t_adr)[5] = T.adr; uint32_t (&t_cnt)[4] = T.cnt;
     const uint32_t t_scr = T.scr, t_ori = T.ori, t_mq0 = T.mq0;
@@ -512,15 +558,22 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, 
         for (int i = tid; i < 512; i += WG) s_oc[i] = 0;
         __syncthreads();
         int nzero = 0;
+        double part_deep = 0;
+        const uint16_t *d4s = P.out.dp4 + (size_t)is * 4 * S;
         for (int s0 = 0; s0 < S; s0 += WG) {
             const int s = s0 + tid;
             int oi = -1;
-            if (s < S) { const uint32_t cnt4 = P.cr.cnt4[c0 + s]; oi = (int)(((cnt4 >> 16) & 0xff) + ((cnt4 >> 24) & 0xff)); }
+            if (s < S) oi = (int)d4s[2 * (size_t)S + s] + (int)d4s[3 * (size_t)S + s];     // the DP4 planes written above (counts over all reads)
             nzero += __popcll(__ballot(oi == 0));
-            if (oi > 0) atomicAdd(&s_oc[oi], 1);
+            if (oi > 0 && oi < 512) atomicAdd(&s_oc[oi], 1);
+            else if (oi >= 512) {                                 // a cell far past 255 reads: its term on its own
+                double tmp = dev_logsumexp2(log(2 * (1 - f)), log(f) + oi * log2 - q);
+                tmp += log(f) + oi * log(q / p) - q + p;
+                part_deep += tmp;
+            }
         }
         __syncthreads();
-        double part = 0;
+        double part = part_deep;
         for (int k0 = 0; k0 < 512; k0 += WG) {
             const int oi = k0 + tid;
             const int cnt = oi == 0 ? nzero : s_oc[oi];
@@ -596,7 +649,7 @@ void launch_combine(const CombineParams &p, hipStream_t s)
     auto al = [](const void *ptr, uintptr_t a) { return ptr == nullptr || reinterpret_cast<uintptr_t>(ptr) % a == 0; };
     q.vec4 = (p.n_smpl % 4 == 0) && !BCFGPU_ABL(p, 1024) &&
              al(p.cr.p15, 16) && al(p.cr.pa, 16) && al(p.cr.cnt4, 16) && al(p.cr.adf, 16) && al(p.cr.adr, 16) && al(p.cr.misc, 16) && al(p.cr.qs64, 8) &&
-             al(p.out.pl, 4) && al(p.out.dp4, 4) && al(p.out.scr, 4) && al(p.out.adf, 4) && al(p.out.adr, 4) && al(p.out.qs, 8);
+             al(p.out.pl, 4) && al(p.out.dp4, 8) && al(p.out.scr, 8) && al(p.out.adf, 8) && al(p.out.adr, 8) && al(p.out.qs, 16);
     if (q.vec4) hipLaunchKernelGGL(combine_kernel<4>, dim3(q.n_sites), dim3(WG), 0, s, q);
     else hipLaunchKernelGGL(combine_kernel<1>, dim3(q.n_sites), dim3(WG), 0, s, q);
 }

@@ -707,7 +707,9 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
         p.ref2 = d_ref2; p.qpack = d_qpack; p.q2p = q2p; p.score1 = d_s1; p.score2 = d_s2;
         p.pjob = d_pjob; p.key_in = d_k0; p.val_in = d_v0; p.key_sorted = d_k1; p.val_sorted = d_v1; p.list2 = d_list2; p.queue = d_queue;
         p.wide = d_wide; p.tot = d_tot;
-        p.force_wide = getenv("BCFGPU_FORCE_WIDE") != nullptr;      // tests: every job through the rolling-row kernel
+#ifdef BCFGPU_DIAG
+        p.force_wide = getenv("BCFGPU_FORCE_WIDE") != nullptr;      // diagnostics build only: every job through the rolling-row kernel
+#endif
         hipEvent_t e0 = nullptr, e1 = nullptr;
         hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0, st);

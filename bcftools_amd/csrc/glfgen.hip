@@ -572,55 +572,52 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ?
         uint16_t *kp_w = s_key + (part ? beg - abase : 0);       // the lane's keys
         const uint16_t *kp = kp_w;
         const int cnt_raw = part ? (int)(end - beg) : 0;
-        // A cell with more than 255 usable reads: errmod_cal would draw a random 255 of them (htslib errmod.c, hts_drand48),
-        // which no parallel order can reproduce.  Here the cell keeps its first 255 usable reads and the later ones are
-        // removed from the pileup altogether, as a depth cap would: their keys are cleared and what phase A added for them
-        // to the site's totals and histograms is taken back.  Counted in P.trunc (bcfgpu_truncated_cells).
+        // A cell with more than 255 usable reads.  bcf_call_glfgen counts every read (QS, ADF/ADR, anno[], SCR, the site's I16
+        // sums and histograms: bam2bcf.c:203-252, all done by phase A or below over all keys); only errmod_cal cuts its input to
+        // 255 (bam2bcf.c:256; htslib errmod.c draws them with hts_drand48, a process-wide generator no parallel order can replay).
+        // Here the cell's counts over ALL reads go to a WideRec (kernels.h), and the keys past the 255th usable read are cleared
+        // so that everything below -- which only feeds the likelihoods of such a cell -- sees the 255 reads errmod_cal takes.
+        // Counted in P.trunc (bcfgpu_truncated_cells: cells whose PLs may deviate from a reference run).
         if (__any(cnt_raw > BCFGPU_MAX_DEPTH)) {
-            uint32_t acc = 0, ntr = 0;
-            const int nchk = cnt_raw > BCFGPU_MAX_DEPTH ? cnt_raw : 0;
-            int *hist_c = LDS_HIST ? s_hist + (site - site0) * HP_SIZE : P.hist + (long)site * H_SIZE;
-            unsigned long long *tot_c = LDS_HIST ? s_tot + (site - site0) * SITE_NSUM : P.site_sums + (size_t)site * SITE_NSUM;
-            for (int i = 0; i < nchk; ++i) {
-                if (kp_w[i] == 0) continue;
-                if (acc < BCFGPU_MAX_DEPTH) { ++acc; continue; }
-                kp_w[i] = 0; ++ntr;
-                // the read's contributions, as phase A computed them (bam2bcf.c:173-252)
-                const uint32_t idx = beg + (uint32_t)i, w = p_rd[idx];
-                uint32_t b, bq;
-                if (INDEL) {
-                    const uint32_t ax = p_aux[idx];
-                    b = (ax >> 16) & 0xf; bq = ax & 0xff;
-                    if (bq < min_baseQ) b = 0;
-                    b = min(b, 4u);
-                } else { bq = w & 0xff; b = (uint32_t)nt16_int((int)((w >> 16) & 15) ? (int)((w >> 16) & 15) : (int)P.ref16[site]); }
-                uint32_t mapQ = (w >> 8) & 0xff;
-                if (mapQ == 255) mapQ = DEF_MAPQ;
-                const uint32_t is0 = mapQ == 0;
-                mapQ = min(mapQ, capQ);
-                const uint32_t md = min(w >> 24, (uint32_t)CAP_DIST), rev = (w >> 20) & 1;
-                const bool diff = INDEL ? b != 0 : !(ref4c < 4 && (int)b == ref4c);
-                const bool isref = !INDEL && (int)((w >> 16) & 15) == (int)P.ref16[site];
-                const int o = diff ? 2 : 0;
-                auto sub = [&](int j, uint32_t v) { if (v) atomicAdd(&tot_c[j], 0ull - (unsigned long long)v); };
-                sub(0 + o, bq); sub(1 + o, bq * bq); sub(4 + o, mapQ); sub(5 + o, mapQ * mapQ); sub(8 + o, md); sub(9 + o, md * md);
-                sub(12, 1u); sub(13, is0);
-                const uint32_t aoff = isref ? 0u : (uint32_t)H_ALT_OFF, imq = min(mapQ, 59u);
-                const uint32_t ep = want_epos ? p_epos[idx] : 0u;
-                if (LDS_HIST) {
-                    const int inc = isref ? 1 : 0x10000;
-                    atomicSub(&hist_c[H_REF_POS + ep], inc);
-                    atomicSub(&hist_c[H_REF_BQ + min(bq, 59u)], inc);
-                    atomicSub(&hist_c[H_REF_MQ + imq], inc);
-                    atomicSub(&hist_c[HP_MQS + imq], rev ? 0x10000 : 1);
-                } else {
-                    atomicSub(&hist_c[aoff + H_REF_POS + ep], 1);
-                    atomicSub(&hist_c[aoff + H_REF_BQ + min(bq, 59u)], 1);
-                    atomicSub(&hist_c[aoff + H_REF_MQ + imq], 1);
-                    atomicSub(&hist_c[(rev ? H_REV_MQS : H_FWD_MQS) + imq], 1);
+            if (cnt_raw > BCFGPU_MAX_DEPTH) {
+                uint32_t nus = 0;
+                for (int i = 0; i < cnt_raw; ++i) nus += kp_w[i] != 0 ? 1u : 0u;
+                const volatile unsigned long long *t = reinterpret_cast<const volatile unsigned long long*>(P.crp);
+                uint64_t *qs64_p = reinterpret_cast<uint64_t*>(t[2]); uint32_t *misc_p = reinterpret_cast<uint32_t*>(t[6]);
+                uint32_t mark = 0;
+                if (nus > BCFGPU_MAX_DEPTH) {
+                    uint32_t qs[4] = {0, 0, 0, 0}, af[4] = {0, 0, 0, 0}, ar[4] = {0, 0, 0, 0}, cn[4] = {0, 0, 0, 0}, sc = 0, acc = 0;
+                    const bool all_diff = !INDEL && ref4c >= 4;
+                    for (int i = 0; i < cnt_raw; ++i) {
+                        const uint32_t k = kp_w[i];
+                        if (k == 0) continue;
+                        const uint32_t rev = KEY_REV(k), q = KEY_Q(k), b = KEY_B(k);
+                        const uint32_t dr = ((all_diff || !(k & KEY_PRIM)) ? 2u : 0u) | rev;     // anno[0<<2 | is_diff<<1 | is_rev]
+                        #pragma unroll
+                        for (uint32_t x = 0; x < 4; ++x) {
+                            qs[x] += b == x ? q : 0u;
+                            af[x] += (b == x && !rev) ? 1u : 0u; ar[x] += (b == x && rev) ? 1u : 0u;
+                            cn[x] += dr == x ? 1u : 0u;
+                        }
+                        sc += KEY_SC(k);
+                        if (++acc > BCFGPU_MAX_DEPTH) kp_w[i] = 0;
+                    }
+                    const uint32_t slot = atomicAdd(P.wide_ctr, 1u);
+                    const uint32_t big = af[0] | af[1] | af[2] | af[3] | ar[0] | ar[1] | ar[2] | ar[3] | cn[0] | cn[1] | cn[2] | cn[3] | sc;
+                    if (slot >= P.wide_cap || big > 0xffffu) atomicExch(P.err, BCFGPU_E_DEPTH);     // (16-bit count planes; the list is sized n_reads / 256)
+                    else {
+                        WideRec *w = reinterpret_cast<WideRec*>(t[7]) + slot;
+                        #pragma unroll
+                        for (int x = 0; x < 4; ++x) { w->qs[x] = qs[x]; w->ad[x] = af[x] | ar[x] << 16; }
+                        w->cnt[0] = cn[0] | cn[1] << 16; w->cnt[1] = cn[2] | cn[3] << 16;
+                        w->scr = sc; w->n = nus; w->cell = (uint32_t)cell; w->pad[0] = w->pad[1] = w->pad[2] = 0;
+                        qs64_p[cell] = WIDE_QS_MARK | slot;      // where combine_kernel's frequency pass finds the record
+                        mark = CR_WIDE;
+                    }
+                    atomicAdd(P.trunc, 1u);
                 }
+                misc_p[cell] = mark;             // read back where the cell's planes are stored (below)
             }
-            if (ntr) atomicAdd(P.trunc, 1u);
         }
         GLF_STAMP(3)
         // pass 1: the quality mask of the primary base; the few other reads are gathered at the front of the slice
@@ -762,9 +759,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ?
             const uint32_t n_fwd = n - n_rev;
             const uint32_t d_rev = all_diff ? n_rev : o_rev, d_fwd = all_diff ? n_fwd : n_other - o_rev;
             const uint32_t cnt4 = (n_fwd - d_fwd) | (n_rev - d_rev) << 8 | d_fwd << 16 | d_rev << 24;
-            cr.qs64[cell] = qs64;
+            // (an over-deep cell: its mark and its WideRec index were left above; qs64 keeps the index, the packed counts below are
+            // those of the 255 reads the likelihoods were made of -- their sum is the n of errmod_cal)
+            uint32_t wm = 0;
+            if (cnt_raw > BCFGPU_MAX_DEPTH) wm = *reinterpret_cast<volatile uint32_t*>(&cr.misc[cell]) & CR_WIDE;
+            if (!wm) cr.qs64[cell] = qs64;
             cr.adf[cell] = (uint32_t)ad64; cr.adr[cell] = (uint32_t)(ad64 >> 32); cr.cnt4[cell] = cnt4;
-            cr.misc[cell] = code | (scr & 0xff) << 8;  // mq0 and ori_depth only feed site totals: site_sums[12..13]
+            cr.misc[cell] = code | wm | (scr & 0xff) << 8;  // mq0 and ori_depth only feed site totals: site_sums[12..13]
             done = true;
         }
         if (nb == 0xffffffffu) break;

@@ -29,7 +29,7 @@ struct GvcfParams {
     const int32_t *pos, *rid;
     const uint8_t *brk;
     const bcfgpu_site *site;
-    const uint8_t *pl, *dp4;
+    const uint8_t *pl; const uint16_t *dp4;
     const uint8_t *ref_only; const int32_t *dp32, *end;      // the `call -g` form (bcfgpu.h)
     int32_t *range, *head, *scan;       // workspace
     int32_t *blk, *min_dp;
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void gvcf_site_kernel(const GvcfParams P)
         const int32_t *d = P.dp32 + (size_t)site * S;
         for (int s = lane; s < S; s += 64) m = min(m, d[s]);
     } else {
-        const uint8_t *d = P.dp4 + (size_t)site * 4 * S;
+        const uint16_t *d = P.dp4 + (size_t)site * 4 * S;
         for (int s = lane; s < S; s += 64) m = min(m, (int)d[s] + d[S + s] + d[2 * S + s] + d[3 * S + s]);
     }
     for (int o = 32; o; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void gvcf_reduce_kernel(const GvcfParams P, int
         P.dp_out[(size_t)b * S + s] = dp;
         return;
     }
-    const uint8_t *d = P.dp4 + (size_t)first * 4 * S + s, *p = P.pl + (size_t)first * BCFGPU_MAX_PL * S + s;
+    const uint16_t *d = P.dp4 + (size_t)first * 4 * S + s; const uint8_t *p = P.pl + (size_t)first * BCFGPU_MAX_PL * S + s;
     int dp = (int)d[0] + d[S] + d[2 * S] + d[3 * S];
     const int pl0 = p[0];
     int pl1 = p[S], pl2 = p[2 * S];

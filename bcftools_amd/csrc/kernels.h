@@ -41,10 +41,27 @@ struct CallretPlanes {
     uint32_t *adf;    // [ncells]      ADF[0..3] packed 4 x u8
     uint32_t *adr;    // [ncells]      ADR[0..3] packed 4 x u8
     uint32_t *cnt4;   // [ncells]      anno[0..3] packed 4 x u8
-    uint32_t *misc;   // [ncells]      code | SCR<<8; code = the cell's base 0..4, or CR_FULL: all 15 likelihoods are in p15
+    uint32_t *misc;   // [ncells]      code | SCR<<8; code = the cell's base 0..4, or CR_FULL: all 15 likelihoods are in p15;
+                      //               | CR_WIDE: the cell has more than 255 usable reads -- its packed counts above are those of the 255
+                      //               reads errmod_cal took, qs64 is WIDE_QS_MARK | the index of its WideRec, which has the counts over all reads
+    struct WideRec *wide;   // [wide_cap]
 };
 
-enum : uint32_t { CR_FULL = 0x80 };
+enum : uint32_t { CR_FULL = 0x80, CR_WIDE = 0x40 };
+// qs64 of a CR_WIDE cell: this mark (QS[3] = 0xffff cannot come from 255 reads of quality <= 63) | the index of its WideRec
+#define WIDE_QS_MARK (0xffffull << 48)
+
+// What bcf_call_glfgen leaves for a cell of more than 255 usable reads, over ALL of them (bam2bcf.c:203-226): such cells are
+// rare (never under mpileup's default -d 250 with one file per sample), so the planes above keep their packed form and these
+// records are handed out by an atomic counter; a tile of n reads has at most n/256 of them.
+struct WideRec {
+    uint32_t qs[4];        // QS[0..3]
+    uint32_t ad[4];        // ADF[b] | ADR[b] << 16
+    uint32_t cnt[2];       // anno[0] | anno[1] << 16, anno[2] | anno[3] << 16
+    uint32_t scr, n;       // SCR; usable reads (bcf_call_glfgen's return value)
+    uint32_t cell, pad[3];
+};
+static_assert(sizeof(WideRec) == 64, "one cache-line-aligned record per over-deep cell");
 
 struct GlfgenParams {
     int n_sites, n_smpl, is_indel;
@@ -64,7 +81,9 @@ struct GlfgenParams {
     int *hist;                      // [n_sites][H_SIZE], zeroed before launch
     unsigned long long *site_sums;  // [n_sites][SITE_NSUM] site totals of anno[4..15], ori_depth, mq0 (exact integers), zeroed before launch
     int *err;                       // device error word
-    unsigned int *trunc;            // cells cut to their first 255 usable reads (counter)
+    unsigned int *trunc;            // cells whose likelihoods come from their first 255 usable reads (counter)
+    uint32_t *wide_ctr;             // [0] WideRecs handed out by this launch (zeroed before launch)
+    uint32_t wide_cap;              // records in crp->wide
     // cells whose pileup does not fit the LDS key window: listed by the tile launch, worked on by the launch that follows
     uint32_t *deep_list;            // [deep_cap][2]: cell, offset of its keys in deep_keys
     uint32_t *deep_ctr;             // [0] cells listed, [1] keys handed out, [2] set when the list or the scratch ran out (zeroed before launch)
@@ -100,7 +119,7 @@ struct McallParams {
     const void *pl;
     const float *qs;                // [site][5] or NULL (fused: msite->qsum)
     const int32_t *ad;              // i32 planes or NULL
-    const uint8_t *ad_u8, *ad_u8b; const uint16_t *qs_u16;   // fused -G sources (mpileup-stage ADF/ADR or QS planes, stride 5)
+    const uint16_t *ad_u16, *ad_u16b; const int32_t *qs_i32;   // fused -G sources (mpileup-stage ADF/ADR or QS planes, stride 5)
     const uint8_t *ploidy;
     const int32_t *grp;
     int32_t *grp_rng;               // [n_grp][3] workspace: first sample, last sample + 1 and number of samples of every group (launch_mcall fills it)

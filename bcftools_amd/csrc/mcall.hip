@@ -273,16 +273,17 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                     #pragma unroll
                     for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = P.ad[((size_t)is * P.n_al_max + k) * Ss + s + j];
                 } else if (k < nals) {
-                    if (P.qs_u16) {
+                    if (P.qs_i32) {
                         #pragma unroll
-                        for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = (int)P.qs_u16[((size_t)is * 5 + k) * Ss + s + j];
+                        for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = (int)P.qs_i32[((size_t)is * 5 + k) * Ss + s + j];
                     } else {
-                        const uint8_t *pa = P.ad_u8 + ((size_t)is * 5 + k) * Ss + s, *pb = P.ad_u8b + ((size_t)is * 5 + k) * Ss + s;
-                        uint32_t wa = 0, wb = 0;
-                        if (rem >= 4) { __builtin_memcpy(&wa, pa, 4); __builtin_memcpy(&wb, pb, 4); }
-                        else for (int j = 0; j < rem; ++j) { wa |= (uint32_t)pa[j] << (8 * j); wb |= (uint32_t)pb[j] << (8 * j); }
+                        // FORMAT/AD = ADF + ADR (bam2bcf.c:892-896): a lane's four samples of a 16-bit plane are one 8-byte load
+                        const uint16_t *pa = P.ad_u16 + ((size_t)is * 5 + k) * Ss + s, *pb = P.ad_u16b + ((size_t)is * 5 + k) * Ss + s;
+                        uint16_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
+                        if (rem >= 4 && ((reinterpret_cast<uintptr_t>(pa) | reinterpret_cast<uintptr_t>(pb)) & 7) == 0) { __builtin_memcpy(wa, pa, 8); __builtin_memcpy(wb, pb, 8); }
+                        else for (int j = 0; j < 4 && j < rem; ++j) { wa[j] = pa[j]; wb[j] = pb[j]; }
                         #pragma unroll
-                        for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = (int)((wa >> (8 * j)) & 0xff) + (int)((wb >> (8 * j)) & 0xff);
+                        for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = (int)wa[j] + (int)wb[j];
                     }
                 }
             }
@@ -592,7 +593,8 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             // (few samples: 4*nq consecutive samples per lane with nq = 2 or 1, so that the 16 lanes' columns stay filled)
             // a group's samples lie in [first, last] (grp_range_kernel): consecutive for populations listed one after the
             // other, and then the groups' scans together read every sample once
-            const int s_first = (ngrp > 1 && P.grp_rng) ? (P.grp_rng[3 * g] & ~3) : 0, s_last = (ngrp > 1 && P.grp_rng) ? P.grp_rng[3 * g + 1] : S;
+            const int s_last = (ngrp > 1 && P.grp_rng) ? P.grp_rng[3 * g + 1] : S;
+            const int s_first = (ngrp > 1 && P.grp_rng) ? (min(P.grp_rng[3 * g], s_last) & ~3) : 0;
             const int span = s_last - s_first;
             const int nq = span > 128 ? 4 : span > 64 ? 2 : 1;
             for (int s0 = s_first; s0 < (BCFGPU_ABL(P, 16) ? 0 : s_last); s0 += 64 * nq) {
@@ -717,7 +719,9 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             setbits = rowbits;
         } else {
         for (int t = 0; t < nsub; ++t) { s_man[t * WGS + tid] = 1.0; s_exp[t * WGS + tid] = 0; }
-        const int g_first = (ngrp > 1 && P.grp_rng) ? P.grp_rng[3 * g] : 0, g_last = (ngrp > 1 && P.grp_rng) ? P.grp_rng[3 * g + 1] : S;
+        // (a group no sample belongs to keeps {INT_MAX, 0, 0}: an empty range, not a start that overflows when tid is added)
+        const int g_last = (ngrp > 1 && P.grp_rng) ? P.grp_rng[3 * g + 1] : S;
+        const int g_first = (ngrp > 1 && P.grp_rng) ? min(P.grp_rng[3 * g], g_last) : 0;
         for (int s = g_first + tid; s < (BCFGPU_ABL(P, 16) ? 0 : g_last); s += WGS) {
             if (ngrp > 1 && GRP_OF(s) != g) continue;
             int pl[NG]; double pdg[NG];

@@ -62,6 +62,7 @@ struct PileupParams {
     int n_reads;                    // reads of the pool (bcfgpu_gap_prep_tile)
     uint32_t n_bases;               // bases of the pool's seq16 / qual
     const int *d_span;              // the longest reference span of a read, as pileup_meta_kernel left it (max_span once the host has read it)
+    int ref_len;                    // length of the contig handed to bcfgpu_pileup (bcfgpu_gap_prep_tile: the end of par->ref)
 };
 
 // first k in [lo, hi) with a[k] > x
@@ -799,6 +800,7 @@ static int pool_pileup_impl(const char *who, bcfgpu_ctx *ctx, const int32_t *r_s
     }
     #undef PL_CHK
     static_assert(sizeof(PileupParams) <= 256, "fits the context's pileup_state");
+    P.ref_len = ref_len;
     std::memcpy(bcfgpu_internal_pileup_state(ctx), &P, sizeof P);          // for bcfgpu_pileup_entries
     tile->n_sites = n_sites; tile->is_indel = 0; tile->n_reads = total;
     tile->ref16 = (const int8_t*)d_ref16; tile->plp_off = d_cnt; tile->rd = P.rd; tile->epos = P.epos;
@@ -1067,8 +1069,12 @@ extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32
     int32_t *d_rncig = (int32_t*)GWS(3, (size_t)nr * 4), *d_rcoff = (int32_t*)GWS(4, (size_t)nr * 4), *d_rsoff = (int32_t*)GWS(5, (size_t)nr * 4);
     int32_t *d_pos = (int32_t*)GWS(11, (size_t)n_cols * 4);
     const int pmin = P.beg + cmin, pmax = P.beg + cmax;
-    const long ref_lo = pmin > 65536 ? pmin - 65536 : 0;
-    const long ref_hi = pmax + 1 + (long)strnlen(par->ref + pmax + 1, 65536 + 4096);
+    // The slice of the contig the batch touches.  The contig ends where bcfgpu_pileup was told it ends (ref_len): a candidate
+    // column at or past that end reads nothing of par->ref (bcfgpu_indel_in carries no length of its own).
+    const long ref_end = P.ref_len > 0 ? (long)P.ref_len : 0;
+    const long ref_lo = std::min<long>(pmin > 65536 ? pmin - 65536 : 0, ref_end);
+    const long ref_from = std::min<long>((long)pmax + 1, ref_end);
+    const long ref_hi = ref_from + (long)strnlen(par->ref + ref_from, (size_t)std::min<long>(65536 + 4096, ref_end - ref_from));
     char *d_ref = (char*)GWS(24, (size_t)(ref_hi - ref_lo));
     const bool any_zq = reads && reads->zq && reads->r_has_zq;
     uint8_t *d_zq = any_zq ? (uint8_t*)GWS(9, (size_t)P.n_bases) : nullptr, *d_haszq = any_zq ? (uint8_t*)GWS(10, (size_t)nr) : nullptr;
@@ -1081,7 +1087,7 @@ extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32
     if (any_zq && reads->n_reads != nr) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep_tile: `reads` is not the pool of the last bcfgpu_pileup");
     if (nr) hipLaunchKernelGGL(gap_unpack_reads_kernel, dim3((nr + 255) / 256), dim3(256), 0, stream, P, d_rpos, d_rlq, d_rflag, d_rncig, d_rcoff, d_rsoff);
     hipLaunchKernelGGL(gap_col_pos_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, stream, d_cols, n_cols, P.beg, d_pos);
-    GT_CHK(hipMemcpyAsync(d_ref, par->ref + ref_lo, (size_t)(ref_hi - ref_lo), hipMemcpyHostToDevice, stream));
+    if (ref_hi > ref_lo) GT_CHK(hipMemcpyAsync(d_ref, par->ref + ref_lo, (size_t)(ref_hi - ref_lo), hipMemcpyHostToDevice, stream));
     if (any_zq) {
         GT_CHK(hipMemcpyAsync(d_zq, reads->zq, (size_t)P.n_bases, hipMemcpyHostToDevice, stream));
         GT_CHK(hipMemcpyAsync(d_haszq, reads->r_has_zq, (size_t)nr, hipMemcpyHostToDevice, stream));

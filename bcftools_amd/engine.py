@@ -97,10 +97,26 @@ class Context:
             d.aux = bufs[-1].ptr
         return d, bufs
 
-    def alloc_mplp_out(self, n_sites):
+    def flagged_planes(self):
+        """The planes of bcfgpu_mplp_out the context's fmt_flag / grouping asks for: the others may be NULL (mpileup.c:612-636
+        allocates ADF/ADR/SCR only under their flags) and are then neither computed nor written."""
+        f, names = self.cfg.fmt_flag, ["site", "pl", "dp4"]
+        grp_ad = self.cfg.n_grp > 1 and not self.cfg.grp_tag_is_qs
+        if grp_ad or f & (abi.FMT_AD | abi.FMT_ADF | abi.FMT_ADR | abi.FMT_DPR | abi.INFO_AD | abi.INFO_ADF | abi.INFO_ADR | abi.INFO_DPR):
+            names += ["adf", "adr"]
+        if (self.cfg.n_grp > 1 and self.cfg.grp_tag_is_qs) or f & abi.FMT_QS:
+            names.append("qs")
+        if f & (abi.FMT_SCR | abi.INFO_SCR):
+            names.append("scr")
+        if f & abi.FMT_SP:
+            names.append("sp")
+        return names
+
+    def alloc_mplp_out(self, n_sites, names=None):
         S = self.cfg.n_smpl
         res = host.MplpResult(n_sites, S)
-        names = ["site", "pl", "dp4", "adf", "adr", "qs", "scr", "sp"]
+        if names is None:
+            names = ["site", "pl", "dp4", "adf", "adr", "qs", "scr", "sp"]
         bufs = {k: self.buf(getattr(res, k).nbytes) for k in names}
         o = abi.MplpOut()
         for k in names:

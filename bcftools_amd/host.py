@@ -76,11 +76,11 @@ class MplpResult:
         self.n_sites, self.n_smpl = n_sites, n_smpl
         self.site = np.zeros(n_sites, dtype=SITE_DTYPE)
         self.pl = np.zeros((n_sites, abi.MAX_PL, n_smpl), dtype=np.uint8)
-        self.dp4 = np.zeros((n_sites, 4, n_smpl), dtype=np.uint8)
-        self.adf = np.zeros((n_sites, 5, n_smpl), dtype=np.uint8)
-        self.adr = np.zeros((n_sites, 5, n_smpl), dtype=np.uint8)
-        self.qs = np.zeros((n_sites, 5, n_smpl), dtype=np.uint16)
-        self.scr = np.zeros((n_sites, n_smpl), dtype=np.uint8)
+        self.dp4 = np.zeros((n_sites, 4, n_smpl), dtype=np.uint16)
+        self.adf = np.zeros((n_sites, 5, n_smpl), dtype=np.uint16)
+        self.adr = np.zeros((n_sites, 5, n_smpl), dtype=np.uint16)
+        self.qs = np.zeros((n_sites, 5, n_smpl), dtype=np.int32)
+        self.scr = np.zeros((n_sites, n_smpl), dtype=np.uint16)
         self.sp = np.zeros((n_sites, n_smpl), dtype=np.uint8)
 
     def as_struct(self):

@@ -196,14 +196,14 @@ def main_mixed(a):
     dt = abi.Tile()
     dt.n_sites, dt.is_indel, dt.n_reads = T, 0, R
     dt.ref16, dt.plp_off, dt.rd, dt.epos = (tile["ref16"].data_ptr(), tile["plp_off"].data_ptr(), tile["rd"].data_ptr(), tile["epos"].data_ptr())
-    mo, mbufs, _ = ctx.alloc_mplp_out(T)
+    mo, mbufs, _ = ctx.alloc_mplp_out(T, ctx.flagged_planes())
     co, cbufs, _ = ctx.alloc_call_out(T, abi.MAX_PL)
     rec_cap = 64 << 20
     recbuf = torch.empty(rec_cap, dtype=torch.uint8, device=dev)
     counts = torch.zeros(4, dtype=torch.int64, device=dev)
     # ---- indel side: the pool in HBM (bcfgpu_pileup, untimed like the resident SNP tile), outputs of the indel pass and its calls ----
     pool = indeldrv.DevicePool(ctx, b)
-    imo, imb, ires = ctx.alloc_mplp_out(n_ind)
+    imo, imb, ires = ctx.alloc_mplp_out(n_ind, ctx.flagged_planes())
     ctx.sync()
 
     def step():
@@ -546,7 +546,7 @@ def main_pileup(a):
     tiles = [abi.Tile(), abi.Tile()]
     outs = []
     for c in ctxs:
-        mo, mbufs, _ = c.alloc_mplp_out(n_sites)
+        mo, mbufs, _ = c.alloc_mplp_out(n_sites, c.flagged_planes())
         co = abi.CallOut()
         csite = torch.zeros(n_sites * C.sizeof(abi.CallSite), dtype=torch.uint8, device="cuda")
         cgt = torch.zeros(n_sites * 2 * S, dtype=torch.int8, device="cuda")
@@ -670,7 +670,7 @@ def main():
     dt.ref16, dt.plp_off, dt.rd, dt.epos = (tile["ref16"].data_ptr(), tile["plp_off"].data_ptr(),
                                             tile["rd"].data_ptr(), tile["epos"].data_ptr())
     # outputs (device)
-    mo, mbufs, _ = ctx.alloc_mplp_out(T)
+    mo, mbufs, _ = ctx.alloc_mplp_out(T, ctx.flagged_planes())
     co = abi.CallOut()
     csite = torch.zeros(T * C.sizeof(abi.CallSite), dtype=torch.uint8, device=dev)
     cgt = torch.zeros(T * 2 * S, dtype=torch.int8, device=dev)

@@ -102,7 +102,7 @@ int main(int argc, char **argv)
     memset(&mo, 0, sizeof mo);
     mo.site = dev_alloc(ctx, (size_t)n_sites * sizeof(bcfgpu_site));
     mo.pl   = dev_alloc(ctx, ncell * BCFGPU_MAX_PL);
-    mo.dp4  = dev_alloc(ctx, ncell * 4);
+    mo.dp4  = dev_alloc(ctx, ncell * 4 * sizeof(uint16_t));
     bcfgpu_call_out co;
     memset(&co, 0, sizeof co);
     co.site = dev_alloc(ctx, (size_t)n_sites * sizeof(bcfgpu_call_site));

@@ -69,7 +69,7 @@ static void *rank_main(void *arg)
         CHECK(bcfgpu_memcpy_h2d(ctx, d_ep, epos + r0, (size_t)nr));
         free(loff);
         bcfgpu_mplp_out mo; memset(&mo, 0, sizeof mo);
-        mo.site = dev_alloc(ctx, (size_t)ns * sizeof(bcfgpu_site)); mo.pl = dev_alloc(ctx, ncell * BCFGPU_MAX_PL); mo.dp4 = dev_alloc(ctx, ncell * 4);
+        mo.site = dev_alloc(ctx, (size_t)ns * sizeof(bcfgpu_site)); mo.pl = dev_alloc(ctx, ncell * BCFGPU_MAX_PL); mo.dp4 = dev_alloc(ctx, ncell * 4 * sizeof(uint16_t));
         bcfgpu_call_out co; memset(&co, 0, sizeof co);
         co.site = dev_alloc(ctx, (size_t)ns * sizeof(bcfgpu_call_site)); co.gt = dev_alloc(ctx, ncell * 2);
         co.pl = dev_alloc(ctx, ncell * BCFGPU_MAX_PL * sizeof(int32_t));

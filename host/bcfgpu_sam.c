@@ -545,7 +545,7 @@ static void pool_keep(pool_t *P, int *first, int F, const uint8_t *keep)
     first[F] = m; P->n = m;
 }
 
-typedef struct { const uint8_t *pl, *dp4, *adf, *adr, *sp, *scr; const uint16_t *qs; } planes_t;        /* host copies of bcfgpu_mplp_out's planes */
+typedef struct { const uint8_t *pl, *sp; const uint16_t *dp4, *adf, *adr, *scr; const int32_t *qs; } planes_t;        /* host copies of bcfgpu_mplp_out's planes */
 
 static void put_counts(const char *lead, const int32_t *f, const int32_t *r, int n)
 {
@@ -591,7 +591,7 @@ static void print_record(const char *contig, int pos1, const char *alleles, cons
     for (int s = 0; s < S; ++s) {
         fputc('\t', LN);
         for (int j = 0; j < x; ++j) fprintf(LN, "%s%d", j ? "," : "", pp->pl[(k * BCFGPU_MAX_PL + j) * Ss + s]);
-        const uint8_t *d = pp->dp4 + k * 4 * Ss + s;                         /* FORMAT/DP, DV, DP4 from DP4 (bam2bcf.c:851-886) */
+        const uint16_t *d = pp->dp4 + k * 4 * Ss + s;                        /* FORMAT/DP, DV, DP4 from DP4 (bam2bcf.c:851-886) */
         if (fmt_flag & BCFGPU_FMT_DP) fprintf(LN, ":%d", d[0] + d[Ss] + d[2 * Ss] + d[3 * Ss]);
         if (fmt_flag & BCFGPU_FMT_DV) fprintf(LN, ":%d", d[2 * Ss] + d[3 * Ss]);
         if (fmt_flag & BCFGPU_FMT_SP) fprintf(LN, ":%d", pp->sp[k * Ss + s]);
@@ -632,7 +632,8 @@ static void run_mpileup(bcfgpu_ctx *ctx, const bcfgpu_tile *tile, int n, bcfgpu_
     }
     CHECK(bcfgpu_sync(ctx));
     *site = (bcfgpu_site *)h[0];
-    pp->pl = h[1]; pp->dp4 = h[2]; pp->adf = h[3]; pp->adr = h[4]; pp->qs = (const uint16_t *)h[5]; pp->scr = h[6]; pp->sp = h[7];
+    pp->pl = h[1]; pp->dp4 = (const uint16_t *)h[2]; pp->adf = (const uint16_t *)h[3]; pp->adr = (const uint16_t *)h[4]; pp->qs = (const int32_t *)h[5];
+    pp->scr = (const uint16_t *)h[6]; pp->sp = h[7];
     for (int w = 3; w < 8; ++w) bcfgpu_free(ctx, d[w]);
     if (keep_site) { *keep_site = d[0]; *keep_pl = d[1]; *keep_dp4 = d[2]; }
     else { bcfgpu_free(ctx, d[0]); bcfgpu_free(ctx, d[1]); bcfgpu_free(ctx, d[2]); }

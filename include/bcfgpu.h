@@ -46,16 +46,17 @@
 extern "C" {
 #endif
 
-#define BCFGPU_VERSION 1
+#define BCFGPU_VERSION 2          /* 2: DP4/ADF/ADR/SCR planes are u16, the QS planes i32 (cells of any depth keep their counts) */
 
 /* error codes */
 #define BCFGPU_OK          0
 #define BCFGPU_E_ARG      -1   /* bad argument / NULL pointer                       */
 #define BCFGPU_E_NOMEM    -2   /* host or device allocation failed                  */
 #define BCFGPU_E_HIP      -3   /* a HIP runtime call failed (see bcfgpu_last_error) */
-#define BCFGPU_E_DEPTH    -4   /* a (site,sample) cell holds more pileup entries than one workgroup can stage (several
-                                  thousand; see bcfgpu_depth_cap).  Cells with more than 255 *usable* reads are not an
-                                  error: they are cut to their first 255 (bcfgpu_truncated_cells) */
+#define BCFGPU_E_DEPTH    -4   /* a (site,sample) cell holds more pileup entries than the context's scratch for over-deep cells
+                                  (several thousand stay in LDS, more go through a global scratch sized from max_reads), or more than
+                                  65535 reads of one base and strand (the u16 count planes).  Cells with more than 255 *usable* reads are
+                                  not an error: see bcfgpu_truncated_cells */
 #define BCFGPU_E_NODEV    -5   /* no HIP device: the product path has no CPU fallback  */
 #define BCFGPU_E_RANGE    -6   /* tile larger than the context's capacity           */
 
@@ -89,8 +90,8 @@ extern "C" {
 #define BCFGPU_MAX_PL      15         /* 5*(5+1)/2 */
 #define BCFGPU_NPOS        100        /* bca->npos,  bam2bcf.c:55 */
 #define BCFGPU_NQUAL       60         /* bca->nqual, bam2bcf.c:58 */
-#define BCFGPU_MAX_DEPTH   255        /* usable reads of a (site,sample) cell: what errmod_cal takes without subsampling and what the
-                                         u8 count planes hold; later reads of a deeper cell are dropped */
+#define BCFGPU_MAX_DEPTH   255        /* reads of a (site,sample) cell errmod_cal takes without subsampling (htslib errmod.c); every count,
+                                         QS sum, I16 sum and histogram is over ALL usable reads whatever their number (bam2bcf.c:203-252) */
 
 /* sentinels, identical to htslib's bcf_int32_missing / bcf_int32_vector_end */
 #define BCFGPU_INT32_MISSING     (INT32_MIN)
@@ -170,19 +171,21 @@ typedef struct {
  * plane strides are n_smpl; the per-site block of each array holds `planes`
  * planes whatever n_alleles is, so addressing does not depend on the data:
  *      pl [site][BCFGPU_MAX_PL][n_smpl]      u8   PL (<=255, bam2bcf.c:645-647); first n_alleles*(n_alleles+1)/2 planes valid
- *      dp4[site][4][n_smpl]                  u8   DP4 (anno[0..3], bam2bcf.c:650-659)
- *      adf/adr[site][5][n_smpl]              u8   ADF/ADR in *allele order* (bam2bcf.c:668-697); first n_alleles planes valid
- *      qs [site][5][n_smpl]                  u16  FMT/QS in allele order (bam2bcf.c:698-712)
- *      scr[site][n_smpl]                     u8   SCR[1+i]
+ *      dp4[site][4][n_smpl]                  u16  DP4 (anno[0..3], bam2bcf.c:650-659)
+ *      adf/adr[site][5][n_smpl]              u16  ADF/ADR in *allele order* (bam2bcf.c:668-697); first n_alleles planes valid
+ *      qs [site][5][n_smpl]                  i32  FMT/QS in allele order (bam2bcf.c:698-712)
+ *      scr[site][n_smpl]                     u16  SCR[1+i]
  *      sp [site][n_smpl]                     u8   FMT/SP: Phred-scaled two-sided Fisher exact test of DP4 (bam2bcf.c:867-885)
+ * The count planes are 16 bits wide so that a cell deeper than 255 reads keeps its counts over all of its reads, as
+ * bcf_call_glfgen does (only errmod_cal's input is cut to 255, bam2bcf.c:256); a count past 65535 is BCFGPU_E_DEPTH.
  */
 typedef struct {
     bcfgpu_site *site;        /* [n_sites] */
     uint8_t  *pl;
-    uint8_t  *dp4;
-    uint8_t  *adf, *adr;      /* may be NULL when no AD-type flag is set */
-    uint16_t *qs;             /* may be NULL unless BCFGPU_FMT_QS or grouped calling on QS */
-    uint8_t  *scr;            /* may be NULL unless an SCR flag is set */
+    uint16_t *dp4;
+    uint16_t *adf, *adr;      /* may be NULL when no AD-type flag is set */
+    int32_t  *qs;             /* may be NULL unless BCFGPU_FMT_QS or grouped calling on QS */
+    uint16_t *scr;            /* may be NULL unless an SCR flag is set */
     uint8_t  *sp;             /* may be NULL unless BCFGPU_FMT_SP is set */
 } bcfgpu_mplp_out;
 
@@ -259,10 +262,11 @@ int  bcfgpu_sync(bcfgpu_ctx *ctx);
 int  bcfgpu_host_alloc(size_t bytes, void **ptr);
 int  bcfgpu_host_free(void *ptr);
 /* Cells of the launches since the last call that held more than BCFGPU_MAX_DEPTH usable reads.  errmod_cal (htslib errmod.c)
- * would shuffle such a cell's reads with hts_drand48 and keep 255 -- a draw from a process-wide generator that depends on the
- * order in which the whole run visits its cells.  Here the cell keeps its first 255 usable reads and the later ones are removed
- * from the pileup (from PL, AD, DP4, QS and from the site's I16 / histograms alike), as a depth cap would.  With mpileup's
- * default -d 250 per file (bcfgpu_depth_cap) such cells arise only where the cap lets reads through (new start positions). */
+ * shuffles such a cell's reads with hts_drand48 and keeps 255 -- a draw from a process-wide generator that depends on the
+ * order in which the whole run visits its cells.  Here the LIKELIHOODS of such a cell (p[25], hence its PLs) come from its
+ * first 255 usable reads; everything else the reference computes over all reads -- DP4, AD/ADF/ADR, QS, SCR, I16, the bias-test
+ * histograms, depth -- is over all reads here too.  The counter tells how many cells' PLs may deviate from a reference run.
+ * With mpileup's default -d 250 per file (bcfgpu_depth_cap) such cells arise only where the cap lets reads through. */
 int  bcfgpu_truncated_cells(bcfgpu_ctx *ctx, uint32_t *n_cells);
 /* enqueue on an externally owned hipStream_t (e.g. torch's current stream); NULL = the context's own */
 int  bcfgpu_set_stream(bcfgpu_ctx *ctx, void *hip_stream);
@@ -509,7 +513,7 @@ typedef struct {
                                          reads): it joins nothing and blk is -1; or NULL */
     const bcfgpu_site *site;          /* the mpileup stage's output for the tile (n_alleles, unseen are read) */
     const uint8_t *pl;                /* bcfgpu_mplp_out.pl  */
-    const uint8_t *dp4;               /* bcfgpu_mplp_out.dp4: FORMAT/DP is the sum of the four (bam2bcf.c:853-858) */
+    const uint16_t *dp4;              /* bcfgpu_mplp_out.dp4: FORMAT/DP is the sum of the four (bam2bcf.c:853-858) */
     /* The form `bcftools call -g` needs (vcfcall.c:1145-1149: gvcf_write(.., ret==1)): the records are whatever the caller
      * read, so what gvcf_write looks at comes as arrays of its own, and site / pl / dp4 are not read (may be NULL):
      *   ref_only [n_sites] u8: 1 = the record may join a block (mcall() kept the reference allele only)

@@ -37,13 +37,18 @@ typedef struct {
 /* bcf_call_glfgen, bam2bcf.c:147-258 */
 static int glfgen(const bcfgpu_cfg *cfg, const orc_errmod *em, site_hist *h,
                   int _n, const uint32_t *rd, const uint8_t *epos_arr, const uint32_t *aux_arr,
-                  int ref_base, orc_callret *r, uint16_t *bases, int *err)
+                  int ref_base, orc_callret *r, uint16_t **bases_p, int *max_bases, int *err)
 {
     int i, n, ref4, is_indel, ori_depth = 0;
     memset(r, 0, sizeof(*r));
     if (ref_base >= 0) { ref4 = nt16_int[ref_base]; is_indel = 0; }
     else ref4 = 4, is_indel = 1;
     if (_n == 0) { r->n = -1; return -1; }
+    if (*max_bases < _n) {                  /* "enlarge the bases array if necessary", bam2bcf.c:164-168 */
+        *max_bases = _n;
+        *bases_p = (uint16_t*) realloc(*bases_p, 2 * (size_t)*max_bases);
+    }
+    uint16_t *bases = *bases_p;
     for (i = n = 0; i < _n; ++i) {
         uint32_t w = rd[i];
         int q, b, mapQ, baseQ, is_diff, min_dist, seqQ;
@@ -75,7 +80,6 @@ static int glfgen(const bcfgpu_cfg *cfg, const orc_errmod *em, site_hist *h,
         if (q > mapQ) q = mapQ;
         if (q > 63) q = 63;
         if (q < 4) q = 4;
-        if (n >= BCFGPU_MAX_DEPTH) { *err = BCFGPU_E_DEPTH; return -1; }
         bases[n++] = q<<5 | is_rev<<4 | b;
         if ((cfg->fmt_flag & (BCFGPU_INFO_SCR|BCFGPU_FMT_SCR)) && (w & BCFGPU_RD_SCLIP)) r->SCR++;
         if (b < 4) {
@@ -302,12 +306,12 @@ static int combine(const bcfgpu_cfg *cfg, int n, const orc_callret *calls, const
                 PL[(size_t)j*S + i] = (uint8_t) y;
             }
         }
-        uint8_t *DP4 = out->dp4 + (size_t)is * 4 * S;
+        uint16_t *DP4 = out->dp4 + (size_t)is * 4 * S;
         for (i = 0; i < n; i++) {
-            DP4[0*S+i] = (uint8_t)(int) calls[i].anno[0];
-            DP4[1*S+i] = (uint8_t)(int) calls[i].anno[1];
-            DP4[2*S+i] = (uint8_t)(int) calls[i].anno[2];
-            DP4[3*S+i] = (uint8_t)(int) calls[i].anno[3];
+            DP4[0*S+i] = (uint16_t)(int) calls[i].anno[0];
+            DP4[1*S+i] = (uint16_t)(int) calls[i].anno[1];
+            DP4[2*S+i] = (uint16_t)(int) calls[i].anno[2];
+            DP4[3*S+i] = (uint16_t)(int) calls[i].anno[3];
         }
         /* FMT/SP: what bcf_call2bcf derives from DP4 (bam2bcf.c:867-885) */
         if (out->sp && (cfg->fmt_flag & BCFGPU_FMT_SP))
@@ -315,7 +319,7 @@ static int combine(const bcfgpu_cfg *cfg, int n, const orc_callret *calls, const
                 out->sp[(size_t)is*S + i] = (uint8_t) orc_format_sp(DP4[0*S+i], DP4[1*S+i], DP4[2*S+i], DP4[3*S+i]);
         for (i = 0; i < n; i++) {
             call->scr_tot += calls[i].SCR;
-            if (out->scr) out->scr[(size_t)is*S + i] = (uint8_t) calls[i].SCR;
+            if (out->scr) out->scr[(size_t)is*S + i] = (uint16_t) calls[i].SCR;
         }
         /* ADF/ADR reordered to allele order, with site totals (bam2bcf.c:668-697) */
         for (i = 0; i < n; i++) {
@@ -325,8 +329,8 @@ static int combine(const bcfgpu_cfg *cfg, int n, const orc_callret *calls, const
                 int vf = aj < 4 ? calls[i].ADF[aj] : 0;
                 call->adr_tot[j] += vr;
                 call->adf_tot[j] += vf;
-                if (out->adr) out->adr[((size_t)is*5 + j)*S + i] = (uint8_t) vr;
-                if (out->adf) out->adf[((size_t)is*5 + j)*S + i] = (uint8_t) vf;
+                if (out->adr) out->adr[((size_t)is*5 + j)*S + i] = (uint16_t) vr;
+                if (out->adf) out->adf[((size_t)is*5 + j)*S + i] = (uint16_t) vf;
             }
         }
         /* FMT/QS reordered (bam2bcf.c:698-712) */
@@ -334,7 +338,7 @@ static int combine(const bcfgpu_cfg *cfg, int n, const orc_callret *calls, const
             for (i = 0; i < n; i++)
                 for (j = 0; j < call->n_alleles; j++) {
                     int aj = call->a[j];
-                    out->qs[((size_t)is*5 + j)*S + i] = (uint16_t)(aj < 4 ? calls[i].QS[aj] : 0);
+                    out->qs[((size_t)is*5 + j)*S + i] = (int32_t)(aj < 4 ? calls[i].QS[aj] : 0);
                 }
         call->shift = (int)(sum_min + .499);
     }
@@ -372,7 +376,8 @@ int orc_mpileup(const bcfgpu_cfg *cfg_in, const bcfgpu_tile *tile, const bcfgpu_
     }
     const int S = cfg.n_smpl;
     orc_callret *bcr = (orc_callret*) malloc(sizeof(orc_callret) * S);
-    uint16_t bases[256];
+    uint16_t *bases = NULL;
+    int max_bases = 0;
     site_hist h;
     int is, s, err = 0;
     for (is = 0; is < tile->n_sites && !err; is++) {
@@ -382,13 +387,13 @@ int orc_mpileup(const bcfgpu_cfg *cfg_in, const bcfgpu_tile *tile, const bcfgpu_
             size_t k = (size_t)is*S + s;
             uint32_t beg = tile->plp_off[k], end = tile->plp_off[k+1];
             glfgen(&cfg, em, &h, (int)(end-beg), tile->rd + beg, tile->epos + beg,
-                   tile->aux ? tile->aux + beg : NULL, ref_base, &bcr[s], bases, &err);
+                   tile->aux ? tile->aux + beg : NULL, ref_base, &bcr[s], &bases, &max_bases, &err);
             if (err) break;
             if (ret_dbg) ret_dbg[k] = bcr[s];
         }
         if (err) break;
         combine(&cfg, S, bcr, &h, ref_base, is, out);
     }
-    free(bcr);
+    free(bcr); free(bases);
     return err;
 }

@@ -31,6 +31,12 @@ typedef struct orc_errmod orc_errmod;
 orc_errmod *orc_errmod_init(double depcorr);
 void orc_errmod_destroy(orc_errmod *em);
 int  orc_errmod_cal(const orc_errmod *em, int n, int m, uint16_t *bases, float *q);
+/* cells deeper than 255 reads (see errmod.c): the reference's random draw (rule 0, default; orc_srand48_reset() puts the
+ * generator back to the state a fresh process has) or the first 255 reads in pileup order (rule 1) */
+void orc_errmod_deep_rule(int rule);
+void orc_srand48_reset(void);
+double orc_drand48(void);
+uint64_t orc_rand48_state(void);
 const double *orc_errmod_fk(const orc_errmod *em);
 const double *orc_errmod_beta(const orc_errmod *em);
 const double *orc_errmod_lhet(const orc_errmod *em);

@@ -94,6 +94,34 @@ static void sort_u16(int n, uint16_t *a)
     }
 }
 
+/* ---- errmod_cal's subsampling of cells deeper than 255 reads.  PARITY UNPINNED: htslib's source is not in the reference
+ * tree and no golden of the reference reaches 256 reads in a cell; restated from htslib's published code:
+ *   hts_drand48 (hts_os.c / os/rand.c, NetBSD's rand48): X <- (0x5DEECE66D * X + 0xB) mod 2^48 from the default seed
+ *     0x1234ABCD330E (mpileup never calls hts_srand48), returning X / 2^48 AFTER the step;
+ *   ks_shuffle (ksort.h): for (i = n; i > 1; --i) { j = (int)(hts_drand48() * i); swap(a[j], a[i-1]); }
+ * The generator is process-wide: a cell's draw depends on every deeper-than-255 cell the run visited before it.
+ * orc_errmod_deep_rule(1) replaces the draw by "the first 255 reads in pileup order", the rule the device library uses when it
+ * is not told the generator's position (bcfgpu_truncated_cells). */
+static uint64_t rand48_x = 0x1234ABCD330EULL;
+static int deep_rule = 0;
+double orc_drand48(void)
+{
+    rand48_x = (0x5DEECE66DULL * rand48_x + 0xBULL) & 0xFFFFFFFFFFFFULL;
+    return ldexp((double)(rand48_x & 0xffff), -48) + ldexp((double)((rand48_x >> 16) & 0xffff), -32) + ldexp((double)(rand48_x >> 32), -16);
+}
+void orc_srand48_reset(void) { rand48_x = 0x1234ABCD330EULL; }
+uint64_t orc_rand48_state(void) { return rand48_x; }
+void orc_errmod_deep_rule(int rule) { deep_rule = rule; }
+static void shuffle_u16(int n, uint16_t *a)
+{
+    int i, j;
+    for (i = n; i > 1; --i) {
+        uint16_t tmp;
+        j = (int)(orc_drand48() * i);
+        tmp = a[j]; a[j] = a[i-1]; a[i-1] = tmp;
+    }
+}
+
 int orc_errmod_cal(const orc_errmod *em, int n, int m, uint16_t *bases, float *q)
 {
     double fsum[16], bsum[16];
@@ -102,7 +130,10 @@ int orc_errmod_cal(const orc_errmod *em, int n, int m, uint16_t *bases, float *q
 
     memset(q, 0, m * m * sizeof(float));
     if (n == 0) return 0;
-    if (n > 255) return BCFGPU_E_DEPTH;   /* htslib: ks_shuffle + keep 255 (hts_drand48); not restated */
+    if (n > 255) {                          /* htslib errmod.c: "then sample 255 bases": ks_shuffle(uint16_t, n, bases); n = 255 */
+        if (deep_rule == 0) shuffle_u16(n, bases);
+        n = 255;                            /* rule 1: the first 255 in pileup order */
+    }
     sort_u16(n, bases);
     memset(w, 0, sizeof(w));
     memset(fsum, 0, sizeof(fsum)); memset(bsum, 0, sizeof(bsum)); memset(c, 0, sizeof(c));

@@ -202,44 +202,48 @@ def test_empty_and_zero_depth(gpu_ctx_factory):
     assert res.site.shape == (0,)
 
 
-def _cut_to_255(tile, min_baseQ=13):
-    """The tile with every cell's usable reads (bam2bcf.c:173-194) after the 255th removed."""
-    off = tile.plp_off.astype(np.int64)
-    keep = np.ones(len(tile.rd), bool)
-    usable = ((tile.rd & (abi.RD_SKIP | abi.RD_DEL)) == 0) & ((tile.rd & 0xff) >= min_baseQ)
-    for c in np.nonzero(np.diff(off) > 255)[0]:
-        u = np.nonzero(usable[off[c]:off[c + 1]])[0]
-        keep[off[c] + u[255:]] = False
-    n = np.add.reduceat(np.r_[keep, False].astype(np.int64), off[:-1]) if len(off) > 1 else np.zeros(0, np.int64)
-    n[np.diff(off) == 0] = 0
-    new_off = np.zeros_like(off)
-    np.cumsum(n, out=new_off[1:])
-    return host.HostTile(tile.n_smpl, tile.ref16, new_off.astype(np.uint32), tile.rd[keep], tile.epos[keep])
-
-
-@pytest.mark.parametrize("n_smpl,depths,seed", [(2, [420, 0], 31), (40, None, 32), (3, [345, 255, 900], 33)])
-def test_cells_over_255_keep_their_first_255(gpu_ctx_factory, n_smpl, depths, seed):
-    """A cell with more than 255 usable reads is not an error (the reference never fails here): it keeps its first 255 and
-    the later ones are removed from the pileup, for the cell's PL/AD/DP4 and the site's I16 / histograms alike -- the
-    result is the oracle's on the tile without those reads."""
+@pytest.mark.parametrize("n_smpl,depths,seed", [(2, [420, 0], 31), (40, None, 32), (3, [345, 255, 900], 33), (5, [256, 5000, 257, 1300, 2048], 34)])
+def test_cells_over_255_count_every_read(gpu_ctx_factory, n_smpl, depths, seed):
+    """A cell with more than 255 usable reads (256 ... 5000 here) is not an error and loses nothing: DP4, AD/ADF/ADR, QS, SCR, SP,
+    the site's I16 sums, depth and the bias-test histograms are over ALL of its reads, as bcf_call_glfgen has them
+    (bam2bcf.c:203-252); only errmod_cal's input is cut to 255 reads (bam2bcf.c:256).  The oracle is fed the uncut pileup."""
     if depths is None:
         tile = synth.numpy_tile(seed, 6, n_smpl, depth=240.0, var_rate=0.5, max_depth=400)
     else:
         rng = np.random.default_rng(seed)
         R = int(sum(depths))
         rd = (rng.choice([11, 25, 37, 40], R) | (rng.choice([0, 20, 60, 60, 60], R) << 8) | ((1 << rng.integers(0, 4, R)) << 16)
-              | (rng.integers(0, 2, R) << 20) | (rng.integers(0, 40, R) << 24)).astype(np.uint32)
+              | (rng.integers(0, 2, R) << 20) | (rng.integers(0, 2, R) << 21) | (rng.integers(0, 40, R) << 24)).astype(np.uint32)
         tile = host.HostTile(n_smpl, np.array([1], dtype=np.int8), np.r_[0, np.cumsum(depths)].astype(np.uint32), rd,
                              rng.integers(0, 100, R).astype(np.uint8))
-    cut = _cut_to_255(tile)
-    assert len(cut.rd) < len(tile.rd)
-    cfg = abi.default_cfg(n_smpl, max_sites=len(tile.ref16), max_reads=len(tile.rd), fmt_flag=abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD)
+    flags = abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD | abi.FMT_QS | abi.FMT_SCR | abi.INFO_SCR | abi.FMT_SP | abi.FMT_DP4
+    cfg = abi.default_cfg(n_smpl, max_sites=len(tile.ref16), max_reads=len(tile.rd), fmt_flag=flags)
     ctx = gpu_ctx_factory(cfg)
     got = ctx.mpileup(tile)
-    assert_mplp_equal(got, orc.mpileup(cfg, cut))
+    want, cr = orc.mpileup(cfg, tile, want_callret=True)
+    assert (cr["n"] > 255).any() and int(want.dp4.max()) > 255
+    assert_mplp_equal(got, want)
     n = abi.C.c_uint32()
-    assert ctx.L.bcfgpu_truncated_cells(ctx.h, abi.C.byref(n)) == 0 and n.value > 0
+    assert ctx.L.bcfgpu_truncated_cells(ctx.h, abi.C.byref(n)) == 0 and n.value == int((cr["n"] > 255).sum())
     assert ctx.L.bcfgpu_truncated_cells(ctx.h, abi.C.byref(n)) == 0 and n.value == 0      # reading resets the counter
+    # every integer field is what the reference's own rule (the random draw of 255) gives too: only the likelihoods differ
+    ref = orc.mpileup(cfg, tile, deep_rule=0)
+    for k in ["dp4", "adf", "adr", "qs", "scr", "sp"]:
+        np.testing.assert_array_equal(getattr(got, k), getattr(ref, k), err_msg=k)
+    for k in ["depth", "ori_depth", "mq0", "adf_tot", "adr_tot", "scr_tot", "anno"]:
+        np.testing.assert_array_equal(got.site[k], ref.site[k], err_msg="site." + k)
+
+
+def test_count_planes_past_65535_are_refused(gpu_ctx_factory):
+    """The count planes are 16 bits wide: a cell with more reads of one base and strand than that is reported (BCFGPU_E_DEPTH),
+    never wrapped."""
+    n = 70000
+    rd = np.full(n, 40 | (60 << 8) | (1 << 16) | (20 << 24), np.uint32)
+    tile = host.HostTile(1, np.array([1], dtype=np.int8), np.array([0, n], np.uint32), rd, np.zeros(n, np.uint8))
+    ctx = gpu_ctx_factory(abi.default_cfg(1, max_sites=1, max_reads=n))
+    with pytest.raises(Exception) as e:
+        ctx.mpileup(tile)
+    assert "65535" in str(e.value) or "-4" in str(e.value)
 
 
 def _lone_deep_cells(n_smpl, depths, seed, usable_frac=0.015, n_sites=1):
@@ -276,13 +280,12 @@ def test_cell_at_the_edge_of_the_staging_window(gpu_ctx_factory):
     (40, 3, [5], 3000, 0.015, 51),                       # a shallow tile with one cell of a few thousand entries
     (40, 3, [0, 60, 119], 7000, 0.015, 52),              # the first cell of the tile, one in the middle, the last one
     (8, 2, [3, 4, 5], 20000, 0.01, 53),                  # neighbours, each far past the largest window (16384 keys)
-    (3, 1, [1], 40000, 0.02, 54),                        # > 255 usable reads inside a listed cell: the first 255 count
+    (3, 1, [1], 40000, 0.02, 54),                        # > 255 usable reads inside a listed cell: every read counts, 255 feed the likelihoods
     (300, 1, [7, 250], 9000, 0.05, 55),
 ])
 def test_cells_deeper_than_the_key_window(gpu_ctx_factory, n_smpl, n_sites, where, size, usable, seed):
     """Amplicon-like pile-ups: a few cells with thousands of entries in an otherwise ordinary tile.  They are listed by the tile
-    launch and worked on by a workgroup each; the rest of the tile proceeds.  Equal to the oracle on the pileup cut to every
-    cell's first 255 usable reads."""
+    launch and worked on by a workgroup each; the rest of the tile proceeds.  Equal to the oracle on the same (uncut) pileup."""
     rng = np.random.default_rng(seed)
     depths = rng.poisson(12, n_sites * n_smpl).astype(np.int64)
     for k, c in enumerate(where):
@@ -295,9 +298,8 @@ def test_cells_deeper_than_the_key_window(gpu_ctx_factory, n_smpl, n_sites, wher
     tile.rd[plain] = (tile.rd[plain] & ~np.uint32(0xff)) | rng.choice([11, 25, 37, 40], int(plain.sum())).astype(np.uint32)
     cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), fmt_flag=abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD)
     ctx = gpu_ctx_factory(cfg)
-    cut = _cut_to_255(tile)
     got = ctx.mpileup(tile)
-    assert_mplp_equal(got, orc.mpileup(cfg, cut))
+    assert_mplp_equal(got, orc.mpileup(cfg, tile))
     got2 = ctx.mpileup(tile)                              # the list and its counters start over with every launch
     assert_mplp_equal(got2, got)
 
