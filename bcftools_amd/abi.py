@@ -210,6 +210,10 @@ PROTOTYPES = {
     "bcfgpu_mplp_out_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "bcfgpu_truncated_cells": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "bcfgpu_depth_cap": (C.c_int, [C.POINTER(Reads), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "bcfgpu_depth_cap_new": (C.c_void_p, [C.c_int32, C.c_int32]),
+    "bcfgpu_depth_cap_push": (C.c_int, [C.c_void_p, C.POINTER(Reads), C.c_void_p, C.c_void_p]),
+    "bcfgpu_depth_cap_reset": (None, [C.c_void_p]),
+    "bcfgpu_depth_cap_free": (None, [C.c_void_p]),
     "bcfgpu_compact_calls": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(CallOut), C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "bcfgpu_compact_calls_async": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(CallOut), C.c_int32, C.c_int32, C.c_void_p,

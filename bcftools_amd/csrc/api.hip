@@ -297,18 +297,30 @@ void bcfgpu_pack_read(int nt16, int baseQ, int mapQ, int is_rev, int has_softcli
 // read is dropped.  bam_plp_auto pushes a read only when the buffer cannot yield the next column, i.e. iter->pos is the start of
 // the read kept last and every earlier column has been handed out: the buffer then holds the kept reads that end at or after
 // that position (reads are released at the first column they no longer cover), and mp->cnt counts them plus the list's tail node.
-int bcfgpu_depth_cap(const bcfgpu_reads *rd, const int32_t *r_smpl, int32_t n_smpl, int32_t max_depth, uint8_t *keep)
-{
-    if (!rd || !keep || rd->n_reads < 0 || (rd->n_reads && !r_smpl) || n_smpl <= 0) return set_err(BCFGPU_E_ARG, "bcfgpu_depth_cap: bad arguments");
-    const int n = rd->n_reads;
-    if (max_depth <= 0) { for (int r = 0; r < n; ++r) keep[r] = 1; return 0; }
+struct bcfgpu_depth_state {
     struct St { std::vector<int32_t> ends; int32_t last_pos = INT32_MIN; };      // ends: a min-heap of the buffered reads' ends
-    std::vector<St> st(n_smpl);
+    std::vector<St> st;
+    int32_t max_depth;
+};
+bcfgpu_depth_state *bcfgpu_depth_cap_new(int32_t n_smpl, int32_t max_depth)
+{
+    if (n_smpl <= 0) { set_err(BCFGPU_E_ARG, "bcfgpu_depth_cap_new: bad arguments"); return nullptr; }
+    bcfgpu_depth_state *d = new bcfgpu_depth_state();
+    d->st.resize(n_smpl); d->max_depth = max_depth;
+    return d;
+}
+void bcfgpu_depth_cap_free(bcfgpu_depth_state *d) { delete d; }
+void bcfgpu_depth_cap_reset(bcfgpu_depth_state *d) { if (d) for (auto &S : d->st) { S.ends.clear(); S.last_pos = INT32_MIN; } }
+int bcfgpu_depth_cap_push(bcfgpu_depth_state *d, const bcfgpu_reads *rd, const int32_t *r_smpl, uint8_t *keep)
+{
+    if (!d || !rd || !keep || rd->n_reads < 0 || (rd->n_reads && !r_smpl)) return set_err(BCFGPU_E_ARG, "bcfgpu_depth_cap_push: bad arguments");
+    const int n = rd->n_reads, n_smpl = (int)d->st.size(), max_depth = d->max_depth;
+    if (max_depth <= 0) { for (int r = 0; r < n; ++r) keep[r] = 1; return 0; }
     auto cmp = [](int32_t a, int32_t b) { return a > b; };
     for (int r = 0; r < n; ++r) {
         const int s = r_smpl[r];
         if (s < 0 || s >= n_smpl) return set_err(BCFGPU_E_ARG, "bcfgpu_depth_cap: sample index out of range");
-        St &S = st[s];
+        bcfgpu_depth_state::St &S = d->st[s];
         const int32_t p = rd->r_pos[r];
         if (p < S.last_pos) return set_err(BCFGPU_E_ARG, "bcfgpu_depth_cap: the reads of a sample are not in position order");
         int32_t e = p;                                          // pos + bam_cigar2rlen: the raw end, not bam_endpos (which makes a read
@@ -323,6 +335,13 @@ int bcfgpu_depth_cap(const bcfgpu_reads *rd, const int32_t *r_smpl, int32_t n_sm
         S.last_pos = p;
     }
     return 0;
+}
+int bcfgpu_depth_cap(const bcfgpu_reads *rd, const int32_t *r_smpl, int32_t n_smpl, int32_t max_depth, uint8_t *keep)
+{
+    if (!rd || !keep || rd->n_reads < 0 || (rd->n_reads && !r_smpl) || n_smpl <= 0) return set_err(BCFGPU_E_ARG, "bcfgpu_depth_cap: bad arguments");
+    bcfgpu_depth_state d;
+    d.st.resize(n_smpl); d.max_depth = max_depth;
+    return bcfgpu_depth_cap_push(&d, rd, r_smpl, keep);
 }
 
 size_t bcfgpu_mplp_out_bytes(const bcfgpu_ctx *c, int n_sites, int which)

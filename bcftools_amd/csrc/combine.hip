@@ -230,7 +230,7 @@ template <int V> __device__ __forceinline__ void store_i32(int32_t *p, const uin
 }
 template <int NAL, int V>
 __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTotals &T, const int (&gs)[15], const int (&g1s)[15], const int (&g2s)[15], const int (&as)[5],
-                                              int is, long c0, int base, int cn, int tid, long ncells, double *s_min)
+                                              int is, long c0, int base, int cn, int tid, long ncells, double *s_min, uint32_t &wide_seen)
 {
     constexpr int X = NAL * (NAL + 1) / 2;
     const size_t Ss = (size_t)P.n_smpl;
@@ -295,9 +295,10 @@ __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTota
         }
         #pragma unroll
         for (int v = 0; v < V; ++v) s_min[i + v] = (double)mn[v];        // widened here, by all lanes, for the sequential sum
-        bool any_wide = false;
+        uint32_t any_wide = 0;
         #pragma unroll
-        for (int v = 0; v < V; ++v) any_wide |= (misc[v] & CR_WIDE) != 0;
+        for (int v = 0; v < V; ++v) any_wide |= misc[v];
+        any_wide &= CR_WIDE;
         if (NAL > 0 && !BCFGPU_ABL(P, 512)) {
             uint16_t *DP4 = P.out.dp4 + (size_t)is * 4 * Ss + s;
             uint32_t b[V];
@@ -333,39 +334,42 @@ __device__ __forceinline__ void sample_planes(const CombineParams &P, SampleTota
                 }
             }
         }
-        // Cells of more than 255 usable reads (rare): the packed counts above are those of the 255 reads the likelihoods were made
-        // of; what the record carries is the counts over all reads (kernels.h WideRec).  The cell's plane entries are written again
-        // and what it added to the lane's totals is replaced (the same expressions subtracted: exact in modular arithmetic).
-        if (__any(any_wide)) {
-            #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                if (!(misc[v] & CR_WIDE)) continue;
-                const WideRec *w = P.cr.wide + (uint32_t)P.cr.qs64[cell + v];
-                const uint32_t wc[4] = { w->cnt[0] & 0xffffu, w->cnt[0] >> 16, w->cnt[1] & 0xffffu, w->cnt[1] >> 16 };
-                #pragma unroll
-                for (int j = 0; j < 4; ++j) T.cnt[j] += wc[j] - ((cnt4[v] >> (8 * j)) & 0xff);
-                if (NAL > 0 && !BCFGPU_ABL(P, 512)) {
-                    #pragma unroll
-                    for (int j = 0; j < 4; ++j) P.out.dp4[((size_t)is * 4 + j) * Ss + s + v] = (uint16_t)wc[j];
-                    T.scr += w->scr - ((misc[v] >> 8) & 0xff);
-                    if (P.out.scr) P.out.scr[(size_t)is * Ss + s + v] = (uint16_t)w->scr;
-                    #pragma unroll
-                    for (int j = 0; j < NAL; ++j) {
-                        const int aj = as[j];
-                        const uint32_t ad = aj < 4 ? w->ad[aj] : 0u, nf = ad & 0xffffu, nr = ad >> 16;
-                        T.adf[j] += nf - (aj < 4 ? (adf[v] >> (8 * aj)) & 0xff : 0);
-                        T.adr[j] += nr - (aj < 4 ? (adr[v] >> (8 * aj)) & 0xff : 0);
-                        if (P.out.adf) P.out.adf[((size_t)is * 5 + j) * Ss + s + v] = (uint16_t)nf;
-                        if (P.out.adr) P.out.adr[((size_t)is * 5 + j) * Ss + s + v] = (uint16_t)nr;
-                        if (P.out.qs) P.out.qs[((size_t)is * 5 + j) * Ss + s + v] = (int32_t)(aj < 4 ? w->qs[aj] : 0u);
-                    }
-                }
-            }
-        }
+        wide_seen |= any_wide;
         #pragma unroll
         for (int v = 0; v < V; ++v) {
             #pragma unroll
             for (int j = 0; j < 4; ++j) T.cnt[j] += (cnt4[v] >> (8 * j)) & 0xff;
+        }
+    }
+}
+
+// Cells of more than 255 usable reads (rare: none under mpileup's default -d 250 with a file per sample).  What sample_planes
+// took from the packed planes for such a cell are the counts of the 255 reads its likelihoods were made of; its WideRec
+// (kernels.h) has the counts over all reads, as bcf_call_glfgen leaves them (bam2bcf.c:203-226).  A pass of its own over the
+// site's samples, entered only when sample_planes met such a cell: the cell's plane entries are written again, and what it
+// added to the lane's totals is replaced (the same expressions subtracted: exact in modular arithmetic).
+__device__ __forceinline__ void fix_wide_cells(const CombineParams &P, SampleTotals &T, const int (&as)[5], int nal, bool live, int is, long c0, int tid)
+{
+    const size_t Ss = (size_t)P.n_smpl;
+    for (int s = tid; s < P.n_smpl; s += WG) {
+        const uint32_t misc = P.cr.misc[c0 + s];
+        if (!(misc & CR_WIDE)) continue;
+        const uint32_t cnt4 = P.cr.cnt4[c0 + s], adf = P.cr.adf[c0 + s], adr = P.cr.adr[c0 + s];
+        const WideRec *w = P.cr.wide + (uint32_t)P.cr.qs64[c0 + s];
+        const uint32_t wc[4] = { w->cnt[0] & 0xffffu, w->cnt[0] >> 16, w->cnt[1] & 0xffffu, w->cnt[1] >> 16 };
+        for (int j = 0; j < 4; ++j) T.cnt[j] += wc[j] - ((cnt4 >> (8 * j)) & 0xff);
+        if (!live) continue;
+        for (int j = 0; j < 4; ++j) P.out.dp4[((size_t)is * 4 + j) * Ss + s] = (uint16_t)wc[j];
+        T.scr += w->scr - ((misc >> 8) & 0xff);
+        if (P.out.scr) P.out.scr[(size_t)is * Ss + s] = (uint16_t)w->scr;
+        for (int j = 0; j < nal; ++j) {
+            const int aj = as[j];
+            const uint32_t ad = aj < 4 ? w->ad[aj] : 0u, nf = ad & 0xffffu, nr = ad >> 16;
+            T.adf[j] += nf - (aj < 4 ? (adf >> (8 * aj)) & 0xff : 0);
+            T.adr[j] += nr - (aj < 4 ? (adr >> (8 * aj)) & 0xff : 0);
+            if (P.out.adf) P.out.adf[((size_t)is * 5 + j) * Ss + s] = (uint16_t)nf;
+            if (P.out.adr) P.out.adr[((size_t)is * 5 + j) * Ss + s] = (uint16_t)nr;
+            if (P.out.qs) P.out.qs[((size_t)is * 5 + j) * Ss + s] = (int32_t)(aj < 4 ? w->qs[aj] : 0u);
         }
     }
 }
@@ -477,17 +481,18 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, 
     #pragma unroll
     for (int j = 0; j < 5; ++j) as[j] = __builtin_amdgcn_readfirstlane(j < nal ? sh.a[j] : 4);
     double *s_min = reinterpret_cast<double*>(s_stage);
+    uint32_t wide_seen = 0;
     for (int base = 0; base < S; base += CHUNK) {
         const int cn = min(CHUNK, S - base);
         __syncthreads();
         const bool live = !dead && !BCFGPU_ABL(P, 256);
         #define PLANES(V_) switch (live ? nal : 0) { \
-            case 1: sample_planes<1, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min); break; \
-            case 2: sample_planes<2, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min); break; \
-            case 3: sample_planes<3, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min); break; \
-            case 4: sample_planes<4, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min); break; \
-            case 5: sample_planes<5, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min); break; \
-            default: sample_planes<0, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min); break; }
+            case 1: sample_planes<1, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min, wide_seen); break; \
+            case 2: sample_planes<2, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min, wide_seen); break; \
+            case 3: sample_planes<3, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min, wide_seen); break; \
+            case 4: sample_planes<4, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min, wide_seen); break; \
+            case 5: sample_planes<5, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min, wide_seen); break; \
+            default: sample_planes<0, V_>(P, T, gs, g1s, g2s, as, is, c0, base, cn, tid, ncells, s_min, wide_seen); break; }
         PLANES(V)
         #undef PLANES
         __syncthreads();
@@ -510,6 +515,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, 
             __syncthreads();                                          // (sh.sum_min was read by every lane above)
             if (tid == 0) sh.sum_min = acc;
         }
+    }
+    if (__any(wide_seen != 0)) {
+        int as5[5];
+        #pragma unroll
+        for (int j = 0; j < 5; ++j) as5[j] = as[j];
+        fix_wide_cells(P, T, as5, nal, !dead && !BCFGPU_ABL(P, 256), is, c0, tid);
+        __syncthreads();                                          // the SP / SGB passes below read the DP4 planes
     }
     // FMT/SP (bam2bcf.c:867-885): a Fisher exact test per sample, in its own pass -- its loops over the table's margins
     // diverge between lanes, and only samples with at least two reads in every margin enter them

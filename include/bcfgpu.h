@@ -452,6 +452,15 @@ int  bcfgpu_pool_download(bcfgpu_ctx *ctx, uint8_t *qual, uint8_t *zq, uint8_t *
  * One sample = one input file (mpileup counts per file).  reads: the pool after the read filters of mplp_func, every sample's
  * reads in position order; keep: out [n_reads], 1 = the read enters the pileup.  max_depth <= 0: keep everything. */
 int  bcfgpu_depth_cap(const bcfgpu_reads *reads, const int32_t *r_smpl, int32_t n_smpl, int32_t max_depth, uint8_t *keep);
+/* The same for a caller that streams a sorted file through the region in batches (host/bcfgpu_sam cuts a region into tiles): the
+ * iterator's buffer (the ends of the reads kept so far, the position of the read kept last, per file) lives in the state between
+ * the calls, so the batches' keep[] together are what one call over all the reads would give.  _reset: a new region (the
+ * reference restarts its iterators per region, mpileup.c:652-683). */
+typedef struct bcfgpu_depth_state bcfgpu_depth_state;
+bcfgpu_depth_state *bcfgpu_depth_cap_new(int32_t n_smpl, int32_t max_depth);
+int  bcfgpu_depth_cap_push(bcfgpu_depth_state *st, const bcfgpu_reads *reads, const int32_t *r_smpl, uint8_t *keep);
+void bcfgpu_depth_cap_reset(bcfgpu_depth_state *st);
+void bcfgpu_depth_cap_free(bcfgpu_depth_state *st);
 
 /* The pileup entries of selected columns of the last bcfgpu_pileup on this context, in the form bcfgpu_gap_prep takes them
  * (bcfgpu_indel_in: what bcf_call_gap_prep reads of bam_pileup1_t): for column cols[i] and sample s the entries
