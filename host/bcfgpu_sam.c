@@ -1,28 +1,39 @@
 /*  bcfgpu_sam.c -- `bcftools mpileup` over SAM / BAM files with every stage of the path on the device, in plain C over the
  *  C-ABI of include/bcfgpu.h (SNP and indel records).
  *
- *      bcfgpu_sam [options] <ref.fa> <contig> <beg> <end> <file.sam|file.bam> [...]             (beg, end 1-based inclusive)
+ *      bcfgpu_sam [options] -f ref.fa [-r CHR[:BEG[-END]],...] file.sam|file.bam [...]         (mpileup's own spelling, mpileup.c:952-1003)
+ *      bcfgpu_sam [options] ref.fa contig beg end file.sam|file.bam [...]                       (beg, end 1-based inclusive)
  *      options: -a TAG,..  --gvcf INT,..  -O v|z|u|b  -o FILE  -d INT  -s LIST  -S FILE  -G FILE  --ignore-RG
- *               -B  -E  -A  -q INT  -Q INT  --ff INT  --rf INT                                  (as `bcftools mpileup`)
+ *               -B  -E  -A  -q INT  -Q INT  -C INT  --ff INT  --rf INT  -I -o INT -e INT -h INT -m INT -F FLOAT -p -L INT   (as `bcftools mpileup`)
+ *               --tile COLUMNS  columns per device tile (default 16384);  --gpus N  region shards, a process per shard
  *               --list-samples: print "sample <TAB> reads entering the pileup <TAB> files" and stop (no device needed)
  *
+ *  A region is streamed through in TILES: the files are read in step with the tiles -- a position-sorted file no
+ *  further than the tile's, and in the end the region's, last column -- a read stays in host memory while it can still cover a
+ *  column, and what the device holds at any time is one tile's reads and columns.  Memory is bounded by the tile, not by the
+ *  region (mpileup_reg() walks column by column with the iterator's buffer, mpileup.c:327-367); several regions run one after the
+ *  other (mpileup.c:652-683).
+ *
  *  What stays on the host is what mpileup.c and htslib's pileup do before any arithmetic: parsing (SAM text; BAM = BGZF +
- *  binary records), the read -> sample map of bam_sample.c (@RG SM, RG:Z tags, -s/-S/-G), the read filters of mplp_func
- *  (mpileup.c:183-246: unmapped, --rf/--ff flags, reads of dropped read groups, -q, orphans), the iterator's per-file depth
- *  cap (bcfgpu_depth_cap) and the pairing of overlapping mates (htslib overlap_push).  Then, each a call on the flat read pool:
- *      bcfgpu_pool_upload          the pool to HBM, once
+ *  binary records, inflated block by block), the read -> sample map of bam_sample.c (@RG SM, RG:Z tags, -s/-S/-G), the read
+ *  filters of mplp_func (mpileup.c:183-246: unmapped, --rf/--ff flags, reads of dropped read groups, -q, orphans), the
+ *  iterator's per-file depth cap (bcfgpu_depth_cap_push, its buffer carried from tile to tile) and the pairing of overlapping
+ *  mates (htslib overlap_push).  Then per tile, each a call on the flat read pool:
+ *      bcfgpu_pool_upload          the tile's reads to HBM, once
  *      bcfgpu_pool_baq             BAQ (sam_prob_realn, mpileup.c:234)
  *      bcfgpu_pool_overlap_tweak   mate-overlap qualities (bam_mplp_init_overlaps, mpileup.c:640)
- *      bcfgpu_pool_pileup          the pileup columns of the region, built in HBM
- *      bcfgpu_mpileup        bcf_call_glfgen x samples + bcf_call_combine per column (mpileup.c:343-347)
+ *      bcfgpu_pool_pileup          the pileup columns of the tile, built in HBM
+ *      bcfgpu_mpileup              bcf_call_glfgen x samples + bcf_call_combine per column (mpileup.c:343-347)
  *  and for the columns where some read is followed by an indel (mpileup.c:354-365):
  *      bcfgpu_gap_prep_tile (bcf_call_gap_prep on the candidate columns, in HBM) -> bcfgpu_mpileup on its indel tile
+ *  with -C INT: bcfgpu_pool_baq + bcfgpu_pool_cap_mapq on every batch of reads as it comes off the files (mpileup.c:234-241),
+ *  with --gvcf: bcfgpu_gvcf_blocks per tile, the block that reaches a tile's end joined with the next tile's first (gvcf.c:88-226);
  *  and the record loop writes what bcf_call2bcf (bam2bcf.c:756-906) puts in the record, in its order, under mpileup's header
  *  (mpileup.c:510-602), as VCF, bgzipped VCF or BCF (host/vcfio.c).  tests/test_c_host.py compares the whole output with the
- *  reference's goldens test/mpileup/mpileup.{1..11}.out and mpileup-SCR.out.
- *  Not here: CRAM input, sam_cap_mapq (-C; htslib's source is not in the reference tree and no golden exercises it), BED
- *  files (-l/-T), --illumina1.3+; a sample fed by several files has its reads merged by position (the reference appends file
- *  after file: same records unless a cell passes 255 usable reads, where errmod's subsampling depends on the order anyway).
+ *  reference's goldens test/mpileup/mpileup.{1..11}.out, mpileup-SCR.out, indel-AD.1.out -- one tile and many.
+ *  Not here: CRAM input, index files (a region far into a file is reached by reading up to it), BED files (-l/-T),
+ *  --illumina1.3+; a sample fed by several files has its reads merged by position (the reference appends file after file: same
+ *  records unless a cell passes 255 usable reads, where errmod's subsampling depends on the order anyway).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -35,6 +46,8 @@
 #include <unistd.h>
 #include <sys/types.h>
 #include <sys/wait.h>
+#include <fcntl.h>
+#include <signal.h>
 #include "bcfgpu.h"
 #include "vcfio.h"
 
@@ -272,12 +285,6 @@ static int reg_beg = 0, reg_end = 0x7fffffff;   /* the region: only reads that o
 static void pool_add(pool_t *P, int file, int smpl, const char *qname, int flag, int pos, int mapq, int rnext_same, int mpos, int isize,
                      const uint32_t *cig, int ncig, int lq, const uint8_t *seq16, const uint8_t *qual)
 {
-    {   /* [pos, endpos) against the region (a read without a reference span counts as one base: bam_endpos) */
-        int e = pos;
-        for (int c = 0; c < ncig; ++c) { const int op = cig[c] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) e += (int)(cig[c] >> 4); }
-        if (e == pos) e = pos + 1;
-        if (pos >= reg_end || e <= reg_beg) return;
-    }
     if (P->n == P->cap) {
         P->cap = P->cap ? 2 * P->cap : 1024;
         #define G(a) P->a = grow(P->a, (size_t)P->cap * sizeof *P->a)
@@ -285,7 +292,7 @@ static void pool_add(pool_t *P, int file, int smpl, const char *qname, int flag,
         #undef G
     }
     const int r = P->n++;
-    P->qname[r] = strdup(qname);
+    P->qname[r] = (char *)qname;                       /* borrowed: the live window owns the name */
     P->flag[r] = flag; P->pos[r] = pos; P->mapq[r] = (uint8_t)mapq; P->smpl[r] = smpl; P->file[r] = file; P->has_zq[r] = 0;
     P->rnext_same[r] = rnext_same; P->mpos[r] = mpos; P->isize[r] = isize;
     P->cig_off[r] = (int32_t)P->ncigs; P->ncig[r] = ncig;
@@ -321,41 +328,103 @@ static void contig_line(vio_hdr *h, const char *name, int nlen, long length)
     vio_hdr_append(h, buf);
 }
 
-typedef struct { uint8_t *d; size_t n; } blob_t;
-static blob_t slurp(const char *path)
-{
-    blob_t b = { NULL, 0 };
-    FILE *f = fopen(path, "rb");
-    if (!f) DIE("cannot open %s\n", path);
-    size_t cap = 0, got;
-    do { if (b.n + (1 << 16) > cap) { cap = cap ? 2 * cap : 1 << 20; b.d = grow(b.d, cap + 1); } got = fread(b.d + b.n, 1, 1 << 16, f); b.n += got; } while (got);
-    fclose(f);
-    b.d[b.n] = 0;
-    return b;
-}
-/* a BGZF file (a series of gzip members, SAM spec 4.1) inflated whole */
-static blob_t bgzf_inflate(const blob_t in)
-{
-    blob_t out = { NULL, 0 };
-    size_t cap = 0, at = 0;
-    while (at < in.n) {
-        z_stream z; memset(&z, 0, sizeof z);
-        if (inflateInit2(&z, 15 + 16) != Z_OK) DIE("zlib: inflateInit2 failed\n");
-        z.next_in = in.d + at; z.avail_in = (uInt)(in.n - at > (1u << 30) ? (1u << 30) : in.n - at);
-        int rc;
-        do {
-            if (out.n + (1 << 16) > cap) { cap = cap ? 2 * cap : 1 << 20; out.d = grow(out.d, cap); }
-            z.next_out = out.d + out.n; z.avail_out = (uInt)(cap - out.n);
-            rc = inflate(&z, Z_NO_FLUSH);
-            out.n = cap - z.avail_out;
-            if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) DIE("zlib: corrupt BGZF block\n");
-        } while (rc != Z_STREAM_END);
-        at = (size_t)(z.next_in - in.d);
-        inflateEnd(&z);
-    }
-    return out;
-}
+/* ---- streaming input: one reader per file (SAM text, or BAM = BGZF + binary records, SAM spec 4.2), reads handed out in file
+ * order.  A read leaves the reader only if it is on the region's contig, overlaps the region, passes the flag filters of
+ * mplp_func (mpileup.c:183-246) and belongs to an output sample; a position-sorted file is read no further than the region's
+ * end (htslib's region iterator stops there too). ---- */
+typedef struct {
+    char *qname; int flag, pos, mapq, rnext_same, mpos, isize, ncig, lq, end, smpl;
+    uint32_t *cig; uint8_t *seq16, *qual;
+} lrec_t;
+static void lrec_free(lrec_t *r) { if (r) { free(r->qname); free(r->cig); free(r->seq16); free(r->qual); free(r); } }
+
+typedef struct {
+    const char *path; FILE *fp; int is_bam, eof, done, seen_contig;
+    z_stream zs; int zs_on; uint8_t *zin;                   /* BAM: the BGZF stream, inflated member after member */
+    uint8_t *buf; size_t buf_n, buf_rd, buf_cap;            /* BAM: inflated bytes not yet consumed */
+    int tid, n_ref; char **ref_name; int32_t *ref_len;      /* BAM: the reference dictionary; tid = the region's contig */
+    char *text;                                             /* the header text ('@' lines) */
+    char *line; size_t line_cap; int have_line;             /* SAM: one text line of look-ahead */
+    lrec_t *pend;                                           /* the next read, not yet taken */
+} reader_t;
+
 static int32_t le32(const uint8_t *p) { return (int32_t)((uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24); }
+
+/* at least `need` inflated bytes at buf + buf_rd; 0 at the end of the file */
+static int bz_fill(reader_t *r, size_t need)
+{
+    if (r->buf_n - r->buf_rd >= need) return 1;
+    if (r->buf_rd) { memmove(r->buf, r->buf + r->buf_rd, r->buf_n - r->buf_rd); r->buf_n -= r->buf_rd; r->buf_rd = 0; }
+    if (r->buf_cap < need + (1 << 16)) { r->buf_cap = need + (1 << 17); r->buf = grow(r->buf, r->buf_cap); }
+    while (r->buf_n < need) {
+        if (r->zs.avail_in == 0) {
+            if (r->eof) break;
+            const size_t got = fread(r->zin, 1, 1 << 16, r->fp);
+            if (!got) { r->eof = 1; break; }
+            r->zs.next_in = r->zin; r->zs.avail_in = (uInt)got;
+        }
+        r->zs.next_out = r->buf + r->buf_n; r->zs.avail_out = (uInt)(r->buf_cap - r->buf_n);
+        const int rc = inflate(&r->zs, Z_NO_FLUSH);
+        r->buf_n = r->buf_cap - r->zs.avail_out;
+        if (rc == Z_STREAM_END) { if (inflateReset(&r->zs) != Z_OK) DIE("zlib: inflateReset failed\n"); }     /* the next BGZF block */
+        else if (rc != Z_OK && rc != Z_BUF_ERROR) DIE("%s: corrupt BGZF block\n", r->path);
+    }
+    return r->buf_n - r->buf_rd >= need;
+}
+
+static void reader_close(reader_t *r)
+{
+    if (r->fp) fclose(r->fp);
+    if (r->zs_on) inflateEnd(&r->zs);
+    free(r->zin); free(r->buf); free(r->text); free(r->line);
+    for (int i = 0; i < r->n_ref; ++i) free(r->ref_name[i]);
+    free(r->ref_name); free(r->ref_len);
+    lrec_free(r->pend);
+    const char *p = r->path;
+    memset(r, 0, sizeof *r); r->path = p;
+}
+
+/* opens the file and reads its header (r->text; BAM: the reference dictionary too) */
+static void reader_open(reader_t *r, const char *path)
+{
+    memset(r, 0, sizeof *r);
+    r->path = path; r->tid = -1;
+    r->fp = fopen(path, "rb");
+    if (!r->fp) DIE("cannot open %s\n", path);
+    const int c0 = fgetc(r->fp), c1 = fgetc(r->fp);
+    rewind(r->fp);
+    if (c0 == 0x1f && c1 == 0x8b) {
+        r->is_bam = 1; r->zin = grow(NULL, 1 << 16);
+        if (inflateInit2(&r->zs, 15 + 16) != Z_OK) DIE("zlib: inflateInit2 failed\n");
+        r->zs_on = 1;
+        if (!bz_fill(r, 12) || memcmp(r->buf + r->buf_rd, "BAM\1", 4)) DIE("%s: not a BAM file\n", path);
+        const size_t l_text = (uint32_t)le32(r->buf + r->buf_rd + 4);
+        if (!bz_fill(r, 12 + l_text)) DIE("%s: truncated BAM header\n", path);
+        r->text = grow(NULL, l_text + 1); memcpy(r->text, r->buf + r->buf_rd + 8, l_text); r->text[l_text] = 0;
+        r->n_ref = le32(r->buf + r->buf_rd + 8 + l_text);
+        r->buf_rd += 12 + l_text;
+        r->ref_name = grow(NULL, (size_t)(r->n_ref + 1) * sizeof *r->ref_name); r->ref_len = grow(NULL, (size_t)(r->n_ref + 1) * sizeof *r->ref_len);
+        for (int i = 0; i < r->n_ref; ++i) {
+            if (!bz_fill(r, 4)) DIE("%s: truncated BAM header\n", path);
+            const int l_name = le32(r->buf + r->buf_rd);
+            if (l_name < 1 || !bz_fill(r, 8 + (size_t)l_name)) DIE("%s: truncated BAM header\n", path);
+            r->ref_name[i] = grow(NULL, (size_t)l_name + 1); memcpy(r->ref_name[i], r->buf + r->buf_rd + 4, (size_t)l_name); r->ref_name[i][l_name] = 0;
+            r->ref_len[i] = le32(r->buf + r->buf_rd + 4 + l_name);
+            r->buf_rd += 8 + (size_t)l_name;
+        }
+        return;
+    }
+    /* SAM text: the '@' lines; the first other line stays as look-ahead */
+    size_t tl = 0, tcap = 0;
+    ssize_t n;
+    while ((n = getline(&r->line, &r->line_cap, r->fp)) > 0) {
+        if (r->line[0] != '@') { r->have_line = 1; break; }
+        if (tl + (size_t)n + 1 > tcap) { tcap = (tl + (size_t)n + 1) * 2; r->text = grow(r->text, tcap); }
+        memcpy(r->text + tl, r->line, (size_t)n); tl += (size_t)n;
+    }
+    if (!r->text) r->text = grow(NULL, 1);
+    r->text[tl] = 0;
+}
 
 /* the value of the RG:Z tag in a BAM record's auxiliary data (SAM spec 4.2.4), or NULL */
 static const char *bam_aux_rg(const uint8_t *a, const uint8_t *end)
@@ -382,90 +451,86 @@ static const char *bam_aux_rg(const uint8_t *a, const uint8_t *end)
     return NULL;
 }
 
-/* one input file: its header decides the samples (add_file), its reads on `contig` that pass the filters join the pool.
- * Returns 0 when the file is dropped (no usable read group).  h: the VCF header to receive ##contig lines, or NULL. */
-static int read_file(const char *path, const char *contig, int file, sfile_t *sf, pool_t *P, vio_hdr *h)
+static int ref_span_end(int pos, const uint32_t *cig, int ncig)
 {
-    blob_t raw = slurp(path);
-    uint8_t seqbuf[1 << 16], qualbuf[1 << 16];
-    if (raw.n >= 4 && raw.d[0] == 0x1f && raw.d[1] == 0x8b) {
-        /* ---- BAM (SAM spec 4.2) ---- */
-        blob_t b = bgzf_inflate(raw);
-        free(raw.d);
-        if (b.n < 12 || memcmp(b.d, "BAM\1", 4)) DIE("%s: not a BAM file\n", path);
-        const size_t l_text = (uint32_t)le32(b.d + 4);
-        char *text = malloc(l_text + 1); memcpy(text, b.d + 8, l_text); text[l_text] = 0;
-        size_t at = 8 + l_text;
-        const int n_ref = le32(b.d + at); at += 4;
-        int tid = -1;
-        for (int i = 0; i < n_ref; ++i) {
-            const int l_name = le32(b.d + at); const char *name = (const char *)b.d + at + 4;
-            const int l_ref = le32(b.d + at + 4 + l_name);
-            if (!strcmp(name, contig)) tid = i;
-            at += 8 + (size_t)l_name;
-            (void)l_ref;
+    int e = pos;
+    for (int c = 0; c < ncig; ++c) { const int op = cig[c] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) e += (int)(cig[c] >> 4); }
+    return e;
+}
+/* [pos, endpos) against [lo, hi) (a read without a reference span counts as one base: bam_endpos) */
+static int overlaps(int pos, int end, int lo, int hi) { if (end == pos) end = pos + 1; return pos < hi && end > lo; }
+
+static lrec_t *lrec_new(const char *qname, int flag, int pos, int mapq, int rnext_same, int mpos, int isize, const uint32_t *cig, int ncig, int lq, int smpl)
+{
+    lrec_t *x = grow(NULL, sizeof *x);
+    x->qname = strdup(qname); x->flag = flag; x->pos = pos; x->mapq = mapq; x->rnext_same = rnext_same; x->mpos = mpos; x->isize = isize;
+    x->ncig = ncig; x->lq = lq; x->smpl = smpl;
+    x->cig = grow(NULL, (size_t)(ncig + 1) * 4); memcpy(x->cig, cig, (size_t)ncig * 4);
+    x->end = ref_span_end(pos, cig, ncig);
+    x->seq16 = grow(NULL, (size_t)lq + 1); x->qual = grow(NULL, (size_t)lq + 1);
+    return x;
+}
+
+/* the next read of the file that can enter the pileup of region [reg_beg, reg_end) of `contig`, into r->pend; r->done at the end */
+static void reader_fetch(reader_t *r, const char *contig, const sfile_t *sf)
+{
+    if (r->pend || r->done) return;
+    uint32_t cig[4096];
+    if (r->is_bam) {
+        if (r->tid < 0) {
+            for (int i = 0; i < r->n_ref; ++i) if (!strcmp(r->ref_name[i], contig)) r->tid = i;
+            if (r->tid < 0) { r->done = 1; return; }
         }
-        if (!add_file(sf, path, text)) { free(text); free(b.d); return 0; }
-        if (h) {
-            size_t a2 = 12 + l_text;
-            for (int i = 0; i < n_ref; ++i) {
-                const int l_name = le32(b.d + a2);
-                contig_line(h, (const char *)b.d + a2 + 4, l_name - 1, le32(b.d + a2 + 4 + l_name));
-                a2 += 8 + (size_t)l_name;
-            }
-        }
-        free(text);
-        while (at + 36 <= b.n) {
-            const uint8_t *r = b.d + at;
-            const size_t bs = (uint32_t)le32(r);
-            if (at + 4 + bs > b.n) DIE("%s: truncated BAM record\n", path);
-            at += 4 + bs;
-            const int refid = le32(r + 4), pos = le32(r + 8), l_name = r[12], mapq = r[13];
-            const int n_cig = r[16] | r[17] << 8, flag = r[18] | r[19] << 8, l_seq = le32(r + 20);
-            const int next_ref = le32(r + 24), next_pos = le32(r + 28), tlen = le32(r + 32);
-            if (refid != tid || refid < 0 || !read_passes(flag, mapq)) continue;
-            const char *qname = (const char *)r + 36;
-            const uint8_t *cg = r + 36 + l_name, *sq = cg + 4 * (size_t)n_cig, *ql = sq + (l_seq + 1) / 2, *aux = ql + l_seq;
-            const int smpl = sample_of(sf, bam_aux_rg(aux, r + 4 + bs));
-            if (smpl < 0) continue;
-            if (l_seq > (int)sizeof seqbuf) DIE("%s: read longer than %d\n", path, (int)sizeof seqbuf);
-            uint32_t cig[4096];
-            if (n_cig > 4096) DIE("%s: CIGAR with more than 4096 operations\n", path);
+        for (;;) {
+            if (!bz_fill(r, 4)) { r->done = 1; return; }
+            const size_t bs = (uint32_t)le32(r->buf + r->buf_rd);
+            if (bs < 32 || !bz_fill(r, 4 + bs)) DIE("%s: truncated BAM record\n", r->path);
+            const uint8_t *b = r->buf + r->buf_rd;
+            r->buf_rd += 4 + bs;
+            const int refid = le32(b + 4), pos = le32(b + 8), l_name = b[12], mapq = b[13];
+            const int n_cig = b[16] | b[17] << 8, flag = b[18] | b[19] << 8, l_seq = le32(b + 20);
+            const int next_ref = le32(b + 24), next_pos = le32(b + 28), tlen = le32(b + 32);
+            if (refid == r->tid) r->seen_contig = 1;
+            /* a position-sorted file: nothing of the region follows a read past its end, or the reads of the next contig */
+            if (r->seen_contig && (refid != r->tid || pos >= reg_end)) { r->done = 1; return; }
+            if (refid != r->tid || !read_passes(flag, mapq)) continue;
+            if (n_cig > 4096) DIE("%s: CIGAR with more than 4096 operations\n", r->path);
+            const uint8_t *cg = b + 36 + l_name, *sq = cg + 4 * (size_t)n_cig, *ql = sq + (l_seq + 1) / 2, *aux = ql + l_seq;
+            if (aux > b + 4 + bs) DIE("%s: malformed BAM record\n", r->path);
             for (int c = 0; c < n_cig; ++c) cig[c] = (uint32_t)le32(cg + 4 * c);
-            for (int i = 0; i < l_seq; ++i) { seqbuf[i] = (sq[i >> 1] >> ((~i & 1) << 2)) & 15; qualbuf[i] = ql[i]; }
-            pool_add(P, file, smpl, qname, flag, pos, mapq, next_ref == refid, next_pos, tlen, cig, n_cig, l_seq, seqbuf, qualbuf);
+            if (!overlaps(pos, ref_span_end(pos, cig, n_cig), reg_beg, reg_end)) continue;
+            const int smpl = sample_of(sf, bam_aux_rg(aux, b + 4 + bs));
+            if (smpl < 0) continue;
+            lrec_t *x = lrec_new((const char *)b + 36, flag, pos, mapq, next_ref == refid, next_pos, tlen, cig, n_cig, l_seq, smpl);
+            for (int i = 0; i < l_seq; ++i) { x->seq16[i] = (sq[i >> 1] >> ((~i & 1) << 2)) & 15; x->qual[i] = ql[i]; }
+            r->pend = x;
+            return;
         }
-        free(b.d);
-        return 1;
     }
-    /* ---- SAM text ---- */
-    char *txt = (char *)raw.d, *body = txt;
-    while (*body == '@') { char *e = strchr(body, '\n'); if (!e) { body += strlen(body); break; } body = e + 1; }
-    {
-        const char save = *body; *body = 0;
-        const int ok = add_file(sf, path, txt);
-        if (ok && h)
-            for (const char *l = txt; l && *l; ) {                          /* @SQ -> ##contig (mpileup.c:533-540) */
-                if (!strncmp(l, "@SQ\t", 4)) {
-                    const char *e = strchr(l, '\n'), *sn = strstr(l, "\tSN:"), *ln = strstr(l, "\tLN:");
-                    if (sn && ln && (!e || (sn < e && ln < e))) { sn += 4; contig_line(h, sn, (int)strcspn(sn, "\t\r\n"), atol(ln + 4)); }
-                }
-                l = strchr(l, '\n'); if (l) ++l;
-            }
-        *body = save;
-        if (!ok) { free(raw.d); return 0; }
-    }
-    for (char *line = body; line && *line; ) {
-        char *eol = strchr(line, '\n');
-        if (eol) *eol = 0;
-        char *next = eol ? eol + 1 : NULL;
-        { size_t l = strlen(line); if (l && line[l - 1] == '\r') line[l - 1] = 0; }
+    for (;;) {
+        if (!r->have_line) {
+            if (getline(&r->line, &r->line_cap, r->fp) <= 0) { r->done = 1; return; }
+        }
+        r->have_line = 0;
+        char *line = r->line;
+        { size_t l = strlen(line); while (l && (line[l - 1] == '\n' || line[l - 1] == '\r')) line[--l] = 0; }
         char *fld[12]; int nf = 0; char *rest = NULL;
         for (char *s = line; nf < 11 && s; ) { fld[nf++] = s; s = strchr(s, '\t'); if (s) *s++ = 0; rest = s; }
-        line = next;
         if (nf < 11) continue;
-        const int flag = atoi(fld[1]), mapq = atoi(fld[4]);
-        if (strcmp(fld[2], contig) || !read_passes(flag, mapq)) continue;
+        const int flag = atoi(fld[1]), mapq = atoi(fld[4]), pos = atoi(fld[3]) - 1;
+        const int on = !strcmp(fld[2], contig);
+        if (on) r->seen_contig = 1;
+        if (r->seen_contig && (!on || pos >= reg_end) && !(flag & 4)) { r->done = 1; return; }
+        if (!on || !read_passes(flag, mapq)) continue;
+        int ncig = 0;
+        for (const char *c = fld[5]; *c && *c != '*'; ) {
+            char *e; const long l = strtol(c, &e, 10);
+            const char *ops = "MIDNSHP=X", *o = *e ? strchr(ops, *e) : NULL;
+            if (!o || ncig == 4096) DIE("bad CIGAR in %s\n", r->path);
+            cig[ncig++] = (uint32_t)l << 4 | (uint32_t)(o - ops);
+            c = e + 1;
+        }
+        if (!overlaps(pos, ref_span_end(pos, cig, ncig), reg_beg, reg_end)) continue;
         const char *rg = NULL;
         for (char *t = rest; t && *t; ) {                                    /* the optional fields: RG:Z:<id> */
             char *e = strchr(t, '\t'); if (e) *e = 0;
@@ -474,22 +539,26 @@ static int read_file(const char *path, const char *contig, int file, sfile_t *sf
         }
         const int smpl = sample_of(sf, rg);
         if (smpl < 0) continue;
-        uint32_t cig[4096]; int ncig = 0;
-        for (const char *c = fld[5]; *c && *c != '*'; ) {
-            char *e; const long l = strtol(c, &e, 10);
-            const char *ops = "MIDNSHP=X", *o = *e ? strchr(ops, *e) : NULL;
-            if (!o || ncig == 4096) DIE("bad CIGAR in %s\n", path);
-            cig[ncig++] = (uint32_t)l << 4 | (uint32_t)(o - ops);
-            c = e + 1;
-        }
         const int lq = fld[9][0] == '*' ? 0 : (int)strlen(fld[9]);
-        if (lq > (int)sizeof seqbuf) DIE("%s: read longer than %d\n", path, (int)sizeof seqbuf);
-        for (int i = 0; i < lq; ++i) { seqbuf[i] = (uint8_t)nt16_of(fld[9][i]); qualbuf[i] = fld[10][0] == '*' && !fld[10][1] ? 0xff : (uint8_t)(fld[10][i] - 33); }
-        pool_add(P, file, smpl, fld[0], flag, atoi(fld[3]) - 1, mapq, !strcmp(fld[6], "=") || !strcmp(fld[6], fld[2]), atoi(fld[7]) - 1, atoi(fld[8]),
-                 cig, ncig, lq, seqbuf, qualbuf);
+        lrec_t *x = lrec_new(fld[0], flag, pos, mapq, !strcmp(fld[6], "=") || !strcmp(fld[6], fld[2]), atoi(fld[7]) - 1, atoi(fld[8]), cig, ncig, lq, smpl);
+        const int noq = fld[10][0] == '*' && !fld[10][1];
+        for (int i = 0; i < lq; ++i) { x->seq16[i] = (uint8_t)nt16_of(fld[9][i]); x->qual[i] = noq ? 0xff : (uint8_t)(fld[10][i] - 33); }
+        r->pend = x;
+        return;
     }
-    free(raw.d);
-    return 1;
+}
+
+/* the ##contig lines of the VCF header from the first file's dictionary (mpileup.c:533-540) */
+static void header_contigs(const reader_t *r, vio_hdr *h)
+{
+    if (r->is_bam) { for (int i = 0; i < r->n_ref; ++i) contig_line(h, r->ref_name[i], (int)strlen(r->ref_name[i]), r->ref_len[i]); return; }
+    for (const char *l = r->text; l && *l; ) {
+        if (!strncmp(l, "@SQ\t", 4)) {
+            const char *e = strchr(l, '\n'), *sn = strstr(l, "\tSN:"), *ln = strstr(l, "\tLN:");
+            if (sn && ln && (!e || (sn < e && ln < e))) { sn += 4; contig_line(h, sn, (int)strcspn(sn, "\t\r\n"), atol(ln + 4)); }
+        }
+        l = strchr(l, '\n'); if (l) ++l;
+    }
 }
 
 /* overlap_push (htslib sam.c) over the reads of one sample in file order: which pairs tweak_overlap_quality sees */
@@ -525,27 +594,10 @@ static int find_pairs(const pool_t *P, int r0, int r1, int32_t *pa, int32_t *pb)
 /* what bcf_call2bcf writes into a record (bam2bcf.c:756-906); alleles: the ready REF\tALT text */
 static int fmt_flag = BCFGPU_INFO_VDB | BCFGPU_INFO_RPB;                     /* mpileup's default annotations + -a */
 
-/* the reads with keep[r] != 0 stay, in order; first[] (the pool is file-major) follows */
-static void pool_keep(pool_t *P, int *first, int F, const uint8_t *keep)
-{
-    int m = 0;
-    for (int s = 0, r = 0; s < F; ++s) {
-        const int e = first[s + 1];
-        first[s] = m;
-        for (; r < e; ++r) {
-            if (!keep[r]) { free(P->qname[r]); continue; }
-            if (m != r) {
-                #define MV(a) P->a[m] = P->a[r]
-                MV(pos); MV(lq); MV(flag); MV(ncig); MV(cig_off); MV(seq_off); MV(smpl); MV(file); MV(end); MV(mpos); MV(isize); MV(rnext_same); MV(mapq); MV(has_zq); MV(qname);
-                #undef MV
-            }
-            ++m;
-        }
-    }
-    first[F] = m; P->n = m;
-}
 
 typedef struct { const uint8_t *pl, *sp; const uint16_t *dp4, *adf, *adr, *scr; const int32_t *qs; } planes_t;        /* host copies of bcfgpu_mplp_out's planes */
+
+static void planes_free(planes_t *p) { free((void *)p->pl); free((void *)p->sp); free((void *)p->dp4); free((void *)p->adf); free((void *)p->adr); free((void *)p->scr); free((void *)p->qs); memset(p, 0, sizeof *p); }
 
 static void put_counts(const char *lead, const int32_t *f, const int32_t *r, int n)
 {
@@ -639,16 +691,462 @@ static void run_mpileup(bcfgpu_ctx *ctx, const bcfgpu_tile *tile, int n, bcfgpu_
     else { bcfgpu_free(ctx, d[0]); bcfgpu_free(ctx, d[1]); bcfgpu_free(ctx, d[2]); }
 }
 
+/* ---- options (file scope: the tile loop and its helpers read them) ---- */
+static int32_t gv_range[16]; static int gv_n = 0;                             /* mpileup --gvcf INT,.. (gvcf.c:44-67) */
+static int max_depth = 250, baq_flag = 3, min_baseQ = 13, cap_thres = 0, no_indels = 0, max_indel_depth = 250;
+static int openQ = 40, extQ = 20, tandemQ = 100, min_support = 1, per_sample_flt = 0; static double min_frac = 0.002;   /* mpileup.c:937-950 */
+static int device = 0, tile_cols = 16384;
+
+typedef struct { char *contig; int beg, end; } region_t;                      /* 0-based [beg, end); end < 0: to the contig's end */
+
+/* ---- the device context, re-created when a tile needs more room than the last one had ---- */
+static bcfgpu_ctx *ctx; static int ctx_S, ctx_sites; static uint64_t ctx_reads; static unsigned long long n_wide_cells;
+static void ensure_ctx(int S, int n_sites, uint64_t n_reads)
+{
+    if (ctx && ctx_S == S && n_sites <= ctx_sites && n_reads <= ctx_reads) return;
+    if (ctx) { uint32_t nw = 0; CHECK(bcfgpu_truncated_cells(ctx, &nw)); n_wide_cells += nw; bcfgpu_destroy(ctx); ctx = NULL; }
+    bcfgpu_cfg cfg; memset(&cfg, 0, sizeof cfg);
+    ctx_S = S; ctx_sites = n_sites > ctx_sites ? n_sites : ctx_sites; ctx_reads = n_reads + n_reads / 2 + 4096;
+    cfg.device = device; cfg.n_smpl = S; cfg.max_sites = ctx_sites; cfg.max_reads = ctx_reads;   /* every base is in <= 1 column */
+    cfg.min_baseQ = min_baseQ; cfg.capQ = 60; cfg.errmod_theta = 0.; cfg.fmt_flag = fmt_flag;
+    cfg.call_theta = 1.1e-3; cfg.n_grp = 1; cfg.ploidy_max = 2;
+    CHECK(bcfgpu_create(&cfg, &ctx));
+}
+
+/* ---- gVCF blocks across tiles (and adjacent regions): the reference's gvcf_write keeps a block open over any distance
+ * (gvcf.c:88-226).  bcfgpu_gvcf_blocks ends every block with its call; the block that reaches a tile's last column is held
+ * back here and joined with the first block of the next tile when gvcf_write would have gone on: the same sequence, the
+ * next position, the same depth range (gvcf.c:130-131).  Per sample the smallest DP and the smallest (PL[1], PL[2]) pair in
+ * that order; PL[0], REF and INFO/QS stay the first record's (gvcf.c:160-210). ---- */
+static struct { int on, S; char *contig; int start_pos, end1, min_dp, range; char ref; float qs0, qs1; int32_t *dp; uint8_t *pl; } PB;
+static void block_line(const char *contig, int start_pos, int end1, int min_dp, char refc, float qs0, float qs1, const uint8_t *pl, const int32_t *dp, int S)
+{
+    fprintf(LN, "%s\t%d\t.\t%c\t<*>\t.\t.\t", contig, start_pos + 1, refc);
+    if (start_pos + 1 < end1) fprintf(LN, "END=%d;", end1);                   /* gvcf.c:150-151 */
+    fprintf(LN, "MinDP=%d;QS=%g,%g\tPL:DP", min_dp, (double)qs0, (double)qs1);
+    for (int s = 0; s < S; ++s) fprintf(LN, "\t%d,%d,%d:%d", pl[s], pl[(size_t)S + s], pl[2 * (size_t)S + s], dp[s]);
+    end_record();
+}
+static void pending_flush(void)
+{
+    if (!PB.on) return;
+    block_line(PB.contig, PB.start_pos, PB.end1, PB.min_dp, PB.ref, PB.qs0, PB.qs1, PB.pl, PB.dp, PB.S);
+    PB.on = 0;
+}
+static int pending_joins(const char *contig, const bcfgpu_gvcf_block *B) { return PB.on && !strcmp(PB.contig, contig) && B->start_pos == PB.end1 && B->range == PB.range; }
+static void pending_merge(const bcfgpu_gvcf_block *B, const uint8_t *pl, const int32_t *dp)
+{
+    const int S = PB.S;
+    PB.end1 = B->end1; if (B->min_dp < PB.min_dp) PB.min_dp = B->min_dp;
+    for (int s = 0; s < S; ++s) {
+        if (dp[s] < PB.dp[s]) PB.dp[s] = dp[s];
+        const uint8_t a = pl[(size_t)S + s], c = pl[2 * (size_t)S + s];
+        if (a < PB.pl[(size_t)S + s] || (a == PB.pl[(size_t)S + s] && c < PB.pl[2 * (size_t)S + s])) { PB.pl[(size_t)S + s] = a; PB.pl[2 * (size_t)S + s] = c; }
+    }
+}
+static void pending_set(const char *contig, const bcfgpu_gvcf_block *B, char refc, float qs0, float qs1, const uint8_t *pl, const int32_t *dp, int S)
+{
+    if (!PB.dp || PB.S != S) { PB.dp = grow(PB.dp, (size_t)S * 4); PB.pl = grow(PB.pl, (size_t)S * 3); PB.S = S; }
+    free(PB.contig); PB.contig = strdup(contig);
+    PB.on = 1; PB.start_pos = B->start_pos; PB.end1 = B->end1; PB.min_dp = B->min_dp; PB.range = B->range; PB.ref = refc; PB.qs0 = qs0; PB.qs1 = qs1;
+    memcpy(PB.dp, dp, (size_t)S * 4); memcpy(PB.pl, pl, (size_t)S * 3);
+}
+
+/* ---- one tile: columns [t0, t1) of `contig` from the reads in P (all the reads that overlap the tile, file-major; file f =
+ * [first[f], first[f+1])).  Every stage on the device; the records of the tile are written in position order. ---- */
+static unsigned long long tot_entries, tot_pairs;
+static void process_tile(pool_t *P, const int *first, int F, int S, const char *contig, const char *ref, int ref_len, int t0, int t1)
+{
+    const int n_sites = t1 - t0;
+    ensure_ctx(S, n_sites, (uint64_t)P->nbase + 64);
+    /* mate overlaps: htslib pairs the reads inside one file's iterator (bam_mplp_init_overlaps, mpileup.c:640) */
+    int32_t *pa = malloc((size_t)(P->n + 1) * sizeof *pa), *pb = malloc((size_t)(P->n + 1) * sizeof *pb);
+    int np = 0;
+    for (int f = 0; f < F; ++f) np += find_pairs(P, first[f], first[f + 1], pa + np, pb + np);
+    tot_pairs += (unsigned long long)np;
+    /* a sample fed by several files (mpileup.c:275-293 appends file after file): its reads merged by position, files in
+     * order at equal positions, as bcfgpu_pileup wants them; the pairs follow their reads */
+    {
+        int sorted = 1;
+        int32_t *last = malloc((size_t)S * sizeof *last);
+        for (int s = 0; s < S; ++s) last[s] = INT32_MIN;
+        for (int r = 0; r < P->n && sorted; ++r) { if (P->pos[r] < last[P->smpl[r]]) sorted = 0; last[P->smpl[r]] = P->pos[r]; }
+        free(last);
+        if (!sorted) {
+            int32_t *ord = malloc((size_t)P->n * sizeof *ord), *tmp = malloc((size_t)P->n * sizeof *tmp), *inv = malloc((size_t)P->n * sizeof *inv);
+            for (int r = 0; r < P->n; ++r) ord[r] = r;
+            for (int w = 1; w < P->n; w *= 2) {                              /* bottom-up merge sort: stable */
+                for (int lo = 0; lo < P->n; lo += 2 * w) {
+                    const int mid = lo + w < P->n ? lo + w : P->n, hi = lo + 2 * w < P->n ? lo + 2 * w : P->n;
+                    int i = lo, j = mid, k = lo;
+                    while (i < mid && j < hi) tmp[k++] = P->pos[ord[j]] < P->pos[ord[i]] ? ord[j++] : ord[i++];
+                    while (i < mid) tmp[k++] = ord[i++];
+                    while (j < hi) tmp[k++] = ord[j++];
+                }
+                int32_t *t = ord; ord = tmp; tmp = t;
+            }
+            for (int r = 0; r < P->n; ++r) inv[ord[r]] = r;
+            #define PERM(a) do { void *n_ = malloc((size_t)P->n * sizeof *P->a); for (int r = 0; r < P->n; ++r) memcpy((char *)n_ + (size_t)r * sizeof *P->a, &P->a[ord[r]], sizeof *P->a); \
+                                 memcpy(P->a, n_, (size_t)P->n * sizeof *P->a); free(n_); } while (0)
+            PERM(pos); PERM(lq); PERM(flag); PERM(ncig); PERM(cig_off); PERM(seq_off); PERM(smpl); PERM(file); PERM(end); PERM(mpos); PERM(isize);
+            PERM(rnext_same); PERM(mapq); PERM(has_zq); PERM(qname);
+            #undef PERM
+            for (int i = 0; i < np; ++i) { pa[i] = inv[pa[i]]; pb[i] = inv[pb[i]]; }
+            free(ord); free(tmp); free(inv);
+        }
+    }
+
+    bcfgpu_reads rd; memset(&rd, 0, sizeof rd);
+    rd.n_reads = P->n; rd.r_pos = P->pos; rd.r_lq = P->lq; rd.r_flag = P->flag; rd.r_ncig = P->ncig; rd.r_cig_off = P->cig_off;
+    rd.r_seq_off = P->seq_off; rd.cig = P->cig; rd.seq16 = P->seq16; rd.qual = P->qual; rd.zq = P->zq; rd.r_has_zq = P->has_zq;
+
+    /* the pool goes up once and stays in HBM: BAQ (new qualities and ZQ bytes for the reads it applies to; not with -B), the
+     * mate-overlap tweak, the pileup of the tile -- each on the copy the stage before left there */
+    CHECK(bcfgpu_pool_upload(ctx, &rd, NULL, P->mapq));
+    if (baq_flag) CHECK(bcfgpu_pool_baq(ctx, ref, ref_len, baq_flag, NULL));
+    CHECK(bcfgpu_pool_overlap_tweak(ctx, np, pa, pb));
+    free(pa); free(pb);
+    bcfgpu_tile tile;
+    int32_t *col_n = malloc((size_t)(n_sites + 1) * sizeof *col_n);
+    uint8_t *col_indel = malloc((size_t)n_sites + 1);
+    CHECK(bcfgpu_pool_pileup(ctx, P->smpl, NULL, t0, t1, ref, ref_len, &tile, col_n, col_indel));
+    tot_entries += (unsigned long long)tile.n_reads;
+    void *d_site = NULL, *d_pl = NULL, *d_dp4 = NULL;
+    bcfgpu_site *site = NULL;
+    planes_t snp_planes;
+    run_mpileup(ctx, &tile, n_sites, &site, &snp_planes, gv_n ? &d_site : NULL, &d_pl, &d_dp4);
+
+    /* ---- indel records (mpileup.c:354-365): candidate columns -> bcf_call_gap_prep -> second pass with p->aux ---- */
+    int nc = 0;
+    int32_t *cand = malloc((size_t)(n_sites + 1) * sizeof *cand);
+    for (int k = 0; k < n_sites; ++k)
+        if (!no_indels && col_indel[k] && col_n[k] < max_indel_depth * S) cand[nc++] = k;     /* mpileup.c:354 */
+    bcfgpu_site *isite = NULL;
+    planes_t ind_planes; memset(&ind_planes, 0, sizeof ind_planes); int32_t *live = NULL; int nlive = 0;
+    int32_t *g_types = NULL, *g_maxins = NULL, *g_indelreg = NULL, *g_support = NULL; float *g_frac = NULL; int8_t *g_inscns = NULL;
+    if (nc) {
+        /* everything stays in HBM: the candidates' entries, the stage on the pool bcfgpu_pileup left there, p->aux straight
+         * into the indel pass's tile over all candidate columns (the host pool is passed for its ZQ bytes) */
+        bcfgpu_indel_in in; memset(&in, 0, sizeof in);
+        in.n_sites = nc; in.n_smpl = S; in.ref = ref;
+        in.openQ = openQ; in.extQ = extQ; in.tandemQ = tandemQ; in.min_support = min_support; in.per_sample_flt = per_sample_flt; in.min_frac = min_frac;
+        bcfgpu_indel_out out; memset(&out, 0, sizeof out);
+        int32_t *gret = malloc((size_t)nc * 4);
+        g_types = malloc((size_t)nc * 16); g_inscns = malloc((size_t)nc * 4 * INSCNS_CAP); g_maxins = malloc((size_t)nc * 4);
+        g_indelreg = malloc((size_t)nc * 4); g_support = malloc((size_t)nc * 4); g_frac = malloc((size_t)nc * 4);
+        out.ret = gret; out.p_aux = NULL; out.indel_types = g_types; out.inscns = g_inscns; out.maxins = g_maxins;
+        out.indelreg = g_indelreg; out.max_support = g_support; out.max_frac = g_frac;
+        bcfgpu_tile ti;
+        /* (with BAQ the ZQ bytes are the pool's, in HBM; with -B the reads' own tags, if any, go up from the host) */
+        CHECK(bcfgpu_gap_prep_tile(ctx, nc, cand, baq_flag ? NULL : &rd, &in, &out, INSCNS_CAP, &ti));
+        live = malloc((size_t)nc * 4);
+        for (int i = 0; i < nc; ++i) if (gret[i] == 0) live[nlive++] = i;
+        if (nlive) run_mpileup(ctx, &ti, nc, &isite, &ind_planes, NULL, NULL, NULL);      /* records of columns with ret < 0 are not used */
+        free(gret);
+    }
+
+    /* ---- --gvcf: reference-only records collapse into blocks (gvcf_write, gvcf.c:88-226) on the planes still in HBM ---- */
+    int32_t *gv_blk = NULL, *gv_dp = NULL; bcfgpu_gvcf_block *gv_block = NULL; uint8_t *gv_pl = NULL; int32_t nb = 0;
+    int open_block = -1;                 /* the block that reaches the tile's last column and may go on in the next tile */
+    if (gv_n) {
+        int32_t *pos = malloc((size_t)n_sites * 4); uint8_t *brk = calloc((size_t)n_sites, 1);
+        for (int k = 0; k < n_sites; ++k) { pos[k] = t0 + k; if (col_n[k] == 0) brk[k] |= 2; }
+        for (int j = 0; j < nlive; ++j) if (isite[live[j]].ret == 0) brk[cand[live[j]]] |= 1;      /* an indel record follows the SNP record */
+        void *d_pos, *d_brk, *d_blk, *d_min, *d_block, *d_gdp, *d_gpl;
+        CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_pos)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites, &d_brk));
+        CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_blk)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_min));
+        CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * sizeof(bcfgpu_gvcf_block), &d_block));
+        CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * S * 4, &d_gdp)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 3 * S, &d_gpl));
+        CHECK(bcfgpu_memcpy_h2d(ctx, d_pos, pos, (size_t)n_sites * 4)); CHECK(bcfgpu_memcpy_h2d(ctx, d_brk, brk, (size_t)n_sites));
+        bcfgpu_gvcf_in gi; memset(&gi, 0, sizeof gi);
+        gi.n_sites = n_sites; gi.n_range = gv_n; gi.dp_range = gv_range; gi.pos = d_pos; gi.brk = d_brk;
+        gi.site = d_site; gi.pl = d_pl; gi.dp4 = d_dp4;
+        bcfgpu_gvcf_out go = { d_blk, d_min, d_block, d_gdp, d_gpl };
+        CHECK(bcfgpu_gvcf_blocks(ctx, &gi, &go, &nb));
+        gv_blk = malloc((size_t)n_sites * 4); gv_block = malloc((size_t)(nb + 1) * sizeof *gv_block);
+        gv_dp = malloc((size_t)(nb + 1) * S * 4); gv_pl = malloc((size_t)(nb + 1) * 3 * S);
+        CHECK(bcfgpu_memcpy_d2h(ctx, gv_blk, d_blk, (size_t)n_sites * 4)); CHECK(bcfgpu_memcpy_d2h(ctx, gv_block, d_block, (size_t)nb * sizeof *gv_block));
+        CHECK(bcfgpu_memcpy_d2h(ctx, gv_dp, d_gdp, (size_t)nb * S * 4)); CHECK(bcfgpu_memcpy_d2h(ctx, gv_pl, d_gpl, (size_t)nb * 3 * S));
+        CHECK(bcfgpu_sync(ctx));
+        /* open at the tile's end: the last column is in a block and no indel record follows it */
+        if (gv_blk[n_sites - 1] >= 0 && !(brk[n_sites - 1] & 1)) open_block = gv_blk[n_sites - 1];
+        bcfgpu_free(ctx, d_pos); bcfgpu_free(ctx, d_brk); bcfgpu_free(ctx, d_blk); bcfgpu_free(ctx, d_min); bcfgpu_free(ctx, d_block);
+        bcfgpu_free(ctx, d_gdp); bcfgpu_free(ctx, d_gpl); free(pos); free(brk);
+        bcfgpu_free(ctx, d_site); bcfgpu_free(ctx, d_pl); bcfgpu_free(ctx, d_dp4);
+    }
+
+    /* ---- the record loop: the SNP record of a column, then its indel record (mpileup.c:343-366) ---- */
+    static const char *nt = "ACGTN";
+    int jl = 0;
+    for (int k = 0; k < n_sites; ++k) {
+        if (col_n[k] == 0) continue;                                         /* no read: no record */
+        const bcfgpu_site *c = &site[k];
+        if (gv_blk && gv_blk[k] >= 0) {                                      /* inside a block: one line when the block ends */
+            const int b = gv_blk[k];
+            const bcfgpu_gvcf_block *B = &gv_block[b];
+            if (B->first_site == k) {                                        /* the block starts: does it continue the one held back? */
+                if (PB.on && !pending_joins(contig, B)) pending_flush();
+            }
+            if (B->last_site == k) {
+                const bcfgpu_site *f = &site[B->first_site];
+                const char refc = nt[f->ori_ref < 0 || f->ori_ref > 4 ? 4 : f->ori_ref];
+                const uint8_t *bpl = gv_pl + (size_t)b * 3 * S; const int32_t *bdp = gv_dp + (size_t)b * S;
+                if (PB.on) pending_merge(B, bpl, bdp);                       /* (a block that did not join was flushed at its first site) */
+                else if (b == open_block) pending_set(contig, B, refc, f->qsum[0], f->qsum[1], bpl, bdp, S);
+                else block_line(contig, B->start_pos, B->end1, B->min_dp, refc, f->qsum[0], f->qsum[1], bpl, bdp, S);
+                if (PB.on && b != open_block) pending_flush();               /* joined, and it ends inside this tile */
+            }
+        } else {
+        pending_flush();                                                     /* a record that cannot join ends the block (gvcf.c:107) */
+        char als[64]; int o = 0;
+        als[o++] = nt[c->ori_ref < 0 || c->ori_ref > 4 ? 4 : c->ori_ref]; als[o++] = '\t';
+        for (int j = 1; j < c->n_alleles; ++j) {
+            if (j > 1) als[o++] = ',';
+            if (j == c->unseen) { memcpy(als + o, "<*>", 3); o += 3; } else als[o++] = nt[c->a[j]];
+        }
+        if (c->n_alleles < 2) als[o++] = '.';
+        als[o] = 0;
+        print_record(contig, t0 + k + 1, als, "", c, &snp_planes, (size_t)k, S);
+        }
+        while (jl < nlive && cand[live[jl]] < k) ++jl;
+        if (jl < nlive && cand[live[jl]] == k && isite[live[jl]].ret == 0) {
+            /* REF / ALT of an indel record (bam2bcf.c:767-790) */
+            pending_flush();
+            const int i = live[jl], p = t0 + k, ireg = g_indelreg[i], mi = g_maxins[i];
+            char *txt = malloc((size_t)(5 * (ireg + mi + 8)) + 64), prefix[64];
+            int t = 0;
+            for (int j = 0; j <= ireg; ++j) txt[t++] = ref[p + j];
+            txt[t++] = '\t';
+            for (int a = 1; a < 4 && isite[i].a[a] >= 0; ++a) {
+                const int ai = isite[i].a[a], ty = g_types[i * 4 + ai];
+                if (a > 1) txt[t++] = ',';
+                txt[t++] = ref[p];
+                if (ty < 0) { for (int j = p + 1 - ty; j < p + 1 + ireg; ++j) txt[t++] = ref[j]; }
+                else {
+                    for (int j = 0; j < ty; ++j) txt[t++] = nt[g_inscns[(size_t)i * 4 * INSCNS_CAP + (size_t)ai * mi + j]];
+                    for (int j = p + 1; j < p + 1 + ireg; ++j) txt[t++] = ref[j];
+                }
+            }
+            txt[t] = 0;
+            snprintf(prefix, sizeof prefix, "INDEL;IDV=%d;IMF=%g;", g_support[i], (double)g_frac[i]);
+            print_record(contig, p + 1, txt, prefix, &isite[i], &ind_planes, (size_t)i, S);
+            free(txt);
+        }
+    }
+    /* a column without reads ends a block too (a gap in positions, gvcf.c:131): nothing stays open past it */
+    if (gv_n && PB.on && (open_block < 0 || PB.end1 != t1)) pending_flush();
+    free(site); planes_free(&snp_planes); free(isite); planes_free(&ind_planes);
+    free(col_n); free(col_indel); free(cand); free(live);
+    free(g_types); free(g_maxins); free(g_indelreg); free(g_support); free(g_frac); free(g_inscns);
+    free(gv_blk); free(gv_block); free(gv_dp); free(gv_pl);
+}
+
+/* ---- the live window: the reads of every file that passed the filters and the depth cap and may still cover a column ---- */
+typedef struct { lrec_t **r; int n, cap; } lwin_t;
+static void lwin_push(lwin_t *w, lrec_t *x) { if (w->n == w->cap) { w->cap = w->cap ? 2 * w->cap : 256; w->r = grow(w->r, (size_t)w->cap * sizeof *w->r); } w->r[w->n++] = x; }
+
+static void pool_clear(pool_t *P) { P->n = 0; P->ncigs = 0; P->nbase = 0; }
+static void pool_add_rec(pool_t *P, int file, const lrec_t *x)
+{
+    pool_add(P, file, x->smpl, x->qname, x->flag, x->pos, x->mapq, x->rnext_same, x->mpos, x->isize, x->cig, x->ncig, x->lq, x->seq16, x->qual);
+}
+
+/* mpileup -C INT (mpileup.c:234-241) for a batch of reads: after BAQ, sam_cap_mapq lowers the mapping quality of reads with
+ * many mismatches or drops them; then the -q and orphan filters, which read_passes() left for here.  keep[i] = 0: dropped. */
+static bcfgpu_ctx *cap_ctx;
+static void cap_batch(lrec_t **b, int n, int S, const char *ref, int ref_len, uint8_t *keep)
+{
+    static pool_t Q;
+    pool_clear(&Q);
+    for (int i = 0; i < n; ++i) pool_add_rec(&Q, 0, b[i]);
+    if (!cap_ctx) {
+        bcfgpu_cfg c0; memset(&c0, 0, sizeof c0);
+        c0.device = device; c0.n_smpl = S; c0.max_sites = 1; c0.max_reads = 64; c0.min_baseQ = min_baseQ; c0.capQ = 60; c0.n_grp = 1; c0.ploidy_max = 2;
+        CHECK(bcfgpu_create(&c0, &cap_ctx));
+    }
+    bcfgpu_reads r0; memset(&r0, 0, sizeof r0);
+    r0.n_reads = Q.n; r0.r_pos = Q.pos; r0.r_lq = Q.lq; r0.r_flag = Q.flag; r0.r_ncig = Q.ncig; r0.r_cig_off = Q.cig_off;
+    r0.r_seq_off = Q.seq_off; r0.cig = Q.cig; r0.seq16 = Q.seq16; r0.qual = Q.qual; r0.zq = Q.zq; r0.r_has_zq = Q.has_zq;
+    /* the batch goes up once; BAQ and the cap run on that copy (the qualities sam_cap_mapq sees are BAQ's) */
+    CHECK(bcfgpu_pool_upload(cap_ctx, &r0, NULL, Q.mapq));
+    if (baq_flag) CHECK(bcfgpu_pool_baq(cap_ctx, ref, ref_len, baq_flag, NULL));
+    int32_t *capv = malloc((size_t)(n + 1) * sizeof *capv);
+    CHECK(bcfgpu_pool_cap_mapq(cap_ctx, ref, ref_len, cap_thres, capv));
+    for (int i = 0; i < n; ++i) {
+        keep[i] = capv[i] >= 0;
+        if (keep[i] && b[i]->mapq > capv[i]) b[i]->mapq = capv[i];
+        if (b[i]->mapq < min_mq) keep[i] = 0;
+        if (!keep_orphans && (b[i]->flag & 1) && !(b[i]->flag & 2)) keep[i] = 0;
+    }
+    free(capv);
+}
+
+static region_t parse_region(const char *s)
+{
+    region_t g; memset(&g, 0, sizeof g);
+    const char *colon = strrchr(s, ':');
+    g.beg = 0; g.end = -1;
+    if (!colon) { g.contig = strdup(s); return g; }
+    g.contig = strndup(s, (size_t)(colon - s));
+    char *e; long b = strtol(colon + 1, &e, 10);
+    if (e == colon + 1) { free(g.contig); g.contig = strdup(s); return g; }          /* a colon inside the contig's name */
+    g.beg = (int)(b > 0 ? b - 1 : 0);
+    if (*e == '-' && e[1]) g.end = (int)strtol(e + 1, NULL, 10);
+    else if (*e != '-') g.end = (int)b;                                              /* "chr:pos": one position */
+    return g;
+}
+
+/* ---- --gpus N: the parent of the shard processes.  It touches no device: it starts one process per shard, each writing its
+ * record stream (uncompressed BCF) to an anonymous temporary file the parent holds open, and writes the streams out in shard
+ * order -- which is genomic order -- once the shards are through.  With --gvcf the last block of a shard and the first of the
+ * next are joined where gvcf_write would have gone on (the same rule as between two tiles).
+ * (The records of `mpileup` are every column's PL / DP planes, encoded on the host of the shard that computed them: a device
+ * gather -- bcfgpu_gather_bytes, what the call-side drivers use for their compacted call records -- would carry host-made
+ * bytes through HBM and back.) ---- */
+typedef struct { char *line; int is_block, pos1, end1, min_dp; } gline_t;
+static int gline_parse(gline_t *g, char *line)
+{
+    g->line = line; g->is_block = 0;
+    char *f[10]; int nf = 0;
+    char *dup = strdup(line);
+    for (char *s = dup; nf < 10 && s; ) { f[nf++] = s; s = strchr(s, '\t'); if (s) *s++ = 0; }
+    if (nf >= 9 && !strcmp(f[4], "<*>") && strstr(f[7], "MinDP=") && !strcmp(f[8], "PL:DP")) {
+        g->is_block = 1; g->pos1 = atoi(f[1]);
+        const char *e = strstr(f[7], "END="); g->end1 = e == f[7] || (e && e[-1] == ';') ? atoi(e + 4) : g->pos1;
+        g->min_dp = atoi(strstr(f[7], "MinDP=") + 6);
+    }
+    free(dup);
+    return g->is_block;
+}
+static int dp_range_of(int min_dp) { int r = 0; while (r < gv_n && min_dp >= gv_range[r]) ++r; return r; }
+/* a (held back) + b, both block lines of the same contig: the joined line, malloc'ed */
+static char *gline_join(const gline_t *a, const gline_t *b)
+{
+    char *fa[10], *fb[10]; int na = 0, nb = 0;
+    char *da = strdup(a->line), *db = strdup(b->line);
+    for (char *s = da; na < 9 && s; ) { fa[na++] = s; s = strchr(s, '\t'); if (s) *s++ = 0; if (na == 9) fa[9] = s; }
+    for (char *s = db; nb < 9 && s; ) { fb[nb++] = s; s = strchr(s, '\t'); if (s) *s++ = 0; if (nb == 9) fb[9] = s; }
+    const char *qs = strstr(fa[7], "QS=");
+    char *out = NULL; size_t len = 0;
+    FILE *m = open_memstream(&out, &len);
+    fprintf(m, "%s\t%d\t.\t%s\t<*>\t.\t.\tEND=%d;MinDP=%d;%s\tPL:DP", fa[0], a->pos1, fa[3], b->end1, a->min_dp < b->min_dp ? a->min_dp : b->min_dp, qs ? qs : "");
+    char *sa = fa[9], *sb = fb[9];
+    while (sa && sb && *sa && *sb) {
+        int pa[3], pb_[3], da_, db_;
+        if (sscanf(sa, "%d,%d,%d:%d", &pa[0], &pa[1], &pa[2], &da_) != 4 || sscanf(sb, "%d,%d,%d:%d", &pb_[0], &pb_[1], &pb_[2], &db_) != 4) DIE("--gvcf: cannot join two blocks\n");
+        if (pb_[1] < pa[1] || (pb_[1] == pa[1] && pb_[2] < pa[2])) { pa[1] = pb_[1]; pa[2] = pb_[2]; }
+        fprintf(m, "\t%d,%d,%d:%d", pa[0], pa[1], pa[2], da_ < db_ ? da_ : db_);
+        sa = strchr(sa, '\t'); if (sa) ++sa;
+        sb = strchr(sb, '\t'); if (sb) ++sb;
+    }
+    fclose(m); free(da); free(db);
+    return out;
+}
+
+static int run_shards(int n_gpus, int argc0, char **argv0, int first_file, const char *ref_path, region_t *reg, int n_reg,
+                      const char *out_path, char out_mode)
+{
+    /* the shards: the columns of all regions, in order, cut into n_gpus contiguous runs */
+    long total = 0;
+    for (int i = 0; i < n_reg; ++i) total += reg[i].end - reg[i].beg;
+    const int n_sh = (long)n_gpus < total ? n_gpus : (total > 0 ? (int)total : 1);
+    pid_t *pid = malloc((size_t)n_sh * sizeof *pid);
+    int *rfd = malloc((size_t)n_sh * sizeof *rfd);
+    extern char **environ;
+    for (int k = 0; k < n_sh; ++k) {
+        const long c0 = total * k / n_sh, c1 = total * (k + 1) / n_sh;
+        char *rl = NULL; size_t rlen = 0; FILE *m = open_memstream(&rl, &rlen);
+        long at = 0; int nr = 0;
+        for (int i = 0; i < n_reg; ++i) {
+            const long lo = at > c0 ? at : c0, hi = at + (reg[i].end - reg[i].beg) < c1 ? at + (reg[i].end - reg[i].beg) : c1;
+            if (lo < hi) fprintf(m, "%s%s:%ld-%ld", nr++ ? "," : "", reg[i].contig, reg[i].beg + (lo - at) + 1, reg[i].beg + (hi - at));
+            at += reg[i].end - reg[i].beg;
+        }
+        fclose(m);
+        /* the shard's records go to an anonymous temporary file this process holds open (no name anyone could predict or
+         * replace); the shard inherits the descriptor and opens it by number */
+        FILE *tf = tmpfile();
+        if (!tf) DIE("tmpfile failed\n");
+        const int tfd = dup(fileno(tf));
+        if (tfd < 0 || fcntl(tfd, F_SETFD, 0)) DIE("tmpfile descriptor\n");
+        fclose(tf);
+        char **av = malloc((size_t)(argc0 + 16) * sizeof *av);
+        int n = 0;
+        char sk[24], sfd[40]; snprintf(sk, sizeof sk, "%d", k); snprintf(sfd, sizeof sfd, "/dev/fd/%d", tfd);
+        av[n++] = argv0[0]; av[n++] = "--shard"; av[n++] = strdup(sk);
+        for (int i = 1; i < first_file; ++i) {                   /* the options, without -O / -o FILE / --output / --gpus / -r / -f and the old positional region */
+            const char *o = argv0[i];
+            if (!strcmp(o, "--gpus") || !strcmp(o, "--output") || !strcmp(o, "-O") || !strcmp(o, "-r") || !strcmp(o, "--regions") || !strcmp(o, "-f") || !strcmp(o, "--fasta-ref")) { ++i; continue; }
+            if (!strncmp(o, "-O", 2) && o[2]) continue;
+            if (!strcmp(o, "-o")) { char *e; strtol(argv0[i + 1], &e, 10); if (*e) { ++i; continue; } }
+            if (o[0] != '-') break;                              /* the positional form: ref.fa contig beg end come from -f / -r below */
+            av[n++] = argv0[i];
+            if (o[0] == '-' && i + 1 < first_file && argv0[i + 1][0] != '-' && strcmp(o, "-B") && strcmp(o, "-E") && strcmp(o, "-A") && strcmp(o, "-p") && strcmp(o, "-I")
+                && strcmp(o, "--ignore-RG") && strcmp(o, "--list-samples")) av[n++] = argv0[++i];
+        }
+        av[n++] = "-f"; av[n++] = (char *)ref_path; av[n++] = "-r"; av[n++] = rl;
+        av[n++] = "-O"; av[n++] = "u"; av[n++] = "--output"; av[n++] = strdup(sfd);
+        for (int i = first_file; i < argc0; ++i) av[n++] = argv0[i];
+        av[n] = NULL;
+        if (posix_spawn(&pid[k], "/proc/self/exe", NULL, NULL, av, environ)) {
+            for (int j = 0; j < k; ++j) { kill(pid[j], SIGTERM); waitpid(pid[j], NULL, 0); }          /* no orphans behind a failed start */
+            DIE("cannot start shard %d\n", k);
+        }
+        rfd[k] = tfd;
+        free(av);
+    }
+    int bad = 0;
+    for (int k = 0; k < n_sh; ++k) { int st = 0; if (waitpid(pid[k], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st)) bad = 1; }
+    if (bad) DIE("a shard failed\n");
+    fprintf(stderr, "[bcfgpu_sam] %d region shards, one process each; their record streams (uncompressed BCF) are emitted in shard order on the host\n", n_sh);
+    char *lb = NULL; size_t lcap = 0;
+    gline_t held; char *held_line = NULL; memset(&held, 0, sizeof held);
+    for (int k = 0; k < n_sh; ++k) {
+        char path[40]; snprintf(path, sizeof path, "/dev/fd/%d", rfd[k]);
+        vio_file *fk = vio_open_read(path);
+        vio_hdr *hk = fk ? vio_read_hdr(fk) : NULL;
+        if (!fk || !hk) DIE("shard %d: %s\n", k, vio_error());
+        if (k == 0) {
+            hdr = hk;
+            fout = vio_open_write(out_path, out_mode);
+            if (!fout || vio_write_hdr(fout, hdr)) DIE("%s\n", vio_error());
+        }
+        int rr, first = 1;
+        while ((rr = vio_read_line(fk, hk, &lb, &lcap)) > 0) {
+            if (!lb[0]) continue;
+            gline_t g;
+            if (gv_n && gline_parse(&g, lb)) {
+                /* the shard's first line continues the block the shard before ended with? */
+                if (held_line && first && !strncmp(held_line, lb, strcspn(lb, "\t") + 1) && g.pos1 == held.end1 + 1 && dp_range_of(g.min_dp) == dp_range_of(held.min_dp)) {
+                    char *j = gline_join(&held, &g);
+                    free(held_line); held_line = j; gline_parse(&held, held_line);
+                } else {
+                    if (held_line) { if (vio_write_line(fout, hdr, held_line)) DIE("%s\n", vio_error()); free(held_line); }
+                    held_line = strdup(lb); gline_parse(&held, held_line);
+                }
+            } else {
+                if (held_line) { if (vio_write_line(fout, hdr, held_line)) DIE("%s\n", vio_error()); free(held_line); held_line = NULL; }
+                if (vio_write_line(fout, hdr, lb)) DIE("%s\n", vio_error());
+            }
+            first = 0;
+        }
+        if (rr < 0) DIE("shard %d: %s\n", k, vio_error());
+        vio_close(fk);
+        if (k) vio_hdr_free(hk);
+    }
+    if (held_line) { if (vio_write_line(fout, hdr, held_line)) DIE("%s\n", vio_error()); free(held_line); }
+    free(lb);
+    if (vio_close(fout)) DIE("%s\n", vio_error());
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
-    int32_t gv_range[16]; int gv_n = 0;                                       /* mpileup --gvcf INT,.. (gvcf.c:44-67) */
-    char out_mode = 'v'; const char *out_path = "-"; int max_depth = 250;      /* mpileup -O, -o, -d (mpileup.c:937-950) */
-    int baq_flag = 3, min_baseQ = 13, list_only = 0;
-    int n_gpus = 1, shard = -1;                                               /* --gpus N: region shards, one process per shard; --shard K: this is shard K */
+    char out_mode = 'v'; const char *out_path = "-";                           /* mpileup -O, -o (mpileup.c:937-950) */
+    int list_only = 0, n_gpus = 1, shard = -1;                                /* --gpus N: region shards, one process per shard; --shard K: this is shard K */
+    const char *ref_path = NULL, *reg_arg = NULL;
     char **argv0 = argv; const int argc0 = argc;
-    int cap_thres = 0;                                                        /* mpileup -C (adjust-MQ), mpileup.c:938 */
-    int openQ = 40, extQ = 20, tandemQ = 100, min_support = 1, per_sample_flt = 0, no_indels = 0, max_indel_depth = 250; double min_frac = 0.002;   /* mpileup.c:937-950 */
-    while (argc > 2 && argv[1][0] == '-') {
+    while (argc > 2 && argv[1][0] == '-' && argv[1][1]) {
         if (!strcmp(argv[1], "-a")) {                                         /* mpileup -a, mpileup.c:parse_format_flag */
             static const struct { const char *name; int bit; } tags[] = {
                 { "DP", BCFGPU_FMT_DP }, { "DV", BCFGPU_FMT_DV }, { "SP", BCFGPU_FMT_SP }, { "DP4", BCFGPU_FMT_DP4 }, { "DPR", BCFGPU_FMT_DPR },
@@ -664,7 +1162,7 @@ int main(int argc, char **argv)
             }
             free(list);
             argv += 2; argc -= 2;
-        } else if (!strcmp(argv[1], "--gvcf")) {
+        } else if (!strcmp(argv[1], "--gvcf") || !strcmp(argv[1], "-g")) {
             char *list = strdup(argv[2]);
             for (char *t = strtok(list, ","); t; t = strtok(NULL, ",")) { if (gv_n == 16) DIE("--gvcf: at most 16 limits\n"); gv_range[gv_n++] = atoi(t); }
             free(list);
@@ -679,6 +1177,9 @@ int main(int argc, char **argv)
             argv += 2; argc -= 2;
         }
         else if (!strcmp(argv[1], "--output")) { out_path = argv[2]; argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-f") || !strcmp(argv[1], "--fasta-ref")) { ref_path = argv[2]; argv += 2; argc -= 2; }      /* mpileup.c:1008,1056 */
+        else if (!strcmp(argv[1], "-r") || !strcmp(argv[1], "--regions")) { reg_arg = argv[2]; argv += 2; argc -= 2; }          /* mpileup.c:1011,1057 */
+        else if (!strcmp(argv[1], "--tile")) { tile_cols = atoi(argv[2]); if (tile_cols < 1) DIE("--tile: at least one column\n"); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-d")) { max_depth = atoi(argv[2]); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-s")) { add_samples(argv[2], 0); argv += 2; argc -= 2; }            /* mpileup.c:1058-1059,1087,1016 */
         else if (!strcmp(argv[1], "-S")) { add_samples(argv[2], 1); argv += 2; argc -= 2; }
@@ -704,98 +1205,64 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "--rf")) { rflag_require = (int)strtol(argv[2], NULL, 0); argv += 2; argc -= 2; }
         else break;
     }
-    if (argc < 6) {
-        fprintf(stderr, "usage: bcfgpu_sam [-a TAG,..] [--gvcf INT,..] [-O v|z|u|b] [-o out] [-d INT] [-s LIST | -S FILE] [-G FILE] [--ignore-RG]\n"
-                        "                  [-B | -E] [-A] [-q INT] [-Q INT] [-C INT] [--ff INT] [--rf INT] [-I] [-o INT] [-e INT] [-h INT] [-m INT] [-F FLOAT] [-p] [-L INT]\n"
-                        "                  ref.fa contig beg end file.sam|file.bam [...]\n");
-        return 2;
+    /* two spellings of what to run on: mpileup's own (-f REF [-r CHR[:BEG[-END]],...] files), or "ref.fa contig beg end files" */
+    region_t *reg = NULL; int n_reg = 0;
+    int n_in; char **in_path;
+    if (ref_path) {
+        if (argc < 2) goto usage;
+        n_in = argc - 1; in_path = argv + 1;
+        if (reg_arg) {
+            char *list = strdup(reg_arg);
+            for (char *t = strtok(list, ","); t; t = strtok(NULL, ",")) { reg = grow(reg, (size_t)(n_reg + 1) * sizeof *reg); reg[n_reg++] = parse_region(t); }
+            free(list);
+        }
+    } else {
+        if (argc < 6) goto usage;
+        ref_path = argv[1];
+        reg = grow(NULL, sizeof *reg); n_reg = 1;
+        reg[0].contig = strdup(argv[2]); reg[0].beg = atoi(argv[3]) - 1; reg[0].end = atoi(argv[4]);     /* 1-based inclusive -> 0-based [beg, end) */
+        n_in = argc - 5; in_path = argv + 5;
     }
     defer_mq_filters = cap_thres > 10;
-    const char *contig = argv[2];
-    const int beg = atoi(argv[3]) - 1, end = atoi(argv[4]);                 /* 0-based [beg, end) */
-    if (n_gpus > 1 && shard < 0 && !list_only) {
-        /* ---- several GPUs (the reference's -r regions + `bcftools concat`, mpileup.c:652-683, vcfconcat.c:420):
-         * the region is cut into contiguous shards, a process per shard (shard k on device k mod the devices present), each
-         * writing its records as VCF text; rank order is genomic order, so the files are written out one after the other, the
-         * header from the first.  Sites are independent, and a shard reads the reads that overlap it: the records equal the
-         * single-process run's.  (This process makes no device call before it starts the others.) ---- */
-        if (gv_n) DIE("--gpus with --gvcf: a block would end at every shard boundary; not supported\n");
-        const int n_sh = n_gpus < end - beg ? n_gpus : (end - beg > 0 ? end - beg : 1);
-        pid_t *pid = malloc((size_t)n_sh * sizeof *pid);
-        char (*tmp)[256] = malloc((size_t)n_sh * sizeof *tmp);
-        for (int k = 0; k < n_sh; ++k) {
-            const long b0 = beg + (long)(end - beg) * k / n_sh, e0 = beg + (long)(end - beg) * (k + 1) / n_sh;
-            snprintf(tmp[k], sizeof tmp[k], "/tmp/bcfgpu_sam.%d.%d.vcf", (int)getpid(), k);
-            char **av = malloc((size_t)(argc0 + 12) * sizeof *av);
-            int n = 0;
-            av[n++] = argv0[0];
-            static char sb[16][24];
-            snprintf(sb[0], 24, "%d", k); snprintf(sb[1], 24, "%ld", b0 + 1); snprintf(sb[2], 24, "%ld", e0);
-            av[n++] = "--shard"; av[n++] = sb[0];
-            const int first_pos = argc0 - argc + 1;              /* index of ref.fa in argv0 */
-            for (int i = 1; i < first_pos; ++i) {                /* the options, without -O / -o FILE / --output / --gpus */
-                const char *o = argv0[i];
-                if (!strcmp(o, "--gpus") || !strcmp(o, "--output") || !strcmp(o, "-O")) { ++i; continue; }
-                if (!strncmp(o, "-O", 2) && o[2]) continue;
-                if (!strcmp(o, "-o")) { char *e; strtol(argv0[i + 1], &e, 10); if (*e) { ++i; continue; } }
-                av[n++] = argv0[i];
-            }
-            av[n++] = "-O"; av[n++] = "v"; av[n++] = "--output"; av[n++] = tmp[k];
-            av[n++] = argv0[first_pos]; av[n++] = argv0[first_pos + 1];
-            char *rb = strdup(sb[1]), *re = strdup(sb[2]);
-            av[n++] = rb; av[n++] = re;
-            for (int i = first_pos + 4; i < argc0; ++i) av[n++] = argv0[i];
-            av[n] = NULL;
-            extern char **environ;
-            if (posix_spawn(&pid[k], "/proc/self/exe", NULL, NULL, av, environ)) DIE("cannot start shard %d\n", k);
-            free(av);
-        }
-        int bad = 0;
-        for (int k = 0; k < n_sh; ++k) { int st = 0; if (waitpid(pid[k], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st)) bad = 1; }
-        if (bad) { for (int k = 0; k < n_sh; ++k) unlink(tmp[k]); DIE("a shard failed\n"); }
-        fprintf(stderr, "[bcfgpu_sam] %d region shards, one process each; ordered emit on the host (records are text: no device gather)\n", n_sh);
-        vio_file *f0 = vio_open_read(tmp[0]);
-        if (!f0) DIE("%s\n", vio_error());
-        hdr = vio_read_hdr(f0);
-        if (!hdr) DIE("%s\n", vio_error());
-        fout = vio_open_write(out_path, out_mode);
-        if (!fout || vio_write_hdr(fout, hdr)) DIE("%s\n", vio_error());
-        char *lb = NULL; size_t lcap = 0; int rr;
-        while ((rr = vio_read_line(f0, hdr, &lb, &lcap)) > 0) if (lb[0] && vio_write_line(fout, hdr, lb)) DIE("%s\n", vio_error());
-        if (rr < 0) DIE("%s\n", vio_error());
-        vio_close(f0); unlink(tmp[0]);
-        for (int k = 1; k < n_sh; ++k) {                         /* the other shards wrote records only */
-            FILE *fk = fopen(tmp[k], "r");
-            if (!fk) DIE("cannot read %s\n", tmp[k]);
-            ssize_t nl;
-            while ((nl = getline(&lb, &lcap, fk)) > 0) {
-                if (lb[nl - 1] == '\n') lb[nl - 1] = 0;
-                if (lb[0] && lb[0] != '#' && vio_write_line(fout, hdr, lb)) DIE("%s\n", vio_error());
-            }
-            fclose(fk); unlink(tmp[k]);
-        }
-        free(lb);
-        if (vio_close(fout)) DIE("%s\n", vio_error());
-        return 0;
-    }
-    reg_beg = beg; reg_end = end;
-    int device = 0;                                                           /* shard k of --gpus runs on device k mod the devices present */
-    if (shard > 0 && !list_only) { const int nd = bcfgpu_device_count(); device = nd > 0 ? shard % nd : 0; if (nd > 1) fprintf(stderr, "[bcfgpu_sam] shard %d on device %d of %d\n", shard, device, nd); }
-    const int n_in = argc - 5, n_sites = end - beg;
-    int ref_len = 0;
-    char *ref = read_contig(argv[1], contig, &ref_len);
-    pool_t P; memset(&P, 0, sizeof P);
-    int *first = malloc((size_t)(n_in + 1) * sizeof *first);                  /* the pool is file-major: file f = [first[f], first[f+1]) */
+
+    /* ---- the input files: their headers decide the samples (bam_smpl_add_bam) and give the ##contig lines ---- */
+    reader_t *rdr = calloc((size_t)n_in, sizeof *rdr);
     sfile_t *sfile = calloc((size_t)n_in, sizeof *sfile);
-    /* ---- the VCF header, in mpileup's order (mpileup.c:510-602) ---- */
+    const char **kept_path = calloc((size_t)n_in, sizeof *kept_path);
     hdr = vio_hdr_new();
-    { char b[4096]; snprintf(b, sizeof b, "##reference=file://%s", argv[1]); vio_hdr_append(hdr, b); }
+    { char b[4096]; snprintf(b, sizeof b, "##reference=file://%s", ref_path); vio_hdr_append(hdr, b); }
     int F = 0;                                                                /* files kept (mpileup.c:442-455 drops the others) */
-    for (int i = 0; i < n_in; ++i) { first[F] = P.n; if (read_file(argv[5 + i], contig, F, &sfile[F], &P, F == 0 ? hdr : NULL)) ++F; }
-    first[F] = P.n;
+    char **all_contig = NULL; int n_all = 0;                                   /* no -r: every sequence of the first file's dictionary */
+    for (int i = 0; i < n_in; ++i) {
+        reader_open(&rdr[F], in_path[i]);
+        if (i == 0 && !reg) {
+            if (rdr[F].is_bam) for (int k = 0; k < rdr[F].n_ref; ++k) { all_contig = grow(all_contig, (size_t)(n_all + 1) * sizeof *all_contig); all_contig[n_all++] = strdup(rdr[F].ref_name[k]); }
+            else for (const char *l = rdr[F].text; l && *l; ) {
+                if (!strncmp(l, "@SQ\t", 4)) { const char *sn = strstr(l, "\tSN:"), *e = strchr(l, '\n'); if (sn && (!e || sn < e)) { sn += 4; all_contig = grow(all_contig, (size_t)(n_all + 1) * sizeof *all_contig); all_contig[n_all++] = strndup(sn, strcspn(sn, "\t\r\n")); } }
+                l = strchr(l, '\n'); if (l) ++l;
+            }
+        }
+        if (!add_file(&sfile[F], in_path[i], rdr[F].text)) { reader_close(&rdr[F]); continue; }
+        if (F == 0) header_contigs(&rdr[0], hdr);
+        reader_close(&rdr[F]);
+        kept_path[F++] = in_path[i];
+    }
+    if (!reg) { for (int k = 0; k < n_all; ++k) { reg = grow(reg, (size_t)(n_reg + 1) * sizeof *reg); reg[n_reg].contig = all_contig[k]; reg[n_reg].beg = 0; reg[n_reg++].end = -1; } }
+    if (!n_reg) DIE("no region to run on: no -r and no sequence dictionary in the first file\n");
     const int S = SM.nsmpl;
     if (!F || !S) DIE("no sample left to call\n");
     char **sample = SM.smpl;
+    /* the contigs' sequences (one at a time in memory), and the open ends of the regions */
+    char *ref = NULL, *ref_name = NULL; int ref_len = 0;
+    for (int i = 0; i < n_reg; ++i) {
+        if (reg[i].end >= 0) continue;
+        int len = 0; char *sq = read_contig(ref_path, reg[i].contig, &len);
+        reg[i].end = len; free(sq);
+    }
+    if (n_gpus > 1 && shard < 0 && !list_only)
+        return run_shards(n_gpus, argc0, argv0, argc0 - n_in, ref_path, reg, n_reg, out_path, out_mode);
+    if (shard > 0 && !list_only) { const int nd = bcfgpu_device_count(); device = nd > 0 ? shard % nd : 0; if (nd > 1) fprintf(stderr, "[bcfgpu_sam] shard %d on device %d of %d\n", shard, device, nd); }
+    /* ---- the VCF header, in mpileup's order (mpileup.c:510-602) ---- */
     {
         #define HL(cond, text) do { if (cond) vio_hdr_append(hdr, text); } while (0)
         HL(1, "##ALT=<ID=*,Description=\"Represents allele(s) other than observed.\">");
@@ -839,234 +1306,108 @@ int main(int argc, char **argv)
         LN = open_memstream(&ln_buf, &ln_len);
         if (!LN) DIE("open_memstream failed\n");
     }
-    /* ---- mpileup -C INT (mpileup.c:234-241): after BAQ, sam_cap_mapq lowers the mapping quality of reads with many
-     * mismatches or drops them; then the -q and orphan filters, which read_passes() left for here ---- */
-    if (cap_thres > 10 && P.n && !list_only) {
-        bcfgpu_cfg c0; memset(&c0, 0, sizeof c0);
-        c0.device = device; c0.n_smpl = S; c0.max_sites = 1; c0.max_reads = 64; c0.min_baseQ = min_baseQ; c0.capQ = 60; c0.n_grp = 1; c0.ploidy_max = 2;
-        bcfgpu_ctx *cx = NULL;
-        CHECK(bcfgpu_create(&c0, &cx));
-        bcfgpu_reads r0; memset(&r0, 0, sizeof r0);
-        r0.n_reads = P.n; r0.r_pos = P.pos; r0.r_lq = P.lq; r0.r_flag = P.flag; r0.r_ncig = P.ncig; r0.r_cig_off = P.cig_off;
-        r0.r_seq_off = P.seq_off; r0.cig = P.cig; r0.seq16 = P.seq16; r0.qual = P.qual; r0.zq = P.zq; r0.r_has_zq = P.has_zq;
-        /* the pool goes up once; BAQ and the cap run on that copy (the qualities sam_cap_mapq sees are BAQ's) */
-        CHECK(bcfgpu_pool_upload(cx, &r0, NULL, P.mapq));
-        if (baq_flag) CHECK(bcfgpu_pool_baq(cx, ref, ref_len, baq_flag, NULL));
-        int32_t *capv = malloc((size_t)P.n * sizeof *capv);
-        CHECK(bcfgpu_pool_cap_mapq(cx, ref, ref_len, cap_thres, capv));
-        uint8_t *keep = malloc((size_t)P.n);
-        for (int r = 0; r < P.n; ++r) {
-            keep[r] = capv[r] >= 0;
-            if (keep[r] && P.mapq[r] > capv[r]) P.mapq[r] = (uint8_t)capv[r];
-            if (P.mapq[r] < min_mq) keep[r] = 0;
-            if (!keep_orphans && (P.flag[r] & 1) && !(P.flag[r] & 2)) keep[r] = 0;
-        }
-        pool_keep(&P, first, F, keep);
-        free(keep); free(capv);
-        bcfgpu_destroy(cx);
-    }
-    /* ---- the per-file depth cap of the pileup iterator (mpileup -d, mpileup.c:646): reads it drops leave the pool ---- */
-    if (max_depth > 0 && P.n) {
-        bcfgpu_reads r0; memset(&r0, 0, sizeof r0);
-        r0.n_reads = P.n; r0.r_pos = P.pos; r0.r_ncig = P.ncig; r0.r_cig_off = P.cig_off; r0.cig = P.cig;
-        uint8_t *keep = malloc((size_t)P.n);
-        CHECK(bcfgpu_depth_cap(&r0, P.file, F, max_depth, keep));
-        pool_keep(&P, first, F, keep);
-        free(keep);
-    }
 
+    /* ---- the regions, one after the other (mpileup.c:652-683), each streamed through in tiles of tile_cols columns: the files
+     * are read in step with the tiles (a sorted file no further than the tile's end), a read stays in memory while it can still
+     * cover a column, and what is on the device at any time is one tile.  SURVEY 8e: "shards further cut into tiles". ---- */
+    bcfgpu_depth_state *dcap = bcfgpu_depth_cap_new(F, max_depth);             /* the iterators' buffers (mpileup -d), one per file */
+    if (!dcap) DIE("%s\n", bcfgpu_last_error());
+    lwin_t *win = calloc((size_t)F, sizeof *win);
+    pool_t P; memset(&P, 0, sizeof P);
+    int *first = malloc((size_t)(F + 1) * sizeof *first);
+    long long *n_in_smpl = calloc((size_t)S, sizeof *n_in_smpl); int *nf_smpl = calloc((size_t)S, sizeof *nf_smpl), *lastf_smpl = malloc((size_t)S * sizeof *lastf_smpl);
+    for (int s = 0; s < S; ++s) lastf_smpl[s] = -1;
+    unsigned long long n_reads_tot = 0, n_cols_tot = 0; int n_tiles = 0;
+    for (int g = 0; g < n_reg; ++g) {
+        const char *contig = reg[g].contig;
+        if (!ref_name || strcmp(ref_name, contig)) { free(ref); free(ref_name); ref = read_contig(ref_path, contig, &ref_len); ref_name = strdup(contig); }
+        reg_beg = reg[g].beg; reg_end = reg[g].end;
+        if (reg_end <= reg_beg) continue;
+        for (int f = 0; f < F; ++f) { reader_open(&rdr[f], kept_path[f]); for (int i = 0; i < win[f].n; ++i) lrec_free(win[f].r[i]); win[f].n = 0; }
+        bcfgpu_depth_cap_reset(dcap);
+        for (int t0 = reg_beg; t0 < reg_end; t0 += tile_cols) {
+            const int t1 = t0 + tile_cols < reg_end ? t0 + tile_cols : reg_end;
+            /* stage 1: the reads that start before the tile's end come off the files, through -C (BAQ + sam_cap_mapq + the
+             * deferred filters) and the depth cap, into the live window */
+            for (int f = 0; f < F; ++f) {
+                lrec_t **b = NULL; int nb = 0, bcap = 0;
+                for (;;) {
+                    reader_fetch(&rdr[f], contig, &sfile[f]);
+                    lrec_t *x = rdr[f].pend;
+                    if (!x || x->pos >= t1) break;
+                    rdr[f].pend = NULL;
+                    if (nb == bcap) { bcap = bcap ? 2 * bcap : 256; b = grow(b, (size_t)bcap * sizeof *b); }
+                    b[nb++] = x;
+                }
+                if (!nb) { free(b); continue; }
+                uint8_t *keep = malloc((size_t)nb);
+                memset(keep, 1, (size_t)nb);
+                if (cap_thres > 10 && !list_only) cap_batch(b, nb, S, ref, ref_len, keep);
+                int m = 0;
+                for (int i = 0; i < nb; ++i) { if (keep[i]) b[m++] = b[i]; else lrec_free(b[i]); }
+                if (max_depth > 0 && m) {
+                    /* bcfgpu_depth_cap_push wants the batch as arrays */
+                    int32_t *pos = malloc((size_t)m * 4), *ncg = malloc((size_t)m * 4), *coff = malloc((size_t)m * 4), *fl = malloc((size_t)m * 4);
+                    size_t nc = 0; for (int i = 0; i < m; ++i) nc += (size_t)b[i]->ncig;
+                    uint32_t *cg = malloc((nc + 1) * 4);
+                    nc = 0;
+                    for (int i = 0; i < m; ++i) { pos[i] = b[i]->pos; ncg[i] = b[i]->ncig; coff[i] = (int32_t)nc; fl[i] = f; memcpy(cg + nc, b[i]->cig, (size_t)b[i]->ncig * 4); nc += (size_t)b[i]->ncig; }
+                    bcfgpu_reads r0; memset(&r0, 0, sizeof r0);
+                    r0.n_reads = m; r0.r_pos = pos; r0.r_ncig = ncg; r0.r_cig_off = coff; r0.cig = cg;
+                    CHECK(bcfgpu_depth_cap_push(dcap, &r0, fl, keep));
+                    free(pos); free(ncg); free(coff); free(fl); free(cg);
+                } else memset(keep, 1, (size_t)nb);
+                for (int i = 0; i < m; ++i) {
+                    if (!keep[i]) { lrec_free(b[i]); continue; }
+                    lwin_push(&win[f], b[i]);
+                    const int s = b[i]->smpl;
+                    ++n_in_smpl[s]; ++n_reads_tot;
+                    if (lastf_smpl[s] != f) { ++nf_smpl[s]; lastf_smpl[s] = f; }
+                }
+                free(keep); free(b);
+            }
+            if (!list_only) {
+                /* stage 2: the tile's pool = the reads of the window that overlap the tile, file after file */
+                pool_clear(&P);
+                for (int f = 0; f < F; ++f) {
+                    first[f] = P.n;
+                    for (int i = 0; i < win[f].n; ++i) { const lrec_t *x = win[f].r[i]; if (overlaps(x->pos, x->end, t0, t1)) pool_add_rec(&P, f, x); }
+                }
+                first[F] = P.n;
+                process_tile(&P, first, F, S, contig, ref, ref_len, t0, t1);
+                n_cols_tot += (unsigned long long)(t1 - t0); ++n_tiles;
+            }
+            /* reads that end at or before the next tile's first column are through */
+            for (int f = 0; f < F; ++f) {
+                int m = 0;
+                for (int i = 0; i < win[f].n; ++i) { lrec_t *x = win[f].r[i]; if ((x->end == x->pos ? x->pos + 1 : x->end) > t1) win[f].r[m++] = x; else lrec_free(x); }
+                win[f].n = m;
+            }
+        }
+        for (int f = 0; f < F; ++f) reader_close(&rdr[f]);
+    }
     if (list_only) {
         /* --list-samples: what the host side decided, one line per output sample -- name, reads that enter the pileup, files they
          * come from -- and nothing else (the read-group plumbing, the filters and the depth cap run without a device) */
-        for (int s = 0; s < S; ++s) {
-            int nr = 0, nf = 0, lastf = -1;
-            for (int r = 0; r < P.n; ++r) if (P.smpl[r] == s) { ++nr; if (P.file[r] != lastf) { ++nf; lastf = P.file[r]; } }
-            printf("%s\t%d\t%d\n", sample[s], nr, nf);
-        }
+        for (int s = 0; s < S; ++s) printf("%s\t%lld\t%d\n", sample[s], n_in_smpl[s], nf_smpl[s]);
         return 0;
     }
-    bcfgpu_cfg cfg; memset(&cfg, 0, sizeof cfg);
-    cfg.device = device; cfg.n_smpl = S; cfg.max_sites = n_sites; cfg.max_reads = (uint64_t)P.nbase + 64;   /* every base is in <= 1 column */
-    cfg.min_baseQ = min_baseQ; cfg.capQ = 60; cfg.errmod_theta = 0.; cfg.fmt_flag = fmt_flag;
-    cfg.call_theta = 1.1e-3; cfg.n_grp = 1; cfg.ploidy_max = 2;
-    bcfgpu_ctx *ctx = NULL;
-    CHECK(bcfgpu_create(&cfg, &ctx));
-
-    /* mate overlaps: htslib pairs the reads inside one file's iterator (bam_mplp_init_overlaps, mpileup.c:640) */
-    int32_t *pa = malloc((size_t)(P.n + 1) * sizeof *pa), *pb = malloc((size_t)(P.n + 1) * sizeof *pb);
-    int np = 0;
-    for (int f = 0; f < F; ++f) np += find_pairs(&P, first[f], first[f + 1], pa + np, pb + np);
-    /* a sample fed by several files (mpileup.c:275-293 appends file after file): its reads merged by position, files in
-     * order at equal positions, as bcfgpu_pileup wants them; the pairs follow their reads */
-    {
-        int sorted = 1;
-        int32_t *last = malloc((size_t)S * sizeof *last);
-        for (int s = 0; s < S; ++s) last[s] = INT32_MIN;
-        for (int r = 0; r < P.n && sorted; ++r) { if (P.pos[r] < last[P.smpl[r]]) sorted = 0; last[P.smpl[r]] = P.pos[r]; }
-        free(last);
-        if (!sorted) {
-            int32_t *ord = malloc((size_t)P.n * sizeof *ord), *tmp = malloc((size_t)P.n * sizeof *tmp), *inv = malloc((size_t)P.n * sizeof *inv);
-            for (int r = 0; r < P.n; ++r) ord[r] = r;
-            for (int w = 1; w < P.n; w *= 2) {                               /* bottom-up merge sort: stable */
-                for (int lo = 0; lo < P.n; lo += 2 * w) {
-                    const int mid = lo + w < P.n ? lo + w : P.n, hi = lo + 2 * w < P.n ? lo + 2 * w : P.n;
-                    int i = lo, j = mid, k = lo;
-                    while (i < mid && j < hi) tmp[k++] = P.pos[ord[j]] < P.pos[ord[i]] ? ord[j++] : ord[i++];
-                    while (i < mid) tmp[k++] = ord[i++];
-                    while (j < hi) tmp[k++] = ord[j++];
-                }
-                int32_t *t = ord; ord = tmp; tmp = t;
-            }
-            for (int r = 0; r < P.n; ++r) inv[ord[r]] = r;
-            #define PERM(a) do { void *n_ = malloc((size_t)P.n * sizeof *P.a); for (int r = 0; r < P.n; ++r) memcpy((char *)n_ + (size_t)r * sizeof *P.a, &P.a[ord[r]], sizeof *P.a); \
-                                 memcpy(P.a, n_, (size_t)P.n * sizeof *P.a); free(n_); } while (0)
-            PERM(pos); PERM(lq); PERM(flag); PERM(ncig); PERM(cig_off); PERM(seq_off); PERM(smpl); PERM(file); PERM(end); PERM(mpos); PERM(isize);
-            PERM(rnext_same); PERM(mapq); PERM(has_zq); PERM(qname);
-            #undef PERM
-            for (int i = 0; i < np; ++i) { pa[i] = inv[pa[i]]; pb[i] = inv[pb[i]]; }
-            free(ord); free(tmp); free(inv);
-        }
-    }
-
-    bcfgpu_reads rd; memset(&rd, 0, sizeof rd);
-    rd.n_reads = P.n; rd.r_pos = P.pos; rd.r_lq = P.lq; rd.r_flag = P.flag; rd.r_ncig = P.ncig; rd.r_cig_off = P.cig_off;
-    rd.r_seq_off = P.seq_off; rd.cig = P.cig; rd.seq16 = P.seq16; rd.qual = P.qual; rd.zq = P.zq; rd.r_has_zq = P.has_zq;
-
-    /* the pool goes up once and stays in HBM: BAQ (new qualities and ZQ bytes for the reads it applies to; not with -B), the
-     * mate-overlap tweak, the pileup of the region -- each on the copy the stage before left there */
-    CHECK(bcfgpu_pool_upload(ctx, &rd, NULL, P.mapq));
-    if (baq_flag) CHECK(bcfgpu_pool_baq(ctx, ref, ref_len, baq_flag, NULL));
-    CHECK(bcfgpu_pool_overlap_tweak(ctx, np, pa, pb));
-    /* the pileup of the region and the SNP pass */
-    bcfgpu_tile tile;
-    int32_t *col_n = malloc((size_t)(n_sites + 1) * sizeof *col_n);
-    uint8_t *col_indel = malloc((size_t)n_sites + 1);
-    CHECK(bcfgpu_pool_pileup(ctx, P.smpl, NULL, beg, end, ref, ref_len, &tile, col_n, col_indel));
-    void *d_site, *d_pl, *d_dp4;
-    bcfgpu_site *site = NULL;
-    planes_t snp_planes;
-    run_mpileup(ctx, &tile, n_sites, &site, &snp_planes, gv_n ? &d_site : NULL, &d_pl, &d_dp4);
-
-    /* ---- indel records (mpileup.c:354-365): candidate columns -> bcf_call_gap_prep -> second pass with p->aux ---- */
-    int nc = 0;
-    int32_t *cand = malloc((size_t)(n_sites + 1) * sizeof *cand);
-    for (int k = 0; k < n_sites; ++k)
-        if (!no_indels && col_indel[k] && col_n[k] < max_indel_depth * S) cand[nc++] = k;     /* mpileup.c:354 */      /* max_indel_depth */
-    bcfgpu_site *isite = NULL;
-    planes_t ind_planes; memset(&ind_planes, 0, sizeof ind_planes); int32_t *live = NULL; int nlive = 0;
-    int32_t *g_types = NULL, *g_maxins = NULL, *g_indelreg = NULL, *g_support = NULL; float *g_frac = NULL; int8_t *g_inscns = NULL;
-    if (nc) {
-        /* everything stays in HBM: the candidates' entries, the stage on the pool bcfgpu_pileup left there, p->aux straight
-         * into the indel pass's tile over all candidate columns (the host pool is passed for its ZQ bytes) */
-        bcfgpu_indel_in in; memset(&in, 0, sizeof in);
-        in.n_sites = nc; in.n_smpl = S; in.ref = ref;
-        in.openQ = openQ; in.extQ = extQ; in.tandemQ = tandemQ; in.min_support = min_support; in.per_sample_flt = per_sample_flt; in.min_frac = min_frac;
-        bcfgpu_indel_out out; memset(&out, 0, sizeof out);
-        int32_t *gret = malloc((size_t)nc * 4);
-        g_types = malloc((size_t)nc * 16); g_inscns = malloc((size_t)nc * 4 * INSCNS_CAP); g_maxins = malloc((size_t)nc * 4);
-        g_indelreg = malloc((size_t)nc * 4); g_support = malloc((size_t)nc * 4); g_frac = malloc((size_t)nc * 4);
-        out.ret = gret; out.p_aux = NULL; out.indel_types = g_types; out.inscns = g_inscns; out.maxins = g_maxins;
-        out.indelreg = g_indelreg; out.max_support = g_support; out.max_frac = g_frac;
-        bcfgpu_tile ti;
-        /* (with BAQ the ZQ bytes are the pool's, in HBM; with -B the reads' own tags, if any, go up from the host) */
-        CHECK(bcfgpu_gap_prep_tile(ctx, nc, cand, baq_flag ? NULL : &rd, &in, &out, INSCNS_CAP, &ti));
-        live = malloc((size_t)nc * 4);
-        for (int i = 0; i < nc; ++i) if (gret[i] == 0) live[nlive++] = i;
-        if (nlive) run_mpileup(ctx, &ti, nc, &isite, &ind_planes, NULL, NULL, NULL);      /* records of columns with ret < 0 are not used */
-        free(gret);
-    }
-
-    {   /* cells cut to their first 255 usable reads (errmod_cal would draw a random 255: bcfgpu.h, bcfgpu_truncated_cells) */
-        uint32_t ncut = 0;
-        CHECK(bcfgpu_truncated_cells(ctx, &ncut));
-        if (ncut) fprintf(stderr, "[bcfgpu_sam] warning: %u (site, sample) cells held more than 255 usable reads and were cut to their first 255 "
-                                  "(DP, AD, QS count the kept reads only; bcftools subsamples at random inside errmod_cal): lower -d or split the sample's files\n", ncut);
-    }
-    /* ---- --gvcf: reference-only records collapse into blocks (gvcf_write, gvcf.c:88-226) on the planes still in HBM ---- */
-    int32_t *gv_blk = NULL, *gv_dp = NULL; bcfgpu_gvcf_block *gv_block = NULL; uint8_t *gv_pl = NULL;
-    if (gv_n) {
-        int32_t *pos = malloc((size_t)n_sites * 4); uint8_t *brk = calloc((size_t)n_sites, 1);
-        for (int k = 0; k < n_sites; ++k) { pos[k] = beg + k; if (col_n[k] == 0) brk[k] |= 2; }
-        for (int j = 0; j < nlive; ++j) if (isite[live[j]].ret == 0) brk[cand[live[j]]] |= 1;      /* an indel record follows the SNP record */
-        void *d_pos, *d_brk, *d_blk, *d_min, *d_block, *d_gdp, *d_gpl;
-        CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_pos)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites, &d_brk));
-        CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_blk)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_min));
-        CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * sizeof(bcfgpu_gvcf_block), &d_block));
-        CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * S * 4, &d_gdp)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 3 * S, &d_gpl));
-        CHECK(bcfgpu_memcpy_h2d(ctx, d_pos, pos, (size_t)n_sites * 4)); CHECK(bcfgpu_memcpy_h2d(ctx, d_brk, brk, (size_t)n_sites));
-        bcfgpu_gvcf_in gi; memset(&gi, 0, sizeof gi);
-        gi.n_sites = n_sites; gi.n_range = gv_n; gi.dp_range = gv_range; gi.pos = d_pos; gi.brk = d_brk;
-        gi.site = d_site; gi.pl = d_pl; gi.dp4 = d_dp4;
-        bcfgpu_gvcf_out go = { d_blk, d_min, d_block, d_gdp, d_gpl };
-        int32_t nb = 0;
-        CHECK(bcfgpu_gvcf_blocks(ctx, &gi, &go, &nb));
-        gv_blk = malloc((size_t)n_sites * 4); gv_block = malloc((size_t)(nb + 1) * sizeof *gv_block);
-        gv_dp = malloc((size_t)(nb + 1) * S * 4); gv_pl = malloc((size_t)(nb + 1) * 3 * S);
-        CHECK(bcfgpu_memcpy_d2h(ctx, gv_blk, d_blk, (size_t)n_sites * 4)); CHECK(bcfgpu_memcpy_d2h(ctx, gv_block, d_block, (size_t)nb * sizeof *gv_block));
-        CHECK(bcfgpu_memcpy_d2h(ctx, gv_dp, d_gdp, (size_t)nb * S * 4)); CHECK(bcfgpu_memcpy_d2h(ctx, gv_pl, d_gpl, (size_t)nb * 3 * S));
-        CHECK(bcfgpu_sync(ctx));
-        bcfgpu_free(ctx, d_pos); bcfgpu_free(ctx, d_brk); bcfgpu_free(ctx, d_blk); bcfgpu_free(ctx, d_min); bcfgpu_free(ctx, d_block);
-        bcfgpu_free(ctx, d_gdp); bcfgpu_free(ctx, d_gpl); free(pos); free(brk);
-    }
-
-    /* ---- the record loop: the SNP record of a column, then its indel record (mpileup.c:343-366) ---- */
-    static const char *nt = "ACGTN";
-    int jl = 0;
-    for (int k = 0; k < n_sites; ++k) {
-        if (col_n[k] == 0) continue;                                         /* no read: no record */
-        const bcfgpu_site *c = &site[k];
-        if (gv_blk && gv_blk[k] >= 0) {                                      /* inside a block: one line when the block ends */
-            const int b = gv_blk[k];
-            const bcfgpu_gvcf_block *B = &gv_block[b];
-            if (B->last_site == k) {
-                const bcfgpu_site *f = &site[B->first_site];
-                fprintf(LN, "%s\t%d\t.\t%c\t<*>\t.\t.\t", contig, B->start_pos + 1, nt[f->ori_ref < 0 || f->ori_ref > 4 ? 4 : f->ori_ref]);
-                if (B->start_pos + 1 < B->end1) fprintf(LN, "END=%d;", B->end1);                  /* gvcf.c:150-151 */
-                fprintf(LN, "MinDP=%d;QS=%g,%g\tPL:DP", B->min_dp, (double)f->qsum[0], (double)f->qsum[1]);
-                for (int s = 0; s < S; ++s)
-                    fprintf(LN, "\t%d,%d,%d:%d", gv_pl[((size_t)b * 3) * S + s], gv_pl[((size_t)b * 3 + 1) * S + s], gv_pl[((size_t)b * 3 + 2) * S + s],
-                           gv_dp[(size_t)b * S + s]);
-                end_record();
-            }
-        } else {
-        char als[64]; int o = 0;
-        als[o++] = nt[c->ori_ref < 0 || c->ori_ref > 4 ? 4 : c->ori_ref]; als[o++] = '\t';
-        for (int j = 1; j < c->n_alleles; ++j) {
-            if (j > 1) als[o++] = ',';
-            if (j == c->unseen) { memcpy(als + o, "<*>", 3); o += 3; } else als[o++] = nt[c->a[j]];
-        }
-        if (c->n_alleles < 2) als[o++] = '.';
-        als[o] = 0;
-        print_record(contig, beg + k + 1, als, "", c, &snp_planes, (size_t)k, S);
-        }
-        while (jl < nlive && cand[live[jl]] < k) ++jl;
-        if (jl < nlive && cand[live[jl]] == k && isite[live[jl]].ret == 0) {
-            /* REF / ALT of an indel record (bam2bcf.c:767-790) */
-            const int i = live[jl], p = beg + k, ireg = g_indelreg[i], mi = g_maxins[i];
-            char *txt = malloc((size_t)(5 * (ireg + mi + 8)) + 64), prefix[64];
-            int t = 0;
-            for (int j = 0; j <= ireg; ++j) txt[t++] = ref[p + j];
-            txt[t++] = '\t';
-            for (int a = 1; a < 4 && isite[i].a[a] >= 0; ++a) {
-                const int ai = isite[i].a[a], ty = g_types[i * 4 + ai];
-                if (a > 1) txt[t++] = ',';
-                txt[t++] = ref[p];
-                if (ty < 0) { for (int j = p + 1 - ty; j < p + 1 + ireg; ++j) txt[t++] = ref[j]; }
-                else {
-                    for (int j = 0; j < ty; ++j) txt[t++] = nt[g_inscns[(size_t)i * 4 * INSCNS_CAP + (size_t)ai * mi + j]];
-                    for (int j = p + 1; j < p + 1 + ireg; ++j) txt[t++] = ref[j];
-                }
-            }
-            txt[t] = 0;
-            snprintf(prefix, sizeof prefix, "INDEL;IDV=%d;IMF=%g;", g_support[i], (double)g_frac[i]);
-            print_record(contig, p + 1, txt, prefix, &isite[i], &ind_planes, (size_t)i, S);
-            free(txt);
-        }
-    }
-    fprintf(stderr, "%d reads of %d samples, %d overlapping pairs, %llu pileup entries in %d columns\n",
-            P.n, S, np, (unsigned long long)tile.n_reads, n_sites);
-    if (gv_n) { bcfgpu_free(ctx, d_site); bcfgpu_free(ctx, d_pl); bcfgpu_free(ctx, d_dp4); }
+    pending_flush();
+    if (ctx) { uint32_t nw = 0; CHECK(bcfgpu_truncated_cells(ctx, &nw)); n_wide_cells += nw; }
+    if (n_wide_cells) fprintf(stderr, "[bcfgpu_sam] note: %llu (site, sample) cells held more than 255 usable reads: their DP, AD, QS, I16 count every read, as bcftools' do; "
+                                      "their PLs come from the first 255 reads where bcftools' errmod_cal draws 255 at random\n", n_wide_cells);
+    fprintf(stderr, "%llu reads of %d samples, %llu overlapping pairs, %llu pileup entries in %llu columns (%d tiles of <= %d)\n",
+            n_reads_tot, S, tot_pairs, tot_entries, n_cols_tot, n_tiles, tile_cols);
     if (vio_close(fout)) DIE("%s\n", vio_error());
-    bcfgpu_destroy(ctx);
+    if (ctx) bcfgpu_destroy(ctx);
+    if (cap_ctx) bcfgpu_destroy(cap_ctx);
+    bcfgpu_depth_cap_free(dcap);
     return 0;
+usage:
+    fprintf(stderr, "usage: bcfgpu_sam [-a TAG,..] [--gvcf INT,..] [-O v|z|u|b] [-o out] [-d INT] [-s LIST | -S FILE] [-G FILE] [--ignore-RG]\n"
+                    "                  [-B | -E] [-A] [-q INT] [-Q INT] [-C INT] [--ff INT] [--rf INT] [-I] [-o INT] [-e INT] [-h INT] [-m INT] [-F FLOAT] [-p] [-L INT]\n"
+                    "                  [--tile COLUMNS] [--gpus N]\n"
+                    "                  -f ref.fa [-r CHR[:BEG[-END]],...] file.sam|file.bam [...]      (as `bcftools mpileup`)\n"
+                    "              or  ref.fa contig beg end file.sam|file.bam [...]                    (beg, end 1-based inclusive)\n");
+    return 2;
 }

@@ -294,6 +294,57 @@ def test_c_sam_driver_region_shards_match_the_whole_contig(golden_dir, gpus):
     assert sum(1 for ln in out.splitlines() if not ln.startswith("#")) == 4002
 
 
+TILE_CASES = {
+    # golden: (options, reference, regions, input files): mpileup's own spelling, -f REF [-r REGIONS] files (mpileup.c:952-1003)
+    "mpileup.11.out": (["-s", "^HG99999"], "mpileup.ref.fa", "17:1-4200", ["mpileup.3.sam", "mpileup.4.sam"]),   # SNP and indel records over a contig
+    "mpileup.2.out": (["-a", "DP,DV"], "mpileup.ref.fa", "17:100-600", ["mpileup.1.sam", "mpileup.2.sam", "mpileup.3.sam"]),
+    "mpileup.6.out": (["-a", "DP,DV", "--gvcf", "0,2,5"], "mpileup.ref.fa", "17:100-600", ["mpileup.1.sam", "mpileup.2.sam", "mpileup.3.sam"]),
+    "indel-AD.1.out": (["-a", "AD"], "indel-AD.1.fa", None, ["indel-AD.1.sam"]),                                 # no -r: every sequence of the file (test.pl:658)
+}
+
+
+def _tile_cmd(G, goldf, extra, regions="same"):
+    opts, ref, reg, files = TILE_CASES[goldf]
+    if regions != "same":
+        reg = regions
+    return [SAM_EXE] + extra + opts + ["-f", os.path.join(G, ref)] + (["-r", reg] if reg else []) + [os.path.join(G, f) for f in files]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile", [64, 512])
+@pytest.mark.parametrize("goldf", sorted(TILE_CASES))
+def test_c_sam_driver_streams_a_region_in_tiles(golden_dir, goldf, tile):
+    """`bcfgpu_sam --tile N`: the region cut into tiles of N columns, the files read in step with the tiles, the depth cap's
+    buffer and the open gVCF block carried from tile to tile, indel candidates next to a tile's edge realigned from the reads
+    that cover them: the reference's goldens whole-file, as VCF and through BCF, whatever the tile size (mpileup_reg() walks a
+    region column by column, mpileup.c:327-367; gvcf_write keeps a block over any distance, gvcf.c:88-226)."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    whole_file_checks(_tile_cmd(G, goldf, ["--tile", str(tile)]), os.path.join(G, goldf))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("goldf,regions", [("mpileup.2.out", "17:100-300,17:301-302,17:303-600"), ("mpileup.6.out", "17:100-257,17:258-600"),
+                                           ("mpileup.11.out", "17:1-1000,17:1001-4200")])
+def test_c_sam_driver_runs_several_regions(golden_dir, goldf, regions):
+    """`-r REG,REG,...` (mpileup.c:652-683): the regions one after the other, each with its own pass over the files; adjacent
+    regions give the records of the whole stretch, a gVCF block going on across the seam as the reference's gvcf_write would
+    carry it (the same sequence, the next position, the same depth range)."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    whole_file_checks(_tile_cmd(G, goldf, ["--tile", "128"], regions), os.path.join(G, goldf))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_c_sam_driver_region_shards_join_gvcf_blocks(golden_dir, gpus):
+    """`--gpus N --gvcf`: the block a shard ends with and the block the next one starts with are joined by the process that
+    writes the shards out, by gvcf_write's rule: test/mpileup/mpileup.6.out whole-file from 2 and 3 shards."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    whole_file_checks(_tile_cmd(G, "mpileup.6.out", ["--gpus", str(gpus)]), os.path.join(G, "mpileup.6.out"))
+
+
 @pytest.mark.gpu
 def test_c_sam_driver_reads_bam_and_counts_soft_clips(golden_dir):
     """BAM input (BGZF + BAM records parsed in C) and -a INFO/SCR,FMT/SCR: the whole of test/mpileup/mpileup-SCR.out (test.pl:659)."""
