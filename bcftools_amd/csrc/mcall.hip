@@ -486,7 +486,50 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     }
 
     // ---- per group: mcall_find_best_alleles ----
+    // BATCH (the matrix-core scan with sample groups): what a group costs beside its scan -- the enumeration of its subsets, the
+    // logarithms of its row products, the maximum / log-sum-exp over its subsets -- is done for several groups at once, CPG
+    // lanes a group (a 64-lane wavefront holds GB = 64 / CPG groups), and the coefficient matrix of a group is formed in
+    // registers from the subset list instead of being staged through LDS: no workgroup barrier inside a batch but the two
+    // around its last step.  (One group after the other, each with its own set-up and reductions, was 1 450 of a site's
+    // instructions per group: profiles/r4_mcall_grp_probe.txt.)
+    constexpr bool BATCH = FAST && GRP;
+    const int CPG = ngrp == 1 ? 64 : (NSUB > 15 ? 32 : 16), GB = 64 / CPG;
+    __shared__ uint32_t s_sid[BATCH ? 64 : 1];            // [GB][CPG] a group's subsets: ia | ib << 8 | ic << 16 (0xff: absent)
+    __shared__ int s_nsub[BATCH ? 4 : 1], s_set[BATCH ? 4 : 1], s_rede2[BATCH ? 64 : 1], s_dipe[BATCH ? 4 : 1], s_rals[BATCH ? 4 : 1];
+    __shared__ double s_red2[BATCH ? 64 : 1], s_dipm[BATCH ? 4 : 1], s_rmax[BATCH ? 4 : 1], s_rsum[BATCH ? 4 : 1], s_rref[BATCH ? 4 : 1], s_rqual[BATCH ? 4 : 1];
     for (int g = 0; g < ngrp; ++g) {
+        if constexpr (BATCH) {
+            if (g % GB == 0) {
+                // the subsets of the batch's groups: lane (group, candidate of the canonical enumeration), compacted per group
+                __syncthreads();
+                const int gl = tid / CPG, c = tid % CPG, gg = g + gl;
+                const float *qf = s_gq + (gg < ngrp ? gg : ngrp - 1) * 5;
+                const int npair = nals > 1 ? nals * (nals - 1) / 2 : 0;
+                const int ntrip = nals > 2 ? nals * (nals - 1) * (nals - 2) / 6 : 0;
+                int ia = 0xff, ib = 0xff, ic = 0xff;
+                bool valid = false;
+                if (c < nals) { ia = c; valid = true; }
+                else if (c < nals + npair) {
+                    const int cc = c - nals;
+                    ia = 1; while ((ia + 1) * ia / 2 <= cc) ia++;
+                    ib = cc - ia * (ia - 1) / 2;
+                    valid = qf[ia] != 0 && qf[ib] != 0;
+                } else if (c < nals + npair + ntrip) {
+                    int cc = c - nals - npair;
+                    ia = 2; while ((ia + 1) * ia * (ia - 1) / 6 <= cc) ia++;
+                    cc -= ia * (ia - 1) * (ia - 2) / 6;
+                    ib = 1; while ((ib + 1) * ib / 2 <= cc) ib++;
+                    ic = cc - ib * (ib - 1) / 2;
+                    valid = qf[ia] != 0 && qf[ib] != 0 && qf[ic] != 0;
+                }
+                valid = valid && gg < ngrp;
+                const unsigned long long bal = __ballot(valid);
+                const unsigned long long seg = CPG == 64 ? bal : (bal >> (gl * CPG)) & ((1ull << CPG) - 1);
+                if (valid) s_sid[gl * CPG + __popcll(seg & ((1ull << c) - 1))] = (uint32_t)ia | (uint32_t)ib << 8 | (uint32_t)ic << 16;
+                if (c == 0) s_nsub[gl] = __popcll(seg);
+                __syncthreads();
+            }
+        } else {
         __syncthreads();
         if (tid < 5) sh.qsum[tid] = s_gq[g * 5 + tid];
         __syncthreads();
@@ -536,13 +579,45 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             if (tid == 0) sh.nsub = __popcll(bal);
         }
         __syncthreads();
-        const int nsub = sh.nsub;
+        }
+        const int nsub = BATCH ? s_nsub[g % GB] : sh.nsub;
         int setbits = 0;
         if constexpr (FAST) {
             // ---- subset scan on the matrix cores ----
             // Rows = subsets (+ an all-ones row for the samples' normalisation sums), columns = samples, k = genotypes.
             // Haploid samples use a second coefficient matrix (f_a P(aa) + f_b P(bb) [+ f_c P(cc)], mcall.c:643,688);
             // samples of other groups, of ploidy 0 (pairs/triples only) or without data contribute nothing.
+            const int col = tid & 15, kq = tid >> 4;
+            double a[TILES][4], ah[HAP ? TILES : 1][4];
+            if constexpr (BATCH) {
+                // the lane's elements of the coefficient matrices, rows col (+ 16 t), genotypes 4 kk + kq, straight from the subset
+                // list: genotype k = (x <= y) has f_x f_y (twice that when x != y) if both alleles are in the subset; the
+                // frequencies inside the subset are float quotients, widened (mcall.c:629-630, 671-673); the haploid matrix has
+                // f_x on the homozygous genotypes (mcall.c:643, 688); row nsub is the all-ones row of the normalisation sums
+                const float *qf = s_gq + g * 5;
+                #pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    const int row = t * 16 + col;
+                    const uint32_t sid = row < nsub ? s_sid[(g % GB) * CPG + row] : 0xffffffu;
+                    const int ia = (int)(sid & 0xff), ib = (int)((sid >> 8) & 0xff), ic = (int)((sid >> 16) & 0xff);
+                    double fa = 1.0, fb = 0.0, fc = 0.0;
+                    if (row < nsub && ib != 0xff) {
+                        if (ic == 0xff) { const float den = qf[ia] + qf[ib]; fa = (double)(qf[ia] / den); fb = (double)(qf[ib] / den); }
+                        else { const float den = qf[ia] + qf[ib] + qf[ic]; fa = (double)(qf[ia] / den); fb = (double)(qf[ib] / den); fc = (double)(qf[ic] / den); }
+                    }
+                    #pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int k = 4 * kk + kq;
+                        const int y = (int)((0x5444443333222110ull >> (4 * k)) & 15), x = k - y * (y + 1) / 2;
+                        const double fx = x == ia ? fa : x == ib ? fb : x == ic ? fc : 0.0, fy = y == ia ? fa : y == ib ? fb : y == ic ? fc : 0.0;
+                        double av = 0.0, hv = 0.0;
+                        if (row < nsub) { av = x == y ? fx * fx : 2 * fy * fx; hv = x == y ? fx : 0.0; }
+                        else if (row == nsub) av = k < ngts ? 1.0 : 0.0;
+                        a[t][kk] = av;
+                        if (HAP) ah[t][kk] = hv;
+                    }
+                }
+            } else {
             double *s_coef = reinterpret_cast<double*>(s_union);            // [TILES*16 rows][16 genotypes]
             double *s_coefh = s_coef + TILES * 256;                         // HAP: the haploid rows
             for (int i = tid; i < TILES * 256 * (HAP ? 2 : 1); i += WGS) s_coef[i] = 0.0;
@@ -564,8 +639,6 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             }
             if (tid < ngts) s_coef[nsub * 16 + tid] = 1.0;                  // the sum row
             __syncthreads();
-            const int col = tid & 15, kq = tid >> 4;
-            double a[TILES][4], ah[HAP ? TILES : 1][4];
             #pragma unroll
             for (int t = 0; t < TILES; ++t)
                 #pragma unroll
@@ -573,6 +646,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                     a[t][kk] = s_coef[(t * 16 + col) * 16 + 4 * kk + kq];
                     if (HAP) ah[t][kk] = s_coefh[(t * 16 + col) * 16 + 4 * kk + kq];
                 }
+            }
             // this lane accumulates rows kq + 4r (+16t) over the sample columns col, col+16, ...
             double man[TILES][4]; int ex[TILES][4];
             #pragma unroll
@@ -698,7 +772,8 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                     }
                     const int row = t * 16 + kq + 4 * r;
                     if (col == 0 && row <= nsub) {
-                        sh.red[row] = m; sh.rede[row] = e;          // log taken below, one row per lane
+                        if constexpr (BATCH) { s_red2[(g % GB) * CPG + row] = m; s_rede2[(g % GB) * CPG + row] = e; }
+                        else { sh.red[row] = m; sh.rede[row] = e; }  // log taken below, one row per lane
                         if (f) rowbits |= 1 << row;
                     }
                 }
@@ -710,12 +785,17 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                     e += __shfl_xor(e, o) + frexp_exp(mm);
                     m = frexp_mant(mm);
                 }
-                if (col == 0 && kq == (nsub & 3)) { sh.red[31] = m; sh.rede[31] = e; }      // (at most 26 rows are in use)
+                if (col == 0 && kq == (nsub & 3)) {
+                    if constexpr (BATCH) { s_dipm[g % GB] = m; s_dipe[g % GB] = e; }
+                    else { sh.red[31] = m; sh.rede[31] = e; }      // (at most 26 rows are in use)
+                }
             }
+            if constexpr (!BATCH) {
             __syncthreads();
             if (tid <= nsub || (HAP && tid == 31)) sh.red[tid] = log(sh.red[tid]) + (double)sh.rede[tid] * 0.693147180559945309417232121458;
             __syncthreads();
             if (HAP && tid == 0) sh.red_dip = sh.red[31];
+            }
             setbits = rowbits;
         } else {
         for (int t = 0; t < nsub; ++t) { s_man[t * WGS + tid] = 1.0; s_exp[t * WGS + tid] = 0; }
@@ -773,6 +853,67 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
         }
         }
         setbits = wor(setbits);
+        if constexpr (BATCH) {
+            if (tid == 0) s_set[g % GB] = setbits;
+            if (g % GB != GB - 1 && g != ngrp - 1) continue;             // the batch goes on: its groups are finished together
+            // ---- the batch's groups side by side, CPG lanes each: logarithms of the row products, UPDATE_MAX_LKs over the
+            // visited subsets (mcall.c:582-585, 600-698; the first maximum in visiting order wins), one log-sum-exp for lk_sum ----
+            __syncthreads();
+            const int g0 = g - g % GB, gl = tid / CPG, c = tid % CPG;
+            const bool live = g0 + gl <= g;
+            const int ns = live ? s_nsub[gl] : 0;
+            const double LN2 = 0.693147180559945309417232121458;
+            double lg = 0.0, dip = 0.0;
+            if (live && c <= ns) lg = log(s_red2[gl * CPG + c]) + (double)s_rede2[gl * CPG + c] * LN2;
+            if (HAP && live) dip = log(s_dipm[gl]) + (double)s_dipe[gl] * LN2;
+            const double rsum = __shfl(lg, gl * CPG + ns);               // the row of the normalisation sums
+            const int set = live ? s_set[gl] : 0;
+            const double theta = P.theta;
+            double lk_tot = -HUGE_VAL, lk_add = -HUGE_VAL, v = 0.0;
+            int als = 0;
+            if (live && c < ns) {
+                const uint32_t sid = s_sid[gl * CPG + c];
+                const int ia = (int)(sid & 0xff), ib = (int)((sid >> 8) & 0xff), ic = (int)((sid >> 16) & 0xff);
+                // divide out the product of the normalisation sums of the samples that contributed to this row
+                v = lg - ((HAP && ib != 0xff) ? dip : rsum);
+                als = 1 << ia;
+                if (ia != 0) v += theta;
+                if (ib != 0xff) { als |= 1 << ib; if (ib != 0) v += theta; }
+                if (ic != 0xff) { als |= 1 << ic; if (ic != 0) v += theta; }
+                if ((set >> c) & 1) { lk_tot = v; if (als != 1) lk_add = v; }
+            }
+            const double refc = __shfl(v, gl * CPG);                     // subset 0 is the REF-only one
+            double m = lk_tot; int mi = c;
+            double ma = lk_add;
+            for (int o = CPG >> 1; o > 0; o >>= 1) {
+                const double om = __shfl_xor(m, o); const int oi = __shfl_xor(mi, o);
+                if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+                const double oa = __shfl_xor(ma, o);
+                ma = oa > ma ? oa : ma;
+            }
+            int max_als_b = __shfl(als, gl * CPG + mi);
+            if (m == -HUGE_VAL) max_als_b = 0;
+            double e = lk_add != -HUGE_VAL ? exp(lk_add - ma) : 0.0;
+            for (int o = CPG >> 1; o > 0; o >>= 1) e += __shfl_xor(e, o);
+            const double lk_sum_b = ma != -HUGE_VAL ? ma + log(e) : -HUGE_VAL;
+            if (live && c == 0) {
+                s_rmax[gl] = m; s_rsum[gl] = lk_sum_b; s_rref[gl] = refc; s_rals[gl] = max_als_b;
+                s_rqual[gl] = m != -HUGE_VAL ? -4.343 * (refc - lse2(lk_sum_b, refc)) : 0.0;
+            }
+            __syncthreads();
+            if (tid == 0) {                                              // in group order, as the reference walks them (mcall.c:1546-1560)
+                for (int b = 0; b <= g - g0; ++b) {
+                    const int max_als2 = s_rals[b];
+                    int n = 0;
+                    for (int i = 0; i < nals; i++) if (max_als2 & 1 << i) n++;
+                    sh.als_new |= max_als2;
+                    if (s_rmax[b] != -HUGE_VAL && sh.max_qual < s_rqual[b]) { sh.max_qual = s_rqual[b]; sh.lk_sum = s_rsum[b]; sh.ref_lk = s_rref[b]; }
+                    grp_als_tab[(g0 + b) * 2] = max_als2;
+                    grp_als_tab[(g0 + b) * 2 + 1] = n;
+                }
+            }
+            continue;
+        }
         if (tid == 0) sh.redset = setbits;
         __syncthreads();
         // UPDATE_MAX_LKs over the visited subsets (mcall.c:582-585, 600-698), lane t = subset t: the first maximum in

@@ -45,8 +45,10 @@ def parse():
     ap.add_argument("--haploid-frac", type=float, default=0.0, help="snp mode: fraction of haploid samples (ploidy array; general caller path)")
     ap.add_argument("--extras", type=int, default=1, help="snp mode at N=1: also measure the BASELINE configs[4] shape (sample groups + ploidy array) and "
                                                           "the indel stage (configs[2] shape) in child processes and embed their results under \"extra\" (0: skip)")
+    ap.add_argument("--indel-read-rate", type=float, default=0.005, help="wgs mode: fraction of reads that carry a noise indel (SURVEY 8d: 0.5 %%)")
+    ap.add_argument("--true-indel-rate", type=float, default=0.002, help="wgs mode: true indel sites per column")
     ap.add_argument("--indel-callers", type=int, default=1, help="indel mode: also time the host-pointer form of the stage on one 32-column batch (0: skip)")
-    ap.add_argument("--mode", choices=["snp", "indel", "baq", "pileup", "gvcf", "mixed"], default="snp",
+    ap.add_argument("--mode", choices=["snp", "indel", "baq", "pileup", "gvcf", "mixed", "wgs"], default="snp",
                     help="snp: the headline pipeline (default).  indel: bcf_call_gap_prep on synthetic indel-candidate columns "
                          "(BASELINE configs[2] shape, 500 samples), reports DP cells/s of the realignment kernel.  "
                          "baq: bcfgpu_baq (sam_prob_realn) over the reads of the same synthetic columns.  "
@@ -256,6 +258,227 @@ def main_mixed(a):
         out["cpu_baseline"] = {"value": 1.0 / (t_snp + 0.1 * t_ind), "unit": "sites/s", "cores": 1, "kind": "port",
                                "sample": "oracle on one host core: mpileup+mcall on the first %d columns (%.2f ms each), orc_gap_prep on the first %d "
                                          "candidate columns (%.1f ms each); per pileup column = SNP cost + a tenth of the indel cost" % (ns, t_snp * 1e3, k, t_ind * 1e3)}
+    print(json.dumps(out), flush=True)
+    ctx.close()
+
+
+def main_wgs(a):
+    """BASELINE configs[3] end to end on one GPU, scaled to one region: 1000 samples x 30x of READS (not a ready-made tile) over
+    --sites columns, with sequencing / alignment indel noise on --indel-read-rate of the reads (0.5 %) and true indel
+    sites every 1 / --true-indel-rate columns.  The read pool is resident in HBM (bcfgpu_pool_upload) and BAQ'd (mpileup's
+    default), the columns are built there (bcfgpu_pool_pileup): `front_ms` -- then every timed step is what `mpileup | call -m`
+    does per column: the SNP path over all columns (bcfgpu_pipeline + compaction of the variant records), candidate typing on
+    every column where some read carries an indel (mpileup.c:354, bam2bcf_indel.c:106-188), realignment of all reads of the
+    columns that pass -m / -F (bcfgpu_gap_prep_tile) and the indel pass (bcfgpu_mpileup on the tile it returns).
+    value = columns / wall time of a step.  cpu_baseline: the oracle on the first columns / candidate columns of the same
+    region, one host core; the candidates' p->aux is compared with the device's on the way."""
+    import torch
+    from bcftools_amd import abi, engine, host
+    from bcftools_amd.lib import check
+    from tests.helpers import indeldrv, mplpdrv, orc
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    S = a.samples
+    n_sites = 1024 if a.sites is None else a.sites
+    L, beg = 100, 300
+    end = beg + n_sites
+    rng = np.random.default_rng(a.seed)
+    per = int((n_sites + L) * a.depth / L)
+    n = per * S
+    pos = np.sort(rng.integers(beg - L + 1, end, size=(S, per)), axis=1).astype(np.int32).ravel()
+    smpl = np.repeat(np.arange(S, dtype=np.int32), per)
+    ref_codes = rng.integers(0, 4, end + 3 * L).astype(np.uint8)
+    refseq = "".join("ACGT"[i] for i in ref_codes)
+    # ---- indels: noise on a fraction of the reads (length 1..3, weights 1/len, insertion or deletion, anywhere 10 bases off the
+    # ends), and true indel sites (allele frequency 0.1, genotypes HWE) carried by the reads that span them ----
+    lens = np.array([1, 2, 3]); w = 1.0 / lens
+    ilen = np.zeros(n, np.int64)                                   # > 0 insertion, < 0 deletion
+    ioff = np.zeros(n, np.int64)                                   # query bases before the indel
+    noisy = rng.random(n) < a.indel_read_rate
+    ilen[noisy] = lens[rng.choice(3, int(noisy.sum()), p=w / w.sum())] * rng.choice([-1, 1], int(noisy.sum()))
+    ioff[noisy] = rng.integers(10, L - 10, int(noisy.sum()))
+    n_true = int(n_sites * a.true_indel_rate + 0.5)
+    if n_true:
+        tsite = np.sort(rng.choice(np.arange(beg + 20, end - 20), n_true, replace=False)).astype(np.int64)
+        tlen = lens[rng.choice(3, n_true, p=w / w.sum())] * rng.choice([-1, 1], n_true)
+        geno = rng.binomial(2, 0.1, (S, n_true))
+        k = np.searchsorted(tsite, pos.astype(np.int64) + 10)
+        kk = np.minimum(k, n_true - 1)
+        span = (k < n_true) & (tsite[kk] < pos.astype(np.int64) + L - 10)
+        carry = span & (rng.random(n) < geno[smpl, kk] * 0.5)
+        ilen[carry] = tlen[kk[carry]]
+        ioff[carry] = tsite[kk[carry]] - pos[carry] + 1             # the indel follows reference position tsite
+    al = np.abs(ilen)
+    ins = np.where(ilen > 0, al, 0)
+    c3 = np.stack([ioff << 4, (al << 4) | np.where(ilen > 0, 1, 2), (L - ioff - ins) << 4], axis=1)
+    ncig = np.where(ilen != 0, 3, 1).astype(np.int32)
+    c3[ilen == 0, 0] = L << 4
+    cig = c3[np.arange(3)[None, :] < ncig[:, None]].astype(np.uint32)
+    cig_off = np.concatenate([[0], np.cumsum(ncig)[:-1]]).astype(np.int32)
+    seq = np.empty(n * L, np.uint8)
+    qual = rng.choice(np.array([11, 25, 37, 40], np.uint8), n * L, p=[0.07, 0.08, 0.35, 0.5])
+    j = np.arange(L, dtype=np.int64)[None, :]
+    for r0 in range(0, n, 1 << 16):
+        r1 = min(n, r0 + (1 << 16))
+        il, io = ilen[r0:r1, None], ioff[r0:r1, None]
+        after = j >= io
+        shift = np.where(il < 0, -il, -np.minimum(il, np.maximum(j - io, 0)))
+        idx = np.maximum(pos[r0:r1, None].astype(np.int64), 0) + j + np.where(after, shift, 0)
+        b = ref_codes[idx]
+        is_ins = after & (il > 0) & (j - io < il)
+        b = np.where(is_ins, rng.integers(0, 4, b.shape), b)
+        err = rng.random(b.shape) < 0.003
+        b = np.where(err, (b + rng.integers(1, 4, b.shape)) & 3, b)
+        seq[r0 * L:r1 * L] = (1 << b).astype(np.uint8).ravel()
+    mapq = np.where(rng.random(n) < 0.92, 60, rng.integers(0, 60, n)).astype(np.uint8)
+    arrs = dict(r_pos=pos, r_lq=np.full(n, L, np.int32), r_flag=(rng.integers(0, 2, n) * 16).astype(np.int32), r_ncig=ncig, r_cig_off=cig_off,
+                r_seq_off=(np.arange(n, dtype=np.int64) * L).astype(np.int32), cig=cig, seq16=seq, qual=qual, zq=np.zeros(1, np.uint8),
+                r_has_zq=np.zeros(n, np.uint8))
+    rd = abi.Reads()
+    rd.n_reads = n
+    for k_, v in arrs.items():
+        setattr(rd, k_, v.ctypes.data)
+    ref_b = refseq.encode()
+    # ---- the front of the chain, once: pool -> HBM, BAQ, the columns ----
+    ctx0 = engine.Context(abi.default_cfg(S, max_sites=1, max_reads=64))
+    t = abi.Tile()
+    check(ctx0.L.bcfgpu_pileup(ctx0.h, C.byref(rd), mapq.ctypes.data, smpl.ctypes.data, beg, end, ref_b, len(refseq), C.byref(t), None, None))
+    entries = int(t.n_reads)
+    ctx0.close()
+    cfg = abi.default_cfg(S, max_sites=n_sites, max_reads=entries + 64)
+    ctx = engine.Context(cfg)
+    Lb = ctx.L
+    tile = abi.Tile()
+    col_n, col_indel = np.zeros(n_sites, np.int32), np.zeros(n_sites, np.uint8)
+
+    def front():
+        t0 = time.perf_counter()
+        check(Lb.bcfgpu_pool_upload(ctx.h, C.byref(rd), None, mapq.ctypes.data))
+        ctx.sync(); t1 = time.perf_counter()
+        if a.baq:
+            check(Lb.bcfgpu_pool_baq(ctx.h, ref_b, len(refseq), 3, None))
+        ctx.sync(); t2 = time.perf_counter()
+        check(Lb.bcfgpu_pool_pileup(ctx.h, smpl.ctypes.data, None, beg, end, ref_b, len(refseq), C.byref(tile), col_n.ctypes.data, col_indel.ctypes.data))
+        ctx.sync(); t3 = time.perf_counter()
+        return (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3
+    front()
+    f_up, f_baq, f_plp = front()
+    cand = np.ascontiguousarray(np.nonzero((col_indel != 0) & (col_n < 250 * S))[0], dtype=np.int32)      # mpileup.c:354, -L 250
+    nc = len(cand)
+    mo, mbufs, _ = ctx.alloc_mplp_out(n_sites, ctx.flagged_planes())
+    co, cbufs, _ = ctx.alloc_call_out(n_sites, abi.MAX_PL)
+    imo, imb, ires = ctx.alloc_mplp_out(max(nc, 1), ctx.flagged_planes())
+    rec_cap = 256 << 20
+    recbuf = torch.empty(rec_cap, dtype=torch.uint8, device="cuda")
+    counts = torch.zeros(4, dtype=torch.int64, device="cuda")
+    par = abi.IndelIn()
+    par.ref = ref_b
+    for k_, v in indeldrv.DEFAULTS.items():
+        setattr(par, k_, v)
+    CAP = indeldrv.CAP
+    gout = dict(ret=np.zeros(max(nc, 1), np.int32), indel_types=np.zeros((max(nc, 1), 4), np.int32), inscns=np.zeros((max(nc, 1), 4 * CAP), np.int8),
+                maxins=np.zeros(max(nc, 1), np.int32), indelreg=np.zeros(max(nc, 1), np.int32), max_support=np.zeros(max(nc, 1), np.int32),
+                max_frac=np.zeros(max(nc, 1), np.float32))
+    oo = abi.IndelOut()
+    oo.ret, oo.indel_types, oo.inscns = gout["ret"].ctypes.data, gout["indel_types"].ctypes.data, gout["inscns"].ctypes.data
+    oo.maxins, oo.indelreg, oo.max_support, oo.max_frac = (gout["maxins"].ctypes.data, gout["indelreg"].ctypes.data, gout["max_support"].ctypes.data,
+                                                           gout["max_frac"].ctypes.data)
+    itile = abi.Tile()
+    st = abi.GapStats()
+    split = dict(snp=0.0, gap=0.0, ipass=0.0)
+
+    def step(timed=False):
+        t0 = time.perf_counter()
+        check(Lb.bcfgpu_pipeline(ctx.h, C.byref(tile), None, None, C.byref(mo), C.byref(co)))
+        check(Lb.bcfgpu_compact_calls_async(ctx.h, n_sites, 0, mo.site, C.byref(co), abi.MAX_PL, 2, recbuf.data_ptr(), rec_cap, counts.data_ptr()))
+        if timed:
+            ctx.sync()
+        t1 = time.perf_counter()
+        if nc:
+            check(Lb.bcfgpu_gap_prep_tile(ctx.h, nc, cand.ctypes.data, None, C.byref(par), C.byref(oo), CAP, C.byref(itile)))
+            if timed:
+                ctx.sync()
+            t2 = time.perf_counter()
+            check(Lb.bcfgpu_mpileup(ctx.h, C.byref(itile), C.byref(imo)))
+        else:
+            t2 = t1
+        if timed:
+            ctx.sync()
+            split["snp"] += t1 - t0; split["gap"] += t2 - t1; split["ipass"] += time.perf_counter() - t2
+    for _ in range(max(1, a.warmup)):
+        step()
+    ctx.sync()
+    steps = max(1, a.steps)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    per_step = (time.perf_counter() - t0) / steps
+    for _ in range(2):
+        step(True)
+    check(Lb.bcfgpu_gap_prep_stats(ctx.h, C.byref(st)))
+    nb_, nr_ = C.c_uint64(), C.c_uint32()
+    check(Lb.bcfgpu_compact_counts(ctx.h, counts.data_ptr(), C.byref(nb_), C.byref(nr_)))
+    n_live = int((gout["ret"][:nc] == 0).sum()) if nc else 0
+    if nc:
+        ctx._download(imb, ires)
+    n_irec = int(((ires.site["ret"][:nc] == 0) & (gout["ret"][:nc] == 0)).sum()) if nc else 0
+    out = {"metric": "pileup columns/sec with their indel records (mpileup | call -m), %d samples x %.0fx of reads with indel noise" % (S, a.depth),
+           "value": n_sites / per_step, "unit": "sites/s", "n_gpus": 1, "steps": steps, "ms_per_step": per_step * 1e3, "higher_is_better": True,
+           "dtype": "u8/i32 + f64 likelihood sums; f64 pair-HMM", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[3] shape on one GPU, one region: SNP path over every column + candidate typing on every column with an "
+                                  "indel read + realignment of the columns that pass -m 1 -F 0.002 + the indel pass; read pool and columns resident in HBM",
+                      "samples": S, "depth": a.depth, "columns": n_sites, "reads": n, "read_length": L, "pileup_entries": entries,
+                      "indel_read_rate": a.indel_read_rate, "true_indel_sites": n_true, "baq": bool(a.baq),
+                      "candidate_columns": nc, "realigned_columns": n_live, "indel_records": n_irec, "variant_records": int(nr_.value),
+                      "realignment_jobs": int(st.n_jobs), "realignment_passes": int(st.n_passes)},
+           "split_ms": {"snp_pipeline_and_compaction": split["snp"] / 2 * 1e3, "gap_prep_tile": split["gap"] / 2 * 1e3, "indel_pass": split["ipass"] / 2 * 1e3,
+                        "realignment_kernels": float(st.kernel_ms)},
+           "front_ms": {"pool_upload_pcie": f_up, "pool_baq": f_baq, "pool_pileup": f_plp,
+                        "note": "once per region, before the timed steps (the steps start from columns resident in HBM, like the headline)"},
+           "with_front": {"sites_per_s": n_sites / (per_step + (f_up + f_baq + f_plp) * 1e-3), "note": "columns / (step + upload + BAQ + pileup): a region from host reads to records"},
+           "note": "the indel path is the Amdahl term of a large cohort: with %d samples nearly every column has some read with an indel" % S}
+    if a.cpu_seconds > 0:
+        # ---- the oracle on one core: the SNP path on the first columns (their tile downloaded), bcf_call_gap_prep on the first candidates ----
+        ns = min(n_sites, 8)
+        off = np.zeros(ns * S + 1, np.uint32)
+        check(Lb.bcfgpu_memcpy_d2h(ctx.h, off.ctypes.data, tile.plp_off, off.nbytes))
+        nr_h = int(off[-1])
+        rdh, eph, r16 = np.zeros(nr_h, np.uint32), np.zeros(nr_h, np.uint8), np.zeros(ns, np.int8)
+        check(Lb.bcfgpu_memcpy_d2h(ctx.h, rdh.ctypes.data, tile.rd, rdh.nbytes)); check(Lb.bcfgpu_memcpy_d2h(ctx.h, eph.ctypes.data, tile.epos, eph.nbytes))
+        check(Lb.bcfgpu_memcpy_d2h(ctx.h, r16.ctypes.data, tile.ref16, r16.nbytes))
+        sub = host.HostTile(S, r16, off, rdh, eph)
+        orc.mpileup(cfg, sub)
+        c0 = time.perf_counter()
+        m = orc.mpileup(cfg, sub)
+        orc.mcall(cfg, host.CallInput(S, m.site["n_alleles"], np.maximum(m.site["unseen"], 0), m.pl.astype(np.int32), m.site["qsum"]))
+        t_snp = (time.perf_counter() - c0) / ns
+        t_ind, k = 0.0, 0
+        if nc:
+            # the pool as the device sees it after BAQ, and the candidates' pileup entries
+            q_h, z_h, mq_h = np.zeros(n * L, np.uint8), np.zeros(n * L, np.uint8), np.zeros(n, np.uint8)
+            check(Lb.bcfgpu_pool_download(ctx.h, q_h.ctypes.data, z_h.ctypes.data, mq_h.ctypes.data))
+            kmax = min(nc, 4)
+            cols = np.ascontiguousarray(cand[:kmax])
+            tot_e = int(col_n[cols].sum())
+            so = np.zeros(kmax * S + 1, np.int32); pr = np.zeros(tot_e, np.int32); pq = np.zeros(tot_e, np.int32); pi = np.zeros(tot_e, np.int32)
+            check(Lb.bcfgpu_pileup_entries(ctx.h, kmax, cols.ctypes.data, so.ctypes.data, pr.ctypes.data, pq.ctypes.data, pi.ctypes.data, tot_e))
+            has_zq = np.full(n, 1 if a.baq else 0, np.uint8)
+            b = dict(n_sites=kmax, n_smpl=S, ref=ref_b, pos=(cols + beg).astype(np.int32), smpl_off=so, p_read=pr, p_qpos=pq, p_indel=pi,
+                     reads=dict(arrs, n_reads=n, qual=q_h, zq=z_h, r_has_zq=has_zq))
+            c0 = time.perf_counter()
+            while k < kmax and (k < 1 or time.perf_counter() - c0 < a.cpu_seconds):
+                want = indeldrv.gap_prep_oracle_site(b, k)
+                assert (want is None) == (gout["ret"][k] != 0), "bcf_call_gap_prep: device and oracle disagree on candidate column %d" % k
+                if want is not None:
+                    assert np.array_equal(gout["indel_types"][k], want["indel_types"]), "indel types of candidate column %d" % k
+                k += 1
+            t_ind = (time.perf_counter() - c0) / k
+        frac = nc / n_sites
+        out["cpu_baseline"] = {"value": 1.0 / (t_snp + frac * t_ind), "unit": "sites/s", "cores": 1, "kind": "port",
+                               "sample": "oracle on one host core: mpileup+mcall on the first %d columns (%.1f ms each), orc_gap_prep on the first %d candidate "
+                                         "columns (%.0f ms each; results compared with the device's); per column = SNP cost + %.2f x the candidate cost"
+                                         % (ns, t_snp * 1e3, k, t_ind * 1e3, frac)}
     print(json.dumps(out), flush=True)
     ctx.close()
 
@@ -623,6 +846,8 @@ def main():
         return main_indel(a)
     if a.mode == "mixed":
         return main_mixed(a)
+    if a.mode == "wgs":
+        return main_wgs(a)
     if a.mode == "baq":
         return main_baq(a)
     if a.mode == "gvcf":
@@ -858,6 +1083,9 @@ def main():
                 res = [p.communicate()[0].split() for p in procs]
                 if all(len(r) == 2 for r in res):
                     tmax = max(float(r[1]) for r in res)
+                    # (scalar keys of cpu_baseline itself, so that a parser that keeps one level of it keeps them)
+                    out["cpu_baseline"]["all_cores_value"] = sum(int(r[0]) for r in res) / tmax
+                    out["cpu_baseline"]["all_cores_cores"] = ncore
                     out["cpu_baseline"]["all_cores"] = {"value": sum(int(r[0]) for r in res) / tmax, "unit": "sites/s",
                                                         "cores": ncore, "sample": "%d region shards of %d sites x %d passes, one "
                                                         "oracle process per core, %.1f s" % (ncore, per, reps, tmax)}
@@ -883,14 +1111,18 @@ def main():
             hfb = child(["--mode", "pileup", "--baq", "1", "--packed", "1", "--sites", "4096", "--steps", "4", "--cpu-seconds", "0", "--cpu-all-cores", "0",
                          "--extras", "0", "--seed", str(a.seed)])
             bq = child(["--mode", "baq", "--steps", "6", "--cpu-seconds", "5", "--cpu-all-cores", "0", "--extras", "0", "--seed", str(a.seed)])
+            wgs = child(["--mode", "wgs", "--steps", "3", "--warmup", "1", "--cpu-seconds", "6", "--cpu-all-cores", "0", "--extras", "0", "--baq", "1",
+                         "--samples", str(S), "--depth", str(a.depth), "--seed", str(a.seed)])
             out["extra"] = {
+                "configs3_mixed": {k: wgs.get(k) for k in ("metric", "value", "unit", "ms_per_step", "config", "split_ms", "front_ms", "with_front", "cpu_baseline", "note", "error") if k in wgs},
                 "configs2_mixed": {k: mix.get(k) for k in ("metric", "value", "unit", "ms_per_step", "config", "split_ms", "cpu_baseline", "error") if k in mix},
                 "host_fed_pileup": {k: hf.get(k) for k in ("metric", "value", "unit", "config", "whole_call_ms", "pcie", "host_fed_pipeline", "byte_per_base_form", "error") if k in hf},
                 "host_fed_chain_with_baq": {k: hfb.get(k) for k in ("config", "whole_call_ms", "pcie", "host_fed_pipeline", "error") if k in hfb},
                 "baq_stage": {k: bq.get(k) for k in ("metric", "value", "unit", "config", "whole_call_ms", "pool_form", "cpu_baseline", "error") if k in bq},
                 "configs4_shape": {k: c4.get(k) for k in ("value", "unit", "ms_per_step", "config", "roofline", "error") if k in c4},
                 "indel_stage": {k: ind.get(k) for k in ("metric", "value", "unit", "config", "kernel", "host_ms", "indel_pass", "host_pointer_form", "cpu_baseline", "error") if k in ind},
-                "note": "configs4_shape: the same tile through call -G (4 sample groups on FORMAT/AD) with a ploidy array (25 % haploid); "
+                "note": "configs3_mixed: --mode wgs, the honest end-to-end line of the headline shape -- 1000 samples x 30x of reads with 0.5 % indel noise: SNP path on every "
+                        "column + candidate typing + realignment + indel pass; configs4_shape: the same tile through call -G (4 sample groups on FORMAT/AD) with a ploidy array (25 % haploid); "
                         "indel_stage: bcf_call_gap_prep on 500-sample indel-candidate columns (BASELINE configs[2] shape), bcfgpu_gap_prep_tile on a read pool resident in HBM; "
                         "configs2_mixed: SNP path + indel path per step at the configs[2] mix (10 % indel sites); host_fed_pileup: --mode pileup, the read "
                         "pool crossing PCIe every region (DESIGN.md 5); host_fed_chain_with_baq: the same with BAQ on the pool in HBM before the pileup (what a user of "

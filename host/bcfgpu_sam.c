@@ -697,7 +697,8 @@ static int max_depth = 250, baq_flag = 3, min_baseQ = 13, cap_thres = 0, no_inde
 static int openQ = 40, extQ = 20, tandemQ = 100, min_support = 1, per_sample_flt = 0; static double min_frac = 0.002;   /* mpileup.c:937-950 */
 static int device = 0, tile_cols = 16384;
 
-typedef struct { char *contig; int beg, end; } region_t;                      /* 0-based [beg, end); end < 0: to the contig's end */
+typedef struct { char *contig; int beg, end, open; } region_t;                /* 0-based [beg, end); open: to wherever the reads end (no END given) */
+#define OPEN_END 0x3fffffff
 
 /* ---- the device context, re-created when a tile needs more room than the last one had ---- */
 static bcfgpu_ctx *ctx; static int ctx_S, ctx_sites; static uint64_t ctx_reads; static unsigned long long n_wide_cells;
@@ -1059,7 +1060,10 @@ static int run_shards(int n_gpus, int argc0, char **argv0, int first_file, const
         long at = 0; int nr = 0;
         for (int i = 0; i < n_reg; ++i) {
             const long lo = at > c0 ? at : c0, hi = at + (reg[i].end - reg[i].beg) < c1 ? at + (reg[i].end - reg[i].beg) : c1;
-            if (lo < hi) fprintf(m, "%s%s:%ld-%ld", nr++ ? "," : "", reg[i].contig, reg[i].beg + (lo - at) + 1, reg[i].beg + (hi - at));
+            if (lo < hi) {
+                if (reg[i].open && hi == at + (reg[i].end - reg[i].beg)) fprintf(m, "%s%s:%ld-", nr++ ? "," : "", reg[i].contig, reg[i].beg + (lo - at) + 1);
+                else fprintf(m, "%s%s:%ld-%ld", nr++ ? "," : "", reg[i].contig, reg[i].beg + (lo - at) + 1, reg[i].beg + (hi - at));
+            }
             at += reg[i].end - reg[i].beg;
         }
         fclose(m);
@@ -1252,15 +1256,15 @@ int main(int argc, char **argv)
     const int S = SM.nsmpl;
     if (!F || !S) DIE("no sample left to call\n");
     char **sample = SM.smpl;
-    /* the contigs' sequences (one at a time in memory), and the open ends of the regions */
+    /* the contigs' sequences (one at a time in memory).  A region without an END runs to wherever the reads end -- past the
+     * contig's last base if they do, as the reference's iterator does (reference base N there); for the shards it is cut at
+     * the contig's length and the last piece stays open */
     char *ref = NULL, *ref_name = NULL; int ref_len = 0;
-    for (int i = 0; i < n_reg; ++i) {
-        if (reg[i].end >= 0) continue;
-        int len = 0; char *sq = read_contig(ref_path, reg[i].contig, &len);
-        reg[i].end = len; free(sq);
-    }
-    if (n_gpus > 1 && shard < 0 && !list_only)
+    for (int i = 0; i < n_reg; ++i) if (reg[i].end < 0) { reg[i].open = 1; reg[i].end = OPEN_END; }
+    if (n_gpus > 1 && shard < 0 && !list_only) {
+        for (int i = 0; i < n_reg; ++i) if (reg[i].open) { int len = 0; char *sq = read_contig(ref_path, reg[i].contig, &len); reg[i].end = len > reg[i].beg ? len : reg[i].beg + 1; free(sq); }
         return run_shards(n_gpus, argc0, argv0, argc0 - n_in, ref_path, reg, n_reg, out_path, out_mode);
+    }
     if (shard > 0 && !list_only) { const int nd = bcfgpu_device_count(); device = nd > 0 ? shard % nd : 0; if (nd > 1) fprintf(stderr, "[bcfgpu_sam] shard %d on device %d of %d\n", shard, device, nd); }
     /* ---- the VCF header, in mpileup's order (mpileup.c:510-602) ---- */
     {
@@ -1317,7 +1321,7 @@ int main(int argc, char **argv)
     int *first = malloc((size_t)(F + 1) * sizeof *first);
     long long *n_in_smpl = calloc((size_t)S, sizeof *n_in_smpl); int *nf_smpl = calloc((size_t)S, sizeof *nf_smpl), *lastf_smpl = malloc((size_t)S * sizeof *lastf_smpl);
     for (int s = 0; s < S; ++s) lastf_smpl[s] = -1;
-    unsigned long long n_reads_tot = 0, n_cols_tot = 0; int n_tiles = 0;
+    unsigned long long n_reads_tot = 0, n_cols_tot = 0; int n_tiles = 0, max_span = 0;
     for (int g = 0; g < n_reg; ++g) {
         const char *contig = reg[g].contig;
         if (!ref_name || strcmp(ref_name, contig)) { free(ref); free(ref_name); ref = read_contig(ref_path, contig, &ref_len); ref_name = strdup(contig); }
@@ -1325,17 +1329,25 @@ int main(int argc, char **argv)
         if (reg_end <= reg_beg) continue;
         for (int f = 0; f < F; ++f) { reader_open(&rdr[f], kept_path[f]); for (int i = 0; i < win[f].n; ++i) lrec_free(win[f].r[i]); win[f].n = 0; }
         bcfgpu_depth_cap_reset(dcap);
-        for (int t0 = reg_beg; t0 < reg_end; t0 += tile_cols) {
+        for (int t0 = reg_beg; t0 < reg_end; ) {
             const int t1 = t0 + tile_cols < reg_end ? t0 + tile_cols : reg_end;
+            /* The tile's pool is the reads that overlap the tile widened by `margin` on both sides: the realignment of an indel
+             * candidate reads a read's bases and qualities up to INDEL_WINDOW_SIZE columns beyond the tile (bam2bcf_indel.c:38,
+             * 174-175), and those qualities carry the mate-overlap tweak of a mate that may lie wholly outside the tile -- so a
+             * read's mate has to be in the pool with it.  margin = the longest reference span seen so far + the window. */
+            int margin = max_span + 64, margin_read;
             /* stage 1: the reads that start before the tile's end come off the files, through -C (BAQ + sam_cap_mapq + the
              * deferred filters) and the depth cap, into the live window */
+            do {                                                             /* (again when a longer read widened the margin) */
+            margin_read = margin;
             for (int f = 0; f < F; ++f) {
                 lrec_t **b = NULL; int nb = 0, bcap = 0;
                 for (;;) {
                     reader_fetch(&rdr[f], contig, &sfile[f]);
                     lrec_t *x = rdr[f].pend;
-                    if (!x || x->pos >= t1) break;
+                    if (!x || x->pos >= t1 + margin) break;
                     rdr[f].pend = NULL;
+                    if (x->end - x->pos > max_span) max_span = x->end - x->pos;
                     if (nb == bcap) { bcap = bcap ? 2 * bcap : 256; b = grow(b, (size_t)bcap * sizeof *b); }
                     b[nb++] = x;
                 }
@@ -1366,22 +1378,33 @@ int main(int argc, char **argv)
                 }
                 free(keep); free(b);
             }
+            margin = max_span + 64;
+            } while (margin > margin_read);
             if (!list_only) {
                 /* stage 2: the tile's pool = the reads of the window that overlap the tile, file after file */
                 pool_clear(&P);
                 for (int f = 0; f < F; ++f) {
                     first[f] = P.n;
-                    for (int i = 0; i < win[f].n; ++i) { const lrec_t *x = win[f].r[i]; if (overlaps(x->pos, x->end, t0, t1)) pool_add_rec(&P, f, x); }
+                    for (int i = 0; i < win[f].n; ++i) { const lrec_t *x = win[f].r[i]; if (overlaps(x->pos, x->end, t0 - margin, t1 + margin)) pool_add_rec(&P, f, x); }
                 }
                 first[F] = P.n;
-                process_tile(&P, first, F, S, contig, ref, ref_len, t0, t1);
-                n_cols_tot += (unsigned long long)(t1 - t0); ++n_tiles;
+                if (P.n) { process_tile(&P, first, F, S, contig, ref, ref_len, t0, t1); ++n_tiles; }
+                else pending_flush();                                       /* columns without a read: a gap ends a gVCF block (gvcf.c:131) */
+                n_cols_tot += (unsigned long long)(t1 - t0);
             }
-            /* reads that end at or before the next tile's first column are through */
+            /* reads that end before the next tile's pool begins are through */
+            int left = 0, next_pos = OPEN_END, more = 0;
             for (int f = 0; f < F; ++f) {
                 int m = 0;
-                for (int i = 0; i < win[f].n; ++i) { lrec_t *x = win[f].r[i]; if ((x->end == x->pos ? x->pos + 1 : x->end) > t1) win[f].r[m++] = x; else lrec_free(x); }
-                win[f].n = m;
+                for (int i = 0; i < win[f].n; ++i) { lrec_t *x = win[f].r[i]; if ((x->end == x->pos ? x->pos + 1 : x->end) > t1 - margin) win[f].r[m++] = x; else lrec_free(x); }
+                win[f].n = m; left += m;
+                reader_fetch(&rdr[f], contig, &sfile[f]);
+                if (rdr[f].pend) { more = 1; if (rdr[f].pend->pos < next_pos) next_pos = rdr[f].pend->pos; }
+            }
+            t0 = t1;
+            if (!left) {
+                if (!more) break;                                           /* nothing left on this region: every file is through */
+                if (next_pos - margin > t0) t0 = next_pos - margin;         /* a stretch without reads: on to the next read */
             }
         }
         for (int f = 0; f < F; ++f) reader_close(&rdr[f]);
