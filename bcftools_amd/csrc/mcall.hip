@@ -304,7 +304,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
         float *frow = side_by_side ? P.grp_frac + (size_t)is * 5 * S4 : nullptr;
         fetch_ad(0);
         if (side_by_side) {
-            for (int base = 0; base < S; base += SB) {
+            for (int base = 0; base < (BCFGPU_ABL(P, 128) ? 0 : S); base += SB) {
                 int xc[5][4];
                 #pragma unroll
                 for (int k = 0; k < 5; ++k)
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             __syncthreads();                                             // (the fractions are this workgroup's own: a workgroup-scope fence)
             if (tid < ngrp * 5 && tid % 5 < nals) {
                 const int g = tid / 5, a = tid % 5;
-                const int first = P.grp_rng[3 * g], last = P.grp_rng[3 * g + 2] ? P.grp_rng[3 * g + 1] : first;
+                const int first = P.grp_rng[3 * g], last = (P.grp_rng[3 * g + 2] && !BCFGPU_ABL(P, 128)) ? P.grp_rng[3 * g + 1] : first;
                 const float *fp = frow + a * S4;
                 float acc = 0.f;
                 int i = first;

@@ -996,7 +996,7 @@ def main():
         # FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950, separate passes), never scaled: a run
         # with another tile shape reports null
         traffic = traffic_source = None
-        for tf in ("r3_traffic.json", "r2_traffic.json"):
+        for tf in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
                 if tj["samples"] == S and abs(tj["depth"] - a.depth) < 1e-9 and tj["sites"] == T:
@@ -1113,6 +1113,40 @@ def main():
             bq = child(["--mode", "baq", "--steps", "6", "--cpu-seconds", "5", "--cpu-all-cores", "0", "--extras", "0", "--seed", str(a.seed)])
             wgs = child(["--mode", "wgs", "--steps", "3", "--warmup", "1", "--cpu-seconds", "6", "--cpu-all-cores", "0", "--extras", "0", "--baq", "1",
                          "--samples", str(S), "--depth", str(a.depth), "--seed", str(a.seed)])
+            # ---- HBM bytes of the dominant kernel, measured in this run: two child passes under rocprofv3 --pmc (FETCH_SIZE and
+            # WRITE_SIZE apart, nothing but --kernel-trace beside them), corrected as MI355X_MICROARCH.md prescribes for gfx950 ----
+            live = None
+            try:
+                import shutil, tempfile, csv, glob
+                prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+                if prof:
+                    kb = {}
+                    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+                        d = tempfile.mkdtemp(prefix="bcfgpu_pmc_", dir="/tmp")
+                        subprocess.run([prof, "--kernel-trace", "--pmc", cname, "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
+                                        os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--samples", str(S), "--depth", str(a.depth),
+                                        "--sites", str(T)] + common, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+                        first, tot = None, 0.0
+                        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                            for r in csv.DictReader(open(f)):
+                                if "glfgen_kernel" not in r["Kernel_Name"] or r["Counter_Name"] != cname:
+                                    continue
+                                key = (r["Kernel_Name"], r["Dispatch_Id"])
+                                if first is None:
+                                    first = key
+                                if key == first:
+                                    tot += float(r["Counter_Value"])
+                        shutil.rmtree(d, ignore_errors=True)
+                        if first is not None:
+                            kb[cname] = tot
+                    if len(kb) == 2:
+                        live = int((2 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024)
+                        out["roofline"]["traffic"] = live
+                        out["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child passes of this "
+                                                             "bench on the same launch shape, first glfgen_kernel dispatch); gfx950: 2 x FETCH_SIZE + WRITE_SIZE, KiB")
+                        out["roofline"]["traffic_counters_kib"] = kb
+            except Exception as e:                           # the counters are an extra: the headline does not depend on them
+                out["roofline"]["traffic_live_error"] = repr(e)[:200]
             out["extra"] = {
                 "configs3_mixed": {k: wgs.get(k) for k in ("metric", "value", "unit", "ms_per_step", "config", "split_ms", "front_ms", "with_front", "cpu_baseline", "note", "error") if k in wgs},
                 "configs2_mixed": {k: mix.get(k) for k in ("metric", "value", "unit", "ms_per_step", "config", "split_ms", "cpu_baseline", "error") if k in mix},
