@@ -38,7 +38,7 @@ struct bcfgpu_ctx {
     int *d_hist = nullptr, *d_err = nullptr;       // d_err: [0] error word, [1] cells past 255 usable reads, [2..4] counters of glfgen's deep-cell list, [5] WideRecs of the launch
     uint16_t *d_keys = nullptr;                    // glfgen in two launches (BCFGPU_GLFGEN_SPLIT=1): 2 bytes per read between them
     int32_t *d_grp_rng = nullptr;                  // mcall: sample range of every -G group
-    float *d_grp_frac = nullptr; size_t grp_frac_bytes = 0;   // mcall -G: a site's allele fractions per sample (the group sums run side by side from it); grow-only, sized per launch
+    float *d_grp_q = nullptr; size_t grp_q_bytes = 0;   // mcall -G: the groups' frequency sums of a launch (grow-only)
     uint32_t *d_deep_list = nullptr; uint16_t *d_deep_keys = nullptr; uint32_t deep_cap = 0, deep_key_cap = 0, wide_cap = 0;
     CallretPlanes *d_crp = nullptr;
     unsigned long long *d_site_sums = nullptr;
@@ -190,7 +190,7 @@ void bcfgpu_destroy(bcfgpu_ctx *c)
     hipSetDevice(c->cfg.device);
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     for (void *p : c->owned) hipFree(p);
-    if (c->d_grp_frac) hipFree(c->d_grp_frac);
+    if (c->d_grp_q) hipFree(c->d_grp_q);
     for (auto &w : c->ws) if (w.p) hipFree(w.p);
     for (auto &w : c->pinned) if (w.p) hipHostFree(w.p);
     for (hipEvent_t e : c->pool) hipEventDestroy(e);
@@ -538,20 +538,18 @@ int bcfgpu_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_mplp_out
     return 0;
 }
 
-// The -G fractions scratch [n_sites][5][n_smpl rounded up to 4] for a launch of n_sites (grow-only; the kernel indexes it by
-// site, so it is sized from the launch, not from cfg.max_sites: a call-only context has max_sites = 0).  NULL when it cannot
-// be had: the kernel then takes the chained group sums.
-static float *grp_frac_for(bcfgpu_ctx *c, int n_sites)
+// call -G: the groups' frequency sums of a launch, [n_sites][n_grp][5] floats (grow-only; sized from the launch, not from
+// cfg.max_sites: a call-only context has max_sites = 0)
+static float *grp_q_for(bcfgpu_ctx *c, int n_sites)
 {
     if (c->cfg.n_grp <= 1 || n_sites <= 0) return nullptr;
-    const size_t bytes = (size_t)n_sites * 5 * (((size_t)c->cfg.n_smpl + 3) & ~(size_t)3) * sizeof(float);
-    if (bytes <= c->grp_frac_bytes) return c->d_grp_frac;
-    if (bytes > ((size_t)16 << 30)) return nullptr;
-    if (c->d_grp_frac) { hipStreamSynchronize(c->stream); hipFree(c->d_grp_frac); c->d_grp_frac = nullptr; c->grp_frac_bytes = 0; }
+    const size_t bytes = (size_t)n_sites * c->cfg.n_grp * 5 * sizeof(float);
+    if (bytes <= c->grp_q_bytes) return c->d_grp_q;
+    if (c->d_grp_q) { hipStreamSynchronize(c->stream); hipFree(c->d_grp_q); c->d_grp_q = nullptr; c->grp_q_bytes = 0; }
     void *p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    c->d_grp_frac = (float*)p; c->grp_frac_bytes = bytes;
-    return c->d_grp_frac;
+    if (hipMalloc(&p, bytes + bytes / 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    c->d_grp_q = (float*)p; c->grp_q_bytes = bytes + bytes / 4;
+    return c->d_grp_q;
 }
 
 int bcfgpu_mcall(bcfgpu_ctx *c, const bcfgpu_call_in *in, const bcfgpu_call_out *out)
@@ -569,7 +567,8 @@ int bcfgpu_mcall(bcfgpu_ctx *c, const bcfgpu_call_in *in, const bcfgpu_call_out 
     m.pl_is_u8 = 0; m.call_flag = c->cfg.call_flag; m.output_tags = c->cfg.output_tags; m.n_grp = c->cfg.n_grp;
     m.theta = c->call_theta_log; m.pl2p = c->d_pl2p;
     m.nals = in->nals; m.unseen = in->unseen; m.msite = nullptr; m.pl = in->pl; m.qs = in->qs; m.ad = in->ad;
-    m.grp_rng = c->d_grp_rng; m.grp_frac = grp_frac_for(c, m.n_sites);
+    m.grp_rng = c->d_grp_rng; m.grp_q = grp_q_for(c, m.n_sites);
+    if (c->cfg.n_grp > 1 && !m.grp_q) return set_err(BCFGPU_E_NOMEM, "call -G: workspace of the groups' frequency sums");
     m.ploidy = in->ploidy; m.grp = c->cfg.n_grp > 1 ? in->grp : nullptr; m.prior_an = in->prior_an; m.prior_ac = in->prior_ac; m.i16 = in->i16;
     m.out = *out; m.out_n_gt_max = in->n_gt_max; m.err = c->d_err;
     if (c->timing == 1) hipEventRecord(c->ev[2], c->stream);
@@ -604,7 +603,8 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
     m.msite = mout->site; m.pl = mout->pl; m.qs = nullptr; m.ad = nullptr;
     m.qs_i32 = (c->cfg.n_grp > 1 && c->cfg.grp_tag_is_qs) ? mout->qs : nullptr;
     if (c->cfg.n_grp > 1 && !c->cfg.grp_tag_is_qs) { m.ad_u16 = mout->adf; m.ad_u16b = mout->adr; }   // FORMAT/AD = ADF+ADR (bam2bcf.c:892-896)
-    m.grp_rng = c->d_grp_rng; m.grp_frac = grp_frac_for(c, m.n_sites);
+    m.grp_rng = c->d_grp_rng; m.grp_q = grp_q_for(c, m.n_sites);
+    if (c->cfg.n_grp > 1 && !m.grp_q) return set_err(BCFGPU_E_NOMEM, "call -G: workspace of the groups' frequency sums");
     m.ploidy = ploidy; m.grp = c->cfg.n_grp > 1 ? grp : nullptr;
     m.out = *cout; m.out_n_gt_max = BCFGPU_MAX_PL; m.err = c->d_err;
 #ifdef BCFGPU_DIAG

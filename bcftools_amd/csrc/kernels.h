@@ -123,7 +123,7 @@ struct McallParams {
     const uint8_t *ploidy;
     const int32_t *grp;
     int32_t *grp_rng;               // [n_grp][3] workspace: first sample, last sample + 1 and number of samples of every group (launch_mcall fills it)
-    float *grp_frac;                // [n_sites][5][(n_smpl + 3) & ~3] workspace, or NULL: the samples' allele fractions of a site, for the group sums
+    float *grp_q;                   // [n_sites][n_grp][5] workspace: the groups' allele-frequency sums (grp_qsum_kernel -> mcall_kernel)
     const int32_t *prior_an, *prior_ac;
     const float *i16;               // [site][16] INFO/I16 or NULL (fused: msite->anno)
     bcfgpu_call_out out;

@@ -58,7 +58,7 @@ struct PileupParams {
     // out
     uint32_t *cnt;                  // [n_cells + 1] pass 1: reads per cell; after the scan: plp_off
     uint32_t *rd; uint8_t *epos;    // pass 2
-    uint32_t *col_indel;            // [n_sites] != 0 when some entry of the column is followed by an indel
+    uint32_t *col_indel;            // [n_sites] entries of the column that are followed by an indel (n_alt of bam2bcf_indel.c:117-140)
     int n_reads;                    // reads of the pool (bcfgpu_gap_prep_tile)
     uint32_t n_bases;               // bases of the pool's seq16 / qual
     const int *d_span;              // the longest reference span of a read, as pileup_meta_kernel left it (max_span once the host has read it)
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
     // fetched one trip ahead, its base and quality bytes are requested in the trip that resolves its CIGAR and used two
     // trips later, so that a trip waits for loads issued one and two trips ago instead of three dependent ones in a row
     // (at three wavefronts per SIMD -- the LDS staging -- the wavefronts sat in s_waitcnt 70 % of their time).
-    uint32_t any_indel = 0;
+    uint32_t any_indel = 0;                                              // entries of the cell that are followed by an indel
     const uint4 *meta4 = reinterpret_cast<const uint4*>(P.meta);
     uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;                          // the record of read k, fetched ahead
     const int k_last = P.n_reads - 1;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
                         rx += l;
                     } else if (op == 1 || op == 4) y += l;
                 }
-                any_indel |= indel != 0;
+                any_indel += indel != 0 ? 1u : 0u;
                 // get_position, bam2bcf.c:80-114
                 int iread = 0;
                 edist = qpos + 1;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
         trip(k, n0, n1, na0, na1, qa);
         trip(k + 1, na0, na1, n0, n1, qb);
     }
-    if (any_indel && live && P.col_indel) atomicOr(&P.col_indel[site], 1u);
+    if (!FILL && any_indel && live && P.col_indel) atomicAdd(&P.col_indel[site], any_indel);      // (the count pass: once per entry)
     }
     if (FILL && staged) {
         __syncthreads();
@@ -276,7 +276,22 @@ struct EntriesParams {
     const int32_t *cols;            // [n_cols] column indices
     uint32_t *sel_cnt;              // [n_cols*n_smpl + 1] counts, then offsets
     int32_t *e_read, *e_qpos, *e_indel;
+    const uint8_t *col_keep;        // NULL, or [n_cols]: 0 = the column has no entries as far as the stage is concerned (gap_support_kernel)
 };
+
+// bcf_call_gap_prep gives up on a column whose indel reads, pooled over the samples, are fewer than min_support or a smaller
+// share of the column's reads than min_frac (bam2bcf_indel.c:150-154, the default: no -p / per_sample_flt) -- in a large
+// cohort nearly every column has some read with an indel and nearly none passes.  Decided here from two numbers the pileup
+// left per column, before any of the column's entries is listed: a column that fails has no entries for the stage, and the
+// stage returns -1 for it as the reference does.
+__global__ __launch_bounds__(256) void gap_support_kernel(const PileupParams P, const int32_t *cols, int n_cols, int min_support, double min_frac, uint8_t *keep)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_cols) return;
+    const long c = cols[i];
+    const uint32_t n_alt = P.col_indel[c], n_tot = P.cnt[(c + 1) * P.n_smpl] - P.cnt[c * P.n_smpl];
+    keep[i] = (n_tot == 0 || (double)n_alt / n_tot < min_frac || (int)n_alt < min_support) ? 0 : 1;
+}
 
 // what the pileup says about read record m at reference position x (htslib resolve_cigar): query offset, indel after x
 __device__ __forceinline__ void entry_of_read(const ReadMeta &m, const uint32_t *cig, int x, int &qpos, int &indel)
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(256) void entries_kernel(const EntriesParams E)
         if (i >= (long)E.n_cols * P.n_smpl) return;
         const int ci = (int)(i / P.n_smpl), s = (int)(i - (long)ci * P.n_smpl);
         const long cell = (long)E.cols[ci] * P.n_smpl + s;
-        E.sel_cnt[i] = P.cnt[cell + 1] - P.cnt[cell];
+        E.sel_cnt[i] = (E.col_keep && !E.col_keep[ci]) ? 0u : P.cnt[cell + 1] - P.cnt[cell];
         return;
     }
     const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -334,6 +349,7 @@ __global__ __launch_bounds__(256) void entries_kernel(const EntriesParams E)
     const int hi = upper_bound(P.s_pos, lo0, hi0, x);
     const int lo = upper_bound(P.s_pos, lo0, hi, x - P.max_span);
     uint32_t o = E.sel_cnt[i];
+    if (E.col_keep && !E.col_keep[ci]) return;
     for (int kb = lo; kb < hi; kb += 64) {
         const int k = kb + lane;
         bool covers = false;
@@ -362,6 +378,7 @@ __global__ __launch_bounds__(256) void subtile_kernel(const EntriesParams E, uin
     const int ci = (int)(i / P.n_smpl), s = (int)(i - (long)ci * P.n_smpl);
     const long cell = (long)E.cols[ci] * P.n_smpl + s;
     const uint32_t b = P.cnt[cell], e = P.cnt[cell + 1];
+    if (E.col_keep && !E.col_keep[ci]) { if (!FILL) E.sel_cnt[i] = 0; return; }
     if (!FILL) { E.sel_cnt[i] = e - b; return; }
     uint32_t o = E.sel_cnt[i];
     for (uint32_t k = b; k < e; ++k, ++o) { rd_out[o] = P.rd[k]; ep_out[o] = P.epos[k]; }
@@ -1049,12 +1066,17 @@ extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32
     #define GT_CHK(call) do { if ((call) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, #call); } while (0)
     #define GWS(slot, bytes) bcfgpu_internal_ws(ctx, 40 + (slot), (bytes) + 64)      /* the slots bcfgpu_gap_prep uses for its uploads */
     // ---- the columns' pileup entries (read, query offset, indel after the position), on the device ----
-    int32_t *d_cols = (int32_t*)bcfgpu_internal_ws(ctx, 21, (size_t)n_cols * 4 + 16);
+    int32_t *d_cols = (int32_t*)bcfgpu_internal_ws(ctx, 21, (size_t)n_cols * 5 + 64);     // the columns, then a byte per column (gap_support_kernel)
     uint32_t *d_sel = (uint32_t*)bcfgpu_internal_ws(ctx, 25, (nsel + 1) * 4 + (size_t)n_cols + 64);
     if (!d_cols || !d_sel) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
     GT_CHK(hipMemcpyAsync(d_cols, cols, (size_t)n_cols * 4, hipMemcpyHostToDevice, stream));
     GT_CHK(hipMemsetAsync(d_sel, 0, (nsel + 1) * 4 + (size_t)n_cols + 64, stream));
-    E.n_cols = n_cols; E.cols = d_cols; E.sel_cnt = d_sel;
+    E.n_cols = n_cols; E.cols = d_cols; E.sel_cnt = d_sel; E.col_keep = nullptr;
+    if (!par->per_sample_flt && P.col_indel) {
+        uint8_t *d_keep = reinterpret_cast<uint8_t*>(d_cols + n_cols);
+        hipLaunchKernelGGL(gap_support_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, stream, P, d_cols, n_cols, par->min_support, par->min_frac, d_keep);
+        E.col_keep = d_keep;
+    }
     const int grid = (int)((nsel + 255) / 256);
     hipLaunchKernelGGL(entries_kernel<false>, dim3(grid), dim3(256), 0, stream, E);
     size_t tmp_bytes = 0;

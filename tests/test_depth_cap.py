@@ -74,6 +74,29 @@ def test_depth_cap_matches_iterator_replay(seed, n_smpl, n_reads, maxcnt):
         m = np.nonzero(smpl == s)[0]
         first = m[np.r_[True, np.diff(pos[m]) != 0]]
         assert keep[first].all()
+    # the same reads pushed through the iterator's state in batches (a region streamed in tiles, host/bcfgpu_sam.c): per
+    # sample in position order, batch boundaries at arbitrary positions -- reads that start at a boundary position land on either side
+    st = L.bcfgpu_depth_cap_new(n_smpl, maxcnt)
+    assert st
+    keep2 = np.zeros(n_reads, np.uint8)
+    cuts = np.r_[-1, np.sort(rng.integers(0, 200, 7)), 10 ** 9]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        idx = np.nonzero((pos > lo) & (pos <= hi))[0]                 # the batch: every sample's reads of this position range, samples in order
+        if not len(idx):
+            continue
+        b = abi.Reads()
+        bp, bn, bo, bs = (np.ascontiguousarray(x[idx]) for x in (pos, ncig, coff, smpl))
+        b.n_reads = len(idx)
+        b.r_pos, b.r_ncig, b.r_cig_off, b.cig = bp.ctypes.data, bn.ctypes.data, bo.ctypes.data, cig.ctypes.data
+        kb = np.zeros(len(idx), np.uint8)
+        assert L.bcfgpu_depth_cap_push(st, C.byref(b), bs.ctypes.data, kb.ctypes.data) == 0
+        keep2[idx] = kb
+    np.testing.assert_array_equal(keep2, keep)
+    L.bcfgpu_depth_cap_reset(st)
+    kb = np.zeros(n_reads, np.uint8)
+    assert L.bcfgpu_depth_cap_push(st, C.byref(rd), smpl.ctypes.data, kb.ctypes.data) == 0      # after a reset: a new region, the whole of it at once
+    np.testing.assert_array_equal(kb, keep)
+    L.bcfgpu_depth_cap_free(st)
 
 
 def test_depth_cap_rejects_unsorted_reads():
