@@ -55,6 +55,29 @@ __device__ __forceinline__ int wsumi(int v)
     return v;
 }
 
+// A value of the lane's partner inside its row of 16 lanes, by data-parallel-primitive moves (no trip through the LDS
+// crossbar as __shfl_xor makes): the four pairings quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror join
+// lanes, quads, halves -- after them every lane of the row holds the reduction over its 16 lanes.
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const uint32_t lo = (uint32_t)dpp_i32<CTRL>((int)(uint32_t)b), hi = (uint32_t)dpp_i32<CTRL>((int)(uint32_t)(b >> 32));
+    return __builtin_bit_cast(double, (unsigned long long)hi << 32 | lo);
+}
+// product of the 16 lanes' (mantissa, exponent) pairs, renormalised at every step, and the OR of their flags
+template <int CTRL> __device__ __forceinline__ void row16_step(double &m, int &e, int &f)
+{
+    const double mm = m * dpp_f64<CTRL>(m);
+    e += dpp_i32<CTRL>(e) + __builtin_amdgcn_frexp_exp(mm);
+    m = __builtin_amdgcn_frexp_mant(mm);
+    f |= dpp_i32<CTRL>(f);
+}
+__device__ __forceinline__ void row16_product(double &m, int &e, int &f)
+{
+    row16_step<0xB1>(m, e, f); row16_step<0x4E>(m, e, f); row16_step<0x141>(m, e, f); row16_step<0x140>(m, e, f);
+}
+
 // one allele subset of mcall_find_best_alleles: genotype indices and frequency products
 struct Subset {
     int ia, ib, ic;             // ib/ic = -1 when absent
@@ -175,7 +198,13 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 #define MCALL_WAVES 4        // wavefronts per SIMD of the all-diploid FAST instantiations
 #endif
 template <int MAXA, int NSUB, bool FAST, bool HAP, bool GRP>
-__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 : (HAP || GRP) ? 3 : MCALL_WAVES, !FAST ? 8 : (HAP || GRP) ? 3 : MCALL_WAVES))) void mcall_kernel(const McallParams P)
+#ifndef MCALL_WAVES_GRP
+#define MCALL_WAVES_GRP 3    // ... of the instantiations with sample groups
+#endif
+#ifndef MCALL_WAVES_HAP
+#define MCALL_WAVES_HAP 3    // ... with a ploidy array (two coefficient matrices)
+#endif
+__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 : HAP ? MCALL_WAVES_HAP : GRP ? MCALL_WAVES_GRP : MCALL_WAVES, !FAST ? 8 : HAP ? MCALL_WAVES_HAP : GRP ? MCALL_WAVES_GRP : MCALL_WAVES))) void mcall_kernel(const McallParams P)
 {
     constexpr int NG = MAXA * (MAXA + 1) / 2;
     constexpr int TILES = NSUB >= 16 ? 2 : 1;     // 16-row tiles of the coefficient matrix (subsets + the sum row)
@@ -585,13 +614,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     double m = man[t][r]; int e = ex[t][r]; int f = (setbits >> (t * 4 + r)) & 1;
-                    #pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) {
-                        const double mm = m * __shfl_xor(m, o);
-                        e += __shfl_xor(e, o) + frexp_exp(mm);
-                        m = frexp_mant(mm);
-                        f |= __shfl_xor(f, o);
-                    }
+                    row16_product(m, e, f);
                     const int row = t * 16 + kq + 4 * r;
                     if (col == 0 && row <= nsub) {
                         if constexpr (BATCH) { s_red2[(g % GB) * CPG + row] = m; s_rede2[(g % GB) * CPG + row] = e; }
@@ -600,13 +623,8 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                     }
                 }
             if (HAP) {
-                double m = sdm; int e = sde;
-                #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) {
-                    const double mm = m * __shfl_xor(m, o);
-                    e += __shfl_xor(e, o) + frexp_exp(mm);
-                    m = frexp_mant(mm);
-                }
+                double m = sdm; int e = sde, f_ = 0;
+                row16_product(m, e, f_);
                 if (col == 0 && kq == (nsub & 3)) {
                     if constexpr (BATCH) { s_dipm[g % GB] = m; s_dipe[g % GB] = e; }
                     else { sh.red[31] = m; sh.rede[31] = e; }      // (at most 26 rows are in use)
@@ -998,7 +1016,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
 // sample order -- sequential float32 sums, the reference's rounding -- from FORMAT/AD (or QS), for every site that mcall_kernel
 // will work on.  One wavefront per site; out[site][grp][5].  Its registers are few (the calling kernel's matrix-core scan is
 // what needs many), so that eight wavefronts share a SIMD and cover one another's round trips and chains.
-__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(6, 8))) void grp_qsum_kernel(const McallParams P)
+__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(4, 8))) void grp_qsum_kernel(const McallParams P)
 {
     extern __shared__ __align__(16) unsigned char dsm[];
     float *s_gq = reinterpret_cast<float*>(dsm);              // [n_grp][5]
