@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void pileup_kernel(const PileupParams P)
         trip(k, n0, n1, na0, na1, qa);
         trip(k + 1, na0, na1, n0, n1, qb);
     }
-    if (!FILL && any_indel && live && P.col_indel) atomicAdd(&P.col_indel[site], any_indel);      // (the count pass: once per entry)
+    if (any_indel && live && P.col_indel) atomicAdd(&P.col_indel[site], any_indel);                // (the fill pass walks the CIGARs: once per entry)
     }
     if (FILL && staged) {
         __syncthreads();
