@@ -1,5 +1,6 @@
 #!/bin/bash
-# Kernel stats (rocprofv3 --kernel-trace --stats) of the secondary modes: BAQ / overlaps, the host-fed pileup, call -G with a ploidy array.
+# Kernel stats (rocprofv3 --kernel-trace --stats) of the secondary modes: BAQ / overlaps, the host-fed pileup, call -G with a ploidy array,
+# the end-to-end region of --mode wgs (configs3_mixed).
 # bash tools/prof_others.sh [tag] -> gpurun_out/others_<tag>/<tag>_{baq,pileup,mcall_grp}_kernel_stats.csv
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -11,3 +12,4 @@ run() { name=$1; shift; rocprofv3 --kernel-trace --stats -d $OUT/$name -o s --ou
 run baq --mode baq --steps 3
 run pileup --mode pileup --steps 4
 run mcall_grp --groups 4 --haploid-frac 0.25 --steps 4
+run wgs --mode wgs --baq 1 --steps 3 --warmup 1
