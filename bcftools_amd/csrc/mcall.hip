@@ -1012,23 +1012,21 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     }
 }
 
+// (A workgroup of four wavefronts per site -- all 256 lanes normalising a round of 1024 samples, the groups dealt to the
+// wavefronts -- was measured at 0.37 ms per 32 768-site tile against 0.32 ms for this one-wavefront form: the kernel is bound
+// by its trips to memory and the start of its workgroups, not by the additions.)
 // The groups' allele-frequency sums of `call -G` (mcall.c:1474-1503): qsum[grp][j] += AD[j] / sum(AD) over the group's samples in
 // sample order -- sequential float32 sums, the reference's rounding -- from FORMAT/AD (or QS), for every site that mcall_kernel
-// will work on; out[site][grp][5].  A workgroup of four wavefronts per site: all 256 lanes normalise the samples of a round
-// (1024 samples, four consecutive ones a lane) into LDS, then the chains run -- groups that are runs of consecutive samples
-// (the usual -G file) dealt to the wavefronts, wavefront w taking groups w, w + 4, ... as lanes (group, allele), so that the
-// chains of four groups advance at once and a wavefront issues one addition per sample of ITS groups only; any other grouping:
-// five chains over all samples with a group switch, on the first wavefront.
-#define QW 256
-__global__ __launch_bounds__(QW) __attribute__((amdgpu_waves_per_eu(4, 8))) void grp_qsum_kernel(const McallParams P)
+// will work on.  One wavefront per site; out[site][grp][5].  Its registers are few (the calling kernel's matrix-core scan is
+// what needs many), so that eight wavefronts share a SIMD and cover one another's round trips and chains.
+__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(4, 8))) void grp_qsum_kernel(const McallParams P)
 {
     extern __shared__ __align__(16) unsigned char dsm[];
     float *s_gq = reinterpret_cast<float*>(dsm);              // [n_grp][5]
-    constexpr int SB = 4 * QW;                                  // samples per round
-    __shared__ __align__(16) float s_fr[5 * SB];                // [5][SB] fractions of the round's samples
-    __shared__ int s_gg[SB];                                    // their groups (general path)
-    __shared__ int s_runs;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int SB = 4 * WGS;                                 // samples per staging round: four consecutive ones per lane
+    constexpr int UB = (5 * SB) * (int)sizeof(float) + SB * (int)sizeof(int);
+    __shared__ __align__(16) unsigned char s_union[UB];
+    const int tid = threadIdx.x;
     const int is = blockIdx.x;
     const int S = P.n_smpl;
     const size_t Ss = (size_t)S;
@@ -1040,125 +1038,131 @@ __global__ __launch_bounds__(QW) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     // the records mcall_kernel refuses or never reaches (vcfcall.c:1112-1115) need no sums
     if (nals < 1 || nals > BCFGPU_MAX_ALLELES || ngts > P.n_gt_max || (P.ad && nals > P.n_al_max) || unseen < 0 || unseen >= nals) return;
     if ((P.call_flag & BCFGPU_CALL_VARONLY) && (nals == 1 || (nals == 2 && unseen > 0))) return;
-    for (int i = tid; i < ngrp * 5; i += QW) s_gq[i] = 0;
-    const int nad = P.ad ? P.n_al_max : nals;
-    // the next round's counts and groups are requested before the current ones are normalised (the loop is a chain of memory
-    // round trips otherwise); a lane's four samples of a 16-bit plane are one 8-byte load
-    int xn[5][4], gnx[4];
-    auto fetch_ad = [&](int base, bool want_grp) {
-        const int s = base + 4 * tid, rem = S - s;
-        #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            #pragma unroll
-            for (int j = 0; j < 4; ++j) xn[k][j] = VEND;
-            if (rem <= 0 || k >= nad) continue;
-            if (P.ad) {
-                #pragma unroll
-                for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = P.ad[((size_t)is * P.n_al_max + k) * Ss + s + j];
-            } else if (k < nals) {
-                if (P.qs_i32) {
-                    #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = (int)P.qs_i32[((size_t)is * 5 + k) * Ss + s + j];
-                } else {
-                    // FORMAT/AD = ADF + ADR (bam2bcf.c:892-896)
-                    const uint16_t *pa = P.ad_u16 + ((size_t)is * 5 + k) * Ss + s, *pb = P.ad_u16b + ((size_t)is * 5 + k) * Ss + s;
-                    uint16_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
-                    if (rem >= 4 && ((reinterpret_cast<uintptr_t>(pa) | reinterpret_cast<uintptr_t>(pb)) & 7) == 0) { __builtin_memcpy(wa, pa, 8); __builtin_memcpy(wb, pb, 8); }
-                    else for (int j = 0; j < 4 && j < rem; ++j) { wa[j] = pa[j]; wb[j] = pb[j]; }
-                    #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = (int)wa[j] + (int)wb[j];
-                }
-            }
-        }
-        if (want_grp) {
-            #pragma unroll
-            for (int j = 0; j < 4; ++j) gnx[j] = j < rem ? GRP_OF(s + j) : 0;
-        }
-    };
-    // this lane's four samples of the round: AD[k] / sum(AD) where the reference adds something, +0 elsewhere (mcall.c:1488-1500)
-    auto normalise = [&](const int (&xc)[5][4], int cn) {
-        float fr[5][4];
-        #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int v[5];
-            float sum = 0;
-            int nvalid = 0;                                   // values before the first vector_end
-            #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                v[k] = VEND;
-                if (k < nad && nvalid == k) {
-                    const int x = xc[k][j];
-                    if (x != VEND) { v[k] = x; nvalid = k + 1; if (x != MISSING) sum += (float)x; }
-                }
-            }
-            #pragma unroll
-            for (int k = 0; k < 5; ++k)
-                fr[k][j] = (4 * tid + j < cn && sum != 0.f && k < nvalid && v[k] != MISSING) ? (float)v[k] / sum : 0.f;
-        }
-        #pragma unroll
-        for (int k = 0; k < 5; ++k)
-            if (k < nals) *reinterpret_cast<float4*>(s_fr + k * SB + 4 * tid) = make_float4(fr[k][0], fr[k][1], fr[k][2], fr[k][3]);
-    };
-    // are the groups runs of consecutive samples (grp_check_kernel counted them beside their ranges)?
-    if (tid == 0) s_runs = (P.grp_rng != nullptr && ngrp <= 48) ? 1 : 0;
-    __syncthreads();
-    if (tid < ngrp && P.grp_rng && ngrp <= 48) {
-        const int f = P.grp_rng[3 * tid], l = P.grp_rng[3 * tid + 1], n = P.grp_rng[3 * tid + 2];
-        if (!(n == 0 || l - f == n)) s_runs = 0;
-    }
-    __syncthreads();
-    const bool runs = s_runs != 0;
-    fetch_ad(0, !runs);
-    if (runs) {
-        const int gl = lane / 5, ca = lane % 5, cg = wave + 4 * gl;
-        const bool chain = lane < 60 && cg < ngrp && ca < nals;
-        int gfirst = 0, glast = 0;
-        if (chain && P.grp_rng[3 * cg + 2]) { gfirst = P.grp_rng[3 * cg]; glast = P.grp_rng[3 * cg + 1]; }
-        float gacc = 0.f;
-        for (int base = 0; base < (BCFGPU_ABL(P, 128) ? 0 : S); base += SB) {
-            const int cn = min(SB, S - base);
-            __syncthreads();                                         // (the chains of the round before are through with s_fr)
-            int xc[5][4];
-            #pragma unroll
-            for (int k = 0; k < 5; ++k)
-                #pragma unroll
-                for (int j = 0; j < 4; ++j) xc[k][j] = xn[k][j];
-            if (base + SB < S) fetch_ad(base + SB, false);
-            normalise(xc, cn);
-            __syncthreads();
-            const int lo = max(gfirst, base), hi = min(glast, base + cn);
-            if (chain && lo < hi) {
-                const float *fp = s_fr + ca * SB - base;               // indexed by sample
-                int i = lo;
-                for (; i < hi && (i & 3); ++i) gacc += fp[i];
-                const float4 *q4 = reinterpret_cast<const float4*>(fp + i);
-                const int nb = (hi - i) >> 2;                          // whole float4s; four of them in flight
-                float4 c0 = make_float4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
-                if (nb > 0) c0 = q4[0];
-                if (nb > 1) c1 = q4[1];
-                if (nb > 2) c2 = q4[2];
-                if (nb > 3) c3 = q4[3];
-                for (int b4 = 0; b4 < nb; b4 += 4) {
-                    const float4 a0 = c0, a1 = c1, a2 = c2, a3 = c3;
-                    if (b4 + 4 < nb) c0 = q4[b4 + 4];
-                    if (b4 + 5 < nb) c1 = q4[b4 + 5];
-                    if (b4 + 6 < nb) c2 = q4[b4 + 6];
-                    if (b4 + 7 < nb) c3 = q4[b4 + 7];
-                    gacc += a0.x; gacc += a0.y; gacc += a0.z; gacc += a0.w;
-                    if (b4 + 1 < nb) { gacc += a1.x; gacc += a1.y; gacc += a1.z; gacc += a1.w; }
-                    if (b4 + 2 < nb) { gacc += a2.x; gacc += a2.y; gacc += a2.z; gacc += a2.w; }
-                    if (b4 + 3 < nb) { gacc += a3.x; gacc += a3.y; gacc += a3.z; gacc += a3.w; }
-                }
-                for (i += 4 * nb; i < hi; ++i) gacc += fp[i];
-            }
-        }
-        __syncthreads();
-        if (chain) s_gq[cg * 5 + ca] = gacc;
-    } else {
-        // any grouping: lane j < 5 of the first wavefront adds allele j's fractions in sample order, keeping the running sum of
-        // the current group in a register (the samples of a group tend to follow one another)
+    {
+        // group qsum from FORMAT/AD (or QS): qsum[grp][j] += AD[j]/sum in sample order (mcall.c:1478-1503).
+        // 64 samples at a time: every lane normalises one sample (coalesced plane reads), then lane j < 5 adds allele
+        // j's fractions in sample order -- the sequential float32 sum of the reference -- keeping the running sum of
+        // the current group in a register (samples of a group are usually consecutive).
+        for (int i = tid; i < ngrp * 5; i += WGS) s_gq[i] = 0;
+        constexpr int SB = 4 * WGS;                                 // samples per staging round: four consecutive ones per lane
+        float *s_fr = reinterpret_cast<float*>(s_union);            // [5][SB] fractions of the staged samples
+        int *s_gg = reinterpret_cast<int*>(s_fr + 5 * SB);          // [SB] their groups
+        static_assert(UB >= (int)((5 * SB) * sizeof(float) + SB * sizeof(int)), "staging fits in s_union");
+        const int nad = P.ad ? P.n_al_max : nals;
         int cur = -1;
         float acc = 0.f;
+        // the next round's counts and groups are requested before the current ones are normalised and added (the loop is a
+        // chain of memory round trips otherwise); a lane's four samples of a byte plane are one 4-byte load
+        int xn[5][4], gnx[4];
+        auto fetch_ad = [&](int base) {
+            const int s = base + 4 * tid, rem = S - s;
+            #pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) xn[k][j] = VEND;
+                if (rem <= 0 || k >= nad) continue;
+                if (P.ad) {
+                    #pragma unroll
+                    for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = P.ad[((size_t)is * P.n_al_max + k) * Ss + s + j];
+                } else if (k < nals) {
+                    if (P.qs_i32) {
+                        #pragma unroll
+                        for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = (int)P.qs_i32[((size_t)is * 5 + k) * Ss + s + j];
+                    } else {
+                        // FORMAT/AD = ADF + ADR (bam2bcf.c:892-896): a lane's four samples of a 16-bit plane are one 8-byte load
+                        const uint16_t *pa = P.ad_u16 + ((size_t)is * 5 + k) * Ss + s, *pb = P.ad_u16b + ((size_t)is * 5 + k) * Ss + s;
+                        uint16_t wa[4] = {0, 0, 0, 0}, wb[4] = {0, 0, 0, 0};
+                        if (rem >= 4 && ((reinterpret_cast<uintptr_t>(pa) | reinterpret_cast<uintptr_t>(pb)) & 7) == 0) { __builtin_memcpy(wa, pa, 8); __builtin_memcpy(wb, pb, 8); }
+                        else for (int j = 0; j < 4 && j < rem; ++j) { wa[j] = pa[j]; wb[j] = pb[j]; }
+                        #pragma unroll
+                        for (int j = 0; j < 4; ++j) if (j < rem) xn[k][j] = (int)wa[j] + (int)wb[j];
+                    }
+                }
+            }
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) gnx[j] = j < rem ? GRP_OF(s + j) : 0;
+        };
+        // Groups that are runs of consecutive samples (the usual -G file): lane (group, allele) keeps its group's running sum and
+        // adds, round by round, the fractions of its group's samples of that round from LDS -- the reference's order for every
+        // group (mcall.c:1485-1500), without a group test per sample and without the five chains over all samples of the general
+        // path below.  (Round 3 left the fractions in a global scratch row per allele and let every chain read its stretch
+        // back: sixteen dependent trips to L2 per chain, a quarter of the kernel at four groups: profiles/r4_mcall_ablations.txt.)
+        bool side_by_side = P.grp_rng != nullptr && ngrp * 5 <= WGS;
+        if (side_by_side) {
+            bool ok = true;
+            if (tid < ngrp) { const int f = P.grp_rng[3 * tid], l = P.grp_rng[3 * tid + 1], n = P.grp_rng[3 * tid + 2]; ok = n == 0 || l - f == n; }
+            side_by_side = __all(ok);
+        }
+        fetch_ad(0);
+        if (side_by_side) {
+            const int cg = tid / 5, ca = tid % 5;
+            const bool chain = tid < ngrp * 5 && ca < nals;
+            int gfirst = 0, glast = 0;
+            if (chain && P.grp_rng[3 * cg + 2]) { gfirst = P.grp_rng[3 * cg]; glast = P.grp_rng[3 * cg + 1]; }
+            float gacc = 0.f;
+            for (int base = 0; base < (BCFGPU_ABL(P, 128) ? 0 : S); base += SB) {
+                const int cn = min(SB, S - base);
+                __syncthreads();                                         // (the chains of the round before are through with s_fr)
+                int xc[5][4];
+                #pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    #pragma unroll
+                    for (int j = 0; j < 4; ++j) xc[k][j] = xn[k][j];
+                fetch_ad(base + SB);
+                {
+                    float fr[5][4];
+                    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int v[5];
+                        float sum = 0;
+                        int nvalid = 0;                                   // values before the first vector_end
+                        #pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            v[k] = VEND;
+                            if (k < nad && nvalid == k) {
+                                const int x = xc[k][j];
+                                if (x != VEND) { v[k] = x; nvalid = k + 1; if (x != MISSING) sum += (float)x; }
+                            }
+                        }
+                        #pragma unroll
+                        for (int k = 0; k < 5; ++k)                       // +0 where the reference adds nothing (and past the last sample)
+                            fr[k][j] = (4 * tid + j < cn && sum != 0.f && k < nvalid && v[k] != MISSING) ? (float)v[k] / sum : 0.f;
+                    }
+                    #pragma unroll
+                    for (int k = 0; k < 5; ++k)
+                        if (k < nals) *reinterpret_cast<float4*>(s_fr + k * SB + 4 * tid) = make_float4(fr[k][0], fr[k][1], fr[k][2], fr[k][3]);
+                }
+                __syncthreads();
+                const int lo = max(gfirst, base), hi = min(glast, base + cn);
+                if (chain && lo < hi) {
+                    const float *fp = s_fr + ca * SB - base;               // indexed by sample
+                    int i = lo;
+                    for (; i < hi && (i & 3); ++i) gacc += fp[i];
+                    const float4 *q4 = reinterpret_cast<const float4*>(fp + i);
+                    const int nb = (hi - i) >> 2;                          // whole float4s; four of them in flight
+                    float4 c0 = make_float4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
+                    if (nb > 0) c0 = q4[0];
+                    if (nb > 1) c1 = q4[1];
+                    if (nb > 2) c2 = q4[2];
+                    if (nb > 3) c3 = q4[3];
+                    for (int b4 = 0; b4 < nb; b4 += 4) {
+                        const float4 a0 = c0, a1 = c1, a2 = c2, a3 = c3;
+                        if (b4 + 4 < nb) c0 = q4[b4 + 4];
+                        if (b4 + 5 < nb) c1 = q4[b4 + 5];
+                        if (b4 + 6 < nb) c2 = q4[b4 + 6];
+                        if (b4 + 7 < nb) c3 = q4[b4 + 7];
+                        gacc += a0.x; gacc += a0.y; gacc += a0.z; gacc += a0.w;
+                        if (b4 + 1 < nb) { gacc += a1.x; gacc += a1.y; gacc += a1.z; gacc += a1.w; }
+                        if (b4 + 2 < nb) { gacc += a2.x; gacc += a2.y; gacc += a2.z; gacc += a2.w; }
+                        if (b4 + 3 < nb) { gacc += a3.x; gacc += a3.y; gacc += a3.z; gacc += a3.w; }
+                    }
+                    for (i += 4 * nb; i < hi; ++i) gacc += fp[i];
+                }
+            }
+            __syncthreads();
+            if (chain) s_gq[cg * 5 + ca] = gacc;
+            cur = -1;                                                     // (nothing left in the running-group register)
+        } else
         for (int base = 0; base < (BCFGPU_ABL(P, 128) ? 0 : S); base += SB) {
             const int cn = min(SB, S - base);
             __syncthreads();
@@ -1169,26 +1173,70 @@ __global__ __launch_bounds__(QW) __attribute__((amdgpu_waves_per_eu(4, 8))) void
                 for (int j = 0; j < 4; ++j) xc[k][j] = xn[k][j];
             #pragma unroll
             for (int j = 0; j < 4; ++j) gcur[j] = gnx[j];
-            if (base + SB < S) fetch_ad(base + SB, true);
-            normalise(xc, cn);
+            fetch_ad(base + SB);
             #pragma unroll
-            for (int j = 0; j < 4; ++j) if (4 * tid + j < cn) s_gg[4 * tid + j] = gcur[j];
+            for (int j = 0; j < 4; ++j) {
+                const int ls = 4 * tid + j;                        // the sample's place in the round
+                if (ls < cn) {
+                    int v[5];
+                    float sum = 0;
+                    int nvalid = 0;                                   // values before the first vector_end
+                    #pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        v[k] = VEND;
+                        if (k < nad && nvalid == k) {
+                            const int x = xc[k][j];
+                            if (x != VEND) { v[k] = x; nvalid = k + 1; if (x != MISSING) sum += (float)x; }
+                        }
+                    }
+                    #pragma unroll
+                    for (int k = 0; k < 5; ++k)                       // +0 where the reference adds nothing
+                        s_fr[k * SB + ls] = (sum != 0.f && k < nvalid && v[k] != MISSING) ? (float)v[k] / sum : 0.f;
+                    s_gg[ls] = gcur[j];
+                }
+            }
             __syncthreads();
             if (tid < 5 && tid < nals) {
-                for (int ls = 0; ls < cn; ++ls) {
-                    const int g = s_gg[ls];
-                    if (g != cur) {
-                        if (cur >= 0) s_gq[cur * 5 + tid] = acc;
-                        cur = g; acc = s_gq[g * 5 + tid];
+                // sixteen samples per trip: their four LDS read pairs are in flight together (one read pair per trip leaves the
+                // lane waiting out an LDS round trip for every four additions)
+                const float4 *fr4 = reinterpret_cast<const float4*>(s_fr + tid * SB);
+                const int4 *gg4 = reinterpret_cast<const int4*>(s_gg);
+                const int nb = (cn + 3) >> 2;                      // the tail of the last block holds +0 / stale groups: see below
+                for (int b0 = 0; b0 < nb; b0 += 4) {
+                    float4 fq[4]; int4 gq4[4];
+                    #pragma unroll
+                    for (int u = 0; u < 4; ++u) if (b0 + u < nb) { fq[u] = fr4[b0 + u]; gq4[u] = gg4[b0 + u]; }
+                    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int b4 = b0 + u;
+                        if (b4 >= nb) break;
+                        const float4 f = fq[u]; const int4 gv = gq4[u];
+                        const float fv[4] = {f.x, f.y, f.z, f.w};
+                        const int gs4[4] = {gv.x, gv.y, gv.z, gv.w};
+                        // four samples of the running group (groups are usually runs of consecutive samples): just the four adds
+                        if (4 * b4 + 3 < cn && ((gv.x ^ cur) | (gv.y ^ cur) | (gv.z ^ cur) | (gv.w ^ cur)) == 0) {
+                            acc += f.x; acc += f.y; acc += f.z; acc += f.w;
+                            continue;
+                        }
+                        #pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (4 * b4 + k < cn) {
+                                const int g = gs4[k];
+                                if (g != cur) {
+                                    if (cur >= 0) s_gq[cur * 5 + tid] = acc;
+                                    cur = g; acc = s_gq[g * 5 + tid];
+                                }
+                                acc += fv[k];
+                            }
+                        }
                     }
-                    acc += s_fr[tid * SB + ls];
                 }
             }
         }
         if (tid < 5 && tid < nals && cur >= 0) s_gq[cur * 5 + tid] = acc;
     }
     __syncthreads();
-    for (int i = tid; i < ngrp * 5; i += QW) P.grp_q[(size_t)is * ngrp * 5 + i] = s_gq[i];
+    for (int i = tid; i < ngrp * 5; i += WGS) P.grp_q[(size_t)is * ngrp * 5 + i] = s_gq[i];
 }
 
 // DP4, MQ and PV4 from I16 (mcall.c:1659-1679; test16 of ccall.c:103-138): per-site scalar work with loops of its own
@@ -1248,7 +1296,7 @@ void launch_mcall(const McallParams &p, hipStream_t s)
         if (p.grp_rng) hipLaunchKernelGGL(grp_range_init_kernel, dim3((ngrp + 255) / 256), dim3(256), 0, s, p.grp_rng, ngrp);
         hipLaunchKernelGGL(grp_check_kernel, dim3((p.n_smpl + 255) / 256), dim3(256), 0, s, p.grp, p.n_smpl, ngrp, p.err, p.grp_rng);
     }
-    if (p.grp && ngrp > 1) hipLaunchKernelGGL(grp_qsum_kernel, dim3(p.n_sites), dim3(QW), (size_t)ngrp * 5 * sizeof(float), s, p);
+    if (p.grp && ngrp > 1) hipLaunchKernelGGL(grp_qsum_kernel, dim3(p.n_sites), dim3(WGS), (size_t)ngrp * 5 * sizeof(float), s, p);
     #define MCALL_LAUNCH3(FAST_, HAP_, GRP_) do { \
         hipLaunchKernelGGL((mcall_kernel<3, 7, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \
         hipLaunchKernelGGL((mcall_kernel<5, 15, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \
