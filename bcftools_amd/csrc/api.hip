@@ -57,11 +57,12 @@ struct bcfgpu_ctx {
     struct Ws { void *p = nullptr; size_t bytes = 0; };
     alignas(16) unsigned char pileup_state[256] = {0};   // csrc/pileup.hip: the parameters of the last bcfgpu_pileup
     alignas(16) unsigned char pool_state[256] = {0};     // kernels.h DevPool: the read pool bcfgpu_pool_upload left in HBM
-    Ws ws[136];                    // grow-only device workspaces of the host-fed stages (0-15: BAQ / overlaps, 16-35: pileup, 36-39: gVCF / indel tile, 40-103: gap_prep, 104-135: the resident read pool and its stages)
+    Ws ws[144];                    // grow-only device workspaces of the host-fed stages (0-15: BAQ / overlaps, 16-35: pileup, 36-39: gVCF / indel tile, 40-103: gap_prep, 104-135: the resident read pool and its stages, 136-143: errmod_cal's draw)
     int n_cu = 256;                // compute units of the device (grid size of the work-queue kernels)
     hipStream_t side[8] = {};      // created on first use: the realignment kernels of different band widths run side by side
     hipEvent_t side_ev[9] = {};    // [0..7] a side stream's work is done, [8] the fork point on the main stream
     Ws pinned[8];                  // grow-only pinned host staging buffers
+    DrawState draw;                // errmod_cal's generator and the plan of the next launches (draw.hip)
 };
 
 extern "C" {
@@ -480,6 +481,11 @@ static int enqueue_mpileup(bcfgpu_ctx *c, const bcfgpu_tile *tile, const bcfgpu_
     g.deep_list = c->d_deep_list; g.deep_ctr = reinterpret_cast<uint32_t*>(c->d_err + 2); g.deep_keys = c->d_deep_keys;
     g.deep_cap = c->deep_cap; g.deep_key_cap = c->deep_key_cap;
     g.keys = c->d_keys;
+    {   // the plan bcfgpu_errmod_plan made for this pass of this tile, if any: it serves this one launch
+        const int kind = tile->is_indel ? 1 : 0;
+        g.draw_bits = (c->draw.rd[kind] && c->draw.rd[kind] == tile->rd) ? c->draw.bits[kind] : nullptr;
+        c->draw.rd[kind] = nullptr;
+    }
     g.wide_ctr = reinterpret_cast<uint32_t*>(c->d_err + 5); g.wide_cap = c->wide_cap;
     HIPCHK(hipMemsetAsync(c->d_err + 2, 0, 4 * sizeof(int), c->stream));
 #ifdef BCFGPU_DIAG
@@ -619,6 +625,7 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
 }
 
 bcfgpu_gap_stats *bcfgpu_internal_gap_stats(bcfgpu_ctx *c) { return &c->gap; }
+DrawState *bcfgpu_internal_draw_state(bcfgpu_ctx *c) { return &c->draw; }
 const bcfgpu_cfg *bcfgpu_internal_cfg(const bcfgpu_ctx *c) { return c ? &c->cfg : nullptr; }
 void *bcfgpu_internal_pileup_state(bcfgpu_ctx *c) { return c ? c->pileup_state : nullptr; }
 void *bcfgpu_internal_pool_state(bcfgpu_ctx *c) { return c ? c->pool_state : nullptr; }
@@ -626,7 +633,7 @@ void *bcfgpu_internal_pool_state(bcfgpu_ctx *c) { return c ? c->pool_state : nul
 // workspace `slot` of at least `bytes` (contents undefined); nullptr when the allocation fails
 void *bcfgpu_internal_ws(bcfgpu_ctx *c, int slot, size_t bytes)
 {
-    if (!c || slot < 0 || slot >= 136) return nullptr;
+    if (!c || slot < 0 || slot >= 144) return nullptr;
     auto &w = c->ws[slot];
     if (w.bytes >= bytes && w.p) return w.p;
     hipSetDevice(c->cfg.device);

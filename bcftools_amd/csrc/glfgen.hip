@@ -588,6 +588,14 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ?
                 if (nus > BCFGPU_MAX_DEPTH) {
                     uint32_t qs[4] = {0, 0, 0, 0}, af[4] = {0, 0, 0, 0}, ar[4] = {0, 0, 0, 0}, cn[4] = {0, 0, 0, 0}, sc = 0, acc = 0;
                     const bool all_diff = !INDEL && ref4c >= 4;
+                    // which 255 feed the likelihoods: the ones bcfgpu_errmod_plan drew for this cell (draw.hip: its bitmap has
+                    // exactly 255 of the cell's usable reads marked), else the first 255
+                    bool planned = false;
+                    if (P.draw_bits) {
+                        uint32_t nm = 0;
+                        for (int i = 0; i < cnt_raw; ++i) { const uint32_t ri = beg + (uint32_t)i; nm += (kp_w[i] != 0 && ((P.draw_bits[ri >> 5] >> (ri & 31)) & 1u)) ? 1u : 0u; }
+                        planned = nm == BCFGPU_MAX_DEPTH;
+                    }
                     for (int i = 0; i < cnt_raw; ++i) {
                         const uint32_t k = kp_w[i];
                         if (k == 0) continue;
@@ -600,7 +608,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ?
                             cn[x] += dr == x ? 1u : 0u;
                         }
                         sc += KEY_SC(k);
-                        if (++acc > BCFGPU_MAX_DEPTH) kp_w[i] = 0;
+                        bool stays = ++acc <= BCFGPU_MAX_DEPTH;
+                        if (planned) { const uint32_t ri = beg + (uint32_t)i; stays = ((P.draw_bits[ri >> 5] >> (ri & 31)) & 1u) != 0; }
+                        if (!stays) kp_w[i] = 0;
                     }
                     const uint32_t slot = atomicAdd(P.wide_ctr, 1u);
                     const uint32_t big = af[0] | af[1] | af[2] | af[3] | ar[0] | ar[1] | ar[2] | ar[3] | cn[0] | cn[1] | cn[2] | cn[3] | sc;
@@ -614,7 +624,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ?
                         qs64_p[cell] = WIDE_QS_MARK | slot;      // where combine_kernel's frequency pass finds the record
                         mark = CR_WIDE;
                     }
-                    atomicAdd(P.trunc, 1u);
+                    if (!planned) atomicAdd(P.trunc, 1u);
                 }
                 misc_p[cell] = mark;             // read back where the cell's planes are stored (below)
             }

@@ -83,6 +83,7 @@ struct GlfgenParams {
     int *err;                       // device error word
     unsigned int *trunc;            // cells whose likelihoods come from their first 255 usable reads (counter)
     uint32_t *wide_ctr;             // [0] WideRecs handed out by this launch (zeroed before launch)
+    const uint32_t *draw_bits;      // NULL, or a bit per read of the tile: the 255 reads bcfgpu_errmod_plan drew for every over-deep cell
     uint32_t wide_cap;              // records in crp->wide
     // cells whose pileup does not fit the LDS key window: listed by the tile launch, worked on by the launch that follows
     uint32_t *deep_list;            // [deep_cap][2]: cell, offset of its keys in deep_keys
@@ -93,6 +94,14 @@ struct GlfgenParams {
 #ifdef BCFGPU_DIAG
     unsigned long long *stamps;     // [16] cycle totals per kernel phase
 #endif
+};
+
+// errmod_cal's draw for over-deep cells (draw.hip): the generator's position, and the plan of the passes about to run
+struct DrawState {
+    uint64_t x = 0x1234ABCD330EULL;      // hts_drand48's state: htslib's default seed in a fresh process
+    const uint32_t *rd[2] = {nullptr, nullptr};   // the read records of the planned SNP / indel tile (a plan serves one launch per pass)
+    uint32_t *bits[2] = {nullptr, nullptr};       // their bitmaps
+    uint32_t n_planned = 0;
 };
 
 struct CombineParams {

@@ -156,6 +156,35 @@ class Context:
             self.release(tb + list(ob.values()))
         return res
 
+    def mpileup_planned(self, snp, indel=None, cols=None, ret=None):
+        """bcfgpu_errmod_plan over the two passes of a tile, then bcfgpu_mpileup of each: the over-deep cells' likelihoods come from
+        errmod_cal's own draw (hts_drand48, the context's generator), in mpileup_reg()'s visit order.  snp / indel: HostTiles (indel
+        may be None); cols: the SNP-tile column of every indel site; ret: bcf_call_gap_prep's return per indel site (None: all 0).
+        Returns (MplpResult of the SNP pass, MplpResult of the indel pass or None)."""
+        ds, sb = self.upload_tile(snp)
+        di, ib = (self.upload_tile(indel) if indel is not None else (None, []))
+        outs = []
+        try:
+            c = None if cols is None else np.ascontiguousarray(cols, dtype=np.int32)
+            r = None if ret is None else np.ascontiguousarray(ret, dtype=np.int32)
+            check(self.L.bcfgpu_errmod_plan(self.h, C.byref(ds), C.byref(di) if di is not None else None,
+                                            None if c is None else c.ctypes.data, None if r is None else r.ctypes.data))
+            for dt, t in ((ds, snp), (di, indel)):
+                if dt is None:
+                    outs.append(None)
+                    continue
+                o, ob, res = self.alloc_mplp_out(t.n_sites)
+                for b in ob.values():
+                    check(self.L.bcfgpu_memset(self.h, b.ptr, 0, b.nbytes))
+                check(self.L.bcfgpu_mpileup(self.h, C.byref(dt), C.byref(o)))
+                self.sync()
+                self._download(ob, res)
+                self.release(list(ob.values()))
+                outs.append(res)
+        finally:
+            self.release(sb + ib)
+        return outs[0], outs[1]
+
     def gvcf_blocks(self, res, pos, dp_range, rid=None, brk=None):
         """gvcf_write over the records of a host MplpResult (bcfgpu_gvcf_blocks); returns a host GvcfResult."""
         n, S = res.n_sites, self.cfg.n_smpl

@@ -705,13 +705,15 @@ static bcfgpu_ctx *ctx; static int ctx_S, ctx_sites; static uint64_t ctx_reads; 
 static void ensure_ctx(int S, int n_sites, uint64_t n_reads)
 {
     if (ctx && ctx_S == S && n_sites <= ctx_sites && n_reads <= ctx_reads) return;
-    if (ctx) { uint32_t nw = 0; CHECK(bcfgpu_truncated_cells(ctx, &nw)); n_wide_cells += nw; bcfgpu_destroy(ctx); ctx = NULL; }
+    uint64_t rng = 0; int have_rng = 0;                                       /* errmod_cal's generator is the process's: it moves to the new context */
+    if (ctx) { uint32_t nw = 0; CHECK(bcfgpu_truncated_cells(ctx, &nw)); n_wide_cells += nw; rng = bcfgpu_errmod_state(ctx); have_rng = 1; bcfgpu_destroy(ctx); ctx = NULL; }
     bcfgpu_cfg cfg; memset(&cfg, 0, sizeof cfg);
     ctx_S = S; ctx_sites = n_sites > ctx_sites ? n_sites : ctx_sites; ctx_reads = n_reads + n_reads / 2 + 4096;
     cfg.device = device; cfg.n_smpl = S; cfg.max_sites = ctx_sites; cfg.max_reads = ctx_reads;   /* every base is in <= 1 column */
     cfg.min_baseQ = min_baseQ; cfg.capQ = 60; cfg.errmod_theta = 0.; cfg.fmt_flag = fmt_flag;
     cfg.call_theta = 1.1e-3; cfg.n_grp = 1; cfg.ploidy_max = 2;
     CHECK(bcfgpu_create(&cfg, &ctx));
+    if (have_rng) CHECK(bcfgpu_errmod_seed(ctx, rng));
 }
 
 /* ---- gVCF blocks across tiles (and adjacent regions): the reference's gvcf_write keeps a block open over any distance
@@ -812,12 +814,9 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
     uint8_t *col_indel = malloc((size_t)n_sites + 1);
     CHECK(bcfgpu_pool_pileup(ctx, P->smpl, NULL, t0, t1, ref, ref_len, &tile, col_n, col_indel));
     tot_entries += (unsigned long long)tile.n_reads;
-    void *d_site = NULL, *d_pl = NULL, *d_dp4 = NULL;
-    bcfgpu_site *site = NULL;
-    planes_t snp_planes;
-    run_mpileup(ctx, &tile, n_sites, &site, &snp_planes, gv_n ? &d_site : NULL, &d_pl, &d_dp4);
-
-    /* ---- indel records (mpileup.c:354-365): candidate columns -> bcf_call_gap_prep -> second pass with p->aux ---- */
+    /* ---- indel candidates (mpileup.c:354-365): candidate columns -> bcf_call_gap_prep.  Before either pass of bcf_call_glfgen runs:
+     * errmod_cal's draw for cells of more than 255 reads is planned over BOTH passes of the tile in the reference's visit order --
+     * position by position the SNP pass, then the indel pass where gap_prep returned >= 0 (bcfgpu_errmod_plan) ---- */
     int nc = 0;
     int32_t *cand = malloc((size_t)(n_sites + 1) * sizeof *cand);
     for (int k = 0; k < n_sites; ++k)
@@ -825,6 +824,8 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
     bcfgpu_site *isite = NULL;
     planes_t ind_planes; memset(&ind_planes, 0, sizeof ind_planes); int32_t *live = NULL; int nlive = 0;
     int32_t *g_types = NULL, *g_maxins = NULL, *g_indelreg = NULL, *g_support = NULL; float *g_frac = NULL; int8_t *g_inscns = NULL;
+    int32_t *gret = NULL;
+    bcfgpu_tile ti; memset(&ti, 0, sizeof ti);
     if (nc) {
         /* everything stays in HBM: the candidates' entries, the stage on the pool bcfgpu_pileup left there, p->aux straight
          * into the indel pass's tile over all candidate columns (the host pool is passed for its ZQ bytes) */
@@ -832,19 +833,24 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
         in.n_sites = nc; in.n_smpl = S; in.ref = ref;
         in.openQ = openQ; in.extQ = extQ; in.tandemQ = tandemQ; in.min_support = min_support; in.per_sample_flt = per_sample_flt; in.min_frac = min_frac;
         bcfgpu_indel_out out; memset(&out, 0, sizeof out);
-        int32_t *gret = malloc((size_t)nc * 4);
+        gret = malloc((size_t)nc * 4);
         g_types = malloc((size_t)nc * 16); g_inscns = malloc((size_t)nc * 4 * INSCNS_CAP); g_maxins = malloc((size_t)nc * 4);
         g_indelreg = malloc((size_t)nc * 4); g_support = malloc((size_t)nc * 4); g_frac = malloc((size_t)nc * 4);
         out.ret = gret; out.p_aux = NULL; out.indel_types = g_types; out.inscns = g_inscns; out.maxins = g_maxins;
         out.indelreg = g_indelreg; out.max_support = g_support; out.max_frac = g_frac;
-        bcfgpu_tile ti;
         /* (with BAQ the ZQ bytes are the pool's, in HBM; with -B the reads' own tags, if any, go up from the host) */
         CHECK(bcfgpu_gap_prep_tile(ctx, nc, cand, baq_flag ? NULL : &rd, &in, &out, INSCNS_CAP, &ti));
         live = malloc((size_t)nc * 4);
         for (int i = 0; i < nc; ++i) if (gret[i] == 0) live[nlive++] = i;
-        if (nlive) run_mpileup(ctx, &ti, nc, &isite, &ind_planes, NULL, NULL, NULL);      /* records of columns with ret < 0 are not used */
-        free(gret);
     }
+    CHECK(bcfgpu_errmod_plan(ctx, &tile, nlive ? &ti : NULL, cand, gret));
+    /* ---- the SNP pass, then the indel pass on the tile gap_prep left (records of columns with ret < 0 are not used) ---- */
+    void *d_site = NULL, *d_pl = NULL, *d_dp4 = NULL;
+    bcfgpu_site *site = NULL;
+    planes_t snp_planes;
+    run_mpileup(ctx, &tile, n_sites, &site, &snp_planes, gv_n ? &d_site : NULL, &d_pl, &d_dp4);
+    if (nlive) run_mpileup(ctx, &ti, nc, &isite, &ind_planes, NULL, NULL, NULL);
+    free(gret);
 
     /* ---- --gvcf: reference-only records collapse into blocks (gvcf_write, gvcf.c:88-226) on the planes still in HBM ---- */
     int32_t *gv_blk = NULL, *gv_dp = NULL; bcfgpu_gvcf_block *gv_block = NULL; uint8_t *gv_pl = NULL; int32_t nb = 0;
@@ -1417,8 +1423,8 @@ int main(int argc, char **argv)
     }
     pending_flush();
     if (ctx) { uint32_t nw = 0; CHECK(bcfgpu_truncated_cells(ctx, &nw)); n_wide_cells += nw; }
-    if (n_wide_cells) fprintf(stderr, "[bcfgpu_sam] note: %llu (site, sample) cells held more than 255 usable reads: their DP, AD, QS, I16 count every read, as bcftools' do; "
-                                      "their PLs come from the first 255 reads where bcftools' errmod_cal draws 255 at random\n", n_wide_cells);
+    if (n_wide_cells) fprintf(stderr, "[bcfgpu_sam] note: %llu (site, sample) cells of more than 255 usable reads were left to the first-255 rule "
+                                      "(columns whose indel pass does not run); every other such cell got errmod_cal's own draw\n", n_wide_cells);
     fprintf(stderr, "%llu reads of %d samples, %llu overlapping pairs, %llu pileup entries in %llu columns (%d tiles of <= %d)\n",
             n_reads_tot, S, tot_pairs, tot_entries, n_cols_tot, n_tiles, tile_cols);
     if (vio_close(fout)) DIE("%s\n", vio_error());

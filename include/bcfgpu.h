@@ -265,9 +265,26 @@ int  bcfgpu_host_free(void *ptr);
  * shuffles such a cell's reads with hts_drand48 and keeps 255 -- a draw from a process-wide generator that depends on the
  * order in which the whole run visits its cells.  Here the LIKELIHOODS of such a cell (p[25], hence its PLs) come from its
  * first 255 usable reads; everything else the reference computes over all reads -- DP4, AD/ADF/ADR, QS, SCR, I16, the bias-test
- * histograms, depth -- is over all reads here too.  The counter tells how many cells' PLs may deviate from a reference run.
+ * histograms, depth -- is over all reads here too.  The counter tells how many cells' PLs may deviate from a reference run
+ * (cells that bcfgpu_errmod_plan drew for are not counted: see there).
  * With mpileup's default -d 250 per file (bcfgpu_depth_cap) such cells arise only where the cap lets reads through. */
 int  bcfgpu_truncated_cells(bcfgpu_ctx *ctx, uint32_t *n_cells);
+/* errmod_cal's own rule for such cells: the random draw, replayed.  hts_drand48 is a 48-bit linear congruential generator,
+ * one per process, started from htslib's default seed; a cell of n > 255 reads takes n - 1 numbers from it (ks_shuffle) and
+ * keeps the first 255 of the shuffled order; the cells draw in the order mpileup_reg() visits them -- position by position,
+ * the samples of the SNP pass, then the samples of the indel pass where bcf_call_gap_prep returned >= 0 (mpileup.c:343-360).
+ * bcfgpu_errmod_plan ranks the over-deep cells of a tile's two passes in that order, jumps the generator to each cell's place
+ * and marks the 255 reads it keeps; the NEXT bcfgpu_mpileup / bcfgpu_pipeline of each of the two tiles uses the marks (its
+ * likelihoods are then errmod_cal's, and bcfgpu_truncated_cells does not count those cells), and the context's generator
+ * moves on by the numbers drawn, as the process-wide one does.
+ *   snp     the SNP pass's tile (or NULL);  indel  the indel pass's tile as bcfgpu_gap_prep_tile left it (or NULL)
+ *   indel_cols  HOST [indel->n_sites]: the SNP-tile column of every site of the indel tile (the `cols` of bcfgpu_gap_prep_tile)
+ *   indel_ret   HOST [indel->n_sites] or NULL: bcf_call_gap_prep's return values -- only sites with 0 are visited
+ * Synchronises the stream.  Without a plan the first 255 usable reads of such a cell are taken (see above).
+ * bcfgpu_errmod_seed / _state: the generator's 48-bit state (a new context starts at 0x1234ABCD330E, a fresh process). */
+int  bcfgpu_errmod_plan(bcfgpu_ctx *ctx, const bcfgpu_tile *snp, const bcfgpu_tile *indel, const int32_t *indel_cols, const int32_t *indel_ret);
+int  bcfgpu_errmod_seed(bcfgpu_ctx *ctx, uint64_t state);
+uint64_t bcfgpu_errmod_state(bcfgpu_ctx *ctx);
 /* enqueue on an externally owned hipStream_t (e.g. torch's current stream); NULL = the context's own */
 int  bcfgpu_set_stream(bcfgpu_ctx *ctx, void *hip_stream);
 

@@ -87,13 +87,14 @@ def gvcf_blocks(res, pos, dp_range, rid=None, brk=None):
     return GvcfResult(nb, blk, min_dp, block, dpo, plo)
 
 
-def mpileup(cfg, tile, want_callret=False, deep_rule=1):
+def mpileup(cfg, tile, want_callret=False, deep_rule=1, reset=True):
     """Run the oracle's mpileup stage on a HostTile.  deep_rule: what errmod_cal does to a cell of more than 255 usable reads --
     1 (default here): the first 255 in pileup order, the rule of the device library when it is not told where the reference's
     generator stands; 0: the reference's own ks_shuffle draw from a freshly started hts_drand48 (oracle/errmod.c).  Every count,
     QS, I16 sum and histogram is over all reads under either rule."""
     lib().orc_errmod_deep_rule(int(deep_rule))
-    lib().orc_srand48_reset()
+    if reset:                                # (reset=False: the generator goes on from where the last call left it, as the process-wide one does)
+        lib().orc_srand48_reset()
     res = MplpResult(tile.n_sites, tile.n_smpl)
     t, o = tile.as_struct(), res.as_struct()
     cr = np.zeros(tile.n_sites * tile.n_smpl, dtype=CALLRET_DTYPE) if want_callret else None

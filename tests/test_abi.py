@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     L = lib.load()
     hdr = open(os.path.join(ROOT, "include", "bcfgpu.h")).read()
-    declared = set(re.findall(r"^(?:int|void|size_t|const char|bcfgpu_[a-z_]+)\s+\*?(bcfgpu_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void|size_t|uint64_t|const char|bcfgpu_[a-z_]+)\s+\*?(bcfgpu_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
     assert declared, "no declarations found"
     for name in declared:
         assert hasattr(L, name), "libbcfgpu.so does not export %s" % name

@@ -1,0 +1,91 @@
+"""errmod_cal's random draw for cells of more than 255 usable reads, replayed on the device (bcfgpu_errmod_plan, csrc/draw.hip):
+hts_drand48 is one generator per process and mpileup_reg() visits, position by position, the samples of the SNP pass and then
+the samples of the indel pass where bcf_call_gap_prep returned >= 0 (mpileup.c:343-360).  The oracle (oracle/errmod.c, rule 0)
+is run in exactly that order, one site at a time, its generator going on from call to call; the device ranks the deep cells of
+both passes, jumps the generator to each cell's place and must give the same PLs, bit for bit.  PARITY UNPINNED at the root
+(both sides restate htslib's published hts_drand48 / ks_shuffle; tests/test_oracle_errmod_deep.py checks the oracle's
+against libc)."""
+import numpy as np
+import pytest
+
+from bcftools_amd import abi, host
+from tests.helpers import orc
+from tests.test_gpu_parity import assert_mplp_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _tile(rng, n_sites, n_smpl, depths, is_indel=False):
+    R = int(np.sum(depths))
+    rd = (rng.choice([11, 25, 37, 40], R) | (rng.choice([0, 20, 60, 60, 60], R) << 8) | ((1 << rng.integers(0, 4, R)) << 16)
+          | (rng.integers(0, 2, R) << 20) | (rng.integers(0, 40, R) << 24)).astype(np.uint32)
+    aux = None
+    if is_indel:
+        aux = (rng.choice([0, 0, 0, 1, 2], R).astype(np.uint32) << 16) | (rng.integers(20, 60, R).astype(np.uint32) << 8) | rng.integers(5, 60, R).astype(np.uint32)
+    return host.HostTile(n_smpl, rng.choice([1, 2, 4, 8], n_sites).astype(np.int8), np.r_[0, np.cumsum(depths)].astype(np.uint32), rd,
+                         rng.integers(0, 100, R).astype(np.uint8), aux=aux, is_indel=1 if is_indel else 0)
+
+
+def _oracle_in_visit_order(cfg, snp, indel, cols, ret):
+    """The reference's loop: per position the SNP pass, then the indel pass of that position if it runs; one generator."""
+    want_s, want_i = host.MplpResult(snp.n_sites, snp.n_smpl), (host.MplpResult(indel.n_sites, indel.n_smpl) if indel is not None else None)
+    col_of = {int(c): i for i, c in enumerate(cols)} if indel is not None else {}
+    first = True
+    for k in range(snp.n_sites):
+        r = orc.mpileup(cfg, snp.select_sites([k]), deep_rule=0, reset=first)
+        first = False
+        for name in ("site", "pl", "dp4", "adf", "adr", "qs", "scr", "sp"):
+            getattr(want_s, name)[k] = getattr(r, name)[0]
+        if k in col_of and ret[col_of[k]] == 0:
+            i = col_of[k]
+            r = orc.mpileup(cfg, indel.select_sites([i]), deep_rule=0, reset=False)
+            for name in ("site", "pl", "dp4", "adf", "adr", "qs", "scr", "sp"):
+                getattr(want_i, name)[i] = getattr(r, name)[0]
+    return want_s, want_i, int(orc.lib().orc_rand48_state())
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_draw_of_both_passes_in_visit_order(gpu_ctx_factory, seed):
+    rng = np.random.default_rng(seed)
+    n_smpl, n_sites = 3, 6
+    ds = rng.poisson(40, n_sites * n_smpl)
+    for c in (1, 5, 6, 11, 16):                                  # deep cells scattered over the SNP pass
+        ds[c] = rng.integers(300, 1500)
+    snp = _tile(rng, n_sites, n_smpl, ds)
+    cols = np.array([1, 3, 4], np.int32)
+    ret = np.array([0, -1, 0], np.int32)                         # the indel pass runs at columns 1 and 4 only
+    di = rng.poisson(40, len(cols) * n_smpl)
+    for c in (0, 2, 4, 7):                                       # deep cells in the indel pass too, one of them (4) at the column without a pass
+        di[c] = rng.integers(300, 900)
+    indel = _tile(rng, len(cols), n_smpl, di, is_indel=True)
+    flags = abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD | abi.FMT_QS
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=max(len(snp.rd), len(indel.rd)), fmt_flag=flags)
+    ctx = gpu_ctx_factory(cfg)
+    want_s, want_i, state = _oracle_in_visit_order(cfg, snp, indel, cols, ret)
+    got_s, got_i = ctx.mpileup_planned(snp, indel, cols, ret)
+    assert_mplp_equal(got_s, want_s)
+    live = ret == 0
+    for k in ("pl", "dp4", "adf", "adr", "qs"):
+        np.testing.assert_array_equal(getattr(got_i, k)[live], getattr(want_i, k)[live], err_msg="indel pass " + k)
+    np.testing.assert_array_equal(got_i.site["shift"][live], want_i.site["shift"][live])
+    assert int(ctx.L.bcfgpu_errmod_state(ctx.h)) == state       # the generator stands where the reference's would
+    n = abi.C.c_uint32()
+    assert ctx.L.bcfgpu_truncated_cells(ctx.h, abi.C.byref(n)) == 0
+    assert n.value == 1                                          # only the deep cell of the column whose indel pass does not run was left to the first-255 rule
+    # the next tile goes on with the same generator: the same tile again draws other reads
+    got2, _ = ctx.mpileup_planned(snp)
+    assert not np.array_equal(got2.pl, got_s.pl)
+    first = orc.mpileup(cfg, snp, deep_rule=0)                    # a fresh process on the SNP pass alone ...
+    ctx.L.bcfgpu_errmod_seed(ctx.h, 0x1234ABCD330E)
+    got3, _ = ctx.mpileup_planned(snp)                           # ... is what a re-seeded context gives
+    assert_mplp_equal(got3, first)
+
+
+def test_without_a_plan_the_first_255_are_taken(gpu_ctx_factory):
+    rng = np.random.default_rng(9)
+    snp = _tile(rng, 2, 2, [400, 30, 20, 700])
+    cfg = abi.default_cfg(2, max_sites=2, max_reads=len(snp.rd))
+    ctx = gpu_ctx_factory(cfg)
+    assert_mplp_equal(ctx.mpileup(snp), orc.mpileup(cfg, snp, deep_rule=1))
+    n = abi.C.c_uint32()
+    assert ctx.L.bcfgpu_truncated_cells(ctx.h, abi.C.byref(n)) == 0 and n.value == 2
