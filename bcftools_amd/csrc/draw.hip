@@ -58,6 +58,7 @@ struct DrawScanParams {
     const int32_t *cols;            // indel pass: SNP-tile column of every site; NULL for the SNP pass
     const int32_t *ret;             // indel pass: bcf_call_gap_prep's return per site (only 0 is visited); NULL = all
     DrawEnt *ent; uint32_t *n_ent; uint32_t cap;
+    uint32_t *bits;                 // the pass's bitmap (for the cells of columns without an indel pass)
     unsigned long long *tot_usable;
 };
 
@@ -77,10 +78,17 @@ __global__ __launch_bounds__(256) void draw_scan_kernel(const DrawScanParams P)
     const uint32_t b = P.off[cell], e = P.off[cell + 1];
     if (e - b <= BCFGPU_MAX_DEPTH) return;
     const int site = (int)(cell / P.n_smpl), s = (int)(cell - (long)site * P.n_smpl);
-    if (P.is_indel && P.ret && P.ret[site] != 0) return;                      // the indel pass does not run there (mpileup.c:354)
     uint32_t n = 0;
     for (uint32_t i = b; i < e; ++i) n += draw_usable(P.rd[i], P.is_indel != 0, (uint32_t)P.min_baseQ) ? 1u : 0u;
     if (n <= BCFGPU_MAX_DEPTH) return;
+    if (P.is_indel && P.ret && P.ret[site] != 0) {
+        // the indel pass does not run there (mpileup.c:354): no draw is spent on the cell and nothing of it is written out; its
+        // first 255 usable reads are marked so that the likelihood kernel has a complete plan and counts nothing as cut
+        uint32_t m = 0;
+        for (uint32_t i = b; i < e && m < BCFGPU_MAX_DEPTH; ++i)
+            if (draw_usable(P.rd[i], true, (uint32_t)P.min_baseQ)) { atomicOr(&P.bits[i >> 5], 1u << (i & 31)); ++m; }
+        return;
+    }
     const uint32_t slot = atomicAdd(P.n_ent, 1u);
     if (slot >= P.cap) return;
     const long col = P.cols ? P.cols[site] : site;
@@ -166,7 +174,7 @@ extern "C" int bcfgpu_errmod_plan(bcfgpu_ctx *ctx, const bcfgpu_tile *snp, const
         DrawScanParams Q{};
         Q.n_sites = tiles[t]->n_sites; Q.n_smpl = S; Q.is_indel = t; Q.min_baseQ = cfg->min_baseQ < 0 ? 0 : cfg->min_baseQ;
         Q.off = tiles[t]->plp_off; Q.rd = tiles[t]->rd; Q.cols = t ? d_cols : nullptr; Q.ret = t ? d_ret : nullptr;
-        Q.ent = d_ent; Q.n_ent = reinterpret_cast<uint32_t*>(d_ctr); Q.cap = cap; Q.tot_usable = d_ctr + 1;
+        Q.bits = bits[t]; Q.ent = d_ent; Q.n_ent = reinterpret_cast<uint32_t*>(d_ctr); Q.cap = cap; Q.tot_usable = d_ctr + 1;
         const long ncells = (long)Q.n_sites * S;
         hipLaunchKernelGGL(draw_scan_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, stream, Q);
     }

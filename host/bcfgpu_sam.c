@@ -1424,7 +1424,7 @@ int main(int argc, char **argv)
     pending_flush();
     if (ctx) { uint32_t nw = 0; CHECK(bcfgpu_truncated_cells(ctx, &nw)); n_wide_cells += nw; }
     if (n_wide_cells) fprintf(stderr, "[bcfgpu_sam] note: %llu (site, sample) cells of more than 255 usable reads were left to the first-255 rule "
-                                      "(columns whose indel pass does not run); every other such cell got errmod_cal's own draw\n", n_wide_cells);
+                                      "instead of errmod_cal's draw\n", n_wide_cells);
     fprintf(stderr, "%llu reads of %d samples, %llu overlapping pairs, %llu pileup entries in %llu columns (%d tiles of <= %d)\n",
             n_reads_tot, S, tot_pairs, tot_entries, n_cols_tot, n_tiles, tile_cols);
     if (vio_close(fout)) DIE("%s\n", vio_error());

@@ -462,3 +462,51 @@ def test_c_call_driver_constrained_alleles(golden_dir, vcff, goldf, tab, ins):
     cmd = [CALL_EXE, "-m", "-A", "-C", "alleles", "-T", os.path.join(G, tab)] + (["-i"] if ins else []) + [os.path.join(G, vcff)]
     out = whole_file_checks(cmd, os.path.join(G, goldf))
     assert sum(1 for ln in out.splitlines() if not ln.startswith("#")) > 0
+
+
+def _deep_sam(path, ref, sample, seed, n_reads, lo, hi, rlen=100):
+    """n_reads reads of one sample over [lo, hi) of contig 17: the reference's bases with a few mismatches, some reads with a
+    2-base insertion or a 3-base deletion at a common place, so that both passes have cells of several hundred usable reads."""
+    rng = np.random.default_rng(seed)
+    with open(path, "w") as f:
+        f.write("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:17\tLN:%d\n@RG\tID:%s\tSM:%s\n" % (len(ref), sample, sample))
+        for i, pos in enumerate(sorted(int(x) for x in rng.integers(lo, hi, n_reads))):
+            seq = list(ref[pos:pos + rlen + 3])
+            for k in np.flatnonzero(rng.random(len(seq)) < 0.01):
+                seq[k] = "ACGT"[int(rng.integers(0, 4))]
+            cut = (lo + hi) // 2 + 20 - pos                       # the indels sit at one reference position
+            kind = rng.choice(3, p=[0.7, 0.15, 0.15]) if 10 < cut < rlen - 10 else 0
+            if kind == 1:
+                seq, cig = seq[:cut] + ["G", "T"] + seq[cut:rlen - 2], "%dM2I%dM" % (cut, rlen - 2 - cut)
+            elif kind == 2:
+                seq, cig = seq[:cut] + seq[cut + 3:rlen + 3], "%dM3D%dM" % (cut, rlen - cut)
+            else:
+                seq, cig = seq[:rlen], "%dM" % rlen
+            qual = "".join(chr(33 + int(q)) for q in rng.integers(15, 41, rlen))
+            f.write("r%d\t%d\t17\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\tRG:Z:%s\n" % (i, 16 * int(rng.integers(0, 2)), pos + 1, int(rng.choice([20, 40, 60])),
+                                                                         cig, "".join(seq), qual, sample))
+
+
+@pytest.mark.gpu
+def test_c_sam_driver_draw_does_not_depend_on_the_tiles(golden_dir, tmp_path):
+    """Cells of more than 255 usable reads (-d 10000, and -L 10000 so that indels are called at that depth): bcfgpu_sam plans errmod_cal's draw for every tile (bcfgpu_errmod_plan) and
+    the generator goes on from tile to tile as it goes on from position to position in one mpileup process, so the records
+    cannot depend on where the tiles are cut; none of the cells is left to the first-255 rule."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    ref = "".join(ln.strip() for ln in open(os.path.join(G, "mpileup.ref.fa")) if not ln.startswith(">"))
+    files = []
+    for s, (name, n) in enumerate((("deepA", 900), ("deepB", 500))):
+        files.append(str(tmp_path / (name + ".sam")))
+        _deep_sam(files[-1], ref, name, 40 + s, n, 1000, 1150)
+    outs = []
+    for tile in (None, 16, 50):
+        cmd = [SAM_EXE, "-d", "10000", "-L", "10000", "-a", "AD,DP"] + (["--tile", str(tile)] if tile else []) + ["-f", os.path.join(G, "mpileup.ref.fa"), "-r", "17:990-1260"] + files
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        assert "first 255" not in p.stderr, p.stderr
+        outs.append([ln for ln in p.stdout.splitlines() if not ln.startswith("##")])
+    recs = [ln.split("\t") for ln in outs[0][1:]]
+    deep = [r for r in recs if max(int(x.split(":")[r[8].split(":").index("DP")]) for x in r[9:]) > 255]
+    assert len(deep) > 100 and any("INDEL" in r[7] for r in deep)          # FORMAT/DP past 255 in both kinds of record
+    assert outs[1] == outs[0] and outs[2] == outs[0]
