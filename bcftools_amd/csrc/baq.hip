@@ -189,7 +189,11 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
     const int wl = job & 63;
     // (M and I of a cell side by side in a lane's 16 bytes: one dwordx4 store / load per cell -- the phase is bound by the
     // issue of its vector-memory instructions, and there are half as many this way)
+#ifdef BAQ_EXP_ROWMASK      // experiment (tools/file_variants.sh): the rows folded onto a few, so that the scratch stays in cache -- wrong results, the time says what HBM costs
+    #define FR2(i, p) reinterpret_cast<double2*>(P.F)[((wbase + (size_t)((i) & BAQ_EXP_ROWMASK)) * NP + (size_t)(p)) * 64 + wl]
+#else
     #define FR2(i, p) reinterpret_cast<double2*>(P.F)[((wbase + (size_t)(i)) * NP + (size_t)(p)) * 64 + wl]
+#endif
     #define SC(i) P.S[(wbase + (size_t)(i)) * 64 + wl]
     const int bw2 = bw * 2 + 1;
     const double d = 0.001, e_ = 0.1;
@@ -281,6 +285,9 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
         #pragma unroll
         for (int p = 1; p < NP; ++p) {
             M[p] *= r; I[p] *= r; D[p] *= r;
+#ifdef BAQ_EXP_NOSTORE       // experiment: the forward rows are not written (never true at run time)
+            if (P.n_jobs < 0)
+#endif
             FR2(i, p) = make_double2(M[p], I[p]);
         }
     }
@@ -293,6 +300,9 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
             if (p >= plo && p <= phi) sum += M[p] * sM + I[p] * sI;
         SC(l_query + 1) = sum;
     }
+#if defined(BAQ_EXP_PHASE) && BAQ_EXP_PHASE == 1   // experiment: the forward pass only
+    if (l_query > 0) { q[0] = (uint8_t)M[1]; return; }
+#endif
     // ---- backward with the posterior maximum of every row ----
     // x is max(0, l_query - bw) here.  Row l_query:
     {
@@ -487,7 +497,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAQ_WAVES, 8
         if (bw < abs(j.l_ref - j.l_query)) bw = abs(j.l_ref - j.l_query);
         baq_fb_reg<(BWM > 0 ? BWM : 1)>(P, job, j, ref, seq, iqual, bw, state, q, s_q2p);
     } else baq_fb_scratch(P, job, j, ref, seq, iqual, state, q);
+#if !defined(BAQ_EXP_PHASE) || BAQ_EXP_PHASE == 0
     baq_cap(P, j, iqual, state, q, qout, zout);
+#endif
 }
 
 // ---- the same stage on the pool bcfgpu_pool_upload left in HBM: the host half above as a kernel ----
@@ -775,7 +787,7 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
         P.ncell = reg ? 2 * (2 * (c ? BAQ_BWM2 : BAQ_BWM) + 3) : 3 * (2 * counts[2] + 1) + 6;       // doubles per matrix row
         const size_t per_mat = (size_t)(P.max_lq + 2) * P.ncell * sizeof(double);  // one matrix of one read
         const size_t per_job = reg ? per_mat : 2 * per_mat;
-        size_t chunk = ((size_t)8 << 30) / per_job;                                // (8 GiB of scratch: 288 GB of HBM are there to be used)
+        size_t chunk = ((size_t)24 << 30) / per_job;                               // (up to 24 GiB of scratch of the 288 GB: one launch for ~9e5 reads of 100 bases -- every launch ends with a round of wavefronts that does not fill the chip)
         chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
         if (chunk > nj) chunk = (nj + 63) & ~(size_t)63;
         P.stride = chunk;

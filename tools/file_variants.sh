@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 SRC=$1; PAT=$2; BARGS=$3; shift 3
 : > $R/gpurun_out/filevar.txt
-OBJS="glfgen.o combine.o mcall.o indel.o gap_prep.o baq.o overlap.o pileup.o gvcf.o gather.o capmapq.o api.o tables.o"
+OBJS="glfgen.o combine.o mcall.o indel.o gap_prep.o baq.o overlap.o pileup.o gvcf.o gather.o capmapq.o draw.o api.o tables.o"
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   cd $R/bcftools_amd/csrc

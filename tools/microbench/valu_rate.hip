@@ -120,6 +120,26 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned *out, int reps, unsi
             if (KIND == 85) OP8_FMT("v_writelane_b32 %0, s10, 3", "v_writelane_b32 %1, s10, 3", "v_writelane_b32 %2, s10, 3", "v_writelane_b32 %3, s10, 3",
                                     "v_writelane_b32 %4, s10, 3", "v_writelane_b32 %5, s10, 3", "v_writelane_b32 %6, s10, 3", "v_writelane_b32 %7, s10, 3");
             if (KIND == 86) OP8_64("v_fma_f64 %0, %0, %8, %8\n;");
+            if (KIND == 100) OP8_64("v_mul_f64");
+            if (KIND == 101) OP8_64("v_add_f64");
+            if (KIND == 102) asm volatile("v_mul_f64 %0, %0, %1\nv_mul_f64 %0, %0, %1\nv_mul_f64 %0, %0, %1\nv_mul_f64 %0, %0, %1\n"
+                                          "v_mul_f64 %0, %0, %1\nv_mul_f64 %0, %0, %1\nv_mul_f64 %0, %0, %1\nv_mul_f64 %0, %0, %1\n" : "+v"(d0) : "v"(dc));   // one dependent chain
+            if (KIND == 103) asm volatile("v_add_f64 %0, %0, %1\nv_add_f64 %0, %0, %1\nv_add_f64 %0, %0, %1\nv_add_f64 %0, %0, %1\n"
+                                          "v_add_f64 %0, %0, %1\nv_add_f64 %0, %0, %1\nv_add_f64 %0, %0, %1\nv_add_f64 %0, %0, %1\n" : "+v"(d0) : "v"(dc));
+            if (KIND == 104) asm volatile("v_mul_f64 %0, %0, %2\nv_mul_f64 %1, %1, %2\nv_mul_f64 %0, %0, %2\nv_mul_f64 %1, %1, %2\n"
+                                          "v_mul_f64 %0, %0, %2\nv_mul_f64 %1, %1, %2\nv_mul_f64 %0, %0, %2\nv_mul_f64 %1, %1, %2\n" : "+v"(d0), "+v"(d1) : "v"(dc));   // two chains
+            if (KIND == 105) asm volatile("v_mul_f64 %0, %0, %1\nv_add_f64 %0, %0, %1\nv_mul_f64 %0, %0, %1\nv_add_f64 %0, %0, %1\n"
+                                          "v_mul_f64 %0, %0, %1\nv_add_f64 %0, %0, %1\nv_mul_f64 %0, %0, %1\nv_add_f64 %0, %0, %1\n" : "+v"(d0) : "v"(dc));   // mul -> add chain (the D recurrence)
+            if (KIND == 106) asm volatile("v_cmp_gt_f64 vcc, %0, %1\nv_cndmask_b32 %2, %2, %3, vcc\nv_cmp_gt_f64 vcc, %1, %0\nv_cndmask_b32 %2, %2, %3, vcc\n"
+                                          "v_cmp_gt_f64 vcc, %0, %1\nv_cndmask_b32 %2, %2, %3, vcc\nv_cmp_gt_f64 vcc, %1, %0\nv_cndmask_b32 %2, %2, %3, vcc\n" : "+v"(d0), "+v"(d1), "+v"(a0) : "v"(c) : "vcc");
+            if (KIND == 107) OP8_FMT("v_cmp_lt_u32_e32 vcc, %0, %8", "s_nop 4", "v_cndmask_b32_e32 %2, %2, %8, vcc", "v_cndmask_b32_e32 %3, %3, %8, vcc",
+                                     "v_cndmask_b32_e32 %4, %4, %8, vcc", "v_cndmask_b32_e32 %5, %5, %8, vcc", "v_cndmask_b32_e32 %6, %6, %8, vcc", "v_cndmask_b32_e32 %7, %7, %8, vcc");
+            if (KIND == 108) OP8_FMT("v_cmp_lt_u32_e32 vcc, %0, %8", "v_add_u32 %1, %1, %8", "v_cndmask_b32_e32 %2, %2, %8, vcc", "v_add_u32 %3, %3, %8",
+                                     "v_cndmask_b32_e32 %4, %4, %8, vcc", "v_add_u32 %5, %5, %8", "v_cndmask_b32_e32 %6, %6, %8, vcc", "v_add_u32 %7, %7, %8");
+            if (KIND == 109) OP8_FMT("v_cmp_lt_u32_e64 s[10:11], %0, %8", "v_cndmask_b32_e64 %1, %1, %8, s[10:11]", "v_cndmask_b32_e64 %2, %2, %8, s[10:11]", "v_cndmask_b32_e64 %3, %3, %8, s[10:11]",
+                                     "v_cndmask_b32_e64 %4, %4, %8, s[10:11]", "v_cndmask_b32_e64 %5, %5, %8, s[10:11]", "v_cndmask_b32_e64 %6, %6, %8, s[10:11]", "v_cndmask_b32_e64 %7, %7, %8, s[10:11]");
+            if (KIND == 110) OP8_FMT("s_and_saveexec_b64 s[10:11], vcc", "v_add_u32 %1, %1, %8", "s_or_b64 exec, exec, s[10:11]", "v_add_u32 %3, %3, %8",
+                                     "s_and_saveexec_b64 s[12:13], vcc", "v_add_u32 %5, %5, %8", "s_or_b64 exec, exec, s[12:13]", "v_add_u32 %7, %7, %8");      // exec-mask toggles around single VALU ops
             if (KIND == 88) OP8_32("v_fmac_f32");
             if (KIND == 89) OP8_3("v_dot4_u32_u8");
             if (KIND == 90) OP8_32("v_pk_add_u16 %0, %0, %8\n;");
@@ -267,6 +287,17 @@ int main(int argc, char **argv)
     run<80>("v_lshlrev_b64", d_out, n, ghz);
     run<81>("v_lshrrev_b64", d_out, n, ghz);
     run<86>("v_fma_f64", d_out, n, ghz);
+    run<100>("v_mul_f64", d_out, n, ghz);
+    run<101>("v_add_f64", d_out, n, ghz);
+    run<102>("mul_f64 chain", d_out, n, ghz);
+    run<103>("add_f64 chain", d_out, n, ghz);
+    run<104>("mul_f64 2 chains", d_out, n, ghz);
+    run<105>("mul>add f64 chain", d_out, n, ghz);
+    run<106>("cmp_f64>cnd", d_out, n, ghz);
+    run<107>("cmp,nop,6 cnd vcc", d_out, n, ghz);
+    run<108>("cmp,add,cnd vcc..", d_out, n, ghz);
+    run<109>("cmp, 7 cnd sgpr", d_out, n, ghz);
+    run<110>("saveexec toggles", d_out, n, ghz);
     run<3>("v_add_f64", d_out, n, ghz);
     run<4>("v_mul_f64", d_out, n, ghz);
     return 0;
