@@ -138,6 +138,13 @@ __global__ __launch_bounds__(256) void rate_kernel(unsigned *out, int reps, unsi
                                      "v_cndmask_b32_e32 %4, %4, %8, vcc", "v_add_u32 %5, %5, %8", "v_cndmask_b32_e32 %6, %6, %8, vcc", "v_add_u32 %7, %7, %8");
             if (KIND == 109) OP8_FMT("v_cmp_lt_u32_e64 s[10:11], %0, %8", "v_cndmask_b32_e64 %1, %1, %8, s[10:11]", "v_cndmask_b32_e64 %2, %2, %8, s[10:11]", "v_cndmask_b32_e64 %3, %3, %8, s[10:11]",
                                      "v_cndmask_b32_e64 %4, %4, %8, s[10:11]", "v_cndmask_b32_e64 %5, %5, %8, s[10:11]", "v_cndmask_b32_e64 %6, %6, %8, s[10:11]", "v_cndmask_b32_e64 %7, %7, %8, s[10:11]");
+            if (KIND == 111) OP8_FMT("v_cmp_lt_u32_e32 vcc, %0, %8", "v_cndmask_b32_e32 %1, %1, %8, vcc", "v_cndmask_b32_e32 %2, %2, %8, vcc", "v_add_u32 %3, %3, %8",
+                                     "v_add_u32 %4, %4, %8", "v_add_u32 %5, %5, %8", "v_add_u32 %6, %6, %8", "v_add_u32 %7, %7, %8");     // the (lo, hi) pair of a double's select
+            if (KIND == 112) OP8_FMT("v_cmp_lt_u32_e32 vcc, %0, %8", "v_cndmask_b32_e32 %1, %1, %8, vcc", "v_cndmask_b32_e64 %2, %2, %8, vcc", "v_add_u32 %3, %3, %8",
+                                     "v_add_u32 %4, %4, %8", "v_add_u32 %5, %5, %8", "v_add_u32 %6, %6, %8", "v_add_u32 %7, %7, %8");     // the same, second one VOP3
+            if (KIND == 113) asm volatile("v_cmp_lt_u32_e32 vcc, %0, %5\nv_cndmask_b32_e32 %1, %1, %5, vcc\nv_mul_f64 %3, %3, %6\nv_cndmask_b32_e32 %2, %2, %5, vcc\n"
+                                          "v_mul_f64 %4, %4, %6\nv_cndmask_b32_e32 %0, %0, %5, vcc\nv_mul_f64 %3, %3, %6\nv_cndmask_b32_e32 %1, %1, %5, vcc\n"
+                                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(d0), "+v"(d1) : "v"(c), "v"(dc) : "vcc");      // selects with fp64 work between them
             if (KIND == 110) OP8_FMT("s_and_saveexec_b64 s[10:11], vcc", "v_add_u32 %1, %1, %8", "s_or_b64 exec, exec, s[10:11]", "v_add_u32 %3, %3, %8",
                                      "s_and_saveexec_b64 s[12:13], vcc", "v_add_u32 %5, %5, %8", "s_or_b64 exec, exec, s[12:13]", "v_add_u32 %7, %7, %8");      // exec-mask toggles around single VALU ops
             if (KIND == 88) OP8_32("v_fmac_f32");
@@ -295,8 +302,11 @@ int main(int argc, char **argv)
     run<105>("mul>add f64 chain", d_out, n, ghz);
     run<106>("cmp_f64>cnd", d_out, n, ghz);
     run<107>("cmp,nop,6 cnd vcc", d_out, n, ghz);
-    run<108>("cmp,add,cnd vcc..", d_out, n, ghz);
+    run<108>("alt: cmp,add,cnd..", d_out, n, ghz);
     run<109>("cmp, 7 cnd sgpr", d_out, n, ghz);
+    run<111>("pair: cmp,2 cnd,5 add", d_out, n, ghz);
+    run<112>("pair: cnd e32+e64", d_out, n, ghz);
+    run<113>("pair: cnd,mul_f64 alt", d_out, n, ghz);
     run<110>("saveexec toggles", d_out, n, ghz);
     run<3>("v_add_f64", d_out, n, ghz);
     run<4>("v_mul_f64", d_out, n, ghz);
