@@ -464,18 +464,23 @@ def test_c_call_driver_constrained_alleles(golden_dir, vcff, goldf, tab, ins):
     assert sum(1 for ln in out.splitlines() if not ln.startswith("#")) > 0
 
 
-def _deep_sam(path, ref, sample, seed, n_reads, lo, hi, rlen=100):
+def _deep_sam(path, ref, sample, seed, n_reads, lo, hi, rlen=100, indels=True, err=0.01, snps=None):
     """n_reads reads of one sample over [lo, hi) of contig 17: the reference's bases with a few mismatches, some reads with a
-    2-base insertion or a 3-base deletion at a common place, so that both passes have cells of several hundred usable reads."""
+    2-base insertion or a 3-base deletion at a common place, so that both passes have cells of several hundred usable reads.
+    snps: {0-based position: fraction of the reads that carry another base there} -- at 10-30 % the PLs of a cell of 255 reads stay
+    below their cap of 255 and so depend on which reads errmod_cal draws."""
     rng = np.random.default_rng(seed)
     with open(path, "w") as f:
         f.write("@HD\tVN:1.0\tSO:coordinate\n@SQ\tSN:17\tLN:%d\n@RG\tID:%s\tSM:%s\n" % (len(ref), sample, sample))
         for i, pos in enumerate(sorted(int(x) for x in rng.integers(lo, hi, n_reads))):
             seq = list(ref[pos:pos + rlen + 3])
-            for k in np.flatnonzero(rng.random(len(seq)) < 0.01):
+            for k in np.flatnonzero(rng.random(len(seq)) < err):
                 seq[k] = "ACGT"[int(rng.integers(0, 4))]
+            for q_, fr in (snps or {}).items():
+                if pos <= q_ < pos + rlen and rng.random() < fr:
+                    seq[q_ - pos] = "ACGT"[("ACGT".index(ref[q_].upper()) + 1) % 4] if ref[q_].upper() in "ACGT" else "A"
             cut = (lo + hi) // 2 + 20 - pos                       # the indels sit at one reference position
-            kind = rng.choice(3, p=[0.7, 0.15, 0.15]) if 10 < cut < rlen - 10 else 0
+            kind = rng.choice(3, p=[0.7, 0.15, 0.15]) if indels and 10 < cut < rlen - 10 else 0
             if kind == 1:
                 seq, cig = seq[:cut] + ["G", "T"] + seq[cut:rlen - 2], "%dM2I%dM" % (cut, rlen - 2 - cut)
             elif kind == 2:
@@ -510,3 +515,39 @@ def test_c_sam_driver_draw_does_not_depend_on_the_tiles(golden_dir, tmp_path):
     deep = [r for r in recs if max(int(x.split(":")[r[8].split(":").index("DP")]) for x in r[9:]) > 255]
     assert len(deep) > 100 and any("INDEL" in r[7] for r in deep)          # FORMAT/DP past 255 in both kinds of record
     assert outs[1] == outs[0] and outs[2] == outs[0]
+
+
+@pytest.mark.gpu
+def test_c_sam_driver_deep_cells_match_the_oracle_in_visit_order(golden_dir, tmp_path):
+    """`bcfgpu_sam -B -I -d 10000 --tile 32` on cells of 300-900 usable reads against the oracle (oracle/errmod.c's restatement of
+    errmod_cal's draw, rule 0) run the way one mpileup process runs: position by position, sample by sample, one generator.  PL,
+    DP and AD of every record; the draw crosses nine tile seams on the way."""
+    from tests.helpers import vcf
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    ref = sam.read_fasta(os.path.join(G, "mpileup.ref.fa"))
+    refs = "".join(ln.strip() for ln in open(os.path.join(G, "mpileup.ref.fa")) if not ln.startswith(">"))
+    files = []
+    for k, (name, n) in enumerate((("deepA", 700), ("deepB", 400))):
+        files.append(str(tmp_path / (name + ".sam")))
+        _deep_sam(files[-1], refs, name, 50 + k, n, 1000, 1120, indels=False, snps={q_: (0.1, 0.15, 0.2, 0.3)[(q_ // 5) % 4] for q_ in range(1003, 1215, 5)})
+    out = str(tmp_path / "deep.vcf")
+    cmd = [SAM_EXE, "-B", "-I", "-d", "10000", "--tile", "32", "-a", "AD,DP", "-o", out, "-f", os.path.join(G, "mpileup.ref.fa"), "-r", "17:1001-1300"] + files
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "first 255" not in p.stderr
+    got = vcf.Vcf(out)
+    t = sam.build_tile([sam.Sam(f) for f in files], ref, "17", 1000, 1299, sam.MplpOpts())
+    tile = host.HostTile(2, t["ref16"], t["plp_off"], t["rd"], t["epos"])
+    cfg = abi.default_cfg(2, max_sites=tile.n_sites, max_reads=len(tile.rd), fmt_flag=abi.FMT_AD | abi.FMT_DP)
+    assert [q + 1 for q in t["positions"]] == [r.pos for r in got.recs]
+    deep = open_pl = 0
+    for i, r in enumerate(got.recs):
+        res = orc.mpileup(cfg, tile.select_sites([i]), deep_rule=0, reset=(i == 0))
+        open_pl += int(np.sum((res.pl_of(0) > 0) & (res.pl_of(0) < 255)))
+        na = int(res.site[0]["n_alleles"])
+        for s_ in range(2):
+            assert [int(x) for x in r.fmt("PL", s_).split(",")] == res.pl_of(0)[s_].tolist(), (r.pos, s_)
+            assert [int(x) for x in r.fmt("AD", s_).split(",")] == [int(res.adf[0][a][s_]) + int(res.adr[0][a][s_]) for a in range(na)], (r.pos, s_)
+            deep += int(r.fmt("DP", s_)) > 255
+    assert deep > 150 and open_pl > 100
