@@ -33,7 +33,7 @@
  *  reference's goldens test/mpileup/mpileup.{1..11}.out, mpileup-SCR.out, indel-AD.1.out -- one tile and many.
  *  Not here: CRAM input, index files (a region far into a file is reached by reading up to it), BED files (-l/-T),
  *  --illumina1.3+; a sample fed by several files has its reads merged by position (the reference appends file after file: same
- *  records unless a cell passes 255 usable reads, where errmod's subsampling depends on the order anyway).
+ *  records unless a cell passes 255 usable reads, where errmod_cal's draw then meets the reads in another order).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -48,6 +48,8 @@
 #include <sys/wait.h>
 #include <fcntl.h>
 #include <signal.h>
+#include <sys/syscall.h>
+extern long syscall(long number, ...);       /* (unistd.h keeps it back under -std=c99 -D_POSIX_C_SOURCE) */
 #include "bcfgpu.h"
 #include "vcfio.h"
 
@@ -1050,6 +1052,7 @@ static char *gline_join(const gline_t *a, const gline_t *b)
     return out;
 }
 
+static const char *shard_transport = "";
 static int run_shards(int n_gpus, int argc0, char **argv0, int first_file, const char *ref_path, region_t *reg, int n_reg,
                       const char *out_path, char out_mode)
 {
@@ -1073,13 +1076,19 @@ static int run_shards(int n_gpus, int argc0, char **argv0, int first_file, const
             at += reg[i].end - reg[i].beg;
         }
         fclose(m);
-        /* the shard's records go to an anonymous temporary file this process holds open (no name anyone could predict or
-         * replace); the shard inherits the descriptor and opens it by number */
-        FILE *tf = tmpfile();
-        if (!tf) DIE("tmpfile failed\n");
-        const int tfd = dup(fileno(tf));
-        if (tfd < 0 || fcntl(tfd, F_SETFD, 0)) DIE("tmpfile descriptor\n");
-        fclose(tf);
+        /* the shard's records go to shared memory: an anonymous memory file (memfd_create: pages in RAM, no name in any file
+         * system, nothing anyone could predict or replace) that this process holds open; the shard inherits the descriptor and
+         * opens it by number.  (Where the kernel has no memfd_create: an unlinked temporary file, held the same way.) */
+        int tfd = (int)syscall(SYS_memfd_create, "bcfgpu_shard", 0u);
+        if (tfd >= 0) shard_transport = "memfd (shared memory)";
+        else {
+            FILE *tf = tmpfile();
+            if (!tf) DIE("tmpfile failed\n");
+            tfd = dup(fileno(tf));
+            fclose(tf);
+            shard_transport = "unlinked temporary file";
+        }
+        if (tfd < 0 || fcntl(tfd, F_SETFD, 0)) DIE("shard descriptor\n");
         char **av = malloc((size_t)(argc0 + 16) * sizeof *av);
         int n = 0;
         char sk[24], sfd[40]; snprintf(sk, sizeof sk, "%d", k); snprintf(sfd, sizeof sfd, "/dev/fd/%d", tfd);
@@ -1108,7 +1117,7 @@ static int run_shards(int n_gpus, int argc0, char **argv0, int first_file, const
     int bad = 0;
     for (int k = 0; k < n_sh; ++k) { int st = 0; if (waitpid(pid[k], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st)) bad = 1; }
     if (bad) DIE("a shard failed\n");
-    fprintf(stderr, "[bcfgpu_sam] %d region shards, one process each; their record streams (uncompressed BCF) are emitted in shard order on the host\n", n_sh);
+    fprintf(stderr, "[bcfgpu_sam] %d region shards, one process each; their record streams (uncompressed BCF through %s) are emitted in shard order on the host\n", n_sh, shard_transport);
     char *lb = NULL; size_t lcap = 0;
     gline_t held; char *held_line = NULL; memset(&held, 0, sizeof held);
     for (int k = 0; k < n_sh; ++k) {
