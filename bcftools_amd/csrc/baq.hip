@@ -40,6 +40,9 @@ struct BaqParams {
     double *F, *B, *S;                        // [max_lq+1][ncell][stride] forward / backward; [max_lq+2][stride] scales
     int32_t *state;                           // [pool offset] posterior state per base (k-1)<<2 | {0 M, 1 I}
     uint8_t *q, *tmp;                         // [pool offset] posterior quality; scratch for the extended cap
+    int32_t *wstate; uint8_t *wq, *wleft;     // the same three for the register-row classes, a wavefront's reads side by side: [job >> 6][base][lane]
+                                              // (a lane's own 100-byte stretch made every access of the cap 64 cache lines, and the
+                                              // two stores per row of the backward pass 64 partial sectors each)
     uint8_t *qual_out, *zq_out;
 };
 
@@ -177,7 +180,7 @@ __device__ void baq_fb_scratch(const BaqParams &P, int job, const BaqJob &j, con
 // of the ~40 accesses of the scratch version.
 template <int BWM>
 __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const uint8_t *ref, const uint8_t *seq,
-                           const uint8_t *iqual, int bw, int32_t *state, uint8_t *q, const float *lq2p)
+                           const uint8_t *iqual, int bw, int32_t *state, uint8_t *q, const int pst, const float *lq2p)     // state / q of base i at [i * pst]
 {
     constexpr int NP = 2 * BWM + 3;
     const int l_query = j.l_query, l_ref = j.l_ref;
@@ -392,13 +395,18 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
             }
             {   // the forward values of row i - 1
                 const int i1 = i > 1 ? i - 1 : 1;
+#ifdef BAQ_EXP_NOLOAD       // experiment: the forward rows are not read back (never true at run time): the backward pass on stale values
+                if (P.n_jobs < 0)
+#endif
+                {
                 #pragma unroll
                 for (int p = 1; p < NP; ++p) { const double2 t = FR2(i1, p); fr0[p] = t.x; fr1[p] = t.y; }
+                }
             }
             max /= sum;
-            state[i - 1] = max_k;
+            state[(size_t)(i - 1) * pst] = max_k;
             const int kq = (int)(-4.343 * log(1. - max) + .499);
-            q[i - 1] = (uint8_t)(kq > 100 ? 99 : kq);
+            q[(size_t)(i - 1) * pst] = (uint8_t)(kq > 100 ? 99 : kq);
         }
     }
     #undef FR2
@@ -412,12 +420,16 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
 // maximum, the minimum, the ZQ byte and the new quality, four bases per trip with all loads of a trip issued before the
 // first is used (a lane's bytes are its own 100-byte stretch: every access is a round trip to L2, and one wait per byte
 // made this phase a third of the kernel).
-__device__ void baq_cap(const BaqParams &P, const BaqJob &j, const uint8_t *iqual, const int32_t *state, const uint8_t *q,
+__device__ void baq_cap(const BaqParams &P, const BaqJob &j, const uint8_t *iqual, const int32_t *state_, const uint8_t *q_, uint8_t *left_, const int pst,
                         uint8_t *qout, uint8_t *zout)
 {
+    // state / q / left of base i at [i * pst]: pst = 64 for a wavefront's reads side by side (the lanes' loads of one base are one
+    // stretch of memory), 1 for a read's own arrays (the scratch class)
+    struct { const int32_t *p; int st; __device__ int operator[](int i) const { return p[(size_t)i * st]; } } state{state_, pst};
+    struct { const uint8_t *p; int st; __device__ uint32_t operator[](int i) const { return p[(size_t)i * st]; } } q{q_, pst};
+    struct { uint8_t *p; int st; __device__ uint8_t &operator[](int i) const { return p[(size_t)i * st]; } } left{left_, pst};
     const uint32_t *cigar = P.cig + j.cig_off;
     const bool apply = (P.flag & 1) != 0, extend = (P.flag & 2) != 0;
-    uint8_t *left = P.tmp + 2 * (size_t)j.seq_off;
     int x = j.pos, y = 0;
     for (int k = 0; k < j.n_cigar; ++k) {
         const int op = cigar[k] & 0xf, l = (int)(cigar[k] >> 4);
@@ -489,16 +501,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAQ_WAVES, 8
         return;
     }
     const uint8_t *ref = P.tref + j.ref_off;
-    int32_t *state = P.state + j.seq_off;
-    uint8_t *q = P.q + j.seq_off;
+    // the register-row classes keep state / posterior quality / left maxima of a wavefront's reads side by side
+    const size_t wv = ((size_t)(job >> 6) * (size_t)P.max_lq) * 64 + (size_t)(job & 63);
+    int32_t *state = BWM > 0 ? P.wstate + wv : P.state + j.seq_off;
+    uint8_t *q = BWM > 0 ? P.wq + wv : P.q + j.seq_off;
+    uint8_t *left = BWM > 0 ? P.wleft + wv : P.tmp + 2 * (size_t)j.seq_off;
+    const int pst = BWM > 0 ? 64 : 1;
     if (BWM > 0) {
         int bw = j.l_ref > j.l_query ? j.l_ref : j.l_query;
         if (bw > j.bw) bw = j.bw;
         if (bw < abs(j.l_ref - j.l_query)) bw = abs(j.l_ref - j.l_query);
-        baq_fb_reg<(BWM > 0 ? BWM : 1)>(P, job, j, ref, seq, iqual, bw, state, q, s_q2p);
+        baq_fb_reg<(BWM > 0 ? BWM : 1)>(P, job, j, ref, seq, iqual, bw, state, q, pst, s_q2p);
     } else baq_fb_scratch(P, job, j, ref, seq, iqual, state, q);
 #if !defined(BAQ_EXP_PHASE) || BAQ_EXP_PHASE == 0
-    baq_cap(P, j, iqual, state, q, qout, zout);
+    baq_cap(P, j, iqual, state, q, left, pst, qout, zout);
 #endif
 }
 
@@ -705,6 +721,12 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
         d_B = reg ? nullptr : bcfgpu_internal_ws(ctx, 1, per_mat * chunk);
         d_S = bcfgpu_internal_ws(ctx, 2, (size_t)(max_lq + 2) * chunk * sizeof(double));
         if (!d_jobs || !d_F || (!reg && !d_B) || !d_S) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_baq: device workspace");
+        if (reg) {                                                   // state / posterior quality / left maxima, a wavefront's reads side by side
+            const size_t wn = chunk * (size_t)max_lq;
+            uint8_t *d_w = (uint8_t*)bcfgpu_internal_ws(ctx, 5, wn * 6 + 64);
+            if (!d_w) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_baq: device workspace");
+            P.wstate = (int32_t*)d_w; P.wq = d_w + wn * 4; P.wleft = d_w + wn * 5;
+        }
         BQ_CHK(hipMemcpyAsync(d_jobs, cls[c].data(), nj * sizeof(BaqJob), hipMemcpyHostToDevice, stream));
         P.F = (double*)d_F; P.B = (double*)d_B; P.S = (double*)d_S;
         for (size_t j0 = 0; j0 < nj; j0 += chunk) {
@@ -794,6 +816,12 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
         void *d_F = bcfgpu_internal_ws(ctx, 4, per_mat * chunk), *d_B = reg ? nullptr : bcfgpu_internal_ws(ctx, 1, per_mat * chunk);
         void *d_S = bcfgpu_internal_ws(ctx, 2, (size_t)(P.max_lq + 2) * chunk * sizeof(double));
         if (!d_F || (!reg && !d_B) || !d_S) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_baq: device workspace");
+        if (reg) {                                                   // state / posterior quality / left maxima, a wavefront's reads side by side
+            const size_t wn = chunk * (size_t)P.max_lq;
+            uint8_t *d_w = (uint8_t*)bcfgpu_internal_ws(ctx, 5, wn * 6 + 64);
+            if (!d_w) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_baq: device workspace");
+            P.wstate = (int32_t*)d_w; P.wq = d_w + wn * 4; P.wleft = d_w + wn * 5;
+        }
         P.F = (double*)d_F; P.B = (double*)d_B; P.S = (double*)d_S;
         for (size_t j0 = 0; j0 < nj; j0 += chunk) {
             P.n_jobs = (int)(nj - j0 < chunk ? nj - j0 : chunk);
