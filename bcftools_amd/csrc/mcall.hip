@@ -1054,8 +1054,8 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         // the next round's counts and groups are requested before the current ones are normalised and added (the loop is a
         // chain of memory round trips otherwise); a lane's four samples of a byte plane are one 4-byte load
         int xn[5][4], gnx[4];
-        auto fetch_ad = [&](int base) {
-            const int s = base + 4 * tid, rem = S - s;
+        auto fetch_at = [&](const int s) __attribute__((always_inline)) {   // the lane's four samples s .. s+3
+            const int rem = S - s;
             #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 #pragma unroll
@@ -1082,6 +1082,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             #pragma unroll
             for (int j = 0; j < 4; ++j) gnx[j] = j < rem ? GRP_OF(s + j) : 0;
         };
+        auto fetch_ad = [&](int base) __attribute__((always_inline)) { fetch_at(base + 4 * tid); };
         // Groups that are runs of consecutive samples (the usual -G file): lane (group, allele) keeps its group's running sum and
         // adds, round by round, the fractions of its group's samples of that round from LDS -- the reference's order for every
         // group (mcall.c:1485-1500), without a group test per sample and without the five chains over all samples of the general
@@ -1093,23 +1094,36 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             if (tid < ngrp) { const int f = P.grp_rng[3 * tid], l = P.grp_rng[3 * tid + 1], n = P.grp_rng[3 * tid + 2]; ok = n == 0 || l - f == n; }
             side_by_side = __all(ok);
         }
-        fetch_ad(0);
         if (side_by_side) {
+            // A round stages, for EVERY group, the next CH of its samples (LPG = 64 / n_grp lanes a group, four consecutive samples a
+            // lane, from the group's first sample rounded down to a multiple of four: aligned loads; samples outside the group's
+            // range count as +0), so all the chains work in every round: n / CH rounds of CH additions per chain instead of S / 256
+            // rounds in which one group's chains add 256 values while the others wait.
             const int cg = tid / 5, ca = tid % 5;
             const bool chain = tid < ngrp * 5 && ca < nals;
-            int gfirst = 0, glast = 0;
-            if (chain && P.grp_rng[3 * cg + 2]) { gfirst = P.grp_rng[3 * cg]; glast = P.grp_rng[3 * cg + 1]; }
+            const int LPG = WGS / ngrp, CH = 4 * LPG;
+            const int lg = tid / LPG, li = tid % LPG;
+            int lf = 0, ll = 0;                                           // the range of the lane's group
+            if (lg < ngrp && P.grp_rng[3 * lg + 2]) { lf = P.grp_rng[3 * lg]; ll = P.grp_rng[3 * lg + 1]; }
+            const int la0 = lf & ~3;
+            int rounds = (ll - la0 + CH - 1) / CH;
+            #pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rounds = max(rounds, __shfl_xor(rounds, o));
+            auto lane_s = [&](int r) { const int s = la0 + r * CH + 4 * li; return (lg < ngrp && s < ll) ? s : S; };
+            int cspan = 0;                                                // the chain's group: samples from its aligned start
+            if (chain && P.grp_rng[3 * cg + 2]) cspan = P.grp_rng[3 * cg + 1] - (P.grp_rng[3 * cg] & ~3);
             float gacc = 0.f;
-            for (int base = 0; base < (BCFGPU_ABL(P, 128) ? 0 : S); base += SB) {
-                const int cn = min(SB, S - base);
+            fetch_at(lane_s(0));
+            for (int r = 0; r < (BCFGPU_ABL(P, 128) ? 0 : rounds); ++r) {
                 __syncthreads();                                         // (the chains of the round before are through with s_fr)
                 int xc[5][4];
                 #pragma unroll
                 for (int k = 0; k < 5; ++k)
                     #pragma unroll
                     for (int j = 0; j < 4; ++j) xc[k][j] = xn[k][j];
-                fetch_ad(base + SB);
-                {
+                const int s0 = lane_s(r);
+                fetch_at(lane_s(r + 1));
+                if (lg < ngrp) {
                     float fr[5][4];
                     #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -1124,22 +1138,19 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                 if (x != VEND) { v[k] = x; nvalid = k + 1; if (x != MISSING) sum += (float)x; }
                             }
                         }
+                        const bool mine = s0 + j >= lf && s0 + j < ll;   // (s0 = S past the group's end: nothing was loaded)
                         #pragma unroll
-                        for (int k = 0; k < 5; ++k)                       // +0 where the reference adds nothing (and past the last sample)
-                            fr[k][j] = (4 * tid + j < cn && sum != 0.f && k < nvalid && v[k] != MISSING) ? (float)v[k] / sum : 0.f;
+                        for (int k = 0; k < 5; ++k)                       // +0 where the reference adds nothing (and outside the group)
+                            fr[k][j] = (mine && sum != 0.f && k < nvalid && v[k] != MISSING) ? (float)v[k] / sum : 0.f;
                     }
                     #pragma unroll
                     for (int k = 0; k < 5; ++k)
-                        if (k < nals) *reinterpret_cast<float4*>(s_fr + k * SB + 4 * tid) = make_float4(fr[k][0], fr[k][1], fr[k][2], fr[k][3]);
+                        if (k < nals) *reinterpret_cast<float4*>(s_fr + k * SB + lg * CH + 4 * li) = make_float4(fr[k][0], fr[k][1], fr[k][2], fr[k][3]);
                 }
                 __syncthreads();
-                const int lo = max(gfirst, base), hi = min(glast, base + cn);
-                if (chain && lo < hi) {
-                    const float *fp = s_fr + ca * SB - base;               // indexed by sample
-                    int i = lo;
-                    for (; i < hi && (i & 3); ++i) gacc += fp[i];
-                    const float4 *q4 = reinterpret_cast<const float4*>(fp + i);
-                    const int nb = (hi - i) >> 2;                          // whole float4s; four of them in flight
+                if (chain && r * CH < cspan) {
+                    const float4 *q4 = reinterpret_cast<const float4*>(s_fr + ca * SB + cg * CH);
+                    const int nb = LPG;                                    // float4s of the round; four of them in flight
                     float4 c0 = make_float4(0, 0, 0, 0), c1 = c0, c2 = c0, c3 = c0;
                     if (nb > 0) c0 = q4[0];
                     if (nb > 1) c1 = q4[1];
@@ -1156,13 +1167,13 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                         if (b4 + 2 < nb) { gacc += a2.x; gacc += a2.y; gacc += a2.z; gacc += a2.w; }
                         if (b4 + 3 < nb) { gacc += a3.x; gacc += a3.y; gacc += a3.z; gacc += a3.w; }
                     }
-                    for (i += 4 * nb; i < hi; ++i) gacc += fp[i];
                 }
             }
             __syncthreads();
             if (chain) s_gq[cg * 5 + ca] = gacc;
             cur = -1;                                                     // (nothing left in the running-group register)
-        } else
+        } else {
+        fetch_ad(0);
         for (int base = 0; base < (BCFGPU_ABL(P, 128) ? 0 : S); base += SB) {
             const int cn = min(SB, S - base);
             __syncthreads();
@@ -1232,6 +1243,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     }
                 }
             }
+        }
         }
         if (tid < 5 && tid < nals && cur >= 0) s_gq[cur * 5 + tid] = acc;
     }
