@@ -237,8 +237,8 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
         SC(1) = sum;
         #pragma unroll
         for (int p = 1; p < NP; ++p) {
+            FR2(1, p) = make_double2(M[p], I[p]);               // (unscaled, like every stored row: see the loop below)
             if (p >= 2 && p - 1 <= end) { M[p] /= sum; I[p] /= sum; D[p] /= sum; }
-            FR2(1, p) = make_double2(M[p], I[p]);
         }
     }
     int x = 0;
@@ -287,11 +287,16 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
         const double r = 1. / sum;
         #pragma unroll
         for (int p = 1; p < NP; ++p) {
-            M[p] *= r; I[p] *= r; D[p] *= r;
+            // Only the ODD rows go to memory, and UNSCALED (M', I'; the scale is stored anyway): the backward pass re-forms an
+            // even row from the odd row below it while it forms that row's posterior.  Unscaled, because the row above needs D of
+            // this one, which is not stored: D' is the recurrence D'[p] = m2 M'[p-1] + m8 D'[p-1] over the UNSCALED M' -- re-run
+            // in the same order it gives the same bits, and the scaled row is re-formed by the same multiplication as here.
+            // Half the bytes of round 3's every-row store.
 #ifdef BAQ_EXP_NOSTORE       // experiment: the forward rows are not written (never true at run time)
             if (P.n_jobs < 0)
 #endif
-            FR2(i, p) = make_double2(M[p], I[p]);
+            if (i & 1) FR2(i, p) = make_double2(M[p], I[p]);
+            M[p] *= r; I[p] *= r; D[p] *= r;
         }
     }
     {
@@ -308,8 +313,9 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
 #endif
     // ---- backward with the posterior maximum of every row ----
     // x is max(0, l_query - bw) here.  Row l_query:
+    const double sl = SC(l_query);
     {
-        const double sl = SC(l_query), sl1 = SC(l_query + 1);
+        const double sl1 = SC(l_query + 1);
         const int phi = l_ref - x + 1 < bw2 ? l_ref - x + 1 : bw2;
         const int plo = x == 0 ? 2 : 1;
         #pragma unroll
@@ -326,9 +332,11 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
     constexpr uint64_t WMASK = (NP * 3 >= 64) ? ~0ull : ((1ull << (NP * 3)) - 1);
     // The forward row of the posterior, the scale, the query byte and the reference byte of a row are requested while the row
     // before it (i + 1) is being worked on: the forward values of row i - 1 right after row i's posterior has consumed its own.
+    // fr0 / fr1: the stored (odd, unscaled) row the next posterior works from -- its own for an odd row, the row below for an even one
     double fr0[NP], fr1[NP];
+    fr0[0] = fr1[0] = 0.;
     #pragma unroll
-    for (int p = 1; p < NP; ++p) { const double2 t = FR2(l_query, p); fr0[p] = t.x; fr1[p] = t.y; }
+    for (int p = 1; p < NP; ++p) { const double2 t = FR2((l_query & 1) ? l_query : l_query - 1, p); fr0[p] = t.x; fr1[p] = t.y; }
 
     uint32_t bq_n = 0, bs_n = 0, br_n = 0;                // bytes of row l_query - 1
     double sc_n = 1.;
@@ -337,12 +345,14 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
         bq_n = iqual[in]; bs_n = seq[in]; br_n = ref_at(xi1); sc_n = SC(i1 > 1 ? i1 : 1);
     }
     for (int i = l_query; i >= 1; --i) {
+        double sc_i = sl;                                 // the scale of row i
         if (i < l_query) {
             // b[i] from b[i+1], in place, descending p
             const int xi = i - bw > 0 ? i - bw : 0;
             const bool slide = xi != x;                   // the band of row i+1 sits one column to the right
             const uint32_t cq = bq_n, cs = bs_n, cr = br_n;
             const double csc = sc_n;
+            sc_i = csc;
             {   // row i - 1's bytes and scale
                 const int i1 = i - 1 > 1 ? i - 1 : 1, xi1 = i1 - bw > 0 ? i1 - bw : 0;
                 bq_n = iqual[i1]; bs_n = seq[i1]; br_n = ref_at(xi1); sc_n = SC(i1);
@@ -384,23 +394,62 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
             const int plo = x == 0 ? 2 : 1, phi = end - x + 1;
             double sum = 0., max = 0.;
             int max_k = -1;
-            #pragma unroll
-            for (int p = 1; p < NP; ++p) {
-                if (p >= plo && p <= phi) {
-                    const int k = p + x - 1;
-                    double z;
-                    z = fr0[p] * M[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 0; } sum += z;
-                    z = fr1[p] * I[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 1; } sum += z;
+            const double r_i = 1. / sc_i;                 // (row 1 was scaled by a division, every other row by this reciprocal)
+            if (i & 1) {
+                // an odd row: its own stored values, scaled as the forward pass scaled them
+                #pragma unroll
+                for (int p = 1; p < NP; ++p) {
+                    if (p >= plo && p <= phi) {
+                        const int k = p + x - 1;
+                        const double fM = i == 1 ? fr0[p] / sc_i : fr0[p] * r_i, fI = i == 1 ? fr1[p] / sc_i : fr1[p] * r_i;
+                        double z;
+                        z = fM * M[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 0; } sum += z;
+                        z = fI * I[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 1; } sum += z;
+                    }
                 }
-            }
-            {   // the forward values of row i - 1
-                const int i1 = i > 1 ? i - 1 : 1;
+                // the stored row the next two posteriors work from: row i - 2 (row i - 1 is re-formed from it, then it is its own)
 #ifdef BAQ_EXP_NOLOAD       // experiment: the forward rows are not read back (never true at run time): the backward pass on stale values
                 if (P.n_jobs < 0)
 #endif
-                {
+                if (i >= 3) {
+                    #pragma unroll
+                    for (int p = 1; p < NP; ++p) { const double2 t = FR2(i - 2, p); fr0[p] = t.x; fr1[p] = t.y; }
+                }
+            } else {
+                // an even row: re-formed cell by cell from the stored row below (fr = row i - 1, unscaled) exactly as the forward pass
+                // formed it -- the row below scaled by its own factor (row 1: divided), its D by the recurrence over the unscaled M',
+                // the three-term sums in the forward pass's order, then this row's scale
+                const double sc_b = sc_n, r_b = 1. / sc_b;                    // the row below: SC(i - 1)
+                const bool b1 = i == 2;                                       // ... is row 1: divided by its sum, D = 0
+                const bool fslide = i > bw;                                   // the band of row i sits one column to the right of row i - 1's
+                const int xb_ = i - 1 - bw > 0 ? i - 1 - bw : 0;
+                const int endb = l_ref < i - 1 + bw ? l_ref : i - 1 + bw;
+                const int plob = xb_ == 0 ? 2 : 1, phib = endb - xb_ + 1;     // the row below's range (row 1: 2 .. min(l_ref, bw + 1) + 1, the same formula)
+                const double qli = (double)lq2p[bq_n];                        // row i's own base and quality (requested a row ago)
+                const int qyi = nt16_to_4((int)bs_n);
+                auto sb = [&](double v) { return b1 ? v / sc_b : v * r_b; };
+                double dprev = 0.;                                            // D'[p - 1] of the row below, unscaled
                 #pragma unroll
-                for (int p = 1; p < NP; ++p) { const double2 t = FR2(i1, p); fr0[p] = t.x; fr1[p] = t.y; }
+                for (int p = 1; p < NP; ++p) {
+                    const double dcur = (!b1 && p >= plob && p <= phib) ? m[2] * fr0[p - 1] + m[8] * dprev : 0.;   // D'[p]
+                    if (p >= plo && p <= phi) {
+                        const int k = p + x - 1;
+                        // the reference base of column k - 1 = ref[p + x - 2]: one position down the backward window; position 0 is the
+                        // base that slides in for the row below (br_n)
+                        const int rb = p == 1 ? (int)br_n : (int)((rb_w >> (3 * (p - 1))) & 7);
+                        const double e = (rb > 3 || qyi > 3) ? 1. : rb == qyi ? 1. - qli : qli * EM;
+                        const double gM = sb(fslide ? fr0[p] : fr0[p - 1]), gI = sb(fslide ? fr1[p] : fr1[p - 1]);
+                        const double gD = b1 ? 0. : (fslide ? dcur : dprev) * r_b;
+                        const double uM = sb(fslide ? (p + 1 < NP ? fr0[p + 1 < NP ? p + 1 : p] : 0.) : fr0[p]);
+                        const double uI = sb(fslide ? (p + 1 < NP ? fr1[p + 1 < NP ? p + 1 : p] : 0.) : fr1[p]);
+                        const double f0 = e * (m[0] * gM + m[3] * gI + m[6] * gD);
+                        const double f1 = EI * (m[1] * uM + m[4] * uI);
+                        const double fM = f0 * r_i, fI = f1 * r_i;
+                        double z;
+                        z = fM * M[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 0; } sum += z;
+                        z = fI * I[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 1; } sum += z;
+                    }
+                    dprev = dcur;
                 }
             }
             max /= sum;
