@@ -30,6 +30,7 @@ struct BaqJob {
     int32_t l_ref, l_query, bw, xb, pos, n_cigar, ret;
 };
 
+#define BAQ_ROWS_KEPT(max_lq) (((max_lq) + 1) / 2 + 1)      // forward rows the register-row classes keep per read: the odd ones
 struct BaqParams {
     int n_jobs, ncell, max_lq, flag;
     size_t stride;                            // jobs per chunk (scratch row stride)
@@ -189,13 +190,14 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
     // rows of all reads of a launch interleaved -- [row][cell][read] -- consecutive stores of a wavefront were megabytes
     // apart, every one on a DRAM page and a TLB entry of its own: 1.8 TB/s.)  M and I only: the posterior never reads D.
     const size_t wbase = (size_t)(job >> 6) * (size_t)(P.max_lq + 2);
+    const size_t wbF = (size_t)(job >> 6) * (size_t)BAQ_ROWS_KEPT(P.max_lq);    // the odd rows 1, 3, 5, ... in slots 0, 1, 2, ...
     const int wl = job & 63;
     // (M and I of a cell side by side in a lane's 16 bytes: one dwordx4 store / load per cell -- the phase is bound by the
     // issue of its vector-memory instructions, and there are half as many this way)
 #ifdef BAQ_EXP_ROWMASK      // experiment (tools/file_variants.sh): the rows folded onto a few, so that the scratch stays in cache -- wrong results, the time says what HBM costs
-    #define FR2(i, p) reinterpret_cast<double2*>(P.F)[((wbase + (size_t)((i) & BAQ_EXP_ROWMASK)) * NP + (size_t)(p)) * 64 + wl]
+    #define FR2(i, p) reinterpret_cast<double2*>(P.F)[((wbF + (size_t)(((i) >> 1) & BAQ_EXP_ROWMASK)) * NP + (size_t)(p)) * 64 + wl]
 #else
-    #define FR2(i, p) reinterpret_cast<double2*>(P.F)[((wbase + (size_t)(i)) * NP + (size_t)(p)) * 64 + wl]
+    #define FR2(i, p) reinterpret_cast<double2*>(P.F)[((wbF + (size_t)((i) >> 1)) * NP + (size_t)(p)) * 64 + wl]
 #endif
     #define SC(i) P.S[(wbase + (size_t)(i)) * 64 + wl]
     const int bw2 = bw * 2 + 1;
@@ -758,7 +760,7 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
         if (!nj) continue;
         const bool reg = c < 2;
         P.ncell = reg ? 2 * (2 * (c ? BAQ_BWM2 : BAQ_BWM) + 3) : 3 * (2 * cls_bw[c] + 1) + 6;       // doubles per matrix row
-        const size_t per_mat = (size_t)(max_lq + 2) * P.ncell * sizeof(double);    // one matrix of one read
+        const size_t per_mat = (size_t)(reg ? BAQ_ROWS_KEPT(max_lq) : max_lq + 2) * P.ncell * sizeof(double);    // one matrix of one read (register-row classes: the odd rows)
         const size_t per_job = reg ? per_mat : 2 * per_mat;
         size_t chunk = ((size_t)2 << 30) / per_job;
         chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
@@ -856,7 +858,7 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
         if (!nj) continue;
         const bool reg = c < 2;
         P.ncell = reg ? 2 * (2 * (c ? BAQ_BWM2 : BAQ_BWM) + 3) : 3 * (2 * counts[2] + 1) + 6;       // doubles per matrix row
-        const size_t per_mat = (size_t)(P.max_lq + 2) * P.ncell * sizeof(double);  // one matrix of one read
+        const size_t per_mat = (size_t)(reg ? BAQ_ROWS_KEPT(P.max_lq) : P.max_lq + 2) * P.ncell * sizeof(double);  // one matrix of one read (register-row classes: the odd rows)
         const size_t per_job = reg ? per_mat : 2 * per_mat;
         size_t chunk = ((size_t)24 << 30) / per_job;                               // (up to 24 GiB of scratch of the 288 GB: one launch for ~9e5 reads of 100 bases -- every launch ends with a round of wavefronts that does not fill the chip)
         chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);

@@ -542,13 +542,23 @@ def main_baq(a):
     check(ctx.L.bcfgpu_pool_download(ctx.h, qp.ctypes.data, zp.ctypes.data, None))
     assert np.array_equal(qp, qo) and np.array_equal(zp, zo)
     lq = int(R["r_lq"][0])
-    scratch = 2 * (lq + 1) * 34 * 8                                 # the forward rows of a read (M and I of 17 cells): written once, read once
+    rows_kept = (lq + 1) // 2 + 1                                   # the odd forward rows (the even ones are re-formed by the backward pass)
+    scratch = 2 * rows_kept * 32 * 8                                # M' and I' of 16 band positions per kept row: written once, read once
+    # fp64 work per read, counted as the reference's multiplies and adds (no FMA: contraction would change the rounding the ZQ bytes and
+    # the new qualities are compared on): forward 19 per band cell (M 6, I 4, D 3, the row sum 3, the scale 3), backward 20 (M 6, I 3, D 4,
+    # the scale 3, the posterior 4), an even row re-formed 24 per cell: 16 cells x (19 + 20 + 12) per row
+    flops = lq * 16 * (19 + 20 + 12)
     out["pool_form"] = {"stage_ms": tpool * 1e3, "value": R["n_reads"] / tpool, "unit": "reads/s",
                         "roofline": {"bound": "hbm", "bytes_per_read": scratch + 4 * lq, "achieved": R["n_reads"] * (scratch + 4 * lq) / tpool / 1e9,
-                                     "peak": 8000.0, "unit": "GB/s", "frac": R["n_reads"] * (scratch + 4 * lq) / tpool / 8e12},
-                        "note": "bcfgpu_pool_baq on the pool in HBM (window and band per read on the device, forward rows through a "
-                                "[row][cell][read] scratch, backward rows in registers), wall time of the call incl. its one wait; results "
-                                "equal to the host-pointer call"}
+                                     "peak": 8000.0, "unit": "GB/s", "frac": R["n_reads"] * (scratch + 4 * lq) / tpool / 8e12,
+                                     "algorithmic_bytes_per_read": 4 * lq, "scratch_over_algorithmic": scratch / (4.0 * lq),
+                                     "fp64_flop_per_s": R["n_reads"] * flops / tpool,
+                                     "fp64_frac_of_vector_peak": R["n_reads"] * flops / tpool / 78.6e12,
+                                     "fp64_frac_of_mul_add_peak": R["n_reads"] * flops / tpool / 39.3e12},
+                        "note": "bcfgpu_pool_baq on the pool in HBM (window and band per read on the device; of the forward rows only the odd ones "
+                                "go through the [row][cell][lane] scratch, unscaled, the backward pass re-forms the even ones; backward rows in "
+                                "registers), wall time of the call incl. its one wait; results equal to the host-pointer call.  bytes_per_read is "
+                                "the kernel's OWN row traffic plus the read's input and output (algorithmic_bytes_per_read)"}
     # the mate-overlap tweak over the same pool: consecutive reads of the pool taken as mates (reads of one column overlap
     # around it), whole call with host pointers; the C oracle on one core beside it, results compared
     npair = R["n_reads"] // 2
