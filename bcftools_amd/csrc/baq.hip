@@ -337,6 +337,7 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
     // fr0 / fr1: the stored (odd, unscaled) row the next posterior works from -- its own for an odd row, the row below for an even one
     double fr0[NP], fr1[NP];
     fr0[0] = fr1[0] = 0.;
+    bool fr_scaled = false;                               // row 1 in fr has been divided by its sum
     #pragma unroll
     for (int p = 1; p < NP; ++p) { const double2 t = FR2((l_query & 1) ? l_query : l_query - 1, p); fr0[p] = t.x; fr1[p] = t.y; }
 
@@ -397,13 +398,23 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
             double sum = 0., max = 0.;
             int max_k = -1;
             const double r_i = 1. / sc_i;                 // (row 1 was scaled by a division, every other row by this reciprocal)
+            // Row 1 in fr (at i = 2, or at i = 1 for a read of one base) is divided by its sum once, in place -- as the forward pass
+            // did -- and from then on counts as scaled: the loops below multiply it by 1.  (A division in every cell of every row,
+            // selected away for all rows but two, was a quarter of the pass.)
+            if (i <= 2 && !fr_scaled) {
+                const double s1 = i == 1 ? sc_i : sc_n;
+                #pragma unroll
+                for (int p = 1; p < NP; ++p) { fr0[p] /= s1; fr1[p] /= s1; }
+                fr_scaled = true;
+            }
             if (i & 1) {
                 // an odd row: its own stored values, scaled as the forward pass scaled them
+                const double r_o = i == 1 ? 1. : r_i;
                 #pragma unroll
                 for (int p = 1; p < NP; ++p) {
                     if (p >= plo && p <= phi) {
                         const int k = p + x - 1;
-                        const double fM = i == 1 ? fr0[p] / sc_i : fr0[p] * r_i, fI = i == 1 ? fr1[p] / sc_i : fr1[p] * r_i;
+                        const double fM = fr0[p] * r_o, fI = fr1[p] * r_o;
                         double z;
                         z = fM * M[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 0; } sum += z;
                         z = fI * I[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 1; } sum += z;
@@ -421,15 +432,15 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
                 // an even row: re-formed cell by cell from the stored row below (fr = row i - 1, unscaled) exactly as the forward pass
                 // formed it -- the row below scaled by its own factor (row 1: divided), its D by the recurrence over the unscaled M',
                 // the three-term sums in the forward pass's order, then this row's scale
-                const double sc_b = sc_n, r_b = 1. / sc_b;                    // the row below: SC(i - 1)
-                const bool b1 = i == 2;                                       // ... is row 1: divided by its sum, D = 0
+                const bool b1 = i == 2;                                       // the row below is row 1: already divided by its sum (above), D = 0
+                const double r_b = b1 ? 1. : 1. / sc_n;                       // the row below's scale: 1 / SC(i - 1)
                 const bool fslide = i > bw;                                   // the band of row i sits one column to the right of row i - 1's
                 const int xb_ = i - 1 - bw > 0 ? i - 1 - bw : 0;
                 const int endb = l_ref < i - 1 + bw ? l_ref : i - 1 + bw;
                 const int plob = xb_ == 0 ? 2 : 1, phib = endb - xb_ + 1;     // the row below's range (row 1: 2 .. min(l_ref, bw + 1) + 1, the same formula)
                 const double qli = (double)lq2p[bq_n];                        // row i's own base and quality (requested a row ago)
                 const int qyi = nt16_to_4((int)bs_n);
-                auto sb = [&](double v) { return b1 ? v / sc_b : v * r_b; };
+                auto sb = [&](double v) { return v * r_b; };
                 double dprev = 0.;                                            // D'[p - 1] of the row below, unscaled
                 #pragma unroll
                 for (int p = 1; p < NP; ++p) {
