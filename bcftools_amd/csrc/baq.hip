@@ -3,8 +3,10 @@
 //
 // Per read: reference window and band (realn.c), the banded glocal pair-HMM of probaln_glocal() with the full
 // forward and backward passes and the posterior maximum per query base (probaln.c), then the quality cap
-// (plain or extended).  One lane per read; the scaled forward and backward matrices live in a scratch buffer laid
-// out [row][cell][read] so that the 64 reads of a wavefront touch consecutive doubles.  All arithmetic is fp64 in the
+// (plain or extended).  One lane per read.  The usual bands (half-width 7 or 8) keep the current row of both passes in
+// registers: of the forward matrix only the odd rows go to memory (unscaled, [row][cell][lane]: a wavefront's reads side by
+// side), and the backward pass re-forms the even ones from the row below while it forms their posterior (baq_fb_reg).  Wider
+// bands keep both matrices in a scratch buffer [row][cell][read] (baq_fb_scratch).  All arithmetic is fp64 in the
 // reference's operation order, so state / posterior quality, and therefore the new base qualities, are identical to
 // the CPU's.  The host half (window, band, 2-bit reference) is a few integer operations per read.
 #include <hip/hip_runtime.h>
@@ -174,10 +176,10 @@ __device__ void baq_fb_scratch(const BaqParams &P, int job, const BaqJob &j, con
 
 
 // The same with the current row in registers, for bands of half-width <= BWM (the default band of 7 fits): the forward
-// pass keeps its scaled row in registers and stores it once (the posterior needs f*b per cell), the backward pass
-// keeps its row in registers and reads the forward row back.  Position p of a row is reference column
-// k = p + max(0, i-bw) - 1, htslib's set_u() slot, so both passes update in place (see probaln_fwd_reg in indel.hip);
-// the reference window travels in a 64-bit register, 3 bits per base.  One matrix write and one read per cell instead
+// pass keeps its scaled row in registers and stores every other one (the posterior needs f*b per cell), the backward pass
+// keeps its row in registers, reads the stored forward rows back and re-forms the others.  Position p of a row is reference
+// column k = p + max(0, i-bw) - 1, htslib's set_u() slot, so both passes update in place (see probaln_fwd_reg in indel.hip);
+// the reference window travels in a 64-bit register, 3 bits per base.  Half a matrix write and half a read per cell instead
 // of the ~40 accesses of the scratch version.
 template <int BWM>
 __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const uint8_t *ref, const uint8_t *seq,
@@ -185,7 +187,6 @@ __device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const u
 {
     constexpr int NP = 2 * BWM + 3;
     const int l_query = j.l_query, l_ref = j.l_ref;
-    const size_t st = P.stride;
     // A wavefront's rows are one contiguous block, [row][cell][lane]: consecutive stores are 512 bytes apart.  (With the
     // rows of all reads of a launch interleaved -- [row][cell][read] -- consecutive stores of a wavefront were megabytes
     // apart, every one on a DRAM page and a TLB entry of its own: 1.8 TB/s.)  M and I only: the posterior never reads D.
