@@ -135,3 +135,42 @@ def test_baq_matches_oracle_on_random_cigars(gpu_ctx_factory, seed, flag):
             np.testing.assert_array_equal(r.qual, wq, err_msg=r.qname)
             np.testing.assert_array_equal(r.zq, wz, err_msg=r.qname)
     assert sum(rc == 0 for rc, _, _ in want) > 300
+
+
+def test_baq_on_reads_of_one_to_nine_bases(gpu_ctx_factory):
+    """Reads of 1 .. 9 bases, every length on both strands of the parity the row store turns on: only the odd forward rows are
+    kept, row 1 is scaled by a division and row 2 is re-formed from it, a read of one base has nothing but row 1 (csrc/baq.hip)."""
+    rng = np.random.default_rng(7)
+    L = 300
+    refseq = "".join("ACGT"[i] for i in rng.integers(0, 4, L))
+
+    class Rd:
+        pass
+    reads = []
+    for n in range(1, 10):
+        for rep in range(24):
+            pos = int(rng.integers(0, L - n + 1)) if rep else (0 if n % 2 else L - n)     # also flush with both ends of the contig
+            seq = "".join(refseq[pos + k] if rng.random() > 0.1 else "ACGT"[int(rng.integers(0, 4))] for k in range(n))
+            r = Rd()
+            r.pos, r.seq, r.l_qseq, r.flag, r.qname = pos, seq, n, 0, "t%d_%d" % (n, rep)
+            r.qual = rng.integers(2, 42, n).astype(np.int32)
+            r.bamcigar = np.array([(n << 4) | 0], dtype=np.uint32)
+            r.zq = None
+            reads.append(r)
+    order = rng.permutation(len(reads))                       # lengths mixed inside the wavefronts
+    reads = [reads[i] for i in order]
+    for flag in (3, 7):
+        rs = []
+        for r in reads:
+            c = Rd(); c.__dict__.update(r.__dict__); c.qual = r.qual.copy(); rs.append(c)
+        ctx = gpu_ctx_factory(abi.default_cfg(1, max_sites=1, max_reads=64))
+        want = _oracle(rs, refseq, flag)
+        ret = M.apply_baq_hip(rs, refseq, ctx, flag)
+        n_ok = 0
+        for r, (rc, wq, wz), rr in zip(rs, want, ret):
+            assert (rc == 0) == (rr == 0), r.qname
+            if rc == 0:
+                n_ok += 1
+                np.testing.assert_array_equal(r.qual, wq, err_msg=r.qname)
+                np.testing.assert_array_equal(r.zq, wz, err_msg=r.qname)
+        assert n_ok > 150

@@ -89,3 +89,25 @@ def test_without_a_plan_the_first_255_are_taken(gpu_ctx_factory):
     assert_mplp_equal(ctx.mpileup(snp), orc.mpileup(cfg, snp, deep_rule=1))
     n = abi.C.c_uint32()
     assert ctx.L.bcfgpu_truncated_cells(ctx.h, abi.C.byref(n)) == 0 and n.value == 2
+
+
+def test_a_plan_without_deep_cells_spends_nothing_and_bad_arguments_are_refused(gpu_ctx_factory):
+    rng = np.random.default_rng(11)
+    snp = _tile(rng, 3, 2, [40, 255, 30, 200, 10, 0])             # 255 reads is not over-deep
+    cfg = abi.default_cfg(2, max_sites=3, max_reads=len(snp.rd))
+    ctx = gpu_ctx_factory(cfg)
+    s0 = int(ctx.L.bcfgpu_errmod_state(ctx.h))
+    got, _ = ctx.mpileup_planned(snp)
+    assert int(ctx.L.bcfgpu_errmod_state(ctx.h)) == s0 == 0x1234ABCD330E
+    assert_mplp_equal(got, orc.mpileup(cfg, snp, deep_rule=0))
+    assert ctx.L.bcfgpu_errmod_plan(ctx.h, None, None, None, None) == abi.E_ARG
+    assert ctx.L.bcfgpu_errmod_plan(None, None, None, None, None) == abi.E_ARG
+    # an indel tile without the columns it belongs to cannot be ranked
+    ind = _tile(rng, 1, 2, [300, 20], is_indel=True)
+    ds, sb = ctx.upload_tile(snp)
+    di, ib = ctx.upload_tile(ind)
+    try:
+        assert ctx.L.bcfgpu_errmod_plan(ctx.h, abi.C.byref(ds), abi.C.byref(di), None, None) == abi.E_ARG
+        assert int(ctx.L.bcfgpu_errmod_state(ctx.h)) == s0
+    finally:
+        ctx.release(sb + ib)
