@@ -607,6 +607,16 @@ static void put_counts(const char *lead, const int32_t *f, const int32_t *r, int
     for (int j = 0; j < n; ++j) fprintf(LN, "%s%d", j ? "," : "", (f ? f[j] : 0) + (r ? r[j] : 0));
 }
 
+static char *put_int(char *o, int64_t v)
+{
+    char t[24]; int n = 0;
+    uint64_t u = v < 0 ? (uint64_t)(-v) : (uint64_t)v;
+    if (v < 0) *o++ = '-';
+    do { t[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    while (n) *o++ = t[--n];
+    return o;
+}
+
 /* what bcf_call2bcf writes into a record, in its order (bam2bcf.c:756-906); alleles: the ready REF\tALT text */
 static void print_record(const char *contig, int pos1, const char *alleles, const char *prefix, const bcfgpu_site *c,
                          const planes_t *pp, size_t k, int S)
@@ -642,26 +652,36 @@ static void print_record(const char *contig, int pos1, const char *alleles, cons
     if (fmt_flag & BCFGPU_FMT_QS) fputs(":QS", LN);
     const int x = na * (na + 1) / 2;
     const size_t Ss = (size_t)S;
+    /* the samples' columns: small non-negative integers, thousands of them per record -- written by hand into one buffer (a
+     * printf call per number was three fifths of a run's wall time at 40 samples) */
+    static char *sb; static size_t sbcap;
+    const size_t need = (size_t)S * (size_t)(16 + 4 * x + 12 * 4 + 12 * 20 + 16) + 64;    /* generous: every number at most 11 characters */
+    if (need > sbcap) { sbcap = need; sb = grow(sb, sbcap); }
+    char *o = sb;
+    #define PUT_INT(v_) (o = put_int(o, (int64_t)(v_)))
     for (int s = 0; s < S; ++s) {
-        fputc('\t', LN);
-        for (int j = 0; j < x; ++j) fprintf(LN, "%s%d", j ? "," : "", pp->pl[(k * BCFGPU_MAX_PL + j) * Ss + s]);
+        *o++ = '\t';
+        for (int j = 0; j < x; ++j) { if (j) *o++ = ','; PUT_INT(pp->pl[(k * BCFGPU_MAX_PL + j) * Ss + s]); }
         const uint16_t *d = pp->dp4 + k * 4 * Ss + s;                        /* FORMAT/DP, DV, DP4 from DP4 (bam2bcf.c:851-886) */
-        if (fmt_flag & BCFGPU_FMT_DP) fprintf(LN, ":%d", d[0] + d[Ss] + d[2 * Ss] + d[3 * Ss]);
-        if (fmt_flag & BCFGPU_FMT_DV) fprintf(LN, ":%d", d[2 * Ss] + d[3 * Ss]);
-        if (fmt_flag & BCFGPU_FMT_SP) fprintf(LN, ":%d", pp->sp[k * Ss + s]);
-        if (fmt_flag & BCFGPU_FMT_DP4) fprintf(LN, ":%d,%d,%d,%d", d[0], d[Ss], d[2 * Ss], d[3 * Ss]);
+        if (fmt_flag & BCFGPU_FMT_DP) { *o++ = ':'; PUT_INT(d[0] + d[Ss] + d[2 * Ss] + d[3 * Ss]); }
+        if (fmt_flag & BCFGPU_FMT_DV) { *o++ = ':'; PUT_INT(d[2 * Ss] + d[3 * Ss]); }
+        if (fmt_flag & BCFGPU_FMT_SP) { *o++ = ':'; PUT_INT(pp->sp[k * Ss + s]); }
+        if (fmt_flag & BCFGPU_FMT_DP4) { *o++ = ':'; PUT_INT(d[0]); *o++ = ','; PUT_INT(d[Ss]); *o++ = ','; PUT_INT(d[2 * Ss]); *o++ = ','; PUT_INT(d[3 * Ss]); }
         for (int which = 0; which < 4; ++which) {                            /* ADF, ADR, AD, DPR */
             static const int bit[4] = { BCFGPU_FMT_ADF, BCFGPU_FMT_ADR, BCFGPU_FMT_AD, BCFGPU_FMT_DPR };
             if (!(fmt_flag & bit[which])) continue;
-            fputc(':', LN);
+            *o++ = ':';
             for (int j = 0; j < na; ++j) {
                 const int f = pp->adf[(k * 5 + j) * Ss + s], r = pp->adr[(k * 5 + j) * Ss + s];
-                fprintf(LN, "%s%d", j ? "," : "", which == 0 ? f : which == 1 ? r : f + r);
+                if (j) *o++ = ',';
+                PUT_INT(which == 0 ? f : which == 1 ? r : f + r);
             }
         }
-        if (fmt_flag & BCFGPU_FMT_SCR) fprintf(LN, ":%d", pp->scr[k * Ss + s]);
-        if (fmt_flag & BCFGPU_FMT_QS) { fputc(':', LN); for (int j = 0; j < na; ++j) fprintf(LN, "%s%d", j ? "," : "", pp->qs[(k * 5 + j) * Ss + s]); }
+        if (fmt_flag & BCFGPU_FMT_SCR) { *o++ = ':'; PUT_INT(pp->scr[k * Ss + s]); }
+        if (fmt_flag & BCFGPU_FMT_QS) { *o++ = ':'; for (int j = 0; j < na; ++j) { if (j) *o++ = ','; PUT_INT(pp->qs[(k * 5 + j) * Ss + s]); } }
     }
+    #undef PUT_INT
+    fwrite(sb, 1, (size_t)(o - sb), LN);
     end_record();
 }
 
@@ -760,9 +780,15 @@ static void pending_set(const char *contig, const bcfgpu_gvcf_block *B, char ref
 /* ---- one tile: columns [t0, t1) of `contig` from the reads in P (all the reads that overlap the tile, file-major; file f =
  * [first[f], first[f+1])).  Every stage on the device; the records of the tile are written in position order. ---- */
 static unsigned long long tot_entries, tot_pairs;
+/* --timing: where the wall time of a run goes (seconds): reading and parsing the files, building a tile's pool, the device
+ * stages of a tile (every call up to the records' planes on the host), writing the records */
+#include <time.h>
+static int want_timing; static double t_read, t_pool, t_dev, t_emit;
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 static void process_tile(pool_t *P, const int *first, int F, int S, const char *contig, const char *ref, int ref_len, int t0, int t1)
 {
     const int n_sites = t1 - t0;
+    const double tw0 = want_timing ? now_s() : 0.;
     ensure_ctx(S, n_sites, (uint64_t)P->nbase + 64);
     /* mate overlaps: htslib pairs the reads inside one file's iterator (bam_mplp_init_overlaps, mpileup.c:640) */
     int32_t *pa = malloc((size_t)(P->n + 1) * sizeof *pa), *pb = malloc((size_t)(P->n + 1) * sizeof *pb);
@@ -887,6 +913,8 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
     /* ---- the record loop: the SNP record of a column, then its indel record (mpileup.c:343-366) ---- */
     static const char *nt = "ACGTN";
     int jl = 0;
+    const double tw1 = want_timing ? now_s() : 0.;
+    t_dev += tw1 - tw0;
     for (int k = 0; k < n_sites; ++k) {
         if (col_n[k] == 0) continue;                                         /* no read: no record */
         const bcfgpu_site *c = &site[k];
@@ -948,6 +976,7 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
     free(col_n); free(col_indel); free(cand); free(live);
     free(g_types); free(g_maxins); free(g_indelreg); free(g_support); free(g_frac); free(g_inscns);
     free(gv_blk); free(gv_block); free(gv_dp); free(gv_pl);
+    if (want_timing) t_emit += now_s() - tw1;
 }
 
 /* ---- the live window: the reads of every file that passed the filters and the depth cap and may still cover a column ---- */
@@ -1198,6 +1227,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "--output")) { out_path = argv[2]; argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-f") || !strcmp(argv[1], "--fasta-ref")) { ref_path = argv[2]; argv += 2; argc -= 2; }      /* mpileup.c:1008,1056 */
         else if (!strcmp(argv[1], "-r") || !strcmp(argv[1], "--regions")) { reg_arg = argv[2]; argv += 2; argc -= 2; }          /* mpileup.c:1011,1057 */
+        else if (!strcmp(argv[1], "--timing")) { want_timing = 1; argv += 1; argc -= 1; }
         else if (!strcmp(argv[1], "--tile")) { tile_cols = atoi(argv[2]); if (tile_cols < 1) DIE("--tile: at least one column\n"); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-d")) { max_depth = atoi(argv[2]); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-s")) { add_samples(argv[2], 0); argv += 2; argc -= 2; }            /* mpileup.c:1058-1059,1087,1016 */
@@ -1351,6 +1381,7 @@ int main(int argc, char **argv)
              * 174-175), and those qualities carry the mate-overlap tweak of a mate that may lie wholly outside the tile -- so a
              * read's mate has to be in the pool with it.  margin = the longest reference span seen so far + the window. */
             int margin = max_span + 64, margin_read;
+            const double tr0 = want_timing ? now_s() : 0.;
             /* stage 1: the reads that start before the tile's end come off the files, through -C (BAQ + sam_cap_mapq + the
              * deferred filters) and the depth cap, into the live window */
             do {                                                             /* (again when a longer read widened the margin) */
@@ -1395,6 +1426,8 @@ int main(int argc, char **argv)
             }
             margin = max_span + 64;
             } while (margin > margin_read);
+            const double tr1 = want_timing ? now_s() : 0.;
+            t_read += tr1 - tr0;
             if (!list_only) {
                 /* stage 2: the tile's pool = the reads of the window that overlap the tile, file after file */
                 pool_clear(&P);
@@ -1403,6 +1436,7 @@ int main(int argc, char **argv)
                     for (int i = 0; i < win[f].n; ++i) { const lrec_t *x = win[f].r[i]; if (overlaps(x->pos, x->end, t0 - margin, t1 + margin)) pool_add_rec(&P, f, x); }
                 }
                 first[F] = P.n;
+                if (want_timing) t_pool += now_s() - tr1;
                 if (P.n) { process_tile(&P, first, F, S, contig, ref, ref_len, t0, t1); ++n_tiles; }
                 else pending_flush();                                       /* columns without a read: a gap ends a gVCF block (gvcf.c:131) */
                 n_cols_tot += (unsigned long long)(t1 - t0);
@@ -1436,6 +1470,7 @@ int main(int argc, char **argv)
                                       "instead of errmod_cal's draw\n", n_wide_cells);
     fprintf(stderr, "%llu reads of %d samples, %llu overlapping pairs, %llu pileup entries in %llu columns (%d tiles of <= %d)\n",
             n_reads_tot, S, tot_pairs, tot_entries, n_cols_tot, n_tiles, tile_cols);
+    if (want_timing) fprintf(stderr, "[bcfgpu_sam] seconds: reading and parsing the files %.3f, tile pools %.3f, device stages %.3f, writing records %.3f\n", t_read, t_pool, t_dev, t_emit);
     if (vio_close(fout)) DIE("%s\n", vio_error());
     if (ctx) bcfgpu_destroy(ctx);
     if (cap_ctx) bcfgpu_destroy(cap_ctx);
