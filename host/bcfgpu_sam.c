@@ -607,16 +607,6 @@ static void put_counts(const char *lead, const int32_t *f, const int32_t *r, int
     for (int j = 0; j < n; ++j) fprintf(LN, "%s%d", j ? "," : "", (f ? f[j] : 0) + (r ? r[j] : 0));
 }
 
-static char *put_int(char *o, int64_t v)
-{
-    char t[24]; int n = 0;
-    uint64_t u = v < 0 ? (uint64_t)(-v) : (uint64_t)v;
-    if (v < 0) *o++ = '-';
-    do { t[n++] = (char)('0' + u % 10); u /= 10; } while (u);
-    while (n) *o++ = t[--n];
-    return o;
-}
-
 /* what bcf_call2bcf writes into a record, in its order (bam2bcf.c:756-906); alleles: the ready REF\tALT text */
 static void print_record(const char *contig, int pos1, const char *alleles, const char *prefix, const bcfgpu_site *c,
                          const planes_t *pp, size_t k, int S)
@@ -652,37 +642,33 @@ static void print_record(const char *contig, int pos1, const char *alleles, cons
     if (fmt_flag & BCFGPU_FMT_QS) fputs(":QS", LN);
     const int x = na * (na + 1) / 2;
     const size_t Ss = (size_t)S;
-    /* the samples' columns: small non-negative integers, thousands of them per record -- written by hand into one buffer (a
-     * printf call per number was three fifths of a run's wall time at 40 samples) */
-    static char *sb; static size_t sbcap;
-    const size_t need = (size_t)S * (size_t)(16 + 4 * x + 12 * 4 + 12 * 20 + 16) + 64;    /* generous: every number at most 11 characters */
-    if (need > sbcap) { sbcap = need; sb = grow(sb, sbcap); }
-    char *o = sb;
-    #define PUT_INT(v_) (o = put_int(o, (int64_t)(v_)))
-    for (int s = 0; s < S; ++s) {
-        *o++ = '\t';
-        for (int j = 0; j < x; ++j) { if (j) *o++ = ','; PUT_INT(pp->pl[(k * BCFGPU_MAX_PL + j) * Ss + s]); }
-        const uint16_t *d = pp->dp4 + k * 4 * Ss + s;                        /* FORMAT/DP, DV, DP4 from DP4 (bam2bcf.c:851-886) */
-        if (fmt_flag & BCFGPU_FMT_DP) { *o++ = ':'; PUT_INT(d[0] + d[Ss] + d[2 * Ss] + d[3 * Ss]); }
-        if (fmt_flag & BCFGPU_FMT_DV) { *o++ = ':'; PUT_INT(d[2 * Ss] + d[3 * Ss]); }
-        if (fmt_flag & BCFGPU_FMT_SP) { *o++ = ':'; PUT_INT(pp->sp[k * Ss + s]); }
-        if (fmt_flag & BCFGPU_FMT_DP4) { *o++ = ':'; PUT_INT(d[0]); *o++ = ','; PUT_INT(d[Ss]); *o++ = ','; PUT_INT(d[2 * Ss]); *o++ = ','; PUT_INT(d[3 * Ss]); }
-        for (int which = 0; which < 4; ++which) {                            /* ADF, ADR, AD, DPR */
-            static const int bit[4] = { BCFGPU_FMT_ADF, BCFGPU_FMT_ADR, BCFGPU_FMT_AD, BCFGPU_FMT_DPR };
-            if (!(fmt_flag & bit[which])) continue;
-            *o++ = ':';
+    /* the samples' columns go to the writer as integer arrays, one per FORMAT key in the order of the keys above (a printf call
+     * per number, and a parse of every number on the way into a BCF record, were three fifths of a run's wall time at 40 samples) */
+    static int32_t *col[12]; static size_t colcap[12];
+    int width[12], nk = 0;
+    #define COL(w_) (width[nk] = (w_), (colcap[nk] < (size_t)S * (size_t)(w_) ? (colcap[nk] = (size_t)S * (size_t)(w_), col[nk] = grow(col[nk], colcap[nk] * 4)) : col[nk]), col[nk++])
+    { int32_t *a = COL(x); for (int s = 0; s < S; ++s) for (int j = 0; j < x; ++j) a[(size_t)s * x + j] = pp->pl[(k * BCFGPU_MAX_PL + j) * Ss + s]; }
+    const uint16_t *d = pp->dp4 + k * 4 * Ss;                                /* FORMAT/DP, DV, DP4 from DP4 (bam2bcf.c:851-886) */
+    if (fmt_flag & BCFGPU_FMT_DP) { int32_t *a = COL(1); for (int s = 0; s < S; ++s) a[s] = d[s] + d[Ss + s] + d[2 * Ss + s] + d[3 * Ss + s]; }
+    if (fmt_flag & BCFGPU_FMT_DV) { int32_t *a = COL(1); for (int s = 0; s < S; ++s) a[s] = d[2 * Ss + s] + d[3 * Ss + s]; }
+    if (fmt_flag & BCFGPU_FMT_SP) { int32_t *a = COL(1); for (int s = 0; s < S; ++s) a[s] = pp->sp[k * Ss + s]; }
+    if (fmt_flag & BCFGPU_FMT_DP4) { int32_t *a = COL(4); for (int s = 0; s < S; ++s) for (int j = 0; j < 4; ++j) a[(size_t)s * 4 + j] = d[(size_t)j * Ss + s]; }
+    for (int which = 0; which < 4; ++which) {                                /* ADF, ADR, AD, DPR */
+        static const int bit[4] = { BCFGPU_FMT_ADF, BCFGPU_FMT_ADR, BCFGPU_FMT_AD, BCFGPU_FMT_DPR };
+        if (!(fmt_flag & bit[which])) continue;
+        int32_t *a = COL(na);
+        for (int s = 0; s < S; ++s)
             for (int j = 0; j < na; ++j) {
                 const int f = pp->adf[(k * 5 + j) * Ss + s], r = pp->adr[(k * 5 + j) * Ss + s];
-                if (j) *o++ = ',';
-                PUT_INT(which == 0 ? f : which == 1 ? r : f + r);
+                a[(size_t)s * na + j] = which == 0 ? f : which == 1 ? r : f + r;
             }
-        }
-        if (fmt_flag & BCFGPU_FMT_SCR) { *o++ = ':'; PUT_INT(pp->scr[k * Ss + s]); }
-        if (fmt_flag & BCFGPU_FMT_QS) { *o++ = ':'; for (int j = 0; j < na; ++j) { if (j) *o++ = ','; PUT_INT(pp->qs[(k * 5 + j) * Ss + s]); } }
     }
-    #undef PUT_INT
-    fwrite(sb, 1, (size_t)(o - sb), LN);
-    end_record();
+    if (fmt_flag & BCFGPU_FMT_SCR) { int32_t *a = COL(1); for (int s = 0; s < S; ++s) a[s] = pp->scr[k * Ss + s]; }
+    if (fmt_flag & BCFGPU_FMT_QS) { int32_t *a = COL(na); for (int s = 0; s < S; ++s) for (int j = 0; j < na; ++j) a[(size_t)s * na + j] = pp->qs[(k * 5 + j) * Ss + s]; }
+    #undef COL
+    fputc(0, LN); fflush(LN);
+    if (vio_write_record_int(fout, hdr, ln_buf, nk, width, (const int32_t *const *)col)) { fprintf(stderr, "%s\n", vio_error()); exit(1); }
+    rewind(LN);
 }
 
 /* bcfgpu_mpileup over a tile; the site records and the planes come back to the host.  keep_*: the device copies of the

@@ -417,7 +417,9 @@ static int32_t int_val(const char *s, size_t n)
 static int count_char(const char *s, size_t n, char c) { int k = 0; for (size_t i = 0; i < n; ++i) k += s[i] == c; return k; }
 
 /* one VCF text record -> BCF2 (l_shared, l_indiv, shared, indiv) appended to `out` */
-static int encode_record(const vio_hdr *h, const char *line, sbuf *out)
+/* vals != NULL: the per-sample columns are not in `line` (which ends with the FORMAT keys) but in integer arrays, n_keys of them,
+ * vals[k][s * width[k] + j] (vio_write_record_int) */
+static int encode_record(const vio_hdr *h, const char *line, sbuf *out, int n_keys, const int *width, const int32_t *const *vals)
 {
     const char *fld[10]; size_t fl[10]; int nf = 0;
     const char *p = line;
@@ -476,7 +478,7 @@ static int encode_record(const vio_hdr *h, const char *line, sbuf *out)
     int n_fmt = 0, n_sample = 0;
     /* FORMAT keys */
     int fkey[64];
-    if (nf == 9 && samples && h->n_smpl) {
+    if (nf == 9 && (samples || vals) && h->n_smpl) {
         n_sample = h->n_smpl;
         const char *q = fld[8], *qe = fld[8] + fl[8];
         while (q < qe && n_fmt < 64) {
@@ -509,6 +511,17 @@ static int encode_record(const vio_hdr *h, const char *line, sbuf *out)
     }
     sb_put(&sh, inf.s ? inf.s : "", inf.l);
     free(inf.s);
+    if (n_fmt && vals) {
+        /* per-sample fields from the caller's arrays: what the text path below would have parsed out of the line */
+        const int S = n_sample;
+        if (n_fmt != n_keys) { free(sh.s); return fail("%d FORMAT keys, %d columns of values", n_fmt, n_keys); }
+        for (int k = 0; k < n_fmt; ++k) {
+            const int d = fkey[k];
+            if (h->dict[d].fmt_type != T_INT || !strcmp(h->dict[d].id, "GT") || width[k] < 1) { free(sh.s); free(in.s); return fail("FORMAT/%s cannot be written from integer columns", h->dict[d].id); }
+            enc_int1(&in, d);
+            if (S * width[k] == 1) enc_int1(&in, vals[k][0]); else enc_vint(&in, S * width[k], vals[k], width[k]);
+        }
+    } else
     /* per-sample fields: the columns of every sample split once */
     if (n_fmt) {
         const int S = n_sample;
@@ -702,7 +715,42 @@ int vio_write_line(vio_file *f, const vio_hdr *h, const char *line)
 {
     if (!f->bcf) return out_bytes(f, line, strlen(line)) || out_bytes(f, "\n", 1);
     f->rec.l = 0;
-    if (encode_record(h, line, &f->rec)) return -1;
+    if (encode_record(h, line, &f->rec, 0, NULL, NULL)) return -1;
+    return out_bytes(f, f->rec.s, f->rec.l);
+}
+int vio_write_record_int(vio_file *f, const vio_hdr *h, const char *head, int n_keys, const int *width, const int32_t *const *vals)
+{
+    f->rec.l = 0;
+    if (f->bcf) {
+        if (encode_record(h, head, &f->rec, n_keys, width, vals)) return -1;
+        return out_bytes(f, f->rec.s, f->rec.l);
+    }
+    /* VCF text: the head, then every sample's columns (a vector ends at VIO_INT_VEND; an empty one and a missing value are '.');
+     * written straight into the buffer, room for a sample's columns reserved at once */
+    sb_put(&f->rec, head, strlen(head));
+    size_t per = 2;
+    for (int k = 0; k < n_keys; ++k) per += (size_t)width[k] * 12 + 1;
+    for (int s = 0; s < h->n_smpl; ++s) {
+        sb_need(&f->rec, per);
+        char *o = f->rec.s + f->rec.l;
+        *o++ = '\t';
+        for (int k = 0; k < n_keys; ++k) {
+            if (k) *o++ = ':';
+            const int32_t *a = vals[k] + (size_t)s * (size_t)width[k];
+            for (int j = 0; j < width[k]; ++j) {
+                if (a[j] == I_VEND) { if (!j) *o++ = '.'; break; }
+                if (j) *o++ = ',';
+                if (a[j] == I_MISSING) { *o++ = '.'; continue; }
+                char t[16]; int n = 0;
+                uint32_t u = a[j] < 0 ? (uint32_t)(-(int64_t)a[j]) : (uint32_t)a[j];
+                if (a[j] < 0) *o++ = '-';
+                do { t[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+                while (n) *o++ = t[--n];
+            }
+        }
+        f->rec.l = (size_t)(o - f->rec.s);
+    }
+    sb_putc(&f->rec, '\n');
     return out_bytes(f, f->rec.s, f->rec.l);
 }
 int vio_read_line(vio_file *f, const vio_hdr *h, char **line, size_t *cap)

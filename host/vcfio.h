@@ -11,6 +11,7 @@
 #ifndef VCFIO_H
 #define VCFIO_H
 #include <stddef.h>
+#include <stdint.h>
 #include <stdio.h>
 
 typedef struct vio_hdr vio_hdr;
@@ -34,6 +35,13 @@ const char *vio_hdr_line(const vio_hdr *h, int i);              /* meta line i (
 vio_file *vio_open_write(const char *path, char mode);          /* path "-" = stdout; mode 'v', 'z', 'u' or 'b' */
 int  vio_write_hdr(vio_file *f, const vio_hdr *h);
 int  vio_write_line(vio_file *f, const vio_hdr *h, const char *line);   /* one VCF record as text, without the newline */
+/* A record whose per-sample columns are integers, handed over as arrays instead of text: `head` = the first nine columns (CHROM .. FORMAT,
+ * tab separated, no newline); for the k-th FORMAT key the n_samples x width[k] values vals[k][s * width[k] + j] (VIO_INT_VEND after a sample's
+ * last value, VIO_INT_MISSING for '.').  The same bytes as vio_write_line of the full text line, as VCF and as BCF -- without a number being
+ * printed and parsed back on the way into a BCF record. */
+#define VIO_INT_MISSING INT32_MIN
+#define VIO_INT_VEND    (INT32_MIN + 1)
+int  vio_write_record_int(vio_file *f, const vio_hdr *h, const char *head, int n_keys, const int *width, const int32_t *const *vals);
 vio_file *vio_open_read(const char *path);                      /* path "-" = stdin; VCF, bgzipped VCF or BCF2, detected */
 vio_hdr *vio_read_hdr(vio_file *f);
 int  vio_read_line(vio_file *f, const vio_hdr *h, char **line, size_t *cap);   /* 1: a record (as VCF text) in *line, 0: end, <0: error */
