@@ -57,7 +57,7 @@ struct bcfgpu_ctx {
     struct Ws { void *p = nullptr; size_t bytes = 0; };
     alignas(16) unsigned char pileup_state[256] = {0};   // csrc/pileup.hip: the parameters of the last bcfgpu_pileup
     alignas(16) unsigned char pool_state[256] = {0};     // kernels.h DevPool: the read pool bcfgpu_pool_upload left in HBM
-    Ws ws[144];                    // grow-only device workspaces of the host-fed stages (0-15: BAQ / overlaps, 16-35: pileup, 36-39: gVCF / indel tile, 40-103: gap_prep, 104-135: the resident read pool and its stages, 136-143: errmod_cal's draw)
+    Ws ws[152];                    // grow-only device workspaces of the host-fed stages (0-15: BAQ / overlaps, 16-35: pileup, 36-39: gVCF / indel tile, 40-103: gap_prep, 104-135: the resident read pool and its stages, 136-143: errmod_cal's draw, 144-151: BAQ's smaller band classes, which run beside the main one)
     int n_cu = 256;                // compute units of the device (grid size of the work-queue kernels)
     hipStream_t side[8] = {};      // created on first use: the realignment kernels of different band widths run side by side
     hipEvent_t side_ev[9] = {};    // [0..7] a side stream's work is done, [8] the fork point on the main stream
@@ -633,7 +633,7 @@ void *bcfgpu_internal_pool_state(bcfgpu_ctx *c) { return c ? c->pool_state : nul
 // workspace `slot` of at least `bytes` (contents undefined); nullptr when the allocation fails
 void *bcfgpu_internal_ws(bcfgpu_ctx *c, int slot, size_t bytes)
 {
-    if (!c || slot < 0 || slot >= 144) return nullptr;
+    if (!c || slot < 0 || slot >= 152) return nullptr;
     auto &w = c->ws[slot];
     if (w.bytes >= bytes && w.p) return w.p;
     hipSetDevice(c->cfg.device);

@@ -21,6 +21,7 @@ int bcfgpu_set_error(int code, const char *what);
 extern "C" int bcfgpu_internal_device(bcfgpu_ctx *ctx, hipStream_t *stream, const float **q2p);
 extern "C" void *bcfgpu_internal_ws(bcfgpu_ctx *ctx, int slot, size_t bytes);
 extern "C" void *bcfgpu_internal_pinned(bcfgpu_ctx *ctx, int slot, size_t bytes);
+extern "C" int bcfgpu_internal_side(bcfgpu_ctx *ctx, hipStream_t **streams, hipEvent_t **events);
 
 namespace bcfgpu {
 
@@ -865,10 +866,22 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
     P.seq16 = D.seq16; P.qual = D.qual; P.cig = D.cig;
     P.q2p = d_q2p; P.state = (int32_t*)d_state; P.q = (uint8_t*)d_q; P.tmp = (uint8_t*)d_tmp;
     P.qual_out = d_qo; P.zq_out = d_zo;
-    for (int c = 0; c < 3; ++c) {
+    // The three band classes are independent (their reads are disjoint): the two small ones (band 8: a few per cent of the reads;
+    // wider bands: a handful) go to side streams with row buffers of their own and are launched FIRST, so that their few hundred
+    // wavefronts run beside the main class instead of after it -- a launch of 178 wavefronts takes as long as its slowest
+    // wavefront, half a millisecond with the chip otherwise idle.
+    hipStream_t *side = nullptr; hipEvent_t *sev = nullptr;
+    if (bcfgpu_internal_side(ctx, &side, &sev)) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_baq: side streams");
+    BQ_CHK(hipEventRecord(sev[0], stream));
+    static const int slotF[3] = { 4, 144, 147 }, slotS[3] = { 2, 145, 148 }, slotW[3] = { 5, 146, -1 };
+    bool used_side[3] = { false, false, false };
+    for (int ci = 0; ci < 3; ++ci) {
+        const int c = ci == 0 ? 1 : ci == 1 ? 2 : 0;                              // the small classes first
         const size_t nj = (size_t)counts[c == 2 ? 6 : c];
         if (!nj) continue;
         const bool reg = c < 2;
+        hipStream_t st = c == 0 ? stream : side[c - 1];
+        if (c) { BQ_CHK(hipStreamWaitEvent(st, sev[0], 0)); used_side[c] = true; }
         P.ncell = reg ? 2 * (2 * (c ? BAQ_BWM2 : BAQ_BWM) + 3) : 3 * (2 * counts[2] + 1) + 6;       // doubles per matrix row
         const size_t per_mat = (size_t)(reg ? BAQ_ROWS_KEPT(P.max_lq) : P.max_lq + 2) * P.ncell * sizeof(double);  // one matrix of one read (register-row classes: the odd rows)
         const size_t per_job = reg ? per_mat : 2 * per_mat;
@@ -876,12 +889,12 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
         chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
         if (chunk > nj) chunk = (nj + 63) & ~(size_t)63;
         P.stride = chunk;
-        void *d_F = bcfgpu_internal_ws(ctx, 4, per_mat * chunk), *d_B = reg ? nullptr : bcfgpu_internal_ws(ctx, 1, per_mat * chunk);
-        void *d_S = bcfgpu_internal_ws(ctx, 2, (size_t)(P.max_lq + 2) * chunk * sizeof(double));
+        void *d_F = bcfgpu_internal_ws(ctx, slotF[c], per_mat * chunk), *d_B = reg ? nullptr : bcfgpu_internal_ws(ctx, 1, per_mat * chunk);
+        void *d_S = bcfgpu_internal_ws(ctx, slotS[c], (size_t)(P.max_lq + 2) * chunk * sizeof(double));
         if (!d_F || (!reg && !d_B) || !d_S) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_baq: device workspace");
         if (reg) {                                                   // state / posterior quality / left maxima, a wavefront's reads side by side
             const size_t wn = chunk * (size_t)P.max_lq;
-            uint8_t *d_w = (uint8_t*)bcfgpu_internal_ws(ctx, 5, wn * 6 + 64);
+            uint8_t *d_w = (uint8_t*)bcfgpu_internal_ws(ctx, slotW[c], wn * 6 + 64);
             if (!d_w) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_baq: device workspace");
             P.wstate = (int32_t*)d_w; P.wq = d_w + wn * 4; P.wleft = d_w + wn * 5;
         }
@@ -889,12 +902,14 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
         for (size_t j0 = 0; j0 < nj; j0 += chunk) {
             P.n_jobs = (int)(nj - j0 < chunk ? nj - j0 : chunk);
             P.jobs = (c == 0 ? Q.jobs0 : c == 1 ? Q.jobs1 : Q.jobs2) + j0;
-            if (c == 0)      hipLaunchKernelGGL(baq_kernel<BAQ_BWM>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
-            else if (c == 1) hipLaunchKernelGGL(baq_kernel<BAQ_BWM2>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
-            else             hipLaunchKernelGGL(baq_kernel<0>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
+            if (c == 0)      hipLaunchKernelGGL(baq_kernel<BAQ_BWM>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, st, P);
+            else if (c == 1) hipLaunchKernelGGL(baq_kernel<BAQ_BWM2>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, st, P);
+            else             hipLaunchKernelGGL(baq_kernel<0>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, st, P);
         }
         BQ_CHK(hipGetLastError());
     }
+    for (int c = 1; c < 3; ++c)
+        if (used_side[c]) { BQ_CHK(hipEventRecord(sev[c], side[c - 1])); BQ_CHK(hipStreamWaitEvent(stream, sev[c], 0)); }
     if (ret) {
         BQ_CHK(hipMemcpyAsync(ret, Q.ret, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
         BQ_CHK(hipStreamSynchronize(stream));
