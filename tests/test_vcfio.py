@@ -133,3 +133,22 @@ def test_truncated_and_malformed_bcf_is_refused_not_overrun(tmp_path, golden_dir
         open(p, "wb").write(data)
         r = subprocess.run([VIEW, p], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode != 0, i
+
+
+def test_records_from_integer_columns_are_the_text_line_byte_for_byte(golden_dir, tmp_path):
+    """vio_write_record_int (what host/bcfgpu_sam writes its records through: the per-sample columns as integer arrays) against
+    vio_write_line of the same record's text, on every mpileup golden: the BCF2 bytes and the VCF text must not differ, and the
+    records must really have gone through it."""
+    build()
+    total = 0
+    for f in goldens(golden_dir):
+        if os.sep + "mpileup" + os.sep not in f:
+            continue
+        for mode in "uv":
+            a, b = str(tmp_path / ("a." + mode)), str(tmp_path / ("b." + mode))
+            subprocess.check_call([VIEW, "-O", mode, "-o", a, f])
+            p = subprocess.run([VIEW, "--int-columns", "-O", mode, "-o", b, f], stderr=subprocess.PIPE, universal_newlines=True, check=True)
+            assert open(a, "rb").read() == open(b, "rb").read(), (f, mode)
+            if mode == "u":
+                total += int(p.stderr.split()[0])
+    assert total > 5000
