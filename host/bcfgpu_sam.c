@@ -48,6 +48,7 @@
 #include <sys/wait.h>
 #include <fcntl.h>
 #include <signal.h>
+#include <pthread.h>
 #include <sys/syscall.h>
 extern long syscall(long number, ...);       /* (unistd.h keeps it back under -std=c99 -D_POSIX_C_SOURCE) */
 #include "bcfgpu.h"
@@ -347,7 +348,11 @@ typedef struct {
     int tid, n_ref; char **ref_name; int32_t *ref_len;      /* BAM: the reference dictionary; tid = the region's contig */
     char *text;                                             /* the header text ('@' lines) */
     char *line; size_t line_cap; int have_line;             /* SAM: one text line of look-ahead */
-    lrec_t *pend;                                           /* the next read, not yet taken */
+    lrec_t *pend;                                           /* the next read parsed, not yet handed on (the parsing side's) */
+    /* the consuming side: parsed reads wait in a ring (filled by a parsing thread, below); head = the next read, not yet taken */
+    lrec_t *head; int drained;
+    lrec_t **q; int q_rd, q_n, q_done;                      /* ring of RQ_CAP reads; q_done: the parsing side is through with the region */
+    struct parser *owner;
 } reader_t;
 
 static int32_t le32(const uint8_t *p) { return (int32_t)((uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24); }
@@ -474,7 +479,7 @@ static lrec_t *lrec_new(const char *qname, int flag, int pos, int mapq, int rnex
 }
 
 /* the next read of the file that can enter the pileup of region [reg_beg, reg_end) of `contig`, into r->pend; r->done at the end */
-static void reader_fetch(reader_t *r, const char *contig, const sfile_t *sf)
+static void reader_parse(reader_t *r, const char *contig, const sfile_t *sf)
 {
     if (r->pend || r->done) return;
     uint32_t cig[4096];
@@ -548,6 +553,96 @@ static void reader_fetch(reader_t *r, const char *contig, const sfile_t *sf)
         r->pend = x;
         return;
     }
+}
+
+/* ---- parsing beside the device: up to N_PARSERS threads, thread t owning the readers f = t, t + N, ...  A thread parses the
+ * next read of each of its files in turn into that file's ring and sleeps when all its rings are full; the main thread takes the
+ * reads from the rings in file order, as it took them from the files.  (Parsing SAM text / inflating BAM was a quarter of a run's
+ * wall time and waited for the device and the record writer: profiles/r4_sam_driver_probe.txt.)  One region at a time: the
+ * threads are started when the region's files are open and joined before they are closed. ---- */
+#define RQ_CAP 8192
+#define N_PARSERS 8
+struct parser {
+    pthread_t th; pthread_mutex_t mu; pthread_cond_t data, space;
+    reader_t *rdr; const sfile_t *sf; int first, step, n_files; const char *contig; int stop;
+};
+static void *parser_main(void *arg)
+{
+    struct parser *p = arg;
+    for (;;) {
+        int progress = 0, live = 0;
+        for (int f = p->first; f < p->n_files; f += p->step) {
+            reader_t *r = &p->rdr[f];
+            if (r->q_done) continue;
+            ++live;
+            pthread_mutex_lock(&p->mu);
+            const int room = RQ_CAP - r->q_n, stop = p->stop;
+            pthread_mutex_unlock(&p->mu);
+            if (stop) return NULL;
+            if (!room) continue;
+            int got = 0; lrec_t *batch[64];
+            while (got < 64 && got < room) {                       /* parsed outside the lock, handed over in batches */
+                reader_parse(r, p->contig, &p->sf[f]);
+                if (!r->pend) break;
+                batch[got++] = r->pend; r->pend = NULL;
+            }
+            pthread_mutex_lock(&p->mu);
+            for (int i = 0; i < got; ++i) { r->q[(r->q_rd + r->q_n) % RQ_CAP] = batch[i]; ++r->q_n; }
+            if (got < 64 && got < room) r->q_done = 1;              /* the file has nothing more for this region */
+            pthread_cond_broadcast(&p->data);
+            pthread_mutex_unlock(&p->mu);
+            progress += got;
+        }
+        if (!live) return NULL;
+        if (!progress) {                                            /* every ring of this thread is full: wait for the consumer */
+            pthread_mutex_lock(&p->mu);
+            int full = 1;
+            for (int f = p->first; f < p->n_files && full; f += p->step) if (!p->rdr[f].q_done && p->rdr[f].q_n < RQ_CAP) full = 0;
+            if (full && !p->stop) pthread_cond_wait(&p->space, &p->mu);
+            const int stop = p->stop;
+            pthread_mutex_unlock(&p->mu);
+            if (stop) return NULL;
+        }
+    }
+}
+static struct parser parsers[N_PARSERS]; static int n_parsers;
+static void parsers_start(reader_t *rdr, const sfile_t *sf, int F, const char *contig)
+{
+    n_parsers = F < N_PARSERS ? F : N_PARSERS;
+    for (int f = 0; f < F; ++f) { rdr[f].q = grow(NULL, RQ_CAP * sizeof *rdr[f].q); rdr[f].q_rd = rdr[f].q_n = rdr[f].q_done = 0; rdr[f].head = NULL; rdr[f].drained = 0; rdr[f].owner = &parsers[f % n_parsers]; }
+    for (int t = 0; t < n_parsers; ++t) {
+        struct parser *p = &parsers[t];
+        memset(p, 0, sizeof *p);
+        pthread_mutex_init(&p->mu, NULL); pthread_cond_init(&p->data, NULL); pthread_cond_init(&p->space, NULL);
+        p->rdr = rdr; p->sf = sf; p->first = t; p->step = n_parsers; p->n_files = F; p->contig = contig;
+        if (pthread_create(&p->th, NULL, parser_main, p)) DIE("cannot start a parsing thread\n");
+    }
+}
+static void parsers_stop(reader_t *rdr, int F)
+{
+    for (int t = 0; t < n_parsers; ++t) {
+        struct parser *p = &parsers[t];
+        pthread_mutex_lock(&p->mu); p->stop = 1; pthread_cond_broadcast(&p->space); pthread_mutex_unlock(&p->mu);
+        pthread_join(p->th, NULL);
+        pthread_mutex_destroy(&p->mu); pthread_cond_destroy(&p->data); pthread_cond_destroy(&p->space);
+    }
+    for (int f = 0; f < F; ++f) {
+        for (int i = 0; i < rdr[f].q_n; ++i) lrec_free(rdr[f].q[(rdr[f].q_rd + i) % RQ_CAP]);
+        free(rdr[f].q); rdr[f].q = NULL; rdr[f].q_n = 0;
+        lrec_free(rdr[f].head); rdr[f].head = NULL;
+    }
+    n_parsers = 0;
+}
+/* the next read of the file into r->head (NULL when the file has no more for the region) */
+static void reader_fetch(reader_t *r)
+{
+    if (r->head || r->drained) return;
+    struct parser *p = r->owner;
+    pthread_mutex_lock(&p->mu);
+    while (!r->q_n && !r->q_done) pthread_cond_wait(&p->data, &p->mu);
+    if (r->q_n) { r->head = r->q[r->q_rd]; r->q_rd = (r->q_rd + 1) % RQ_CAP; if (r->q_n-- == RQ_CAP) pthread_cond_signal(&p->space); }
+    else r->drained = 1;
+    pthread_mutex_unlock(&p->mu);
 }
 
 /* the ##contig lines of the VCF header from the first file's dictionary (mpileup.c:533-540) */
@@ -1046,7 +1141,7 @@ static int dp_range_of(int min_dp) { int r = 0; while (r < gv_n && min_dp >= gv_
 /* a (held back) + b, both block lines of the same contig: the joined line, malloc'ed */
 static char *gline_join(const gline_t *a, const gline_t *b)
 {
-    char *fa[10], *fb[10]; int na = 0, nb = 0;
+    char *fa[10] = {0}, *fb[10] = {0}; int na = 0, nb = 0;
     char *da = strdup(a->line), *db = strdup(b->line);
     for (char *s = da; na < 9 && s; ) { fa[na++] = s; s = strchr(s, '\t'); if (s) *s++ = 0; if (na == 9) fa[9] = s; }
     for (char *s = db; nb < 9 && s; ) { fb[nb++] = s; s = strchr(s, '\t'); if (s) *s++ = 0; if (nb == 9) fb[9] = s; }
@@ -1360,6 +1455,7 @@ int main(int argc, char **argv)
         if (reg_end <= reg_beg) continue;
         for (int f = 0; f < F; ++f) { reader_open(&rdr[f], kept_path[f]); for (int i = 0; i < win[f].n; ++i) lrec_free(win[f].r[i]); win[f].n = 0; }
         bcfgpu_depth_cap_reset(dcap);
+        parsers_start(rdr, sfile, F, contig);
         for (int t0 = reg_beg; t0 < reg_end; ) {
             const int t1 = t0 + tile_cols < reg_end ? t0 + tile_cols : reg_end;
             /* The tile's pool is the reads that overlap the tile widened by `margin` on both sides: the realignment of an indel
@@ -1375,10 +1471,10 @@ int main(int argc, char **argv)
             for (int f = 0; f < F; ++f) {
                 lrec_t **b = NULL; int nb = 0, bcap = 0;
                 for (;;) {
-                    reader_fetch(&rdr[f], contig, &sfile[f]);
-                    lrec_t *x = rdr[f].pend;
+                    reader_fetch(&rdr[f]);
+                    lrec_t *x = rdr[f].head;
                     if (!x || x->pos >= t1 + margin) break;
-                    rdr[f].pend = NULL;
+                    rdr[f].head = NULL;
                     if (x->end - x->pos > max_span) max_span = x->end - x->pos;
                     if (nb == bcap) { bcap = bcap ? 2 * bcap : 256; b = grow(b, (size_t)bcap * sizeof *b); }
                     b[nb++] = x;
@@ -1433,8 +1529,8 @@ int main(int argc, char **argv)
                 int m = 0;
                 for (int i = 0; i < win[f].n; ++i) { lrec_t *x = win[f].r[i]; if ((x->end == x->pos ? x->pos + 1 : x->end) > t1 - margin) win[f].r[m++] = x; else lrec_free(x); }
                 win[f].n = m; left += m;
-                reader_fetch(&rdr[f], contig, &sfile[f]);
-                if (rdr[f].pend) { more = 1; if (rdr[f].pend->pos < next_pos) next_pos = rdr[f].pend->pos; }
+                reader_fetch(&rdr[f]);
+                if (rdr[f].head) { more = 1; if (rdr[f].head->pos < next_pos) next_pos = rdr[f].head->pos; }
             }
             t0 = t1;
             if (!left) {
@@ -1442,6 +1538,7 @@ int main(int argc, char **argv)
                 if (next_pos - margin > t0) t0 = next_pos - margin;         /* a stretch without reads: on to the next read */
             }
         }
+        parsers_stop(rdr, F);
         for (int f = 0; f < F; ++f) reader_close(&rdr[f]);
     }
     if (list_only) {
