@@ -27,12 +27,12 @@ static void sb_u32(sbuf *b, uint32_t v) { sb_put(b, &v, 4); }       /* little-en
 
 /* ---- header ---- */
 enum { T_FLAG = 0, T_INT = 1, T_FLOAT = 2, T_STR = 3, T_NONE = -1 };
-typedef struct { char *id; int info_type, fmt_type; } dict_ent;
+typedef struct { char *id; size_t len; int info_type, fmt_type; } dict_ent;     /* len = strlen(id): a record looks a dozen keys up */
 struct vio_hdr { char **line; int n_line, m_line; dict_ent *dict; int n_dict; char **ctg; int n_ctg; char **smpl; int n_smpl; };
 
 static int dict_find(const vio_hdr *h, const char *id, size_t len)
 {
-    for (int i = 0; i < h->n_dict; ++i) if (h->dict[i].id && strlen(h->dict[i].id) == len && !memcmp(h->dict[i].id, id, len)) return i;
+    for (int i = 0; i < h->n_dict; ++i) if (h->dict[i].id && h->dict[i].len == len && !memcmp(h->dict[i].id, id, len)) return i;
     return -1;
 }
 static int dict_at(vio_hdr *h, const char *id, size_t len, int idx)
@@ -42,10 +42,10 @@ static int dict_at(vio_hdr *h, const char *id, size_t len, int idx)
     if (idx < 0) idx = h->n_dict;
     if (idx >= h->n_dict) {
         h->dict = realloc(h->dict, (size_t)(idx + 1) * sizeof *h->dict);
-        for (int k = h->n_dict; k <= idx; ++k) { h->dict[k].id = NULL; h->dict[k].info_type = h->dict[k].fmt_type = T_NONE; }
+        for (int k = h->n_dict; k <= idx; ++k) { h->dict[k].id = NULL; h->dict[k].len = 0; h->dict[k].info_type = h->dict[k].fmt_type = T_NONE; }
         h->n_dict = idx + 1;
     }
-    h->dict[idx].id = malloc(len + 1); memcpy(h->dict[idx].id, id, len); h->dict[idx].id[len] = 0;
+    h->dict[idx].id = malloc(len + 1); memcpy(h->dict[idx].id, id, len); h->dict[idx].id[len] = 0; h->dict[idx].len = len;
     return idx;
 }
 /* value of KEY= inside the <...> of a meta line, or NULL */

@@ -39,7 +39,7 @@ for k in range(a.samples):
             f.write("r%d\t%d\tchr1\t%d\t60\t100M\t*\t0\t0\t%s\t%s\tRG:Z:s%d\n" % (i, 16 * int(rng.integers(0, 2)), q + 1, "".join(seq), qual, k))
     nreads += n
 print("wrote %d reads of %d samples over %d kb in %.0f s" % (nreads, a.samples, a.kb, time.time() - t0), flush=True)
-for opts, om in ((["-B"], "u"), (["-B"], "v"), ([], "u")):
+for opts, om in ((["-B"], "u"), (["-B"], "v"), ([], "u"), (["-B", "--tile", "4096"], "u"), (["-B", "--tile", "65536"], "u")):
     t0 = time.time()
     p = subprocess.run([exe, "--timing"] + opts + ["-O", om, "-o", os.path.join(d, "out." + om), "-f", fa, "-r", "chr1"] + files, stderr=subprocess.PIPE, universal_newlines=True)
     dt = time.time() - t0
