@@ -694,11 +694,25 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ?
                 if (!__any(cb > 0)) continue;
                 // key7 of the lane's i-th other read if it shows base b, else -1
                 auto src = [=](int i) { const uint32_t k = kp[i]; return (int)KEY_B(k) == b ? (int)(k & 0x7f) : -1; };
-                uint64_t qm = 0;
                 const int no = cb > 0 ? (int)n_other : 0;
+                double bs;
+                if (!__any(cb > 1)) {
+                    // No cell of the wavefront has two reads of this base (sequencing errors: three wavefronts in four): a lane's walk
+                    // would be its one read -- the first of its strand and of its base, fk[0] * beta[q][0][n] added to +0 -- without the
+                    // slot counting and the run bookkeeping around it.
+                    int key = -1;
+                    for (int i = 0; __any(i < no); ++i) { const int k7 = i < no ? src(i) : -1; if (k7 >= 0) key = k7; }
+                    const uint32_t off1 = key >= 0 ? ((uint32_t)(key >> 1) << 19) + brow : brow;
+                    const double B1 = *reinterpret_cast<const double*>(bbase + off1);
+                    const double F1 = key >= 0 ? s_fk[0] : s_fk[256];
+                    bs = 0.;
+                    bs += F1 * B1;
+                } else {
+                uint64_t qm = 0;
                 for (int i = 0; i < no; ++i) { const int key = src(i); if (key >= 0) qm |= 1ull << (key >> 1); }
                 uint32_t r_, q_;
-                const double bs = walk_runs(s_cnt, qm, s_fk, bbase, tid, brow, src, no, r_, q_);
+                bs = walk_runs(s_cnt, qm, s_fk, bbase, tid, brow, src, no, r_, q_);
+                }
                 if (cb > 0) {
                     #pragma unroll
                     for (int bb = 0; bb < 5; ++bb) if (bb == b) bsum[bb] = bs;
