@@ -560,7 +560,7 @@ static void reader_parse(reader_t *r, const char *contig, const sfile_t *sf)
  * reads from the rings in file order, as it took them from the files.  (Parsing SAM text / inflating BAM was a quarter of a run's
  * wall time and waited for the device and the record writer: profiles/r4_sam_driver_probe.txt.)  One region at a time: the
  * threads are started when the region's files are open and joined before they are closed. ---- */
-#define RQ_CAP 8192
+static int RQ_CAP = 8192;      /* reads a file's ring holds: 8192, fewer with many files (about a million reads waiting in all) */
 #define N_PARSERS 8
 struct parser {
     pthread_t th; pthread_mutex_t mu; pthread_cond_t data, space;
@@ -609,7 +609,8 @@ static struct parser parsers[N_PARSERS]; static int n_parsers;
 static void parsers_start(reader_t *rdr, const sfile_t *sf, int F, const char *contig)
 {
     n_parsers = F < N_PARSERS ? F : N_PARSERS;
-    for (int f = 0; f < F; ++f) { rdr[f].q = grow(NULL, RQ_CAP * sizeof *rdr[f].q); rdr[f].q_rd = rdr[f].q_n = rdr[f].q_done = 0; rdr[f].head = NULL; rdr[f].drained = 0; rdr[f].owner = &parsers[f % n_parsers]; }
+    RQ_CAP = (1 << 20) / (F > 0 ? F : 1); if (RQ_CAP > 8192) RQ_CAP = 8192; if (RQ_CAP < 64) RQ_CAP = 64;
+    for (int f = 0; f < F; ++f) { rdr[f].q = grow(NULL, (size_t)RQ_CAP * sizeof *rdr[f].q); rdr[f].q_rd = rdr[f].q_n = rdr[f].q_done = 0; rdr[f].head = NULL; rdr[f].drained = 0; rdr[f].owner = &parsers[f % n_parsers]; }
     for (int t = 0; t < n_parsers; ++t) {
         struct parser *p = &parsers[t];
         memset(p, 0, sizeof *p);
