@@ -574,10 +574,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ?
         const int cnt_raw = part ? (int)(end - beg) : 0;
         // A cell with more than 255 usable reads.  bcf_call_glfgen counts every read (QS, ADF/ADR, anno[], SCR, the site's I16
         // sums and histograms: bam2bcf.c:203-252, all done by phase A or below over all keys); only errmod_cal cuts its input to
-        // 255 (bam2bcf.c:256; htslib errmod.c draws them with hts_drand48, a process-wide generator no parallel order can replay).
-        // Here the cell's counts over ALL reads go to a WideRec (kernels.h), and the keys past the 255th usable read are cleared
-        // so that everything below -- which only feeds the likelihoods of such a cell -- sees the 255 reads errmod_cal takes.
-        // Counted in P.trunc (bcfgpu_truncated_cells: cells whose PLs may deviate from a reference run).
+        // 255 (bam2bcf.c:256; htslib errmod.c draws them with hts_drand48, one generator for the whole process).
+        // Here the cell's counts over ALL reads go to a WideRec (kernels.h), and the keys errmod_cal would not take are cleared
+        // so that everything below -- which only feeds the likelihoods of such a cell -- sees 255 reads: the ones marked by
+        // bcfgpu_errmod_plan (draw.hip: the draw replayed in mpileup's visit order), else the first 255, which is counted in
+        // P.trunc (bcfgpu_truncated_cells: cells whose PLs may deviate from a reference run).
         if (__any(cnt_raw > BCFGPU_MAX_DEPTH)) {
             if (cnt_raw > BCFGPU_MAX_DEPTH) {
                 uint32_t nus = 0;
