@@ -31,8 +31,8 @@
  *  and the record loop writes what bcf_call2bcf (bam2bcf.c:756-906) puts in the record, in its order, under mpileup's header
  *  (mpileup.c:510-602), as VCF, bgzipped VCF or BCF (host/vcfio.c).  tests/test_c_host.py compares the whole output with the
  *  reference's goldens test/mpileup/mpileup.{1..11}.out, mpileup-SCR.out, indel-AD.1.out -- one tile and many.
- *  Not here: CRAM input, index files (a region far into a file is reached by reading up to it), BED files (-l/-T),
- *  --illumina1.3+; a sample fed by several files has its reads merged by position (the reference appends file after file: same
+ *  Not here: CRAM input, index files (a region far into a file is reached by reading up to it), BED files (-l/-T);
+ *  a sample fed by several files has its reads merged by position (the reference appends file after file: same
  *  records unless a cell passes 255 usable reads, where errmod_cal's draw then meets the reads in another order).
  */
 #include <stdio.h>
@@ -282,6 +282,7 @@ static int sample_of(const sfile_t *f, const char *rg)                      /* b
 
 /* ---- reading: SAM text or BAM; the read filters of mplp_func (mpileup.c:183-246) ---- */
 static int rflag_require = 0, rflag_filter = 4 | 256 | 512 | 1024, min_mq = 0, keep_orphans = 0;
+static int illumina13;                                                          /* mpileup -6: qualities in the Illumina-1.3+ encoding (mpileup.c:216-221) */
 static int defer_mq_filters = 0;
 static int reg_beg = 0, reg_end = 0x7fffffff;   /* the region: only reads that overlap it enter the pool, as htslib's region iterator hands them out */      /* -C: sam_cap_mapq comes between the flag filters and the -q / orphan filters (mpileup.c:234-241) */
 
@@ -510,6 +511,7 @@ static void reader_parse(reader_t *r, const char *contig, const sfile_t *sf)
             if (smpl < 0) continue;
             lrec_t *x = lrec_new((const char *)b + 36, flag, pos, mapq, next_ref == refid, next_pos, tlen, cig, n_cig, l_seq, smpl);
             for (int i = 0; i < l_seq; ++i) { x->seq16[i] = (sq[i >> 1] >> ((~i & 1) << 2)) & 15; x->qual[i] = ql[i]; }
+            if (illumina13) for (int i = 0; i < l_seq; ++i) x->qual[i] = x->qual[i] > 31 ? (uint8_t)(x->qual[i] - 31) : 0;
             r->pend = x;
             return;
         }
@@ -550,6 +552,7 @@ static void reader_parse(reader_t *r, const char *contig, const sfile_t *sf)
         lrec_t *x = lrec_new(fld[0], flag, pos, mapq, !strcmp(fld[6], "=") || !strcmp(fld[6], fld[2]), atoi(fld[7]) - 1, atoi(fld[8]), cig, ncig, lq, smpl);
         const int noq = fld[10][0] == '*' && !fld[10][1];
         for (int i = 0; i < lq; ++i) { x->seq16[i] = (uint8_t)nt16_of(fld[9][i]); x->qual[i] = noq ? 0xff : (uint8_t)(fld[10][i] - 33); }
+        if (illumina13) for (int i = 0; i < lq; ++i) x->qual[i] = x->qual[i] > 31 ? (uint8_t)(x->qual[i] - 31) : 0;
         r->pend = x;
         return;
     }
@@ -1211,7 +1214,7 @@ static int run_shards(int n_gpus, int argc0, char **argv0, int first_file, const
             if (!strcmp(o, "-o")) { char *e; strtol(argv0[i + 1], &e, 10); if (*e) { ++i; continue; } }
             if (o[0] != '-') break;                              /* the positional form: ref.fa contig beg end come from -f / -r below */
             av[n++] = argv0[i];
-            if (o[0] == '-' && i + 1 < first_file && argv0[i + 1][0] != '-' && strcmp(o, "-B") && strcmp(o, "-E") && strcmp(o, "-A") && strcmp(o, "-p") && strcmp(o, "-I")
+            if (o[0] == '-' && i + 1 < first_file && argv0[i + 1][0] != '-' && strcmp(o, "-B") && strcmp(o, "-E") && strcmp(o, "-A") && strcmp(o, "-p") && strcmp(o, "-I") && strcmp(o, "-6") && strcmp(o, "--illumina1.3+") && strcmp(o, "--timing")
                 && strcmp(o, "--ignore-RG") && strcmp(o, "--list-samples")) av[n++] = argv0[++i];
         }
         av[n++] = "-f"; av[n++] = (char *)ref_path; av[n++] = "-r"; av[n++] = rl;
@@ -1319,6 +1322,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "--list-samples")) { list_only = 1; ++argv; --argc; }
         else if (!strcmp(argv[1], "--gpus")) { n_gpus = atoi(argv[2]); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "--shard")) { shard = atoi(argv[2]); argv += 2; argc -= 2; }                 /* host logic only: no device needed */
+        else if (!strcmp(argv[1], "-6") || !strcmp(argv[1], "--illumina1.3+")) { illumina13 = 1; ++argv; --argc; }                  /* mpileup.c:1057 */
         else if (!strcmp(argv[1], "-B")) { baq_flag = 0; ++argv; --argc; }                             /* mpileup.c:1045,1062 */
         else if (!strcmp(argv[1], "-E")) { baq_flag = 7; ++argv; --argc; }
         else if (!strcmp(argv[1], "-A")) { keep_orphans = 1; ++argv; --argc; }
@@ -1562,7 +1566,7 @@ int main(int argc, char **argv)
     return 0;
 usage:
     fprintf(stderr, "usage: bcfgpu_sam [-a TAG,..] [--gvcf INT,..] [-O v|z|u|b] [-o out] [-d INT] [-s LIST | -S FILE] [-G FILE] [--ignore-RG]\n"
-                    "                  [-B | -E] [-A] [-q INT] [-Q INT] [-C INT] [--ff INT] [--rf INT] [-I] [-o INT] [-e INT] [-h INT] [-m INT] [-F FLOAT] [-p] [-L INT]\n"
+                    "                  [-B | -E] [-6] [-A] [-q INT] [-Q INT] [-C INT] [--ff INT] [--rf INT] [-I] [-o INT] [-e INT] [-h INT] [-m INT] [-F FLOAT] [-p] [-L INT]\n"
                     "                  [--tile COLUMNS] [--gpus N]\n"
                     "                  -f ref.fa [-r CHR[:BEG[-END]],...] file.sam|file.bam [...]      (as `bcftools mpileup`)\n"
                     "              or  ref.fa contig beg end file.sam|file.bam [...]                    (beg, end 1-based inclusive)\n");

@@ -551,3 +551,22 @@ def test_c_sam_driver_deep_cells_match_the_oracle_in_visit_order(golden_dir, tmp
             assert [int(x) for x in r.fmt("AD", s_).split(",")] == [int(res.adf[0][a][s_]) + int(res.adr[0][a][s_]) for a in range(na)], (r.pos, s_)
             deep += int(r.fmt("DP", s_)) > 255
     assert deep > 150 and open_pl > 100
+
+
+@pytest.mark.gpu
+def test_c_sam_driver_illumina13_qualities(golden_dir, tmp_path):
+    """`-6` / `--illumina1.3+` (mpileup.c:216-221: every quality q becomes q > 31 ? q - 31 : 0 as the read comes off the file): the
+    input of mpileup.1.out with its qualities re-encoded 31 higher gives, with -6, the golden of the original."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    shifted = []
+    for i in (1, 2, 3):
+        shifted.append(str(tmp_path / ("illumina13.%d.sam" % i)))
+        with open(shifted[-1], "w") as out:
+            for ln in open(os.path.join(G, "mpileup.%d.sam" % i)):
+                f = ln.rstrip("\n").split("\t")
+                if not ln.startswith("@") and len(f) > 10 and f[10] != "*":
+                    assert max(ord(c) for c in f[10]) + 31 < 127
+                    f[10] = "".join(chr(ord(c) + 31) for c in f[10])
+                out.write("\t".join(f) + "\n")
+    whole_file_checks([SAM_EXE, "-6", os.path.join(G, "mpileup.ref.fa"), "17", "100", "150"] + shifted, os.path.join(G, "mpileup.1.out"))
