@@ -1,7 +1,7 @@
 /*  bcfgpu_sam.c -- `bcftools mpileup` over SAM / BAM files with every stage of the path on the device, in plain C over the
  *  C-ABI of include/bcfgpu.h (SNP and indel records).
  *
- *      bcfgpu_sam [options] -f ref.fa [-r CHR[:BEG[-END]],...] file.sam|file.bam [...]         (mpileup's own spelling, mpileup.c:952-1003)
+ *      bcfgpu_sam [options] -f ref.fa [-r CHR[:BEG[-END]],... | -R FILE] [-b FILE] file.sam|file.bam [...]         (mpileup's own spelling, mpileup.c:952-1003)
  *      bcfgpu_sam [options] ref.fa contig beg end file.sam|file.bam [...]                       (beg, end 1-based inclusive)
  *      options: -a TAG,..  --gvcf INT,..  -O v|z|u|b  -o FILE  -d INT  -s LIST  -S FILE  -G FILE  --ignore-RG
  *               -B  -E  -A  -q INT  -Q INT  -C INT  --ff INT  --rf INT  -I -o INT -e INT -h INT -m INT -F FLOAT -p -L INT   (as `bcftools mpileup`)
@@ -282,6 +282,7 @@ static int sample_of(const sfile_t *f, const char *rg)                      /* b
 
 /* ---- reading: SAM text or BAM; the read filters of mplp_func (mpileup.c:183-246) ---- */
 static int rflag_require = 0, rflag_filter = 4 | 256 | 512 | 1024, min_mq = 0, keep_orphans = 0;
+static int no_overlaps;                                                         /* mpileup -x: the mates' overlaps are left alone (mpileup.c:1005) */
 static int illumina13;                                                          /* mpileup -6: qualities in the Illumina-1.3+ encoding (mpileup.c:216-221) */
 static int defer_mq_filters = 0;
 static int reg_beg = 0, reg_end = 0x7fffffff;   /* the region: only reads that overlap it enter the pool, as htslib's region iterator hands them out */      /* -C: sam_cap_mapq comes between the flag filters and the -q / orphan filters (mpileup.c:234-241) */
@@ -878,7 +879,7 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
     /* mate overlaps: htslib pairs the reads inside one file's iterator (bam_mplp_init_overlaps, mpileup.c:640) */
     int32_t *pa = malloc((size_t)(P->n + 1) * sizeof *pa), *pb = malloc((size_t)(P->n + 1) * sizeof *pb);
     int np = 0;
-    for (int f = 0; f < F; ++f) np += find_pairs(P, first[f], first[f + 1], pa + np, pb + np);
+    if (!no_overlaps) for (int f = 0; f < F; ++f) np += find_pairs(P, first[f], first[f + 1], pa + np, pb + np);
     tot_pairs += (unsigned long long)np;
     /* a sample fed by several files (mpileup.c:275-293 appends file after file): its reads merged by position, files in
      * order at equal positions, as bcfgpu_pileup wants them; the pairs follow their reads */
@@ -1209,12 +1210,12 @@ static int run_shards(int n_gpus, int argc0, char **argv0, int first_file, const
         av[n++] = argv0[0]; av[n++] = "--shard"; av[n++] = strdup(sk);
         for (int i = 1; i < first_file; ++i) {                   /* the options, without -O / -o FILE / --output / --gpus / -r / -f and the old positional region */
             const char *o = argv0[i];
-            if (!strcmp(o, "--gpus") || !strcmp(o, "--output") || !strcmp(o, "-O") || !strcmp(o, "-r") || !strcmp(o, "--regions") || !strcmp(o, "-f") || !strcmp(o, "--fasta-ref")) { ++i; continue; }
+            if (!strcmp(o, "--gpus") || !strcmp(o, "--output") || !strcmp(o, "-O") || !strcmp(o, "-r") || !strcmp(o, "--regions") || !strcmp(o, "-R") || !strcmp(o, "--regions-file") || !strcmp(o, "-f") || !strcmp(o, "--fasta-ref")) { ++i; continue; }
             if (!strncmp(o, "-O", 2) && o[2]) continue;
             if (!strcmp(o, "-o")) { char *e; strtol(argv0[i + 1], &e, 10); if (*e) { ++i; continue; } }
             if (o[0] != '-') break;                              /* the positional form: ref.fa contig beg end come from -f / -r below */
             av[n++] = argv0[i];
-            if (o[0] == '-' && i + 1 < first_file && argv0[i + 1][0] != '-' && strcmp(o, "-B") && strcmp(o, "-E") && strcmp(o, "-A") && strcmp(o, "-p") && strcmp(o, "-I") && strcmp(o, "-6") && strcmp(o, "--illumina1.3+") && strcmp(o, "--timing")
+            if (o[0] == '-' && i + 1 < first_file && argv0[i + 1][0] != '-' && strcmp(o, "-B") && strcmp(o, "-E") && strcmp(o, "-A") && strcmp(o, "-p") && strcmp(o, "-I") && strcmp(o, "-6") && strcmp(o, "--illumina1.3+") && strcmp(o, "--timing") && strcmp(o, "-x") && strcmp(o, "--ignore-overlaps")
                 && strcmp(o, "--ignore-RG") && strcmp(o, "--list-samples")) av[n++] = argv0[++i];
         }
         av[n++] = "-f"; av[n++] = (char *)ref_path; av[n++] = "-r"; av[n++] = rl;
@@ -1277,7 +1278,7 @@ int main(int argc, char **argv)
 {
     char out_mode = 'v'; const char *out_path = "-";                           /* mpileup -O, -o (mpileup.c:937-950) */
     int list_only = 0, n_gpus = 1, shard = -1;                                /* --gpus N: region shards, one process per shard; --shard K: this is shard K */
-    const char *ref_path = NULL, *reg_arg = NULL;
+    const char *ref_path = NULL, *reg_arg = NULL, *reg_file = NULL, *file_list = NULL;
     char **argv0 = argv; const int argc0 = argc;
     while (argc > 2 && argv[1][0] == '-' && argv[1][1]) {
         if (!strcmp(argv[1], "-a")) {                                         /* mpileup -a, mpileup.c:parse_format_flag */
@@ -1312,6 +1313,10 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "--output")) { out_path = argv[2]; argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-f") || !strcmp(argv[1], "--fasta-ref")) { ref_path = argv[2]; argv += 2; argc -= 2; }      /* mpileup.c:1008,1056 */
         else if (!strcmp(argv[1], "-r") || !strcmp(argv[1], "--regions")) { reg_arg = argv[2]; argv += 2; argc -= 2; }          /* mpileup.c:1011,1057 */
+        else if (!strcmp(argv[1], "-R") || !strcmp(argv[1], "--regions-file")) { reg_file = argv[2]; argv += 2; argc -= 2; }    /* mpileup.c:1031 */
+        else if (!strcmp(argv[1], "-b") || !strcmp(argv[1], "--bam-list")) { file_list = argv[2]; argv += 2; argc -= 2; }       /* mpileup.c:1072 */
+        else if (!strcmp(argv[1], "-x") || !strcmp(argv[1], "--ignore-overlaps")) { no_overlaps = 1; ++argv; --argc; }          /* mpileup.c:1005 */
+        else if (!strcmp(argv[1], "--threads")) { argv += 2; argc -= 2; }                                                      /* (the output's compression threads: nothing to do here) */
         else if (!strcmp(argv[1], "--timing")) { want_timing = 1; argv += 1; argc -= 1; }
         else if (!strcmp(argv[1], "--tile")) { tile_cols = atoi(argv[2]); if (tile_cols < 1) DIE("--tile: at least one column\n"); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-d")) { max_depth = atoi(argv[2]); argv += 2; argc -= 2; }
@@ -1343,20 +1348,57 @@ int main(int argc, char **argv)
     /* two spellings of what to run on: mpileup's own (-f REF [-r CHR[:BEG[-END]],...] files), or "ref.fa contig beg end files" */
     region_t *reg = NULL; int n_reg = 0;
     int n_in; char **in_path;
+    int n_pos;                                                                /* input files named on the command line (the others: -b) */
     if (ref_path) {
-        if (argc < 2) goto usage;
-        n_in = argc - 1; in_path = argv + 1;
+        if (argc < 2 && !file_list) goto usage;
+        n_in = n_pos = argc - 1; in_path = argv + 1;
+        if (file_list) {
+            /* -b FILE: a file of input paths, one per line, empty lines and trailing blanks allowed (read_file_list, mpileup.c:733-790) */
+            FILE *fl = fopen(file_list, "r");
+            if (!fl) DIE("cannot open %s\n", file_list);
+            char **all = grow(NULL, (size_t)(n_in + 1) * sizeof *all);
+            memcpy(all, in_path, (size_t)n_in * sizeof *all);
+            char *ln = NULL; size_t lcap = 0;
+            while (getline(&ln, &lcap, fl) > 0) {
+                size_t l = strlen(ln);
+                while (l && isspace((unsigned char)ln[l - 1])) ln[--l] = 0;
+                if (!l) continue;
+                all = grow(all, (size_t)(n_in + 2) * sizeof *all);
+                all[n_in++] = strdup(ln);
+            }
+            free(ln); fclose(fl);
+            if (n_in == n_pos) DIE("No files read from %s\n", file_list);
+            in_path = all;
+        }
         if (reg_arg) {
             char *list = strdup(reg_arg);
             for (char *t = strtok(list, ","); t; t = strtok(NULL, ",")) { reg = grow(reg, (size_t)(n_reg + 1) * sizeof *reg); reg[n_reg++] = parse_region(t); }
             free(list);
+        }
+        if (reg_file) {
+            /* -R FILE: tab-delimited CHROM, POS and, optionally, END (1-based, inclusive), or CHROM alone; '#' starts a comment */
+            FILE *fr = fopen(reg_file, "r");
+            if (!fr) DIE("cannot open %s\n", reg_file);
+            char *ln = NULL; size_t lcap = 0;
+            while (getline(&ln, &lcap, fr) > 0) {
+                size_t l = strlen(ln);
+                while (l && isspace((unsigned char)ln[l - 1])) ln[--l] = 0;
+                if (!l || ln[0] == '#') continue;
+                char *c1 = strchr(ln, '\t'), *c2 = c1 ? strchr(c1 + 1, '\t') : NULL;
+                char spec[1200];
+                if (!c1) snprintf(spec, sizeof spec, "%s", ln);
+                else { *c1 = 0; if (c2) *c2 = 0; snprintf(spec, sizeof spec, "%.1000s:%ld-%ld", ln, atol(c1 + 1), c2 ? atol(c2 + 1) : atol(c1 + 1)); }
+                reg = grow(reg, (size_t)(n_reg + 1) * sizeof *reg); reg[n_reg++] = parse_region(spec);
+            }
+            free(ln); fclose(fr);
+            if (!n_reg) DIE("no region in %s\n", reg_file);
         }
     } else {
         if (argc < 6) goto usage;
         ref_path = argv[1];
         reg = grow(NULL, sizeof *reg); n_reg = 1;
         reg[0].contig = strdup(argv[2]); reg[0].beg = atoi(argv[3]) - 1; reg[0].end = atoi(argv[4]);     /* 1-based inclusive -> 0-based [beg, end) */
-        n_in = argc - 5; in_path = argv + 5;
+        n_in = n_pos = argc - 5; in_path = argv + 5;
     }
     defer_mq_filters = cap_thres > 10;
 
@@ -1394,7 +1436,7 @@ int main(int argc, char **argv)
     for (int i = 0; i < n_reg; ++i) if (reg[i].end < 0) { reg[i].open = 1; reg[i].end = OPEN_END; }
     if (n_gpus > 1 && shard < 0 && !list_only) {
         for (int i = 0; i < n_reg; ++i) if (reg[i].open) { int len = 0; char *sq = read_contig(ref_path, reg[i].contig, &len); reg[i].end = len > reg[i].beg ? len : reg[i].beg + 1; free(sq); }
-        return run_shards(n_gpus, argc0, argv0, argc0 - n_in, ref_path, reg, n_reg, out_path, out_mode);
+        return run_shards(n_gpus, argc0, argv0, argc0 - n_pos, ref_path, reg, n_reg, out_path, out_mode);
     }
     if (shard > 0 && !list_only) { const int nd = bcfgpu_device_count(); device = nd > 0 ? shard % nd : 0; if (nd > 1) fprintf(stderr, "[bcfgpu_sam] shard %d on device %d of %d\n", shard, device, nd); }
     /* ---- the VCF header, in mpileup's order (mpileup.c:510-602) ---- */
@@ -1566,9 +1608,9 @@ int main(int argc, char **argv)
     return 0;
 usage:
     fprintf(stderr, "usage: bcfgpu_sam [-a TAG,..] [--gvcf INT,..] [-O v|z|u|b] [-o out] [-d INT] [-s LIST | -S FILE] [-G FILE] [--ignore-RG]\n"
-                    "                  [-B | -E] [-6] [-A] [-q INT] [-Q INT] [-C INT] [--ff INT] [--rf INT] [-I] [-o INT] [-e INT] [-h INT] [-m INT] [-F FLOAT] [-p] [-L INT]\n"
+                    "                  [-B | -E] [-6] [-x] [-A] [-q INT] [-Q INT] [-C INT] [--ff INT] [--rf INT] [-I] [-o INT] [-e INT] [-h INT] [-m INT] [-F FLOAT] [-p] [-L INT]\n"
                     "                  [--tile COLUMNS] [--gpus N]\n"
-                    "                  -f ref.fa [-r CHR[:BEG[-END]],...] file.sam|file.bam [...]      (as `bcftools mpileup`)\n"
+                    "                  -f ref.fa [-r CHR[:BEG[-END]],... | -R FILE] [-b FILE] file.sam|file.bam [...]      (as `bcftools mpileup`)\n"
                     "              or  ref.fa contig beg end file.sam|file.bam [...]                    (beg, end 1-based inclusive)\n");
     return 2;
 }

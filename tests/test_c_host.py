@@ -570,3 +570,35 @@ def test_c_sam_driver_illumina13_qualities(golden_dir, tmp_path):
                     f[10] = "".join(chr(ord(c) + 31) for c in f[10])
                 out.write("\t".join(f) + "\n")
     whole_file_checks([SAM_EXE, "-6", os.path.join(G, "mpileup.ref.fa"), "17", "100", "150"] + shifted, os.path.join(G, "mpileup.1.out"))
+
+
+@pytest.mark.gpu
+def test_c_sam_driver_file_list_and_regions_file(golden_dir, tmp_path):
+    """`-b FILE` (the inputs listed in a file, mpileup.c:733-790, 1072) and `-R FILE` (the regions in a file, mpileup.c:1031): the
+    whole of mpileup.2.out from a list of its three inputs and a one-line regions file -- also through two region shards."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    lst, regs = str(tmp_path / "inputs.txt"), str(tmp_path / "regions.txt")
+    with open(lst, "w") as f:
+        f.write("\n".join(os.path.join(G, "mpileup.%d.sam" % i) + "  " for i in (1, 2, 3)) + "\n\n")
+    with open(regs, "w") as f:
+        f.write("# CHROM POS END\n17\t100\t600\n")
+    base = [SAM_EXE, "-a", "DP,DV", "-f", os.path.join(G, "mpileup.ref.fa"), "-R", regs, "-b", lst]
+    whole_file_checks(base, os.path.join(G, "mpileup.2.out"))
+    whole_file_checks(base[:1] + ["--gpus", "2"] + base[1:], os.path.join(G, "mpileup.2.out"))
+
+
+@pytest.mark.gpu
+def test_c_sam_driver_ignore_overlaps(golden_dir):
+    """`-x` / `--ignore-overlaps` (mpileup.c:1005): the mates' overlapping bases keep their qualities -- the same columns as
+    mpileup.2.out, other likelihoods where mates overlap."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    cmd = [SAM_EXE, "-a", "DP,DV", "-f", os.path.join(G, "mpileup.ref.fa"), "-r", "17:100-600"] + [os.path.join(G, "mpileup.%d.sam" % i) for i in (1, 2, 3)]
+    a = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, check=True)
+    b = subprocess.run(cmd[:1] + ["-x"] + cmd[1:], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, check=True)
+    ra = [ln.split("\t") for ln in a.stdout.splitlines() if not ln.startswith("#")]
+    rb = [ln.split("\t") for ln in b.stdout.splitlines() if not ln.startswith("#")]
+    assert [r[:2] for r in ra] == [r[:2] for r in rb] and len(ra) > 400
+    assert "0 overlapping pairs" in b.stderr and "0 overlapping pairs" not in a.stderr
+    assert sum(x[7:] != y[7:] for x, y in zip(ra, rb)) > 10
