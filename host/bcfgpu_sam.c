@@ -1316,6 +1316,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "-R") || !strcmp(argv[1], "--regions-file")) { reg_file = argv[2]; argv += 2; argc -= 2; }    /* mpileup.c:1031 */
         else if (!strcmp(argv[1], "-b") || !strcmp(argv[1], "--bam-list")) { file_list = argv[2]; argv += 2; argc -= 2; }       /* mpileup.c:1072 */
         else if (!strcmp(argv[1], "-x") || !strcmp(argv[1], "--ignore-overlaps")) { no_overlaps = 1; ++argv; --argc; }          /* mpileup.c:1005 */
+        else if (!strcmp(argv[1], "-P") || !strcmp(argv[1], "--platforms")) { argv += 2; argc -= 2; }                          /* read and never used by the reference either (mpileup.c:353, 1052) */
         else if (!strcmp(argv[1], "--threads")) { argv += 2; argc -= 2; }                                                      /* (the output's compression threads: nothing to do here) */
         else if (!strcmp(argv[1], "--timing")) { want_timing = 1; argv += 1; argc -= 1; }
         else if (!strcmp(argv[1], "--tile")) { tile_cols = atoi(argv[2]); if (tile_cols < 1) DIE("--tile: at least one column\n"); argv += 2; argc -= 2; }
