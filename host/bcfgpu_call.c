@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
 #include <stdint.h>
 #include "bcfgpu.h"
 #include "vcfio.h"
@@ -303,9 +304,36 @@ static int pick_target(const char *chrom, int pos, const char *ref, char **alts,
     return best;
 }
 
+/* the sites `call` passes over before anything else (vcfcall.c:1095-1099): -V snps / indels by htslib's bcf_is_snp (every allele one
+ * base that is not '*', or the symbolic <X> / <*>), and -- unless -M -- a reference allele that starts with N */
+static int unwanted_site(const char *line, int acgt_only, int skip_kind)
+{
+    const char *f = line; int tabs = 0;
+    for (; *f && tabs < 3; ++f) if (*f == '\t') ++tabs;
+    if (tabs < 3) return 0;
+    const char *ref = f, *re = strchr(ref, '\t');
+    if (!re) return 0;
+    const char *alt = re + 1, *ae = strchr(alt, '\t');
+    if (!ae) ae = alt + strlen(alt);
+    if (skip_kind) {
+        int is_snp = (re - ref == 1 && ref[0] != '*');
+        if (!(ae - alt == 1 && alt[0] == '.'))
+            for (const char *a = alt; is_snp && a < ae; ) {
+                const char *e = memchr(a, ',', (size_t)(ae - a)); if (!e) e = ae;
+                const size_t l = (size_t)(e - a);
+                if (!((l == 1 && a[0] != '*') || (l == 3 && a[0] == '<' && (a[1] == 'X' || a[1] == '*') && a[2] == '>'))) is_snp = 0;
+                a = e + 1;
+            }
+        if (skip_kind == 1 && is_snp) return 1;                  /* -V snps: CF_INDEL_ONLY */
+        if (skip_kind == 2 && !is_snp) return 1;                 /* -V indels: CF_NO_INDEL */
+    }
+    return acgt_only && (ref[0] == 'N' || ref[0] == 'n');
+}
+
 int main(int argc, char **argv)
 {
     int varonly = 0, out_tags = 0, keepalt = 0;
+    int acgt_only = 1, skip_kind = 0;                           /* vcfcall.c:937 (CF_ACGT_ONLY is the default); -V: 1 = snps, 2 = indels */
     const char *tgt_file = NULL; double prior = 1.1e-3;
     const char *smpl_file = NULL, *ploidy_file = NULL, *grp_arg = NULL, *grp_tag = NULL;
     char prior_an_tag[64] = "", prior_ac_tag[64] = "";
@@ -315,6 +343,15 @@ int main(int argc, char **argv)
         if (!strcmp(argv[1], "-v")) { varonly = 1; ++argv; --argc; }
         else if (!strcmp(argv[1], "-m")) { ++argv; --argc; }                                     /* the multiallelic caller: the only one here */
         else if (!strcmp(argv[1], "-A")) { keepalt = 1; ++argv; --argc; }
+        else if (!strcmp(argv[1], "-M") || !strcmp(argv[1], "--keep-masked-refs")) { acgt_only = 0; ++argv; --argc; }      /* vcfcall.c:1000 */
+        else if (!strcmp(argv[1], "-N") || !strcmp(argv[1], "--skip-Ns")) { acgt_only = 1; ++argv; --argc; }               /* vcfcall.c:1001: the default */
+        else if ((!strcmp(argv[1], "-V") || !strcmp(argv[1], "--skip-variants")) && argc > 3) {                              /* vcfcall.c:1032-1036 */
+            if (!strcasecmp(argv[2], "snps")) skip_kind = 1; else if (!strcasecmp(argv[2], "indels")) skip_kind = 2;
+            else DIE("Unknown skip category \"%s\" (-V argument must be \"snps\" or \"indels\")\n", argv[2]);
+            argv += 2; argc -= 2;
+        }
+        else if (!strcmp(argv[1], "--threads") && argc > 3) { argv += 2; argc -= 2; }                                        /* (compression threads: nothing to do here) */
+        else if (!strcmp(argv[1], "--no-version")) { ++argv; --argc; }                                                       /* (no ##bcftools_callVersion lines are written anyway) */
         else if (!strcmp(argv[1], "-i")) { insert_missed = 1; ++argv; --argc; }
         else if (!strcmp(argv[1], "-C") && argc > 3) { if (strcmp(argv[2], "alleles")) DIE("-C: only `alleles` is supported\n"); cals = 1; argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-T") && argc > 3) { tgt_file = argv[2]; argv += 2; argc -= 2; }
@@ -356,7 +393,7 @@ int main(int argc, char **argv)
     }
     if (gv_n && varonly) DIE("The two options cannot be combined: --variants-only and --gvcf\n");       /* vcfcall.c:1085 */
     if (gv_n && cals) DIE("-g with -C alleles is not supported\n");
-    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-g INT,...] [-S samples.txt] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] [-A] [-P theta] [-C alleles -T targets.tab [-i]] [-O v|z|u|b] [-o out] in.vcf|in.bcf\n"); return 2; }
+    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-M] [-V snps|indels] [-g INT,...] [-S samples.txt] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] [-A] [-P theta] [-C alleles -T targets.tab [-i]] [-O v|z|u|b] [-o out] in.vcf|in.bcf\n"); return 2; }
     /* ploidy definition (ploidy.c): regions per sex, '*' lines = the sex's default; the last sex named is the default sex */
     preg_t *preg = NULL; int npreg = 0; char last_sex[64] = "";
     if (ploidy_file) {
@@ -426,21 +463,22 @@ int main(int argc, char **argv)
             int skip = ti < 0;
             if (!skip) {
                 tgt[ti].used = 1;
-                if (insert_missed) {                             /* tgt_flush (vcfcall.c:426-455) */
+                int un = 0;
+                for (int i = 0; i < nalt2; ++i) { const char *a = av[i]; if (!un && (a[0] == 'X' || (a[0] == '<' && (a[1] == 'X' || a[1] == '*') && a[2] == '>'))) un = 1 + i; }
+                owned = constrain_line(buf, &tgt[ti], S_in, &un);
+                if (!owned) skip = 1; else use = owned;
+                if (!skip && unwanted_site(use, acgt_only, skip_kind)) { free(owned); owned = NULL; skip = 1; }   /* (the skipped record flushes no targets either: vcfcall.c:1095-1099 come before tgt_flush) */
+                if (!skip && insert_missed) {                    /* tgt_flush (vcfcall.c:426-455) */
                     const long p0 = pos2 - 1;
                     if (!prev_chrom) flush_region(f2[0], 0, p0 - 1);
                     else if (strcmp(prev_chrom, f2[0])) { flush_region(prev_chrom, prev_pos0 + 1, 1L << 40); flush_region(f2[0], 0, p0 - 1); }
                     else flush_region(prev_chrom, prev_pos0, p0 - 1);
                     free(prev_chrom); prev_chrom = strdup(f2[0]); prev_pos0 = p0;
                 }
-                int un = 0;
-                for (int i = 0; i < nalt2; ++i) { const char *a = av[i]; if (!un && (a[0] == 'X' || (a[0] == '<' && (a[1] == 'X' || a[1] == '*') && a[2] == '>'))) un = 1 + i; }
-                owned = constrain_line(buf, &tgt[ti], S_in, &un);
-                if (!owned) skip = 1; else use = owned;
             }
             free(av); free(ac); free(f2); free(c2);
             if (skip) continue;
-        }
+        } else if (unwanted_site(use, acgt_only, skip_kind)) continue;
         if (n == cap) { cap = cap ? 2 * cap : 1024; recs = realloc(recs, (size_t)cap * sizeof *recs); }
         if (cals) push_event(0, n);
         rec_t *r = &recs[n++];

@@ -602,3 +602,39 @@ def test_c_sam_driver_ignore_overlaps(golden_dir):
     assert [r[:2] for r in ra] == [r[:2] for r in rb] and len(ra) > 400
     assert "0 overlapping pairs" in b.stderr and "0 overlapping pairs" not in a.stderr
     assert sum(x[7:] != y[7:] for x, y in zip(ra, rb)) > 10
+
+
+@pytest.mark.gpu
+def test_c_call_driver_skips_masked_refs_and_variant_kinds(golden_dir, tmp_path):
+    """The sites `call` passes over before calling (vcfcall.c:1095-1099): a reference allele that starts with N is skipped unless
+    -M is given (CF_ACGT_ONLY is the default, vcfcall.c:937), -V snps / -V indels by htslib's bcf_is_snp.  Input: the
+    reference's test/call input mpileup.c.vcf with every fifth record's REF masked."""
+    from tests.helpers import vcf
+    build_host()
+    G = os.path.join(golden_dir, "call")
+    src, masked = os.path.join(G, "mpileup.c.vcf"), str(tmp_path / "masked.vcf")
+    n_rec = n_masked = 0
+    with open(masked, "w") as out:
+        for ln in open(src):
+            if not ln.startswith("#"):
+                f = ln.split("\t")
+                if n_rec % 5 == 0 and len(f[3]) == 1:
+                    f[3] = "N"; n_masked += 1
+                ln = "\t".join(f)
+                n_rec += 1
+            out.write(ln)
+
+    def run(args, path):
+        p = subprocess.run([CALL_EXE] + args + [path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+        assert p.returncode == 0, p.stderr
+        return [vcf.Rec(l) for l in p.stdout.splitlines() if not l.startswith("#")]
+    base = run([], src)
+    kept = run(["-M"], masked)                                   # every record comes out, the masked ones with REF N
+    dflt = run([], masked)
+    assert len(kept) == len(base) and sum(r.ref == "N" for r in kept) == n_masked > 5
+    assert [(r.pos, r.ref) for r in dflt] == [(r.pos, r.ref) for r in kept if r.ref != "N"]
+    snps = run(["-V", "indels"], src)
+    indels = run(["-V", "snps"], src)
+    assert [(r.pos, r.alleles) for r in snps] == [(r.pos, r.alleles) for r in base if vcf.is_snp(r)]
+    assert [(r.pos, r.alleles) for r in indels] == [(r.pos, r.alleles) for r in base if not vcf.is_snp(r)]
+    assert len(indels) >= 1 and len(snps) + len(indels) == len(base)
