@@ -1,7 +1,7 @@
 /*  bcfgpu_call.c -- `bcftools call -m [-v]` over a VCF from `bcftools mpileup`, in plain C over the C-ABI of
  *  include/bcfgpu.h: the record loop of main_vcfcall (vcfcall.c:1089-1148) with mcall() on the device.
  *
- *      bcfgpu_call [-v] [-S samples.txt] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]]
+ *      bcfgpu_call [-v] [-S samples.txt | -s NAME,...] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]]
  *                  [-F AN_TAG,AC_TAG] [-a GQ,GP] <in.vcf>
  *          -S: the samples to keep, in that order: NAME [PLOIDY|SEX] per line, or a PED file (vcfcall.c:202-344)
  *          --ploidy-file: CHROM FROM TO SEX PLOIDY lines, '*' = default for the sex (ploidy.c)
@@ -335,7 +335,7 @@ int main(int argc, char **argv)
     int varonly = 0, out_tags = 0, keepalt = 0;
     int acgt_only = 1, skip_kind = 0;                           /* vcfcall.c:937 (CF_ACGT_ONLY is the default); -V: 1 = snps, 2 = indels */
     const char *tgt_file = NULL; double prior = 1.1e-3;
-    const char *smpl_file = NULL, *ploidy_file = NULL, *grp_arg = NULL, *grp_tag = NULL;
+    const char *smpl_file = NULL, *smpl_list = NULL, *ploidy_file = NULL, *grp_arg = NULL, *grp_tag = NULL;
     char prior_an_tag[64] = "", prior_ac_tag[64] = "";
     char out_mode = 'v'; const char *out_path = "-";
     int32_t gv_range[16]; int gv_n = 0;                         /* -g INT,...: gvcf_init (gvcf.c:47-73) */
@@ -388,12 +388,14 @@ int main(int argc, char **argv)
             gv_n = nt; free(t); free(c); ++argv; --argc;
         }
         else if (!strcmp(argv[1], "-S") && argc > 3) { smpl_file = argv[2]; argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "-s") && argc > 3) { smpl_list = argv[2]; smpl_file = argv[2]; argv += 2; argc -= 2; }          /* -s LIST: the names, comma-separated (vcfcall.c:1050) */
+        else if (!strcmp(argv[1], "-p") && argc > 3) { argv += 2; argc -= 2; }                                                 /* --pval-threshold: read by the consensus caller only (vcfcall.c:1038) */
         else if (!strcmp(argv[1], "--ploidy-file") && argc > 3) { ploidy_file = argv[2]; argv += 2; argc -= 2; }
         else break;
     }
     if (gv_n && varonly) DIE("The two options cannot be combined: --variants-only and --gvcf\n");       /* vcfcall.c:1085 */
     if (gv_n && cals) DIE("-g with -C alleles is not supported\n");
-    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-M] [-V snps|indels] [-g INT,...] [-S samples.txt] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] [-A] [-P theta] [-C alleles -T targets.tab [-i]] [-O v|z|u|b] [-o out] in.vcf|in.bcf\n"); return 2; }
+    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-M] [-V snps|indels] [-g INT,...] [-S samples.txt | -s NAME,...] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] [-A] [-P theta] [-C alleles -T targets.tab [-i]] [-O v|z|u|b] [-o out] in.vcf|in.bcf\n"); return 2; }
     /* ploidy definition (ploidy.c): regions per sex, '*' lines = the sex's default; the last sex named is the default sex */
     preg_t *preg = NULL; int npreg = 0; char last_sex[64] = "";
     if (ploidy_file) {
@@ -428,7 +430,9 @@ int main(int argc, char **argv)
         spec = malloc((size_t)(S > 0 ? S : 1) * sizeof *spec);
         for (int s = 0; s < S; ++s) { col[s] = s; strcpy(spec[s], ploidy_file ? last_sex : "2"); }   /* vcfcall.c:645-650 */
         if (smpl_file) {
-            FILE *sf = fopen(smpl_file, "r");
+            char *lbuf = NULL;
+            if (smpl_list) { lbuf = strdup(smpl_list); for (char *c = lbuf; *c; ++c) if (*c == ',') *c = '\n'; }
+            FILE *sf = smpl_list ? fmemopen(lbuf, strlen(lbuf), "r") : fopen(smpl_file, "r");
             if (!sf) DIE("cannot open %s\n", smpl_file);
             char ln[1024]; int m = 0;
             while (fgets(ln, sizeof ln, sf)) {
@@ -442,7 +446,7 @@ int main(int argc, char **argv)
                 if (m == S_in) DIE("too many samples in %s\n", smpl_file);
                 col[m] = i; strcpy(spec[m], sp); ++m;
             }
-            fclose(sf);
+            fclose(sf); free(lbuf);
             S = m;
         }
     }
