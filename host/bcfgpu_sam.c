@@ -1215,7 +1215,7 @@ static int run_shards(int n_gpus, int argc0, char **argv0, int first_file, const
             if (!strcmp(o, "-o")) { char *e; strtol(argv0[i + 1], &e, 10); if (*e) { ++i; continue; } }
             if (o[0] != '-') break;                              /* the positional form: ref.fa contig beg end come from -f / -r below */
             av[n++] = argv0[i];
-            if (o[0] == '-' && i + 1 < first_file && argv0[i + 1][0] != '-' && strcmp(o, "-B") && strcmp(o, "-E") && strcmp(o, "-A") && strcmp(o, "-p") && strcmp(o, "-I") && strcmp(o, "-6") && strcmp(o, "--illumina1.3+") && strcmp(o, "--timing") && strcmp(o, "-x") && strcmp(o, "--ignore-overlaps")
+            if (o[0] == '-' && i + 1 < first_file && argv0[i + 1][0] != '-' && strcmp(o, "-B") && strcmp(o, "-E") && strcmp(o, "-A") && strcmp(o, "-p") && strcmp(o, "-I") && strcmp(o, "-6") && strcmp(o, "--illumina1.3+") && strcmp(o, "--timing") && strcmp(o, "-x") && strcmp(o, "--ignore-overlaps") && strcmp(o, "--no-version")
                 && strcmp(o, "--ignore-RG") && strcmp(o, "--list-samples")) av[n++] = argv0[++i];
         }
         av[n++] = "-f"; av[n++] = (char *)ref_path; av[n++] = "-r"; av[n++] = rl;
@@ -1279,6 +1279,16 @@ int main(int argc, char **argv)
     char out_mode = 'v'; const char *out_path = "-";                           /* mpileup -O, -o (mpileup.c:937-950) */
     int list_only = 0, n_gpus = 1, shard = -1;                                /* --gpus N: region shards, one process per shard; --shard K: this is shard K */
     const char *ref_path = NULL, *reg_arg = NULL, *reg_file = NULL, *file_list = NULL;
+    {   /* mpileup's long option names (mpileup.c:952-1003) are read as their short forms */
+        static const char *alias[][2] = {
+            { "--count-orphans", "-A" }, { "--no-BAQ", "-B" }, { "--adjust-MQ", "-C" }, { "--max-depth", "-d" }, { "--redo-BAQ", "-E" },
+            { "--read-groups", "-G" }, { "--min-MQ", "-q" }, { "--min-BQ", "-Q" }, { "--incl-flags", "--rf" }, { "--excl-flags", "--ff" },
+            { "--annotate", "-a" }, { "--output-type", "-O" }, { "--samples", "-s" }, { "--samples-file", "-S" }, { "--ext-prob", "-e" },
+            { "--gap-frac", "-F" }, { "--tandem-qual", "-h" }, { "--skip-indels", "-I" }, { "--max-idepth", "-L" }, { "--min-ireads", "-m" },
+            { "--open-prob", "-o" }, { "--per-sample-mF", "-p" } };
+        for (int i = 1; i < argc; ++i)
+            for (size_t k = 0; k < sizeof alias / sizeof alias[0]; ++k) if (!strcmp(argv[i], alias[k][0])) argv[i] = (char *)alias[k][1];
+    }
     char **argv0 = argv; const int argc0 = argc;
     while (argc > 2 && argv[1][0] == '-' && argv[1][1]) {
         if (!strcmp(argv[1], "-a")) {                                         /* mpileup -a, mpileup.c:parse_format_flag */
@@ -1317,6 +1327,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "-b") || !strcmp(argv[1], "--bam-list")) { file_list = argv[2]; argv += 2; argc -= 2; }       /* mpileup.c:1072 */
         else if (!strcmp(argv[1], "-x") || !strcmp(argv[1], "--ignore-overlaps")) { no_overlaps = 1; ++argv; --argc; }          /* mpileup.c:1005 */
         else if (!strcmp(argv[1], "-P") || !strcmp(argv[1], "--platforms")) { argv += 2; argc -= 2; }                          /* read and never used by the reference either (mpileup.c:353, 1052) */
+        else if (!strcmp(argv[1], "--no-version")) { ++argv; --argc; }                                                          /* (no ##bcftoolsVersion / ##bcftoolsCommand lines are written anyway) */
         else if (!strcmp(argv[1], "--threads")) { argv += 2; argc -= 2; }                                                      /* (the output's compression threads: nothing to do here) */
         else if (!strcmp(argv[1], "--timing")) { want_timing = 1; argv += 1; argc -= 1; }
         else if (!strcmp(argv[1], "--tile")) { tile_cols = atoi(argv[2]); if (tile_cols < 1) DIE("--tile: at least one column\n"); argv += 2; argc -= 2; }

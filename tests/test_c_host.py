@@ -639,3 +639,17 @@ def test_c_call_driver_skips_masked_refs_and_variant_kinds(golden_dir, tmp_path)
     assert [(r.pos, r.alleles) for r in snps] == [(r.pos, r.alleles) for r in base if vcf.is_snp(r)]
     assert [(r.pos, r.alleles) for r in indels] == [(r.pos, r.alleles) for r in base if not vcf.is_snp(r)]
     assert len(indels) >= 1 and len(snps) + len(indels) == len(base)
+
+
+def test_c_sam_driver_reads_mpileups_long_option_names(golden_dir):
+    """mpileup's long option names (mpileup.c:952-1003) give what their short forms give: --list-samples needs no device."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    files = [os.path.join(G, "mpileup.%d.sam" % i) for i in (1, 2, 3, 4)]
+    short = [SAM_EXE, "--list-samples", "-s", "^HG99999", "-q", "10", "-d", "100", "-A", "--ff", "0x704", "-f", os.path.join(G, "mpileup.ref.fa"), "-r", "17:1-4200"] + files
+    long_ = [SAM_EXE, "--list-samples", "--samples", "^HG99999", "--min-MQ", "10", "--max-depth", "100", "--count-orphans", "--excl-flags", "0x704",
+             "--fasta-ref", os.path.join(G, "mpileup.ref.fa"), "--regions", "17:1-4200"] + files
+    a = subprocess.run(short, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    b = subprocess.run(long_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+    assert a.stdout == b.stdout and len(a.stdout.splitlines()) == 3
