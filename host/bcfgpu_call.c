@@ -332,6 +332,15 @@ static int unwanted_site(const char *line, int acgt_only, int skip_kind)
 
 int main(int argc, char **argv)
 {
+    {   /* call's long option names (vcfcall.c:946-981) are read as their short forms; -f is the old spelling of -a (vcfcall.c:995) */
+        static const char *alias[][2] = {
+            { "--variants-only", "-v" }, { "--multiallelic-caller", "-m" }, { "--keep-alts", "-A" }, { "--insert-missed", "-i" }, { "--constrain", "-C" },
+            { "--targets-file", "-T" }, { "--prior", "-P" }, { "--output-type", "-O" }, { "--output", "-o" }, { "--group-samples", "-G" },
+            { "--prior-freqs", "-F" }, { "--annotate", "-a" }, { "--format-fields", "-a" }, { "-f", "-a" }, { "--samples-file", "-S" }, { "--samples", "-s" },
+            { "--pval-threshold", "-p" } };
+        for (int i = 1; i < argc; ++i)
+            for (size_t k = 0; k < sizeof alias / sizeof alias[0]; ++k) if (!strcmp(argv[i], alias[k][0])) argv[i] = (char *)alias[k][1];
+    }
     int varonly = 0, out_tags = 0, keepalt = 0;
     int acgt_only = 1, skip_kind = 0;                           /* vcfcall.c:937 (CF_ACGT_ONLY is the default); -V: 1 = snps, 2 = indels */
     const char *tgt_file = NULL; double prior = 1.1e-3;

@@ -362,6 +362,7 @@ CALL_EXE = os.path.join(ROOT, "host", "bcfgpu_call")
 @pytest.mark.parametrize("vcff,goldf,args,n", [
     ("mpileup.vcf", "mpileup.1.out", "-v", 11), ("mpileup.vcf", "mpileup.3.out", "-v -S {G}/mpileup.3.samples", None),
     ("mpileup.vcf", "mpileup.3.out", "-v -s HG00100,HG00101,HG00102 -p 0.5 --threads 2", None),   # the same samples as a list (vcfcall.c:1050)
+    ("mpileup.vcf", "mpileup.3.out", "--multiallelic-caller --variants-only --samples-file {G}/mpileup.3.samples", None),   # long option names
     ("mpileup.vcf", "mpileup.4.out", "-v -S {G}/mpileup.4.samples", None), ("mpileup.vcf", "mpileup.5.out", "-v -S {G}/mpileup.5.samples", None),
     ("mpileup.X.vcf", "mpileup.X.out", "-v -S {G}/mpileup.samples --ploidy-file {G}/mpileup.ploidy", None),      # sexes + ploidy file: haploid males on X
     ("mpileup.X.vcf", "mpileup.X.out", "-v -S {G}/mpileup.ped --ploidy-file {G}/mpileup.ploidy", None),          # the same from a PED file
