@@ -1,7 +1,7 @@
 /*  bcfgpu_call.c -- `bcftools call -m [-v]` over a VCF from `bcftools mpileup`, in plain C over the C-ABI of
  *  include/bcfgpu.h: the record loop of main_vcfcall (vcfcall.c:1089-1148) with mcall() on the device.
  *
- *      bcfgpu_call [-v] [-S samples.txt | -s NAME,...] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]]
+ *      bcfgpu_call [-v] [-S samples.txt | -s NAME,...] [--ploidy-file file | --ploidy GRCh37|GRCh38|X|Y|1] [-G -|groups.txt [--group-samples-tag TAG]]
  *                  [-F AN_TAG,AC_TAG] [-a GQ,GP] <in.vcf>
  *          -S: the samples to keep, in that order: NAME [PLOIDY|SEX] per line, or a PED file (vcfcall.c:202-344)
  *          --ploidy-file: CHROM FROM TO SEX PLOIDY lines, '*' = default for the sex (ploidy.c)
@@ -344,7 +344,7 @@ int main(int argc, char **argv)
     int varonly = 0, out_tags = 0, keepalt = 0;
     int acgt_only = 1, skip_kind = 0;                           /* vcfcall.c:937 (CF_ACGT_ONLY is the default); -V: 1 = snps, 2 = indels */
     const char *tgt_file = NULL; double prior = 1.1e-3;
-    const char *smpl_file = NULL, *smpl_list = NULL, *ploidy_file = NULL, *grp_arg = NULL, *grp_tag = NULL;
+    const char *smpl_file = NULL, *smpl_list = NULL, *ploidy_file = NULL, *ploidy_alias = NULL, *grp_arg = NULL, *grp_tag = NULL;
     char prior_an_tag[64] = "", prior_ac_tag[64] = "";
     char out_mode = 'v'; const char *out_path = "-";
     int32_t gv_range[16]; int gv_n = 0;                         /* -g INT,...: gvcf_init (gvcf.c:47-73) */
@@ -400,15 +400,45 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "-s") && argc > 3) { smpl_list = argv[2]; smpl_file = argv[2]; argv += 2; argc -= 2; }          /* -s LIST: the names, comma-separated (vcfcall.c:1050) */
         else if (!strcmp(argv[1], "-p") && argc > 3) { argv += 2; argc -= 2; }                                                 /* --pval-threshold: read by the consensus caller only (vcfcall.c:1038) */
         else if (!strcmp(argv[1], "--ploidy-file") && argc > 3) { ploidy_file = argv[2]; argv += 2; argc -= 2; }
+        else if (!strcmp(argv[1], "--ploidy") && argc > 3) { ploidy_alias = argv[2]; argv += 2; argc -= 2; }                       /* vcfcall.c:976, 827-855 */
+        else if (!strcmp(argv[1], "-X")) { ploidy_alias = "X"; ++argv; --argc; }                                                  /* vcfcall.c:991 */
+        else if (!strcmp(argv[1], "-Y")) { ploidy_alias = "Y"; ++argv; --argc; }                                                  /* vcfcall.c:992 */
         else break;
     }
     if (gv_n && varonly) DIE("The two options cannot be combined: --variants-only and --gvcf\n");       /* vcfcall.c:1085 */
     if (gv_n && cals) DIE("-g with -C alleles is not supported\n");
-    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-M] [-V snps|indels] [-g INT,...] [-S samples.txt | -s NAME,...] [--ploidy-file file] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] [-A] [-P theta] [-C alleles -T targets.tab [-i]] [-O v|z|u|b] [-o out] in.vcf|in.bcf\n"); return 2; }
+    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-M] [-V snps|indels] [-g INT,...] [-S samples.txt | -s NAME,...] [--ploidy-file file | --ploidy GRCh37|GRCh38|X|Y|1] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] [-A] [-P theta] [-C alleles -T targets.tab [-i]] [-O v|z|u|b] [-o out] in.vcf|in.bcf\n"); return 2; }
     /* ploidy definition (ploidy.c): regions per sex, '*' lines = the sex's default; the last sex named is the default sex */
     preg_t *preg = NULL; int npreg = 0; char last_sex[64] = "";
+    char *alias_text = NULL;
+    if (ploidy_alias) {
+        /* --ploidy ALIAS: the definitions `call` carries with it (vcfcall.c:138-199), in the format of a --ploidy-file: the
+         * haploid stretches of the human sex chromosomes outside the pseudo-autosomal regions and the mitochondrion, by assembly;
+         * "X" / "Y" / "1": males haploid / males haploid and females absent / everybody haploid, whatever the sequence */
+        static const struct { const char *name; long x_par1_end, x_par2_beg, x_end, y_end; } asm_[2] = {
+            { "GRCh37", 60000, 2699521, 154931043, 59373566 }, { "GRCh38", 9999, 2781480, 155701381, 57227415 } };
+        size_t al = 0; FILE *m = open_memstream(&alias_text, &al);
+        int known = 0;
+        for (int k = 0; k < 2; ++k)
+            if (!strcmp(ploidy_alias, asm_[k].name)) {
+                for (int pre = 0; pre < 2; ++pre) {
+                    const char *c = pre ? "chr" : "";
+                    fprintf(m, "%sX 1 %ld M 1\n%sX %ld %ld M 1\n%sY 1 %ld M 1\n%sY 1 %ld F 0\n", c, asm_[k].x_par1_end, c, asm_[k].x_par2_beg, asm_[k].x_end, c, asm_[k].y_end, c, asm_[k].y_end);
+                    fprintf(m, "%s 1 16569 M 1\n%s 1 16569 F 1\n", pre ? "chrM" : "MT", pre ? "chrM" : "MT");
+                }
+                fprintf(m, "* * * M 2\n* * * F 2\n");
+                known = 1;
+            }
+        if (!strcmp(ploidy_alias, "X")) { fprintf(m, "* * * M 1\n* * * F 2\n"); known = 1; }
+        if (!strcmp(ploidy_alias, "Y")) { fprintf(m, "* * * M 1\n* * * F 0\n"); known = 1; }
+        if (!strcmp(ploidy_alias, "1")) { fprintf(m, "* * * * 1\n"); known = 1; }
+        fclose(m);
+        if (!known) DIE("--ploidy: GRCh37, GRCh38, X, Y or 1 (or a --ploidy-file)\n");
+        if (ploidy_file) DIE("--ploidy and --ploidy-file exclude each other\n");
+        ploidy_file = "--ploidy";
+    }
     if (ploidy_file) {
-        FILE *pf = fopen(ploidy_file, "r");
+        FILE *pf = alias_text ? fmemopen(alias_text, strlen(alias_text), "r") : fopen(ploidy_file, "r");
         if (!pf) DIE("cannot open %s\n", ploidy_file);
         char ln[1024], c[256], a[64], b[64], sx[64]; int pl;
         while (fgets(ln, sizeof ln, pf))
@@ -524,6 +554,8 @@ int main(int argc, char **argv)
                     if (preg[i].from >= 0 && !strcmp(preg[i].chrom, r->fld[0]) && !strcmp(preg[i].sex, spec[s]) && preg[i].from <= pos1 && pos1 <= preg[i].to) { pl = preg[i].ploidy; found = 1; }
                 for (int i = 0; i < npreg && !found; ++i)
                     if (preg[i].from < 0 && !strcmp(preg[i].sex, spec[s])) { pl = preg[i].ploidy; found = 1; }
+                for (int i = 0; i < npreg && !found; ++i)                       /* a sex without a default of its own takes the "*" sex's (ploidy.c:122-127) */
+                    if (preg[i].from < 0 && !strcmp(preg[i].sex, "*")) { pl = preg[i].ploidy; found = 1; }
             }
             r->ploidy[s] = (uint8_t)pl;
         }

@@ -654,3 +654,28 @@ def test_c_sam_driver_reads_mpileups_long_option_names(golden_dir):
     b = subprocess.run(long_, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
     assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
     assert a.stdout == b.stdout and len(a.stdout.splitlines()) == 3
+
+
+@pytest.mark.gpu
+def test_c_call_driver_predefined_ploidies(golden_dir, tmp_path):
+    """`call --ploidy ALIAS` (vcfcall.c:138-199, 827-855): the definitions call carries with it give what the same lines give as a
+    --ploidy-file -- GRCh37 (males haploid on X outside the pseudo-autosomal regions), X, 1 -- on the reference's mpileup.X.vcf."""
+    build_host()
+    G = os.path.join(golden_dir, "call")
+    src, smp = os.path.join(G, "mpileup.X.vcf"), os.path.join(G, "mpileup.samples")
+
+    def run(args):
+        p = subprocess.run([CALL_EXE] + args + [src], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+        assert p.returncode == 0, p.stderr
+        return [l for l in p.stdout.splitlines() if not l.startswith("##")]
+    cases = {"GRCh37": "X 1 60000 M 1\nX 2699521 154931043 M 1\nY 1 59373566 M 1\nY 1 59373566 F 0\n* * * M 2\n* * * F 2\n",
+             "X": "* * * M 1\n* * * F 2\n", "Y": "* * * M 1\n* * * F 0\n", "1": "* * * * 1\n"}
+    outs = {}
+    for alias, text in cases.items():
+        f = str(tmp_path / ("ploidy." + alias))
+        open(f, "w").write(text)
+        outs[alias] = run(["-v", "-S", smp, "--ploidy", alias])
+        assert outs[alias] == run(["-v", "-S", smp, "--ploidy-file", f]), alias
+        assert len(outs[alias]) > 3
+    assert outs["X"] != outs["1"] and outs["GRCh37"] == outs["X"]      # (every site of the input lies in X's first haploid stretch)
+    assert run(["-v", "-S", smp, "-X"]) == outs["X"]
