@@ -304,10 +304,51 @@ static int pick_target(const char *chrom, int pos, const char *ref, char **alts,
     return best;
 }
 
+/* ---- -t / -T / -r / -R: the sites to look at, as (sequence, first, last) with 1-based inclusive positions; last < 0: to the end ---- */
+typedef struct { char *chrom; long beg, end; } sflt_t;
+static sflt_t *sflt; static int n_sflt;
+static void site_filter_add(const char *spec)
+{
+    sflt = realloc(sflt, (size_t)(n_sflt + 1) * sizeof *sflt);
+    sflt_t *q = &sflt[n_sflt++];
+    const char *c = strrchr(spec, ':');
+    q->beg = 1; q->end = -1;
+    if (!c) { q->chrom = strdup(spec); return; }
+    q->chrom = strndup(spec, (size_t)(c - spec));
+    char *e; q->beg = strtol(c + 1, &e, 10);
+    if (e == c + 1) { free(q->chrom); q->chrom = strdup(spec); q->beg = 1; return; }      /* a ':' inside the sequence name */
+    if (*e == '-') { q->end = e[1] ? strtol(e + 1, NULL, 10) : -1; } else q->end = q->beg;
+}
+static void site_filter_file(const char *path)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) DIE("cannot open %s\n", path);
+    char ln[4096], c[1024]; long a, b;
+    while (fgets(ln, sizeof ln, f)) {
+        if (ln[0] == '#') continue;
+        const int k = sscanf(ln, "%1023s %ld %ld", c, &a, &b);
+        if (k < 1) continue;
+        sflt = realloc(sflt, (size_t)(n_sflt + 1) * sizeof *sflt);
+        sflt[n_sflt].chrom = strdup(c); sflt[n_sflt].beg = k >= 2 ? a : 1; sflt[n_sflt].end = k >= 3 ? b : k == 2 ? a : -1;
+        ++n_sflt;
+    }
+    fclose(f);
+}
+static int site_filter_has(const char *line)
+{
+    const char *t = strchr(line, '\t');
+    if (!t) return 0;
+    const long pos = atol(t + 1);
+    for (int i = 0; i < n_sflt; ++i)
+        if (strlen(sflt[i].chrom) == (size_t)(t - line) && !strncmp(sflt[i].chrom, line, (size_t)(t - line)) && pos >= sflt[i].beg && (sflt[i].end < 0 || pos <= sflt[i].end)) return 1;
+    return 0;
+}
+
 /* the sites `call` passes over before anything else (vcfcall.c:1095-1099): -V snps / indels by htslib's bcf_is_snp (every allele one
  * base that is not '*', or the symbolic <X> / <*>), and -- unless -M -- a reference allele that starts with N */
 static int unwanted_site(const char *line, int acgt_only, int skip_kind)
 {
+    if (n_sflt && !site_filter_has(line)) return 1;
     const char *f = line; int tabs = 0;
     for (; *f && tabs < 3; ++f) if (*f == '\t') ++tabs;
     if (tabs < 3) return 0;
@@ -364,6 +405,14 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "-i")) { insert_missed = 1; ++argv; --argc; }
         else if (!strcmp(argv[1], "-C") && argc > 3) { if (strcmp(argv[2], "alleles")) DIE("-C: only `alleles` is supported\n"); cals = 1; argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-T") && argc > 3) { tgt_file = argv[2]; argv += 2; argc -= 2; }
+        else if ((!strcmp(argv[1], "-t") || !strcmp(argv[1], "--targets") || !strcmp(argv[1], "-r") || !strcmp(argv[1], "--regions")) && argc > 3) {
+            /* -t / -r CHR[:POS | :BEG-END],...: only the records whose POS lies there (bcf_sr_set_targets / _regions, vcfcall.c:612-626; -r without
+             * an index is a filter over the stream here) */
+            char *c = strdup(argv[2]); int nt; char **t = split(c, ',', &nt);
+            for (int i = 0; i < nt; ++i) site_filter_add(t[i]);
+            free(t); free(c); argv += 2; argc -= 2;
+        }
+        else if ((!strcmp(argv[1], "-R") || !strcmp(argv[1], "--regions-file")) && argc > 3) { site_filter_file(argv[2]); argv += 2; argc -= 2; }
         else if (!strcmp(argv[1], "-P") && argc > 3) { prior = atof(argv[2]); argv += 2; argc -= 2; }      /* vcfcall.c:931-943 */
         else if (!strcmp(argv[1], "-O") && argc > 3) { out_mode = argv[2][0]; argv += 2; argc -= 2; }      /* version.c:67-82 */
         else if (!strncmp(argv[1], "-O", 2) && argv[1][2]) { out_mode = argv[1][2]; ++argv; --argc; }
@@ -407,7 +456,7 @@ int main(int argc, char **argv)
     }
     if (gv_n && varonly) DIE("The two options cannot be combined: --variants-only and --gvcf\n");       /* vcfcall.c:1085 */
     if (gv_n && cals) DIE("-g with -C alleles is not supported\n");
-    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-M] [-V snps|indels] [-g INT,...] [-S samples.txt | -s NAME,...] [--ploidy-file file | --ploidy GRCh37|GRCh38|X|Y|1] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] [-A] [-P theta] [-C alleles -T targets.tab [-i]] [-O v|z|u|b] [-o out] in.vcf|in.bcf\n"); return 2; }
+    if (argc != 2) { fprintf(stderr, "usage: bcfgpu_call [-v] [-M] [-V snps|indels] [-t|-r REGIONS] [-T|-R FILE] [-g INT,...] [-S samples.txt | -s NAME,...] [--ploidy-file file | --ploidy GRCh37|GRCh38|X|Y|1] [-G -|groups.txt [--group-samples-tag TAG]] [-F AN,AC] [-a GQ,GP] [-A] [-P theta] [-C alleles -T targets.tab [-i]] [-O v|z|u|b] [-o out] in.vcf|in.bcf\n"); return 2; }
     /* ploidy definition (ploidy.c): regions per sex, '*' lines = the sex's default; the last sex named is the default sex */
     preg_t *preg = NULL; int npreg = 0; char last_sex[64] = "";
     char *alias_text = NULL;
@@ -491,6 +540,7 @@ int main(int argc, char **argv)
     }
     char *prev_chrom = NULL; long prev_pos0 = 0;
     if (cals) { if (!tgt_file) DIE("-C alleles needs -T targets\n"); tgt_parse(tgt_file); }
+    else if (tgt_file) site_filter_file(tgt_file);           /* -T without -C alleles: the targets restrict the sites (vcfcall.c:612-617) */
     int rrc;
     while ((rrc = vio_read_line(fin, hdr, &buf, &bufcap)) > 0) {
         size_t l = strlen(buf);

@@ -679,3 +679,29 @@ def test_c_call_driver_predefined_ploidies(golden_dir, tmp_path):
         assert len(outs[alias]) > 3
     assert outs["X"] != outs["1"] and outs["GRCh37"] == outs["X"]      # (every site of the input lies in X's first haploid stretch)
     assert run(["-v", "-S", smp, "-X"]) == outs["X"]
+
+
+@pytest.mark.gpu
+def test_c_call_driver_targets_and_regions(golden_dir, tmp_path):
+    """`call -t / -r REGIONS`, `-T / -R FILE` (without -C alleles: the sites to look at, vcfcall.c:612-626): the records of the full run
+    whose position lies in the targets, nothing else."""
+    build_host()
+    G = os.path.join(golden_dir, "call")
+    src = os.path.join(G, "mpileup.vcf")
+
+    def run(args):
+        p = subprocess.run([CALL_EXE] + args + [src], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+        assert p.returncode == 0, p.stderr
+        return [l for l in p.stdout.splitlines() if not l.startswith("#")]
+    full = run([])
+    pos = [int(l.split("\t")[1]) for l in full]
+    lo, hi, one = pos[len(pos) // 4], pos[len(pos) // 2], pos[-3]
+    want = [l for l, q in zip(full, pos) if lo <= q <= hi or q == one]
+    assert 3 < len(want) < len(full)
+    chrom = full[0].split("\t")[0]
+    spec = "%s:%d-%d,%s:%d" % (chrom, lo, hi, chrom, one)
+    assert run(["-t", spec]) == want and run(["-r", spec]) == want
+    f = str(tmp_path / "targets.tab")
+    open(f, "w").write("# CHROM POS END\n%s\t%d\t%d\n%s\t%d\n" % (chrom, lo, hi, chrom, one))
+    assert run(["-T", f]) == want and run(["-R", f]) == want
+    assert run(["-t", chrom]) == full and run(["-t", "no_such_sequence"]) == []
