@@ -1,7 +1,7 @@
 /*  bcfgpu_sam.c -- `bcftools mpileup` over SAM / BAM files with every stage of the path on the device, in plain C over the
  *  C-ABI of include/bcfgpu.h (SNP and indel records).
  *
- *      bcfgpu_sam [options] -f ref.fa [-r CHR[:BEG[-END]],... | -R FILE] [-b FILE] file.sam|file.bam [...]         (mpileup's own spelling, mpileup.c:952-1003)
+ *      bcfgpu_sam [options] -f ref.fa [-r CHR[:BEG[-END]],... | -R FILE] [-t [^]REG,... | -T [^]FILE] [-b FILE] file.sam|file.bam [...]         (mpileup's own spelling, mpileup.c:952-1003)
  *      bcfgpu_sam [options] ref.fa contig beg end file.sam|file.bam [...]                       (beg, end 1-based inclusive)
  *      options: -a TAG,..  --gvcf INT,..  -O v|z|u|b  -o FILE  -d INT  -s LIST  -S FILE  -G FILE  --ignore-RG
  *               -B  -E  -A  -q INT  -Q INT  -C INT  --ff INT  --rf INT  -I -o INT -e INT -h INT -m INT -F FLOAT -p -L INT   (as `bcftools mpileup`)
@@ -31,7 +31,7 @@
  *  and the record loop writes what bcf_call2bcf (bam2bcf.c:756-906) puts in the record, in its order, under mpileup's header
  *  (mpileup.c:510-602), as VCF, bgzipped VCF or BCF (host/vcfio.c).  tests/test_c_host.py compares the whole output with the
  *  reference's goldens test/mpileup/mpileup.{1..11}.out, mpileup-SCR.out, indel-AD.1.out -- one tile and many.
- *  Not here: CRAM input, index files (a region far into a file is reached by reading up to it), BED files (-l/-T);
+ *  Not here: CRAM input, index files (a region far into a file is reached by reading up to it);
  *  a sample fed by several files has its reads merged by position (the reference appends file after file: same
  *  records unless a cell passes 255 usable reads, where errmod_cal's draw then meets the reads in another order).
  */
@@ -283,6 +283,60 @@ static int sample_of(const sfile_t *f, const char *rg)                      /* b
 /* ---- reading: SAM text or BAM; the read filters of mplp_func (mpileup.c:183-246) ---- */
 static int rflag_require = 0, rflag_filter = 4 | 256 | 512 | 1024, min_mq = 0, keep_orphans = 0;
 static int no_overlaps;                                                         /* mpileup -x: the mates' overlaps are left alone (mpileup.c:1005) */
+/* -t / -T: the targets (mpileup.c:198-212, 330-335, 1033-1051): reads that overlap none of them never enter the pileup, columns outside
+ * them give no record; a leading ^ turns the list into the columns to leave out (the reads are chosen as without it, as in the reference).
+ * 0-based inclusive [beg, end]; end < 0: to the end of the sequence */
+typedef struct { char *chrom; long beg, end; } target_t;
+static target_t *target; static int n_target, target_incl = 1;
+static void target_add(const char *chrom, size_t cl, long beg, long end)
+{
+    target = realloc(target, (size_t)(n_target + 1) * sizeof *target);
+    target[n_target].chrom = strndup(chrom, cl); target[n_target].beg = beg; target[n_target].end = end; ++n_target;
+}
+static void target_spec(const char *spec)                                          /* CHR, CHR:POS, CHR:BEG-END (1-based) */
+{
+    const char *c = strrchr(spec, ':'); char *e = NULL;
+    long a = c ? strtol(c + 1, &e, 10) : 0;
+    if (!c || e == c + 1) { target_add(spec, strlen(spec), 0, -1); return; }
+    const long b = *e == '-' ? (e[1] ? strtol(e + 1, NULL, 10) : 0) : a;
+    target_add(spec, (size_t)(c - spec), a - 1, b ? b - 1 : -1);
+}
+static void target_file(const char *path)                                          /* CHROM <tab> POS [<tab> END], 1-based inclusive */
+{
+    FILE *f = fopen(path, "r");
+    if (!f) { fprintf(stderr, "Could not read file \"%s\"\n", path); exit(1); }
+    char ln[4096], c[1024]; long a, b;
+    while (fgets(ln, sizeof ln, f)) {
+        if (ln[0] == '#') continue;
+        const int k = sscanf(ln, "%1023s %ld %ld", c, &a, &b);
+        if (k >= 1) target_add(c, strlen(c), k >= 2 ? a - 1 : 0, k >= 3 ? b - 1 : k == 2 ? a - 1 : -1);
+    }
+    fclose(f);
+}
+/* does [beg, end] of `chrom` overlap a target?  *inside: it lies wholly inside one */
+static int target_overlap(const char *chrom, long beg, long end, int *inside)
+{
+    int ov = 0;
+    if (inside) *inside = 0;
+    for (int i = 0; i < n_target; ++i) {
+        if (strcmp(target[i].chrom, chrom)) continue;
+        const long tb = target[i].beg, te = target[i].end < 0 ? (1L << 40) : target[i].end;
+        if (beg <= te && end >= tb) { ov = 1; if (inside && beg >= tb && end <= te) *inside = 1; }
+    }
+    return ov;
+}
+static int target_keeps_read(const char *chrom, long beg, long end)                /* mpileup.c:198-212 */
+{
+    /* As the reference has it: a read goes on if it overlaps a listed stretch -- with the ^ form too (its "exclude only reads which are
+     * fully contained" loop runs only when nothing overlaps, over no region, so a read clear of the list is dropped there as well). */
+    return !n_target || target_overlap(chrom, beg, end, NULL);
+}
+static int target_keeps_column(const char *chrom, long pos)                        /* mpileup.c:330-335 */
+{
+    if (!n_target) return 1;
+    const int ov = target_overlap(chrom, pos, pos, NULL);
+    return target_incl ? ov : !ov;
+}
 static int illumina13;                                                          /* mpileup -6: qualities in the Illumina-1.3+ encoding (mpileup.c:216-221) */
 static int defer_mq_filters = 0;
 static int reg_beg = 0, reg_end = 0x7fffffff;   /* the region: only reads that overlap it enter the pool, as htslib's region iterator hands them out */      /* -C: sam_cap_mapq comes between the flag filters and the -q / orphan filters (mpileup.c:234-241) */
@@ -508,6 +562,7 @@ static void reader_parse(reader_t *r, const char *contig, const sfile_t *sf)
             if (aux > b + 4 + bs) DIE("%s: malformed BAM record\n", r->path);
             for (int c = 0; c < n_cig; ++c) cig[c] = (uint32_t)le32(cg + 4 * c);
             if (!overlaps(pos, ref_span_end(pos, cig, n_cig), reg_beg, reg_end)) continue;
+            if (!target_keeps_read(contig, pos, ref_span_end(pos, cig, n_cig) - 1)) continue;
             const int smpl = sample_of(sf, bam_aux_rg(aux, b + 4 + bs));
             if (smpl < 0) continue;
             lrec_t *x = lrec_new((const char *)b + 36, flag, pos, mapq, next_ref == refid, next_pos, tlen, cig, n_cig, l_seq, smpl);
@@ -541,6 +596,7 @@ static void reader_parse(reader_t *r, const char *contig, const sfile_t *sf)
             c = e + 1;
         }
         if (!overlaps(pos, ref_span_end(pos, cig, ncig), reg_beg, reg_end)) continue;
+        if (!target_keeps_read(contig, pos, ref_span_end(pos, cig, ncig) - 1)) continue;
         const char *rg = NULL;
         for (char *t = rest; t && *t; ) {                                    /* the optional fields: RG:Z:<id> */
             char *e = strchr(t, '\t'); if (e) *e = 0;
@@ -971,7 +1027,7 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
     int open_block = -1;                 /* the block that reaches the tile's last column and may go on in the next tile */
     if (gv_n) {
         int32_t *pos = malloc((size_t)n_sites * 4); uint8_t *brk = calloc((size_t)n_sites, 1);
-        for (int k = 0; k < n_sites; ++k) { pos[k] = t0 + k; if (col_n[k] == 0) brk[k] |= 2; }
+        for (int k = 0; k < n_sites; ++k) { pos[k] = t0 + k; if (col_n[k] == 0 || !target_keeps_column(contig, t0 + k)) brk[k] |= 2; }
         for (int j = 0; j < nlive; ++j) if (isite[live[j]].ret == 0) brk[cand[live[j]]] |= 1;      /* an indel record follows the SNP record */
         void *d_pos, *d_brk, *d_blk, *d_min, *d_block, *d_gdp, *d_gpl;
         CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_pos)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites, &d_brk));
@@ -1003,6 +1059,7 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
     t_dev += tw1 - tw0;
     for (int k = 0; k < n_sites; ++k) {
         if (col_n[k] == 0) continue;                                         /* no read: no record */
+        if (!target_keeps_column(contig, t0 + k)) continue;                  /* outside the targets: no record (mpileup.c:330-335) */
         const bcfgpu_site *c = &site[k];
         if (gv_blk && gv_blk[k] >= 0) {                                      /* inside a block: one line when the block ends */
             const int b = gv_blk[k];
@@ -1324,6 +1381,16 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[1], "-f") || !strcmp(argv[1], "--fasta-ref")) { ref_path = argv[2]; argv += 2; argc -= 2; }      /* mpileup.c:1008,1056 */
         else if (!strcmp(argv[1], "-r") || !strcmp(argv[1], "--regions")) { reg_arg = argv[2]; argv += 2; argc -= 2; }          /* mpileup.c:1011,1057 */
         else if (!strcmp(argv[1], "-R") || !strcmp(argv[1], "--regions-file")) { reg_file = argv[2]; argv += 2; argc -= 2; }    /* mpileup.c:1031 */
+        else if (!strcmp(argv[1], "-t") || !strcmp(argv[1], "--targets")) {                                                     /* mpileup.c:1033-1045 */
+            const char *a = argv[2]; if (a[0] == '^') { ++a; target_incl = 0; }
+            char *list = strdup(a);
+            for (char *t = strtok(list, ","); t; t = strtok(NULL, ",")) target_spec(t);
+            free(list); argv += 2; argc -= 2;
+        }
+        else if (!strcmp(argv[1], "-T") || !strcmp(argv[1], "--targets-file")) {                                                /* mpileup.c:1046-1051 */
+            const char *a = argv[2]; if (a[0] == '^') { ++a; target_incl = 0; }
+            target_file(a); argv += 2; argc -= 2;
+        }
         else if (!strcmp(argv[1], "-b") || !strcmp(argv[1], "--bam-list")) { file_list = argv[2]; argv += 2; argc -= 2; }       /* mpileup.c:1072 */
         else if (!strcmp(argv[1], "-x") || !strcmp(argv[1], "--ignore-overlaps")) { no_overlaps = 1; ++argv; --argc; }          /* mpileup.c:1005 */
         else if (!strcmp(argv[1], "-P") || !strcmp(argv[1], "--platforms")) { argv += 2; argc -= 2; }                          /* read and never used by the reference either (mpileup.c:353, 1052) */

@@ -705,3 +705,30 @@ def test_c_call_driver_targets_and_regions(golden_dir, tmp_path):
     open(f, "w").write("# CHROM POS END\n%s\t%d\t%d\n%s\t%d\n" % (chrom, lo, hi, chrom, one))
     assert run(["-T", f]) == want and run(["-R", f]) == want
     assert run(["-t", chrom]) == full and run(["-t", "no_such_sequence"]) == []
+
+
+@pytest.mark.gpu
+def test_c_sam_driver_targets(golden_dir, tmp_path):
+    """`-t REG,...` / `-T FILE` (mpileup.c:198-212, 330-335): the columns inside the targets, from the reads that overlap them.  With
+    -B and -I every column depends on its own reads only, so the records are those of the untargeted run at the targets' positions
+    (the depth cap aside: -d 100000); `^` gives the columns outside the list from the same reads."""
+    build_host()
+    G = os.path.join(golden_dir, "mpileup")
+    cmd = [SAM_EXE, "-B", "-I", "-x", "-d", "100000", "-f", os.path.join(G, "mpileup.ref.fa"), "-r", "17:100-600"] + [os.path.join(G, "mpileup.%d.sam" % i) for i in (1, 2, 3)]
+
+    def run(extra):
+        p = subprocess.run(cmd[:1] + extra + cmd[1:], stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+        assert p.returncode == 0, p.stderr
+        return [l for l in p.stdout.splitlines() if not l.startswith("#")]
+    full = run([])
+    pos = lambda l: int(l.split("\t")[1])
+    inside = lambda q: 150 <= q <= 180 or q == 300 or 420 <= q <= 425
+    want = [l for l in full if inside(pos(l))]
+    assert len(want) == 31 + 1 + 6
+    assert run(["-t", "17:150-180,17:300,17:420-425"]) == want
+    f = str(tmp_path / "targets.tab")
+    open(f, "w").write("17\t150\t180\n17\t300\n17\t420\t425\n")
+    assert run(["-T", f]) == want
+    # ^: the other columns -- of the reads that overlap the list (as the reference selects them)
+    out = run(["-t", "^17:150-180,17:300,17:420-425"])
+    assert out and all(not inside(pos(l)) for l in out) and {pos(l) for l in out} < {pos(l) for l in full}
