@@ -38,6 +38,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
 #include <stdint.h>
 #include <ctype.h>
 #include <math.h>
@@ -1349,17 +1350,19 @@ int main(int argc, char **argv)
     char **argv0 = argv; const int argc0 = argc;
     while (argc > 2 && argv[1][0] == '-' && argv[1][1]) {
         if (!strcmp(argv[1], "-a")) {                                         /* mpileup -a, mpileup.c:parse_format_flag */
+            /* parse_format_flag (mpileup.c:794-826): the names without regard to case, FORMAT tags with or without "FORMAT/" or "FMT/" */
             static const struct { const char *name; int bit; } tags[] = {
                 { "DP", BCFGPU_FMT_DP }, { "DV", BCFGPU_FMT_DV }, { "SP", BCFGPU_FMT_SP }, { "DP4", BCFGPU_FMT_DP4 }, { "DPR", BCFGPU_FMT_DPR },
-                { "AD", BCFGPU_FMT_AD }, { "ADF", BCFGPU_FMT_ADF }, { "ADR", BCFGPU_FMT_ADR }, { "INFO/DPR", BCFGPU_INFO_DPR },
-                { "INFO/AD", BCFGPU_INFO_AD }, { "INFO/ADF", BCFGPU_INFO_ADF }, { "INFO/ADR", BCFGPU_INFO_ADR },
-                { "SCR", BCFGPU_FMT_SCR }, { "FMT/SCR", BCFGPU_FMT_SCR }, { "FORMAT/SCR", BCFGPU_FMT_SCR }, { "INFO/SCR", BCFGPU_INFO_SCR },
-                { "QS", BCFGPU_FMT_QS }, { "FMT/QS", BCFGPU_FMT_QS }, { "FORMAT/QS", BCFGPU_FMT_QS } };
+                { "AD", BCFGPU_FMT_AD }, { "ADF", BCFGPU_FMT_ADF }, { "ADR", BCFGPU_FMT_ADR }, { "SCR", BCFGPU_FMT_SCR }, { "QS", BCFGPU_FMT_QS },
+                { "INFO/DPR", BCFGPU_INFO_DPR }, { "INFO/AD", BCFGPU_INFO_AD }, { "INFO/ADF", BCFGPU_INFO_ADF }, { "INFO/ADR", BCFGPU_INFO_ADR },
+                { "INFO/SCR", BCFGPU_INFO_SCR } };
             char *list = strdup(argv[2]);
             for (char *t = strtok(list, ","); t; t = strtok(NULL, ",")) {
+                const char *name = !strncasecmp(t, "FORMAT/", 7) ? t + 7 : !strncasecmp(t, "FMT/", 4) ? t + 4 : t;
                 size_t i;
-                for (i = 0; i < sizeof tags / sizeof tags[0]; ++i) if (!strcmp(t, tags[i].name)) { fmt_flag |= tags[i].bit; break; }
-                if (i == sizeof tags / sizeof tags[0]) DIE("unknown tag %s\n", t);
+                for (i = 0; i < sizeof tags / sizeof tags[0]; ++i)
+                    if (!strcasecmp(name, tags[i].name) && (name == t || strncasecmp(tags[i].name, "INFO/", 5))) { fmt_flag |= tags[i].bit; break; }
+                if (i == sizeof tags / sizeof tags[0]) { fprintf(stderr, "Could not parse tag \"%s\" in \"%s\"\n", t, argv[2]); exit(1); }
             }
             free(list);
             argv += 2; argc -= 2;
