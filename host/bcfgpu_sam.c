@@ -920,14 +920,148 @@ static void pending_set(const char *contig, const bcfgpu_gvcf_block *B, char ref
     memcpy(PB.dp, dp, (size_t)S * 4); memcpy(PB.pl, pl, (size_t)S * 3);
 }
 
-/* ---- one tile: columns [t0, t1) of `contig` from the reads in P (all the reads that overlap the tile, file-major; file f =
- * [first[f], first[f+1])).  Every stage on the device; the records of the tile are written in position order. ---- */
 static unsigned long long tot_entries, tot_pairs;
 /* --timing: where the wall time of a run goes (seconds): reading and parsing the files, building a tile's pool, the device
  * stages of a tile (every call up to the records' planes on the host), writing the records */
 #include <time.h>
 static int want_timing; static double t_read, t_pool, t_dev, t_emit;
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+/* ---- a tile's records, written beside the device stages of the next tile: process_tile() hands everything the record loop reads over
+ * as a job (host copies only: sites, planes, the indel columns' results, the gVCF blocks) and goes on; one worker thread takes the
+ * jobs in order.  The pending gVCF block (PB) and the output are the worker's while it runs: whoever else needs them waits for it
+ * (emit_wait). ---- */
+typedef struct {
+    int n_sites, t0, t1, S, nlive, open_block;
+    const char *contig, *ref;
+    int32_t *col_n; uint8_t *col_indel; int32_t *cand, *live;
+    bcfgpu_site *site, *isite; planes_t snp_planes, ind_planes;
+    int32_t *g_types, *g_maxins, *g_indelreg, *g_support; float *g_frac; int8_t *g_inscns;
+    int32_t *gv_blk, *gv_dp; bcfgpu_gvcf_block *gv_block; uint8_t *gv_pl;
+} emit_job_t;
+static void emit_tile(emit_job_t *J)
+{
+    const int n_sites = J->n_sites, t0 = J->t0, t1 = J->t1, S = J->S, nlive = J->nlive, open_block = J->open_block;
+    const char *contig = J->contig, *ref = J->ref;
+    int32_t *col_n = J->col_n; uint8_t *col_indel = J->col_indel; int32_t *cand = J->cand, *live = J->live;
+    bcfgpu_site *site = J->site, *isite = J->isite; planes_t snp_planes = J->snp_planes, ind_planes = J->ind_planes;
+    int32_t *g_types = J->g_types, *g_maxins = J->g_maxins, *g_indelreg = J->g_indelreg, *g_support = J->g_support; float *g_frac = J->g_frac; int8_t *g_inscns = J->g_inscns;
+    int32_t *gv_blk = J->gv_blk, *gv_dp = J->gv_dp; bcfgpu_gvcf_block *gv_block = J->gv_block; uint8_t *gv_pl = J->gv_pl;
+    /* ---- the record loop: the SNP record of a column, then its indel record (mpileup.c:343-366) ---- */
+    static const char *nt = "ACGTN";
+    int jl = 0;
+    const double tw1 = want_timing ? now_s() : 0.;
+    for (int k = 0; k < n_sites; ++k) {
+        if (col_n[k] == 0) continue;                                         /* no read: no record */
+        if (!target_keeps_column(contig, t0 + k)) continue;                  /* outside the targets: no record (mpileup.c:330-335) */
+        const bcfgpu_site *c = &site[k];
+        if (gv_blk && gv_blk[k] >= 0) {                                      /* inside a block: one line when the block ends */
+            const int b = gv_blk[k];
+            const bcfgpu_gvcf_block *B = &gv_block[b];
+            if (B->first_site == k) {                                        /* the block starts: does it continue the one held back? */
+                if (PB.on && !pending_joins(contig, B)) pending_flush();
+            }
+            if (B->last_site == k) {
+                const bcfgpu_site *f = &site[B->first_site];
+                const char refc = nt[f->ori_ref < 0 || f->ori_ref > 4 ? 4 : f->ori_ref];
+                const uint8_t *bpl = gv_pl + (size_t)b * 3 * S; const int32_t *bdp = gv_dp + (size_t)b * S;
+                if (PB.on) pending_merge(B, bpl, bdp);                       /* (a block that did not join was flushed at its first site) */
+                else if (b == open_block) pending_set(contig, B, refc, f->qsum[0], f->qsum[1], bpl, bdp, S);
+                else block_line(contig, B->start_pos, B->end1, B->min_dp, refc, f->qsum[0], f->qsum[1], bpl, bdp, S);
+                if (PB.on && b != open_block) pending_flush();               /* joined, and it ends inside this tile */
+            }
+        } else {
+        pending_flush();                                                     /* a record that cannot join ends the block (gvcf.c:107) */
+        char als[64]; int o = 0;
+        als[o++] = nt[c->ori_ref < 0 || c->ori_ref > 4 ? 4 : c->ori_ref]; als[o++] = '\t';
+        for (int j = 1; j < c->n_alleles; ++j) {
+            if (j > 1) als[o++] = ',';
+            if (j == c->unseen) { memcpy(als + o, "<*>", 3); o += 3; } else als[o++] = nt[c->a[j]];
+        }
+        if (c->n_alleles < 2) als[o++] = '.';
+        als[o] = 0;
+        print_record(contig, t0 + k + 1, als, "", c, &snp_planes, (size_t)k, S);
+        }
+        while (jl < nlive && cand[live[jl]] < k) ++jl;
+        if (jl < nlive && cand[live[jl]] == k && isite[live[jl]].ret == 0) {
+            /* REF / ALT of an indel record (bam2bcf.c:767-790) */
+            pending_flush();
+            const int i = live[jl], p = t0 + k, ireg = g_indelreg[i], mi = g_maxins[i];
+            char *txt = malloc((size_t)(5 * (ireg + mi + 8)) + 64), prefix[64];
+            int t = 0;
+            for (int j = 0; j <= ireg; ++j) txt[t++] = ref[p + j];
+            txt[t++] = '\t';
+            for (int a = 1; a < 4 && isite[i].a[a] >= 0; ++a) {
+                const int ai = isite[i].a[a], ty = g_types[i * 4 + ai];
+                if (a > 1) txt[t++] = ',';
+                txt[t++] = ref[p];
+                if (ty < 0) { for (int j = p + 1 - ty; j < p + 1 + ireg; ++j) txt[t++] = ref[j]; }
+                else {
+                    for (int j = 0; j < ty; ++j) txt[t++] = nt[g_inscns[(size_t)i * 4 * INSCNS_CAP + (size_t)ai * mi + j]];
+                    for (int j = p + 1; j < p + 1 + ireg; ++j) txt[t++] = ref[j];
+                }
+            }
+            txt[t] = 0;
+            snprintf(prefix, sizeof prefix, "INDEL;IDV=%d;IMF=%g;", g_support[i], (double)g_frac[i]);
+            print_record(contig, p + 1, txt, prefix, &isite[i], &ind_planes, (size_t)i, S);
+            free(txt);
+        }
+    }
+    /* a column without reads ends a block too (a gap in positions, gvcf.c:131): nothing stays open past it */
+    if (gv_n && PB.on && (open_block < 0 || PB.end1 != t1)) pending_flush();
+    free(site); planes_free(&snp_planes); free(isite); planes_free(&ind_planes);
+    free(col_n); free(col_indel); free(cand); free(live);
+    free(g_types); free(g_maxins); free(g_indelreg); free(g_support); free(g_frac); free(g_inscns);
+    free(gv_blk); free(gv_block); free(gv_dp); free(gv_pl);
+    if (want_timing) t_emit += now_s() - tw1;
+}
+
+static struct { pthread_t th; pthread_mutex_t mu; pthread_cond_t cv; emit_job_t job; int on, have, busy, stop; } EM;
+static void *emit_main(void *arg)
+{
+    (void)arg;
+    for (;;) {
+        pthread_mutex_lock(&EM.mu);
+        while (!EM.have && !EM.stop) pthread_cond_wait(&EM.cv, &EM.mu);
+        if (!EM.have) { pthread_mutex_unlock(&EM.mu); return NULL; }
+        emit_job_t j = EM.job; EM.have = 0; EM.busy = 1;
+        pthread_cond_broadcast(&EM.cv);
+        pthread_mutex_unlock(&EM.mu);
+        emit_tile(&j);
+        pthread_mutex_lock(&EM.mu); EM.busy = 0; pthread_cond_broadcast(&EM.cv); pthread_mutex_unlock(&EM.mu);
+    }
+}
+/* the worker has written everything handed over so far (before anybody else touches the output, the pending block or the reference) */
+static void emit_wait(void)
+{
+    if (!EM.on) return;
+    pthread_mutex_lock(&EM.mu);
+    while (EM.have || EM.busy) pthread_cond_wait(&EM.cv, &EM.mu);
+    pthread_mutex_unlock(&EM.mu);
+}
+static void emit_submit(const emit_job_t *j)
+{
+    if (!EM.on) {
+        pthread_mutex_init(&EM.mu, NULL); pthread_cond_init(&EM.cv, NULL);
+        if (pthread_create(&EM.th, NULL, emit_main, NULL)) DIE("cannot start the record writer\n");
+        EM.on = 1;
+    }
+    pthread_mutex_lock(&EM.mu);
+    while (EM.have) pthread_cond_wait(&EM.cv, &EM.mu);          /* (one tile waiting while one is written) */
+    EM.job = *j; EM.have = 1;
+    pthread_cond_broadcast(&EM.cv);
+    pthread_mutex_unlock(&EM.mu);
+}
+static void emit_finish(void)
+{
+    if (!EM.on) return;
+    emit_wait();
+    pthread_mutex_lock(&EM.mu); EM.stop = 1; pthread_cond_broadcast(&EM.cv); pthread_mutex_unlock(&EM.mu);
+    pthread_join(EM.th, NULL);
+    EM.on = 0; EM.stop = 0;
+}
+
+/* ---- one tile: columns [t0, t1) of `contig` from the reads in P (all the reads that overlap the tile, file-major; file f =
+ * [first[f], first[f+1])).  Every stage on the device; the records of the tile are written in position order. ---- */
 static void process_tile(pool_t *P, const int *first, int F, int S, const char *contig, const char *ref, int ref_len, int t0, int t1)
 {
     const int n_sites = t1 - t0;
@@ -1053,74 +1187,16 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
         bcfgpu_free(ctx, d_site); bcfgpu_free(ctx, d_pl); bcfgpu_free(ctx, d_dp4);
     }
 
-    /* ---- the record loop: the SNP record of a column, then its indel record (mpileup.c:343-366) ---- */
-    static const char *nt = "ACGTN";
-    int jl = 0;
-    const double tw1 = want_timing ? now_s() : 0.;
-    t_dev += tw1 - tw0;
-    for (int k = 0; k < n_sites; ++k) {
-        if (col_n[k] == 0) continue;                                         /* no read: no record */
-        if (!target_keeps_column(contig, t0 + k)) continue;                  /* outside the targets: no record (mpileup.c:330-335) */
-        const bcfgpu_site *c = &site[k];
-        if (gv_blk && gv_blk[k] >= 0) {                                      /* inside a block: one line when the block ends */
-            const int b = gv_blk[k];
-            const bcfgpu_gvcf_block *B = &gv_block[b];
-            if (B->first_site == k) {                                        /* the block starts: does it continue the one held back? */
-                if (PB.on && !pending_joins(contig, B)) pending_flush();
-            }
-            if (B->last_site == k) {
-                const bcfgpu_site *f = &site[B->first_site];
-                const char refc = nt[f->ori_ref < 0 || f->ori_ref > 4 ? 4 : f->ori_ref];
-                const uint8_t *bpl = gv_pl + (size_t)b * 3 * S; const int32_t *bdp = gv_dp + (size_t)b * S;
-                if (PB.on) pending_merge(B, bpl, bdp);                       /* (a block that did not join was flushed at its first site) */
-                else if (b == open_block) pending_set(contig, B, refc, f->qsum[0], f->qsum[1], bpl, bdp, S);
-                else block_line(contig, B->start_pos, B->end1, B->min_dp, refc, f->qsum[0], f->qsum[1], bpl, bdp, S);
-                if (PB.on && b != open_block) pending_flush();               /* joined, and it ends inside this tile */
-            }
-        } else {
-        pending_flush();                                                     /* a record that cannot join ends the block (gvcf.c:107) */
-        char als[64]; int o = 0;
-        als[o++] = nt[c->ori_ref < 0 || c->ori_ref > 4 ? 4 : c->ori_ref]; als[o++] = '\t';
-        for (int j = 1; j < c->n_alleles; ++j) {
-            if (j > 1) als[o++] = ',';
-            if (j == c->unseen) { memcpy(als + o, "<*>", 3); o += 3; } else als[o++] = nt[c->a[j]];
-        }
-        if (c->n_alleles < 2) als[o++] = '.';
-        als[o] = 0;
-        print_record(contig, t0 + k + 1, als, "", c, &snp_planes, (size_t)k, S);
-        }
-        while (jl < nlive && cand[live[jl]] < k) ++jl;
-        if (jl < nlive && cand[live[jl]] == k && isite[live[jl]].ret == 0) {
-            /* REF / ALT of an indel record (bam2bcf.c:767-790) */
-            pending_flush();
-            const int i = live[jl], p = t0 + k, ireg = g_indelreg[i], mi = g_maxins[i];
-            char *txt = malloc((size_t)(5 * (ireg + mi + 8)) + 64), prefix[64];
-            int t = 0;
-            for (int j = 0; j <= ireg; ++j) txt[t++] = ref[p + j];
-            txt[t++] = '\t';
-            for (int a = 1; a < 4 && isite[i].a[a] >= 0; ++a) {
-                const int ai = isite[i].a[a], ty = g_types[i * 4 + ai];
-                if (a > 1) txt[t++] = ',';
-                txt[t++] = ref[p];
-                if (ty < 0) { for (int j = p + 1 - ty; j < p + 1 + ireg; ++j) txt[t++] = ref[j]; }
-                else {
-                    for (int j = 0; j < ty; ++j) txt[t++] = nt[g_inscns[(size_t)i * 4 * INSCNS_CAP + (size_t)ai * mi + j]];
-                    for (int j = p + 1; j < p + 1 + ireg; ++j) txt[t++] = ref[j];
-                }
-            }
-            txt[t] = 0;
-            snprintf(prefix, sizeof prefix, "INDEL;IDV=%d;IMF=%g;", g_support[i], (double)g_frac[i]);
-            print_record(contig, p + 1, txt, prefix, &isite[i], &ind_planes, (size_t)i, S);
-            free(txt);
-        }
+    /* ---- the records: handed to the writer (emit_tile), which runs beside the next tile's device stages ---- */
+    if (want_timing) t_dev += now_s() - tw0;
+    {
+        emit_job_t J; memset(&J, 0, sizeof J);
+        J.n_sites = n_sites; J.t0 = t0; J.t1 = t1; J.S = S; J.nlive = nlive; J.open_block = open_block; J.contig = contig; J.ref = ref;
+        J.col_n = col_n; J.col_indel = col_indel; J.cand = cand; J.live = live; J.site = site; J.isite = isite; J.snp_planes = snp_planes; J.ind_planes = ind_planes;
+        J.g_types = g_types; J.g_maxins = g_maxins; J.g_indelreg = g_indelreg; J.g_support = g_support; J.g_frac = g_frac; J.g_inscns = g_inscns;
+        J.gv_blk = gv_blk; J.gv_dp = gv_dp; J.gv_block = gv_block; J.gv_pl = gv_pl;
+        emit_submit(&J);
     }
-    /* a column without reads ends a block too (a gap in positions, gvcf.c:131): nothing stays open past it */
-    if (gv_n && PB.on && (open_block < 0 || PB.end1 != t1)) pending_flush();
-    free(site); planes_free(&snp_planes); free(isite); planes_free(&ind_planes);
-    free(col_n); free(col_indel); free(cand); free(live);
-    free(g_types); free(g_maxins); free(g_indelreg); free(g_support); free(g_frac); free(g_inscns);
-    free(gv_blk); free(gv_block); free(gv_dp); free(gv_pl);
-    if (want_timing) t_emit += now_s() - tw1;
 }
 
 /* ---- the live window: the reads of every file that passed the filters and the depth cap and may still cover a column ---- */
@@ -1579,7 +1655,7 @@ int main(int argc, char **argv)
     unsigned long long n_reads_tot = 0, n_cols_tot = 0; int n_tiles = 0, max_span = 0;
     for (int g = 0; g < n_reg; ++g) {
         const char *contig = reg[g].contig;
-        if (!ref_name || strcmp(ref_name, contig)) { free(ref); free(ref_name); ref = read_contig(ref_path, contig, &ref_len); ref_name = strdup(contig); }
+        if (!ref_name || strcmp(ref_name, contig)) { emit_wait(); free(ref); free(ref_name); ref = read_contig(ref_path, contig, &ref_len); ref_name = strdup(contig); }    /* (the writer may still read the old sequence) */
         reg_beg = reg[g].beg; reg_end = reg[g].end;
         if (reg_end <= reg_beg) continue;
         for (int f = 0; f < F; ++f) { reader_open(&rdr[f], kept_path[f]); for (int i = 0; i < win[f].n; ++i) lrec_free(win[f].r[i]); win[f].n = 0; }
@@ -1649,7 +1725,7 @@ int main(int argc, char **argv)
                 first[F] = P.n;
                 if (want_timing) t_pool += now_s() - tr1;
                 if (P.n) { process_tile(&P, first, F, S, contig, ref, ref_len, t0, t1); ++n_tiles; }
-                else pending_flush();                                       /* columns without a read: a gap ends a gVCF block (gvcf.c:131) */
+                else { emit_wait(); pending_flush(); }                      /* columns without a read: a gap ends a gVCF block (gvcf.c:131) */
                 n_cols_tot += (unsigned long long)(t1 - t0);
             }
             /* reads that end before the next tile's pool begins are through */
@@ -1676,6 +1752,7 @@ int main(int argc, char **argv)
         for (int s = 0; s < S; ++s) printf("%s\t%lld\t%d\n", sample[s], n_in_smpl[s], nf_smpl[s]);
         return 0;
     }
+    emit_finish();
     pending_flush();
     if (ctx) { uint32_t nw = 0; CHECK(bcfgpu_truncated_cells(ctx, &nw)); n_wide_cells += nw; }
     if (n_wide_cells) fprintf(stderr, "[bcfgpu_sam] note: %llu (site, sample) cells of more than 255 usable reads were left to the first-255 rule "
