@@ -255,8 +255,8 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
         return;
     }
     const double *s_pl2p = P.pl2p;
-    __shared__ double s_p2[FAST ? 256 : 1];                   // 10^(-PL/10), PL = 0..255
-    if constexpr (FAST) for (int i = tid; i < 256; i += WGS) s_p2[i] = P.pl2p[i];
+    __shared__ double s_p2[FAST ? 264 : 1];                   // 10^(-PL/10), PL = 0..255; [256] = 0: what a sample without data (or a slot past the genotypes) looks up
+    if constexpr (FAST) { for (int i = tid; i < 256; i += WGS) s_p2[i] = P.pl2p[i]; if (tid < 8) s_p2[256 + tid] = 0.0; }
 
     // The 5-allele instantiations split the sites by the number of subsets to visit (LDS for the running products): more
     // than 15 only when all five alleles have a non-zero frequency (5 + 10 + 10 subsets).  With sample groups the
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                     double b[4];
                     #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
-                        b[kk] = (has && gpk[kk] >= 0) ? s_p2[(w[kk] >> (8 * j)) & 0xff] : 0.0;
+                        b[kk] = s_p2[(has && gpk[kk] >= 0) ? (w[kk] >> (8 * j)) & 0xff : 256u];    // (an unconditional look-up: no branch around the read; the next sample's look-ups requested a sample ahead: slower)
                     #pragma unroll
                     for (int t = 0; t < TILES; ++t) {
                         d4_t d = {0., 0., 0., 0.}, dh = {0., 0., 0., 0.};
