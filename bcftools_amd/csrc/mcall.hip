@@ -238,6 +238,8 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
         nals = P.msite[is].n_alleles;
         unseen = P.msite[is].unseen > 0 ? P.msite[is].unseen : 0;     // vcfcall.c:1102-1111
     } else { nals = P.nals[is]; unseen = P.unseen[is]; }
+    // (one site per workgroup: the same in every lane -- said so, these decide scalar branches instead of lane masks)
+    nals = __builtin_amdgcn_readfirstlane(nals); unseen = __builtin_amdgcn_readfirstlane(unseen);
     const int ngts = nals * (nals + 1) / 2;
     // A record outside what the planes can hold (mcall() itself takes up to 32 alleles, mcall.c:1539; B2B_MAX_ALLELES = 5 is
     // what mpileup writes): refused record by record, ret = -2, and the call as a whole reports BCFGPU_E_RANGE at the next sync.
