@@ -776,7 +776,16 @@ static void print_record(const char *contig, int pos1, const char *alleles, cons
     if (fmt_flag & BCFGPU_INFO_DPR) put_counts(";DPR=", c->adf_tot, c->adr_tot, na);
     if (fmt_flag & BCFGPU_INFO_SCR) fprintf(LN, ";SCR=%d", c->scr_tot);
     fputs(";I16=", LN);
-    for (int j = 0; j < 16; ++j) fprintf(LN, "%s%g", j ? "," : "", (double)(float)c->anno[j]);
+    for (int j = 0; j < 16; ++j) {
+        /* %g of a whole number below a million is its digits: most of the sixteen sums are (counts, sums of qualities) */
+        const double v = (double)(float)c->anno[j];
+        if (j) fputc(',', LN);
+        if (v >= 0 && v < 1e6 && v == (double)(long)v && !(v == 0 && signbit(v))) {
+            char t[8]; int n = 0; long u = (long)v;
+            do { t[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+            while (n) fputc(t[--n], LN);
+        } else fprintf(LN, "%g", v);
+    }
     fputs(";QS=", LN);
     for (int j = 0; j < na; ++j) fprintf(LN, "%s%g", j ? "," : "", (double)c->qsum[j]);
     /* the bias statistics: HUGE_VAL = the tag is left out (bam2bcf.c:835-840) */
