@@ -599,7 +599,9 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                             if (HAP && t * 16 + kq + 4 * r == nsub && (pd == 1 || pd == 2) && d[r] != 0.0) sdm *= d[r];
                         }
                     }
-                    if (j & 1) {
+                    // (renormalised once per word of four samples: four factors are at least 1e-102 together, far from the range's end, and
+                    // splitting off a power of two is exact whenever it is done; every other sample was 1 % slower, every eighth no faster)
+                    if (j == 3) {
                         #pragma unroll
                         for (int t = 0; t < TILES; ++t)
                             #pragma unroll
