@@ -259,6 +259,10 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     const double *s_pl2p = P.pl2p;
     __shared__ double s_p2[FAST ? 264 : 1];                   // 10^(-PL/10), PL = 0..255; [256] = 0: what a sample without data (or a slot past the genotypes) looks up
     if constexpr (FAST) { for (int i = tid; i < 256; i += WGS) s_p2[i] = P.pl2p[i]; if (tid < 8) s_p2[256 + tid] = 0.0; }
+    // one group: the subset scan notes which samples carry data, four of them a byte (bit j: sample 4i+j), for the genotypes of a
+    // site that stays REF-only (below)
+    constexpr int NZ_MAX_S = 4096;
+    __shared__ uint8_t s_nz[FAST ? NZ_MAX_S / 4 : 1];
 
     // The 5-allele instantiations split the sites by the number of subsets to visit (LDS for the running products): more
     // than 15 only when all five alleles have a non-zero frequency (5 + 10 + 10 subsets).  With sample groups the
@@ -574,6 +578,8 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                 uint32_t any = w[0] | w[1] | w[2] | w[3];
                 any |= __shfl_xor(any, 16);
                 any |= __shfl_xor(any, 32);
+                if (ngrp == 1 && kq == 0 && S <= NZ_MAX_S && sb0 + 4 * q < S)
+                    s_nz[(sb0 + 4 * q) >> 2] = (uint8_t)(((any & 0xffu) ? 1u : 0u) | ((any & 0xff00u) ? 2u : 0u) | ((any & 0xff0000u) ? 4u : 0u) | ((any & 0xff000000u) ? 8u : 0u));
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool has = ((any >> (8 * j)) & 0xff) != 0 && ((gmask >> j) & 1);
@@ -862,8 +868,43 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             for (int k = 0; k < NG; ++k) pl_nx[k] = (k < ngts && s < S) ? (uint32_t)plb2[(size_t)k * Ss + s] : 0u;
         }
     };
-    if (!BCFGPU_ABL(P, 32)) fetch_pl(tid);
-    for (int s = tid; s < (BCFGPU_ABL(P, 32) ? 0 : S); s += WGS) {
+    // A site that stays REF-only (most of them) needs of its samples only "any data at all?" (mcall_set_ref_genotypes,
+    // mcall.c:529-541): four samples a lane and a 4-byte store per GT plane, from the subset scan's notes or (sample groups)
+    // from a 4-byte load per PL plane -- four trips to memory for 1000 samples where the general loop below makes sixteen
+    bool gt_done = BCFGPU_ABL(P, 32);
+    if constexpr (FAST) {
+        int8_t *gt0 = P.out.gt + (size_t)is * 2 * Ss;
+        if (!gt_done && !is_variant && ref_only && !(S & 3) && !(((uintptr_t)plb2 | (uintptr_t)gt0) & 3)) {
+            const bool noted = ngrp == 1 && S <= NZ_MAX_S;       // the scan's notes: no PL is read again
+            for (int s4 = tid * 4; s4 < S; s4 += WGS * 4) {
+                uint32_t any = 0;
+                if (noted) {
+                    const uint32_t nib = s_nz[s4 >> 2];
+                    any = (nib & 1u) | (nib & 2u) << 7 | (nib & 4u) << 14 | (nib & 8u) << 21;
+                } else {
+                    #pragma unroll
+                    for (int k = 0; k < NG; ++k)
+                        if (k < ngts) any |= *reinterpret_cast<const uint32_t*>(plb2 + (size_t)k * Ss + s4);
+                }
+                uint32_t w = 0, w1 = 0, pw = 0x02020202u;
+                if (HAP && P.ploidy) __builtin_memcpy(&pw, P.ploidy + s4, 4);
+                #pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t pd = (pw >> (8 * b)) & 0xFFu;
+                    const bool called = ((any >> (8 * b)) & 0xFFu) && pd;
+                    if (called) ac_loc[0] += (int)pd;
+                    const uint32_t g0 = called ? 0u : (uint32_t)(uint8_t)BCFGPU_GT_MISSING;
+                    w |= g0 << (8 * b);
+                    w1 |= (pd == 2 ? g0 : (uint32_t)(uint8_t)BCFGPU_GT_VECTOR_END) << (8 * b);
+                }
+                *reinterpret_cast<uint32_t*>(gt0 + s4) = w;
+                *reinterpret_cast<uint32_t*>(gt0 + Ss + s4) = w1;
+            }
+            gt_done = true;
+        }
+    }
+    if (!gt_done) fetch_pl(tid);
+    for (int s = tid; s < (gt_done ? 0 : S); s += WGS) {
         const int ploidy = (FAST && !HAP) ? 2 : (P.ploidy ? P.ploidy[s] : 2);    // FAST without HAP is launched only without a ploidy array
         // P(D|G) = raw/psum is formed lazily below, with the same division the reference performs (bit-exact genotypes)
         double psum = 0;

@@ -130,6 +130,40 @@ def test_pipeline_diploid_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth
         np.testing.assert_array_equal(cgot.gq[live], cwant.gq[live])
 
 
+@pytest.mark.parametrize("n_grp", [1, 3])
+@pytest.mark.parametrize("with_ploidy", [False, True])
+@pytest.mark.parametrize("n_sites,n_smpl,depth,seed", [(96, 40, 0.7, 41), (64, 260, 1.5, 42), (48, 1000, 2.0, 43), (96, 42, 0.7, 44)])
+def test_pipeline_ref_only_sites(gpu_ctx_factory, n_sites, n_smpl, depth, seed, with_ploidy, n_grp):
+    """Sites that stay REF-only: GT is 0/0 (0 for a haploid sample) where a sample has data and ./. (.) where it has none or
+    its ploidy is 0 (mcall_set_ref_genotypes, mcall.c:529-541).  Sample counts that are multiples of four take the kernel's
+    four-samples-per-lane path -- from the subset scan's notes with one group, from the PL planes with several -- and 42 the
+    general loop; 260 and 1000 need more than one round of 256 samples."""
+    tile = synth.numpy_tile(seed, n_sites, n_smpl, depth=depth, var_rate=0.0)
+    kw = dict(fmt_flag=abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD, n_grp=n_grp) if n_grp > 1 else {}
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), **kw)
+    rng = np.random.default_rng(seed)
+    ploidy = rng.choice([0, 1, 2, 2], size=n_smpl).astype(np.uint8) if with_ploidy else None
+    grp = rng.integers(0, n_grp, n_smpl).astype(np.int32) if n_grp > 1 else None
+    mwant = orc.mpileup(cfg, tile)
+    na = mwant.site["n_alleles"]
+    ad = None
+    if n_grp > 1:
+        src = mwant.adf.astype(np.int32) + mwant.adr.astype(np.int32)
+        ad = np.where(np.arange(5)[None, :, None] < na[:, None, None], src, abi.INT32_VECTOR_END).astype(np.int32)
+    cin = host.CallInput(n_smpl, na, np.maximum(mwant.site["unseen"], 0), mwant.pl.astype(np.int32), mwant.site["qsum"],
+                         ad=ad, ploidy=ploidy, grp=grp, i16=mwant.site["anno"].astype(np.float32))
+    cwant = orc.mcall(cfg, cin)
+    ref_only = (cwant.site["ret"] > 0) & (cwant.site["als_new"] == 1)
+    assert ref_only.sum() >= 8
+    g = cwant.gt[ref_only]
+    assert (g == -1).any() and (g == 0).any() and (not with_ploidy or (g == -2).any())
+    mgot, cgot = gpu_ctx_factory(cfg).pipeline(tile, ploidy=ploidy, grp=grp)
+    assert_mplp_equal(mgot, mwant)
+    assert_call_equal(cgot, cwant, n_smpl)
+    np.testing.assert_array_equal(cgot.gt[ref_only], g)
+    np.testing.assert_array_equal(cgot.site["ac"][ref_only], cwant.site["ac"][ref_only])
+
+
 @pytest.mark.parametrize("theta", [0.0, 1e-2, 1e-4, 0.9])
 @pytest.mark.parametrize("n_smpl,with_ploidy", [(100, False), (40, True)])
 def test_pipeline_nondefault_prior(gpu_ctx_factory, theta, n_smpl, with_ploidy):
