@@ -259,10 +259,11 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     const double *s_pl2p = P.pl2p;
     __shared__ double s_p2[FAST ? 264 : 1];                   // 10^(-PL/10), PL = 0..255; [256] = 0: what a sample without data (or a slot past the genotypes) looks up
     if constexpr (FAST) { for (int i = tid; i < 256; i += WGS) s_p2[i] = P.pl2p[i]; if (tid < 8) s_p2[256 + tid] = 0.0; }
-    // one group: the subset scan notes which samples carry data, four of them a byte (bit j: sample 4i+j), for the genotypes of a
-    // site that stays REF-only (below)
+    // the subset scan notes which samples carry data, four of them a byte (bit j: sample 4i+j), for the genotypes of a site that
+    // stays REF-only (below); 0x80: no group's scan came by (the planes are read then)
     constexpr int NZ_MAX_S = 4096;
-    __shared__ uint8_t s_nz[FAST ? NZ_MAX_S / 4 : 1];
+    __shared__ __align__(4) uint8_t s_nz[FAST ? NZ_MAX_S / 4 : 4];
+    if constexpr (FAST) { if (S <= NZ_MAX_S) for (int i = tid; i < (S + 15) / 16; i += WGS) reinterpret_cast<uint32_t*>(s_nz)[i] = 0x80808080u; }
 
     // The 5-allele instantiations split the sites by the number of subsets to visit (LDS for the running products): more
     // than 15 only when all five alleles have a non-zero frequency (5 + 10 + 10 subsets).  With sample groups the
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                 uint32_t any = w[0] | w[1] | w[2] | w[3];
                 any |= __shfl_xor(any, 16);
                 any |= __shfl_xor(any, 32);
-                if (ngrp == 1 && kq == 0 && S <= NZ_MAX_S && sb0 + 4 * q < S)
+                if (kq == 0 && S <= NZ_MAX_S && sb0 + 4 * q < S)
                     s_nz[(sb0 + 4 * q) >> 2] = (uint8_t)(((any & 0xffu) ? 1u : 0u) | ((any & 0xff00u) ? 2u : 0u) | ((any & 0xff0000u) ? 4u : 0u) | ((any & 0xff000000u) ? 8u : 0u));
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -875,11 +876,10 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     if constexpr (FAST) {
         int8_t *gt0 = P.out.gt + (size_t)is * 2 * Ss;
         if (!gt_done && !is_variant && ref_only && !(S & 3) && !(((uintptr_t)plb2 | (uintptr_t)gt0) & 3)) {
-            const bool noted = ngrp == 1 && S <= NZ_MAX_S;       // the scan's notes: no PL is read again
             for (int s4 = tid * 4; s4 < S; s4 += WGS * 4) {
                 uint32_t any = 0;
-                if (noted) {
-                    const uint32_t nib = s_nz[s4 >> 2];
+                const uint32_t nib = S <= NZ_MAX_S ? s_nz[s4 >> 2] : 0x80u;
+                if (!(nib & 0x80u)) {                            // the scan's note: no PL is read again
                     any = (nib & 1u) | (nib & 2u) << 7 | (nib & 4u) << 14 | (nib & 8u) << 21;
                 } else {
                     #pragma unroll
