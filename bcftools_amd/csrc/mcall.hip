@@ -85,10 +85,11 @@ struct Subset {
     double fa, fb, fc, fa2, fb2, fc2, fab, fac, fbc;
 };
 
+template <int NSUB>
 struct CallShared {
     float qsum[5];              // current group's allele frequencies
     int nsub;                   // subsets visited for the current group
-    Subset sub[25];
+    Subset sub[NSUB];               // (the kernel's LDS decides how many sites a CU holds: 15 subsets leave room for 16)
     double red[32];             // reduced log-likelihood sums, indexed like sub[] (FAST: + the sum row at [nsub])
     int rede[32];               // FAST: binary exponents of the row products before the logarithm
     int redset;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     constexpr int TILES = NSUB >= 16 ? 2 : 1;     // 16-row tiles of the coefficient matrix (subsets + the sum row)
     extern __shared__ __align__(16) unsigned char dsm[];
     float *s_gq = reinterpret_cast<float*>(dsm);              // [n_grp][5] group qsum, then [n_grp][2] best allele sets
-    __shared__ CallShared sh;
+    __shared__ CallShared<NSUB> sh;
     __shared__ double s_pdg[FAST ? 1 : NG * WGS];   // the lane's current sample: raw P(D|G) (not yet divided by its sum)
     int *s_fill = reinterpret_cast<int*>(s_pdg);   // scratch of set_pdg's rare missing-value path (used before s_pdg is written)
     // pass 1: per-lane running products of the subset likelihoods, kept as mantissa (f64) and exponent (i32):
