@@ -258,8 +258,8 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
         return;
     }
     const double *s_pl2p = P.pl2p;
-    __shared__ double s_p2[FAST ? 264 : 1];                   // 10^(-PL/10), PL = 0..255; [256] = 0: what a sample without data (or a slot past the genotypes) looks up
-    if constexpr (FAST) { for (int i = tid; i < 256; i += WGS) s_p2[i] = P.pl2p[i]; if (tid < 8) s_p2[256 + tid] = 0.0; }
+    __shared__ double s_p2[FAST ? 264 : 1];                   // 10^(-PL/10), PL = 0..255; [256] = 0: what a sample without data (or a slot past the genotypes) looks up; [257] = 1
+    if constexpr (FAST) { for (int i = tid; i < 256; i += WGS) s_p2[i] = P.pl2p[i]; if (tid < 8) s_p2[256 + tid] = tid == 1 ? 1.0 : 0.0; }   // [257] = 1: the free slot of a sample without data (subset scan)
     // the subset scan notes which samples carry data, four of them a byte (bit j: sample 4i+j), for the genotypes of a site that
     // stays REF-only (below); 0x80: no group's scan came by (the planes are read then)
     constexpr int NZ_MAX_S = 4096;
@@ -447,6 +447,13 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                 const int sl = 4 * kk + kq;
                 gpk[kk] = sl < nals ? (sl + 1) * (sl + 2) / 2 - 1 : sl < ngts ? (int)((0xDCBA876431ull >> (4 * (sl - nals))) & 15) : -1;
             }
+            // Without a ploidy array, slot ngts -- the first one past the genotypes, always inside the last block of four the products
+            // visit (ngts is 1, 3, 6, 10 or 15) -- carries the coefficient 1 in every row and the value 1 for a sample that is not
+            // scanned (no data, another group), 0 for one that is: every product of such a sample is exactly 1, the products of the
+            // others are what they were (+ 0.0), and the running products take them all without a test.
+            uint32_t nodata[4];
+            #pragma unroll
+            for (int kk = 0; kk < 4; ++kk) nodata[kk] = (!HAP && 4 * kk + kq == ngts) ? 257u : 256u;
             double a[TILES][4], ah[HAP ? TILES : 1][4];
             if constexpr (BATCH) {
                 // the lane's elements of the coefficient matrices, rows col (+ 16 t), genotypes 4 kk + kq, straight from the subset
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                         double av = 0.0, hv = 0.0;
                         if (row < nsub) { av = x == y ? fx * fx : 2 * fy * fx; hv = x == y ? fx : 0.0; }
                         else if (row == nsub) av = gpk[kk] >= 0 ? 1.0 : 0.0;
-                        a[t][kk] = av;
+                        a[t][kk] = nodata[kk] == 257u ? 1.0 : av;
                         if (HAP) ah[t][kk] = hv;
                     }
                 }
@@ -502,7 +509,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             for (int t = 0; t < TILES; ++t)
                 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    a[t][kk] = gpk[kk] >= 0 ? s_coef[(t * 16 + col) * 16 + gpk[kk]] : 0.0;
+                    a[t][kk] = gpk[kk] >= 0 ? s_coef[(t * 16 + col) * 16 + gpk[kk]] : nodata[kk] == 257u ? 1.0 : 0.0;
                     if (HAP) ah[t][kk] = gpk[kk] >= 0 ? s_coefh[(t * 16 + col) * 16 + gpk[kk]] : 0.0;
                 }
             }
@@ -586,10 +593,11 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                 for (int j = 0; j < 4; ++j) {
                     const bool has = ((any >> (8 * j)) & 0xff) != 0 && ((gmask >> j) & 1);
                     const int pd = (int)((pw >> (8 * j)) & 0xff);
+                    if (!HAP && has) setbits = (1 << (TILES * 4)) - 1;       // (a scanned sample's products are all positive)
                     double b[4];
                     #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
-                        b[kk] = s_p2[(has && gpk[kk] >= 0) ? (w[kk] >> (8 * j)) & 0xff : 256u];    // (an unconditional look-up: no branch around the read; the next sample's look-ups requested a sample ahead: slower)
+                        b[kk] = s_p2[has ? (gpk[kk] >= 0 ? (w[kk] >> (8 * j)) & 0xff : 256u) : nodata[kk]];    // (an unconditional look-up: no branch around the read; the next sample's look-ups requested a sample ahead: slower)
                     #pragma unroll
                     for (int t = 0; t < TILES; ++t) {
                         d4_t d = {0., 0., 0., 0.}, dh = {0., 0., 0., 0.};
@@ -603,7 +611,8 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
                         for (int r = 0; r < 4; ++r) {
                             double v = d[r];
                             if (HAP && !((singles >> (t * 4 + r)) & 1)) v = pd == 2 ? d[r] : pd == 1 ? dh[r] : 0.0;
-                            if (v != 0.0) { man[t][r] *= v; setbits |= 1 << (t * 4 + r); }
+                            if constexpr (!HAP) man[t][r] *= v;
+                            else if (v != 0.0) { man[t][r] *= v; setbits |= 1 << (t * 4 + r); }
                             if (HAP && t * 16 + kq + 4 * r == nsub && (pd == 1 || pd == 2) && d[r] != 0.0) sdm *= d[r];
                         }
                     }
