@@ -138,6 +138,7 @@ struct McallParams {
     bcfgpu_call_out out;
     int out_n_gt_max;               // plane count of out.pl / out.gp
     int *err;                       // device error word
+    int small_too;                  // mcall_kernel<5, 15, ...> also takes the sites of at most three alleles (launch_mcall)
     BCFGPU_ABL_FIELD
 };
 

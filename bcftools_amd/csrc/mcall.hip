@@ -245,11 +245,12 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     // A record outside what the planes can hold (mcall() itself takes up to 32 alleles, mcall.c:1539; B2B_MAX_ALLELES = 5 is
     // what mpileup writes): refused record by record, ret = -2, and the call as a whole reports BCFGPU_E_RANGE at the next sync.
     if (nals < 1 || nals > BCFGPU_MAX_ALLELES || ngts > P.n_gt_max || (P.ad && nals > P.n_al_max) || unseen < 0 || unseen >= nals) {
-        if (MAXA == 3 && tid == 0) { write_skipped(cs, -2); atomicExch(P.err, BCFGPU_E_RANGE); }
+        if ((MAXA == 3 || (P.small_too && NSUB == 15)) && tid == 0) { write_skipped(cs, -2); atomicExch(P.err, BCFGPU_E_RANGE); }
         return;
     }
-    // two instantiations share the grid: sites with <=3 alleles run in the small one, the rest in the general one
-    if ((nals <= 3) != (MAXA == 3)) return;
+    // the instantiations share the grid: sites with <=3 alleles run in the small one, the rest in the general ones -- or, with
+    // many samples (launch_mcall), in mcall_kernel<5, 15, ...> as well, and the small one is not launched
+    if (P.small_too ? (nals <= 3 && NSUB == 25) : (nals <= 3) != (MAXA == 3)) return;
     if (BCFGPU_ABL(P, 8)) return;
 
     // record-loop prologue of vcfcall.c:1112-1115: with -v a REF-only record never reaches mcall()
@@ -1354,9 +1355,14 @@ __global__ void grp_check_kernel(const int32_t *grp, int n_smpl, int n_grp, int 
     } else { atomicMin(&rng[3 * g], s); atomicMax(&rng[3 * g + 1], s + 1); atomicAdd(&rng[3 * g + 2], 1); }
 }
 
-void launch_mcall(const McallParams &p, hipStream_t s)
+void launch_mcall(const McallParams &p_in, hipStream_t s)
 {
-    if (p.n_sites == 0) return;
+    if (p_in.n_sites == 0) return;
+    #ifndef MCALL_SMALL_TOO_SAMPLES
+    #define MCALL_SMALL_TOO_SAMPLES 256
+    #endif
+    McallParams p = p_in;
+    p.small_too = p.n_smpl >= MCALL_SMALL_TOO_SAMPLES ? 1 : 0;        // (below)
     const int ngrp = p.n_grp > 1 ? p.n_grp : 1;
     const size_t lds = (size_t)ngrp * 5 * sizeof(float) + (size_t)ngrp * 2 * sizeof(int);
     if (p.grp && ngrp > 1) {
@@ -1364,8 +1370,11 @@ void launch_mcall(const McallParams &p, hipStream_t s)
         hipLaunchKernelGGL(grp_check_kernel, dim3((p.n_smpl + 255) / 256), dim3(256), 0, s, p.grp, p.n_smpl, ngrp, p.err, p.grp_rng);
     }
     if (p.grp && ngrp > 1) hipLaunchKernelGGL(grp_qsum_kernel, dim3(p.n_sites), dim3(WGS), (size_t)ngrp * 5 * sizeof(float), s, p);
+    // Each instantiation is launched over all sites and a workgroup leaves at once when the site is another's: 25-45 us a launch of
+    // 32 768 workgroups.  With many samples nearly every site shows four or five alleles (sequencing errors alone), so the small
+    // instantiation is not launched then and the few sites it would take run in the 15-subset one (same arithmetic, longer loops).
     #define MCALL_LAUNCH3(FAST_, HAP_, GRP_) do { \
-        hipLaunchKernelGGL((mcall_kernel<3, 7, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \
+        if (!p.small_too) hipLaunchKernelGGL((mcall_kernel<3, 7, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \
         hipLaunchKernelGGL((mcall_kernel<5, 15, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \
         hipLaunchKernelGGL((mcall_kernel<5, 25, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); } while (0)
     if (p.pl_is_u8 && !BCFGPU_ABL(p, 64)) {

@@ -111,6 +111,7 @@ def test_pipeline_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, seed, flags, 
     (128, 130, 3.0, 24, abi.CALL_VARONLY, 0),
     (200, 1, 20.0, 25, 0, abi.CALL_FMT_GQ | abi.CALL_FMT_GP),
     (100, 17, 12.0, 26, abi.CALL_KEEPALT, abi.CALL_FMT_PV4),
+    (96, 300, 0.5, 27, 0, abi.CALL_FMT_GQ),             # many samples, few reads: sites of two or three alleles in the 15-subset instantiation
 ])
 def test_pipeline_diploid_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth, seed, flags, tags):
     """All-diploid, single-group calling from the mpileup stage's u8 PL planes: the allele-subset scan runs on
