@@ -133,12 +133,13 @@ def test_pipeline_diploid_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth
 
 @pytest.mark.parametrize("n_grp", [1, 3])
 @pytest.mark.parametrize("with_ploidy", [False, True])
-@pytest.mark.parametrize("n_sites,n_smpl,depth,seed", [(96, 40, 0.7, 41), (64, 260, 1.5, 42), (48, 1000, 2.0, 43), (96, 42, 0.7, 44)])
+@pytest.mark.parametrize("n_sites,n_smpl,depth,seed", [(96, 40, 0.7, 41), (64, 260, 1.5, 42), (48, 1000, 2.0, 43), (96, 42, 0.7, 44), (16, 4100, 0.3, 45)])
 def test_pipeline_ref_only_sites(gpu_ctx_factory, n_sites, n_smpl, depth, seed, with_ploidy, n_grp):
     """Sites that stay REF-only: GT is 0/0 (0 for a haploid sample) where a sample has data and ./. (.) where it has none or
     its ploidy is 0 (mcall_set_ref_genotypes, mcall.c:529-541).  Sample counts that are multiples of four take the kernel's
     four-samples-per-lane path -- from the subset scan's notes with one group, from the PL planes with several -- and 42 the
-    general loop; 260 and 1000 need more than one round of 256 samples."""
+    general loop; 260 and 1000 need more than one round of 256 samples; past 4096 samples the scan keeps no notes and the path reads
+    the PL planes, four samples a load."""
     tile = synth.numpy_tile(seed, n_sites, n_smpl, depth=depth, var_rate=0.0)
     kw = dict(fmt_flag=abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD, n_grp=n_grp) if n_grp > 1 else {}
     cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), **kw)
