@@ -25,7 +25,7 @@ def build(force=False):
     cmd = ["make", "-s", "-C", os.path.join(_HERE, "csrc")]
     if force:
         subprocess.check_call(cmd + ["clean"])
-    subprocess.check_call(cmd)
+    subprocess.check_call(cmd + ["-j%d" % max(1, min(8, os.cpu_count() or 1))])      # (a file per job: mcall.hip alone is a minute)
     return SO_PATH
 
 
