@@ -18,7 +18,13 @@ for r in csv.DictReader(open('/tmp/sv/s_kernel_stats.csv')):
     n=r['Name']
     if any(p in n for p in '$PAT'.split('|')): print(n.split('(')[0].replace('void ','').replace('bcfgpu::',''), 'avg %.3f ms;' % (float(r['AverageNs'])/1e6), end=' ')
 ")
-  echo "$name: $k" >> $R/gpurun_out/sovar.txt
+  v=$(python3 -c "
+import json
+for l in open('/tmp/sv.log'):
+    if l.startswith('{'):
+        d=json.loads(l); print('value %.4g %s, %.3f ms/step' % (d['value'], d['unit'], d.get('ms_per_step', 0)))
+" 2>/dev/null | tail -1)
+  echo "$name: $v; $k" >> $R/gpurun_out/sovar.txt
 done
 cp /tmp/libbcfgpu.product.so $R/bcftools_amd/libbcfgpu.so
 cat $R/gpurun_out/sovar.txt
