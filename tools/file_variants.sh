@@ -8,8 +8,9 @@ export TMPDIR=/tmp
 SRC=$1; PAT=$2; BARGS=$3; shift 3
 : > $R/gpurun_out/filevar.txt
 OBJS="glfgen.o combine.o mcall.o indel.o gap_prep.o baq.o overlap.o pileup.o gvcf.o gather.o capmapq.o draw.o api.o tables.o"
+PROD=$(make -s -C $R/bcftools_amd/csrc print-flags-${SRC%.hip})          # the product's own options of this file (csrc/Makefile)
 for spec in "$@"; do
-  name=${spec%%:*}; flags=${spec#*:}
+  name=${spec%%:*}; flags="$PROD ${spec#*:}"
   cd $R/bcftools_amd/csrc
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-value $flags -c $SRC -o ${SRC%.hip}.o 2>/dev/null || { echo "$name: build failed" >> $R/gpurun_out/filevar.txt; continue; }
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libbcfgpu.so $OBJS -ldl
