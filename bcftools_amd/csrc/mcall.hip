@@ -1362,7 +1362,7 @@ void launch_mcall(const McallParams &p_in, hipStream_t s)
     #define MCALL_SMALL_TOO_SAMPLES 256
     #endif
     McallParams p = p_in;
-    p.small_too = p.n_smpl >= MCALL_SMALL_TOO_SAMPLES ? 1 : 0;        // (below)
+    p.small_too = (p.pl_is_u8 && p.n_smpl >= MCALL_SMALL_TOO_SAMPLES) ? 1 : 0;        // (below; the fused pipeline's launches only)
     const int ngrp = p.n_grp > 1 ? p.n_grp : 1;
     const size_t lds = (size_t)ngrp * 5 * sizeof(float) + (size_t)ngrp * 2 * sizeof(int);
     if (p.grp && ngrp > 1) {
