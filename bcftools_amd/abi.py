@@ -156,7 +156,8 @@ class GvcfOut(C.Structure):
 
 class GapStats(C.Structure):
     _fields_ = [("n_jobs", C.c_uint64), ("n_passes", C.c_uint64), ("dp_cells", C.c_uint64),
-                ("kernel_ms", C.c_float), ("prepare_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float)]
+                ("kernel_ms", C.c_float), ("prepare_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float),
+                ("n_wide", C.c_uint64)]
 
 
 class Timing(C.Structure):

@@ -724,6 +724,7 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
         GP_CHK(hipMemcpyAsync(h_small, d_tot, sizeof(GapTotals), hipMemcpyDeviceToHost, st));
         GP_CHK(hipStreamSynchronize(st));                       // how many jobs need the wide-band version, and how wide
         memcpy(&tot, h_small, sizeof tot);
+        gs.n_wide = tot.n_wide;
         if (tot.n_wide) {
             p.ncell = 3 * (2 * tot.max_eff + 1) + 6;
             size_t chunk = ((size_t)1 << 30) / (2 * (size_t)p.ncell * sizeof(double));

@@ -132,11 +132,15 @@ def tile_from_torch(t):
                          t["rd"].cpu().numpy().view(np.uint32), t["epos"].cpu().numpy())
 
 
-def indel_batch(seed, n_sites, n_smpl, depth=30.0, read_len=100, max_depth=200):
+def indel_batch(seed, n_sites, n_smpl, depth=30.0, read_len=100, max_depth=200, lens=None, lens2=None):
     """Synthetic input of bcfgpu_gap_prep (BASELINE configs[2] shape: indel-candidate columns): a random reference with
     one indel locus every 300 bp (length -3..+3, weights 1/|len|), HWE carriers, Poisson depth, reads of `read_len`
     bases placed so that the locus falls inside them, substitution errors at 10^(-Q/10).  Every pileup entry owns its
     read (the flat pool of bcfgpu_reads allows sharing; sharing does not change the work).
+    `lens`: the indel lengths a locus draws its type from (default -3..+3; long ones, e.g. (-40, -25, 12, 8), put the
+    realignment's band |type| + 3 of bam2bcf_indel.c:293-294 past the register-resident classes).  `lens2`: a second
+    type per locus, drawn from this set and carried by a third of the carriers, so that one column has jobs of several
+    band widths (types of 1-3 bp next to a long one).
 
     Returns dict(ref=bytes, reads=dict of the bcfgpu_reads arrays, pos, smpl_off, p_read, p_qpos, p_indel, itype)."""
     rng = np.random.Generator(np.random.Philox(key=int(seed)))
@@ -144,10 +148,16 @@ def indel_batch(seed, n_sites, n_smpl, depth=30.0, read_len=100, max_depth=200):
     L = 200 + 300 * n_sites + 300
     ref2 = rng.integers(0, 4, L)
     pos = (200 + 300 * np.arange(n_sites)).astype(np.int32)
-    lens = np.array([-3, -2, -1, 1, 2, 3])
+    lens = np.array([-3, -2, -1, 1, 2, 3] if lens is None else list(lens))
+    max_len = int(max(3, np.abs(lens).max(), 0 if lens2 is None else np.abs(np.array(list(lens2))).max()))
+    assert max_len + 24 < read_len and max_len < 100
     w = 1.0 / np.abs(lens)
-    itype = lens[rng.choice(6, size=n_sites, p=w / w.sum())]
-    ins2 = rng.integers(0, 4, (n_sites, 3))
+    itype = lens[rng.choice(len(lens), size=n_sites, p=w / w.sum())]
+    ins2 = rng.integers(0, 4, (n_sites, max_len))
+    itype2 = None
+    if lens2 is not None:
+        l2 = np.array(list(lens2))
+        itype2 = l2[rng.integers(0, len(l2), n_sites)]
     af = np.clip(rng.beta(0.5, 5.0, n_sites), 0.05, 0.5)
     nalt = rng.binomial(2, np.repeat(af, S))
     n = np.minimum(rng.poisson(depth, n_sites * S), max_depth).astype(np.int64)
@@ -158,16 +168,18 @@ def indel_batch(seed, n_sites, n_smpl, depth=30.0, read_len=100, max_depth=200):
     site = cell // S
     carrier = rng.random(R) < nalt[cell] * 0.5
     carrier ^= rng.random(R) < 0.005                               # alignment/sequencing indel noise
-    qpos = rng.integers(8, read_len - 12, R)
+    qpos = rng.integers(8, read_len - 12 - (max_len if max_len > 3 else 0), R)
     start = pos[site].astype(np.int64) - qpos
     ilen = np.where(carrier, itype[site], 0).astype(np.int64)
+    if itype2 is not None:
+        ilen = np.where(carrier & (rng.random(R) < 1.0 / 3), itype2[site], ilen)
     j = np.arange(read_len)[None, :]
     after = j > qpos[:, None]
     shift = np.where(ilen[:, None] < 0, -ilen[:, None], -np.minimum(ilen[:, None], np.maximum(j - qpos[:, None], 0)))
     base = ref2[start[:, None] + j + np.where(after, shift, 0)]
     k = j - qpos[:, None] - 1
     is_ins = after & (ilen[:, None] > 0) & (k < ilen[:, None])
-    base = np.where(is_ins, ins2[site[:, None], np.clip(k, 0, 2)], base)
+    base = np.where(is_ins, ins2[site[:, None], np.clip(k, 0, max_len - 1)], base)
     bq = BQ_VALUES[rng.choice(len(BQ_VALUES), size=(R, read_len), p=BQ_PMF)]
     err = rng.random((R, read_len)) < 10.0 ** (-bq / 10.0)
     base = np.where(err, (base + rng.integers(1, 4, (R, read_len))) % 4, base)

@@ -574,6 +574,8 @@ typedef struct {
     uint64_t n_jobs, n_passes, dp_cells;
     float kernel_ms;             /* probaln_kernel launches, HIP events on the context's stream */
     float prepare_ms, finalize_ms, total_ms;   /* host typing/consensus, host scoring, whole call (wall clock) */
+    uint64_t n_wide;             /* jobs whose band (|type| + 3 clipped as probaln_glocal clips it) is wider than the widest
+                                  * register-resident class: they ran in the rolling-row kernel (types of about 8 bp and more) */
 } bcfgpu_gap_stats;
 int  bcfgpu_gap_prep_stats(const bcfgpu_ctx *ctx, bcfgpu_gap_stats *out);
 

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from bcftools_amd import abi, synth
+from bcftools_amd.lib import check
 from tests.helpers import indeldrv, orc
 from tests.test_gpu_parity import EXACT_SITE, FLOAT_SITE
 
@@ -31,11 +32,66 @@ def test_batched_gap_prep_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth
     assert st.n_jobs > 0 and st.n_passes >= st.n_jobs and st.dp_cells > 0 and st.kernel_ms > 0
 
 
-@pytest.mark.parametrize("n_sites,n_smpl,depth,seed", [(24, 40, 15.0, 51), (10, 200, 25.0, 52)])
-def test_indel_records_match_oracle(gpu_ctx_factory, n_sites, n_smpl, depth, seed):
+LONG = (-40, -25, -12, -8, 8, 12, 25, 40)      # bands of 11..43: past PROBALN_BW_MAX, the rolling-row kernel
+SHORT = (-3, -2, -1, 1, 2, 3)                  # bands of 4..6: the register-resident classes
+
+
+@pytest.mark.parametrize("n_sites,n_smpl,depth,seed,lens,lens2,kw", [
+    (16, 12, 15.0, 101, LONG, SHORT, {}),                  # a long and a short type in the same column
+    (10, 40, 20.0, 102, LONG, None, {}),                   # one long type per column
+    (8, 6, 30.0, 103, (-40, 40, -25, 25), SHORT, dict(min_support=2)),
+    (12, 25, 12.0, 104, LONG, LONG, dict(per_sample_flt=1, min_frac=0.05)),   # two long types in a column
+    (6, 100, 30.0, 105, (-9, -8, 8, 9, 7, -7), SHORT, {}),  # the boundary: |type| = 7 is the widest register class
+])
+def test_long_indels_through_the_wide_band_kernel(gpu_ctx_factory, n_sites, n_smpl, depth, seed, lens, lens2, kw):
+    """Indels of 8 bp and more: bam2bcf_indel.c:293-294 gives their realignment the band |type| + 3, wider than the widest
+    register-resident class, so probaln_glocal (:346, :352) runs in probaln_wide_kernel -- for every read of the column,
+    against that type.  The same column's short types stay in the register classes.  Every output of bcf_call_gap_prep
+    (p->aux, types, inscns, indelreg, max_support, max_frac) against the oracle, through both entry points, on the product
+    build (no environment switch)."""
+    b = synth.indel_batch(seed, n_sites, n_smpl, depth=depth, lens=lens, lens2=lens2)
+    assert (np.abs(b["itype"]) >= 7).any()
+    ctx = gpu_ctx_factory(abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(b["p_read"]) + 64))
+    got, st = indeldrv.gap_prep_gpu(ctx, b, **kw)
+    live = long_seen = 0
+    for k in range(n_sites):
+        want = indeldrv.gap_prep_oracle_site(b, k, **kw)
+        indeldrv.assert_site_equal(got, k, want)
+        if want is not None:
+            live += 1
+            t = want["indel_types"]
+            long_seen += bool(((np.abs(t) >= 8) & (t != 10000)).any())
+    assert live > 0 and long_seen > 0
+    assert 0 < st.n_wide < st.n_jobs, (st.n_wide, st.n_jobs)      # wide-band jobs and register-class jobs in one call
+    assert st.n_passes >= st.n_jobs // 2 and st.dp_cells > 0
+    # the device-pool form: the same core fed from bcfgpu_pileup's pool
+    pool = indeldrv.DevicePool(ctx, b)
+    got_t, st_t, tile = pool.gap_prep_tile(want_aux=True, **kw)
+    np.testing.assert_array_equal(got_t["ret"], got["ret"])
+    ok = got["ret"] == 0          # (what bca holds after a call that returned -1 is not read by anyone: mpileup.c:354-364)
+    for key in ("indel_types", "inscns", "maxins", "indelreg", "max_support", "max_frac"):
+        np.testing.assert_array_equal(got_t[key][ok], got[key][ok], err_msg=key)
+    cell = np.repeat(np.arange(n_sites * n_smpl), np.diff(b["smpl_off"]))
+    dev2batch = pool.order[np.argsort(cell[pool.order], kind="stable")]
+    # a column the pooled support filter (bam2bcf_indel.c:150-154) turns away has no entries in the tile form: its ret is < 0
+    # and the entries of the other columns follow one another
+    off = np.zeros(n_sites * n_smpl + 1, np.uint32)
+    check(ctx.L.bcfgpu_memcpy_d2h(ctx.h, off.ctypes.data, tile.plp_off, off.nbytes))
+    n_col = np.diff(off[::n_smpl].astype(np.int64))
+    full = np.diff(b["smpl_off"][::n_smpl].astype(np.int64))
+    assert ((n_col == full) | ((n_col == 0) & (got["ret"] < 0))).all()
+    keep = np.repeat(n_col > 0, full)
+    assert tile.n_reads == int(keep.sum())
+    np.testing.assert_array_equal(got_t["aux"][:tile.n_reads], got["aux"][dev2batch][keep], err_msg="p->aux")
+    assert st_t.n_wide == st.n_wide
+
+
+@pytest.mark.parametrize("n_sites,n_smpl,depth,seed,bkw", [(24, 40, 15.0, 51, {}), (10, 200, 25.0, 52, {}),
+                                                           (12, 30, 20.0, 53, dict(lens=LONG, lens2=SHORT))])
+def test_indel_records_match_oracle(gpu_ctx_factory, n_sites, n_smpl, depth, seed, bkw):
     """The whole indel record path on synthetic columns: bcfgpu_gap_prep -> p->aux -> the indel pass of
     glfgen/combine (ref_base = -1), against the oracle running the same two steps."""
-    b = synth.indel_batch(seed, n_sites, n_smpl, depth=depth)
+    b = synth.indel_batch(seed, n_sites, n_smpl, depth=depth, **bkw)
     fmt = abi.INFO_VDB | abi.INFO_RPB | abi.FMT_AD
     gctx = gpu_ctx_factory(abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=64))
     got, _ = indeldrv.gap_prep_gpu(gctx, b)
