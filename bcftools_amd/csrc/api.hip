@@ -595,7 +595,6 @@ int bcfgpu_pipeline(bcfgpu_ctx *c, const bcfgpu_tile *tile, const uint8_t *ploid
         return set_err(BCFGPU_E_ARG, "bcfgpu_pipeline: bad arguments");
     int rc = check_tile(c, tile);
     if (rc) return rc;
-    if (tile->is_indel) return set_err(BCFGPU_E_ARG, "bcfgpu_pipeline: SNP tiles only (run indel tiles through bcfgpu_mpileup + bcfgpu_mcall)");
     if (tile->n_sites == 0) return 0;
     if (c->cfg.n_grp > 1 && (!grp || (c->cfg.grp_tag_is_qs ? !mout->qs : (!mout->adf || !mout->adr))))
         return set_err(BCFGPU_E_ARG, "bcfgpu_pipeline: -G needs grp and the AD (or QS) planes");

@@ -238,9 +238,14 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     if (P.msite) {
         nals = P.msite[is].n_alleles;
         unseen = P.msite[is].unseen > 0 ? P.msite[is].unseen : 0;     // vcfcall.c:1102-1111
+        if (P.msite[is].ret < 0) nals = -1;                           // mpileup wrote no record here (an indel column without an ALT allele, bam2bcf.c:611)
     } else { nals = P.nals[is]; unseen = P.unseen[is]; }
     // (one site per workgroup: the same in every lane -- said so, these decide scalar branches instead of lane masks)
     nals = __builtin_amdgcn_readfirstlane(nals); unseen = __builtin_amdgcn_readfirstlane(unseen);
+    if (P.msite && nals == -1) {                                      // nothing to call: the site's call record says "skipped", no error
+        if ((MAXA == 3 || (P.small_too && NSUB == 15)) && tid == 0) write_skipped(cs, 0);
+        return;
+    }
     const int ngts = nals * (nals + 1) / 2;
     // A record outside what the planes can hold (mcall() itself takes up to 32 alleles, mcall.c:1539; B2B_MAX_ALLELES = 5 is
     // what mpileup writes): refused record by record, ret = -2, and the call as a whole reports BCFGPU_E_RANGE at the next sync.
@@ -1088,7 +1093,7 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const size_t Ss = (size_t)S;
     const int ngrp = P.n_grp;
     int nals, unseen;
-    if (P.msite) { nals = P.msite[is].n_alleles; unseen = P.msite[is].unseen > 0 ? P.msite[is].unseen : 0; }
+    if (P.msite) { nals = P.msite[is].ret < 0 ? 0 : P.msite[is].n_alleles; unseen = P.msite[is].unseen > 0 ? P.msite[is].unseen : 0; }
     else { nals = P.nals[is]; unseen = P.unseen[is]; }
     const int ngts = nals * (nals + 1) / 2;
     // the records mcall_kernel refuses or never reaches (vcfcall.c:1112-1115) need no sums

@@ -28,6 +28,7 @@
 
 extern "C" int bcfgpu_internal_device(bcfgpu_ctx *ctx, hipStream_t *stream, const float **q2p);
 extern "C" void *bcfgpu_internal_ws(bcfgpu_ctx *ctx, int slot, size_t bytes);
+extern "C" void *bcfgpu_internal_pinned(bcfgpu_ctx *ctx, int slot, size_t bytes);
 extern "C" const bcfgpu_cfg *bcfgpu_internal_cfg(const bcfgpu_ctx *ctx);
 extern "C" void *bcfgpu_internal_pileup_state(bcfgpu_ctx *ctx);
 int bcfgpu_set_error(int code, const char *what);
@@ -281,17 +282,8 @@ struct EntriesParams {
 
 // bcf_call_gap_prep gives up on a column whose indel reads, pooled over the samples, are fewer than min_support or a smaller
 // share of the column's reads than min_frac (bam2bcf_indel.c:150-154, the default: no -p / per_sample_flt) -- in a large
-// cohort nearly every column has some read with an indel and nearly none passes.  Decided here from two numbers the pileup
-// left per column, before any of the column's entries is listed: a column that fails has no entries for the stage, and the
-// stage returns -1 for it as the reference does.
-__global__ __launch_bounds__(256) void gap_support_kernel(const PileupParams P, const int32_t *cols, int n_cols, int min_support, double min_frac, uint8_t *keep)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_cols) return;
-    const long c = cols[i];
-    const uint32_t n_alt = P.col_indel[c], n_tot = P.cnt[(c + 1) * P.n_smpl] - P.cnt[c * P.n_smpl];
-    keep[i] = (n_tot == 0 || (double)n_alt / n_tot < min_frac || (int)n_alt < min_support) ? 0 : 1;
-}
+// cohort nearly every column has some read with an indel and nearly none passes.  gap_keep_kernel (below) decides it from two
+// numbers the pileup left per column, before any of the column's entries is listed.
 
 // what the pileup says about read record m at reference position x (htslib resolve_cigar): query offset, indel after x
 __device__ __forceinline__ void entry_of_read(const ReadMeta &m, const uint32_t *cig, int x, int &qpos, int &indel)
@@ -382,6 +374,61 @@ __global__ __launch_bounds__(256) void subtile_kernel(const EntriesParams E, uin
     if (!FILL) { E.sel_cnt[i] = e - b; return; }
     uint32_t o = E.sel_cnt[i];
     for (uint32_t k = b; k < e; ++k, ++o) { rd_out[o] = P.rd[k]; ep_out[o] = P.epos[k]; }
+}
+
+// The candidate columns bcf_call_gap_prep goes on with: the pooled support filter above and the compaction of the columns that
+// pass it, in one workgroup (a tile has some ten thousand candidates; in a large cohort a hundredth of them passes).
+// kcols[j] = the column, kidx[j] = its place in `cols`; n_keep[0] = how many.  use_filter = 0 (per_sample_flt): every column.
+__global__ __launch_bounds__(1024) void gap_keep_kernel(const PileupParams P, const int32_t *cols, int n_cols, int use_filter, int min_support,
+                                                        double min_frac, int32_t *kcols, int32_t *kidx, int32_t *n_keep)
+{
+    __shared__ int s_wave[16], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n_cols; i0 += 1024) {
+        const int i = i0 + tid;
+        bool keep = false;
+        long c = 0;
+        if (i < n_cols) {
+            c = cols[i];
+            keep = true;
+            if (use_filter) {
+                const uint32_t n_alt = P.col_indel[c], n_tot = P.cnt[(c + 1) * P.n_smpl] - P.cnt[c * P.n_smpl];
+                keep = !(n_tot == 0 || (double)n_alt / n_tot < min_frac || (int)n_alt < min_support);
+            }
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (lane == 0) s_wave[wave] = (int)__popcll(m);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (keep) { const int at = before + (int)__popcll(m & ((1ull << lane) - 1)); kcols[at] = (int32_t)c; kidx[at] = i; }
+        __syncthreads();
+        if (tid == 0) { int t = s_base; for (int w = 0; w < 16; ++w) t += s_wave[w]; s_base = t; }
+        __syncthreads();
+    }
+    if (tid == 0) n_keep[0] = s_base;
+}
+
+// The indel pass's tile: the columns where bcf_call_gap_prep returned 0 (mpileup.c:354-360), picked from the columns the stage
+// ran on.  lk[j] = the place of tile column j among those columns, lcols[j] = its column of the pileup; ksel = the entry offsets
+// of the stage's columns.  COUNT: lsel[j*S + s] = entries of the cell (scanned by the caller); else a lane per cell copies the
+// cell's read records from the pileup and its p->aux words from the stage's entry-ordered array.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void live_tile_kernel(const PileupParams P, int n_live, const int32_t *lcols, const int32_t *lk, const uint32_t *ksel,
+                                                        uint32_t *lsel, const uint32_t *aux_in, uint32_t *rd_out, uint8_t *ep_out, uint32_t *aux_out)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)n_live * P.n_smpl) return;
+    const int j = (int)(i / P.n_smpl), s = (int)(i - (long)j * P.n_smpl);
+    const size_t kc = (size_t)lk[j] * P.n_smpl + s;
+    const uint32_t kb = ksel[kc], n = ksel[kc + 1] - kb;
+    if (COUNT) { lsel[i] = n; return; }
+    const long cell = (long)lcols[j] * P.n_smpl + s;
+    const uint32_t b = P.cnt[cell];
+    uint32_t o = lsel[i];
+    for (uint32_t k = 0; k < n; ++k, ++o) { rd_out[o] = P.rd[b + k]; ep_out[o] = P.epos[b + k]; aux_out[o] = aux_in[kb + k]; }
 }
 
 // One record per read (reference span, constants) from the caller's per-read arrays: a pass over the CIGARs, one lane per read
@@ -1041,7 +1088,7 @@ extern "C" bcfgpu_gap_stats *bcfgpu_internal_gap_stats(bcfgpu_ctx *ctx);
 extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols, const bcfgpu_reads *reads,
                                     const bcfgpu_indel_in *par, const bcfgpu_indel_out *out, int inscns_cap, bcfgpu_tile *tile)
 {
-    if (!ctx || n_cols < 0 || (n_cols && !cols) || !par || !par->ref || !out || !out->ret || !out->indel_types || !tile)
+    if (!ctx || n_cols < 0 || (n_cols && !cols) || !par || !par->ref || !out || !out->ret || !out->indel_types || !tile || inscns_cap < 0)
         return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep_tile: bad arguments");
     hipStream_t stream = nullptr;
     if (bcfgpu_internal_device(ctx, &stream, nullptr)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep_tile: bad context");
@@ -1050,6 +1097,7 @@ extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32
     const PileupParams &P = E.P;
     if (!P.cnt) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep_tile: no bcfgpu_pileup on this context yet");
     std::memset(tile, 0, sizeof *tile);
+    tile->is_indel = 1;
     bcfgpu_gap_stats &gs = *bcfgpu_internal_gap_stats(ctx);
     gs = bcfgpu_gap_stats{};
     if (n_cols == 0) return BCFGPU_OK;
@@ -1057,26 +1105,46 @@ extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32
     auto ms_since = [](std::chrono::steady_clock::time_point t0) {
         return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     const int S = P.n_smpl, nr = P.n_reads;
-    int cmin = INT32_MAX, cmax = 0;
-    for (int i = 0; i < n_cols; ++i) {
+    for (int i = 0; i < n_cols; ++i)
         if (cols[i] < 0 || cols[i] >= P.n_sites) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep_tile: column out of range");
-        cmin = std::min(cmin, cols[i]); cmax = std::max(cmax, cols[i]);
-    }
-    const size_t nsel = (size_t)n_cols * S;
+    // every column starts as "bcf_call_gap_prep returned -1": the columns the stage goes on with overwrite their rows below
+    for (int i = 0; i < n_cols; ++i) { out->ret[i] = -1; for (int t = 0; t < 4; ++t) out->indel_types[(size_t)i * 4 + t] = 10000; }
+    if (out->inscns) std::memset(out->inscns, 0, (size_t)n_cols * 4 * inscns_cap);
+    if (out->maxins) std::memset(out->maxins, 0, (size_t)n_cols * 4);
+    if (out->indelreg) std::memset(out->indelreg, 0, (size_t)n_cols * 4);
+    if (out->max_support) std::memset(out->max_support, 0, (size_t)n_cols * 4);
+    if (out->max_frac) std::memset(out->max_frac, 0, (size_t)n_cols * 4);
     #define GT_CHK(call) do { if ((call) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, #call); } while (0)
     #define GWS(slot, bytes) bcfgpu_internal_ws(ctx, 40 + (slot), (bytes) + 64)      /* the slots bcfgpu_gap_prep uses for its uploads */
-    // ---- the columns' pileup entries (read, query offset, indel after the position), on the device ----
-    int32_t *d_cols = (int32_t*)bcfgpu_internal_ws(ctx, 21, (size_t)n_cols * 5 + 64);     // the columns, then a byte per column (gap_support_kernel)
-    uint32_t *d_sel = (uint32_t*)bcfgpu_internal_ws(ctx, 25, (nsel + 1) * 4 + (size_t)n_cols + 64);
-    if (!d_cols || !d_sel) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
+    // ---- the columns the stage goes on with: those that pass the pooled support filter (bam2bcf_indel.c:150-154; every column with
+    // per_sample_flt), compacted on the device.  Nothing below touches a column that fails: no entry of it is listed, no workgroup
+    // of the stage is started for it. ----
+    int32_t *d_cols = (int32_t*)bcfgpu_internal_ws(ctx, 21, (size_t)n_cols * 12 + 64);     // cols, then the kept columns, then their places in cols
+    int32_t *d_nk = (int32_t*)bcfgpu_internal_ws(ctx, 143, 64);
+    int32_t *h_k = (int32_t*)bcfgpu_internal_pinned(ctx, 2, (size_t)n_cols * 4 + 64);    // [0] the count, [16..] the places
+    if (!d_cols || !d_nk || !h_k) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
+    int32_t *d_kcols = d_cols + n_cols, *d_kidx = d_cols + 2 * (size_t)n_cols;
     GT_CHK(hipMemcpyAsync(d_cols, cols, (size_t)n_cols * 4, hipMemcpyHostToDevice, stream));
-    GT_CHK(hipMemsetAsync(d_sel, 0, (nsel + 1) * 4 + (size_t)n_cols + 64, stream));
-    E.n_cols = n_cols; E.cols = d_cols; E.sel_cnt = d_sel; E.col_keep = nullptr;
-    if (!par->per_sample_flt && P.col_indel) {
-        uint8_t *d_keep = reinterpret_cast<uint8_t*>(d_cols + n_cols);
-        hipLaunchKernelGGL(gap_support_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, stream, P, d_cols, n_cols, par->min_support, par->min_frac, d_keep);
-        E.col_keep = d_keep;
-    }
+    hipLaunchKernelGGL(gap_keep_kernel, dim3(1), dim3(1024), 0, stream, P, d_cols, n_cols, (!par->per_sample_flt && P.col_indel) ? 1 : 0,
+                       par->min_support, par->min_frac, d_kcols, d_kidx, d_nk);
+    GT_CHK(hipMemcpyAsync(h_k, d_nk, 4, hipMemcpyDeviceToHost, stream));
+    GT_CHK(hipMemcpyAsync(h_k + 16, d_kidx, (size_t)n_cols * 4, hipMemcpyDeviceToHost, stream));
+    // meanwhile: the reads as bcfgpu_gap_prep's kernels index them
+    int32_t *d_rpos = (int32_t*)GWS(0, (size_t)nr * 4), *d_rlq = (int32_t*)GWS(1, (size_t)nr * 4), *d_rflag = (int32_t*)GWS(2, (size_t)nr * 4);
+    int32_t *d_rncig = (int32_t*)GWS(3, (size_t)nr * 4), *d_rcoff = (int32_t*)GWS(4, (size_t)nr * 4), *d_rsoff = (int32_t*)GWS(5, (size_t)nr * 4);
+    if (!d_rpos || !d_rlq || !d_rflag || !d_rncig || !d_rcoff || !d_rsoff) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
+    if (nr) hipLaunchKernelGGL(gap_unpack_reads_kernel, dim3((nr + 255) / 256), dim3(256), 0, stream, P, d_rpos, d_rlq, d_rflag, d_rncig, d_rcoff, d_rsoff);
+    GT_CHK(hipStreamSynchronize(stream));                       // how many columns go on
+    const int nk = h_k[0];
+    std::vector<int32_t> kidx(h_k + 16, h_k + 16 + nk);
+    gs.prepare_ms = ms_since(t_begin);
+    if (nk == 0) { gs.total_ms = ms_since(t_begin); return BCFGPU_OK; }
+    const size_t nsel = (size_t)nk * S;
+    // ---- their pileup entries (read, query offset, indel after the position), on the device ----
+    uint32_t *d_sel = (uint32_t*)bcfgpu_internal_ws(ctx, 25, (nsel + 1) * 4 + 64);
+    if (!d_sel) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
+    GT_CHK(hipMemsetAsync(d_sel, 0, (nsel + 1) * 4, stream));
+    E.n_cols = nk; E.cols = d_kcols; E.sel_cnt = d_sel; E.col_keep = nullptr;
     const int grid = (int)((nsel + 255) / 256);
     hipLaunchKernelGGL(entries_kernel<false>, dim3(grid), dim3(256), 0, stream, E);
     size_t tmp_bytes = 0;
@@ -1086,10 +1154,10 @@ extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32
     GT_CHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_sel, d_sel, (int)(nsel + 1), stream));
     uint32_t total = 0;
     GT_CHK(hipMemcpyAsync(&total, d_sel + nsel, 4, hipMemcpyDeviceToHost, stream));
-    // meanwhile: the reads as bcfgpu_gap_prep's kernels index them, the columns' positions, the reference slice, ZQ
-    int32_t *d_rpos = (int32_t*)GWS(0, (size_t)nr * 4), *d_rlq = (int32_t*)GWS(1, (size_t)nr * 4), *d_rflag = (int32_t*)GWS(2, (size_t)nr * 4);
-    int32_t *d_rncig = (int32_t*)GWS(3, (size_t)nr * 4), *d_rcoff = (int32_t*)GWS(4, (size_t)nr * 4), *d_rsoff = (int32_t*)GWS(5, (size_t)nr * 4);
-    int32_t *d_pos = (int32_t*)GWS(11, (size_t)n_cols * 4);
+    // meanwhile: the columns' positions, the reference slice, ZQ
+    int cmin = INT32_MAX, cmax = 0;
+    for (int j = 0; j < nk; ++j) { cmin = std::min(cmin, cols[kidx[j]]); cmax = std::max(cmax, cols[kidx[j]]); }
+    int32_t *d_pos = (int32_t*)GWS(11, (size_t)nk * 4);
     const int pmin = P.beg + cmin, pmax = P.beg + cmax;
     // The slice of the contig the batch touches.  The contig ends where bcfgpu_pileup was told it ends (ref_len): a candidate
     // column at or past that end reads nothing of par->ref (bcfgpu_indel_in carries no length of its own).
@@ -1104,11 +1172,9 @@ extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32
         const DevPool &D = *static_cast<const DevPool*>(bcfgpu_internal_pool_state(ctx));
         if (!any_zq && D.valid && D.zq && D.r_has_zq && D.n_reads == nr && D.seq16 == P.seq16) { d_zq = D.zq; d_haszq = D.r_has_zq; }
     }
-    if (!d_rpos || !d_rlq || !d_rflag || !d_rncig || !d_rcoff || !d_rsoff || !d_pos || !d_ref || (any_zq && (!d_zq || !d_haszq)))
-        return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
+    if (!d_pos || !d_ref || (any_zq && (!d_zq || !d_haszq))) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
     if (any_zq && reads->n_reads != nr) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_gap_prep_tile: `reads` is not the pool of the last bcfgpu_pileup");
-    if (nr) hipLaunchKernelGGL(gap_unpack_reads_kernel, dim3((nr + 255) / 256), dim3(256), 0, stream, P, d_rpos, d_rlq, d_rflag, d_rncig, d_rcoff, d_rsoff);
-    hipLaunchKernelGGL(gap_col_pos_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, stream, d_cols, n_cols, P.beg, d_pos);
+    hipLaunchKernelGGL(gap_col_pos_kernel, dim3((nk + 255) / 256), dim3(256), 0, stream, d_kcols, nk, P.beg, d_pos);
     if (ref_hi > ref_lo) GT_CHK(hipMemcpyAsync(d_ref, par->ref + ref_lo, (size_t)(ref_hi - ref_lo), hipMemcpyHostToDevice, stream));
     if (any_zq) {
         GT_CHK(hipMemcpyAsync(d_zq, reads->zq, (size_t)P.n_bases, hipMemcpyHostToDevice, stream));
@@ -1117,19 +1183,13 @@ extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32
     GT_CHK(hipStreamSynchronize(stream));                       // the entry count sizes everything that follows
     if ((total >> 31) != 0) return bcfgpu_set_error(BCFGPU_E_RANGE, "bcfgpu_gap_prep_tile: too many pileup entries in one call, use fewer columns");
     int32_t *d_e = (int32_t*)bcfgpu_internal_ws(ctx, 24, (size_t)total * 12 + 16);
-    const size_t ep_at = (((size_t)total + 4) * 4 + 255) & ~(size_t)255;
-    uint8_t *d_out = (uint8_t*)bcfgpu_internal_ws(ctx, 26, ep_at + (size_t)total + 64);
     uint32_t *d_aux = (uint32_t*)GWS(27, ((size_t)total + 4) * 4);
-    if (!d_e || !d_out || !d_aux) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
+    if (!d_e || !d_aux) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
     E.e_read = d_e; E.e_qpos = d_e + total; E.e_indel = d_e + 2 * (size_t)total;
-    if (total) {
-        hipLaunchKernelGGL(entries_kernel<true>, dim3((unsigned)((nsel + 3) / 4)), dim3(256), 0, stream, E);
-        // the indel pass's tile: the same entries' read records, p->aux to come from the stage below
-        hipLaunchKernelGGL(subtile_kernel<true>, dim3(grid), dim3(256), 0, stream, E, (uint32_t*)d_out, d_out + ep_at);
-    }
+    if (total) hipLaunchKernelGGL(entries_kernel<true>, dim3((unsigned)((nsel + 3) / 4)), dim3(256), 0, stream, E);
     GT_CHK(hipGetLastError());
     GapIn g{};
-    g.n_sites = n_cols; g.n_smpl = S; g.n_reads = nr;
+    g.n_sites = nk; g.n_smpl = S; g.n_reads = nr;
     g.pos = d_pos; g.smpl_off = reinterpret_cast<const int32_t*>(d_sel); g.p_read = E.e_read; g.p_qpos = E.e_qpos; g.p_indel = E.e_indel;
     g.r_pos = d_rpos; g.r_lq = d_rlq; g.r_flag = d_rflag; g.r_ncig = d_rncig; g.r_cig_off = d_rcoff; g.r_seq_off = d_rsoff;
     g.cig = P.cig; g.seq16 = P.seq16; g.qual = P.qual; g.zq = d_zq; g.r_has_zq = d_haszq;
@@ -1137,17 +1197,62 @@ extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32
     g.openQ = par->openQ; g.extQ = par->extQ; g.tandemQ = par->tandemQ; g.min_support = par->min_support; g.per_sample_flt = par->per_sample_flt;
     g.min_frac = par->min_frac;
     gs.prepare_ms = ms_since(t_begin);
-    const int rc = bcfgpu_internal_gap_core(ctx, g, (size_t)total, d_aux, out, inscns_cap);
+    // the stage's per-column results, by kept column; scattered to the caller's rows afterwards
+    std::vector<int32_t> k_ret(nk), k_types((size_t)nk * 4), k_maxins(nk), k_ireg(nk), k_msup(nk);
+    std::vector<float> k_mfrac(nk);
+    std::vector<int8_t> k_inscns(out->inscns ? (size_t)nk * 4 * inscns_cap : 0);
+    bcfgpu_indel_out ko{};
+    ko.ret = k_ret.data(); ko.indel_types = k_types.data(); ko.maxins = k_maxins.data(); ko.indelreg = k_ireg.data();
+    ko.max_support = k_msup.data(); ko.max_frac = k_mfrac.data(); ko.inscns = out->inscns ? k_inscns.data() : nullptr;
+    const int rc = bcfgpu_internal_gap_core(ctx, g, (size_t)total, d_aux, &ko, inscns_cap);
     if (rc) return rc;
-    if (out->p_aux && total) {                                  // optional: the entries' words for the caller as well
-        GT_CHK(hipMemcpyAsync(out->p_aux, d_aux, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+    std::vector<int32_t> lk, lcols;
+    for (int j = 0; j < nk; ++j) {
+        const size_t i = (size_t)kidx[j];
+        out->ret[i] = k_ret[j];
+        std::memcpy(out->indel_types + i * 4, &k_types[(size_t)j * 4], 16);
+        if (out->inscns && inscns_cap) std::memcpy(out->inscns + i * 4 * inscns_cap, &k_inscns[(size_t)j * 4 * inscns_cap], (size_t)4 * inscns_cap);
+        if (out->maxins) out->maxins[i] = k_maxins[j];
+        if (out->indelreg) out->indelreg[i] = k_ireg[j];
+        if (out->max_support) out->max_support[i] = k_msup[j];
+        if (out->max_frac) out->max_frac[i] = k_mfrac[j];
+        if (k_ret[j] == 0) { lk.push_back(j); lcols.push_back(cols[i]); }
+    }
+    // ---- the indel pass's tile: the columns with ret == 0 (mpileup.c:354-360), their records from the pileup, p->aux from the stage ----
+    const int nl = (int)lk.size();
+    if (nl == 0) { gs.total_ms = ms_since(t_begin); return BCFGPU_OK; }
+    const size_t nlsel = (size_t)nl * S;
+    int32_t *d_l = (int32_t*)bcfgpu_internal_ws(ctx, 144, (size_t)nl * 8 + 64);
+    uint32_t *d_lsel = (uint32_t*)bcfgpu_internal_ws(ctx, 145, (nlsel + 1) * 4 + (size_t)nl + 64);
+    if (!d_l || !d_lsel) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
+    GT_CHK(hipMemcpyAsync(d_l, lk.data(), (size_t)nl * 4, hipMemcpyHostToDevice, stream));
+    GT_CHK(hipMemcpyAsync(d_l + nl, lcols.data(), (size_t)nl * 4, hipMemcpyHostToDevice, stream));
+    GT_CHK(hipMemsetAsync(d_lsel, 0, (nlsel + 1) * 4 + (size_t)nl + 64, stream));
+    const int lgrid = (int)((nlsel + 255) / 256);
+    hipLaunchKernelGGL(live_tile_kernel<true>, dim3(lgrid), dim3(256), 0, stream, P, nl, d_l + nl, d_l, d_sel, d_lsel,
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint8_t*)nullptr, (uint32_t*)nullptr);
+    GT_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_lsel, d_lsel, (int)(nlsel + 1), stream));
+    d_tmp = bcfgpu_internal_ws(ctx, 23, tmp_bytes + 16);
+    if (!d_tmp) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
+    GT_CHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_lsel, d_lsel, (int)(nlsel + 1), stream));
+    uint32_t ltotal = 0;
+    GT_CHK(hipMemcpyAsync(&ltotal, d_lsel + nlsel, 4, hipMemcpyDeviceToHost, stream));
+    GT_CHK(hipStreamSynchronize(stream));                       // (lk / lcols are this call's host vectors)
+    const size_t ep_at = (((size_t)ltotal + 4) * 4 + 255) & ~(size_t)255, aux_at = (ep_at + ltotal + 64 + 255) & ~(size_t)255;
+    uint8_t *d_out = (uint8_t*)bcfgpu_internal_ws(ctx, 26, aux_at + ((size_t)ltotal + 4) * 4);
+    if (!d_out) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
+    if (ltotal) hipLaunchKernelGGL(live_tile_kernel<false>, dim3(lgrid), dim3(256), 0, stream, P, nl, d_l + nl, d_l, d_sel, d_lsel,
+                                   (const uint32_t*)d_aux, (uint32_t*)d_out, d_out + ep_at, (uint32_t*)(d_out + aux_at));
+    GT_CHK(hipGetLastError());
+    if (out->p_aux && ltotal) {                                 // optional: the tile's p->aux words for the caller as well
+        GT_CHK(hipMemcpyAsync(out->p_aux, d_out + aux_at, (size_t)ltotal * 4, hipMemcpyDeviceToHost, stream));
         GT_CHK(hipStreamSynchronize(stream));
     }
     gs.total_ms = ms_since(t_begin);
     #undef GT_CHK
     #undef GWS
-    tile->n_sites = n_cols; tile->is_indel = 1; tile->n_reads = total;
-    tile->ref16 = reinterpret_cast<const int8_t*>(d_sel + nsel + 1);       // (zeros: the indel pass does not read it)
-    tile->plp_off = d_sel; tile->rd = (const uint32_t*)d_out; tile->epos = d_out + ep_at; tile->aux = d_aux;
+    tile->n_sites = nl; tile->is_indel = 1; tile->n_reads = ltotal;
+    tile->ref16 = reinterpret_cast<const int8_t*>(d_lsel + nlsel + 1);     // (zeros: the indel pass does not read it)
+    tile->plp_off = d_lsel; tile->rd = (const uint32_t*)d_out; tile->epos = d_out + ep_at; tile->aux = (const uint32_t*)(d_out + aux_at);
     return BCFGPU_OK;
 }

@@ -47,6 +47,7 @@ def parse():
                                                           "the indel stage (configs[2] shape) in child processes and embed their results under \"extra\" (0: skip)")
     ap.add_argument("--indel-read-rate", type=float, default=0.005, help="wgs mode: fraction of reads that carry a noise indel (SURVEY 8d: 0.5 %%)")
     ap.add_argument("--true-indel-rate", type=float, default=0.01, help="wgs mode: true indel sites per column")
+    ap.add_argument("--long-indel-frac", type=float, default=0.05, help="wgs mode: fraction of the indels (noise and true) that are 8-40 bases long")
     ap.add_argument("--indel-callers", type=int, default=1, help="indel mode: also time the host-pointer form of the stage on one 32-column batch (0: skip)")
     ap.add_argument("--mode", choices=["snp", "indel", "baq", "pileup", "gvcf", "mixed", "wgs"], default="snp",
                     help="snp: the headline pipeline (default).  indel: bcf_call_gap_prep on synthetic indel-candidate columns "
@@ -118,8 +119,8 @@ def main_indel(a):
         tmg = ctx.last_timing()
         tot["pass_glfgen"] += tmg["glfgen_ms"]; tot["pass_combine"] += tmg["combine_ms"]
     ctx._download(ob, res)
-    live = got["ret"] == 0
-    records = int(((res.site["ret"] == 0) & live).sum())
+    n_live = int((got["ret"] == 0).sum())                      # the tile holds the columns with ret == 0, in order
+    records = int((res.site["ret"][:n_live] == 0).sum())
     per = lambda k: tot[k] / steps
     cells_per_s = tot["cells"] / (tot["kernel"] * 1e-3)
     out = {"metric": "indel-candidate columns/sec through bcf_call_gap_prep (typing, consensus, realignment, indelQ: all device kernels), %d samples x %.0fx" % (S, a.depth),
@@ -138,7 +139,7 @@ def main_indel(a):
                                    "(contraction would change the integer scores): the mul/add-only peak is half the 78.6 TFLOP/s vector FMA peak"},
            "host_ms": {"prepare": per("prepare"), "finalize": per("finalize"), "whole_call": per("wall") * 1e3, "library_total": per("total")},
            "indel_pass": {"records": records, "glfgen_indel_ms": per("pass_glfgen"), "combine_ms": per("pass_combine"),
-                          "note": "glfgen_kernel<INDEL> + combine_kernel on the tile gap_prep_tile left in HBM (all candidate columns), kernel times"}}
+                          "note": "glfgen_kernel<INDEL> + combine_kernel on the tile gap_prep_tile left in HBM (the columns with ret == 0), kernel times"}}
     # the host-pointer form of the same stage (every array over PCIe both ways), for comparison: 32-column batches
     if a.indel_callers > 0:
         hb = synth.indel_batch(a.seed, min(32, n_sites), S, depth=a.depth)
@@ -154,9 +155,10 @@ def main_indel(a):
         # the oracle on one host core, first columns; results compared with the device path (entries matched through the pool order)
         cell = np.repeat(np.arange(n_sites * S), np.diff(b["smpl_off"]))
         dev2batch = pool.order[np.argsort(cell[pool.order], kind="stable")]
-        gaux, _, _ = pool.gap_prep_tile(want_aux=True)
+        gaux, _, gt = pool.gap_prep_tile(want_aux=True)
+        keep = np.repeat(np.repeat(gaux["ret"] == 0, S), np.diff(b["smpl_off"]))      # the tile's entries: the columns with ret == 0
         aux_batch = np.zeros(E, np.uint32)
-        aux_batch[dev2batch] = gaux["aux"]
+        aux_batch[dev2batch[keep]] = gaux["aux"][:gt.n_reads]
         chk = dict(got, aux=aux_batch)
         t0 = time.perf_counter()
         k = 0
@@ -228,7 +230,7 @@ def main_mixed(a):
     nb_, nr_ = C.c_uint64(), C.c_uint32()
     check(L.bcfgpu_compact_counts(ctx.h, counts.data_ptr(), C.byref(nb_), C.byref(nr_)))
     ctx._download(imb, ires)
-    live = got["ret"] == 0
+    n_live = int((got["ret"] == 0).sum())                      # the indel tile holds the columns with ret == 0, in order
     per_step = (t1 - t0) / steps
     out = {"metric": "pileup columns/sec with their indel records (mpileup | call -m, 10 %% indel sites), %d samples x %.0fx" % (S, a.depth),
            "value": T / per_step, "unit": "sites/s", "n_gpus": 1, "steps": steps, "ms_per_step": per_step * 1e3, "higher_is_better": True,
@@ -236,7 +238,7 @@ def main_mixed(a):
            "config": {"workload": "BASELINE configs[2] shape scaled to one step: SNP path over %d columns + bcf_call_gap_prep and the indel pass over %d "
                                   "candidate columns, inputs resident in HBM" % (T, n_ind),
                       "samples": S, "depth": a.depth, "snp_columns": T, "indel_columns": n_ind, "snp_reads": R, "indel_pileup_entries": E,
-                      "variant_records": int(nr_.value), "indel_records": int(((ires.site["ret"] == 0) & live).sum())},
+                      "variant_records": int(nr_.value), "indel_records": int((ires.site["ret"][:n_live] == 0).sum())},
            "split_ms": {"gap_prep_realignment_kernels": kern / steps, "gap_prep_host_prepare": prep / steps},
            "note": "the indel path is the Amdahl term: %d candidate columns cost far more than %d SNP columns" % (n_ind, T)}
     if a.cpu_seconds > 0:
@@ -279,7 +281,7 @@ def main_wgs(a):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     S = a.samples
-    n_sites = 1024 if a.sites is None else a.sites
+    n_sites = 16384 if a.sites is None else a.sites            # host/bcfgpu_sam's default tile (--tile)
     L, beg = 100, 300
     end = beg + n_sites
     rng = np.random.default_rng(a.seed)
@@ -289,22 +291,30 @@ def main_wgs(a):
     smpl = np.repeat(np.arange(S, dtype=np.int32), per)
     ref_codes = rng.integers(0, 4, end + 3 * L).astype(np.uint8)
     refseq = "".join("ACGT"[i] for i in ref_codes)
-    # ---- indels: noise on a fraction of the reads (length 1..3, weights 1/len, insertion or deletion, anywhere 10 bases off the
-    # ends), and true indel sites (allele frequency 0.1, genotypes HWE) carried by the reads that span them ----
+    # ---- indels: noise on a fraction of the reads (anywhere 10 bases off the ends; length 1..3 with weights 1/len, or -- one in
+    # twenty -- 8..40 bases, the lengths whose realignment band |type| + 3 is past the register-resident classes), and true indel
+    # sites (allele frequency 0.1, genotypes HWE, the same mix of lengths) carried by the reads that span them ----
     lens = np.array([1, 2, 3]); w = 1.0 / lens
+    long_lens = np.array([8, 12, 25, 40])
+
+    def draw_lens(k):
+        v = lens[rng.choice(3, k, p=w / w.sum())]
+        lg = rng.random(k) < a.long_indel_frac
+        v[lg] = long_lens[rng.integers(0, len(long_lens), int(lg.sum()))]
+        return v * rng.choice([-1, 1], k)
     ilen = np.zeros(n, np.int64)                                   # > 0 insertion, < 0 deletion
     ioff = np.zeros(n, np.int64)                                   # query bases before the indel
     noisy = rng.random(n) < a.indel_read_rate
-    ilen[noisy] = lens[rng.choice(3, int(noisy.sum()), p=w / w.sum())] * rng.choice([-1, 1], int(noisy.sum()))
-    ioff[noisy] = rng.integers(10, L - 10, int(noisy.sum()))
+    ilen[noisy] = draw_lens(int(noisy.sum()))
+    ioff[noisy] = rng.integers(10, L - 10 - np.maximum(ilen[noisy], 0))
     n_true = int(n_sites * a.true_indel_rate + 0.5)
     if n_true:
         tsite = np.sort(rng.choice(np.arange(beg + 20, end - 20), n_true, replace=False)).astype(np.int64)
-        tlen = lens[rng.choice(3, n_true, p=w / w.sum())] * rng.choice([-1, 1], n_true)
+        tlen = draw_lens(n_true)
         geno = rng.binomial(2, 0.1, (S, n_true))
         k = np.searchsorted(tsite, pos.astype(np.int64) + 10)
         kk = np.minimum(k, n_true - 1)
-        span = (k < n_true) & (tsite[kk] < pos.astype(np.int64) + L - 10)
+        span = (k < n_true) & (tsite[kk] < pos.astype(np.int64) + L - 10 - np.maximum(tlen[kk], 0))
         carry = span & (rng.random(n) < geno[smpl, kk] * 0.5)
         ilen[carry] = tlen[kk[carry]]
         ioff[carry] = tsite[kk[carry]] - pos[carry] + 1             # the indel follows reference position tsite
@@ -315,21 +325,34 @@ def main_wgs(a):
     c3[ilen == 0, 0] = L << 4
     cig = c3[np.arange(3)[None, :] < ncig[:, None]].astype(np.uint32)
     cig_off = np.concatenate([[0], np.cumsum(ncig)[:-1]]).astype(np.int32)
-    seq = np.empty(n * L, np.uint8)
-    qual = rng.choice(np.array([11, 25, 37, 40], np.uint8), n * L, p=[0.07, 0.08, 0.35, 0.5])
-    j = np.arange(L, dtype=np.int64)[None, :]
-    for r0 in range(0, n, 1 << 16):
-        r1 = min(n, r0 + (1 << 16))
-        il, io = ilen[r0:r1, None], ioff[r0:r1, None]
+    # the bases and qualities (n x L bytes each: half a gigabyte at the default size) are drawn on the device, in chunks of reads
+    dev = torch.device("cuda", 0)
+    tg = torch.Generator(device=dev)
+    tg.manual_seed(int(a.seed))
+    ref_t = torch.from_numpy(ref_codes.astype(np.int64)).to(dev)
+    seq_t = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    qual_t = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    q_vals = torch.tensor([11, 25, 37, 40], dtype=torch.uint8, device=dev)
+    q_cdf = torch.tensor([0.07, 0.15, 0.50], device=dev)
+    j = torch.arange(L, dtype=torch.int64, device=dev)[None, :]
+    CH = 1 << 19
+    for r0 in range(0, n, CH):
+        r1 = min(n, r0 + CH)
+        il = torch.from_numpy(ilen[r0:r1]).to(dev)[:, None]
+        io = torch.from_numpy(ioff[r0:r1]).to(dev)[:, None]
+        p0 = torch.from_numpy(pos[r0:r1].astype(np.int64)).to(dev).clamp_(min=0)[:, None]
         after = j >= io
-        shift = np.where(il < 0, -il, -np.minimum(il, np.maximum(j - io, 0)))
-        idx = np.maximum(pos[r0:r1, None].astype(np.int64), 0) + j + np.where(after, shift, 0)
-        b = ref_codes[idx]
+        shift = torch.where(il < 0, -il, -torch.minimum(il, (j - io).clamp(min=0)))
+        b = ref_t[p0 + j + torch.where(after, shift, torch.zeros_like(shift))]
         is_ins = after & (il > 0) & (j - io < il)
-        b = np.where(is_ins, rng.integers(0, 4, b.shape), b)
-        err = rng.random(b.shape) < 0.003
-        b = np.where(err, (b + rng.integers(1, 4, b.shape)) & 3, b)
-        seq[r0 * L:r1 * L] = (1 << b).astype(np.uint8).ravel()
+        b = torch.where(is_ins, torch.randint(0, 4, b.shape, generator=tg, device=dev), b)
+        err = torch.rand(b.shape, generator=tg, device=dev) < 0.003
+        b = torch.where(err, (b + torch.randint(1, 4, b.shape, generator=tg, device=dev)) & 3, b)
+        seq_t[r0 * L:r1 * L] = (1 << b).to(torch.uint8).reshape(-1)
+        qual_t[r0 * L:r1 * L] = q_vals[torch.bucketize(torch.rand((r1 - r0) * L, generator=tg, device=dev), q_cdf)]
+    seq, qual = seq_t.cpu().numpy(), qual_t.cpu().numpy()
+    del seq_t, qual_t, ref_t
+    torch.cuda.empty_cache()
     mapq = np.where(rng.random(n) < 0.92, 60, rng.integers(0, 60, n)).astype(np.uint8)
     arrs = dict(r_pos=pos, r_lq=np.full(n, L, np.int32), r_flag=(rng.integers(0, 2, n) * 16).astype(np.int32), r_ncig=ncig, r_cig_off=cig_off,
                 r_seq_off=(np.arange(n, dtype=np.int64) * L).astype(np.int32), cig=cig, seq16=seq, qual=qual, zq=np.zeros(1, np.uint8),
@@ -367,10 +390,11 @@ def main_wgs(a):
     nc = len(cand)
     mo, mbufs, _ = ctx.alloc_mplp_out(n_sites, ctx.flagged_planes())
     co, cbufs, _ = ctx.alloc_call_out(n_sites, abi.MAX_PL)
-    imo, imb, ires = ctx.alloc_mplp_out(max(nc, 1), ctx.flagged_planes())
     rec_cap = 256 << 20
     recbuf = torch.empty(rec_cap, dtype=torch.uint8, device="cuda")
+    irecbuf = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     counts = torch.zeros(4, dtype=torch.int64, device="cuda")
+    icounts = torch.zeros(4, dtype=torch.int64, device="cuda")
     par = abi.IndelIn()
     par.ref = ref_b
     for k_, v in indeldrv.DEFAULTS.items():
@@ -386,6 +410,13 @@ def main_wgs(a):
     itile = abi.Tile()
     st = abi.GapStats()
     split = dict(snp=0.0, gap=0.0, ipass=0.0)
+    # the indel pass's outputs hold the columns bcf_call_gap_prep accepts (the indel tile's sites): counted by a first call
+    n_acc = 1
+    if nc:
+        check(Lb.bcfgpu_gap_prep_tile(ctx.h, nc, cand.ctypes.data, None, C.byref(par), C.byref(oo), CAP, C.byref(itile)))
+        n_acc = max(1, int(itile.n_sites))
+    imo, imb, ires = ctx.alloc_mplp_out(n_acc, ctx.flagged_planes())
+    ico, icb, icres = ctx.alloc_call_out(n_acc, abi.MAX_PL)
 
     def step(timed=False):
         t0 = time.perf_counter()
@@ -399,7 +430,11 @@ def main_wgs(a):
             if timed:
                 ctx.sync()
             t2 = time.perf_counter()
-            check(Lb.bcfgpu_mpileup(ctx.h, C.byref(itile), C.byref(imo)))
+            if itile.n_sites:
+                # the indel records through call -m as well (mpileup.c:357-364 -> vcfcall.c:1137), the variant ones compacted
+                assert itile.n_sites <= n_acc
+                check(Lb.bcfgpu_pipeline(ctx.h, C.byref(itile), None, None, C.byref(imo), C.byref(ico)))
+                check(Lb.bcfgpu_compact_calls_async(ctx.h, itile.n_sites, 0, imo.site, C.byref(ico), abi.MAX_PL, 2, irecbuf.data_ptr(), 64 << 20, icounts.data_ptr()))
         else:
             t2 = t1
         if timed:
@@ -419,10 +454,14 @@ def main_wgs(a):
     check(Lb.bcfgpu_gap_prep_stats(ctx.h, C.byref(st)))
     nb_, nr_ = C.c_uint64(), C.c_uint32()
     check(Lb.bcfgpu_compact_counts(ctx.h, counts.data_ptr(), C.byref(nb_), C.byref(nr_)))
+    inb_, inr_ = C.c_uint64(), C.c_uint32()
+    if nc and itile.n_sites:
+        check(Lb.bcfgpu_compact_counts(ctx.h, icounts.data_ptr(), C.byref(inb_), C.byref(inr_)))
     n_live = int((gout["ret"][:nc] == 0).sum()) if nc else 0
+    assert n_live == (int(itile.n_sites) if nc else 0)
     if nc:
         ctx._download(imb, ires)
-    n_irec = int(((ires.site["ret"][:nc] == 0) & (gout["ret"][:nc] == 0)).sum()) if nc else 0
+    n_irec = int((ires.site["ret"][:n_live] == 0).sum()) if nc else 0      # (the indel tile holds the columns with ret == 0, in order)
     out = {"metric": "pileup columns/sec with their indel records (mpileup | call -m), %d samples x %.0fx of reads with indel noise" % (S, a.depth),
            "value": n_sites / per_step, "unit": "sites/s", "n_gpus": 1, "steps": steps, "ms_per_step": per_step * 1e3, "higher_is_better": True,
            "dtype": "u8/i32 + f64 likelihood sums; f64 pair-HMM", "data": "synthetic",
@@ -430,10 +469,18 @@ def main_wgs(a):
                                   "indel read + realignment of the columns that pass -m 1 -F 0.002 + the indel pass; read pool and columns resident in HBM",
                       "samples": S, "depth": a.depth, "columns": n_sites, "reads": n, "read_length": L, "pileup_entries": entries,
                       "indel_read_rate": a.indel_read_rate, "true_indel_sites": n_true, "baq": bool(a.baq),
+                      "long_indel_frac": a.long_indel_frac,
                       "candidate_columns": nc, "realigned_columns": n_live, "indel_records": n_irec, "variant_records": int(nr_.value),
-                      "realignment_jobs": int(st.n_jobs), "realignment_passes": int(st.n_passes)},
-           "split_ms": {"snp_pipeline_and_compaction": split["snp"] / 2 * 1e3, "gap_prep_tile": split["gap"] / 2 * 1e3, "indel_pass": split["ipass"] / 2 * 1e3,
+                      "indel_variant_records": int(inr_.value),
+                      "realignment_jobs": int(st.n_jobs), "realignment_wide_band_jobs": int(st.n_wide), "realignment_passes": int(st.n_passes)},
+           "split_ms": {"snp_pipeline_and_compaction": split["snp"] / 2 * 1e3, "gap_prep_tile": split["gap"] / 2 * 1e3, "indel_pass_and_call": split["ipass"] / 2 * 1e3,
                         "realignment_kernels": float(st.kernel_ms)},
+           "us_per_column": {"snp_pipeline_and_compaction": split["snp"] / 2 * 1e6 / n_sites, "gap_prep_tile": split["gap"] / 2 * 1e6 / n_sites,
+                             "indel_pass_and_call": split["ipass"] / 2 * 1e6 / n_sites, "pool_upload_pcie": f_up * 1e3 / n_sites,
+                             "pool_baq": f_baq * 1e3 / n_sites, "pool_pileup": f_plp * 1e3 / n_sites},
+           "realignment": {"dp_cells": int(st.dp_cells), "kernel_ms": float(st.kernel_ms),
+                           "fp64_frac_of_mul_add_peak": (float(st.dp_cells) * 6.0 / (float(st.kernel_ms) * 1e-3) / 39.3e12) if st.kernel_ms > 0 else None,
+                           "note": "18 fp64 multiplies/adds per band position (3 cells), no FMA: peak 39.3 TFLOP/s; kernel_ms covers job decode, sort and all band classes"},
            "front_ms": {"pool_upload_pcie": f_up, "pool_baq": f_baq, "pool_pileup": f_plp,
                         "note": "once per region, before the timed steps (the steps start from columns resident in HBM, like the headline)"},
            "with_front": {"sites_per_s": n_sites / (per_step + (f_up + f_baq + f_plp) * 1e-3), "note": "columns / (step + upload + BAQ + pileup): a region from host reads to records"},

@@ -991,7 +991,7 @@ static void emit_tile(emit_job_t *J)
         print_record(contig, t0 + k + 1, als, "", c, &snp_planes, (size_t)k, S);
         }
         while (jl < nlive && cand[live[jl]] < k) ++jl;
-        if (jl < nlive && cand[live[jl]] == k && isite[live[jl]].ret == 0) {
+        if (jl < nlive && cand[live[jl]] == k && isite[jl].ret == 0) {      /* (site jl of the indel tile = the jl-th candidate with ret == 0) */
             /* REF / ALT of an indel record (bam2bcf.c:767-790) */
             pending_flush();
             const int i = live[jl], p = t0 + k, ireg = g_indelreg[i], mi = g_maxins[i];
@@ -999,8 +999,8 @@ static void emit_tile(emit_job_t *J)
             int t = 0;
             for (int j = 0; j <= ireg; ++j) txt[t++] = ref[p + j];
             txt[t++] = '\t';
-            for (int a = 1; a < 4 && isite[i].a[a] >= 0; ++a) {
-                const int ai = isite[i].a[a], ty = g_types[i * 4 + ai];
+            for (int a = 1; a < 4 && isite[jl].a[a] >= 0; ++a) {
+                const int ai = isite[jl].a[a], ty = g_types[i * 4 + ai];
                 if (a > 1) txt[t++] = ',';
                 txt[t++] = ref[p];
                 if (ty < 0) { for (int j = p + 1 - ty; j < p + 1 + ireg; ++j) txt[t++] = ref[j]; }
@@ -1011,7 +1011,7 @@ static void emit_tile(emit_job_t *J)
             }
             txt[t] = 0;
             snprintf(prefix, sizeof prefix, "INDEL;IDV=%d;IMF=%g;", g_support[i], (double)g_frac[i]);
-            print_record(contig, p + 1, txt, prefix, &isite[i], &ind_planes, (size_t)i, S);
+            print_record(contig, p + 1, txt, prefix, &isite[jl], &ind_planes, (size_t)jl, S);
             free(txt);
         }
     }
@@ -1141,8 +1141,9 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
     int32_t *gret = NULL;
     bcfgpu_tile ti; memset(&ti, 0, sizeof ti);
     if (nc) {
-        /* everything stays in HBM: the candidates' entries, the stage on the pool bcfgpu_pileup left there, p->aux straight
-         * into the indel pass's tile over all candidate columns (the host pool is passed for its ZQ bytes) */
+        /* everything stays in HBM: the entries of the candidates that pass the pooled support filter, the stage on the pool
+         * bcfgpu_pileup left there, p->aux straight into the indel pass's tile -- the candidates with ret == 0, in order (the host
+         * pool is passed for its ZQ bytes) */
         bcfgpu_indel_in in; memset(&in, 0, sizeof in);
         in.n_sites = nc; in.n_smpl = S; in.ref = ref;
         in.openQ = openQ; in.extQ = extQ; in.tandemQ = tandemQ; in.min_support = min_support; in.per_sample_flt = per_sample_flt; in.min_frac = min_frac;
@@ -1157,13 +1158,18 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
         live = malloc((size_t)nc * 4);
         for (int i = 0; i < nc; ++i) if (gret[i] == 0) live[nlive++] = i;
     }
-    CHECK(bcfgpu_errmod_plan(ctx, &tile, nlive ? &ti : NULL, cand, gret));
-    /* ---- the SNP pass, then the indel pass on the tile gap_prep left (records of columns with ret < 0 are not used) ---- */
+    {
+        int32_t *live_col = malloc((size_t)(nlive + 1) * 4);                 /* the SNP-tile column of every site of the indel tile */
+        for (int j = 0; j < nlive; ++j) live_col[j] = cand[live[j]];
+        CHECK(bcfgpu_errmod_plan(ctx, &tile, nlive ? &ti : NULL, live_col, NULL));
+        free(live_col);
+    }
+    /* ---- the SNP pass, then the indel pass on the tile gap_prep left (the columns where it returned 0, mpileup.c:354-360) ---- */
     void *d_site = NULL, *d_pl = NULL, *d_dp4 = NULL;
     bcfgpu_site *site = NULL;
     planes_t snp_planes;
     run_mpileup(ctx, &tile, n_sites, &site, &snp_planes, gv_n ? &d_site : NULL, &d_pl, &d_dp4);
-    if (nlive) run_mpileup(ctx, &ti, nc, &isite, &ind_planes, NULL, NULL, NULL);
+    if (nlive) run_mpileup(ctx, &ti, nlive, &isite, &ind_planes, NULL, NULL, NULL);
     free(gret);
 
     /* ---- --gvcf: reference-only records collapse into blocks (gvcf_write, gvcf.c:88-226) on the planes still in HBM ---- */
@@ -1172,7 +1178,7 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
     if (gv_n) {
         int32_t *pos = malloc((size_t)n_sites * 4); uint8_t *brk = calloc((size_t)n_sites, 1);
         for (int k = 0; k < n_sites; ++k) { pos[k] = t0 + k; if (col_n[k] == 0 || !target_keeps_column(contig, t0 + k)) brk[k] |= 2; }
-        for (int j = 0; j < nlive; ++j) if (isite[live[j]].ret == 0) brk[cand[live[j]]] |= 1;      /* an indel record follows the SNP record */
+        for (int j = 0; j < nlive; ++j) if (isite[j].ret == 0) brk[cand[live[j]]] |= 1;      /* an indel record follows the SNP record */
         void *d_pos, *d_brk, *d_blk, *d_min, *d_block, *d_gdp, *d_gpl;
         CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_pos)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites, &d_brk));
         CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_blk)); CHECK(bcfgpu_malloc(ctx, (size_t)n_sites * 4, &d_min));

@@ -278,8 +278,10 @@ int  bcfgpu_truncated_cells(bcfgpu_ctx *ctx, uint32_t *n_cells);
  * likelihoods are then errmod_cal's, and bcfgpu_truncated_cells does not count those cells), and the context's generator
  * moves on by the numbers drawn, as the process-wide one does.
  *   snp     the SNP pass's tile (or NULL);  indel  the indel pass's tile as bcfgpu_gap_prep_tile left it (or NULL)
- *   indel_cols  HOST [indel->n_sites]: the SNP-tile column of every site of the indel tile (the `cols` of bcfgpu_gap_prep_tile)
- *   indel_ret   HOST [indel->n_sites] or NULL: bcf_call_gap_prep's return values -- only sites with 0 are visited
+ *   indel_cols  HOST [indel->n_sites]: the SNP-tile column of every site of the indel tile (bcfgpu_gap_prep_tile: the entries of
+ *               its `cols` with ret == 0, in order)
+ *   indel_ret   HOST [indel->n_sites] or NULL: bcf_call_gap_prep's return values where the indel tile holds columns it turned
+ *               away as well (bcfgpu_pileup_indel_tile over all candidates) -- only sites with 0 are visited
  * Synchronises the stream.  Without a plan the first 255 usable reads of such a cell are taken (see above).
  * bcfgpu_errmod_seed / _state: the generator's 48-bit state (a new context starts at 0x1234ABCD330E, a fresh process). */
 int  bcfgpu_errmod_plan(bcfgpu_ctx *ctx, const bcfgpu_tile *snp, const bcfgpu_tile *indel, const int32_t *indel_cols, const int32_t *indel_ret);
@@ -304,7 +306,10 @@ int  bcfgpu_mpileup(bcfgpu_ctx *ctx, const bcfgpu_tile *tile, const bcfgpu_mplp_
 /* mcall for every site of `in`; ploidy/groups/prior as described above */
 int  bcfgpu_mcall(bcfgpu_ctx *ctx, const bcfgpu_call_in *in, const bcfgpu_call_out *out);
 
-/* mpileup stage followed by the call stage with PL/QS kept in HBM (SNP tiles).
+/* mpileup stage followed by the call stage with PL/QS kept in HBM: `mpileup | call -m` for the tile's records, SNP tiles and
+ * indel tiles alike (the reference pipes both kinds of record through mcall(), mpileup.c:357-364 -> vcfcall.c:1137; an indel
+ * record has no <*> allele, vcfcall.c:1102-1111).  A site where the mpileup stage wrote no record (site.ret < 0: an indel
+ * column without an ALT allele, bam2bcf.c:611) gets a call record with ret = 0 and is not an error.
  * `ploidy` and `grp` as in bcfgpu_call_in (device pointers or NULL).  `mout` receives the
  * mpileup-stage results (input of the call stage), `cout` the calls. */
 int  bcfgpu_pipeline(bcfgpu_ctx *ctx, const bcfgpu_tile *tile, const uint8_t *ploidy, const int32_t *grp,
@@ -503,10 +508,15 @@ int  bcfgpu_pileup_indel_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *co
  *   reads  HOST, the pool handed to bcfgpu_pileup, or NULL: only zq / r_has_zq are read (the "ZQ" bytes bcfgpu_baq left;
  *          uploaded here because the pileup itself does not need them)
  *   par    the options of bcfgpu_indel_in (openQ ... min_frac) and `ref`; its array pointers are ignored
- *   out    HOST arrays per column as for bcfgpu_gap_prep; p_aux may be NULL (the words stay on the device)
- *   tile   out: DEVICE pointers, the indel pass's tile over ALL n_cols columns (is_indel = 1, aux set), ready for
- *          bcfgpu_mpileup; the records of columns with ret[i] < 0 are to be dropped by the caller (mpileup.c:354).
- *          Valid until the next bcfgpu_gap_prep_tile / bcfgpu_gap_prep / bcfgpu_pileup* call on this context. */
+ *   out    HOST arrays per column of `cols` as for bcfgpu_gap_prep (a column with ret[i] = -1 has INDEL_NULL types and zeros
+ *          elsewhere: what bca holds after such a call is read by no one, mpileup.c:354); p_aux may be NULL (the words stay
+ *          on the device), else it receives the words of the TILE's entries (below), tile->n_reads of them
+ *   tile   out: DEVICE pointers, the indel pass's tile (is_indel = 1, aux set), ready for bcfgpu_mpileup: the columns with
+ *          ret[i] == 0 and only those, in the order of `cols` -- site j of the tile is the j-th such column (mpileup.c:354-360
+ *          runs the indel pass where bcf_call_gap_prep returned >= 0).  n_sites = 0 when there is none.
+ *          Valid until the next bcfgpu_gap_prep_tile / bcfgpu_gap_prep / bcfgpu_pileup* call on this context.
+ * Without per_sample_flt the pooled support filter of bam2bcf_indel.c:150-154 is decided on the device from two counts the
+ * pileup left per column, and nothing else -- no entry, no workgroup of the stage -- touches a column that fails it. */
 int  bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32_t *cols, const bcfgpu_reads *reads,
                           const bcfgpu_indel_in *par, const bcfgpu_indel_out *out, int inscns_cap, bcfgpu_tile *tile);
 

@@ -132,3 +132,34 @@ def assert_site_equal(got, k, want):
     assert got["max_frac"][k] == np.float32(want["max_frac"])
     n = 4 * want["maxins"]
     np.testing.assert_array_equal(got["inscns"][k][:n], want["inscns"][:n])
+
+
+def assert_tile_matches_host_batch(ctx, b, pool, got_t, tile, got):
+    """bcfgpu_gap_prep_tile's outputs (got_t, tile: the pool form) against bcfgpu_gap_prep's on the same batch (got: host pointers,
+    entries in the batch's order).  The tile holds the columns with ret == 0 and only those, in order (mpileup.c:354-360); its
+    entries come in pool order (position-sorted per sample), so p->aux is compared read by read."""
+    from bcftools_amd.lib import check
+    S, ns = b["n_smpl"], b["n_sites"]
+    np.testing.assert_array_equal(got_t["ret"], got["ret"])
+    ok = got["ret"] == 0          # (what bca holds after a call that returned -1 is read by no one: mpileup.c:354-364)
+    for key in ("indel_types", "inscns", "maxins", "indelreg", "max_support", "max_frac"):
+        np.testing.assert_array_equal(got_t[key][ok], got[key][ok], err_msg=key)
+    assert (got_t["indel_types"][~ok] == 10000).all()
+    live = np.nonzero(ok)[0]
+    assert tile.n_sites == len(live) and tile.is_indel == 1
+    full = np.diff(b["smpl_off"].astype(np.int64))                       # entries per (column, sample) cell of the batch
+    want_cnt = full.reshape(ns, S)[live].ravel()
+    assert tile.n_reads == int(want_cnt.sum())
+    if len(live) == 0:
+        return
+    off = np.zeros(len(live) * S + 1, np.uint32)
+    check(ctx.L.bcfgpu_memcpy_d2h(ctx.h, off.ctypes.data, tile.plp_off, off.nbytes))
+    np.testing.assert_array_equal(np.diff(off.astype(np.int64)), want_cnt, err_msg="tile.plp_off")
+    cell = np.repeat(np.arange(ns * S), full)
+    dev2batch = pool.order[np.argsort(cell[pool.order], kind="stable")]  # the batch's entries, column-major, each cell in pool order
+    keep = np.repeat(np.repeat(ok, S), full)
+    if got_t["aux"].size:
+        np.testing.assert_array_equal(got_t["aux"][:tile.n_reads], got["aux"][dev2batch][keep], err_msg="p->aux")
+    aux_d = np.zeros(tile.n_reads, np.uint32)
+    check(ctx.L.bcfgpu_memcpy_d2h(ctx.h, aux_d.ctypes.data, tile.aux, aux_d.nbytes))
+    np.testing.assert_array_equal(aux_d, got["aux"][dev2batch][keep], err_msg="tile.aux")

@@ -5,7 +5,6 @@ import numpy as np
 import pytest
 
 from bcftools_amd import abi, synth
-from bcftools_amd.lib import check
 from tests.helpers import indeldrv, orc
 from tests.test_gpu_parity import EXACT_SITE, FLOAT_SITE
 
@@ -67,22 +66,7 @@ def test_long_indels_through_the_wide_band_kernel(gpu_ctx_factory, n_sites, n_sm
     # the device-pool form: the same core fed from bcfgpu_pileup's pool
     pool = indeldrv.DevicePool(ctx, b)
     got_t, st_t, tile = pool.gap_prep_tile(want_aux=True, **kw)
-    np.testing.assert_array_equal(got_t["ret"], got["ret"])
-    ok = got["ret"] == 0          # (what bca holds after a call that returned -1 is not read by anyone: mpileup.c:354-364)
-    for key in ("indel_types", "inscns", "maxins", "indelreg", "max_support", "max_frac"):
-        np.testing.assert_array_equal(got_t[key][ok], got[key][ok], err_msg=key)
-    cell = np.repeat(np.arange(n_sites * n_smpl), np.diff(b["smpl_off"]))
-    dev2batch = pool.order[np.argsort(cell[pool.order], kind="stable")]
-    # a column the pooled support filter (bam2bcf_indel.c:150-154) turns away has no entries in the tile form: its ret is < 0
-    # and the entries of the other columns follow one another
-    off = np.zeros(n_sites * n_smpl + 1, np.uint32)
-    check(ctx.L.bcfgpu_memcpy_d2h(ctx.h, off.ctypes.data, tile.plp_off, off.nbytes))
-    n_col = np.diff(off[::n_smpl].astype(np.int64))
-    full = np.diff(b["smpl_off"][::n_smpl].astype(np.int64))
-    assert ((n_col == full) | ((n_col == 0) & (got["ret"] < 0))).all()
-    keep = np.repeat(n_col > 0, full)
-    assert tile.n_reads == int(keep.sum())
-    np.testing.assert_array_equal(got_t["aux"][:tile.n_reads], got["aux"][dev2batch][keep], err_msg="p->aux")
+    indeldrv.assert_tile_matches_host_batch(ctx, b, pool, got_t, tile, got)
     assert st_t.n_wide == st.n_wide
 
 
@@ -164,10 +148,6 @@ def test_gap_prep_tile_on_a_device_pool_matches_the_host_batch(gpu_ctx_factory, 
     assert np.array_equal(pool.col_n[pool.cols], np.diff(b["smpl_off"][::n_smpl]))
     for rep in range(2):                      # the second call runs on workspaces the first one left behind
         got, st, tile = pool.gap_prep_tile(want_aux=True)
-        for key in ("ret", "indel_types", "inscns", "maxins", "indelreg", "max_support", "max_frac"):
-            np.testing.assert_array_equal(got[key], want[key], err_msg=key)
-        cell = np.repeat(np.arange(n_sites * n_smpl), np.diff(b["smpl_off"]))
-        dev2batch = pool.order[np.argsort(cell[pool.order], kind="stable")]
-        np.testing.assert_array_equal(got["aux"], want["aux"][dev2batch], err_msg="p->aux")
-        assert tile.n_sites == n_sites and tile.n_reads == len(b["p_read"]) and tile.is_indel == 1
+        indeldrv.assert_tile_matches_host_batch(ctx, b, pool, got, tile, want)
+        assert (want["ret"] == 0).any()
         assert st.n_jobs > 0 and st.n_passes >= st.n_jobs // 2

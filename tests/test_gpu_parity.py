@@ -378,6 +378,47 @@ def test_indel_pass_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, seed):
         np.testing.assert_allclose(g[m], w[m], rtol=2e-6, atol=1e-30, err_msg=k)
 
 
+@pytest.mark.parametrize("n_sites,n_smpl,seed,flags,with_ploidy", [(40, 100, 31, 0, False), (64, 7, 32, abi.CALL_VARONLY, False),
+                                                                   (48, 260, 33, 0, True)])
+def test_indel_records_through_the_fused_caller(gpu_ctx_factory, n_sites, n_smpl, seed, flags, with_ploidy):
+    """`mpileup | call -m` for indel records (mpileup.c:357-364 -> vcfcall.c:1137): the indel pass's tile through
+    bcfgpu_pipeline -- PLs of the indel types stay in HBM between the two stages -- against the oracle's mpileup followed by
+    its mcall on the records mpileup would have written (ret == 0).  An indel record carries no <*> allele."""
+    base = synth.numpy_tile(seed, n_sites, n_smpl, depth=20.0, var_rate=0.0)
+    rng = np.random.default_rng(seed)
+    R = len(base.rd)
+    cell = np.repeat(np.arange(n_sites * n_smpl), np.diff(base.plp_off.astype(np.int64)))
+    site = cell // n_smpl
+    has_indel = rng.random(n_sites) < 0.7
+    carrier = rng.random(n_sites * n_smpl) < 0.3
+    typ = np.where(has_indel[site] & carrier[cell] & (rng.random(R) < 0.5), rng.integers(1, 4, R), 0)
+    aux = (typ.astype(np.uint32) << 16) | (rng.integers(10, 200, R).astype(np.uint32) << 8) | rng.integers(0, 80, R).astype(np.uint32)
+    tile = host.HostTile(n_smpl, base.ref16, base.plp_off, base.rd, base.epos, aux=aux, is_indel=1)
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=R, call_flag=flags, output_tags=abi.CALL_FMT_GQ)
+    ploidy = rng.choice([1, 2, 2, 2], size=n_smpl).astype(np.uint8) if with_ploidy else None
+    mwant = orc.mpileup(cfg, tile)
+    live = mwant.site["ret"] == 0
+    assert live.any() and (~live).any()
+    mgot, cgot = gpu_ctx_factory(cfg).pipeline(tile, ploidy=ploidy)
+    np.testing.assert_array_equal(mgot.site["ret"], mwant.site["ret"])
+    np.testing.assert_array_equal(mgot.pl[live], mwant.pl[live])
+    assert (mwant.site["unseen"][live] < 0).all()
+    idx = np.nonzero(live)[0]
+    cin = host.CallInput(n_smpl, mwant.site["n_alleles"][idx], np.zeros(len(idx), np.int32), mwant.pl[idx].astype(np.int32),
+                         mwant.site["qsum"][idx], ploidy=ploidy, i16=mwant.site["anno"][idx].astype(np.float32))
+    cwant = orc.mcall(cfg, cin)
+    assert (cgot.site["ret"][~live] == 0).all()               # no record from mpileup: nothing called, no error
+    for k in ("ret", "nals_new", "als_new", "an"):
+        np.testing.assert_array_equal(cgot.site[k][idx], cwant.site[k], err_msg=k)
+    called = cwant.site["ret"] > 0
+    assert called.any()
+    np.testing.assert_allclose(cgot.site["qual"][idx][called], cwant.site["qual"][called], rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(cgot.site["ac"][idx][called], cwant.site["ac"][called])
+    np.testing.assert_array_equal(cgot.gt[idx][called], cwant.gt[called])
+    var = called & (cwant.site["als_new"] != 1)
+    np.testing.assert_array_equal(cgot.gq[idx][var], cwant.gq[var])
+
+
 def test_library_and_torch_share_one_hip_runtime():
     """PyTorch ships its own libamdhip64: the binding imports torch before dlopen()ing libbcfgpu.so, so a process can
     create a context first and touch torch's device afterwards (the order the unit tests use when run one file at a time)."""
