@@ -157,7 +157,7 @@ class GvcfOut(C.Structure):
 class GapStats(C.Structure):
     _fields_ = [("n_jobs", C.c_uint64), ("n_passes", C.c_uint64), ("dp_cells", C.c_uint64),
                 ("kernel_ms", C.c_float), ("prepare_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float),
-                ("n_wide", C.c_uint64)]
+                ("n_wide", C.c_uint64), ("n_scratch", C.c_uint64), ("band_jobs", C.c_uint32 * 8)]
 
 
 class Timing(C.Structure):

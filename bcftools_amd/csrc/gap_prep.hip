@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void gap_scan_kernel(GapSite *sites, int n_sit
         int m = 0;
         for (int k = 0; k < 256; ++k) m = w == 2 ? m + s_max[w][k] : max(m, s_max[w][k]);
         if (w == 0) tot->max_L = m; else if (w == 1) tot->max_bw = m; else if (w == 2) tot->n_live = m; else if (w == 3) tot->max_ref2 = m; else if (w == 4) tot->max_qstride = m; else tot->max_N = m;
-    } else if (tid == 10) { tot->n_wide = 0; tot->max_eff = 0; tot->n_passes = 0; tot->dp_cells = 0; }
+    } else if (tid == 10) { tot->n_wide = 0; tot->max_eff = 0; tot->n_passes = 0; tot->dp_cells = 0; tot->n_lds = 0; }
     __syncthreads();
     jobs = s_sum[0][tid]; ref2 = s_sum[1][tid]; ins = s_sum[2][tid]; q8 = s_sum[3][tid];
     for (int is = i0; is < i1; ++is) {
@@ -645,7 +645,7 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
     // small outputs share one block: ret, types[4], maxins, indelreg, max_support, max_frac per site, then the totals
     const size_t so_ret = 0, so_types = (size_t)ns * 4, so_maxins = so_types + (size_t)ns * 16, so_ireg = so_maxins + (size_t)ns * 4,
                  so_msup = so_ireg + (size_t)ns * 4, so_mfrac = so_msup + (size_t)ns * 4, so_tot = (so_mfrac + (size_t)ns * 4 + 15) & ~(size_t)15,
-                 so_bytes = so_tot + sizeof(GapTotals);
+                 so_bytes = so_tot + sizeof(GapTotals) + sizeof(ProbalnQueue);
     uint8_t *d_small = (uint8_t*)WS(28, so_bytes);
     uint8_t *h_small = (uint8_t*)bcfgpu_internal_pinned(ctx, 0, so_bytes);
     if (!d_sites || !d_rinfo || !d_small || !h_small) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
@@ -673,7 +673,10 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
         const size_t nj = (size_t)tot.n_jobs;
         int32_t *d_inscnt = (int32_t*)WS(16, (size_t)tot.ins_bytes * 5 * 4);
         int8_t *d_inscns = (int8_t*)WS(17, (size_t)tot.ins_bytes);
-        uint8_t *d_ref2 = (uint8_t*)WS(18, (size_t)tot.ref2_bytes + 64);      // (the realignment reads 8 bytes at a time, up to two groups ahead)
+        // (the realignment reads 8 bytes at a time, up to two groups ahead; the LDS class reads the bases under its whole band, which
+        // hangs over a row's ends by up to PROBALN_LDS16_MAX + 16 positions: 512 bytes of padding on both sides)
+        uint8_t *d_ref2 = (uint8_t*)WS(18, (size_t)tot.ref2_bytes + 1024);
+        if (d_ref2) d_ref2 += 512;
         int32_t *d_s1 = (int32_t*)WS(19, nj * 4), *d_s2 = (int32_t*)WS(20, nj * 4);
         uint32_t *d_wide = (uint32_t*)WS(21, nj * 4);
         GapEntry *d_ent = (GapEntry*)WS(29, n_ent * sizeof(GapEntry));
@@ -707,6 +710,7 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
         p.ref2 = d_ref2; p.qpack = d_qpack; p.q2p = q2p; p.score1 = d_s1; p.score2 = d_s2;
         p.pjob = d_pjob; p.key_in = d_k0; p.val_in = d_v0; p.key_sorted = d_k1; p.val_sorted = d_v1; p.list2 = d_list2; p.queue = d_queue;
         p.wide = d_wide; p.tot = d_tot;
+        p.n_lds_hint = tot.max_bw > PROBALN_BW_MAX ? 1 : 0;           // some site has a type of 8 bases or more
 #ifdef BCFGPU_DIAG
         p.force_wide = getenv("BCFGPU_FORCE_WIDE") != nullptr;      // diagnostics build only: every job through the rolling-row kernel
 #endif
@@ -722,9 +726,17 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
                 return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_gap_prep: side streams");
         }
         GP_CHK(hipMemcpyAsync(h_small, d_tot, sizeof(GapTotals), hipMemcpyDeviceToHost, st));
+        GP_CHK(hipMemcpyAsync(h_small + sizeof(GapTotals), d_queue, sizeof(ProbalnQueue), hipMemcpyDeviceToHost, st));
         GP_CHK(hipStreamSynchronize(st));                       // how many jobs need the wide-band version, and how wide
         memcpy(&tot, h_small, sizeof tot);
-        gs.n_wide = tot.n_wide;
+        {   // jobs by band width (statistics): the register classes, the five groups of the LDS class, sixteen-a-wavefront, scratch
+            ProbalnQueue hq;
+            memcpy(&hq, h_small + sizeof(GapTotals), sizeof hq);
+            gs.band_jobs[0] = hq.cls_begin[PROBALN_CLS_LDS] - hq.cls_begin[PROBALN_BW_MIN];
+            for (int g = 0; g <= PROBALN_LDS_GROUPS; ++g) gs.band_jobs[1 + g] = hq.lds_begin[g + 1] - hq.lds_begin[g];
+            gs.band_jobs[7] = tot.n_wide;
+        }
+        gs.n_wide = (uint64_t)tot.n_wide + tot.n_lds; gs.n_scratch = tot.n_wide;
         if (tot.n_wide) {
             p.ncell = 3 * (2 * tot.max_eff + 1) + 6;
             size_t chunk = ((size_t)1 << 30) / (2 * (size_t)p.ncell * sizeof(double));

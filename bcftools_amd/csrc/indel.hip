@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <type_traits>
+#include <algorithm>
 #include "kernels.h"
 
 namespace bcfgpu {
@@ -407,19 +408,24 @@ __global__ __launch_bounds__(256) void probaln_jobs_kernel(const ProbalnParams P
     uint32_t cls = PROBALN_CLS_NONE;
     PJob pj{};
     if (!j.skip && j.l_ref > 0 && j.l_query > 0) {
-        if (j.eff > PROBALN_BW_MAX || j.l_ref > 65535 || j.l_query > 65535 || P.force_wide) {
+        if (j.eff > PROBALN_LDS16_MAX || j.l_ref > 65535 || j.l_query > 65535 || P.force_wide) {
             P.wide[atomicAdd(&P.tot->n_wide, 1u)] = job;
             atomicMax(&P.tot->max_eff, j.eff);
             cls = PROBALN_CLS_WIDE;
         } else {
-            cls = j.eff < PROBALN_BW_MIN ? PROBALN_BW_MIN : j.eff;
+            cls = j.eff > PROBALN_LDS_MAX ? PROBALN_CLS_LDS16 : j.eff > PROBALN_BW_MAX ? PROBALN_CLS_LDS : j.eff < PROBALN_BW_MIN ? PROBALN_BW_MIN : j.eff;
+            if (cls >= PROBALN_CLS_LDS) atomicAdd(&P.tot->n_lds, 1u);
             pj.ref_off = j.ref_off; pj.q8 = j.q8; pj.l_ref = (uint16_t)j.l_ref; pj.l_query = (uint16_t)j.l_query; pj.eff = (uint16_t)j.eff;
         }
     }
     int dl = j.l_ref - j.l_query + 16;
     dl = dl < 0 ? 0 : dl > 31 ? 31 : dl;
+    const uint32_t lq = (uint32_t)(j.l_query > 255 ? 255 : j.l_query < 0 ? 0 : j.l_query);
     P.pjob[job] = pj;
-    P.key_in[job] = cls << 13 | (uint32_t)(j.l_query > 255 ? 255 : j.l_query < 0 ? 0 : j.l_query) << 5 | (uint32_t)dl;
+    // the LDS class is sorted by band width first: a wavefront's jobs share the sweep over the widest band among them
+    P.key_in[job] = cls == PROBALN_CLS_LDS ? cls << 13 | (uint32_t)j.eff << 6 | lq >> 2
+                  : cls == PROBALN_CLS_LDS16 ? cls << 13 | (uint32_t)(j.eff >> 2 > 127 ? 127 : j.eff >> 2) << 6 | lq >> 2
+                  : cls << 13 | lq << 5 | (uint32_t)dl;
     P.val_in[job] = job;
 }
 
@@ -432,6 +438,17 @@ __global__ void probaln_bounds_kernel(const uint32_t *key_sorted, int n, Probaln
     while (lo < hi) { const int mid = (lo + hi) >> 1; if ((key_sorted[mid] >> 13) >= (uint32_t)c) hi = mid; else lo = mid + 1; }
     q->cls_begin[c] = (uint32_t)lo;
     if (c < 16) { q->next1[c] = 0; q->next2[c] = 0; q->n2[c] = 0; }
+    if (c <= PROBALN_LDS_GROUPS + 1) {
+        // group g of the LDS class: the jobs with band widths in (cap[g-1], cap[g]]; lds_begin[g] = keys below class | (cap[g-1] + 1) << 6;
+        // the last range is the sixteen-jobs-a-wavefront class
+        const int caps[PROBALN_LDS_GROUPS] = PROBALN_LDS_CAPS;
+        const uint32_t thr = c == 0 ? PROBALN_CLS_LDS << 13 : c == PROBALN_LDS_GROUPS ? PROBALN_CLS_LDS16 << 13
+                           : c == PROBALN_LDS_GROUPS + 1 ? (PROBALN_CLS_LDS16 + 1) << 13 : PROBALN_CLS_LDS << 13 | (uint32_t)(caps[c - 1] + 1) << 6;
+        int a = 0, b = n;
+        while (a < b) { const int mid = (a + b) >> 1; if (key_sorted[mid] >= thr) b = mid; else a = mid + 1; }
+        q->lds_begin[c] = (uint32_t)a;
+        if (c <= PROBALN_LDS_GROUPS) q->lds_next[c] = 0;
+    }
 }
 
 // PASS 1: the jobs of class BW in sorted order, parameter set {1e-4, 1e-2}; jobs scoring above 5 are listed for
@@ -490,7 +507,440 @@ __global__ __launch_bounds__(64) void probaln_exact_kernel(const ProbalnParams P
     if (threadIdx.x == 0 && passes) { atomicAdd(&P.tot->n_passes, passes); atomicAdd(&P.tot->dp_cells, cells); }
 }
 
-// The listed jobs with bands wider than PROBALN_BW_MAX: two rolling rows per job in the scratch buffer, both parameter sets.
+// ---- bands wider than the register classes (indels of 8 bases and more: bw = |type| + 3, bam2bcf_indel.c:293-294): the row in LDS ----
+// One lane per job as before, one wavefront per workgroup, the band in the same always-sliding layout as above -- position p
+// of row i is reference column k = p + i - bw - 1 -- but the row lives in LDS, [cell][lane] doubles (conflict-free: a wavefront's
+// lanes read consecutive 8-byte words), and is updated IN PLACE: the new cell p needs the old cells p (diagonal) and p + 1
+// (above), so a sweep over ascending p that carries the old cell p in registers can overwrite slot p as it goes.  Two things
+// keep the LDS bytes at 16 per cell instead of 48 (two rows of three states):
+//   * the row is stored UNSCALED; the factor 1/s_i of the row (a division for row 1, as probaln.c has it) is applied where the
+//     next row reads a value -- the same single rounding as scaling the stored row;
+//   * D is not stored: D'[p] = m2 M'[p-1] + m8 D'[p-1] is a recurrence over the row's own unscaled M', so the next row's sweep
+//     re-runs it one cell behind its own -- the same operations in the same order, hence the same bits (what baq.hip does for
+//     its even rows).
+// Every sum keeps the reference's order; cells outside the band or the reference are exact zeros, as in the edge rows above.
+// A wavefront sweeps to the widest band and the longest query among its 64 jobs (sorted by band, then length).
+__device__ __forceinline__ int wave_max_i(int v)
+{
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o); v = w > v ? w : v; }
+    return v;
+}
+// LS: the lanes that hold a job (64, or 16 for the bands no 64 jobs fit LDS with); cell p of this lane's column at [p * LS], the
+// cell's M' and I' side by side (one 16-byte LDS access).  The sweep runs in groups of eight cells: a group's reads of the row
+// above go out a whole group ahead of their use (they touch cells this group's stores do not), and so does the 8-byte load of
+// the bases under the next group.  A group all of whose cells are inside every job's band and reference, with no N under
+// them, runs without masks (a wave-uniform choice, as in the register classes).
+__device__ __forceinline__ int wave_min_i(int v)
+{
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o); v = w < v ? w : v; }
+    return v;
+}
+template <int LS>
+__device__ __forceinline__ int probaln_fwd_lds(const uint8_t *ref, int l_ref, const uint8_t *qp, int l_query, int bw, const double2 *emt,
+                               double d, double e_, double2 *sR, bool active, bool owns)
+{
+    if (!active) { l_ref = 0; l_query = 0; bw = 0; }
+    const int W = active ? 2 * bw + 1 : 0;
+    const int Wmax = wave_max_i(W), Lmax = wave_max_i(l_query);
+    if (Wmax == 0) return 0;
+    const int Wc = (Wmax + 7) & ~7;                                          // whole groups: cells 0 .. Wc + 1 are this lane's
+    const double sMc = 1. / (2 * l_query + 2), sIc = sMc;
+    const double m0 = (1 - d - d) * (1 - sMc), m1 = d * (1 - sMc), m2 = m1;
+    const double m3 = (1 - e_) * (1 - sIc), m4 = e_ * (1 - sIc);
+    const double m6 = 1 - e_, m8 = e_;
+    const double m1q = EI * m1, m4q = EI * m4;
+    const double bM = (1 - d) / l_ref, bI = d / l_ref;
+    double prod = 1., Pr1 = 0., scale = 1.;
+    uint64_t qw = *(const uint64_t*)qp;                      // (a lane without a job reads its pool's first bytes: any value will do)
+    {   // f[1]: k = p - bw; stored scaled (a division, probaln.c): the factor the next row applies to it is 1
+        double sum = 0.;
+        const int end = l_ref < bw + 1 ? l_ref : bw + 1;
+        const int qb = (int)(qw & 0xff);
+        const double2 em = emt[qb];
+        const uint32_t qy = qb & 7;
+        if (owns) { sR[0] = make_double2(0., 0.); sR[(size_t)(Wc + 1) * LS] = make_double2(0., 0.); }
+        for (int p = 1; p <= Wc; ++p) {
+            const int k = p - bw;
+            const bool live = p <= W && k >= 1 && k <= end;
+            const uint32_t rb = live ? ref[k - 1] : 0u;
+            const double e = rb > 3 ? 1. : rb == qy ? em.x : em.y;
+            const double a = live ? e * bM : 0., b = live ? EI * bI : 0.;
+            if (owns) sR[(size_t)p * LS] = make_double2(a, b);
+            sum += a + b;
+        }
+        for (int p = 1; p <= Wc; ++p) {
+            const double2 c = sR[(size_t)p * LS];
+            if (owns) sR[(size_t)p * LS] = make_double2(c.x / sum, c.y / sum);
+        }
+        prod *= sum;
+        if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
+    }
+    // Rows 2 .. the longest query of the wavefront, run by every lane (see probaln_fwd_regs): a lane takes its score when its own
+    // last row is done and sweeps on over its own column with values nobody reads.
+    auto row = [&](int i, bool mine, int hi, int hio, int clear, int pa, int pz) {           // pa, pz: first cell of the first / last group to sweep
+        const bool first = i == 2;                                             // the row above is row 1: it has no D
+        qw = ((i - 1) & 7) == 0 ? *(const uint64_t*)(qp + (i - 1)) : qw >> 8;
+        const int qb = (int)(qw & 0xff);
+        const double2 em = emt[qb];
+        const uint32_t qyi = qb & 7;
+        const uint8_t *rrow = ref + (i - bw - 2);                              // the base under cell p: rrow[p] (the pool is padded on both sides)
+        double Mo_un = 0., Do_un = 0.;                                         // the row above, unscaled: M'[p-1], D'[p-1] (zeros in front of the first group)
+        const double2 c1 = sR[(size_t)pa * LS];
+        double Mc_un = c1.x, Mc = c1.x * scale, Ic = c1.y * scale;             // ... its cell p: M' unscaled, M and I scaled
+        double Mn = 0., Dn = 0.;                                               // this row: M[p-1], D[p-1]
+        double sum = 0.;
+        uint64_t rw_next;
+        __builtin_memcpy(&rw_next, rrow + pa, 8);
+        double2 nx[8], nn[8];
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) nx[u] = sR[(size_t)(pa + 1 + u) * LS];
+        for (int p0 = pa; p0 <= pz; p0 += 8) {
+            const uint64_t rw = rw_next;
+            __builtin_memcpy(&rw_next, rrow + p0 + 8, 8);
+            double2 *cR = sR + (size_t)p0 * LS;
+            if (p0 + 8 <= pz) {
+                #pragma unroll
+                for (int u = 0; u < 8; ++u) nn[u] = cR[(size_t)(9 + u) * LS];
+            }
+            const bool masked = first || p0 + 7 > clear || __builtin_amdgcn_ballot_w64(mine && (rw & 0x0404040404040404ull) != 0) != 0;
+            if (!masked) {
+                #pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double Mx_un = nx[u].x, Mx = Mx_un * scale, Ix = nx[u].y * scale;
+                    Do_un = m2 * Mo_un + m8 * Do_un;
+                    const double Ds = Do_un * scale;
+                    const uint32_t rb = (uint32_t)(rw >> (8 * u)) & 0xffu;
+                    const double e = rb == qyi ? em.x : em.y;
+                    const double f0 = e * (m0 * Mc + m3 * Ic + m6 * Ds);
+                    const double f1 = m1q * Mx + m4q * Ix;
+                    const double f2 = m2 * Mn + m8 * Dn;
+                    sum += f0 + f1 + f2;
+                    if (LS == 64 || owns) cR[(size_t)u * LS] = make_double2(f0, f1);
+                    Mo_un = Mc_un; Mc_un = Mx_un; Mc = Mx; Ic = Ix;
+                    Mn = f0; Dn = f2;
+                }
+            } else {
+                #pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int p = p0 + u;
+                    const double Mx_un = nx[u].x, Mx = Mx_un * scale, Ix = nx[u].y * scale;
+                    const double tvo = (!first && p <= hio) ? 1. : 0.;
+                    Do_un = tvo * (m2 * Mo_un + m8 * Do_un);                   // D' of the row above at p, as that row formed it
+                    const double Ds = Do_un * scale;
+                    const bool live = p <= hi;
+                    const uint32_t rb = (uint32_t)(rw >> (8 * u)) & 0xffu;
+                    double e = rb > 3 ? 1. : rb == qyi ? em.x : em.y;
+                    e = live ? e : 0.;
+                    const double tv = live ? 1. : 0.;
+                    const double f0 = e * (m0 * Mc + m3 * Ic + m6 * Ds);
+                    const double f1 = tv * (m1q * Mx + m4q * Ix);              // (past `hi` the cell above may be an earlier row's: zero, as the full sweep has it)
+                    const double f2 = tv * (m2 * Mn + m8 * Dn);
+                    sum += f0 + f1 + f2;
+                    if (LS == 64 || owns) cR[(size_t)u * LS] = make_double2(f0, f1);
+                    Mo_un = Mc_un; Mc_un = Mx_un; Mc = Mx; Ic = Ix;
+                    Mn = f0; Dn = f2;
+                }
+            }
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) nx[u] = nn[u];
+        }
+        scale = 1. / sum;
+        prod *= sum;
+        if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
+    };
+    int result = 0;
+    for (int i = 2; ; ++i) {
+        if (i - 1 == l_query) {       // this lane's last row is done: f[l_query + 1] over its cells inside the reference, then the score
+            int hl = l_ref - (l_query - bw) + 1; hl = hl < W ? hl : W;
+            double fsum = 0.;
+            for (int p = 1; p <= hl; ++p) {
+                const double2 c = sR[(size_t)p * LS];
+                fsum += (c.x * scale) * sMc + (c.y * scale) * sIc;
+            }
+            double pr = prod * fsum, P1 = Pr1;
+            if (pr < 1e-100) { P1 += -4.343 * log(pr); pr = 1.; }
+            P1 += -4.343 * log(pr * l_ref * l_query);
+            result = (int)(P1 + .499);
+        }
+        if (i > Lmax) break;
+        const bool mine = i <= l_query;
+        int hi = l_ref - (i - bw) + 1; hi = hi < W ? hi : W;                   // cells past it lie beyond the reference (or this job's band)
+        int hio = l_ref - (i - 1 - bw) + 1; hio = hio < W ? hio : W;           // the same for the row above (its D is re-run)
+        const int clear = wave_min_i(mine ? (hi < hio ? hi : hio) : 0x7fffffff);
+        // Cells in front of the reference's first column (p < bw + 2 - i) are zeros since row 1 and stay zeros; cells past `hi` are
+        // zeros in this row and are not read by any later row (hi only falls): the sweep covers the groups of eight in between,
+        // over all lanes.  (What a skipped group holds past `hi` is an earlier row's: nothing reads it, see f[l_query + 1] above.)
+        int lo = bw + 2 - i; lo = lo < 1 ? 1 : lo;
+        const int lo_min = wave_min_i(mine ? lo : 0x7fffffff), hi_max = wave_max_i(mine ? hi : 0);
+        if (hi_max < 1) continue;
+        row(i, mine, hi, hio, clear, ((lo_min - 1) & ~7) + 1, ((hi_max - 1) & ~7) + 1);
+    }
+    return result;
+}
+
+// The same sweep with the whole row in registers: NC groups of eight cells, everything unrolled, so that every cell is a named
+// register pair (M', I') -- four registers a cell instead of the six of probaln_fwd_exact (D re-run, see above), which is what
+// lets a band of 43 (88 cells) fit the 512 registers a lane has at one wavefront per SIMD.  The register file of a CU is three
+// times its LDS: bands up to 43 run here with every SIMD busy, where their rows in LDS leave room for one or two wavefronts a CU.
+template <int NC>
+__device__ __forceinline__ int probaln_fwd_regs(const uint8_t *ref, int l_ref, const uint8_t *qp, int l_query, int bw, const double2 *emt,
+                                                double d, double e_, bool active)
+{
+    constexpr int WC = NC * 8;
+    if (!active) { l_ref = 0; l_query = 0; bw = 0; }
+    const int W = active ? 2 * bw + 1 : 0;
+    const int Wmax = wave_max_i(W), Lmax = wave_max_i(l_query);
+    if (Wmax == 0) return 0;
+    double2 R[WC + 2];                                       // cells 0 .. WC + 1 (the two ends stay zero)
+    const double sMc = 1. / (2 * l_query + 2), sIc = sMc;
+    const double m0 = (1 - d - d) * (1 - sMc), m1 = d * (1 - sMc), m2 = m1;
+    const double m3 = (1 - e_) * (1 - sIc), m4 = e_ * (1 - sIc);
+    const double m6 = 1 - e_, m8 = e_;
+    const double m1q = EI * m1, m4q = EI * m4;
+    const double bM = (1 - d) / l_ref, bI = d / l_ref;
+    double prod = 1., Pr1 = 0., scale = 1.;
+    uint64_t qw = *(const uint64_t*)qp;                      // (a lane without a job reads its pool's first bytes: any value will do)
+    {   // f[1]: k = p - bw
+        double sum = 0.;
+        const int end = l_ref < bw + 1 ? l_ref : bw + 1;
+        const int qb = (int)(qw & 0xff);
+        const double2 em = emt[qb];
+        const uint32_t qy = qb & 7;
+        R[0] = make_double2(0., 0.); R[WC + 1] = make_double2(0., 0.);
+        #pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            uint64_t rw;
+            __builtin_memcpy(&rw, ref + (8 * c - bw), 8);     // the bases under cells 8c + 1 .. 8c + 8: ref[k - 1], k = p - bw (the pool is padded)
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int p = 8 * c + u + 1, k = p - bw;
+                const bool live = p <= W && k >= 1 && k <= end;
+                const uint32_t rb = live ? (uint32_t)(rw >> (8 * u)) & 0xffu : 0u;
+                const double e = rb > 3 ? 1. : rb == qy ? em.x : em.y;
+                const double a = live ? e * bM : 0., b = live ? EI * bI : 0.;
+                R[p] = make_double2(a, b);
+                sum += a + b;
+            }
+        }
+        #pragma unroll
+        for (int p = 1; p <= WC; ++p) { R[p].x /= sum; R[p].y /= sum; }        // (row 1 is scaled by a division, probaln.c; later rows keep their factor for the next row's reads: x * 1 = x here)
+        prod *= sum;
+        if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
+    }
+    // Rows 2 .. the longest query of the wavefront, run by EVERY lane: a lane takes its score when its own last row is done
+    // (f[l_query + 1] below reads the row, it does not change it) and computes on with values nobody reads -- a lane-divergent
+    // branch around the sweep would keep two copies of the row's registers apart.
+    auto row = [&](int i, bool mine, int hi, int hio, int clear, int ca, int cz) {           // ca, cz: first and last group of eight to sweep
+        const bool first = i == 2;                            // the row above is row 1: it has no D
+        qw = ((i - 1) & 7) == 0 ? *(const uint64_t*)(qp + (i - 1)) : qw >> 8;
+        const int qb = (int)(qw & 0xff);
+        const double2 em = emt[qb];
+        const uint32_t qyi = qb & 7;
+        const uint8_t *rrow = ref + (i - bw - 2);
+        auto sc = [&](double x) { return x * scale; };
+        double Mo_un = 0., Do_un = 0.;
+        double Mc_un = R[1].x, Mc = sc(R[1].x), Ic = sc(R[1].y);
+        double Mn = 0., Dn = 0.;
+        double sum = 0.;
+        uint64_t rw_next;
+        __builtin_memcpy(&rw_next, rrow + 1, 8);
+        #pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int p0 = 1 + 8 * c;
+            if (c < ca) {                                     // (wave-uniform) a group of zeros in front of the reference: step over it
+                if (c + 1 < NC) { __builtin_memcpy(&rw_next, rrow + p0 + 8, 8); Mc_un = R[p0 + 8].x; Mc = sc(Mc_un); Ic = sc(R[p0 + 8].y); }
+            } else if (c <= cz) {
+                const uint64_t rw = rw_next;
+                if (c + 1 < NC) __builtin_memcpy(&rw_next, rrow + p0 + 8, 8);
+                const bool masked = first || p0 + 7 > clear || __builtin_amdgcn_ballot_w64(mine && (rw & 0x0404040404040404ull) != 0) != 0;
+                if (!masked) {
+                    #pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double2 nx = R[p0 + u + 1];
+                        const double Mx_un = nx.x, Mx = Mx_un * scale, Ix = nx.y * scale;
+                        Do_un = m2 * Mo_un + m8 * Do_un;
+                        const double Ds = Do_un * scale;
+                        const uint32_t rb = (uint32_t)(rw >> (8 * u)) & 0xffu;
+                        const double e = rb == qyi ? em.x : em.y;
+                        const double f0 = e * (m0 * Mc + m3 * Ic + m6 * Ds);
+                        const double f1 = m1q * Mx + m4q * Ix;
+                        const double f2 = m2 * Mn + m8 * Dn;
+                        sum += f0 + f1 + f2;
+                        R[p0 + u] = make_double2(f0, f1);
+                        Mo_un = Mc_un; Mc_un = Mx_un; Mc = Mx; Ic = Ix;
+                        Mn = f0; Dn = f2;
+                        if (NC > 4) __builtin_amdgcn_sched_barrier(0);         // (a cell's instructions stay together: the scheduler's taste for
+                    }
+                } else {
+                    #pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int p = p0 + u;
+                        const double2 nx = R[p0 + u + 1];
+                        const double Mx_un = nx.x, Mx = sc(Mx_un), Ix = sc(nx.y);
+                        const double tvo = (!first && p <= hio) ? 1. : 0.;
+                        Do_un = tvo * (m2 * Mo_un + m8 * Do_un);
+                        const double Ds = Do_un * scale;
+                        const bool live = p <= hi;
+                        const uint32_t rb = (uint32_t)(rw >> (8 * u)) & 0xffu;
+                        double e = rb > 3 ? 1. : rb == qyi ? em.x : em.y;
+                        e = live ? e : 0.;
+                        const double tv = live ? 1. : 0.;
+                        const double f0 = e * (m0 * Mc + m3 * Ic + m6 * Ds);
+                        const double f1 = tv * (m1q * Mx + m4q * Ix);          // (past `hi` the cell above may be an earlier row's: zero, as the full sweep has it)
+                        const double f2 = tv * (m2 * Mn + m8 * Dn);
+                        sum += f0 + f1 + f2;
+                        R[p0 + u] = make_double2(f0, f1);
+                        Mo_un = Mc_un; Mc_un = Mx_un; Mc = Mx; Ic = Ix;
+                        Mn = f0; Dn = f2;
+                        if (NC > 4) __builtin_amdgcn_sched_barrier(0);         // (a cell's instructions stay together: the scheduler's taste for
+                    }
+                }
+            }
+        }
+        scale = 1. / sum;
+        prod *= sum;
+        if (prod < 1e-100) { Pr1 += -4.343 * log(prod); prod = 1.; }
+    };
+    int result = 0;
+    for (int i = 2; ; ++i) {
+        if (i - 1 == l_query) {       // this lane's last row is done: f[l_query + 1] over its cells inside the reference, then the score
+            int hl = l_ref - (l_query - bw) + 1; hl = hl < W ? hl : W;
+            double fsum = 0.;
+            #pragma unroll
+            for (int p = 1; p <= WC; ++p) {
+                const double keep = p <= hl ? 1. : 0.;        // (a cell past it holds an earlier row's value, or a zero: it adds +0 either way)
+                fsum += keep * ((R[p].x * scale) * sMc + (R[p].y * scale) * sIc);
+            }
+            double pr = prod * fsum, P1 = Pr1;
+            if (pr < 1e-100) { P1 += -4.343 * log(pr); pr = 1.; }
+            P1 += -4.343 * log(pr * l_ref * l_query);
+            result = (int)(P1 + .499);
+        }
+        if (i > Lmax) break;
+        const bool mine = i <= l_query;
+        int hi = l_ref - (i - bw) + 1; hi = hi < W ? hi : W;
+        int hio = l_ref - (i - 1 - bw) + 1; hio = hio < W ? hio : W;
+        const int clear = wave_min_i(mine ? (hi < hio ? hi : hio) : 0x7fffffff);
+        // (the groups of eight in front of the reference's first column hold zeros and stay zeros, those past `hi` of every lane are
+        // zeros in this row and read by no later row: see probaln_fwd_lds)
+        int lo = bw + 2 - i; lo = lo < 1 ? 1 : lo;
+        const int lo_min = wave_min_i(mine ? lo : 0x7fffffff), hi_max = wave_max_i(mine ? hi : 0);
+        if (hi_max < 1) continue;
+        row(i, mine, hi, hio, clear, (lo_min - 1) >> 3, (hi_max - 1) >> 3);
+    }
+    return result;
+}
+
+// Group `grp` of the LDS class through the register-resident sweep (the groups whose bands fit it): one lane per job, both
+// parameter sets one after the other.
+template <int NC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void probaln_regs_kernel(const ProbalnParams P, int grp)
+{
+    __shared__ double2 s_emt[256];
+    __builtin_amdgcn_s_setprio(2);                            // (one wavefront a SIMD with a long chunk each: ahead of the register classes' three or four)
+    ProbalnQueue *Q = P.queue;
+    const uint32_t c0 = Q->lds_begin[grp], n = Q->lds_begin[grp + 1] - c0;
+    if (n == 0) return;
+    for (int b = threadIdx.x; b < 256; b += 64) {
+        const double ql = (double)P.q2p[b >> 3];
+        s_emt[b] = (b & 7) > 3 ? make_double2(1., 1.) : make_double2(1. - ql, ql * EM);
+    }
+    __syncthreads();
+    unsigned long long cells = 0, passes = 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (threadIdx.x == 0) base = atomicAdd(&Q->lds_next[grp], 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const uint32_t i = base + threadIdx.x;
+        const bool have = i < n;
+        uint32_t job = 0;
+        PJob j{};
+        if (have) { job = P.val_sorted[c0 + i]; j = P.pjob[job]; }
+        const bool fits = have && 2 * (int)j.eff + 1 <= NC * 8;                // (always: the groups are cut by band width)
+        const uint8_t *ref = P.ref2 + j.ref_off, *qp = P.qpack + (size_t)j.q8 * 8;
+        int s1 = 0, s2 = 0;
+        bool go = fits;
+        #pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const int sc = probaln_fwd_regs<NC>(ref, j.l_ref, qp, j.l_query, j.eff, s_emt, pass ? 1e-6 : 1e-4, pass ? 1e-3 : 1e-2, go);
+            if (pass == 0) { s1 = s2 = sc; go = fits && sc > 5; if (__builtin_amdgcn_ballot_w64(go) == 0) break; }
+            else if (go) s2 = sc;
+        }
+        if (fits) {
+            auto pack = [&](int sc) { int l = (int)(100. * sc / j.l_query + .499); if (l > 255) l = 255; return sc << 8 | l; };
+            P.score1[job] = pack(s1);
+            P.score2[job] = pack(s2);
+            const unsigned long long c1 = (unsigned long long)j.l_query * (2 * j.eff + 1) * 3;
+            cells += go ? 2 * c1 : c1;
+            passes += go ? 2 : 1;
+        }
+    }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { passes += __shfl_xor(passes, o); cells += __shfl_xor(cells, o); }
+    if (threadIdx.x == 0 && passes) { atomicAdd(&P.tot->n_passes, passes); atomicAdd(&P.tot->dp_cells, cells); }
+}
+
+// Group `grp` of the LDS class (LS = 64), or the sixteen-jobs class (LS = 16, grp = PROBALN_LDS_GROUPS): both parameter sets of a
+// job in the lane that holds it (nearly every job of a realigned column scores above 5 with the first).  wcells: the cells
+// the launch's LDS holds per lane.
+template <int LS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void probaln_lds_kernel(const ProbalnParams P, int grp, int wcells)
+{
+    extern __shared__ double2 s_lds[];                     // (M', I')[wcells][LS], then the emission table
+    // These wavefronts are few and each has a long way to go alone (one or two a CU), beside launches that fill every SIMD with
+    // three or four wavefronts of their own: at equal priority a wavefront here would get a quarter of its SIMD's issue slots and
+    // the whole stage would wait for it.
+    __builtin_amdgcn_s_setprio(3);
+    double2 *s_emt = s_lds + (size_t)wcells * LS;
+    ProbalnQueue *Q = P.queue;
+    const uint32_t c0 = Q->lds_begin[grp], n = Q->lds_begin[grp + 1] - c0;
+    if (n == 0) return;
+    for (int b = threadIdx.x; b < 256; b += 64) {
+        const double ql = (double)P.q2p[b >> 3];
+        s_emt[b] = (b & 7) > 3 ? make_double2(1., 1.) : make_double2(1. - ql, ql * EM);
+    }
+    __syncthreads();
+    const bool owns = threadIdx.x < LS;                    // (LS = 16: the other lanes hold no job and own no column)
+    double2 *sR = s_lds + (owns ? threadIdx.x : 0);
+    unsigned long long cells = 0, passes = 0;
+    for (;;) {
+        uint32_t base = 0;
+        if (threadIdx.x == 0) base = atomicAdd(&Q->lds_next[grp], (uint32_t)LS);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const uint32_t i = base + threadIdx.x;
+        const bool have = threadIdx.x < LS && i < n;
+        uint32_t job = 0;
+        PJob j{};
+        if (have) { job = P.val_sorted[c0 + i]; j = P.pjob[job]; }
+        const bool fits = have && PROBALN_LDS_CELLS((int)j.eff) <= wcells;     // (always: the groups are cut by band width)
+        const uint8_t *ref = P.ref2 + j.ref_off, *qp = P.qpack + (size_t)j.q8 * 8;
+        int s1 = 0, s2 = 0;
+        bool again = fits;
+        #pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const int sc = probaln_fwd_lds<LS>(ref, j.l_ref, qp, j.l_query, j.eff, s_emt, pass ? 1e-6 : 1e-4, pass ? 1e-3 : 1e-2, sR, again, owns);
+            if (pass == 0) { s1 = s2 = sc; again = fits && sc > 5; if (__builtin_amdgcn_ballot_w64(again) == 0) break; }
+            else if (again) s2 = sc;
+        }
+        if (fits) {
+            auto pack = [&](int sc) { int l = (int)(100. * sc / j.l_query + .499); if (l > 255) l = 255; return sc << 8 | l; };
+            P.score1[job] = pack(s1);
+            P.score2[job] = pack(s2);
+            const unsigned long long c1 = (unsigned long long)j.l_query * (2 * j.eff + 1) * 3;
+            cells += again ? 2 * c1 : c1;
+            passes += again ? 2 : 1;
+        }
+    }
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { passes += __shfl_xor(passes, o); cells += __shfl_xor(cells, o); }
+    if (threadIdx.x == 0 && passes) { atomicAdd(&P.tot->n_passes, passes); atomicAdd(&P.tot->dp_cells, cells); }
+}
+
+// The listed jobs with bands wider than PROBALN_LDS16_MAX (or lengths past 16 bits): two rolling rows per job in the scratch buffer, both parameter sets.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void probaln_wide_kernel(const ProbalnParams P)
 {
     const int i = blockIdx.x * 64 + threadIdx.x;
@@ -534,9 +984,12 @@ template <int BW> static void launch_exact_class(const ProbalnParams &p, hipStre
     hipLaunchKernelGGL((probaln_exact_kernel<BW, 1>), dim3(grid), dim3(64), 0, s, p);
     hipLaunchKernelGGL((probaln_exact_kernel<BW, 2>), dim3(grid), dim3(64), 0, s, p);
 }
-// Both passes of every band width.  The widths are independent of one another, and the narrow classes hold most jobs while
-// a wide one may hold a few dozen whose single wavefront takes as long as a large class does: each width runs on a stream
-// of its own between a fork and a join on the caller's stream (side[8], ev[9] from the context), widest first.
+// Both passes of every band width, on three streams between a fork and a join on the caller's (side[0..1], ev[0..2] and ev[8]
+// from the context; the runtime spreads streams over four hardware queues, so more streams would only queue up behind one
+// another).  Every launch is a grid of persistent wavefronts pulling 64 jobs at a time from its class's counter, so a class with
+// few jobs costs one such chunk, not a launch's worth of idle machine; the two chains of machine-filling launches share the
+// CUs wavefront by wavefront.  The classes whose wavefronts are few and slow -- the bands past 43, one or two wavefronts a CU
+// in LDS -- go first on a stream of their own and run beside everything else.
 int launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu, hipStream_t *side, hipEvent_t *ev)
 {
     if (p.n_jobs <= 0) return 0;
@@ -544,21 +997,35 @@ int launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu, hipStr
     unsigned grid = (unsigned)n_cu * 4u * 3u;
     const unsigned need = (unsigned)((p.n_jobs + 63) / 64);
     if (grid > need) grid = need;
+    hipStream_t tail = side[0], second = side[1];
     if (hipEventRecord(ev[8], s) != hipSuccess) return -1;
-    for (int i = 0; i < 8; ++i) {
-        if (hipStreamWaitEvent(side[i], ev[8], 0) != hipSuccess) return -1;
-        switch (i) {
-            case 0: launch_exact_class<10>(p, side[i], grid); break;
-            case 1: launch_exact_class<9>(p, side[i], grid); break;
-            case 2: launch_exact_class<8>(p, side[i], grid); break;
-            case 3: launch_exact_class<7>(p, side[i], grid); break;
-            case 4: launch_exact_class<6>(p, side[i], grid); break;
-            case 5: launch_exact_class<5>(p, side[i], grid); break;
-            case 6: launch_exact_class<4>(p, side[i], grid); break;
-            default: launch_exact_class<3>(p, side[i], grid); break;
+    if (hipStreamWaitEvent(tail, ev[8], 0) != hipSuccess || hipStreamWaitEvent(second, ev[8], 0) != hipSuccess) return -1;
+    if (p.n_lds_hint != 0) {
+        static const int caps[PROBALN_LDS_GROUPS] = PROBALN_LDS_CAPS;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(probaln_lds_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(probaln_lds_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+        {
+            const int wcells = PROBALN_LDS_CELLS(PROBALN_LDS16_MAX);
+            const size_t lds = (size_t)wcells * 16 * 16 + 256 * sizeof(double2);
+            hipLaunchKernelGGL(probaln_lds_kernel<16>, dim3(std::min((unsigned)n_cu, need)), dim3(64), lds, tail, p, PROBALN_LDS_GROUPS, wcells);
         }
-        if (hipEventRecord(ev[i], side[i]) != hipSuccess || hipStreamWaitEvent(s, ev[i], 0) != hipSuccess) return -1;
+        for (int g = PROBALN_LDS_GROUPS - 1; g >= 3; --g) {
+            const int wcells = PROBALN_LDS_CELLS(caps[g]);
+            const size_t lds = (size_t)wcells * 64 * 16 + 256 * sizeof(double2);
+            const unsigned per_cu = (unsigned)((160 * 1024) / lds);
+            hipLaunchKernelGGL(probaln_lds_kernel<64>, dim3(std::min((unsigned)n_cu * per_cu, need)), dim3(64), lds, tail, p, g, wcells);
+        }
+        // bands 11 .. 43: the row in registers, one wavefront a SIMD
+        hipLaunchKernelGGL(probaln_regs_kernel<11>, dim3(std::min((unsigned)n_cu * 4u, need)), dim3(64), 0, second, p, 2);
+        hipLaunchKernelGGL(probaln_regs_kernel<8>, dim3(std::min((unsigned)n_cu * 4u, need)), dim3(64), 0, s, p, 1);
+        hipLaunchKernelGGL(probaln_regs_kernel<4>, dim3(std::min((unsigned)n_cu * 4u, need)), dim3(64), 0, second, p, 0);
     }
+    launch_exact_class<10>(p, second, grid); launch_exact_class<9>(p, s, grid);
+    launch_exact_class<8>(p, second, grid);  launch_exact_class<7>(p, s, grid);
+    launch_exact_class<6>(p, second, grid);  launch_exact_class<5>(p, s, grid);
+    launch_exact_class<4>(p, second, grid);  launch_exact_class<3>(p, s, grid);
+    if (hipEventRecord(ev[0], tail) != hipSuccess || hipStreamWaitEvent(s, ev[0], 0) != hipSuccess) return -1;
+    if (hipEventRecord(ev[1], second) != hipSuccess || hipStreamWaitEvent(s, ev[1], 0) != hipSuccess) return -1;
     return 0;
 }
 void launch_probaln_wide(const ProbalnParams &p, hipStream_t s)

@@ -189,13 +189,22 @@ struct GapTotals {
     unsigned long long n_passes, dp_cells;       // statistics of the realignment (bcfgpu_gap_stats)
     unsigned long long qpack8;                   // 8-byte units of the packed-query pool
     int32_t max_L, max_bw, n_live, max_ref2, max_qstride, max_N;   // max_N: most pileup entries of a live site
-    uint32_t n_wide;                             // jobs whose band does not fit the register-resident pass
+    uint32_t n_wide;                             // jobs whose band fits neither the registers nor LDS (or whose lengths exceed 16 bits)
     int32_t max_eff;                             // their widest band
+    uint32_t n_lds;                              // jobs of the LDS class (bands PROBALN_BW_MAX + 1 .. PROBALN_LDS_MAX)
 };
 // realignment jobs (indel.hip): bands of half-width PROBALN_BW_MIN..PROBALN_BW_MAX run with the row in registers, one kernel
-// instantiation per width (narrower bands in the smallest); wider ones from rolling rows in a scratch buffer
+// instantiation per width (narrower bands in the smallest); wider ones, up to PROBALN_LDS_MAX, with the row in LDS (class
+// PROBALN_CLS_LDS, sorted by band width and cut into PROBALN_LDS_GROUPS launches by the LDS a wavefront needs; PROBALN_CLS_LDS16:
+// sixteen jobs a wavefront for the bands no 64 jobs fit LDS with); what is wider still, or longer than the 16-bit fields of a
+// PJob, from rolling rows in a global scratch buffer (PROBALN_CLS_WIDE)
 #define PROBALN_BW_MIN 3
 #define PROBALN_BW_MAX 10
+#define PROBALN_LDS_MAX 73                       // 64 jobs a wavefront: (2 * 73 + 1 -> 152 cells + 2) x 64 lanes x 16 bytes + the emission table <= 160 KiB
+#define PROBALN_LDS16_MAX 300                    // 16 jobs a wavefront: 610 cells x 16 lanes x 16 bytes
+#define PROBALN_LDS_GROUPS 5
+#define PROBALN_CLS_LDS 11u
+#define PROBALN_CLS_LDS16 12u
 #define PROBALN_CLS_WIDE 14u
 #define PROBALN_CLS_NONE 15u
 struct PJob { uint32_t ref_off, q8; uint16_t l_ref, l_query, eff, pad; };      // one decoded job: offsets into ref2 / the packed queries (8-byte units)
@@ -203,7 +212,13 @@ struct ProbalnQueue {
     uint32_t cls_begin[17];                      // first sorted slot of every class (class = key >> 13)
     uint32_t next1[16], next2[16];               // work counters of the two passes
     uint32_t n2[16];                             // jobs listed for the second parameter set, per class
+    uint32_t lds_begin[PROBALN_LDS_GROUPS + 2];  // class PROBALN_CLS_LDS: first sorted slot of every band-width group; then class PROBALN_CLS_LDS16
+    uint32_t lds_next[PROBALN_LDS_GROUPS + 1];   // work counters of the groups
 };
+// the widest band of every group of the LDS class (host and device), and the cells a lane's column needs for a band: whole
+// groups of eight cells and a guard cell at either end
+#define PROBALN_LDS_CAPS {15, 31, 43, 58, PROBALN_LDS_MAX}     /* the first three groups run with the row in registers (4, 8, 11 groups of eight cells) */
+#define PROBALN_LDS_CELLS(cap) ((((2 * (cap) + 1) + 7) & ~7) + 2)
 struct ProbalnParams {
     GapIn gin;
     const GapSite *sites;
@@ -224,10 +239,11 @@ struct ProbalnParams {
     size_t scratch_stride;                       // jobs per chunk; scratch is [2][ncell][stride] doubles
     double *scratch;
     int force_wide;                              // tests: every job through the rolling-row version
+    int n_lds_hint;                              // 0: no launch of the LDS class is needed (no site has a type of 8 bases or more)
 };
 void launch_probaln_jobs(const ProbalnParams &p, hipStream_t s);
 void launch_probaln_bounds(const ProbalnParams &p, hipStream_t s);
-int launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu, hipStream_t *side, hipEvent_t *ev);
+int launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu, hipStream_t *side, hipEvent_t *ev);      // (the LDS class too)
 void launch_probaln_wide(const ProbalnParams &p, hipStream_t s);
 void launch_gap_entries(const GapIn &in, const GapSite *sites, int n_ent, GapEntry *ent, int max_qstride, uint8_t *qpack, hipStream_t s);
 

@@ -149,8 +149,9 @@ def indel_batch(seed, n_sites, n_smpl, depth=30.0, read_len=100, max_depth=200, 
     ref2 = rng.integers(0, 4, L)
     pos = (200 + 300 * np.arange(n_sites)).astype(np.int32)
     lens = np.array([-3, -2, -1, 1, 2, 3] if lens is None else list(lens))
-    max_len = int(max(3, np.abs(lens).max(), 0 if lens2 is None else np.abs(np.array(list(lens2))).max()))
-    assert max_len + 24 < read_len and max_len < 100
+    all_lens = np.concatenate([lens, [] if lens2 is None else np.array(list(lens2))]).astype(np.int64)
+    max_len = int(max(3, all_lens.max()))                              # the longest insertion (inside the read); deletions only widen the span
+    assert max_len + 24 < read_len and read_len - int(min(0, all_lens.min())) < 290      # (loci are 300 bases apart)
     w = 1.0 / np.abs(lens)
     itype = lens[rng.choice(len(lens), size=n_sites, p=w / w.sum())]
     ins2 = rng.integers(0, 4, (n_sites, max_len))

@@ -300,7 +300,7 @@ def main_wgs(a):
     def draw_lens(k):
         v = lens[rng.choice(3, k, p=w / w.sum())]
         lg = rng.random(k) < a.long_indel_frac
-        v[lg] = long_lens[rng.integers(0, len(long_lens), int(lg.sum()))]
+        v[lg] = long_lens[rng.choice(len(long_lens), int(lg.sum()), p=(1.0 / long_lens) / (1.0 / long_lens).sum())]      # weights 1/len as well
         return v * rng.choice([-1, 1], k)
     ilen = np.zeros(n, np.int64)                                   # > 0 insertion, < 0 deletion
     ioff = np.zeros(n, np.int64)                                   # query bases before the indel
@@ -472,7 +472,8 @@ def main_wgs(a):
                       "long_indel_frac": a.long_indel_frac,
                       "candidate_columns": nc, "realigned_columns": n_live, "indel_records": n_irec, "variant_records": int(nr_.value),
                       "indel_variant_records": int(inr_.value),
-                      "realignment_jobs": int(st.n_jobs), "realignment_wide_band_jobs": int(st.n_wide), "realignment_passes": int(st.n_passes)},
+                      "realignment_jobs": int(st.n_jobs), "realignment_wide_band_jobs": int(st.n_wide), "realignment_passes": int(st.n_passes),
+                      "realignment_jobs_by_band": dict(zip(["<=10", "11-15", "16-31", "32-43", "44-58", "59-73", "74-300", ">300"], [int(x) for x in st.band_jobs]))},
            "split_ms": {"snp_pipeline_and_compaction": split["snp"] / 2 * 1e3, "gap_prep_tile": split["gap"] / 2 * 1e3, "indel_pass_and_call": split["ipass"] / 2 * 1e3,
                         "realignment_kernels": float(st.kernel_ms)},
            "us_per_column": {"snp_pipeline_and_compaction": split["snp"] / 2 * 1e6 / n_sites, "gap_prep_tile": split["gap"] / 2 * 1e6 / n_sites,

@@ -585,7 +585,11 @@ typedef struct {
     float kernel_ms;             /* probaln_kernel launches, HIP events on the context's stream */
     float prepare_ms, finalize_ms, total_ms;   /* host typing/consensus, host scoring, whole call (wall clock) */
     uint64_t n_wide;             /* jobs whose band (|type| + 3 clipped as probaln_glocal clips it) is wider than the widest
-                                  * register-resident class: they ran in the rolling-row kernel (types of about 8 bp and more) */
+                                  * register-resident class (types of about 8 bp and more): the row of the pair-HMM lives in LDS */
+    uint64_t n_scratch;          /* ... of these, the jobs too wide (or too long) for LDS as well: rolling rows in a global scratch
+                                  * buffer (bands past 300, reads past 65 535 bases) */
+    uint32_t band_jobs[8];       /* jobs by band: <= 10 (a register class per width), 11-15, 16-31, 32-43 (the row in registers, D re-run),
+                                  * 44-58, 59-73 (the row in LDS), 74-300 (in LDS, sixteen jobs a wavefront), beyond (scratch) */
 } bcfgpu_gap_stats;
 int  bcfgpu_gap_prep_stats(const bcfgpu_ctx *ctx, bcfgpu_gap_stats *out);
 

@@ -31,7 +31,7 @@ def test_batched_gap_prep_matches_oracle(gpu_ctx_factory, n_sites, n_smpl, depth
     assert st.n_jobs > 0 and st.n_passes >= st.n_jobs and st.dp_cells > 0 and st.kernel_ms > 0
 
 
-LONG = (-40, -25, -12, -8, 8, 12, 25, 40)      # bands of 11..43: past PROBALN_BW_MAX, the rolling-row kernel
+LONG = (-40, -25, -12, -8, 8, 12, 25, 40)      # bands of 11..43: past PROBALN_BW_MAX, the row of the pair-HMM in LDS
 SHORT = (-3, -2, -1, 1, 2, 3)                  # bands of 4..6: the register-resident classes
 
 
@@ -41,11 +41,12 @@ SHORT = (-3, -2, -1, 1, 2, 3)                  # bands of 4..6: the register-res
     (8, 6, 30.0, 103, (-40, 40, -25, 25), SHORT, dict(min_support=2)),
     (12, 25, 12.0, 104, LONG, LONG, dict(per_sample_flt=1, min_frac=0.05)),   # two long types in a column
     (6, 100, 30.0, 105, (-9, -8, 8, 9, 7, -7), SHORT, {}),  # the boundary: |type| = 7 is the widest register class
+    (8, 16, 15.0, 106, (-90, -80, -74, -71, -70, 45, 60), SHORT, {}),   # bands past 73: sixteen jobs a wavefront (LDS holds no 64 such rows)
+    (5, 300, 30.0, 107, (10, -10, 15, -15, 47, -47), (8, -8, 2), {}),   # many jobs per band class: whole wavefronts, several launches' worth
 ])
 def test_long_indels_through_the_wide_band_kernel(gpu_ctx_factory, n_sites, n_smpl, depth, seed, lens, lens2, kw):
     """Indels of 8 bp and more: bam2bcf_indel.c:293-294 gives their realignment the band |type| + 3, wider than the widest
-    register-resident class, so probaln_glocal (:346, :352) runs in probaln_wide_kernel -- for every read of the column,
-    against that type.  The same column's short types stay in the register classes.  Every output of bcf_call_gap_prep
+    register-resident class, so probaln_glocal (:346, :352) runs in probaln_lds_kernel<64> (bands up to 73) or <16> (up to 300) -- for every read of the column, against that type.  The same column's short types stay in the register classes.  Every output of bcf_call_gap_prep
     (p->aux, types, inscns, indelreg, max_support, max_frac) against the oracle, through both entry points, on the product
     build (no environment switch)."""
     b = synth.indel_batch(seed, n_sites, n_smpl, depth=depth, lens=lens, lens2=lens2)
@@ -62,6 +63,7 @@ def test_long_indels_through_the_wide_band_kernel(gpu_ctx_factory, n_sites, n_sm
             long_seen += bool(((np.abs(t) >= 8) & (t != 10000)).any())
     assert live > 0 and long_seen > 0
     assert 0 < st.n_wide < st.n_jobs, (st.n_wide, st.n_jobs)      # wide-band jobs and register-class jobs in one call
+    assert st.n_scratch == 0                                     # (bands past 300 only)
     assert st.n_passes >= st.n_jobs // 2 and st.dp_cells > 0
     # the device-pool form: the same core fed from bcfgpu_pileup's pool
     pool = indeldrv.DevicePool(ctx, b)
