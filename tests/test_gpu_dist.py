@@ -104,3 +104,40 @@ def test_two_ranks_on_the_device_engine_match_one_context(tmp_path, gpu_ctx_fact
         sites.append(int(h["site"]))
         o += int(h["bytes"])
     assert o == len(got) and sites == sorted(sites) and len(sites) == n_rec
+
+
+def test_bench_rehearsal_two_ranks_match_one_process():
+    """bench.py's N > 1 path as the round-end driver starts it -- `python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2` -- rehearsed on one GPU (BCFGPU_BENCH_REHEARSE=1: both ranks share the device, the gather goes over gloo): the
+    JSON line's gathered bytes per step must be what the two ranks' shards compact to, i.e. twice what one process compacts from
+    the same per-rank tile (every rank draws its tile from the same seed + rank, so rank 0's share is the single run's).  The
+    launcher is a fresh child of pytest: nothing in it has touched the GPU before torch.distributed.run starts the ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "2", "--warmup", "1", "--sites", "2048", "--samples", "200", "--cpu-seconds", "0", "--cpu-all-cores", "0", "--extras", "0"]
+    env = dict(os.environ, BCFGPU_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def last_json(out):
+        for ln in reversed(out.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        raise AssertionError("no JSON line:\n" + out[-2000:])
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = last_json(one.stdout)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, (two.stderr or two.stdout)[-3000:]
+    j2 = last_json(two.stdout)
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and "rehearsal" in j2
+    assert j2["config"]["sites_per_step_per_gpu"] == j1["config"]["sites_per_step_per_gpu"] == 2048
+    b1 = j1["config"]["record_bytes_per_step_per_gpu"]
+    assert b1 > 0 and j2["config"]["record_bytes_per_step_per_gpu"] == b1          # rank 0's shard is the single process's tile
+    g = j2["config"]["gathered_bytes_last_step"]
+    assert g >= b1 and g > 0
+    # every rank's records arrive: the other rank's shard (another seed) compacts to about as much as rank 0's
+    assert 1.5 * b1 < g < 2.5 * b1, (g, b1)
+    assert j2["value"] > 0 and j2["ms_per_step"] > 0
