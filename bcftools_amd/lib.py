@@ -10,7 +10,9 @@ import subprocess
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libbcfgpu.so")
+# BCFGPU_SO: another build of the same library (tools/file_variants.sh, tools/so_variants.sh time experiment builds without
+# touching the in-tree product library)
+SO_PATH = os.environ.get("BCFGPU_SO") or os.path.join(_HERE, "libbcfgpu.so")
 _LIB = None
 
 

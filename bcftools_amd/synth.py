@@ -61,7 +61,7 @@ def numpy_tile(seed, n_sites, n_smpl, depth=30.0, var_rate=0.01, max_depth=200, 
     return host.HostTile(S, ref16, off.astype(np.uint32), rd, epos)
 
 
-def _torch_chunk(g, n_sites, S, dev, depth, var_rate, max_depth):
+def _torch_chunk(g, n_sites, S, dev, depth, var_rate, max_depth, fixed_depth=False):
     import torch
 
     def rnd(n):
@@ -80,6 +80,8 @@ def _torch_chunk(g, n_sites, S, dev, depth, var_rate, max_depth):
     afc = af.repeat_interleave(S)
     nalt = (rnd(n_sites * S) < afc).to(torch.int64) + (rnd(n_sites * S) < afc).to(torch.int64)
     n = torch.poisson(torch.full((n_sites * S,), float(depth), device=dev), generator=g).to(torch.int64).clamp_(0, max_depth)
+    if fixed_depth:                                  # (an experiment's shape: every cell equally deep, no lane of a wavefront waits for a deeper cell)
+        n = torch.full_like(n, int(depth))
     R = int(n.sum().item())
     cell = torch.repeat_interleave(torch.arange(n_sites * S, device=dev), n)
     site = cell // S
@@ -101,7 +103,7 @@ def _torch_chunk(g, n_sites, S, dev, depth, var_rate, max_depth):
     return ref16, n, rd32, epos
 
 
-def torch_tile(seed, n_sites, n_smpl, device, depth=30.0, var_rate=0.01, max_depth=200, chunk_cells=1 << 21):
+def torch_tile(seed, n_sites, n_smpl, device, depth=30.0, var_rate=0.01, max_depth=200, chunk_cells=1 << 21, fixed_depth=False):
     """Same shape of data generated on `device` with torch's Philox generator, in chunks of sites.
     Returns dict(ref16 i8, plp_off i32 (u32 bit pattern), rd i32 (u32 bit pattern), epos u8, n_reads, ...)."""
     import torch
@@ -113,7 +115,7 @@ def torch_tile(seed, n_sites, n_smpl, device, depth=30.0, var_rate=0.01, max_dep
     done = 0
     while done < n_sites:
         m = min(per, n_sites - done)
-        r16, n, rd32, ep = _torch_chunk(g, m, S, device, depth, var_rate, max_depth)
+        r16, n, rd32, ep = _torch_chunk(g, m, S, device, depth, var_rate, max_depth, fixed_depth)
         refs.append(r16); ns.append(n); rds.append(rd32); eps.append(ep)
         done += m
     n = torch.cat(ns)

@@ -47,6 +47,7 @@ def parse():
                                                           "the indel stage (configs[2] shape) in child processes and embed their results under \"extra\" (0: skip)")
     ap.add_argument("--indel-read-rate", type=float, default=0.005, help="wgs mode: fraction of reads that carry a noise indel (SURVEY 8d: 0.5 %%)")
     ap.add_argument("--true-indel-rate", type=float, default=0.01, help="wgs mode: true indel sites per column")
+    ap.add_argument("--fixed-depth", type=int, default=0, help="snp mode (experiment): 1 = every cell exactly --depth reads deep instead of Poisson(--depth)")
     ap.add_argument("--long-indel-frac", type=float, default=0.05, help="wgs mode: fraction of the indels (noise and true) that are 8-40 bases long")
     ap.add_argument("--indel-callers", type=int, default=1, help="indel mode: also time the host-pointer form of the stage on one 32-column batch (0: skip)")
     ap.add_argument("--mode", choices=["snp", "indel", "baq", "pileup", "gvcf", "mixed", "wgs"], default="snp",
@@ -945,7 +946,7 @@ def main():
     # one-wavefront-per-site kernels lose less to their last partial round (16384: 3.5, 32768: 3.7, 65536: 3.7 M sites/s)
     S, T = a.samples, (a.sites if a.sites is not None else 32768)
     # ---- synthetic tile, generated on the device; each rank owns a different region shard ----
-    tile = synth.torch_tile(a.seed + rank, T, S, dev, depth=a.depth, var_rate=a.var_rate)
+    tile = synth.torch_tile(a.seed + rank, T, S, dev, depth=a.depth, var_rate=a.var_rate, fixed_depth=bool(a.fixed_depth))
     torch.cuda.synchronize()
     R = tile["n_reads"]
 

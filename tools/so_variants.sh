@@ -1,15 +1,15 @@
 #!/bin/bash
 # Experiments on a GPU box with libraries built beforehand (bcftools_amd/variants/<name>.so, e.g. one object compiled with other flags):
-# each takes libbcfgpu.so's place in turn for one bench run under rocprofv3 --stats; the kernels whose names match are listed.
+# each is loaded in place of libbcfgpu.so (BCFGPU_SO, bcftools_amd/lib.py) for one bench run under rocprofv3 --stats; the kernels whose
+# names match are listed.  The product library is never touched.
 # usage: bash tools/so_variants.sh "<pattern>|<pattern>" "<bench args>"   -> gpurun_out/sovar.txt
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 PAT=$1; BARGS=$2
-cp $R/bcftools_amd/libbcfgpu.so /tmp/libbcfgpu.product.so
 : > $R/gpurun_out/sovar.txt
 for so in $R/bcftools_amd/variants/*.so; do
   name=$(basename $so .so)
-  cp $so $R/bcftools_amd/libbcfgpu.so
+  export BCFGPU_SO=$so
   cd /tmp; rm -rf /tmp/sv
   rocprofv3 --kernel-trace --stats -d /tmp/sv -o s --output-format csv -- python3 $R/bench.py $BARGS > /tmp/sv.log 2>&1 || { echo "$name: run failed" >> $R/gpurun_out/sovar.txt; tail -3 /tmp/sv.log; continue; }
   k=$(python3 -c "
@@ -26,5 +26,5 @@ for l in open('/tmp/sv.log'):
 " 2>/dev/null | tail -1)
   echo "$name: $v; $k" >> $R/gpurun_out/sovar.txt
 done
-cp /tmp/libbcfgpu.product.so $R/bcftools_amd/libbcfgpu.so
+unset BCFGPU_SO
 cat $R/gpurun_out/sovar.txt
