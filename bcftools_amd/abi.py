@@ -211,6 +211,7 @@ PROTOTYPES = {
     "bcfgpu_mplp_out_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "bcfgpu_truncated_cells": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "bcfgpu_errmod_plan": (C.c_int, [C.c_void_p, C.POINTER(Tile), C.POINTER(Tile), C.c_void_p, C.c_void_p]),
+    "bcfgpu_errmod_plan_visit": (C.c_int, [C.c_void_p, C.POINTER(Tile), C.c_void_p, C.POINTER(Tile), C.c_void_p, C.c_void_p]),
     "bcfgpu_errmod_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
     "bcfgpu_errmod_state": (C.c_uint64, [C.c_void_p]),
     "bcfgpu_depth_cap": (C.c_int, [C.POINTER(Reads), C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

@@ -57,6 +57,7 @@ struct DrawScanParams {
     const uint32_t *off, *rd;
     const int32_t *cols;            // indel pass: SNP-tile column of every site; NULL for the SNP pass
     const int32_t *ret;             // indel pass: bcf_call_gap_prep's return per site (only 0 is visited); NULL = all
+    const uint8_t *visit;           // SNP pass: 0 = mpileup_reg() passes the column over before bcf_call_glfgen (a position outside -t / -T targets, mpileup.c:330-335); NULL = all
     DrawEnt *ent; uint32_t *n_ent; uint32_t cap;
     uint32_t *bits;                 // the pass's bitmap (for the cells of columns without an indel pass)
     unsigned long long *tot_usable;
@@ -81,12 +82,13 @@ __global__ __launch_bounds__(256) void draw_scan_kernel(const DrawScanParams P)
     uint32_t n = 0;
     for (uint32_t i = b; i < e; ++i) n += draw_usable(P.rd[i], P.is_indel != 0, (uint32_t)P.min_baseQ) ? 1u : 0u;
     if (n <= BCFGPU_MAX_DEPTH) return;
-    if (P.is_indel && P.ret && P.ret[site] != 0) {
-        // the indel pass does not run there (mpileup.c:354): no draw is spent on the cell and nothing of it is written out; its
-        // first 255 usable reads are marked so that the likelihood kernel has a complete plan and counts nothing as cut
+    if ((P.is_indel && P.ret && P.ret[site] != 0) || (!P.is_indel && P.visit && !P.visit[site])) {
+        // the pass does not run there (mpileup.c:354; :330-335 for a column outside the targets): no draw is spent on the cell and
+        // nothing of it is written out; its first 255 usable reads are marked so that the likelihood kernel has a complete plan and
+        // counts nothing as cut
         uint32_t m = 0;
         for (uint32_t i = b; i < e && m < BCFGPU_MAX_DEPTH; ++i)
-            if (draw_usable(P.rd[i], true, (uint32_t)P.min_baseQ)) { atomicOr(&P.bits[i >> 5], 1u << (i & 31)); ++m; }
+            if (draw_usable(P.rd[i], P.is_indel != 0, (uint32_t)P.min_baseQ)) { atomicOr(&P.bits[i >> 5], 1u << (i & 31)); ++m; }
         return;
     }
     const uint32_t slot = atomicAdd(P.n_ent, 1u);
@@ -136,7 +138,14 @@ using namespace bcfgpu;
 
 #define DR_CHK(call) do { if ((call) != hipSuccess) return bcfgpu_set_error(BCFGPU_E_HIP, #call); } while (0)
 
+extern "C" int bcfgpu_errmod_plan_visit(bcfgpu_ctx *ctx, const bcfgpu_tile *snp, const uint8_t *snp_visit, const bcfgpu_tile *indel, const int32_t *indel_cols,
+                                        const int32_t *indel_ret);
 extern "C" int bcfgpu_errmod_plan(bcfgpu_ctx *ctx, const bcfgpu_tile *snp, const bcfgpu_tile *indel, const int32_t *indel_cols, const int32_t *indel_ret)
+{
+    return bcfgpu_errmod_plan_visit(ctx, snp, nullptr, indel, indel_cols, indel_ret);
+}
+extern "C" int bcfgpu_errmod_plan_visit(bcfgpu_ctx *ctx, const bcfgpu_tile *snp, const uint8_t *snp_visit, const bcfgpu_tile *indel, const int32_t *indel_cols,
+                                        const int32_t *indel_ret)
 {
     if (!ctx || (!snp && !indel)) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_errmod_plan: bad arguments");
     if (indel && indel->n_sites && !indel_cols) return bcfgpu_set_error(BCFGPU_E_ARG, "bcfgpu_errmod_plan: the indel tile's columns are needed");
@@ -169,11 +178,17 @@ extern "C" int bcfgpu_errmod_plan(bcfgpu_ctx *ctx, const bcfgpu_tile *snp, const
         DR_CHK(hipMemcpyAsync(d_cols, indel_cols, (size_t)indel->n_sites * 4, hipMemcpyHostToDevice, stream));
         if (indel_ret) { d_ret = d_cols + indel->n_sites; DR_CHK(hipMemcpyAsync(d_ret, indel_ret, (size_t)indel->n_sites * 4, hipMemcpyHostToDevice, stream)); }
     }
+    uint8_t *d_visit = nullptr;
+    if (snp && snp_visit && snp->n_sites) {
+        d_visit = (uint8_t*)bcfgpu_internal_ws(ctx, 146, (size_t)snp->n_sites + 64);
+        if (!d_visit) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_errmod_plan: device workspace");
+        DR_CHK(hipMemcpyAsync(d_visit, snp_visit, (size_t)snp->n_sites, hipMemcpyHostToDevice, stream));
+    }
     for (int t = 0; t < 2; ++t) {
         if (!tiles[t] || !tiles[t]->n_sites || !n_reads[t]) continue;
         DrawScanParams Q{};
         Q.n_sites = tiles[t]->n_sites; Q.n_smpl = S; Q.is_indel = t; Q.min_baseQ = cfg->min_baseQ < 0 ? 0 : cfg->min_baseQ;
-        Q.off = tiles[t]->plp_off; Q.rd = tiles[t]->rd; Q.cols = t ? d_cols : nullptr; Q.ret = t ? d_ret : nullptr;
+        Q.off = tiles[t]->plp_off; Q.rd = tiles[t]->rd; Q.cols = t ? d_cols : nullptr; Q.ret = t ? d_ret : nullptr; Q.visit = t ? nullptr : d_visit;
         Q.bits = bits[t]; Q.ent = d_ent; Q.n_ent = reinterpret_cast<uint32_t*>(d_ctr); Q.cap = cap; Q.tot_usable = d_ctr + 1;
         const long ncells = (long)Q.n_sites * S;
         hipLaunchKernelGGL(draw_scan_kernel, dim3((unsigned)((ncells + 255) / 256)), dim3(256), 0, stream, Q);

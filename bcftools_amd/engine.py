@@ -156,7 +156,7 @@ class Context:
             self.release(tb + list(ob.values()))
         return res
 
-    def mpileup_planned(self, snp, indel=None, cols=None, ret=None):
+    def mpileup_planned(self, snp, indel=None, cols=None, ret=None, visit=None):
         """bcfgpu_errmod_plan over the two passes of a tile, then bcfgpu_mpileup of each: the over-deep cells' likelihoods come from
         errmod_cal's own draw (hts_drand48, the context's generator), in mpileup_reg()'s visit order.  snp / indel: HostTiles (indel
         may be None); cols: the SNP-tile column of every indel site; ret: bcf_call_gap_prep's return per indel site (None: all 0).
@@ -167,8 +167,13 @@ class Context:
         try:
             c = None if cols is None else np.ascontiguousarray(cols, dtype=np.int32)
             r = None if ret is None else np.ascontiguousarray(ret, dtype=np.int32)
-            check(self.L.bcfgpu_errmod_plan(self.h, C.byref(ds), C.byref(di) if di is not None else None,
-                                            None if c is None else c.ctypes.data, None if r is None else r.ctypes.data))
+            if visit is None:
+                check(self.L.bcfgpu_errmod_plan(self.h, C.byref(ds), C.byref(di) if di is not None else None,
+                                                None if c is None else c.ctypes.data, None if r is None else r.ctypes.data))
+            else:                                            # visit: 0 = mpileup_reg() passes the SNP-tile column over (outside the targets)
+                v = np.ascontiguousarray(visit, dtype=np.uint8)
+                check(self.L.bcfgpu_errmod_plan_visit(self.h, C.byref(ds), v.ctypes.data, C.byref(di) if di is not None else None,
+                                                      None if c is None else c.ctypes.data, None if r is None else r.ctypes.data))
             for dt, t in ((ds, snp), (di, indel)):
                 if dt is None:
                     outs.append(None)

@@ -1134,7 +1134,7 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
     int nc = 0;
     int32_t *cand = malloc((size_t)(n_sites + 1) * sizeof *cand);
     for (int k = 0; k < n_sites; ++k)
-        if (!no_indels && col_indel[k] && col_n[k] < max_indel_depth * S) cand[nc++] = k;     /* mpileup.c:354 */
+        if (!no_indels && col_indel[k] && col_n[k] < max_indel_depth * S && target_keeps_column(contig, t0 + k)) cand[nc++] = k;     /* mpileup.c:330-335, :354 */
     bcfgpu_site *isite = NULL;
     planes_t ind_planes; memset(&ind_planes, 0, sizeof ind_planes); int32_t *live = NULL; int nlive = 0;
     int32_t *g_types = NULL, *g_maxins = NULL, *g_indelreg = NULL, *g_support = NULL; float *g_frac = NULL; int8_t *g_inscns = NULL;
@@ -1161,8 +1161,11 @@ static void process_tile(pool_t *P, const int *first, int F, int S, const char *
     {
         int32_t *live_col = malloc((size_t)(nlive + 1) * 4);                 /* the SNP-tile column of every site of the indel tile */
         for (int j = 0; j < nlive; ++j) live_col[j] = cand[live[j]];
-        CHECK(bcfgpu_errmod_plan(ctx, &tile, nlive ? &ti : NULL, live_col, NULL));
-        free(live_col);
+        /* a column outside the targets is passed over before bcf_call_glfgen (mpileup.c:330-335): errmod_cal spends no draw there */
+        uint8_t *visit = malloc((size_t)n_sites + 1);
+        for (int k = 0; k < n_sites; ++k) visit[k] = (uint8_t)target_keeps_column(contig, t0 + k);
+        CHECK(bcfgpu_errmod_plan_visit(ctx, &tile, visit, nlive ? &ti : NULL, live_col, NULL));
+        free(live_col); free(visit);
     }
     /* ---- the SNP pass, then the indel pass on the tile gap_prep left (the columns where it returned 0, mpileup.c:354-360) ---- */
     void *d_site = NULL, *d_pl = NULL, *d_dp4 = NULL;

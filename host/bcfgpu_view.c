@@ -16,6 +16,7 @@
 
 
 /* 0: the record went out through vio_write_record_int; 1: it does not qualify (the caller writes the text line) */
+static int int_pad = 0;         /* --int-columns-pad N: the columns handed over N values wider than any sample needs (a caller with fixed-width planes) */
 static int write_int_columns(vio_file *fo, const vio_hdr *h, char *line, long *n_done)
 {
     const int S = vio_hdr_nsamples(h);
@@ -40,7 +41,7 @@ static int write_int_columns(vio_file *fo, const vio_hdr *h, char *line, long *n
         if (*q) ++q;
     }
     int32_t *col[32];
-    for (int k = 0; k < nk; ++k) col[k] = malloc((size_t)S * (size_t)width[k] * 4);
+    for (int k = 0; k < nk; ++k) { width[k] += int_pad; col[k] = malloc((size_t)S * (size_t)width[k] * 4); }
     q = smp + 1;
     int ok = 1;
     for (int s = 0; s < S && ok; ++s)
@@ -78,6 +79,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
         else if (!strcmp(argv[i], "-H")) no_hdr = 1;
         else if (!strcmp(argv[i], "--int-columns")) int_cols = 1;
+        else if (!strcmp(argv[i], "--int-columns-pad") && i + 1 < argc) { int_cols = 1; int_pad = atoi(argv[++i]); }
         else in = argv[i];
     }
     if (!in) { fprintf(stderr, "usage: bcfgpu_view [-O v|z|u|b] [-o out] [-H] <in|->\n"); return 2; }

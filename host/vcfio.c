@@ -519,7 +519,22 @@ static int encode_record(const vio_hdr *h, const char *line, sbuf *out, int n_ke
             const int d = fkey[k];
             if (h->dict[d].fmt_type != T_INT || !strcmp(h->dict[d].id, "GT") || width[k] < 1) { free(sh.s); free(in.s); return fail("FORMAT/%s cannot be written from integer columns", h->dict[d].id); }
             enc_int1(&in, d);
-            if (S * width[k] == 1) enc_int1(&in, vals[k][0]); else enc_vint(&in, S * width[k], vals[k], width[k]);
+            /* the vector's length is that of the sample with most values, as the text path sizes it: columns where every sample
+             * ends early (VIO_INT_VEND) are not written */
+            int w = 1;
+            for (int s2 = 0; s2 < S && w < width[k]; ++s2) {
+                const int32_t *v = vals[k] + (size_t)s2 * width[k];
+                int c = width[k];
+                while (c > 1 && v[c - 1] == VIO_INT_VEND) --c;
+                if (c > w) w = c;
+            }
+            if (w == width[k]) { if (S * w == 1) enc_int1(&in, vals[k][0]); else enc_vint(&in, S * w, vals[k], w); }
+            else {
+                int32_t *t = malloc((size_t)S * (size_t)w * sizeof *t);
+                for (int s2 = 0; s2 < S; ++s2) memcpy(t + (size_t)s2 * w, vals[k] + (size_t)s2 * width[k], (size_t)w * sizeof *t);
+                if (S * w == 1) enc_int1(&in, t[0]); else enc_vint(&in, S * w, t, w);
+                free(t);
+            }
         }
     } else
     /* per-sample fields: the columns of every sample split once */

@@ -285,6 +285,11 @@ int  bcfgpu_truncated_cells(bcfgpu_ctx *ctx, uint32_t *n_cells);
  * Synchronises the stream.  Without a plan the first 255 usable reads of such a cell are taken (see above).
  * bcfgpu_errmod_seed / _state: the generator's 48-bit state (a new context starts at 0x1234ABCD330E, a fresh process). */
 int  bcfgpu_errmod_plan(bcfgpu_ctx *ctx, const bcfgpu_tile *snp, const bcfgpu_tile *indel, const int32_t *indel_cols, const int32_t *indel_ret);
+/* The same with the columns mpileup_reg() passes over before either pass (positions outside the -t / -T targets, mpileup.c:330-335:
+ * no bcf_call_glfgen there, hence no draw): snp_visit HOST [snp->n_sites] or NULL, 0 = the column is not visited.  (Indel sites on
+ * such columns: give them a non-zero indel_ret, or leave them out of the indel tile.) */
+int  bcfgpu_errmod_plan_visit(bcfgpu_ctx *ctx, const bcfgpu_tile *snp, const uint8_t *snp_visit, const bcfgpu_tile *indel,
+                              const int32_t *indel_cols, const int32_t *indel_ret);
 int  bcfgpu_errmod_seed(bcfgpu_ctx *ctx, uint64_t state);
 uint64_t bcfgpu_errmod_state(bcfgpu_ctx *ctx);
 /* enqueue on an externally owned hipStream_t (e.g. torch's current stream); NULL = the context's own */

@@ -81,6 +81,30 @@ def test_draw_of_both_passes_in_visit_order(gpu_ctx_factory, seed):
     assert_mplp_equal(got3, first)
 
 
+def test_columns_outside_the_targets_spend_no_draw(gpu_ctx_factory):
+    """mpileup -t / -T: mpileup_reg() passes a position outside the targets over before bcf_call_glfgen (mpileup.c:330-335), so a
+    cell of more than 255 reads there takes nothing from hts_drand48 -- the deep cells of the visited columns draw what a reference run
+    over the visited columns alone would (bcfgpu_errmod_plan_visit)."""
+    rng = np.random.default_rng(21)
+    n_smpl, n_sites = 2, 6
+    ds = rng.poisson(40, n_sites * n_smpl)
+    for c in (0, 3, 4, 7, 10):
+        ds[c] = rng.integers(300, 1200)
+    snp = _tile(rng, n_sites, n_smpl, ds)
+    visit = np.array([1, 0, 1, 1, 0, 1], np.uint8)                # columns 1 and 4 lie outside the targets (cells 3 and 8, 9: deep cell 3)
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(snp.rd))
+    ctx = gpu_ctx_factory(cfg)
+    kept = np.nonzero(visit)[0]
+    want = orc.mpileup(cfg, snp.select_sites(list(kept)), deep_rule=0)             # the reference's run: the visited columns, one generator
+    state = int(orc.lib().orc_rand48_state())
+    got, _ = ctx.mpileup_planned(snp, visit=visit)
+    for k in ("pl", "dp4", "adf", "adr", "qs"):
+        np.testing.assert_array_equal(getattr(got, k)[kept], getattr(want, k), err_msg=k)
+    assert int(ctx.L.bcfgpu_errmod_state(ctx.h)) == state
+    n = abi.C.c_uint32()
+    assert ctx.L.bcfgpu_truncated_cells(ctx.h, abi.C.byref(n)) == 0 and n.value == 0
+
+
 def test_without_a_plan_the_first_255_are_taken(gpu_ctx_factory):
     rng = np.random.default_rng(9)
     snp = _tile(rng, 2, 2, [400, 30, 20, 700])

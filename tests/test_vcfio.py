@@ -152,3 +152,15 @@ def test_records_from_integer_columns_are_the_text_line_byte_for_byte(golden_dir
             if mode == "u":
                 total += int(p.stderr.split()[0])
     assert total > 5000
+
+
+def test_integer_columns_wider_than_any_sample_needs(golden_dir, tmp_path):
+    """A caller with fixed-width planes hands over columns in which EVERY sample ends early (VIO_INT_VEND in the last places): the
+    vector written is as long as the longest sample's, as the text path sizes it -- the same BCF2 bytes, not a wider vector."""
+    build()
+    f = [g for g in goldens(golden_dir) if g.endswith(os.path.join("mpileup", "mpileup.2.out"))][0]
+    a, b = str(tmp_path / "a.u"), str(tmp_path / "b.u")
+    subprocess.check_call([VIEW, "-O", "u", "-o", a, f])
+    p = subprocess.run([VIEW, "--int-columns-pad", "2", "-O", "u", "-o", b, f], stderr=subprocess.PIPE, universal_newlines=True, check=True)
+    assert int(p.stderr.split()[0]) > 100
+    assert open(a, "rb").read() == open(b, "rb").read()
