@@ -685,6 +685,7 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
         uint32_t *d_k0 = (uint32_t*)WS(32, nj * 4), *d_v0 = (uint32_t*)WS(33, nj * 4), *d_k1 = (uint32_t*)WS(34, nj * 4), *d_v1 = (uint32_t*)WS(35, nj * 4);
         uint32_t *d_list2 = (uint32_t*)WS(36, nj * 4);
         ProbalnQueue *d_queue = (ProbalnQueue*)WS(38, sizeof(ProbalnQueue));
+        double2 *d_emt = (double2*)bcfgpu_internal_ws(ctx, 147, 256 * sizeof(double2));
         int32_t *d_sumq = (int32_t*)WS(39, (size_t)ns * 64 * 4);
         uint8_t *d_otype = (uint8_t*)WS(40, (size_t)ns * 64);
         size_t sort_bytes = 0;
@@ -692,7 +693,7 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
         void *d_sort = WS(37, sort_bytes);
         if (out->inscns) d_oinscns = (int8_t*)WS(22, (size_t)ns * 4 * inscns_cap);
         if (!d_inscnt || !d_inscns || !d_ref2 || !d_s1 || !d_s2 || !d_wide || !d_ent || !d_qpack || !d_pjob || !d_k0 || !d_v0 || !d_k1 || !d_v1 ||
-            !d_list2 || !d_queue || !d_sort || !d_sumq || !d_otype || (out->inscns && !d_oinscns))
+            !d_list2 || !d_queue || !d_emt || !d_sort || !d_sumq || !d_otype || (out->inscns && !d_oinscns))
             return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep: device workspace");
         if (tot.ins_bytes) { GP_CHK(hipMemsetAsync(d_inscnt, 0, (size_t)tot.ins_bytes * 5 * 4, st)); GP_CHK(hipMemsetAsync(d_inscns, 0, (size_t)tot.ins_bytes, st)); }
         GP_CHK(hipMemsetAsync(d_s1, 0, nj * 4, st)); GP_CHK(hipMemsetAsync(d_s2, 0, nj * 4, st));
@@ -707,7 +708,7 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
         ProbalnParams p{};
         p.ent = d_ent;
         p.gin = g; p.sites = d_sites; p.n_sites = ns; p.n_jobs = (int)nj;
-        p.ref2 = d_ref2; p.qpack = d_qpack; p.q2p = q2p; p.score1 = d_s1; p.score2 = d_s2;
+        p.ref2 = d_ref2; p.qpack = d_qpack; p.q2p = q2p; p.emt = d_emt; p.score1 = d_s1; p.score2 = d_s2;
         p.pjob = d_pjob; p.key_in = d_k0; p.val_in = d_v0; p.key_sorted = d_k1; p.val_sorted = d_v1; p.list2 = d_list2; p.queue = d_queue;
         p.wide = d_wide; p.tot = d_tot;
         p.n_lds_hint = tot.max_bw > PROBALN_BW_MAX ? 1 : 0;           // some site has a type of 8 bases or more
@@ -733,7 +734,8 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
             ProbalnQueue hq;
             memcpy(&hq, h_small + sizeof(GapTotals), sizeof hq);
             gs.band_jobs[0] = hq.cls_begin[PROBALN_CLS_LDS] - hq.cls_begin[PROBALN_BW_MIN];
-            for (int g = 0; g <= PROBALN_LDS_GROUPS; ++g) gs.band_jobs[1 + g] = hq.lds_begin[g + 1] - hq.lds_begin[g];
+            for (int g = 0; g < PROBALN_LDS_GROUPS; ++g) gs.band_jobs[1 + g] = hq.lds_begin[g + 1] - hq.lds_begin[g];
+            gs.band_jobs[1 + PROBALN_LDS_GROUPS] = hq.lds_begin[PROBALN_LDS_GROUPS + 2] - hq.lds_begin[PROBALN_LDS_GROUPS];
             gs.band_jobs[7] = tot.n_wide;
         }
         gs.n_wide = (uint64_t)tot.n_wide + tot.n_lds; gs.n_scratch = tot.n_wide;

@@ -438,16 +438,17 @@ __global__ void probaln_bounds_kernel(const uint32_t *key_sorted, int n, Probaln
     while (lo < hi) { const int mid = (lo + hi) >> 1; if ((key_sorted[mid] >> 13) >= (uint32_t)c) hi = mid; else lo = mid + 1; }
     q->cls_begin[c] = (uint32_t)lo;
     if (c < 16) { q->next1[c] = 0; q->next2[c] = 0; q->n2[c] = 0; }
-    if (c <= PROBALN_LDS_GROUPS + 1) {
+    if (c <= PROBALN_LDS_GROUPS + 2) {
         // group g of the LDS class: the jobs with band widths in (cap[g-1], cap[g]]; lds_begin[g] = keys below class | (cap[g-1] + 1) << 6;
-        // the last range is the sixteen-jobs-a-wavefront class
+        // the last two ranges are the sixteen-jobs-a-wavefront class (its key holds the band width >> 2)
         const int caps[PROBALN_LDS_GROUPS] = PROBALN_LDS_CAPS;
         const uint32_t thr = c == 0 ? PROBALN_CLS_LDS << 13 : c == PROBALN_LDS_GROUPS ? PROBALN_CLS_LDS16 << 13
-                           : c == PROBALN_LDS_GROUPS + 1 ? (PROBALN_CLS_LDS16 + 1) << 13 : PROBALN_CLS_LDS << 13 | (uint32_t)(caps[c - 1] + 1) << 6;
+                           : c == PROBALN_LDS_GROUPS + 1 ? PROBALN_CLS_LDS16 << 13 | (uint32_t)((PROBALN_LDS16_SPLIT >> 2) + 1) << 6
+                           : c == PROBALN_LDS_GROUPS + 2 ? (PROBALN_CLS_LDS16 + 1) << 13 : PROBALN_CLS_LDS << 13 | (uint32_t)(caps[c - 1] + 1) << 6;
         int a = 0, b = n;
         while (a < b) { const int mid = (a + b) >> 1; if (key_sorted[mid] >= thr) b = mid; else a = mid + 1; }
         q->lds_begin[c] = (uint32_t)a;
-        if (c <= PROBALN_LDS_GROUPS) q->lds_next[c] = 0;
+        if (c <= PROBALN_LDS_GROUPS + 1) q->lds_next[c] = 0;
     }
 }
 
@@ -458,16 +459,13 @@ __global__ void probaln_bounds_kernel(const uint32_t *key_sorted, int n, Probaln
 template <int BW, int PASS>
 __global__ __launch_bounds__(64) void probaln_exact_kernel(const ProbalnParams P)
 {
-    __shared__ double2 s_emt[256];
+    // (the emission table is read from device memory -- 4 KB, resident in every CU's cache -- not from LDS: a workgroup of this
+    // kernel then needs no LDS at all and fits beside the wide-band classes' workgroups, which take a CU's whole LDS)
+    const double2 *s_emt = P.emt;
     ProbalnQueue *Q = P.queue;
     const uint32_t c0 = Q->cls_begin[BW];
     const uint32_t n = PASS == 1 ? Q->cls_begin[BW + 1] - c0 : Q->n2[BW];
     if (n == 0) return;                                   // (the same for every wavefront of the launch)
-    for (int b = threadIdx.x; b < 256; b += 64) {
-        const double ql = (double)P.q2p[b >> 3];
-        s_emt[b] = (b & 7) > 3 ? make_double2(1., 1.) : make_double2(1. - ql, ql * EM);
-    }
-    __syncthreads();
     unsigned long long cells = 0, passes = 0;
     const double gd = PASS == 1 ? 1e-4 : 1e-6, ge = PASS == 1 ? 1e-2 : 1e-3;
     for (;;) {
@@ -838,16 +836,11 @@ __device__ __forceinline__ int probaln_fwd_regs(const uint8_t *ref, int l_ref, c
 template <int NC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void probaln_regs_kernel(const ProbalnParams P, int grp)
 {
-    __shared__ double2 s_emt[256];
+    const double2 *s_emt = P.emt;                             // (device memory, not LDS: see probaln_exact_kernel)
     __builtin_amdgcn_s_setprio(2);                            // (one wavefront a SIMD with a long chunk each: ahead of the register classes' three or four)
     ProbalnQueue *Q = P.queue;
     const uint32_t c0 = Q->lds_begin[grp], n = Q->lds_begin[grp + 1] - c0;
     if (n == 0) return;
-    for (int b = threadIdx.x; b < 256; b += 64) {
-        const double ql = (double)P.q2p[b >> 3];
-        s_emt[b] = (b & 7) > 3 ? make_double2(1., 1.) : make_double2(1. - ql, ql * EM);
-    }
-    __syncthreads();
     unsigned long long cells = 0, passes = 0;
     for (;;) {
         uint32_t base = 0;
@@ -971,8 +964,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void pr
     if (threadIdx.x == 0 && passes) { atomicAdd(&P.tot->n_passes, passes); atomicAdd(&P.tot->dp_cells, cells); }
 }
 
+// the emission values of a (query base, capped quality) byte: (match, mismatch) = (1 - 10^(-q/10), 10^(-q/10) / 3); an N in the read: (1, 1)
+__global__ void probaln_emt_kernel(const float *q2p, double2 *emt)
+{
+    const int b = threadIdx.x;
+    const double ql = (double)q2p[b >> 3];
+    emt[b] = (b & 7) > 3 ? make_double2(1., 1.) : make_double2(1. - ql, ql * EM);
+}
 void launch_probaln_jobs(const ProbalnParams &p, hipStream_t s)
 {
+    hipLaunchKernelGGL(probaln_emt_kernel, dim3(1), dim3(256), 0, s, p.q2p, p.emt);
     if (p.n_jobs > 0) hipLaunchKernelGGL(probaln_jobs_kernel, dim3((p.n_jobs + 255) / 256), dim3(256), 0, s, p);
 }
 void launch_probaln_bounds(const ProbalnParams &p, hipStream_t s)
@@ -984,7 +985,7 @@ template <int BW> static void launch_exact_class(const ProbalnParams &p, hipStre
     hipLaunchKernelGGL((probaln_exact_kernel<BW, 1>), dim3(grid), dim3(64), 0, s, p);
     hipLaunchKernelGGL((probaln_exact_kernel<BW, 2>), dim3(grid), dim3(64), 0, s, p);
 }
-// Both passes of every band width, on three streams between a fork and a join on the caller's (side[0..1], ev[0..2] and ev[8]
+// Both passes of every band width, on four streams between a fork and a join on the caller's (side[0..2], ev[0..2] and ev[8]
 // from the context; the runtime spreads streams over four hardware queues, so more streams would only queue up behind one
 // another).  Every launch is a grid of persistent wavefronts pulling 64 jobs at a time from its class's counter, so a class with
 // few jobs costs one such chunk, not a launch's worth of idle machine; the two chains of machine-filling launches share the
@@ -997,23 +998,27 @@ int launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu, hipStr
     unsigned grid = (unsigned)n_cu * 4u * 3u;
     const unsigned need = (unsigned)((p.n_jobs + 63) / 64);
     if (grid > need) grid = need;
-    hipStream_t tail = side[0], second = side[1];
+    hipStream_t tail = side[0], second = side[1], tail2 = side[2];
     if (hipEventRecord(ev[8], s) != hipSuccess) return -1;
-    if (hipStreamWaitEvent(tail, ev[8], 0) != hipSuccess || hipStreamWaitEvent(second, ev[8], 0) != hipSuccess) return -1;
+    if (hipStreamWaitEvent(tail, ev[8], 0) != hipSuccess || hipStreamWaitEvent(second, ev[8], 0) != hipSuccess ||
+        hipStreamWaitEvent(tail2, ev[8], 0) != hipSuccess) return -1;
     if (p.n_lds_hint != 0) {
         static const int caps[PROBALN_LDS_GROUPS] = PROBALN_LDS_CAPS;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(probaln_lds_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(probaln_lds_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
-        {
-            const int wcells = PROBALN_LDS_CELLS(PROBALN_LDS16_MAX);
+        // the sixteen-jobs class: bands to PROBALN_LDS16_SPLIT (the bulk: 58 KB, two workgroups a CU) on one stream, the rest behind it
+        for (int h = 0; h < 2; ++h) {
+            const int wcells = PROBALN_LDS_CELLS(h == 0 ? PROBALN_LDS16_SPLIT : PROBALN_LDS16_MAX);
             const size_t lds = (size_t)wcells * 16 * 16 + 256 * sizeof(double2);
-            hipLaunchKernelGGL(probaln_lds_kernel<16>, dim3(std::min((unsigned)n_cu, need)), dim3(64), lds, tail, p, PROBALN_LDS_GROUPS, wcells);
+            const unsigned per_cu = (unsigned)((160 * 1024) / lds);
+            hipLaunchKernelGGL(probaln_lds_kernel<16>, dim3(std::min((unsigned)n_cu * per_cu, need)), dim3(64), lds, tail, p, PROBALN_LDS_GROUPS + h, wcells);
         }
+        // bands 44 .. 73, 64 jobs a wavefront, on a stream of their own beside the sixteen-jobs class
         for (int g = PROBALN_LDS_GROUPS - 1; g >= 3; --g) {
             const int wcells = PROBALN_LDS_CELLS(caps[g]);
             const size_t lds = (size_t)wcells * 64 * 16 + 256 * sizeof(double2);
             const unsigned per_cu = (unsigned)((160 * 1024) / lds);
-            hipLaunchKernelGGL(probaln_lds_kernel<64>, dim3(std::min((unsigned)n_cu * per_cu, need)), dim3(64), lds, tail, p, g, wcells);
+            hipLaunchKernelGGL(probaln_lds_kernel<64>, dim3(std::min((unsigned)n_cu * per_cu, need)), dim3(64), lds, tail2, p, g, wcells);
         }
         // bands 11 .. 43: the row in registers, one wavefront a SIMD
         hipLaunchKernelGGL(probaln_regs_kernel<11>, dim3(std::min((unsigned)n_cu * 4u, need)), dim3(64), 0, second, p, 2);
@@ -1026,6 +1031,7 @@ int launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu, hipStr
     launch_exact_class<4>(p, second, grid);  launch_exact_class<3>(p, s, grid);
     if (hipEventRecord(ev[0], tail) != hipSuccess || hipStreamWaitEvent(s, ev[0], 0) != hipSuccess) return -1;
     if (hipEventRecord(ev[1], second) != hipSuccess || hipStreamWaitEvent(s, ev[1], 0) != hipSuccess) return -1;
+    if (hipEventRecord(ev[2], tail2) != hipSuccess || hipStreamWaitEvent(s, ev[2], 0) != hipSuccess) return -1;
     return 0;
 }
 void launch_probaln_wide(const ProbalnParams &p, hipStream_t s)

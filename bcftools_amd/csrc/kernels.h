@@ -202,6 +202,7 @@ struct GapTotals {
 #define PROBALN_BW_MAX 10
 #define PROBALN_LDS_MAX 73                       // 64 jobs a wavefront: (2 * 73 + 1 -> 152 cells + 2) x 64 lanes x 16 bytes + the emission table <= 160 KiB
 #define PROBALN_LDS16_MAX 300                    // 16 jobs a wavefront: 610 cells x 16 lanes x 16 bytes
+#define PROBALN_LDS16_SPLIT 103                  // ... in two launches: bands to 103 (210 cells: 58 KB, two workgroups a CU) and the rest
 #define PROBALN_LDS_GROUPS 5
 #define PROBALN_CLS_LDS 11u
 #define PROBALN_CLS_LDS16 12u
@@ -212,8 +213,8 @@ struct ProbalnQueue {
     uint32_t cls_begin[17];                      // first sorted slot of every class (class = key >> 13)
     uint32_t next1[16], next2[16];               // work counters of the two passes
     uint32_t n2[16];                             // jobs listed for the second parameter set, per class
-    uint32_t lds_begin[PROBALN_LDS_GROUPS + 2];  // class PROBALN_CLS_LDS: first sorted slot of every band-width group; then class PROBALN_CLS_LDS16
-    uint32_t lds_next[PROBALN_LDS_GROUPS + 1];   // work counters of the groups
+    uint32_t lds_begin[PROBALN_LDS_GROUPS + 3];  // class PROBALN_CLS_LDS: first sorted slot of every band-width group; then class PROBALN_CLS_LDS16: bands to PROBALN_LDS16_SPLIT, wider
+    uint32_t lds_next[PROBALN_LDS_GROUPS + 2];   // work counters of the groups
 };
 // the widest band of every group of the LDS class (host and device), and the cells a lane's column needs for a band: whole
 // groups of eight cells and a guard cell at either end
@@ -227,6 +228,7 @@ struct ProbalnParams {
     const uint8_t *ref2;                         // realignment targets, base codes 0..4
     const uint8_t *qpack;                        // packed queries (gap_qpack_kernel)
     const float *q2p;                            // 10^(-q/10) as float, q = 0..255 (htslib g_qual2prob)
+    double2 *emt;                                // [256] emission values by packed query byte (probaln_emt_kernel)
     int32_t *score1, *score2;                    // sc<<8 | norm, bam2bcf_indel.c:348-356
     PJob *pjob;                                  // [n_jobs]
     uint32_t *key_in, *val_in;                   // [n_jobs] sort keys and job numbers as probaln_jobs_kernel writes them
