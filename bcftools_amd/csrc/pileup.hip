@@ -702,6 +702,16 @@ static int pool_upload_impl(const char *who, bcfgpu_ctx *ctx, const bcfgpu_reads
     return BCFGPU_OK;
 }
 
+namespace bcfgpu {
+__global__ __launch_bounds__(256) void col_counts_kernel(const uint32_t *off, const uint32_t *col_indel, int n_sites, int S, uint32_t *out)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_sites) return;
+    out[2 * k] = off[(size_t)(k + 1) * S] - off[(size_t)k * S];
+    out[2 * k + 1] = col_indel[k];
+}
+}  // namespace bcfgpu
+
 static int pool_pileup_impl(const char *who, bcfgpu_ctx *ctx, const int32_t *r_smpl, const int32_t *given_off, int32_t beg, int32_t end,
                             const char *ref, int32_t ref_len, bcfgpu_tile *tile, int32_t *col_n, uint8_t *col_indel)
 {
@@ -846,20 +856,18 @@ static int pool_pileup_impl(const char *who, bcfgpu_ctx *ctx, const int32_t *r_s
     if (total) hipLaunchKernelGGL(pileup_kernel<true>, dim3(grid), dim3(256), 0, stream, P);
     PL_CHK(hipGetLastError());
     if (trace) { hipStreamSynchronize(stream); fprintf(stderr, "[pileup] tile filled at %.2f ms\n", ms_now()); }
-    if (col_n || col_indel) {
-        std::vector<uint32_t> off, ci;
-        if (col_n) {
-            off.resize(ncells + 1);
-            PL_CHK(hipMemcpyAsync(off.data(), d_cnt, (ncells + 1) * 4, hipMemcpyDeviceToHost, stream));
-        }
-        if (col_indel) {
-            ci.resize(n_sites);
-            PL_CHK(hipMemcpyAsync(ci.data(), P.col_indel, (size_t)n_sites * 4, hipMemcpyDeviceToHost, stream));
-        }
+    if ((col_n || col_indel) && n_sites) {
+        // per column: its entries (the difference of two offsets, formed on the device: the offsets themselves are 4 bytes a cell and
+        // stay in HBM) and whether any is followed by an indel; two words a column come back, through page-locked memory
+        uint32_t *d_cc = (uint32_t*)bcfgpu_internal_ws(ctx, 148, (size_t)n_sites * 8 + 64);
+        uint32_t *h_cc = (uint32_t*)bcfgpu_internal_pinned(ctx, 3, (size_t)n_sites * 8 + 64);
+        if (!d_cc || !h_cc) return fail(BCFGPU_E_NOMEM, "device workspace");
+        hipLaunchKernelGGL(col_counts_kernel, dim3((n_sites + 255) / 256), dim3(256), 0, stream, d_cnt, P.col_indel, n_sites, S, d_cc);
+        PL_CHK(hipMemcpyAsync(h_cc, d_cc, (size_t)n_sites * 8, hipMemcpyDeviceToHost, stream));
         PL_CHK(hipStreamSynchronize(stream));
         for (int k = 0; k < n_sites; ++k) {
-            if (col_n) col_n[k] = (int32_t)(off[(size_t)(k + 1) * S] - off[(size_t)k * S]);
-            if (col_indel) col_indel[k] = ci[k] ? 1 : 0;
+            if (col_n) col_n[k] = (int32_t)h_cc[2 * k];
+            if (col_indel) col_indel[k] = h_cc[2 * k + 1] ? 1 : 0;
         }
     }
     #undef PL_CHK
