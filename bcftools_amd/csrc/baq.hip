@@ -48,6 +48,7 @@ struct BaqParams {
                                               // (a lane's own 100-byte stretch made every access of the cap 64 cache lines, and the
                                               // two stores per row of the backward pass 64 partial sectors each)
     uint8_t *qual_out, *zq_out;
+    int lds_rows;                             // scratch class: 1 = the working rows in LDS (baq_fb_lds; the launch carries 2 * ncell * BAQ_WIDE_LANES doubles)
 };
 
 __device__ __forceinline__ int set_u(int b, int i, int k) { int x = i - b; x = x > 0 ? x : 0; return (k - x + 1) * 3; }
@@ -173,6 +174,172 @@ __device__ void baq_fb_scratch(const BaqParams &P, int job, const BaqJob &j, con
     }
     #undef FM
     #undef SC
+}
+
+
+// The same arithmetic, cell by cell, with the two rows a pass works on in LDS (rowA / rowB: this lane's columns, cell c at
+// [c * LANES]) instead of in the scratch matrices.  In baq_fb_scratch every cell waits for global-memory round trips -- the
+// row above, and the cell it has just stored -- and a read with a 40-base indel (a band of 43: 87 cells x 100 rows x three
+// passes) takes 65 ms whatever else the chip is doing.  Here the forward pass reads the row above from LDS, carries the cell
+// to the left in registers and only STORES its scaled rows to the scratch matrix F (the posterior needs f x b per cell); the
+// backward pass keeps its rows in LDS alone and forms a row's posterior maximum as soon as the row is scaled, from F's row
+// (loads nothing waits for but that row's own sums).  Every expression is baq_fb_scratch's, in its order.
+template <int LANES>
+__device__ void baq_fb_lds(const BaqParams &P, int job, const BaqJob &j, const uint8_t *ref, const uint8_t *seq,
+                           const uint8_t *iqual, int32_t *state, uint8_t *q, double *rowA, double *rowB, double *rowF, uint8_t *lref)
+{
+    const int l_query = j.l_query, l_ref = j.l_ref;
+    const size_t st = P.stride;
+    #define FG(i, c) P.F[((size_t)(i) * P.ncell + (c)) * st + job]
+    #define SC(i) P.S[(size_t)(i) * st + job]
+    #define LR(buf, c) (buf)[(size_t)(c) * LANES]
+    int bw = l_ref > l_query ? l_ref : l_query;
+    if (bw > j.bw) bw = j.bw;
+    if (bw < abs(l_ref - l_query)) bw = abs(l_ref - l_query);
+    const int bw2 = bw * 2 + 1, nc = bw2 * 3 + 6;
+    const double d = 0.001, e_ = 0.1;
+    double m[9];
+    const double sM = 1. / (2 * l_query + 2), sI = sM;
+    m[0] = (1 - d - d) * (1 - sM); m[1] = m[2] = d * (1 - sM);
+    m[3] = (1 - e_) * (1 - sI); m[4] = e_ * (1 - sI); m[5] = 0.;
+    m[6] = 1 - e_; m[7] = 0.; m[8] = e_;
+    const double bM = (1 - d) / l_ref, bI = d / l_ref;
+    auto qy = [&](int i) { return nt16_to_4(seq[i]); };
+    auto qp = [&](int i) { return (double)P.q2p[iqual[i]]; };
+    double *prev = rowA, *cur = rowB;
+    // the window's bases into LDS, eight loads in flight at a time (a load per cell from device memory is a wait per cell)
+    #define RF(k) lref[(size_t)(k) * LANES]
+    for (int k0 = 0; k0 < l_ref; k0 += 8) {
+        uint8_t t[8];
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = ref[k0 + u < l_ref ? k0 + u : l_ref - 1];
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) if (k0 + u < l_ref) RF(k0 + u) = t[u];
+    }
+    // ---- forward ----
+    SC(0) = 1.;
+    for (int c = 0; c < nc; ++c) LR(cur, c) = 0.;
+    {
+        double sum = 0.;
+        const int beg = 1, end = l_ref < bw + 1 ? l_ref : bw + 1;
+        const double q0 = qp(0);
+        const int y0 = qy(0);
+        for (int k = beg; k <= end; ++k) {
+            const int rk = RF(k - 1);
+            const double e = (rk > 3 || y0 > 3) ? 1. : rk == y0 ? 1. - q0 : q0 * EM;
+            const int u = set_u(bw, 1, k);
+            const double a = e * bM, b = EI * bI;
+            LR(cur, u) = a; LR(cur, u + 1) = b;
+            sum += a + b;
+        }
+        SC(1) = sum;
+        const int _beg = set_u(bw, 1, beg), _end = set_u(bw, 1, end) + 2;
+        for (int k = _beg; k <= _end; ++k) { const double v = LR(cur, k) / sum; LR(cur, k) = v; FG(1, k) = v; }
+    }
+    for (int i = 2; i <= l_query; ++i) {
+        { double *t = prev; prev = cur; cur = t; }
+        for (int c = 0; c < nc; ++c) LR(cur, c) = 0.;
+        const double qli = qp(i - 1);
+        const int qyi = qy(i - 1);
+        int beg = 1, end = l_ref, x;
+        x = i - bw; beg = beg > x ? beg : x;
+        x = i + bw; end = end < x ? end : x;
+        double sum = 0.;
+        double lM = 0., lD = 0.;                        // f[i][k-1]: M and D of the cell to the left (zeros in front of the band)
+        for (int k = beg; k <= end; ++k) {
+            const int rk = RF(k - 1);
+            const double e = (rk > 3 || qyi > 3) ? 1. : rk == qyi ? 1. - qli : qli * EM;
+            const int u = set_u(bw, i, k), v11 = set_u(bw, i - 1, k - 1), v10 = set_u(bw, i - 1, k);
+            const double f0 = e * (m[0] * LR(prev, v11) + m[3] * LR(prev, v11 + 1) + m[6] * LR(prev, v11 + 2));
+            const double f1 = EI * (m[1] * LR(prev, v10) + m[4] * LR(prev, v10 + 1));
+            const double f2 = m[2] * lM + m[8] * lD;
+            LR(cur, u) = f0; LR(cur, u + 1) = f1; LR(cur, u + 2) = f2;
+            sum += f0 + f1 + f2;
+            lM = f0; lD = f2;
+        }
+        SC(i) = sum;
+        const int _beg = set_u(bw, i, beg), _end = set_u(bw, i, end) + 2;
+        const double r = 1. / sum;
+        for (int k = _beg; k <= _end; ++k) { const double v = LR(cur, k) * r; LR(cur, k) = v; FG(i, k) = v; }
+    }
+    double sl1;
+    {
+        double sum = 0.;
+        for (int k = 1; k <= l_ref; ++k) {
+            const int u = set_u(bw, l_query, k);
+            if (u < 3 || u >= bw2 * 3 + 3) continue;
+            sum += LR(cur, u) * sM + LR(cur, u + 1) * sI;
+        }
+        sl1 = sum;
+    }
+    // the posterior maximum of row i from the scaled backward row `b` (LDS) and the scaled forward row (scratch)
+    auto map_row = [&](int i, const double *b) {
+        double sum = 0., max = 0.;
+        int beg = 1, end = l_ref, x, max_k = -1;
+        x = i - bw; beg = beg > x ? beg : x;
+        x = i + bw; end = end < x ? end : x;
+        // the scaled forward row from the scratch matrix into LDS, eight loads in flight at a time
+        const int c0 = set_u(bw, i, beg), c1 = set_u(bw, i, end) + 1;
+        for (int c = c0; c <= c1; c += 8) {
+            double t[8];
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = FG(i, c + u <= c1 ? c + u : c1);
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) if (c + u <= c1) LR(rowF, c + u) = t[u];
+        }
+        for (int k = beg; k <= end; ++k) {
+            const int u = set_u(bw, i, k);
+            double z;
+            z = LR(rowF, u) * LR(b, u);         if (z > max) { max = z; max_k = (k - 1) << 2 | 0; } sum += z;
+            z = LR(rowF, u + 1) * LR(b, u + 1); if (z > max) { max = z; max_k = (k - 1) << 2 | 1; } sum += z;
+        }
+        max /= sum;
+        state[i - 1] = max_k;
+        const int kq = (int)(-4.343 * log(1. - max) + .499);
+        q[i - 1] = (uint8_t)(kq > 100 ? 99 : kq);
+    };
+    // ---- backward, each row's posterior maximum right behind it ----
+    double *nxt = prev;                                 // (the forward rows are done with: the two buffers serve the backward pass)
+    for (int c = 0; c < nc; ++c) LR(cur, c) = 0.;
+    {
+        const double sl = SC(l_query);
+        for (int k = 1; k <= l_ref; ++k) {
+            const int u = set_u(bw, l_query, k);
+            if (u < 3 || u >= bw2 * 3 + 3) continue;
+            LR(cur, u) = sM / sl / sl1; LR(cur, u + 1) = sI / sl / sl1;
+        }
+    }
+    map_row(l_query, cur);
+    for (int i = l_query - 1; i >= 1; --i) {
+        { double *t = nxt; nxt = cur; cur = t; }
+        for (int c = 0; c < nc; ++c) LR(cur, c) = 0.;
+        int beg = 1, end = l_ref, x;
+        double y = (i > 1);
+        const double qli1 = qp(i);
+        const int qyi1 = qy(i);
+        x = i - bw; beg = beg > x ? beg : x;
+        x = i + bw; end = end < x ? end : x;
+        double rD = 0.;                                 // b[i][k+1]'s D, unscaled (zero past the band)
+        for (int k = end; k >= beg; --k) {
+            const int u = set_u(bw, i, k), v11 = set_u(bw, i + 1, k + 1), v10 = set_u(bw, i + 1, k);
+            const int rk = k >= l_ref ? 4 : RF(k);
+            const double e = (k >= l_ref ? 0 : (rk > 3 || qyi1 > 3) ? 1. : rk == qyi1 ? 1. - qli1 : qli1 * EM) * LR(nxt, v11);
+            const double b10 = LR(nxt, v10 + 1), b01 = rD;
+            const double vM = e * m[0] + EI * m[1] * b10 + m[2] * b01;
+            const double vI = e * m[3] + EI * m[4] * b10;
+            const double vD = (e * m[6] + m[8] * b01) * y;
+            LR(cur, u) = vM; LR(cur, u + 1) = vI; LR(cur, u + 2) = vD;
+            rD = vD;
+        }
+        const int _beg = set_u(bw, i, beg), _end = set_u(bw, i, end) + 2;
+        y = 1. / SC(i);
+        for (int k = _beg; k <= _end; ++k) LR(cur, k) *= y;
+        map_row(i, cur);
+    }
+    #undef FG
+    #undef SC
+    #undef LR
+    #undef RF
 }
 
 
@@ -545,6 +712,7 @@ __device__ void baq_cap(const BaqParams &P, const BaqJob &j, const uint8_t *iqua
 // + 8: a deletion of even length gives 8) keep their rows in registers; wider ones (indels of 8 and more) go through scratch
 #define BAQ_BWM 7
 #define BAQ_BWM2 8
+#define BAQ_WIDE_LANES 8
 
 #ifndef BAQ_WAVES
 #define BAQ_WAVES 2          // wavefronts per SIMD the register rows allow; 3 and 4 (spills, or without the one-row-ahead loads): 1.4x - 2.3x slower
@@ -555,7 +723,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAQ_WAVES, 8
     __shared__ float s_q2p[256];
     for (int t = threadIdx.x; t < 256; t += 64) s_q2p[t] = P.q2p[t];
     __syncthreads();
-    const int job = blockIdx.x * 64 + threadIdx.x;
+    // The scratch class (BWM = 0: reads with an indel of eight bases or more, a few in a thousand) is a handful of wavefronts with a
+    // long way to go each -- every cell a round trip to the scratch rows -- so a wavefront takes BAQ_WIDE_LANES reads, not 64:
+    // eight times the wavefronts in flight for the same reads (64 reads a wavefront: 65 ms for 17 000 reads beside 46 ms for the
+    // other 4.9 million).
+    constexpr int LANES = BWM > 0 ? 64 : BAQ_WIDE_LANES;
+    if (threadIdx.x >= LANES) return;
+    const int job = blockIdx.x * LANES + threadIdx.x;
     if (job >= P.n_jobs) return;
     const BaqJob j = P.jobs[job];
     const uint8_t *seq = P.seq16 + j.seq_off, *iqual = P.qual + j.seq_off;
@@ -576,6 +750,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAQ_WAVES, 8
         if (bw > j.bw) bw = j.bw;
         if (bw < abs(j.l_ref - j.l_query)) bw = abs(j.l_ref - j.l_query);
         baq_fb_reg<(BWM > 0 ? BWM : 1)>(P, job, j, ref, seq, iqual, bw, state, q, pst, s_q2p);
+    } else if (P.lds_rows && j.l_ref <= P.max_lq + P.ncell / 6 + 16) {        // (the window fits the LDS copy: always, realn.c trims it to the read and its band)
+        extern __shared__ double s_rows[];                   // [3][ncell][LANES] doubles, then the window's bases [max l_ref][LANES]
+        const size_t rw = (size_t)P.ncell * LANES;
+        baq_fb_lds<LANES>(P, job, j, ref, seq, iqual, state, q, s_rows + threadIdx.x, s_rows + rw + threadIdx.x, s_rows + 2 * rw + threadIdx.x,
+                          reinterpret_cast<uint8_t*>(s_rows + 3 * rw) + threadIdx.x);
     } else baq_fb_scratch(P, job, j, ref, seq, iqual, state, q);
 #if !defined(BAQ_EXP_PHASE) || BAQ_EXP_PHASE == 0
     baq_cap(P, j, iqual, state, q, left, pst, qout, zout);
@@ -667,6 +846,19 @@ __global__ __launch_bounds__(256) void baq_ref4_kernel(const char *ref, size_t n
 using namespace bcfgpu;
 
 #define BQ_CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return bcfgpu_set_error(BCFGPU_E_HIP, #call); } } while (0)
+
+// the scratch class: BAQ_WIDE_LANES reads a wavefront; the working rows in LDS when two rows of the class's widest band fit (bands
+// to about 200), else every cell through the scratch matrices
+static void launch_baq_wide(BaqParams P, hipStream_t st)
+{
+    // three rows of the class's widest band (two working rows, the forward row of the posterior) and the window's bases: a window is
+    // at most the read and its band long (realn.c trims it to that)
+    const size_t lds = 3 * (size_t)P.ncell * BAQ_WIDE_LANES * sizeof(double) + ((size_t)P.max_lq + (size_t)P.ncell / 6 + 16) * BAQ_WIDE_LANES;
+    P.lds_rows = lds <= 150 * 1024 ? 1 : 0;
+    if (P.lds_rows && lds > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(baq_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(baq_kernel<0>, dim3((P.n_jobs + BAQ_WIDE_LANES - 1) / BAQ_WIDE_LANES), dim3(64), P.lds_rows ? lds : 0, st, P);
+}
 
 extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *ref, int32_t ref_len, int flag,
                           uint8_t *qual_out, uint8_t *zq_out, int32_t *ret)
@@ -798,7 +990,7 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
             P.jobs = (const BaqJob*)d_jobs + j0;
             if (c == 0)      hipLaunchKernelGGL(baq_kernel<BAQ_BWM>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
             else if (c == 1) hipLaunchKernelGGL(baq_kernel<BAQ_BWM2>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
-            else             hipLaunchKernelGGL(baq_kernel<0>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
+            else             launch_baq_wide(P, stream);
         }
         BQ_CHK(hipGetLastError());
     }
@@ -904,7 +1096,7 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
             P.jobs = (c == 0 ? Q.jobs0 : c == 1 ? Q.jobs1 : Q.jobs2) + j0;
             if (c == 0)      hipLaunchKernelGGL(baq_kernel<BAQ_BWM>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, st, P);
             else if (c == 1) hipLaunchKernelGGL(baq_kernel<BAQ_BWM2>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, st, P);
-            else             hipLaunchKernelGGL(baq_kernel<0>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, st, P);
+            else             launch_baq_wide(P, st);
         }
         BQ_CHK(hipGetLastError());
     }

@@ -180,7 +180,7 @@ extern "C" int bcfgpu_errmod_plan_visit(bcfgpu_ctx *ctx, const bcfgpu_tile *snp,
     }
     uint8_t *d_visit = nullptr;
     if (snp && snp_visit && snp->n_sites) {
-        d_visit = (uint8_t*)bcfgpu_internal_ws(ctx, 146, (size_t)snp->n_sites + 64);
+        d_visit = (uint8_t*)bcfgpu_internal_ws(ctx, 132, (size_t)snp->n_sites + 64);
         if (!d_visit) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_errmod_plan: device workspace");
         DR_CHK(hipMemcpyAsync(d_visit, snp_visit, (size_t)snp->n_sites, hipMemcpyHostToDevice, stream));
     }

@@ -685,7 +685,7 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
         uint32_t *d_k0 = (uint32_t*)WS(32, nj * 4), *d_v0 = (uint32_t*)WS(33, nj * 4), *d_k1 = (uint32_t*)WS(34, nj * 4), *d_v1 = (uint32_t*)WS(35, nj * 4);
         uint32_t *d_list2 = (uint32_t*)WS(36, nj * 4);
         ProbalnQueue *d_queue = (ProbalnQueue*)WS(38, sizeof(ProbalnQueue));
-        double2 *d_emt = (double2*)bcfgpu_internal_ws(ctx, 147, 256 * sizeof(double2));
+        double2 *d_emt = (double2*)bcfgpu_internal_ws(ctx, 133, 256 * sizeof(double2));
         int32_t *d_sumq = (int32_t*)WS(39, (size_t)ns * 64 * 4);
         uint8_t *d_otype = (uint8_t*)WS(40, (size_t)ns * 64);
         size_t sort_bytes = 0;

@@ -423,8 +423,10 @@ __global__ __launch_bounds__(256) void probaln_jobs_kernel(const ProbalnParams P
     const uint32_t lq = (uint32_t)(j.l_query > 255 ? 255 : j.l_query < 0 ? 0 : j.l_query);
     P.pjob[job] = pj;
     // the LDS class is sorted by band width first: a wavefront's jobs share the sweep over the widest band among them
-    P.key_in[job] = cls == PROBALN_CLS_LDS ? cls << 13 | (uint32_t)j.eff << 6 | lq >> 2
-                  : cls == PROBALN_CLS_LDS16 ? cls << 13 | (uint32_t)(j.eff >> 2 > 127 ? 127 : j.eff >> 2) << 6 | lq >> 2
+    // (... then by which of the two sequences is the longer one -- the band's live cells sit at opposite ends of it -- then by length)
+    const uint32_t dir = j.l_ref > j.l_query ? 1u : 0u;
+    P.key_in[job] = cls == PROBALN_CLS_LDS ? cls << 13 | (uint32_t)j.eff << 6 | dir << 5 | lq >> 3
+                  : cls == PROBALN_CLS_LDS16 ? cls << 13 | (uint32_t)(j.eff >> 2 > 127 ? 127 : j.eff >> 2) << 6 | dir << 5 | lq >> 3
                   : cls << 13 | lq << 5 | (uint32_t)dl;
     P.val_in[job] = job;
 }

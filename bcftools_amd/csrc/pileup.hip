@@ -859,7 +859,7 @@ static int pool_pileup_impl(const char *who, bcfgpu_ctx *ctx, const int32_t *r_s
     if ((col_n || col_indel) && n_sites) {
         // per column: its entries (the difference of two offsets, formed on the device: the offsets themselves are 4 bytes a cell and
         // stay in HBM) and whether any is followed by an indel; two words a column come back, through page-locked memory
-        uint32_t *d_cc = (uint32_t*)bcfgpu_internal_ws(ctx, 148, (size_t)n_sites * 8 + 64);
+        uint32_t *d_cc = (uint32_t*)bcfgpu_internal_ws(ctx, 134, (size_t)n_sites * 8 + 64);
         uint32_t *h_cc = (uint32_t*)bcfgpu_internal_pinned(ctx, 3, (size_t)n_sites * 8 + 64);
         if (!d_cc || !h_cc) return fail(BCFGPU_E_NOMEM, "device workspace");
         hipLaunchKernelGGL(col_counts_kernel, dim3((n_sites + 255) / 256), dim3(256), 0, stream, d_cnt, P.col_indel, n_sites, S, d_cc);
@@ -1230,8 +1230,8 @@ extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32
     const int nl = (int)lk.size();
     if (nl == 0) { gs.total_ms = ms_since(t_begin); return BCFGPU_OK; }
     const size_t nlsel = (size_t)nl * S;
-    int32_t *d_l = (int32_t*)bcfgpu_internal_ws(ctx, 144, (size_t)nl * 8 + 64);
-    uint32_t *d_lsel = (uint32_t*)bcfgpu_internal_ws(ctx, 145, (nlsel + 1) * 4 + (size_t)nl + 64);
+    int32_t *d_l = (int32_t*)bcfgpu_internal_ws(ctx, 130, (size_t)nl * 8 + 64);
+    uint32_t *d_lsel = (uint32_t*)bcfgpu_internal_ws(ctx, 131, (nlsel + 1) * 4 + (size_t)nl + 64);
     if (!d_l || !d_lsel) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
     GT_CHK(hipMemcpyAsync(d_l, lk.data(), (size_t)nl * 4, hipMemcpyHostToDevice, stream));
     GT_CHK(hipMemcpyAsync(d_l + nl, lcols.data(), (size_t)nl * 4, hipMemcpyHostToDevice, stream));
