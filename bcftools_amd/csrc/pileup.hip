@@ -419,16 +419,23 @@ template <bool COUNT>
 __global__ __launch_bounds__(256) void live_tile_kernel(const PileupParams P, int n_live, const int32_t *lcols, const int32_t *lk, const uint32_t *ksel,
                                                         uint32_t *lsel, const uint32_t *aux_in, uint32_t *rd_out, uint8_t *ep_out, uint32_t *aux_out)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)n_live * P.n_smpl) return;
-    const int j = (int)(i / P.n_smpl), s = (int)(i - (long)j * P.n_smpl);
-    const size_t kc = (size_t)lk[j] * P.n_smpl + s;
-    const uint32_t kb = ksel[kc], n = ksel[kc + 1] - kb;
-    if (COUNT) { lsel[i] = n; return; }
-    const long cell = (long)lcols[j] * P.n_smpl + s;
-    const uint32_t b = P.cnt[cell];
-    uint32_t o = lsel[i];
-    for (uint32_t k = 0; k < n; ++k, ++o) { rd_out[o] = P.rd[b + k]; ep_out[o] = P.epos[b + k]; aux_out[o] = aux_in[kb + k]; }
+    if (COUNT) {                                             // a lane per cell
+        const long i = (long)blockIdx.x * 256 + threadIdx.x;
+        if (i >= (long)n_live * P.n_smpl) return;
+        const int j = (int)(i / P.n_smpl), s = (int)(i - (long)j * P.n_smpl);
+        const size_t kc = (size_t)lk[j] * P.n_smpl + s;
+        lsel[i] = ksel[kc + 1] - ksel[kc];
+        return;
+    }
+    // a lane per (tile column, entry of the column): a column's entries are one stretch of the pileup, of the stage's array and of the tile
+    for (int j = blockIdx.y; j < n_live; j += gridDim.y) {
+        const size_t kc0 = (size_t)lk[j] * P.n_smpl;
+        const uint32_t kb = ksel[kc0], n = ksel[kc0 + P.n_smpl] - kb;
+        const uint32_t b = P.cnt[(size_t)lcols[j] * P.n_smpl], o = lsel[(size_t)j * P.n_smpl];
+        for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+            rd_out[o + k] = P.rd[b + k]; ep_out[o + k] = P.epos[b + k]; aux_out[o + k] = aux_in[kb + k];
+        }
+    }
 }
 
 // One record per read (reference span, constants) from the caller's per-read arrays: a pass over the CIGARs, one lane per read
@@ -1249,7 +1256,7 @@ extern "C" int bcfgpu_gap_prep_tile(bcfgpu_ctx *ctx, int32_t n_cols, const int32
     const size_t ep_at = (((size_t)ltotal + 4) * 4 + 255) & ~(size_t)255, aux_at = (ep_at + ltotal + 64 + 255) & ~(size_t)255;
     uint8_t *d_out = (uint8_t*)bcfgpu_internal_ws(ctx, 26, aux_at + ((size_t)ltotal + 4) * 4);
     if (!d_out) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_gap_prep_tile: device workspace");
-    if (ltotal) hipLaunchKernelGGL(live_tile_kernel<false>, dim3(lgrid), dim3(256), 0, stream, P, nl, d_l + nl, d_l, d_sel, d_lsel,
+    if (ltotal) hipLaunchKernelGGL(live_tile_kernel<false>, dim3(32, nl < 65535 ? nl : 65535), dim3(256), 0, stream, P, nl, d_l + nl, d_l, d_sel, d_lsel,
                                    (const uint32_t*)d_aux, (uint32_t*)d_out, d_out + ep_at, (uint32_t*)(d_out + aux_at));
     GT_CHK(hipGetLastError());
     if (out->p_aux && ltotal) {                                 // optional: the tile's p->aux words for the caller as well

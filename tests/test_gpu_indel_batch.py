@@ -43,6 +43,7 @@ SHORT = (-3, -2, -1, 1, 2, 3)                  # bands of 4..6: the register-res
     (6, 100, 30.0, 105, (-9, -8, 8, 9, 7, -7), SHORT, {}),  # the boundary: |type| = 7 is the widest register class
     (8, 16, 15.0, 106, (-90, -80, -74, -71, -70, 45, 60), SHORT, {}),   # bands past 73: sixteen jobs a wavefront (LDS holds no 64 such rows)
     (5, 300, 30.0, 107, (10, -10, 15, -15, 47, -47), (8, -8, 2), {}),   # many jobs per band class: whole wavefronts, several launches' worth
+    (3, 1000, 30.0, 108, (-25, 12, 40), SHORT, {}),                     # BASELINE configs[3] shape: 1000 samples x 30x
 ])
 def test_long_indels_through_the_wide_band_kernel(gpu_ctx_factory, n_sites, n_smpl, depth, seed, lens, lens2, kw):
     """Indels of 8 bp and more: bam2bcf_indel.c:293-294 gives their realignment the band |type| + 3, wider than the widest
