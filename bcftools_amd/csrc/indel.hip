@@ -771,7 +771,7 @@ __device__ __forceinline__ int probaln_fwd_regs(const uint8_t *ref, int l_ref, c
                         R[p0 + u] = make_double2(f0, f1);
                         Mo_un = Mc_un; Mc_un = Mx_un; Mc = Mx; Ic = Ix;
                         Mn = f0; Dn = f2;
-                        if (NC > 4) __builtin_amdgcn_sched_barrier(0);         // (a cell's instructions stay together: the scheduler's taste for
+                        if (NC > 4) __builtin_amdgcn_sched_barrier(0);         // (a cell's instructions stay together)
                     }
                 } else {
                     #pragma unroll
@@ -794,7 +794,7 @@ __device__ __forceinline__ int probaln_fwd_regs(const uint8_t *ref, int l_ref, c
                         R[p0 + u] = make_double2(f0, f1);
                         Mo_un = Mc_un; Mc_un = Mx_un; Mc = Mx; Ic = Ix;
                         Mn = f0; Dn = f2;
-                        if (NC > 4) __builtin_amdgcn_sched_barrier(0);         // (a cell's instructions stay together: the scheduler's taste for
+                        if (NC > 4) __builtin_amdgcn_sched_barrier(0);         // (a cell's instructions stay together)
                     }
                 }
             }

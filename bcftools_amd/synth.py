@@ -134,9 +134,9 @@ def tile_from_torch(t):
                          t["rd"].cpu().numpy().view(np.uint32), t["epos"].cpu().numpy())
 
 
-def indel_batch(seed, n_sites, n_smpl, depth=30.0, read_len=100, max_depth=200, lens=None, lens2=None):
+def indel_batch(seed, n_sites, n_smpl, depth=30.0, read_len=100, max_depth=200, lens=None, lens2=None, spacing=300):
     """Synthetic input of bcfgpu_gap_prep (BASELINE configs[2] shape: indel-candidate columns): a random reference with
-    one indel locus every 300 bp (length -3..+3, weights 1/|len|), HWE carriers, Poisson depth, reads of `read_len`
+    one indel locus every `spacing` (300) bp (length -3..+3, weights 1/|len|), HWE carriers, Poisson depth, reads of `read_len`
     bases placed so that the locus falls inside them, substitution errors at 10^(-Q/10).  Every pileup entry owns its
     read (the flat pool of bcfgpu_reads allows sharing; sharing does not change the work).
     `lens`: the indel lengths a locus draws its type from (default -3..+3; long ones, e.g. (-40, -25, 12, 8), put the
@@ -147,13 +147,13 @@ def indel_batch(seed, n_sites, n_smpl, depth=30.0, read_len=100, max_depth=200, 
     Returns dict(ref=bytes, reads=dict of the bcfgpu_reads arrays, pos, smpl_off, p_read, p_qpos, p_indel, itype)."""
     rng = np.random.Generator(np.random.Philox(key=int(seed)))
     S = n_smpl
-    L = 200 + 300 * n_sites + 300
+    L = 200 + spacing * n_sites + spacing
     ref2 = rng.integers(0, 4, L)
-    pos = (200 + 300 * np.arange(n_sites)).astype(np.int32)
+    pos = (200 + spacing * np.arange(n_sites)).astype(np.int32)
     lens = np.array([-3, -2, -1, 1, 2, 3] if lens is None else list(lens))
     all_lens = np.concatenate([lens, [] if lens2 is None else np.array(list(lens2))]).astype(np.int64)
     max_len = int(max(3, all_lens.max()))                              # the longest insertion (inside the read); deletions only widen the span
-    assert max_len + 24 < read_len and read_len - int(min(0, all_lens.min())) < 290      # (loci are 300 bases apart)
+    assert max_len + 24 < read_len and read_len - int(min(0, all_lens.min())) < spacing - 10      # (loci are `spacing` bases apart)
     w = 1.0 / np.abs(lens)
     itype = lens[rng.choice(len(lens), size=n_sites, p=w / w.sum())]
     ins2 = rng.integers(0, 4, (n_sites, max_len))
