@@ -48,10 +48,12 @@ def test_baq_matches_oracle_on_reference_reads(golden_dir, gpu_ctx_factory, samf
         assert n_applied > 0
 
 
-@pytest.mark.parametrize("kw", [{}, dict(lens=(-40, -25, -12, -8, 8, 12, 25, 40), lens2=(-3, 2, 60, -90))])
+@pytest.mark.parametrize("kw", [{}, dict(lens=(-40, -25, -12, -8, 8, 12, 25, 40), lens2=(-3, 2, 60, -90)),
+                                dict(lens=(-305, -320), lens2=(-2, 3), spacing=900)])     # bands past what three LDS rows hold: the scratch matrices
 def test_baq_matches_oracle_on_synthetic_reads(gpu_ctx_factory, kw):
     """... the second case: reads with indels of 8-90 bases, whose band (the indel's length + 3, realn.c) is past the two
-    register-row classes: the class with its working rows in LDS (baq_fb_lds)."""
+    register-row classes: the class with its working rows in LDS (baq_fb_lds); the third: a 305-320 base deletion, whose band does
+    not fit LDS (baq_fb_scratch)."""
     b = synth.indel_batch(77, 6, 20, depth=12.0, **kw)
     refseq = b["ref"].decode()
     R = b["reads"]
