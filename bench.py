@@ -1065,7 +1065,7 @@ def main():
         # FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes for gfx950, separate passes), never scaled: a run
         # with another tile shape reports null
         traffic = traffic_source = None
-        for tf in ("r4_traffic.json", "r3_traffic.json", "r2_traffic.json"):
+        for tf in ("r5_traffic.json", "r4_traffic.json", "r3_traffic.json", "r2_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
                 if tj["samples"] == S and abs(tj["depth"] - a.depth) < 1e-9 and tj["sites"] == T:
