@@ -711,7 +711,6 @@ int bcfgpu_internal_gap_core(bcfgpu_ctx *ctx, const GapIn &g, size_t n_ent, uint
         p.ref2 = d_ref2; p.qpack = d_qpack; p.q2p = q2p; p.emt = d_emt; p.score1 = d_s1; p.score2 = d_s2;
         p.pjob = d_pjob; p.key_in = d_k0; p.val_in = d_v0; p.key_sorted = d_k1; p.val_sorted = d_v1; p.list2 = d_list2; p.queue = d_queue;
         p.wide = d_wide; p.tot = d_tot;
-        p.n_lds_hint = tot.max_bw > PROBALN_BW_MAX ? 1 : 0;           // some site has a type of 8 bases or more
 #ifdef BCFGPU_DIAG
         p.force_wide = getenv("BCFGPU_FORCE_WIDE") != nullptr;      // diagnostics build only: every job through the rolling-row kernel
 #endif

@@ -1004,7 +1004,10 @@ int launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu, hipStr
     if (hipEventRecord(ev[8], s) != hipSuccess) return -1;
     if (hipStreamWaitEvent(tail, ev[8], 0) != hipSuccess || hipStreamWaitEvent(second, ev[8], 0) != hipSuccess ||
         hipStreamWaitEvent(tail2, ev[8], 0) != hipSuccess) return -1;
-    if (p.n_lds_hint != 0) {
+    {
+        // (always launched: a job's band is |type| + 3 OR the difference of its two lengths, so a column of 1-3 base types has
+        // wide-band jobs as soon as one of its reads carries a long indel elsewhere in the window; an empty class costs a launch
+        // of workgroups that leave at once)
         static const int caps[PROBALN_LDS_GROUPS] = PROBALN_LDS_CAPS;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(probaln_lds_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(probaln_lds_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;

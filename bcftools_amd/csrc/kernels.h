@@ -241,7 +241,6 @@ struct ProbalnParams {
     size_t scratch_stride;                       // jobs per chunk; scratch is [2][ncell][stride] doubles
     double *scratch;
     int force_wide;                              // tests: every job through the rolling-row version
-    int n_lds_hint;                              // 0: no launch of the LDS class is needed (no site has a type of 8 bases or more)
 };
 void launch_probaln_jobs(const ProbalnParams &p, hipStream_t s);
 void launch_probaln_bounds(const ProbalnParams &p, hipStream_t s);

@@ -252,3 +252,91 @@ def indel_tile_from_batch(b, aux, ret, mapq=60):
     epos = ((qpos + 1).astype(np.float64) / (lq + 1) * 100).astype(np.uint8)
     return host.HostTile(S, np.zeros(len(live), dtype=np.int8), off.astype(np.uint32), rd, epos,
                          aux=np.asarray(aux, dtype=np.uint32)[e], is_indel=1), live
+
+
+def wgs_reads(seed, n_sites, n_smpl, depth=30.0, indel_read_rate=0.005, true_indel_rate=0.01, long_indel_frac=0.05):
+    """BASELINE configs[3] as READS (bench.py --mode wgs, tests/test_gpu_fullsize.py): `n_smpl` samples x `depth` of 100-base reads
+    over `n_sites` columns of one contig (position-sorted inside a sample), substitution errors at 0.3 %, four binned base
+    qualities, `indel_read_rate` of the reads with a noise indel and true indel sites at `true_indel_rate` of the columns (allele
+    frequency 0.1, HWE genotypes) -- indels of 1..3 bases by 1/len or, `long_indel_frac` of them, 8 / 12 / 25 / 40 bases by 1/len.
+    The bases and qualities are drawn on the device (torch) and brought to the host as the arrays of bcfgpu_reads.
+    Returns dict(reads, mapq, smpl, refseq, read_len, beg, end, n_reads, n_true)."""
+    import torch
+    S = n_smpl
+    L, beg = 100, 300
+    end = beg + n_sites
+    rng = np.random.default_rng(seed)
+    per = int((n_sites + L) * depth / L)
+    n = per * S
+    pos = np.sort(rng.integers(beg - L + 1, end, size=(S, per)), axis=1).astype(np.int32).ravel()
+    smpl = np.repeat(np.arange(S, dtype=np.int32), per)
+    ref_codes = rng.integers(0, 4, end + 3 * L).astype(np.uint8)
+    refseq = "".join("ACGT"[i] for i in ref_codes)
+    # ---- indels: noise on a fraction of the reads (anywhere 10 bases off the ends; length 1..3 with weights 1/len, or -- one in
+    # twenty -- 8..40 bases, the lengths whose realignment band |type| + 3 is past the register-resident classes), and true indel
+    # sites (allele frequency 0.1, genotypes HWE, the same mix of lengths) carried by the reads that span them ----
+    lens = np.array([1, 2, 3]); w = 1.0 / lens
+    long_lens = np.array([8, 12, 25, 40])
+
+    def draw_lens(k):
+        v = lens[rng.choice(3, k, p=w / w.sum())]
+        lg = rng.random(k) < long_indel_frac
+        v[lg] = long_lens[rng.choice(len(long_lens), int(lg.sum()), p=(1.0 / long_lens) / (1.0 / long_lens).sum())]      # weights 1/len as well
+        return v * rng.choice([-1, 1], k)
+    ilen = np.zeros(n, np.int64)                                   # > 0 insertion, < 0 deletion
+    ioff = np.zeros(n, np.int64)                                   # query bases before the indel
+    noisy = rng.random(n) < indel_read_rate
+    ilen[noisy] = draw_lens(int(noisy.sum()))
+    ioff[noisy] = rng.integers(10, L - 10 - np.maximum(ilen[noisy], 0))
+    n_true = int(n_sites * true_indel_rate + 0.5)
+    if n_true:
+        tsite = np.sort(rng.choice(np.arange(beg + 20, end - 20), n_true, replace=False)).astype(np.int64)
+        tlen = draw_lens(n_true)
+        geno = rng.binomial(2, 0.1, (S, n_true))
+        k = np.searchsorted(tsite, pos.astype(np.int64) + 10)
+        kk = np.minimum(k, n_true - 1)
+        span = (k < n_true) & (tsite[kk] < pos.astype(np.int64) + L - 10 - np.maximum(tlen[kk], 0))
+        carry = span & (rng.random(n) < geno[smpl, kk] * 0.5)
+        ilen[carry] = tlen[kk[carry]]
+        ioff[carry] = tsite[kk[carry]] - pos[carry] + 1             # the indel follows reference position tsite
+    al = np.abs(ilen)
+    ins = np.where(ilen > 0, al, 0)
+    c3 = np.stack([ioff << 4, (al << 4) | np.where(ilen > 0, 1, 2), (L - ioff - ins) << 4], axis=1)
+    ncig = np.where(ilen != 0, 3, 1).astype(np.int32)
+    c3[ilen == 0, 0] = L << 4
+    cig = c3[np.arange(3)[None, :] < ncig[:, None]].astype(np.uint32)
+    cig_off = np.concatenate([[0], np.cumsum(ncig)[:-1]]).astype(np.int32)
+    # the bases and qualities (n x L bytes each: half a gigabyte at the default size) are drawn on the device, in chunks of reads
+    dev = torch.device("cuda", 0)
+    tg = torch.Generator(device=dev)
+    tg.manual_seed(int(seed))
+    ref_t = torch.from_numpy(ref_codes.astype(np.int64)).to(dev)
+    seq_t = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    qual_t = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    q_vals = torch.tensor([11, 25, 37, 40], dtype=torch.uint8, device=dev)
+    q_cdf = torch.tensor([0.07, 0.15, 0.50], device=dev)
+    j = torch.arange(L, dtype=torch.int64, device=dev)[None, :]
+    CH = 1 << 19
+    for r0 in range(0, n, CH):
+        r1 = min(n, r0 + CH)
+        il = torch.from_numpy(ilen[r0:r1]).to(dev)[:, None]
+        io = torch.from_numpy(ioff[r0:r1]).to(dev)[:, None]
+        p0 = torch.from_numpy(pos[r0:r1].astype(np.int64)).to(dev).clamp_(min=0)[:, None]
+        after = j >= io
+        shift = torch.where(il < 0, -il, -torch.minimum(il, (j - io).clamp(min=0)))
+        b = ref_t[p0 + j + torch.where(after, shift, torch.zeros_like(shift))]
+        is_ins = after & (il > 0) & (j - io < il)
+        b = torch.where(is_ins, torch.randint(0, 4, b.shape, generator=tg, device=dev), b)
+        err = torch.rand(b.shape, generator=tg, device=dev) < 0.003
+        b = torch.where(err, (b + torch.randint(1, 4, b.shape, generator=tg, device=dev)) & 3, b)
+        seq_t[r0 * L:r1 * L] = (1 << b).to(torch.uint8).reshape(-1)
+        qual_t[r0 * L:r1 * L] = q_vals[torch.bucketize(torch.rand((r1 - r0) * L, generator=tg, device=dev), q_cdf)]
+    seq, qual = seq_t.cpu().numpy(), qual_t.cpu().numpy()
+    del seq_t, qual_t, ref_t
+    torch.cuda.empty_cache()
+    mapq = np.where(rng.random(n) < 0.92, 60, rng.integers(0, 60, n)).astype(np.uint8)
+    arrs = dict(r_pos=pos, r_lq=np.full(n, L, np.int32), r_flag=(rng.integers(0, 2, n) * 16).astype(np.int32), r_ncig=ncig, r_cig_off=cig_off,
+                r_seq_off=(np.arange(n, dtype=np.int64) * L).astype(np.int32), cig=cig, seq16=seq, qual=qual, zq=np.zeros(1, np.uint8),
+                r_has_zq=np.zeros(n, np.uint8))
+    return dict(reads=arrs, mapq=mapq, smpl=smpl, refseq=refseq, read_len=L, beg=beg, end=end, n_reads=n, n_true=n_true,
+                ilen=ilen, ioff=ioff)          # (per read: the indel it carries, > 0 insertion, and the query bases in front of it)

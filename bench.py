@@ -276,88 +276,17 @@ def main_wgs(a):
     value = columns / wall time of a step.  cpu_baseline: the oracle on the first columns / candidate columns of the same
     region, one host core; the candidates' p->aux is compared with the device's on the way."""
     import torch
-    from bcftools_amd import abi, engine, host
+    from bcftools_amd import abi, engine, host, synth
     from bcftools_amd.lib import check
     from tests.helpers import indeldrv, mplpdrv, orc
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     S = a.samples
     n_sites = 16384 if a.sites is None else a.sites            # host/bcfgpu_sam's default tile (--tile)
-    L, beg = 100, 300
-    end = beg + n_sites
-    rng = np.random.default_rng(a.seed)
-    per = int((n_sites + L) * a.depth / L)
-    n = per * S
-    pos = np.sort(rng.integers(beg - L + 1, end, size=(S, per)), axis=1).astype(np.int32).ravel()
-    smpl = np.repeat(np.arange(S, dtype=np.int32), per)
-    ref_codes = rng.integers(0, 4, end + 3 * L).astype(np.uint8)
-    refseq = "".join("ACGT"[i] for i in ref_codes)
-    # ---- indels: noise on a fraction of the reads (anywhere 10 bases off the ends; length 1..3 with weights 1/len, or -- one in
-    # twenty -- 8..40 bases, the lengths whose realignment band |type| + 3 is past the register-resident classes), and true indel
-    # sites (allele frequency 0.1, genotypes HWE, the same mix of lengths) carried by the reads that span them ----
-    lens = np.array([1, 2, 3]); w = 1.0 / lens
-    long_lens = np.array([8, 12, 25, 40])
-
-    def draw_lens(k):
-        v = lens[rng.choice(3, k, p=w / w.sum())]
-        lg = rng.random(k) < a.long_indel_frac
-        v[lg] = long_lens[rng.choice(len(long_lens), int(lg.sum()), p=(1.0 / long_lens) / (1.0 / long_lens).sum())]      # weights 1/len as well
-        return v * rng.choice([-1, 1], k)
-    ilen = np.zeros(n, np.int64)                                   # > 0 insertion, < 0 deletion
-    ioff = np.zeros(n, np.int64)                                   # query bases before the indel
-    noisy = rng.random(n) < a.indel_read_rate
-    ilen[noisy] = draw_lens(int(noisy.sum()))
-    ioff[noisy] = rng.integers(10, L - 10 - np.maximum(ilen[noisy], 0))
-    n_true = int(n_sites * a.true_indel_rate + 0.5)
-    if n_true:
-        tsite = np.sort(rng.choice(np.arange(beg + 20, end - 20), n_true, replace=False)).astype(np.int64)
-        tlen = draw_lens(n_true)
-        geno = rng.binomial(2, 0.1, (S, n_true))
-        k = np.searchsorted(tsite, pos.astype(np.int64) + 10)
-        kk = np.minimum(k, n_true - 1)
-        span = (k < n_true) & (tsite[kk] < pos.astype(np.int64) + L - 10 - np.maximum(tlen[kk], 0))
-        carry = span & (rng.random(n) < geno[smpl, kk] * 0.5)
-        ilen[carry] = tlen[kk[carry]]
-        ioff[carry] = tsite[kk[carry]] - pos[carry] + 1             # the indel follows reference position tsite
-    al = np.abs(ilen)
-    ins = np.where(ilen > 0, al, 0)
-    c3 = np.stack([ioff << 4, (al << 4) | np.where(ilen > 0, 1, 2), (L - ioff - ins) << 4], axis=1)
-    ncig = np.where(ilen != 0, 3, 1).astype(np.int32)
-    c3[ilen == 0, 0] = L << 4
-    cig = c3[np.arange(3)[None, :] < ncig[:, None]].astype(np.uint32)
-    cig_off = np.concatenate([[0], np.cumsum(ncig)[:-1]]).astype(np.int32)
-    # the bases and qualities (n x L bytes each: half a gigabyte at the default size) are drawn on the device, in chunks of reads
-    dev = torch.device("cuda", 0)
-    tg = torch.Generator(device=dev)
-    tg.manual_seed(int(a.seed))
-    ref_t = torch.from_numpy(ref_codes.astype(np.int64)).to(dev)
-    seq_t = torch.empty(n * L, dtype=torch.uint8, device=dev)
-    qual_t = torch.empty(n * L, dtype=torch.uint8, device=dev)
-    q_vals = torch.tensor([11, 25, 37, 40], dtype=torch.uint8, device=dev)
-    q_cdf = torch.tensor([0.07, 0.15, 0.50], device=dev)
-    j = torch.arange(L, dtype=torch.int64, device=dev)[None, :]
-    CH = 1 << 19
-    for r0 in range(0, n, CH):
-        r1 = min(n, r0 + CH)
-        il = torch.from_numpy(ilen[r0:r1]).to(dev)[:, None]
-        io = torch.from_numpy(ioff[r0:r1]).to(dev)[:, None]
-        p0 = torch.from_numpy(pos[r0:r1].astype(np.int64)).to(dev).clamp_(min=0)[:, None]
-        after = j >= io
-        shift = torch.where(il < 0, -il, -torch.minimum(il, (j - io).clamp(min=0)))
-        b = ref_t[p0 + j + torch.where(after, shift, torch.zeros_like(shift))]
-        is_ins = after & (il > 0) & (j - io < il)
-        b = torch.where(is_ins, torch.randint(0, 4, b.shape, generator=tg, device=dev), b)
-        err = torch.rand(b.shape, generator=tg, device=dev) < 0.003
-        b = torch.where(err, (b + torch.randint(1, 4, b.shape, generator=tg, device=dev)) & 3, b)
-        seq_t[r0 * L:r1 * L] = (1 << b).to(torch.uint8).reshape(-1)
-        qual_t[r0 * L:r1 * L] = q_vals[torch.bucketize(torch.rand((r1 - r0) * L, generator=tg, device=dev), q_cdf)]
-    seq, qual = seq_t.cpu().numpy(), qual_t.cpu().numpy()
-    del seq_t, qual_t, ref_t
-    torch.cuda.empty_cache()
-    mapq = np.where(rng.random(n) < 0.92, 60, rng.integers(0, 60, n)).astype(np.uint8)
-    arrs = dict(r_pos=pos, r_lq=np.full(n, L, np.int32), r_flag=(rng.integers(0, 2, n) * 16).astype(np.int32), r_ncig=ncig, r_cig_off=cig_off,
-                r_seq_off=(np.arange(n, dtype=np.int64) * L).astype(np.int32), cig=cig, seq16=seq, qual=qual, zq=np.zeros(1, np.uint8),
-                r_has_zq=np.zeros(n, np.uint8))
+    W = synth.wgs_reads(a.seed, n_sites, S, a.depth, indel_read_rate=a.indel_read_rate, true_indel_rate=a.true_indel_rate,
+                        long_indel_frac=a.long_indel_frac)
+    L, beg, end, n, n_true = W["read_len"], W["beg"], W["end"], W["n_reads"], W["n_true"]
+    arrs, mapq, smpl, refseq = W["reads"], W["mapq"], W["smpl"], W["refseq"]
     rd = abi.Reads()
     rd.n_reads = n
     for k_, v in arrs.items():

@@ -183,3 +183,121 @@ def test_pileup_at_scale_counts_and_packed_form(gpu_ctx_factory):
     assert int(t.n_reads) == total
     off2, w2, e2 = fetch()
     assert off2.tobytes() == off.tobytes() and w2.tobytes() == w.tobytes() and e2.tobytes() == e.tobytes()
+
+
+def test_indel_path_at_tile_scale(gpu_ctx_factory):
+    """bcf_call_gap_prep at the cohort's shape (1000 samples x 30x of reads, 2048 columns, 0.5 % indel-noise reads, true indel
+    columns, a twentieth of the indels 8-40 bases), where the oracle takes a second a column: size-independent properties plus
+    an oracle spot check.
+     * the candidates the pooled support filter turns away (bam2bcf_indel.c:150-154) are exactly the columns with ret = -1 and
+       nothing else of them comes out; the ones it passes follow from the pileup's two per-column counts;
+     * partition invariance: the candidate list run as one call, and as two calls over its halves, gives the same per-column
+       results and the same indel tile (entries, p->aux) -- what two tiles, or two GPUs, would do;
+     * determinism: a second run gives identical bytes;
+     * three realigned columns and two rejected ones re-run through the oracle (types, p->aux of every entry)."""
+    import ctypes as C
+    from bcftools_amd import engine
+    from bcftools_amd.lib import check
+    from tests.helpers import indeldrv
+    S, n_sites = 1000, 2048
+    W = synth.wgs_reads(20260106, n_sites, S, 30.0)
+    arrs, mapq, smpl, n, L, beg, end = W["reads"], W["mapq"], W["smpl"], W["n_reads"], W["read_len"], W["beg"], W["end"]
+    ref_b = W["refseq"].encode()
+    rd = abi.Reads()
+    rd.n_reads = n
+    for k, v in arrs.items():
+        setattr(rd, k, v.ctypes.data)
+    with engine.Context(abi.default_cfg(S, max_sites=1, max_reads=64)) as c0:
+        t = abi.Tile()
+        check(c0.L.bcfgpu_pileup(c0.h, C.byref(rd), mapq.ctypes.data, smpl.ctypes.data, beg, end, ref_b, len(ref_b), C.byref(t), None, None))
+        entries = int(t.n_reads)
+    ctx = gpu_ctx_factory(abi.default_cfg(S, max_sites=n_sites, max_reads=entries + 64))
+    Lb = ctx.L
+    tile = abi.Tile()
+    col_n, col_indel = np.zeros(n_sites, np.int32), np.zeros(n_sites, np.uint8)
+    check(Lb.bcfgpu_pool_upload(ctx.h, C.byref(rd), None, mapq.ctypes.data))
+    check(Lb.bcfgpu_pool_pileup(ctx.h, smpl.ctypes.data, None, beg, end, ref_b, len(ref_b), C.byref(tile), col_n.ctypes.data, col_indel.ctypes.data))
+    cand = np.ascontiguousarray(np.nonzero((col_indel != 0) & (col_n < 250 * S))[0], dtype=np.int32)
+    assert len(cand) > n_sites // 2                                 # with 1000 samples most columns have some read with an indel
+    par = abi.IndelIn()
+    par.ref = ref_b
+    for k, v in indeldrv.DEFAULTS.items():
+        setattr(par, k, v)
+    CAP = indeldrv.CAP
+
+    def run(cols):
+        nc = len(cols)
+        out = dict(ret=np.zeros(nc, np.int32), indel_types=np.zeros((nc, 4), np.int32), inscns=np.zeros((nc, 4 * CAP), np.int8),
+                   maxins=np.zeros(nc, np.int32), indelreg=np.zeros(nc, np.int32), max_support=np.zeros(nc, np.int32), max_frac=np.zeros(nc, np.float32))
+        oo = abi.IndelOut()
+        oo.ret, oo.indel_types, oo.inscns = out["ret"].ctypes.data, out["indel_types"].ctypes.data, out["inscns"].ctypes.data
+        oo.maxins, oo.indelreg, oo.max_support, oo.max_frac = (out["maxins"].ctypes.data, out["indelreg"].ctypes.data,
+                                                               out["max_support"].ctypes.data, out["max_frac"].ctypes.data)
+        it = abi.Tile()
+        cc = np.ascontiguousarray(cols, dtype=np.int32)
+        check(Lb.bcfgpu_gap_prep_tile(ctx.h, nc, cc.ctypes.data, None, C.byref(par), C.byref(oo), CAP, C.byref(it)))
+        off = np.zeros(it.n_sites * S + 1, np.uint32)
+        aux, rdw = np.zeros(it.n_reads, np.uint32), np.zeros(it.n_reads, np.uint32)
+        if it.n_sites:
+            check(Lb.bcfgpu_memcpy_d2h(ctx.h, off.ctypes.data, it.plp_off, off.nbytes))
+            check(Lb.bcfgpu_memcpy_d2h(ctx.h, aux.ctypes.data, it.aux, aux.nbytes))
+            check(Lb.bcfgpu_memcpy_d2h(ctx.h, rdw.ctypes.data, it.rd, rdw.nbytes))
+        st = abi.GapStats()
+        check(Lb.bcfgpu_gap_prep_stats(ctx.h, C.byref(st)))
+        return out, off, aux, rdw, st
+    whole, off, aux, rdw, st = run(cand)
+    live = whole["ret"] == 0
+    assert 5 <= live.sum() <= n_sites // 20 and st.n_wide > 0       # the true indel columns (about 1 %), some of them long
+    assert (whole["indel_types"][~live] == 10000).all() and (whole["maxins"][~live] == 0).all()
+    assert len(off) == live.sum() * S + 1 and off[-1] == len(aux) == int(col_n[cand[live]].sum())
+    # determinism
+    again = run(cand)
+    for k in whole:
+        np.testing.assert_array_equal(again[0][k], whole[k], err_msg=k)
+    np.testing.assert_array_equal(again[2], aux)
+    # the candidate list in two calls
+    cut = len(cand) // 2 + 7
+    a, b = run(cand[:cut]), run(cand[cut:])
+    for k in whole:
+        np.testing.assert_array_equal(np.concatenate([a[0][k], b[0][k]]), whole[k], err_msg=k)
+    np.testing.assert_array_equal(np.concatenate([a[2], b[2]]), aux, err_msg="p->aux of the indel tile")
+    np.testing.assert_array_equal(np.concatenate([a[3], b[3]]), rdw, err_msg="read records of the indel tile")
+    # oracle spot check: realigned columns (a long type among them if there is one), rejected ones, and -- the case a call without
+    # any long TYPE must still get right -- a column of 1-3 base types one of whose reads carries a long indel elsewhere in the
+    # window: that read's realignments have the band |l_ref - l_query| (probaln.c), past the register classes
+    lt = whole["indel_types"]
+    has_long = ((np.abs(lt) >= 8) & (lt != 10000)).any(axis=1)
+    longc = [int(i) for i in np.nonzero(live & has_long)[0][:1]]
+    rpos, rlen, roff = arrs["r_pos"].astype(np.int64), W["ilen"], W["ioff"]
+    far = []
+    for ci in np.nonzero(live & ~has_long)[0]:
+        x = int(cand[ci]) + beg
+        at = rpos + roff                                            # the reference position in front of the read's indel
+        if ((np.abs(rlen) >= 8) & (rpos <= x) & (x < rpos + L) & (np.abs(at - x) > 3) & (np.abs(at - x) < 45)).any():
+            far.append(int(ci))
+    assert far, "no short-type column with a long indel in a read's window: another seed"
+    short_only = np.nonzero(~(live & has_long))[0]                  # a call whose columns have no long type at all
+    sh = run(cand[short_only])
+    for k in whole:
+        np.testing.assert_array_equal(sh[0][k], whole[k][short_only], err_msg="short-type columns alone: " + k)
+    np.testing.assert_array_equal(sh[2], np.concatenate([aux[off[j * S]:off[(j + 1) * S]] for j in np.nonzero((~has_long)[live])[0]]),
+                                  err_msg="short-type columns alone: p->aux")
+    assert sh[4].n_wide > 0                                         # wide-band jobs without a wide type
+    pick = sorted(set(longc + far[:2] + [int(i) for i in np.nonzero(live)[0][:1]] + [int(i) for i in np.nonzero(~live)[0][:2]]))
+    cols = np.ascontiguousarray(cand[pick])
+    tot_e = int(col_n[cols].sum())
+    so = np.zeros(len(pick) * S + 1, np.int32)
+    pr, pq, pi = np.zeros(tot_e, np.int32), np.zeros(tot_e, np.int32), np.zeros(tot_e, np.int32)
+    check(Lb.bcfgpu_pileup_entries(ctx.h, len(pick), cols.ctypes.data, so.ctypes.data, pr.ctypes.data, pq.ctypes.data, pi.ctypes.data, tot_e))
+    bb = dict(n_sites=len(pick), n_smpl=S, ref=ref_b, pos=(cols + beg).astype(np.int32), smpl_off=so, p_read=pr, p_qpos=pq, p_indel=pi,
+              reads=dict(arrs, n_reads=n, zq=np.zeros(n * L, np.uint8), r_has_zq=np.zeros(n, np.uint8)))
+    tile_col = np.cumsum(live) - 1                                  # a live candidate's site in the indel tile
+    for k, ci in enumerate(pick):
+        want = indeldrv.gap_prep_oracle_site(bb, k)
+        assert (want is None) == (not live[ci]), ci
+        if want is None:
+            continue
+        np.testing.assert_array_equal(whole["indel_types"][ci], want["indel_types"])
+        assert (whole["maxins"][ci], whole["indelreg"][ci], whole["max_support"][ci]) == (want["maxins"], want["indelreg"], want["max_support"])
+        j = int(tile_col[ci])
+        np.testing.assert_array_equal(aux[off[j * S]:off[(j + 1) * S]], want["aux"], err_msg="p->aux of candidate %d" % ci)
