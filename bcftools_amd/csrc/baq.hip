@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <vector>
+#include <type_traits>
 #include <cstring>
 #include <cstdlib>
 #include "kernels.h"
@@ -343,302 +344,397 @@ __device__ void baq_fb_lds(const BaqParams &P, int job, const BaqJob &j, const u
 }
 
 
-// The same with the current row in registers, for bands of half-width <= BWM (the default band of 7 fits): the forward
-// pass keeps its scaled row in registers and stores every other one (the posterior needs f*b per cell), the backward pass
-// keeps its row in registers, reads the stored forward rows back and re-forms the others.  Position p of a row is reference
-// column k = p + max(0, i-bw) - 1, htslib's set_u() slot, so both passes update in place (see probaln_fwd_reg in indel.hip);
-// the reference window travels in a 64-bit register, 3 bits per base.  Half a matrix write and half a read per cell instead
-// of the ~40 accesses of the scratch version.
-template <int BWM>
-__device__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const uint8_t *ref, const uint8_t *seq,
-                           const uint8_t *iqual, int bw, int32_t *state, uint8_t *q, const int pst, const float *lq2p)     // state / q of base i at [i * pst]
+__device__ __forceinline__ double uniform_f64(double x)      // the first running lane's value, in scalar registers
 {
-    constexpr int NP = 2 * BWM + 3;
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// The same with the current row in registers, for bands of half-width <= BW (the default band of 7 fits): the forward pass
+// keeps its scaled row in registers and stores every other one (the posterior needs f*b per cell), the backward pass keeps
+// its row in registers, reads the stored forward rows back and re-forms the others.
+// Layout: ALWAYS SLIDING, as in probaln_fwd_exact (indel.hip) -- position p (1..W, W = 2 BW + 1) of row i is reference column
+// k = p + i - bw - 1, for every row.  (htslib's set_u() pins the band to column 0 for the first bw rows; the layout is storage
+// only: the cells and the order of every sum are the reference's.)  Then
+//   forward   f[i][k] reads f[i-1][k-1] = old p,  f[i-1][k] = old p + 1,  f[i][k-1] = new p - 1        (ascending p, in place)
+//   backward  b[i][k] reads b[i+1][k+1] = old p,  b[i+1][k] = old p - 1,  b[i][k+1] = new p + 1        (descending p, in place)
+// with no choice between a sliding and a resting band in any cell.  Cells under the band's lower edge (k < 1) are zero in the
+// forward rows by construction (their three neighbours are); in the backward rows they hold values no live cell reads (a live
+// cell's neighbours have k >= 1) and their posterior term is 0 * b = 0.  So only the upper edge -- k > l_ref, or a band narrower
+// than BW -- needs masks, and a read of 100 bases in a window of 107 has no such row at all.  Every row body exists twice, each
+// straight-line code: the fast one (every cell of the row alive for EVERY read of the wavefront, no N under the band: no range
+// test, no mask, an emission = one comparison of byte codes and a select of the row's two values) and the edge one (masks, N,
+// reads of other lengths).  Each pass is a run of edge rows, a run of fast rows while every read of the wavefront qualifies, and
+// edge rows to the end -- separate loops, not a choice per row: with both bodies behind one branch the compiler forms the
+// products they share (m0 * M[p], ... -- 75 of them) in front of the branch and keeps them alive across it, 150 registers the
+// kernel does not have.  (Round 4's single body tested plo <= p <= phi and chose between the resting and the sliding neighbour
+// in every cell: 47 instructions a cell for the 19 fp64 operations of the forward recurrence.)
+// The reference window travels in W bytes of registers, a byte code per position (forward: one down per row, backward: one up).
+// The backward pass counts its rows down from the longest read of the wavefront, a shorter read joining at its own last row, so
+// that the row number -- odd or even: which posterior body runs -- is the same for all lanes.
+template <int BW>
+__device__ __forceinline__ void baq_fb_reg(const BaqParams &P, int job, const BaqJob &j, const uint8_t *ref, const uint8_t *seq,
+                                           const uint8_t *iqual, int bw, const float *lq2p)
+{
+    constexpr int W = 2 * BW + 1, NB = (W + 3) / 4, NP = 2 * BW + 3;
+    using Fast = std::true_type; using Edge = std::false_type;
     const int l_query = j.l_query, l_ref = j.l_ref;
     // A wavefront's rows are one contiguous block, [row][cell][lane]: consecutive stores are 512 bytes apart.  (With the
     // rows of all reads of a launch interleaved -- [row][cell][read] -- consecutive stores of a wavefront were megabytes
-    // apart, every one on a DRAM page and a TLB entry of its own: 1.8 TB/s.)  M and I only: the posterior never reads D.
-    const size_t wbase = (size_t)(job >> 6) * (size_t)(P.max_lq + 2);
-    const size_t wbF = (size_t)(job >> 6) * (size_t)BAQ_ROWS_KEPT(P.max_lq);    // the odd rows 1, 3, 5, ... in slots 0, 1, 2, ...
-    const int wl = job & 63;
-    // (M and I of a cell side by side in a lane's 16 bytes: one dwordx4 store / load per cell -- the phase is bound by the
-    // issue of its vector-memory instructions, and there are half as many this way)
-#ifdef BAQ_EXP_ROWMASK      // experiment (tools/file_variants.sh): the rows folded onto a few, so that the scratch stays in cache -- wrong results, the time says what HBM costs
-    #define FR2(i, p) reinterpret_cast<double2*>(P.F)[((wbF + (size_t)(((i) >> 1) & BAQ_EXP_ROWMASK)) * NP + (size_t)(p)) * 64 + wl]
-#else
-    #define FR2(i, p) reinterpret_cast<double2*>(P.F)[((wbF + (size_t)((i) >> 1)) * NP + (size_t)(p)) * 64 + wl]
-#endif
-    #define SC(i) P.S[(wbase + (size_t)(i)) * 64 + wl]
-    const int bw2 = bw * 2 + 1;
+    // apart, every one on a DRAM page and a TLB entry of its own: 1.8 TB/s.)  M and I only: the posterior never reads D;
+    // M and I of a cell side by side in a lane's 16 bytes: one dwordx4 store / load per cell.
+    // (the wavefront's base and the row's offset are the same for all lanes -- the row number is: scalar address arithmetic, the
+    // lane's 16 or 8 bytes the only vector part)
+    const unsigned wave = blockIdx.x, lane = threadIdx.x;         // = job >> 6, job & 63
+    double2 *const Fw = reinterpret_cast<double2*>(P.F) + (size_t)wave * (size_t)BAQ_ROWS_KEPT(P.max_lq) * NP * 64;
+    double *const Sw = P.S + (size_t)wave * (size_t)(P.max_lq + 2) * 64;
+    int32_t *const stw = P.wstate + (size_t)wave * (size_t)P.max_lq * 64;
+    uint8_t *const qw = P.wq + (size_t)wave * (size_t)P.max_lq * 64;
+    #define FR2(i, p) (Fw + ((size_t)((i) >> 1) * NP + (size_t)(p)) * 64)[lane]       // the odd rows 1, 3, 5, ... in slots 0, 1, 2, ...
+    #define SC(i) (Sw + (size_t)(i) * 64)[lane]
     const double d = 0.001, e_ = 0.1;
-    double m[9];
     const double sM = 1. / (2 * l_query + 2), sI = sM;
-    m[0] = (1 - d - d) * (1 - sM); m[1] = m[2] = d * (1 - sM);
-    m[3] = (1 - e_) * (1 - sI); m[4] = e_ * (1 - sI); m[5] = 0.;
-    m[6] = 1 - e_; m[7] = 0.; m[8] = e_;
+    const double m0 = (1 - d - d) * (1 - sM), m1 = d * (1 - sM), m2 = m1;
+    const double m3 = (1 - e_) * (1 - sI), m4 = e_ * (1 - sI);
+    const double m6 = 1 - e_, m8 = e_;
+    const double m1q = EI * m1, m4q = EI * m4;            // (EI = 1/4: scaling by a power of two commutes with rounding)
+    // The fast rows run only while all reads of the wavefront have one length: then the coefficients are the same in every lane and
+    // sit in scalar registers there (14 vector registers of the 256 the two passes need; the edge rows use the lanes' own).
+    const int lq_u = __builtin_amdgcn_readfirstlane(l_query);
+    const double m0u = uniform_f64(m0), m1qu = uniform_f64(m1q), m2u = uniform_f64(m2), m3u = uniform_f64(m3), m4qu = uniform_f64(m4q);
     const double bM = (1 - d) / l_ref, bI = d / l_ref;
-    auto qy = [&](int i) { return nt16_to_4(seq[i]); };
-    auto qp = [&](int i) { return (double)lq2p[iqual[i]]; };          // (float)pow(10, -Q/10), from the workgroup's copy in LDS
-    double M[NP], I[NP], D[NP];
+    const int top = 2 * bw + 1, lq1 = l_query - 1, lr1 = l_ref - 1;
+    double M[W + 2], I[W + 2], D[W + 2];
     #pragma unroll
-    for (int p = 0; p < NP; ++p) M[p] = I[p] = D[p] = 0.;
+    for (int p = 0; p < W + 2; ++p) M[p] = I[p] = D[p] = 0.;
+    // window: the code of the reference base under position p in byte p - 1 (forward: ref[k - 1], k the column of p in this row);
+    // 0 outside the reference -- a dead cell's emission is never used
+    uint32_t wv[NB];
+    #pragma unroll
+    for (int b = 0; b < NB; ++b) wv[b] = 0;
+    #pragma unroll
+    for (int p = 1; p <= W; ++p) { const int k = p - bw; wv[(p - 1) >> 2] |= (uint32_t)((k >= 1 && k <= l_ref) ? ref[k - 1] : 0) << (8 * ((p - 1) & 3)); }
+    auto wbyte = [&](int p) { return (wv[(p - 1) >> 2] >> (8 * ((p - 1) & 3))) & 0xffu; };
+    auto wdown = [&](uint32_t top_code) {                  // every position one down, top_code into position W
+        #pragma unroll
+        for (int b = 0; b + 1 < NB; ++b) wv[b] = __builtin_amdgcn_alignbyte(wv[b + 1], wv[b], 1);
+        wv[NB - 1] >>= 8;
+        wv[(W - 1) >> 2] |= top_code << (8 * ((W - 1) & 3));
+    };
+    auto wup = [&](uint32_t bottom_code) {                 // every position one up, bottom_code into position 1
+        #pragma unroll
+        for (int b = NB - 1; b >= 1; --b) wv[b] = __builtin_amdgcn_alignbyte(wv[b], wv[b - 1], 3);
+        wv[0] = (wv[0] << 8) | bottom_code;
+        if (W & 3) wv[NB - 1] &= (1u << (8 * (W & 3))) - 1u;
+    };
+    auto any_n = [&]() { uint32_t a = 0;
+        #pragma unroll
+        for (int b = 0; b < NB; ++b) a |= wv[b];
+        return (a & 0x04040404u) != 0; };
+    auto ref_at = [&](int k) { return (uint32_t)ref[k < 0 ? 0 : k > lr1 ? lr1 : k]; };   // (clamped: requested whether or not it is used)
     // ---- forward ----
     // The bytes a row needs (the query base, its quality, the reference base that slides into the band) are requested one row
-    // ahead, BEFORE the 32 stores of the row in between: vmcnt counts loads and stores in issue order, so a load requested
-    // after a row's stores is only known to be there when those stores are -- every row waited for its predecessor's writes
-    // to reach memory (80 % of a wavefront's life in s_waitcnt).
-    uint64_t rw = 0;                                      // base of position p (column k = p + x - 1, ref[k-1]) in bits [3p, 3p+3)
-    #pragma unroll
-    for (int p = 2; p < NP; ++p) rw |= (uint64_t)(p - 2 < l_ref ? ref[p - 2] : 4) << (3 * p);
-    {
+    // ahead, BEFORE the stores of the row in between: vmcnt counts loads and stores in issue order, so a load requested
+    // after a row's stores is only known to be there when those stores are.
+    double s_last;                                         // the scale of the last row
+    {   // row 1: k = p - bw
         double sum = 0.;
         const int end = l_ref < bw + 1 ? l_ref : bw + 1;
-        const double q0 = qp(0);
-        const int y0 = qy(0);
+        const double q0 = (double)lq2p[iqual[0]];
+        const uint32_t y0 = (uint32_t)nt16_to_4(seq[0]);
         #pragma unroll
-        for (int p = 2; p < NP; ++p) {
-            if (p - 1 <= end) {
-                const int rb = (int)((rw >> (3 * p)) & 7);
-                const double e = (rb > 3 || y0 > 3) ? 1. : rb == y0 ? 1. - q0 : q0 * EM;
-                const double a = e * bM, b = EI * bI;
-                M[p] = a; I[p] = b;
-                sum += a + b;
-            }
+        for (int p = 1; p <= W; ++p) {
+            const bool live = p > bw && p <= bw + end;
+            const uint32_t rb = wbyte(p);
+            const double e = (rb > 3 || y0 > 3) ? 1. : rb == y0 ? 1. - q0 : q0 * EM;
+            const double a = live ? e * bM : 0., b = live ? EI * bI : 0.;
+            M[p] = a; I[p] = b;
+            sum += a + b;
         }
         SC(1) = sum;
+        s_last = sum;
         #pragma unroll
-        for (int p = 1; p < NP; ++p) {
-            FR2(1, p) = make_double2(M[p], I[p]);               // (unscaled, like every stored row: see the loop below)
-            if (p >= 2 && p - 1 <= end) { M[p] /= sum; I[p] /= sum; D[p] /= sum; }
+        for (int p = 1; p <= W; ++p) {
+            FR2(1, p) = make_double2(M[p], I[p]);          // (unscaled, like every stored row: see below)
+            M[p] /= sum; I[p] /= sum;
         }
     }
-    int x = 0;
-    const int lq1 = l_query - 1, lr1 = l_ref - 1;
-    auto ref_at = [&](int k) { return (uint32_t)ref[k < 0 ? 0 : k > lr1 ? lr1 : k]; };   // (clamped: requested whether or not the band slides)
-    uint32_t nq = iqual[1 < lq1 ? 1 : lq1], ns = seq[1 < lq1 ? 1 : lq1], nr = ref_at(NP - 3 + 2 - bw);
-    for (int i = 2; i <= l_query; ++i) {
+    uint32_t nq = iqual[1 < lq1 ? 1 : lq1], ns = seq[1 < lq1 ? 1 : lq1], nr = ref_at(W + 2 - bw - 2);
+    auto fwd_row = [&](const int i, auto kind) {
+        constexpr bool FAST = decltype(kind)::value;
         const uint32_t cq = nq, cs = ns, cr = nr;
         {   // row i + 1's bytes
             const int in = i < lq1 ? i : lq1;
-            nq = iqual[in]; ns = seq[in]; nr = ref_at(NP - 3 + (i + 1) - bw);
+            nq = iqual[in]; ns = seq[in]; nr = ref_at(W + (i + 1) - bw - 2);
         }
         const double qli = (double)lq2p[cq];
-        const int qyi = nt16_to_4((int)cs);
-        const bool slide = i > bw;
-        if (slide) {
-            ++x;
-            rw >>= 3;
-            const int nk = (NP - 1) + x - 2;                      // = NP - 3 + i - bw
-            rw |= (uint64_t)(nk < l_ref ? cr : 4u) << (3 * (NP - 1));
-        }
-        const int end = l_ref < i + bw ? l_ref : i + bw;
-        const int plo = x == 0 ? 2 : 1, phi = end - x + 1;
+        const uint32_t qyi = (uint32_t)nt16_to_4((int)cs);
+        const double ex = qyi > 3 ? 1. : 1. - qli, ey = qyi > 3 ? 1. : qli * EM;      // the row's emission over a matching / another base
+        wdown(W + i - bw - 1 <= l_ref ? cr : 0u);
         double sum = 0.;
-        double cM = M[0], cI = I[0], cD = D[0];
-        M[0] = I[0] = D[0] = 0.;
-        #pragma unroll
-        for (int p = 1; p < NP; ++p) {
-            const double oM = M[p], oI = I[p], oD = D[p];
-            const double nM = p + 1 < NP ? M[p + 1 < NP ? p + 1 : p] : 0., nI = p + 1 < NP ? I[p + 1 < NP ? p + 1 : p] : 0.;
-            double f0 = 0., f1 = 0., f2 = 0.;
-            if (p >= plo && p <= phi) {
-                const int rb = (int)((rw >> (3 * p)) & 7);
-                const double e = (rb > 3 || qyi > 3) ? 1. : rb == qyi ? 1. - qli : qli * EM;
-                const double gM = slide ? oM : cM, gI = slide ? oI : cI, gD = slide ? oD : cD;
-                const double uM = slide ? nM : oM, uI = slide ? nI : oI;
-                f0 = e * (m[0] * gM + m[3] * gI + m[6] * gD);
-                f1 = EI * (m[1] * uM + m[4] * uI);
-                f2 = m[2] * M[p - 1] + m[8] * D[p - 1];
+        if (FAST) {
+            #pragma unroll
+            for (int p = 1; p <= W; ++p) {
+                const double e = wbyte(p) == qyi ? ex : ey;
+                const double f0 = e * (m0u * M[p] + m3u * I[p] + m6 * D[p]);
+                const double f1 = m1qu * M[p + 1] + m4qu * I[p + 1];
+                const double f2 = m2u * M[p - 1] + m8 * D[p - 1];
                 sum += f0 + f1 + f2;
+                M[p] = f0; I[p] = f1; D[p] = f2;
             }
-            M[p] = f0; I[p] = f1; D[p] = f2;
-            cM = oM; cI = oI; cD = oD;
+        } else {
+            const int hi = l_ref - (i - bw) + 1 < top ? l_ref - (i - bw) + 1 : top;
+            #pragma unroll
+            for (int p = 1; p <= W; ++p) {
+                const bool live = p <= hi;
+                const uint32_t rb = wbyte(p);
+                double e = rb > 3 ? 1. : rb == qyi ? ex : ey;
+                e = live ? e : 0.;
+                const double tv = live ? 1. : 0.;
+                const double f0 = e * (m0 * M[p] + m3 * I[p] + m6 * D[p]);
+                const double f1 = m1q * M[p + 1] + m4q * I[p + 1];
+                const double f2 = tv * (m2 * M[p - 1] + m8 * D[p - 1]);
+                sum += f0 + f1 + f2;
+                M[p] = f0; I[p] = f1; D[p] = f2;
+            }
         }
         SC(i) = sum;
+        s_last = sum;
         const double r = 1. / sum;
-        #pragma unroll
-        for (int p = 1; p < NP; ++p) {
-            // Only the ODD rows go to memory, and UNSCALED (M', I'; the scale is stored anyway): the backward pass re-forms an
-            // even row from the odd row below it while it forms that row's posterior.  Unscaled, because the row above needs D of
-            // this one, which is not stored: D' is the recurrence D'[p] = m2 M'[p-1] + m8 D'[p-1] over the UNSCALED M' -- re-run
-            // in the same order it gives the same bits, and the scaled row is re-formed by the same multiplication as here.
-            // Half the bytes of round 3's every-row store.
+        // Only the ODD rows go to memory, and UNSCALED (M', I'; the scale is stored anyway): the backward pass re-forms an
+        // even row from the odd row below it while it forms that row's posterior.  Unscaled, because the row above needs D of
+        // this one, which is not stored: D' is the recurrence D'[p] = m2 M'[p-1] + m8 D'[p-1] over the UNSCALED M' -- re-run
+        // in the same order it gives the same bits, and the scaled row is re-formed by the same multiplication as here.
 #ifdef BAQ_EXP_NOSTORE       // experiment: the forward rows are not written (never true at run time)
-            if (P.n_jobs < 0)
+        if (P.n_jobs < 0)
 #endif
-            if (i & 1) FR2(i, p) = make_double2(M[p], I[p]);
-            M[p] *= r; I[p] *= r; D[p] *= r;
+        if (i & 1) {
+            #pragma unroll
+            for (int p = 1; p <= W; ++p) {
+                // (non-temporal, like the loads that bring the row back: 6 GB a launch pass through once each way, a hundred rows
+                // apart -- the forward pass alone, bound by these stores, 1.67 -> 1.18 ms for 482 k reads)
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                v2d t; t.x = M[p]; t.y = I[p];
+                __builtin_nontemporal_store(t, reinterpret_cast<v2d*>(&FR2(i, p)));
+            }
         }
-    }
-    {
-        double sum = 0.;
-        const int phi = l_ref - x + 1 < bw2 ? l_ref - x + 1 : bw2;
-        const int plo = x == 0 ? 2 : 1;
         #pragma unroll
-        for (int p = 1; p < NP; ++p)
-            if (p >= plo && p <= phi) sum += M[p] * sM + I[p] * sI;
-        SC(l_query + 1) = sum;
+        for (int p = 1; p <= W; ++p) { M[p] *= r; I[p] *= r; D[p] *= r; }
+    };
+    {
+        int i = 2;
+        // fast rows: every cell of the row inside the reference, for every read of the wavefront, no N about to be under the band
+        for (;; ++i) {
+            const bool fast = i <= l_query && l_query == lq_u && bw == BW && i + bw <= l_ref && !any_n() && nr < 4;
+            if (__builtin_amdgcn_ballot_w64(!fast) != 0) break;
+            fwd_row(i, Fast());
+        }
+        #pragma unroll 1
+        for (; i <= l_query; ++i) fwd_row(i, Edge());
     }
+    double s_end = 0.;                                     // f[l_query + 1]: over the last row (dead cells are zero)
+    #pragma unroll
+    for (int p = 1; p <= W; ++p) s_end += M[p] * sM + I[p] * sI;
+    SC(l_query + 1) = s_end;
 #if defined(BAQ_EXP_PHASE) && BAQ_EXP_PHASE == 1   // experiment: the forward pass only
-    if (l_query > 0) { q[0] = (uint8_t)M[1]; return; }
+    if (l_query > 0) { qw[lane] = (uint8_t)M[1]; return; }
 #endif
     // ---- backward with the posterior maximum of every row ----
-    // x is max(0, l_query - bw) here.  Row l_query:
-    const double sl = SC(l_query);
-    {
-        const double sl1 = SC(l_query + 1);
-        const int phi = l_ref - x + 1 < bw2 ? l_ref - x + 1 : bw2;
-        const int plo = x == 0 ? 2 : 1;
+    // Iteration i: b[i] from b[i+1] (not for the last row), then the posterior of row i.  The window is the forward pass's: the
+    // step's emission is that of (row i+1, column k+1) = the forward window of row i+1 at the same position; then it moves one
+    // up and is row i's own, which the re-forming of an even row reads.
+    // fr0 / fr1: the stored (odd, unscaled) row the next posterior works from -- its own for an odd row, the row below for an even
+    // one; requested while the rows in between are worked on
+    // (60 registers beside the 60 of the backward row and what a cell needs: more than the 256 of two wavefronts a SIMD -- the kernel
+    // runs one wavefront a SIMD, with up to 512, see BAQ_WAVES.  Staging the row in LDS instead (copied there by global_load_lds, no
+    // destination register) fits two wavefronts and was 7 % faster on its own, but its 16 KB a wavefront keep the wide-band class's
+    // workgroups, which need 50 KB of LDS each, off the compute units: the handful of reads of that class then ran after the others
+    // instead of beside them, 55 ms for a pool of 4.9 M reads that is through the register classes in 45.)
+    double fr0[W + 2], fr1[W + 2];
+    fr0[0] = fr1[0] = fr0[W + 1] = fr1[W + 1] = 0.;
+    auto fr_request = [&](int row) {
         #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const bool in = p >= plo && p <= phi;
-            M[p] = in ? sM / sl / sl1 : 0.; I[p] = in ? sI / sl / sl1 : 0.; D[p] = 0.;
+        for (int p = 1; p <= W; ++p) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2d t = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(&FR2(row, p)));
+            fr0[p] = t.x; fr1[p] = t.y;
         }
-    }
-    // backward window: position p holds ref[p + x - 1] (the emission of column k+1), 7 beyond the reference
-    auto bcode = [&](int idx) { return (uint64_t)(idx >= 0 && idx < l_ref ? ref[idx] : 7); };
-    uint64_t rb_w = 0;
-    #pragma unroll
-    for (int p = 1; p < NP; ++p) rb_w |= bcode(p + x - 1) << (3 * p);
-    constexpr uint64_t WMASK = (NP * 3 >= 64) ? ~0ull : ((1ull << (NP * 3)) - 1);
-    // The forward row of the posterior, the scale, the query byte and the reference byte of a row are requested while the row
-    // before it (i + 1) is being worked on: the forward values of row i - 1 right after row i's posterior has consumed its own.
-    // fr0 / fr1: the stored (odd, unscaled) row the next posterior works from -- its own for an odd row, the row below for an even one
-    double fr0[NP], fr1[NP];
-    fr0[0] = fr1[0] = 0.;
-    bool fr_scaled = false;                               // row 1 in fr has been divided by its sum
-    #pragma unroll
-    for (int p = 1; p < NP; ++p) { const double2 t = FR2((l_query & 1) ? l_query : l_query - 1, p); fr0[p] = t.x; fr1[p] = t.y; }
-
-    uint32_t bq_n = 0, bs_n = 0, br_n = 0;                // bytes of row l_query - 1
-    double sc_n = 1.;
-    {
-        const int in = lq1 > 0 ? lq1 : 0, i1 = l_query - 1, xi1 = i1 - bw > 0 ? i1 - bw : 0;
-        bq_n = iqual[in]; bs_n = seq[in]; br_n = ref_at(xi1); sc_n = SC(i1 > 1 ? i1 : 1);
-    }
-    for (int i = l_query; i >= 1; --i) {
-        double sc_i = sl;                                 // the scale of row i
-        if (i < l_query) {
-            // b[i] from b[i+1], in place, descending p
-            const int xi = i - bw > 0 ? i - bw : 0;
-            const bool slide = xi != x;                   // the band of row i+1 sits one column to the right
-            const uint32_t cq = bq_n, cs = bs_n, cr = br_n;
-            const double csc = sc_n;
-            sc_i = csc;
-            {   // row i - 1's bytes and scale
-                const int i1 = i - 1 > 1 ? i - 1 : 1, xi1 = i1 - bw > 0 ? i1 - bw : 0;
-                bq_n = iqual[i1]; bs_n = seq[i1]; br_n = ref_at(xi1); sc_n = SC(i1);
-            }
-            if (slide) { rb_w = ((rb_w << 3) & WMASK & ~7ull) | ((uint64_t)(xi < l_ref ? cr : 7u) << 3); }
-            x = xi;
-            const double qli1 = (double)lq2p[cq];
-            const int qyi1 = nt16_to_4((int)cs);
-            const int end = l_ref < i + bw ? l_ref : i + bw;
-            const int plo = x == 0 ? 2 : 1, phi = end - x + 1;
-            const double y = (i > 1);
-            double cM = 0., cI = 0., cD = 0.;             // old [p+1]
+    };
+    auto fr = [&](int p) { return make_double2(fr0[p], fr1[p]); };
+    bool fr_scaled = false;                                // row 1 in fr has been divided by its sum
+    // bytes of the query: hi = base i (row i+1's, the step's), lo = base i-1 (row i's own); the scale of rows i and i-1; the
+    // reference base that enters the window from below -- all requested an iteration ahead
+    uint32_t q_hi = 0, s_hi = 0, q_lo = 0, s_lo = 0, r_in = 0;
+    double sc_i = 1., sc_n = 1.;
+    auto bwd_row = [&](const int i, auto kind) {
+        constexpr bool FAST = decltype(kind)::value;
+        if (!FAST && i == l_query) {                       // this read's last row: where its backward pass starts
+            const int lo = bw + 2 - l_query > 1 ? bw + 2 - l_query : 1;
+            const int hi = l_ref - l_query + bw + 1 < top ? l_ref - l_query + bw + 1 : top;
+            const double vM = sM / s_last / s_end, vI = sI / s_last / s_end;
             #pragma unroll
-            for (int p = NP - 2; p >= 1; --p) {
-                const double oM = M[p], oI = I[p], oD = D[p];
-                double nM = 0., nI = 0., nD = 0.;
-                if (p >= plo && p <= phi) {
-                    const int rb = (int)((rb_w >> (3 * p)) & 7);
-                    const double em = rb == 7 ? 0. : (rb > 3 || qyi1 > 3) ? 1. : rb == qyi1 ? 1. - qli1 : qli1 * EM;
-                    const double e = em * (slide ? oM : cM);
-                    const double b10 = slide ? I[p - 1] : oI;
-                    const double b01 = D[p + 1];
-                    nM = e * m[0] + EI * m[1] * b10 + m[2] * b01;
-                    nI = e * m[3] + EI * m[4] * b10;
-                    nD = (e * m[6] + m[8] * b01) * y;
-                }
-                M[p] = nM; I[p] = nI; D[p] = nD;
-                cM = oM; cI = oI; cD = oD;
+            for (int p = 1; p <= W; ++p) {
+                const bool in = p >= lo && p <= hi;
+                M[p] = in ? vM : 0.; I[p] = in ? vI : 0.;
             }
-            (void)cI; (void)cD;
-            M[NP - 1] = I[NP - 1] = D[NP - 1] = 0.;
-            const double y2 = 1. / csc;
-            #pragma unroll
-            for (int p = 1; p < NP; ++p) { M[p] *= y2; I[p] *= y2; D[p] *= y2; }
+            q_lo = iqual[lq1]; s_lo = seq[lq1];
+            sc_i = s_last; sc_n = SC(l_query - 1 > 1 ? l_query - 1 : 1);
+            fr_request((l_query & 1) ? l_query : l_query - 1);
         }
-        // posterior of row i (probaln.c MAP): first maximum over k ascending, M before I
-        {
-            const int end = l_ref < i + bw ? l_ref : i + bw;
-            const int plo = x == 0 ? 2 : 1, phi = end - x + 1;
-            double sum = 0., max = 0.;
-            int max_k = -1;
-            const double r_i = 1. / sc_i;                 // (row 1 was scaled by a division, every other row by this reciprocal)
-            // Row 1 in fr (at i = 2, or at i = 1 for a read of one base) is divided by its sum once, in place -- as the forward pass
-            // did -- and from then on counts as scaled: the loops below multiply it by 1.  (A division in every cell of every row,
-            // selected away for all rows but two, was a quarter of the pass.)
-            if (i <= 2 && !fr_scaled) {
-                const double s1 = i == 1 ? sc_i : sc_n;
+        const int i2 = i - 2 > 0 ? i - 2 : 0;
+        const uint32_t rq_q = iqual[i2], rq_s = seq[i2], rq_r = ref_at(i - bw - 2);
+        const double rq_sc = SC(i - 2 > 1 ? i - 2 : 1);
+        const double r_i = 1. / sc_i;                     // (row 1 was scaled by a division, every other row by this reciprocal)
+        if (FAST || i < l_query) {
+            const double qli = (double)lq2p[q_hi];
+            const uint32_t qyi = (uint32_t)nt16_to_4((int)s_hi);
+            const double ex = qyi > 3 ? 1. : 1. - qli, ey = qyi > 3 ? 1. : qli * EM;
+            if (FAST) {
+                double b01 = 0.;                           // b[i][k+1].D, unscaled: the row's D state lives in this chain only
                 #pragma unroll
-                for (int p = 1; p < NP; ++p) { fr0[p] /= s1; fr1[p] /= s1; }
-                fr_scaled = true;
-            }
-            if (i & 1) {
-                // an odd row: its own stored values, scaled as the forward pass scaled them
-                const double r_o = i == 1 ? 1. : r_i;
-                #pragma unroll
-                for (int p = 1; p < NP; ++p) {
-                    if (p >= plo && p <= phi) {
-                        const int k = p + x - 1;
-                        const double fM = fr0[p] * r_o, fI = fr1[p] * r_o;
-                        double z;
-                        z = fM * M[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 0; } sum += z;
-                        z = fI * I[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 1; } sum += z;
-                    }
-                }
-                // the stored row the next two posteriors work from: row i - 2 (row i - 1 is re-formed from it, then it is its own)
-#ifdef BAQ_EXP_NOLOAD       // experiment: the forward rows are not read back (never true at run time): the backward pass on stale values
-                if (P.n_jobs < 0)
-#endif
-                if (i >= 3) {
-                    #pragma unroll
-                    for (int p = 1; p < NP; ++p) { const double2 t = FR2(i - 2, p); fr0[p] = t.x; fr1[p] = t.y; }
+                for (int p = W; p >= 1; --p) {
+                    const double e = (wbyte(p) == qyi ? ex : ey) * M[p];
+                    const double b10 = I[p - 1];
+                    M[p] = e * m0u + m1qu * b10 + m2u * b01;
+                    I[p] = e * m3u + m4qu * b10;
+                    b01 = e * m6 + m8 * b01;              // (times y = 1; row 1's D, y = 0, is read by nothing)
                 }
             } else {
-                // an even row: re-formed cell by cell from the stored row below (fr = row i - 1, unscaled) exactly as the forward pass
-                // formed it -- the row below scaled by its own factor (row 1: divided), its D by the recurrence over the unscaled M',
-                // the three-term sums in the forward pass's order, then this row's scale
-                const bool b1 = i == 2;                                       // the row below is row 1: already divided by its sum (above), D = 0
-                const double r_b = b1 ? 1. : 1. / sc_n;                       // the row below's scale: 1 / SC(i - 1)
-                const bool fslide = i > bw;                                   // the band of row i sits one column to the right of row i - 1's
-                const int xb_ = i - 1 - bw > 0 ? i - 1 - bw : 0;
-                const int endb = l_ref < i - 1 + bw ? l_ref : i - 1 + bw;
-                const int plob = xb_ == 0 ? 2 : 1, phib = endb - xb_ + 1;     // the row below's range (row 1: 2 .. min(l_ref, bw + 1) + 1, the same formula)
-                const double qli = (double)lq2p[bq_n];                        // row i's own base and quality (requested a row ago)
-                const int qyi = nt16_to_4((int)bs_n);
-                auto sb = [&](double v) { return v * r_b; };
-                double dprev = 0.;                                            // D'[p - 1] of the row below, unscaled
+                const int lo = bw + 2 - i > 1 ? bw + 2 - i : 1;
+                const int hi = l_ref - i + bw + 1 < top ? l_ref - i + bw + 1 : top;
+                const double y = (i > 1);
+                double b01 = 0.;
                 #pragma unroll
-                for (int p = 1; p < NP; ++p) {
-                    const double dcur = (!b1 && p >= plob && p <= phib) ? m[2] * fr0[p - 1] + m[8] * dprev : 0.;   // D'[p]
-                    if (p >= plo && p <= phi) {
-                        const int k = p + x - 1;
-                        // the reference base of column k - 1 = ref[p + x - 2]: one position down the backward window; position 0 is the
-                        // base that slides in for the row below (br_n)
-                        const int rb = p == 1 ? (int)br_n : (int)((rb_w >> (3 * (p - 1))) & 7);
-                        const double e = (rb > 3 || qyi > 3) ? 1. : rb == qyi ? 1. - qli : qli * EM;
-                        const double gM = sb(fslide ? fr0[p] : fr0[p - 1]), gI = sb(fslide ? fr1[p] : fr1[p - 1]);
-                        const double gD = b1 ? 0. : (fslide ? dcur : dprev) * r_b;
-                        const double uM = sb(fslide ? (p + 1 < NP ? fr0[p + 1 < NP ? p + 1 : p] : 0.) : fr0[p]);
-                        const double uI = sb(fslide ? (p + 1 < NP ? fr1[p + 1 < NP ? p + 1 : p] : 0.) : fr1[p]);
-                        const double f0 = e * (m[0] * gM + m[3] * gI + m[6] * gD);
-                        const double f1 = EI * (m[1] * uM + m[4] * uI);
-                        const double fM = f0 * r_i, fI = f1 * r_i;
-                        double z;
-                        z = fM * M[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 0; } sum += z;
-                        z = fI * I[p]; if (z > max) { max = z; max_k = (k - 1) << 2 | 1; } sum += z;
-                    }
-                    dprev = dcur;
+                for (int p = W; p >= 1; --p) {
+                    const bool live = p >= lo && p <= hi;
+                    const uint32_t rb = wbyte(p);
+                    const double em = p + i - bw - 1 >= l_ref ? 0. : rb > 3 ? 1. : rb == qyi ? ex : ey;    // column k+1 beyond the reference: no emission
+                    const double e = em * M[p];
+                    const double b10 = I[p - 1];
+                    const double nM = e * m0 + m1q * b10 + m2 * b01;
+                    const double nI = e * m3 + m4q * b10;
+                    const double nD = (e * m6 + m8 * b01) * y;
+                    M[p] = live ? nM : 0.; I[p] = live ? nI : 0.; b01 = live ? nD : 0.;
                 }
             }
-            max /= sum;
-            state[(size_t)(i - 1) * pst] = max_k;
-            const int kq = (int)(-4.343 * log(1. - max) + .499);
-            q[(size_t)(i - 1) * pst] = (uint8_t)(kq > 100 ? 99 : kq);
+            #pragma unroll
+            for (int p = 1; p <= W; ++p) { M[p] *= r_i; I[p] *= r_i; }       // (the D state of a backward row is read within the row only)
+            wup(i - bw - 1 >= 0 && i - bw - 1 < l_ref ? r_in : 0u);
         }
+        // posterior of row i (probaln.c MAP): first maximum over k ascending, M before I.  A dead cell's term is 0 (its forward
+        // value is), and a zero never beats the running maximum: no range test.
+        double sum = 0., max = 0.;
+        int best = -1;                                    // p << 2 | state of the maximum
+        // Row 1 in fr (at i = 2, or at i = 1 for a read of one base) is divided by its sum once, in place -- as the forward pass
+        // did -- and from then on counts as scaled.
+        if (!FAST && i <= 2 && !fr_scaled) {
+            const double s1 = i == 1 ? sc_i : sc_n;
+            #pragma unroll
+            for (int p = 1; p <= W; ++p) { fr0[p] /= s1; fr1[p] /= s1; }
+            fr_scaled = true;
+        }
+        if (i & 1) {
+            // an odd row: its own stored values, scaled as the forward pass scaled them
+            const double r_o = i == 1 ? 1. : r_i;
+            #pragma unroll
+            for (int p = 1; p <= W; ++p) {
+                const double2 t = fr(p);
+                const double fM = t.x * r_o, fI = t.y * r_o;
+                double z;
+                z = fM * M[p]; if (z > max) { max = z; best = p << 2 | 0; } sum += z;
+                z = fI * I[p]; if (z > max) { max = z; best = p << 2 | 1; } sum += z;
+            }
+            // the stored row the next two posteriors work from: row i - 2 (row i - 1 is re-formed from it, then it is its own)
+#ifdef BAQ_EXP_NOLOAD       // experiment: the forward rows are not read back (never true at run time): the backward pass on stale values
+            if (P.n_jobs < 0)
+#endif
+            if (i >= 3) fr_request(i - 2);
+        } else {
+            // an even row: re-formed cell by cell from the stored row below (fr = row i - 1, unscaled) exactly as the forward pass
+            // formed it -- the row below scaled by its own factor (row 1: divided, above), its D by the recurrence over the unscaled
+            // M', the three-term sums in the forward pass's order, then this row's scale
+            const double qli = (double)lq2p[q_lo];        // row i's own base and quality
+            const uint32_t qyi = (uint32_t)nt16_to_4((int)s_lo);
+            const double ex = qyi > 3 ? 1. : 1. - qli, ey = qyi > 3 ? 1. : qli * EM;
+            if (FAST) {
+                const double r_b = 1. / sc_n;             // the row below's scale: 1 / SC(i - 1)
+                const double2 t1 = fr(1);
+                double gM = t1.x * r_b, gI = t1.y * r_b, dp = 0., mp = 0., mc = t1.x;     // the row below at p, scaled; D'[p - 1], M'[p - 1], M'[p] unscaled
+                #pragma unroll
+                for (int p = 1; p <= W; ++p) {
+                    const double dc = m2u * mp + m8 * dp;                                // D'[p]
+                    const double gD = dc * r_b;
+                    const double2 tn = fr(p + 1);
+                    const double uM = tn.x * r_b, uI = tn.y * r_b;
+                    const double e = wbyte(p) == qyi ? ex : ey;
+                    const double f0 = e * (m0u * gM + m3u * gI + m6 * gD);
+                    const double f1 = m1qu * uM + m4qu * uI;
+                    const double fM = f0 * r_i, fI = f1 * r_i;
+                    double z;
+                    z = fM * M[p]; if (z > max) { max = z; best = p << 2 | 0; } sum += z;
+                    z = fI * I[p]; if (z > max) { max = z; best = p << 2 | 1; } sum += z;
+                    dp = dc; gM = uM; gI = uI; mp = mc; mc = tn.x;
+                }
+            } else {
+                const bool b1 = i == 2;                                       // the row below is row 1: already divided by its sum, D = 0
+                const double r_b = b1 ? 1. : 1. / sc_n;
+                const int hib = l_ref - (i - 1) + bw + 1 < top ? l_ref - (i - 1) + bw + 1 : top;     // the row below's live cells end here
+                const int hi = l_ref - i + bw + 1 < top ? l_ref - i + bw + 1 : top;
+                double dp = 0.;
+                #pragma unroll
+                for (int p = 1; p <= W; ++p) {
+                    const double2 tp = fr(p - 1), tc = fr(p), tn = fr(p + 1);
+                    const double dc = (!b1 && p <= hib) ? m2 * tp.x + m8 * dp : 0.;
+                    const uint32_t rb = wbyte(p);
+                    const double e = rb > 3 ? 1. : rb == qyi ? ex : ey;
+                    const double gM = tc.x * r_b, gI = tc.y * r_b, gD = dc * r_b;
+                    const double uM = tn.x * r_b, uI = tn.y * r_b;
+                    const double f0 = e * (m0 * gM + m3 * gI + m6 * gD);
+                    const double f1 = m1q * uM + m4q * uI;
+                    const double fM = p <= hi ? f0 * r_i : 0., fI = p <= hi ? f1 * r_i : 0.;
+                    double z;
+                    z = fM * M[p]; if (z > max) { max = z; best = p << 2 | 0; } sum += z;
+                    z = fI * I[p]; if (z > max) { max = z; best = p << 2 | 1; } sum += z;
+                    dp = dc;
+                }
+            }
+        }
+        max /= sum;
+        (stw + (size_t)(i - 1) * 64)[lane] = best < 0 ? -1 : ((i - bw - 2) << 2) + best;      // (k - 1) << 2 | state, k = p + i - bw - 1
+        const int kq = (int)(-4.343 * log(1. - max) + .499);
+        (qw + (size_t)(i - 1) * 64)[lane] = (uint8_t)(kq > 100 ? 99 : kq);
+        q_hi = q_lo; s_hi = s_lo; q_lo = rq_q; s_lo = rq_s; r_in = rq_r;
+        sc_i = sc_n; sc_n = rq_sc;
+    };
+    {
+        // the longest read of the wavefront (the lanes that run: the others have returned)
+        int i = 0;
+        {
+            bool todo = true;
+            for (;;) {
+                const uint64_t m = __builtin_amdgcn_ballot_w64(todo);
+                if (m == 0) break;
+                const int v = __builtin_amdgcn_readlane(l_query, (int)__builtin_ctzll(m));
+                i = v > i ? v : i;
+                if (l_query <= v) todo = false;
+            }
+        }
+        // A fast iteration: every lane past its own last row, the step's and the row's cells all inside the reference, not the rows 2
+        // and 1 (row 1 was scaled by a division and has no D), no N in the window before or after it moves.
+        auto fast_at = [&](int r) { return r < l_query && l_query == lq_u && r > 2 && bw == BW && r + bw + 1 <= l_ref && !any_n() && r_in < 4; };
+        #pragma unroll 1
+        for (; i >= 1; --i) {
+            if (__builtin_amdgcn_ballot_w64(!fast_at(i)) == 0) break;
+            if (i <= l_query) bwd_row(i, Edge());
+        }
+        for (; i >= 1; --i) {
+            if (__builtin_amdgcn_ballot_w64(!fast_at(i)) != 0) break;
+            bwd_row(i, Fast());
+        }
+        #pragma unroll 1
+        for (; i >= 1; --i)
+            if (i <= l_query) bwd_row(i, Edge());
     }
     #undef FR2
     #undef SC
@@ -714,11 +810,13 @@ __device__ void baq_cap(const BaqParams &P, const BaqJob &j, const uint8_t *iqua
 #define BAQ_BWM2 8
 #define BAQ_WIDE_LANES 8
 
+// Wavefronts per SIMD the compiler is to leave room for: one for the register-row classes -- the two rows of the backward pass, the
+// stored forward row and a cell's operands are 330 - 390 registers (with two wavefronts and 256 the row loops spill: 1.2x - 2x slower).
 #ifndef BAQ_WAVES
-#define BAQ_WAVES 2          // wavefronts per SIMD the register rows allow; 3 and 4 (spills, or without the one-row-ahead loads): 1.4x - 2.3x slower
+#define BAQ_WAVES(bwm) ((bwm) > 0 ? 1 : 2)
 #endif
 template <int BWM>          // 0: both matrices in scratch, any band
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAQ_WAVES, 8))) void baq_kernel(const BaqParams P)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAQ_WAVES(BWM), 8))) void baq_kernel(const BaqParams P)
 {
     __shared__ float s_q2p[256];
     for (int t = threadIdx.x; t < 256; t += 64) s_q2p[t] = P.q2p[t];
@@ -749,7 +847,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAQ_WAVES, 8
         int bw = j.l_ref > j.l_query ? j.l_ref : j.l_query;
         if (bw > j.bw) bw = j.bw;
         if (bw < abs(j.l_ref - j.l_query)) bw = abs(j.l_ref - j.l_query);
-        baq_fb_reg<(BWM > 0 ? BWM : 1)>(P, job, j, ref, seq, iqual, bw, state, q, pst, s_q2p);
+        baq_fb_reg<(BWM > 0 ? BWM : 1)>(P, job, j, ref, seq, iqual, bw, s_q2p);
     } else if (P.lds_rows && j.l_ref <= P.max_lq + P.ncell / 6 + 16) {        // (the window fits the LDS copy: always, realn.c trims it to the read and its band)
         extern __shared__ double s_rows[];                   // [3][ncell][LANES] doubles, then the window's bases [max l_ref][LANES]
         const size_t rw = (size_t)P.ncell * LANES;
@@ -814,25 +912,39 @@ __global__ __launch_bounds__(256) void baq_prep_kernel(const BaqPrepParams P)
             if (j.l_ref > 0) { wlo = xb; whi = xe; }
         }
     }
-    // one atomic per wavefront and class (every lane on the two counters would queue up behind one another)
+    // One atomic per WORKGROUP and class, and the maxima only when they would change a counter: every lane, or every wavefront, on
+    // the same few counters queue up behind one another in L2 (3.7 ms for 4.9 M reads with one set of atomics a wavefront).
+    __shared__ int s_cnt[4][3], s_base[3], s_red[4][4];
+    const int wave = threadIdx.x >> 6;
+    unsigned long long m[3];
     #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == c);
-        if (!m) continue;
-        int base = 0;
-        if (lane == __builtin_ctzll(m)) base = atomicAdd(&P.counts[c == 2 ? 6 : c], (int)__popcll(m));
-        base = __shfl(base, __builtin_ctzll(m));
-        if (cls == c) (c == 0 ? P.jobs0 : c == 1 ? P.jobs1 : P.jobs2)[base + (int)__popcll(m & ((1ull << lane) - 1))] = j;
-    }
+    for (int c = 0; c < 3; ++c) { m[c] = __builtin_amdgcn_ballot_w64(cls == c); if (lane == 0) s_cnt[wave][c] = (int)__popcll(m[c]); }
     int wb = cls == 2 ? b : 1;
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { wb = max(wb, __shfl_xor(wb, o)); lq = max(lq, __shfl_xor(lq, o)); wlo = min(wlo, __shfl_xor(wlo, o)); whi = max(whi, __shfl_xor(whi, o)); }
-    if (lane == 0) {
-        if (wb > 1) atomicMax(&P.counts[2], wb);
-        if (lq > 1) atomicMax(&P.counts[3], lq);
-        if (wlo != INT32_MAX) { atomicMin(&P.counts[4], wlo); atomicMax(&P.counts[5], whi); }
+    if (lane == 0) { s_red[wave][0] = wb; s_red[wave][1] = lq; s_red[wave][2] = wlo; s_red[wave][3] = whi; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x, tot = s_cnt[0][c] + s_cnt[1][c] + s_cnt[2][c] + s_cnt[3][c];
+        s_base[c] = tot ? atomicAdd(&P.counts[c == 2 ? 6 : c], tot) : 0;
+    } else if (threadIdx.x == 64) {
+        int xb_ = 1, xl = 1, xlo = INT32_MAX, xhi = 0;
+        for (int w = 0; w < 4; ++w) { xb_ = max(xb_, s_red[w][0]); xl = max(xl, s_red[w][1]); xlo = min(xlo, s_red[w][2]); xhi = max(xhi, s_red[w][3]); }
+        volatile int *cnt = P.counts;                      // (a stale value only costs an atomic that changes nothing)
+        if (xb_ > 1 && xb_ > cnt[2]) atomicMax(&P.counts[2], xb_);
+        if (xl > 1 && xl > cnt[3]) atomicMax(&P.counts[3], xl);
+        if (xlo != INT32_MAX) { if (xlo < cnt[4]) atomicMin(&P.counts[4], xlo); if (xhi > cnt[5]) atomicMax(&P.counts[5], xhi); }
+    }
+    __syncthreads();
+    #pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (cls != c) continue;
+        int base = s_base[c];
+        for (int w = 0; w < wave; ++w) base += s_cnt[w][c];
+        (c == 0 ? P.jobs0 : c == 1 ? P.jobs1 : P.jobs2)[base + (int)__popcll(m[c] & ((1ull << lane) - 1))] = j;
     }
 }
+
 __global__ __launch_bounds__(256) void baq_ref4_kernel(const char *ref, size_t n, uint8_t *out)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -179,3 +179,47 @@ def test_baq_on_reads_of_one_to_nine_bases(gpu_ctx_factory):
                 np.testing.assert_array_equal(r.qual, wq, err_msg=r.qname)
                 np.testing.assert_array_equal(r.zq, wz, err_msg=r.qname)
         assert n_ok > 150
+
+
+def test_baq_on_reads_of_one_length_over_a_reference_with_n(gpu_ctx_factory):
+    """Wavefronts whose reads all have one length run the mask-free row bodies of baq_fb_reg -- until a read of the wavefront gets
+    an N under its band, or its band reaches the end of the contig: from that row on the wavefront runs the masked bodies, in the
+    forward pass and again (from the other side) in the backward pass.  256 reads of 100 bases, plain 100M, over a reference with
+    an N, a run of N and reads flush with both ends of the contig; a few reads carry an N of their own."""
+    rng = np.random.default_rng(2024)
+    L, n = 2000, 100
+    ref = [("ACGT"[i]) for i in rng.integers(0, 4, L)]
+    ref[500] = "N"
+    for k in range(1200, 1207):
+        ref[k] = "N"
+    refseq = "".join(ref)
+
+    class Rd:
+        pass
+    reads = []
+    for i in range(256):
+        pos = int(rng.integers(0, L - n + 1))
+        if i % 32 == 0:
+            pos = 0 if i % 64 == 0 else L - n
+        if i % 16 == 5:
+            pos = int(rng.integers(420, 500))                  # the N comes under the band somewhere inside the read
+        seq = [refseq[pos + k] if rng.random() > 0.02 else "ACGT"[int(rng.integers(0, 4))] for k in range(n)]
+        if i % 23 == 0:
+            seq[int(rng.integers(0, n))] = "N"
+        r = Rd()
+        r.pos, r.seq, r.l_qseq, r.flag, r.qname = pos, "".join(seq), n, 0, "u%d" % i
+        r.qual = rng.integers(2, 42, n).astype(np.int32)
+        r.bamcigar = np.array([(n << 4) | 0], dtype=np.uint32)
+        r.zq = None
+        reads.append(r)
+    for flag in (3, 1):
+        rs = []
+        for r in reads:
+            c = Rd(); c.__dict__.update(r.__dict__); c.qual = r.qual.copy(); rs.append(c)
+        ctx = gpu_ctx_factory(abi.default_cfg(1, max_sites=1, max_reads=64))
+        want = _oracle(rs, refseq, flag)
+        ret = M.apply_baq_hip(rs, refseq, ctx, flag)
+        for r, (rc, wq, wz), rr in zip(rs, want, ret):
+            assert rc == 0 and rr == 0, r.qname
+            np.testing.assert_array_equal(r.qual, wq, err_msg=r.qname)
+            np.testing.assert_array_equal(r.zq, wz, err_msg=r.qname)
