@@ -945,6 +945,39 @@ __global__ __launch_bounds__(256) void baq_prep_kernel(const BaqPrepParams P)
     }
 }
 
+// The wide-band class's jobs in descending order of their band (a counting sort, one workgroup: the class is a few reads in a
+// thousand).  A wavefront of the class takes BAQ_WIDE_LANES reads and sweeps to the widest band among them: in arrival order
+// nearly every wavefront had one of the widest (a pool with indels of 8 - 40 bases: mean band 34, mean of a wavefront's maximum
+// 70), and the widest, which run longest, start first.
+__global__ __launch_bounds__(1024) void baq_sort_wide_kernel(const BaqJob *in, int n, BaqJob *out)
+{
+    __shared__ int s_hist[1024], s_part[1024];
+    auto key = [](const BaqJob &j) {
+        int b = j.l_ref > j.l_query ? j.l_ref : j.l_query;
+        if (b > j.bw) b = j.bw;
+        if (b < abs(j.l_ref - j.l_query)) b = abs(j.l_ref - j.l_query);
+        return 1023 - (b > 1023 ? 1023 : b);               // (ascending key = descending band)
+    };
+    const int tid = threadIdx.x;
+    s_hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) atomicAdd(&s_hist[key(in[i])], 1);
+    __syncthreads();
+    // exclusive prefix of the 1024 counts
+    const int v = s_hist[tid];
+    s_part[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int t = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += t;
+        __syncthreads();
+    }
+    s_hist[tid] = s_part[tid] - v;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) { const BaqJob j = in[i]; out[atomicAdd(&s_hist[key(j)], 1)] = j; }
+}
+
 __global__ __launch_bounds__(256) void baq_ref4_kernel(const char *ref, size_t n, uint8_t *out)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1176,6 +1209,12 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
     // wavefront, half a millisecond with the chip otherwise idle.
     hipStream_t *side = nullptr; hipEvent_t *sev = nullptr;
     if (bcfgpu_internal_side(ctx, &side, &sev)) return bcfgpu_set_error(BCFGPU_E_HIP, "bcfgpu_pool_baq: side streams");
+    BaqJob *jobs2 = Q.jobs2;                               // the wide class's jobs, sorted by band (before anything else is on the chip:
+    if (counts[6] > 0) {                                   // one workgroup, 20 us alone, 15 ms behind a launch that fills it)
+        jobs2 = (BaqJob*)bcfgpu_internal_ws(ctx, 128, (size_t)counts[6] * sizeof(BaqJob) + 64);
+        if (!jobs2) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_baq: device workspace");
+        hipLaunchKernelGGL(baq_sort_wide_kernel, dim3(1), dim3(1024), 0, stream, Q.jobs2, counts[6], jobs2);
+    }
     BQ_CHK(hipEventRecord(sev[0], stream));
     static const int slotF[3] = { 4, 144, 147 }, slotS[3] = { 2, 145, 148 }, slotW[3] = { 5, 146, -1 };
     bool used_side[3] = { false, false, false };
@@ -1186,6 +1225,7 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
         const bool reg = c < 2;
         hipStream_t st = c == 0 ? stream : side[c - 1];
         if (c) { BQ_CHK(hipStreamWaitEvent(st, sev[0], 0)); used_side[c] = true; }
+
         P.ncell = reg ? 2 * (2 * (c ? BAQ_BWM2 : BAQ_BWM) + 3) : 3 * (2 * counts[2] + 1) + 6;       // doubles per matrix row
         const size_t per_mat = (size_t)(reg ? BAQ_ROWS_KEPT(P.max_lq) : P.max_lq + 2) * P.ncell * sizeof(double);  // one matrix of one read (register-row classes: the odd rows)
         const size_t per_job = reg ? per_mat : 2 * per_mat;
@@ -1205,7 +1245,7 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
         P.F = (double*)d_F; P.B = (double*)d_B; P.S = (double*)d_S;
         for (size_t j0 = 0; j0 < nj; j0 += chunk) {
             P.n_jobs = (int)(nj - j0 < chunk ? nj - j0 : chunk);
-            P.jobs = (c == 0 ? Q.jobs0 : c == 1 ? Q.jobs1 : Q.jobs2) + j0;
+            P.jobs = (c == 0 ? Q.jobs0 : c == 1 ? Q.jobs1 : jobs2) + j0;
             if (c == 0)      hipLaunchKernelGGL(baq_kernel<BAQ_BWM>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, st, P);
             else if (c == 1) hipLaunchKernelGGL(baq_kernel<BAQ_BWM2>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, st, P);
             else             launch_baq_wide(P, st);
