@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <vector>
+#include <algorithm>
 #include <type_traits>
 #include <cstring>
 #include <cstdlib>
@@ -808,14 +809,17 @@ __device__ void baq_cap(const BaqParams &P, const BaqJob &j, const uint8_t *iqua
 // + 8: a deletion of even length gives 8) keep their rows in registers; wider ones (indels of 8 and more) go through scratch
 #define BAQ_BWM 7
 #define BAQ_BWM2 8
+#define BAQ_BWM3 16         // bands of 9 .. 16 (reads with an indel of 6 .. 13 bases: most of the reads past band 8) are a class of their own:
+#define BAQ_MID_LANES 32    // the LDS rows of such a band are short enough for 32 reads a wavefront (the wider ones: BAQ_WIDE_LANES).  (A
+                            // register row of 33 cells does not fit: 198 registers for the forward row alone, 1 600 spilled.)
 #define BAQ_WIDE_LANES 8
 
 // Wavefronts per SIMD the compiler is to leave room for: one for the register-row classes -- the two rows of the backward pass, the
 // stored forward row and a cell's operands are 330 - 390 registers (with two wavefronts and 256 the row loops spill: 1.2x - 2x slower).
 #ifndef BAQ_WAVES
-#define BAQ_WAVES(bwm) ((bwm) > 0 ? 1 : 2)
+#define BAQ_WAVES(bwm) ((bwm) > 0 ? 1 : 2)     // (bwm <= 0: the LDS-row classes)
 #endif
-template <int BWM>          // 0: both matrices in scratch, any band
+template <int BWM>          // 0: any band, the rows in LDS (or both matrices in scratch), BAQ_WIDE_LANES reads a wavefront; < 0: the same with -BWM reads
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAQ_WAVES(BWM), 8))) void baq_kernel(const BaqParams P)
 {
     __shared__ float s_q2p[256];
@@ -825,7 +829,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAQ_WAVES(BW
     // long way to go each -- every cell a round trip to the scratch rows -- so a wavefront takes BAQ_WIDE_LANES reads, not 64:
     // eight times the wavefronts in flight for the same reads (64 reads a wavefront: 65 ms for 17 000 reads beside 46 ms for the
     // other 4.9 million).
-    constexpr int LANES = BWM > 0 ? 64 : BAQ_WIDE_LANES;
+    constexpr int LANES = BWM > 0 ? 64 : BWM == 0 ? BAQ_WIDE_LANES : -BWM;
     if (threadIdx.x >= LANES) return;
     const int job = blockIdx.x * LANES + threadIdx.x;
     if (job >= P.n_jobs) return;
@@ -865,8 +869,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BAQ_WAVES(BW
 struct BaqPrepParams {
     DevPool D;
     int ref_len;                     // bases of the contig (up to its terminating NUL)
-    BaqJob *jobs0, *jobs1, *jobs2;
-    int *counts;                     // [0],[1],[6] jobs per class (band <= 7, 8, wider)  [2] widest band  [3] longest query  [4] lowest xb  [5] highest xe
+    BaqJob *jobs0, *jobs1, *jobs2, *jobs3;
+    int *counts;                     // [0],[1],[7],[6] jobs per class (band <= 7, 8, <= 16, wider)  [2] widest band  [3] longest query  [4] lowest xb  [5] highest xe
     int32_t *ret; uint8_t *has_zq;
 };
 __global__ __launch_bounds__(256) void baq_prep_kernel(const BaqPrepParams P)
@@ -907,26 +911,26 @@ __global__ __launch_bounds__(256) void baq_prep_kernel(const BaqPrepParams P)
             b = j.l_ref > j.l_query ? j.l_ref : j.l_query;
             if (b > j.bw) b = j.bw;
             if (b < abs(j.l_ref - j.l_query)) b = abs(j.l_ref - j.l_query);
-            cls = b <= BAQ_BWM ? 0 : b <= BAQ_BWM2 ? 1 : 2;
+            cls = b <= BAQ_BWM ? 0 : b <= BAQ_BWM2 ? 1 : b <= BAQ_BWM3 ? 3 : 2;
             lq = l_qseq;
             if (j.l_ref > 0) { wlo = xb; whi = xe; }
         }
     }
     // One atomic per WORKGROUP and class, and the maxima only when they would change a counter: every lane, or every wavefront, on
     // the same few counters queue up behind one another in L2 (3.7 ms for 4.9 M reads with one set of atomics a wavefront).
-    __shared__ int s_cnt[4][3], s_base[3], s_red[4][4];
+    __shared__ int s_cnt[4][4], s_base[4], s_red[4][4];
     const int wave = threadIdx.x >> 6;
-    unsigned long long m[3];
+    unsigned long long m[4];
     #pragma unroll
-    for (int c = 0; c < 3; ++c) { m[c] = __builtin_amdgcn_ballot_w64(cls == c); if (lane == 0) s_cnt[wave][c] = (int)__popcll(m[c]); }
+    for (int c = 0; c < 4; ++c) { m[c] = __builtin_amdgcn_ballot_w64(cls == c); if (lane == 0) s_cnt[wave][c] = (int)__popcll(m[c]); }
     int wb = cls == 2 ? b : 1;
     #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { wb = max(wb, __shfl_xor(wb, o)); lq = max(lq, __shfl_xor(lq, o)); wlo = min(wlo, __shfl_xor(wlo, o)); whi = max(whi, __shfl_xor(whi, o)); }
     if (lane == 0) { s_red[wave][0] = wb; s_red[wave][1] = lq; s_red[wave][2] = wlo; s_red[wave][3] = whi; }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    if (threadIdx.x < 4) {
         const int c = threadIdx.x, tot = s_cnt[0][c] + s_cnt[1][c] + s_cnt[2][c] + s_cnt[3][c];
-        s_base[c] = tot ? atomicAdd(&P.counts[c == 2 ? 6 : c], tot) : 0;
+        s_base[c] = tot ? atomicAdd(&P.counts[c == 2 ? 6 : c == 3 ? 7 : c], tot) : 0;
     } else if (threadIdx.x == 64) {
         int xb_ = 1, xl = 1, xlo = INT32_MAX, xhi = 0;
         for (int w = 0; w < 4; ++w) { xb_ = max(xb_, s_red[w][0]); xl = max(xl, s_red[w][1]); xlo = min(xlo, s_red[w][2]); xhi = max(xhi, s_red[w][3]); }
@@ -937,11 +941,11 @@ __global__ __launch_bounds__(256) void baq_prep_kernel(const BaqPrepParams P)
     }
     __syncthreads();
     #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 4; ++c) {
         if (cls != c) continue;
         int base = s_base[c];
         for (int w = 0; w < wave; ++w) base += s_cnt[w][c];
-        (c == 0 ? P.jobs0 : c == 1 ? P.jobs1 : P.jobs2)[base + (int)__popcll(m[c] & ((1ull << lane) - 1))] = j;
+        (c == 0 ? P.jobs0 : c == 1 ? P.jobs1 : c == 2 ? P.jobs2 : P.jobs3)[base + (int)__popcll(m[c] & ((1ull << lane) - 1))] = j;
     }
 }
 
@@ -994,15 +998,17 @@ using namespace bcfgpu;
 
 // the scratch class: BAQ_WIDE_LANES reads a wavefront; the working rows in LDS when two rows of the class's widest band fit (bands
 // to about 200), else every cell through the scratch matrices
+template <int BWM>          // 0: the wide class, -BAQ_MID_LANES: bands up to BAQ_BWM3
 static void launch_baq_wide(BaqParams P, hipStream_t st)
 {
+    constexpr int LANES = BWM == 0 ? BAQ_WIDE_LANES : -BWM;
     // three rows of the class's widest band (two working rows, the forward row of the posterior) and the window's bases: a window is
     // at most the read and its band long (realn.c trims it to that)
-    const size_t lds = 3 * (size_t)P.ncell * BAQ_WIDE_LANES * sizeof(double) + ((size_t)P.max_lq + (size_t)P.ncell / 6 + 16) * BAQ_WIDE_LANES;
+    const size_t lds = 3 * (size_t)P.ncell * LANES * sizeof(double) + ((size_t)P.max_lq + (size_t)P.ncell / 6 + 16) * LANES;
     P.lds_rows = lds <= 150 * 1024 ? 1 : 0;
     if (P.lds_rows && lds > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(baq_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(baq_kernel<0>, dim3((P.n_jobs + BAQ_WIDE_LANES - 1) / BAQ_WIDE_LANES), dim3(64), P.lds_rows ? lds : 0, st, P);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(baq_kernel<BWM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(baq_kernel<BWM>, dim3((P.n_jobs + LANES - 1) / LANES), dim3(64), P.lds_rows ? lds : 0, st, P);
 }
 
 extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *ref, int32_t ref_len, int flag,
@@ -1075,10 +1081,10 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
 #else
     const bool force_scratch = false;
 #endif
-    std::vector<BaqJob> cls[3];
-    int cls_bw[3] = {1, 1, 1};
+    std::vector<BaqJob> cls[4];
+    int cls_bw[4] = {1, 1, 1, 1};
     for (const BaqJob &j : jobs) {
-        const int b = j.ret < 0 ? 1 : eff_bw(j), c = force_scratch ? 2 : b <= BAQ_BWM ? 0 : b <= BAQ_BWM2 ? 1 : 2;
+        const int b = j.ret < 0 ? 1 : eff_bw(j), c = force_scratch ? 2 : b <= BAQ_BWM ? 0 : b <= BAQ_BWM2 ? 1 : b <= BAQ_BWM3 ? 3 : 2;
         cls[c].push_back(j);
         if (b > cls_bw[c]) cls_bw[c] = b;
     }
@@ -1105,7 +1111,9 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
     P.tref = (const uint8_t*)d_tref; P.seq16 = (const uint8_t*)d_seq; P.qual = (const uint8_t*)d_qual; P.cig = (const uint32_t*)d_cig;
     P.q2p = d_q2p; P.state = (int32_t*)d_state; P.q = (uint8_t*)d_q; P.tmp = (uint8_t*)d_tmp;
     P.qual_out = (uint8_t*)d_qo; P.zq_out = (uint8_t*)d_zo;
-    for (int c = 0; c < 3; ++c) {
+    // (the wide class in descending order of the band, as baq_sort_wide_kernel leaves it in the pool form)
+    std::stable_sort(cls[2].begin(), cls[2].end(), [&](const BaqJob &x, const BaqJob &y) { return eff_bw(x) > eff_bw(y); });
+    for (int c = 0; c < 4; ++c) {
         const size_t nj = cls[c].size();
         if (!nj) continue;
         const bool reg = c < 2;
@@ -1135,7 +1143,8 @@ extern "C" int bcfgpu_baq(bcfgpu_ctx *ctx, const bcfgpu_reads *rd, const char *r
             P.jobs = (const BaqJob*)d_jobs + j0;
             if (c == 0)      hipLaunchKernelGGL(baq_kernel<BAQ_BWM>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
             else if (c == 1) hipLaunchKernelGGL(baq_kernel<BAQ_BWM2>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, stream, P);
-            else             launch_baq_wide(P, stream);
+            else if (c == 3) launch_baq_wide<-BAQ_MID_LANES>(P, stream);
+            else             launch_baq_wide<0>(P, stream);
         }
         BQ_CHK(hipGetLastError());
     }
@@ -1167,6 +1176,7 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
     Q.jobs0 = (BaqJob*)bcfgpu_internal_ws(ctx, 0, (size_t)n * sizeof(BaqJob) + 64);
     Q.jobs1 = (BaqJob*)bcfgpu_internal_ws(ctx, 3, (size_t)n * sizeof(BaqJob) + 64);
     Q.jobs2 = (BaqJob*)bcfgpu_internal_ws(ctx, 127, (size_t)n * sizeof(BaqJob) + 64);
+    Q.jobs3 = (BaqJob*)bcfgpu_internal_ws(ctx, 135, (size_t)n * sizeof(BaqJob) + 64);
     Q.counts = (int*)bcfgpu_internal_ws(ctx, 115, 64);
     Q.ret = (int32_t*)bcfgpu_internal_ws(ctx, 116, (size_t)n * 4 + 64);
     Q.has_zq = (uint8_t*)bcfgpu_internal_ws(ctx, 117, (size_t)n + 64);
@@ -1174,7 +1184,7 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
     uint8_t *d_qo = (uint8_t*)bcfgpu_internal_ws(ctx, qo_slot, nbase + 64);
     uint8_t *d_zo = (uint8_t*)bcfgpu_internal_ws(ctx, 120, nbase + 64);
     void *d_state = bcfgpu_internal_ws(ctx, 11, (nbase + 4) * 4), *d_q = bcfgpu_internal_ws(ctx, 12, nbase + 16), *d_tmp = bcfgpu_internal_ws(ctx, 13, 2 * nbase + 16);
-    if (!Q.jobs0 || !Q.jobs1 || !Q.jobs2 || !Q.counts || !Q.ret || !Q.has_zq || !d_qo || !d_zo || !d_state || !d_q || !d_tmp)
+    if (!Q.jobs0 || !Q.jobs1 || !Q.jobs2 || !Q.jobs3 || !Q.counts || !Q.ret || !Q.has_zq || !d_qo || !d_zo || !d_state || !d_q || !d_tmp)
         return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_baq: device workspace");
     const int init[8] = {0, 0, 1, 1, INT32_MAX, 0, 0, 0};
     int counts[8];
@@ -1203,8 +1213,10 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
     P.seq16 = D.seq16; P.qual = D.qual; P.cig = D.cig;
     P.q2p = d_q2p; P.state = (int32_t*)d_state; P.q = (uint8_t*)d_q; P.tmp = (uint8_t*)d_tmp;
     P.qual_out = d_qo; P.zq_out = d_zo;
-    // The three band classes are independent (their reads are disjoint): the two small ones (band 8: a few per cent of the reads;
-    // wider bands: a handful) go to side streams with row buffers of their own and are launched FIRST, so that their few hundred
+    // The four band classes are independent (their reads are disjoint): the three small ones (band 8: a few per cent of the reads;
+    // bands to 16 and wider ones: a handful, whose workgroups share the compute units' LDS, so the second of them starts when the
+    // first has drained -- 23 ms together beside the main class's 39; a raised wave priority for the main class changed nothing)
+    // go to side streams with row buffers of their own and are launched FIRST, so that their few hundred
     // wavefronts run beside the main class instead of after it -- a launch of 178 wavefronts takes as long as its slowest
     // wavefront, half a millisecond with the chip otherwise idle.
     hipStream_t *side = nullptr; hipEvent_t *sev = nullptr;
@@ -1216,24 +1228,23 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
         hipLaunchKernelGGL(baq_sort_wide_kernel, dim3(1), dim3(1024), 0, stream, Q.jobs2, counts[6], jobs2);
     }
     BQ_CHK(hipEventRecord(sev[0], stream));
-    static const int slotF[3] = { 4, 144, 147 }, slotS[3] = { 2, 145, 148 }, slotW[3] = { 5, 146, -1 };
-    bool used_side[3] = { false, false, false };
-    for (int ci = 0; ci < 3; ++ci) {
-        const int c = ci == 0 ? 1 : ci == 1 ? 2 : 0;                              // the small classes first
-        const size_t nj = (size_t)counts[c == 2 ? 6 : c];
+    static const int slotF[4] = { 4, 144, 147, 149 }, slotS[4] = { 2, 145, 148, 150 }, slotW[4] = { 5, 146, 1, 151 };    // (W of the LDS-row classes: their second matrix)
+    bool used_side[4] = { false, false, false, false };
+    for (int ci = 0; ci < 4; ++ci) {
+        const int c = ci == 0 ? 2 : ci == 1 ? 3 : ci == 2 ? 1 : 0;                // the small classes first, the slowest of them in front
+        const size_t nj = (size_t)counts[c == 2 ? 6 : c == 3 ? 7 : c];
         if (!nj) continue;
         const bool reg = c < 2;
         hipStream_t st = c == 0 ? stream : side[c - 1];
         if (c) { BQ_CHK(hipStreamWaitEvent(st, sev[0], 0)); used_side[c] = true; }
-
-        P.ncell = reg ? 2 * (2 * (c ? BAQ_BWM2 : BAQ_BWM) + 3) : 3 * (2 * counts[2] + 1) + 6;       // doubles per matrix row
+        P.ncell = reg ? 2 * (2 * (c ? BAQ_BWM2 : BAQ_BWM) + 3) : 3 * (2 * (c == 3 ? BAQ_BWM3 : counts[2]) + 1) + 6;       // doubles per matrix row
         const size_t per_mat = (size_t)(reg ? BAQ_ROWS_KEPT(P.max_lq) : P.max_lq + 2) * P.ncell * sizeof(double);  // one matrix of one read (register-row classes: the odd rows)
         const size_t per_job = reg ? per_mat : 2 * per_mat;
         size_t chunk = ((size_t)24 << 30) / per_job;                               // (up to 24 GiB of scratch of the 288 GB: one launch for ~9e5 reads of 100 bases -- every launch ends with a round of wavefronts that does not fill the chip)
         chunk = chunk < 64 ? 64 : (chunk & ~(size_t)63);
         if (chunk > nj) chunk = (nj + 63) & ~(size_t)63;
         P.stride = chunk;
-        void *d_F = bcfgpu_internal_ws(ctx, slotF[c], per_mat * chunk), *d_B = reg ? nullptr : bcfgpu_internal_ws(ctx, 1, per_mat * chunk);
+        void *d_F = bcfgpu_internal_ws(ctx, slotF[c], per_mat * chunk), *d_B = reg ? nullptr : bcfgpu_internal_ws(ctx, slotW[c], per_mat * chunk);
         void *d_S = bcfgpu_internal_ws(ctx, slotS[c], (size_t)(P.max_lq + 2) * chunk * sizeof(double));
         if (!d_F || (!reg && !d_B) || !d_S) return bcfgpu_set_error(BCFGPU_E_NOMEM, "bcfgpu_pool_baq: device workspace");
         if (reg) {                                                   // state / posterior quality / left maxima, a wavefront's reads side by side
@@ -1245,14 +1256,15 @@ extern "C" int bcfgpu_pool_baq(bcfgpu_ctx *ctx, const char *ref, int32_t ref_len
         P.F = (double*)d_F; P.B = (double*)d_B; P.S = (double*)d_S;
         for (size_t j0 = 0; j0 < nj; j0 += chunk) {
             P.n_jobs = (int)(nj - j0 < chunk ? nj - j0 : chunk);
-            P.jobs = (c == 0 ? Q.jobs0 : c == 1 ? Q.jobs1 : jobs2) + j0;
+            P.jobs = (c == 0 ? Q.jobs0 : c == 1 ? Q.jobs1 : c == 2 ? jobs2 : Q.jobs3) + j0;
             if (c == 0)      hipLaunchKernelGGL(baq_kernel<BAQ_BWM>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, st, P);
             else if (c == 1) hipLaunchKernelGGL(baq_kernel<BAQ_BWM2>, dim3((P.n_jobs + 63) / 64), dim3(64), 0, st, P);
-            else             launch_baq_wide(P, st);
+            else if (c == 3) launch_baq_wide<-BAQ_MID_LANES>(P, st);
+            else             launch_baq_wide<0>(P, st);
         }
         BQ_CHK(hipGetLastError());
     }
-    for (int c = 1; c < 3; ++c)
+    for (int c = 1; c < 4; ++c)
         if (used_side[c]) { BQ_CHK(hipEventRecord(sev[c], side[c - 1])); BQ_CHK(hipStreamWaitEvent(stream, sev[c], 0)); }
     if (ret) {
         BQ_CHK(hipMemcpyAsync(ret, Q.ret, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
