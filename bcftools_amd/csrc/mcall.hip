@@ -191,6 +191,202 @@ __device__ __forceinline__ void write_skipped(bcfgpu_call_site *cs, int ret)
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
+// ---- the subset scan of the sites with at most fifteen subsets: a lane per sample, the vector ALU only ----
+// The scan is (subset coefficients) x (genotypes x samples), but the coefficient matrix is sparse -- a single allele has one
+// non-zero, a pair three, a triple six: 47 of the 256 entries of a 4-allele site's 16 x 16 tile -- and on this chip an fp64
+// matrix instruction does its 1024 multiply-adds in the 64 cycles the vector ALU needs for as many (profiles/r4_mfma_f64_valu.txt),
+// and holds the SIMD meanwhile.  So the sites of up to four alleles with a frequency (all but the 25-subset instantiation)
+// are scanned a lane per sample: the sample's P(D|G) from the table, 42 multiply-adds for its six pairs and four triples with
+// the coefficients in scalar registers, one multiplication into each subset's running product; no padding of rows or of the
+// inner dimension.  The alleles are visited in a permuted order -- those with a frequency first -- by permuting which PL plane
+// a genotype slot is loaded from (wavefront-uniform), so that the subsets are compile-time register indices.
+#include "mcall_rows16.h"
+
+// One group's scan.  NZ = alleles with a frequency (1..4; a group without any runs as NZ = 1: it has no pair).  `permw`: nibble x =
+// the allele visited as x, those with a frequency first, both parts in the reference's order, so that pair i / triple i of the
+// permuted enumeration is the i-th pair / triple mcall_find_best_alleles visits (mcall.c:617-698).  Slots of the result: 0-4 the
+// single alleles in permuted order, 5.. the pairs, then the triples, then the row of the samples' normalisation sums; lane l
+// returns slot l >> 2.  HAP: haploid samples take f_a P(aa) + f_b P(bb) (+ f_c P(cc)) (mcall.c:643, 688), samples of ploidy 0
+// enter the single-allele rows only, and (dip_m, dip_e) is the normalisation product over the samples of ploidy 1 or 2.
+template <int NZ, bool HAP>
+__device__ __forceinline__ void sparse_scan(const McallParams &P, const uint8_t *plb, const int S, const int nals, const int g, const int ngrp,
+                                            const int s_first, const int s_last, const float *qf, const uint32_t permw, const double *s_p2, uint8_t *s_nz,
+                                            const bool note_nz, double &out_m, int &out_e, double &dip_m, int &dip_e, bool &f_single, bool &f_pt)
+{
+    constexpr int NP = NZ * (NZ - 1) / 2, NT = NZ * (NZ - 1) * (NZ - 2) / 6, SUMSLOT = 5 + NP + NT;
+    constexpr int PX[6] = {1, 2, 2, 3, 3, 3}, PY[6] = {0, 0, 1, 0, 1, 2};
+    constexpr int TX[4] = {2, 3, 3, 3}, TY[4] = {1, 1, 2, 2}, TW[4] = {0, 0, 0, 1};
+    const int tid = threadIdx.x;
+    const size_t Ss = (size_t)S;
+    // the coefficients: lane i < 6 forms pair i's, lane 6 + i triple i's (float quotients widened, mcall.c:629-630, 671-673)
+    double cfa = 0., cfb = 0., cfc = 0.;
+    if (NP > 0) {
+        const int i = tid < 6 ? tid : (tid - 6) & 3;
+        const int x = tid < 6 ? (0x333221 >> (4 * i)) & 15 : (0x3332 >> (4 * i)) & 15;
+        const int y = tid < 6 ? (0x210100 >> (4 * i)) & 15 : (0x2211 >> (4 * i)) & 15;
+        const int w = tid < 6 ? -1 : (0x1000 >> (4 * i)) & 15;
+        const float qa = qf[(permw >> (4 * x)) & 7], qb = qf[(permw >> (4 * y)) & 7], qc = w >= 0 ? qf[(permw >> (4 * w)) & 7] : 0.f;
+        const float den = w >= 0 ? qa + qb + qc : qa + qb;
+        cfa = (double)(qa / den); cfb = (double)(qb / den); cfc = (double)(qc / den);
+    }
+    // diploid samples: pairs as f_a^2 P(aa) + f_b^2 P(bb) + 2 f_a f_b P(ab) with the three products in scalar registers; triples (and,
+    // with a ploidy array, the pairs too) from the frequencies alone -- f_a (f_a P(aa) + f_b 2P(ab) + f_c 2P(ac)) + f_b (f_b P(bb) +
+    // f_c 2P(bc)) + f_c f_c P(cc): twelve scalar values instead of twenty-four, and the haploid sum falls out of its first terms
+    constexpr bool PDIRECT = !HAP;
+    double k_a2[NP > 0 ? NP : 1], k_b2[NP > 0 ? NP : 1], k_ab[NP > 0 ? NP : 1], k_pa[NP > 0 ? NP : 1], k_pb[NP > 0 ? NP : 1];
+    double k_ta[NT > 0 ? NT : 1], k_tb[NT > 0 ? NT : 1], k_tc[NT > 0 ? NT : 1];
+    {
+        const double a2 = cfa * cfa, b2 = cfb * cfb, ab = 2 * cfa * cfb;
+        #pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (PDIRECT) { k_a2[i] = readlane_f64(a2, i); k_b2[i] = readlane_f64(b2, i); k_ab[i] = readlane_f64(ab, i); }
+            else { k_pa[i] = readlane_f64(cfa, i); k_pb[i] = readlane_f64(cfb, i); }
+        }
+        #pragma unroll
+        for (int i = 0; i < NT; ++i) { k_ta[i] = readlane_f64(cfa, 6 + i); k_tb[i] = readlane_f64(cfb, 6 + i); k_tc[i] = readlane_f64(cfc, 6 + i); }
+    }
+    double man[16]; int ex[16];
+    #pragma unroll
+    for (int r = 0; r < 16; ++r) { man[r] = 1.0; ex[r] = 0; }
+    double sdm = 1.0; int sde = 0;
+    bool fs = false, fp = false;
+    // the PL plane of permuted genotype (x >= y)
+    uint32_t offv = 0;                                                       // lane c: byte offset of the plane of permuted genotype c = (x >= y)
+    if (tid < 15) {
+        const int x = (int)((0x444443333222110ull >> (4 * tid)) & 15), y = (int)((0x432103210210100ull >> (4 * tid)) & 15);
+        offv = (uint32_t)a2gt((int)((permw >> (4 * x)) & 7), (int)((permw >> (4 * y)) & 7)) * (uint32_t)S;
+    }
+    // A lane takes four consecutive samples, one 4-byte word per plane: 256 samples a trip.
+    for (int s0 = s_first; s0 < (BCFGPU_ABL(P, 16) ? 0 : s_last); s0 += 4 * WGS) {
+        const int sb = s0 + 4 * tid, rem = S - sb;
+        const bool live = rem > 0 && sb < s_last;
+        // permuted genotype slot c is loaded from the plane lane c of `offv` names (one v_readlane per plane and trip)
+        uint32_t w[15];
+        if (__all(!live || rem >= 4)) {
+            const uint32_t at = live ? (uint32_t)sb : 0u;            // (a lane past the range reads a word it does not use)
+            #pragma unroll
+            for (int x = 0; x < 5; ++x) {
+                #pragma unroll
+                for (int y = 0; y <= x; ++y) {
+                    const int c = x * (x + 1) / 2 + y;
+                    uint32_t v = 0;
+                    if (x < NZ || x < nals) __builtin_memcpy(&v, plb + ((uint32_t)__builtin_amdgcn_readlane((int)offv, c) + at), 4);
+                    w[c] = v;
+                }
+            }
+        } else {                                                     // the trip that holds the last samples of a count not divisible by four
+            #pragma unroll
+            for (int c = 0; c < 15; ++c) {
+                uint32_t v = 0;
+                if (live && c < nals * (nals + 1) / 2) {
+                    const uint8_t *src = plb + ((uint32_t)__builtin_amdgcn_readlane((int)offv, c) + (uint32_t)sb);
+                    if (rem >= 4) __builtin_memcpy(&v, src, 4);
+                    else { v = src[0]; if (rem > 1) v |= (uint32_t)src[1] << 8; if (rem > 2) v |= (uint32_t)src[2] << 16; }
+                }
+                w[c] = v;
+            }
+        }
+        uint32_t pw = 0x02020202u, gm = live ? 0xfu : 0u;
+        if (live && (HAP || ngrp > 1)) {
+            if (rem >= 4) {
+                if (HAP) __builtin_memcpy(&pw, P.ploidy + sb, 4);
+                if (ngrp > 1) {
+                    int gv[4];
+                    __builtin_memcpy(gv, P.grp + sb, 16);
+                    gm = (gv[0] == g ? 1u : 0u) | (gv[1] == g ? 2u : 0u) | (gv[2] == g ? 4u : 0u) | (gv[3] == g ? 8u : 0u);
+                }
+            } else {
+                #pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < rem) {
+                        if (HAP) pw = (pw & ~(0xffu << (8 * j))) | (uint32_t)P.ploidy[sb + j] << (8 * j);
+                        if (ngrp > 1 && GRP_OF(sb + j) != g) gm &= ~(1u << j);
+                    }
+            }
+        }
+        uint32_t any = 0;
+        #pragma unroll
+        for (int c = 0; c < 15; ++c) any |= w[c];
+        // which samples carry data, for the genotypes of a site that stays REF-only (set_pdg: all PLs 0 = no data, mcall.c:529-535)
+        if (note_nz && live)
+            s_nz[sb >> 2] = (uint8_t)(((any & 0xffu) ? 1u : 0u) | ((any & 0xff00u) ? 2u : 0u) | ((any & 0xff0000u) ? 4u : 0u) | ((any & 0xff000000u) ? 8u : 0u));
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool has = ((any >> (8 * j)) & 0xff) != 0 && ((gm >> j) & 1);
+            const int pd = HAP ? (int)((pw >> (8 * j)) & 0xff) : 2;
+            if (has) {
+                fs = true;
+                double p[15];
+                double sum = 0.;
+                #pragma unroll
+                for (int x = 0; x < 5; ++x) {
+                    if (x < NZ || x < nals) {
+                        #pragma unroll
+                        for (int y = 0; y <= x; ++y) {
+                            const int c = x * (x + 1) / 2 + y;
+                            p[c] = s_p2[(w[c] >> (8 * j)) & 0xff];
+                            sum += p[c];
+                        }
+                        man[x] *= p[x * (x + 3) / 2];
+                    }
+                }
+                man[SUMSLOT] *= sum;
+                if (!HAP || pd == 1 || pd == 2) {
+                    fp = true;
+                    if (HAP) sdm *= sum;
+                    const bool dipl = !HAP || pd == 2;
+                    // twice the heterozygous values (exact), for the forms built from the frequencies alone
+                    double h2[10];
+                    #pragma unroll
+                    for (int x = 1; x < NZ; ++x)
+                        #pragma unroll
+                        for (int y = 0; y < x; ++y) h2[x * (x - 1) / 2 + y] = p[x * (x + 1) / 2 + y] + p[x * (x + 1) / 2 + y];
+                    #pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        const int x = PX[i], y = PY[i];
+                        const double paa = p[x * (x + 3) / 2], pbb = p[y * (y + 3) / 2];
+                        double v;
+                        if (PDIRECT) v = __builtin_fma(k_ab[i], p[x * (x + 1) / 2 + y], __builtin_fma(k_b2[i], pbb, k_a2[i] * paa));
+                        else {
+                            const double ta = k_pa[i] * paa, tb = k_pb[i] * pbb;
+                            const double v2 = __builtin_fma(k_pa[i], __builtin_fma(k_pb[i], h2[x * (x - 1) / 2 + y], ta), k_pb[i] * tb);
+                            v = dipl ? v2 : ta + tb;
+                        }
+                        man[5 + i] *= v;
+                    }
+                    #pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        const int x = TX[i], y = TY[i], z = TW[i];
+                        const double ta = k_ta[i] * p[x * (x + 3) / 2], tb = k_tb[i] * p[y * (y + 3) / 2], tc = k_tc[i] * p[z * (z + 3) / 2];
+                        const double ua = __builtin_fma(k_tc[i], h2[x * (x - 1) / 2 + z], __builtin_fma(k_tb[i], h2[x * (x - 1) / 2 + y], ta));
+                        const double ub = __builtin_fma(k_tc[i], h2[y * (y - 1) / 2 + z], tb);
+                        const double v2 = __builtin_fma(k_ta[i], ua, __builtin_fma(k_tb[i], ub, k_tc[i] * tc));
+                        man[5 + NP + i] *= (HAP && !dipl) ? ta + tb + tc : v2;
+                    }
+                }
+            }
+        }
+        // (renormalised once per word of four samples: four factors are at least 1e-150 together; splitting off a power of two is exact)
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) { ex[r] += frexp_exp(man[r]); man[r] = frexp_mant(man[r]); }
+        if (HAP) { sde += frexp_exp(sdm); sdm = frexp_mant(sdm); }
+    }
+    f_single = __any(fs); f_pt = __any(fp);
+    rows16_product(man, ex);
+    out_m = man[0]; out_e = ex[0];
+    if (HAP) {
+        int f_ = 0;
+        row16_product(sdm, sde, f_);
+        #pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const double mm = sdm * __shfl_xor(sdm, o);
+            sde += __shfl_xor(sde, o) + frexp_exp(mm);
+            sdm = frexp_mant(mm);
+        }
+        dip_m = sdm; dip_e = sde;
+    }
+}
+
 // FAST: the u8-PL case of the fused pipeline (HAP: with a ploidy array; sample groups in both).  The subset scan of find_best_alleles is the
 // matrix product (subset coefficients [rows] x genotypes [k]) * (genotypes [k] x samples [cols]) and runs on the
 // f64 matrix cores (v_mfma_f64_16x16x4_f64), 16 samples per issue; an extra all-ones row yields each sample's
@@ -437,7 +633,62 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
         }
         const int nsub = BATCH ? s_nsub[g % GB] : sh.nsub;
         int setbits = 0;
-        if constexpr (FAST) {
+        if constexpr (FAST && NSUB <= 15) {
+            // ---- subset scan, a lane per sample (sparse_scan above): every site but those of the 25-subset instantiation ----
+            const float *qf = s_gq + g * 5;
+            uint32_t nzm = 0;
+            #pragma unroll
+            for (int a = 0; a < 5; ++a) if (a < nals && qf[a] != 0.f) nzm |= 1u << a;
+            nzm = __builtin_amdgcn_readfirstlane(nzm);
+            const int nz = __popc(nzm);
+            uint32_t permw = 0;
+            {
+                int n = 0;
+                #pragma unroll
+                for (int a = 0; a < 5; ++a) if (a < nals && ((nzm >> a) & 1)) { permw |= (uint32_t)a << (4 * n); ++n; }
+                #pragma unroll
+                for (int a = 0; a < 5; ++a) if (a < nals && !((nzm >> a) & 1)) { permw |= (uint32_t)a << (4 * n); ++n; }
+            }
+            const uint8_t *plb = reinterpret_cast<const uint8_t*>(P.pl) + (size_t)is * BCFGPU_MAX_PL * Ss;
+            // a group's samples lie in [first, last] (grp_range_kernel): consecutive for populations listed one after the
+            // other, and then the groups' scans together read every sample once
+            const int s_last = (ngrp > 1 && P.grp_rng) ? P.grp_rng[3 * g + 1] : S;
+            const int s_first = (ngrp > 1 && P.grp_rng) ? (min(P.grp_rng[3 * g], s_last) & ~3) : 0;
+            double rm = 1.0, dm = 1.0; int re = 0, de = 0;
+            bool f_single = false, f_pt = false;
+            const bool note = S <= NZ_MAX_S;
+            switch (nz) {
+            case 4:  sparse_scan<4, HAP>(P, plb, S, nals, g, ngrp, s_first, s_last, qf, permw, s_p2, s_nz, note, rm, re, dm, de, f_single, f_pt); break;
+            case 3:  sparse_scan<3, HAP>(P, plb, S, nals, g, ngrp, s_first, s_last, qf, permw, s_p2, s_nz, note, rm, re, dm, de, f_single, f_pt); break;
+            case 2:  sparse_scan<2, HAP>(P, plb, S, nals, g, ngrp, s_first, s_last, qf, permw, s_p2, s_nz, note, rm, re, dm, de, f_single, f_pt); break;
+            default: sparse_scan<1, HAP>(P, plb, S, nals, g, ngrp, s_first, s_last, qf, permw, s_p2, s_nz, note, rm, re, dm, de, f_single, f_pt); break;
+            }
+            // slot -> the row of the subset list: single allele x -> its own index, pairs and triples in visiting order, the sums last
+            const int np = nz * (nz - 1) / 2, nt = nz * (nz - 1) * (nz - 2) / 6;
+            const int slot = tid >> 2;
+            int row = -1;
+            if (slot < 5) { if (slot < nals) row = (int)((permw >> (4 * slot)) & 7); }
+            else if (slot < 5 + np + nt) row = nals + slot - 5;
+            else if (slot == 5 + np + nt) row = nsub;
+            if ((tid & 3) == 0 && row >= 0) {
+                if constexpr (BATCH) { s_red2[(g % GB) * CPG + row] = rm; s_rede2[(g % GB) * CPG + row] = re; }
+                else { sh.red[row] = rm; sh.rede[row] = re; }      // log taken below, one row per lane
+            }
+            if (HAP && tid == 0) {
+                if constexpr (BATCH) { s_dipm[g % GB] = dm; s_dipe[g % GB] = de; }
+                else { sh.red[31] = dm; sh.rede[31] = de; }        // (at most 16 rows are in use)
+            }
+            if constexpr (!BATCH) {
+            __syncthreads();
+            if (tid <= nsub || (HAP && tid == 31)) sh.red[tid] = log(sh.red[tid]) + (double)sh.rede[tid] * 0.693147180559945309417232121458;
+            __syncthreads();
+            if (HAP && tid == 0) sh.red_dip = sh.red[31];
+            }
+            // the rows some sample entered: the single alleles and the sums with any sample that has data, pairs and triples with
+            // one of ploidy 1 or 2 among them
+            const int single_rows = ((1 << nals) - 1) | (1 << nsub);
+            setbits = (f_single ? single_rows : 0) | (f_pt ? ((1 << nsub) - 1) & ~((1 << nals) - 1) : 0);
+        } else if constexpr (FAST) {
             // ---- subset scan on the matrix cores ----
             // Rows = subsets (+ an all-ones row for the samples' normalisation sums), columns = samples, k = genotypes.
             // Haploid samples use a second coefficient matrix (f_a P(aa) + f_b P(bb) [+ f_c P(cc)], mcall.c:643,688);
