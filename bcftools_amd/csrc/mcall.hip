@@ -208,15 +208,19 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // single alleles in permuted order, 5.. the pairs, then the triples, then the row of the samples' normalisation sums; lane l
 // returns slot l >> 2.  HAP: haploid samples take f_a P(aa) + f_b P(bb) (+ f_c P(cc)) (mcall.c:643, 688), samples of ploidy 0
 // enter the single-allele rows only, and (dip_m, dip_e) is the normalisation product over the samples of ploidy 1 or 2.
+#ifndef MCALL_SCAN_INLINE
+#define MCALL_SCAN_INLINE __forceinline__
+#endif
 template <int NZ, bool HAP>
-__device__ __forceinline__ void sparse_scan(const McallParams &P, const uint8_t *plb, const int S, const int nals, const int g, const int ngrp,
+__device__ MCALL_SCAN_INLINE void sparse_scan(const McallParams &P, const uint8_t *plb, const int S, const int nals, const int g, const int ngrp,
                                             const int s_first, const int s_last, const float *qf, const uint32_t permw, const double *s_p2, uint8_t *s_nz,
                                             const bool note_nz, double &out_m, int &out_e, double &dip_m, int &dip_e, bool &f_single, bool &f_pt)
 {
     constexpr int NP = NZ * (NZ - 1) / 2, NT = NZ * (NZ - 1) * (NZ - 2) / 6, SUMSLOT = 5 + NP + NT;
     constexpr int PX[6] = {1, 2, 2, 3, 3, 3}, PY[6] = {0, 0, 1, 0, 1, 2};
     constexpr int TX[4] = {2, 3, 3, 3}, TY[4] = {1, 1, 2, 2}, TW[4] = {0, 0, 0, 1};
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));        // (what is derived from the lane number is formed here, per group: hoisted out of the loop over the groups it holds registers through all of it)
     const size_t Ss = (size_t)S;
     // the coefficients: lane i < 6 forms pair i's, lane 6 + i triple i's (float quotients widened, mcall.c:629-630, 671-673)
     double cfa = 0., cfb = 0., cfc = 0.;
@@ -233,8 +237,13 @@ __device__ __forceinline__ void sparse_scan(const McallParams &P, const uint8_t 
     // with a ploidy array, the pairs too) from the frequencies alone -- f_a (f_a P(aa) + f_b 2P(ab) + f_c 2P(ac)) + f_b (f_b P(bb) +
     // f_c 2P(bc)) + f_c f_c P(cc): twelve scalar values instead of twenty-four, and the haploid sum falls out of its first terms
     constexpr bool PDIRECT = !HAP;
+    #ifndef MCALL_TRIPLE_DIRECT
+    #define MCALL_TRIPLE_DIRECT 0
+    #endif
+    constexpr bool TDIRECT = !HAP && MCALL_TRIPLE_DIRECT;      // (24 more scalar registers: measured, profiles/r5_mcall_sparse.txt)
     double k_a2[NP > 0 ? NP : 1], k_b2[NP > 0 ? NP : 1], k_ab[NP > 0 ? NP : 1], k_pa[NP > 0 ? NP : 1], k_pb[NP > 0 ? NP : 1];
     double k_ta[NT > 0 ? NT : 1], k_tb[NT > 0 ? NT : 1], k_tc[NT > 0 ? NT : 1];
+    double k_t2[NT > 0 ? NT : 1][6];                             // TDIRECT: f_a^2, f_b^2, f_c^2, 2 f_a f_b, 2 f_a f_c, 2 f_b f_c
     {
         const double a2 = cfa * cfa, b2 = cfb * cfb, ab = 2 * cfa * cfb;
         #pragma unroll
@@ -243,7 +252,12 @@ __device__ __forceinline__ void sparse_scan(const McallParams &P, const uint8_t 
             else { k_pa[i] = readlane_f64(cfa, i); k_pb[i] = readlane_f64(cfb, i); }
         }
         #pragma unroll
-        for (int i = 0; i < NT; ++i) { k_ta[i] = readlane_f64(cfa, 6 + i); k_tb[i] = readlane_f64(cfb, 6 + i); k_tc[i] = readlane_f64(cfc, 6 + i); }
+        for (int i = 0; i < NT; ++i) {
+            if (TDIRECT) {
+                k_t2[i][0] = readlane_f64(a2, 6 + i); k_t2[i][1] = readlane_f64(b2, 6 + i); k_t2[i][2] = readlane_f64(cfc * cfc, 6 + i);
+                k_t2[i][3] = readlane_f64(ab, 6 + i); k_t2[i][4] = readlane_f64(2 * cfa * cfc, 6 + i); k_t2[i][5] = readlane_f64(2 * cfb * cfc, 6 + i);
+            } else { k_ta[i] = readlane_f64(cfa, 6 + i); k_tb[i] = readlane_f64(cfb, 6 + i); k_tc[i] = readlane_f64(cfc, 6 + i); }
+        }
     }
     double man[16]; int ex[16];
     #pragma unroll
@@ -337,6 +351,7 @@ __device__ __forceinline__ void sparse_scan(const McallParams &P, const uint8_t 
                     const bool dipl = !HAP || pd == 2;
                     // twice the heterozygous values (exact), for the forms built from the frequencies alone
                     double h2[10];
+                    if (!(PDIRECT && TDIRECT))
                     #pragma unroll
                     for (int x = 1; x < NZ; ++x)
                         #pragma unroll
@@ -357,6 +372,12 @@ __device__ __forceinline__ void sparse_scan(const McallParams &P, const uint8_t 
                     #pragma unroll
                     for (int i = 0; i < NT; ++i) {
                         const int x = TX[i], y = TY[i], z = TW[i];
+                        if (TDIRECT) {
+                            man[5 + NP + i] *= __builtin_fma(k_t2[i][5], p[y * (y + 1) / 2 + z], __builtin_fma(k_t2[i][4], p[x * (x + 1) / 2 + z],
+                                               __builtin_fma(k_t2[i][3], p[x * (x + 1) / 2 + y], __builtin_fma(k_t2[i][2], p[z * (z + 3) / 2],
+                                               __builtin_fma(k_t2[i][1], p[y * (y + 3) / 2], k_t2[i][0] * p[x * (x + 3) / 2])))));
+                            continue;
+                        }
                         const double ta = k_ta[i] * p[x * (x + 3) / 2], tb = k_tb[i] * p[y * (y + 3) / 2], tc = k_tc[i] * p[z * (z + 3) / 2];
                         const double ua = __builtin_fma(k_tc[i], h2[x * (x - 1) / 2 + z], __builtin_fma(k_tb[i], h2[x * (x - 1) / 2 + y], ta));
                         const double ub = __builtin_fma(k_tc[i], h2[y * (y - 1) / 2 + z], tb);
@@ -401,21 +422,21 @@ template <int MAXA, int NSUB, bool FAST, bool HAP, bool GRP>
 #ifndef MCALL_WAVES_HAP
 #define MCALL_WAVES_HAP 3    // ... with a ploidy array (two coefficient matrices)
 #endif
-__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 : HAP ? MCALL_WAVES_HAP : GRP ? MCALL_WAVES_GRP : MCALL_WAVES, !FAST ? 8 : HAP ? MCALL_WAVES_HAP : GRP ? MCALL_WAVES_GRP : MCALL_WAVES))) void mcall_kernel(const McallParams P)
+__global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 : (HAP || GRP) && NSUB > 15 ? 3 : HAP ? MCALL_WAVES_HAP : GRP ? MCALL_WAVES_GRP : MCALL_WAVES, !FAST ? 8 : (HAP || GRP) && NSUB > 15 ? 3 : HAP ? MCALL_WAVES_HAP : GRP ? MCALL_WAVES_GRP : MCALL_WAVES))) void mcall_kernel(const McallParams P)
 {
     constexpr int NG = MAXA * (MAXA + 1) / 2;
     constexpr int TILES = NSUB >= 16 ? 2 : 1;     // 16-row tiles of the coefficient matrix (subsets + the sum row)
     extern __shared__ __align__(16) unsigned char dsm[];
     float *s_gq = reinterpret_cast<float*>(dsm);              // [n_grp][5] group qsum, then [n_grp][2] best allele sets
-    __shared__ CallShared<NSUB> sh;
+    __shared__ CallShared<(FAST && GRP) ? 1 : NSUB> sh;        // (the batched groups of FAST && GRP keep their subsets in s_sid)
     __shared__ double s_pdg[FAST ? 1 : NG * WGS];   // the lane's current sample: raw P(D|G) (not yet divided by its sum)
     int *s_fill = reinterpret_cast<int*>(s_pdg);   // scratch of set_pdg's rare missing-value path (used before s_pdg is written)
     // pass 1: per-lane running products of the subset likelihoods, kept as mantissa (f64) and exponent (i32):
     //         sum_s log(val_s) = log(prod_s val_s), so each sample costs a multiply + frexp instead of a log()
     // pass 2: the lane's current sample: PLs after set_pdg's in-place fills, genotype posteriors
     // FAST: pass 1 = the coefficient matrix; pass 2 = the lane's PL bytes (u8) and genotype posteriors (f32)
-    constexpr int U1 = FAST ? TILES * 16 * 16 * 8 * (HAP ? 2 : 1) : NSUB * WGS * 12, U2 = FAST ? NG * WGS * 5 : NG * WGS * 8, U3 = GRP ? 6 * 4 * WGS * 4 : 0,
-                  UB = (U1 > U2 ? U1 : U2) > U3 ? (U1 > U2 ? U1 : U2) : U3;     // U3: the staging of the group frequencies (6 words x 256 samples)
+    constexpr int U1 = FAST ? TILES * 16 * 16 * 8 * (HAP ? 2 : 1) : NSUB * WGS * 12, U2 = FAST ? NG * WGS * 5 : NG * WGS * 8,
+                  UB = U1 > U2 ? U1 : U2;
     __shared__ __align__(8) unsigned char s_union[UB];
     double *s_man = reinterpret_cast<double*>(s_union);
     int    *s_exp = reinterpret_cast<int*>(s_union + NSUB * WGS * 8);
