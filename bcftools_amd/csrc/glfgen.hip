@@ -218,6 +218,122 @@ __device__ __forceinline__ double walk_runs(uint32_t *s_slot, uint64_t qm, const
     return bs;
 }
 
+// ---- the walk with one read per step and the step number in a scalar register (GLF_WALK == 2) ----
+// count_ends(): count_runs() whose rank dwords end up as  quality << 19 | end_fwd << 8 | end_rev : the lane's reads of the round in
+// walking order are numbered 0 .. nr - 1; those of rank r are [end_fwd of rank r - 1, end_fwd), its reverse-strand reads first, up
+// to end_rev.  walk_ends() then takes step t in every lane at once: the k row of the table is (reads of earlier rounds + t), the
+// same for the whole wavefront but for a per-lane constant, the descriptor is used up when t reaches its end_fwd, the read is a
+// reverse-strand one while t < end_rev, and the forward strand's running count is t minus the reverse strand's.  A step is then
+// two compares and a handful of selects instead of the run bookkeeping of walk_runs() (which lets a lane take up to WR reads
+// of its current run and so needs a step count of its own per lane).
+template <bool FIRST, class Src>
+__device__ __forceinline__ uint32_t count_ends(uint32_t *s_slot, uint64_t qm, int tid, Src src, int nsrc, uint32_t &nr)
+{
+    #pragma unroll
+    for (int k = 0; k < NRANK; ++k) s_slot[k * WG + tid] = 0;
+    const uint64_t qm1 = qm >> 1;
+    for (int j = 0; __any(j < nsrc); j += FU) {
+        int k4[FU];
+        #pragma unroll
+        for (int u = 0; u < FU; ++u) k4[u] = j + u < nsrc ? src(j + u) : -1;
+        #pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int key = k4[u], q = (key >> 1) & 63;
+            if (key >= 0 && (FIRST || ((qm >> q) & 1ull))) {
+                const int r = __popcll(qm1 >> q);
+                if (r < NRANK) atomicAdd(&s_slot[r * WG + tid], (key & 1) ? 1u : 0x100u);
+            }
+        }
+    }
+    uint32_t qs = 0, acc = 0;
+    uint64_t m = qm;
+    for (int r = 0; r < NRANK && __any(m != 0); ++r) {
+        const int q = 63 - __clzll((long long)(m | 1ull));
+        const uint32_t c = s_slot[r * WG + tid];
+        if (m != 0) {
+            const uint32_t er = acc + (c & 0xffu);
+            acc = er + (c >> 8);
+            qs += (uint32_t)q * (acc - (er - (c & 0xffu)));
+            s_slot[r * WG + tid] = (uint32_t)q << 19 | acc << 8 | er;
+        }
+        m &= ~(1ull << q);
+    }
+    nr = acc;
+    return qs;
+}
+#ifndef GLF_PD
+#define GLF_PD 2            // steps of the walk in flight
+#endif
+template <class Src>
+__device__ __forceinline__ double walk_ends(uint32_t *s_slot, uint64_t qm, const double *s_fk, const char *bbase, int tid,
+                                            uint32_t brow, Src src, int nsrc, uint32_t &rev_out, uint32_t &qs_out, int ab = 0)
+{
+    double bs = 0;
+    uint32_t qs = 0;
+    uint32_t wr = 0;          // reverse-strand reads walked so far
+    uint32_t tl = 0;          // reads walked in earlier rounds
+    uint32_t vrow = brow;     // brow + tl << 11: the lane's part of the k row
+    bool first = true;
+    while (__any(qm != 0)) {
+        uint32_t nr;
+        qs += first ? count_ends<true>(s_slot, qm, tid, src, nsrc, nr) : count_ends<false>(s_slot, qm, tid, src, nsrc, nr);
+        first = false;
+        // the deepest lane's reads: the steps of the round
+        uint32_t T = nr;
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) T = max(T, (uint32_t)__shfl_xor((int)T, o));
+        T = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
+        uint32_t d = s_slot[tid], ridx = 1, d_nx = s_slot[WG + tid];
+        const uint32_t tb = tl;
+        auto step = [&](const uint32_t t, uint32_t &voff, uint32_t &wi) {
+            const bool pop = t == ((d >> 8) & 0xffu);                  // the rank's reads are walked: the next one's descriptor
+            d = pop ? d_nx : d;
+            ridx += pop ? 1u : 0u;
+            d_nx = s_slot[min(ridx, (uint32_t)NRANK - 1u) * WG + tid];
+            const bool act = t < nr, rev = t < (d & 0xffu);
+            const uint32_t w = rev ? wr : t + tb - wr;
+            wr += (act && rev) ? 1u : 0u;
+            wi = act ? w : 256u;
+            voff = act ? (d & 0x1f80000u) + vrow : brow;
+        };
+        #define WALK2_LOAD(B, F, t_, voff_, wi_) do { \
+            B = (ab & 1024) ? 1.0 : *reinterpret_cast<const double*>(bbase + ((size_t)(t_) << 11) + (voff_)); \
+            F = (ab & 2048) ? (double)(wi_) : s_fk[(wi_)]; } while (0)
+        double bx[GLF_PD], fx[GLF_PD];
+        #pragma unroll
+        for (int u = 0; u < GLF_PD; ++u) { uint32_t voff, wi; step((uint32_t)u, voff, wi); WALK2_LOAD(bx[u], fx[u], (uint32_t)u, voff, wi); }
+        for (uint32_t t = GLF_PD; t < T + GLF_PD; t += GLF_PD) {        // (steps past every lane's reads add +0 times a finite entry of the q = 0 rows)
+            #pragma unroll
+            for (int u = 0; u < GLF_PD; ++u) {
+                bs += fx[u] * bx[u];
+                uint32_t voff, wi;
+                step(t + (uint32_t)u, voff, wi);
+                WALK2_LOAD(bx[u], fx[u], t + (uint32_t)u, voff, wi);
+            }
+        }
+        #pragma unroll
+        for (int u = 0; u < GLF_PD; ++u) bs += fx[u] * bx[u];
+        #undef WALK2_LOAD
+        tl += nr; vrow += nr << 11;
+        if (__any(__popcll(qm) > NRANK)) {
+            uint64_t m = qm;
+            for (int k = 0; k < NRANK && m; ++k) m &= ~(1ull << (63 - __clzll((long long)m)));
+            qm = m;
+        } else qm = 0;
+    }
+    rev_out = wr; qs_out = qs;
+    return bs;
+}
+#ifndef GLF_FETCH_GLOBAL
+#define GLF_FETCH_GLOBAL 0
+#endif
+#ifndef GLF_WALK
+#define GLF_WALK 1
+#endif
+#if GLF_WALK == 2
+#define walk_runs walk_ends
+#endif
+
 // per-lane partial sums of phase A (one site segment of one staging round)
 struct ReadSums {
     uint32_t t_bq, t_bq2, t_mq, t_mq2, t_md, t_md2;    // all accepted reads: baseQ, mapQ, min_dist and their squares
@@ -478,8 +594,21 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ?
             const uint32_t g0 = rb & ~3u;
             uint4 w4n = make_uint4(0, 0, 0, 0), a4n = make_uint4(0, 0, 0, 0);
             uint32_t e4n = 0;
+            // (the pointers went through scalar registers as opaque values: said to be global memory again, the loads are global_load
+            // with a scalar base, not flat_load -- which also counts on the LDS counter and needs a 64-bit address per lane)
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(1))) u32x4_t *g_u4;
+            typedef const __attribute__((address_space(1))) uint32_t *g_u32;
             auto fetch = [&](uint32_t i4) {
                 if (i4 >= re) return;
+#if GLF_FETCH_GLOBAL
+                if (__all(i4 >= re || i4 + 3 < n_reads_tot)) {   // (wave-uniform: but for the wavefront that holds the tile's last reads)
+                    const u32x4_t wq = *(g_u4)(const void*)(p_rd + i4);
+                    w4n = make_uint4(wq.x, wq.y, wq.z, wq.w);
+                    if (want_epos) e4n = *(g_u32)(const void*)(p_epos + i4);
+                    if (INDEL) { const u32x4_t aq = *(g_u4)(const void*)(p_aux + i4); a4n = make_uint4(aq.x, aq.y, aq.z, aq.w); }
+                } else
+#endif
                 if (i4 + 3 < n_reads_tot) {
                     w4n = *reinterpret_cast<const uint4*>(p_rd + i4);
                     if (want_epos) e4n = *reinterpret_cast<const uint32_t*>(p_epos + i4);
