@@ -596,9 +596,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ?
             uint32_t e4n = 0;
             // (the pointers went through scalar registers as opaque values: said to be global memory again, the loads are global_load
             // with a scalar base, not flat_load -- which also counts on the LDS counter and needs a 64-bit address per lane)
+#if GLF_FETCH_GLOBAL
             typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
             typedef const __attribute__((address_space(1))) u32x4_t *g_u4;
             typedef const __attribute__((address_space(1))) uint32_t *g_u32;
+#endif
             auto fetch = [&](uint32_t i4) {
                 if (i4 >= re) return;
 #if GLF_FETCH_GLOBAL
