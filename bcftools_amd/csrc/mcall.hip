@@ -211,7 +211,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 #ifndef MCALL_SCAN_INLINE
 #define MCALL_SCAN_INLINE __forceinline__
 #endif
-template <int NZ, bool HAP>
+template <int NZ, bool HAP, int SPL>
 __device__ MCALL_SCAN_INLINE void sparse_scan(const McallParams &P, const uint8_t *plb, const int S, const int nals, const int g, const int ngrp,
                                             const int s_first, const int s_last, const float *qf, const uint32_t permw, const double *s_p2, uint8_t *s_nz,
                                             const bool note_nz, double &out_m, int &out_e, double &dip_m, int &dip_e, bool &f_single, bool &f_pt)
@@ -270,13 +270,14 @@ __device__ MCALL_SCAN_INLINE void sparse_scan(const McallParams &P, const uint8_
         const int x = (int)((0x444443333222110ull >> (4 * tid)) & 15), y = (int)((0x432103210210100ull >> (4 * tid)) & 15);
         offv = (uint32_t)a2gt((int)((permw >> (4 * x)) & 7), (int)((permw >> (4 * y)) & 7)) * (uint32_t)S;
     }
-    // A lane takes four consecutive samples, one 4-byte word per plane: 256 samples a trip.
-    for (int s0 = s_first; s0 < (BCFGPU_ABL(P, 16) ? 0 : s_last); s0 += 4 * WGS) {
-        const int sb = s0 + 4 * tid, rem = S - sb;
+    // A lane takes SPL = four consecutive samples, one 4-byte word per plane: 256 samples a trip; SPL = 1 (a byte per plane) for a range of
+    // at most 128 samples -- a small group: 38 samples of 1000 in 26 populations would keep ten lanes busy at four a lane.
+    for (int s0 = s_first; s0 < (BCFGPU_ABL(P, 16) ? 0 : s_last); s0 += SPL * WGS) {
+        const int sb = s0 + SPL * tid, rem = S - sb;
         const bool live = rem > 0 && sb < s_last;
         // permuted genotype slot c is loaded from the plane lane c of `offv` names (one v_readlane per plane and trip)
         uint32_t w[15];
-        if (__all(!live || rem >= 4)) {
+        if (SPL == 1 || __all(!live || rem >= 4)) {
             const uint32_t at = live ? (uint32_t)sb : 0u;            // (a lane past the range reads a word it does not use)
             #pragma unroll
             for (int x = 0; x < 5; ++x) {
@@ -284,7 +285,7 @@ __device__ MCALL_SCAN_INLINE void sparse_scan(const McallParams &P, const uint8_
                 for (int y = 0; y <= x; ++y) {
                     const int c = x * (x + 1) / 2 + y;
                     uint32_t v = 0;
-                    if (x < NZ || x < nals) __builtin_memcpy(&v, plb + ((uint32_t)__builtin_amdgcn_readlane((int)offv, c) + at), 4);
+                    if (x < NZ || x < nals) { if (SPL == 4) __builtin_memcpy(&v, plb + ((uint32_t)__builtin_amdgcn_readlane((int)offv, c) + at), 4); else v = plb[(uint32_t)__builtin_amdgcn_readlane((int)offv, c) + at]; }
                     w[c] = v;
                 }
             }
@@ -302,7 +303,10 @@ __device__ MCALL_SCAN_INLINE void sparse_scan(const McallParams &P, const uint8_
         }
         uint32_t pw = 0x02020202u, gm = live ? 0xfu : 0u;
         if (live && (HAP || ngrp > 1)) {
-            if (rem >= 4) {
+            if (SPL == 1) {
+                if (HAP) pw = P.ploidy[sb];
+                if (ngrp > 1) gm = P.grp[sb] == g ? 1u : 0u;
+            } else if (rem >= 4) {
                 if (HAP) __builtin_memcpy(&pw, P.ploidy + sb, 4);
                 if (ngrp > 1) {
                     int gv[4];
@@ -322,10 +326,10 @@ __device__ MCALL_SCAN_INLINE void sparse_scan(const McallParams &P, const uint8_
         #pragma unroll
         for (int c = 0; c < 15; ++c) any |= w[c];
         // which samples carry data, for the genotypes of a site that stays REF-only (set_pdg: all PLs 0 = no data, mcall.c:529-535)
-        if (note_nz && live)
+        if (SPL == 4 && note_nz && live)
             s_nz[sb >> 2] = (uint8_t)(((any & 0xffu) ? 1u : 0u) | ((any & 0xff00u) ? 2u : 0u) | ((any & 0xff0000u) ? 4u : 0u) | ((any & 0xff000000u) ? 8u : 0u));
         #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SPL; ++j) {
             const bool has = ((any >> (8 * j)) & 0xff) != 0 && ((gm >> j) & 1);
             const int pd = HAP ? (int)((pw >> (8 * j)) & 0xff) : 2;
             if (has) {
@@ -387,7 +391,7 @@ __device__ MCALL_SCAN_INLINE void sparse_scan(const McallParams &P, const uint8_
                 }
             }
         }
-        // (renormalised once per word of four samples: four factors are at least 1e-150 together; splitting off a power of two is exact)
+        // (renormalised once per trip, at most four samples: four factors are at least 1e-150 together; splitting off a power of two is exact)
         #pragma unroll
         for (int r = 0; r < 16; ++r) { ex[r] += frexp_exp(man[r]); man[r] = frexp_mant(man[r]); }
         if (HAP) { sde += frexp_exp(sdm); sdm = frexp_mant(sdm); }
@@ -678,12 +682,17 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
             double rm = 1.0, dm = 1.0; int re = 0, de = 0;
             bool f_single = false, f_pt = false;
             const bool note = S <= NZ_MAX_S;
+            // (a range of at most 128 samples -- a small group, few samples -- is scanned a sample a lane)
+            const bool narrow = s_last - s_first <= 2 * WGS;
+            #define SCAN(NZ_) do { if (narrow) sparse_scan<NZ_, HAP, 1>(P, plb, S, nals, g, ngrp, s_first, s_last, qf, permw, s_p2, s_nz, note, rm, re, dm, de, f_single, f_pt); \
+                                   else sparse_scan<NZ_, HAP, 4>(P, plb, S, nals, g, ngrp, s_first, s_last, qf, permw, s_p2, s_nz, note, rm, re, dm, de, f_single, f_pt); } while (0)
             switch (nz) {
-            case 4:  sparse_scan<4, HAP>(P, plb, S, nals, g, ngrp, s_first, s_last, qf, permw, s_p2, s_nz, note, rm, re, dm, de, f_single, f_pt); break;
-            case 3:  sparse_scan<3, HAP>(P, plb, S, nals, g, ngrp, s_first, s_last, qf, permw, s_p2, s_nz, note, rm, re, dm, de, f_single, f_pt); break;
-            case 2:  sparse_scan<2, HAP>(P, plb, S, nals, g, ngrp, s_first, s_last, qf, permw, s_p2, s_nz, note, rm, re, dm, de, f_single, f_pt); break;
-            default: sparse_scan<1, HAP>(P, plb, S, nals, g, ngrp, s_first, s_last, qf, permw, s_p2, s_nz, note, rm, re, dm, de, f_single, f_pt); break;
+            case 4:  SCAN(4); break;
+            case 3:  SCAN(3); break;
+            case 2:  SCAN(2); break;
+            default: SCAN(1); break;
             }
+            #undef SCAN
             // slot -> the row of the subset list: single allele x -> its own index, pairs and triples in visiting order, the sums last
             const int np = nz * (nz - 1) / 2, nt = nz * (nz - 1) * (nz - 2) / 6;
             const int slot = tid >> 2;

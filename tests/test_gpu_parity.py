@@ -221,6 +221,48 @@ def test_pipeline_with_sample_groups_matches_oracle(gpu_ctx_factory, n_sites, n_
     assert_call_equal(cgot, cwant, n_smpl)
 
 
+@pytest.mark.parametrize("n_sites,n_smpl,n_grp,depth,ploidies,seed", [
+    (400, 40, 8, 14.0, None, 71),        # five samples a group: some groups lack an allele that others (and later alleles) show
+    (48, 90, 3, 12.0, None, 72),         # groups without a ploidy array, variant sites
+    (48, 203, 5, 10.0, [0, 1, 2, 2], 73),    # ploidy 0 among variant sites, a sample count not divisible by four, shuffled groups
+    (16, 1003, 1, 8.0, None, 74),        # one group, the last word of three samples
+    (12, 5000, 1, 6.0, [1, 2, 2], 75),   # past the 4096 samples the scan keeps data-presence notes for
+    (12, 4104, 4, 6.0, [0, 1, 2], 76)])
+def test_subset_scan_corners(gpu_ctx_factory, n_sites, n_smpl, n_grp, depth, ploidies, seed):
+    """The lane-per-sample subset scan of mcall_find_best_alleles (csrc/mcall.hip, sparse_scan): the alleles with a frequency are
+    visited first by permuting the PL planes, so a group whose frequency is zero for an allele BETWEEN two it has must pick the
+    reference's subsets (mcall.c:617-698 skips qsum == 0) in the reference's order; samples of ploidy 0 enter the single-allele
+    rows only; ragged sample counts; more samples than the scan notes data presence for."""
+    tile = synth.numpy_tile(seed, n_sites, n_smpl, depth=depth, var_rate=0.6)
+    fmt = abi.INFO_VDB | abi.INFO_RPB | (abi.FMT_AD if n_grp > 1 else 0)
+    kw = dict(n_grp=n_grp) if n_grp > 1 else {}
+    cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), fmt_flag=fmt, **kw)
+    rng = np.random.default_rng(seed)
+    ploidy = rng.choice(ploidies, size=n_smpl).astype(np.uint8) if ploidies else None
+    grp = None
+    if n_grp > 1:
+        grp = (np.arange(n_smpl) * n_grp // n_smpl).astype(np.int32)
+        if seed % 2: rng.shuffle(grp)
+    mwant = orc.mpileup(cfg, tile)
+    na = mwant.site["n_alleles"]
+    ad = None
+    if n_grp > 1:
+        src = mwant.adf.astype(np.int32) + mwant.adr.astype(np.int32)
+        ad = np.where(np.arange(5)[None, :, None] < na[:, None, None], src, abi.INT32_VECTOR_END).astype(np.int32)
+        if seed == 71:
+            # the case the test is for: some (site, group) has no read of allele j but reads of an allele after it
+            gsum = np.stack([np.where(ad >= 0, ad, 0)[:, :, grp == g].sum(axis=2) for g in range(n_grp)], axis=1)   # [site][group][allele]
+            hole = (gsum[:, :, 1:-1] == 0) & (np.cumsum(gsum[:, :, ::-1], axis=2)[:, :, ::-1][:, :, 2:] > 0)
+            assert hole.sum() >= 5
+    cin = host.CallInput(n_smpl, na, np.maximum(mwant.site["unseen"], 0), mwant.pl.astype(np.int32), mwant.site["qsum"],
+                         ad=ad, ploidy=ploidy, grp=grp, i16=mwant.site["anno"].astype(np.float32))
+    cwant = orc.mcall(cfg, cin)
+    mgot, cgot = gpu_ctx_factory(cfg).pipeline(tile, ploidy=ploidy, grp=grp)
+    assert_mplp_equal(mgot, mwant)
+    assert_call_equal(cgot, cwant, n_smpl)
+    assert (cwant.site["nals_new"] > 1).any()
+
+
 def test_empty_and_zero_depth(gpu_ctx_factory):
     n_smpl = 4
     cfg = abi.default_cfg(n_smpl, max_sites=8, max_reads=64)
