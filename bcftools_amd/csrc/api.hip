@@ -657,6 +657,14 @@ void *bcfgpu_internal_pinned(bcfgpu_ctx *c, int slot, size_t bytes)
     return w.p;
 }
 
+// The realignment and BAQ stages fork their band classes onto side streams meant to run beside one another.  The HIP runtime
+// multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); two streams of one queue run their
+// kernels one after the other, and with this context's streams beside the host program's own that happens: the realignment's
+// second chain of classes started only when the wide-band stream it shared a queue with had drained (29.0 ms a 16 384-column
+// tile; 25.6 ms with eight queues, profiles/r5_hw_queues.txt).  The variable is read when the runtime starts, i.e. at the first
+// HIP call of the process: set here, when the library is loaded, unless the user has set it.
+__attribute__((constructor)) static void bcfgpu_runtime_knobs() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 // for the stages implemented in their own translation units: bind the device, hand out the stream and shared tables
 int bcfgpu_internal_n_cu(const bcfgpu_ctx *c) { return c ? c->n_cu : 256; }
 

@@ -988,8 +988,9 @@ template <int BW> static void launch_exact_class(const ProbalnParams &p, hipStre
     hipLaunchKernelGGL((probaln_exact_kernel<BW, 2>), dim3(grid), dim3(64), 0, s, p);
 }
 // Both passes of every band width, on four streams between a fork and a join on the caller's (side[0..2], ev[0..2] and ev[8]
-// from the context; the runtime spreads streams over four hardware queues, so more streams would only queue up behind one
-// another).  Every launch is a grid of persistent wavefronts pulling 64 jobs at a time from its class's counter, so a class with
+// from the context; the runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues -- api.hip raises it to
+// eight when the library is loaded: on the default four, two of these streams shared a queue and ran one after the other;
+// the three register-row classes on a fifth stream of their own, beside both chains, was slower: profiles/r5_hw_queues.txt).  Every launch is a grid of persistent wavefronts pulling 64 jobs at a time from its class's counter, so a class with
 // few jobs costs one such chunk, not a launch's worth of idle machine; the two chains of machine-filling launches share the
 // CUs wavefront by wavefront.  The classes whose wavefronts are few and slow -- the bands past 43, one or two wavefronts a CU
 // in LDS -- go first on a stream of their own and run beside everything else.

@@ -19,6 +19,10 @@ import os
 import sys
 import time
 
+# (bcftools_amd/csrc/api.hip: the stages' side streams need hardware queues of their own; the library sets this when it is loaded, but the
+# runtime reads it at the process's first HIP call, which here may be torch's)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
