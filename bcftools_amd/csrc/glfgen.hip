@@ -96,6 +96,31 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 #ifndef WR
 #define WR 2            // reads of a run taken per step of the errmod walk
 #endif
+#ifndef GLF_WIDE_KEYS
+#define GLF_WIDE_KEYS 0      // the counting pass and pass 1 read four keys as one (unaligned) 8-byte LDS read instead of four 2-byte ones
+#endif
+// the sources of count_runs(): key7 of the j-th element or -1 -- the reads of the primary base (rejected reads are zeros), or those
+// of the lane's other reads that show base b
+struct PrimSrc {
+    const uint16_t *kpp;
+    __device__ __forceinline__ int operator()(int j) const { const uint32_t k = kpp[j]; return k ? (int)(k & 0x7f) : -1; }
+    __device__ __forceinline__ void quad(int j, int n, int (&k4)[4]) const
+    {
+        uint64_t w; __builtin_memcpy(&w, kpp + j, 8);
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t k = (uint32_t)(w >> (16 * u)) & 0xffffu; k4[u] = (j + u < n && k) ? (int)(k & 0x7f) : -1; }
+    }
+};
+struct BaseSrc {
+    const uint16_t *kp; int b;
+    __device__ __forceinline__ int operator()(int i) const { const uint32_t k = kp[i]; return (int)KEY_B(k) == b ? (int)(k & 0x7f) : -1; }
+    __device__ __forceinline__ void quad(int j, int n, int (&k4)[4]) const
+    {
+        uint64_t w; __builtin_memcpy(&w, kp + j, 8);
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) { const uint32_t k = (uint32_t)(w >> (16 * u)) & 0xffffu; k4[u] = (j + u < n && (int)KEY_B(k) == b) ? (int)(k & 0x7f) : -1; }
+    }
+};
 template <bool FIRST, class Src>
 __device__ __forceinline__ uint32_t count_runs(uint32_t *s_slot, uint64_t qm, int tid, Src src, int nsrc)
 {
@@ -105,8 +130,13 @@ __device__ __forceinline__ uint32_t count_runs(uint32_t *s_slot, uint64_t qm, in
     // FU source elements per trip: their reads are in flight before the first count is added
     for (int j = 0; __any(j < nsrc); j += FU) {
         int k4[FU];
+#if GLF_WIDE_KEYS
+        static_assert(FU == 4, "the four keys of a trip are one 8-byte read");
+        src.quad(j, nsrc, k4);
+#else
         #pragma unroll
         for (int u = 0; u < FU; ++u) k4[u] = j + u < nsrc ? src(j + u) : -1;
+#endif
         #pragma unroll
         for (int u = 0; u < FU; ++u) {
             const int key = k4[u], q = (key >> 1) & 63;
@@ -234,8 +264,13 @@ __device__ __forceinline__ uint32_t count_ends(uint32_t *s_slot, uint64_t qm, in
     const uint64_t qm1 = qm >> 1;
     for (int j = 0; __any(j < nsrc); j += FU) {
         int k4[FU];
+#if GLF_WIDE_KEYS
+        static_assert(FU == 4, "the four keys of a trip are one 8-byte read");
+        src.quad(j, nsrc, k4);
+#else
         #pragma unroll
         for (int u = 0; u < FU; ++u) k4[u] = j + u < nsrc ? src(j + u) : -1;
+#endif
         #pragma unroll
         for (int u = 0; u < FU; ++u) {
             const int key = k4[u], q = (key >> 1) & 63;
@@ -770,10 +805,20 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ?
         uint32_t n_b4 = 0;           // reads showing neither A, C, G nor T
         uint32_t o_rev = 0, n_other = 0;
         {
+#if GLF_WIDE_KEYS
+            uint64_t kw = 0, kw_nx;                             // four keys per 8-byte read, the next four requested a group ahead
+            __builtin_memcpy(&kw_nx, kp, 8);                    // (up to seven keys past the slice: inside the key array's slack)
+#else
             uint32_t k_nx = kp[0];
+#endif
             for (int i = 0; i < (BCFGPU_ABL(P, 4) ? 0 : cnt_raw); ++i) {
+#if GLF_WIDE_KEYS
+                if ((i & 3) == 0) { kw = kw_nx; __builtin_memcpy(&kw_nx, kp + i + 4, 8); } else kw >>= 16;
+                const uint32_t k = (uint32_t)kw & 0xffffu;
+#else
                 const uint32_t k = k_nx;
                 k_nx = kp[i + 1];                               // one past the slice stays inside the key array's slack
+#endif
                 const uint32_t pb = (k >> 11) & 1u;             // KEY_PRIM
                 qmask |= (uint64_t)pb << KEY_Q(k);
                 n_prim += pb;
@@ -801,7 +846,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ?
         // (a) the primary base
         if (!BCFGPU_ABL(P, 2)) {
             const uint16_t *kpp = kp + n_other;               // primary-base keys and zeros (rejected reads)
-            auto psrc = [=](int j) { const uint32_t k = kpp[j]; return k ? (int)(k & 0x7f) : -1; };
+            const PrimSrc psrc{kpp};
             const double bs = walk_runs(s_cnt, qmask, s_fk, bbase, tid, brow, psrc, dead_cell ? 0 : cnt_raw - (int)n_other, prim_rev, qs_prim,
                                         BCFGPU_ABL_MASK(P));
             #pragma unroll
@@ -825,7 +870,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(PHASE == 1 ?
                 if (b == primary || dead_cell) cb = 0;
                 if (!__any(cb > 0)) continue;
                 // key7 of the lane's i-th other read if it shows base b, else -1
-                auto src = [=](int i) { const uint32_t k = kp[i]; return (int)KEY_B(k) == b ? (int)(k & 0x7f) : -1; };
+                const BaseSrc src{kp, b};
                 const int no = cb > 0 ? (int)n_other : 0;
                 double bs;
                 if (!__any(cb > 1)) {
