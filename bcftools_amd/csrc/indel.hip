@@ -1027,28 +1027,16 @@ int launch_probaln_exact(const ProbalnParams &p, hipStream_t s, int n_cu, hipStr
             hipLaunchKernelGGL(probaln_lds_kernel<64>, dim3(std::min((unsigned)n_cu * per_cu, need)), dim3(64), lds, tail2, p, g, wcells);
         }
         // bands 11 .. 43: the row in registers, one wavefront a SIMD
-#ifndef PROBALN_LAYOUT
-#define PROBALN_LAYOUT 0
-#endif
-#if PROBALN_LAYOUT == 0
         hipLaunchKernelGGL(probaln_regs_kernel<11>, dim3(std::min((unsigned)n_cu * 4u, need)), dim3(64), 0, second, p, 2);
         hipLaunchKernelGGL(probaln_regs_kernel<8>, dim3(std::min((unsigned)n_cu * 4u, need)), dim3(64), 0, s, p, 1);
         hipLaunchKernelGGL(probaln_regs_kernel<4>, dim3(std::min((unsigned)n_cu * 4u, need)), dim3(64), 0, second, p, 0);
     }
+    // (other layouts measured with eight hardware queues, none better: every narrow band in one chain, in either order; the register-row
+    // classes on a stream of their own beside one or two chains; two chains of two wavefronts a SIMD: profiles/r5_hw_queues.txt)
     launch_exact_class<10>(p, second, grid); launch_exact_class<9>(p, s, grid);
     launch_exact_class<8>(p, second, grid);  launch_exact_class<7>(p, s, grid);
     launch_exact_class<6>(p, second, grid);  launch_exact_class<5>(p, s, grid);
     launch_exact_class<4>(p, second, grid);  launch_exact_class<3>(p, s, grid);
-#else
-        // (one wavefront a SIMD and half its registers: one after the other on a stream of their own, beside the chain of the narrow bands)
-        hipLaunchKernelGGL(probaln_regs_kernel<8>, dim3(std::min((unsigned)n_cu * 4u, need)), dim3(64), 0, second, p, 1);
-        hipLaunchKernelGGL(probaln_regs_kernel<11>, dim3(std::min((unsigned)n_cu * 4u, need)), dim3(64), 0, second, p, 2);
-        hipLaunchKernelGGL(probaln_regs_kernel<4>, dim3(std::min((unsigned)n_cu * 4u, need)), dim3(64), 0, second, p, 0);
-    }
-    // the narrow bands: one chain (two of them side by side have each other's code in the instruction cache: --mode indel 9 % slower)
-    launch_exact_class<4>(p, s, grid); launch_exact_class<3>(p, s, grid); launch_exact_class<5>(p, s, grid); launch_exact_class<6>(p, s, grid);
-    launch_exact_class<10>(p, s, grid); launch_exact_class<9>(p, s, grid); launch_exact_class<8>(p, s, grid); launch_exact_class<7>(p, s, grid);
-#endif
     if (hipEventRecord(ev[0], tail) != hipSuccess || hipStreamWaitEvent(s, ev[0], 0) != hipSuccess) return -1;
     if (hipEventRecord(ev[1], second) != hipSuccess || hipStreamWaitEvent(s, ev[1], 0) != hipSuccess) return -1;
     if (hipEventRecord(ev[2], tail2) != hipSuccess || hipStreamWaitEvent(s, ev[2], 0) != hipSuccess) return -1;
