@@ -227,13 +227,15 @@ def test_pipeline_with_sample_groups_matches_oracle(gpu_ctx_factory, n_sites, n_
     (48, 203, 5, 10.0, [0, 1, 2, 2], 73),    # ploidy 0 among variant sites, a sample count not divisible by four, shuffled groups
     (16, 1003, 1, 8.0, None, 74),        # one group, the last word of three samples
     (12, 5000, 1, 6.0, [1, 2, 2], 75),   # past the 4096 samples the scan keeps data-presence notes for
-    (12, 4104, 4, 6.0, [0, 1, 2], 76)])
+    (12, 4104, 4, 6.0, [0, 1, 2], 76),
+    (60, 300, 1, 12.0, None, 77),        # N in the reference at a third of the sites: five alleles, the reference allele without a frequency
+    (60, 260, 3, 12.0, [1, 2, 2], 78)])
 def test_subset_scan_corners(gpu_ctx_factory, n_sites, n_smpl, n_grp, depth, ploidies, seed):
     """The lane-per-sample subset scan of mcall_find_best_alleles (csrc/mcall.hip, sparse_scan): the alleles with a frequency are
     visited first by permuting the PL planes, so a group whose frequency is zero for an allele BETWEEN two it has must pick the
     reference's subsets (mcall.c:617-698 skips qsum == 0) in the reference's order; samples of ploidy 0 enter the single-allele
     rows only; ragged sample counts; more samples than the scan notes data presence for."""
-    tile = synth.numpy_tile(seed, n_sites, n_smpl, depth=depth, var_rate=0.6)
+    tile = synth.numpy_tile(seed, n_sites, n_smpl, depth=depth, var_rate=0.6, ref_n_rate=0.35 if seed >= 77 else 0.0)
     fmt = abi.INFO_VDB | abi.INFO_RPB | (abi.FMT_AD if n_grp > 1 else 0)
     kw = dict(n_grp=n_grp) if n_grp > 1 else {}
     cfg = abi.default_cfg(n_smpl, max_sites=n_sites, max_reads=len(tile.rd), fmt_flag=fmt, **kw)
@@ -261,6 +263,8 @@ def test_subset_scan_corners(gpu_ctx_factory, n_sites, n_smpl, n_grp, depth, plo
     assert_mplp_equal(mgot, mwant)
     assert_call_equal(cgot, cwant, n_smpl)
     assert (cwant.site["nals_new"] > 1).any()
+    if seed >= 77:
+        assert (na == 5).any()
 
 
 def test_empty_and_zero_depth(gpu_ctx_factory):
