@@ -403,11 +403,23 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, 
     float myq = 0.f;
     float *s_frt = reinterpret_cast<float*>(s_stage);          // [4 alleles][CHUNK/2] normalised QS of the staged samples
     constexpr int HC = CHUNK / 2;
+    // (a chunk's packed QS words are all requested before the first is used, and the next chunk's before this chunk's sequential
+    // sum is run: the loop was a chain of memory round trips, one per 64 samples)
+    constexpr int QU = HC / WG;
+    unsigned long long qv[QU];
+    auto fetch_qs = [&](int base) {
+        #pragma unroll
+        for (int u = 0; u < QU; ++u) { const int i = base + tid + u * WG; qv[u] = i < S ? P.cr.qs64[c0 + i] : 0ull; }
+    };
+    fetch_qs(0);
     for (int base = 0; base < S; base += HC) {
         const int cn = min(HC, S - base);
         __syncthreads();
-        for (int i = tid; i < cn; i += WG) {
-            const unsigned long long v = P.cr.qs64[c0 + base + i];
+        #pragma unroll
+        for (int u = 0; u < QU; ++u) {
+            const int i = tid + u * WG;
+            if (i >= cn) break;
+            const unsigned long long v = qv[u];
             float q0 = (float)(int)(v & 0xffff), q1 = (float)(int)((v >> 16) & 0xffff);
             float q2 = (float)(int)((v >> 32) & 0xffff), q3 = (float)(int)((v >> 48) & 0xffff);
             if ((uint32_t)(v >> 48) == 0xffffu) {               // WIDE_QS_MARK: a cell of more than 255 usable reads, QS over all of them
@@ -422,6 +434,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, 
             s_frt[i] = f.x; s_frt[HC + i] = f.y; s_frt[2 * HC + i] = f.z; s_frt[3 * HC + i] = f.w;
         }
         __syncthreads();
+        if (base + HC < S) fetch_qs(base + HC);
         if (tid < 4 && !BCFGPU_ABL(P, 8192)) myq = seq_sum_f32(myq, s_frt + tid * HC, cn);
     }
     if (tid < 4) s_q[tid] = myq;
@@ -572,10 +585,18 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, 
         int nzero = 0;
         double part_deep = 0;
         const uint16_t *d4s = P.out.dp4 + (size_t)is * 4 * S;
-        for (int s0 = 0; s0 < S; s0 += WG) {
-            const int s = s0 + tid;
-            int oi = -1;
-            if (s < S) oi = (int)d4s[2 * (size_t)S + s] + (int)d4s[3 * (size_t)S + s];     // the DP4 planes written above (counts over all reads)
+        for (int sb = 0; sb < S; sb += 4 * WG) {
+          // (four rounds of 64 samples requested together: the loop is a chain of round trips to the planes otherwise)
+          int oi4[4];
+          #pragma unroll
+          for (int u = 0; u < 4; ++u) {
+              const int s = sb + u * WG + tid;
+              oi4[u] = s < S ? (int)d4s[2 * (size_t)S + s] + (int)d4s[3 * (size_t)S + s] : -1;     // the DP4 planes written above (counts over all reads)
+          }
+          #pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (sb + u * WG >= S) break;
+            const int oi = oi4[u];
             nzero += __popcll(__ballot(oi == 0));
             if (oi > 0 && oi < 512) atomicAdd(&s_oc[oi], 1);
             else if (oi >= 512) {                                 // a cell far past 255 reads: its term on its own
@@ -583,6 +604,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, 
                 tmp += log(f) + oi * log(q / p) - q + p;
                 part_deep += tmp;
             }
+          }
         }
         __syncthreads();
         double part = part_deep;
