@@ -29,6 +29,17 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// the same for per-lane 32-bit partial sums whose sum over 16 lanes stays below 2^32: four adds inside each row of 16 lanes by
+// data-parallel-primitive moves (no trip through the LDS crossbar), the four row sums added as scalars
+__device__ __forceinline__ unsigned long long wave_sum_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false);    // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false);    // row_mirror
+    return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16)
+         + (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
     #pragma unroll
@@ -428,8 +439,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, 
             }
             float sum = 0;
             sum += q0; sum += q1; sum += q2; sum += q3;
-            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sum != 0.f) f = make_float4(q0 / sum, q1 / sum, q2 / sum, q3 / sum);
+            // q / sum is +0 for q = 0 and 1 for q = sum, exactly; most cells show one base, the same one for all the samples of a site:
+            // an allele none of the wavefront's 64 samples needs a real division for (a wave-uniform test) takes the select
+            auto frac = [&](float q) -> float {
+                if (__any(q != 0.f && q != sum)) return sum != 0.f ? q / sum : 0.f;
+                return q != 0.f ? 1.0f : 0.0f;
+            };
+            const float4 f = make_float4(frac(q0), frac(q1), frac(q2), frac(q3));
             // adding +0 for empty samples leaves the running sum unchanged
             s_frt[i] = f.x; s_frt[HC + i] = f.y; s_frt[2 * HC + i] = f.z; s_frt[3 * HC + i] = f.w;
         }
@@ -549,15 +565,18 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(COMB_WAVES, 
     // wave reductions of the integer totals, then one LDS atomic per wave
     {
         unsigned long long v;
+        // (a lane's partial sum is at most S / 64 samples of 65 535 reads: sixteen of them fit 32 bits up to 262 144 samples)
+        const bool narrow = S <= 262144;
+        auto wsum = [&](uint32_t x) -> unsigned long long { return narrow ? wave_sum_u32(x) : wave_sum_u64((unsigned long long)x); };
         #pragma unroll
-        for (int j = 0; j < 5; ++j) { v = wave_sum_u64((unsigned long long)t_adf[j]); if (lane == 0 && v) atomicAdd(&sh.tot[j], v); }
+        for (int j = 0; j < 5; ++j) { v = wsum(t_adf[j]); if (lane == 0 && v) atomicAdd(&sh.tot[j], v); }
         #pragma unroll
-        for (int j = 0; j < 5; ++j) { v = wave_sum_u64((unsigned long long)t_adr[j]); if (lane == 0 && v) atomicAdd(&sh.tot[5 + j], v); }
-        v = wave_sum_u64((unsigned long long)t_scr); if (lane == 0 && v) atomicAdd(&sh.tot[10], v);
-        v = wave_sum_u64((unsigned long long)t_ori); if (lane == 0 && v) atomicAdd(&sh.tot[11], v);
-        v = wave_sum_u64((unsigned long long)t_mq0); if (lane == 0 && v) atomicAdd(&sh.tot[12], v);
+        for (int j = 0; j < 5; ++j) { v = wsum(t_adr[j]); if (lane == 0 && v) atomicAdd(&sh.tot[5 + j], v); }
+        v = wsum(t_scr); if (lane == 0 && v) atomicAdd(&sh.tot[10], v);
+        v = wsum(t_ori); if (lane == 0 && v) atomicAdd(&sh.tot[11], v);
+        v = wsum(t_mq0); if (lane == 0 && v) atomicAdd(&sh.tot[12], v);
         #pragma unroll
-        for (int j = 0; j < 4; ++j) { v = wave_sum_u64((unsigned long long)t_cnt[j]); if (lane == 0 && v) atomicAdd(&sh.tot[13 + j], v); }
+        for (int j = 0; j < 4; ++j) { v = wsum(t_cnt[j]); if (lane == 0 && v) atomicAdd(&sh.tot[13 + j], v); }
         if (tid < 12) sh.tot[17 + tid] = P.site_sums[(size_t)is * SITE_NSUM + tid];
         if (tid == 12) sh.tot[29] = P.site_sums[(size_t)is * SITE_NSUM + 12];     // ori_depth and mq0 come as site totals
         if (tid == 13) sh.tot[30] = P.site_sums[(size_t)is * SITE_NSUM + 13];
