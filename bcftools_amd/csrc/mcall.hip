@@ -486,7 +486,12 @@ __global__ __launch_bounds__(WGS) __attribute__((amdgpu_waves_per_eu(!FAST ? 1 :
     }
     const double *s_pl2p = P.pl2p;
     __shared__ double s_p2[FAST ? 264 : 1];                   // 10^(-PL/10), PL = 0..255; [256] = 0: what a sample without data (or a slot past the genotypes) looks up; [257] = 1
-    if constexpr (FAST) { for (int i = tid; i < 256; i += WGS) s_p2[i] = P.pl2p[i]; if (tid < 8) s_p2[256 + tid] = tid == 1 ? 1.0 : 0.0; }   // [257] = 1: the free slot of a sample without data (subset scan)
+    if constexpr (FAST) {
+        // (the lane's four entries requested together: as a loop this was four round trips, one after the other)
+        const double t0 = P.pl2p[tid], t1 = P.pl2p[tid + WGS], t2 = P.pl2p[tid + 2 * WGS], t3 = P.pl2p[tid + 3 * WGS];
+        s_p2[tid] = t0; s_p2[tid + WGS] = t1; s_p2[tid + 2 * WGS] = t2; s_p2[tid + 3 * WGS] = t3;
+        if (tid < 8) s_p2[256 + tid] = tid == 1 ? 1.0 : 0.0;
+    }   // [257] = 1: the free slot of a sample without data (subset scan)
     // the subset scan notes which samples carry data, four of them a byte (bit j: sample 4i+j), for the genotypes of a site that
     // stays REF-only (below); 0x80: no group's scan came by (the planes are read then)
     constexpr int NZ_MAX_S = 4096;
