@@ -8,10 +8,11 @@
 //
 // The work per site is a chain of short, dependent steps, so throughput comes from having thousands of sites in
 // flight: one 64-lane workgroup per site, no workgroup barriers that matter.  The allele-subset scan of
-// find_best_alleles is a (subsets x genotypes) * (genotypes x samples) product: the FAST instantiations (diploid, one
-// group, u8 PLs of the fused pipeline) run it on the f64 matrix cores; the general ones (ploidy arrays, -G groups,
-// missing PLs, int32 PLs of a VCF) keep a sample's P(D|G) in the lane's LDS column and index it with run-time
-// genotype indices.  Genotype calling runs lanes over samples in both.
+// find_best_alleles is a (subsets x genotypes) * (genotypes x samples) product with a sparse left factor: the FAST
+// instantiations (u8 PLs of the fused pipeline; ploidy arrays and -G groups as template parameters) scan a lane per sample
+// with the subsets' coefficients in scalar registers (sparse_scan below; the 25-subset instantiation alone still uses dense
+// tiles on the f64 matrix cores); the general ones (missing PLs, int32 PLs of a VCF) keep a sample's P(D|G) in the lane's
+// LDS column and index it with run-time genotype indices.  Genotype calling runs lanes over samples in both.
 //
 // Integer results (GT, AC/AN, trimmed PL, GQ) are exact; log-likelihood sums are accumulated as running products
 // (mantissa, exponent), so QUAL agrees with the sequential CPU sum of logs to ~1e-13 relative, far inside the 1e-4
@@ -413,9 +414,9 @@ __device__ MCALL_SCAN_INLINE void sparse_scan(const McallParams &P, const uint8_
 }
 
 // FAST: the u8-PL case of the fused pipeline (HAP: with a ploidy array; sample groups in both).  The subset scan of find_best_alleles is the
-// matrix product (subset coefficients [rows] x genotypes [k]) * (genotypes [k] x samples [cols]) and runs on the
-// f64 matrix cores (v_mfma_f64_16x16x4_f64), 16 samples per issue; an extra all-ones row yields each sample's
-// normalisation sum, whose product is divided out at the end.
+// product (subset coefficients [rows] x genotypes [k]) * (genotypes [k] x samples [cols]); a row for each sample's
+// normalisation sum comes with it, whose product is divided out at the end.  NSUB <= 15: sparse_scan() above, a lane per sample;
+// NSUB = 25 (five alleles with a frequency): dense tiles on the f64 matrix cores (v_mfma_f64_16x16x4_f64), 16 samples per issue.
 #ifndef MCALL_WAVES
 #define MCALL_WAVES 4        // wavefronts per SIMD of the all-diploid FAST instantiations
 #endif
@@ -1669,7 +1670,7 @@ void launch_mcall(const McallParams &p_in, hipStream_t s)
         hipLaunchKernelGGL((mcall_kernel<5, 15, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); \
         hipLaunchKernelGGL((mcall_kernel<5, 25, FAST_, HAP_, GRP_>), dim3(p.n_sites), dim3(WGS), lds, s, p); } while (0)
     if (p.pl_is_u8 && !BCFGPU_ABL(p, 64)) {
-        // u8 PLs (the fused pipeline): subset scan on the matrix cores; the haploid coefficient set only with a ploidy
+        // u8 PLs (the fused pipeline): the lane-per-sample subset scan (matrix cores for 25 subsets); the haploid forms only with a ploidy
         // array, the group handling only with more than one group
         if (p.ploidy) MCALL_LAUNCH3(true, true, true);
         else if (ngrp > 1) MCALL_LAUNCH3(true, false, true);
