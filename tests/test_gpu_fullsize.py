@@ -107,6 +107,42 @@ def test_sampled_sites_match_oracle(big):
     assert_call_equal(cg, cw, N_SMPL)
 
 
+def test_groups_and_ploidy_at_full_size(big, gpu_ctx_factory):
+    """BASELINE configs[4] shape on the same tile: call -G on four sample groups (frequencies from FORMAT/AD) with a ploidy array.
+    Region-shard invariance of the call records, and a sample of sites -- variant ones among them -- against the oracle."""
+    tile, cfg0, ctx0, m0, c0 = big
+    n_grp = 4
+    cfg = abi.default_cfg(N_SMPL, max_sites=N_SITES, max_reads=len(tile.rd), fmt_flag=FMT, n_grp=n_grp)
+    ctx = gpu_ctx_factory(cfg)
+    rng = np.random.default_rng(11)
+    ploidy = rng.choice([0, 1, 2, 2, 2], size=N_SMPL).astype(np.uint8)
+    grp = (np.arange(N_SMPL) * n_grp // N_SMPL).astype(np.int32)
+    m, c = ctx.pipeline(tile, ploidy=ploidy, grp=grp)
+    np.testing.assert_array_equal(m.pl, m0.pl)                       # the mpileup stage does not know about groups
+    cut = 2311
+    parts = [ctx.pipeline(tile.select_sites(np.arange(a, b)), ploidy=ploidy, grp=grp) for a, b in ((0, cut), (cut, N_SITES))]
+    assert np.concatenate([p[1].site for p in parts]).tobytes() == c.site.tobytes()
+    np.testing.assert_array_equal(np.concatenate([p[1].gt for p in parts]), c.gt)
+    var = np.nonzero(c.site["als_new"] != 1)[0]
+    assert len(var) > 0
+    pick = np.unique(np.concatenate([rng.choice(N_SITES, 6, replace=False), rng.choice(var, min(10, len(var)), replace=False)]))
+    sub = tile.select_sites(pick)
+    scfg = abi.default_cfg(N_SMPL, max_sites=sub.n_sites, max_reads=len(sub.rd), fmt_flag=FMT, n_grp=n_grp)
+    mw = orc.mpileup(scfg, sub)
+    na = mw.site["n_alleles"]
+    src = mw.adf.astype(np.int32) + mw.adr.astype(np.int32)
+    ad = np.where(np.arange(5)[None, :, None] < na[:, None, None], src, abi.INT32_VECTOR_END).astype(np.int32)
+    cin = host.CallInput(N_SMPL, na, np.maximum(mw.site["unseen"], 0), mw.pl.astype(np.int32), mw.site["qsum"],
+                         ad=ad, ploidy=ploidy, grp=grp, i16=mw.site["anno"].astype(np.float32))
+    cw = orc.mcall(scfg, cin)
+
+    class Rows:
+        pass
+    cg = Rows()
+    cg.site, cg.gt, cg.pl = c.site[pick], c.gt[pick], c.pl[pick]
+    assert_call_equal(cg, cw, N_SMPL)
+
+
 def test_pileup_at_scale_counts_and_packed_form(gpu_ctx_factory):
     """bcfgpu_pileup over 2048 columns x 1000 samples x 30x (6e7 entries): every cell's entry count equals the number of the
     sample's reads whose reference span covers the column (a difference array on the host), and the packed form of the same
